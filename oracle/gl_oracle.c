@@ -1,0 +1,542 @@
+/*
+ * gl_oracle.c -- CPU ORACLE for the STARK hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * This file is a plain-C restatement of the algorithms that the reference
+ * (okx/xlayer-prover, snapshot 2024_10_08) runs on its Starks::genProof path:
+ * Goldilocks field, cubic extension, NTT/INTT/extendPol, Poseidon permutation,
+ * linear hash, Merkle tree, Fiat-Shamir transcript, FRI fold/transpose/query.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load it.  The product (xlayer_prover_amd/) never links or calls it.
+ *
+ * Provenance.  The arithmetic library the reference calls
+ * (github.com/0xPolygonHermez/goldilocks, git submodule `src/goldilocks`,
+ * .gitmodules:1-3) is NOT vendored in the snapshot and its pinned commit is
+ * unknown.  Each function below therefore restates the *published algorithm*
+ * and is anchored to the reference's own call sites and in-tree restatements
+ * (cited per function).  Parity is PINNED by golden data held in the
+ * reference's testvectors (see tests/golden/make_fixtures.py and
+ * tests/test_oracle_golden.py):
+ *   - 1243 Poseidon known answers (`db` objects of testvectors JSON files),
+ *   - two complete STARK proofs (recursive1 / recursive2 zkin files): every
+ *     Merkle path, the transcript-derived query indices and every FRI fold.
+ * The LDE *values* are not pinned by any golden file (no committed trace is in
+ * the tree): extendPol is checked against a naive O(n^2) evaluation instead,
+ * and its evaluation-domain convention (shift = 7, natural order, W32 below)
+ * is pinned through the FRI fold relations of the golden proofs.
+ *
+ * All cited paths are relative to /root/reference.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef uint64_t u64;
+typedef unsigned __int128 u128;
+
+#define GL_P 0xFFFFFFFF00000001ULL
+
+/* ------------------------------------------------------------------ field */
+/* Goldilocks::Element arithmetic (absent lib; semantics = Z/pZ, canonical
+ * outputs).  Used everywhere e.g. src/starkpil/polinomial.hpp:140-229. */
+static inline u64 gl_canon(u64 a) { return a >= GL_P ? a - GL_P : a; }
+static inline u64 gl_add(u64 a, u64 b)
+{
+    a = gl_canon(a); b = gl_canon(b);
+    u64 s = a + b;
+    if (s < a || s >= GL_P) s -= GL_P;
+    return s;
+}
+static inline u64 gl_sub(u64 a, u64 b)
+{
+    a = gl_canon(a); b = gl_canon(b);
+    return a >= b ? a - b : a + (GL_P - b);
+}
+static inline u64 gl_mul(u64 a, u64 b)
+{
+    return (u64)(((u128)a * (u128)b) % (u128)GL_P);
+}
+static u64 gl_pow(u64 a, u64 e)
+{
+    u64 r = 1;
+    while (e) { if (e & 1) r = gl_mul(r, a); a = gl_mul(a, a); e >>= 1; }
+    return r;
+}
+static inline u64 gl_inv(u64 a) { return gl_pow(a, GL_P - 2); }
+
+u64 orc_add(u64 a, u64 b) { return gl_add(a, b); }
+u64 orc_sub(u64 a, u64 b) { return gl_sub(a, b); }
+u64 orc_mul(u64 a, u64 b) { return gl_mul(a, b); }
+u64 orc_inv(u64 a) { return gl_inv(a); }
+u64 orc_pow(u64 a, u64 e) { return gl_pow(a, e); }
+
+/* Goldilocks::w(n): primitive 2^n-th root of unity, w(n) = W32^(2^(32-n)).
+ * W32 is pinned by the golden proofs' FRI folds: with
+ * 7^((p-1)/2^32) every fold check fails.  Call sites: starks.hpp:149-160,
+ * friProve.cpp:36, zhInv.cpp:12-26. */
+#define GL_W32 7277203076849721926ULL
+#define GL_SHIFT 7ULL /* Goldilocks::shift(), friProve.cpp:12-13 */
+u64 orc_w(unsigned n)
+{
+    u64 w = GL_W32;
+    for (unsigned i = 32; i > n; i--) w = gl_mul(w, w);
+    return w;
+}
+u64 orc_shift(void) { return GL_SHIFT; }
+
+/* -------------------------------------------------------- cubic extension */
+/* Fp[x]/(x^3 - x - 1); Karatsuba form exactly as polinomial.hpp:195-205. */
+static inline void gl3_mul(u64 o[3], const u64 a[3], const u64 b[3])
+{
+    u64 A = gl_mul(gl_add(a[0], a[1]), gl_add(b[0], b[1]));
+    u64 B = gl_mul(gl_add(a[0], a[2]), gl_add(b[0], b[2]));
+    u64 C = gl_mul(gl_add(a[1], a[2]), gl_add(b[1], b[2]));
+    u64 D = gl_mul(a[0], b[0]);
+    u64 E = gl_mul(a[1], b[1]);
+    u64 F = gl_mul(a[2], b[2]);
+    u64 G = gl_sub(D, E);
+    u64 r0 = gl_sub(gl_add(C, G), F);
+    u64 r1 = gl_sub(gl_sub(gl_sub(gl_add(A, C), E), E), D);
+    u64 r2 = gl_sub(B, G);
+    o[0] = r0; o[1] = r1; o[2] = r2;
+}
+void orc_mul3(u64 o[3], const u64 a[3], const u64 b[3]) { gl3_mul(o, a, b); }
+
+/* ---------------------------------------------------------------- Poseidon */
+/* Permutation restated from src/sm/poseidon_g/poseidon_g_executor.cpp:201-230
+ * (round loop), :325-331 (pow7), constants :11-101, MDS
+ * poseidon_g_executor.hpp:37-50: M[i][j] = MCIRC[(j-i) mod 12] + (i==j)*MDIAG[i]. */
+static const u64 POSEIDON_C[360] = {
+#include "poseidon_constants.inc"
+};
+static const u64 MCIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+static const u64 MDIAG[12] = {8, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+static inline u64 pow7(u64 a)
+{
+    u64 a2 = gl_mul(a, a), a4 = gl_mul(a2, a2), a3 = gl_mul(a, a2);
+    return gl_mul(a3, a4);
+}
+
+static void poseidon_perm(u64 st[12])
+{
+    for (int r = 0; r < 30; r++) {
+        for (int i = 0; i < 12; i++) st[i] = gl_add(st[i], POSEIDON_C[12 * r + i]);
+        if (r < 4 || r >= 26) {
+            for (int i = 0; i < 12; i++) st[i] = pow7(st[i]);
+        } else {
+            st[0] = pow7(st[0]);
+        }
+        u64 acc[12];
+        for (int x = 0; x < 12; x++) {
+            u64 a = 0;
+            for (int y = 0; y < 12; y++) {
+                u64 m = MCIRC[(y - x + 12) % 12] + (x == y ? MDIAG[x] : 0);
+                a = gl_add(a, gl_mul(st[y], m));
+            }
+            acc[x] = a;
+        }
+        memcpy(st, acc, sizeof(acc));
+    }
+}
+
+/* PoseidonGoldilocks::hash_full_result(out12,in12): transcript.cpp:23,46 */
+void orc_poseidon_perm(u64 out[12], const u64 in[12])
+{
+    u64 st[12];
+    for (int i = 0; i < 12; i++) st[i] = gl_canon(in[i]);
+    poseidon_perm(st);
+    memcpy(out, st, sizeof(st));
+}
+
+/* linear_hash: leaf rule of PoseidonGoldilocks::merkletree* (called at
+ * merkleTreeGL.cpp:39-43): n==0 -> zeros; n<=4 -> copy,
+ * zero-pad, no permutation; else sponge rate 8 / capacity 4, capacity starts
+ * at 0^4, last block zero-padded, output = state[0..3]. */
+void orc_linear_hash(u64 out[4], const u64 *in, u64 n)
+{
+    if (n <= 4) {
+        for (u64 i = 0; i < 4; i++) out[i] = i < n ? gl_canon(in[i]) : 0;
+        return;
+    }
+    u64 st[12];
+    u64 cap[4] = {0, 0, 0, 0};
+    u64 rem = n;
+    while (rem) {
+        u64 take = rem < 8 ? rem : 8;
+        for (u64 i = 0; i < 8; i++) st[i] = i < take ? gl_canon(in[i]) : 0;
+        memcpy(st + 8, cap, sizeof(cap));
+        poseidon_perm(st);
+        memcpy(cap, st, sizeof(cap));
+        in += take;
+        rem -= take;
+    }
+    memcpy(out, cap, sizeof(cap));
+}
+
+/* PoseidonGoldilocks::merkletree_avx(tree,input,ncols,nrows)
+ * (merkleTreeGL.cpp:37-44): level 0 = linear_hash of each row, then binary
+ * levels node = perm(left|right|0^4)[0..3]; buffer = level0 | level1 | ... |
+ * root, (2h-1)*4 elements (merkleTreeGL.hpp:61-68). */
+void orc_merkletree(u64 *nodes, const u64 *src, u64 w, u64 h)
+{
+#pragma omp parallel for schedule(static)
+    for (u64 i = 0; i < h; i++) orc_linear_hash(nodes + 4 * i, src + i * w, w);
+    u64 off = 0, cnt = h;
+    while (cnt > 1) {
+        u64 *cur = nodes + off, *nxt = nodes + off + 4 * cnt;
+#pragma omp parallel for schedule(static)
+        for (u64 j = 0; j < cnt / 2; j++) {
+            u64 st[12];
+            memcpy(st, cur + 8 * j, 8 * sizeof(u64));
+            st[8] = st[9] = st[10] = st[11] = 0;
+            poseidon_perm(st);
+            memcpy(nxt + 4 * j, st, 4 * sizeof(u64));
+        }
+        off += 4 * cnt;
+        cnt /= 2;
+    }
+}
+
+/* MerkleTreeGL::getGroupProof (merkleTreeGL.cpp:12-35): proof = row ||
+ * siblings bottom-up, sibling at level k = nodes[off_k + ((idx>>k)^1)*4]. */
+void orc_merkle_proof(u64 *proof, const u64 *nodes, const u64 *src, u64 w, u64 h, u64 idx)
+{
+    memcpy(proof, src + idx * w, w * sizeof(u64));
+    proof += w;
+    u64 off = 0, cnt = h;
+    while (cnt > 1) {
+        memcpy(proof, nodes + off + (idx ^ 1) * 4, 4 * sizeof(u64));
+        proof += 4;
+        off += 4 * cnt;
+        cnt /= 2;
+        idx >>= 1;
+    }
+}
+
+/* Verifier-side fold of a Merkle path (used only to pin the oracle against the
+ * golden proofs): returns the root implied by leaf `row[0..w)` at `idx`. */
+void orc_merkle_root_from_path(u64 root[4], const u64 *row, u64 w, const u64 *sib, u64 nsib, u64 idx)
+{
+    u64 cur[4];
+    orc_linear_hash(cur, row, w);
+    for (u64 k = 0; k < nsib; k++) {
+        u64 st[12];
+        if (idx & 1) { memcpy(st, sib + 4 * k, 32); memcpy(st + 4, cur, 32); }
+        else         { memcpy(st, cur, 32); memcpy(st + 4, sib + 4 * k, 32); }
+        st[8] = st[9] = st[10] = st[11] = 0;
+        poseidon_perm(st);
+        memcpy(cur, st, 32);
+        idx >>= 1;
+    }
+    memcpy(root, cur, 32);
+}
+
+/* DFS over the 2^nsib left/right choices of one path until it reproduces
+ * `root`; returns the leaf index or (u64)-1.  SURVEY.md Appendix B step 3:
+ * how a query index is recovered from a golden proof without the verkey. */
+static int dfs_idx(const u64 cur[4], const u64 *sib, u64 k, u64 nsib, const u64 root[4], u64 acc, u64 *found)
+{
+    if (k == nsib) {
+        if (memcmp(cur, root, 32) == 0) { *found = acc; return 1; }
+        return 0;
+    }
+    for (u64 bit = 0; bit < 2; bit++) {
+        u64 st[12];
+        if (bit) { memcpy(st, sib + 4 * k, 32); memcpy(st + 4, cur, 32); }
+        else     { memcpy(st, cur, 32); memcpy(st + 4, sib + 4 * k, 32); }
+        st[8] = st[9] = st[10] = st[11] = 0;
+        poseidon_perm(st);
+        if (dfs_idx(st, sib, k + 1, nsib, root, acc | (bit << k), found)) return 1;
+    }
+    return 0;
+}
+u64 orc_find_merkle_index(const u64 *row, u64 w, const u64 *sib, u64 nsib, const u64 root[4])
+{
+    u64 leaf[4], found = (u64)-1;
+    orc_linear_hash(leaf, row, w);
+    dfs_idx(leaf, sib, 0, nsib, root, 0, &found);
+    return found;
+}
+
+/* --------------------------------------------------------------------- NTT */
+static unsigned ilog2(u64 n) { unsigned l = 0; while ((1ULL << l) < n) l++; return l; }
+static inline u64 bitrev(u64 x, unsigned bits)
+{
+    u64 r = 0;
+    for (unsigned i = 0; i < bits; i++) { r = (r << 1) | (x & 1); x >>= 1; }
+    return r;
+}
+
+/* One column, in place, natural in / natural out, iterative radix-2 DIT.
+ * X[k] = sum_j x[j] w^(jk), w = w(log2 n) (forward) or its inverse, inverse
+ * also scales by 1/n.  Semantics of NTT_Goldilocks::NTT/INTT as used at
+ * starks.cpp:262,285,326-327 and friProve.cpp:100-102; an independent scalar
+ * statement of the same transform is tools/starkpil/bctree/build_const_tree.cpp:242-288. */
+static void ntt_col(u64 *a, u64 n, int inverse)
+{
+    unsigned lg = ilog2(n);
+    for (u64 i = 0; i < n; i++) {
+        u64 j = bitrev(i, lg);
+        if (i < j) { u64 t = a[i]; a[i] = a[j]; a[j] = t; }
+    }
+    for (unsigned s = 1; s <= lg; s++) {
+        u64 m = 1ULL << s, h = m >> 1;
+        u64 wm = orc_w(s);
+        if (inverse) wm = gl_inv(wm);
+        for (u64 k = 0; k < n; k += m) {
+            u64 w = 1;
+            for (u64 j = 0; j < h; j++) {
+                u64 t = gl_mul(w, a[k + j + h]);
+                u64 u = a[k + j];
+                a[k + j] = gl_add(u, t);
+                a[k + j + h] = gl_sub(u, t);
+                w = gl_mul(w, wm);
+            }
+        }
+    }
+    if (inverse) {
+        u64 ninv = gl_inv(n % GL_P);
+        for (u64 i = 0; i < n; i++) a[i] = gl_mul(a[i], ninv);
+    }
+}
+
+/* Row-major [n][ncols] matrices, one transform per column (dst may alias src:
+ * `ntt.INTT(LEv, LEv, N, 3)` starks.cpp:326). */
+void orc_ntt(u64 *dst, const u64 *src, u64 n, u64 ncols, int inverse)
+{
+    if (n == 0 || ncols == 0) return;
+#pragma omp parallel
+    {
+        u64 *col = (u64 *)malloc(n * sizeof(u64));
+#pragma omp for schedule(dynamic, 1)
+        for (u64 c = 0; c < ncols; c++) {
+            for (u64 i = 0; i < n; i++) col[i] = gl_canon(src[i * ncols + c]);
+            ntt_col(col, n, inverse);
+            /* all reads of column c precede its writes; other columns untouched */
+            for (u64 i = 0; i < n; i++) dst[i * ncols + c] = col[i];
+        }
+        free(col);
+    }
+}
+
+/* Naive O(n^2) DFT of one column: the independent check for ntt_col. */
+void orc_dft_naive(u64 *dst, const u64 *src, u64 n, int inverse)
+{
+    u64 w = orc_w(ilog2(n));
+    if (inverse) w = gl_inv(w);
+    u64 ninv = inverse ? gl_inv(n % GL_P) : 1;
+    for (u64 k = 0; k < n; k++) {
+        u64 wk = gl_pow(w, k), acc = 0, x = 1;
+        for (u64 j = 0; j < n; j++) { acc = gl_add(acc, gl_mul(src[j], x)); x = gl_mul(x, wk); }
+        dst[k] = gl_mul(acc, ninv);
+    }
+}
+
+/* NTT_Goldilocks::extendPol(out,in,N_ext,N,ncols,buf) (starks.cpp:53,134,215):
+ * coeff = INTT_N(col); coeff[i] *= shift^i; zero-pad to N_ext; out = NTT_Next.
+ * => out[k][c] = P_c(shift * w(log2 N_ext)^k).  Scalar restatement in the
+ * reference: build_const_tree.cpp:360-396 (x shift^i / N) and :398-531. */
+void orc_extend_pol(u64 *out, const u64 *in, u64 n_ext, u64 n, u64 ncols)
+{
+    if (n == 0 || ncols == 0) return;
+#pragma omp parallel
+    {
+        u64 *col = (u64 *)malloc(n_ext * sizeof(u64));
+#pragma omp for schedule(dynamic, 1)
+        for (u64 c = 0; c < ncols; c++) {
+            for (u64 i = 0; i < n; i++) col[i] = gl_canon(in[i * ncols + c]);
+            ntt_col(col, n, 1);
+            u64 s = 1;
+            for (u64 i = 0; i < n; i++) { col[i] = gl_mul(col[i], s); s = gl_mul(s, GL_SHIFT); }
+            for (u64 i = n; i < n_ext; i++) col[i] = 0;
+            ntt_col(col, n_ext, 0);
+            for (u64 i = 0; i < n_ext; i++) out[i * ncols + c] = col[i];
+        }
+        free(col);
+    }
+}
+
+/* Naive evaluation: out[k] = P(shift*w_ext^k) by Horner over INTT coefficients
+ * computed with the naive DFT.  Independent check of orc_extend_pol. */
+void orc_extend_naive(u64 *out, const u64 *in, u64 n_ext, u64 n)
+{
+    u64 *coef = (u64 *)malloc(n * sizeof(u64));
+    orc_dft_naive(coef, in, n, 1);
+    u64 wext = orc_w(ilog2(n_ext));
+    for (u64 k = 0; k < n_ext; k++) {
+        u64 x = gl_mul(GL_SHIFT, gl_pow(wext, k)), acc = 0;
+        for (u64 i = n; i-- > 0;) acc = gl_add(gl_mul(acc, x), coef[i]);
+        out[k] = acc;
+    }
+    free(coef);
+}
+
+/* -------------------------------------------------------------- Transcript */
+/* src/starkpil/transcript/transcript.cpp:4-87, transcript.hpp:13-37. */
+typedef struct {
+    u64 state[4];
+    u64 pending[8];
+    u64 out[12];
+    u64 pending_cursor;
+    u64 out_cursor;
+} orc_transcript;
+
+void orc_transcript_init(orc_transcript *t) { memset(t, 0, sizeof(*t)); }
+static void transcript_absorb(orc_transcript *t)
+{
+    u64 in[12];
+    memcpy(in, t->pending, 64);
+    memcpy(in + 8, t->state, 32);
+    orc_poseidon_perm(t->out, in);
+    t->out_cursor = 12;
+    memset(t->pending, 0, 64);
+    t->pending_cursor = 0;
+    memcpy(t->state, t->out, 32);
+}
+void orc_transcript_put(orc_transcript *t, const u64 *in, u64 n)
+{
+    for (u64 i = 0; i < n; i++) {
+        t->pending[t->pending_cursor++] = in[i];
+        t->out_cursor = 0;
+        if (t->pending_cursor == 8) transcript_absorb(t);
+    }
+}
+u64 orc_transcript_get1(orc_transcript *t)
+{
+    if (t->out_cursor == 0) transcript_absorb(t);
+    u64 r = t->out[(12 - t->out_cursor) % 12];
+    t->out_cursor--;
+    return r;
+}
+void orc_transcript_get_field(orc_transcript *t, u64 out[3])
+{
+    for (int i = 0; i < 3; i++) out[i] = orc_transcript_get1(t);
+}
+/* transcript.cpp:57-87: 63 bits per field element, LSB first. */
+void orc_transcript_get_permutations(orc_transcript *t, u64 *res, u64 n, u64 nbits)
+{
+    u64 total = n * nbits;
+    u64 nfields = (total - 1) / 63 + 1;
+    u64 *f = (u64 *)malloc(nfields * sizeof(u64));
+    for (u64 i = 0; i < nfields; i++) f[i] = orc_transcript_get1(t);
+    u64 cf = 0, cb = 0;
+    for (u64 i = 0; i < n; i++) {
+        u64 a = 0;
+        for (u64 j = 0; j < nbits; j++) {
+            u64 bit = (gl_canon(f[cf]) >> cb) & 1;
+            if (bit) a += (1ULL << j);
+            if (++cb == 63) { cb = 0; cf++; }
+        }
+        res[i] = a;
+    }
+    free(f);
+}
+
+/* --------------------------------------------------------------------- FRI */
+/* One folding step of FRIProve::prove, friProve.cpp:44-108 (+polMulAxi :192,
+ * evalPol :201).  pol: 2^bits ext-3 elements; pol2: 2^(bits-red).
+ *   g-th output = Horner_x( INTT_nX({pol[i*M+g]}_i) (.) (sinv*w(bits)^-g)^i ),
+ * M = 2^(bits-red), nX = 2^red.  red == 0 is the copy at :87-90. */
+void orc_fri_fold(u64 *pol2, const u64 *pol, unsigned bits, unsigned red, const u64 x[3], u64 shift_inv)
+{
+    u64 M = 1ULL << (bits - red), nX = 1ULL << red;
+    if (red == 0) { memcpy(pol2, pol, M * 3 * sizeof(u64)); return; }
+    u64 wi = gl_inv(orc_w(bits));
+#pragma omp parallel
+    {
+        u64 *col = (u64 *)malloc(nX * 3 * sizeof(u64));
+        u64 *tmp = (u64 *)malloc(nX * sizeof(u64));
+#pragma omp for schedule(static)
+        for (u64 g = 0; g < M; g++) {
+            for (u64 i = 0; i < nX; i++) memcpy(col + 3 * i, pol + 3 * (i * M + g), 24);
+            for (int d = 0; d < 3; d++) {
+                for (u64 i = 0; i < nX; i++) tmp[i] = gl_canon(col[3 * i + d]);
+                ntt_col(tmp, nX, 1);
+                for (u64 i = 0; i < nX; i++) col[3 * i + d] = tmp[i];
+            }
+            u64 acc = gl_mul(shift_inv, gl_pow(wi, g)), r = 1;
+            for (u64 i = 0; i < nX; i++) {
+                for (int d = 0; d < 3; d++) col[3 * i + d] = gl_mul(col[3 * i + d], r);
+                r = gl_mul(r, acc);
+            }
+            u64 res[3];
+            memcpy(res, col + 3 * (nX - 1), 24);
+            for (u64 i = nX - 1; i-- > 0;) {
+                u64 t[3];
+                gl3_mul(t, res, x);
+                for (int d = 0; d < 3; d++) res[d] = gl_add(t[d], col[3 * i + d]);
+            }
+            memcpy(pol2 + 3 * g, res, 24);
+        }
+        free(col);
+        free(tmp);
+    }
+}
+
+/* FRIProve::getTransposed, friProve.cpp:252-271: w = 2^tbits, h = n/w,
+ * dst[i*h + j] = src[j*w + i], ext-3 elements. */
+void orc_transpose3(u64 *dst, const u64 *src, u64 n, unsigned tbits)
+{
+    u64 w = 1ULL << tbits, h = n / w;
+    for (u64 i = 0; i < w; i++)
+        for (u64 j = 0; j < h; j++) memcpy(dst + 3 * (i * h + j), src + 3 * (j * w + i), 24);
+}
+
+/* Verifier-side fold of one FRI query (pins orc_fri_fold's conventions against
+ * the golden proofs): vals = the nX ext-3 values of tree row `g`, laid out as
+ * the reference's transposed group; returns the folded value at index g. */
+void orc_fri_fold_one(u64 out[3], const u64 *vals, unsigned bits, unsigned red, u64 g, const u64 x[3], u64 shift_inv)
+{
+    u64 nX = 1ULL << red;
+    u64 *col = (u64 *)malloc(nX * 3 * sizeof(u64));
+    u64 *tmp = (u64 *)malloc(nX * sizeof(u64));
+    memcpy(col, vals, nX * 24);
+    for (int d = 0; d < 3; d++) {
+        for (u64 i = 0; i < nX; i++) tmp[i] = gl_canon(col[3 * i + d]);
+        ntt_col(tmp, nX, 1);
+        for (u64 i = 0; i < nX; i++) col[3 * i + d] = tmp[i];
+    }
+    u64 acc = gl_mul(shift_inv, gl_pow(gl_inv(orc_w(bits)), g)), r = 1;
+    for (u64 i = 0; i < nX; i++) {
+        for (int d = 0; d < 3; d++) col[3 * i + d] = gl_mul(col[3 * i + d], r);
+        r = gl_mul(r, acc);
+    }
+    u64 res[3];
+    memcpy(res, col + 3 * (nX - 1), 24);
+    for (u64 i = nX - 1; i-- > 0;) {
+        u64 t[3];
+        gl3_mul(t, res, x);
+        for (int d = 0; d < 3; d++) res[d] = gl_add(t[d], col[3 * i + d]);
+    }
+    memcpy(out, res, 24);
+    free(col);
+    free(tmp);
+}
+
+/* Synthetic trace generator shared by tests and bench:
+ * x[i] = splitmix64(seed ^ i) mod p. */
+static inline u64 splitmix64(u64 z)
+{
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+void orc_fill(u64 *dst, u64 n, u64 seed, u64 start)
+{
+#pragma omp parallel for schedule(static)
+    for (u64 i = 0; i < n; i++) dst[i] = splitmix64(seed ^ (start + i)) % GL_P;
+}
+
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,207 @@
+"""ctypes binding of oracle/libgl_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg; never by the product package (xlayer_prover_amd).  See gl_oracle.c header
+for provenance and pinning.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libgl_oracle.so")
+P = 0xFFFFFFFF00000001
+u64 = C.c_uint64
+_pu64 = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "gl_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def _load():
+    build()
+    lib = C.CDLL(_SO)
+    sig = {
+        "orc_add": (u64, [u64, u64]), "orc_sub": (u64, [u64, u64]), "orc_mul": (u64, [u64, u64]),
+        "orc_inv": (u64, [u64]), "orc_pow": (u64, [u64, u64]), "orc_w": (u64, [C.c_uint]),
+        "orc_shift": (u64, []),
+        "orc_mul3": (None, [_pu64, _pu64, _pu64]),
+        "orc_poseidon_perm": (None, [_pu64, _pu64]),
+        "orc_linear_hash": (None, [_pu64, _pu64, u64]),
+        "orc_merkletree": (None, [_pu64, _pu64, u64, u64]),
+        "orc_merkle_proof": (None, [_pu64, _pu64, _pu64, u64, u64, u64]),
+        "orc_merkle_root_from_path": (None, [_pu64, _pu64, u64, _pu64, u64, u64]),
+        "orc_find_merkle_index": (u64, [_pu64, u64, _pu64, u64, _pu64]),
+        "orc_ntt": (None, [_pu64, _pu64, u64, u64, C.c_int]),
+        "orc_dft_naive": (None, [_pu64, _pu64, u64, C.c_int]),
+        "orc_extend_pol": (None, [_pu64, _pu64, u64, u64, u64]),
+        "orc_extend_naive": (None, [_pu64, _pu64, u64, u64]),
+        "orc_fri_fold": (None, [_pu64, _pu64, C.c_uint, C.c_uint, _pu64, u64]),
+        "orc_fri_fold_one": (None, [_pu64, _pu64, C.c_uint, C.c_uint, u64, _pu64, u64]),
+        "orc_transpose3": (None, [_pu64, _pu64, u64, C.c_uint]),
+        "orc_fill": (None, [_pu64, u64, u64, u64]),
+        "orc_num_threads": (C.c_int, []),
+        "orc_transcript_init": (None, [C.c_void_p]),
+        "orc_transcript_put": (None, [C.c_void_p, _pu64, u64]),
+        "orc_transcript_get1": (u64, [C.c_void_p]),
+        "orc_transcript_get_permutations": (None, [C.c_void_p, _pu64, u64, u64]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(lib, name)
+        f.restype = res
+        f.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def _a(x):
+    return np.ascontiguousarray(np.asarray(x, dtype=np.uint64))
+
+
+def add(a, b): return lib.orc_add(a, b)
+def sub(a, b): return lib.orc_sub(a, b)
+def mul(a, b): return lib.orc_mul(a, b)
+def inv(a): return lib.orc_inv(a)
+def pow_(a, e): return lib.orc_pow(a, e)
+def w(n): return lib.orc_w(n)
+def shift(): return lib.orc_shift()
+
+
+def mul3(a, b):
+    o = np.zeros(3, np.uint64)
+    lib.orc_mul3(o, _a(a), _a(b))
+    return o
+
+
+def perm(state12):
+    o = np.zeros(12, np.uint64)
+    lib.orc_poseidon_perm(o, _a(state12))
+    return o
+
+
+def linear_hash(vals):
+    v = _a(vals).ravel()
+    o = np.zeros(4, np.uint64)
+    lib.orc_linear_hash(o, v if v.size else np.zeros(1, np.uint64), v.size)
+    return o
+
+
+def merkletree(src, w_, h):
+    src = _a(src).ravel()
+    nodes = np.zeros((2 * h - 1) * 4, np.uint64)
+    lib.orc_merkletree(nodes, src if src.size else np.zeros(1, np.uint64), w_, h)
+    return nodes
+
+
+def merkle_proof(nodes, src, w_, h, idx):
+    nsib = max(h.bit_length() - 1, 0)
+    proof = np.zeros(max(w_ + 4 * nsib, 1), np.uint64)
+    s = _a(src).ravel()
+    lib.orc_merkle_proof(proof, _a(nodes), s if s.size else np.zeros(1, np.uint64), w_, h, idx)
+    return proof[: w_ + 4 * nsib]
+
+
+def merkle_root_from_path(row, sib, idx):
+    row = _a(row).ravel()
+    sib = _a(sib).ravel()
+    o = np.zeros(4, np.uint64)
+    lib.orc_merkle_root_from_path(o, row if row.size else np.zeros(1, np.uint64), row.size,
+                                  sib if sib.size else np.zeros(1, np.uint64), sib.size // 4, idx)
+    return o
+
+
+def find_merkle_index(row, sib, root):
+    row = _a(row).ravel()
+    sib = _a(sib).ravel()
+    return lib.orc_find_merkle_index(row, row.size, sib, sib.size // 4, _a(root))
+
+
+def ntt(src, n, ncols, inverse=False):
+    src = _a(src).ravel()
+    dst = np.zeros(n * ncols, np.uint64)
+    if n * ncols:
+        lib.orc_ntt(dst, src, n, ncols, 1 if inverse else 0)
+    return dst.reshape(n, ncols)
+
+
+def dft_naive(col, inverse=False):
+    col = _a(col).ravel()
+    dst = np.zeros(col.size, np.uint64)
+    lib.orc_dft_naive(dst, col, col.size, 1 if inverse else 0)
+    return dst
+
+
+def extend_pol(src, n_ext, n, ncols):
+    src = _a(src).ravel()
+    out = np.zeros(n_ext * ncols, np.uint64)
+    if n * ncols:
+        lib.orc_extend_pol(out, src, n_ext, n, ncols)
+    return out.reshape(n_ext, ncols)
+
+
+def extend_naive(col, n_ext):
+    col = _a(col).ravel()
+    out = np.zeros(n_ext, np.uint64)
+    lib.orc_extend_naive(out, col, n_ext, col.size)
+    return out
+
+
+def fri_fold(pol, bits, red, x, shift_inv):
+    pol = _a(pol).ravel()
+    out = np.zeros(3 << (bits - red), np.uint64)
+    lib.orc_fri_fold(out, pol, bits, red, _a(x), shift_inv)
+    return out.reshape(-1, 3)
+
+
+def fri_fold_one(vals, bits, red, g, x, shift_inv):
+    o = np.zeros(3, np.uint64)
+    lib.orc_fri_fold_one(o, _a(vals).ravel(), bits, red, g, _a(x), shift_inv)
+    return o
+
+
+def transpose3(src, n, tbits):
+    dst = np.zeros(3 * n, np.uint64)
+    lib.orc_transpose3(dst, _a(src).ravel(), n, tbits)
+    return dst.reshape(n, 3)
+
+
+def fill(n, seed, start=0):
+    dst = np.zeros(n, np.uint64)
+    if n:
+        lib.orc_fill(dst, n, seed, start)
+    return dst
+
+
+def num_threads():
+    return lib.orc_num_threads()
+
+
+class Transcript:
+    """Mirror of reference Transcript (transcript.hpp:13-37) on the oracle."""
+
+    def __init__(self):
+        self._buf = (C.c_uint64 * 26)()
+        lib.orc_transcript_init(C.addressof(self._buf))
+
+    def put(self, vals):
+        v = _a(vals).ravel()
+        if v.size:
+            lib.orc_transcript_put(C.addressof(self._buf), v, v.size)
+
+    def get1(self):
+        return lib.orc_transcript_get1(C.addressof(self._buf))
+
+    def get_field(self):
+        return np.array([self.get1() for _ in range(3)], np.uint64)
+
+    def get_permutations(self, n, nbits):
+        res = np.zeros(n, np.uint64)
+        lib.orc_transcript_get_permutations(C.addressof(self._buf), res, n, nbits)
+        return res
