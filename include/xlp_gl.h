@@ -1,0 +1,107 @@
+/*
+ * xlp_gl.h -- C ABI of libxlp_gl.so: the MI355X (gfx950) replacement for the
+ * Goldilocks field library calls made on the Starks::genProof hot path of
+ * okx/xlayer-prover.  Every entry point names the reference interface it
+ * replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - field elements are uint64_t; inputs may be any value in [0, 2^64)
+ *     (canonical or not), outputs are canonical (< p = 2^64 - 2^32 + 1);
+ *   - matrices are row-major [rows][ncols] exactly like the reference slab
+ *     (src/starkpil/stark_info.cpp:473-482);
+ *   - every function returns 0 on success, non-zero on error;
+ *     xlp_last_error() then describes it.  The reference's functions return
+ *     void and call exitProcess() on failure (src/utils/exit_process.cpp:7);
+ *     the C++ shim (xlayer_prover_amd/host/) converts non-zero into that;
+ *   - the caller owns every buffer; nothing is retained past return except
+ *     caches owned by the process-wide context (twiddle tables, scratch);
+ *   - there is NO CPU fallback: without a usable HIP device every call fails.
+ *
+ * Two layers:
+ *   xlp_*      host pointers  (drop-in for today's call sites: the data lives
+ *              in the prover's host slab, src/prover/prover.cpp:94-115)
+ *   xlp_dev_*  device pointers, asynchronous on the context's stream (for a
+ *              GPU-resident genProof; used by bench.py and the tests)
+ */
+#ifndef XLP_GL_H
+#define XLP_GL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- context ------------------------------------------------------------ */
+/* Bind the library to HIP device `device` (creates the stream and caches).
+ * Idempotent.  Replaces nothing in the reference (CPU library needs no init);
+ * closest analogue: NTT_Goldilocks constructor building twiddles, starks.hpp:81-82. */
+int xlp_init(int device);
+/* Use an existing hipStream_t (e.g. torch's current stream) for all xlp_dev_* work. */
+int xlp_set_stream(void* hip_stream);
+int xlp_sync(void);
+void xlp_shutdown(void);
+const char* xlp_last_error(void);
+/* 0xMMmmpp */
+int xlp_version(void);
+
+/* ---- host-pointer API (drop-in) ----------------------------------------- */
+/* NTT_Goldilocks::NTT / ::INTT(dst, src, size, ncols, buffer, nphase, nblock)
+ * -- starks.cpp:262,285,326-327; friProve.cpp:100-102.  Natural order in and
+ * out; inverse != 0 applies w^-1 and the 1/n scaling.  dst may equal src. */
+int xlp_ntt(uint64_t* dst, const uint64_t* src, uint64_t n, uint64_t ncols, int inverse);
+
+/* NTT_Goldilocks::extendPol(out, in, N_ext, N, ncols, buffer) -- starks.cpp:53,134,215.
+ * out[k][c] = P_c(shift * w(log2 n_ext)^k), shift = 7.  `scratch` is accepted
+ * for signature parity and ignored by the host-pointer entry point. */
+int xlp_extend(uint64_t* out, const uint64_t* in, uint64_t n_ext, uint64_t n, uint64_t ncols, uint64_t* scratch);
+
+/* PoseidonGoldilocks::merkletree_avx / merkletree_avx512 / merkletree
+ * (tree, input, num_cols, num_rows) -- merkleTreeGL.cpp:39-43, starks.cpp:688-692,
+ * tools/starkpil/bctree/build_const_tree.cpp:582.
+ * nodes: (2h-1)*4 elements = level0 | level1 | ... | root (merkleTreeGL.hpp:61-68). */
+int xlp_merkle(uint64_t* nodes, const uint64_t* src, uint64_t w, uint64_t h);
+
+/* PoseidonGoldilocks::hash_full_result(out12, in12) -- transcript.cpp:23,46. */
+int xlp_perm(uint64_t out[12], const uint64_t in[12]);
+/* Batched form of the above: `count` independent 12-word states. */
+int xlp_perm_batch(uint64_t* out, const uint64_t* in, uint64_t count);
+
+/* PoseidonGoldilocks::linear_hash(out4, in, n) -- the leaf rule of merkletree;
+ * here for `h` rows of width `w` at once (out: h*4). */
+int xlp_linear_hash(uint64_t* out, const uint64_t* src, uint64_t w, uint64_t h);
+
+/* One folding step of FRIProve::prove -- friProve.cpp:44-108 (+polMulAxi :192,
+ * evalPol :201).  pol: 2^bits ext-3 elements; pol2: 2^(bits-red);
+ * x: the challenge special_x; shift_inv: current polShiftInv (friProve.cpp:33,142-148). */
+int xlp_fri_fold(uint64_t* pol2, const uint64_t* pol, uint32_t bits, uint32_t red, const uint64_t x[3], uint64_t shift_inv);
+
+/* FRIProve::getTransposed(aux, pol, trasposeBits) -- friProve.cpp:252-271.
+ * n ext-3 elements; dst[i*h + j] = src[j*w + i], w = 2^tbits, h = n / w. */
+int xlp_transpose3(uint64_t* dst, const uint64_t* src, uint64_t n, uint32_t tbits);
+
+/* ---- device-pointer API -------------------------------------------------- */
+/* Same semantics as above; pointers are device memory on the bound device;
+ * calls enqueue on the context stream and return without synchronising. */
+int xlp_dev_ntt(uint64_t* dst, const uint64_t* src, uint64_t n, uint64_t ncols, int inverse);
+/* scratch: device buffer of >= 2*n*ncols elements, or NULL to use the context's. */
+int xlp_dev_extend(uint64_t* out, const uint64_t* in, uint64_t n_ext, uint64_t n, uint64_t ncols, uint64_t* scratch);
+int xlp_dev_merkle(uint64_t* nodes, const uint64_t* src, uint64_t w, uint64_t h);
+int xlp_dev_perm_batch(uint64_t* out, const uint64_t* in, uint64_t count);
+int xlp_dev_linear_hash(uint64_t* out, const uint64_t* src, uint64_t w, uint64_t h);
+int xlp_dev_fri_fold(uint64_t* pol2, const uint64_t* pol, uint32_t bits, uint32_t red, const uint64_t x[3], uint64_t shift_inv);
+int xlp_dev_transpose3(uint64_t* dst, const uint64_t* src, uint64_t n, uint32_t tbits);
+/* Synthetic trace: dst[i] = splitmix64(seed ^ (start + i)) mod p. */
+int xlp_dev_fill(uint64_t* dst, uint64_t n, uint64_t seed, uint64_t start);
+
+/* Plain device memory helpers so a C++/cgo/ctypes host needs no HIP headers. */
+int xlp_dev_alloc(void** ptr, size_t bytes);
+int xlp_dev_free(void* ptr);
+int xlp_copy_h2d(void* dst_dev, const void* src_host, size_t bytes);
+int xlp_copy_d2h(void* dst_host, const void* src_dev, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XLP_GL_H */

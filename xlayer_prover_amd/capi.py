@@ -1,0 +1,225 @@
+"""ctypes binding of libxlp_gl.so (the C ABI declared in include/xlp_gl.h).
+
+There is deliberately no fallback: if the shared library is missing or no HIP
+device can be bound, every call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+P = 0xFFFFFFFF00000001
+
+# name -> (argtypes) ; all return int.  Mirrors include/xlp_gl.h one to one.
+_pu = C.c_void_p
+_u64 = C.c_uint64
+_u32 = C.c_uint32
+SIGNATURES = {
+    "xlp_init": [C.c_int],
+    "xlp_set_stream": [C.c_void_p],
+    "xlp_sync": [],
+    "xlp_version": [],
+    "xlp_ntt": [_pu, _pu, _u64, _u64, C.c_int],
+    "xlp_extend": [_pu, _pu, _u64, _u64, _u64, _pu],
+    "xlp_merkle": [_pu, _pu, _u64, _u64],
+    "xlp_perm": [_pu, _pu],
+    "xlp_perm_batch": [_pu, _pu, _u64],
+    "xlp_linear_hash": [_pu, _pu, _u64, _u64],
+    "xlp_fri_fold": [_pu, _pu, _u32, _u32, _pu, _u64],
+    "xlp_transpose3": [_pu, _pu, _u64, _u32],
+    "xlp_dev_ntt": [_pu, _pu, _u64, _u64, C.c_int],
+    "xlp_dev_extend": [_pu, _pu, _u64, _u64, _u64, _pu],
+    "xlp_dev_merkle": [_pu, _pu, _u64, _u64],
+    "xlp_dev_perm_batch": [_pu, _pu, _u64],
+    "xlp_dev_linear_hash": [_pu, _pu, _u64, _u64],
+    "xlp_dev_fri_fold": [_pu, _pu, _u32, _u32, _pu, _u64],
+    "xlp_dev_transpose3": [_pu, _pu, _u64, _u32],
+    "xlp_dev_fill": [_pu, _u64, _u64, _u64],
+    "xlp_dev_alloc": [C.POINTER(C.c_void_p), C.c_size_t],
+    "xlp_dev_free": [_pu],
+    "xlp_copy_h2d": [_pu, _pu, C.c_size_t],
+    "xlp_copy_d2h": [_pu, _pu, C.c_size_t],
+}
+VOID_SIGNATURES = {"xlp_shutdown": [], }
+STR_SIGNATURES = {"xlp_last_error": []}
+
+
+class XlpError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libxlp_gl.so")
+
+
+def load():
+    """dlopen libxlp_gl.so and bind every symbol of include/xlp_gl.h (no GPU needed)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    # One HIP runtime per process: torch ships its own libamdhip64.so.7; if it is
+    # importable, load it FIRST so that our NEEDED libamdhip64.so.7 resolves (by
+    # SONAME) to the copy torch uses.  Two runtimes in one process cannot both
+    # bind the GPU ("No HIP GPUs are available").
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    path = lib_path()
+    if not os.path.exists(path):
+        raise XlpError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(there is no CPU fallback)")
+    lib = C.CDLL(path)
+    for name, args in SIGNATURES.items():
+        f = getattr(lib, name)
+        f.argtypes = args
+        f.restype = C.c_int
+    for name, args in VOID_SIGNATURES.items():
+        f = getattr(lib, name)
+        f.argtypes = args
+        f.restype = None
+    lib.xlp_last_error.argtypes = []
+    lib.xlp_last_error.restype = C.c_char_p
+    _LIB = lib
+    return lib
+
+
+def _ck(rc, what):
+    if rc != 0:
+        raise XlpError(f"{what} failed: {load().xlp_last_error().decode()}")
+
+
+def init(device=0):
+    _ck(load().xlp_init(device), "xlp_init")
+
+
+def sync():
+    _ck(load().xlp_sync(), "xlp_sync")
+
+
+def use_torch_stream():
+    """Run xlp_dev_* work on torch's current HIP stream (so torch events bracket it)."""
+    import torch
+    _ck(load().xlp_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)), "xlp_set_stream")
+
+
+# ----------------------------------------------------------------- host layer
+def _np(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.uint64))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def ntt(src, n, ncols, inverse=False, inplace=False):
+    src = _np(src).reshape(-1)
+    assert src.size == n * ncols
+    dst = src if inplace else np.empty_like(src)
+    _ck(load().xlp_ntt(_p(dst), _p(src), n, ncols, 1 if inverse else 0), "xlp_ntt")
+    return dst.reshape(n, ncols)
+
+
+def extend(src, n_ext, n, ncols):
+    src = _np(src).reshape(-1)
+    assert src.size == n * ncols
+    out = np.empty(n_ext * ncols, np.uint64)
+    _ck(load().xlp_extend(_p(out), _p(src), n_ext, n, ncols, None), "xlp_extend")
+    return out.reshape(n_ext, ncols)
+
+
+def merkle(src, w, h):
+    src = _np(src).reshape(-1)
+    assert src.size == w * h
+    nodes = np.empty((2 * h - 1) * 4, np.uint64)
+    _ck(load().xlp_merkle(_p(nodes), _p(src) if src.size else None, w, h), "xlp_merkle")
+    return nodes
+
+
+def perm(state):
+    s = _np(state).reshape(-1)
+    assert s.size == 12
+    out = np.empty(12, np.uint64)
+    _ck(load().xlp_perm(_p(out), _p(s)), "xlp_perm")
+    return out
+
+
+def perm_batch(states):
+    s = _np(states).reshape(-1, 12)
+    out = np.empty_like(s)
+    _ck(load().xlp_perm_batch(_p(out), _p(s), s.shape[0]), "xlp_perm_batch")
+    return out
+
+
+def linear_hash(src, w, h):
+    src = _np(src).reshape(-1)
+    out = np.empty(4 * h, np.uint64)
+    _ck(load().xlp_linear_hash(_p(out), _p(src) if src.size else None, w, h), "xlp_linear_hash")
+    return out.reshape(h, 4)
+
+
+def fri_fold(pol, bits, red, x, shift_inv):
+    pol = _np(pol).reshape(-1)
+    assert pol.size == 3 << bits
+    x = _np(x)
+    out = np.empty(3 << (bits - red), np.uint64)
+    _ck(load().xlp_fri_fold(_p(out), _p(pol), bits, red, _p(x), int(shift_inv)), "xlp_fri_fold")
+    return out.reshape(-1, 3)
+
+
+def transpose3(src, n, tbits):
+    src = _np(src).reshape(-1)
+    out = np.empty(3 * n, np.uint64)
+    _ck(load().xlp_transpose3(_p(out), _p(src), n, tbits), "xlp_transpose3")
+    return out.reshape(n, 3)
+
+
+# --------------------------------------------------------------- device layer
+# torch int64 CUDA tensors carry the uint64 words (torch is only the allocator).
+def _dp(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def dev_fill(t, seed, start=0):
+    _ck(load().xlp_dev_fill(_dp(t), t.numel(), seed, start), "xlp_dev_fill")
+
+
+def dev_ntt(dst, src, n, ncols, inverse=False):
+    _ck(load().xlp_dev_ntt(_dp(dst), _dp(src), n, ncols, 1 if inverse else 0), "xlp_dev_ntt")
+
+
+def dev_extend(out, src, n_ext, n, ncols, scratch=None):
+    _ck(load().xlp_dev_extend(_dp(out), _dp(src), n_ext, n, ncols, _dp(scratch) if scratch is not None else None), "xlp_dev_extend")
+
+
+def dev_merkle(nodes, src, w, h):
+    _ck(load().xlp_dev_merkle(_dp(nodes), _dp(src), w, h), "xlp_dev_merkle")
+
+
+def dev_perm_batch(out, src, count):
+    _ck(load().xlp_dev_perm_batch(_dp(out), _dp(src), count), "xlp_dev_perm_batch")
+
+
+def dev_linear_hash(out, src, w, h):
+    _ck(load().xlp_dev_linear_hash(_dp(out), _dp(src), w, h), "xlp_dev_linear_hash")
+
+
+def dev_fri_fold(pol2, pol, bits, red, x, shift_inv):
+    x = _np(x)
+    _ck(load().xlp_dev_fri_fold(_dp(pol2), _dp(pol), bits, red, _p(x), int(shift_inv)), "xlp_dev_fri_fold")
+
+
+def dev_transpose3(dst, src, n, tbits):
+    _ck(load().xlp_dev_transpose3(_dp(dst), _dp(src), n, tbits), "xlp_dev_transpose3")
+
+
+def to_np(t):
+    """device int64 tensor -> host uint64 ndarray"""
+    return t.detach().cpu().numpy().view(np.uint64)
+
+
+def from_np(a, device="cuda"):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(device)

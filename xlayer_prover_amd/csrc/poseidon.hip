@@ -1,0 +1,173 @@
+// Poseidon-Goldilocks permutation, linear hash and Merkle tree for gfx950.
+//
+// Replaces PoseidonGoldilocks::hash_full_result (transcript.cpp:23,46),
+// ::merkletree_avx / merkletree_avx512 (merkleTreeGL.cpp:39-43) of the
+// reference's absent goldilocks submodule.  Permutation parameters restated
+// from src/sm/poseidon_g/poseidon_g_executor.cpp:201-230 (t=12, RF=8, RP=22,
+// x^7, MDS = circ(17,15,41,16,2,28,13,13,39,18,34,20) + diag(8,0,...)).
+//
+// The kernels are integer-ALU bound: one permutation per lane,
+// state in 24 VGPRs, MDS by 32x32->64 multiply-adds against the small
+// circulant constants (the two 32-bit halves of each state word are
+// accumulated separately so no product exceeds 64 bits), one reduction per
+// output word.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gl_field.hpp"
+#include "xlp_internal.hpp"
+
+namespace xlp {
+using gl::u32;
+using gl::u64;
+
+__constant__ u64 POSEIDON_C[360] = {
+#include "poseidon_constants.inc"
+};
+
+__device__ __forceinline__ u64 pow7(u64 a)
+{
+    u64 a2 = gl::sqr(a), a4 = gl::sqr(a2), a3 = gl::mul(a, a2);
+    return gl::mul(a3, a4);
+}
+
+// M * st, M[i][j] = MCIRC[(j-i) mod 12] (+8 on [0][0]); inputs "any", outputs "any".
+__device__ __forceinline__ void mds(u64 (&st)[12])
+{
+    constexpr u32 MC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    u32 lo[12], hi[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) { lo[j] = (u32)st[j]; hi[j] = (u32)(st[j] >> 32); }
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        u64 L = 0, H = 0;
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const u32 m = MC[(j - i + 12) % 12] + ((i == 0 && j == 0) ? 8u : 0u);
+            L += (u64)lo[j] * m;   // < 2^32 * 49 * 12 < 2^42
+            H += (u64)hi[j] * m;
+        }
+        // value = L + H*2^32 = L + Hl*2^32 + Hh*2^64 ; Hh < 2^10
+        const u64 Hl = (u64)(u32)H << 32, Hh = H >> 32;
+        u64 lo64 = L + Hl;
+        const u64 c = lo64 < Hl;             // carry into 2^64
+        lo64 += (Hh + c) * gl::EPS;          // (Hh+c)*EPS < 2^43: may wrap once more
+        if (lo64 < (Hh + c) * gl::EPS) lo64 += gl::EPS;
+        st[i] = lo64;
+    }
+}
+
+__device__ __forceinline__ void permute(u64 (&st)[12])
+{
+#pragma unroll 1
+    for (int r = 0; r < 30; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], POSEIDON_C[12 * r + i]);  // any + canon
+        if (r < 4 || r >= 26) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) st[i] = pow7(st[i]);
+        } else {
+            st[0] = pow7(st[0]);
+        }
+        mds(st);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = gl::canon(st[i]);
+}
+
+// hash_full_result on `count` independent 12-word states.
+__global__ __launch_bounds__(256) void perm_kernel(u64* out, const u64* in, u64 count)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    u64 st[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) st[k] = in[12 * i + k];
+    permute(st);
+#pragma unroll
+    for (int k = 0; k < 12; k++) out[12 * i + k] = st[k];
+}
+
+// Leaf level: out[4*row..] = linear_hash(src[row][0..w)).
+// w <= 4: copy + zero-pad, no permutation.
+__global__ __launch_bounds__(256) void linear_hash_kernel(u64* out, const u64* src, u64 w, u64 h)
+{
+    u64 row = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= h) return;
+    const u64* in = src + row * w;
+    u64 st[12];
+    if (w <= 4) {
+        for (u64 k = 0; k < 4; k++) out[4 * row + k] = k < w ? gl::canon(in[k]) : 0;
+        return;
+    }
+    st[8] = st[9] = st[10] = st[11] = 0;
+    u64 rem = w;
+    while (rem) {
+        if (rem >= 8) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) st[k] = in[k];
+            in += 8; rem -= 8;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) st[k] = (u64)k < rem ? in[k] : 0;
+            rem = 0;
+        }
+        permute(st);
+        st[8] = st[0]; st[9] = st[1]; st[10] = st[2]; st[11] = st[3];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[4 * row + k] = st[k];
+}
+
+// One tree level: nxt[j] = perm(cur[2j] | cur[2j+1] | 0^4)[0..3].
+__global__ __launch_bounds__(256) void merkle_level_kernel(u64* nxt, const u64* cur, u64 count)
+{
+    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    u64 st[12];
+#pragma unroll
+    for (int k = 0; k < 8; k++) st[k] = cur[8 * j + k];
+    st[8] = st[9] = st[10] = st[11] = 0;
+    permute(st);
+#pragma unroll
+    for (int k = 0; k < 4; k++) nxt[4 * j + k] = st[k];
+}
+
+int poseidon_init(Ctx*) { return 0; }
+
+int dev_perm(Ctx* ctx, u64* out, const u64* in, u64 count)
+{
+    if (!count) return 0;
+    hipLaunchKernelGGL(perm_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, out, in, count);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
+int dev_linear_hash(Ctx* ctx, u64* out, const u64* src, u64 w, u64 h)
+{
+    if (!h) return 0;
+    if (w == 0) { XLP_HIP(hipMemsetAsync(out, 0, h * 4 * sizeof(u64), ctx->stream)); return 0; }
+    hipLaunchKernelGGL(linear_hash_kernel, dim3((unsigned)((h + 255) / 256)), dim3(256), 0, ctx->stream, out, src, w, h);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
+// PoseidonGoldilocks::merkletree_avx(tree, input, ncols, nrows): nodes =
+// level0 | level1 | ... | root, (2h-1)*4 elements (merkleTreeGL.hpp:61-68).
+int dev_merkle(Ctx* ctx, u64* nodes, const u64* src, u64 w, u64 h)
+{
+    if (!h) return 0;
+    if (h & (h - 1)) return xlp_fail("merkletree: number of rows is not a power of two");
+    if (dev_linear_hash(ctx, nodes, src, w, h)) return -1;
+    u64 off = 0, cnt = h;
+    while (cnt > 1) {
+        u64 half = cnt / 2;
+        hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, ctx->stream, nodes + off + 4 * cnt,
+                           nodes + off, half);
+        off += 4 * cnt;
+        cnt = half;
+    }
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace xlp

@@ -1,0 +1,305 @@
+// C ABI of libxlp_gl.so (declared in include/xlp_gl.h): context management,
+// host-pointer drop-in entry points (stage through device memory) and the
+// device-pointer entry points.  No CPU fallback exists: every entry point
+// fails if no HIP device can be bound.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <mutex>
+#include <string>
+#include "../../include/xlp_gl.h"
+#include "xlp_internal.hpp"
+
+namespace xlp {
+
+static thread_local std::string g_err;
+static Ctx g_ctx;
+static std::mutex g_mu;
+
+int xlp_fail(const char* msg)
+{
+    g_err = msg;
+    return -1;
+}
+int xlp_fail_hip(hipError_t e, const char* file, int line)
+{
+    char buf[512];
+    snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s:%d", (int)e, hipGetErrorString(e), file, line);
+    g_err = buf;
+    (void)hipGetLastError();
+    return -1;
+}
+
+int ctx_scratch(Ctx* ctx, size_t bytes, int slot, u64** out)
+{
+    if (ctx->scratch_bytes[slot] < bytes) {
+        if (ctx->scratch[slot]) {
+            XLP_HIP(hipStreamSynchronize(ctx->stream));
+            XLP_HIP(hipFree(ctx->scratch[slot]));
+            ctx->scratch[slot] = nullptr;
+            ctx->scratch_bytes[slot] = 0;
+        }
+        XLP_HIP(hipMalloc(&ctx->scratch[slot], bytes));
+        ctx->scratch_bytes[slot] = bytes;
+    }
+    *out = (u64*)ctx->scratch[slot];
+    return 0;
+}
+
+static int ensure_init()
+{
+    if (g_ctx.inited) return 0;
+    return xlp_init(0);
+}
+
+// RAII device staging buffer for the host-pointer entry points.
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes)
+    {
+        if (bytes == 0) bytes = 8;
+        XLP_HIP(hipMalloc(&p, bytes));
+        return 0;
+    }
+    u64* u() { return (u64*)p; }
+};
+
+}  // namespace xlp
+
+using namespace xlp;
+
+extern "C" {
+
+int xlp_version(void) { return 0x000100; }
+
+const char* xlp_last_error(void) { return g_err.c_str(); }
+
+int xlp_init(int device)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_ctx.inited && g_ctx.device == device) return 0;
+    if (g_ctx.inited) return xlp_fail("xlp_init: already bound to another device");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return xlp_fail("xlp_init: no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return xlp_fail("xlp_init: device index out of range");
+    XLP_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    XLP_HIP(hipGetDeviceProperties(&prop, device));
+    g_ctx.device = device;
+    XLP_HIP(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
+    g_ctx.own_stream = true;
+    if (ntt_init(&g_ctx)) return -1;
+    if (poseidon_init(&g_ctx)) return -1;
+    g_ctx.inited = true;
+    return 0;
+}
+
+int xlp_set_stream(void* hip_stream)
+{
+    if (ensure_init()) return -1;
+    XLP_HIP(hipStreamSynchronize(g_ctx.stream));
+    if (g_ctx.own_stream) { XLP_HIP(hipStreamDestroy(g_ctx.stream)); g_ctx.own_stream = false; }
+    g_ctx.stream = (hipStream_t)hip_stream;
+    return 0;
+}
+
+int xlp_sync(void)
+{
+    if (ensure_init()) return -1;
+    XLP_HIP(hipStreamSynchronize(g_ctx.stream));
+    return 0;
+}
+
+void xlp_shutdown(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_ctx.inited) return;
+    (void)hipStreamSynchronize(g_ctx.stream);
+    for (auto& kv : g_ctx.tables) (void)hipFree(kv.second);
+    g_ctx.tables.clear();
+    for (int i = 0; i < 4; i++) {
+        if (g_ctx.scratch[i]) (void)hipFree(g_ctx.scratch[i]);
+        g_ctx.scratch[i] = nullptr;
+        g_ctx.scratch_bytes[i] = 0;
+    }
+    if (g_ctx.own_stream) (void)hipStreamDestroy(g_ctx.stream);
+    g_ctx.stream = nullptr;
+    g_ctx.own_stream = false;
+    g_ctx.inited = false;
+}
+
+// ------------------------------------------------------------- device layer
+int xlp_dev_ntt(uint64_t* dst, const uint64_t* src, uint64_t n, uint64_t ncols, int inverse)
+{
+    if (ensure_init()) return -1;
+    return dev_ntt(&g_ctx, dst, src, n, ncols, inverse);
+}
+int xlp_dev_extend(uint64_t* out, const uint64_t* in, uint64_t n_ext, uint64_t n, uint64_t ncols, uint64_t* scratch)
+{
+    if (ensure_init()) return -1;
+    return dev_extend(&g_ctx, out, in, n_ext, n, ncols, scratch);
+}
+int xlp_dev_merkle(uint64_t* nodes, const uint64_t* src, uint64_t w, uint64_t h)
+{
+    if (ensure_init()) return -1;
+    return dev_merkle(&g_ctx, nodes, src, w, h);
+}
+int xlp_dev_perm_batch(uint64_t* out, const uint64_t* in, uint64_t count)
+{
+    if (ensure_init()) return -1;
+    return dev_perm(&g_ctx, out, in, count);
+}
+int xlp_dev_linear_hash(uint64_t* out, const uint64_t* src, uint64_t w, uint64_t h)
+{
+    if (ensure_init()) return -1;
+    return dev_linear_hash(&g_ctx, out, src, w, h);
+}
+int xlp_dev_fri_fold(uint64_t* pol2, const uint64_t* pol, uint32_t bits, uint32_t red, const uint64_t x[3], uint64_t shift_inv)
+{
+    if (ensure_init()) return -1;
+    return dev_fri_fold(&g_ctx, pol2, pol, bits, red, x, shift_inv);
+}
+int xlp_dev_transpose3(uint64_t* dst, const uint64_t* src, uint64_t n, uint32_t tbits)
+{
+    if (ensure_init()) return -1;
+    return dev_transpose3(&g_ctx, dst, src, n, tbits);
+}
+int xlp_dev_fill(uint64_t* dst, uint64_t n, uint64_t seed, uint64_t start)
+{
+    if (ensure_init()) return -1;
+    return dev_fill(&g_ctx, dst, n, seed, start);
+}
+
+int xlp_dev_alloc(void** ptr, size_t bytes)
+{
+    if (ensure_init()) return -1;
+    XLP_HIP(hipMalloc(ptr, bytes ? bytes : 8));
+    return 0;
+}
+int xlp_dev_free(void* ptr)
+{
+    if (!ptr) return 0;
+    XLP_HIP(hipFree(ptr));
+    return 0;
+}
+int xlp_copy_h2d(void* dst_dev, const void* src_host, size_t bytes)
+{
+    if (ensure_init()) return -1;
+    if (!bytes) return 0;
+    XLP_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, g_ctx.stream));
+    XLP_HIP(hipStreamSynchronize(g_ctx.stream));
+    return 0;
+}
+int xlp_copy_d2h(void* dst_host, const void* src_dev, size_t bytes)
+{
+    if (ensure_init()) return -1;
+    if (!bytes) return 0;
+    XLP_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, g_ctx.stream));
+    XLP_HIP(hipStreamSynchronize(g_ctx.stream));
+    return 0;
+}
+
+// --------------------------------------------------------------- host layer
+#define H2D(buf, host, bytes) do { if (xlp_copy_h2d((buf).p, (host), (bytes))) return -1; } while (0)
+#define D2H(host, buf, bytes) do { if (xlp_copy_d2h((host), (buf).p, (bytes))) return -1; } while (0)
+
+int xlp_ntt(uint64_t* dst, const uint64_t* src, uint64_t n, uint64_t ncols, int inverse)
+{
+    if (ensure_init()) return -1;
+    if (n == 0 || ncols == 0) return 0;
+    if (!dst || !src) return xlp_fail("xlp_ntt: null pointer");
+    const size_t bytes = n * ncols * sizeof(u64);
+    DevBuf a;
+    if (a.alloc(bytes)) return -1;
+    H2D(a, src, bytes);
+    if (dev_ntt(&g_ctx, a.u(), a.u(), n, ncols, inverse)) return -1;
+    D2H(dst, a, bytes);
+    return 0;
+}
+
+int xlp_extend(uint64_t* out, const uint64_t* in, uint64_t n_ext, uint64_t n, uint64_t ncols, uint64_t* scratch)
+{
+    (void)scratch;
+    if (ensure_init()) return -1;
+    if (n == 0 || ncols == 0) return 0;
+    if (!out || !in) return xlp_fail("xlp_extend: null pointer");
+    DevBuf a, b;
+    if (a.alloc(n * ncols * sizeof(u64)) || b.alloc(n_ext * ncols * sizeof(u64))) return -1;
+    H2D(a, in, n * ncols * sizeof(u64));
+    if (dev_extend(&g_ctx, b.u(), a.u(), n_ext, n, ncols, nullptr)) return -1;
+    D2H(out, b, n_ext * ncols * sizeof(u64));
+    return 0;
+}
+
+int xlp_merkle(uint64_t* nodes, const uint64_t* src, uint64_t w, uint64_t h)
+{
+    if (ensure_init()) return -1;
+    if (h == 0) return 0;
+    if (!nodes || (w && !src)) return xlp_fail("xlp_merkle: null pointer");
+    if (h & (h - 1)) return xlp_fail("merkletree: number of rows is not a power of two");
+    DevBuf a, b;
+    if (a.alloc(w * h * sizeof(u64)) || b.alloc((2 * h - 1) * 4 * sizeof(u64))) return -1;
+    H2D(a, src, w * h * sizeof(u64));
+    if (dev_merkle(&g_ctx, b.u(), a.u(), w, h)) return -1;
+    D2H(nodes, b, (2 * h - 1) * 4 * sizeof(u64));
+    return 0;
+}
+
+int xlp_perm_batch(uint64_t* out, const uint64_t* in, uint64_t count)
+{
+    if (ensure_init()) return -1;
+    if (count == 0) return 0;
+    if (!out || !in) return xlp_fail("xlp_perm: null pointer");
+    DevBuf a;
+    if (a.alloc(count * 12 * sizeof(u64))) return -1;
+    H2D(a, in, count * 12 * sizeof(u64));
+    if (dev_perm(&g_ctx, a.u(), a.u(), count)) return -1;
+    D2H(out, a, count * 12 * sizeof(u64));
+    return 0;
+}
+int xlp_perm(uint64_t out[12], const uint64_t in[12]) { return xlp_perm_batch(out, in, 1); }
+
+int xlp_linear_hash(uint64_t* out, const uint64_t* src, uint64_t w, uint64_t h)
+{
+    if (ensure_init()) return -1;
+    if (h == 0) return 0;
+    if (!out || (w && !src)) return xlp_fail("xlp_linear_hash: null pointer");
+    DevBuf a, b;
+    if (a.alloc(w * h * sizeof(u64)) || b.alloc(h * 4 * sizeof(u64))) return -1;
+    H2D(a, src, w * h * sizeof(u64));
+    if (dev_linear_hash(&g_ctx, b.u(), a.u(), w, h)) return -1;
+    D2H(out, b, h * 4 * sizeof(u64));
+    return 0;
+}
+
+int xlp_fri_fold(uint64_t* pol2, const uint64_t* pol, uint32_t bits, uint32_t red, const uint64_t x[3], uint64_t shift_inv)
+{
+    if (ensure_init()) return -1;
+    if (!pol2 || !pol || !x) return xlp_fail("xlp_fri_fold: null pointer");
+    if (red > bits) return xlp_fail("fri_fold: reduction exceeds polynomial size");
+    if (bits > 34) return xlp_fail("fri_fold: polynomial too large");
+    DevBuf a, b;
+    const size_t nin = (3ull << bits) * sizeof(u64), nout = (3ull << (bits - red)) * sizeof(u64);
+    if (a.alloc(nin) || b.alloc(nout)) return -1;
+    H2D(a, pol, nin);
+    if (dev_fri_fold(&g_ctx, b.u(), a.u(), bits, red, x, shift_inv)) return -1;
+    D2H(pol2, b, nout);
+    return 0;
+}
+
+int xlp_transpose3(uint64_t* dst, const uint64_t* src, uint64_t n, uint32_t tbits)
+{
+    if (ensure_init()) return -1;
+    if (n == 0) return 0;
+    if (!dst || !src) return xlp_fail("xlp_transpose3: null pointer");
+    DevBuf a, b;
+    if (a.alloc(3 * n * sizeof(u64)) || b.alloc(3 * n * sizeof(u64))) return -1;
+    H2D(a, src, 3 * n * sizeof(u64));
+    if (dev_transpose3(&g_ctx, b.u(), a.u(), n, tbits)) return -1;
+    D2H(dst, b, 3 * n * sizeof(u64));
+    return 0;
+}
+
+}  // extern "C"

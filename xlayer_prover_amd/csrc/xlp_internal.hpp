@@ -1,0 +1,70 @@
+// Internal declarations shared by the HIP translation units of libxlp_gl.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <map>
+#include <string>
+#include <tuple>
+
+namespace xlp {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+// Host-side scalar Goldilocks helpers: used only to derive launch constants
+// (roots of unity, 1/n, coset generators) -- never on the data path.
+namespace hgl {
+constexpr u64 P = 0xFFFFFFFF00000001ULL;
+inline u64 mul(u64 a, u64 b) { return (u64)(((unsigned __int128)a * b) % P); }
+inline u64 add(u64 a, u64 b) { return (u64)(((unsigned __int128)a + b) % P); }
+inline u64 sub(u64 a, u64 b) { return (u64)(((unsigned __int128)a + P - (b % P)) % P); }
+inline u64 pow(u64 a, u64 e)
+{
+    u64 r = 1;
+    while (e) { if (e & 1) r = mul(r, a); a = mul(a, a); e >>= 1; }
+    return r;
+}
+inline u64 inv(u64 a) { return pow(a, P - 2); }
+}  // namespace hgl
+
+int xlp_fail(const char* msg);             // records msg, returns -1
+int xlp_fail_hip(hipError_t e, const char* file, int line);
+
+#define XLP_HIP(expr)                                                   \
+    do {                                                                \
+        hipError_t _e = (expr);                                         \
+        if (_e != hipSuccess) return xlp_fail_hip(_e, __FILE__, __LINE__); \
+    } while (0)
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::map<std::tuple<u32, u64, u64>, u64*> tables;  // (L, root, mult) -> device power tables
+    void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[4] = {0, 0, 0, 0};
+    bool inited = false;
+};
+
+// Grow-only device scratch slots owned by the context.
+int ctx_scratch(Ctx* ctx, size_t bytes, int slot, u64** out);
+
+u64 host_w(unsigned n);  // Goldilocks::w(n)
+
+// ntt.hip
+int ntt_init(Ctx* ctx);
+int dev_ntt(Ctx* ctx, u64* dst, const u64* src, u64 n, u64 ncols, int inverse);
+int dev_extend(Ctx* ctx, u64* out, const u64* in, u64 n_ext, u64 n, u64 ncols, u64* scratch);
+
+// poseidon.hip
+int poseidon_init(Ctx* ctx);
+int dev_perm(Ctx* ctx, u64* out, const u64* in, u64 count);
+int dev_linear_hash(Ctx* ctx, u64* out, const u64* src, u64 w, u64 h);
+int dev_merkle(Ctx* ctx, u64* nodes, const u64* src, u64 w, u64 h);
+
+// fri.hip
+int dev_fri_fold(Ctx* ctx, u64* pol2, const u64* pol, u32 bits, u32 red, const u64 x[3], u64 shift_inv);
+int dev_transpose3(Ctx* ctx, u64* dst, const u64* src, u64 n, u32 tbits);
+int dev_fill(Ctx* ctx, u64* dst, u64 n, u64 seed, u64 start);
+
+}  // namespace xlp
