@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the STARK hot path on MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic input:
+BASELINE.json configs[1], the LDE (NTT_Goldilocks::extendPol, starks.cpp:53)
+of a 2^23 x 8 Goldilocks trace to 2^24 x 8 (blow-up 2), inputs resident in HBM.
+Metric: Goldilocks NTT throughput in GFE/s = output field elements / second,
+whole job (all ranks).  With --gpus N each rank extends its own 8-column shard
+of an (8N)-column trace (columns are independent: weak scaling, no data-path
+collective).
+
+Prints ONE JSON line (rank 0) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LOG_N = 23
+NCOLS = 8
+EXT_BITS = 1
+SEED = 0x5EED0002
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PASS_LAUNCHES_PER_LDE = 9        # ntt_pass_kernel launches per extendPol at this size (3 INTT + 2 cosets x 3)
+
+
+def cpu_baseline(log_n, ncols, budget_s=20.0):
+    """Oracle (restated CPU path, OpenMP over columns) timed on this host, bounded sample."""
+    from oracle import gl_oracle as orc
+    threads = orc.num_threads()
+    # pick a sample size whose run time is ~10-30 s: calibrate on 2^16
+    n = 1 << 16
+    src = orc.fill(n * ncols, SEED).reshape(n, ncols)
+    t0 = time.perf_counter()
+    orc.extend_pol(src, n << EXT_BITS, n, ncols)
+    t = time.perf_counter() - t0
+    per_fe_log = t / (n * ncols * 17)                # ~ n log n model
+    lg = 16
+    while lg < log_n and per_fe_log * (1 << (lg + 1)) * ncols * (lg + 2) < budget_s:
+        lg += 1
+    n = 1 << lg
+    src = orc.fill(n * ncols, SEED).reshape(n, ncols)
+    t0 = time.perf_counter()
+    orc.extend_pol(src, n << EXT_BITS, n, ncols)
+    t = time.perf_counter() - t0
+    return {
+        "value": (n << EXT_BITS) * ncols / t / 1e9, "unit": "GFE/s", "cores": min(threads, ncols), "kind": "port",
+        "sample": f"oracle extendPol 2^{lg} x {ncols} -> 2^{lg + EXT_BITS} x {ncols} ({t:.2f} s, OpenMP over columns, "
+                  f"scalar u128 arithmetic; restated CPU path, not the reference's AVX2 binary)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--log-n", type=int, default=LOG_N)
+    ap.add_argument("--ncols", type=int, default=NCOLS)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from xlayer_prover_amd import capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    capi.init(local_rank)
+    capi.use_torch_stream()
+
+    n, ncols = 1 << args.log_n, args.ncols
+    n_ext = n << EXT_BITS
+    src = torch.empty(n * ncols, dtype=torch.int64, device=dev)
+    out = torch.empty(n_ext * ncols, dtype=torch.int64, device=dev)
+    scratch = torch.empty(2 * n * ncols, dtype=torch.int64, device=dev)
+    # rank r owns columns [8r, 8r+8) of the synthetic trace: element index = row*(8*world) + col
+    capi.dev_fill(src, SEED, rank * n * ncols)
+
+    def step():
+        capi.dev_extend(out, src, n_ext, n, ncols, scratch)
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    dev_ms = ev0.elapsed_time(ev1)           # HIP events on the stream the kernels run on
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        fe_per_step = n_ext * ncols * world
+        value = fe_per_step / (elapsed / args.steps) / 1e9
+        # roofline of the dominant kernel (ntt_pass_kernel): algorithmic bytes of one LDE =
+        # 8*N*ncols in + 8*N_ext*ncols out (24 B per input element at blow-up 2),
+        # spread over the kernel's launches in one LDE; duration from the HIP events above.
+        alg_bytes_lde = 8 * n * ncols + 8 * n_ext * ncols
+        launches = PASS_LAUNCHES_PER_LDE if args.log_n == LOG_N else None
+        kern_ms_lde = dev_ms / args.steps
+        achieved = alg_bytes_lde / (kern_ms_lde * 1e-3) / 1e9
+        roofline = {
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": "xlp::ntt_pass_kernel", "launches_per_step": launches,
+            "avg_launch_ms": round(kern_ms_lde / launches, 4) if launches else None,
+            "alg_bytes_per_launch": alg_bytes_lde / launches if launches else None,
+        }
+        line = {
+            "metric": "Goldilocks NTT GFE/s (LDE 2^%d x %d, blow-up 2)" % (args.log_n, ncols),
+            "value": round(value, 3), "unit": "GFE/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64 (Goldilocks p=2^64-2^32+1)", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: extendPol 2^%d x %d -> 2^%d x %d per GPU, row-major, "
+                                   "inputs resident in HBM" % (args.log_n, ncols, args.log_n + EXT_BITS, ncols),
+                       "columns_total": ncols * world, "sharding": "independent columns per rank, no collective"},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.log_n, ncols)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
