@@ -95,6 +95,10 @@ int xlp_dev_transpose3(uint64_t* dst, const uint64_t* src, uint64_t n, uint32_t 
 /* Synthetic trace: dst[i] = splitmix64(seed ^ (start + i)) mod p. */
 int xlp_dev_fill(uint64_t* dst, uint64_t n, uint64_t seed, uint64_t start);
 
+/* Test hook: out[i] = op(a[i], b[i]) using the device field functions the kernels are built
+ * from (op codes: csrc/fri.hip field_op_kernel).  Host pointers.  Not part of the reference surface. */
+int xlp_field_op(uint64_t* out, const uint64_t* a, const uint64_t* b, uint64_t n, int op);
+
 /* Plain device memory helpers so a C++/cgo/ctypes host needs no HIP headers. */
 int xlp_dev_alloc(void** ptr, size_t bytes);
 int xlp_dev_free(void* ptr);

@@ -224,3 +224,37 @@ def test_transpose3_vs_oracle(xlp, orc, n, tb):
         pytest.skip("2^tb must divide n")
     src = orc.fill(3 * n, 5).reshape(n, 3)
     assert (xlp.transpose3(src, n, tb) == orc.transpose3(src, n, tb)).all()
+
+
+# --------------------------------------------------------------- field layer
+def _field_inputs():
+    rng = np.random.default_rng(11)
+    sp = np.array([0, 1, 2, P - 2, P - 1, P, P + 1, 2**64 - 1, 2**64 - 2, 2**32 - 1, 2**32, 2**32 + 1, 2**63, 2**63 - 1,
+                   0xFFFFFFFF00000000, 0xFFFFFFFEFFFFFFFF, 0x00000000FFFFFFFF, 0xFFFFFFFF, 1 << 48, (1 << 48) - 1], np.uint64)
+    a, b = np.meshgrid(sp, sp)
+    a = np.concatenate([a.reshape(-1), rng.integers(0, 2**64, 4000, dtype=np.uint64)])
+    b = np.concatenate([b.reshape(-1), rng.integers(0, 2**64, 4000, dtype=np.uint64)])
+    return a, b
+
+
+def test_field_ops_exhaustive_edges(xlp):
+    a, b = _field_inputs()
+    ai = [int(x) for x in a]
+    bi = [int(x) for x in b]
+    exp = {
+        0: [(x % P + y % P) % P for x, y in zip(ai, bi)],
+        1: [(x % P - y % P) % P for x, y in zip(ai, bi)],
+        2: [(x * y) % P for x, y in zip(ai, bi)],
+        3: [x % P for x in ai],
+        4: [(x + y) % P for x, y in zip(ai, bi)],
+        5: [(x - y) % P for x, y in zip(ai, bi)],
+    }
+    for op, e in exp.items():
+        got = xlp.field_op(a, b, op)
+        assert [int(v) for v in got] == e, f"field op {op}"
+    for k in (1, 12, 24, 32, 36, 48, 60, 64, 72, 84, 95):
+        got = xlp.field_op(a, b, 100 + k)
+        assert [int(v) for v in got] == [(x << k) % P for x in ai], f"mul_pow2c<{k}>"
+    for k in (0, 1, 31, 32, 33, 63, 64, 65, 95):
+        got = xlp.field_op(a, b, 200 + k)
+        assert [int(v) for v in got] == [(x << k) % P for x in ai], f"mul_pow2({k})"

@@ -37,6 +37,7 @@ SIGNATURES = {
     "xlp_dev_fri_fold": [_pu, _pu, _u32, _u32, _pu, _u64],
     "xlp_dev_transpose3": [_pu, _pu, _u64, _u32],
     "xlp_dev_fill": [_pu, _u64, _u64, _u64],
+    "xlp_field_op": [_pu, _pu, _pu, _u64, C.c_int],
     "xlp_dev_alloc": [C.POINTER(C.c_void_p), C.c_size_t],
     "xlp_dev_free": [_pu],
     "xlp_copy_h2d": [_pu, _pu, C.c_size_t],
@@ -174,6 +175,14 @@ def transpose3(src, n, tbits):
     out = np.empty(3 * n, np.uint64)
     _ck(load().xlp_transpose3(_p(out), _p(src), n, tbits), "xlp_transpose3")
     return out.reshape(n, 3)
+
+
+def field_op(a, b, op):
+    a = _np(a).reshape(-1)
+    b = _np(b).reshape(-1)
+    out = np.empty_like(a)
+    _ck(load().xlp_field_op(_p(out), _p(a), _p(b), a.size, op), "xlp_field_op")
+    return out
 
 
 # --------------------------------------------------------------- device layer

@@ -133,6 +133,46 @@ __global__ void fill_kernel(u64* dst, u64 n, u64 seed, u64 start)
     for (; i < n; i += stride) dst[i] = gl::canon(splitmix64(seed ^ (start + i)));
 }
 
+// Field-layer self-test hook (tests/ only): out[i] = op(a[i], b[i]) with the exact device
+// functions the kernels use.  op: 0 addc, 1 subc, 2 mulc, 3 canon(a), 4 add(any,canon), 5 sub(any,canon),
+// 100+K: canon(mul_pow2c<K>(a)) for the shifts a radix-16 butterfly uses.
+__global__ void field_op_kernel(u64* out, const u64* a, const u64* b, u64 n, int op)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 x = a[i], y = b[i];
+    u64 r = 0;
+    switch (op) {
+        case 0: r = gl::addc(gl::canon(x), gl::canon(y)); break;
+        case 1: r = gl::subc(gl::canon(x), gl::canon(y)); break;
+        case 2: r = gl::mulc(x, y); break;
+        case 3: r = gl::canon(x); break;
+        case 4: r = gl::canon(gl::add(x, gl::canon(y))); break;
+        case 5: r = gl::canon(gl::sub(x, gl::canon(y))); break;
+        case 112: r = gl::canon(gl::mul_pow2c<12>(x)); break;
+        case 124: r = gl::canon(gl::mul_pow2c<24>(x)); break;
+        case 136: r = gl::canon(gl::mul_pow2c<36>(x)); break;
+        case 148: r = gl::canon(gl::mul_pow2c<48>(x)); break;
+        case 160: r = gl::canon(gl::mul_pow2c<60>(x)); break;
+        case 172: r = gl::canon(gl::mul_pow2c<72>(x)); break;
+        case 184: r = gl::canon(gl::mul_pow2c<84>(x)); break;
+        case 132: r = gl::canon(gl::mul_pow2c<32>(x)); break;
+        case 164: r = gl::canon(gl::mul_pow2c<64>(x)); break;
+        case 195: r = gl::canon(gl::mul_pow2c<95>(x)); break;
+        case 101: r = gl::canon(gl::mul_pow2c<1>(x)); break;
+        default: r = gl::canon(gl::mul_pow2(x, (unsigned)(op - 200))); break;   // 200+k: run-time shift k < 96
+    }
+    out[i] = r;
+}
+
+int dev_field_op(Ctx* ctx, u64* out, const u64* a, const u64* b, u64 n, int op)
+{
+    if (!n) return 0;
+    hipLaunchKernelGGL(field_op_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, out, a, b, n, op);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int RED>
 static int launch_fold(Ctx* ctx, const FoldParams& p)
 {

@@ -3,13 +3,16 @@
 // Replaces the arithmetic of the reference's (absent) goldilocks submodule as
 // it is used on the Starks::genProof path (e.g. polinomial.hpp:140-229,
 // friProve.cpp:192-217).  Written for CDNA4's 32-bit VALU: a field element is
-// one u64 in a VGPR pair; products are built from 32x32->64 multiply-adds
-// (v_mad_u64_u32) and reduced with 2^64 = 2^32 - 1, 2^96 = -1 (mod p).
+// one u64 in a VGPR pair; sums are 32-bit carry chains (v_add_co/v_addc_co via
+// __builtin_addc, which hipcc lowers without 64-bit compares), products are
+// four v_mad_u64_u32 and the reduction uses 2^64 = 2^32 - 1, 2^96 = -1 (mod p).
+// Measured on MI355X (profiles/r1/ubench_*.txt): add/sub ~6 VALU slots,
+// mul ~35, mul by a constant power of two ~12-18.
 //
-// Representation invariants (documented per function):
+// Representation:
 //   "canon"  value in [0, p)
-//   "any"    value in [0, 2^64), congruent to the element (lazy form)
-// Kernels canonicalise once, on the store to HBM.
+//   "any"    value in [0, 2^64), congruent to the element
+// Stated per function; kernels store canonical values to HBM.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,75 +25,133 @@ typedef uint32_t u32;
 constexpr u64 P = 0xFFFFFFFF00000001ULL;
 constexpr u64 EPS = 0xFFFFFFFFULL;  // 2^64 mod p = 2^32 - 1
 
-__device__ __forceinline__ u64 canon(u64 a) { return a >= P ? a - P : a; }
+__device__ __forceinline__ u64 pack(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
 
-// any + canon -> any   (at least one operand must be canonical)
-__device__ __forceinline__ u64 add(u64 a, u64 b)
+// hipcc (ROCm 7.2, gfx950) mis-combines two adjacent carry chains when the
+// second operand of a link is the constant 0: (hi - 0 - borrow) + 0 + carry is
+// folded into ONE v_addc whose carry-out is not the carry of the second add
+// (caught by tests/test_gpu_parity.py::test_field_ops_exhaustive_edges).
+// An empty asm makes the link's result opaque, which keeps the chains apart;
+// it emits no instruction.
+__device__ __forceinline__ void opaque(u32& x) { asm("" : "+v"(x)); }
+
+// any -> canon : a >= p  <=>  a + EPS carries out of 64 bits (p + EPS = 2^64)
+__device__ __forceinline__ u64 canon(u64 a)
 {
-    u64 s = a + b;
-    return s < a ? s + EPS : s;
+    u32 c0, c1;
+    u32 tlo = __builtin_addc((u32)a, 0xFFFFFFFFu, 0u, &c0);
+    u32 thi = __builtin_addc((u32)(a >> 32), 0u, c0, &c1);
+    opaque(tlo); opaque(thi);
+    return c1 ? pack(tlo, thi) : a;
 }
-// any - canon -> any
-__device__ __forceinline__ u64 sub(u64 a, u64 b)
-{
-    u64 d = a - b;
-    return a < b ? d - EPS : d;
-}
-// canon + canon -> canon
+
+// canon + canon -> canon   (6 VALU: 2 add, 2 add, 2 select)
 __device__ __forceinline__ u64 addc(u64 a, u64 b)
 {
-    u64 s = a + b;
-    return (s < a || s >= P) ? s - P : s;
+    u32 c1, c2, c3, c4;
+    u32 lo = __builtin_addc((u32)a, (u32)b, 0u, &c1);
+    u32 hi = __builtin_addc((u32)(a >> 32), (u32)(b >> 32), c1, &c2);
+    opaque(lo); opaque(hi);
+    u32 tlo = __builtin_addc(lo, 0xFFFFFFFFu, 0u, &c3);   // s - p  ==  s + EPS (mod 2^64)
+    u32 thi = __builtin_addc(hi, 0u, c3, &c4);
+    opaque(tlo); opaque(thi);
+    return (c2 | c4) ? pack(tlo, thi) : pack(lo, hi);
 }
-// canon - canon -> canon
+// canon - canon -> canon   (5 VALU)
 __device__ __forceinline__ u64 subc(u64 a, u64 b)
 {
-    u64 d = a - b;
-    return a < b ? d + P : d;
+    u32 b1, b2, b3, b4;
+    u32 lo = __builtin_subc((u32)a, (u32)b, 0u, &b1);
+    u32 hi = __builtin_subc((u32)(a >> 32), (u32)(b >> 32), b1, &b2);
+    opaque(lo); opaque(hi);
+    u32 m = b2 ? 0xFFFFFFFFu : 0u;                          // borrow: + p  ==  - EPS (mod 2^64)
+    u32 rlo = __builtin_subc(lo, m, 0u, &b3);
+    u32 rhi = __builtin_subc(hi, 0u, b3, &b4);
+    opaque(rlo); opaque(rhi);
+    return pack(rlo, rhi);
 }
-__device__ __forceinline__ u64 neg(u64 a)  // canon -> canon
+// any + canon -> any
+__device__ __forceinline__ u64 add(u64 a, u64 b)
 {
-    return a ? P - a : 0;
+    u32 c1, c2, c3, c4;
+    u32 lo = __builtin_addc((u32)a, (u32)b, 0u, &c1);
+    u32 hi = __builtin_addc((u32)(a >> 32), (u32)(b >> 32), c1, &c2);
+    opaque(lo); opaque(hi);
+    u32 m = c2 ? 0xFFFFFFFFu : 0u;                          // carry: 2^64 = EPS (no second carry: b < p)
+    u32 rlo = __builtin_addc(lo, m, 0u, &c3);
+    u32 rhi = __builtin_addc(hi, 0u, c3, &c4);
+    opaque(rlo); opaque(rhi);
+    return pack(rlo, rhi);
 }
+// any - canon -> any
+__device__ __forceinline__ u64 sub(u64 a, u64 b) { return subc(a, b); }  // same sequence, same argument
 
-// (hi:lo) 128-bit -> any.   x = lo + hi_lo*2^64 + hi_hi*2^96 = lo + hi_lo*(2^32-1) - hi_hi
+__device__ __forceinline__ u64 neg(u64 a) { return a ? P - a : 0; }  // canon -> canon
+
+// lo + hl*EPS - hh  (mod p) -> any, where (hh:hl) = hi.   This is (hi:lo) mod p.
 __device__ __forceinline__ u64 reduce128(u64 lo, u64 hi)
 {
-    u32 hh = (u32)(hi >> 32), hl = (u32)hi;
-    u64 t0 = lo - hh;
-    if (lo < hh) t0 -= EPS;                 // borrow: +p  (no second borrow: lo-hh > -2^32)
-    u64 t1 = ((u64)hl << 32) - hl;          // hl * (2^32 - 1)
-    u64 r = t0 + t1;
-    if (r < t1) r += EPS;                   // carry: 2^64 = 2^32-1 (no second carry)
-    return r;
+    const u32 hh = (u32)(hi >> 32), hl = (u32)hi;
+    u32 b1, b2, b3, b4;
+    u32 l0 = __builtin_subc((u32)lo, hh, 0u, &b1);
+    u32 l1 = __builtin_subc((u32)(lo >> 32), 0u, b1, &b2);
+    opaque(l0); opaque(l1);
+    u32 m = b2 ? 0xFFFFFFFFu : 0u;            // borrow: +p (no second borrow: lo - hh > -2^32)
+    l0 = __builtin_subc(l0, m, 0u, &b3);
+    l1 = __builtin_subc(l1, 0u, b3, &b4);
+    opaque(l0); opaque(l1);
+    const u64 t1 = (u64)hl * 0xFFFFFFFFu;     // hl * EPS <= 2^64 - 2^33 + 1
+    u32 c1, c2, c3, c4;
+    u32 r0 = __builtin_addc(l0, (u32)t1, 0u, &c1);
+    u32 r1 = __builtin_addc(l1, (u32)(t1 >> 32), c1, &c2);
+    opaque(r0); opaque(r1);
+    u32 m2 = c2 ? 0xFFFFFFFFu : 0u;           // carry: 2^64 = EPS (no second carry)
+    r0 = __builtin_addc(r0, m2, 0u, &c3);
+    r1 = __builtin_addc(r1, 0u, c3, &c4);
+    opaque(r0); opaque(r1);
+    return pack(r0, r1);
 }
 
 // any * any -> any
 __device__ __forceinline__ u64 mul(u64 a, u64 b)
 {
-    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-    u64 p0 = (u64)a0 * b0;
-    u64 p1 = (u64)a0 * b1 + (p0 >> 32);
-    u64 p2 = (u64)a1 * b0 + (u32)p1;
-    u64 hi = (u64)a1 * b1 + (p1 >> 32) + (p2 >> 32);
-    u64 lo = (p2 << 32) | (u32)p0;
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 p0 = (u64)a0 * b0;
+    const u64 p1 = (u64)a0 * b1 + (p0 >> 32);
+    const u64 p2 = (u64)a1 * b0 + (u32)p1;
+    const u64 hi = (u64)a1 * b1 + (p1 >> 32) + (p2 >> 32);
+    const u64 lo = (p2 << 32) | (u32)p0;
     return reduce128(lo, hi);
 }
 __device__ __forceinline__ u64 sqr(u64 a) { return mul(a, a); }
 __device__ __forceinline__ u64 mulc(u64 a, u64 b) { return canon(mul(a, b)); }
 
-// any * 2^k (0 <= k < 96, compile-time friendly) -> any
+// any * 2^K (compile-time 0 <= K < 96) -> any.   K = 32q + r:
+//   Y = a << r = (y2:y1:y0);  a*2^K = Y * 2^(32q);  2^64 = EPS, 2^96 = -1, 2^128 = -2^32.
+template <int K>
+__device__ __forceinline__ u64 mul_pow2c(u64 a)
+{
+    static_assert(K >= 0 && K < 96, "shift out of range");
+    if constexpr (K == 0) return a;
+    constexpr int q = K / 32, r = K % 32;
+    const u32 x0 = (u32)a, x1 = (u32)(a >> 32);
+    u32 y0, y1, y2;
+    if constexpr (r == 0) { y0 = x0; y1 = x1; y2 = 0; }
+    else { y0 = x0 << r; y1 = (x1 << r) | (x0 >> (32 - r)); y2 = x1 >> (32 - r); }
+    if constexpr (q == 0) return reduce128(pack(y0, y1), (u64)y2);            // (y1:y0) + y2*EPS
+    else if constexpr (q == 1) return reduce128(pack(0u, y0), pack(y1, y2));  // (y0:0) + y1*EPS - y2
+    else {
+        // y0*2^64 + y1*2^96 + y2*2^128 = y0*EPS - (y2:y1)
+        const u64 t = (u64)y0 * 0xFFFFFFFFu;   // canon (<= 2^64 - 2^33 + 1 < p)
+        return subc(t, canon(pack(y1, y2)));
+    }
+}
+// run-time shift (used off the hot path only)
 __device__ __forceinline__ u64 mul_pow2(u64 a, unsigned k)
 {
-    // a*2^k as (hi:lo) 128-bit when k < 64, else shift in two steps
     if (k == 0) return a;
-    if (k < 64) {
-        u64 lo = a << k, hi = a >> (64 - k);
-        return reduce128(lo, hi);
-    }
-    // k in [64,96): a*2^64*2^(k-64); 2^64 = EPS
-    u64 t = reduce128(0, a);                // a * 2^64
-    return mul_pow2(t, k - 64);
+    if (k < 64) return reduce128(a << k, a >> (64 - k));
+    return mul_pow2(reduce128(0, a), k - 64);
 }
 
 __device__ __forceinline__ u64 pow(u64 a, u64 e)

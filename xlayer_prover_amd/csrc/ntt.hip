@@ -6,16 +6,18 @@
 //
 // Design (MI355X-first, not a translation of the AVX code):
 //  * data stays row-major [rows][ncols] as in the reference slab
-//    (stark_info.cpp:473-482); a workgroup owns a TILE = 2^b points of one
-//    strided sub-sequence x 8 "vector lanes" (8 adjacent columns, or adjacent
-//    rows x columns when ncols < 8) so every global access is a 64-byte
-//    segment, and tiles that are adjacent in memory are given to workgroups
-//    that run on the same XCD at the same time (shared L2 merges the lines).
-//  * a size-2^L transform is ceil(L/11) passes; inside a pass the tile sits in
-//    LDS (<= 136 KiB) and is processed by radix-16 butterflies held in VGPRs:
-//    the 64th roots of unity of Goldilocks are powers of two (w(6) = 8), so a
-//    16-point DFT needs only shifts/adds; one general twiddle multiply per
-//    element per radix-16 round.
+//    (stark_info.cpp:473-482).  A workgroup owns a TILE = 2^b points of one
+//    strided sub-sequence x V "vector lanes" (V adjacent columns, or adjacent
+//    rows x columns when ncols < V), so every global access is a V*8-byte
+//    segment; tiles that are adjacent in memory go to workgroups that run on
+//    the same XCD at the same time (blockIdx -> tile swizzle), so the XCD's L2
+//    sees whole lines.
+//  * a size-2^L transform is split four-step style into passes of <= 12 bits
+//    (2 passes up to 2^23).  Inside a pass the tile sits in LDS (<= 136 KiB)
+//    and is processed by radix-16 butterflies held in VGPRs: the 64th roots of
+//    unity of Goldilocks are powers of two (w(6) = 8), so a 16-point DFT needs
+//    only shifts/adds; one table twiddle multiply per element per round and
+//    one cross-pass twiddle per element per pass.
 //  * INTT runs decimation-in-frequency (natural in, digit-reversed out) and
 //    the forward NTT of the LDE runs decimation-in-time (digit-reversed in,
 //    natural out), so no bit-reversal pass ever touches HBM.
@@ -29,11 +31,11 @@ using gl::u32;
 using gl::u64;
 
 // ------------------------------------------------------------------ params
-constexpr int MAX_DIGITS = 12;
+constexpr int MAX_PASSES = 4;
 
 enum RowMode : u32 {
     ROW_POS = 0,      // row = position
-    ROW_NATURAL = 1,  // row = digit-reversed position (natural transform index)
+    ROW_NATURAL = 1,  // row = natural transform index of the position (global digit reversal)
     ROW_COSET = 2,    // row = (position << ext_bits) | coset   (LDE output interleave)
 };
 
@@ -43,51 +45,66 @@ struct PassParams {
     u64 ncols;         // row stride (elements) of src and dst
     u32 L;             // log2 of transform size
     u32 s, b;          // this pass transforms position bits [s, s+b)
-    u32 C, R;          // vector lane v in [0,8): r = v / C (adjacent low rows), c = v % C (columns); valid if r < R
+    u32 C, R;          // vector lane v in [0,V): r = v / C (adjacent low rows), c = v % C (columns); valid if r < R
     u32 n_colchunks;   // ceil(ncols / C)
     u32 n_logroups;    // ceil(2^s / R)
     u64 ntiles;        // real tile count (grid is padded to a multiple of 8)
-    u32 inverse;       // use inverse 16-point DFT ordering (tables hold inverse roots)
-    u32 dit;           // 0: DIF (butterfly then twiddle), 1: DIT (twiddle then butterfly)
+    u32 inverse;       // inverse 16-point DFT ordering (tables hold inverse roots)
     u32 src_mode, dst_mode;
     u32 ext_bits, coset;
-    u32 n_digits;      // global digit list (top -> bottom) for digit reversal
-    u32 digit_bits[MAX_DIGITS];
-    const u64* tw_lo;  // tw_lo[i] = w^i, i < 4096            (w = w(L) or its inverse)
-    const u64* tw_hi;  // tw_hi[i] = w^(i << 12), i < 2^(L-12)   (L > 12 only)
-    const u64* sc_lo;  // optional load-scale tables, indexed by the natural (coefficient) index
+    u32 np;            // pass structure of the whole transform, top -> bottom (for natural-index maps)
+    u32 pass_b[MAX_PASSES];
+    const u64* tw;     // in-tile twiddles: tw[i] = w(b)^i, i < 2^b            (or inverse root)
+    const u64* cr_lo;  // cross-pass twiddles of root w(L): cr_lo[i] = w^i (i < 4096), cr_hi[i] = w^(i << 12)
+    const u64* cr_hi;
+    const u64* sc_lo;  // optional load-scale tables indexed by the natural (coefficient) index (two-level like cr_*)
     const u64* sc_hi;
     u64 final_scale;   // multiplied into every stored element if != 1 (1/n of a stand-alone INTT)
 };
 
-__device__ __forceinline__ u64 digit_reverse(const PassParams& p, u64 pos)
+// natural in-tile index of tile position tpos (digits top->bottom: dtop,4,4,.. ; top digit = lowest weight)
+__device__ __forceinline__ u32 tile_natural(u32 tpos, u32 b)
 {
-    u64 k = 0;
-    u32 consumed = 0, shift = 0;
-    for (u32 i = 0; i < p.n_digits; i++) {
-        u32 d = p.digit_bits[i];
-        consumed += d;
-        u64 dv = (pos >> (p.L - consumed)) & ((1u << d) - 1);
+    const u32 m = (b + 3) >> 2;
+    const u32 dtop = b - 4 * (m - 1);
+    u32 k = tpos >> (b - dtop);  // top digit -> weight 0
+    u32 shift = dtop;
+    for (u32 r = 1; r < m; r++) {
+        const u32 dv = (tpos >> (4 * (m - 1 - r))) & 15;
         k |= dv << shift;
-        shift += d;
+        shift += 4;
     }
     return k;
 }
 
-__device__ __forceinline__ u64 twiddle(const PassParams& p, u64 e)
+// natural transform index held at `pos` after all DIF passes (== index expected at `pos` before DIT passes)
+__device__ __forceinline__ u64 natural_index(const PassParams& p, u64 pos)
 {
-    // w^e, e < 2^L
-    u64 t = p.tw_lo[e & 4095];
-    if (p.L > 12) {
-        u64 eh = e >> 12;
-        if (eh) t = gl::mul(t, p.tw_hi[eh]);
+    u64 k = 0;
+    u32 consumed = 0, shift = 0;
+    for (u32 i = 0; i < p.np; i++) {
+        const u32 b = p.pass_b[i];
+        consumed += b;
+        const u32 tpos = (u32)(pos >> (p.L - consumed)) & ((1u << b) - 1);
+        k |= (u64)tile_natural(tpos, b) << shift;
+        shift += b;
+    }
+    return k;
+}
+
+__device__ __forceinline__ u64 two_level(const u64* lo, const u64* hi, u64 e, bool has_hi)
+{
+    u64 t = lo[e & 4095];
+    if (has_hi) {
+        const u64 eh = e >> 12;
+        if (eh) t = gl::mul(t, hi[eh]);
     }
     return t;
 }
 
 // ------------------------------------------------- in-register 2^D-point DFT
 // Forward DFT with w = w(D) = 2^(192 >> D) (w(4)=2^12, w(3)=2^24, w(2)=2^48,
-// w(1)=-1): DIF network, x[bitrev(k)] = X[k] on return.  Values canonical.
+// w(1)=-1): DIF network, x[brev(k)] = X[k] on return.  Canonical in and out.
 template <int D>
 __device__ __forceinline__ constexpr int brev(int k)
 {
@@ -96,172 +113,184 @@ __device__ __forceinline__ constexpr int brev(int k)
     return r;
 }
 
-template <int D>
-__device__ __forceinline__ void dft_regs(u64 (&x)[1 << D])
+template <int D, int T, int BLK, int J>
+__device__ __forceinline__ void bfly(u64 (&x)[1 << D])
 {
-#pragma unroll
-    for (int t = 0; t < D; t++) {
-        const int half = 1 << (D - 1 - t);
-#pragma unroll
-        for (int blk = 0; blk < (1 << t); blk++) {
-#pragma unroll
-            for (int j = 0; j < half; j++) {
-                const int i0 = blk * 2 * half + j, i1 = i0 + half;
-                u64 a = x[i0], b = x[i1];
-                x[i0] = gl::addc(a, b);
-                u64 d = gl::subc(a, b);
-                const int sh = j * (96 / half);  // w_{2half}^j = 2^(j*96/half)
-                x[i1] = sh ? gl::canon(gl::mul_pow2(d, sh)) : d;
-            }
-        }
+    constexpr int half = 1 << (D - 1 - T);
+    constexpr int i0 = BLK * 2 * half + J, i1 = i0 + half;
+    constexpr int sh = J * (96 / half);  // w_{2half}^J = 2^(J*96/half)
+    const u64 a = x[i0], b = x[i1];
+    x[i0] = gl::addc(a, b);
+    const u64 d = gl::subc(a, b);
+    if constexpr (sh == 0) x[i1] = d;
+    else x[i1] = gl::canon(gl::mul_pow2c<sh>(d));
+}
+template <int D, int T, int IDX>
+__device__ __forceinline__ void stage_rec(u64 (&x)[1 << D])
+{
+    constexpr int half = 1 << (D - 1 - T);
+    if constexpr (IDX < (1 << (D - 1))) {
+        bfly<D, T, IDX / half, IDX % half>(x);
+        stage_rec<D, T, IDX + 1>(x);
     }
 }
+template <int D, int T>
+__device__ __forceinline__ void dft_rec(u64 (&x)[1 << D])
+{
+    if constexpr (T < D) {
+        stage_rec<D, T, 0>(x);
+        dft_rec<D, T + 1>(x);
+    }
+}
+template <int D>
+__device__ __forceinline__ void dft_regs(u64 (&x)[1 << D]) { dft_rec<D, 0>(x); }
 
 // --------------------------------------------------------------- tile engine
+template <int V>
 struct TileCtx {
     const PassParams& p;
-    u64* sm;           // LDS tile: row(pos) * 8 + v
+    u64* sm;           // LDS tile: lds_row(pos) * V + v
     u64 hi, lo0;       // tile coordinates
     u32 c0;
 };
 
 __device__ __forceinline__ u32 lds_row(u32 pos) { return pos + (pos >> 4); }
 
-__device__ __forceinline__ bool lane_valid(const TileCtx& t, u32 v, u32& r, u32& c)
-{
-    r = v / t.p.C;
-    c = v % t.p.C;
-    return r < t.p.R && (t.lo0 + r) < (1ull << t.p.s) && (t.c0 + c) < t.p.ncols;
-}
-
-__device__ __forceinline__ u64 global_pos(const TileCtx& t, u32 tpos, u32 r)
-{
-    return (t.hi << (t.p.s + t.p.b)) | ((u64)tpos << t.p.s) | (t.lo0 + r);
-}
-
-__device__ __forceinline__ u64 map_row(const PassParams& p, u32 mode, u64 pos)
-{
-    if (mode == ROW_POS) return pos;
-    if (mode == ROW_NATURAL) return digit_reverse(p, pos);
-    return (pos << p.ext_bits) | p.coset;
-}
-
-// One radix-2^D round over tile digit at bit offset tp.  FIRST: inputs come
-// from global memory; LAST: outputs go to global memory; otherwise LDS.
-template <int D>
-__device__ __forceinline__ void round_body(const TileCtx& t, u32 tp, bool first, bool last)
+// One radix-2^D round over the tile digit at bit offset tp.
+//  FIRST: inputs come from global memory (+ load scale, + DIT cross twiddle)
+//  LAST : outputs go to global memory (+ DIF cross twiddle, + final scale)
+template <int V, int D, bool DIT, bool FIRST, bool LAST>
+__device__ __forceinline__ void round_body(const TileCtx<V>& t, u32 tp)
 {
     const PassParams& p = t.p;
     constexpr int RAD = 1 << D;
-    const u32 ngroups = (1u << (p.b - D)) * 8;
-    const u32 gpos_bits = p.s + tp;  // global bit offset of this digit
+    constexpr u32 VB = V == 8 ? 3 : 2;
+    const u32 ngroups = (1u << (p.b - D)) * V;
+    const bool has_tw = tp > 0;
+    const u32 tshift = p.b - tp - D;          // in-tile twiddle exponent = digit * low << tshift
+    const bool has_cross = p.s > 0;
+    const u32 cshift = p.L - p.s - p.b;       // cross exponent = k_tile * lo << cshift
+    const bool has_hi = p.L > 12;
     for (u32 g = threadIdx.x; g < ngroups; g += blockDim.x) {
-        const u32 v = g & 7;
-        const u32 rest = g >> 3;
+        const u32 v = g & (V - 1);
+        const u32 rest = g >> VB;
         const u32 low = rest & ((1u << tp) - 1);
         const u32 high = rest >> tp;
         const u32 base = (high << (tp + D)) | low;
-        u32 r, c;
-        const bool valid = lane_valid(t, v, r, c);
-        // twiddle exponent factor: (global low bits below the digit) << (L - gpos_bits - D)
-        const u64 lowglobal = valid ? (((u64)low << p.s) | (t.lo0 + r)) : 0;  // invalid lanes: exponent 0
-        const u32 tshift = p.L - gpos_bits - D;
-        const bool has_tw = gpos_bits > 0;
+        const u32 r = v / p.C, c = v % p.C;
+        const u64 lo = t.lo0 + r;
+        const bool valid = r < p.R && lo < (1ull << p.s) && (t.c0 + c) < p.ncols;
         u64 x[RAD];
-        // ---- gather (+ DIT twiddle)
+        // ---- gather (+ DIT twiddles)
 #pragma unroll
         for (int j = 0; j < RAD; j++) {
             const u32 tpos = base + ((u32)j << tp);
             u64 val = 0;
-            if (first) {
+            if constexpr (FIRST) {
                 if (valid) {
-                    const u64 pos = global_pos(t, tpos, r);
-                    const u64 row = map_row(p, p.src_mode, pos);
+                    const u64 pos = (t.hi << (p.s + p.b)) | ((u64)tpos << p.s) | lo;
+                    const u64 row = p.src_mode == ROW_POS ? pos : natural_index(p, pos);
                     val = gl::canon(p.src[row * p.ncols + t.c0 + c]);
-                    if (p.sc_lo) {
-                        const u64 ci = digit_reverse(p, pos);  // coefficient index
-                        u64 sc = p.sc_lo[ci & 4095];
-                        if (p.L > 12) sc = gl::mul(sc, p.sc_hi[ci >> 12]);
-                        val = gl::mulc(val, sc);
-                    }
+                    if (p.sc_lo) val = gl::mulc(val, two_level(p.sc_lo, p.sc_hi, natural_index(p, pos), has_hi));
+                    if (DIT && has_cross)
+                        val = gl::mulc(val, two_level(p.cr_lo, p.cr_hi, ((u64)tile_natural(tpos, p.b) * lo) << cshift, has_hi));
                 }
             } else {
-                val = t.sm[lds_row(tpos) * 8 + v];
+                val = t.sm[lds_row(tpos) * V + v];
             }
-            if (p.dit && has_tw && j) val = gl::mulc(val, twiddle(p, ((u64)j * lowglobal) << tshift));
+            if (DIT && has_tw && j) val = gl::mulc(val, p.tw[((u32)j * low) << tshift]);
             x[j] = val;
         }
         dft_regs<D>(x);
-        // ---- scatter (+ DIF twiddle)
+        // ---- scatter (+ DIF twiddles)
 #pragma unroll
         for (int k = 0; k < RAD; k++) {
             // forward: X[k] = x[brev(k)];  inverse: X^-1[k] = X[(RAD-k)%RAD]
             u64 val = p.inverse ? x[brev<D>((RAD - k) % RAD)] : x[brev<D>(k)];
-            if (!p.dit && has_tw && k) val = gl::mulc(val, twiddle(p, ((u64)k * lowglobal) << tshift));
+            if (!DIT && has_tw && k) val = gl::mulc(val, p.tw[((u32)k * low) << tshift]);
             const u32 tpos = base + ((u32)k << tp);
-            if (last) {
+            if constexpr (LAST) {
                 if (valid) {
+                    if (!DIT && has_cross)
+                        val = gl::mulc(val, two_level(p.cr_lo, p.cr_hi, ((u64)tile_natural(tpos, p.b) * lo) << cshift, has_hi));
                     if (p.final_scale != 1) val = gl::mulc(val, p.final_scale);
-                    const u64 pos = global_pos(t, tpos, r);
-                    const u64 row = map_row(p, p.dst_mode, pos);
+                    const u64 pos = (t.hi << (p.s + p.b)) | ((u64)tpos << p.s) | lo;
+                    u64 row = pos;
+                    if (p.dst_mode == ROW_NATURAL) row = natural_index(p, pos);
+                    else if (p.dst_mode == ROW_COSET) row = (pos << p.ext_bits) | p.coset;
                     p.dst[row * p.ncols + t.c0 + c] = val;
                 }
             } else {
-                t.sm[lds_row(tpos) * 8 + v] = val;
+                t.sm[lds_row(tpos) * V + v] = val;
             }
         }
     }
 }
 
-__device__ __forceinline__ void round_dispatch(const TileCtx& t, u32 d, u32 tp, bool first, bool last)
+template <int V, bool DIT, bool FIRST, bool LAST>
+__device__ __forceinline__ void round_dispatch(const TileCtx<V>& t, u32 d, u32 tp)
 {
     switch (d) {
-        case 1: round_body<1>(t, tp, first, last); break;
-        case 2: round_body<2>(t, tp, first, last); break;
-        case 3: round_body<3>(t, tp, first, last); break;
-        default: round_body<4>(t, tp, first, last); break;
+        case 1: round_body<V, 1, DIT, FIRST, LAST>(t, tp); break;
+        case 2: round_body<V, 2, DIT, FIRST, LAST>(t, tp); break;
+        case 3: round_body<V, 3, DIT, FIRST, LAST>(t, tp); break;
+        default: round_body<V, 4, DIT, FIRST, LAST>(t, tp); break;
     }
 }
 
-__global__ __launch_bounds__(1024) void ntt_pass_kernel(const PassParams p)
+// XCD-aware tile assignment: blocks b, b+8, b+16.. share an XCD and run
+// concurrently; give them tiles that are adjacent in memory (column-chunk
+// fastest, then low-row group, then hi).
+template <int V>
+__device__ __forceinline__ bool locate_tile(const PassParams& p, TileCtx<V>& t)
 {
-    extern __shared__ u64 sm[];
-    // ---- XCD-aware tile assignment: blocks b, b+8, b+16.. share an XCD and
-    // run concurrently; give them tiles that are adjacent in memory
-    // (column-chunk fastest, then low-row group, then hi).
     const u64 bid = blockIdx.x;
     u64 tile = bid;
     if (gridDim.x >= 16) tile = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);  // gridDim.x % 8 == 0 here
-    if (tile >= p.ntiles) return;  // block-uniform: grid padding only
-    TileCtx t{p, sm, 0, 0, 0};
+    if (tile >= p.ntiles) return false;  // block-uniform: grid padding only
     const u64 cc = tile % p.n_colchunks;
     const u64 rest = tile / p.n_colchunks;
     t.c0 = (u32)(cc * p.C);
     t.lo0 = (rest % p.n_logroups) * p.R;
     t.hi = rest / p.n_logroups;
+    return true;
+}
 
+template <int V, bool DIT>
+__global__ __launch_bounds__(1024) void ntt_pass_kernel(const PassParams p)
+{
+    extern __shared__ u64 sm[];
+    TileCtx<V> t{p, sm, 0, 0, 0};
+    if (!locate_tile<V>(p, t)) return;
     const u32 m = (p.b + 3) / 4;
     const u32 dtop = p.b - 4 * (m - 1);
-    if (!p.dit) {
-        for (u32 r = 0; r < m; r++) {
-            const u32 d = r == 0 ? dtop : 4;
-            const u32 tp = 4 * (m - 1 - r);
-            round_dispatch(t, d, tp, r == 0, r == m - 1);
-            if (r + 1 < m) __syncthreads();
+    if (m == 1) {
+        round_dispatch<V, DIT, true, true>(t, dtop, 0);
+        return;
+    }
+    if (!DIT) {
+        // top digit first
+        round_dispatch<V, DIT, true, false>(t, dtop, 4 * (m - 1));
+        __syncthreads();
+        for (u32 r = 1; r + 1 < m; r++) {
+            round_body<V, 4, DIT, false, false>(t, 4 * (m - 1 - r));
+            __syncthreads();
         }
+        round_body<V, 4, DIT, false, true>(t, 0);
     } else {
-        for (u32 q = 0; q < m; q++) {
-            const u32 r = m - 1 - q;
-            const u32 d = r == 0 ? dtop : 4;
-            const u32 tp = 4 * (m - 1 - r);
-            round_dispatch(t, d, tp, q == 0, q == m - 1);
-            if (q + 1 < m) __syncthreads();
+        // bottom digit first
+        round_body<V, 4, DIT, true, false>(t, 0);
+        __syncthreads();
+        for (u32 r = m - 2; r >= 1; r--) {
+            round_body<V, 4, DIT, false, false>(t, 4 * (m - 1 - r));
+            __syncthreads();
         }
+        round_dispatch<V, DIT, false, true>(t, dtop, 4 * (m - 1));
     }
 }
 
 // -------------------------------------------------------------- table kernels
-// out[i] = base^(i << shift), i < count
+// out[i] = mult * base^(i << shift), i < count
 __global__ void pow_table_kernel(u64* out, u64 base, u32 shift, u64 count, u64 mult)
 {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -295,7 +324,7 @@ u64 host_w(unsigned n)
     return w;
 }
 
-// Power tables of `root` over exponents < 2^L, split 12/L-12 (device memory, cached in ctx).
+// Two-level power tables of `root` over exponents < 2^L: [0,4096) = mult*root^i, [4096..) = root^(i<<12).
 static int get_tables(Ctx* ctx, u32 L, u64 root, u64 mult, const u64** lo, const u64** hi)
 {
     auto key = std::make_tuple(L, root, mult);
@@ -317,60 +346,79 @@ static int get_tables(Ctx* ctx, u32 L, u64 root, u64 mult, const u64** lo, const
 
 struct Plan {
     u32 L, np;
-    u32 b[4], s[4];
-    u32 n_digits;
-    u32 digit_bits[MAX_DIGITS];
+    u32 b[MAX_PASSES], s[MAX_PASSES];
 };
 
+// passes of <= 12 bits, top -> bottom; the bottom pass is the big one (12 bits,
+// V=4: its data is contiguous), upper passes <= 11 bits (V=8: 64-byte segments).
 static Plan make_plan(u32 L)
 {
     Plan pl{};
     pl.L = L;
-    pl.np = L == 0 ? 0 : (L + 10) / 11;
+    if (L <= 12) { pl.np = L ? 1 : 0; pl.b[0] = L; pl.s[0] = 0; return pl; }
+    u32 rest = L - 12;
+    u32 nup = (rest + 10) / 11;
+    pl.np = nup + 1;
+    for (u32 i = 0; i < nup; i++) pl.b[i] = rest / nup + (i < rest % nup ? 1 : 0);
+    pl.b[nup] = 12;
     u32 acc = 0;
-    for (u32 i = 0; i < pl.np; i++) pl.b[i] = L / pl.np + (i < L % pl.np ? 1 : 0);
     for (u32 i = pl.np; i-- > 0;) { pl.s[i] = acc; acc += pl.b[i]; }
-    pl.n_digits = 0;
-    for (u32 i = 0; i < pl.np; i++) {
-        u32 m = (pl.b[i] + 3) / 4, dtop = pl.b[i] - 4 * (m - 1);
-        for (u32 r = 0; r < m; r++) pl.digit_bits[pl.n_digits++] = r == 0 ? dtop : 4;
-    }
     return pl;
 }
 
-static int launch_pass(Ctx* ctx, PassParams& p)
+template <int V, bool DIT>
+static int launch_pass_v(Ctx* ctx, PassParams& p)
 {
     const u64 ncols = p.ncols;
-    p.C = ncols < 8 ? (u32)ncols : 8;
+    p.C = ncols < (u64)V ? (u32)ncols : V;
     u32 R = 1;
-    while (R * 2 * p.C <= 8 && (u64)R * 2 <= (1ull << p.s)) R *= 2;
+    while (R * 2 * p.C <= (u32)V && (u64)R * 2 <= (1ull << p.s)) R *= 2;
     p.R = R;
     p.n_colchunks = (u32)((ncols + p.C - 1) / p.C);
     p.n_logroups = (u32)(((1ull << p.s) + R - 1) / R);
     u64 ntiles = (u64)p.n_colchunks * p.n_logroups * (1ull << (p.L - p.s - p.b));
     u64 grid = ntiles < 16 ? ntiles : (ntiles + 7) / 8 * 8;
     if (grid > 0x7fffffffULL) return xlp_fail("ntt: grid too large");
-    u32 groups = (1u << (p.b > 4 ? p.b - 4 : 0)) * 8;
+    u32 groups = (1u << (p.b > 4 ? p.b - 4 : 0)) * V;
     u32 threads = groups < 64 ? 64 : (groups > 1024 ? 1024 : groups);
     u32 rows = 1u << p.b;
-    size_t lds = (size_t)(rows + (rows >> 4) + 1) * 8 * sizeof(u64);
+    size_t lds = (size_t)(rows + (rows >> 4) + 1) * V * sizeof(u64);
     p.ntiles = ntiles;
-    hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)grid), dim3(threads), lds, ctx->stream, p);
+    hipLaunchKernelGGL((ntt_pass_kernel<V, DIT>), dim3((unsigned)grid), dim3(threads), lds, ctx->stream, p);
     XLP_HIP(hipGetLastError());
     return 0;
 }
 
-static void fill_digits(PassParams& p, const Plan& pl)
+static int launch_pass(Ctx* ctx, PassParams& p, bool dit)
 {
-    p.n_digits = pl.n_digits;
-    for (u32 i = 0; i < pl.n_digits; i++) p.digit_bits[i] = pl.digit_bits[i];
+    // V=4 only for 12-bit tiles (LDS capacity); they are the bottom pass whose rows are contiguous
+    if (p.b == 12) return dit ? launch_pass_v<4, true>(ctx, p) : launch_pass_v<4, false>(ctx, p);
+    return dit ? launch_pass_v<8, true>(ctx, p) : launch_pass_v<8, false>(ctx, p);
+}
+
+static void fill_plan(PassParams& p, const Plan& pl)
+{
+    p.np = pl.np;
+    for (u32 i = 0; i < pl.np; i++) p.pass_b[i] = pl.b[i];
 }
 
 int ntt_init(Ctx* ctx)
 {
-    XLP_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    XLP_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    XLP_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    XLP_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    XLP_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     (void)ctx;
     return 0;
+}
+
+// in-tile twiddle table for a pass of b bits: tw[i] = root(2^b)^i (single level, <= 4096 entries)
+static int get_tile_table(Ctx* ctx, u32 b, bool inverse, const u64** tw)
+{
+    u64 root = host_w(b);
+    if (inverse) root = hgl::inv(root);
+    const u64* hi;
+    return get_tables(ctx, b, root, 1, tw, &hi);
 }
 
 // Stand-alone NTT / INTT, natural order in and out.  dst may alias src.
@@ -390,8 +438,8 @@ int dev_ntt(Ctx* ctx, u64* dst, const u64* src, u64 n, u64 ncols, int inverse)
     Plan pl = make_plan(L);
     u64 root = host_w(L);
     if (inverse) root = hgl::inv(root);
-    const u64 *tlo, *thi;
-    if (get_tables(ctx, L, root, 1, &tlo, &thi)) return -1;
+    const u64 *clo, *chi;
+    if (get_tables(ctx, L, root, 1, &clo, &chi)) return -1;
     u64* work = nullptr;
     if (pl.np > 1) {
         if (ctx_scratch(ctx, n * ncols * sizeof(u64), 0, &work)) return -1;
@@ -399,17 +447,18 @@ int dev_ntt(Ctx* ctx, u64* dst, const u64* src, u64 n, u64 ncols, int inverse)
     for (u32 i = 0; i < pl.np; i++) {
         PassParams p{};
         p.ncols = ncols; p.L = L; p.s = pl.s[i]; p.b = pl.b[i];
-        p.inverse = inverse ? 1 : 0; p.dit = 0;
-        p.tw_lo = tlo; p.tw_hi = thi; p.sc_lo = nullptr; p.sc_hi = nullptr;
+        p.inverse = inverse ? 1 : 0;
+        if (get_tile_table(ctx, p.b, inverse, &p.tw)) return -1;
+        p.cr_lo = clo; p.cr_hi = chi; p.sc_lo = nullptr; p.sc_hi = nullptr;
         p.final_scale = 1;
-        fill_digits(p, pl);
+        fill_plan(p, pl);
         const bool first = i == 0, last = i == pl.np - 1;
         p.src = first ? src : work;
         p.dst = last ? dst : work;
         p.src_mode = ROW_POS;
         p.dst_mode = last ? ROW_NATURAL : ROW_POS;
         if (last && inverse) p.final_scale = hgl::inv(n % hgl::P);
-        if (launch_pass(ctx, p)) return -1;
+        if (launch_pass(ctx, p, false)) return -1;
     }
     return 0;
 }
@@ -451,14 +500,15 @@ int dev_extend(Ctx* ctx, u64* out, const u64* in, u64 n_ext, u64 n, u64 ncols, u
     for (u32 i = 0; i < pl.np; i++) {
         PassParams p{};
         p.ncols = ncols; p.L = L; p.s = pl.s[i]; p.b = pl.b[i];
-        p.inverse = 1; p.dit = 0;
-        p.tw_lo = ilo; p.tw_hi = ihi;
+        p.inverse = 1;
+        if (get_tile_table(ctx, p.b, true, &p.tw)) return -1;
+        p.cr_lo = ilo; p.cr_hi = ihi;
         p.final_scale = 1;
-        fill_digits(p, pl);
+        fill_plan(p, pl);
         p.src = i == 0 ? in : A;
         p.dst = A;
         p.src_mode = ROW_POS; p.dst_mode = ROW_POS;
-        if (launch_pass(ctx, p)) return -1;
+        if (launch_pass(ctx, p, false)) return -1;
     }
     // ---- per coset r: coefficients * (shift*w_ext^r)^i / n, then DIT NTT -> out rows (q << e) | r
     const u64 wext = host_w(Le);
@@ -470,10 +520,11 @@ int dev_extend(Ctx* ctx, u64* out, const u64* in, u64 n_ext, u64 n, u64 ncols, u
             const u32 i = pl.np - 1 - q;  // DIT: bottom pass first
             PassParams p{};
             p.ncols = ncols; p.L = L; p.s = pl.s[i]; p.b = pl.b[i];
-            p.inverse = 0; p.dit = 1;
-            p.tw_lo = flo; p.tw_hi = fhi;
+            p.inverse = 0;
+            if (get_tile_table(ctx, p.b, false, &p.tw)) return -1;
+            p.cr_lo = flo; p.cr_hi = fhi;
             p.final_scale = 1;
-            fill_digits(p, pl);
+            fill_plan(p, pl);
             const bool first = q == 0, last = q == pl.np - 1;
             p.src = first ? A : B;
             p.dst = last ? out : B;
@@ -481,7 +532,7 @@ int dev_extend(Ctx* ctx, u64* out, const u64* in, u64 n_ext, u64 n, u64 ncols, u
             p.dst_mode = last ? ROW_COSET : ROW_POS;
             p.ext_bits = e; p.coset = (u32)r;
             if (first) { p.sc_lo = slo; p.sc_hi = shi; }
-            if (launch_pass(ctx, p)) return -1;
+            if (launch_pass(ctx, p, true)) return -1;
         }
     }
     return 0;

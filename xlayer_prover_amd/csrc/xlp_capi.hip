@@ -289,6 +289,19 @@ int xlp_fri_fold(uint64_t* pol2, const uint64_t* pol, uint32_t bits, uint32_t re
     return 0;
 }
 
+int xlp_field_op(uint64_t* out, const uint64_t* a, const uint64_t* b, uint64_t n, int op)
+{
+    if (ensure_init()) return -1;
+    if (n == 0) return 0;
+    DevBuf da, db, dc;
+    if (da.alloc(n * 8) || db.alloc(n * 8) || dc.alloc(n * 8)) return -1;
+    H2D(da, a, n * 8);
+    H2D(db, b, n * 8);
+    if (dev_field_op(&g_ctx, dc.u(), da.u(), db.u(), n, op)) return -1;
+    D2H(out, dc, n * 8);
+    return 0;
+}
+
 int xlp_transpose3(uint64_t* dst, const uint64_t* src, uint64_t n, uint32_t tbits)
 {
     if (ensure_init()) return -1;
