@@ -138,6 +138,14 @@ def test_extend_vs_oracle_more(xlp, orc, lg, ext, ncols):
     assert (xlp.extend(src, n_ext, n, ncols) == orc.extend_pol(src, n_ext, n, ncols)).all()
 
 
+@pytest.mark.parametrize("lg,ext,ncols", [(17, 1, 8), (17, 3, 70), (18, 2, 11), (19, 1, 9), (20, 1, 8), (21, 1, 4), (22, 1, 5), (17, 2, 4), (17, 0, 8)])
+def test_extend_fast_path_vs_oracle(xlp, orc, lg, ext, ncols):
+    """three-kernel LDE path (2^17 <= N <= 2^23, ncols >= 4): all column-chunk / tail-mask shapes"""
+    n, n_ext = 1 << lg, 1 << (lg + ext)
+    src = edge_matrix(orc, n, ncols, 0x5EED0042 + lg)
+    assert (xlp.extend(src, n_ext, n, ncols) == orc.extend_pol(src, n_ext, n, ncols)).all()
+
+
 def test_lde_config2_device_resident_properties(xlp, orc):
     """BASELINE config 2 at full size (2^23 x 8 -> 2^24 x 8) through the device API:
     (a) one whole column against the oracle, (b) size-independent properties:

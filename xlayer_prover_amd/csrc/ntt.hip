@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include "gl_field.hpp"
 #include "xlp_internal.hpp"
+#include "ntt_common.hpp"
 
 namespace xlp {
 using gl::u32;
@@ -102,49 +103,6 @@ __device__ __forceinline__ u64 two_level(const u64* lo, const u64* hi, u64 e, bo
     return t;
 }
 
-// ------------------------------------------------- in-register 2^D-point DFT
-// Forward DFT with w = w(D) = 2^(192 >> D) (w(4)=2^12, w(3)=2^24, w(2)=2^48,
-// w(1)=-1): DIF network, x[brev(k)] = X[k] on return.  Canonical in and out.
-template <int D>
-__device__ __forceinline__ constexpr int brev(int k)
-{
-    int r = 0;
-    for (int i = 0; i < D; i++) r |= ((k >> i) & 1) << (D - 1 - i);
-    return r;
-}
-
-template <int D, int T, int BLK, int J>
-__device__ __forceinline__ void bfly(u64 (&x)[1 << D])
-{
-    constexpr int half = 1 << (D - 1 - T);
-    constexpr int i0 = BLK * 2 * half + J, i1 = i0 + half;
-    constexpr int sh = J * (96 / half);  // w_{2half}^J = 2^(J*96/half)
-    const u64 a = x[i0], b = x[i1];
-    x[i0] = gl::addc(a, b);
-    const u64 d = gl::subc(a, b);
-    if constexpr (sh == 0) x[i1] = d;
-    else x[i1] = gl::canon(gl::mul_pow2c<sh>(d));
-}
-template <int D, int T, int IDX>
-__device__ __forceinline__ void stage_rec(u64 (&x)[1 << D])
-{
-    constexpr int half = 1 << (D - 1 - T);
-    if constexpr (IDX < (1 << (D - 1))) {
-        bfly<D, T, IDX / half, IDX % half>(x);
-        stage_rec<D, T, IDX + 1>(x);
-    }
-}
-template <int D, int T>
-__device__ __forceinline__ void dft_rec(u64 (&x)[1 << D])
-{
-    if constexpr (T < D) {
-        stage_rec<D, T, 0>(x);
-        dft_rec<D, T + 1>(x);
-    }
-}
-template <int D>
-__device__ __forceinline__ void dft_regs(u64 (&x)[1 << D]) { dft_rec<D, 0>(x); }
-
 // --------------------------------------------------------------- tile engine
 template <int V>
 struct TileCtx {
@@ -153,8 +111,6 @@ struct TileCtx {
     u64 hi, lo0;       // tile coordinates
     u32 c0;
 };
-
-__device__ __forceinline__ u32 lds_row(u32 pos) { return pos + (pos >> 4); }
 
 // One radix-2^D round over the tile digit at bit offset tp.
 //  FIRST: inputs come from global memory (+ load scale, + DIT cross twiddle)
@@ -325,7 +281,7 @@ u64 host_w(unsigned n)
 }
 
 // Two-level power tables of `root` over exponents < 2^L: [0,4096) = mult*root^i, [4096..) = root^(i<<12).
-static int get_tables(Ctx* ctx, u32 L, u64 root, u64 mult, const u64** lo, const u64** hi)
+int get_pow_tables(Ctx* ctx, u32 L, u64 root, u64 mult, const u64** lo, const u64** hi)
 {
     auto key = std::make_tuple(L, root, mult);
     auto it = ctx->tables.find(key);
@@ -418,7 +374,7 @@ static int get_tile_table(Ctx* ctx, u32 b, bool inverse, const u64** tw)
     u64 root = host_w(b);
     if (inverse) root = hgl::inv(root);
     const u64* hi;
-    return get_tables(ctx, b, root, 1, tw, &hi);
+    return get_pow_tables(ctx, b, root, 1, tw, &hi);
 }
 
 // Stand-alone NTT / INTT, natural order in and out.  dst may alias src.
@@ -439,7 +395,7 @@ int dev_ntt(Ctx* ctx, u64* dst, const u64* src, u64 n, u64 ncols, int inverse)
     u64 root = host_w(L);
     if (inverse) root = hgl::inv(root);
     const u64 *clo, *chi;
-    if (get_tables(ctx, L, root, 1, &clo, &chi)) return -1;
+    if (get_pow_tables(ctx, L, root, 1, &clo, &chi)) return -1;
     u64* work = nullptr;
     if (pl.np > 1) {
         if (ctx_scratch(ctx, n * ncols * sizeof(u64), 0, &work)) return -1;
@@ -477,6 +433,7 @@ int dev_extend(Ctx* ctx, u64* out, const u64* in, u64 n_ext, u64 n, u64 ncols, u
     const u32 e = Le - L;
     const u64 ncoset = 1ull << e;
     const u64 ninv = hgl::inv(n % hgl::P);
+    if (lde_fast_supported(L, e, ncols)) return dev_extend_fast(ctx, out, in, L, e, ncols);
     if (L == 0) {
         // constant polynomial: every output row equals the input row
         const u64 cnt = n_ext * ncols;
@@ -495,8 +452,8 @@ int dev_extend(Ctx* ctx, u64* out, const u64* in, u64 n_ext, u64 n, u64 ncols, u
     // ---- INTT (DIF): in -> A, coefficients left in digit-reversed positions
     const u64 wn = host_w(L);
     const u64 *ilo, *ihi, *flo, *fhi;
-    if (get_tables(ctx, L, hgl::inv(wn), 1, &ilo, &ihi)) return -1;
-    if (get_tables(ctx, L, wn, 1, &flo, &fhi)) return -1;
+    if (get_pow_tables(ctx, L, hgl::inv(wn), 1, &ilo, &ihi)) return -1;
+    if (get_pow_tables(ctx, L, wn, 1, &flo, &fhi)) return -1;
     for (u32 i = 0; i < pl.np; i++) {
         PassParams p{};
         p.ncols = ncols; p.L = L; p.s = pl.s[i]; p.b = pl.b[i];
@@ -515,7 +472,7 @@ int dev_extend(Ctx* ctx, u64* out, const u64* in, u64 n_ext, u64 n, u64 ncols, u
     for (u64 r = 0; r < ncoset; r++) {
         const u64 g = hgl::mul(7, hgl::pow(wext, r));
         const u64 *slo, *shi;
-        if (get_tables(ctx, L, g, ninv, &slo, &shi)) return -1;
+        if (get_pow_tables(ctx, L, g, ninv, &slo, &shi)) return -1;
         for (u32 q = 0; q < pl.np; q++) {
             const u32 i = pl.np - 1 - q;  // DIT: bottom pass first
             PassParams p{};

@@ -56,6 +56,10 @@ int ntt_init(Ctx* ctx);
 int dev_ntt(Ctx* ctx, u64* dst, const u64* src, u64 n, u64 ncols, int inverse);
 int dev_extend(Ctx* ctx, u64* out, const u64* in, u64 n_ext, u64 n, u64 ncols, u64* scratch);
 
+// ntt_lde.hip (three-kernel fast path of extendPol)
+bool lde_fast_supported(u32 L, u32 e, u64 ncols);
+int dev_extend_fast(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ncols);
+
 // poseidon.hip
 int poseidon_init(Ctx* ctx);
 int dev_perm(Ctx* ctx, u64* out, const u64* in, u64 count);
