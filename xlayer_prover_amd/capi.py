@@ -52,7 +52,8 @@ class XlpError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libxlp_gl.so")
+    # XLP_LIB selects an alternative build (ablation studies, tools/ablate.sh); default = the in-tree product
+    return os.environ.get("XLP_LIB") or os.path.join(_HERE, "libxlp_gl.so")
 
 
 def load():

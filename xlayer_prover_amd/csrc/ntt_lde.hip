@@ -23,6 +23,15 @@
 #include "xlp_internal.hpp"
 #include "ntt_common.hpp"
 
+#ifndef XLP_ABL
+#define XLP_ABL 0   // ablation builds (tools/ablate.sh): 1 no twiddle loads, 2 +no global data traffic, 3 +no DFT, 4 +no twiddle muls
+#endif
+#if XLP_ABL == 4
+#define XLP_TWMUL(a, b) ((a) ^ (b))
+#else
+#define XLP_TWMUL(a, b) gl::mulc((a), (b))
+#endif
+
 namespace xlp {
 
 constexpr int LDE_MAX_COSETS = 8;
@@ -38,7 +47,8 @@ struct LdeParams {
     const u64 *twi_12, *twf_12;    // in-tile twiddles of the 12-bit pass
     const u64 *cri_lo, *cri_hi;    // two-level powers of w(L)^-1
     const u64 *crf_lo, *crf_hi;    // two-level powers of w(L)
-    const u64* sk2[LDE_MAX_COSETS];  // sk2[r][k2] = (g_r^(2^BT))^k2, k2 < 4096
+    const u64* tw2[LDE_MAX_COSETS];  // tw2[r][pos]: twiddle of the 2nd DIT round of lde_mid with the coset scale folded in
+    const u64* hk[LDE_MAX_COSETS];   // hk[r][j] = (g_r^(2^BT))^(256 j), j < 16
     const u64* ur[LDE_MAX_COSETS];   // ur[r][j]   = g_r^j / N,       j  < 2^BT
 };
 
@@ -59,8 +69,14 @@ __device__ __forceinline__ u32 xcd_tile()
 }
 
 // One radix-2^D round over the tile digit at bit offset TP (compile-time geometry).
-template <int B, int V, int TP, int D, bool DIT, bool INV, class Load, class Store>
-__device__ __forceinline__ void fast_round(const u64* __restrict__ tw, Load load, Store store)
+// Written in explicit phases -- (1) all twiddle loads, (2) all data loads, (3) arithmetic,
+// (4) all stores -- because hipcc otherwise serialises "load; s_waitcnt vmcnt(0); use" per
+// element (a full L2 round trip each).  pre/post return per-position factors (LDS cross
+// twiddles) and are only evaluated when HAS_PRE / HAS_POST.
+struct NoFactor { __device__ __forceinline__ u64 operator()(u32) const { return 1; } };
+
+template <int B, int V, int TP, int D, bool DIT, bool INV, bool HAS_PRE, bool HAS_POST, class Load, class Store, class Pre, class Post, bool POSTW = false>
+__device__ __forceinline__ void fast_round(const u64* __restrict__ tw, Load load, Store store, Pre pre, Post post)
 {
     constexpr int RAD = 1 << D;
     constexpr u32 VB = V == 8 ? 3 : 2;
@@ -72,25 +88,68 @@ __device__ __forceinline__ void fast_round(const u64* __restrict__ tw, Load load
         const u32 low = rest & ((1u << TP) - 1);
         const u32 high = rest >> TP;
         const u32 base = (high << (TP + D)) | low;
+        // LDS row of input/output j is affine in j (no carries between the digit fields):
+        // lds_row(base + (j << TP)) = lds_row(base) + j * RS  -> one address register + immediates
+        constexpr u32 RS = TP >= 4 ? (1u << TP) + ((1u << TP) >> 4) : (1u << TP);
+        static_assert(TP == 0 || TP >= 4, "digit offsets are multiples of 4");
+        const u32 r0 = lds_row(base);
+        u64 twr[RAD];
+        if constexpr (POSTW) {
+            // position-indexed twiddles (scale folded in): one factor per input, j = 0 included
+#pragma unroll
+            for (int j = 0; j < RAD; j++) twr[j] = tw[base + ((u32)j << TP)];
+        } else if constexpr (TP > 0) {
+#pragma unroll
+            for (int j = 1; j < RAD; j++) {
+#if XLP_ABL >= 1 && XLP_ABL != 6
+                twr[j] = 0x123456789ULL + j * low;   // ablation: no twiddle loads
+#else
+                twr[j] = tw[((u32)j * low) << TSHIFT];
+#endif
+            }
+        }
         u64 x[RAD];
 #pragma unroll
-        for (int j = 0; j < RAD; j++) {
-            u64 val = load(base + ((u32)j << TP), v);
-            if constexpr (DIT && TP > 0) {
-                if (j) val = gl::mulc(val, tw[((u32)j * low) << TSHIFT]);
-            }
-            x[j] = val;
-        }
-        dft_regs<D>(x);
+        for (int j = 0; j < RAD; j++) x[j] = load(base + ((u32)j << TP), v, r0 + (u32)j * RS);
+        if constexpr (HAS_PRE) {
+            u64 f[RAD];
 #pragma unroll
-        for (int k = 0; k < RAD; k++) {
-            u64 val = x[brev<D>(INV ? (RAD - k) % RAD : k)];
-            if constexpr (!DIT && TP > 0) {
-                if (k) val = gl::mulc(val, tw[((u32)k * low) << TSHIFT]);
-            }
-            store(base + ((u32)k << TP), v, val);
+            for (int j = 0; j < RAD; j++) f[j] = pre(base + ((u32)j << TP));
+#pragma unroll
+            for (int j = 0; j < RAD; j++) x[j] = XLP_TWMUL(x[j], f[j]);
         }
+        if constexpr (POSTW) {
+#pragma unroll
+            for (int j = 0; j < RAD; j++) x[j] = XLP_TWMUL(x[j], twr[j]);
+        } else if constexpr (DIT && TP > 0) {
+#pragma unroll
+            for (int j = 1; j < RAD; j++) x[j] = XLP_TWMUL(x[j], twr[j]);
+        }
+#if XLP_ABL != 3
+        dft_regs<D>(x);
+#endif
+        u64 y[RAD];
+#pragma unroll
+        for (int k = 0; k < RAD; k++) y[k] = x[brev<D>(INV ? (RAD - k) % RAD : k)];
+        if constexpr (!DIT && TP > 0) {
+#pragma unroll
+            for (int k = 1; k < RAD; k++) y[k] = XLP_TWMUL(y[k], twr[k]);
+        }
+        if constexpr (HAS_POST) {
+            u64 f[RAD];
+#pragma unroll
+            for (int k = 0; k < RAD; k++) f[k] = post(base + ((u32)k << TP));
+#pragma unroll
+            for (int k = 0; k < RAD; k++) y[k] = XLP_TWMUL(y[k], f[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < RAD; k++) store(base + ((u32)k << TP), v, y[k], r0 + (u32)k * RS);
     }
+}
+template <int B, int V, int TP, int D, bool DIT, bool INV, class Load, class Store>
+__device__ __forceinline__ void fast_round(const u64* __restrict__ tw, Load load, Store store)
+{
+    fast_round<B, V, TP, D, DIT, INV, false, false>(tw, load, store, NoFactor{}, NoFactor{});
 }
 
 __device__ __forceinline__ u64 two_level12(const u64* __restrict__ lo, const u64* __restrict__ hi, u64 e)
@@ -101,10 +160,13 @@ __device__ __forceinline__ u64 two_level12(const u64* __restrict__ lo, const u64
 }
 
 // ------------------------------------------------------------------------ K1
+#ifndef XLP_TOPV
+#define XLP_TOPV 8
+#endif
 template <int BT>
 __global__ __launch_bounds__(1024) void lde_top_dif(const LdeParams p)
 {
-    constexpr int V = 8, m = (BT + 3) / 4, dtop = BT - 4 * (m - 1);
+    constexpr int V = XLP_TOPV, m = (BT + 3) / 4, dtop = BT - 4 * (m - 1);
     extern __shared__ u64 smem[];
     u64* sm = smem;                                        // tile
     u64* cross = smem + ((1u << BT) + (1u << BT) / 16 + 1) * V;  // cross[k1], natural k1
@@ -113,29 +175,37 @@ __global__ __launch_bounds__(1024) void lde_top_dif(const LdeParams p)
     const u32 cc = tile % ncc, lo = tile / ncc;
     for (u32 k = threadIdx.x; k < (1u << BT); k += blockDim.x) cross[k] = gl::canon(two_level12(p.cri_lo, p.cri_hi, (u64)k * lo));
     const u32 c = cc * V;
-    auto gload = [&](u32 tpos, u32 v) -> u64 {
-        if (c + v >= p.wc) return 0;
+    // lanes past the chunk's last column read its last column (always in bounds) and never store
+    auto gload = [&](u32 tpos, u32 v, u32) -> u64 {
+        const u32 col = c + v < p.wc ? c + v : p.wc - 1;
         const u64 row = ((u64)tpos << 12) | lo;
-        return gl::canon(p.in[row * p.ld_in + p.col0 + c + v]);
+#if XLP_ABL >= 2 && XLP_ABL != 6
+        return row * 0x9E3779B97F4A7C15ULL + col;
+#else
+        return gl::canon(p.in[row * p.ld_in + p.col0 + col]);
+#endif
     };
-    auto lload = [&](u32 tpos, u32 v) -> u64 { return sm[lds_row(tpos) * V + v]; };
-    auto lstore = [&](u32 tpos, u32 v, u64 val) { sm[lds_row(tpos) * V + v] = val; };
-    auto gstore = [&](u32 tpos, u32 v, u64 val) {
-        if (c + v >= p.wc) return;
-        val = gl::mulc(val, cross[tile_natural_c<BT>(tpos)]);
+    auto lload = [&](u32, u32 v, u32 lrow) -> u64 { return sm[lrow * V + v]; };
+    auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { sm[lrow * V + v] = val; };
+    auto gstore = [&](u32 tpos, u32 v, u64 val, u32) {
         const u64 row = ((u64)tpos << 12) | lo;
-        p.A[row * p.wc + c + v] = val;
+#if XLP_ABL >= 2 && XLP_ABL != 6
+        if (val == 0x1234567ULL) p.A[row * p.wc + c + v] = val;
+#else
+        if (c + v < p.wc) p.A[row * p.wc + c + v] = val;
+#endif
     };
+    auto crossf = [&](u32 tpos) -> u64 { return cross[tile_natural_c<BT>(tpos)]; };
     if constexpr (m == 2) {
         fast_round<BT, V, 4, dtop, false, true>(p.twi_bt, gload, lstore);
         __syncthreads();
-        fast_round<BT, V, 0, 4, false, true>(p.twi_bt, lload, gstore);
+        fast_round<BT, V, 0, 4, false, true, false, true>(p.twi_bt, lload, gstore, NoFactor{}, crossf);
     } else {
         fast_round<BT, V, 8, dtop, false, true>(p.twi_bt, gload, lstore);
         __syncthreads();
         fast_round<BT, V, 4, 4, false, true>(p.twi_bt, lload, lstore);
         __syncthreads();
-        fast_round<BT, V, 0, 4, false, true>(p.twi_bt, lload, gstore);
+        fast_round<BT, V, 0, 4, false, true, false, true>(p.twi_bt, lload, gstore, NoFactor{}, crossf);
     }
 }
 
@@ -149,13 +219,13 @@ __global__ __launch_bounds__(1024) void lde_mid(const LdeParams p, u32 BT)
     const u32 cc = tile % ncc, hi = tile / ncc;
     const u32 c = cc * V;
     const u64 n = 1ull << p.L;
-    auto gload = [&](u32 tpos, u32 v) -> u64 {
-        if (c + v >= p.wc) return 0;
+    auto gload = [&](u32 tpos, u32 v, u32) -> u64 {
+        const u32 col = c + v < p.wc ? c + v : p.wc - 1;
         const u64 row = ((u64)hi << 12) | tpos;
-        return p.A[row * p.wc + c + v];
+        return p.A[row * p.wc + col];
     };
-    auto lload = [&](u32 tpos, u32 v) -> u64 { return sm[lds_row(tpos) * V + v]; };
-    auto lstore = [&](u32 tpos, u32 v, u64 val) { sm[lds_row(tpos) * V + v] = val; };
+    auto lload = [&](u32, u32 v, u32 lrow) -> u64 { return sm[lrow * V + v]; };
+    auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { sm[lrow * V + v] = val; };
     // ---- inverse NTT over the low 12 bits (DIF); last round keeps its outputs in VGPRs
     fast_round<B, V, 8, 4, false, true>(p.twi_12, gload, lstore);
     __syncthreads();
@@ -167,32 +237,36 @@ __global__ __launch_bounds__(1024) void lde_mid(const LdeParams p, u32 BT)
     {
         u64 x[16];
 #pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = sm[lds_row(base + j) * V + v];
+        for (int j = 0; j < 16; j++) x[j] = sm[(lds_row(base) + j) * V + v];
         dft_regs<4>(x);
 #pragma unroll
         for (int k = 0; k < 16; k++) X[k] = x[brev<4>((16 - k) % 16)];   // coefficient at tile position base + k
     }
     const bool valid = c + v < p.wc;
     // ---- every coset: scale, forward NTT over the same 12 bits (DIT), -> B_r
+    // Coset scale S_r[k2] = G^k2 (G = g_r^(2^BT), k2 = natural index of the tile position):
+    // for the 16 inputs of one thread k2 = nb + 256 j, so S = G^nb * H[j], H[j] = G^(256 j)
+    // workgroup-uniform.  H[j] is applied here; G^nb is constant over a thread's DFT16, commutes
+    // with it, and is folded into the position-indexed twiddle table tw2[r] of the next round.
     for (u32 r = 0; r < (1u << p.e); r++) {
-        const u64* __restrict__ sk = p.sk2[r];
+        const u64* __restrict__ hk = p.hk[r];
         u64* __restrict__ Br = p.B + (u64)r * n * p.wc;
         __syncthreads();   // previous users of the LDS tile are done
         {
             u64 x[16];
+            x[0] = X[0];
 #pragma unroll
-            for (int j = 0; j < 16; j++) x[j] = gl::mulc(X[j], sk[tile_natural_c<B>(base + j)]);
+            for (int j = 1; j < 16; j++) x[j] = gl::mulc(X[j], hk[j]);
             dft_regs<4>(x);
 #pragma unroll
-            for (int k = 0; k < 16; k++) sm[lds_row(base + k) * V + v] = x[brev<4>(k)];
+            for (int k = 0; k < 16; k++) sm[(lds_row(base) + k) * V + v] = x[brev<4>(k)];
         }
         __syncthreads();
-        fast_round<B, V, 4, 4, true, false>(p.twf_12, lload, lstore);
+        fast_round<B, V, 4, 4, true, false, false, false, decltype(lload), decltype(lstore), NoFactor, NoFactor, true>(p.tw2[r], lload, lstore, NoFactor{}, NoFactor{});
         __syncthreads();
-        auto gstore = [&](u32 tpos, u32 vv, u64 val) {
-            if (c + vv >= p.wc) return;
+        auto gstore = [&](u32 tpos, u32 vv, u64 val, u32) {
             const u64 row = ((u64)hi << 12) | tpos;
-            Br[row * p.wc + c + vv] = val;
+            if (c + vv < p.wc) Br[row * p.wc + c + vv] = val;
         };
         fast_round<B, V, 8, 4, true, false>(p.twf_12, lload, gstore);
     }
@@ -203,7 +277,7 @@ __global__ __launch_bounds__(1024) void lde_mid(const LdeParams p, u32 BT)
 template <int BT>
 __global__ __launch_bounds__(1024) void lde_top_dit(const LdeParams p)
 {
-    constexpr int V = 8, m = (BT + 3) / 4, dtop = BT - 4 * (m - 1);
+    constexpr int V = XLP_TOPV, m = (BT + 3) / 4, dtop = BT - 4 * (m - 1);
     extern __shared__ u64 smem[];
     u64* sm = smem;
     u64* cross = smem + ((1u << BT) + (1u << BT) / 16 + 1) * V;  // cross[j1] = g_r^j1 / N * w^(j1*lo)
@@ -218,29 +292,47 @@ __global__ __launch_bounds__(1024) void lde_top_dit(const LdeParams p)
     const u32 c = cc * V;
     const u64 n = 1ull << p.L;
     const u64* __restrict__ Br = p.B + (u64)r * n * p.wc;
-    auto gload = [&](u32 tpos, u32 v) -> u64 {
-        if (c + v >= p.wc) return 0;
+    auto gload = [&](u32 tpos, u32 v, u32) -> u64 {
+        const u32 col = c + v < p.wc ? c + v : p.wc - 1;
         const u64 row = ((u64)tpos << 12) | lo;
-        return gl::mulc(Br[row * p.wc + c + v], cross[tile_natural_c<BT>(tpos)]);
+#if XLP_ABL >= 2 && XLP_ABL != 6
+        return row * 0x9E3779B97F4A7C15ULL + col;
+#else
+        return Br[row * p.wc + col];
+#endif
     };
-    auto lload = [&](u32 tpos, u32 v) -> u64 { return sm[lds_row(tpos) * V + v]; };
-    auto lstore = [&](u32 tpos, u32 v, u64 val) { sm[lds_row(tpos) * V + v] = val; };
-    auto gstore = [&](u32 tpos, u32 v, u64 val) {
-        if (c + v >= p.wc) return;
+    auto crossf = [&](u32 tpos) -> u64 { return cross[tile_natural_c<BT>(tpos)]; };
+    auto lload = [&](u32, u32 v, u32 lrow) -> u64 { return sm[lrow * V + v]; };
+    auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { sm[lrow * V + v] = val; };
+    auto gstore = [&](u32 tpos, u32 v, u64 val, u32) {
         const u64 row = (((((u64)tpos << 12) | lo)) << p.e) | r;
-        p.out[row * p.ld_out + p.col0 + c + v] = val;
+#if XLP_ABL >= 2 && XLP_ABL != 6
+        if (val == 0x1234567ULL) p.out[row * p.ld_out + p.col0 + c + v] = val;
+#else
+        if (c + v < p.wc) p.out[row * p.ld_out + p.col0 + c + v] = val;
+#endif
     };
     if constexpr (m == 2) {
-        fast_round<BT, V, 0, 4, true, false>(p.twf_bt, gload, lstore);
+        fast_round<BT, V, 0, 4, true, false, true, false>(p.twf_bt, gload, lstore, crossf, NoFactor{});
         __syncthreads();
         fast_round<BT, V, 4, dtop, true, false>(p.twf_bt, lload, gstore);
     } else {
-        fast_round<BT, V, 0, 4, true, false>(p.twf_bt, gload, lstore);
+        fast_round<BT, V, 0, 4, true, false, true, false>(p.twf_bt, gload, lstore, crossf, NoFactor{});
         __syncthreads();
         fast_round<BT, V, 4, 4, true, false>(p.twf_bt, lload, lstore);
         __syncthreads();
         fast_round<BT, V, 8, dtop, true, false>(p.twf_bt, lload, gstore);
     }
+}
+
+// tw2[pos] = G^nat(pos & ~15) * w(12)^(((pos >> 4) & 15) * (pos & 15) << 4),  pos < 4096
+__global__ void lde_tw2_kernel(u64* out, const u64* __restrict__ sk /* G^k2 */, const u64* __restrict__ twf12)
+{
+    const u32 pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= 4096) return;
+    const u32 nb = tile_natural_c<12>(pos & ~15u);
+    const u32 jj = (pos >> 4) & 15, low = pos & 15;
+    out[pos] = gl::mulc(sk[nb], twf12[(jj * low) << 4]);
 }
 
 // ----------------------------------------------------------------- host side
@@ -249,7 +341,7 @@ int get_pow_tables(Ctx* ctx, u32 L, u64 root, u64 mult, const u64** lo, const u6
 template <int BT>
 static int launch_top(Ctx* ctx, const LdeParams& p, bool dit)
 {
-    constexpr u32 V = 8;
+    constexpr u32 V = XLP_TOPV;
     const u32 ncc = (p.wc + V - 1) / V;
     const u32 threads = (1u << (BT - 4)) * V < 64 ? 64 : (1u << (BT - 4)) * V;
     const size_t lds = ((size_t)((1u << BT) + (1u << BT) / 16 + 1) * V + (1u << BT)) * sizeof(u64);
@@ -309,7 +401,26 @@ int dev_extend_fast(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ncols)
         const u64 g = hgl::mul(7, hgl::pow(wext, r));          // shift * w_ext^r
         u64 gk = g;
         for (u32 i = 0; i < BT; i++) gk = hgl::mul(gk, gk);    // g^(2^BT)
-        if (get_pow_tables(ctx, 12, gk, 1, &p.sk2[r], &dummy)) return -1;
+        const u64* sk;
+        if (get_pow_tables(ctx, 12, gk, 1, &sk, &dummy)) return -1;
+        // derived tables, cached under (L = 100 + BT / 200 + BT, root = g^(2^BT), mult = 1)
+        {
+            auto key = std::make_tuple(100u + BT, gk, (u64)1);
+            auto it = ctx->tables.find(key);
+            if (it == ctx->tables.end()) {
+                u64* d = nullptr;
+                XLP_HIP(hipMalloc(&d, 4096 * sizeof(u64)));
+                hipLaunchKernelGGL(lde_tw2_kernel, dim3(16), dim3(256), 0, ctx->stream, d, sk, p.twf_12);
+                XLP_HIP(hipGetLastError());
+                it = ctx->tables.emplace(key, d).first;
+            }
+            p.tw2[r] = it->second;
+        }
+        {
+            u64 g256 = gk;
+            for (int i = 0; i < 8; i++) g256 = hgl::mul(g256, g256);   // G^256
+            if (get_pow_tables(ctx, 4, g256, 1, &p.hk[r], &dummy)) return -1;   // 16 entries: (G^256)^j
+        }
         if (get_pow_tables(ctx, BT, g, ninv, &p.ur[r], &dummy)) return -1;
     }
     // column chunks: scratch = (1 + 2^e) * n * wc elements
