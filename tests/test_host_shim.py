@@ -1,0 +1,39 @@
+"""The C++ host-side mirror of the reference interface (xlayer_prover_amd/host):
+a mini Starks::genProof (commit stages + FRIProve::prove) driven through the
+reference-shaped classes over the C ABI, compared field by field with the same
+proof rebuilt by the CPU oracle."""
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "xlayer_prover_amd", "host", "test_host_shim")
+
+
+def test_host_shim_is_built_and_fails_loudly_without_gpu():
+    import torch
+    assert os.path.exists(EXE), "run __graft_entry__.build()"
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is present")
+    r = subprocess.run([EXE, "4", "5", "2", "5", "3"], capture_output=True, text=True)
+    assert r.returncode != 0                       # exitProcess() semantics, no CPU fallback
+    assert "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(6, 7, 4, [7, 4]), (10, 11, 8, [11, 8, 5]), (9, 12, 11, [12, 8, 4]), (8, 9, 5, [9, 9, 6, 3])])
+def test_mini_genproof_matches_oracle(orc, cfg):
+    from tests.mini_stark_oracle import mini_stark_oracle
+    nBits, nBitsExt, nQ, steps = cfg
+    r = subprocess.run([EXE, str(nBits), str(nBitsExt), str(nQ)] + [str(s) for s in steps], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout)
+    exp = mini_stark_oracle(orc, nBits, nBitsExt, nQ, steps)
+    assert set(got.keys()) == set(exp.keys())
+    for k in exp:
+        assert got[k] == exp[k], k
+    # zkin geometry matches the reference's golden files (proof2zkinStark.cpp:8-82): absent cm2 keys
+    assert "s0_vals2" not in got and "s0_siblings2" not in got
+    assert len(got["s0_siblings1"][0]) == nBitsExt and len(got["finalPol"]) == 1 << steps[-1]

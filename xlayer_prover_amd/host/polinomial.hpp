@@ -1,0 +1,3 @@
+// Forwarding header: the reference includes "polinomial.hpp"; everything lives in xlp_host.hpp.
+#pragma once
+#include "xlp_host.hpp"

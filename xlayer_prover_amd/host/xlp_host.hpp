@@ -1,0 +1,546 @@
+// xlp_host.hpp -- host-side C++ mirror of the interface that src/starkpil calls
+// on the (absent) goldilocks submodule and of the starkpil helper classes on the
+// Starks::genProof path, implemented over the C ABI of libxlp_gl.so
+// (include/xlp_gl.h).  Same class / method names, argument meaning and error
+// behaviour as the reference, so starks.cpp / friProve.cpp call sites compile
+// against it unchanged:
+//
+//   Goldilocks, Goldilocks3            field helpers used by the drivers (host scalars only)
+//   NTT_Goldilocks                     starks.hpp:81-82, starks.cpp:53,134,215,262,285,326-327
+//   PoseidonGoldilocks                 transcript.cpp:23,46; merkleTreeGL.cpp:39-43
+//   MerklehashGoldilocks               starks.cpp:684,694
+//   MerkleTreeGL                       merkleTree/merkleTreeGL.hpp:9-79, .cpp:12-44
+//   Transcript                         transcript/transcript.hpp:13-37, .cpp:4-87
+//   Polinomial (view subset)           polinomial.hpp:11-140
+//   MerkleProof/ProofTree/Fri/Proofs/FRIProof     fri/friProof.hpp:11-235
+//   FRIProve::prove                    fri/friProve.cpp:5-190
+//   proof2zkinStark (as a JSON string) fri/proof2zkinStark.cpp:8-82
+//
+// All field arithmetic on data buffers runs on the GPU; the scalar helpers in
+// class Goldilocks exist only because the reference's drivers use them for a
+// handful of per-proof constants (shift powers, challenges).
+// Errors: the reference's library functions return void and end the process via
+// exitProcess() (src/utils/exit_process.cpp:7); a non-zero C-ABI status does the
+// same here (xlp_exit_process, overridable for tests).
+#pragma once
+#include <cassert>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+#include <string>
+#include <vector>
+#include "../../include/xlp_gl.h"
+
+#define FIELD_EXTENSION 3
+#define HASH_SIZE 4
+#define SPONGE_WIDTH 12
+#define RATE 8
+#define CAPACITY 4
+
+inline void xlp_exit_process(const char* what)
+{
+    fprintf(stderr, "xlp_gl error in %s: %s\n", what, xlp_last_error());
+    exit(-1);
+}
+#define XLP_CHECK(call)                         \
+    do {                                        \
+        if ((call) != 0) xlp_exit_process(#call); \
+    } while (0)
+
+// ------------------------------------------------------------------ Goldilocks
+class Goldilocks
+{
+public:
+    typedef struct { uint64_t fe; } Element;
+    static constexpr uint64_t P = 0xFFFFFFFF00000001ULL;
+    static inline Element zero() { return {0}; }
+    static inline Element one() { return {1}; }
+    static inline Element fromU64(uint64_t x) { return {x % P}; }
+    static inline uint64_t toU64(const Element& a) { return a.fe >= P ? a.fe - P : a.fe; }
+    static inline std::string toString(const Element& a) { return std::to_string(toU64(a)); }
+    static inline Element add(const Element& a, const Element& b) { return {(uint64_t)(((unsigned __int128)toU64(a) + toU64(b)) % P)}; }
+    static inline Element sub(const Element& a, const Element& b) { return {(uint64_t)(((unsigned __int128)toU64(a) + P - toU64(b)) % P)}; }
+    static inline Element mul(const Element& a, const Element& b) { return {(uint64_t)(((unsigned __int128)a.fe * b.fe) % P)}; }
+    static inline void mul(Element& r, const Element& a, const Element& b) { r = mul(a, b); }
+    static inline Element square(const Element& a) { return mul(a, a); }
+    static inline Element exp(Element base, uint64_t e)
+    {
+        Element r = one();
+        while (e) { if (e & 1) r = mul(r, base); base = mul(base, base); e >>= 1; }
+        return r;
+    }
+    static inline Element inv(const Element& a) { return exp(a, P - 2); }
+    static inline bool isZero(const Element& a) { return toU64(a) == 0; }
+    static inline bool equal(const Element& a, const Element& b) { return toU64(a) == toU64(b); }
+    // primitive 2^n-th root of unity; W[32] pinned by the reference's golden proofs
+    static inline Element w(uint64_t n)
+    {
+        Element r = {7277203076849721926ULL};
+        for (uint64_t i = 32; i > n; i--) r = square(r);
+        return r;
+    }
+    static inline Element shift() { return {7}; }
+};
+inline Goldilocks::Element operator+(const Goldilocks::Element& a, const Goldilocks::Element& b) { return Goldilocks::add(a, b); }
+inline Goldilocks::Element operator-(const Goldilocks::Element& a, const Goldilocks::Element& b) { return Goldilocks::sub(a, b); }
+inline Goldilocks::Element operator*(const Goldilocks::Element& a, const Goldilocks::Element& b) { return Goldilocks::mul(a, b); }
+static_assert(sizeof(Goldilocks::Element) == sizeof(uint64_t), "Element must be one 64-bit word");
+
+class Goldilocks3
+{
+public:
+    typedef Goldilocks::Element Element[FIELD_EXTENSION];
+    // Fp[x]/(x^3 - x - 1), polinomial.hpp:195-205
+    static inline void mul(Element& r, const Element& a, const Element& b)
+    {
+        typedef Goldilocks G;
+        G::Element A = (a[0] + a[1]) * (b[0] + b[1]), B = (a[0] + a[2]) * (b[0] + b[2]), C = (a[1] + a[2]) * (b[1] + b[2]);
+        G::Element D = a[0] * b[0], E = a[1] * b[1], F = a[2] * b[2], Gg = D - E;
+        G::Element r0 = (C + Gg) - F, r1 = ((((A + C) - E) - E) - D), r2 = B - Gg;
+        r[0] = r0; r[1] = r1; r[2] = r2;
+    }
+    static inline void mul(Element& r, const Element& a, const Goldilocks::Element& b)
+    {
+        r[0] = a[0] * b; r[1] = a[1] * b; r[2] = a[2] * b;
+    }
+    static inline void one(Element& r) { r[0] = Goldilocks::one(); r[1] = Goldilocks::zero(); r[2] = Goldilocks::zero(); }
+};
+
+static inline uint64_t* xlp_raw(Goldilocks::Element* p) { return reinterpret_cast<uint64_t*>(p); }
+static inline const uint64_t* xlp_raw(const Goldilocks::Element* p) { return reinterpret_cast<const uint64_t*>(p); }
+
+// ------------------------------------------------------------- NTT_Goldilocks
+class NTT_Goldilocks
+{
+    uint64_t s_;
+public:
+    // (size, nThreads, extension): table sizes / thread counts are the library's business here
+    NTT_Goldilocks(uint64_t maxDomainSize, uint32_t /*nThreads*/ = 0, int /*extension*/ = 1) : s_(maxDomainSize) { XLP_CHECK(xlp_init(0)); }
+    void NTT(Goldilocks::Element* dst, Goldilocks::Element* src, uint64_t size, uint64_t ncols = 1, Goldilocks::Element* /*buffer*/ = NULL,
+             uint64_t /*nphase*/ = 0, uint64_t /*nblock*/ = 0, bool inverse = false, bool /*extend*/ = false)
+    {
+        XLP_CHECK(xlp_ntt(xlp_raw(dst), xlp_raw(src), size, ncols, inverse ? 1 : 0));
+    }
+    void INTT(Goldilocks::Element* dst, Goldilocks::Element* src, uint64_t size, uint64_t ncols = 1, Goldilocks::Element* buffer = NULL,
+              uint64_t nphase = 0, uint64_t nblock = 0, bool extend = false)
+    {
+        NTT(dst, src, size, ncols, buffer, nphase, nblock, true, extend);
+    }
+    void extendPol(Goldilocks::Element* output, Goldilocks::Element* input, uint64_t N_Extended, uint64_t N, uint64_t ncols,
+                   Goldilocks::Element* buffer = NULL, uint64_t /*nphase*/ = 0, uint64_t /*nblock*/ = 0)
+    {
+        XLP_CHECK(xlp_extend(xlp_raw(output), xlp_raw(input), N_Extended, N, ncols, xlp_raw(buffer)));
+    }
+};
+
+// --------------------------------------------------------- PoseidonGoldilocks
+class PoseidonGoldilocks
+{
+public:
+    static void hash_full_result(Goldilocks::Element* state, const Goldilocks::Element* input)
+    {
+        XLP_CHECK(xlp_perm(xlp_raw(state), xlp_raw(input)));
+    }
+    static void hash(Goldilocks::Element (&state)[CAPACITY], const Goldilocks::Element (&input)[SPONGE_WIDTH])
+    {
+        Goldilocks::Element full[SPONGE_WIDTH];
+        hash_full_result(full, input);
+        std::memcpy(state, full, CAPACITY * sizeof(Goldilocks::Element));
+    }
+    static void linear_hash(Goldilocks::Element* output, Goldilocks::Element* input, uint64_t size)
+    {
+        XLP_CHECK(xlp_linear_hash(xlp_raw(output), xlp_raw(input), size, 1));
+    }
+    static void merkletree(Goldilocks::Element* tree, Goldilocks::Element* input, uint64_t num_cols, uint64_t num_rows, int /*nThreads*/ = 0, uint64_t /*dim*/ = 1)
+    {
+        XLP_CHECK(xlp_merkle(xlp_raw(tree), xlp_raw(input), num_cols, num_rows));
+    }
+    static void merkletree_avx(Goldilocks::Element* tree, Goldilocks::Element* input, uint64_t num_cols, uint64_t num_rows, int n = 0, uint64_t dim = 1)
+    {
+        merkletree(tree, input, num_cols, num_rows, n, dim);
+    }
+    static void merkletree_avx512(Goldilocks::Element* tree, Goldilocks::Element* input, uint64_t num_cols, uint64_t num_rows, int n = 0, uint64_t dim = 1)
+    {
+        merkletree(tree, input, num_cols, num_rows, n, dim);
+    }
+};
+
+class MerklehashGoldilocks
+{
+public:
+    static inline uint64_t getTreeNumElements(uint64_t numRows) { return numRows * HASH_SIZE + (numRows - 1) * HASH_SIZE; }
+    static inline void root(Goldilocks::Element* root, Goldilocks::Element* tree, uint64_t numElementsTree)
+    {
+        std::memcpy(root, &tree[numElementsTree - HASH_SIZE], HASH_SIZE * sizeof(Goldilocks::Element));
+    }
+};
+
+// --------------------------------------------------------------- MerkleTreeGL
+#define MERKLEHASHGL_ARITY 2
+class MerkleTreeGL
+{
+public:
+    uint64_t height;
+    uint64_t width;
+    Goldilocks::Element* source;
+    Goldilocks::Element* nodes;
+    bool isSourceAllocated = false;
+    bool isNodesAllocated = false;
+    MerkleTreeGL() : height(0), width(0), source(NULL), nodes(NULL) {}
+    // file-backed layout [width, height, source(height*width), nodes] (build_const_tree.cpp:566-603)
+    MerkleTreeGL(Goldilocks::Element* tree)
+    {
+        width = Goldilocks::toU64(tree[0]);
+        height = Goldilocks::toU64(tree[1]);
+        source = &tree[2];
+        nodes = &tree[2 + height * width];
+    }
+    MerkleTreeGL(uint64_t _height, uint64_t _width, Goldilocks::Element* _source) : height(_height), width(_width), source(_source)
+    {
+        if (source == NULL) {
+            source = (Goldilocks::Element*)calloc((height * width) != 0 ? height * width : 1, sizeof(Goldilocks::Element));
+            isSourceAllocated = true;
+        }
+        nodes = (Goldilocks::Element*)calloc(getTreeNumElements(), sizeof(Goldilocks::Element));
+        isNodesAllocated = true;
+    }
+    ~MerkleTreeGL()
+    {
+        if (isSourceAllocated) free(source);
+        if (isNodesAllocated) free(nodes);
+    }
+    MerkleTreeGL(const MerkleTreeGL&) = delete;
+    MerkleTreeGL& operator=(const MerkleTreeGL&) = delete;
+    void copySource(Goldilocks::Element* _source) { std::memcpy(source, _source, height * width * sizeof(Goldilocks::Element)); }
+    void merkelize() { PoseidonGoldilocks::merkletree_avx(nodes, source, width, height); }
+    uint64_t getTreeNumElements() { return height * HASH_SIZE + (height - 1) * HASH_SIZE; }
+    void getRoot(Goldilocks::Element* root) { std::memcpy(root, &nodes[getTreeNumElements() - HASH_SIZE], HASH_SIZE * sizeof(Goldilocks::Element)); }
+    uint64_t MerkleProofSize()
+    {
+        uint64_t n = 0;
+        while ((1ULL << n) < height) n++;
+        return height > 1 ? n : 0;
+    }
+    // proof = row || siblings bottom-up (merkleTreeGL.cpp:12-35)
+    void getGroupProof(Goldilocks::Element* proof, uint64_t idx)
+    {
+        for (uint64_t i = 0; i < width; i++) proof[i] = source[idx * width + i];
+        Goldilocks::Element* out = &proof[width];
+        uint64_t off = 0, cnt = height;
+        while (cnt > 1) {
+            std::memcpy(out, &nodes[off + (idx ^ 1) * HASH_SIZE], HASH_SIZE * sizeof(Goldilocks::Element));
+            out += HASH_SIZE;
+            off += cnt * HASH_SIZE;
+            cnt >>= 1;
+            idx >>= 1;
+        }
+    }
+};
+
+// ----------------------------------------------------------------- Transcript
+#define TRANSCRIPT_STATE_SIZE 4
+#define TRANSCRIPT_PENDING_SIZE 8
+#define TRANSCRIPT_OUT_SIZE 12
+class Transcript
+{
+    void _updateState()
+    {
+        Goldilocks::Element inputs[TRANSCRIPT_OUT_SIZE];
+        std::memcpy(inputs, pending, sizeof(pending));
+        std::memcpy(&inputs[TRANSCRIPT_PENDING_SIZE], state, sizeof(state));
+        PoseidonGoldilocks::hash_full_result(out, inputs);
+        out_cursor = TRANSCRIPT_OUT_SIZE;
+        std::memset(pending, 0, sizeof(pending));
+        pending_cursor = 0;
+        std::memcpy(state, out, sizeof(state));
+    }
+    void _add1(Goldilocks::Element input)
+    {
+        pending[pending_cursor++] = input;
+        out_cursor = 0;
+        if (pending_cursor == TRANSCRIPT_PENDING_SIZE) _updateState();
+    }
+public:
+    Goldilocks::Element state[TRANSCRIPT_STATE_SIZE];
+    Goldilocks::Element pending[TRANSCRIPT_PENDING_SIZE];
+    Goldilocks::Element out[TRANSCRIPT_OUT_SIZE];
+    unsigned pending_cursor = 0, out_cursor = 0, state_cursor = 0;
+    Transcript()
+    {
+        std::memset(state, 0, sizeof(state));
+        std::memset(pending, 0, sizeof(pending));
+        std::memset(out, 0, sizeof(out));
+    }
+    void put(Goldilocks::Element* input, uint64_t size) { for (uint64_t i = 0; i < size; i++) _add1(input[i]); }
+    Goldilocks::Element getFields1()
+    {
+        if (out_cursor == 0) _updateState();
+        Goldilocks::Element res = out[(TRANSCRIPT_OUT_SIZE - out_cursor) % TRANSCRIPT_OUT_SIZE];
+        out_cursor--;
+        return res;
+    }
+    void getField(Goldilocks::Element* output) { for (int i = 0; i < 3; i++) output[i] = getFields1(); }
+    // 63 bits per field element, LSB first (transcript.cpp:57-87)
+    void getPermutations(uint64_t* res, uint64_t n, uint64_t nBits)
+    {
+        uint64_t totalBits = n * nBits;
+        uint64_t NFields = (totalBits - 1) / 63 + 1;
+        std::vector<uint64_t> fields(NFields);
+        for (uint64_t i = 0; i < NFields; i++) fields[i] = Goldilocks::toU64(getFields1());
+        uint64_t curField = 0, curBit = 0;
+        for (uint64_t i = 0; i < n; i++) {
+            uint64_t a = 0;
+            for (uint64_t j = 0; j < nBits; j++) {
+                if ((fields[curField] >> curBit) & 1) a += (1ULL << j);
+                if (++curBit == 63) { curBit = 0; curField++; }
+            }
+            res[i] = a;
+        }
+    }
+};
+
+// ----------------------------------------------------------------- Polinomial
+// Strided view (address, degree, dim, offset) -- the subset FRIProve::prove needs.
+class Polinomial
+{
+    Goldilocks::Element* _pAddress = NULL;
+    uint64_t _degree = 0, _dim = 0, _offset = 0;
+    bool _allocated = false;
+public:
+    Polinomial() {}
+    Polinomial(void* pAddress, uint64_t degree, uint64_t dim, uint64_t offset = 0, std::string = "")
+        : _pAddress((Goldilocks::Element*)pAddress), _degree(degree), _dim(dim), _offset(offset ? offset : dim) {}
+    Polinomial(uint64_t degree, uint64_t dim, std::string = "") : _degree(degree), _dim(dim), _offset(dim), _allocated(true)
+    {
+        _pAddress = (Goldilocks::Element*)calloc((degree * dim) != 0 ? degree * dim : 1, sizeof(Goldilocks::Element));
+    }
+    ~Polinomial() { if (_allocated) free(_pAddress); }
+    Polinomial(const Polinomial&) = delete;
+    Polinomial& operator=(const Polinomial&) = delete;
+    Goldilocks::Element* address() { return _pAddress; }
+    uint64_t degree() const { return _degree; }
+    uint64_t dim() const { return _dim; }
+    uint64_t offset() const { return _offset; }
+    Goldilocks::Element* operator[](uint64_t i) { return &_pAddress[i * _offset]; }
+    std::string toString(uint64_t n = 0)
+    {
+        std::ostringstream os;
+        uint64_t cnt = n ? n : _degree;
+        for (uint64_t i = 0; i < cnt; i++) os << (i ? " " : "") << Goldilocks::toString(_pAddress[i * _offset]);
+        return os.str();
+    }
+};
+
+// ------------------------------------------------------------------- FRIProof
+class MerkleProof
+{
+public:
+    std::vector<std::vector<Goldilocks::Element>> v;
+    std::vector<std::vector<Goldilocks::Element>> mp;
+    MerkleProof(uint64_t nLinears, uint64_t elementsTree, Goldilocks::Element* pointer)
+        : v(nLinears, std::vector<Goldilocks::Element>(1, Goldilocks::zero())), mp(elementsTree, std::vector<Goldilocks::Element>(HASH_SIZE, Goldilocks::zero()))
+    {
+        for (uint64_t i = 0; i < nLinears; i++) v[i][0] = pointer[i];
+        for (uint64_t j = 0; j < elementsTree; j++)
+            std::memcpy(&mp[j][0], &pointer[nLinears + j * HASH_SIZE], HASH_SIZE * sizeof(Goldilocks::Element));
+    }
+};
+class ProofTree
+{
+public:
+    std::vector<Goldilocks::Element> root;
+    std::vector<std::vector<MerkleProof>> polQueries;
+    ProofTree() : root(HASH_SIZE) {}
+    void setRoot(Goldilocks::Element* _root) { std::memcpy(&root[0], _root, HASH_SIZE * sizeof(Goldilocks::Element)); }
+};
+class Fri
+{
+public:
+    std::vector<std::vector<Goldilocks::Element>> pol;
+    std::vector<ProofTree> trees;
+    Fri(uint64_t polN, uint64_t dim, uint64_t numSteps) : pol(polN, std::vector<Goldilocks::Element>(dim, Goldilocks::zero())), trees(numSteps) {}
+    void setPol(Goldilocks::Element* pPol)
+    {
+        for (uint64_t i = 0; i < pol.size(); i++) std::memcpy(&pol[i][0], &pPol[i * pol[i].size()], pol[i].size() * sizeof(Goldilocks::Element));
+    }
+};
+class Proofs
+{
+public:
+    std::vector<Goldilocks::Element> root1, root2, root3, root4;
+    Fri fri;
+    std::vector<std::vector<Goldilocks::Element>> evals;
+    Proofs(uint64_t polN, uint64_t dim, uint64_t numSteps, uint64_t evalSize)
+        : root1(HASH_SIZE, Goldilocks::zero()), root2(HASH_SIZE, Goldilocks::zero()), root3(HASH_SIZE, Goldilocks::zero()),
+          root4(HASH_SIZE, Goldilocks::zero()), fri(polN, dim, numSteps), evals(evalSize, std::vector<Goldilocks::Element>(dim, Goldilocks::zero())) {}
+    void setEvals(Goldilocks::Element* _evals)
+    {
+        for (uint64_t i = 0; i < evals.size(); i++) std::memcpy(&evals[i][0], &_evals[i * evals[i].size()], evals[i].size() * sizeof(Goldilocks::Element));
+    }
+};
+class FRIProof
+{
+public:
+    Proofs proofs;
+    std::vector<Goldilocks::Element> publics;
+    FRIProof(uint64_t polN, uint64_t dim, uint64_t numTrees, uint64_t evalSize, uint64_t nPublics)
+        : proofs(polN, dim, numTrees, evalSize), publics(nPublics) {}
+};
+
+// ------------------------------------------------------ StarkInfo (FRI subset)
+struct StepStruct { uint64_t nBits; };
+struct StarkStruct {
+    uint64_t nBits = 0, nBitsExt = 0, nQueries = 0;
+    std::vector<StepStruct> steps;
+};
+struct StarkInfo { StarkStruct starkStruct; };
+
+// -------------------------------------------------------------------- FRIProve
+class FRIProve
+{
+public:
+    // friProve.cpp:5-190.  The polynomial is uploaded once; fold / transpose / Merkle run on
+    // the GPU per step; only roots, the final polynomial and the opened rows come back.
+    static void prove(FRIProof& fproof, MerkleTreeGL** treesGL, Transcript transcript, Polinomial& friPol, uint64_t polBits, StarkInfo starkInfo)
+    {
+        const std::vector<StepStruct>& steps = starkInfo.starkStruct.steps;
+        const uint64_t nSteps = steps.size();
+        Goldilocks::Element polShiftInv = Goldilocks::inv(Goldilocks::shift());
+        std::vector<MerkleTreeGL*> treesFRIGL(nSteps, NULL);
+
+        uint64_t* d_pol = NULL; uint64_t* d_pol2 = NULL; uint64_t* d_aux = NULL; uint64_t* d_nodes = NULL;
+        const uint64_t n0 = 1ULL << polBits;
+        XLP_CHECK(xlp_dev_alloc((void**)&d_pol, n0 * 3 * 8));
+        XLP_CHECK(xlp_dev_alloc((void**)&d_pol2, n0 * 3 * 8));
+        XLP_CHECK(xlp_dev_alloc((void**)&d_aux, n0 * 3 * 8));
+        XLP_CHECK(xlp_dev_alloc((void**)&d_nodes, n0 * 2 * HASH_SIZE * 8));
+        if (friPol.offset() != FIELD_EXTENSION) xlp_exit_process("FRIProve::prove: friPol must be dense (offset == 3)");
+        XLP_CHECK(xlp_copy_h2d(d_pol, friPol.address(), n0 * 3 * 8));
+
+        uint64_t pol2N = 0;
+        for (uint64_t si = 0; si < nSteps; si++) {
+            const uint64_t reductionBits = polBits - steps[si].nBits;
+            pol2N = 1ULL << (polBits - reductionBits);
+            Goldilocks::Element special_x[FIELD_EXTENSION];
+            transcript.getField(special_x);
+            XLP_CHECK(xlp_dev_fri_fold(d_pol2, d_pol, (uint32_t)polBits, (uint32_t)reductionBits, xlp_raw(special_x), Goldilocks::toU64(polShiftInv)));
+            if (si < nSteps - 1) {
+                const uint64_t nGroups = 1ULL << steps[si + 1].nBits;
+                const uint64_t groupSize = (1ULL << steps[si].nBits) / nGroups;
+                XLP_CHECK(xlp_dev_transpose3(d_aux, d_pol2, pol2N, (uint32_t)steps[si + 1].nBits));
+                XLP_CHECK(xlp_dev_merkle(d_nodes, d_aux, groupSize * FIELD_EXTENSION, nGroups));
+                treesFRIGL[si + 1] = new MerkleTreeGL(nGroups, groupSize * FIELD_EXTENSION, NULL);
+                MerkleTreeGL* t = treesFRIGL[si + 1];
+                XLP_CHECK(xlp_copy_d2h(t->source, d_aux, pol2N * 3 * 8));
+                XLP_CHECK(xlp_copy_d2h(t->nodes, d_nodes, t->getTreeNumElements() * 8));
+                Goldilocks::Element rootGL[HASH_SIZE];
+                t->getRoot(rootGL);
+                transcript.put(rootGL, HASH_SIZE);
+                fproof.proofs.fri.trees[si + 1].setRoot(rootGL);
+            } else {
+                std::vector<Goldilocks::Element> last(pol2N * FIELD_EXTENSION);
+                XLP_CHECK(xlp_copy_d2h(last.data(), d_pol2, pol2N * 3 * 8));
+                for (uint64_t i = 0; i < pol2N; i++) transcript.put(&last[i * FIELD_EXTENSION], FIELD_EXTENSION);
+            }
+            std::swap(d_pol, d_pol2);   // friPol <- pol2
+            polBits -= reductionBits;
+            for (uint64_t j = 0; j < reductionBits; j++) polShiftInv = Goldilocks::square(polShiftInv);
+        }
+        // final polynomial back into friPol (reference copies every step; only the last is observable)
+        XLP_CHECK(xlp_copy_d2h(friPol.address(), d_pol, pol2N * 3 * 8));
+        fproof.proofs.fri.setPol(friPol.address());
+
+        const uint64_t nQueries = starkInfo.starkStruct.nQueries;
+        std::vector<uint64_t> ys(nQueries);
+        transcript.getPermutations(ys.data(), nQueries, steps[0].nBits);
+        for (uint64_t si = 0; si < nSteps; si++) {
+            for (uint64_t i = 0; i < nQueries; i++) {
+                if (si == 0) queryPol(fproof, treesGL, ys[i], si);
+                else queryPol(fproof, treesFRIGL[si], ys[i], si);
+            }
+            if (si < nSteps - 1)
+                for (uint64_t i = 0; i < nQueries; i++) ys[i] = ys[i] % (1ULL << steps[si + 1].nBits);
+        }
+        for (MerkleTreeGL* t : treesFRIGL) delete t;
+        XLP_CHECK(xlp_dev_free(d_pol)); XLP_CHECK(xlp_dev_free(d_pol2)); XLP_CHECK(xlp_dev_free(d_aux)); XLP_CHECK(xlp_dev_free(d_nodes));
+    }
+    static void queryPol(FRIProof& fproof, MerkleTreeGL* treesGL[5], uint64_t idx, uint64_t treeIdx)
+    {
+        std::vector<MerkleProof> vMkProof;
+        for (unsigned i = 0; i < 5; i++) {
+            MerkleTreeGL* t = treesGL[i];
+            std::vector<Goldilocks::Element> buff(t->width + t->MerkleProofSize() * HASH_SIZE + 1, Goldilocks::zero());
+            t->getGroupProof(buff.data(), idx);
+            vMkProof.push_back(MerkleProof(t->width, t->MerkleProofSize(), buff.data()));
+        }
+        fproof.proofs.fri.trees[treeIdx].polQueries.push_back(vMkProof);
+    }
+    static void queryPol(FRIProof& fproof, MerkleTreeGL* treeGL, uint64_t idx, uint64_t treeIdx)
+    {
+        std::vector<MerkleProof> vMkProof;
+        std::vector<Goldilocks::Element> buff(treeGL->width + treeGL->MerkleProofSize() * HASH_SIZE + 1, Goldilocks::zero());
+        treeGL->getGroupProof(buff.data(), idx);
+        vMkProof.push_back(MerkleProof(treeGL->width, treeGL->MerkleProofSize(), buff.data()));
+        fproof.proofs.fri.trees[treeIdx].polQueries.push_back(vMkProof);
+    }
+};
+
+// ------------------------------------------------------------- proof -> zkin
+// Emits the zkin layout of proof2zkinStark.cpp:8-82 (decimal strings) directly from a FRIProof.
+namespace xlp_json {
+inline void arr(std::ostringstream& os, const std::vector<Goldilocks::Element>& v)
+{
+    os << "[";
+    for (size_t i = 0; i < v.size(); i++) os << (i ? "," : "") << "\"" << Goldilocks::toString(v[i]) << "\"";
+    os << "]";
+}
+inline void arr2(std::ostringstream& os, const std::vector<std::vector<Goldilocks::Element>>& v)
+{
+    os << "[";
+    for (size_t i = 0; i < v.size(); i++) { os << (i ? "," : ""); arr(os, v[i]); }
+    os << "]";
+}
+inline void vals(std::ostringstream& os, const MerkleProof& m)   // v entries are single elements -> flat array of strings
+{
+    os << "[";
+    for (size_t i = 0; i < m.v.size(); i++) os << (i ? "," : "") << "\"" << Goldilocks::toString(m.v[i][0]) << "\"";
+    os << "]";
+}
+}  // namespace xlp_json
+
+inline std::string proof2zkinStark(FRIProof& proof)
+{
+    using namespace xlp_json;
+    std::ostringstream os;
+    Proofs& p = proof.proofs;
+    os << "{\"root1\":"; arr(os, p.root1);
+    os << ",\"root2\":"; arr(os, p.root2);
+    os << ",\"root3\":"; arr(os, p.root3);
+    os << ",\"root4\":"; arr(os, p.root4);
+    os << ",\"evals\":"; arr2(os, p.evals);
+    const std::vector<ProofTree>& trees = p.fri.trees;
+    for (size_t i = 1; i < trees.size(); i++) {
+        os << ",\"s" << i << "_root\":"; arr(os, trees[i].root);
+        os << ",\"s" << i << "_vals\":[";
+        for (size_t q = 0; q < trees[i].polQueries.size(); q++) { os << (q ? "," : ""); vals(os, trees[i].polQueries[q][0]); }
+        os << "],\"s" << i << "_siblings\":[";
+        for (size_t q = 0; q < trees[i].polQueries.size(); q++) { os << (q ? "," : ""); arr2(os, trees[i].polQueries[q][0].mp); }
+        os << "]";
+    }
+    static const char* names[5] = {"1", "2", "3", "4", "C"};
+    const std::vector<std::vector<MerkleProof>>& q0 = trees[0].polQueries;
+    for (int t = 0; t < 5; t++) {
+        if ((t == 1 || t == 2) && (q0.empty() || q0[0][t].v.empty())) continue;   // absent sections are omitted
+        os << ",\"s0_vals" << names[t] << "\":[";
+        for (size_t q = 0; q < q0.size(); q++) { os << (q ? "," : ""); vals(os, q0[q][t]); }
+        os << "],\"s0_siblings" << names[t] << "\":[";
+        for (size_t q = 0; q < q0.size(); q++) { os << (q ? "," : ""); arr2(os, q0[q][t].mp); }
+        os << "]";
+    }
+    os << ",\"finalPol\":"; arr2(os, p.fri.pol);
+    os << "}";
+    return os.str();
+}
