@@ -266,3 +266,28 @@ def test_field_ops_exhaustive_edges(xlp):
     for k in (0, 1, 31, 32, 33, 63, 64, 65, 95):
         got = xlp.field_op(a, b, 200 + k)
         assert [int(v) for v in got] == [(x << k) % P for x in ai], f"mul_pow2({k})"
+
+
+# ---------------------------------------------------------------- multi-GPU plumbing on one GPU
+def test_gpu_hash_pairs_and_world1_commit(xlp, orc):
+    import torch
+    import torch.distributed as dist
+    from xlayer_prover_amd import shard
+    nodes = orc.fill(16 * 4, 77).reshape(16, 4)
+    got = xlp.to_np(shard.gpu_hash_pairs(xlp.from_np(nodes)))
+    exp = np.stack([orc.perm(list(nodes[2 * i]) + list(nodes[2 * i + 1]) + [0] * 4)[:4] for i in range(8)])
+    assert (got == exp).all()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29631")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n, n_ext, ncols = 1 << 10, 1 << 11, 9
+        full = orc.fill(n * ncols, 0x5EED0004).reshape(n, ncols)
+        root, nodes_t, rows = shard.sharded_commit(xlp.from_np(full), n, n_ext, ncols)
+        xlp.sync()
+        ext = orc.extend_pol(full, n_ext, n, ncols)
+        assert (xlp.to_np(rows) == ext).all()
+        assert (xlp.to_np(nodes_t) == orc.merkletree(ext, ncols, n_ext)).all()
+        assert (xlp.to_np(root) == orc.merkletree(ext, ncols, n_ext)[-4:]).all()
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,78 @@
+"""N > 1 path on CPU: world_size-2 (and 4) gloo processes run the partition / exchange /
+cap-assembly logic of xlayer_prover_amd/shard.py with the oracle standing in for the kernels
+(injected -- the product module never imports it), and the result must equal the
+single-process oracle Merkle tree of the full extended trace."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n, n_ext, ncols, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import gl_oracle as orc
+    from xlayer_prover_amd import shard
+    full = orc.fill(n * ncols, 0x5EED0004).reshape(n, ncols)
+    c0, c1 = shard.col_range(ncols, world, rank)
+    local = torch.from_numpy(full[:, c0:c1].copy().view(np.int64))
+    as_u = lambda t: t.numpy().view(np.uint64)
+    to_t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64))
+    lde = lambda x: to_t(orc.extend_pol(as_u(x), n_ext, n, x.shape[1]))
+    merkle = lambda rows: to_t(orc.merkletree(as_u(rows), rows.shape[1], rows.shape[0]))
+
+    def hash_pairs(nodes):
+        a = as_u(nodes).reshape(-1, 8)
+        return to_t(np.stack([orc.perm(list(r) + [0] * 4)[:4] for r in a]))
+    root, nodes, rows = shard.sharded_commit(local, n, n_ext, ncols, lde=lde, merkle=merkle, hash_pairs=hash_pairs)
+    r0, r1 = shard.row_range(n_ext, world, rank)
+    q.put((rank, as_u(root).tolist(), as_u(rows).tolist() if rank == 0 else None, (r0, r1), as_u(nodes[-4:]).tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,ncols", [(2, 8), (2, 5), (4, 11)])
+def test_sharded_commit_equals_single_process_tree(world, ncols, orc):
+    n, n_ext = 1 << 6, 1 << 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + world * 7 + ncols
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, n_ext, ncols, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full = orc.fill(n * ncols, 0x5EED0004).reshape(n, ncols)
+    ext = orc.extend_pol(full, n_ext, n, ncols)
+    tree = orc.merkletree(ext, ncols, n_ext)
+    exp_root = [int(v) for v in tree[-4:]]
+    per = n_ext // world
+    lvl = int(np.log2(per))                      # sub-roots live at this level of the reference tree
+    off = sum(4 * (n_ext >> k) for k in range(lvl))
+    for rank, root, rows, (r0, r1), sub in res:
+        assert root == exp_root                                        # every rank derives the same root
+        assert sub == [int(v) for v in tree[off + 4 * rank: off + 4 * rank + 4]]   # sub-root = node (lvl, rank)
+        assert (r0, r1) == (rank * per, (rank + 1) * per)
+        if rows is not None:
+            assert rows == ext[r0:r1].tolist()                         # exchange delivered all columns of my rows
+
+
+def test_partitions():
+    from xlayer_prover_amd import shard
+    for W, G in [(751, 8), (168, 8), (408, 8), (6, 4), (8, 2), (5, 2)]:
+        spans = [shard.col_range(W, G, g) for g in range(G)]
+        assert spans[0][0] == 0 and spans[-1][1] == W
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(G - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+    assert [shard.col_range(751, 8, g)[1] - shard.col_range(751, 8, g)[0] for g in range(8)] == [94] * 7 + [93]

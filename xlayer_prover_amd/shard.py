@@ -1,0 +1,110 @@
+"""Multi-GPU commitment of one STARK section, one process per GPU.
+
+    1. LDE          -- rank g owns the columns col_range(W, G, g) (columns are independent:
+                       NTT_Goldilocks::extendPol loops over them, starks.cpp:53)
+    2. exchange     -- all-to-all: the Merkle leaf is a sponge over a WHOLE row in column order
+                       (merkleTreeGL.cpp:39-43), so hashing needs a row partition; each rank keeps
+                       rows row_range(h, G, g) of every column
+    3. hash         -- rank g builds the sub-tree over its rows; its sub-root is node
+                       (level log2(h/G), index g) of the reference's tree
+    4. caps         -- all-gather of the G sub-roots (32 bytes each), top log2 G levels hashed
+                       everywhere -> the root the transcript absorbs (starks.cpp:56-60)
+
+torch.distributed is only the transport (RCCL over xGMI on GPU, gloo in the CPU tests).  The field
+arithmetic is the HIP library's; `hash_pairs` / `lde` / `merkle` are injectable so that the CPU-only
+tests can check the partition / exchange / cap-assembly logic with the oracle as the checker.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def col_range(ncols, world, rank):
+    """contiguous, balanced column shard of rank (first ncols % world ranks get one extra)"""
+    base, rem = divmod(ncols, world)
+    c0 = rank * base + min(rank, rem)
+    return c0, c0 + base + (1 if rank < rem else 0)
+
+
+def row_range(h, world, rank):
+    assert h % world == 0, "row count must be divisible by the number of ranks"
+    per = h // world
+    return rank * per, (rank + 1) * per
+
+
+def columns_to_rows(local, ncols, group=None):
+    """local: [h, wc_local] (this rank's columns of all rows) -> [h / G, ncols] (all columns of this
+    rank's rows).  One all-to-all; direct peer exchange, every xGMI link busy (no ring)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    h, wc = local.shape
+    assert (wc,) == (col_range(ncols, world, rank)[1] - col_range(ncols, world, rank)[0],)
+    per = h // world
+    # send to peer p: rows row_range(p) of my columns
+    send = [local[p * per:(p + 1) * per].contiguous() for p in range(world)]
+    recv = [torch.empty((per, col_range(ncols, world, p)[1] - col_range(ncols, world, p)[0]), dtype=local.dtype, device=local.device)
+            for p in range(world)]
+    dist.all_to_all(recv, send, group=group) if dist.get_backend(group) != "gloo" else _all_to_all_gloo(recv, send, group)
+    return torch.cat(recv, dim=1).contiguous()
+
+
+def _all_to_all_gloo(recv, send, group):
+    # gloo has no all_to_all for CPU tensors: pairwise exchange (tests only)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    recv[rank].copy_(send[rank])
+    reqs = []
+    for p in range(world):
+        if p == rank:
+            continue
+        reqs.append(dist.isend(send[p], p, group=group))
+        reqs.append(dist.irecv(recv[p], p, group=group))
+    for r in reqs:
+        r.wait()
+
+
+def assemble_root(sub_root, hash_pairs, group=None):
+    """sub_root: int64 tensor [4] = root of this rank's row range.  Returns (root[4], caps[G,4]).
+    hash_pairs(nodes[2k,4]) -> [k,4] computes perm(left|right|0^4)[0..3] per pair."""
+    world = dist.get_world_size(group)
+    caps = [torch.empty_like(sub_root) for _ in range(world)]
+    dist.all_gather(caps, sub_root.contiguous(), group=group)
+    level = torch.stack(caps)                       # [G, 4] in rank order == node order
+    top = level
+    while top.shape[0] > 1:
+        top = hash_pairs(top)
+    return top[0], level
+
+
+def gpu_hash_pairs(nodes):
+    """product implementation of hash_pairs: the Merkle-level kernel of libxlp_gl.so"""
+    from . import capi
+    k = nodes.shape[0] // 2
+    # a tree over k*2 leaves of width 4 (no-hash leaf rule) has exactly these pairs at level 1
+    buf = torch.empty((2 * 2 * k - 1) * 4, dtype=torch.int64, device=nodes.device)
+    capi.dev_merkle(buf, nodes.contiguous().view(-1), 4, 2 * k)
+    return buf[2 * k * 4: 2 * k * 4 + k * 4].view(k, 4).clone()
+
+
+def sharded_commit(trace_local, n, n_ext, ncols, group=None, lde=None, merkle=None, hash_pairs=None):
+    """trace_local: int64 [n, wc_local] on this rank's device.  Returns (root[4], nodes_local, ext_rows)."""
+    from . import capi
+    world = dist.get_world_size(group)
+    wc = trace_local.shape[1]
+    if lde is None:
+        def lde(x):
+            out = torch.empty((n_ext, wc), dtype=torch.int64, device=x.device)
+            capi.dev_extend(out, x.contiguous(), n_ext, n, wc)
+            return out
+    if merkle is None:
+        def merkle(rows):
+            h, w = rows.shape
+            nodes = torch.empty((2 * h - 1) * 4, dtype=torch.int64, device=rows.device)
+            capi.dev_merkle(nodes, rows.contiguous(), w, h)
+            return nodes
+    if hash_pairs is None:
+        hash_pairs = gpu_hash_pairs
+    ext_local = lde(trace_local)                               # [n_ext, wc]   column shard
+    ext_rows = columns_to_rows(ext_local, ncols, group)        # [n_ext/G, W]  row shard
+    nodes = merkle(ext_rows)
+    root, _ = assemble_root(nodes[-4:].clone(), hash_pairs, group)
+    return root, nodes, ext_rows
