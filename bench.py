@@ -25,7 +25,8 @@ NCOLS = 8
 EXT_BITS = 1
 SEED = 0x5EED0002
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-PASS_LAUNCHES_PER_LDE = 9        # ntt_pass_kernel launches per extendPol at this size (3 INTT + 2 cosets x 3)
+LDE_KERNELS = ["xlp::lde_top_dif<11>", "xlp::lde_mid", "xlp::lde_top_dit<11>"]   # one launch of each per extendPol
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1", "lde_traffic.json")          # PMC passes of tools/traffic_probe.py
 
 
 def cpu_baseline(log_n, ncols, budget_s=20.0):
@@ -38,9 +39,10 @@ def cpu_baseline(log_n, ncols, budget_s=20.0):
     t0 = time.perf_counter()
     orc.extend_pol(src, n << EXT_BITS, n, ncols)
     t = time.perf_counter() - t0
-    per_fe_log = t / (n * ncols * 17)                # ~ n log n model
+    par = min(threads, ncols)
+    per_fe_log = t / (n * 17) * (1 if par >= ncols else ncols / par)   # ~ n log n per column-batch model
     lg = 16
-    while lg < log_n and per_fe_log * (1 << (lg + 1)) * ncols * (lg + 2) < budget_s:
+    while lg < log_n and per_fe_log * (1 << (lg + 1)) * (lg + 2) < budget_s:
         lg += 1
     n = 1 << lg
     src = orc.fill(n * ncols, SEED).reshape(n, ncols)
@@ -96,6 +98,13 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # per-kernel HIP events (recorded inside the library on the stream the kernels run on)
+    torch.cuda.synchronize()
+    capi.profile_enable(True)
+    for _ in range(3):
+        step()
+    kern_ms_sum, kern_cnt = capi.profile_read()
+    capi.profile_enable(False)
 
     def barrier():
         torch.cuda.synchronize()
@@ -123,19 +132,25 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         fe_per_step = n_ext * ncols * world
         value = fe_per_step / (elapsed / args.steps) / 1e9
-        # roofline of the dominant kernel (ntt_pass_kernel): algorithmic bytes of one LDE =
-        # 8*N*ncols in + 8*N_ext*ncols out (24 B per input element at blow-up 2),
-        # spread over the kernel's launches in one LDE; duration from the HIP events above.
+        # roofline.  Algorithmic bytes of one LDE = 8*N*ncols in + 8*N_ext*ncols out (24 B
+        # per input element at blow-up 2).  One LDE = one launch each of lde_top_dif, lde_mid,
+        # lde_top_dit; the dominant kernel is lde_mid.  `achieved` prices the whole LDE: algorithmic
+        # bytes / (sum of the three kernels' average launch durations, HIP events on their stream).
         alg_bytes_lde = 8 * n * ncols + 8 * n_ext * ncols
-        launches = PASS_LAUNCHES_PER_LDE if args.log_n == LOG_N else None
-        kern_ms_lde = dev_ms / args.steps
-        achieved = alg_bytes_lde / (kern_ms_lde * 1e-3) / 1e9
+        per_kernel_ms = [x / kern_cnt for x in kern_ms_sum] if kern_cnt else [None] * 3
+        lde_kernel_ms = sum(per_kernel_ms) if kern_cnt else dev_ms / args.steps
+        achieved = alg_bytes_lde / (lde_kernel_ms * 1e-3) / 1e9
+        traffic = None
+        if os.path.exists(TRAFFIC_FILE) and args.log_n == LOG_N and ncols == NCOLS:
+            traffic = json.load(open(TRAFFIC_FILE))["hbm_bytes_per_lde"]
         roofline = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-            "kernel": "xlp::ntt_pass_kernel", "launches_per_step": launches,
-            "avg_launch_ms": round(kern_ms_lde / launches, 4) if launches else None,
-            "alg_bytes_per_launch": alg_bytes_lde / launches if launches else None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "kernel": "xlp::lde_mid (dominant) + lde_top_dif + lde_top_dit = one extendPol",
+            "launches_per_step": 3,
+            "avg_launch_ms": {k: round(v, 4) for k, v in zip(LDE_KERNELS, per_kernel_ms)} if kern_cnt else None,
+            "alg_bytes_per_step": alg_bytes_lde,
+            "note": "integer-VALU co-bound (Goldilocks mul = 4 v_mad_u64_u32 + carry chains): see DESIGN.md",
         }
         line = {
             "metric": "Goldilocks NTT GFE/s (LDE 2^%d x %d, blow-up 2)" % (args.log_n, ncols),

@@ -99,6 +99,14 @@ int xlp_dev_fill(uint64_t* dst, uint64_t n, uint64_t seed, uint64_t start);
  * from (op codes: csrc/fri.hip field_op_kernel).  Host pointers.  Not part of the reference surface. */
 int xlp_field_op(uint64_t* out, const uint64_t* a, const uint64_t* b, uint64_t n, int op);
 
+/* Per-kernel timing of the extendPol fast path, measured with HIP events on the context's stream
+ * (the stream the kernels are launched on).  enable(1) clears and starts recording; read() synchronises
+ * and returns the summed milliseconds of {lde_top_dif, lde_mid, lde_top_dit} over `count` recorded
+ * column chunks.  Measurement aid for bench.py; the reference's analogue is TimerStart/TimerStopAndLog
+ * around STARK_STEP_n_LDE (src/starkpil/starks.cpp:49-55). */
+int xlp_profile_enable(int on);
+int xlp_profile_read(double ms_sum[3], uint64_t* count);
+
 /* Plain device memory helpers so a C++/cgo/ctypes host needs no HIP headers. */
 int xlp_dev_alloc(void** ptr, size_t bytes);
 int xlp_dev_free(void* ptr);

@@ -38,6 +38,8 @@ SIGNATURES = {
     "xlp_dev_transpose3": [_pu, _pu, _u64, _u32],
     "xlp_dev_fill": [_pu, _u64, _u64, _u64],
     "xlp_field_op": [_pu, _pu, _pu, _u64, C.c_int],
+    "xlp_profile_enable": [C.c_int],
+    "xlp_profile_read": [C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
     "xlp_dev_alloc": [C.POINTER(C.c_void_p), C.c_size_t],
     "xlp_dev_free": [_pu],
     "xlp_copy_h2d": [_pu, _pu, C.c_size_t],
@@ -99,6 +101,18 @@ def init(device=0):
 
 def sync():
     _ck(load().xlp_sync(), "xlp_sync")
+
+
+def profile_enable(on=True):
+    _ck(load().xlp_profile_enable(1 if on else 0), "xlp_profile_enable")
+
+
+def profile_read():
+    """-> ([ms_top_dif, ms_mid, ms_top_dit] summed, number of recorded LDE column chunks)"""
+    ms = (C.c_double * 3)()
+    cnt = C.c_uint64(0)
+    _ck(load().xlp_profile_read(ms, C.byref(cnt)), "xlp_profile_read")
+    return [ms[0], ms[1], ms[2]], cnt.value
 
 
 def use_torch_stream():

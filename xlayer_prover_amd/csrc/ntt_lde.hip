@@ -438,7 +438,13 @@ int dev_extend_fast(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ncols)
         p.col0 = (u32)col0;
         p.wc = (u32)(ncols - col0 < wc_max ? ncols - col0 : wc_max);
         p.B = p.A + n * p.wc;
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        if (ctx->profile) {
+            for (int i = 0; i < 4; i++) { XLP_HIP(hipEventCreate(&ev[i])); ctx->prof_events.push_back(ev[i]); }
+            XLP_HIP(hipEventRecord(ev[0], ctx->stream));
+        }
         if (launch_top_bt(ctx, p, BT, false)) return -1;
+        if (ctx->profile) XLP_HIP(hipEventRecord(ev[1], ctx->stream));
         {
             const u32 ncc = (p.wc + 3) / 4;
             const u64 grid = (u64)ncc << BT;
@@ -446,7 +452,9 @@ int dev_extend_fast(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ncols)
             hipLaunchKernelGGL(lde_mid, dim3((unsigned)grid), dim3(1024), lds, ctx->stream, p, BT);
             XLP_HIP(hipGetLastError());
         }
+        if (ctx->profile) XLP_HIP(hipEventRecord(ev[2], ctx->stream));
         if (launch_top_bt(ctx, p, BT, true)) return -1;
+        if (ctx->profile) XLP_HIP(hipEventRecord(ev[3], ctx->stream));
     }
     return 0;
 }

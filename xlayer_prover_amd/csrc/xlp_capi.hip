@@ -172,6 +172,32 @@ int xlp_dev_fill(uint64_t* dst, uint64_t n, uint64_t seed, uint64_t start)
     return dev_fill(&g_ctx, dst, n, seed, start);
 }
 
+int xlp_profile_enable(int on)
+{
+    if (ensure_init()) return -1;
+    XLP_HIP(hipStreamSynchronize(g_ctx.stream));
+    for (hipEvent_t e : g_ctx.prof_events) (void)hipEventDestroy(e);
+    g_ctx.prof_events.clear();
+    g_ctx.profile = on != 0;
+    return 0;
+}
+
+int xlp_profile_read(double ms_sum[3], uint64_t* count)
+{
+    if (ensure_init()) return -1;
+    XLP_HIP(hipStreamSynchronize(g_ctx.stream));
+    ms_sum[0] = ms_sum[1] = ms_sum[2] = 0;
+    const size_t n = g_ctx.prof_events.size() / 4;
+    for (size_t i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) {
+            float ms = 0;
+            XLP_HIP(hipEventElapsedTime(&ms, g_ctx.prof_events[4 * i + k], g_ctx.prof_events[4 * i + k + 1]));
+            ms_sum[k] += ms;
+        }
+    *count = n;
+    return 0;
+}
+
 int xlp_dev_alloc(void** ptr, size_t bytes)
 {
     if (ensure_init()) return -1;

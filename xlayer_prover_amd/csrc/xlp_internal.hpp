@@ -5,6 +5,7 @@
 #include <map>
 #include <string>
 #include <tuple>
+#include <vector>
 
 namespace xlp {
 
@@ -44,6 +45,9 @@ struct Ctx {
     void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[4] = {0, 0, 0, 0};
     bool inited = false;
+    // optional per-kernel timing of the LDE fast path (xlp_profile_*): HIP events on ctx->stream
+    bool profile = false;
+    std::vector<hipEvent_t> prof_events;   // 4 events per recorded LDE chunk
 };
 
 // Grow-only device scratch slots owned by the context.
