@@ -90,6 +90,9 @@ def sharded_commit(trace_local, n, n_ext, ncols, group=None, lde=None, merkle=No
     from . import capi
     world = dist.get_world_size(group)
     wc = trace_local.shape[1]
+    if lde is None or merkle is None or hash_pairs is None:
+        # kernels and torch's copies / collectives must be ordered: run the library on torch's current stream
+        capi.use_torch_stream()
     if lde is None:
         def lde(x):
             out = torch.empty((n_ext, wc), dtype=torch.int64, device=x.device)
