@@ -22,9 +22,14 @@
 #include "gl_field.hpp"
 #include "xlp_internal.hpp"
 #include "ntt_common.hpp"
+#include "ntt_lde_common.hpp"
 
 #ifndef XLP_ABL
-#define XLP_ABL 0   // ablation builds (tools/ablate.sh): 1 no twiddle loads, 2 +no global data traffic, 3 +no DFT, 4 +no twiddle muls
+#define XLP_ABL 0
+#endif
+#define XLP_NOLOAD (XLP_ABL == 2 || XLP_ABL == 3 || XLP_ABL == 4 || XLP_ABL == 5 || XLP_ABL == 9)
+#define XLP_NOSTORE (XLP_ABL == 2 || XLP_ABL == 3 || XLP_ABL == 4 || XLP_ABL == 5 || XLP_ABL == 8)
+#if 0   // ablation builds (tools/ablate.sh): 1 no twiddle loads, 2 +no global data traffic, 3 +no DFT, 4 +no twiddle muls
 #endif
 #if XLP_ABL == 4
 #define XLP_TWMUL(a, b) ((a) ^ (b))
@@ -32,49 +37,19 @@
 #define XLP_TWMUL(a, b) gl::mulc((a), (b))
 #endif
 
+#if XLP_ABL == 5
+#define XLP_SYNC() ((void)0)
+#else
+#define XLP_SYNC() __syncthreads()
+#endif
+
 namespace xlp {
-
-constexpr int LDE_MAX_COSETS = 8;
-
-struct LdeParams {
-    const u64* in;  u64 ld_in;     // input matrix [n][ld_in]
-    u64* out;       u64 ld_out;    // output matrix [n << e][ld_out]
-    u64* A;                        // scratch [n][wc]
-    u64* B;                        // scratch [2^e][n][wc]
-    u32 col0, wc;                  // column chunk [col0, col0 + wc)
-    u32 L, e;
-    const u64 *twi_bt, *twf_bt;    // in-tile twiddles of the top pass: w(BT)^-i / w(BT)^i
-    const u64 *twi_12, *twf_12;    // in-tile twiddles of the 12-bit pass
-    const u64 *cri_lo, *cri_hi;    // two-level powers of w(L)^-1
-    const u64 *crf_lo, *crf_hi;    // two-level powers of w(L)
-    const u64* tw2[LDE_MAX_COSETS];  // tw2[r][pos]: twiddle of the 2nd DIT round of lde_mid with the coset scale folded in
-    const u64* hk[LDE_MAX_COSETS];   // hk[r][j] = (g_r^(2^BT))^(256 j), j < 16
-    const u64* ur[LDE_MAX_COSETS];   // ur[r][j]   = g_r^j / N,       j  < 2^BT
-};
-
-template <int B>
-__device__ __forceinline__ u32 tile_natural_c(u32 tpos)
-{
-    constexpr int m = (B + 3) / 4, dtop = B - 4 * (m - 1);
-    if constexpr (m == 1) return tpos;
-    else if constexpr (m == 2) return (tpos >> 4) | ((tpos & 15) << dtop);
-    else return (tpos >> 8) | (((tpos >> 4) & 15) << dtop) | ((tpos & 15) << (dtop + 4));
-}
-
-// blocks b, b+8, b+16.. share an XCD and are co-resident: hand them consecutive tiles
-__device__ __forceinline__ u32 xcd_tile()
-{
-    const u32 bid = blockIdx.x, g = gridDim.x;
-    return (g >= 16 && (g & 7) == 0) ? (bid & 7) * (g >> 3) + (bid >> 3) : bid;
-}
 
 // One radix-2^D round over the tile digit at bit offset TP (compile-time geometry).
 // Written in explicit phases -- (1) all twiddle loads, (2) all data loads, (3) arithmetic,
 // (4) all stores -- because hipcc otherwise serialises "load; s_waitcnt vmcnt(0); use" per
 // element (a full L2 round trip each).  pre/post return per-position factors (LDS cross
 // twiddles) and are only evaluated when HAS_PRE / HAS_POST.
-struct NoFactor { __device__ __forceinline__ u64 operator()(u32) const { return 1; } };
-
 template <int B, int V, int TP, int D, bool DIT, bool INV, bool HAS_PRE, bool HAS_POST, class Load, class Store, class Pre, class Post, bool POSTW = false>
 __device__ __forceinline__ void fast_round(const u64* __restrict__ tw, Load load, Store store, Pre pre, Post post)
 {
@@ -101,7 +76,7 @@ __device__ __forceinline__ void fast_round(const u64* __restrict__ tw, Load load
         } else if constexpr (TP > 0) {
 #pragma unroll
             for (int j = 1; j < RAD; j++) {
-#if XLP_ABL >= 1 && XLP_ABL != 6
+#if XLP_ABL >= 1 && XLP_ABL != 6 && XLP_ABL != 7
                 twr[j] = 0x123456789ULL + j * low;   // ablation: no twiddle loads
 #else
                 twr[j] = tw[((u32)j * low) << TSHIFT];
@@ -152,19 +127,15 @@ __device__ __forceinline__ void fast_round(const u64* __restrict__ tw, Load load
     fast_round<B, V, TP, D, DIT, INV, false, false>(tw, load, store, NoFactor{}, NoFactor{});
 }
 
-__device__ __forceinline__ u64 two_level12(const u64* __restrict__ lo, const u64* __restrict__ hi, u64 e)
-{
-    const u64 t = lo[e & 4095];
-    const u64 eh = e >> 12;
-    return eh ? gl::mul(t, hi[eh]) : t;
-}
-
 // ------------------------------------------------------------------------ K1
 #ifndef XLP_TOPV
 #define XLP_TOPV 8
 #endif
+#ifndef XLP_WGT
+#define XLP_WGT 1024     // threads per workgroup of the LDE kernels (experiment knob)
+#endif
 template <int BT>
-__global__ __launch_bounds__(1024) void lde_top_dif(const LdeParams p)
+__global__ __launch_bounds__(XLP_WGT) void lde_top_dif(const LdeParams p)
 {
     constexpr int V = XLP_TOPV, m = (BT + 3) / 4, dtop = BT - 4 * (m - 1);
     extern __shared__ u64 smem[];
@@ -179,17 +150,25 @@ __global__ __launch_bounds__(1024) void lde_top_dif(const LdeParams p)
     auto gload = [&](u32 tpos, u32 v, u32) -> u64 {
         const u32 col = c + v < p.wc ? c + v : p.wc - 1;
         const u64 row = ((u64)tpos << 12) | lo;
-#if XLP_ABL >= 2 && XLP_ABL != 6
+#if XLP_NOLOAD
         return row * 0x9E3779B97F4A7C15ULL + col;
 #else
         return gl::canon(p.in[row * p.ld_in + p.col0 + col]);
 #endif
     };
+    #if XLP_ABL == 5
+    auto lload = [&](u32 tp_, u32 v, u32 lrow) -> u64 { return (u64)lrow * 0x9E3779B97F4A7C15ULL + v + tp_; };
+#else
     auto lload = [&](u32, u32 v, u32 lrow) -> u64 { return sm[lrow * V + v]; };
+#endif
+    #if XLP_ABL == 5
+    auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { if (val == 0x1234567ULL) sm[lrow * V + v] = val; };
+#else
     auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { sm[lrow * V + v] = val; };
+#endif
     auto gstore = [&](u32 tpos, u32 v, u64 val, u32) {
         const u64 row = ((u64)tpos << 12) | lo;
-#if XLP_ABL >= 2 && XLP_ABL != 6
+#if XLP_NOSTORE
         if (val == 0x1234567ULL) p.A[row * p.wc + c + v] = val;
 #else
         if (c + v < p.wc) p.A[row * p.wc + c + v] = val;
@@ -198,19 +177,19 @@ __global__ __launch_bounds__(1024) void lde_top_dif(const LdeParams p)
     auto crossf = [&](u32 tpos) -> u64 { return cross[tile_natural_c<BT>(tpos)]; };
     if constexpr (m == 2) {
         fast_round<BT, V, 4, dtop, false, true>(p.twi_bt, gload, lstore);
-        __syncthreads();
+        XLP_SYNC();
         fast_round<BT, V, 0, 4, false, true, false, true>(p.twi_bt, lload, gstore, NoFactor{}, crossf);
     } else {
         fast_round<BT, V, 8, dtop, false, true>(p.twi_bt, gload, lstore);
-        __syncthreads();
+        XLP_SYNC();
         fast_round<BT, V, 4, 4, false, true>(p.twi_bt, lload, lstore);
-        __syncthreads();
+        XLP_SYNC();
         fast_round<BT, V, 0, 4, false, true, false, true>(p.twi_bt, lload, gstore, NoFactor{}, crossf);
     }
 }
 
 // ------------------------------------------------------------------------ K2
-__global__ __launch_bounds__(1024) void lde_mid(const LdeParams p, u32 BT)
+__global__ __launch_bounds__(XLP_WGT) void lde_mid(const LdeParams p, u32 BT)
 {
     constexpr int V = 4, B = 12;
     extern __shared__ u64 sm[];
@@ -224,23 +203,36 @@ __global__ __launch_bounds__(1024) void lde_mid(const LdeParams p, u32 BT)
         const u64 row = ((u64)hi << 12) | tpos;
         return p.A[row * p.wc + col];
     };
+    #if XLP_ABL == 5
+    auto lload = [&](u32 tp_, u32 v, u32 lrow) -> u64 { return (u64)lrow * 0x9E3779B97F4A7C15ULL + v + tp_; };
+#else
     auto lload = [&](u32, u32 v, u32 lrow) -> u64 { return sm[lrow * V + v]; };
+#endif
+    #if XLP_ABL == 5
+    auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { if (val == 0x1234567ULL) sm[lrow * V + v] = val; };
+#else
     auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { sm[lrow * V + v] = val; };
+#endif
     // ---- inverse NTT over the low 12 bits (DIF); last round keeps its outputs in VGPRs
     fast_round<B, V, 8, 4, false, true>(p.twi_12, gload, lstore);
-    __syncthreads();
+    XLP_SYNC();
     fast_round<B, V, 4, 4, false, true>(p.twi_12, lload, lstore);
-    __syncthreads();
-    // thread's group in a TP = 0 round (1024 groups == 1024 threads): base = (tid >> 2) << 4, v = tid & 3
-    const u32 v = threadIdx.x & 3, base = (threadIdx.x >> 2) << 4;
-    u64 X[16];
-    {
+    XLP_SYNC();
+    // a thread's groups in a TP = 0 round: g = tid + i * T -> base = (g >> 2) << 4, v = g & 3  (T % 4 == 0)
+    constexpr int NGT = 1024 / XLP_WGT;
+    const u32 v = threadIdx.x & 3;
+    u32 base_[NGT];
+    u64 X[NGT][16];
+#pragma unroll
+    for (int i = 0; i < NGT; i++) {
+        base_[i] = ((threadIdx.x + i * XLP_WGT) >> 2) << 4;
+        const u32 base = base_[i];
         u64 x[16];
 #pragma unroll
         for (int j = 0; j < 16; j++) x[j] = sm[(lds_row(base) + j) * V + v];
         dft_regs<4>(x);
 #pragma unroll
-        for (int k = 0; k < 16; k++) X[k] = x[brev<4>((16 - k) % 16)];   // coefficient at tile position base + k
+        for (int k = 0; k < 16; k++) X[i][k] = x[brev<4>((16 - k) % 16)];   // coefficient at tile position base + k
     }
     const bool valid = c + v < p.wc;
     // ---- every coset: scale, forward NTT over the same 12 bits (DIT), -> B_r
@@ -251,19 +243,21 @@ __global__ __launch_bounds__(1024) void lde_mid(const LdeParams p, u32 BT)
     for (u32 r = 0; r < (1u << p.e); r++) {
         const u64* __restrict__ hk = p.hk[r];
         u64* __restrict__ Br = p.B + (u64)r * n * p.wc;
-        __syncthreads();   // previous users of the LDS tile are done
-        {
-            u64 x[16];
-            x[0] = X[0];
+        XLP_SYNC();   // previous users of the LDS tile are done
 #pragma unroll
-            for (int j = 1; j < 16; j++) x[j] = gl::mulc(X[j], hk[j]);
+        for (int i = 0; i < NGT; i++) {
+            const u32 base = base_[i];
+            u64 x[16];
+            x[0] = X[i][0];
+#pragma unroll
+            for (int j = 1; j < 16; j++) x[j] = gl::mulc(X[i][j], hk[j]);
             dft_regs<4>(x);
 #pragma unroll
             for (int k = 0; k < 16; k++) sm[(lds_row(base) + k) * V + v] = x[brev<4>(k)];
         }
-        __syncthreads();
+        XLP_SYNC();
         fast_round<B, V, 4, 4, true, false, false, false, decltype(lload), decltype(lstore), NoFactor, NoFactor, true>(p.tw2[r], lload, lstore, NoFactor{}, NoFactor{});
-        __syncthreads();
+        XLP_SYNC();
         auto gstore = [&](u32 tpos, u32 vv, u64 val, u32) {
             const u64 row = ((u64)hi << 12) | tpos;
             if (c + vv < p.wc) Br[row * p.wc + c + vv] = val;
@@ -275,7 +269,7 @@ __global__ __launch_bounds__(1024) void lde_mid(const LdeParams p, u32 BT)
 
 // ------------------------------------------------------------------------ K3
 template <int BT>
-__global__ __launch_bounds__(1024) void lde_top_dit(const LdeParams p)
+__global__ __launch_bounds__(XLP_WGT) void lde_top_dit(const LdeParams p)
 {
     constexpr int V = XLP_TOPV, m = (BT + 3) / 4, dtop = BT - 4 * (m - 1);
     extern __shared__ u64 smem[];
@@ -288,25 +282,33 @@ __global__ __launch_bounds__(1024) void lde_top_dit(const LdeParams p)
     const u64* __restrict__ ur = p.ur[r];
     for (u32 j = threadIdx.x; j < (1u << BT); j += blockDim.x)
         cross[j] = gl::mulc(two_level12(p.crf_lo, p.crf_hi, (u64)j * lo), ur[j]);
-    __syncthreads();
+    XLP_SYNC();
     const u32 c = cc * V;
     const u64 n = 1ull << p.L;
     const u64* __restrict__ Br = p.B + (u64)r * n * p.wc;
     auto gload = [&](u32 tpos, u32 v, u32) -> u64 {
         const u32 col = c + v < p.wc ? c + v : p.wc - 1;
         const u64 row = ((u64)tpos << 12) | lo;
-#if XLP_ABL >= 2 && XLP_ABL != 6
+#if XLP_NOLOAD
         return row * 0x9E3779B97F4A7C15ULL + col;
 #else
         return Br[row * p.wc + col];
 #endif
     };
     auto crossf = [&](u32 tpos) -> u64 { return cross[tile_natural_c<BT>(tpos)]; };
+    #if XLP_ABL == 5
+    auto lload = [&](u32 tp_, u32 v, u32 lrow) -> u64 { return (u64)lrow * 0x9E3779B97F4A7C15ULL + v + tp_; };
+#else
     auto lload = [&](u32, u32 v, u32 lrow) -> u64 { return sm[lrow * V + v]; };
+#endif
+    #if XLP_ABL == 5
+    auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { if (val == 0x1234567ULL) sm[lrow * V + v] = val; };
+#else
     auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { sm[lrow * V + v] = val; };
+#endif
     auto gstore = [&](u32 tpos, u32 v, u64 val, u32) {
         const u64 row = (((((u64)tpos << 12) | lo)) << p.e) | r;
-#if XLP_ABL >= 2 && XLP_ABL != 6
+#if XLP_NOSTORE
         if (val == 0x1234567ULL) p.out[row * p.ld_out + p.col0 + c + v] = val;
 #else
         if (c + v < p.wc) p.out[row * p.ld_out + p.col0 + c + v] = val;
@@ -314,13 +316,13 @@ __global__ __launch_bounds__(1024) void lde_top_dit(const LdeParams p)
     };
     if constexpr (m == 2) {
         fast_round<BT, V, 0, 4, true, false, true, false>(p.twf_bt, gload, lstore, crossf, NoFactor{});
-        __syncthreads();
+        XLP_SYNC();
         fast_round<BT, V, 4, dtop, true, false>(p.twf_bt, lload, gstore);
     } else {
         fast_round<BT, V, 0, 4, true, false, true, false>(p.twf_bt, gload, lstore, crossf, NoFactor{});
-        __syncthreads();
+        XLP_SYNC();
         fast_round<BT, V, 4, 4, true, false>(p.twf_bt, lload, lstore);
-        __syncthreads();
+        XLP_SYNC();
         fast_round<BT, V, 8, dtop, true, false>(p.twf_bt, lload, gstore);
     }
 }
@@ -343,7 +345,8 @@ static int launch_top(Ctx* ctx, const LdeParams& p, bool dit)
 {
     constexpr u32 V = XLP_TOPV;
     const u32 ncc = (p.wc + V - 1) / V;
-    const u32 threads = (1u << (BT - 4)) * V < 64 ? 64 : (1u << (BT - 4)) * V;
+    u32 threads = (1u << (BT - 4)) * V < 64 ? 64 : (1u << (BT - 4)) * V;
+    if (threads > XLP_WGT) threads = XLP_WGT;
     const size_t lds = ((size_t)((1u << BT) + (1u << BT) / 16 + 1) * V + (1u << BT)) * sizeof(u64);
     static bool attr_done = false;
     if (!attr_done) {
@@ -449,7 +452,7 @@ int dev_extend_fast(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ncols)
             const u32 ncc = (p.wc + 3) / 4;
             const u64 grid = (u64)ncc << BT;
             const size_t lds = (size_t)(4096 + 256 + 1) * 4 * sizeof(u64);
-            hipLaunchKernelGGL(lde_mid, dim3((unsigned)grid), dim3(1024), lds, ctx->stream, p, BT);
+            hipLaunchKernelGGL(lde_mid, dim3((unsigned)grid), dim3(XLP_WGT), lds, ctx->stream, p, BT);
             XLP_HIP(hipGetLastError());
         }
         if (ctx->profile) XLP_HIP(hipEventRecord(ev[2], ctx->stream));

@@ -88,6 +88,8 @@ int xlp_init(int device)
     hipDeviceProp_t prop;
     XLP_HIP(hipGetDeviceProperties(&prop, device));
     g_ctx.device = device;
+    g_ctx.ncu = (u32)prop.multiProcessorCount / 8 * 8;
+    if (g_ctx.ncu == 0) g_ctx.ncu = 8;
     XLP_HIP(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
     g_ctx.own_stream = true;
     if (ntt_init(&g_ctx)) return -1;

@@ -45,6 +45,7 @@ struct Ctx {
     void* scratch[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[4] = {0, 0, 0, 0};
     bool inited = false;
+    u32 ncu = 256;             // compute units of the bound device (persistent-kernel grid size)
     // optional per-kernel timing of the LDE fast path (xlp_profile_*): HIP events on ctx->stream
     bool profile = false;
     std::vector<hipEvent_t> prof_events;   // 4 events per recorded LDE chunk
