@@ -30,8 +30,11 @@ __device__ __forceinline__ u64 pow7(u64 a)
     return gl::mul(a3, a4);
 }
 
-// M * st, M[i][j] = MCIRC[(j-i) mod 12] (+8 on [0][0]); inputs "any", outputs "any".
-__device__ __forceinline__ void mds(u64 (&st)[12])
+// st <- M * st + c, M[i][j] = MCIRC[(j-i) mod 12] (+8 on [0][0]); inputs "any", outputs "any".
+// `c` (12 canonical words, wave-uniform -> SGPRs) is the NEXT round's constant vector: it is the
+// initial value of the multiply-add chains, so the per-round constant addition costs no instruction.
+template <bool ADDC>
+__device__ __forceinline__ void mds(u64 (&st)[12], const u64* __restrict__ c)
 {
     constexpr u32 MC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     u32 lo[12], hi[12];
@@ -40,36 +43,41 @@ __device__ __forceinline__ void mds(u64 (&st)[12])
 #pragma unroll
     for (int i = 0; i < 12; i++) {
         u64 L = 0, H = 0;
+        if constexpr (ADDC) { L = (u32)c[i]; H = c[i] >> 32; }
 #pragma unroll
         for (int j = 0; j < 12; j++) {
             const u32 m = MC[(j - i + 12) % 12] + ((i == 0 && j == 0) ? 8u : 0u);
-            L += (u64)lo[j] * m;   // < 2^32 * 49 * 12 < 2^42
+            L += (u64)lo[j] * m;   // < 2^32 * 49 * 12 + 2^32 < 2^43
             H += (u64)hi[j] * m;
         }
-        // value = L + H*2^32 = L + Hl*2^32 + Hh*2^64 ; Hh < 2^10
+        // value = L + H*2^32 = L + Hl*2^32 + Hh*2^64 ; Hh < 2^11
         const u64 Hl = (u64)(u32)H << 32, Hh = H >> 32;
         u64 lo64 = L + Hl;
-        const u64 c = lo64 < Hl;             // carry into 2^64
-        lo64 += (Hh + c) * gl::EPS;          // (Hh+c)*EPS < 2^43: may wrap once more
-        if (lo64 < (Hh + c) * gl::EPS) lo64 += gl::EPS;
+        const u64 cy = lo64 < Hl;            // carry into 2^64
+        lo64 += (Hh + cy) * gl::EPS;         // (Hh+cy)*EPS < 2^44: may wrap once more
+        if (lo64 < (Hh + cy) * gl::EPS) lo64 += gl::EPS;
         st[i] = lo64;
     }
 }
 
+// Round r: state already holds + C[r] (added by the previous round's linear layer).
 __device__ __forceinline__ void permute(u64 (&st)[12])
 {
-#pragma unroll 1
-    for (int r = 0; r < 30; r++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], POSEIDON_C[12 * r + i]);  // any + canon
+    for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], POSEIDON_C[i]);  // any + canon
+#pragma unroll 1
+    for (int r = 0; r < 29; r++) {
         if (r < 4 || r >= 26) {
 #pragma unroll
             for (int i = 0; i < 12; i++) st[i] = pow7(st[i]);
         } else {
             st[0] = pow7(st[0]);
         }
-        mds(st);
+        mds<true>(st, &POSEIDON_C[12 * (r + 1)]);
     }
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = pow7(st[i]);
+    mds<false>(st, nullptr);
 #pragma unroll
     for (int i = 0; i < 12; i++) st[i] = gl::canon(st[i]);
 }
