@@ -95,6 +95,22 @@ int xlp_dev_transpose3(uint64_t* dst, const uint64_t* src, uint64_t n, uint32_t 
 /* Synthetic trace: dst[i] = splitmix64(seed ^ (start + i)) mod p. */
 int xlp_dev_fill(uint64_t* dst, uint64_t n, uint64_t seed, uint64_t start);
 
+/* ---- row-scale helpers between the commit stages, device pointers ------------ */
+/* Polinomial::batchInverse / batchInverseParallel(res, src) -- polinomial.hpp:635-720, starks.cpp:358-359.
+ * n elements of dimension dim (1 or 3); res may equal src.  Inputs must be non-zero as in the
+ * reference's use (x - xi on the extended domain); a zero element yields zero. */
+int xlp_dev_batch_inverse(uint64_t* res, const uint64_t* src, uint64_t n, uint32_t dim);
+/* Polinomial::calculateZ(z, num, den) -- polinomial.hpp:586-607: n ext-3 elements each;
+ * z[0] = 1, z[i] = z[i-1] * num[i-1] / den[i-1]. */
+int xlp_dev_calculate_z(uint64_t* z, const uint64_t* num, const uint64_t* den, uint64_t n);
+/* Starks::evmap -- starks.cpp:556-669: evals[i] = sum_{k<n} L_i[k] * pol_i[(k << extend_bits) * row_stride_i],
+ * L_i = LpEv if prime else LEv (ext-3, n rows), pol_i of dimension 1 or 3 (mulAddElement_adim3,
+ * polinomial.hpp:722-744).  `entries` is a HOST array of nev descriptors whose `pol` are device pointers
+ * to (row 0, column) of the extended section; evals: nev x 3 device words. */
+typedef struct xlp_evmap_entry { const uint64_t* pol; uint64_t row_stride; uint32_t dim; uint32_t prime; } xlp_evmap_entry;
+int xlp_dev_evmap(uint64_t* evals, const uint64_t* LEv, const uint64_t* LpEv, uint64_t n, uint32_t extend_bits, uint32_t nev,
+                  const xlp_evmap_entry* entries);
+
 /* Test hook: out[i] = op(a[i], b[i]) using the device field functions the kernels are built
  * from (op codes: csrc/fri.hip field_op_kernel).  Host pointers.  Not part of the reference surface. */
 int xlp_field_op(uint64_t* out, const uint64_t* a, const uint64_t* b, uint64_t n, int op);

@@ -540,3 +540,71 @@ int orc_num_threads(void)
     return 1;
 #endif
 }
+
+/* ------------------------------------------------ "next" tier */
+/* Inverse in Fp[x]/(x^3 - x - 1): adjugate of the multiplication matrix
+ * [[a0,a2,a1],[a1,a0+a2,a1+a2],[a2,a1,a0+a2]] (columns a*1, a*x, a*x^2) over its determinant.
+ * Goldilocks3::inv as used by Polinomial::batchInverse (polinomial.hpp:698-720); inv(0) = 0. */
+void orc_inv3(u64 o[3], const u64 a_[3])
+{
+    u64 a0 = gl_canon(a_[0]), a1 = gl_canon(a_[1]), a2 = gl_canon(a_[2]);
+    u64 m00 = a0, m01 = a2, m02 = a1;
+    u64 m10 = a1, m11 = gl_add(a0, a2), m12 = gl_add(a1, a2);
+    u64 m20 = a2, m21 = a1, m22 = gl_add(a0, a2);
+    /* cofactors of the first row -> first column of the inverse (solves M b = e0) */
+    u64 c00 = gl_sub(gl_mul(m11, m22), gl_mul(m12, m21));
+    u64 c01 = gl_sub(gl_mul(m12, m20), gl_mul(m10, m22));   /* = -(m10 m22 - m12 m20) */
+    u64 c02 = gl_sub(gl_mul(m10, m21), gl_mul(m11, m20));
+    u64 det = gl_add(gl_add(gl_mul(m00, c00), gl_mul(m01, c01)), gl_mul(m02, c02));
+    u64 di = gl_inv(det);
+    /* b = adj(M) e0 / det ; adj(M)[i][0] = cofactor C[0][i] */
+    o[0] = gl_mul(c00, di); o[1] = gl_mul(c01, di); o[2] = gl_mul(c02, di);
+}
+
+/* Polinomial::batchInverse / batchInverseParallel (polinomial.hpp:635-720) for dim 3 (and dim 1):
+ * res[i] = 1 / src[i].  (The reference batches with Montgomery's trick; for non-zero inputs the
+ * results are the exact inverses, which is what is restated.  A zero input maps to zero.) */
+void orc_batch_inverse(u64 *res, const u64 *src, u64 n, unsigned dim)
+{
+#pragma omp parallel for schedule(static)
+    for (u64 i = 0; i < n; i++) {
+        if (dim == 3) orc_inv3(res + 3 * i, src + 3 * i);
+        else res[i] = gl_inv(gl_canon(src[i]));
+    }
+}
+
+/* Polinomial::calculateZ (polinomial.hpp:586-607): z[0] = 1, z[i] = z[i-1] * num[i-1] / den[i-1]. */
+void orc_calculate_z(u64 *z, const u64 *num, const u64 *den, u64 n)
+{
+    if (!n) return;
+    z[0] = 1; z[1] = 0; z[2] = 0;
+    for (u64 i = 1; i < n; i++) {
+        u64 di[3], t[3];
+        orc_inv3(di, den + 3 * (i - 1));
+        gl3_mul(t, num + 3 * (i - 1), di);
+        gl3_mul(z + 3 * i, z + 3 * (i - 1), t);
+    }
+}
+
+/* Starks::evmap (starks.cpp:556-669): evals[i] = sum_k L_i[k] * pol_i[(k << extend_bits) * stride_i + 0..dim_i),
+ * L_i = LpEv if prime_i else LEv (ext-3, N rows); mulAddElement_adim3 (polinomial.hpp:722-744). */
+void orc_evmap(u64 *evals, const u64 *LEv, const u64 *LpEv, u64 n, unsigned extend_bits, unsigned nev,
+               const u64 *const *pols, const u64 *strides, const unsigned *dims, const unsigned *primes)
+{
+    for (unsigned i = 0; i < nev; i++) {
+        u64 acc[3] = {0, 0, 0};
+        const u64 *L = primes[i] ? LpEv : LEv;
+        for (u64 k = 0; k < n; k++) {
+            const u64 *b = pols[i] + (k << extend_bits) * strides[i];
+            const u64 *a = L + 3 * k;
+            if (dims[i] == 1) {
+                for (int d = 0; d < 3; d++) acc[d] = gl_add(acc[d], gl_mul(a[d], b[0]));
+            } else {
+                u64 t[3];
+                gl3_mul(t, a, b);
+                for (int d = 0; d < 3; d++) acc[d] = gl_add(acc[d], t[d]);
+            }
+        }
+        memcpy(evals + 3 * i, acc, 24);
+    }
+}

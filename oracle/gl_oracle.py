@@ -46,6 +46,9 @@ def _load():
         "orc_transpose3": (None, [_pu64, _pu64, u64, C.c_uint]),
         "orc_fill": (None, [_pu64, u64, u64, u64]),
         "orc_num_threads": (C.c_int, []),
+        "orc_inv3": (None, [_pu64, _pu64]),
+        "orc_batch_inverse": (None, [_pu64, _pu64, u64, C.c_uint]),
+        "orc_calculate_z": (None, [_pu64, _pu64, _pu64, u64]),
         "orc_transcript_init": (None, [C.c_void_p]),
         "orc_transcript_put": (None, [C.c_void_p, _pu64, u64]),
         "orc_transcript_get1": (u64, [C.c_void_p]),
@@ -177,6 +180,45 @@ def fill(n, seed, start=0):
     if n:
         lib.orc_fill(dst, n, seed, start)
     return dst
+
+
+def inv3(a):
+    o = np.zeros(3, np.uint64)
+    lib.orc_inv3(o, _a(a))
+    return o
+
+
+def batch_inverse(src, dim=3):
+    src = _a(src).ravel()
+    out = np.zeros_like(src)
+    if src.size:
+        lib.orc_batch_inverse(out, src, src.size // dim, dim)
+    return out.reshape(-1, dim) if dim == 3 else out
+
+
+def calculate_z(num, den):
+    num, den = _a(num).ravel(), _a(den).ravel()
+    z = np.zeros_like(num)
+    if num.size:
+        lib.orc_calculate_z(z, num, den, num.size // 3)
+    return z.reshape(-1, 3)
+
+
+def evmap(LEv, LpEv, n, extend_bits, entries):
+    """entries: list of (ndarray section [rows, width], column, dim, prime)"""
+    nev = len(entries)
+    evals = np.zeros(3 * nev, np.uint64)
+    keep = [_a(e[0]) for e in entries]
+    ptrs = (C.c_void_p * nev)(*[k.ctypes.data + 8 * e[1] for k, e in zip(keep, entries)])
+    strides = _a([k.shape[1] for k in keep])
+    dims = np.ascontiguousarray([e[2] for e in entries], dtype=np.uint32)
+    primes = np.ascontiguousarray([1 if e[3] else 0 for e in entries], dtype=np.uint32)
+    f = lib.orc_evmap
+    f.restype = None
+    f.argtypes = [_pu64, _pu64, _pu64, u64, C.c_uint, C.c_uint, C.c_void_p, _pu64,
+                  np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS"), np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")]
+    f(evals, _a(LEv).ravel(), _a(LpEv).ravel(), n, extend_bits, nev, ptrs, strides, dims, primes)
+    return evals.reshape(nev, 3)
 
 
 def num_threads():

@@ -291,3 +291,64 @@ def test_gpu_hash_pairs_and_world1_commit(xlp, orc):
         assert (xlp.to_np(root) == orc.merkletree(ext, ncols, n_ext)[-4:]).all()
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------- row-scale helpers
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 1000, (1 << 14) + 7])
+def test_batch_inverse_vs_oracle(xlp, orc, n):
+    src = orc.fill(3 * n, 0x5EED0061).reshape(n, 3)
+    if n > 4:
+        src[2] = 0                       # a zero element maps to zero and does not poison its batch
+        src[3] = [0, 5, 0]
+    t = xlp.from_np(src.reshape(-1))
+    out = xlp.from_np(np.zeros(3 * n, np.uint64))
+    xlp.dev_batch_inverse(out, t, n, 3); xlp.sync()
+    got = xlp.to_np(out).reshape(n, 3)
+    assert (got == orc.batch_inverse(src, 3)).all()
+    for i in (0, n - 1):
+        assert list(orc.mul3(got[i], src[i])) == [1, 0, 0]
+    # in place + dim 1
+    xlp.dev_batch_inverse(t, t, n, 3); xlp.sync()
+    assert (xlp.to_np(t).reshape(n, 3) == got).all()
+    b = orc.fill(n, 0x5EED0062)
+    tb = xlp.from_np(b); xlp.dev_batch_inverse(tb, tb, n, 1); xlp.sync()
+    assert (xlp.to_np(tb) == orc.batch_inverse(b, 1)).all()
+
+
+@pytest.mark.parametrize("n", [1, 2, 9, 2048, 2049, 5000, (1 << 16) + 3])
+def test_calculate_z_vs_oracle(xlp, orc, n):
+    num = orc.fill(3 * n, 0x5EED0063).reshape(n, 3)
+    den = orc.fill(3 * n, 0x5EED0064).reshape(n, 3)
+    z = xlp.from_np(np.zeros(3 * n, np.uint64))
+    xlp.dev_calculate_z(z, xlp.from_np(num.reshape(-1)), xlp.from_np(den.reshape(-1)), n); xlp.sync()
+    assert (xlp.to_np(z).reshape(n, 3) == orc.calculate_z(num, den)).all()
+
+
+def test_calculate_z_closes_for_a_permutation(xlp, orc):
+    """grand-product property the reference asserts (polinomial.hpp:603-606): if den is a permutation of num,
+    z[n-1] * num[n-1] / den[n-1] == 1 -- at 2^20 rows, beyond what the sequential oracle does quickly"""
+    n = 1 << 20
+    num = orc.fill(3 * n, 0x5EED0065).reshape(n, 3)
+    den = np.roll(num, 12345, axis=0).copy()
+    z = xlp.from_np(np.zeros(3 * n, np.uint64))
+    xlp.dev_calculate_z(z, xlp.from_np(num.reshape(-1)), xlp.from_np(den.reshape(-1)), n); xlp.sync()
+    zl = xlp.to_np(z).reshape(n, 3)[-1]
+    chk = orc.mul3(zl, orc.mul3(num[-1], orc.inv3(den[-1])))
+    assert list(chk) == [1, 0, 0]
+    assert list(xlp.to_np(z)[:3]) == [1, 0, 0]
+
+
+def test_evmap_vs_oracle(xlp, orc):
+    nbits, eb = 10, 1
+    n, ne = 1 << nbits, 1 << (nbits + eb)
+    LEv = orc.fill(3 * n, 0x5EED0066).reshape(n, 3)
+    LpEv = orc.fill(3 * n, 0x5EED0067).reshape(n, 3)
+    secA = orc.fill(ne * 18, 0x5EED0068).reshape(ne, 18)     # a committed section of 18 base columns
+    secB = orc.fill(ne * 9, 0x5EED0069).reshape(ne, 9)       # 3 ext-3 columns
+    ents = [(secA, 0, 1, False), (secA, 17, 1, True), (secA, 5, 1, False), (secB, 0, 3, False), (secB, 6, 3, True), (secA, 5, 1, True)]
+    exp = orc.evmap(LEv, LpEv, n, eb, ents)
+    tA, tB = xlp.from_np(secA.reshape(-1)), xlp.from_np(secB.reshape(-1))
+    dev_ents = [((tA if e[0] is secA else tB), e[0].shape[1], e[1], e[2], e[3]) for e in ents]
+    ev = xlp.from_np(np.zeros(3 * len(ents), np.uint64))
+    xlp.dev_evmap(ev, xlp.from_np(LEv.reshape(-1)), xlp.from_np(LpEv.reshape(-1)), n, eb, dev_ents); xlp.sync()
+    assert (xlp.to_np(ev).reshape(-1, 3) == exp).all()

@@ -38,6 +38,9 @@ SIGNATURES = {
     "xlp_dev_transpose3": [_pu, _pu, _u64, _u32],
     "xlp_dev_fill": [_pu, _u64, _u64, _u64],
     "xlp_field_op": [_pu, _pu, _pu, _u64, C.c_int],
+    "xlp_dev_batch_inverse": [_pu, _pu, _u64, _u32],
+    "xlp_dev_calculate_z": [_pu, _pu, _pu, _u64],
+    "xlp_dev_evmap": [_pu, _pu, _pu, _u64, _u32, _u32, _pu],
     "xlp_profile_enable": [C.c_int],
     "xlp_profile_read": [C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
     "xlp_dev_alloc": [C.POINTER(C.c_void_p), C.c_size_t],
@@ -237,6 +240,26 @@ def dev_fri_fold(pol2, pol, bits, red, x, shift_inv):
 
 def dev_transpose3(dst, src, n, tbits):
     _ck(load().xlp_dev_transpose3(_dp(dst), _dp(src), n, tbits), "xlp_dev_transpose3")
+
+
+def dev_batch_inverse(res, src, n, dim=3):
+    _ck(load().xlp_dev_batch_inverse(_dp(res), _dp(src), n, dim), "xlp_dev_batch_inverse")
+
+
+def dev_calculate_z(z, num, den, n):
+    _ck(load().xlp_dev_calculate_z(_dp(z), _dp(num), _dp(den), n), "xlp_dev_calculate_z")
+
+
+class EvmapEntry(C.Structure):
+    _fields_ = [("pol", C.c_void_p), ("row_stride", C.c_uint64), ("dim", C.c_uint32), ("prime", C.c_uint32)]
+
+
+def dev_evmap(evals, LEv, LpEv, n, extend_bits, entries):
+    """entries: list of (section tensor [rows*width] on device, width, column, dim, prime)"""
+    arr = (EvmapEntry * len(entries))()
+    for i, (t, width, col, dim, prime) in enumerate(entries):
+        arr[i] = EvmapEntry(t.data_ptr() + 8 * col, width, dim, 1 if prime else 0)
+    _ck(load().xlp_dev_evmap(_dp(evals), _dp(LEv), _dp(LpEv), n, extend_bits, len(entries), C.cast(arr, C.c_void_p)), "xlp_dev_evmap")
 
 
 def to_np(t):

@@ -1,0 +1,269 @@
+// Row-scale helpers of Starks::genProof that sit between the commit stages:
+//   Polinomial::batchInverse / batchInverseParallel   src/starkpil/polinomial.hpp:635-720  (starks.cpp:358-359)
+//   Polinomial::calculateZ                            src/starkpil/polinomial.hpp:586-607  (starks.cpp:180-185)
+//   Starks::evmap                                     src/starkpil/starks.cpp:556-669      (mulAddElement_adim3 polinomial.hpp:722-744)
+// All are scan / reduce / map shapes over 2^23..2^24 rows of Fp or Fp^3 elements.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gl_field.hpp"
+#include "xlp_internal.hpp"
+#include "../../include/xlp_gl.h"
+
+namespace xlp {
+using gl::e3;
+using gl::u32;
+using gl::u64;
+
+__device__ __forceinline__ u64 inv1(u64 a)   // a^(p-2); inv(0) = 0
+{
+    // p - 2 = 0xFFFFFFFEFFFFFFFF : 32 ones, a zero, 31 ones... plain square-and-multiply (off the hot path)
+    u64 r = 1, b = a;
+    u64 e = gl::P - 2;
+#pragma unroll 1
+    for (int i = 0; i < 64; i++) {
+        if (e & 1) r = gl::mul(r, b);
+        b = gl::mul(b, b);
+        e >>= 1;
+    }
+    return gl::canon(r);
+}
+
+// Inverse in Fp[x]/(x^3 - x - 1): first column of adj(M_a) / det(M_a), M_a = matrix of "multiply by a".
+__device__ __forceinline__ e3 inv3(const e3& a)
+{
+    const u64 a0 = a.c[0], a1 = a.c[1], a2 = a.c[2];
+    const u64 m11 = gl::addc(a0, a2), m12 = gl::addc(a1, a2), m22 = m11;
+    const u64 c00 = gl::subc(gl::mulc(m11, m22), gl::mulc(m12, a1));
+    const u64 c01 = gl::subc(gl::mulc(m12, a2), gl::mulc(a1, m22));
+    const u64 c02 = gl::subc(gl::mulc(a1, a1), gl::mulc(m11, a2));
+    const u64 det = gl::addc(gl::addc(gl::mulc(a0, c00), gl::mulc(a2, c01)), gl::mulc(a1, c02));
+    const u64 di = inv1(det);
+    e3 r;
+    r.c[0] = gl::mulc(c00, di); r.c[1] = gl::mulc(c01, di); r.c[2] = gl::mulc(c02, di);
+    return r;
+}
+
+__device__ __forceinline__ e3 load3(const u64* p)
+{
+    e3 r; r.c[0] = gl::canon(p[0]); r.c[1] = gl::canon(p[1]); r.c[2] = gl::canon(p[2]); return r;
+}
+__device__ __forceinline__ void store3(u64* p, const e3& v) { p[0] = v.c[0]; p[1] = v.c[1]; p[2] = v.c[2]; }
+__device__ __forceinline__ e3 one3() { e3 r; r.c[0] = 1; r.c[1] = 0; r.c[2] = 0; return r; }
+__device__ __forceinline__ bool is_zero3(const e3& a) { return (a.c[0] | a.c[1] | a.c[2]) == 0; }
+
+// res[i] = 1 / src[i] (dim 3).  Each lane inverts CH consecutive elements with Montgomery's trick
+// (one field inversion per CH elements); zero elements are passed through as zero.
+constexpr int INV_CH = 4;
+__global__ __launch_bounds__(256) void batch_inverse3_kernel(u64* res, const u64* src, u64 n)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 i0 = t * INV_CH;
+    if (i0 >= n) return;
+    e3 a[INV_CH], pre[INV_CH];
+    bool z[INV_CH];
+    e3 acc = one3();
+#pragma unroll
+    for (int k = 0; k < INV_CH; k++) {
+        const bool ok = i0 + k < n;
+        a[k] = ok ? load3(src + 3 * (i0 + k)) : one3();
+        z[k] = is_zero3(a[k]);
+        if (z[k]) a[k] = one3();
+        pre[k] = acc;
+        acc = gl::mul3(acc, a[k]);
+    }
+    e3 inv = inv3(acc);
+#pragma unroll
+    for (int k = INV_CH - 1; k >= 0; k--) {
+        e3 r = gl::mul3(inv, pre[k]);
+        inv = gl::mul3(inv, a[k]);
+        if (z[k]) { r.c[0] = 0; r.c[1] = 0; r.c[2] = 0; }
+        if (i0 + k < n) store3(res + 3 * (i0 + k), r);
+    }
+}
+
+__global__ __launch_bounds__(256) void batch_inverse1_kernel(u64* res, const u64* src, u64 n)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) res[i] = inv1(gl::canon(src[i]));
+}
+
+// ------------------------------------------------------------- calculateZ = exclusive product scan
+// r[i] = num[i] / den[i];  z[0] = 1, z[i] = prod_{j<i} r[j].   Three phases: per-block inclusive scan of
+// SCAN_PER_BLOCK ratios (+ block product), recursive scan of the block products, apply.
+constexpr int SCAN_T = 256, SCAN_E = 8, SCAN_PER_BLOCK = SCAN_T * SCAN_E;
+
+// mode 0: v[i] = num[i] / den[i] ; mode 1: v[i] = num[i] (already ratios / block products)
+__global__ __launch_bounds__(SCAN_T) void scan3_block_kernel(u64* out_incl, u64* block_prod, const u64* num, const u64* den, u64 n, int mode)
+{
+    __shared__ u64 sh[SCAN_T][3];
+    const u64 base = (u64)blockIdx.x * SCAN_PER_BLOCK + (u64)threadIdx.x * SCAN_E;
+    e3 v[SCAN_E];
+    e3 acc = one3();
+#pragma unroll
+    for (int k = 0; k < SCAN_E; k++) {
+        const u64 i = base + k;
+        e3 x = one3();
+        if (i < n) {
+            x = load3(num + 3 * i);
+            if (mode == 0) x = gl::mul3(x, inv3(load3(den + 3 * i)));
+        }
+        acc = gl::mul3(acc, x);
+        v[k] = acc;                      // inclusive within the thread
+    }
+    sh[threadIdx.x][0] = acc.c[0]; sh[threadIdx.x][1] = acc.c[1]; sh[threadIdx.x][2] = acc.c[2];
+    __syncthreads();
+    // Hillis-Steele inclusive scan of the thread totals
+    for (int off = 1; off < SCAN_T; off <<= 1) {
+        e3 mine, other;
+        const bool act = (int)threadIdx.x >= off;
+        mine.c[0] = sh[threadIdx.x][0]; mine.c[1] = sh[threadIdx.x][1]; mine.c[2] = sh[threadIdx.x][2];
+        if (act) { other.c[0] = sh[threadIdx.x - off][0]; other.c[1] = sh[threadIdx.x - off][1]; other.c[2] = sh[threadIdx.x - off][2]; }
+        __syncthreads();
+        if (act) {
+            mine = gl::mul3(mine, other);
+            sh[threadIdx.x][0] = mine.c[0]; sh[threadIdx.x][1] = mine.c[1]; sh[threadIdx.x][2] = mine.c[2];
+        }
+        __syncthreads();
+    }
+    e3 pre = one3();
+    if (threadIdx.x > 0) { pre.c[0] = sh[threadIdx.x - 1][0]; pre.c[1] = sh[threadIdx.x - 1][1]; pre.c[2] = sh[threadIdx.x - 1][2]; }
+#pragma unroll
+    for (int k = 0; k < SCAN_E; k++) {
+        const u64 i = base + k;
+        if (i < n) store3(out_incl + 3 * i, gl::mul3(pre, v[k]));
+    }
+    if (threadIdx.x == SCAN_T - 1 && block_prod) {
+        block_prod[3 * blockIdx.x + 0] = sh[SCAN_T - 1][0];
+        block_prod[3 * blockIdx.x + 1] = sh[SCAN_T - 1][1];
+        block_prod[3 * blockIdx.x + 2] = sh[SCAN_T - 1][2];
+    }
+}
+
+// incl[i] *= prefix of the blocks before block(i)   (block_incl = inclusive scan of block products)
+__global__ __launch_bounds__(256) void scan3_apply_kernel(u64* incl, const u64* block_incl, u64 n)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 b = i / SCAN_PER_BLOCK;
+    if (b == 0) return;
+    store3(incl + 3 * i, gl::mul3(load3(incl + 3 * i), load3(block_incl + 3 * (b - 1))));
+}
+
+// z[0] = 1, z[i] = incl[i-1]
+__global__ __launch_bounds__(256) void scan3_shift_kernel(u64* z, const u64* incl, u64 n)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (i == 0) { z[0] = 1; z[1] = 0; z[2] = 0; return; }
+    z[3 * i] = incl[3 * (i - 1)]; z[3 * i + 1] = incl[3 * (i - 1) + 1]; z[3 * i + 2] = incl[3 * (i - 1) + 2];
+}
+
+static int scan3_inclusive(Ctx* ctx, u64* incl, const u64* num, const u64* den, u64 n, int mode, u64* scratch, u64 scratch_elems)
+{
+    const u64 nb = (n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;
+    if (3 * nb > scratch_elems && nb > 1) return xlp_fail("scan: scratch too small");
+    u64* bp = nb > 1 ? scratch : nullptr;
+    hipLaunchKernelGGL(scan3_block_kernel, dim3((unsigned)nb), dim3(SCAN_T), 0, ctx->stream, incl, bp, num, den, n, mode);
+    XLP_HIP(hipGetLastError());
+    if (nb > 1) {
+        u64* bincl = scratch + 3 * nb;
+        if (6 * nb > scratch_elems) return xlp_fail("scan: scratch too small");
+        if (scan3_inclusive(ctx, bincl, bp, nullptr, nb, 1, scratch + 6 * nb, scratch_elems - 6 * nb)) return -1;
+        hipLaunchKernelGGL(scan3_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, incl, bincl, n);
+        XLP_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+int dev_calculate_z(Ctx* ctx, u64* z, const u64* num, const u64* den, u64 n)
+{
+    if (!n) return 0;
+    u64* tmp = nullptr;
+    const u64 nb = (n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;
+    const u64 aux = 8 * (nb + 64) * 3;
+    if (ctx_scratch(ctx, (3 * n + aux) * sizeof(u64), 2, &tmp)) return -1;
+    if (scan3_inclusive(ctx, tmp, num, den, n, 0, tmp + 3 * n, aux)) return -1;
+    hipLaunchKernelGGL(scan3_shift_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, z, tmp, n);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
+int dev_batch_inverse(Ctx* ctx, u64* res, const u64* src, u64 n, u32 dim)
+{
+    if (!n) return 0;
+    if (dim == 3) {
+        const u64 thr = (n + INV_CH - 1) / INV_CH;
+        hipLaunchKernelGGL(batch_inverse3_kernel, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, ctx->stream, res, src, n);
+    } else if (dim == 1) {
+        hipLaunchKernelGGL(batch_inverse1_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, res, src, n);
+    } else return xlp_fail("batchInverse: dim must be 1 or 3");
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ evmap
+// evals[i] = sum_k L_i[k] * pol_i[(k << eb) * stride_i ...]: grid (chunks of rows) x (eval i);
+// per-block partial sums -> partial[chunk][i][3]; a second kernel adds the chunks.
+constexpr int EV_T = 256, EV_ROWS = 4096;
+struct EvEntryDev { const u64* pol; u64 stride; u32 dim; u32 prime; };
+
+__global__ __launch_bounds__(EV_T) void evmap_partial_kernel(u64* partial, const u64* LEv, const u64* LpEv, u64 n, u32 eb, const EvEntryDev* ents, u32 nev)
+{
+    __shared__ u64 sh[EV_T][3];
+    const u32 i = blockIdx.y;
+    const EvEntryDev e = ents[i];
+    const u64* L = e.prime ? LpEv : LEv;
+    const u64 k0 = (u64)blockIdx.x * EV_ROWS;
+    e3 acc; acc.c[0] = acc.c[1] = acc.c[2] = 0;
+    for (u64 k = k0 + threadIdx.x; k < k0 + EV_ROWS && k < n; k += EV_T) {
+        const e3 a = load3(L + 3 * k);
+        const u64* b = e.pol + (k << eb) * e.stride;
+        e3 t;
+        if (e.dim == 1) t = gl::mul3s(a, b[0]);
+        else t = gl::mul3(a, load3(b));
+        acc = gl::add3(acc, t);
+    }
+    sh[threadIdx.x][0] = acc.c[0]; sh[threadIdx.x][1] = acc.c[1]; sh[threadIdx.x][2] = acc.c[2];
+    __syncthreads();
+    for (int off = EV_T / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int d = 0; d < 3; d++) sh[threadIdx.x][d] = gl::addc(sh[threadIdx.x][d], sh[threadIdx.x + off][d]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        for (int d = 0; d < 3; d++) partial[((u64)blockIdx.x * nev + i) * 3 + d] = sh[0][d];
+}
+
+__global__ void evmap_final_kernel(u64* evals, const u64* partial, u64 nchunks, u32 nev)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nev * 3) return;
+    u64 s = 0;
+    for (u64 c = 0; c < nchunks; c++) s = gl::addc(s, partial[c * nev * 3 + t]);
+    evals[t] = s;
+}
+
+int dev_evmap(Ctx* ctx, u64* evals, const u64* LEv, const u64* LpEv, u64 n, u32 eb, u32 nev, const xlp_evmap_entry* entries)
+{
+    if (!nev) return 0;
+    if (!n) { XLP_HIP(hipMemsetAsync(evals, 0, (size_t)nev * 24, ctx->stream)); return 0; }
+    const u64 nchunks = (n + EV_ROWS - 1) / EV_ROWS;
+    u64* scratch = nullptr;
+    const size_t ent_bytes = ((size_t)nev * sizeof(EvEntryDev) + 255) / 256 * 256;
+    if (ctx_scratch(ctx, ent_bytes + nchunks * nev * 24, 2, &scratch)) return -1;
+    std::vector<EvEntryDev> h(nev);
+    for (u32 i = 0; i < nev; i++) {
+        if (entries[i].dim != 1 && entries[i].dim != 3) return xlp_fail("evmap: dim must be 1 or 3");
+        h[i] = EvEntryDev{entries[i].pol, entries[i].row_stride, entries[i].dim, entries[i].prime};
+    }
+    XLP_HIP(hipMemcpyAsync(scratch, h.data(), nev * sizeof(EvEntryDev), hipMemcpyHostToDevice, ctx->stream));
+    XLP_HIP(hipStreamSynchronize(ctx->stream));   // h goes out of scope
+    u64* partial = (u64*)((char*)scratch + ent_bytes);
+    hipLaunchKernelGGL(evmap_partial_kernel, dim3((unsigned)nchunks, nev), dim3(EV_T), 0, ctx->stream, partial, LEv, LpEv, n, eb,
+                       (const EvEntryDev*)scratch, nev);
+    hipLaunchKernelGGL(evmap_final_kernel, dim3((nev * 3 + 63) / 64), dim3(64), 0, ctx->stream, evals, partial, nchunks, nev);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace xlp

@@ -174,6 +174,24 @@ int xlp_dev_fill(uint64_t* dst, uint64_t n, uint64_t seed, uint64_t start)
     return dev_fill(&g_ctx, dst, n, seed, start);
 }
 
+int xlp_dev_batch_inverse(uint64_t* res, const uint64_t* src, uint64_t n, uint32_t dim)
+{
+    if (ensure_init()) return -1;
+    return dev_batch_inverse(&g_ctx, res, src, n, dim);
+}
+int xlp_dev_calculate_z(uint64_t* z, const uint64_t* num, const uint64_t* den, uint64_t n)
+{
+    if (ensure_init()) return -1;
+    return dev_calculate_z(&g_ctx, z, num, den, n);
+}
+int xlp_dev_evmap(uint64_t* evals, const uint64_t* LEv, const uint64_t* LpEv, uint64_t n, uint32_t extend_bits, uint32_t nev,
+                  const xlp_evmap_entry* entries)
+{
+    if (ensure_init()) return -1;
+    if (nev && !entries) return xlp_fail("xlp_dev_evmap: null entries");
+    return dev_evmap(&g_ctx, evals, LEv, LpEv, n, extend_bits, nev, entries);
+}
+
 int xlp_profile_enable(int on)
 {
     if (ensure_init()) return -1;

@@ -6,6 +6,7 @@
 #include <string>
 #include <tuple>
 #include <vector>
+#include "../../include/xlp_gl.h"
 
 namespace xlp {
 
@@ -76,5 +77,10 @@ int dev_fri_fold(Ctx* ctx, u64* pol2, const u64* pol, u32 bits, u32 red, const u
 int dev_transpose3(Ctx* ctx, u64* dst, const u64* src, u64 n, u32 tbits);
 int dev_fill(Ctx* ctx, u64* dst, u64 n, u64 seed, u64 start);
 int dev_field_op(Ctx* ctx, u64* out, const u64* a, const u64* b, u64 n, int op);
+
+// polinomial.hip
+int dev_batch_inverse(Ctx* ctx, u64* res, const u64* src, u64 n, u32 dim);
+int dev_calculate_z(Ctx* ctx, u64* z, const u64* num, const u64* den, u64 n);
+int dev_evmap(Ctx* ctx, u64* evals, const u64* LEv, const u64* LpEv, u64 n, u32 eb, u32 nev, const xlp_evmap_entry* entries);
 
 }  // namespace xlp
