@@ -102,6 +102,16 @@ def test_ntt_vs_oracle_widths(xlp, orc, lg, ncols):
     assert (xlp.ntt(src, n, ncols, inverse=True) == orc.ntt(src, n, ncols, inverse=True)).all()
 
 
+@pytest.mark.parametrize("lg,ncols", [(17, 1), (17, 3), (18, 5), (19, 8), (20, 6), (21, 2), (17, 70)])
+def test_ntt_fast_path_vs_oracle(xlp, orc, lg, ncols):
+    """two-kernel stand-alone NTT / INTT path (2^17..2^23 points), incl. in place"""
+    n = 1 << lg
+    src = edge_matrix(orc, n, ncols, 0x5EED0071 + lg)
+    assert (xlp.ntt(src, n, ncols) == orc.ntt(src, n, ncols)).all()
+    buf = src.copy()
+    assert (xlp.ntt(buf, n, ncols, inverse=True, inplace=True) == orc.ntt(src, n, ncols, inverse=True)).all()
+
+
 def test_ntt_inplace_and_roundtrip(xlp, orc):
     n, ncols = 1 << 14, 3
     src = orc.fill(n * ncols, 77).reshape(n, ncols)

@@ -391,6 +391,7 @@ int dev_ntt(Ctx* ctx, u64* dst, const u64* src, u64 n, u64 ncols, int inverse)
         XLP_HIP(hipGetLastError());
         return 0;
     }
+    if (ntt_fast_supported(L, ncols)) return dev_ntt_fast(ctx, dst, src, L, ncols, inverse);
     Plan pl = make_plan(L);
     u64 root = host_w(L);
     if (inverse) root = hgl::inv(root);

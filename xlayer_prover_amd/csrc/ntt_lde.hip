@@ -134,7 +134,7 @@ __device__ __forceinline__ void fast_round(const u64* __restrict__ tw, Load load
 #ifndef XLP_WGT
 #define XLP_WGT 1024     // threads per workgroup of the LDE kernels (experiment knob)
 #endif
-template <int BT>
+template <int BT, bool INV = true>
 __global__ __launch_bounds__(XLP_WGT) void lde_top_dif(const LdeParams p)
 {
     constexpr int V = XLP_TOPV, m = (BT + 3) / 4, dtop = BT - 4 * (m - 1);
@@ -176,15 +176,15 @@ __global__ __launch_bounds__(XLP_WGT) void lde_top_dif(const LdeParams p)
     };
     auto crossf = [&](u32 tpos) -> u64 { return cross[tile_natural_c<BT>(tpos)]; };
     if constexpr (m == 2) {
-        fast_round<BT, V, 4, dtop, false, true>(p.twi_bt, gload, lstore);
+        fast_round<BT, V, 4, dtop, false, INV>(p.twi_bt, gload, lstore);
         XLP_SYNC();
-        fast_round<BT, V, 0, 4, false, true, false, true>(p.twi_bt, lload, gstore, NoFactor{}, crossf);
+        fast_round<BT, V, 0, 4, false, INV, false, true>(p.twi_bt, lload, gstore, NoFactor{}, crossf);
     } else {
-        fast_round<BT, V, 8, dtop, false, true>(p.twi_bt, gload, lstore);
+        fast_round<BT, V, 8, dtop, false, INV>(p.twi_bt, gload, lstore);
         XLP_SYNC();
-        fast_round<BT, V, 4, 4, false, true>(p.twi_bt, lload, lstore);
+        fast_round<BT, V, 4, 4, false, INV>(p.twi_bt, lload, lstore);
         XLP_SYNC();
-        fast_round<BT, V, 0, 4, false, true, false, true>(p.twi_bt, lload, gstore, NoFactor{}, crossf);
+        fast_round<BT, V, 0, 4, false, INV, false, true>(p.twi_bt, lload, gstore, NoFactor{}, crossf);
     }
 }
 
@@ -265,6 +265,44 @@ __global__ __launch_bounds__(XLP_WGT) void lde_mid(const LdeParams p, u32 BT)
         fast_round<B, V, 8, 4, true, false>(p.twf_12, lload, gstore);
     }
     (void)valid; (void)BT;
+}
+
+// ---------------------------------------------------------- stand-alone NTT, bottom pass
+// Second pass of a natural-order NTT / INTT of size 2^(BT+12): DIF over the low 12 bits of one
+// (k1, 4 columns) tile of A, outputs written to their natural rows k1 + 2^BT * k2 (x final_scale).
+template <bool INV>
+__global__ __launch_bounds__(XLP_WGT) void ntt_bot_dif(const LdeParams p, u32 BT, u64 final_scale)
+{
+    constexpr int V = 4, B = 12;
+    extern __shared__ u64 sm[];
+    const u32 ncc = (p.wc + V - 1) / V;
+    const u32 tile = xcd_tile();
+    const u32 cc = tile % ncc, hi = tile / ncc;
+    const u32 c = cc * V;
+    // natural index of the top tile position `hi` (run-time BT: digits dtop,4,4 from the top)
+    const u32 m = (BT + 3) / 4, dtop = BT - 4 * (m - 1);
+    u32 k1 = hi >> (BT - dtop);
+    {
+        u32 shift = dtop;
+        for (u32 r = 1; r < m; r++) { k1 |= ((hi >> (4 * (m - 1 - r))) & 15) << shift; shift += 4; }
+    }
+    auto gload = [&](u32 tpos, u32 v, u32) -> u64 {
+        const u32 col = c + v < p.wc ? c + v : p.wc - 1;
+        const u64 row = ((u64)hi << 12) | tpos;
+        return p.A[row * p.wc + col];
+    };
+    auto lload = [&](u32, u32 v, u32 lrow) -> u64 { return sm[lrow * V + v]; };
+    auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { sm[lrow * V + v] = val; };
+    auto gstore = [&](u32 tpos, u32 v, u64 val, u32) {
+        const u64 row = (u64)k1 + ((u64)tile_natural_c<B>(tpos) << BT);
+        if (final_scale != 1) val = gl::mulc(val, final_scale);
+        if (c + v < p.wc) p.out[row * p.ld_out + p.col0 + c + v] = val;
+    };
+    fast_round<B, V, 8, 4, false, INV>(p.twi_12, gload, lstore);
+    XLP_SYNC();
+    fast_round<B, V, 4, 4, false, INV>(p.twi_12, lload, lstore);
+    XLP_SYNC();
+    fast_round<B, V, 0, 4, false, INV>(p.twi_12, lload, gstore);
 }
 
 // ------------------------------------------------------------------------ K3
@@ -377,6 +415,87 @@ static int launch_top_bt(Ctx* ctx, const LdeParams& p, u32 BT, bool dit)
         case 11: return launch_top<11>(ctx, p, dit);
         default: return xlp_fail("lde fast path: unsupported size");
     }
+}
+
+template <int BT>
+static int launch_top_fwd(Ctx* ctx, const LdeParams& p)
+{
+    constexpr u32 V = XLP_TOPV;
+    const u32 ncc = (p.wc + V - 1) / V;
+    u32 threads = (1u << (BT - 4)) * V < 64 ? 64 : (1u << (BT - 4)) * V;
+    if (threads > XLP_WGT) threads = XLP_WGT;
+    const size_t lds = ((size_t)((1u << BT) + (1u << BT) / 16 + 1) * V + (1u << BT)) * sizeof(u64);
+    static bool attr_done = false;
+    if (!attr_done) {
+        XLP_HIP(hipFuncSetAttribute((const void*)lde_top_dif<BT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((lde_top_dif<BT, false>), dim3((unsigned)((u64)ncc << 12)), dim3(threads), lds, ctx->stream, p);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
+bool ntt_fast_supported(u32 L, u64 ncols) { return L >= 17 && L <= 23 && ncols >= 1; }
+
+// Stand-alone natural-order NTT / INTT, 2^17..2^23 points: top pass (lde_top_dif: NTT over the top BT
+// bits + cross twiddle) into scratch, bottom pass (ntt_bot_dif) to natural rows.  dst may alias src.
+int dev_ntt_fast(Ctx* ctx, u64* dst, const u64* src, u32 L, u64 ncols, int inverse)
+{
+    const u32 BT = L - 12;
+    const u64 n = 1ull << L;
+    LdeParams p{};
+    p.in = src; p.ld_in = ncols; p.out = dst; p.ld_out = ncols; p.L = L; p.e = 0;
+    u64 wn = host_w(L), wbt = host_w(BT), w12 = host_w(12);
+    if (inverse) { wn = hgl::inv(wn); wbt = hgl::inv(wbt); w12 = hgl::inv(w12); }
+    const u64* dummy;
+    // the kernels read their tables through the "inverse" slots; direction is the INV template flag
+    if (get_pow_tables(ctx, BT, wbt, 1, &p.twi_bt, &dummy)) return -1;
+    if (get_pow_tables(ctx, 12, w12, 1, &p.twi_12, &dummy)) return -1;
+    if (get_pow_tables(ctx, L, wn, 1, &p.cri_lo, &p.cri_hi)) return -1;
+    const u32 wc_max = ncols < 64 ? (u32)ncols : 64;
+    // dst may alias src and the bottom pass scatters rows: a whole chunk is transformed into scratch first,
+    // and every chunk's top pass must have read src before any bottom pass writes dst -> two sweeps.
+    u64* scratch = nullptr;
+    const u64 nchunks = (ncols + wc_max - 1) / wc_max;
+    if (ctx_scratch(ctx, (size_t)n * wc_max * nchunks * sizeof(u64), 1, &scratch)) return -1;
+    static bool attr = false;
+    if (!attr) {
+        XLP_HIP(hipFuncSetAttribute((const void*)ntt_bot_dif<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        XLP_HIP(hipFuncSetAttribute((const void*)ntt_bot_dif<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    for (int sweep = 0; sweep < 2; sweep++) {
+        for (u64 ci = 0; ci < nchunks; ci++) {
+            p.col0 = (u32)(ci * wc_max);
+            p.wc = (u32)(ncols - p.col0 < wc_max ? ncols - p.col0 : wc_max);
+            p.A = scratch + ci * n * wc_max;
+            if (sweep == 0) {
+                int rc;
+                if (inverse) rc = launch_top_bt(ctx, p, BT, false);
+                else {
+                    switch (BT) {
+                        case 5: rc = launch_top_fwd<5>(ctx, p); break;
+                        case 6: rc = launch_top_fwd<6>(ctx, p); break;
+                        case 7: rc = launch_top_fwd<7>(ctx, p); break;
+                        case 8: rc = launch_top_fwd<8>(ctx, p); break;
+                        case 9: rc = launch_top_fwd<9>(ctx, p); break;
+                        case 10: rc = launch_top_fwd<10>(ctx, p); break;
+                        default: rc = launch_top_fwd<11>(ctx, p); break;
+                    }
+                }
+                if (rc) return -1;
+            } else {
+                const u32 ncc = (p.wc + 3) / 4;
+                const u64 grid = (u64)ncc << BT;
+                const size_t lds = (size_t)(4096 + 256 + 1) * 4 * sizeof(u64);
+                const u64 fs = inverse ? hgl::inv(n % hgl::P) : 1;
+                if (inverse) hipLaunchKernelGGL(ntt_bot_dif<true>, dim3((unsigned)grid), dim3(XLP_WGT), lds, ctx->stream, p, BT, fs);
+                else hipLaunchKernelGGL(ntt_bot_dif<false>, dim3((unsigned)grid), dim3(XLP_WGT), lds, ctx->stream, p, BT, fs);
+                XLP_HIP(hipGetLastError());
+            }
+        }
+    }
+    return 0;
 }
 
 bool lde_fast_supported(u32 L, u32 e, u64 ncols)

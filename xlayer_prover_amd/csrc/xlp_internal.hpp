@@ -64,6 +64,8 @@ int dev_extend(Ctx* ctx, u64* out, const u64* in, u64 n_ext, u64 n, u64 ncols, u
 
 // ntt_lde.hip (three-kernel fast path of extendPol)
 bool lde_fast_supported(u32 L, u32 e, u64 ncols);
+bool ntt_fast_supported(u32 L, u64 ncols);
+int dev_ntt_fast(Ctx* ctx, u64* dst, const u64* src, u32 L, u64 ncols, int inverse);
 int dev_extend_fast(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ncols);
 
 // poseidon.hip
