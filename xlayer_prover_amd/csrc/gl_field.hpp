@@ -126,24 +126,43 @@ __device__ __forceinline__ u64 mul(u64 a, u64 b)
 __device__ __forceinline__ u64 sqr(u64 a) { return mul(a, a); }
 __device__ __forceinline__ u64 mulc(u64 a, u64 b) { return canon(mul(a, b)); }
 
-// any * 2^K (compile-time 0 <= K < 96) -> any.   K = 32q + r:
-//   Y = a << r = (y2:y1:y0);  a*2^K = Y * 2^(32q);  2^64 = EPS, 2^96 = -1, 2^128 = -2^32.
+// canon(v) for a 65-bit value v = carry * 2^64 + r known to be < 2p:  (carry || r >= p) ? r + EPS : r
+__device__ __forceinline__ u64 canon65(u64 r, bool carry)
+{
+    u32 c0, c1;
+    u32 tlo = __builtin_addc((u32)r, 0xFFFFFFFFu, 0u, &c0);
+    u32 thi = __builtin_addc((u32)(r >> 32), 0u, c0, &c1);
+    opaque(tlo); opaque(thi);
+    return (carry || c1) ? pack(tlo, thi) : r;
+}
+
+// any * 2^K (compile-time 0 <= K < 96) -> CANONICAL.   K = 32q + r, Y = a << r = (y2:y1:y0) (96 bits):
+//   a * 2^K = Y * 2^(32q), reduced with 2^64 = EPS, 2^96 = -1, 2^128 = -2^32.
+// Written with 64-bit shifts and v_mad_u64_u32 (one instruction each on gfx950, all half rate like
+// the 32-bit carry ops they replace).
 template <int K>
 __device__ __forceinline__ u64 mul_pow2c(u64 a)
 {
     static_assert(K >= 0 && K < 96, "shift out of range");
-    if constexpr (K == 0) return a;
+    if constexpr (K == 0) return canon(a);
     constexpr int q = K / 32, r = K % 32;
-    const u32 x0 = (u32)a, x1 = (u32)(a >> 32);
-    u32 y0, y1, y2;
-    if constexpr (r == 0) { y0 = x0; y1 = x1; y2 = 0; }
-    else { y0 = x0 << r; y1 = (x1 << r) | (x0 >> (32 - r)); y2 = x1 >> (32 - r); }
-    if constexpr (q == 0) return reduce128(pack(y0, y1), (u64)y2);            // (y1:y0) + y2*EPS
-    else if constexpr (q == 1) return reduce128(pack(0u, y0), pack(y1, y2));  // (y0:0) + y1*EPS - y2
-    else {
-        // y0*2^64 + y1*2^96 + y2*2^128 = y0*EPS - (y2:y1)
-        const u64 t = (u64)y0 * 0xFFFFFFFFu;   // canon (<= 2^64 - 2^33 + 1 < p)
-        return subc(t, canon(pack(y1, y2)));
+    if constexpr (q == 0) {
+        // (y1:y0) + y2 * EPS   < 2^64 + 2^(32+r) < 2p
+        const u64 z = a << r;
+        const u32 y2 = (u32)(a >> (64 - r));
+        const u64 s = z + (u64)y2 * 0xFFFFFFFFu;
+        return canon65(s, s < z);
+    } else if constexpr (q == 2) {
+        // y0 * EPS - (y2:y1) ; both canonical (y0*EPS <= 2^64 - 2^33 + 1, (y2:y1) < 2^63)
+        const u32 y0 = (u32)a << r;                    // r == 0: y0 = a_lo
+        const u64 w = r ? a >> (32 - r) : a >> 32;     // (y2:y1)
+        const u64 t = (u64)y0 * 0xFFFFFFFFu;
+        return subc(t, w);
+    } else {
+        // (y0:0) + y1 * EPS - y2 = reduce128(lo = y0 << 32, hi = (y2:y1))
+        const u32 y0 = (u32)a << r;
+        const u64 w = r ? a >> (32 - r) : a >> 32;
+        return canon(reduce128((u64)y0 << 32, w));
     }
 }
 // run-time shift (used off the hot path only)

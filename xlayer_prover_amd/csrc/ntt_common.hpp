@@ -27,7 +27,7 @@ __device__ __forceinline__ void bfly(u64 (&x)[1 << D])
     x[i0] = gl::addc(a, b);
     const u64 d = gl::subc(a, b);
     if constexpr (sh == 0) x[i1] = d;
-    else x[i1] = gl::canon(gl::mul_pow2c<sh>(d));
+    else x[i1] = gl::mul_pow2c<sh>(d);   // canonical
 }
 template <int D, int T, int IDX>
 __device__ __forceinline__ void stage_rec(u64 (&x)[1 << D])
