@@ -362,3 +362,53 @@ def test_evmap_vs_oracle(xlp, orc):
     ev = xlp.from_np(np.zeros(3 * len(ents), np.uint64))
     xlp.dev_evmap(ev, xlp.from_np(LEv.reshape(-1)), xlp.from_np(LpEv.reshape(-1)), n, eb, dev_ents); xlp.sync()
     assert (xlp.to_np(ev).reshape(-1, 3) == exp).all()
+
+
+# ---------------------------------------------------------------- full-size properties
+def test_ntt_2p24_generic_path_roundtrip_and_column(xlp, orc):
+    """largest transform of a zkEVM proof (q polynomial, starks.cpp:262,285): 2^24 x 3, device resident:
+    INTT(NTT(x)) == x on everything, one whole column against the oracle"""
+    import torch
+    n, ncols = 1 << 24, 3
+    src = torch.empty(n * ncols, dtype=torch.int64, device="cuda")
+    xlp.dev_fill(src, 0x5EED0081, 0)
+    f = torch.empty_like(src); b = torch.empty_like(src)
+    xlp.dev_ntt(f, src, n, ncols, inverse=False)
+    xlp.dev_ntt(b, f, n, ncols, inverse=True)
+    xlp.sync()
+    assert torch.equal(b, src)
+    h_src = xlp.to_np(src).reshape(n, ncols)
+    col = 1
+    exp = orc.ntt(h_src[:, col].copy(), n, 1).reshape(-1)
+    assert (xlp.to_np(f).reshape(n, ncols)[:, col] == exp).all()
+
+
+def test_merkle_large_subtree_property(xlp, orc):
+    """2^22 x 8 tree (device resident): (a) sampled leaves and their paths verify against the root with the oracle,
+    (b) the root equals the tree over the four quarter-trees' roots (perfect binary tree over natural row order --
+    the property the multi-GPU cap assembly relies on)"""
+    import torch
+    h, w = 1 << 22, 8
+    src = torch.empty(h * w, dtype=torch.int64, device="cuda")
+    xlp.dev_fill(src, 0x5EED0082, 0)
+    nodes = torch.empty((2 * h - 1) * 4, dtype=torch.int64, device="cuda")
+    xlp.dev_merkle(nodes, src, w, h)
+    q = h // 4
+    qroots = []
+    for i in range(4):
+        qn = torch.empty((2 * q - 1) * 4, dtype=torch.int64, device="cuda")
+        xlp.dev_merkle(qn, src[i * q * w:(i + 1) * q * w], w, q)
+        xlp.sync()
+        qroots.append(xlp.to_np(qn[-4:]))
+    xlp.sync()
+    root = xlp.to_np(nodes[-4:])
+    l = [orc.perm(list(qroots[0]) + list(qroots[1]) + [0] * 4)[:4], orc.perm(list(qroots[2]) + list(qroots[3]) + [0] * 4)[:4]]
+    assert list(orc.perm(list(l[0]) + list(l[1]) + [0] * 4)[:4]) == list(root)
+    h_nodes = xlp.to_np(nodes)
+    for idx in (0, 1, 123456, h - 1):
+        row = orc.fill(w, 0x5EED0082, idx * w)
+        assert list(h_nodes[4 * idx:4 * idx + 4]) == list(orc.linear_hash(row))
+        sib, off, cnt, i = [], 0, h, idx
+        while cnt > 1:
+            sib.append(h_nodes[off + (i ^ 1) * 4: off + (i ^ 1) * 4 + 4]); off += 4 * cnt; cnt //= 2; i >>= 1
+        assert list(orc.merkle_root_from_path(row, np.concatenate(sib), idx)) == list(root)
