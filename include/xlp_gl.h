@@ -103,6 +103,10 @@ int xlp_dev_batch_inverse(uint64_t* res, const uint64_t* src, uint64_t n, uint32
 /* Polinomial::calculateZ(z, num, den) -- polinomial.hpp:586-607: n ext-3 elements each;
  * z[0] = 1, z[i] = z[i-1] * num[i-1] / den[i-1]. */
 int xlp_dev_calculate_z(uint64_t* z, const uint64_t* num, const uint64_t* den, uint64_t n);
+/* Polinomial::calculateH1H2_opt1 / _opt3(h1, h2, fPol, tPol, ...) -- polinomial.hpp:349-585, starks.cpp:108-125.
+ * n elements of dimension dim (1 or 3) each, dense.  Fails ("number not included") if a value of f does not
+ * occur in t (the reference calls exitProcess()). */
+int xlp_dev_calculate_h1h2(uint64_t* h1, uint64_t* h2, const uint64_t* f, const uint64_t* t, uint64_t n, uint32_t dim);
 /* Starks::evmap -- starks.cpp:556-669: evals[i] = sum_{k<n} L_i[k] * pol_i[(k << extend_bits) * row_stride_i],
  * L_i = LpEv if prime else LEv (ext-3, n rows), pol_i of dimension 1 or 3 (mulAddElement_adim3,
  * polinomial.hpp:722-744).  `entries` is a HOST array of nev descriptors whose `pol` are device pointers

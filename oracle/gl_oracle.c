@@ -608,3 +608,51 @@ void orc_evmap(u64 *evals, const u64 *LEv, const u64 *LpEv, u64 n, unsigned exte
         memcpy(evals + 3 * i, acc, 24);
     }
 }
+
+/* Polinomial::calculateH1H2_opt1 / _opt3 (polinomial.hpp:349-585), dim = 1 or 3.
+ * Every value of f must occur in t.  Each t index starts with count 1; every f element adds 1 to the
+ * LAST index of t holding its value (the reference's hash chains overwrite the stored index, :378,:496);
+ * the sequence "t[id] repeated count[id] times, id ascending" (length 2n) is dealt alternately to h1, h2.
+ * Returns 0, or 1 if some f value is missing from t (the reference calls exitProcess()). */
+typedef struct { u64 k[3]; u64 idx; } h1h2_ent;
+static int h1h2_cmp(const void *a, const void *b)
+{
+    const h1h2_ent *x = (const h1h2_ent *)a, *y = (const h1h2_ent *)b;
+    for (int d = 0; d < 3; d++) if (x->k[d] != y->k[d]) return x->k[d] < y->k[d] ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+int orc_calculate_h1h2(u64 *h1, u64 *h2, const u64 *f, const u64 *t, u64 n, unsigned dim)
+{
+    h1h2_ent *e = (h1h2_ent *)malloc(n * sizeof(h1h2_ent));
+    u64 *cnt = (u64 *)malloc(n * sizeof(u64));
+    for (u64 i = 0; i < n; i++) {
+        for (unsigned d = 0; d < 3; d++) e[i].k[d] = d < dim ? gl_canon(t[i * dim + d]) : 0;
+        e[i].idx = i;
+        cnt[i] = 1;
+    }
+    qsort(e, n, sizeof(h1h2_ent), h1h2_cmp);
+    /* last index per distinct key = idx of the last entry of each run (sorted by idx within a key) */
+    int missing = 0;
+    for (u64 j = 0; j < n && !missing; j++) {
+        h1h2_ent q;
+        for (unsigned d = 0; d < 3; d++) q.k[d] = d < dim ? gl_canon(f[j * dim + d]) : 0;
+        u64 lo = 0, hi = n;      /* upper bound of the key run */
+        q.idx = (u64)-1;
+        while (lo < hi) { u64 m = (lo + hi) / 2; if (h1h2_cmp(&e[m], &q) <= 0) lo = m + 1; else hi = m; }
+        if (lo == 0 || memcmp(e[lo - 1].k, q.k, sizeof(q.k)) != 0) { missing = 1; break; }
+        cnt[e[lo - 1].idx]++;
+    }
+    if (!missing) {
+        u64 id = 0;
+        for (u64 i = 0; i < n; i++) {
+            if (cnt[id] == 0) id++;
+            cnt[id]--;
+            for (unsigned d = 0; d < dim; d++) h1[i * dim + d] = gl_canon(t[id * dim + d]);
+            if (cnt[id] == 0) id++;
+            cnt[id]--;
+            for (unsigned d = 0; d < dim; d++) h2[i * dim + d] = gl_canon(t[id * dim + d]);
+        }
+    }
+    free(e); free(cnt);
+    return missing;
+}

@@ -49,6 +49,7 @@ def _load():
         "orc_inv3": (None, [_pu64, _pu64]),
         "orc_batch_inverse": (None, [_pu64, _pu64, u64, C.c_uint]),
         "orc_calculate_z": (None, [_pu64, _pu64, _pu64, u64]),
+        "orc_calculate_h1h2": (C.c_int, [_pu64, _pu64, _pu64, _pu64, u64, C.c_uint]),
         "orc_transcript_init": (None, [C.c_void_p]),
         "orc_transcript_put": (None, [C.c_void_p, _pu64, u64]),
         "orc_transcript_get1": (u64, [C.c_void_p]),
@@ -202,6 +203,16 @@ def calculate_z(num, den):
     if num.size:
         lib.orc_calculate_z(z, num, den, num.size // 3)
     return z.reshape(-1, 3)
+
+
+def calculate_h1h2(f, t, dim=1):
+    """-> (h1, h2) or raises ValueError if some f value is not in t"""
+    f, t = _a(f).ravel(), _a(t).ravel()
+    n = t.size // dim
+    h1, h2 = np.zeros_like(t), np.zeros_like(t)
+    if n and lib.orc_calculate_h1h2(h1, h2, f, t, n, dim):
+        raise ValueError("calculateH1H2: number not included")
+    return (h1.reshape(n, dim), h2.reshape(n, dim)) if dim == 3 else (h1, h2)
 
 
 def evmap(LEv, LpEv, n, extend_bits, entries):

@@ -412,3 +412,31 @@ def test_merkle_large_subtree_property(xlp, orc):
         while cnt > 1:
             sib.append(h_nodes[off + (i ^ 1) * 4: off + (i ^ 1) * 4 + 4]); off += 4 * cnt; cnt //= 2; i >>= 1
         assert list(orc.merkle_root_from_path(row, np.concatenate(sib), idx)) == list(root)
+
+
+def _plookup_inputs(orc, n, dim, seed, distinct):
+    """t: table with duplicates, f: every value drawn from t (heavily skewed)"""
+    rng = np.random.default_rng(seed)
+    base = orc.fill(distinct * dim, seed).reshape(distinct, dim)
+    t = base[np.sort(rng.integers(0, distinct, n))]
+    pick = np.minimum((rng.random(n) ** 4 * n).astype(np.int64), n - 1)     # skew: most f hit few rows
+    f = t[pick]
+    return np.ascontiguousarray(f), np.ascontiguousarray(t)
+
+
+@pytest.mark.parametrize("n,dim,distinct", [(1, 1, 1), (8, 1, 3), (8, 3, 8), (1000, 1, 37), (4096, 3, 500), (1 << 16, 1, 1 << 12), (1 << 16, 3, 1 << 16)])
+def test_calculate_h1h2_vs_oracle(xlp, orc, n, dim, distinct):
+    f, t = _plookup_inputs(orc, n, dim, 0x5EED0090 + n, distinct)
+    exp1, exp2 = orc.calculate_h1h2(f, t, dim)
+    h1 = xlp.from_np(np.zeros(n * dim, np.uint64)); h2 = xlp.from_np(np.zeros(n * dim, np.uint64))
+    xlp.dev_calculate_h1h2(h1, h2, xlp.from_np(f.reshape(-1)), xlp.from_np(t.reshape(-1)), n, dim); xlp.sync()
+    assert (xlp.to_np(h1) == exp1.reshape(-1)).all() and (xlp.to_np(h2) == exp2.reshape(-1)).all()
+
+
+def test_calculate_h1h2_number_not_included(xlp, orc):
+    t = np.arange(1, 65, dtype=np.uint64); f = t.copy(); f[10] = 1000
+    h = xlp.from_np(np.zeros(64, np.uint64)); h2 = xlp.from_np(np.zeros(64, np.uint64))
+    with pytest.raises(xlp.XlpError, match="not included"):
+        xlp.dev_calculate_h1h2(h, h2, xlp.from_np(f), xlp.from_np(t), 64, 1)
+    with pytest.raises(ValueError):
+        orc.calculate_h1h2(f, t, 1)

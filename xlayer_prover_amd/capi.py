@@ -41,6 +41,7 @@ SIGNATURES = {
     "xlp_dev_batch_inverse": [_pu, _pu, _u64, _u32],
     "xlp_dev_calculate_z": [_pu, _pu, _pu, _u64],
     "xlp_dev_evmap": [_pu, _pu, _pu, _u64, _u32, _u32, _pu],
+    "xlp_dev_calculate_h1h2": [_pu, _pu, _pu, _pu, _u64, _u32],
     "xlp_profile_enable": [C.c_int],
     "xlp_profile_read": [C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
     "xlp_dev_alloc": [C.POINTER(C.c_void_p), C.c_size_t],
@@ -248,6 +249,10 @@ def dev_batch_inverse(res, src, n, dim=3):
 
 def dev_calculate_z(z, num, den, n):
     _ck(load().xlp_dev_calculate_z(_dp(z), _dp(num), _dp(den), n), "xlp_dev_calculate_z")
+
+
+def dev_calculate_h1h2(h1, h2, f, t, n, dim=1):
+    _ck(load().xlp_dev_calculate_h1h2(_dp(h1), _dp(h2), _dp(f), _dp(t), n, dim), "xlp_dev_calculate_h1h2")
 
 
 class EvmapEntry(C.Structure):

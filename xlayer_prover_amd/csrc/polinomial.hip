@@ -266,4 +266,161 @@ int dev_evmap(Ctx* ctx, u64* evals, const u64* LEv, const u64* LpEv, u64 n, u32 
     return 0;
 }
 
+
+// ------------------------------------------------------------------ calculateH1H2
+// Polinomial::calculateH1H2_opt1 / _opt3 (polinomial.hpp:349-585; called starks.cpp:108-125).
+// The reference walks hash chains sequentially; the observable result only depends on
+//   last[key] = the last index of t holding `key`,  count[i] = 1 + #{j : last[f[j]] == i},
+//   merged    = t[i] repeated count[i] times, i ascending (length 2n);  h1[k] = merged[2k], h2[k] = merged[2k+1].
+// GPU form: open-addressing table (slot owner = one t index of the key, atomicMax of the index),
+// per-f lookup + atomicAdd, exclusive scan of the counts, then ONE THREAD PER OUTPUT ELEMENT that
+// binary-searches its source index -- balanced however skewed the counts are.
+constexpr u32 H_EMPTY = 0xFFFFFFFFu;
+
+template <int DIM>
+__device__ __forceinline__ void load_key(u64 (&k)[3], const u64* p, u64 i)
+{
+    k[0] = gl::canon(p[i * DIM]);
+    k[1] = DIM == 3 ? gl::canon(p[i * DIM + 1]) : 0;
+    k[2] = DIM == 3 ? gl::canon(p[i * DIM + 2]) : 0;
+}
+__device__ __forceinline__ u32 hash_key(const u64 (&k)[3], u32 mask)
+{
+    u64 h = k[0] * 0x9E3779B97F4A7C15ULL ^ (k[1] + 0x7F4A7C15ULL) * 0xBF58476D1CE4E5B9ULL ^ (k[2] + 0x94D049BBULL) * 0x94D049BB133111EBULL;
+    h ^= h >> 29;
+    return (u32)h & mask;
+}
+
+template <int DIM>
+__global__ void h1h2_insert_kernel(u32* owner, u32* last, const u64* t, u64 n, u32 mask)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 k[3], o[3];
+    load_key<DIM>(k, t, i);
+    u32 slot = hash_key(k, mask);
+    for (;;) {
+        u32 cur = atomicCAS(&owner[slot], H_EMPTY, (u32)i);
+        if (cur == H_EMPTY) cur = (u32)i;
+        load_key<DIM>(o, t, cur);
+        if (o[0] == k[0] && o[1] == k[1] && o[2] == k[2]) { atomicMax(&last[slot], (u32)i); return; }
+        slot = (slot + 1) & mask;
+    }
+}
+
+template <int DIM>
+__global__ void h1h2_count_kernel(u32* count, u32* err, const u32* owner, const u32* last, const u64* f, const u64* t, u64 n, u32 mask)
+{
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    u64 k[3], o[3];
+    load_key<DIM>(k, f, j);
+    u32 slot = hash_key(k, mask);
+    for (;;) {
+        const u32 cur = owner[slot];
+        if (cur == H_EMPTY) { atomicExch(err, 1u); return; }     // number not included (reference: exitProcess)
+        load_key<DIM>(o, t, cur);
+        if (o[0] == k[0] && o[1] == k[1] && o[2] == k[2]) { atomicAdd(&count[last[slot]], 1u); return; }
+        slot = (slot + 1) & mask;
+    }
+}
+
+__global__ void fill_u32_kernel(u32* p, u64 n, u32 v)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// exclusive scan of u32 counts (n <= 2^26): per-block scan + block sums + apply
+constexpr int US_T = 256, US_E = 16, US_B = US_T * US_E;
+__global__ __launch_bounds__(US_T) void uscan_block_kernel(u32* out, u32* bsum, const u32* in, u64 n)
+{
+    __shared__ u32 sh[US_T];
+    const u64 base = (u64)blockIdx.x * US_B + (u64)threadIdx.x * US_E;
+    u32 v[US_E], acc = 0;
+#pragma unroll
+    for (int k = 0; k < US_E; k++) { v[k] = acc; acc += base + k < n ? in[base + k] : 0; }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 1; off < US_T; off <<= 1) {
+        u32 a = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += a;
+        __syncthreads();
+    }
+    const u32 pre = threadIdx.x ? sh[threadIdx.x - 1] : 0;
+#pragma unroll
+    for (int k = 0; k < US_E; k++) if (base + k < n) out[base + k] = pre + v[k];
+    if (threadIdx.x == US_T - 1 && bsum) bsum[blockIdx.x] = sh[US_T - 1];
+}
+__global__ void uscan_apply_kernel(u32* out, const u32* boff, u64 n)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] += boff[i / US_B];
+}
+static int uscan_exclusive(Ctx* ctx, u32* out, const u32* in, u64 n, u32* scratch)
+{
+    const u64 nb = (n + US_B - 1) / US_B;
+    hipLaunchKernelGGL(uscan_block_kernel, dim3((unsigned)nb), dim3(US_T), 0, ctx->stream, out, nb > 1 ? scratch : nullptr, in, n);
+    if (nb > 1) {
+        u32* boff = scratch + nb;
+        if (uscan_exclusive(ctx, boff, scratch, nb, boff + nb)) return -1;
+        hipLaunchKernelGGL(uscan_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, out, boff, n);
+    }
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int DIM>
+__global__ void h1h2_expand_kernel(u64* h1, u64* h2, const u64* t, const u32* offs, u64 n)
+{
+    const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= 2 * n) return;
+    // largest i with offs[i] <= pos   (offs ascending, offs[0] = 0, every count >= 1)
+    u64 lo = 0, hi = n;
+    while (hi - lo > 1) { const u64 m = (lo + hi) >> 1; if (offs[m] <= pos) lo = m; else hi = m; }
+    u64* dst = (pos & 1) ? h2 : h1;
+#pragma unroll
+    for (int d = 0; d < DIM; d++) dst[(pos >> 1) * DIM + d] = gl::canon(t[lo * DIM + d]);
+}
+
+template <int DIM>
+static int h1h2_impl(Ctx* ctx, u64* h1, u64* h2, const u64* f, const u64* t, u64 n)
+{
+    u32 ts = 1;
+    while (ts < 2 * n) ts <<= 1;
+    const u32 mask = ts - 1;
+    // scratch: owner[ts] last[ts] count[n] offs[n] err[1] scan[..]
+    const u64 nb = (n + US_B - 1) / US_B;
+    const size_t words = (size_t)2 * ts + 2 * n + 64 + 4 * (nb + 64);
+    u64* raw = nullptr;
+    if (ctx_scratch(ctx, words * sizeof(u32), 3, &raw)) return -1;
+    u32* owner = (u32*)raw; u32* last = owner + ts; u32* count = last + ts; u32* offs = count + n; u32* err = offs + n; u32* scan = err + 64;
+    XLP_HIP(hipMemsetAsync(owner, 0xFF, (size_t)ts * 4, ctx->stream));
+    XLP_HIP(hipMemsetAsync(last, 0, (size_t)ts * 4, ctx->stream));
+    XLP_HIP(hipMemsetAsync(err, 0, 4, ctx->stream));
+    const unsigned g = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(g), dim3(256), 0, ctx->stream, count, n, 1u);
+    hipLaunchKernelGGL(h1h2_insert_kernel<DIM>, dim3(g), dim3(256), 0, ctx->stream, owner, last, t, n, mask);
+    hipLaunchKernelGGL(h1h2_count_kernel<DIM>, dim3(g), dim3(256), 0, ctx->stream, count, err, owner, last, f, t, n, mask);
+    XLP_HIP(hipGetLastError());
+    u32 herr = 0;
+    XLP_HIP(hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, ctx->stream));
+    XLP_HIP(hipStreamSynchronize(ctx->stream));
+    if (herr) return xlp_fail("calculateH1H2: number not included");
+    if (uscan_exclusive(ctx, offs, count, n, scan)) return -1;
+    hipLaunchKernelGGL(h1h2_expand_kernel<DIM>, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, ctx->stream, h1, h2, t, offs, n);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
+int dev_calculate_h1h2(Ctx* ctx, u64* h1, u64* h2, const u64* f, const u64* t, u64 n, u32 dim)
+{
+    if (!n) return 0;
+    if (n > (1ull << 30)) return xlp_fail("calculateH1H2: too many rows");
+    if (dim == 1) return h1h2_impl<1>(ctx, h1, h2, f, t, n);
+    if (dim == 3) return h1h2_impl<3>(ctx, h1, h2, f, t, n);
+    return xlp_fail("calculateH1H2: dim must be 1 or 3");
+}
+
 }  // namespace xlp

@@ -184,6 +184,11 @@ int xlp_dev_calculate_z(uint64_t* z, const uint64_t* num, const uint64_t* den, u
     if (ensure_init()) return -1;
     return dev_calculate_z(&g_ctx, z, num, den, n);
 }
+int xlp_dev_calculate_h1h2(uint64_t* h1, uint64_t* h2, const uint64_t* f, const uint64_t* t, uint64_t n, uint32_t dim)
+{
+    if (ensure_init()) return -1;
+    return dev_calculate_h1h2(&g_ctx, h1, h2, f, t, n, dim);
+}
 int xlp_dev_evmap(uint64_t* evals, const uint64_t* LEv, const uint64_t* LpEv, uint64_t n, uint32_t extend_bits, uint32_t nev,
                   const xlp_evmap_entry* entries)
 {
