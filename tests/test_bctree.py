@@ -1,0 +1,62 @@
+"""GPU `bctree` (xlayer_prover_amd/host/bctree): same CLI / files as the reference tool
+(tools/starkpil/bctree/main.cpp, build_const_tree.cpp:533-603); outputs compared byte for byte with the
+oracle's extendPol + merkletree and parsed the way MerkleTreeGL(Element *tree) does (merkleTreeGL.hpp:24-32)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "xlayer_prover_amd", "host", "bctree")
+
+
+def _run(*args):
+    return subprocess.run([EXE, *args], capture_output=True, text=True)
+
+
+def test_bctree_cli_errors(tmp_path):
+    assert os.path.exists(EXE), "run __graft_entry__.build()"
+    r = _run()
+    assert r.returncode != 0 and "constants input file argument not specified" in r.stderr and "usage: bctree" in r.stderr
+    r = _run("-c", str(tmp_path / "nope.const"), "-s", "x", "-t", "y")
+    assert r.returncode != 0 and "constants file doesn't exist" in r.stderr
+    c = tmp_path / "a.const"; c.write_bytes(b"\0" * 64)
+    r = _run("-c", str(c), "-s", str(tmp_path / "nope.json"), "-t", "y")
+    assert r.returncode != 0 and "starkstruct file doesn't exist" in r.stderr
+    s = tmp_path / "s.json"; s.write_text('{"steps":[{"nBits":5}],"nBits":3,"nBitsExt":4,"verificationHashType":"BN128"}')
+    r = _run("-c", str(c), "-s", str(s))
+    assert r.returncode != 0 and "tree ouput file argument not specified" in r.stderr
+    r = _run("-c", str(c), "-c", str(c), "-s", str(s), "-t", "y")
+    assert r.returncode != 0 and "parameter twice" in r.stderr
+    r = _run("-c", str(c), "-s", str(s), "-t", str(tmp_path / "t"))
+    assert r.returncode != 0 and "BN128" in r.stderr             # other field: outside the path
+    s.write_text('{"nBits":3,"nBitsExt":4,"verificationHashType":"GL"}')
+    c.write_bytes(b"\0" * 72)
+    r = _run("-c", str(c), "-s", str(s), "-t", str(tmp_path / "t"))
+    assert r.returncode != 0 and "const file size" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nbits,nbits_ext,npols", [(3, 4, 1), (6, 8, 5), (10, 11, 23), (13, 14, 9), (17, 18, 8)])
+def test_bctree_files_match_oracle(orc, tmp_path, nbits, nbits_ext, npols):
+    n, next_ = 1 << nbits, 1 << nbits_ext
+    const = orc.fill(n * npols, 0x5EED00C0 + nbits) % np.uint64(orc.P)
+    (tmp_path / "x.const").write_bytes(const.tobytes())
+    # nested "nBits" members must not shadow the top-level one
+    (tmp_path / "x.starkstruct.json").write_text(json.dumps(
+        {"steps": [{"nBits": nbits_ext}, {"nBits": 2}], "nBits": nbits, "nBitsExt": nbits_ext, "nQueries": 4, "verificationHashType": "GL"}, indent=2))
+    r = _run("--const", str(tmp_path / "x.const"), "-s", str(tmp_path / "x.starkstruct.json"), "-t", str(tmp_path / "x.consttree"),
+             "-v", str(tmp_path / "x.verkey.json"))
+    assert r.returncode == 0, r.stderr
+    assert "Files Generated Correctly" in r.stdout
+    tree = np.fromfile(tmp_path / "x.consttree", dtype=np.uint64)
+    ext = orc.extend_pol(const, next_, n, npols)
+    nodes = orc.merkletree(ext, npols, next_)
+    assert tree.size == 2 + next_ * npols + (2 * next_ - 1) * 4
+    assert tree[0] == npols and tree[1] == next_                 # MerkleTreeGL(tree): width, height
+    assert (tree[2:2 + next_ * npols] == ext.reshape(-1)).all()  # source
+    assert (tree[2 + next_ * npols:] == nodes).all()             # nodes
+    vk = json.loads((tmp_path / "x.verkey.json").read_text())
+    assert vk == {"constRoot": [int(v) for v in nodes[-4:]]}
