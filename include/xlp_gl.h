@@ -115,6 +115,67 @@ typedef struct xlp_evmap_entry { const uint64_t* pol; uint64_t row_stride; uint3
 int xlp_dev_evmap(uint64_t* evals, const uint64_t* LEv, const uint64_t* LpEv, uint64_t n, uint32_t extend_bits, uint32_t nev,
                   const xlp_evmap_entry* entries);
 
+/* ---- constraint-expression VM, device pointers ------------------------------------
+ * Replaces ZkevmSteps::step{2prev,3prev,3,42ns,52ns}_parser_first_avx(StepsParams &params, nrows, nrowsBatch)
+ * (src/starkpil/zkevm/chelpers/zkevm.chelpers.*.parser.cpp; called at starks.cpp:73,155,193,241,371): one
+ * straight-line program of field operations evaluated on every row, temporaries per row, operands taken
+ * from the StepsParams buffers (src/starkpil/steps.hpp:4-19).  The reference numbers its ~120 fused
+ * (function, operand-kind) cases per generated file; here ONE orthogonal encoding covers them all (every
+ * reference case is one or two instructions, tools/chelpers_to_xlp.py converts the checked-in tables):
+ *
+ *   code[] (uint64 words) = instruction*;  instruction = head, dst params, a params, b params
+ *   head = op | dst_kind << 8 | a_kind << 16 | b_kind << 24 | dst_dim << 32 | a_dim << 34 | b_dim << 36
+ *   op: 0 COPY (dst = a), 1 ADD, 2 SUB (a - b), 3 MUL.  dim 1 = Goldilocks, 3 = cubic extension; a base
+ *   operand combined with an extension one is embedded as (x, 0, 0) (add13/sub31c/mul13... of the reference);
+ *   dst_dim = max(a_dim, b_dim).  Results are canonical.
+ *
+ *   kind                params                      element c of row i
+ *   XLP_K_TMP1          idx                         tmp1[idx]
+ *   XLP_K_TMP3          idx                         tmp3[idx][c]
+ *   XLP_K_POLS          offset, stride              pols[offset + i * stride + c]
+ *   XLP_K_POLS_PRIME    offset, next, n, stride     pols[offset + ((i + next) % n) * stride + c]
+ *   XLP_K_CONST         col                         const_pols[col + i * n_const_pols]
+ *   XLP_K_CONST_PRIME   col, next, n                const_pols[col + ((i + next) % n) * n_const_pols]
+ *   XLP_K_CONST2NS / _PRIME                         same on const_pols_2ns
+ *   XLP_K_NUMBER        value                       value
+ *   XLP_K_CHALLENGE k / XLP_K_EVAL k                challenges[3k + c] / evals[3k + c]
+ *   XLP_K_PUBLIC        k                           public_inputs[k]
+ *   XLP_K_X_N / XLP_K_X_2NS / XLP_K_ZI              x_n[i] / x_2ns[i] / zi[i % zi_size]   (ZhInv::zhInv, zhInv.hpp:20-23)
+ *   XLP_K_XDIVXSUBXI / XLP_K_XDIVXSUBWXI            x_div_x_sub_xi[3i + c] / x_div_x_sub_wxi[3i + c]
+ *   XLP_K_Q_2NS / XLP_K_F_2NS                       q_2ns[3i + c] / f_2ns[3i + c]
+ *   destinations: TMP1, TMP3, POLS, POLS_PRIME, Q_2NS, F_2NS.
+ *
+ * xlp_expr_create validates the program (kinds, dims, temp indices) and uploads it; xlp_dev_expr_run checks
+ * every operand's address range against the *_size members (elements) for rows [row0, row0 + nrows) before
+ * launching, so a malformed program or short buffer is an error, never a GPU fault. */
+enum {
+    XLP_OP_COPY = 0, XLP_OP_ADD = 1, XLP_OP_SUB = 2, XLP_OP_MUL = 3,
+    XLP_K_NONE = 0, XLP_K_TMP1 = 1, XLP_K_TMP3 = 2, XLP_K_POLS = 3, XLP_K_POLS_PRIME = 4, XLP_K_CONST = 5,
+    XLP_K_CONST_PRIME = 6, XLP_K_CONST2NS = 7, XLP_K_CONST2NS_PRIME = 8, XLP_K_NUMBER = 9, XLP_K_CHALLENGE = 10,
+    XLP_K_PUBLIC = 11, XLP_K_EVAL = 12, XLP_K_X_N = 13, XLP_K_X_2NS = 14, XLP_K_ZI = 15, XLP_K_XDIVXSUBXI = 16,
+    XLP_K_XDIVXSUBWXI = 17, XLP_K_Q_2NS = 18, XLP_K_F_2NS = 19, XLP_K_COUNT = 20
+};
+typedef struct xlp_steps_params {       /* StepsParams, steps.hpp:4-19; all device pointers, sizes in elements */
+    uint64_t* pols;                 uint64_t pols_size;
+    const uint64_t* const_pols;     uint64_t n_const_pols;     uint64_t const_pols_size;
+    const uint64_t* const_pols_2ns; uint64_t n_const_pols_2ns; uint64_t const_pols_2ns_size;
+    const uint64_t* challenges;     uint64_t challenges_size;
+    const uint64_t* public_inputs;  uint64_t public_inputs_size;
+    const uint64_t* evals;          uint64_t evals_size;
+    const uint64_t* x_n;            uint64_t x_n_size;
+    const uint64_t* x_2ns;          uint64_t x_2ns_size;
+    const uint64_t* zi;             uint64_t zi_size;
+    const uint64_t* x_div_x_sub_xi; uint64_t x_div_x_sub_xi_size;
+    const uint64_t* x_div_x_sub_wxi; uint64_t x_div_x_sub_wxi_size;
+    uint64_t* q_2ns;                uint64_t q_2ns_size;
+    uint64_t* f_2ns;                uint64_t f_2ns_size;
+} xlp_steps_params;
+typedef struct xlp_expr_program xlp_expr_program;
+int xlp_expr_create(xlp_expr_program** out, const uint64_t* code, uint64_t ncode, uint64_t ntmp1, uint64_t ntmp3);
+int xlp_expr_destroy(xlp_expr_program* prog);
+/* Evaluate the program on rows row0 .. row0 + nrows - 1 (asynchronous on the context's stream). */
+int xlp_dev_expr_run(const xlp_expr_program* prog, const xlp_steps_params* params, uint64_t row0, uint64_t nrows);
+
 /* Test hook: out[i] = op(a[i], b[i]) using the device field functions the kernels are built
  * from (op codes: csrc/fri.hip field_op_kernel).  Host pointers.  Not part of the reference surface. */
 int xlp_field_op(uint64_t* out, const uint64_t* a, const uint64_t* b, uint64_t n, int op);

@@ -656,3 +656,112 @@ int orc_calculate_h1h2(u64 *h1, u64 *h2, const u64 *f, const u64 *t, u64 n, unsi
     free(e); free(cnt);
     return missing;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Constraint-expression programs: CPU restatement of what one pass of
+ * ZkevmSteps::step*_parser_first_avx does per row (zkevm.chelpers.step3.parser.cpp:11-973 and
+ * siblings), on the orthogonal instruction encoding documented in include/xlp_gl.h.  Operand
+ * addressing follows the reference's expressions:
+ *   pols[args + i * args]                                   (step3.parser.cpp:33, case 1)
+ *   pols[args + (((i + j) + args) % args) * args]            (:52-55, case 5: "prime" rows)
+ *   pConstPols->getElement(col, i) = const[col + i * numPols] (:45, case 3)
+ *   challenges[k] (3 words), publicInputs[k], evals[k] (3 words), x_n[i], x_2ns[i],
+ *   zi.zhInv(i) = ZHInv[i % size] (zhInv.hpp:20-23), xDivXSubXi[i], q_2ns[i*3], f_2ns[i*3].
+ * Base (x) meets extension as (x,0,0): add13/sub13c/sub31c/mul13/mul1c3c of the reference.
+ * PARITY UNPINNED against the reference binary: the generated parsers need the absent goldilocks
+ * library and a starkinfo/witness archive; pinned only by construction on synthetic programs. */
+typedef struct {
+    u64 *pols; u64 pols_size;
+    const u64 *const_pols; u64 n_const_pols; u64 const_pols_size;
+    const u64 *const_pols_2ns; u64 n_const_pols_2ns; u64 const_pols_2ns_size;
+    const u64 *challenges; u64 challenges_size;
+    const u64 *public_inputs; u64 public_inputs_size;
+    const u64 *evals; u64 evals_size;
+    const u64 *x_n; u64 x_n_size;
+    const u64 *x_2ns; u64 x_2ns_size;
+    const u64 *zi; u64 zi_size;
+    const u64 *x_div_x_sub_xi; u64 x_div_x_sub_xi_size;
+    const u64 *x_div_x_sub_wxi; u64 x_div_x_sub_wxi_size;
+    u64 *q_2ns; u64 q_2ns_size;
+    u64 *f_2ns; u64 f_2ns_size;
+} orc_steps_params;
+
+static const int ORC_KPARAMS[20] = {0, 1, 1, 2, 4, 1, 3, 1, 3, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+
+/* address of element 0 of an operand for row i (NULL for temporaries / numbers) */
+static u64 *orc_expr_addr(const orc_steps_params *P, unsigned kind, const u64 *a, u64 i)
+{
+    switch (kind) {
+    case 3: return P->pols + a[0] + i * a[1];
+    case 4: return P->pols + a[0] + ((i + a[1]) % a[2]) * a[3];
+    case 5: return (u64 *)P->const_pols + a[0] + i * P->n_const_pols;
+    case 6: return (u64 *)P->const_pols + a[0] + ((i + a[1]) % a[2]) * P->n_const_pols;
+    case 7: return (u64 *)P->const_pols_2ns + a[0] + i * P->n_const_pols_2ns;
+    case 8: return (u64 *)P->const_pols_2ns + a[0] + ((i + a[1]) % a[2]) * P->n_const_pols_2ns;
+    case 10: return (u64 *)P->challenges + 3 * a[0];
+    case 11: return (u64 *)P->public_inputs + a[0];
+    case 12: return (u64 *)P->evals + 3 * a[0];
+    case 13: return (u64 *)P->x_n + i;
+    case 14: return (u64 *)P->x_2ns + i;
+    case 15: return (u64 *)P->zi + (i % P->zi_size);
+    case 16: return (u64 *)P->x_div_x_sub_xi + 3 * i;
+    case 17: return (u64 *)P->x_div_x_sub_wxi + 3 * i;
+    case 18: return P->q_2ns + 3 * i;
+    case 19: return P->f_2ns + 3 * i;
+    default: return NULL;
+    }
+}
+
+/* returns 0, or 1 + index of the first malformed instruction */
+u64 orc_expr_run(const u64 *code, u64 ncode, u64 ntmp1, u64 ntmp3, const orc_steps_params *P, u64 row0, u64 nrows)
+{
+    u64 *tmp1 = (u64 *)calloc(ntmp1 ? ntmp1 : 1, sizeof(u64));
+    u64 *tmp3 = (u64 *)calloc(ntmp3 ? 3 * ntmp3 : 1, sizeof(u64));
+    u64 bad = 0;
+    for (u64 i = row0; i < row0 + nrows && !bad; i++) {
+        u64 pc = 0, k = 0;
+        while (pc < ncode) {
+            const u64 h = code[pc];
+            const unsigned op = h & 0xff, kd = (h >> 8) & 0xff, ka = (h >> 16) & 0xff, kb = (h >> 24) & 0xff;
+            const unsigned dd = (h >> 32) & 3, da = (h >> 34) & 3, db = (h >> 36) & 3;
+            if (op > 3 || kd >= 20 || ka >= 20 || kb >= 20) { bad = k + 1; break; }
+            const u64 *pd = code + pc + 1, *pa = pd + ORC_KPARAMS[kd], *pb = pa + ORC_KPARAMS[ka];
+            pc += 1 + ORC_KPARAMS[kd] + ORC_KPARAMS[ka] + ORC_KPARAMS[kb];
+            if (pc > ncode) { bad = k + 1; break; }
+            u64 a[3] = {0, 0, 0}, b[3] = {0, 0, 0}, r[3] = {0, 0, 0};
+            const unsigned kinds[2] = {ka, kb}, dims[2] = {da, db};
+            const u64 *prm[2] = {pa, pb};
+            u64 *val[2] = {a, b};
+            for (int s = 0; s < 2; s++) {
+                if (kinds[s] == 0) continue;
+                if (kinds[s] == 1) val[s][0] = tmp1[prm[s][0]];
+                else if (kinds[s] == 2) memcpy(val[s], tmp3 + 3 * prm[s][0], 3 * sizeof(u64));
+                else if (kinds[s] == 9) val[s][0] = gl_canon(prm[s][0]);
+                else {
+                    const u64 *src = orc_expr_addr(P, kinds[s], prm[s], i);
+                    for (unsigned c = 0; c < dims[s]; c++) val[s][c] = gl_canon(src[c]);
+                }
+            }
+            switch (op) {
+            case 0: memcpy(r, a, sizeof(r)); break;
+            case 1: for (int c = 0; c < 3; c++) r[c] = gl_add(a[c], b[c]); break;
+            case 2: for (int c = 0; c < 3; c++) r[c] = gl_sub(a[c], b[c]); break;
+            default:
+                if (da == 3 && db == 3) gl3_mul(r, a, b);
+                else if (da == 3) for (int c = 0; c < 3; c++) r[c] = gl_mul(a[c], b[0]);
+                else if (db == 3) for (int c = 0; c < 3; c++) r[c] = gl_mul(b[c], a[0]);
+                else r[0] = gl_mul(a[0], b[0]);
+            }
+            if (kd == 1) tmp1[pd[0]] = r[0];
+            else if (kd == 2) memcpy(tmp3 + 3 * pd[0], r, 3 * sizeof(u64));
+            else {
+                u64 *dst = orc_expr_addr(P, kd, pd, i);
+                if (!dst || !(kd == 3 || kd == 4 || kd == 18 || kd == 19)) { bad = k + 1; break; }
+                for (unsigned c = 0; c < dd; c++) dst[c] = r[c];
+            }
+            k++;
+        }
+    }
+    free(tmp1); free(tmp3);
+    return bad;
+}

@@ -232,6 +232,40 @@ def evmap(LEv, LpEv, n, extend_bits, entries):
     return evals.reshape(nev, 3)
 
 
+class OrcStepsParams(C.Structure):
+    """orc_steps_params (gl_oracle.c): host pointers + sizes in elements"""
+    _fields_ = [("pols", C.c_void_p), ("pols_size", u64),
+                ("const_pols", C.c_void_p), ("n_const_pols", u64), ("const_pols_size", u64),
+                ("const_pols_2ns", C.c_void_p), ("n_const_pols_2ns", u64), ("const_pols_2ns_size", u64),
+                ("challenges", C.c_void_p), ("challenges_size", u64),
+                ("public_inputs", C.c_void_p), ("public_inputs_size", u64),
+                ("evals", C.c_void_p), ("evals_size", u64),
+                ("x_n", C.c_void_p), ("x_n_size", u64),
+                ("x_2ns", C.c_void_p), ("x_2ns_size", u64),
+                ("zi", C.c_void_p), ("zi_size", u64),
+                ("x_div_x_sub_xi", C.c_void_p), ("x_div_x_sub_xi_size", u64),
+                ("x_div_x_sub_wxi", C.c_void_p), ("x_div_x_sub_wxi_size", u64),
+                ("q_2ns", C.c_void_p), ("q_2ns_size", u64),
+                ("f_2ns", C.c_void_p), ("f_2ns_size", u64)]
+
+
+def expr_run(code, ntmp1, ntmp3, buffers, row0, nrows, n_const_pols=0, n_const_pols_2ns=0):
+    """buffers: name -> C-contiguous uint64 ndarray (modified in place for pols / q_2ns / f_2ns)"""
+    sp = OrcStepsParams()
+    sp.n_const_pols, sp.n_const_pols_2ns = n_const_pols, n_const_pols_2ns
+    for name, a in buffers.items():
+        assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+        setattr(sp, name, a.ctypes.data)
+        setattr(sp, name + "_size", a.size)
+    code = _a(code)
+    f = lib.orc_expr_run
+    f.restype = u64
+    f.argtypes = [_pu64, u64, u64, u64, C.c_void_p, u64, u64]
+    bad = f(code if code.size else np.zeros(1, np.uint64), code.size, ntmp1, ntmp3, C.byref(sp), row0, nrows)
+    if bad:
+        raise ValueError(f"expr_run: malformed instruction {bad - 1}")
+
+
 def num_threads():
     return lib.orc_num_threads()
 

@@ -1,0 +1,96 @@
+"""Constraint-expression VM (csrc/expr.hip) against the oracle interpreter on seeded random
+programs that use every operand kind, op and dimension combination, plus the rejection paths."""
+import numpy as np
+import pytest
+
+from tests.expr_programs import make_buffers, random_program
+from xlayer_prover_amd import expr as E
+
+
+@pytest.fixture(scope="module")
+def xlp():
+    import torch
+    from xlayer_prover_amd import capi
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    capi.init(0)
+    capi.use_torch_stream()
+    return capi
+
+
+def _run_both(xlp, orc, prog, bufs, row0, nrows, nconst, nconst2):
+    dev = {k: xlp.from_np(v) for k, v in bufs.items()}
+    sp = xlp.steps_params(n_const_pols=nconst, n_const_pols_2ns=nconst2, **dev)
+    p = xlp.ExprProgram(prog.code, prog.ntmp1, prog.ntmp3)
+    p.run(sp, row0, nrows); xlp.sync()
+    p.close()
+    exp = {k: v.copy() for k, v in bufs.items()}
+    orc.expr_run(prog.code, prog.ntmp1, prog.ntmp3, exp, row0, nrows, nconst, nconst2)
+    for k in ("pols", "q_2ns", "f_2ns"):
+        got = xlp.to_np(dev[k])
+        assert (got == exp[k]).all(), f"{k}: {np.flatnonzero(got != exp[k])[:5]}"
+    return exp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,ninstr,row0,nrows", [(1, 64, 40, 0, 64), (2, 1000, 300, 0, 1000), (3, 1 << 12, 500, 0, 1 << 12),
+                                                      (4, 777, 200, 100, 500), (5, 1 << 16, 250, 0, 1 << 16), (6, 5, 120, 0, 5), (7, 4096, 150, 4095, 1)])
+def test_expr_random_programs_vs_oracle(xlp, orc, seed, n, ninstr, row0, nrows):
+    prog, width = random_program(seed, n, ninstr)
+    bufs = make_buffers(orc, 0x5EED0100 + seed, n, width)
+    exp = _run_both(xlp, orc, prog, bufs, row0, nrows, 5, 4)
+    assert (exp["pols"] != bufs["pols"]).any()          # the program stored something
+
+
+@pytest.mark.gpu
+def test_expr_many_temporaries_and_full_occupancy(xlp, orc):
+    """zkEVM-scale register file: step42ns needs 1196 + 3 * 175 slots per row (zkevm.chelpers.step42ns.parser.hpp:3-4)"""
+    n = 1 << 17
+    prog, width = random_program(11, n, 1500, ntmp1=1196, ntmp3=175, nstore=20)
+    bufs = make_buffers(orc, 0x5EED0111, n, width)
+    _run_both(xlp, orc, prog, bufs, 0, n, 5, 4)
+
+
+@pytest.mark.gpu
+def test_expr_rejections(xlp, orc):
+    ok = E.Program().add(E.tmp1(0), E.number(1), E.number(2))
+    c = ok.code.copy(); c[0] = (c[0] & ~np.uint64(0xff)) | np.uint64(7)
+    with pytest.raises(xlp.XlpError, match="unknown op"):
+        xlp.ExprProgram(c, 1, 0)
+    with pytest.raises(xlp.XlpError, match="tmp1 index out of range"):
+        xlp.ExprProgram(ok.code, 0, 0)
+    c = ok.code.copy(); c[0] = (c[0] & ~np.uint64(0xff00)) | np.uint64(E.K_NUMBER << 8)
+    with pytest.raises(xlp.XlpError, match="cannot be a destination"):
+        xlp.ExprProgram(c, 1, 0)
+    c = E.Program().add(E.tmp3(0), E.number(1), E.challenge(0)).code
+    c[0] = (c[0] & ~np.uint64(3 << 32)) | np.uint64(1 << 32)
+    with pytest.raises(xlp.XlpError, match="dimension"):
+        xlp.ExprProgram(c, 0, 1)
+    with pytest.raises(xlp.XlpError, match="truncated"):
+        xlp.ExprProgram(ok.code[:2], 1, 0)
+    # bounds: pols too short for the last row, missing buffer, column beyond nConstPols
+    n, w = 16, 4
+    prog = E.Program().copy(E.pols(3, w), E.pols(0, w))
+    p = xlp.ExprProgram(prog.code, 0, 0)
+    full = xlp.from_np(np.zeros(n * w, np.uint64))
+    p.run(xlp.steps_params(pols=full), 0, n)
+    with pytest.raises(xlp.XlpError, match="past the end"):
+        p.run(xlp.steps_params(pols=full[: n * w - 1]), 0, n)
+    with pytest.raises(xlp.XlpError, match="past the end"):
+        p.run(xlp.steps_params(pols=full), 1, n)
+    with pytest.raises(xlp.XlpError, match="no buffer"):
+        p.run(xlp.steps_params(), 0, n)
+    p2 = xlp.ExprProgram(E.Program().copy(E.tmp1(0), E.const(5)).code, 1, 0)
+    with pytest.raises(xlp.XlpError, match="past the end"):
+        p2.run(xlp.steps_params(n_const_pols=5, const_pols=xlp.from_np(np.zeros(5 * n, np.uint64))), 0, n)
+    xlp.sync()
+
+
+def test_expr_assembler_encoding():
+    prog = E.Program().mul(E.tmp3(2), E.pols_prime(7, 1, 64, 9, 3), E.tmp1(4))
+    c = prog.code
+    assert c.size == 1 + 1 + 4 + 1 and prog.ntmp1 == 5 and prog.ntmp3 == 3
+    assert int(c[0]) == E.MUL | E.K_TMP3 << 8 | E.K_POLS_PRIME << 16 | E.K_TMP1 << 24 | 3 << 32 | 3 << 34 | 1 << 36
+    assert [int(v) for v in c[1:]] == [2, 7, 1, 64, 9, 4]
+    with pytest.raises(ValueError):
+        E.Operand(E.K_POLS, (1,), 1)

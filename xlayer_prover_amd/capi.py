@@ -42,6 +42,9 @@ SIGNATURES = {
     "xlp_dev_calculate_z": [_pu, _pu, _pu, _u64],
     "xlp_dev_evmap": [_pu, _pu, _pu, _u64, _u32, _u32, _pu],
     "xlp_dev_calculate_h1h2": [_pu, _pu, _pu, _pu, _u64, _u32],
+    "xlp_expr_create": [C.POINTER(C.c_void_p), _pu, _u64, _u64, _u64],
+    "xlp_expr_destroy": [_pu],
+    "xlp_dev_expr_run": [_pu, _pu, _u64, _u64],
     "xlp_profile_enable": [C.c_int],
     "xlp_profile_read": [C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
     "xlp_dev_alloc": [C.POINTER(C.c_void_p), C.c_size_t],
@@ -253,6 +256,57 @@ def dev_calculate_z(z, num, den, n):
 
 def dev_calculate_h1h2(h1, h2, f, t, n, dim=1):
     _ck(load().xlp_dev_calculate_h1h2(_dp(h1), _dp(h2), _dp(f), _dp(t), n, dim), "xlp_dev_calculate_h1h2")
+
+
+class StepsParams(C.Structure):
+    """xlp_steps_params (include/xlp_gl.h): device pointers + sizes in elements"""
+    _fields_ = [("pols", C.c_void_p), ("pols_size", C.c_uint64),
+                ("const_pols", C.c_void_p), ("n_const_pols", C.c_uint64), ("const_pols_size", C.c_uint64),
+                ("const_pols_2ns", C.c_void_p), ("n_const_pols_2ns", C.c_uint64), ("const_pols_2ns_size", C.c_uint64),
+                ("challenges", C.c_void_p), ("challenges_size", C.c_uint64),
+                ("public_inputs", C.c_void_p), ("public_inputs_size", C.c_uint64),
+                ("evals", C.c_void_p), ("evals_size", C.c_uint64),
+                ("x_n", C.c_void_p), ("x_n_size", C.c_uint64),
+                ("x_2ns", C.c_void_p), ("x_2ns_size", C.c_uint64),
+                ("zi", C.c_void_p), ("zi_size", C.c_uint64),
+                ("x_div_x_sub_xi", C.c_void_p), ("x_div_x_sub_xi_size", C.c_uint64),
+                ("x_div_x_sub_wxi", C.c_void_p), ("x_div_x_sub_wxi_size", C.c_uint64),
+                ("q_2ns", C.c_void_p), ("q_2ns_size", C.c_uint64),
+                ("f_2ns", C.c_void_p), ("f_2ns_size", C.c_uint64)]
+
+
+def steps_params(n_const_pols=0, n_const_pols_2ns=0, **buffers):
+    """buffers: name -> device int64 tensor (members of xlp_steps_params); sizes are taken from the tensors"""
+    sp = StepsParams()
+    sp.n_const_pols, sp.n_const_pols_2ns = n_const_pols, n_const_pols_2ns
+    for name, t in buffers.items():
+        setattr(sp, name, t.data_ptr())
+        setattr(sp, name + "_size", t.numel())
+    sp._keep = buffers
+    return sp
+
+
+class ExprProgram:
+    """xlp_expr_program handle (xlp_expr_create / xlp_expr_destroy)"""
+
+    def __init__(self, code, ntmp1, ntmp3):
+        code = np.ascontiguousarray(code, dtype=np.uint64)
+        self._h = C.c_void_p(None)
+        _ck(load().xlp_expr_create(C.byref(self._h), code.ctypes.data_as(C.c_void_p), code.size, ntmp1, ntmp3), "xlp_expr_create")
+
+    def run(self, params, row0, nrows):
+        _ck(load().xlp_dev_expr_run(self._h, C.byref(params), row0, nrows), "xlp_dev_expr_run")
+
+    def close(self):
+        if self._h:
+            load().xlp_expr_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class EvmapEntry(C.Structure):

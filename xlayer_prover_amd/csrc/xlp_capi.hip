@@ -189,6 +189,17 @@ int xlp_dev_calculate_h1h2(uint64_t* h1, uint64_t* h2, const uint64_t* f, const 
     if (ensure_init()) return -1;
     return dev_calculate_h1h2(&g_ctx, h1, h2, f, t, n, dim);
 }
+int xlp_expr_create(xlp_expr_program** out, const uint64_t* code, uint64_t ncode, uint64_t ntmp1, uint64_t ntmp3)
+{
+    if (ensure_init()) return -1;
+    return expr_create(out, code, ncode, ntmp1, ntmp3);
+}
+int xlp_expr_destroy(xlp_expr_program* prog) { return expr_destroy(prog); }
+int xlp_dev_expr_run(const xlp_expr_program* prog, const xlp_steps_params* params, uint64_t row0, uint64_t nrows)
+{
+    if (ensure_init()) return -1;
+    return dev_expr_run(&g_ctx, prog, params, row0, nrows);
+}
 int xlp_dev_evmap(uint64_t* evals, const uint64_t* LEv, const uint64_t* LpEv, uint64_t n, uint32_t extend_bits, uint32_t nev,
                   const xlp_evmap_entry* entries)
 {

@@ -86,4 +86,10 @@ int dev_calculate_z(Ctx* ctx, u64* z, const u64* num, const u64* den, u64 n);
 int dev_calculate_h1h2(Ctx* ctx, u64* h1, u64* h2, const u64* f, const u64* t, u64 n, u32 dim);
 int dev_evmap(Ctx* ctx, u64* evals, const u64* LEv, const u64* LpEv, u64 n, u32 eb, u32 nev, const xlp_evmap_entry* entries);
 
+
+// expr.hip
+int expr_create(xlp_expr_program** out, const u64* code, u64 ncode, u64 ntmp1, u64 ntmp3);
+int expr_destroy(xlp_expr_program* prog);
+int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params* params, u64 row0, u64 nrows);
+
 }  // namespace xlp
