@@ -94,3 +94,49 @@ def test_expr_assembler_encoding():
     assert [int(v) for v in c[1:]] == [2, 7, 1, 64, 9, 4]
     with pytest.raises(ValueError):
         E.Operand(E.K_POLS, (1,), 1)
+
+
+REAL_STEPS = ["step2prev", "step3prev", "step3", "step42ns", "step52ns"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("step", REAL_STEPS)
+def test_expr_reference_zkevm_programs(xlp, orc, step):
+    """The reference's checked-in zkEVM (fork 9) constraint programs, converted by tools/chelpers_to_xlp.py at
+    build time (oracle/_ref/chelpers, not in the repo), on a 256-row synthetic trace: HIP VM == oracle."""
+    import os
+    from tests import expr_real as R
+    path = os.path.join(R.REF_DIR, f"zkevm.{step}.xlpexpr")
+    if not os.path.exists(path):
+        pytest.skip("converted reference programs not built (needs the reference tree at build time)")
+    code, ntmp1, ntmp3 = R.read_program(path)
+    n = 256
+    code, info = R.shrink(code, n)
+    bufs = R.buffers(orc.fill, 0x5EED0200, n, info)
+    dev = {k: xlp.from_np(v) for k, v in bufs.items()}
+    sp = xlp.steps_params(n_const_pols=info["n_const"], n_const_pols_2ns=info["n_const2"], **dev)
+    p = xlp.ExprProgram(code, ntmp1, ntmp3)
+    p.run(sp, 0, n); xlp.sync(); p.close()
+    exp = {k: v.copy() for k, v in bufs.items()}
+    orc.expr_run(code, ntmp1, ntmp3, exp, 0, n, info["n_const"], info["n_const2"])
+    changed = 0
+    for k in ("pols", "q_2ns", "f_2ns"):
+        assert (xlp.to_np(dev[k]) == exp[k]).all(), k
+        changed += int((exp[k] != bufs[k]).sum())
+    assert changed > 0
+
+
+def test_converter_covers_reference_tables():
+    """Every case of the five zkEVM parsers is recognised and the op/arg tables are consumed exactly
+    (NOPS_ / NARGS_); runs only where the reference tree is mounted."""
+    import os
+    import sys
+    ref = "/root/reference/src/starkpil/zkevm/chelpers"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not present")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import chelpers_to_xlp as conv
+    expect = {"step2prev": (2094, 6804), "step3prev": (6673, 21766), "step3": (13117, 55745), "step42ns": (18546, 94863), "step52ns": (3001, 7619)}
+    for step, (nops, nargs) in expect.items():
+        prog, ntmp1, ntmp3, info = conv.convert(f"{ref}/zkevm.chelpers.{step}.parser.cpp", f"{ref}/zkevm.chelpers.{step}.parser.hpp", step)
+        assert (info["nops"], info["nargs"]) == (nops, nargs) and info["ninstr"] >= nops

@@ -14,16 +14,33 @@
 // instructions touch neighbouring columns, which the L2 turns into whole-line reuse.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <map>
+#include <set>
 #include <string>
+#include <tuple>
 #include <vector>
 #include "gl_field.hpp"
 #include "xlp_internal.hpp"
 
+struct xlp_expr_column {            // one staged column: element (row) = buffer[off + row * stride]
+    uint32_t buf;                   // 0 pols, 1 const_pols (stride = n_const_pols), 2 const_pols_2ns
+    uint64_t off, stride;
+    bool halo, written;
+};
 struct xlp_expr_program {
-    std::vector<uint64_t> code;   // host copy (validated), used for the per-run bounds check
-    uint64_t* d_code = nullptr;
+    std::vector<uint64_t> code;   // validated user program (numbers canonical): bounds checks run on this
     uint64_t ntmp1 = 0, ntmp3 = 0;
     uint64_t ninstr = 0;
+    // compiled form (see "compile" below)
+    std::vector<uint64_t> dcode;
+    uint64_t* d_dcode = nullptr;
+    uint64_t tmp_words = 0;       // words of temporaries per row
+    uint32_t hot_words = 0;       // the first hot_words of them live in LDS
+    std::vector<xlp_expr_column> cols;
+    std::vector<uint32_t> wcols;  // indices of the written columns
+    uint64_t halo = 0, modulus = 0;
 };
 
 namespace xlp {
@@ -152,13 +169,182 @@ static int check_bounds(const xlp_expr_program* prog, const xlp_steps_params& P,
     return 0;
 }
 
+// --------------------------------------------------------------------------------------- compile
+// The user program is rewritten once, at xlp_expr_create, into a device program:
+//  * temporaries: tmp1/tmp3 indices become word offsets in one per-row array, ordered by how often the
+//    program touches them.  On the zkEVM programs 16 words take 90-100 % of all temporary accesses
+//    (the generators keep their accumulators in a few slots), so the first `hot_words` live in LDS
+//    (hot[word][thread], conflict-free ds_read_b64) and only the tail spills to the HBM scratch.
+//  * row-major operands (pols / const pols): an 8-byte gather per lane with the section's row stride costs a
+//    whole 128-byte line per element.  Every column the program names is therefore "staged": a gather kernel
+//    transposes the chunk's rows of exactly those columns into a column-major scratch cols[c][row] (canonical
+//    values, + `halo` rows for next-row operands), the VM reads and writes them fully coalesced, and a scatter
+//    kernel writes the destination columns back.  Operands that cannot be staged (a destination addressed
+//    with a row offset, a second modulus) keep the direct path; a column is either staged or direct, never both.
+//  * instruction fetch: device instructions are fixed 8-word slots (16 for the rare ones with more than 7
+//    parameter words), 8 slots = one 64-word window.  A wave holds the current window in one VGPR pair (lane i =
+//    word i), loads the next one with a single coalesced global_load at the start of the current one, and
+//    decodes with v_readlane -- so the fetch latency is hidden 8 instructions ahead instead of sitting, as a
+//    chain of dependent scalar loads that miss the 16 KiB scalar cache, in front of every instruction.
+enum { XD_TMP = 20, XD_COL = 21, XD_NOP = 7 /* op */ };
+
+static int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+struct ColKey {
+    u32 buf; u64 stride, off;
+    bool operator<(const ColKey& o) const { return std::tie(buf, stride, off) < std::tie(o.buf, o.stride, o.off); }
+};
+
+// (buffer, offset, stride, next, modulus) of a row-major operand; false if the kind is not row-major
+static bool rowmajor(const Operand& o, ColKey& k, u64& next, u64& mod)
+{
+    next = 0; mod = 0;
+    switch (o.kind) {
+    case XLP_K_POLS: k = {0, o.p[1], o.p[0]}; return true;
+    case XLP_K_POLS_PRIME: k = {0, o.p[3], o.p[0]}; next = o.p[1]; mod = o.p[2]; return true;
+    case XLP_K_CONST: k = {1, 0, o.p[0]}; return true;
+    case XLP_K_CONST_PRIME: k = {1, 0, o.p[0]}; next = o.p[1]; mod = o.p[2]; return true;
+    case XLP_K_CONST2NS: k = {2, 0, o.p[0]}; return true;
+    case XLP_K_CONST2NS_PRIME: k = {2, 0, o.p[0]}; next = o.p[1]; mod = o.p[2]; return true;
+    default: return false;
+    }
+}
+
+static void compile(xlp_expr_program* P)
+{
+    const u64* code = P->code.data();
+    const u64 ncode = P->code.size();
+    std::string msg;
+    // ---- temporaries: access counts -> word offsets, densest first
+    std::vector<u64> cnt1(P->ntmp1, 0), cnt3(P->ntmp3, 0);
+    for (u64 pc = 0; pc < ncode;) {
+        Instr in; const u64 nx = decode(code, ncode, pc, in, msg);
+        const Operand* ops[3] = {&in.d, &in.a, &in.b};
+        for (const Operand* o : ops) {
+            if (o->kind == XLP_K_TMP1) cnt1[o->p[0]]++;
+            if (o->kind == XLP_K_TMP3) cnt3[o->p[0]]++;
+        }
+        pc = nx;
+    }
+    struct Slot { u64 cnt; u32 words; u64 idx; };
+    std::vector<Slot> slots;
+    for (u64 i = 0; i < P->ntmp1; i++) slots.push_back({cnt1[i], 1, i});
+    for (u64 i = 0; i < P->ntmp3; i++) slots.push_back({cnt3[i], 3, i});
+    std::stable_sort(slots.begin(), slots.end(), [](const Slot& a, const Slot& b) { return a.cnt > b.cnt; });   // accesses per slot: a
+    std::vector<u64> w1(P->ntmp1, 0), w3(P->ntmp3, 0);                                                        // slot moves as a unit
+    u64 w = 0;
+    for (const Slot& s : slots) { (s.words == 1 ? w1 : w3)[s.idx] = w; w += s.words; }
+    P->tmp_words = w;
+    u64 hot_cap = (u64)env_int("XLP_EXPR_HOT", 8);
+    if (hot_cap > 32) hot_cap = 32;                               // 32 words x 256 threads x 8 B = the 64 KiB a launch may ask for
+    u64 hot = 0;
+    for (const Slot& s : slots) { if (hot + s.words > hot_cap) break; hot += s.words; }
+    P->hot_words = (u32)hot;
+
+    // ---- staging decisions
+    const bool stage = env_int("XLP_EXPR_STAGE", 1) != 0;
+    std::map<ColKey, int> colset;          // key -> flags (1 halo, 2 written)
+    std::set<ColKey> blocked;
+    u64 modulus = 0, halo = 0;
+    if (stage) {
+        for (u64 pc = 0; pc < ncode;) {
+            Instr in; const u64 nx = decode(code, ncode, pc, in, msg);
+            const Operand* ops[3] = {&in.d, &in.a, &in.b};
+            for (int s = 0; s < 3; s++) {
+                ColKey k; u64 next, mod;
+                if (!rowmajor(*ops[s], k, next, mod)) continue;
+                bool direct = false;
+                if (mod) {
+                    if (s == 0) direct = true;                       // destination with a row offset
+                    else if (modulus == 0) modulus = mod;
+                    else if (mod != modulus) direct = true;          // a second modulus
+                    if (next >= mod) direct = true;
+                }
+                if (direct) for (u32 c = 0; c < ops[s]->dim; c++) blocked.insert({k.buf, k.stride, k.off + c});
+            }
+            pc = nx;
+        }
+        for (bool grown = !blocked.empty(); grown;) {          // an operand that shares a column with a direct one is direct too
+            grown = false;
+            for (u64 pc = 0; pc < ncode;) {
+                Instr in; const u64 nx = decode(code, ncode, pc, in, msg);
+                const Operand* ops[3] = {&in.d, &in.a, &in.b};
+                for (int s = 0; s < 3; s++) {
+                    ColKey k; u64 next, mod;
+                    if (!rowmajor(*ops[s], k, next, mod)) continue;
+                    bool hit = false;
+                    for (u32 c = 0; c < ops[s]->dim; c++) hit |= blocked.count({k.buf, k.stride, k.off + c}) != 0;
+                    if (hit) for (u32 c = 0; c < ops[s]->dim; c++) grown |= blocked.insert({k.buf, k.stride, k.off + c}).second;
+                }
+                pc = nx;
+            }
+        }
+        for (u64 pc = 0; pc < ncode;) {
+            Instr in; const u64 nx = decode(code, ncode, pc, in, msg);
+            const Operand* ops[3] = {&in.d, &in.a, &in.b};
+            for (int s = 0; s < 3; s++) {
+                ColKey k; u64 next, mod;
+                if (!rowmajor(*ops[s], k, next, mod)) continue;
+                if (blocked.count({k.buf, k.stride, k.off})) continue;
+                for (u32 c = 0; c < ops[s]->dim; c++) {
+                    int& f = colset[{k.buf, k.stride, k.off + c}];
+                    if (mod && next) { f |= 1; if (next > halo) halo = next; }
+                    if (s == 0) f |= 2;
+                }
+            }
+            pc = nx;
+        }
+    }
+    std::map<ColKey, u32> colidx;
+    for (const auto& kv : colset) {
+        colidx[kv.first] = (u32)P->cols.size();
+        if (kv.second & 2) P->wcols.push_back((u32)P->cols.size());
+        P->cols.push_back({kv.first.buf, kv.first.off, kv.first.stride, (kv.second & 1) != 0, (kv.second & 2) != 0});
+    }
+    P->halo = halo; P->modulus = modulus;
+
+    // ---- device program
+    for (u64 pc = 0; pc < ncode;) {
+        Instr in; const u64 nx = decode(code, ncode, pc, in, msg);
+        const Operand* ops[3] = {&in.d, &in.a, &in.b};
+        u32 kinds[3], np[3];
+        std::vector<u64> prm[3];
+        for (int s = 0; s < 3; s++) {
+            const Operand& o = *ops[s];
+            ColKey k; u64 next, mod;
+            if (o.kind == XLP_K_TMP1) { kinds[s] = XD_TMP; prm[s] = {w1[o.p[0]]}; }
+            else if (o.kind == XLP_K_TMP3) { kinds[s] = XD_TMP; prm[s] = {w3[o.p[0]]}; }
+            else if (rowmajor(o, k, next, mod) && colidx.count(k)) { kinds[s] = XD_COL; prm[s] = {colidx[k], next}; }
+            else { kinds[s] = o.kind; prm[s].assign(o.p, o.p + KIND_PARAMS[o.kind]); }
+            np[s] = (u32)prm[s].size();
+        }
+        const u32 nprm = np[0] + np[1] + np[2];
+        const bool lng = nprm > 7;
+        if (lng && (P->dcode.size() / 8) % 8 == 7) { P->dcode.push_back(XD_NOP); P->dcode.resize(P->dcode.size() + 7, 0); }   // keep both halves in one window
+        const u64 head = (u64)in.op | (u64)kinds[0] << 8 | (u64)kinds[1] << 16 | (u64)kinds[2] << 24 | (u64)in.d.dim << 32 | (u64)in.a.dim << 34 |
+                         (u64)in.b.dim << 36 | (u64)np[0] << 40 | (u64)np[1] << 43 | (u64)np[2] << 46 | (u64)(lng ? 1 : 0) << 49;
+        const size_t start = P->dcode.size();
+        P->dcode.push_back(head);
+        for (int s = 0; s < 3; s++) P->dcode.insert(P->dcode.end(), prm[s].begin(), prm[s].end());
+        P->dcode.resize(start + (lng ? 16 : 8), 0);
+        pc = nx;
+    }
+    while ((P->dcode.size() / 8) % 8) { P->dcode.push_back(XD_NOP); P->dcode.resize(P->dcode.size() + 7, 0); }                    // whole windows
+}
+
 // ------------------------------------------------------------------------------------------ device
 struct ExprArgs {
     const u64* code; u64 ncode;
-    u64* tmp; u64 tstride; u64 ntmp1;
-    u64 row0, nrows;
+    u64* tmp; u64 tstride; u32 hot_words;     // spilled temporaries tmp[word - hot_words][thread]
+    const u64* cols; u64 cap;                 // staged columns cols[c][local row], cap rows each
+    u64 row0, nrows;                          // absolute first row, rows of this launch
     xlp_steps_params P;
 };
+struct ColDesc { u64* base; u64 stride; u64 flags; };   // flags bit0: halo rows wanted
 
 __device__ __forceinline__ u64 uni(u64 v)   // value is wave-uniform: keep it in SGPRs
 {
@@ -166,27 +352,48 @@ __device__ __forceinline__ u64 uni(u64 v)   // value is wave-uniform: keep it in
 }
 __device__ __forceinline__ u64 wrap(u64 r, u64 n) { return (n & (n - 1)) == 0 ? (r & (n - 1)) : r % n; }
 
-__device__ __forceinline__ e3 load_operand(const ExprArgs& A, u32 kind, u32 dim, const u64* p, u64 row, const u64* t1, const u64* t3)
+extern __shared__ u64 xlp_expr_hot[];
+
+__device__ __forceinline__ u64 rl(u64 win, u32 j)   // word j of the window (j wave-uniform)
+{
+    return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(win >> 32), (int)j) << 32) | (u64)(u32)__builtin_amdgcn_readlane((int)(u32)win, (int)j);
+}
+
+#define PRM(i) rl(win, p + (i))
+__device__ __forceinline__ e3 load_operand(const ExprArgs& A, u32 kind, u32 dim, u64 win, u32 p, u64 row, u64 gt)
 {
     e3 v; v.c[0] = v.c[1] = v.c[2] = 0;
     const u64* src = nullptr;
     switch (kind) {
-    case XLP_K_TMP1: v.c[0] = t1[uni(p[0]) * A.tstride]; return v;
-    case XLP_K_TMP3: {
-        const u64* q = t3 + 3 * uni(p[0]) * A.tstride;
-        v.c[0] = q[0]; v.c[1] = q[A.tstride]; v.c[2] = q[2 * A.tstride];
+    case XD_TMP: {
+        const u64 w = PRM(0);
+        if (w < A.hot_words) {                                  // a slot never straddles the boundary
+            const u64* q = xlp_expr_hot + w * 256 + threadIdx.x;
+            v.c[0] = q[0];
+            if (dim == 3) { v.c[1] = q[256]; v.c[2] = q[512]; }
+        } else {
+            const u64* q = A.tmp + (w - A.hot_words) * A.tstride + gt;
+            v.c[0] = q[0];
+            if (dim == 3) { v.c[1] = q[A.tstride]; v.c[2] = q[2 * A.tstride]; }
+        }
         return v;
     }
-    case XLP_K_NUMBER: v.c[0] = uni(p[0]); return v;
-    case XLP_K_POLS: src = A.P.pols + uni(p[0]) + row * uni(p[1]); break;
-    case XLP_K_POLS_PRIME: src = A.P.pols + uni(p[0]) + wrap(row + uni(p[1]), uni(p[2])) * uni(p[3]); break;
-    case XLP_K_CONST: src = A.P.const_pols + uni(p[0]) + row * A.P.n_const_pols; break;
-    case XLP_K_CONST_PRIME: src = A.P.const_pols + uni(p[0]) + wrap(row + uni(p[1]), uni(p[2])) * A.P.n_const_pols; break;
-    case XLP_K_CONST2NS: src = A.P.const_pols_2ns + uni(p[0]) + row * A.P.n_const_pols_2ns; break;
-    case XLP_K_CONST2NS_PRIME: src = A.P.const_pols_2ns + uni(p[0]) + wrap(row + uni(p[1]), uni(p[2])) * A.P.n_const_pols_2ns; break;
-    case XLP_K_CHALLENGE: src = A.P.challenges + 3 * uni(p[0]); break;
-    case XLP_K_EVAL: src = A.P.evals + 3 * uni(p[0]); break;
-    case XLP_K_PUBLIC: src = A.P.public_inputs + uni(p[0]); break;
+    case XD_COL: {
+        const u64* q = A.cols + PRM(0) * A.cap + gt + PRM(1);
+        v.c[0] = q[0];
+        if (dim == 3) { v.c[1] = q[A.cap]; v.c[2] = q[2 * A.cap]; }
+        return v;                                               // staged values are canonical already
+    }
+    case XLP_K_NUMBER: v.c[0] = PRM(0); return v;
+    case XLP_K_POLS: src = A.P.pols + PRM(0) + row * PRM(1); break;
+    case XLP_K_POLS_PRIME: src = A.P.pols + PRM(0) + wrap(row + PRM(1), PRM(2)) * PRM(3); break;
+    case XLP_K_CONST: src = A.P.const_pols + PRM(0) + row * A.P.n_const_pols; break;
+    case XLP_K_CONST_PRIME: src = A.P.const_pols + PRM(0) + wrap(row + PRM(1), PRM(2)) * A.P.n_const_pols; break;
+    case XLP_K_CONST2NS: src = A.P.const_pols_2ns + PRM(0) + row * A.P.n_const_pols_2ns; break;
+    case XLP_K_CONST2NS_PRIME: src = A.P.const_pols_2ns + PRM(0) + wrap(row + PRM(1), PRM(2)) * A.P.n_const_pols_2ns; break;
+    case XLP_K_CHALLENGE: src = A.P.challenges + 3 * PRM(0); break;
+    case XLP_K_EVAL: src = A.P.evals + 3 * PRM(0); break;
+    case XLP_K_PUBLIC: src = A.P.public_inputs + PRM(0); break;
     case XLP_K_X_N: src = A.P.x_n + row; break;
     case XLP_K_X_2NS: src = A.P.x_2ns + row; break;
     case XLP_K_ZI: src = A.P.zi + wrap(row, A.P.zi_size); break;
@@ -201,18 +408,31 @@ __device__ __forceinline__ e3 load_operand(const ExprArgs& A, u32 kind, u32 dim,
     return v;
 }
 
-__device__ __forceinline__ void store_operand(const ExprArgs& A, u32 kind, u32 dim, const u64* p, u64 row, u64* t1, u64* t3, const e3& v)
+__device__ __forceinline__ void store_operand(const ExprArgs& A, u32 kind, u32 dim, u64 win, u32 p, u64 row, u64 gt, const e3& v)
 {
     u64* dst = nullptr;
     switch (kind) {
-    case XLP_K_TMP1: t1[uni(p[0]) * A.tstride] = v.c[0]; return;
-    case XLP_K_TMP3: {
-        u64* q = t3 + 3 * uni(p[0]) * A.tstride;
-        q[0] = v.c[0]; q[A.tstride] = v.c[1]; q[2 * A.tstride] = v.c[2];
+    case XD_TMP: {
+        const u64 w = PRM(0);
+        if (w < A.hot_words) {
+            u64* q = xlp_expr_hot + w * 256 + threadIdx.x;
+            q[0] = v.c[0];
+            if (dim == 3) { q[256] = v.c[1]; q[512] = v.c[2]; }
+        } else {
+            u64* q = A.tmp + (w - A.hot_words) * A.tstride + gt;
+            q[0] = v.c[0];
+            if (dim == 3) { q[A.tstride] = v.c[1]; q[2 * A.tstride] = v.c[2]; }
+        }
         return;
     }
-    case XLP_K_POLS: dst = A.P.pols + uni(p[0]) + row * uni(p[1]); break;
-    case XLP_K_POLS_PRIME: dst = A.P.pols + uni(p[0]) + wrap(row + uni(p[1]), uni(p[2])) * uni(p[3]); break;
+    case XD_COL: {
+        u64* q = const_cast<u64*>(A.cols) + PRM(0) * A.cap + gt;
+        q[0] = v.c[0];
+        if (dim == 3) { q[A.cap] = v.c[1]; q[2 * A.cap] = v.c[2]; }
+        return;
+    }
+    case XLP_K_POLS: dst = A.P.pols + PRM(0) + row * PRM(1); break;
+    case XLP_K_POLS_PRIME: dst = A.P.pols + PRM(0) + wrap(row + PRM(1), PRM(2)) * PRM(3); break;
     case XLP_K_Q_2NS: dst = A.P.q_2ns + 3 * row; break;
     case XLP_K_F_2NS: dst = A.P.f_2ns + 3 * row; break;
     default: return;
@@ -221,45 +441,98 @@ __device__ __forceinline__ void store_operand(const ExprArgs& A, u32 kind, u32 d
     if (dim == 3) { dst[1] = v.c[1]; dst[2] = v.c[2]; }
 }
 
+// One lane per row of the launch (grid covers nrows; no row loop: temporaries and staged columns are per launch).
 __global__ __launch_bounds__(256) void expr_kernel(ExprArgs A)
 {
     const u64 gt = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u64* t1 = A.tmp + gt;
-    u64* t3 = A.tmp + A.ntmp1 * A.tstride + gt;
-    for (u64 r = gt; r < A.nrows; r += A.tstride) {
-        const u64 row = A.row0 + r;
-        u64 pc = 0;
-        while (pc < A.ncode) {
-            const u64 h = uni(A.code[pc]);
-            const u32 op = (u32)(h & 0xff), dk = (u32)((h >> 8) & 0xff), ak = (u32)((h >> 16) & 0xff), bk = (u32)((h >> 24) & 0xff);
+    const u32 lane = threadIdx.x & 63;
+    const bool live = gt < A.nrows;            // dead lanes still take part in the window loads
+    const u64 row = A.row0 + gt;
+    u64 win = A.code[lane];
+    for (u64 base = 0; base < A.ncode; base += 64) {
+        const u64 nxt = base + 64 < A.ncode ? A.code[base + 64 + lane] : 0;
+        for (u32 s = 0; s < 8;) {
+            const u64 h = rl(win, 8 * s);
+            const u32 op = (u32)(h & 0xff);
+            const bool lng = (h >> 49) & 1;
+            if (op == XD_NOP) { s++; continue; }
+            const u32 dk = (u32)((h >> 8) & 0xff), ak = (u32)((h >> 16) & 0xff), bk = (u32)((h >> 24) & 0xff);
             const u32 dd = (u32)((h >> 32) & 3), ad = (u32)((h >> 34) & 3), bd = (u32)((h >> 36) & 3);
-            // parameter words per kind, 3 bits each (KIND_PARAMS)
-            constexpr u64 NP = (1ull << 3) | (1ull << 6) | (2ull << 9) | (4ull << 12) | (1ull << 15) | (3ull << 18) | (1ull << 21) | (3ull << 24) |
-                               (1ull << 27) | (1ull << 30) | (1ull << 33) | (1ull << 36);
-            const u32 nd = (u32)((NP >> (3 * dk)) & 7), na = (u32)((NP >> (3 * ak)) & 7), nb = (u32)((NP >> (3 * bk)) & 7);
-            const u64* pd = A.code + pc + 1;
-            const u64* pa = pd + nd;
-            const u64* pb = pa + na;
-            pc += 1 + nd + na + nb;
-            const e3 a = load_operand(A, ak, ad, pa, row, t1, t3);
-            e3 v;
-            if (op == XLP_OP_COPY) v = a;
-            else {
-                const e3 b = load_operand(A, bk, bd, pb, row, t1, t3);
-                if (op == XLP_OP_ADD) {
-                    v.c[0] = gl::addc(a.c[0], b.c[0]);
-                    if (dd == 3) { v.c[1] = gl::addc(a.c[1], b.c[1]); v.c[2] = gl::addc(a.c[2], b.c[2]); }
-                } else if (op == XLP_OP_SUB) {
-                    v.c[0] = gl::subc(a.c[0], b.c[0]);
-                    if (dd == 3) { v.c[1] = gl::subc(a.c[1], b.c[1]); v.c[2] = gl::subc(a.c[2], b.c[2]); }
-                } else {
-                    if (ad == 3 && bd == 3) v = gl::mul3(a, b);
-                    else if (ad == 3) v = gl::mul3s(a, b.c[0]);
-                    else if (bd == 3) v = gl::mul3s(b, a.c[0]);
-                    else v.c[0] = gl::mulc(a.c[0], b.c[0]);
+            const u32 nd = (u32)((h >> 40) & 7), na = (u32)((h >> 43) & 7);
+            const u32 pd = 8 * s + 1, pa = pd + nd, pb = pa + na;
+            s += lng ? 2 : 1;
+            if (live) {
+                const e3 a = load_operand(A, ak, ad, win, pa, row, gt);
+                e3 v;
+                if (op == XLP_OP_COPY) v = a;
+                else {
+                    const e3 b = load_operand(A, bk, bd, win, pb, row, gt);
+                    if (op == XLP_OP_ADD) {
+                        v.c[0] = gl::addc(a.c[0], b.c[0]);
+                        if (dd == 3) { v.c[1] = gl::addc(a.c[1], b.c[1]); v.c[2] = gl::addc(a.c[2], b.c[2]); }
+                    } else if (op == XLP_OP_SUB) {
+                        v.c[0] = gl::subc(a.c[0], b.c[0]);
+                        if (dd == 3) { v.c[1] = gl::subc(a.c[1], b.c[1]); v.c[2] = gl::subc(a.c[2], b.c[2]); }
+                    } else {
+                        if (ad == 3 && bd == 3) v = gl::mul3(a, b);
+                        else if (ad == 3) v = gl::mul3s(a, b.c[0]);
+                        else if (bd == 3) v = gl::mul3s(b, a.c[0]);
+                        else v.c[0] = gl::mulc(a.c[0], b.c[0]);
+                    }
                 }
+                store_operand(A, dk, dd, win, pd, row, gt, v);
             }
-            store_operand(A, dk, dd, pd, row, t1, t3, v);
+        }
+        win = nxt;
+    }
+}
+
+// cols[c][j] = canon(base_c[((row0 + j) % modulus) * stride_c]),  j < rows (+ halo for flagged columns).
+// 64 columns x 64 rows per workgroup through LDS: reads run along the table (neighbouring entries are
+// neighbouring columns of one section -> contiguous bytes of a row), writes along the rows.
+__global__ __launch_bounds__(256) void expr_gather_kernel(u64* cols, const ColDesc* tab, u32 ncols, u64 cap, u64 row0, u64 rows, u64 halo, u64 modulus)
+{
+    __shared__ u64 tile[64][65];
+    const u32 c0 = blockIdx.x * 64, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const u64 j0 = (u64)blockIdx.y * 64;
+    const u32 c = c0 + lane;
+    ColDesc d = {nullptr, 0, 0};
+    if (c < ncols) d = tab[c];
+    for (u32 r = wv; r < 64; r += 4) {
+        const u64 j = j0 + r;
+        u64 v = 0;
+        if (c < ncols && (j < rows || (j < rows + halo && (d.flags & 1)))) {
+            u64 ar = row0 + j;
+            if (modulus) ar = wrap(ar, modulus);
+            v = gl::canon(d.base[ar * d.stride]);
+        }
+        tile[r][lane] = v;
+    }
+    __syncthreads();
+    for (u32 k = wv; k < 64; k += 4) {
+        const u64 j = j0 + lane;
+        if (c0 + k < ncols && j < rows + halo) cols[(u64)(c0 + k) * cap + j] = tile[lane][k];
+    }
+}
+
+// base_c[(row0 + j) * stride_c] = cols[c][j] for the written columns (list `wl` of table indices), j < rows.
+__global__ __launch_bounds__(256) void expr_scatter_kernel(const u64* cols, const ColDesc* tab, const u32* wl, u32 nw, u64 cap, u64 row0, u64 rows)
+{
+    __shared__ u64 tile[64][65];
+    const u32 k0 = blockIdx.x * 64, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const u64 j0 = (u64)blockIdx.y * 64;
+    for (u32 k = wv; k < 64; k += 4) {
+        const u64 j = j0 + lane;
+        u64 v = 0;
+        if (k0 + k < nw && j < rows) v = cols[(u64)wl[k0 + k] * cap + j];
+        tile[lane][k] = v;
+    }
+    __syncthreads();
+    if (k0 + lane < nw) {
+        const ColDesc d = tab[wl[k0 + lane]];
+        for (u32 r = wv; r < 64; r += 4) {
+            const u64 j = j0 + r;
+            if (j < rows) d.base[(row0 + j) * d.stride] = tile[r][lane];
         }
     }
 }
@@ -271,18 +544,50 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
     if (row0 + nrows < row0) return xlp_fail("expr run: row range overflows");
     if (params->zi && params->zi_size == 0) return xlp_fail("expr run: zi_size is 0");
     if (check_bounds(prog, *params, row0, nrows)) return -1;
-    // one lane per row, up to 8 waves per SIMD; temporaries tmp[slot][thread]
-    const u64 slots = prog->ntmp1 + 3 * prog->ntmp3;
-    u64 blocks = (nrows + 255) / 256;
-    const u64 max_blocks = (u64)ctx->ncu * 8;
-    if (blocks > max_blocks) blocks = max_blocks;
+    const xlp_steps_params& P = *params;
+    // rows per launch: one lane per row at full occupancy (8 waves per SIMD)
+    const u64 chunk_max = (u64)ctx->ncu * 8 * 256;
+    const u64 chunk = nrows < chunk_max ? nrows : chunk_max;
+    const u64 threads = (chunk + 255) / 256 * 256;
+    const u32 ncols = (u32)prog->cols.size(), nw = (u32)prog->wcols.size();
+    const u64 cap = chunk + prog->halo;
     ExprArgs A;
-    A.code = prog->d_code; A.ncode = prog->code.size();
-    A.tstride = blocks * 256; A.ntmp1 = prog->ntmp1;
-    A.row0 = row0; A.nrows = nrows; A.P = *params;
-    A.tmp = nullptr;
-    if (ctx_scratch(ctx, (slots ? slots : 1) * A.tstride * sizeof(u64), 2, &A.tmp)) return -1;
-    hipLaunchKernelGGL(expr_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, A);
+    A.code = prog->d_dcode; A.ncode = prog->dcode.size();
+    A.hot_words = prog->hot_words; A.tstride = threads; A.tmp = nullptr; A.cols = nullptr; A.cap = cap; A.P = P;
+    const u64 spill = prog->tmp_words - prog->hot_words;
+    if (spill && ctx_scratch(ctx, spill * threads * sizeof(u64), 2, &A.tmp)) return -1;
+    u64* cols = nullptr; ColDesc* d_tab = nullptr; u32* d_wl = nullptr;
+    if (ncols) {
+        if (ctx_scratch(ctx, (size_t)ncols * cap * sizeof(u64), 4, &cols)) return -1;
+        u64* raw = nullptr;
+        if (ctx_scratch(ctx, ncols * sizeof(ColDesc) + (nw ? nw : 1) * sizeof(u32), 5, &raw)) return -1;
+        d_tab = (ColDesc*)raw; d_wl = (u32*)(d_tab + ncols);
+        std::vector<ColDesc> tab(ncols);
+        for (u32 c = 0; c < ncols; c++) {
+            const xlp_expr_column& k = prog->cols[c];
+            u64* base = k.buf == 0 ? P.pols : k.buf == 1 ? const_cast<u64*>(P.const_pols) : const_cast<u64*>(P.const_pols_2ns);
+            const u64 stride = k.buf == 0 ? k.stride : k.buf == 1 ? P.n_const_pols : P.n_const_pols_2ns;
+            tab[c] = {base + k.off, stride, k.halo ? 1ull : 0ull};
+        }
+        XLP_HIP(hipMemcpyAsync(d_tab, tab.data(), ncols * sizeof(ColDesc), hipMemcpyHostToDevice, ctx->stream));
+        if (nw) XLP_HIP(hipMemcpyAsync(d_wl, prog->wcols.data(), nw * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+        XLP_HIP(hipStreamSynchronize(ctx->stream));       // `tab` is a stack object
+        A.cols = cols;
+    }
+    const size_t lds = (size_t)prog->hot_words * 256 * sizeof(u64);
+    for (u64 r0 = 0; r0 < nrows; r0 += chunk) {
+        const u64 rows = nrows - r0 < chunk ? nrows - r0 : chunk;
+        if (ncols) {
+            const dim3 grid((ncols + 63) / 64, (unsigned)((rows + prog->halo + 63) / 64));
+            hipLaunchKernelGGL(expr_gather_kernel, grid, dim3(256), 0, ctx->stream, cols, d_tab, ncols, cap, row0 + r0, rows, prog->halo, prog->modulus);
+        }
+        A.row0 = row0 + r0; A.nrows = rows;
+        hipLaunchKernelGGL(expr_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), lds, ctx->stream, A);
+        if (nw) {
+            const dim3 grid((nw + 63) / 64, (unsigned)((rows + 63) / 64));
+            hipLaunchKernelGGL(expr_scatter_kernel, grid, dim3(256), 0, ctx->stream, cols, d_tab, d_wl, nw, cap, row0 + r0, rows);
+        }
+    }
     XLP_HIP(hipGetLastError());
     return 0;
 }
@@ -309,10 +614,11 @@ int expr_create(xlp_expr_program** out, const u64* code, u64 ncode, u64 ntmp1, u
         }
     }
     p->ntmp1 = ntmp1; p->ntmp3 = ntmp3; p->ninstr = ninstr;
-    if (ncode) {
-        hipError_t e = hipMalloc((void**)&p->d_code, ncode * sizeof(u64));
-        if (e == hipSuccess) e = hipMemcpy(p->d_code, p->code.data(), ncode * sizeof(u64), hipMemcpyHostToDevice);
-        if (e != hipSuccess) { if (p->d_code) (void)hipFree(p->d_code); delete p; return xlp_fail_hip(e, __FILE__, __LINE__); }
+    compile(p);
+    if (!p->dcode.empty()) {
+        hipError_t e = hipMalloc((void**)&p->d_dcode, p->dcode.size() * sizeof(u64));
+        if (e == hipSuccess) e = hipMemcpy(p->d_dcode, p->dcode.data(), p->dcode.size() * sizeof(u64), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { if (p->d_dcode) (void)hipFree(p->d_dcode); delete p; return xlp_fail_hip(e, __FILE__, __LINE__); }
     }
     *out = p;
     return 0;
@@ -321,7 +627,7 @@ int expr_create(xlp_expr_program** out, const u64* code, u64 ncode, u64 ntmp1, u
 int expr_destroy(xlp_expr_program* p)
 {
     if (!p) return 0;
-    if (p->d_code) (void)hipFree(p->d_code);
+    if (p->d_dcode) (void)hipFree(p->d_dcode);
     delete p;
     return 0;
 }

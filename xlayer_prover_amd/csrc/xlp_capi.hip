@@ -121,7 +121,7 @@ void xlp_shutdown(void)
     (void)hipStreamSynchronize(g_ctx.stream);
     for (auto& kv : g_ctx.tables) (void)hipFree(kv.second);
     g_ctx.tables.clear();
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < 8; i++) {
         if (g_ctx.scratch[i]) (void)hipFree(g_ctx.scratch[i]);
         g_ctx.scratch[i] = nullptr;
         g_ctx.scratch_bytes[i] = 0;

@@ -544,3 +544,45 @@ inline std::string proof2zkinStark(FRIProof& proof)
     os << "}";
     return os.str();
 }
+
+// ------------------------------------------------------------------ constraint steps
+// GPU counterpart of `class ZkevmSteps : public Steps` (src/starkpil/zkevm/chelpers/zkevmSteps.hpp:10-59,
+// src/starkpil/steps.hpp:21-70).  The five parser programs are loaded from the files tools/chelpers_to_xlp.py
+// writes (one per step, converted from the generated *.parser.{cpp,hpp}); the method names and the
+// (params, nrows, nrowsBatch) signature are the reference's, with StepsParams replaced by its device-pointer
+// form xlp_steps_params (include/xlp_gl.h) because the sections stay resident in HBM between the stages.
+class XlpSteps
+{
+    xlp_expr_program* prog_[5] = {NULL, NULL, NULL, NULL, NULL};
+    static xlp_expr_program* load(const std::string& path)
+    {
+        FILE* f = fopen(path.c_str(), "rb");
+        if (!f) xlp_exit_process(("XlpSteps: cannot open " + path).c_str());
+        uint64_t hdr[4];
+        if (fread(hdr, 8, 4, f) != 4 || hdr[0] != 0x3152505845504c58ULL /* "XLPEXPR1" */) { fclose(f); xlp_exit_process(("XlpSteps: bad header in " + path).c_str()); }
+        std::vector<uint64_t> code(hdr[3]);
+        if (hdr[3] && fread(code.data(), 8, hdr[3], f) != hdr[3]) { fclose(f); xlp_exit_process(("XlpSteps: short read on " + path).c_str()); }
+        fclose(f);
+        xlp_expr_program* p = NULL;
+        XLP_CHECK(xlp_expr_create(&p, code.data(), code.size(), hdr[1], hdr[2]));
+        return p;
+    }
+    void run(int k, const xlp_steps_params& params, uint64_t nrows) { XLP_CHECK(xlp_dev_expr_run(prog_[k], &params, 0, nrows)); }
+
+public:
+    // dir/<name>.step2prev.xlpexpr ... dir/<name>.step52ns.xlpexpr
+    XlpSteps(const std::string& dir, const std::string& name)
+    {
+        static const char* steps[5] = {"step2prev", "step3prev", "step3", "step42ns", "step52ns"};
+        for (int k = 0; k < 5; k++) prog_[k] = load(dir + "/" + name + "." + steps[k] + ".xlpexpr");
+    }
+    ~XlpSteps() { for (int k = 0; k < 5; k++) xlp_expr_destroy(prog_[k]); }
+    XlpSteps(const XlpSteps&) = delete;
+    XlpSteps& operator=(const XlpSteps&) = delete;
+    // nrowsBatch is the reference's SIMD batch (4 / 8, starks.cpp:70-80); one row per lane here, so it is ignored
+    void step2prev_parser_first_avx(const xlp_steps_params& params, uint64_t nrows, uint64_t) { run(0, params, nrows); }
+    void step3prev_parser_first_avx(const xlp_steps_params& params, uint64_t nrows, uint64_t) { run(1, params, nrows); }
+    void step3_parser_first_avx(const xlp_steps_params& params, uint64_t nrows, uint64_t) { run(2, params, nrows); }
+    void step42ns_parser_first_avx(const xlp_steps_params& params, uint64_t nrows, uint64_t) { run(3, params, nrows); }
+    void step52ns_parser_first_avx(const xlp_steps_params& params, uint64_t nrows, uint64_t) { run(4, params, nrows); }
+};
