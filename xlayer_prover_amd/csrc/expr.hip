@@ -360,95 +360,165 @@ __device__ __forceinline__ u64 rl(u64 win, u32 j)   // word j of the window (j w
 }
 
 #define PRM(i) rl(win, p + (i))
-__device__ __forceinline__ e3 load_operand(const ExprArgs& A, u32 kind, u32 dim, u64 win, u32 p, u64 row, u64 gt)
+// R rows per lane: row r of a lane is virtual thread vt = gt + r * T (T = threads of the launch), so every
+// per-row access below stays coalesced; decoding (scalar unit, shared by the 4 SIMDs of a CU and the bottleneck
+// of a one-row-per-lane interpreter) is paid once per R rows.
+template <int R>
+struct Rows { e3 r[R]; };
+
+template <int R>
+__device__ __forceinline__ void load_operand(Rows<R>& out, const ExprArgs& A, u32 kind, u32 dim, u64 win, u32 p, const u64 (&ro)[R], u64 gt, u64 T)
 {
-    e3 v; v.c[0] = v.c[1] = v.c[2] = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) out.r[r].c[0] = out.r[r].c[1] = out.r[r].c[2] = 0;
     const u64* src = nullptr;
+    u64 rstride = 0;                       // element distance between consecutive rows of `src`
     switch (kind) {
     case XD_TMP: {
         const u64 w = PRM(0);
         if (w < A.hot_words) {                                  // a slot never straddles the boundary
-            const u64* q = xlp_expr_hot + w * 256 + threadIdx.x;
-            v.c[0] = q[0];
-            if (dim == 3) { v.c[1] = q[256]; v.c[2] = q[512]; }
+            const u64* q = xlp_expr_hot + w * (R * 256) + threadIdx.x;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                out.r[r].c[0] = q[r * 256];
+                if (dim == 3) { out.r[r].c[1] = q[(R + r) * 256]; out.r[r].c[2] = q[(2 * R + r) * 256]; }
+            }
         } else {
             const u64* q = A.tmp + (w - A.hot_words) * A.tstride + gt;
-            v.c[0] = q[0];
-            if (dim == 3) { v.c[1] = q[A.tstride]; v.c[2] = q[2 * A.tstride]; }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                out.r[r].c[0] = q[r * T];
+                if (dim == 3) { out.r[r].c[1] = q[A.tstride + r * T]; out.r[r].c[2] = q[2 * A.tstride + r * T]; }
+            }
         }
-        return v;
+        return;
     }
     case XD_COL: {
         const u64* q = A.cols + PRM(0) * A.cap + gt + PRM(1);
-        v.c[0] = q[0];
-        if (dim == 3) { v.c[1] = q[A.cap]; v.c[2] = q[2 * A.cap]; }
-        return v;                                               // staged values are canonical already
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            out.r[r].c[0] = q[r * T];
+            if (dim == 3) { out.r[r].c[1] = q[A.cap + r * T]; out.r[r].c[2] = q[2 * A.cap + r * T]; }
+        }
+        return;                                                 // staged values are canonical already
     }
-    case XLP_K_NUMBER: v.c[0] = PRM(0); return v;
-    case XLP_K_POLS: src = A.P.pols + PRM(0) + row * PRM(1); break;
-    case XLP_K_POLS_PRIME: src = A.P.pols + PRM(0) + wrap(row + PRM(1), PRM(2)) * PRM(3); break;
-    case XLP_K_CONST: src = A.P.const_pols + PRM(0) + row * A.P.n_const_pols; break;
-    case XLP_K_CONST_PRIME: src = A.P.const_pols + PRM(0) + wrap(row + PRM(1), PRM(2)) * A.P.n_const_pols; break;
-    case XLP_K_CONST2NS: src = A.P.const_pols_2ns + PRM(0) + row * A.P.n_const_pols_2ns; break;
-    case XLP_K_CONST2NS_PRIME: src = A.P.const_pols_2ns + PRM(0) + wrap(row + PRM(1), PRM(2)) * A.P.n_const_pols_2ns; break;
+    case XLP_K_NUMBER: {
+        const u64 v = PRM(0);
+#pragma unroll
+        for (int r = 0; r < R; r++) out.r[r].c[0] = v;
+        return;
+    }
+    case XLP_K_POLS_PRIME: case XLP_K_CONST_PRIME: case XLP_K_CONST2NS_PRIME: {     // direct next-row operands (rare): per row
+        const u64* base = kind == XLP_K_POLS_PRIME ? A.P.pols : kind == XLP_K_CONST_PRIME ? A.P.const_pols : A.P.const_pols_2ns;
+        const u64 st = kind == XLP_K_POLS_PRIME ? PRM(3) : kind == XLP_K_CONST_PRIME ? A.P.n_const_pols : A.P.n_const_pols_2ns;
+        const u64 off = PRM(0), nx = PRM(1), md = PRM(2);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const u64* q = base + off + wrap(ro[r] + nx, md) * st;
+            out.r[r].c[0] = gl::canon(q[0]);
+            if (dim == 3) { out.r[r].c[1] = gl::canon(q[1]); out.r[r].c[2] = gl::canon(q[2]); }
+        }
+        return;
+    }
+    case XLP_K_ZI: {
+#pragma unroll
+        for (int r = 0; r < R; r++) out.r[r].c[0] = gl::canon(A.P.zi[wrap(ro[r], A.P.zi_size)]);
+        return;
+    }
+    case XLP_K_POLS: rstride = PRM(1); src = A.P.pols + PRM(0); break;
+    case XLP_K_CONST: rstride = A.P.n_const_pols; src = A.P.const_pols + PRM(0); break;
+    case XLP_K_CONST2NS: rstride = A.P.n_const_pols_2ns; src = A.P.const_pols_2ns + PRM(0); break;
     case XLP_K_CHALLENGE: src = A.P.challenges + 3 * PRM(0); break;
     case XLP_K_EVAL: src = A.P.evals + 3 * PRM(0); break;
     case XLP_K_PUBLIC: src = A.P.public_inputs + PRM(0); break;
-    case XLP_K_X_N: src = A.P.x_n + row; break;
-    case XLP_K_X_2NS: src = A.P.x_2ns + row; break;
-    case XLP_K_ZI: src = A.P.zi + wrap(row, A.P.zi_size); break;
-    case XLP_K_XDIVXSUBXI: src = A.P.x_div_x_sub_xi + 3 * row; break;
-    case XLP_K_XDIVXSUBWXI: src = A.P.x_div_x_sub_wxi + 3 * row; break;
-    case XLP_K_Q_2NS: src = A.P.q_2ns + 3 * row; break;
-    case XLP_K_F_2NS: src = A.P.f_2ns + 3 * row; break;
-    default: return v;
+    case XLP_K_X_N: rstride = 1; src = A.P.x_n; break;
+    case XLP_K_X_2NS: rstride = 1; src = A.P.x_2ns; break;
+    case XLP_K_XDIVXSUBXI: rstride = 3; src = A.P.x_div_x_sub_xi; break;
+    case XLP_K_XDIVXSUBWXI: rstride = 3; src = A.P.x_div_x_sub_wxi; break;
+    case XLP_K_Q_2NS: rstride = 3; src = A.P.q_2ns; break;
+    case XLP_K_F_2NS: rstride = 3; src = A.P.f_2ns; break;
+    default: return;
     }
-    v.c[0] = gl::canon(src[0]);
-    if (dim == 3) { v.c[1] = gl::canon(src[1]); v.c[2] = gl::canon(src[2]); }
-    return v;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const u64* q = src + ro[r] * rstride;
+        out.r[r].c[0] = gl::canon(q[0]);
+        if (dim == 3) { out.r[r].c[1] = gl::canon(q[1]); out.r[r].c[2] = gl::canon(q[2]); }
+    }
 }
 
-__device__ __forceinline__ void store_operand(const ExprArgs& A, u32 kind, u32 dim, u64 win, u32 p, u64 row, u64 gt, const e3& v)
+template <int R>
+__device__ __forceinline__ void store_operand(const ExprArgs& A, u32 kind, u32 dim, u64 win, u32 p, const u64 (&ro)[R], u64 gt, u64 T, u64 nrows, const Rows<R>& v)
 {
     u64* dst = nullptr;
+    u64 rstride = 0;
     switch (kind) {
-    case XD_TMP: {
+    case XD_TMP: {                                               // rows past the end compute garbage in their own slots: harmless
         const u64 w = PRM(0);
         if (w < A.hot_words) {
-            u64* q = xlp_expr_hot + w * 256 + threadIdx.x;
-            q[0] = v.c[0];
-            if (dim == 3) { q[256] = v.c[1]; q[512] = v.c[2]; }
+            u64* q = xlp_expr_hot + w * (R * 256) + threadIdx.x;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                q[r * 256] = v.r[r].c[0];
+                if (dim == 3) { q[(R + r) * 256] = v.r[r].c[1]; q[(2 * R + r) * 256] = v.r[r].c[2]; }
+            }
         } else {
             u64* q = A.tmp + (w - A.hot_words) * A.tstride + gt;
-            q[0] = v.c[0];
-            if (dim == 3) { q[A.tstride] = v.c[1]; q[2 * A.tstride] = v.c[2]; }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                q[r * T] = v.r[r].c[0];
+                if (dim == 3) { q[A.tstride + r * T] = v.r[r].c[1]; q[2 * A.tstride + r * T] = v.r[r].c[2]; }
+            }
         }
         return;
     }
     case XD_COL: {
         u64* q = const_cast<u64*>(A.cols) + PRM(0) * A.cap + gt;
-        q[0] = v.c[0];
-        if (dim == 3) { q[A.cap] = v.c[1]; q[2 * A.cap] = v.c[2]; }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (gt + r * T >= nrows) continue;
+            q[r * T] = v.r[r].c[0];
+            if (dim == 3) { q[A.cap + r * T] = v.r[r].c[1]; q[2 * A.cap + r * T] = v.r[r].c[2]; }
+        }
         return;
     }
-    case XLP_K_POLS: dst = A.P.pols + PRM(0) + row * PRM(1); break;
-    case XLP_K_POLS_PRIME: dst = A.P.pols + PRM(0) + wrap(row + PRM(1), PRM(2)) * PRM(3); break;
-    case XLP_K_Q_2NS: dst = A.P.q_2ns + 3 * row; break;
-    case XLP_K_F_2NS: dst = A.P.f_2ns + 3 * row; break;
+    case XLP_K_POLS_PRIME: {
+        const u64 off = PRM(0), nx = PRM(1), md = PRM(2), st = PRM(3);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (gt + r * T >= nrows) continue;
+            u64* q = A.P.pols + off + wrap(ro[r] + nx, md) * st;
+            q[0] = v.r[r].c[0];
+            if (dim == 3) { q[1] = v.r[r].c[1]; q[2] = v.r[r].c[2]; }
+        }
+        return;
+    }
+    case XLP_K_POLS: rstride = PRM(1); dst = A.P.pols + PRM(0); break;
+    case XLP_K_Q_2NS: rstride = 3; dst = A.P.q_2ns; break;
+    case XLP_K_F_2NS: rstride = 3; dst = A.P.f_2ns; break;
     default: return;
     }
-    dst[0] = v.c[0];
-    if (dim == 3) { dst[1] = v.c[1]; dst[2] = v.c[2]; }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if (gt + r * T >= nrows) continue;
+        u64* q = dst + ro[r] * rstride;
+        q[0] = v.r[r].c[0];
+        if (dim == 3) { q[1] = v.r[r].c[1]; q[2] = v.r[r].c[2]; }
+    }
 }
 
-// One lane per row of the launch (grid covers nrows; no row loop: temporaries and staged columns are per launch).
+// Lane gt evaluates rows row0 + gt + r * T, r < R (T = threads of the launch >= ceil(nrows / R)).
+template <int R>
 __global__ __launch_bounds__(256) void expr_kernel(ExprArgs A)
 {
+    const u64 T = (u64)gridDim.x * blockDim.x;
     const u64 gt = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u32 lane = threadIdx.x & 63;
-    const bool live = gt < A.nrows;            // dead lanes still take part in the window loads
-    const u64 row = A.row0 + gt;
+    u64 ro[R];       // absolute row of each of the lane's rows; rows past the end read the last row (in bounds), their stores are masked
+#pragma unroll
+    for (int r = 0; r < R; r++) { const u64 vt = gt + r * T; ro[r] = A.row0 + (vt < A.nrows ? vt : A.nrows - 1); }
     u64 win = A.code[lane];
+    asm volatile("" : "+v"(win));              // wait for the first window HERE: left pending, the wait lands in the loop header
     for (u64 base = 0; base < A.ncode; base += 64) {
         const u64 nxt = base + 64 < A.ncode ? A.code[base + 64 + lane] : 0;
         for (u32 s = 0; s < 8;) {
@@ -461,27 +531,33 @@ __global__ __launch_bounds__(256) void expr_kernel(ExprArgs A)
             const u32 nd = (u32)((h >> 40) & 7), na = (u32)((h >> 43) & 7);
             const u32 pd = 8 * s + 1, pa = pd + nd, pb = pa + na;
             s += lng ? 2 : 1;
-            if (live) {
-                const e3 a = load_operand(A, ak, ad, win, pa, row, gt);
-                e3 v;
-                if (op == XLP_OP_COPY) v = a;
-                else {
-                    const e3 b = load_operand(A, bk, bd, win, pb, row, gt);
+            Rows<R> a, v;
+            load_operand<R>(a, A, ak, ad, win, pa, ro, gt, T);
+            if (op == XLP_OP_COPY) v = a;
+            else {
+                Rows<R> b;
+                load_operand<R>(b, A, bk, bd, win, pb, ro, gt, T);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    e3& o = v.r[r];
+                    const e3& x = a.r[r];
+                    const e3& y = b.r[r];
+                    o.c[0] = o.c[1] = o.c[2] = 0;
                     if (op == XLP_OP_ADD) {
-                        v.c[0] = gl::addc(a.c[0], b.c[0]);
-                        if (dd == 3) { v.c[1] = gl::addc(a.c[1], b.c[1]); v.c[2] = gl::addc(a.c[2], b.c[2]); }
+                        o.c[0] = gl::addc(x.c[0], y.c[0]);
+                        if (dd == 3) { o.c[1] = gl::addc(x.c[1], y.c[1]); o.c[2] = gl::addc(x.c[2], y.c[2]); }
                     } else if (op == XLP_OP_SUB) {
-                        v.c[0] = gl::subc(a.c[0], b.c[0]);
-                        if (dd == 3) { v.c[1] = gl::subc(a.c[1], b.c[1]); v.c[2] = gl::subc(a.c[2], b.c[2]); }
+                        o.c[0] = gl::subc(x.c[0], y.c[0]);
+                        if (dd == 3) { o.c[1] = gl::subc(x.c[1], y.c[1]); o.c[2] = gl::subc(x.c[2], y.c[2]); }
                     } else {
-                        if (ad == 3 && bd == 3) v = gl::mul3(a, b);
-                        else if (ad == 3) v = gl::mul3s(a, b.c[0]);
-                        else if (bd == 3) v = gl::mul3s(b, a.c[0]);
-                        else v.c[0] = gl::mulc(a.c[0], b.c[0]);
+                        if (ad == 3 && bd == 3) o = gl::mul3(x, y);
+                        else if (ad == 3) o = gl::mul3s(x, y.c[0]);
+                        else if (bd == 3) o = gl::mul3s(y, x.c[0]);
+                        else o.c[0] = gl::mulc(x.c[0], y.c[0]);
                     }
                 }
-                store_operand(A, dk, dd, win, pd, row, gt, v);
             }
+            store_operand<R>(A, dk, dd, win, pd, ro, gt, T, A.nrows, v);
         }
         win = nxt;
     }
@@ -545,17 +621,19 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
     if (params->zi && params->zi_size == 0) return xlp_fail("expr run: zi_size is 0");
     if (check_bounds(prog, *params, row0, nrows)) return -1;
     const xlp_steps_params& P = *params;
-    // rows per launch: one lane per row at full occupancy (8 waves per SIMD)
+    // rows per launch: 2^19-class slabs; R rows per lane
+    int R = env_int("XLP_EXPR_ROWS", 2);
+    if (R != 1 && R != 2 && R != 4) R = 2;
     const u64 chunk_max = (u64)ctx->ncu * 8 * 256;
     const u64 chunk = nrows < chunk_max ? nrows : chunk_max;
-    const u64 threads = (chunk + 255) / 256 * 256;
+    const u64 threads_max = ((chunk + R - 1) / R + 255) / 256 * 256;     // lanes of the largest launch
     const u32 ncols = (u32)prog->cols.size(), nw = (u32)prog->wcols.size();
-    const u64 cap = chunk + prog->halo;
+    const u64 cap = (u64)R * threads_max + prog->halo;
     ExprArgs A;
     A.code = prog->d_dcode; A.ncode = prog->dcode.size();
-    A.hot_words = prog->hot_words; A.tstride = threads; A.tmp = nullptr; A.cols = nullptr; A.cap = cap; A.P = P;
+    A.hot_words = prog->hot_words; A.tstride = (u64)R * threads_max; A.tmp = nullptr; A.cols = nullptr; A.cap = cap; A.P = P;
     const u64 spill = prog->tmp_words - prog->hot_words;
-    if (spill && ctx_scratch(ctx, spill * threads * sizeof(u64), 2, &A.tmp)) return -1;
+    if (spill && ctx_scratch(ctx, spill * A.tstride * sizeof(u64), 2, &A.tmp)) return -1;
     u64* cols = nullptr; ColDesc* d_tab = nullptr; u32* d_wl = nullptr;
     if (ncols) {
         if (ctx_scratch(ctx, (size_t)ncols * cap * sizeof(u64), 4, &cols)) return -1;
@@ -574,7 +652,7 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
         XLP_HIP(hipStreamSynchronize(ctx->stream));       // `tab` is a stack object
         A.cols = cols;
     }
-    const size_t lds = (size_t)prog->hot_words * 256 * sizeof(u64);
+    const size_t lds = (size_t)prog->hot_words * R * 256 * sizeof(u64);
     for (u64 r0 = 0; r0 < nrows; r0 += chunk) {
         const u64 rows = nrows - r0 < chunk ? nrows - r0 : chunk;
         if (ncols) {
@@ -582,7 +660,10 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
             hipLaunchKernelGGL(expr_gather_kernel, grid, dim3(256), 0, ctx->stream, cols, d_tab, ncols, cap, row0 + r0, rows, prog->halo, prog->modulus);
         }
         A.row0 = row0 + r0; A.nrows = rows;
-        hipLaunchKernelGGL(expr_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), lds, ctx->stream, A);
+        const dim3 vgrid((unsigned)((((rows + R - 1) / R) + 255) / 256));
+        if (R == 1) hipLaunchKernelGGL(expr_kernel<1>, vgrid, dim3(256), lds, ctx->stream, A);
+        else if (R == 2) hipLaunchKernelGGL(expr_kernel<2>, vgrid, dim3(256), lds, ctx->stream, A);
+        else hipLaunchKernelGGL(expr_kernel<4>, vgrid, dim3(256), lds, ctx->stream, A);
         if (nw) {
             const dim3 grid((nw + 63) / 64, (unsigned)((rows + 63) / 64));
             hipLaunchKernelGGL(expr_scatter_kernel, grid, dim3(256), 0, ctx->stream, cols, d_tab, d_wl, nw, cap, row0 + r0, rows);
