@@ -173,6 +173,14 @@ typedef struct xlp_steps_params {       /* StepsParams, steps.hpp:4-19; all devi
 typedef struct xlp_expr_program xlp_expr_program;
 int xlp_expr_create(xlp_expr_program** out, const uint64_t* code, uint64_t ncode, uint64_t ntmp1, uint64_t ntmp3);
 int xlp_expr_destroy(xlp_expr_program* prog);
+/* Ahead-of-time path (the counterpart of the reference's generated straight-line chelpers,
+ * src/starkpil/zkevm/chelpers/zkevm.chelpers.step3prev.cpp): write the program as HIP source (segments of
+ * straight-line kernels, temporaries in registers), build it with
+ *     hipcc -O3 --offload-arch=gfx950 -shared -fPIC -I xlayer_prover_amd/csrc <src> -o <plugin.so>
+ * and attach the plugin; xlp_dev_expr_run then launches the compiled kernels instead of the interpreter.
+ * xlp_expr_attach refuses a plugin generated from a different program. */
+int xlp_expr_codegen(const xlp_expr_program* prog, const char* hip_source_path);
+int xlp_expr_attach(xlp_expr_program* prog, const char* plugin_so_path);
 /* Evaluate the program on rows row0 .. row0 + nrows - 1 (asynchronous on the context's stream). */
 int xlp_dev_expr_run(const xlp_expr_program* prog, const xlp_steps_params* params, uint64_t row0, uint64_t nrows);
 

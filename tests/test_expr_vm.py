@@ -1,5 +1,7 @@
 """Constraint-expression VM (csrc/expr.hip) against the oracle interpreter on seeded random
 programs that use every operand kind, op and dimension combination, plus the rejection paths."""
+import os
+
 import numpy as np
 import pytest
 
@@ -103,7 +105,8 @@ REAL_STEPS = ["step2prev", "step3prev", "step3", "step42ns", "step52ns"]
 @pytest.mark.parametrize("step", REAL_STEPS)
 def test_expr_reference_zkevm_programs(xlp, orc, step):
     """The reference's checked-in zkEVM (fork 9) constraint programs, converted by tools/chelpers_to_xlp.py at
-    build time (oracle/_ref/chelpers, not in the repo), on a 256-row synthetic trace: HIP VM == oracle."""
+    build time (oracle/_ref/chelpers, not in the repo), on a 256-row synthetic trace: HIP VM == oracle,
+    interpreted and compiled."""
     import os
     from tests import expr_real as R
     path = os.path.join(R.REF_DIR, f"zkevm.{step}.xlpexpr")
@@ -116,7 +119,7 @@ def test_expr_reference_zkevm_programs(xlp, orc, step):
     dev = {k: xlp.from_np(v) for k, v in bufs.items()}
     sp = xlp.steps_params(n_const_pols=info["n_const"], n_const_pols_2ns=info["n_const2"], **dev)
     p = xlp.ExprProgram(code, ntmp1, ntmp3)
-    p.run(sp, 0, n); xlp.sync(); p.close()
+    p.run(sp, 0, n); xlp.sync()
     exp = {k: v.copy() for k, v in bufs.items()}
     orc.expr_run(code, ntmp1, ntmp3, exp, 0, n, info["n_const"], info["n_const2"])
     changed = 0
@@ -124,6 +127,43 @@ def test_expr_reference_zkevm_programs(xlp, orc, step):
         assert (xlp.to_np(dev[k]) == exp[k]).all(), k
         changed += int((exp[k] != bufs[k]).sum())
     assert changed > 0
+    # the same program compiled ahead of time (tools/build_expr_plugins.py, built where hipcc + the reference are)
+    so = os.path.join(R.REF_DIR, f"zkevm.{step}.n8.so")
+    if os.path.exists(so):
+        dev2 = {k: xlp.from_np(v) for k, v in bufs.items()}
+        sp2 = xlp.steps_params(n_const_pols=info["n_const"], n_const_pols_2ns=info["n_const2"], **dev2)
+        p.attach(so)
+        p.run(sp2, 0, n); xlp.sync()
+        for k in ("pols", "q_2ns", "f_2ns"):
+            assert (xlp.to_np(dev2[k]) == exp[k]).all(), "compiled " + k
+    p.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,ninstr,row0,nrows", [(21, 512, 120, 0, 512), (22, 1000, 400, 37, 900), (23, 1 << 14, 700, 0, 1 << 14)])
+def test_expr_compiled_random_programs_vs_oracle(xlp, orc, tmp_path, seed, n, ninstr, row0, nrows):
+    """codegen -> hipcc -> attach on the GPU box, then the compiled kernels against the oracle (and a plugin
+    generated from another program is refused)"""
+    import shutil
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    prog, width = random_program(seed, n, ninstr)
+    bufs = make_buffers(orc, 0x5EED0300 + seed, n, width)
+    dev = {k: xlp.from_np(v) for k, v in bufs.items()}
+    sp = xlp.steps_params(n_const_pols=5, n_const_pols_2ns=4, **dev)
+    p = xlp.ExprProgram(prog.code, prog.ntmp1, prog.ntmp3)
+    so = p.compile(str(tmp_path), "rnd", parts=4)
+    p.run(sp, row0, nrows); xlp.sync()
+    exp = {k: v.copy() for k, v in bufs.items()}
+    orc.expr_run(prog.code, prog.ntmp1, prog.ntmp3, exp, row0, nrows, 5, 4)
+    for k in ("pols", "q_2ns", "f_2ns"):
+        got = xlp.to_np(dev[k])
+        assert (got == exp[k]).all(), f"{k}: {np.flatnonzero(got != exp[k])[:5]}"
+    other, _ = random_program(seed + 100, n, 50)
+    q = xlp.ExprProgram(other.code, other.ntmp1, other.ntmp3)
+    with pytest.raises(xlp.XlpError, match="different program"):
+        q.attach(so)
+    p.close(); q.close()
 
 
 def test_converter_covers_reference_tables():
@@ -140,3 +180,66 @@ def test_converter_covers_reference_tables():
     for step, (nops, nargs) in expect.items():
         prog, ntmp1, ntmp3, info = conv.convert(f"{ref}/zkevm.chelpers.{step}.parser.cpp", f"{ref}/zkevm.chelpers.{step}.parser.hpp", step)
         assert (info["nops"], info["nargs"]) == (nops, nargs) and info["ninstr"] >= nops
+
+
+def _run_generated_on_cpu(tmp_path, code, ntmp1, ntmp3, bufs, row0, nrows, nconst, nconst2):
+    """codegen (no GPU needed) -> host compiler with the CPU stand-ins of tests/jit_cpu + ASan -> run"""
+    import os
+    import subprocess
+    from xlayer_prover_amd import capi
+    here = os.path.dirname(os.path.abspath(__file__))
+    p = capi.ExprProgram(code, ntmp1, ntmp3)
+    src = str(tmp_path / "prog.hip")
+    p.codegen(src); p.close()
+    exe = str(tmp_path / "harness")
+    subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-std=c++17", "-x", "c++",
+                           f"-DPLUGIN_SRC=\"{src}\"", "-I", os.path.join(here, "jit_cpu"), "-I", os.path.join(here, "..", "xlayer_prover_amd", "csrc"),
+                           os.path.join(here, "jit_cpu", "harness.cpp"), "-o", exe])
+    order = ["pols", "const_pols", "const_pols_2ns", "challenges", "public_inputs", "evals", "x_n", "x_2ns", "zi", "x_div_x_sub_xi",
+             "x_div_x_sub_wxi", "q_2ns", "f_2ns"]
+    with open(tmp_path / "in.bin", "wb") as f:
+        f.write(np.array([row0, nrows, nconst, nconst2, 0, 0, 0, 0], np.uint64).tobytes())
+        for k in order:
+            f.write(np.array([bufs[k].size], np.uint64).tobytes()); f.write(bufs[k].tobytes())
+    r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    raw = np.fromfile(tmp_path / "out.bin", dtype=np.uint64)
+    out, q = {}, 0
+    for k in ("pols", "q_2ns", "f_2ns"):
+        n = int(raw[q]); out[k] = raw[q + 1:q + 1 + n]; q += 1 + n
+    return out
+
+
+@pytest.mark.parametrize("seed,n,ninstr,row0,nrows", [(31, 64, 150, 0, 64), (32, 300, 700, 11, 250)])
+def test_expr_generated_code_on_cpu(orc, tmp_path, seed, n, ninstr, row0, nrows):
+    """The ahead-of-time generator's output (same text hipcc compiles) against the oracle, on the CPU under
+    AddressSanitizer: segmenting, liveness across segments, value forwarding and the staged-column indexing."""
+    os.environ["XLP_EXPR_SEG"] = "64"
+    try:
+        prog, width = random_program(seed, n, ninstr)
+        bufs = make_buffers(orc, 0x5EED0400 + seed, n, width)
+        got = _run_generated_on_cpu(tmp_path, prog.code, prog.ntmp1, prog.ntmp3, bufs, row0, nrows, 5, 4)
+    finally:
+        del os.environ["XLP_EXPR_SEG"]
+    exp = {k: v.copy() for k, v in bufs.items()}
+    orc.expr_run(prog.code, prog.ntmp1, prog.ntmp3, exp, row0, nrows, 5, 4)
+    for k in ("pols", "q_2ns", "f_2ns"):
+        assert (got[k] == exp[k]).all(), f"{k}: {np.flatnonzero(got[k] != exp[k])[:5]}"
+
+
+@pytest.mark.parametrize("step", ["step2prev"])
+def test_expr_generated_code_on_cpu_reference_programs(orc, tmp_path, step):
+    """same CPU check on two of the converted reference programs (64-row synthetic slab)"""
+    from tests import expr_real as R
+    path = os.path.join(R.REF_DIR, f"zkevm.{step}.xlpexpr")
+    if not os.path.exists(path):
+        pytest.skip("converted reference programs not built (needs the reference tree at build time)")
+    code, ntmp1, ntmp3 = R.read_program(path)
+    n = 64
+    code, info = R.shrink(code, n)
+    bufs = R.buffers(orc.fill, 0x5EED0500, n, info)
+    got = _run_generated_on_cpu(tmp_path, code, ntmp1, ntmp3, bufs, 0, n, info["n_const"], info["n_const2"])
+    exp = {k: v.copy() for k, v in bufs.items()}
+    orc.expr_run(code, ntmp1, ntmp3, exp, 0, n, info["n_const"], info["n_const2"])
+    for k in ("pols", "q_2ns", "f_2ns"):
+        assert (got[k] == exp[k]).all(), k

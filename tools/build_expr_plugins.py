@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Ahead-of-time plugins for the converted zkEVM programs on the synthetic slab the tests / benchmarks use
+(tests/expr_real.py: sections packed for n rows).  Writes oracle/_ref/chelpers/zkevm.<step>.n<log2 n>.so next to
+the converted programs (git-ignored, travels to the GPU box).  Needs hipcc, no GPU.
+    python tools/build_expr_plugins.py --log-rows 8,19 [--steps step3,...] [--parts 8]"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests import expr_real as R
+from xlayer_prover_amd import capi
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log-rows", default="8,19")
+    ap.add_argument("--steps", default="step2prev,step3prev,step3,step42ns,step52ns")
+    ap.add_argument("--parts", type=int, default=8)
+    ap.add_argument("--force", action="store_true")
+    a = ap.parse_args()
+    for lr in [int(x) for x in a.log_rows.split(",")]:
+        for step in a.steps.split(","):
+            src = os.path.join(R.REF_DIR, f"zkevm.{step}.xlpexpr")
+            name = f"zkevm.{step}.n{lr}"
+            so = os.path.join(R.REF_DIR, name + ".so")
+            if not os.path.exists(src):
+                print("missing", src); continue
+            code, ntmp1, ntmp3 = R.read_program(src)
+            code, _ = R.shrink(code, 1 << lr)
+            p = capi.ExprProgram(code, ntmp1, ntmp3)
+            # regenerate the launcher text (cheap) and rebuild only if it changed: its signature covers the whole
+            # compiled program, so a change of the library's compile step invalidates the plugin too
+            build = os.path.join(R.REF_DIR, "build")
+            os.makedirs(build, exist_ok=True)
+            probe = os.path.join(build, name + ".probe.hip")
+            p.codegen(probe)
+            stamp = os.path.join(build, name + ".stamp")
+            sig = [l for l in open(probe) if "xlpjit_signature" in l][0]
+            if os.path.exists(so) and os.path.exists(stamp) and open(stamp).read() == sig and not a.force:
+                print("up to date", so); continue
+            t = time.time()
+            p.compile(build, name, parts=a.parts)
+            os.replace(os.path.join(build, name + ".so"), so)
+            open(stamp, "w").write(sig)
+            print(f"{so}: {time.time() - t:.1f} s", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -44,6 +44,8 @@ SIGNATURES = {
     "xlp_dev_calculate_h1h2": [_pu, _pu, _pu, _pu, _u64, _u32],
     "xlp_expr_create": [C.POINTER(C.c_void_p), _pu, _u64, _u64, _u64],
     "xlp_expr_destroy": [_pu],
+    "xlp_expr_codegen": [_pu, C.c_char_p],
+    "xlp_expr_attach": [_pu, C.c_char_p],
     "xlp_dev_expr_run": [_pu, _pu, _u64, _u64],
     "xlp_profile_enable": [C.c_int],
     "xlp_profile_read": [C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
@@ -296,6 +298,31 @@ class ExprProgram:
 
     def run(self, params, row0, nrows):
         _ck(load().xlp_dev_expr_run(self._h, C.byref(params), row0, nrows), "xlp_dev_expr_run")
+
+    def codegen(self, path):
+        _ck(load().xlp_expr_codegen(self._h, path.encode()), "xlp_expr_codegen")
+
+    def attach(self, so_path):
+        _ck(load().xlp_expr_attach(self._h, so_path.encode()), "xlp_expr_attach")
+
+    def compile(self, workdir, name="prog", parts=1):
+        """codegen -> hipcc (parts translation units in parallel) -> attach; needs hipcc on the machine"""
+        import subprocess
+        os.makedirs(workdir, exist_ok=True)
+        src, so = os.path.join(workdir, name + ".hip"), os.path.join(workdir, name + ".so")
+        os.environ["XLP_EXPR_PARTS"] = str(parts)
+        try:
+            self.codegen(src)
+        finally:
+            del os.environ["XLP_EXPR_PARTS"]
+        flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I", os.path.join(_HERE, "csrc")]
+        srcs = [src] + [f"{src}.part{k}.hip" for k in range(parts) if os.path.exists(f"{src}.part{k}.hip")]
+        procs = [subprocess.Popen(["hipcc"] + flags + ["-c", f, "-o", f + ".o"]) for f in srcs]
+        if any(p.wait() != 0 for p in procs):
+            raise XlpError("hipcc failed on a generated expression kernel")
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + [f + ".o" for f in srcs])
+        self.attach(so)
+        return so
 
     def close(self):
         if self._h:

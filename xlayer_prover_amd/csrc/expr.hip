@@ -14,7 +14,9 @@
 // instructions touch neighbouring columns, which the L2 turns into whole-line reuse.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <dlfcn.h>
 #include <stdlib.h>
+#include <sstream>
 #include <algorithm>
 #include <map>
 #include <set>
@@ -23,6 +25,7 @@
 #include <vector>
 #include "gl_field.hpp"
 #include "xlp_internal.hpp"
+#include "xlp_expr_jit.h"
 
 struct xlp_expr_column {            // one staged column: element (row) = buffer[off + row * stride]
     uint32_t buf;                   // 0 pols, 1 const_pols (stride = n_const_pols), 2 const_pols_2ns
@@ -41,6 +44,8 @@ struct xlp_expr_program {
     std::vector<xlp_expr_column> cols;
     std::vector<uint32_t> wcols;  // indices of the written columns
     uint64_t halo = 0, modulus = 0;
+    void* jit_handle = nullptr;   // dlopen'ed plugin (xlp_expr_attach)
+    void* jit_launch = nullptr;
 };
 
 namespace xlp {
@@ -613,6 +618,250 @@ __global__ __launch_bounds__(256) void expr_scatter_kernel(const u64* cols, cons
     }
 }
 
+// --------------------------------------------------------------------------------------- ahead-of-time code
+// xlp_expr_codegen writes the compiled program as straight-line HIP: segments of XLP_EXPR_SEG instructions, one
+// __global__ per segment, one row per lane.  Inside a segment every temporary is an SSA value (the compiler
+// allocates registers and hoists the coalesced column loads far ahead of their uses, which the interpreter's
+// decode -> load -> wait -> compute -> store loop cannot); only the temporaries that are live across a segment
+// boundary go through the HBM array tmp[word][lane].  The plugin is built with
+//     hipcc -O3 --offload-arch=gfx950 -shared -fPIC -I<csrc> prog.hip -o prog.so
+// and attached with xlp_expr_attach, after which xlp_dev_expr_run stages the columns exactly as for the
+// interpreter and launches the plugin's kernels instead of expr_kernel.
+static u64 fnv(const void* p, size_t n, u64 h)
+{
+    const unsigned char* b = (const unsigned char*)p;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 0x100000001b3ULL; }
+    return h;
+}
+static u64 program_signature(const xlp_expr_program* P)
+{
+    u64 h = 0xcbf29ce484222325ULL;
+    h = fnv(P->dcode.data(), P->dcode.size() * 8, h);
+    for (const xlp_expr_column& c : P->cols) { h = fnv(&c.buf, 4, h); h = fnv(&c.off, 8, h); h = fnv(&c.stride, 8, h); }
+    h = fnv(&P->tmp_words, 8, h);
+    return h;
+}
+
+struct DInstr { u32 op, k[3], dim[3]; u64 prm[3][4]; };
+
+static std::vector<DInstr> decode_dcode(const xlp_expr_program* P)
+{
+    std::vector<DInstr> out;
+    const std::vector<u64>& c = P->dcode;
+    for (size_t s = 0; s * 8 < c.size();) {
+        const u64 h = c[8 * s];
+        DInstr in;
+        in.op = (u32)(h & 0xff);
+        const bool lng = (h >> 49) & 1;
+        if (in.op == XD_NOP) { s++; continue; }
+        in.k[0] = (u32)((h >> 8) & 0xff); in.k[1] = (u32)((h >> 16) & 0xff); in.k[2] = (u32)((h >> 24) & 0xff);
+        in.dim[0] = (u32)((h >> 32) & 3); in.dim[1] = (u32)((h >> 34) & 3); in.dim[2] = (u32)((h >> 36) & 3);
+        const u32 np[3] = {(u32)((h >> 40) & 7), (u32)((h >> 43) & 7), (u32)((h >> 46) & 7)};
+        size_t q = 8 * s + 1;
+        for (int o = 0; o < 3; o++)
+            for (u32 j = 0; j < 4; j++) in.prm[o][j] = j < np[o] ? c[q++] : 0;
+        out.push_back(in);
+        s += lng ? 2 : 1;
+    }
+    return out;
+}
+
+int expr_codegen(const xlp_expr_program* P, const char* path)
+{
+    if (!P || !path) return xlp_fail("expr codegen: null argument");
+    const std::vector<DInstr> ins = decode_dcode(P);
+    const size_t SEG = (size_t)env_int("XLP_EXPR_SEG", 256);
+    const size_t nseg = (ins.size() + SEG - 1) / SEG;
+    const u64 W = P->tmp_words;
+    // words live at the start of each segment (backward dataflow over the temporaries)
+    std::vector<std::vector<bool>> live_in(nseg + 1, std::vector<bool>(W, false));
+    {
+        std::vector<bool> live(W, false);
+        for (size_t i = ins.size(); i-- > 0;) {
+            const DInstr& in = ins[i];
+            if (in.k[0] == XD_TMP) for (u32 c = 0; c < in.dim[0]; c++) live[in.prm[0][0] + c] = false;
+            for (int o = 1; o < 3; o++) if (in.k[o] == XD_TMP) for (u32 c = 0; c < in.dim[o]; c++) live[in.prm[o][0] + c] = true;
+            if (i % SEG == 0) live_in[i / SEG] = live;
+        }
+    }
+    const std::string prologue =
+        "// generated by xlp_expr_codegen -- do not edit\n#include <hip/hip_runtime.h>\n#include \"gl_field.hpp\"\n#include \"xlp_expr_jit.h\"\n"
+        "typedef unsigned long long u64_;\nusing gl::u64;\n"
+        "static __device__ __forceinline__ u64 wrapr(u64 r, u64 n) { return (n & (n - 1)) == 0 ? (r & (n - 1)) : r % n; }\n";
+    std::vector<std::string> segsrc(nseg);
+    char buf[256];
+    for (size_t sg = 0; sg < nseg; sg++) {
+        std::ostringstream os;
+        os << "extern \"C\" __global__ __launch_bounds__(256) void seg_" << sg << "(XlpJitArgs A)\n{\n"
+              "    const u64 gt = (u64)blockIdx.x * 256 + threadIdx.x;\n    if (gt >= A.nrows) return;\n    const u64 row = A.row0 + gt;\n"
+              "    u64* __restrict__ T = A.tmp + gt; const u64 TS = A.tstride;\n"
+              "    const u64* __restrict__ C = A.cols + gt; u64* __restrict__ CW = A.cols + gt; const u64 CAP = A.cap;\n"
+              "    (void)row; (void)T; (void)TS; (void)C; (void)CW; (void)CAP;\n";
+        const size_t i0 = sg * SEG, i1 = std::min(ins.size(), i0 + SEG);
+        std::set<u64> wcol;                              // columns this segment writes: all their accesses go through CW (restrict-clean)
+        for (size_t i = i0; i < i1; i++) if (ins[i].k[0] == XD_COL) for (u32 c = 0; c < ins[i].dim[0]; c++) wcol.insert(ins[i].prm[0][0] + c);
+        std::map<u64, std::string> tval;                 // tmp word -> SSA name
+        std::map<u64, bool> tdef;                        // defined (not just loaded) in this segment
+        std::map<std::pair<u64, u64>, std::string> cval; // (column, next) -> SSA name
+        std::map<std::string, std::string> dval;         // direct scalar expressions -> SSA name
+        u64 nv = 0;
+        auto fresh = [&]() { snprintf(buf, sizeof buf, "v%llu", (unsigned long long)nv++); return std::string(buf); };
+        auto direct = [&](const std::string& expr) {
+            auto it = dval.find(expr);
+            if (it != dval.end()) return it->second;
+            const std::string n = fresh();
+            os << "    const u64 " << n << " = gl::canon(" << expr << ");\n";
+            dval[expr] = n;
+            return n;
+        };
+        auto num = [&](u64 v) { snprintf(buf, sizeof buf, "0x%llxULL", (unsigned long long)v); return std::string(buf); };
+        // value of component c of a source operand
+        auto src = [&](const DInstr& in, int o, u32 c) -> std::string {
+            const u64* p = in.prm[o];
+            const u32 k = in.k[o];
+            if (c >= in.dim[o]) return "0ULL";
+            switch (k) {
+            case XD_TMP: {
+                const u64 w = p[0] + c;
+                auto it = tval.find(w);
+                if (it != tval.end()) return it->second;
+                const std::string n = fresh();
+                os << "    const u64 " << n << " = T[" << w << "ULL * TS];\n";
+                tval[w] = n; tdef[w] = false;
+                return n;
+            }
+            case XD_COL: {
+                const std::pair<u64, u64> key(p[0] + c, p[1]);
+                auto it = cval.find(key);
+                if (it != cval.end()) return it->second;
+                const std::string n = fresh();
+                os << "    const u64 " << n << " = " << (wcol.count(key.first) ? "CW[" : "C[") << key.first << "ULL * CAP + " << key.second << "ULL];\n";
+                cval[key] = n;
+                return n;
+            }
+            case XLP_K_NUMBER: return num(p[0]);
+            case XLP_K_POLS: return direct("A.P.pols[" + num(p[0] + c) + " + row * " + num(p[1]) + "]");
+            case XLP_K_POLS_PRIME: return direct("A.P.pols[" + num(p[0] + c) + " + wrapr(row + " + num(p[1]) + ", " + num(p[2]) + ") * " + num(p[3]) + "]");
+            case XLP_K_CONST: return direct("A.P.const_pols[" + num(p[0]) + " + row * A.P.n_const_pols]");
+            case XLP_K_CONST_PRIME: return direct("A.P.const_pols[" + num(p[0]) + " + wrapr(row + " + num(p[1]) + ", " + num(p[2]) + ") * A.P.n_const_pols]");
+            case XLP_K_CONST2NS: return direct("A.P.const_pols_2ns[" + num(p[0]) + " + row * A.P.n_const_pols_2ns]");
+            case XLP_K_CONST2NS_PRIME: return direct("A.P.const_pols_2ns[" + num(p[0]) + " + wrapr(row + " + num(p[1]) + ", " + num(p[2]) + ") * A.P.n_const_pols_2ns]");
+            case XLP_K_CHALLENGE: return direct("A.P.challenges[" + num(3 * p[0] + c) + "]");
+            case XLP_K_EVAL: return direct("A.P.evals[" + num(3 * p[0] + c) + "]");
+            case XLP_K_PUBLIC: return direct("A.P.public_inputs[" + num(p[0]) + "]");
+            case XLP_K_X_N: return direct("A.P.x_n[row]");
+            case XLP_K_X_2NS: return direct("A.P.x_2ns[row]");
+            case XLP_K_ZI: return direct("A.P.zi[wrapr(row, A.P.zi_size)]");
+            case XLP_K_XDIVXSUBXI: return direct("A.P.x_div_x_sub_xi[3 * row + " + num(c) + "]");
+            case XLP_K_XDIVXSUBWXI: return direct("A.P.x_div_x_sub_wxi[3 * row + " + num(c) + "]");
+            case XLP_K_Q_2NS: { const std::string n = fresh(); os << "    const u64 " << n << " = gl::canon(A.P.q_2ns[3 * row + " << c << "]);\n"; return n; }
+            case XLP_K_F_2NS: { const std::string n = fresh(); os << "    const u64 " << n << " = gl::canon(A.P.f_2ns[3 * row + " << c << "]);\n"; return n; }
+            default: return "0ULL";
+            }
+        };
+        for (size_t i = i0; i < i1; i++) {
+            const DInstr& in = ins[i];
+            const u32 dd = in.dim[0], ad = in.dim[1], bd = in.dim[2];
+            std::string a[3], b[3], r[3];
+            for (u32 c = 0; c < 3; c++) a[c] = src(in, 1, c);
+            if (in.op != XLP_OP_COPY) for (u32 c = 0; c < 3; c++) b[c] = src(in, 2, c);
+            if (in.op == XLP_OP_COPY) { for (u32 c = 0; c < dd; c++) r[c] = a[c]; }
+            else if (in.op == XLP_OP_ADD || in.op == XLP_OP_SUB) {
+                const char* f = in.op == XLP_OP_ADD ? "gl::addc" : "gl::subc";
+                for (u32 c = 0; c < dd; c++) {
+                    const bool ha = c < ad, hb = c < bd;
+                    if (ha && hb) { r[c] = fresh(); os << "    const u64 " << r[c] << " = " << f << "(" << a[c] << ", " << b[c] << ");\n"; }
+                    else if (ha) r[c] = a[c];
+                    else if (in.op == XLP_OP_ADD) r[c] = b[c];
+                    else { r[c] = fresh(); os << "    const u64 " << r[c] << " = gl::neg(" << b[c] << ");\n"; }
+                }
+            } else {
+                if (ad == 3 && bd == 3) {
+                    const std::string e = fresh();
+                    os << "    const gl::e3 " << e << " = gl::mul3(gl::e3{{" << a[0] << ", " << a[1] << ", " << a[2] << "}}, gl::e3{{" << b[0] << ", " << b[1] << ", " << b[2] << "}});\n";
+                    for (u32 c = 0; c < 3; c++) r[c] = e + ".c[" + std::to_string(c) + "]";
+                } else if (ad == 3 || bd == 3) {
+                    const std::string* x = ad == 3 ? a : b;
+                    const std::string& s = ad == 3 ? b[0] : a[0];
+                    for (u32 c = 0; c < 3; c++) { r[c] = fresh(); os << "    const u64 " << r[c] << " = gl::mulc(" << x[c] << ", " << s << ");\n"; }
+                } else { r[0] = fresh(); os << "    const u64 " << r[0] << " = gl::mulc(" << a[0] << ", " << b[0] << ");\n"; }
+            }
+            // destination
+            const u64* p = in.prm[0];
+            switch (in.k[0]) {
+            case XD_TMP: for (u32 c = 0; c < dd; c++) { tval[p[0] + c] = r[c]; tdef[p[0] + c] = true; } break;
+            case XD_COL:
+                for (u32 c = 0; c < dd; c++) {
+                    os << "    CW[" << (p[0] + c) << "ULL * CAP] = " << r[c] << ";\n";
+                    for (auto it = cval.begin(); it != cval.end();) { if (it->first.first == p[0] + c) it = cval.erase(it); else ++it; }
+                    cval[{p[0] + c, 0}] = r[c];
+                }
+                break;
+            case XLP_K_POLS: for (u32 c = 0; c < dd; c++) os << "    A.P.pols[" << num(p[0] + c) << " + row * " << num(p[1]) << "] = " << r[c] << ";\n"; dval.clear(); break;
+            case XLP_K_POLS_PRIME:
+                for (u32 c = 0; c < dd; c++) os << "    A.P.pols[" << num(p[0] + c) << " + wrapr(row + " << num(p[1]) << ", " << num(p[2]) << ") * " << num(p[3]) << "] = " << r[c] << ";\n";
+                dval.clear();
+                break;
+            case XLP_K_Q_2NS: for (u32 c = 0; c < dd; c++) os << "    A.P.q_2ns[3 * row + " << c << "] = " << r[c] << ";\n"; break;
+            case XLP_K_F_2NS: for (u32 c = 0; c < dd; c++) os << "    A.P.f_2ns[3 * row + " << c << "] = " << r[c] << ";\n"; break;
+            default: break;
+            }
+        }
+        for (const auto& kv : tval)
+            if (tdef[kv.first] && live_in[sg + 1][kv.first]) os << "    T[" << kv.first << "ULL * TS] = " << kv.second << ";\n";
+        os << "}\n";
+        segsrc[sg] = os.str();
+    }
+    // XLP_EXPR_PARTS > 1: the kernels go round-robin to <path>.partK.hip (compiled in parallel, linked with <path>)
+    size_t parts = (size_t)env_int("XLP_EXPR_PARTS", 1);
+    if (parts < 1) parts = 1;
+    if (parts > nseg) parts = nseg ? nseg : 1;
+    auto write_file = [](const std::string& fn, const std::string& text) {
+        FILE* f = fopen(fn.c_str(), "w");
+        if (!f) return false;
+        const bool ok = fwrite(text.data(), 1, text.size(), f) == text.size();
+        fclose(f);
+        return ok;
+    };
+    std::ostringstream os;
+    os << prologue;
+    if (parts == 1) for (size_t sg = 0; sg < nseg; sg++) os << segsrc[sg];
+    else {
+        for (size_t k = 0; k < parts; k++) {
+            std::string text = prologue;
+            for (size_t sg = k; sg < nseg; sg += parts) text += segsrc[sg];
+            if (!write_file(std::string(path) + ".part" + std::to_string(k) + ".hip", text)) return xlp_fail("expr codegen: cannot write a part file");
+        }
+        for (size_t sg = 0; sg < nseg; sg++) os << "extern \"C\" __global__ void seg_" << sg << "(XlpJitArgs A);\n";
+    }
+    os << "extern \"C\" int xlpjit_launch(const XlpJitArgs* a, void* stream)\n{\n    const dim3 g((unsigned)((a->nrows + 255) / 256)), b(256);\n";
+    for (size_t sg = 0; sg < nseg; sg++) os << "    hipLaunchKernelGGL(seg_" << sg << ", g, b, 0, (hipStream_t)stream, *a);\n";
+    os << "    return hipGetLastError() == hipSuccess ? 0 : -1;\n}\n";
+    os << "extern \"C\" u64_ xlpjit_signature(void) { return 0x" << std::hex << program_signature(P) << std::dec << "ULL; }\n";
+    // self-description (used by the CPU harness of the tests): staged columns {buffer, offset, stride, halo | written << 1}
+    os << "extern \"C\" { extern const u64_ xlpjit_info[4]; extern const u64_ xlpjit_cols[][4]; }\n";
+    os << "const u64_ xlpjit_info[4] = {" << P->cols.size() << "ULL, " << P->halo << "ULL, " << P->modulus << "ULL, " << P->tmp_words << "ULL};\n";
+    os << "const u64_ xlpjit_cols[][4] = {";
+    for (const xlp_expr_column& c : P->cols) os << "{" << c.buf << ", " << c.off << "ULL, " << c.stride << "ULL, " << ((c.halo ? 1 : 0) | (c.written ? 2 : 0)) << "},";
+    os << "{0, 0, 0, 0}};\n";
+    return write_file(path, os.str()) ? 0 : xlp_fail("expr codegen: cannot write the output file");
+}
+
+int expr_attach(xlp_expr_program* P, const char* so_path)
+{
+    if (!P || !so_path) return xlp_fail("expr attach: null argument");
+    void* h = dlopen(so_path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return xlp_fail((std::string("expr attach: ") + dlerror()).c_str());
+    xlpjit_signature_fn sig = (xlpjit_signature_fn)dlsym(h, "xlpjit_signature");
+    xlpjit_launch_fn launch = (xlpjit_launch_fn)dlsym(h, "xlpjit_launch");
+    if (!sig || !launch) { dlclose(h); return xlp_fail("expr attach: not an xlp expression plugin"); }
+    if (sig() != program_signature(P)) { dlclose(h); return xlp_fail("expr attach: the plugin was generated from a different program"); }
+    if (P->jit_handle) dlclose(P->jit_handle);
+    P->jit_handle = h;
+    P->jit_launch = (void*)launch;
+    return 0;
+}
+
 int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params* params, u64 row0, u64 nrows)
 {
     if (!prog || !params) return xlp_fail("expr run: null program or params");
@@ -620,10 +869,17 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
     if (row0 + nrows < row0) return xlp_fail("expr run: row range overflows");
     if (params->zi && params->zi_size == 0) return xlp_fail("expr run: zi_size is 0");
     if (check_bounds(prog, *params, row0, nrows)) return -1;
+    if (!prog->d_dcode) {
+        xlp_expr_program* mp = const_cast<xlp_expr_program*>(prog);
+        XLP_HIP(hipMalloc((void**)&mp->d_dcode, prog->dcode.size() * sizeof(u64)));
+        XLP_HIP(hipMemcpy(mp->d_dcode, prog->dcode.data(), prog->dcode.size() * sizeof(u64), hipMemcpyHostToDevice));
+    }
     const xlp_steps_params& P = *params;
-    // rows per launch: 2^19-class slabs; R rows per lane
+    // rows per launch: 2^19-class slabs; R rows per lane (the compiled plugin runs one row per lane)
+    const bool jit = prog->jit_launch != nullptr && env_int("XLP_EXPR_JIT", 1) != 0;
     int R = env_int("XLP_EXPR_ROWS", 2);
     if (R != 1 && R != 2 && R != 4) R = 2;
+    if (jit) R = 1;
     const u64 chunk_max = (u64)ctx->ncu * 8 * 256;
     const u64 chunk = nrows < chunk_max ? nrows : chunk_max;
     const u64 threads_max = ((chunk + R - 1) / R + 255) / 256 * 256;     // lanes of the largest launch
@@ -632,7 +888,7 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
     ExprArgs A;
     A.code = prog->d_dcode; A.ncode = prog->dcode.size();
     A.hot_words = prog->hot_words; A.tstride = (u64)R * threads_max; A.tmp = nullptr; A.cols = nullptr; A.cap = cap; A.P = P;
-    const u64 spill = prog->tmp_words - prog->hot_words;
+    const u64 spill = jit ? prog->tmp_words : prog->tmp_words - prog->hot_words;
     if (spill && ctx_scratch(ctx, spill * A.tstride * sizeof(u64), 2, &A.tmp)) return -1;
     u64* cols = nullptr; ColDesc* d_tab = nullptr; u32* d_wl = nullptr;
     if (ncols) {
@@ -660,10 +916,16 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
             hipLaunchKernelGGL(expr_gather_kernel, grid, dim3(256), 0, ctx->stream, cols, d_tab, ncols, cap, row0 + r0, rows, prog->halo, prog->modulus);
         }
         A.row0 = row0 + r0; A.nrows = rows;
-        const dim3 vgrid((unsigned)((((rows + R - 1) / R) + 255) / 256));
-        if (R == 1) hipLaunchKernelGGL(expr_kernel<1>, vgrid, dim3(256), lds, ctx->stream, A);
-        else if (R == 2) hipLaunchKernelGGL(expr_kernel<2>, vgrid, dim3(256), lds, ctx->stream, A);
-        else hipLaunchKernelGGL(expr_kernel<4>, vgrid, dim3(256), lds, ctx->stream, A);
+        if (jit) {
+            XlpJitArgs J;
+            J.cols = cols; J.cap = cap; J.tmp = A.tmp; J.tstride = A.tstride; J.row0 = row0 + r0; J.nrows = rows; J.P = P;
+            if (((xlpjit_launch_fn)prog->jit_launch)(&J, (void*)ctx->stream)) return xlp_fail("expr run: the compiled plugin failed to launch");
+        } else {
+            const dim3 vgrid((unsigned)((((rows + R - 1) / R) + 255) / 256));
+            if (R == 1) hipLaunchKernelGGL(expr_kernel<1>, vgrid, dim3(256), lds, ctx->stream, A);
+            else if (R == 2) hipLaunchKernelGGL(expr_kernel<2>, vgrid, dim3(256), lds, ctx->stream, A);
+            else hipLaunchKernelGGL(expr_kernel<4>, vgrid, dim3(256), lds, ctx->stream, A);
+        }
         if (nw) {
             const dim3 grid((nw + 63) / 64, (unsigned)((rows + 63) / 64));
             hipLaunchKernelGGL(expr_scatter_kernel, grid, dim3(256), 0, ctx->stream, cols, d_tab, d_wl, nw, cap, row0 + r0, rows);
@@ -696,11 +958,7 @@ int expr_create(xlp_expr_program** out, const u64* code, u64 ncode, u64 ntmp1, u
     }
     p->ntmp1 = ntmp1; p->ntmp3 = ntmp3; p->ninstr = ninstr;
     compile(p);
-    if (!p->dcode.empty()) {
-        hipError_t e = hipMalloc((void**)&p->d_dcode, p->dcode.size() * sizeof(u64));
-        if (e == hipSuccess) e = hipMemcpy(p->d_dcode, p->dcode.data(), p->dcode.size() * sizeof(u64), hipMemcpyHostToDevice);
-        if (e != hipSuccess) { if (p->d_dcode) (void)hipFree(p->d_dcode); delete p; return xlp_fail_hip(e, __FILE__, __LINE__); }
-    }
+    // the device copy is made by the first run: creating, generating code and attaching need no GPU
     *out = p;
     return 0;
 }
@@ -709,6 +967,7 @@ int expr_destroy(xlp_expr_program* p)
 {
     if (!p) return 0;
     if (p->d_dcode) (void)hipFree(p->d_dcode);
+    if (p->jit_handle) dlclose(p->jit_handle);
     delete p;
     return 0;
 }

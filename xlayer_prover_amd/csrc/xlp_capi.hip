@@ -191,10 +191,11 @@ int xlp_dev_calculate_h1h2(uint64_t* h1, uint64_t* h2, const uint64_t* f, const 
 }
 int xlp_expr_create(xlp_expr_program** out, const uint64_t* code, uint64_t ncode, uint64_t ntmp1, uint64_t ntmp3)
 {
-    if (ensure_init()) return -1;
-    return expr_create(out, code, ncode, ntmp1, ntmp3);
+    return expr_create(out, code, ncode, ntmp1, ntmp3);      // host-only: validation + compilation to the device form
 }
 int xlp_expr_destroy(xlp_expr_program* prog) { return expr_destroy(prog); }
+int xlp_expr_codegen(const xlp_expr_program* prog, const char* path) { return expr_codegen(prog, path); }
+int xlp_expr_attach(xlp_expr_program* prog, const char* path) { return expr_attach(prog, path); }
 int xlp_dev_expr_run(const xlp_expr_program* prog, const xlp_steps_params* params, uint64_t row0, uint64_t nrows)
 {
     if (ensure_init()) return -1;

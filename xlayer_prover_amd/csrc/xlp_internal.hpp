@@ -90,6 +90,8 @@ int dev_evmap(Ctx* ctx, u64* evals, const u64* LEv, const u64* LpEv, u64 n, u32 
 // expr.hip
 int expr_create(xlp_expr_program** out, const u64* code, u64 ncode, u64 ntmp1, u64 ntmp3);
 int expr_destroy(xlp_expr_program* prog);
+int expr_codegen(const xlp_expr_program* prog, const char* path);
+int expr_attach(xlp_expr_program* prog, const char* so_path);
 int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params* params, u64 row0, u64 nrows);
 
 }  // namespace xlp
