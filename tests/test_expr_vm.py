@@ -243,3 +243,34 @@ def test_expr_generated_code_on_cpu_reference_programs(orc, tmp_path, step):
     orc.expr_run(code, ntmp1, ntmp3, exp, 0, n, info["n_const"], info["n_const2"])
     for k in ("pols", "q_2ns", "f_2ns"):
         assert (got[k] == exp[k]).all(), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compiled", [False, True])
+def test_expr_multi_slab_run(xlp, orc, tmp_path, compiled):
+    """More rows than one launch holds (2^19-row slabs on a 256-CU part): slab seams, halo rows of next-row operands
+    and the wrap-around at the end of the domain, checked on row windows against the oracle."""
+    import shutil
+    if compiled and shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    n = (1 << 20) + 4096
+    prog, width = random_program(41, n, 160, nstore=8)
+    bufs = make_buffers(orc, 0x5EED0600, n, width)
+    dev = {k: xlp.from_np(v) for k, v in bufs.items()}
+    sp = xlp.steps_params(n_const_pols=5, n_const_pols_2ns=4, **dev)
+    p = xlp.ExprProgram(prog.code, prog.ntmp1, prog.ntmp3)
+    if compiled:
+        p.compile(str(tmp_path), "slab", parts=2)
+    p.run(sp, 0, n); xlp.sync(); p.close()
+    got = {k: xlp.to_np(dev[k]) for k in ("pols", "q_2ns", "f_2ns")}
+    slab = 1 << 19
+    for lo, cnt in [(0, 48), (slab - 40, 80), (2 * slab - 40, 80), (n - 48, 48)]:
+        exp = {k: v.copy() for k, v in bufs.items()}
+        orc.expr_run(prog.code, prog.ntmp1, prog.ntmp3, exp, lo, cnt, 5, 4)
+        # rows the window wrote: same-row stores land in [lo, lo+cnt); next-row stores up to 2 rows further (mod n)
+        rows = np.arange(lo, lo + cnt)
+        for k, per_row in (("pols", width), ("q_2ns", 3), ("f_2ns", 3)):
+            e = exp[k].reshape(n, per_row); b = bufs[k].reshape(n, per_row); g = got[k].reshape(n, per_row)
+            touched = (e != b)
+            assert (g[touched] == e[touched]).all(), (k, lo)
+            assert touched[rows].any() or k != "pols"

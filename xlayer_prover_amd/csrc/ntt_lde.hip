@@ -27,6 +27,21 @@
 #ifndef XLP_ABL
 #define XLP_ABL 0
 #endif
+// Cache policy experiments (tools/ablate.sh 10xx): bit0 input loads, bit1 A stores, bit2 A loads, bit3 B stores,
+// bit4 B loads, bit5 output stores are issued non-temporal.
+#ifndef XLP_NT
+#define XLP_NT 0
+#endif
+template <int BIT> __device__ __forceinline__ gl::u64 gld(const gl::u64* q)
+{
+    if constexpr ((XLP_NT >> BIT) & 1) return __builtin_nontemporal_load(q);
+    else return *q;
+}
+template <int BIT> __device__ __forceinline__ void gst(gl::u64* q, gl::u64 v)
+{
+    if constexpr ((XLP_NT >> BIT) & 1) __builtin_nontemporal_store(v, q);
+    else *q = v;
+}
 #define XLP_NOLOAD (XLP_ABL == 2 || XLP_ABL == 3 || XLP_ABL == 4 || XLP_ABL == 5 || XLP_ABL == 9)
 #define XLP_NOSTORE (XLP_ABL == 2 || XLP_ABL == 3 || XLP_ABL == 4 || XLP_ABL == 5 || XLP_ABL == 8)
 #if 0   // ablation builds (tools/ablate.sh): 1 no twiddle loads, 2 +no global data traffic, 3 +no DFT, 4 +no twiddle muls
@@ -153,7 +168,7 @@ __global__ __launch_bounds__(XLP_WGT) void lde_top_dif(const LdeParams p)
 #if XLP_NOLOAD
         return row * 0x9E3779B97F4A7C15ULL + col;
 #else
-        return gl::canon(p.in[row * p.ld_in + p.col0 + col]);
+        return gl::canon(gld<0>(&p.in[row * p.ld_in + p.col0 + col]));
 #endif
     };
     #if XLP_ABL == 5
@@ -171,7 +186,7 @@ __global__ __launch_bounds__(XLP_WGT) void lde_top_dif(const LdeParams p)
 #if XLP_NOSTORE
         if (val == 0x1234567ULL) p.A[row * p.wc + c + v] = val;
 #else
-        if (c + v < p.wc) p.A[row * p.wc + c + v] = val;
+        if (c + v < p.wc) gst<1>(&p.A[row * p.wc + c + v], val);
 #endif
     };
     auto crossf = [&](u32 tpos) -> u64 { return cross[tile_natural_c<BT>(tpos)]; };
@@ -201,7 +216,7 @@ __global__ __launch_bounds__(XLP_WGT) void lde_mid(const LdeParams p, u32 BT)
     auto gload = [&](u32 tpos, u32 v, u32) -> u64 {
         const u32 col = c + v < p.wc ? c + v : p.wc - 1;
         const u64 row = ((u64)hi << 12) | tpos;
-        return p.A[row * p.wc + col];
+        return gld<2>(&p.A[row * p.wc + col]);
     };
     #if XLP_ABL == 5
     auto lload = [&](u32 tp_, u32 v, u32 lrow) -> u64 { return (u64)lrow * 0x9E3779B97F4A7C15ULL + v + tp_; };
@@ -260,7 +275,7 @@ __global__ __launch_bounds__(XLP_WGT) void lde_mid(const LdeParams p, u32 BT)
         XLP_SYNC();
         auto gstore = [&](u32 tpos, u32 vv, u64 val, u32) {
             const u64 row = ((u64)hi << 12) | tpos;
-            if (c + vv < p.wc) Br[row * p.wc + c + vv] = val;
+            if (c + vv < p.wc) gst<3>(&Br[row * p.wc + c + vv], val);
         };
         fast_round<B, V, 8, 4, true, false>(p.twf_12, lload, gstore);
     }
@@ -289,14 +304,14 @@ __global__ __launch_bounds__(XLP_WGT) void ntt_bot_dif(const LdeParams p, u32 BT
     auto gload = [&](u32 tpos, u32 v, u32) -> u64 {
         const u32 col = c + v < p.wc ? c + v : p.wc - 1;
         const u64 row = ((u64)hi << 12) | tpos;
-        return p.A[row * p.wc + col];
+        return gld<2>(&p.A[row * p.wc + col]);
     };
     auto lload = [&](u32, u32 v, u32 lrow) -> u64 { return sm[lrow * V + v]; };
     auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { sm[lrow * V + v] = val; };
     auto gstore = [&](u32 tpos, u32 v, u64 val, u32) {
         const u64 row = (u64)k1 + ((u64)tile_natural_c<B>(tpos) << BT);
         if (final_scale != 1) val = gl::mulc(val, final_scale);
-        if (c + v < p.wc) p.out[row * p.ld_out + p.col0 + c + v] = val;
+        if (c + v < p.wc) gst<5>(&p.out[row * p.ld_out + p.col0 + c + v], val);
     };
     fast_round<B, V, 8, 4, false, INV>(p.twi_12, gload, lstore);
     XLP_SYNC();
@@ -330,7 +345,7 @@ __global__ __launch_bounds__(XLP_WGT) void lde_top_dit(const LdeParams p)
 #if XLP_NOLOAD
         return row * 0x9E3779B97F4A7C15ULL + col;
 #else
-        return Br[row * p.wc + col];
+        return gld<4>(&Br[row * p.wc + col]);
 #endif
     };
     auto crossf = [&](u32 tpos) -> u64 { return cross[tile_natural_c<BT>(tpos)]; };
@@ -349,7 +364,7 @@ __global__ __launch_bounds__(XLP_WGT) void lde_top_dit(const LdeParams p)
 #if XLP_NOSTORE
         if (val == 0x1234567ULL) p.out[row * p.ld_out + p.col0 + c + v] = val;
 #else
-        if (c + v < p.wc) p.out[row * p.ld_out + p.col0 + c + v] = val;
+        if (c + v < p.wc) gst<5>(&p.out[row * p.ld_out + p.col0 + c + v], val);
 #endif
     };
     if constexpr (m == 2) {
