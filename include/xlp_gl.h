@@ -107,6 +107,13 @@ int xlp_dev_calculate_z(uint64_t* z, const uint64_t* num, const uint64_t* den, u
  * n elements of dimension dim (1 or 3) each, dense.  Fails ("number not included") if a value of f does not
  * occur in t (the reference calls exitProcess()). */
 int xlp_dev_calculate_h1h2(uint64_t* h1, uint64_t* h2, const uint64_t* f, const uint64_t* t, uint64_t n, uint32_t dim);
+/* out[k] = first * ratio^k, k < n, elements of dimension dim (1 or 3; `first`, `ratio`: dim host words each).
+ * Replaces the sequential table loops of Starks: x_n, x_2ns, x (starks.hpp:149-183: ratio = w(nBits) / w(nBitsExt),
+ * first = 1 / shift) and LEv, LpEv before their INTT (starks.cpp:318-322: ratio = xi/shift, w*xi/shift). */
+int xlp_dev_geometric(uint64_t* out, uint64_t n, uint32_t dim, const uint64_t* first, const uint64_t* ratio);
+/* xDivXSubXi / xDivXSubWXi of genProof step 5 (starks.cpp:340-362): out[k] (ext-3) = x[k] / (x[k] - xi), x base
+ * field (n words), xi 3 host words.  x[k] == xi gives zero (the reference would divide by zero). */
+int xlp_dev_x_div_x_sub_xi(uint64_t* out, const uint64_t* x, const uint64_t* xi, uint64_t n);
 /* Starks::evmap -- starks.cpp:556-669: evals[i] = sum_{k<n} L_i[k] * pol_i[(k << extend_bits) * row_stride_i],
  * L_i = LpEv if prime else LEv (ext-3, n rows), pol_i of dimension 1 or 3 (mulAddElement_adim3,
  * polinomial.hpp:722-744).  `entries` is a HOST array of nev descriptors whose `pol` are device pointers

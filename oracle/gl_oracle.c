@@ -765,3 +765,29 @@ u64 orc_expr_run(const u64 *code, u64 ncode, u64 ntmp1, u64 ntmp3, const orc_ste
     free(tmp1); free(tmp3);
     return bad;
 }
+
+/* genProof tables, restated as the reference computes them (sequential products):
+ *   x_n / x_2ns / x   starks.hpp:149-183      out[0] = first, out[k] = out[k-1] * ratio
+ *   LEv / LpEv        starks.cpp:318-322      (same, ext-3, before their INTT)
+ *   xDivXSubXi        starks.cpp:340-362      x[k] * (x[k] - xi)^-1, element by element */
+void orc_geometric(u64 *out, u64 n, unsigned dim, const u64 *first, const u64 *ratio)
+{
+    if (!n) return;
+    u64 cur[3] = {0, 0, 0}, r[3] = {0, 0, 0};
+    for (unsigned c = 0; c < dim; c++) { cur[c] = gl_canon(first[c]); r[c] = gl_canon(ratio[c]); }
+    for (u64 k = 0; k < n; k++) {
+        for (unsigned c = 0; c < dim; c++) out[k * dim + c] = cur[c];
+        if (dim == 1) cur[0] = gl_mul(cur[0], r[0]);
+        else { u64 t[3]; gl3_mul(t, cur, r); memcpy(cur, t, sizeof t); }
+    }
+}
+void orc_x_div_x_sub_xi(u64 *out, const u64 *x, const u64 *xi, u64 n)
+{
+    for (u64 k = 0; k < n; k++) {
+        const u64 xv = gl_canon(x[k]);
+        u64 d[3] = {gl_sub(xv, xi[0]), gl_sub(0, xi[1]), gl_sub(0, xi[2])}, inv[3];
+        if (d[0] == 0 && d[1] == 0 && d[2] == 0) { out[3 * k] = out[3 * k + 1] = out[3 * k + 2] = 0; continue; }
+        orc_inv3(inv, d);
+        for (int c = 0; c < 3; c++) out[3 * k + c] = gl_mul(inv[c], xv);
+    }
+}

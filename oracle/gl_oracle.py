@@ -50,6 +50,8 @@ def _load():
         "orc_batch_inverse": (None, [_pu64, _pu64, u64, C.c_uint]),
         "orc_calculate_z": (None, [_pu64, _pu64, _pu64, u64]),
         "orc_calculate_h1h2": (C.c_int, [_pu64, _pu64, _pu64, _pu64, u64, C.c_uint]),
+        "orc_geometric": (None, [_pu64, u64, C.c_uint, _pu64, _pu64]),
+        "orc_x_div_x_sub_xi": (None, [_pu64, _pu64, _pu64, u64]),
         "orc_transcript_init": (None, [C.c_void_p]),
         "orc_transcript_put": (None, [C.c_void_p, _pu64, u64]),
         "orc_transcript_get1": (u64, [C.c_void_p]),
@@ -213,6 +215,20 @@ def calculate_h1h2(f, t, dim=1):
     if n and lib.orc_calculate_h1h2(h1, h2, f, t, n, dim):
         raise ValueError("calculateH1H2: number not included")
     return (h1.reshape(n, dim), h2.reshape(n, dim)) if dim == 3 else (h1, h2)
+
+
+def geometric(n, dim, first, ratio):
+    out = np.zeros(max(n * dim, 1), np.uint64)
+    lib.orc_geometric(out, n, dim, _a(np.atleast_1d(first)), _a(np.atleast_1d(ratio)))
+    return out[: n * dim].reshape(n, dim) if dim == 3 else out[:n]
+
+
+def x_div_x_sub_xi(x, xi):
+    x = _a(x).ravel()
+    out = np.zeros(max(3 * x.size, 1), np.uint64)
+    if x.size:
+        lib.orc_x_div_x_sub_xi(out, x, _a(xi), x.size)
+    return out[: 3 * x.size].reshape(-1, 3)
 
 
 def evmap(LEv, LpEv, n, extend_bits, entries):

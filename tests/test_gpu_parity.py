@@ -440,3 +440,26 @@ def test_calculate_h1h2_number_not_included(xlp, orc):
         xlp.dev_calculate_h1h2(h, h2, xlp.from_np(f), xlp.from_np(t), 64, 1)
     with pytest.raises(ValueError):
         orc.calculate_h1h2(f, t, 1)
+
+
+@pytest.mark.parametrize("n,dim", [(1, 1), (7, 1), (1 << 12, 1), ((1 << 20) + 17, 1), (5, 3), (1 << 12, 3), (700001, 3)])
+def test_geometric_tables_vs_oracle(xlp, orc, n, dim):
+    """x_n / x_2ns / x (starks.hpp:149-183) and LEv / LpEv (starks.cpp:318-322): out[k] = first * ratio^k"""
+    first = orc.fill(dim, 900 + n); ratio = orc.fill(dim, 901 + n)
+    if dim == 1 and n == 1 << 12:
+        first, ratio = np.array([orc.shift()], np.uint64), np.array([orc.w(12)], np.uint64)     # x_2ns of a 2^12 domain
+    out = xlp.from_np(np.zeros(n * dim, np.uint64))
+    xlp.dev_geometric(out, n, dim, first, ratio); xlp.sync()
+    assert (xlp.to_np(out) == orc.geometric(n, dim, first, ratio).reshape(-1)).all()
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 1000, (1 << 18) + 5])
+def test_x_div_x_sub_xi_vs_oracle(xlp, orc, n):
+    """xDivXSubXi (starks.cpp:340-362), including a point equal to xi (zero difference -> zero)"""
+    x = orc.fill(n, 0x5EED0700 + n)
+    xi = orc.fill(3, 77)
+    if n >= 4:
+        xi[1] = 0; xi[2] = 0; x[2] = xi[0]
+    out = xlp.from_np(np.zeros(3 * n, np.uint64))
+    xlp.dev_x_div_x_sub_xi(out, xlp.from_np(x), xi, n); xlp.sync()
+    assert (xlp.to_np(out).reshape(-1, 3) == orc.x_div_x_sub_xi(x, xi)).all()

@@ -41,6 +41,8 @@ SIGNATURES = {
     "xlp_dev_batch_inverse": [_pu, _pu, _u64, _u32],
     "xlp_dev_calculate_z": [_pu, _pu, _pu, _u64],
     "xlp_dev_evmap": [_pu, _pu, _pu, _u64, _u32, _u32, _pu],
+    "xlp_dev_geometric": [_pu, _u64, _u32, _pu, _pu],
+    "xlp_dev_x_div_x_sub_xi": [_pu, _pu, _pu, _u64],
     "xlp_dev_calculate_h1h2": [_pu, _pu, _pu, _pu, _u64, _u32],
     "xlp_expr_create": [C.POINTER(C.c_void_p), _pu, _u64, _u64, _u64],
     "xlp_expr_destroy": [_pu],
@@ -258,6 +260,18 @@ def dev_calculate_z(z, num, den, n):
 
 def dev_calculate_h1h2(h1, h2, f, t, n, dim=1):
     _ck(load().xlp_dev_calculate_h1h2(_dp(h1), _dp(h2), _dp(f), _dp(t), n, dim), "xlp_dev_calculate_h1h2")
+
+
+def dev_geometric(out, n, dim, first, ratio):
+    f = np.ascontiguousarray(np.atleast_1d(first), dtype=np.uint64); r = np.ascontiguousarray(np.atleast_1d(ratio), dtype=np.uint64)
+    assert f.size == dim and r.size == dim
+    _ck(load().xlp_dev_geometric(_dp(out), n, dim, f.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p)), "xlp_dev_geometric")
+
+
+def dev_x_div_x_sub_xi(out, x, xi, n):
+    v = np.ascontiguousarray(xi, dtype=np.uint64)
+    assert v.size == 3
+    _ck(load().xlp_dev_x_div_x_sub_xi(_dp(out), _dp(x), v.ctypes.data_as(C.c_void_p), n), "xlp_dev_x_div_x_sub_xi")
 
 
 class StepsParams(C.Structure):

@@ -201,6 +201,88 @@ int dev_batch_inverse(Ctx* ctx, u64* res, const u64* src, u64 n, u32 dim)
     return 0;
 }
 
+// ------------------------------------------------------------------ genProof tables (starks.hpp:149-183, starks.cpp:318-362)
+// out[k] = first * ratio^k, k < n: x_n / x_2ns / x (dim 1: ratio = w(nBits), first = 1 or shift) and LEv / LpEv before
+// their INTT (dim 3: ratio = xi / shift).  The reference builds them with n sequential multiplications; here lane t
+// starts from ratio^t (square and multiply) and strides by ratio^T, so the writes are coalesced.
+__device__ __forceinline__ e3 pow3(e3 b, u64 e)
+{
+    e3 r = one3();
+    while (e) { if (e & 1) r = gl::mul3(r, b); b = gl::mul3(b, b); e >>= 1; }
+    return r;
+}
+__global__ __launch_bounds__(256) void geometric_kernel(u64* out, u64 n, u32 dim, e3 first, e3 ratio)
+{
+    const u64 T = (u64)gridDim.x * blockDim.x, t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    if (dim == 1) {
+        u64 v = gl::mulc(first.c[0], gl::pow(ratio.c[0], t));
+        const u64 step = gl::canon(gl::pow(ratio.c[0], T));
+        for (u64 k = t; k < n; k += T) { out[k] = v; v = gl::mulc(v, step); }
+    } else {
+        e3 v = gl::mul3(first, pow3(ratio, t));
+        const e3 step = pow3(ratio, T);
+        for (u64 k = t; k < n; k += T) { store3(out + 3 * k, v); v = gl::mul3(v, step); }
+    }
+}
+
+int dev_geometric(Ctx* ctx, u64* out, u64 n, u32 dim, const u64* first, const u64* ratio)
+{
+    if (!n) return 0;
+    if (dim != 1 && dim != 3) return xlp_fail("geometric: dim must be 1 or 3");
+    e3 f, r;
+    for (int c = 0; c < 3; c++) { f.c[c] = c < (int)dim ? first[c] % hgl::P : 0; r.c[c] = c < (int)dim ? ratio[c] % hgl::P : 0; }
+    u64 blocks = (n + 255) / 256;
+    if (blocks > (u64)ctx->ncu * 8) blocks = (u64)ctx->ncu * 8;
+    hipLaunchKernelGGL(geometric_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, out, n, dim, f, r);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
+// out[k] = x[k] / (x[k] - xi) in Fp^3, x[k] in Fp (starks.cpp:340-362: subElement, batchInverseParallel, mulElement),
+// one pass: each lane inverts INV_CH differences with Montgomery's trick.  x[k] = xi (zero difference) yields zero,
+// as xlp_dev_batch_inverse does.
+__global__ __launch_bounds__(256) void x_div_x_sub_kernel(u64* out, const u64* x, e3 xi, u64 n)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 i0 = t * INV_CH;
+    if (i0 >= n) return;
+    e3 a[INV_CH], pre[INV_CH];
+    u64 xv[INV_CH];
+    bool z[INV_CH];
+    e3 acc = one3();
+#pragma unroll
+    for (int k = 0; k < INV_CH; k++) {
+        const bool ok = i0 + k < n;
+        xv[k] = ok ? gl::canon(x[i0 + k]) : 0;
+        a[k].c[0] = gl::subc(xv[k], xi.c[0]); a[k].c[1] = gl::neg(xi.c[1]); a[k].c[2] = gl::neg(xi.c[2]);
+        if (!ok) a[k] = one3();
+        z[k] = is_zero3(a[k]);
+        if (z[k]) a[k] = one3();
+        pre[k] = acc;
+        acc = gl::mul3(acc, a[k]);
+    }
+    e3 inv = inv3(acc);
+#pragma unroll
+    for (int k = INV_CH - 1; k >= 0; k--) {
+        e3 r = gl::mul3s(gl::mul3(inv, pre[k]), xv[k]);
+        inv = gl::mul3(inv, a[k]);
+        if (z[k]) { r.c[0] = 0; r.c[1] = 0; r.c[2] = 0; }
+        if (i0 + k < n) store3(out + 3 * (i0 + k), r);
+    }
+}
+
+int dev_x_div_x_sub_xi(Ctx* ctx, u64* out, const u64* x, const u64* xi, u64 n)
+{
+    if (!n) return 0;
+    e3 v;
+    for (int c = 0; c < 3; c++) v.c[c] = xi[c] % hgl::P;
+    const u64 thr = (n + INV_CH - 1) / INV_CH;
+    hipLaunchKernelGGL(x_div_x_sub_kernel, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, ctx->stream, out, x, v, n);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------ evmap
 // evals[i] = sum_k L_i[k] * pol_i[(k << eb) * stride_i ...]: grid (chunks of rows) x (eval i);
 // per-block partial sums -> partial[chunk][i][3]; a second kernel adds the chunks.

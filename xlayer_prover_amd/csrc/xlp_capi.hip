@@ -201,6 +201,18 @@ int xlp_dev_expr_run(const xlp_expr_program* prog, const xlp_steps_params* param
     if (ensure_init()) return -1;
     return dev_expr_run(&g_ctx, prog, params, row0, nrows);
 }
+int xlp_dev_geometric(uint64_t* out, uint64_t n, uint32_t dim, const uint64_t* first, const uint64_t* ratio)
+{
+    if (ensure_init()) return -1;
+    if (!first || !ratio) return xlp_fail("xlp_dev_geometric: null first / ratio");
+    return dev_geometric(&g_ctx, out, n, dim, first, ratio);
+}
+int xlp_dev_x_div_x_sub_xi(uint64_t* out, const uint64_t* x, const uint64_t* xi, uint64_t n)
+{
+    if (ensure_init()) return -1;
+    if (!xi) return xlp_fail("xlp_dev_x_div_x_sub_xi: null xi");
+    return dev_x_div_x_sub_xi(&g_ctx, out, x, xi, n);
+}
 int xlp_dev_evmap(uint64_t* evals, const uint64_t* LEv, const uint64_t* LpEv, uint64_t n, uint32_t extend_bits, uint32_t nev,
                   const xlp_evmap_entry* entries)
 {
