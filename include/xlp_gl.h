@@ -114,6 +114,10 @@ int xlp_dev_geometric(uint64_t* out, uint64_t n, uint32_t dim, const uint64_t* f
 /* xDivXSubXi / xDivXSubWXi of genProof step 5 (starks.cpp:340-362): out[k] (ext-3) = x[k] / (x[k] - xi), x base
  * field (n words), xi 3 host words.  x[k] == xi gives zero (the reference would divide by zero). */
 int xlp_dev_x_div_x_sub_xi(uint64_t* out, const uint64_t* x, const uint64_t* xi, uint64_t n);
+/* Step-4 coefficient split between the INTT and the NTT of the quotient (starks.cpp:267-283):
+ * qq2[k * q_deg + p] = qq1[p * n + k] * shift_in^p (k < n, p < q_deg, elements of q_dim words), rows n .. n_ext-1
+ * of qq2 (n_ext rows x q_deg * q_dim columns) zero; shift_in = shift^-n.  Needs q_deg * n <= n_ext. */
+int xlp_dev_q_split(uint64_t* qq2, const uint64_t* qq1, uint64_t n, uint64_t n_ext, uint32_t q_deg, uint32_t q_dim, uint64_t shift_in);
 /* Starks::evmap -- starks.cpp:556-669: evals[i] = sum_{k<n} L_i[k] * pol_i[(k << extend_bits) * row_stride_i],
  * L_i = LpEv if prime else LEv (ext-3, n rows), pol_i of dimension 1 or 3 (mulAddElement_adim3,
  * polinomial.hpp:722-744).  `entries` is a HOST array of nev descriptors whose `pol` are device pointers

@@ -791,3 +791,15 @@ void orc_x_div_x_sub_xi(u64 *out, const u64 *x, const u64 *xi, u64 n)
         for (int c = 0; c < 3; c++) out[3 * k + c] = gl_mul(inv[c], xv);
     }
 }
+
+/* starks.cpp:267-283 (the block loop over ii is only a work partition) */
+void orc_q_split(u64 *qq2, const u64 *qq1, u64 n, u64 n_ext, unsigned qdeg, unsigned qdim, u64 shift_in)
+{
+    memset(qq2, 0, n_ext * qdeg * qdim * sizeof(u64));
+    u64 curS = 1;
+    for (unsigned p = 0; p < qdeg; p++) {
+        for (u64 k = 0; k < n; k++)
+            for (unsigned c = 0; c < qdim; c++) qq2[(k * qdeg + p) * qdim + c] = gl_mul(qq1[(p * n + k) * qdim + c], curS);
+        curS = gl_mul(curS, shift_in);
+    }
+}

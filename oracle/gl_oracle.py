@@ -51,6 +51,7 @@ def _load():
         "orc_calculate_z": (None, [_pu64, _pu64, _pu64, u64]),
         "orc_calculate_h1h2": (C.c_int, [_pu64, _pu64, _pu64, _pu64, u64, C.c_uint]),
         "orc_geometric": (None, [_pu64, u64, C.c_uint, _pu64, _pu64]),
+        "orc_q_split": (None, [_pu64, _pu64, u64, u64, C.c_uint, C.c_uint, u64]),
         "orc_x_div_x_sub_xi": (None, [_pu64, _pu64, _pu64, u64]),
         "orc_transcript_init": (None, [C.c_void_p]),
         "orc_transcript_put": (None, [C.c_void_p, _pu64, u64]),
@@ -215,6 +216,12 @@ def calculate_h1h2(f, t, dim=1):
     if n and lib.orc_calculate_h1h2(h1, h2, f, t, n, dim):
         raise ValueError("calculateH1H2: number not included")
     return (h1.reshape(n, dim), h2.reshape(n, dim)) if dim == 3 else (h1, h2)
+
+
+def q_split(qq1, n, n_ext, qdeg, qdim, shift_in):
+    out = np.zeros(n_ext * qdeg * qdim, np.uint64)
+    lib.orc_q_split(out, _a(qq1).ravel(), n, n_ext, qdeg, qdim, shift_in)
+    return out
 
 
 def geometric(n, dim, first, ratio):

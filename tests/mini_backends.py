@@ -1,0 +1,94 @@
+"""Backends of the toy prover (tests/mini_genproof_flow.py): the HIP library through its C ABI, and the CPU oracle."""
+import numpy as np
+
+from tests import mini_genproof_flow as flow
+
+P = flow.P
+W32 = 7277203076849721926
+
+
+def gl_w(n):
+    w = W32
+    for _ in range(32 - n):
+        w = w * w % P
+    return w
+
+
+def _merkle_proof_host(src, nodes, w, h, idx):
+    row = [int(v) for v in src[idx * w:(idx + 1) * w]]
+    sib, off, cnt, i = [], 0, h, idx
+    while cnt > 1:
+        s = i ^ 1
+        sib.append([int(v) for v in nodes[off + 4 * s: off + 4 * s + 4]])
+        off += 4 * cnt; cnt //= 2; i //= 2
+    return row, sib
+
+
+class OracleBackend:
+    def __init__(self, orc): self.o = orc
+    def sync(self): pass
+    def w(self, n): return gl_w(n)
+    def zeros(self, n): return np.zeros(n, np.uint64)
+    def from_host(self, a): return np.ascontiguousarray(a, dtype=np.uint64).copy()
+    def to_host(self, a): return a
+    def copy_into(self, dst, src): dst[:] = src
+    def extend(self, dst, src, ne, n, w): dst[:] = self.o.extend_pol(src, ne, n, w).reshape(-1)
+    def ntt(self, dst, src, n, w, inverse): dst[:] = self.o.ntt(src.copy(), n, w, inverse).reshape(-1)
+    def merkle(self, src, w, h): return self.o.merkletree(src, w, h)
+    def root(self, nodes, h): return [int(v) for v in nodes[-4:]]
+    def get_cols(self, sec, rows, W, c, d): return np.ascontiguousarray(sec.reshape(rows, W)[:, c:c + d]).reshape(-1)
+    def set_cols(self, sec, rows, W, c, d, vals): sec.reshape(rows, W)[:, c:c + d] = vals.reshape(rows, d)
+    def h1h2(self, h1, h2, f, t, n, dim):
+        a, b = self.o.calculate_h1h2(f, t, dim); h1[:] = a.reshape(-1); h2[:] = b.reshape(-1)
+    def calc_z(self, z, num, den, n): z[:] = self.o.calculate_z(num, den).reshape(-1)
+    def expr_run(self, prog, bufs, nc, nc2, row0, nrows): self.o.expr_run(prog.code, prog.ntmp1, prog.ntmp3, bufs, row0, nrows, nc, nc2)
+    def geometric(self, n, dim, first, ratio): return self.o.geometric(n, dim, np.array(first, np.uint64), np.array(ratio, np.uint64)).reshape(-1).copy()
+    def x_div(self, x, xi, n): return self.o.x_div_x_sub_xi(x, np.array(xi, np.uint64)).reshape(-1)
+    def q_split(self, qq1, n, ne, qdeg, qdim, s): return self.o.q_split(qq1, n, ne, qdeg, qdim, s)
+    def evmap(self, LEv, LpEv, n, eb, ents):
+        return self.o.evmap(LEv, LpEv, n, eb, [(sec.reshape(-1, w), c, d, pr) for sec, w, c, d, pr in ents])
+    def fri_fold(self, pol, bits, red, x, sinv): return self.o.fri_fold(pol, bits, red, np.array(x, np.uint64), sinv).reshape(-1)
+    def transpose3(self, pol2, n, tbits): return self.o.transpose3(pol2, n, tbits).reshape(-1)
+    def perm(self, st): return self.o.perm(np.array(st, np.uint64))
+    def proof(self, src, nodes, w, h, idx): return _merkle_proof_host(src, nodes, w, h, idx)
+
+
+class GpuBackend:
+    def __init__(self, xlp):
+        import torch
+        self.x, self.t, self.progs = xlp, torch, {}
+    def sync(self): self.x.sync()
+    def w(self, n): return gl_w(n)
+    def zeros(self, n): return self.t.zeros(n, dtype=self.t.int64, device="cuda")
+    def from_host(self, a): return self.x.from_np(np.ascontiguousarray(a, dtype=np.uint64))
+    def to_host(self, a): return self.x.to_np(a)
+    def copy_into(self, dst, src): dst.copy_(src)
+    def extend(self, dst, src, ne, n, w): self.x.dev_extend(dst, src, ne, n, w)
+    def ntt(self, dst, src, n, w, inverse): self.x.dev_ntt(dst, src, n, w, inverse)
+    def merkle(self, src, w, h):
+        nodes = self.zeros((2 * h - 1) * 4); self.x.dev_merkle(nodes, src, w, h); return nodes
+    def root(self, nodes, h): return [int(v) for v in self.x.to_np(nodes[-4:])]
+    def get_cols(self, sec, rows, W, c, d): return sec.view(rows, W)[:, c:c + d].contiguous().view(-1)
+    def set_cols(self, sec, rows, W, c, d, vals): sec.view(rows, W)[:, c:c + d] = vals.view(rows, d)
+    def h1h2(self, h1, h2, f, t, n, dim): self.x.dev_calculate_h1h2(h1, h2, f, t, n, dim)
+    def calc_z(self, z, num, den, n): self.x.dev_calculate_z(z, num, den, n)
+    def expr_run(self, prog, bufs, nc, nc2, row0, nrows):
+        if id(prog) not in self.progs:
+            self.progs[id(prog)] = self.x.ExprProgram(prog.code, prog.ntmp1, prog.ntmp3)
+        self.progs[id(prog)].run(self.x.steps_params(n_const_pols=nc, n_const_pols_2ns=nc2, **bufs), row0, nrows)
+    def geometric(self, n, dim, first, ratio):
+        out = self.zeros(n * dim); self.x.dev_geometric(out, n, dim, np.array(first, np.uint64), np.array(ratio, np.uint64)); return out
+    def x_div(self, x, xi, n):
+        out = self.zeros(3 * n); self.x.dev_x_div_x_sub_xi(out, x, np.array(xi, np.uint64), n); return out
+    def q_split(self, qq1, n, ne, qdeg, qdim, s):
+        out = self.zeros(ne * qdeg * qdim); self.x.dev_q_split(out, qq1, n, ne, qdeg, qdim, s); return out
+    def evmap(self, LEv, LpEv, n, eb, ents):
+        ev = self.zeros(3 * len(ents)); self.x.dev_evmap(ev, LEv, LpEv, n, eb, ents); return self.x.to_np(ev).reshape(-1, 3)
+    def fri_fold(self, pol, bits, red, x, sinv):
+        out = self.zeros(3 << (bits - red)); self.x.dev_fri_fold(out, pol, bits, red, np.array(x, np.uint64), sinv); return out
+    def transpose3(self, pol2, n, tbits):
+        out = self.zeros(3 * n); self.x.dev_transpose3(out, pol2, n, tbits); return out
+    def perm(self, st): return self.x.perm(np.array(st, np.uint64))
+    def proof(self, src, nodes, w, h, idx): return _merkle_proof_host(self.x.to_np(src), self.x.to_np(nodes), w, h, idx)
+
+

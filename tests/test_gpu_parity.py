@@ -463,3 +463,13 @@ def test_x_div_x_sub_xi_vs_oracle(xlp, orc, n):
     out = xlp.from_np(np.zeros(3 * n, np.uint64))
     xlp.dev_x_div_x_sub_xi(out, xlp.from_np(x), xi, n); xlp.sync()
     assert (xlp.to_np(out).reshape(-1, 3) == orc.x_div_x_sub_xi(x, xi)).all()
+
+
+@pytest.mark.parametrize("nbits,ebits,qdeg,qdim", [(4, 1, 2, 3), (10, 1, 2, 3), (8, 2, 3, 3), (12, 1, 1, 1)])
+def test_q_split_vs_oracle(xlp, orc, nbits, ebits, qdeg, qdim):
+    n, ne = 1 << nbits, 1 << (nbits + ebits)
+    qq1 = orc.fill(ne * qdim, 0x5EED0800 + nbits)
+    shift_in = orc.pow_(orc.inv(orc.shift()), n)
+    out = xlp.from_np(np.full(ne * qdeg * qdim, 7, np.uint64))
+    xlp.dev_q_split(out, xlp.from_np(qq1), n, ne, qdeg, qdim, shift_in); xlp.sync()
+    assert (xlp.to_np(out) == orc.q_split(qq1, n, ne, qdeg, qdim, shift_in)).all()

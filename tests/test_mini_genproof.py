@@ -1,0 +1,50 @@
+"""The toy prover of tests/mini_genproof_flow.py (every stage of Starks::genProof, starks.cpp:9-404) run on the HIP
+library and on the CPU oracle: all roots, evaluations, FRI layers, query indices and opened rows must agree."""
+import numpy as np
+import pytest
+
+from tests import mini_genproof_flow as flow
+
+from tests.mini_backends import GpuBackend, OracleBackend, gl_w
+
+
+def test_mini_pil_is_satisfied_on_the_oracle(orc):
+    """sanity of the toy system and of the H1H2 / Z restatements together: on the trace domain b = a^2, z[0] = 1 and
+    z' den = z num on EVERY row including the wrap-around -- i.e. the grand product over the plookup closes to 1,
+    which only happens if h1, h2 are the sorted merge the protocol asks for"""
+    out = flow.prove(OracleBackend(orc), 5, [6, 3], 4, seed=3, debug=True)
+    assert len(out["evals"]) == 14 and len(out["fri"]["queries"]) == 4
+    pols, L = out.pop("_state")
+    N = L.N
+    def sec(name):
+        o, w, rows = L.off[name]
+        return pols[o:o + w * rows].reshape(rows, w)
+    cm1, z, tmp = sec("cm1_n"), sec("cm3_n"), sec("tmpExp_n")
+    assert all(int(cm1[i, 1]) == orc.mul(int(cm1[i, 0]), int(cm1[i, 0])) for i in range(N))
+    assert [int(v) for v in z[0]] == [1, 0, 0]
+    for i in range(N):
+        lhs = orc.mul3(z[(i + 1) % N], tmp[i, 9:12]); rhs = orc.mul3(z[i], tmp[i, 6:9])
+        assert (lhs == rhs).all(), i
+    # and the proof verifies: transcript, Merkle paths, C(xi) = Q(xi) Zh(xi), FRI polynomial at the queries, folds
+    from tests.mini_verifier import verify
+    assert verify(orc, out, 5, [6, 3], 4, gl_w)
+    bad = dict(out); bad["evals"] = [list(e) for e in out["evals"]]; bad["evals"][4][0] ^= 1
+    with pytest.raises(AssertionError):
+        verify(orc, bad, 5, [6, 3], 4, gl_w)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nbits,steps,nq", [(5, [6, 3], 4), (8, [9, 6, 3], 8), (11, [12, 8, 4], 16)])
+def test_mini_genproof_gpu_equals_oracle(orc, nbits, steps, nq):
+    import torch
+    from xlayer_prover_amd import capi
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    capi.init(0); capi.use_torch_stream()
+    got = flow.prove(GpuBackend(capi), nbits, steps, nq, seed=nbits)
+    exp = flow.prove(OracleBackend(orc), nbits, steps, nq, seed=nbits)
+    assert got.keys() == exp.keys()
+    for k in exp:
+        assert got[k] == exp[k], k
+    from tests.mini_verifier import verify
+    assert verify(orc, got, nbits, steps, nq, gl_w)          # and what the GPU produced is a valid proof

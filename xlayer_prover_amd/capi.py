@@ -42,6 +42,7 @@ SIGNATURES = {
     "xlp_dev_calculate_z": [_pu, _pu, _pu, _u64],
     "xlp_dev_evmap": [_pu, _pu, _pu, _u64, _u32, _u32, _pu],
     "xlp_dev_geometric": [_pu, _u64, _u32, _pu, _pu],
+    "xlp_dev_q_split": [_pu, _pu, _u64, _u64, _u32, _u32, _u64],
     "xlp_dev_x_div_x_sub_xi": [_pu, _pu, _pu, _u64],
     "xlp_dev_calculate_h1h2": [_pu, _pu, _pu, _pu, _u64, _u32],
     "xlp_expr_create": [C.POINTER(C.c_void_p), _pu, _u64, _u64, _u64],
@@ -260,6 +261,10 @@ def dev_calculate_z(z, num, den, n):
 
 def dev_calculate_h1h2(h1, h2, f, t, n, dim=1):
     _ck(load().xlp_dev_calculate_h1h2(_dp(h1), _dp(h2), _dp(f), _dp(t), n, dim), "xlp_dev_calculate_h1h2")
+
+
+def dev_q_split(qq2, qq1, n, n_ext, q_deg, q_dim, shift_in):
+    _ck(load().xlp_dev_q_split(_dp(qq2), _dp(qq1), n, n_ext, q_deg, q_dim, shift_in), "xlp_dev_q_split")
 
 
 def dev_geometric(out, n, dim, first, ratio):

@@ -283,6 +283,32 @@ int dev_x_div_x_sub_xi(Ctx* ctx, u64* out, const u64* x, const u64* xi, u64 n)
     return 0;
 }
 
+// Step-4 coefficient split (starks.cpp:267-283): qq2[k * qDeg + p] = qq1[p * N + k] * shiftIn^p for k < N, p < qDeg
+// (elements of qDim words); rows N .. NExtended-1 of the (qDeg * qDim)-column matrix the following NTT reads are zero.
+__global__ __launch_bounds__(256) void q_split_kernel(u64* qq2, const u64* qq1, u64 n, u64 n_ext, u32 qdeg, u32 qdim, u64 shift_in)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;      // one (row, p) pair
+    if (t >= n_ext * qdeg) return;
+    const u64 k = t / qdeg;
+    const u32 p = (u32)(t % qdeg);
+    u64* dst = qq2 + t * qdim;
+    if (k >= n) { for (u32 c = 0; c < qdim; c++) dst[c] = 0; return; }
+    const u64 s = gl::pow(shift_in, p);
+    const u64* src = qq1 + ((u64)p * n + k) * qdim;
+    for (u32 c = 0; c < qdim; c++) dst[c] = gl::mulc(src[c], s);
+}
+
+int dev_q_split(Ctx* ctx, u64* qq2, const u64* qq1, u64 n, u64 n_ext, u32 qdeg, u32 qdim, u64 shift_in)
+{
+    if (!n_ext || !qdeg || !qdim) return 0;
+    if (n > n_ext || (u64)qdeg * n > n_ext) return xlp_fail("q split: needs qDeg * N <= NExtended");
+    if (qq2 == qq1) return xlp_fail("q split: in-place is not supported");
+    const u64 thr = n_ext * qdeg;
+    hipLaunchKernelGGL(q_split_kernel, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, ctx->stream, qq2, qq1, n, n_ext, qdeg, qdim, shift_in % hgl::P);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------ evmap
 // evals[i] = sum_k L_i[k] * pol_i[(k << eb) * stride_i ...]: grid (chunks of rows) x (eval i);
 // per-block partial sums -> partial[chunk][i][3]; a second kernel adds the chunks.
