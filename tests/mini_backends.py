@@ -89,6 +89,16 @@ class GpuBackend:
     def transpose3(self, pol2, n, tbits):
         out = self.zeros(3 * n); self.x.dev_transpose3(out, pol2, n, tbits); return out
     def perm(self, st): return self.x.perm(np.array(st, np.uint64))
-    def proof(self, src, nodes, w, h, idx): return _merkle_proof_host(self.x.to_np(src), self.x.to_np(nodes), w, h, idx)
+    def proof(self, src, nodes, w, h, idx):
+        # MerkleTreeGL::getGroupProof (merkleTreeGL.cpp:12-35): only the row and log2(h) sibling nodes leave the GPU
+        row = [int(v) for v in self.x.to_np(src[idx * w:(idx + 1) * w])]
+        pos, off, cnt, i = [], 0, h, idx
+        while cnt > 1:
+            pos.append(off + 4 * (i ^ 1)); off += 4 * cnt; cnt //= 2; i //= 2
+        if not pos:
+            return row, []
+        ix = (self.t.tensor(pos, device="cuda").view(-1, 1) + self.t.arange(4, device="cuda").view(1, 4)).view(-1)
+        sib = self.x.to_np(nodes[ix]).reshape(-1, 4)
+        return row, [[int(v) for v in r] for r in sib]
 
 
