@@ -359,12 +359,19 @@ class EvmapEntry(C.Structure):
     _fields_ = [("pol", C.c_void_p), ("row_stride", C.c_uint64), ("dim", C.c_uint32), ("prime", C.c_uint32)]
 
 
-def dev_evmap(evals, LEv, LpEv, n, extend_bits, entries):
-    """entries: list of (section tensor [rows*width] on device, width, column, dim, prime)"""
+def evmap_entries(entries):
+    """entries: list of (section tensor [rows*width] on device, width, column, dim, prime) -> reusable descriptor array"""
     arr = (EvmapEntry * len(entries))()
     for i, (t, width, col, dim, prime) in enumerate(entries):
         arr[i] = EvmapEntry(t.data_ptr() + 8 * col, width, dim, 1 if prime else 0)
-    _ck(load().xlp_dev_evmap(_dp(evals), _dp(LEv), _dp(LpEv), n, extend_bits, len(entries), C.cast(arr, C.c_void_p)), "xlp_dev_evmap")
+    arr._keep = [e[0] for e in entries]
+    return arr
+
+
+def dev_evmap(evals, LEv, LpEv, n, extend_bits, entries):
+    """entries: the list evmap_entries() takes, or its result (build it once when the call is repeated)"""
+    arr = entries if isinstance(entries, C.Array) else evmap_entries(entries)
+    _ck(load().xlp_dev_evmap(_dp(evals), _dp(LEv), _dp(LpEv), n, extend_bits, len(arr), C.cast(arr, C.c_void_p)), "xlp_dev_evmap")
 
 
 def to_np(t):

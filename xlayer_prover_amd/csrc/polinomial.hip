@@ -4,6 +4,7 @@
 //   Starks::evmap                                     src/starkpil/starks.cpp:556-669      (mulAddElement_adim3 polinomial.hpp:722-744)
 // All are scan / reduce / map shapes over 2^23..2^24 rows of Fp or Fp^3 elements.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 #include "gl_field.hpp"
 #include "xlp_internal.hpp"
@@ -310,36 +311,77 @@ int dev_q_split(Ctx* ctx, u64* qq2, const u64* qq1, u64 n, u64 n_ext, u32 qdeg, 
 }
 
 // ------------------------------------------------------------------ evmap
-// evals[i] = sum_k L_i[k] * pol_i[(k << eb) * stride_i ...]: grid (chunks of rows) x (eval i);
-// per-block partial sums -> partial[chunk][i][3]; a second kernel adds the chunks.
-constexpr int EV_T = 256, EV_ROWS = 4096;
-struct EvEntryDev { const u64* pol; u64 stride; u32 dim; u32 prime; };
+// evals[i] = sum_k L_i[k] * pol_i[(k << eb) * stride_i].  Lanes run along the ENTRIES, sorted by address on the host:
+// neighbouring entries are neighbouring columns of one row-major section, so a wave reads contiguous bytes of a
+// row (a column-per-block layout gathers 8 bytes per 128-byte line: 15x slower at zkEVM widths).  L[k] is
+// wave-uniform per prime flag (one broadcast line).  Blocks cover EV_ROWS rows x EV_T entries and write partial sums
+// partial[chunk][original entry][3]; evmap_final_kernel adds the chunks.
+constexpr int EV_T = 256, EV_ROWS = 4096, EV_SUB = 512;   // rows per block / rows of L staged in LDS at a time
+struct EvEntryDev { const u64* pol; u64 stride; u32 dim; u32 prime; u32 orig; u32 pad; };
+typedef const __attribute__((address_space(1))) u64* gptr_t;   // entry pointers come from memory: tell the compiler they are global
 
 __global__ __launch_bounds__(EV_T) void evmap_partial_kernel(u64* partial, const u64* LEv, const u64* LpEv, u64 n, u32 eb, const EvEntryDev* ents, u32 nev)
 {
-    __shared__ u64 sh[EV_T][3];
-    const u32 i = blockIdx.y;
-    const EvEntryDev e = ents[i];
-    const u64* L = e.prime ? LpEv : LEv;
-    const u64 k0 = (u64)blockIdx.x * EV_ROWS;
-    e3 acc; acc.c[0] = acc.c[1] = acc.c[2] = 0;
-    for (u64 k = k0 + threadIdx.x; k < k0 + EV_ROWS && k < n; k += EV_T) {
-        const e3 a = load3(L + 3 * k);
-        const u64* b = e.pol + (k << eb) * e.stride;
-        e3 t;
-        if (e.dim == 1) t = gl::mul3s(a, b[0]);
-        else t = gl::mul3(a, load3(b));
-        acc = gl::add3(acc, t);
-    }
-    sh[threadIdx.x][0] = acc.c[0]; sh[threadIdx.x][1] = acc.c[1]; sh[threadIdx.x][2] = acc.c[2];
-    __syncthreads();
-    for (int off = EV_T / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off)
-            for (int d = 0; d < 3; d++) sh[threadIdx.x][d] = gl::addc(sh[threadIdx.x][d], sh[threadIdx.x + off][d]);
+    __shared__ u64 sL[2][EV_SUB * 3];                      // LEv / LpEv rows of the current sub-chunk (24 KiB)
+    const u32 ei = blockIdx.x * EV_T + threadIdx.x;          // entry blocks fastest: the blocks of one row range run together
+    const bool live = ei < nev;
+    EvEntryDev e = ents[live ? ei : 0];
+    const u64 k0 = (u64)blockIdx.y * EV_ROWS;
+    const u64 k1 = k0 + EV_ROWS < n ? k0 + EV_ROWS : n;
+    const u64 rstep = e.stride << eb;
+    gptr_t b = (gptr_t)e.pol + k0 * rstep;
+    const u64* l = sL[e.prime ? 1 : 0];
+    // lazy accumulation: the 128-bit products of a row are added unreduced into (lo, hi, overflow count); one
+    // reduction per block (2^128 = -2^32 mod p) instead of a multiply-reduce and an add-reduce per term
+    unsigned __int128 s128[3] = {0, 0, 0};
+    u32 ovf[3] = {0, 0, 0};
+    e3 acc3; acc3.c[0] = acc3.c[1] = acc3.c[2] = 0;         // dim-3 entries: plain extension arithmetic
+    constexpr int U = 8;                                   // rows in flight per lane
+    for (u64 s0 = k0; s0 < k1; s0 += EV_SUB) {
+        const u32 rows = (u32)(k1 - s0 < EV_SUB ? k1 - s0 : EV_SUB);
+        __syncthreads();                                   // previous sub-chunk fully consumed
+        for (u32 i = threadIdx.x; i < rows * 3; i += EV_T) { sL[0][i] = gl::canon(LEv[3 * s0 + i]); sL[1][i] = gl::canon(LpEv[3 * s0 + i]); }
         __syncthreads();
+        if (!live) continue;
+        if (e.dim == 1) {
+            u32 k = 0;
+            for (; k + U <= rows; k += U, b += U * rstep) {
+                u64 v[U];
+#pragma unroll
+                for (int j = 0; j < U; j++) v[j] = b[j * rstep];
+#pragma unroll
+                for (int j = 0; j < U; j++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const unsigned __int128 pr = (unsigned __int128)l[3 * (k + j) + c] * v[j];
+                        s128[c] += pr;
+                        ovf[c] += s128[c] < pr;
+                    }
+            }
+            for (; k < rows; k++, b += rstep)
+                for (int c = 0; c < 3; c++) {
+                    const unsigned __int128 pr = (unsigned __int128)l[3 * k + c] * b[0];
+                    s128[c] += pr;
+                    ovf[c] += s128[c] < pr;
+                }
+        } else {
+            for (u32 k = 0; k < rows; k++, b += rstep) {
+                e3 a, x;
+                a.c[0] = l[3 * k]; a.c[1] = l[3 * k + 1]; a.c[2] = l[3 * k + 2];
+                x.c[0] = gl::canon(b[0]); x.c[1] = gl::canon(b[1]); x.c[2] = gl::canon(b[2]);
+                acc3 = gl::add3(acc3, gl::mul3(a, x));
+            }
+        }
     }
-    if (threadIdx.x == 0)
-        for (int d = 0; d < 3; d++) partial[((u64)blockIdx.x * nev + i) * 3 + d] = sh[0][d];
+    if (!live) return;
+    e3 acc = acc3;
+    if (e.dim == 1)
+        for (int c = 0; c < 3; c++) {
+            const u64 r = gl::canon(gl::reduce128((u64)s128[c], (u64)(s128[c] >> 64)));
+            acc.c[c] = gl::subc(r, gl::mulc((u64)ovf[c], 1ULL << 32));
+        }
+    u64* dst = partial + ((u64)blockIdx.y * nev + e.orig) * 3;
+    dst[0] = acc.c[0]; dst[1] = acc.c[1]; dst[2] = acc.c[2];
 }
 
 __global__ void evmap_final_kernel(u64* evals, const u64* partial, u64 nchunks, u32 nev)
@@ -362,12 +404,13 @@ int dev_evmap(Ctx* ctx, u64* evals, const u64* LEv, const u64* LpEv, u64 n, u32 
     std::vector<EvEntryDev> h(nev);
     for (u32 i = 0; i < nev; i++) {
         if (entries[i].dim != 1 && entries[i].dim != 3) return xlp_fail("evmap: dim must be 1 or 3");
-        h[i] = EvEntryDev{entries[i].pol, entries[i].row_stride, entries[i].dim, entries[i].prime};
+        h[i] = EvEntryDev{entries[i].pol, entries[i].row_stride, entries[i].dim, entries[i].prime, i, 0};
     }
+    std::stable_sort(h.begin(), h.end(), [](const EvEntryDev& x, const EvEntryDev& y) { return x.pol < y.pol; });   // lanes = neighbouring columns
     XLP_HIP(hipMemcpyAsync(scratch, h.data(), nev * sizeof(EvEntryDev), hipMemcpyHostToDevice, ctx->stream));
     XLP_HIP(hipStreamSynchronize(ctx->stream));   // h goes out of scope
     u64* partial = (u64*)((char*)scratch + ent_bytes);
-    hipLaunchKernelGGL(evmap_partial_kernel, dim3((unsigned)nchunks, nev), dim3(EV_T), 0, ctx->stream, partial, LEv, LpEv, n, eb,
+    hipLaunchKernelGGL(evmap_partial_kernel, dim3((nev + EV_T - 1) / EV_T, (unsigned)nchunks), dim3(EV_T), 0, ctx->stream, partial, LEv, LpEv, n, eb,
                        (const EvEntryDev*)scratch, nev);
     hipLaunchKernelGGL(evmap_final_kernel, dim3((nev * 3 + 63) / 64), dim3(64), 0, ctx->stream, evals, partial, nchunks, nev);
     XLP_HIP(hipGetLastError());
