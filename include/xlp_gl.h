@@ -81,6 +81,12 @@ int xlp_fri_fold(uint64_t* pol2, const uint64_t* pol, uint32_t bits, uint32_t re
  * n ext-3 elements; dst[i*h + j] = src[j*w + i], w = 2^tbits, h = n / w. */
 int xlp_transpose3(uint64_t* dst, const uint64_t* src, uint64_t n, uint32_t tbits);
 
+/* Polinomial::batchInverse / calculateZ / calculateH1H2 on host buffers (dense: n elements of `dim` words, the
+ * C++ mirror packs the reference's strided Polinomial views): same semantics as the xlp_dev_* forms below. */
+int xlp_batch_inverse(uint64_t* res, const uint64_t* src, uint64_t n, uint32_t dim);
+int xlp_calculate_z(uint64_t* z, const uint64_t* num, const uint64_t* den, uint64_t n);
+int xlp_calculate_h1h2(uint64_t* h1, uint64_t* h2, const uint64_t* f, const uint64_t* t, uint64_t n, uint32_t dim);
+
 /* ---- device-pointer API -------------------------------------------------- */
 /* Same semantics as above; pointers are device memory on the bound device;
  * calls enqueue on the context stream and return without synchronising. */

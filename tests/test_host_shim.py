@@ -37,3 +37,21 @@ def test_mini_genproof_matches_oracle(orc, cfg):
     # zkin geometry matches the reference's golden files (proof2zkinStark.cpp:8-82): absent cm2 keys
     assert "s0_vals2" not in got and "s0_siblings2" not in got
     assert len(got["s0_siblings1"][0]) == nBitsExt and len(got["finalPol"]) == 1 << steps[-1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,seed", [(5, 1), (64, 2), (1000, 3)])
+def test_polinomial_mirror_matches_oracle(orc, n, seed):
+    """Polinomial::batchInverse / batchInverseParallel / calculateZ / calculateH1H2_opt1 of the C++ mirror (strided
+    views of one slab, polinomial.hpp:249-720) against the oracle"""
+    import numpy as np
+    r = subprocess.run([EXE, "polinomial", str(n), str(seed)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = {k: np.array([int(v) for v in vals], np.uint64) for k, vals in json.loads(r.stdout).items()}
+    slab = got["slab"].reshape(n, 11)
+    a, b = np.ascontiguousarray(slab[:, 0:3]), np.ascontiguousarray(slab[:, 3:6])
+    assert (got["inv3"].reshape(n, 3) == orc.batch_inverse(a.reshape(-1), 3)).all()
+    assert (got["z"].reshape(n, 3) == orc.calculate_z(a, b)).all()
+    assert (got["inv1"] == orc.batch_inverse(np.ascontiguousarray(slab[:, 9]), 1)).all()
+    h1, h2 = orc.calculate_h1h2(got["f"], got["t"], 1)
+    assert (got["h1"] == h1).all() and (got["h2"] == h2).all()

@@ -29,6 +29,9 @@ SIGNATURES = {
     "xlp_linear_hash": [_pu, _pu, _u64, _u64],
     "xlp_fri_fold": [_pu, _pu, _u32, _u32, _pu, _u64],
     "xlp_transpose3": [_pu, _pu, _u64, _u32],
+    "xlp_batch_inverse": [_pu, _pu, _u64, _u32],
+    "xlp_calculate_z": [_pu, _pu, _pu, _u64],
+    "xlp_calculate_h1h2": [_pu, _pu, _pu, _pu, _u64, _u32],
     "xlp_dev_ntt": [_pu, _pu, _u64, _u64, C.c_int],
     "xlp_dev_extend": [_pu, _pu, _u64, _u64, _u64, _pu],
     "xlp_dev_merkle": [_pu, _pu, _u64, _u64],

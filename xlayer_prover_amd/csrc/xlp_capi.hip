@@ -369,6 +369,52 @@ int xlp_fri_fold(uint64_t* pol2, const uint64_t* pol, uint32_t bits, uint32_t re
     return 0;
 }
 
+int xlp_batch_inverse(uint64_t* res, const uint64_t* src, uint64_t n, uint32_t dim)
+{
+    if (ensure_init()) return -1;
+    if (n == 0) return 0;
+    if (!res || !src) return xlp_fail("xlp_batch_inverse: null pointer");
+    if (dim != 1 && dim != 3) return xlp_fail("batchInverse: dim must be 1 or 3");
+    DevBuf a;
+    const size_t bytes = n * dim * sizeof(u64);
+    if (a.alloc(bytes)) return -1;
+    H2D(a, src, bytes);
+    if (dev_batch_inverse(&g_ctx, a.u(), a.u(), n, dim)) return -1;
+    D2H(res, a, bytes);
+    return 0;
+}
+int xlp_calculate_z(uint64_t* z, const uint64_t* num, const uint64_t* den, uint64_t n)
+{
+    if (ensure_init()) return -1;
+    if (n == 0) return 0;
+    if (!z || !num || !den) return xlp_fail("xlp_calculate_z: null pointer");
+    DevBuf a, b, c;
+    const size_t bytes = n * 3 * sizeof(u64);
+    if (a.alloc(bytes) || b.alloc(bytes) || c.alloc(bytes)) return -1;
+    H2D(a, num, bytes);
+    H2D(b, den, bytes);
+    if (dev_calculate_z(&g_ctx, c.u(), a.u(), b.u(), n)) return -1;
+    D2H(z, c, bytes);
+    return 0;
+}
+int xlp_calculate_h1h2(uint64_t* h1, uint64_t* h2, const uint64_t* f, const uint64_t* t, uint64_t n, uint32_t dim)
+{
+    if (ensure_init()) return -1;
+    if (n == 0) return 0;
+    if (!h1 || !h2 || !f || !t) return xlp_fail("xlp_calculate_h1h2: null pointer");
+    if (dim != 1 && dim != 3) return xlp_fail("calculateH1H2: dim must be 1 or 3");
+    DevBuf a, b, c, d;
+    const size_t bytes = n * dim * sizeof(u64);
+    if (a.alloc(bytes) || b.alloc(bytes) || c.alloc(bytes) || d.alloc(bytes)) return -1;
+    H2D(a, f, bytes);
+    H2D(b, t, bytes);
+    if (dev_calculate_h1h2(&g_ctx, c.u(), d.u(), a.u(), b.u(), n, dim)) return -1;
+    XLP_HIP(hipStreamSynchronize(g_ctx.stream));
+    D2H(h1, c, bytes);
+    D2H(h2, d, bytes);
+    return 0;
+}
+
 int xlp_field_op(uint64_t* out, const uint64_t* a, const uint64_t* b, uint64_t n, int op)
 {
     if (ensure_init()) return -1;

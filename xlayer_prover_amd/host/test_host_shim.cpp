@@ -7,8 +7,44 @@
 #include <vector>
 #include "starks_mini.hpp"
 
+// `polinomial <n> <seed>`: Polinomial::batchInverse / calculateZ / calculateH1H2 through STRIDED views of one slab
+// (offset > dim, as the section views of starks.cpp:108-184 are), results as JSON for the oracle comparison.
+static int polinomial_mode(uint64_t n, uint64_t seed)
+{
+    typedef Goldilocks::Element E;
+    const uint64_t W = 11;                                  // slab width: columns 0-2 a, 3-5 b, 6-8 out3, 9 f/h1, 10 t/h2
+    std::vector<E> slab(n * W), tcol(n), fcol(n), h1(n), h2(n), inv1(n);
+    mini_fill(slab.data(), slab.size(), seed);
+    for (uint64_t i = 0; i < n; i++) { tcol[i].fe = (i / 3) * 7 + 1; }                       // table with repeats
+    for (uint64_t i = 0; i < n; i++) fcol[i] = tcol[mini_splitmix64(seed ^ (i + 99)) % n];   // every f value occurs in t
+    auto dump = [](const char* name, Goldilocks::Element* p, uint64_t cnt, uint64_t dim, uint64_t off, bool last) {
+        printf("\"%s\":[", name);
+        for (uint64_t i = 0; i < cnt; i++)
+            for (uint64_t c = 0; c < dim; c++) printf("%s\"%s\"", (i || c) ? "," : "", Goldilocks::toString(p[i * off + c]).c_str());
+        printf("]%s", last ? "" : ",");
+    };
+    printf("{");
+    dump("slab", slab.data(), n * W, 1, 1, false);
+    Polinomial a(&slab[0], n, 3, W), b(&slab[3], n, 3, W), o3(&slab[6], n, 3, W);
+    Polinomial::batchInverse(o3, a);
+    dump("inv3", &slab[6], n, 3, W, false);
+    Polinomial::calculateZ(o3, a, b);
+    dump("z", &slab[6], n, 3, W, false);
+    Polinomial c1(&slab[9], n, 1, W), r1(inv1.data(), n, 1);
+    Polinomial::batchInverseParallel(r1, c1);
+    dump("inv1", inv1.data(), n, 1, 1, false);
+    Polinomial f(fcol.data(), n, 1), t(tcol.data(), n, 1), H1(h1.data(), n, 1), H2(h2.data(), n, 1);
+    Polinomial::calculateH1H2_opt1(H1, H2, f, t, 0, NULL, 0, 0);
+    dump("f", fcol.data(), n, 1, 1, false); dump("t", tcol.data(), n, 1, 1, false);
+    dump("h1", h1.data(), n, 1, 1, false); dump("h2", h2.data(), n, 1, 1, true);
+    printf("}\n");
+    xlp_shutdown();
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc == 4 && std::string(argv[1]) == "polinomial") return polinomial_mode(strtoull(argv[2], 0, 10), strtoull(argv[3], 0, 10));
     if (argc < 5) { fprintf(stderr, "usage: %s nBits nBitsExt nQueries step0 [step1 ...]\n", argv[0]); return 2; }
     MiniStarkConfig cfg;
     cfg.nBits = strtoull(argv[1], 0, 10);

@@ -332,6 +332,51 @@ public:
         for (uint64_t i = 0; i < cnt; i++) os << (i ? " " : "") << Goldilocks::toString(_pAddress[i * _offset]);
         return os.str();
     }
+
+    // ---- row-scale helpers (polinomial.hpp:249-720), same static signatures; the strided view is packed to a
+    // dense buffer, the work runs on the GPU (xlp_batch_inverse / xlp_calculate_z / xlp_calculate_h1h2)
+private:
+    std::vector<uint64_t> pack() const
+    {
+        std::vector<uint64_t> d(_degree * _dim);
+        for (uint64_t i = 0; i < _degree; i++)
+            for (uint64_t c = 0; c < _dim; c++) d[i * _dim + c] = _pAddress[i * _offset + c].fe;
+        return d;
+    }
+    void unpack(const std::vector<uint64_t>& d)
+    {
+        for (uint64_t i = 0; i < _degree; i++)
+            for (uint64_t c = 0; c < _dim; c++) _pAddress[i * _offset + c].fe = d[i * _dim + c];
+    }
+public:
+    static void batchInverse(Polinomial& res, Polinomial& src)
+    {
+        if (res.dim() != src.dim() || res.degree() != src.degree()) xlp_exit_process("Polinomial::batchInverse: shape mismatch");
+        std::vector<uint64_t> a = src.pack();
+        XLP_CHECK(xlp_batch_inverse(a.data(), a.data(), src.degree(), (uint32_t)src.dim()));
+        res.unpack(a);
+    }
+    static void batchInverseParallel(Polinomial& res, Polinomial& src) { batchInverse(res, src); }
+    static void calculateZ(Polinomial& z, Polinomial& num, Polinomial& den)
+    {
+        if (z.dim() != 3 || num.dim() != 3 || den.dim() != 3 || z.degree() != num.degree() || z.degree() != den.degree())
+            xlp_exit_process("Polinomial::calculateZ: three ext-3 polynomials of one degree expected");
+        std::vector<uint64_t> a = num.pack(), b = den.pack(), c(a.size());
+        XLP_CHECK(xlp_calculate_z(c.data(), a.data(), b.data(), z.degree()));
+        z.unpack(c);
+    }
+    static void calculateH1H2(Polinomial& h1, Polinomial& h2, Polinomial& fPol, Polinomial& tPol)
+    {
+        if (h1.dim() != fPol.dim() || h2.dim() != fPol.dim() || tPol.dim() != fPol.dim() || h1.degree() != fPol.degree() ||
+            h2.degree() != fPol.degree() || tPol.degree() != fPol.degree())
+            xlp_exit_process("Polinomial::calculateH1H2: shape mismatch");
+        std::vector<uint64_t> f = fPol.pack(), t = tPol.pack(), a(f.size()), b(f.size());
+        XLP_CHECK(xlp_calculate_h1h2(a.data(), b.data(), f.data(), t.data(), fPol.degree(), (uint32_t)fPol.dim()));   // "Number not included" -> exitProcess
+        h1.unpack(a); h2.unpack(b);
+    }
+    // the reference's scratch-buffer variants (starks.cpp:116,123): the buffer arguments are not needed here
+    static void calculateH1H2_opt1(Polinomial& h1, Polinomial& h2, Polinomial& fPol, Polinomial& tPol, uint64_t, uint64_t*, uint64_t, uint64_t) { calculateH1H2(h1, h2, fPol, tPol); }
+    static void calculateH1H2_opt3(Polinomial& h1, Polinomial& h2, Polinomial& fPol, Polinomial& tPol, uint64_t, uint64_t*, uint64_t, uint64_t) { calculateH1H2(h1, h2, fPol, tPol); }
 };
 
 // ------------------------------------------------------------------- FRIProof
