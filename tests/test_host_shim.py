@@ -55,3 +55,62 @@ def test_polinomial_mirror_matches_oracle(orc, n, seed):
     assert (got["inv1"] == orc.batch_inverse(np.ascontiguousarray(slab[:, 9]), 1)).all()
     h1, h2 = orc.calculate_h1h2(got["f"], got["t"], 1)
     assert (got["h1"] == h1).all() and (got["h2"] == h2).all()
+
+
+def _zkevm_like_starkinfo():
+    """a starkinfo.json with the fork-9 zkEVM geometry: section widths 751 / 168 / 408 / 6 / 389, N = 2^23, blow-up 2.
+    The offsets computed here the way pil-stark lays the slab out (sections in eSection order of use: cm*_n, tmpExp_n,
+    cm*_2ns, q_2ns, f_2ns) must reproduce the offsets baked into the reference's generated step tables."""
+    N, NE = 1 << 23, 1 << 24
+    widths = {"cm1_n": 751, "cm2_n": 168, "cm3_n": 408, "cm4_n": 6, "tmpExp_n": 389, "cm1_2ns": 751, "cm2_2ns": 168, "cm3_2ns": 408, "cm4_2ns": 6,
+              "q_2ns": 3, "f_2ns": 3}
+    order = ["cm1_n", "cm2_n", "cm3_n", "cm4_n", "tmpExp_n", "cm1_2ns", "cm2_2ns", "cm3_2ns", "cm4_2ns", "q_2ns", "f_2ns"]
+    off, o = {}, 0
+    for s in order:
+        off[s] = o
+        o += widths[s] * (N if s.endswith("_n") else NE)
+    deg = {s: (N if s.endswith("_n") else NE) for s in order}
+    var = [{"section": "cm1_n", "dim": 1, "sectionPos": 0}, {"section": "cm1_n", "dim": 1, "sectionPos": 750}, {"section": "cm3_n", "dim": 3, "sectionPos": 405},
+           {"section": "cm2_2ns", "dim": 1, "sectionPos": 7}, {"section": "q_2ns", "dim": 3, "sectionPos": 0}, {"section": "tmpExp_n", "dim": 3, "sectionPos": 12}]
+    op = {"op": "mul", "dest": {"type": "tmp", "id": 4}, "src": [{"type": "cm", "id": 17, "prime": True}, {"type": "number", "value": "18446744069414584320"}]}
+    step = {"tmpUsed": 9, "first": [op], "i": [], "last": []}
+    j = {"starkStruct": {"nBits": 23, "nBitsExt": 24, "nQueries": 128, "verificationHashType": "GL", "steps": [{"nBits": b} for b in (24, 19, 14, 10, 6)]},
+         "mapTotalN": o, "nConstants": 233, "nPublics": 44, "nCm1": 751, "nCm2": 168, "nCm3": 408, "nCm4": 6, "friExpId": 99, "nExps": 3000, "qDim": 3, "qDeg": 2,
+         "mapDeg": deg, "mapOffsets": off, "mapSections": {s: list(range(3)) for s in order}, "mapSectionsN": widths,
+         "mapSectionsN1": {s: widths[s] for s in order}, "mapSectionsN3": {s: 0 for s in order}, "varPolMap": var, "qs": [1, 2], "cm_n": [0, 1], "cm_2ns": [3],
+         "peCtx": [{"tExpId": 1, "fExpId": 2, "zId": 3, "c1Id": 4, "numId": 5, "denId": 6, "c2Id": 7}],
+         "puCtx": [{"tExpId": 1, "fExpId": 2, "h1Id": 8, "h2Id": 9, "zId": 3, "c1Id": 4, "numId": 5, "denId": 6, "c2Id": 7}] * 2,
+         "ciCtx": [], "evMap": [{"type": "cm", "id": 5, "prime": False}, {"type": "const", "id": 2, "prime": True}, {"type": "q", "id": 0, "prime": False}],
+         "step2prev": step, "step3prev": step, "step3": step, "step42ns": step, "step52ns": step,
+         "exps_n": [None, 4], "q_2ns": [None], "cm4_n": [], "cm4_2ns": [1], "tmpExp_n": [None, None, 7], "exp2pol": {"12": 5, "40": 2}}
+    return j, off, widths, var, N, NE
+
+
+def test_starkinfo_mirror_loads_zkevm_geometry(tmp_path):
+    """StarkInfo (stark_info.cpp:21-520) in the C++ mirror; no GPU involved.  The slab offsets must equal the ones
+    recovered from the reference's generated zkEVM step tables (zkevm.chelpers.step*.parser.hpp arguments)."""
+    j, off, widths, var, N, NE = _zkevm_like_starkinfo()
+    # offsets found in the reference's tables (SURVEY.md 8a9; tests/expr_real.py clusters the same values)
+    assert off["cm2_n"] == 6299844608 and off["cm3_n"] == 7709130752 and off["cm4_n"] == 11131682816 and off["tmpExp_n"] == 11182014464
+    assert off["cm1_2ns"] == 14445182976 and off["cm2_2ns"] == 27044872192 and off["cm3_2ns"] == 29863444480 and off["cm4_2ns"] == 36708548608
+    assert off["q_2ns"] == 36809211904 and off["f_2ns"] == 36859543552 and j["mapTotalN"] == 36909875200
+    f = tmp_path / "zkevm.starkinfo.json"
+    f.write_text(json.dumps(j, indent=1))
+    r = subprocess.run([EXE, "starkinfo", str(f)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout)
+    assert (got["nBits"], got["nBitsExt"], got["nQueries"], got["hash"], got["steps"]) == (23, 24, 128, "GL", [24, 19, 14, 10, 6])
+    assert got["mapTotalN"] == j["mapTotalN"] and got["nConstants"] == 233 and got["qDeg"] == 2
+    assert got["constTreeBytes"] == (233 * NE + NE * 4 + (NE - 1) * 4 + 2) * 8
+    sec_order = ["cm1_n", "cm1_2ns", "cm2_n", "cm2_2ns", "cm3_n", "cm3_2ns", "cm4_n", "cm4_2ns", "tmpExp_n", "q_2ns", "f_2ns"]     # eSection numbering
+    assert got["offsets"] == [off[s] for s in sec_order]
+    for v, p in zip(var, got["pols"]):
+        rows = N if v["section"].endswith("_n") else NE
+        base = off[v["section"]] + v["sectionPos"]
+        assert p == [base, rows, v["dim"], widths[v["section"]], rows * v["dim"] * 8, base + 3 * widths[v["section"]]]
+    assert got["evMap"] == [[0, 5, 0], [1, 2, 1], [2, 0, 0]]
+    assert (got["puCtx"], got["peCtx"], got["ciCtx"], got["step3_ops"]) == (2, 1, 0, 1)
+    assert got["step3_first_src"] == [[14, 17, 1, ""], [8, 0, 0, "18446744069414584320"]] and got["exp2pol"] == 2 and got["tmpExp_n"] == 3
+    bad = tmp_path / "bad.json"; bad.write_text('{"starkStruct": {"nBits": 3}}')
+    r = subprocess.run([EXE, "starkinfo", str(bad)], capture_output=True, text=True)
+    assert r.returncode != 0 and "missing member" in r.stderr

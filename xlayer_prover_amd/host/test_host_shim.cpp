@@ -42,8 +42,39 @@ static int polinomial_mode(uint64_t n, uint64_t seed)
     return 0;
 }
 
+// `starkinfo <file>`: loads a starkinfo.json with the mirror of StarkInfo and prints what genProof reads from it
+static int starkinfo_mode(const char* file)
+{
+    StarkInfo si(file);
+    printf("{\"nBits\":%llu,\"nBitsExt\":%llu,\"nQueries\":%llu,\"hash\":\"%s\",\"steps\":[", (unsigned long long)si.starkStruct.nBits,
+           (unsigned long long)si.starkStruct.nBitsExt, (unsigned long long)si.starkStruct.nQueries, si.starkStruct.verificationHashType.c_str());
+    for (size_t i = 0; i < si.starkStruct.steps.size(); i++) printf("%s%llu", i ? "," : "", (unsigned long long)si.starkStruct.steps[i].nBits);
+    printf("],\"mapTotalN\":%llu,\"nConstants\":%llu,\"qDeg\":%llu,\"constTreeBytes\":%llu,\"offsets\":[", (unsigned long long)si.mapTotalN,
+           (unsigned long long)si.nConstants, (unsigned long long)si.qDeg, (unsigned long long)si.getConstTreeSizeInBytes());
+    for (int s = 0; s < eSectionMax; s++) printf("%s%llu", s ? "," : "", (unsigned long long)si.mapOffsets.section[s]);
+    printf("],\"pols\":[");
+    Goldilocks::Element* base = (Goldilocks::Element*)0;
+    for (size_t id = 0; id < si.varPolMap.size(); id++) {
+        Polinomial p; si.getPolinomial(p, base, id);
+        PolInfo pi; si.getPol(base, id, pi);
+        printf("%s[%llu,%llu,%llu,%llu,%llu,%llu]", id ? "," : "", (unsigned long long)(p.address() - base), (unsigned long long)p.degree(),
+               (unsigned long long)p.dim(), (unsigned long long)p.offset(), (unsigned long long)si.getPolSize(id), (unsigned long long)(pi.get(3) - base));
+    }
+    printf("],\"evMap\":[");
+    for (size_t i = 0; i < si.evMap.size(); i++) printf("%s[%d,%llu,%d]", i ? "," : "", (int)si.evMap[i].type, (unsigned long long)si.evMap[i].id, si.evMap[i].prime ? 1 : 0);
+    printf("],\"puCtx\":%zu,\"peCtx\":%zu,\"ciCtx\":%zu,\"step3_ops\":%zu,\"step3_first_src\":[", si.puCtx.size(), si.peCtx.size(), si.ciCtx.size(), si.step3.first.size());
+    if (!si.step3.first.empty())
+        for (size_t k = 0; k < si.step3.first[0].src.size(); k++) {
+            const StepType& t = si.step3.first[0].src[k];
+            printf("%s[%d,%llu,%d,\"%s\"]", k ? "," : "", (int)t.type, (unsigned long long)t.id, t.prime ? 1 : 0, t.value.c_str());
+        }
+    printf("],\"exp2pol\":%zu,\"tmpExp_n\":%zu}\n", si.exp2pol.size(), si.tmpExp_n.size());
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc == 3 && std::string(argv[1]) == "starkinfo") return starkinfo_mode(argv[2]);
     if (argc == 4 && std::string(argv[1]) == "polinomial") return polinomial_mode(strtoull(argv[2], 0, 10), strtoull(argv[3], 0, 10));
     if (argc < 5) { fprintf(stderr, "usage: %s nBits nBitsExt nQueries step0 [step1 ...]\n", argv[0]); return 2; }
     MiniStarkConfig cfg;

@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -435,13 +436,262 @@ public:
         : proofs(polN, dim, numTrees, evalSize), publics(nPublics) {}
 };
 
-// ------------------------------------------------------ StarkInfo (FRI subset)
+// ------------------------------------------------------------------ StarkInfo (stark_info.hpp:19-336, stark_info.cpp:21-520)
+// The contents of <pil>.starkinfo.json: STARK geometry, the slab layout (mapOffsets / mapSectionsN / varPolMap), the
+// plookup / permutation / connection contexts, the evaluation map and the step programs.  Same member names and
+// accessors as the reference; parsed with the small JSON reader below (the image has no nlohmann/json).
+namespace xlp_json {
+struct Value {
+    enum Kind { Null, Bool, Number, String, Array, Object } kind = Null;
+    bool b = false;
+    uint64_t u = 0;                 // numbers are unsigned integers in starkinfo files
+    std::string s;                  // string value, or the literal text of a number
+    std::vector<Value> a;
+    std::vector<std::pair<std::string, Value>> o;
+    bool is_null() const { return kind == Null; }
+    bool contains(const std::string& k) const { for (const auto& kv : o) if (kv.first == k) return true; return false; }
+    size_t size() const { return kind == Array ? a.size() : kind == Object ? o.size() : 0; }
+    const Value& operator[](const std::string& k) const
+    {
+        for (const auto& kv : o) if (kv.first == k) return kv.second;
+        xlp_exit_process(("starkinfo: missing member \"" + k + "\"").c_str());
+        return *this;
+    }
+    const Value& operator[](const char* k) const { return (*this)[std::string(k)]; }
+    const Value& operator[](size_t i) const { if (i >= a.size()) xlp_exit_process("starkinfo: array index out of range"); return a[i]; }
+    operator uint64_t() const { if (kind != Number) xlp_exit_process("starkinfo: number expected"); return u; }
+    operator bool() const { if (kind != Bool) xlp_exit_process("starkinfo: boolean expected"); return b; }
+    std::string str() const { if (kind != String && kind != Number) xlp_exit_process("starkinfo: string expected"); return s; }
+};
+class Parser {
+    const std::string& t; size_t i = 0;
+    void ws() { while (i < t.size() && (t[i] == ' ' || t[i] == '\n' || t[i] == '\t' || t[i] == '\r')) i++; }
+    [[noreturn]] void bad(const char* m) { xlp_exit_process((std::string("starkinfo: JSON error: ") + m + " at byte " + std::to_string(i)).c_str()); abort(); }
+    std::string string_()
+    {
+        std::string r; i++;
+        while (i < t.size() && t[i] != '"') {
+            if (t[i] == '\\' && i + 1 < t.size()) { i++; const char c = t[i]; r += c == 'n' ? '\n' : c == 't' ? '\t' : c; }
+            else r += t[i];
+            i++;
+        }
+        if (i >= t.size()) bad("unterminated string");
+        i++;
+        return r;
+    }
+public:
+    explicit Parser(const std::string& text) : t(text) {}
+    Value value()
+    {
+        ws();
+        if (i >= t.size()) bad("unexpected end");
+        Value v;
+        const char c = t[i];
+        if (c == '{') {
+            v.kind = Value::Object; i++; ws();
+            if (t[i] == '}') { i++; return v; }
+            for (;;) {
+                ws(); if (t[i] != '"') bad("member name expected");
+                std::string k = string_(); ws();
+                if (t[i] != ':') bad("':' expected");
+                i++;
+                v.o.emplace_back(k, value()); ws();
+                if (t[i] == ',') { i++; continue; }
+                if (t[i] == '}') { i++; return v; }
+                bad("',' or '}' expected");
+            }
+        }
+        if (c == '[') {
+            v.kind = Value::Array; i++; ws();
+            if (t[i] == ']') { i++; return v; }
+            for (;;) {
+                v.a.push_back(value()); ws();
+                if (t[i] == ',') { i++; continue; }
+                if (t[i] == ']') { i++; return v; }
+                bad("',' or ']' expected");
+            }
+        }
+        if (c == '"') { v.kind = Value::String; v.s = string_(); return v; }
+        if (t.compare(i, 4, "true") == 0) { v.kind = Value::Bool; v.b = true; i += 4; return v; }
+        if (t.compare(i, 5, "false") == 0) { v.kind = Value::Bool; v.b = false; i += 5; return v; }
+        if (t.compare(i, 4, "null") == 0) { i += 4; return v; }
+        const size_t st = i;
+        while (i < t.size() && (isdigit((unsigned char)t[i]) || t[i] == '-' || t[i] == '+' || t[i] == '.' || t[i] == 'e' || t[i] == 'E')) i++;
+        if (st == i) bad("value expected");
+        v.kind = Value::Number; v.s = t.substr(st, i - st); v.u = strtoull(v.s.c_str(), NULL, 10);
+        return v;
+    }
+};
+}  // namespace xlp_json
+
 struct StepStruct { uint64_t nBits; };
 struct StarkStruct {
     uint64_t nBits = 0, nBitsExt = 0, nQueries = 0;
+    std::string verificationHashType;
     std::vector<StepStruct> steps;
 };
-struct StarkInfo { StarkStruct starkStruct; };
+typedef enum { cm1_n = 0, cm1_2ns = 1, cm2_n = 2, cm2_2ns = 3, cm3_n = 4, cm3_2ns = 5, cm4_n = 6, cm4_2ns = 7, tmpExp_n = 8, q_2ns = 9, f_2ns = 10, eSectionMax = 11 } eSection;
+inline eSection string2section(const std::string s)
+{
+    static const char* names[eSectionMax] = {"cm1_n", "cm1_2ns", "cm2_n", "cm2_2ns", "cm3_n", "cm3_2ns", "cm4_n", "cm4_2ns", "tmpExp_n", "q_2ns", "f_2ns"};
+    for (int i = 0; i < eSectionMax; i++) if (s == names[i]) return (eSection)i;
+    xlp_exit_process(("string2section() found invalid string=" + s).c_str());
+    return eSectionMax;
+}
+struct PolsSections { uint64_t section[eSectionMax] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; };
+struct PolsSectionsVector { std::vector<uint64_t> section[eSectionMax]; };
+struct VarPolMap { eSection section; uint64_t dim; uint64_t sectionPos; };
+struct PolInfo {
+    VarPolMap map; uint64_t N, offset, size; Goldilocks::Element* pAddress;
+    Goldilocks::Element* get(uint64_t step) { return pAddress + step * size; }
+    Goldilocks::Element* get1(uint64_t step) { return pAddress + step * size; }
+    Goldilocks::Element* get2(uint64_t step) { return pAddress + step * size + 1; }
+    Goldilocks::Element* get3(uint64_t step) { return pAddress + step * size + 2; }
+};
+struct PeCtx { uint64_t tExpId, fExpId, zId, c1Id, numId, denId, c2Id; };
+struct PuCtx { uint64_t tExpId, fExpId, h1Id, h2Id, zId, c1Id, numId, denId, c2Id; };
+struct CiCtx { uint64_t zId, numId, denId, c1Id, c2Id; };
+struct EvMap {
+    typedef enum { cm = 0, _const = 1, q = 2 } eType;
+    eType type; uint64_t id; bool prime;
+    void setType(std::string s)
+    {
+        if (s == "cm") type = cm; else if (s == "const") type = _const; else if (s == "q") type = q;
+        else xlp_exit_process(("EvMap::setType() found invalid type: " + s).c_str());
+    }
+};
+struct StepType {
+    typedef enum { tmp = 0, exp = 1, eval = 2, challenge = 3, tree1 = 4, tree2 = 5, tree3 = 6, tree4 = 7, number = 8, x = 9, Z = 10, _public = 11,
+                   xDivXSubXi = 12, xDivXSubWXi = 13, cm = 14, _const = 15, q = 16, Zi = 17, tmpExp = 18, f = 19 } eType;
+    eType type = tmp; uint64_t id = 0; bool prime = false; uint64_t p = 0; std::string value;
+    void setType(std::string s)
+    {
+        static const char* names[20] = {"tmp", "exp", "eval", "challenge", "tree1", "tree2", "tree3", "tree4", "number", "x", "Z", "public", "xDivXSubXi",
+                                        "xDivXSubWXi", "cm", "const", "q", "Zi", "tmpExp", "f"};
+        for (int i = 0; i < 20; i++) if (s == names[i]) { type = (eType)i; return; }
+        xlp_exit_process(("StepType::setType() found invalid type: " + s).c_str());
+    }
+};
+struct StepOperation {
+    typedef enum { add = 0, sub = 1, mul = 2, copy = 3 } eOperation;
+    eOperation op; StepType dest; std::vector<StepType> src;
+    void setOperation(std::string s)
+    {
+        if (s == "add") op = add; else if (s == "sub") op = sub; else if (s == "mul") op = mul; else if (s == "copy") op = copy;
+        else xlp_exit_process(("StepOperation::setOperation() found invalid type: " + s).c_str());
+    }
+};
+struct Step { std::vector<StepOperation> first, i, last; uint64_t tmpUsed = 0; };
+
+class StarkInfo
+{
+public:
+    StarkStruct starkStruct;
+    uint64_t mapTotalN = 0, nConstants = 0, nPublics = 0, nCm1 = 0, nCm2 = 0, nCm3 = 0, nCm4 = 0, qDeg = 0, qDim = 0, friExpId = 0, nExps = 0;
+    PolsSections mapDeg, mapOffsets, mapSectionsN, mapSectionsN1, mapSectionsN3;
+    PolsSectionsVector mapSections;
+    std::vector<VarPolMap> varPolMap;
+    std::vector<uint64_t> qs, cm_n, cm_2ns;
+    std::vector<PeCtx> peCtx;
+    std::vector<PuCtx> puCtx;
+    std::vector<CiCtx> ciCtx;
+    std::vector<EvMap> evMap;
+    Step step2prev, step3prev, step3, step42ns, step52ns;
+    std::vector<uint64_t> exps_n, q_2nsVector, cm4_nVector, cm4_2nsVector, tmpExp_n;
+    std::vector<std::pair<std::string, uint64_t>> exp2pol;
+
+    StarkInfo() {}                                   // synthetic runs fill starkStruct by hand
+    explicit StarkInfo(const std::string& file)      // StarkInfo(config, file), stark_info.cpp:7-19
+    {
+        FILE* f = fopen(file.c_str(), "rb");
+        if (!f) xlp_exit_process(("StarkInfo: cannot open " + file).c_str());
+        std::string text; char buf[65536]; size_t r;
+        while ((r = fread(buf, 1, sizeof buf, f)) > 0) text.append(buf, r);
+        fclose(f);
+        load(xlp_json::Parser(text).value());
+    }
+    void load(const xlp_json::Value& j)
+    {
+        static const char* secs[eSectionMax] = {"cm1_n", "cm1_2ns", "cm2_n", "cm2_2ns", "cm3_n", "cm3_2ns", "cm4_n", "cm4_2ns", "tmpExp_n", "q_2ns", "f_2ns"};
+        const xlp_json::Value& ss = j["starkStruct"];
+        starkStruct.nBits = ss["nBits"]; starkStruct.nBitsExt = ss["nBitsExt"]; starkStruct.nQueries = ss["nQueries"];
+        starkStruct.verificationHashType = ss["verificationHashType"].str();
+        for (size_t i = 0; i < ss["steps"].size(); i++) { StepStruct st; st.nBits = ss["steps"][i]["nBits"]; starkStruct.steps.push_back(st); }
+        mapTotalN = j["mapTotalN"]; nConstants = j["nConstants"]; nPublics = j["nPublics"];
+        nCm1 = j["nCm1"]; nCm2 = j["nCm2"]; nCm3 = j["nCm3"]; nCm4 = j["nCm4"];
+        friExpId = j["friExpId"]; nExps = j["nExps"]; qDim = j["qDim"]; qDeg = j["qDeg"];
+        for (int s = 0; s < eSectionMax; s++) {
+            mapDeg.section[s] = j["mapDeg"][secs[s]]; mapOffsets.section[s] = j["mapOffsets"][secs[s]];
+            mapSectionsN.section[s] = j["mapSectionsN"][secs[s]]; mapSectionsN1.section[s] = j["mapSectionsN1"][secs[s]];
+            mapSectionsN3.section[s] = j["mapSectionsN3"][secs[s]];
+            const xlp_json::Value& v = j["mapSections"][secs[s]];
+            for (size_t i = 0; i < v.size(); i++) mapSections.section[s].push_back(v[i]);
+        }
+        for (size_t i = 0; i < j["varPolMap"].size(); i++) {
+            const xlp_json::Value& m = j["varPolMap"][i];
+            varPolMap.push_back({string2section(m["section"].str()), (uint64_t)m["dim"], (uint64_t)m["sectionPos"]});
+        }
+        auto u64s = [&](const char* k, std::vector<uint64_t>& out) { for (size_t i = 0; i < j[k].size(); i++) out.push_back(j[k][i].is_null() ? 0 : (uint64_t)j[k][i]); };
+        u64s("qs", qs); u64s("cm_n", cm_n); u64s("cm_2ns", cm_2ns);
+        for (size_t i = 0; i < j["peCtx"].size(); i++) {
+            const xlp_json::Value& c = j["peCtx"][i];
+            peCtx.push_back({c["tExpId"], c["fExpId"], c["zId"], c["c1Id"], c["numId"], c["denId"], c["c2Id"]});
+        }
+        for (size_t i = 0; i < j["puCtx"].size(); i++) {
+            const xlp_json::Value& c = j["puCtx"][i];
+            puCtx.push_back({c["tExpId"], c["fExpId"], c["h1Id"], c["h2Id"], c["zId"], c["c1Id"], c["numId"], c["denId"], c["c2Id"]});
+        }
+        for (size_t i = 0; i < j["ciCtx"].size(); i++) {
+            const xlp_json::Value& c = j["ciCtx"][i];
+            ciCtx.push_back({c["zId"], c["numId"], c["denId"], c["c1Id"], c["c2Id"]});
+        }
+        for (size_t i = 0; i < j["evMap"].size(); i++) {
+            EvMap m; m.setType(j["evMap"][i]["type"].str()); m.id = j["evMap"][i]["id"]; m.prime = j["evMap"][i]["prime"];
+            evMap.push_back(m);
+        }
+        auto step = [&](const char* name, Step& st) {
+            st.tmpUsed = j[name]["tmpUsed"];
+            const xlp_json::Value& ops = j[name]["first"];
+            for (size_t i = 0; i < ops.size(); i++) {
+                StepOperation op;
+                op.setOperation(ops[i]["op"].str());
+                auto type_ = [](const xlp_json::Value& v, StepType& ty) {
+                    ty.setType(v["type"].str());
+                    ty.id = v.contains("id") ? (uint64_t)v["id"] : 0;
+                    ty.prime = v.contains("prime") ? (bool)v["prime"] : false;
+                    ty.p = v.contains("p") ? (uint64_t)v["p"] : 0;
+                    if (v.contains("value")) ty.value = v["value"].str();
+                };
+                type_(ops[i]["dest"], op.dest);
+                for (size_t k = 0; k < ops[i]["src"].size(); k++) { StepType ty; type_(ops[i]["src"][k], ty); op.src.push_back(ty); }
+                st.first.push_back(op);
+            }
+        };
+        step("step2prev", step2prev); step("step3prev", step3prev); step("step3", step3); step("step42ns", step42ns); step("step52ns", step52ns);
+        u64s("exps_n", exps_n); u64s("q_2ns", q_2nsVector); u64s("cm4_n", cm4_nVector); u64s("cm4_2ns", cm4_2nsVector); u64s("tmpExp_n", tmpExp_n);
+        for (const auto& kv : j["exp2pol"].o) exp2pol.emplace_back(kv.first, (uint64_t)kv.second);
+    }
+    void getPol(void* pAddress, uint64_t idPol, PolInfo& polInfo)     // stark_info.cpp:456-464
+    {
+        polInfo.map = varPolMap[idPol];
+        polInfo.N = mapDeg.section[polInfo.map.section];
+        polInfo.offset = mapOffsets.section[polInfo.map.section] + polInfo.map.sectionPos;
+        polInfo.size = mapSectionsN.section[polInfo.map.section];
+        polInfo.pAddress = ((Goldilocks::Element*)pAddress) + polInfo.offset;
+    }
+    uint64_t getPolSize(uint64_t polId) { const VarPolMap p = varPolMap[polId]; return mapDeg.section[p.section] * p.dim * sizeof(Goldilocks::Element); }
+    // stark_info.cpp:473-482 (returned by pointer-free value in the reference; Polinomial is not copyable here, so the view is built in place)
+    void getPolinomial(Polinomial& out, Goldilocks::Element* pAddress, uint64_t idPol)
+    {
+        const VarPolMap p = varPolMap[idPol];
+        new (&out) Polinomial(&pAddress[mapOffsets.section[p.section] + p.sectionPos], mapDeg.section[p.section], p.dim, mapSectionsN.section[p.section], std::to_string(idPol));
+    }
+    uint64_t getConstTreeSizeInBytes() const
+    {
+        const uint64_t NExtended = 1ULL << starkStruct.nBitsExt;
+        return (nConstants * NExtended + NExtended * HASH_SIZE + (NExtended - 1) * HASH_SIZE + 2) * sizeof(Goldilocks::Element);
+    }
+};
 
 // -------------------------------------------------------------------- FRIProve
 class FRIProve
