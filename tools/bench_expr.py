@@ -21,12 +21,14 @@ def main():
     ap.add_argument("--log-rows", type=int, default=17)
     ap.add_argument("--steps", default="step2prev,step3prev,step3,step42ns,step52ns")
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--full", action="store_true", help="run every step on its full zkEVM domain (2^23 / 2^24 rows): measured, not extrapolated")
     ap.add_argument("--jit", action="store_true", help="attach the ahead-of-time plugin oracle/_ref/chelpers/zkevm.<step>.so if present")
     a = ap.parse_args()
     capi.init(0); capi.use_torch_stream()
-    n = 1 << a.log_rows
     out = {}
     for step in a.steps.split(","):
+        log_rows = (24 if step.endswith("2ns") else 23) if a.full else a.log_rows
+        n = 1 << log_rows
         path = os.path.join(R.REF_DIR, f"zkevm.{step}.xlpexpr")
         if not os.path.exists(path):
             print("missing", path); continue
@@ -38,7 +40,7 @@ def main():
         dev = R.buffers(fill, 7, n, info)
         sp = capi.steps_params(n_const_pols=info["n_const"], n_const_pols_2ns=info["n_const2"], **dev)
         p = capi.ExprProgram(code, ntmp1, ntmp3)
-        so = os.path.join(R.REF_DIR, f"zkevm.{step}.n{a.log_rows}.so")
+        so = os.path.join(R.REF_DIR, f"zkevm.{step}.n{log_rows}.so")
         mode = "interpreter"
         if a.jit and os.path.exists(so):
             p.attach(so); mode = "compiled"
@@ -52,7 +54,7 @@ def main():
         full = (1 << 24) if step.endswith("2ns") else (1 << 23)
         out[step] = {"mode": mode, "rows": n, "instructions": ninstr, "ntmp1": int(ntmp1), "ntmp3": int(ntmp3), "ms": round(ms, 3),
                      "ns_per_row_instr": round(ms * 1e6 / n / ninstr, 4), "full_domain_s": round(ms / 1e3 * full / n, 3)}
-        p.close(); del dev
+        p.close(); del dev, sp; torch.cuda.empty_cache()
         print(step, out[step], flush=True)
     print(json.dumps(out))
 

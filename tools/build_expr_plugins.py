@@ -19,9 +19,12 @@ def main():
     ap.add_argument("--steps", default="step2prev,step3prev,step3,step42ns,step52ns")
     ap.add_argument("--parts", type=int, default=8)
     ap.add_argument("--force", action="store_true")
+    ap.add_argument("--full", action="store_true", help="full zkEVM domains instead of --log-rows: 2^23 rows for the *prev/step3 programs, 2^24 for the 2ns ones")
     a = ap.parse_args()
-    for lr in [int(x) for x in a.log_rows.split(",")]:
+    sizes = ["full"] if a.full else [int(x) for x in a.log_rows.split(",")]
+    for size in sizes:
         for step in a.steps.split(","):
+            lr = (24 if step.endswith("2ns") else 23) if size == "full" else size
             src = os.path.join(R.REF_DIR, f"zkevm.{step}.xlpexpr")
             name = f"zkevm.{step}.n{lr}"
             so = os.path.join(R.REF_DIR, name + ".so")
