@@ -668,8 +668,10 @@ int orc_calculate_h1h2(u64 *h1, u64 *h2, const u64 *f, const u64 *t, u64 n, unsi
  *   challenges[k] (3 words), publicInputs[k], evals[k] (3 words), x_n[i], x_2ns[i],
  *   zi.zhInv(i) = ZHInv[i % size] (zhInv.hpp:20-23), xDivXSubXi[i], q_2ns[i*3], f_2ns[i*3].
  * Base (x) meets extension as (x,0,0): add13/sub13c/sub31c/mul13/mul1c3c of the reference.
- * PARITY UNPINNED against the reference binary: the generated parsers need the absent goldilocks
- * library and a starkinfo/witness archive; pinned only by construction on synthetic programs. */
+ * Not runnable against the reference binary (the generated parsers need the absent goldilocks library and a
+ * starkinfo/witness archive).  Pinned instead through the reference's two generated forms of the same steps: the
+ * table form and the straight-line form of step2prev / step3prev / step52ns, converted independently, must give
+ * identical outputs under this interpreter (tests/test_expr_vm.py). */
 typedef struct {
     u64 *pols; u64 pols_size;
     const u64 *const_pols; u64 n_const_pols; u64 const_pols_size;

@@ -38,16 +38,17 @@ def operands(code):
         k += 1
 
 
-def shrink(code, n):
-    """-> (new code, info) with info = sizes the buffers need"""
-    code = code.copy()
-    ops = list(operands(code))
+def shrink_many(codes, n):
+    """one relocation for several programs over the same slab -> ([new codes], info)"""
+    codes = [c.copy() for c in codes]
+    allops = [list(operands(c)) for c in codes]
     by_stride = {}
-    for _, _, kind, dim, q in ops:
-        if kind == E.K_POLS:
-            by_stride.setdefault(int(code[q + 1]), set()).add(int(code[q]))
-        elif kind == E.K_POLS_PRIME:
-            by_stride.setdefault(int(code[q + 3]), set()).add(int(code[q]))
+    for code, ops in zip(codes, allops):
+        for _, _, kind, dim, q in ops:
+            if kind == E.K_POLS:
+                by_stride.setdefault(int(code[q + 1]), set()).add(int(code[q]))
+            elif kind == E.K_POLS_PRIME:
+                by_stride.setdefault(int(code[q + 3]), set()).add(int(code[q]))
     remap, top = {}, 0
     for stride, offs in sorted(by_stride.items()):
         lo = None
@@ -57,29 +58,35 @@ def shrink(code, n):
                 top += n * stride
             remap[(stride, o)] = base + (o - lo)
     info = {"pols_size": top + 4, "n_const": 1, "n_const2": 1, "nch": 1, "npub": 1, "nev": 1, "max_next": 0}
-    for _, _, kind, dim, q in ops:
-        if kind == E.K_POLS:
-            code[q] = remap[(int(code[q + 1]), int(code[q]))]
-        elif kind == E.K_POLS_PRIME:
-            code[q] = remap[(int(code[q + 3]), int(code[q]))]
-            info["max_next"] = max(info["max_next"], int(code[q + 1]))
-            code[q + 2] = n
-        elif kind in (E.K_CONST, E.K_CONST_PRIME):
-            info["n_const"] = max(info["n_const"], int(code[q]) + 1)
-        elif kind in (E.K_CONST2NS, E.K_CONST2NS_PRIME):
-            info["n_const2"] = max(info["n_const2"], int(code[q]) + 1)
-        elif kind == E.K_CHALLENGE:
-            info["nch"] = max(info["nch"], int(code[q]) + 1)
-        elif kind == E.K_PUBLIC:
-            info["npub"] = max(info["npub"], int(code[q]) + 1)
-        elif kind == E.K_EVAL:
-            info["nev"] = max(info["nev"], int(code[q]) + 1)
-        if kind in (E.K_CONST_PRIME, E.K_CONST2NS_PRIME):
-            info["max_next"] = max(info["max_next"], int(code[q + 1]))
-            code[q + 2] = n
+    for code, ops in zip(codes, allops):
+        for _, _, kind, dim, q in ops:
+            if kind == E.K_POLS:
+                code[q] = remap[(int(code[q + 1]), int(code[q]))]
+            elif kind == E.K_POLS_PRIME:
+                code[q] = remap[(int(code[q + 3]), int(code[q]))]
+                info["max_next"] = max(info["max_next"], int(code[q + 1]))
+                code[q + 2] = n
+            elif kind in (E.K_CONST, E.K_CONST_PRIME):
+                info["n_const"] = max(info["n_const"], int(code[q]) + 1)
+            elif kind in (E.K_CONST2NS, E.K_CONST2NS_PRIME):
+                info["n_const2"] = max(info["n_const2"], int(code[q]) + 1)
+            elif kind == E.K_CHALLENGE:
+                info["nch"] = max(info["nch"], int(code[q]) + 1)
+            elif kind == E.K_PUBLIC:
+                info["npub"] = max(info["npub"], int(code[q]) + 1)
+            elif kind == E.K_EVAL:
+                info["nev"] = max(info["nev"], int(code[q]) + 1)
+            if kind in (E.K_CONST_PRIME, E.K_CONST2NS_PRIME):
+                info["max_next"] = max(info["max_next"], int(code[q + 1]))
+                code[q + 2] = n
     assert info["max_next"] < n
-    info["sections"] = len({v - (v % 1) for v in remap.values()})
-    return code, info
+    return codes, info
+
+
+def shrink(code, n):
+    """-> (new code, info) with info = sizes the buffers need"""
+    codes, info = shrink_many([code], n)
+    return codes[0], info
 
 
 def buffers(fill, seed, n, info):

@@ -99,6 +99,32 @@ def test_expr_assembler_encoding():
 
 
 REAL_STEPS = ["step2prev", "step3prev", "step3", "step42ns", "step52ns"]
+OTHER_PROGRAMS = [f"{pil}.{step}" for pil in ("c12a", "recursive1", "recursive2", "recursivef") for step in ("step3prev", "step3", "step42ns", "step52ns")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", OTHER_PROGRAMS)
+def test_expr_reference_recursive_programs(xlp, orc, name):
+    """The constraint programs of the reference's other STARKs (c12a, recursive1, recursive2, recursiveF), converted
+    from their straight-line generated C++ by tools/chelpers_cpp_to_xlp.py at build time: HIP VM == oracle, 256 rows."""
+    from tests import expr_real as R
+    path = os.path.join(R.REF_DIR, f"{name}.xlpexpr")
+    if not os.path.exists(path):
+        pytest.skip("converted reference programs not built (needs the reference tree at build time)")
+    code, ntmp1, ntmp3 = R.read_program(path)
+    n = 256
+    code, info = R.shrink(code, n)
+    bufs = R.buffers(orc.fill, 0x5EED0A00, n, info)
+    dev = {k: xlp.from_np(v) for k, v in bufs.items()}
+    p = xlp.ExprProgram(code, ntmp1, ntmp3)
+    p.run(xlp.steps_params(n_const_pols=info["n_const"], n_const_pols_2ns=info["n_const2"], **dev), 0, n); xlp.sync(); p.close()
+    exp = {k: v.copy() for k, v in bufs.items()}
+    orc.expr_run(code, ntmp1, ntmp3, exp, 0, n, info["n_const"], info["n_const2"])
+    changed = 0
+    for k in ("pols", "q_2ns", "f_2ns"):
+        assert (xlp.to_np(dev[k]) == exp[k]).all(), k
+        changed += int((exp[k] != bufs[k]).sum())
+    assert changed > 0
 
 
 @pytest.mark.gpu
@@ -274,3 +300,36 @@ def test_expr_multi_slab_run(xlp, orc, tmp_path, compiled):
             touched = (e != b)
             assert (g[touched] == e[touched]).all(), (k, lo)
             assert touched[rows].any() or k != "pols"
+
+
+@pytest.mark.parametrize("step,cpp,fn", [("step2prev", "step2", "step2prev_first"), ("step3prev", "step3prev", "step3prev_first"),
+                                         ("step52ns", "step52ns", "step52ns_first")])
+def test_reference_table_and_straight_line_forms_agree(orc, step, cpp, fn):
+    """The reference ships three zkEVM steps in TWO generated forms: interpreter tables (`*.parser.hpp` + the case
+    switch of `*.parser.cpp`) and straight-line C++ (`zkevm.chelpers.step3prev.cpp` ...).  Converted independently
+    (tools/chelpers_to_xlp.py / tools/chelpers_cpp_to_xlp.py) and run by the oracle on one synthetic trace they must
+    write identical outputs, instruction for instruction count included: this pins the reading of the table format
+    (operand order of every case, fused cases, the accumulator cases of step52ns) to a second reference artefact."""
+    import sys
+    ref = "/root/reference/src/starkpil/zkevm/chelpers"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not present")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import chelpers_cpp_to_xlp as conv2
+    import chelpers_to_xlp as conv1
+    from tests import expr_real as R
+    p1, ntmp1a, ntmp3a, info1 = conv1.convert(f"{ref}/zkevm.chelpers.{step}.parser.cpp", f"{ref}/zkevm.chelpers.{step}.parser.hpp", step)
+    p2 = conv2.convert(f"{ref}/zkevm.chelpers.{cpp}.cpp", fn)
+    assert p1.ninstr == p2.ninstr and len(p1.words) == len(p2.words)
+    n = 48
+    (c1, c2), info = R.shrink_many([p1.code, p2.code], n)
+    bufs = R.buffers(orc.fill, 0x5EED0900, n, info)
+    out1 = {k: v.copy() for k, v in bufs.items()}
+    out2 = {k: v.copy() for k, v in bufs.items()}
+    orc.expr_run(c1, ntmp1a, ntmp3a, out1, 0, n, info["n_const"], info["n_const2"])
+    orc.expr_run(c2, p2.ntmp1, p2.ntmp3, out2, 0, n, info["n_const"], info["n_const2"])
+    changed = 0
+    for k in ("pols", "q_2ns", "f_2ns"):
+        assert (out1[k] == out2[k]).all(), k
+        changed += int((out1[k] != bufs[k]).sum())
+    assert changed > 100
