@@ -671,7 +671,9 @@ int orc_calculate_h1h2(u64 *h1, u64 *h2, const u64 *f, const u64 *t, u64 n, unsi
  * Not runnable against the reference binary (the generated parsers need the absent goldilocks library and a
  * starkinfo/witness archive).  Pinned instead through the reference's two generated forms of the same steps: the
  * table form and the straight-line form of step2prev / step3prev / step52ns, converted independently, must give
- * identical outputs under this interpreter (tests/test_expr_vm.py). */
+ * identical outputs under this interpreter, and on the golden recursive1 / recursive2 proofs: the converted step52ns
+ * program run on the opened query rows reproduces the committed FRI-polynomial values, the converted step42ns program
+ * at xi satisfies C(xi) = Q(xi) Zh(xi) with the proofs' evaluations (tests/test_expr_vm.py). */
 typedef struct {
     u64 *pols; u64 pols_size;
     const u64 *const_pols; u64 n_const_pols; u64 const_pols_size;

@@ -333,3 +333,175 @@ def test_reference_table_and_straight_line_forms_agree(orc, step, cpp, fn):
         assert (out1[k] == out2[k]).all(), k
         changed += int((out1[k] != bufs[k]).sum())
     assert changed > 100
+
+
+def _golden_fri_polynomial_inputs(orc, golden_dir, proof_name, prog_name):
+    """For every query of a golden recursive proof: a one-row trace made of the OPENED VALUES (rows of trees 1, 3, 4
+    and the constant tree), the proof's evaluations and challenges, x/(x - xi) and x/(x - w xi) at the query point;
+    and the value the prover committed for the FRI polynomial at that point (first FRI tree)."""
+    import json
+    from tests import expr_real as R
+    path = os.path.join(R.REF_DIR, f"{prog_name}.step52ns.xlpexpr")
+    if not os.path.exists(path):
+        pytest.skip("converted reference programs not built (needs the reference tree at build time)")
+    F = json.load(open(os.path.join(golden_dir, proof_name)))
+    code, ntmp1, ntmp3 = R.read_program(path)
+    code, info = R.shrink(code, 1)                       # sections packed for a single row
+    # where each section landed: shrink orders clusters by stride (row width)
+    widths = sorted({len(F["queries"][0][f"s0_vals{t}"]) for t in ("1", "3", "4")})
+    base, o = {}, 0
+    for w in widths:
+        base[w] = o; o += w
+    ints = lambda v: [int(x) for x in v]
+    nbits, nbits_ext = F["nBits"], F["nBitsExt"]
+    xi = ints(F["challenges"]["7"])
+    ch = np.zeros(8 * 3, np.uint64)
+    for k, v in F["challenges"].items():
+        ch[3 * int(k): 3 * int(k) + 3] = ints(v)
+    evals = np.array([int(x) for e in F["evals"] for x in e], np.uint64)
+    w_ext, w_n = orc.w(nbits_ext), orc.w(nbits)
+    wxi = [orc.mul(c, w_n) for c in xi]
+    cases = []
+    for Q in F["queries"]:
+        idx = Q["idx"]
+        pols = np.zeros(info["pols_size"], np.uint64)
+        for t in ("1", "3", "4"):
+            vals = ints(Q[f"s0_vals{t}"])
+            pols[base[len(vals)]: base[len(vals)] + len(vals)] = vals
+        x = orc.mul(orc.shift(), orc.pow_(w_ext, idx))
+        xd = orc.x_div_x_sub_xi(np.array([x], np.uint64), np.array(xi, np.uint64)).reshape(-1)
+        xdw = orc.x_div_x_sub_xi(np.array([x], np.uint64), np.array(wxi, np.uint64)).reshape(-1)
+        bufs = {"pols": pols, "const_pols_2ns": np.array(ints(Q["s0_valsC"]), np.uint64), "challenges": ch.copy(), "evals": evals.copy(),
+                "x_div_x_sub_xi": xd.copy(), "x_div_x_sub_wxi": xdw.copy(), "f_2ns": np.zeros(3, np.uint64)}
+        k = idx >> F["steps_nBits"][1]
+        cases.append((bufs, ints(Q["s1_vals"])[3 * k: 3 * k + 3]))
+    return code, ntmp1, ntmp3, len(F["queries"][0]["s0_valsC"]), cases
+
+
+GOLDEN_FRI = [("proof_recursive2_01.json", "recursive2"), ("proof_recursive1_0.json", "recursive1")]
+
+
+@pytest.mark.parametrize("proof,prog", GOLDEN_FRI)
+def test_golden_proof_fri_polynomial_from_openings(orc, golden_dir, proof, prog):
+    """GOLDEN-DATA PIN of the constraint-program path: the reference's step52ns program (converted), evaluated on the
+    values a golden proof OPENS at each query, must reproduce the value of the FRI polynomial the reference prover
+    committed there (first FRI tree of the same proof).  Ties together: the program conversion, operand semantics
+    (sub13c / mul33c / accumulators), evals order, challenge numbering, xDivXSubXi and the FRI transposed layout."""
+    code, ntmp1, ntmp3, nconst, cases = _golden_fri_polynomial_inputs(orc, golden_dir, proof, prog)
+    assert len(cases) >= 3
+    for bufs, expect in cases:
+        orc.expr_run(code, ntmp1, ntmp3, bufs, 0, 1, 1, nconst)
+        assert [int(v) for v in bufs["f_2ns"]] == expect
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("proof,prog", GOLDEN_FRI)
+def test_golden_proof_fri_polynomial_from_openings_gpu(xlp, orc, golden_dir, proof, prog):
+    """the same golden check through the HIP VM"""
+    code, ntmp1, ntmp3, nconst, cases = _golden_fri_polynomial_inputs(orc, golden_dir, proof, prog)
+    p = xlp.ExprProgram(code, ntmp1, ntmp3)
+    for bufs, expect in cases[:16]:
+        dev = {k: xlp.from_np(v) for k, v in bufs.items()}
+        p.run(xlp.steps_params(n_const_pols=1, n_const_pols_2ns=nconst, **dev), 0, 1); xlp.sync()
+        assert [int(v) for v in xlp.to_np(dev["f_2ns"])] == expect
+    p.close()
+
+
+def _decode(code):
+    """-> list of (op, (kind, dim, params) x 3) from the VM encoding"""
+    from tests import expr_real as R
+    out, cur = [], None
+    for k, s, kind, dim, q in R.operands(code):
+        prm = [int(v) for v in code[q:q + E.KIND_PARAMS[kind]]]
+        if s == 0:
+            cur = [None, (kind, dim, prm)]
+            pc_head = q - 1
+            cur[0] = int(code[pc_head]) & 0xff
+        else:
+            cur.append((kind, dim, prm))
+        if s == 2:
+            out.append(tuple(cur))
+    return out
+
+
+@pytest.mark.parametrize("proof,prog", GOLDEN_FRI)
+def test_golden_proof_constraint_identity_at_xi(orc, golden_dir, proof, prog):
+    """GOLDEN-DATA PIN of the quotient program: the verifier's identity C(xi) = Q(xi) Zh(xi) on a golden proof, with C
+    computed by the reference's own step42ns program (converted) run symbolically at xi -- every column operand replaced
+    by the proof's evaluation of that column (the evaluation map is read off the step52ns program: which column each
+    evals[k] is subtracted from, and whether its group is multiplied by xDivXSubXi or xDivXSubWXi) -- and Q(xi)
+    recombined from the evaluations of the cm4 columns: sum_p xi^(p N) q_p(xi)."""
+    import json
+    from tests import expr_real as R
+    from tests.mini_verifier import add3, sub3, mul3, pow3, emb
+    p42 = os.path.join(R.REF_DIR, f"{prog}.step42ns.xlpexpr"); p52 = os.path.join(R.REF_DIR, f"{prog}.step52ns.xlpexpr")
+    if not (os.path.exists(p42) and os.path.exists(p52)):
+        pytest.skip("converted reference programs not built (needs the reference tree at build time)")
+    F = json.load(open(os.path.join(golden_dir, proof)))
+    ints = lambda v: [int(x) for x in v]
+    N = 1 << F["nBits"]
+    evals = [ints(e) for e in F["evals"]]
+    ch = {int(k): ints(v) for k, v in F["challenges"].items()}
+    xi = ch[7]
+    # ---- evaluation map from step52ns: evals[k] <-> (column, prime)
+    code52, _, _ = R.read_program(p52)
+    tags, evmap = {}, {}
+    for op, d, a, b in _decode(code52):
+        srcs = [a] + ([b] if b[0] != E.K_NONE else [])
+        s = set()
+        for kind, dim, prm in srcs:
+            if kind == E.K_TMP3: s |= tags.get(prm[0], set())
+        ev = [prm[0] for kind, dim, prm in srcs if kind == E.K_EVAL]
+        if ev:
+            col = [x for x in srcs if x[0] in (E.K_POLS, E.K_CONST2NS)]
+            assert op == E.SUB and len(col) == 1
+            key = ("pols", col[0][2][0]) if col[0][0] == E.K_POLS else ("const", col[0][2][0])
+            evmap[ev[0]] = [key, None]
+            s.add(ev[0])
+        for kind, dim, prm in srcs:
+            if kind in (E.K_XDIVXSUBXI, E.K_XDIVXSUBWXI):
+                for k in s: evmap[k][1] = (kind == E.K_XDIVXSUBWXI)
+                s = set()
+        if d[0] == E.K_TMP3: tags[d[2][0]] = s
+    assert len(evmap) == len(evals) and all(v[1] is not None for v in evmap.values())
+    at = {(key, prime): evals[k] for k, (key, prime) in evmap.items()}
+    # ---- step42ns at xi, every value in Fp^3
+    code42, _, _ = R.read_program(p42)
+    zh_inv = [int(v) for v in orc.inv3(sub3(pow3(xi, N), [1, 0, 0]))]
+    t1, t3, Q = {}, {}, None
+
+    def val(o):
+        kind, dim, prm = o
+        if kind == E.K_TMP1: return t1[prm[0]]
+        if kind == E.K_TMP3: return t3[prm[0]]
+        if kind == E.K_POLS: return at[(("pols", prm[0]), False)]
+        if kind == E.K_POLS_PRIME: return at[(("pols", prm[0]), True)]
+        if kind == E.K_CONST2NS: return at[(("const", prm[0]), False)]
+        if kind == E.K_CONST2NS_PRIME: return at[(("const", prm[0]), True)]
+        if kind == E.K_NUMBER: return emb(prm[0])
+        if kind == E.K_CHALLENGE: return ch[prm[0]]
+        if kind == E.K_PUBLIC: return emb(int(F["publics"][prm[0]]))
+        if kind == E.K_X_2NS: return xi
+        if kind == E.K_ZI: return zh_inv
+        raise AssertionError(f"operand kind {kind} not expected in step42ns")
+    for op, d, a, b in _decode(code42):
+        x = val(a)
+        r = x if op == E.COPY else add3(x, val(b)) if op == E.ADD else sub3(x, val(b)) if op == E.SUB else mul3(x, val(b))
+        if d[0] == E.K_TMP1: t1[d[2][0]] = r
+        elif d[0] == E.K_TMP3: t3[d[2][0]] = r
+        elif d[0] == E.K_Q_2NS: Q = r
+        else: raise AssertionError("unexpected destination")
+    assert Q is not None
+    # ---- Q(xi) from the cm4 evaluations: the widest-stride... cm4 is the section whose columns are all ext-3 quotient pieces
+    strides = {}
+    for op, d, a, b in _decode(code52):
+        for kind, dim, prm in (a, b):
+            if kind == E.K_POLS: strides.setdefault(prm[1], set()).add((prm[0], dim))
+    cm4 = [s for s, cols in strides.items() if all(dim == 3 for _, dim in cols) and len(cols) * 3 == s]
+    assert len(cm4) == 1
+    pieces = sorted(off for off, _ in strides[cm4[0]])
+    acc, xn = [0, 0, 0], [1, 0, 0]
+    xiN = pow3(xi, N)
+    for off in pieces:
+        acc = add3(acc, mul3(xn, at[(("pols", off), False)])); xn = mul3(xn, xiN)
+    assert Q == acc, "C(xi) / Zh(xi) computed by the reference's step42ns program != sum_p xi^(pN) q_p(xi) from the proof"
