@@ -505,3 +505,46 @@ def test_golden_proof_constraint_identity_at_xi(orc, golden_dir, proof, prog):
     for off in pieces:
         acc = add3(acc, mul3(xn, at[(("pols", off), False)])); xn = mul3(xn, xiN)
     assert Q == acc, "C(xi) / Zh(xi) computed by the reference's step42ns program != sum_p xi^(pN) q_p(xi) from the proof"
+
+
+@pytest.mark.parametrize("src,fixture,prog", [("finalProof/recursive2.zkin.proof_01.json", "proof_recursive2_01.json", "recursive2"),
+                                              ("aggregatedProof/recursive1.zkin.proof_0.json", "proof_recursive1_0.json", "recursive1")])
+def test_golden_proof_fri_polynomial_all_queries(orc, golden_dir, src, fixture, prog):
+    """the same pin over EVERY query of the reference's proof files (the committed fixtures keep four each); runs only
+    where the reference tree is mounted"""
+    import json
+    from tests import expr_real as R
+    full = os.path.join("/root/reference/testvectors", src)
+    path = os.path.join(R.REF_DIR, f"{prog}.step52ns.xlpexpr")
+    if not (os.path.exists(full) and os.path.exists(path)):
+        pytest.skip("reference tree / converted programs not present")
+    J = json.load(open(full)); F = json.load(open(os.path.join(golden_dir, fixture)))
+    ints = lambda v: [int(x) for x in v]
+    code, ntmp1, ntmp3 = R.read_program(path)
+    code, info = R.shrink(code, 1)
+    widths = sorted({len(J[f"s0_vals{t}"][0]) for t in ("1", "3", "4")})
+    base, o = {}, 0
+    for w in widths:
+        base[w] = o; o += w
+    xi = ints(F["challenges"]["7"])
+    ch = np.zeros(8 * 3, np.uint64)
+    for k, v in F["challenges"].items():
+        ch[3 * int(k): 3 * int(k) + 3] = ints(v)
+    evals = np.array([int(x) for e in F["evals"] for x in e], np.uint64)
+    w_ext, w_n = orc.w(F["nBitsExt"]), orc.w(F["nBits"])
+    wxi = [orc.mul(c, w_n) for c in xi]
+    nq = len(F["ys"])
+    assert nq == len(J["s0_vals1"]) and nq >= 32
+    for q, idx in enumerate(F["ys"]):
+        pols = np.zeros(info["pols_size"], np.uint64)
+        for t in ("1", "3", "4"):
+            vals = ints(J[f"s0_vals{t}"][q])
+            pols[base[len(vals)]: base[len(vals)] + len(vals)] = vals
+        x = orc.mul(orc.shift(), orc.pow_(w_ext, idx))
+        bufs = {"pols": pols, "const_pols_2ns": np.array(ints(J["s0_valsC"][q]), np.uint64), "challenges": ch.copy(), "evals": evals.copy(),
+                "x_div_x_sub_xi": orc.x_div_x_sub_xi(np.array([x], np.uint64), np.array(xi, np.uint64)).reshape(-1).copy(),
+                "x_div_x_sub_wxi": orc.x_div_x_sub_xi(np.array([x], np.uint64), np.array(wxi, np.uint64)).reshape(-1).copy(),
+                "f_2ns": np.zeros(3, np.uint64)}
+        orc.expr_run(code, ntmp1, ntmp3, bufs, 0, 1, 1, len(J["s0_valsC"][q]))
+        k = idx >> F["steps_nBits"][1]
+        assert [int(v) for v in bufs["f_2ns"]] == ints(J["s1_vals"][q])[3 * k: 3 * k + 3], q
