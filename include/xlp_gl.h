@@ -120,6 +120,9 @@ int xlp_dev_geometric(uint64_t* out, uint64_t n, uint32_t dim, const uint64_t* f
 /* xDivXSubXi / xDivXSubWXi of genProof step 5 (starks.cpp:340-362): out[k] (ext-3) = x[k] / (x[k] - xi), x base
  * field (n words), xi 3 host words.  x[k] == xi gives zero (the reference would divide by zero). */
 int xlp_dev_x_div_x_sub_xi(uint64_t* out, const uint64_t* x, const uint64_t* xi, uint64_t n);
+/* Polinomial::copy between strided views -- what transposeH1H2Columns / transposeZColumns / ...Rows (starks.cpp:406-555)
+ * do column by column: dst[i * dst_stride + c] = src[i * src_stride + c] for i < n, c < dim. */
+int xlp_dev_copy_cols(uint64_t* dst, uint64_t dst_stride, const uint64_t* src, uint64_t src_stride, uint64_t n, uint32_t dim);
 /* Step-4 coefficient split between the INTT and the NTT of the quotient (starks.cpp:267-283):
  * qq2[k * q_deg + p] = qq1[p * n + k] * shift_in^p (k < n, p < q_deg, elements of q_dim words), rows n .. n_ext-1
  * of qq2 (n_ext rows x q_deg * q_dim columns) zero; shift_in = shift^-n.  Needs q_deg * n <= n_ext. */

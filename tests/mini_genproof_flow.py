@@ -103,6 +103,56 @@ def programs(L):
     return {"step2prev": s2, "step3prev": s3p, "step3": s3, "step42ns": s4, "step52ns": s5}, evmap
 
 
+def toy_stark_files(outdir, name, nbits, fri_steps, nqueries, seed):
+    """Everything the C++ `Starks` mirror (xlayer_prover_amd/host/starks.hpp) needs to prove the mini PIL: a starkinfo.json
+    in the reference's schema (stark_info.cpp:21-520), the five step programs, the constant and committed polynomials
+    and the publics -- so the C++ genProof can be compared with this module's flow."""
+    import json
+    import os
+    import struct
+    L = Layout(nbits)
+    N, NE = L.N, L.NE
+    progs, evmap = programs(L)
+    off = {k: v[0] for k, v in L.off.items()}
+    end = L.total
+    off["cm4_n"] = 0
+    off["q_2ns"] = end; end += 3 * NE
+    off["f_2ns"] = end; end += 3 * NE
+    widths = {"cm1_n": W1, "cm2_n": W2, "cm3_n": W3, "cm4_n": 0, "tmpExp_n": WT, "cm1_2ns": W1, "cm2_2ns": W2, "cm3_2ns": W3, "cm4_2ns": W4, "q_2ns": 3, "f_2ns": 3}
+    secs = list(widths)
+    var = [("cm1_n", 1, 0), ("cm1_n", 1, 1), ("cm2_n", 3, 0), ("cm2_n", 3, 3), ("cm3_n", 3, 0),
+           ("tmpExp_n", 3, 0), ("tmpExp_n", 3, 3), ("tmpExp_n", 3, 6), ("tmpExp_n", 3, 9),
+           ("cm1_2ns", 1, 0), ("cm1_2ns", 1, 1), ("cm2_2ns", 3, 0), ("cm2_2ns", 3, 3), ("cm3_2ns", 3, 0), ("cm4_2ns", 3, 0), ("cm4_2ns", 3, 3)]
+    cmid = {("cm1_2ns", 0): 0, ("cm1_2ns", 1): 1, ("cm2_2ns", 0): 2, ("cm2_2ns", 3): 3, ("cm3_2ns", 0): 4}
+    qid = {("cm4_2ns", 0): 0, ("cm4_2ns", 3): 1}
+    ev = []
+    for s_, c, d, pr in evmap:
+        if s_ == "const": ev.append({"type": "const", "id": c, "prime": pr})
+        elif (s_, c) in cmid: ev.append({"type": "cm", "id": cmid[(s_, c)], "prime": pr})
+        else: ev.append({"type": "q", "id": qid[(s_, c)], "prime": pr})
+    step = {"tmpUsed": 0, "first": [], "i": [], "last": []}
+    j = {"starkStruct": {"nBits": nbits, "nBitsExt": nbits + 1, "nQueries": nqueries, "verificationHashType": "GL", "steps": [{"nBits": b} for b in fri_steps]},
+         "mapTotalN": end, "nConstants": WC, "nPublics": 4, "nCm1": 2, "nCm2": 2, "nCm3": 1, "nCm4": 2, "friExpId": 0, "nExps": 0, "qDim": QDIM, "qDeg": QDEG,
+         "mapDeg": {s_: (N if s_.endswith("_n") else NE) for s_ in secs}, "mapOffsets": {s_: off[s_] for s_ in secs},
+         "mapSections": {s_: [] for s_ in secs}, "mapSectionsN": widths, "mapSectionsN1": widths, "mapSectionsN3": {s_: 0 for s_ in secs},
+         "varPolMap": [{"section": a, "dim": d, "sectionPos": p_} for a, d, p_ in var], "qs": [14, 15], "cm_n": [0, 1, 2, 3, 4], "cm_2ns": [9, 10, 11, 12, 13],
+         "peCtx": [], "ciCtx": [],
+         "puCtx": [{"tExpId": 101, "fExpId": 100, "h1Id": 2, "h2Id": 3, "zId": 4, "c1Id": 0, "numId": 102, "denId": 103, "c2Id": 0}],
+         "evMap": ev, "step2prev": step, "step3prev": step, "step3": step, "step42ns": step, "step52ns": step,
+         "exps_n": [], "q_2ns": [], "cm4_n": [], "cm4_2ns": [], "tmpExp_n": [], "exp2pol": {"100": 5, "101": 6, "102": 7, "103": 8}}
+    os.makedirs(outdir, exist_ok=True)
+    json.dump(j, open(os.path.join(outdir, name + ".starkinfo.json"), "w"))
+    magic = int.from_bytes(b"XLPEXPR1", "little")
+    for stepname, prog in progs.items():
+        with open(os.path.join(outdir, f"{name}.{stepname}.xlpexpr"), "wb") as f:
+            code = prog.code
+            f.write(struct.pack("<4Q", magic, prog.ntmp1, prog.ntmp3, code.size)); f.write(code.astype("<u8").tobytes())
+    cm1, const, publics = witness(L, seed)
+    cm1.astype("<u8").tofile(os.path.join(outdir, name + ".commit"))
+    const.astype("<u8").tofile(os.path.join(outdir, name + ".const"))
+    publics.astype("<u8").tofile(os.path.join(outdir, name + ".publics"))
+
+
 def witness(L, seed):
     rng = np.random.default_rng(seed)
     a = rng.integers(0, L.N, L.N).astype(np.uint64)

@@ -46,6 +46,7 @@ SIGNATURES = {
     "xlp_dev_evmap": [_pu, _pu, _pu, _u64, _u32, _u32, _pu],
     "xlp_dev_geometric": [_pu, _u64, _u32, _pu, _pu],
     "xlp_dev_q_split": [_pu, _pu, _u64, _u64, _u32, _u32, _u64],
+    "xlp_dev_copy_cols": [_pu, _u64, _pu, _u64, _u64, _u32],
     "xlp_dev_x_div_x_sub_xi": [_pu, _pu, _pu, _u64],
     "xlp_dev_calculate_h1h2": [_pu, _pu, _pu, _pu, _u64, _u32],
     "xlp_expr_create": [C.POINTER(C.c_void_p), _pu, _u64, _u64, _u64],

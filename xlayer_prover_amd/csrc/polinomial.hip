@@ -310,6 +310,26 @@ int dev_q_split(Ctx* ctx, u64* qq2, const u64* qq1, u64 n, u64 n_ext, u32 qdeg, 
     return 0;
 }
 
+// Polinomial::copy between strided views (polinomial.hpp copy(); the transposeH1H2Columns / transposeZColumns /
+// ...Rows helpers of starks.cpp:406-555 are sequences of it): dst[i * dst_stride + c] = src[i * src_stride + c], c < dim.
+__global__ __launch_bounds__(256) void copy_cols_kernel(u64* dst, u64 dst_stride, const u64* src, u64 src_stride, u64 n, u32 dim)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * dim) return;
+    const u64 i = t / dim;
+    const u32 c = (u32)(t % dim);
+    dst[i * dst_stride + c] = src[i * src_stride + c];
+}
+int dev_copy_cols(Ctx* ctx, u64* dst, u64 dst_stride, const u64* src, u64 src_stride, u64 n, u32 dim)
+{
+    if (!n || !dim) return 0;
+    if (dst_stride < dim || src_stride < dim) return xlp_fail("copy cols: stride smaller than dim");
+    const u64 thr = n * dim;
+    hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, ctx->stream, dst, dst_stride, src, src_stride, n, dim);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------ evmap
 // evals[i] = sum_k L_i[k] * pol_i[(k << eb) * stride_i].  Lanes run along the ENTRIES, sorted by address on the host:
 // neighbouring entries are neighbouring columns of one row-major section, so a wave reads contiguous bytes of a

@@ -201,6 +201,11 @@ int xlp_dev_expr_run(const xlp_expr_program* prog, const xlp_steps_params* param
     if (ensure_init()) return -1;
     return dev_expr_run(&g_ctx, prog, params, row0, nrows);
 }
+int xlp_dev_copy_cols(uint64_t* dst, uint64_t dst_stride, const uint64_t* src, uint64_t src_stride, uint64_t n, uint32_t dim)
+{
+    if (ensure_init()) return -1;
+    return dev_copy_cols(&g_ctx, dst, dst_stride, src, src_stride, n, dim);
+}
 int xlp_dev_q_split(uint64_t* qq2, const uint64_t* qq1, uint64_t n, uint64_t n_ext, uint32_t q_deg, uint32_t q_dim, uint64_t shift_in)
 {
     if (ensure_init()) return -1;

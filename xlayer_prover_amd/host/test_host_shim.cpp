@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <vector>
 #include "starks_mini.hpp"
+#include "starks.hpp"
 
 // `polinomial <n> <seed>`: Polinomial::batchInverse / calculateZ / calculateH1H2 through STRIDED views of one slab
 // (offset > dim, as the section views of starks.cpp:108-184 are), results as JSON for the oracle comparison.
@@ -72,8 +73,44 @@ static int starkinfo_mode(const char* file)
     return 0;
 }
 
+// `genproof <dir> <name>`: the GPU-resident Starks::genProof (starks.hpp) on <dir>/<name>.starkinfo.json, <name>.const,
+// <name>.commit (cm1_n), <name>.publics (u64 each) and the step programs <dir>/<name>.<step>.xlpexpr; prints the zkin proof
+static std::vector<Goldilocks::Element> read_u64_file(const std::string& f)
+{
+    FILE* fp = fopen(f.c_str(), "rb");
+    if (!fp) xlp_exit_process(("cannot open " + f).c_str());
+    fseek(fp, 0, SEEK_END); const long sz = ftell(fp); fseek(fp, 0, SEEK_SET);
+    std::vector<Goldilocks::Element> v(sz / 8);
+    if (sz && fread(v.data(), 8, v.size(), fp) != v.size()) xlp_exit_process(("short read on " + f).c_str());
+    fclose(fp);
+    return v;
+}
+static int genproof_mode(const std::string& dir, const std::string& name, bool timers)
+{
+    std::vector<Goldilocks::Element> constPols = read_u64_file(dir + "/" + name + ".const"), cm1 = read_u64_file(dir + "/" + name + ".commit"),
+                                     publics = read_u64_file(dir + "/" + name + ".publics");
+    Starks starks(dir + "/" + name + ".starkinfo.json", constPols.data(), dir, name);
+    starks.logTimers = timers;
+    const StarkStruct& ss = starks.starkInfo.starkStruct;
+    FRIProof proof(1ULL << ss.steps.back().nBits, FIELD_EXTENSION, ss.steps.size(), starks.starkInfo.evMap.size(), starks.starkInfo.nPublics);
+    for (uint64_t i = 0; i < starks.starkInfo.nPublics; i++) proof.publics[i] = publics[i];
+    starks.genProof(proof, publics.data(), starks.constRoot, cm1.data());
+    std::string zkin = proof2zkinStark(proof);
+    std::ostringstream os;
+    os << zkin.substr(0, zkin.size() - 1) << ",\"publics\":";
+    xlp_json::arr(os, proof.publics);
+    os << ",\"verkey\":[";
+    for (int i = 0; i < HASH_SIZE; i++) os << (i ? "," : "") << "\"" << Goldilocks::toString(starks.constRoot[i]) << "\"";
+    os << "]}";
+    const std::string out = os.str();
+    fwrite(out.data(), 1, out.size(), stdout);
+    printf("\n");
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if ((argc == 4 || argc == 5) && std::string(argv[1]) == "genproof") { const int r = genproof_mode(argv[2], argv[3], argc == 5); xlp_shutdown(); return r; }
     if (argc == 3 && std::string(argv[1]) == "starkinfo") return starkinfo_mode(argv[2]);
     if (argc == 4 && std::string(argv[1]) == "polinomial") return polinomial_mode(strtoull(argv[2], 0, 10), strtoull(argv[3], 0, 10));
     if (argc < 5) { fprintf(stderr, "usage: %s nBits nBitsExt nQueries step0 [step1 ...]\n", argv[0]); return 2; }

@@ -190,6 +190,16 @@ public:
     Goldilocks::Element* nodes;
     bool isSourceAllocated = false;
     bool isNodesAllocated = false;
+    // GPU-resident form (used by the GPU-resident Starks below): source / nodes stay in HBM, merkelize() runs there and
+    // getRoot / getGroupProof copy only the root or one row + its sibling path to the host
+    uint64_t* d_source = NULL;
+    uint64_t* d_nodes = NULL;
+    bool ownsDevNodes = false;
+    MerkleTreeGL(uint64_t _height, uint64_t _width, uint64_t* dSource, bool /*deviceTag*/) : height(_height), width(_width), source(NULL), nodes(NULL), d_source(dSource)
+    {
+        XLP_CHECK(xlp_dev_alloc((void**)&d_nodes, (getTreeNumElements() ? getTreeNumElements() : 1) * sizeof(uint64_t)));
+        ownsDevNodes = true;
+    }
     MerkleTreeGL() : height(0), width(0), source(NULL), nodes(NULL) {}
     // file-backed layout [width, height, source(height*width), nodes] (build_const_tree.cpp:566-603)
     MerkleTreeGL(Goldilocks::Element* tree)
@@ -212,13 +222,22 @@ public:
     {
         if (isSourceAllocated) free(source);
         if (isNodesAllocated) free(nodes);
+        if (ownsDevNodes) xlp_dev_free(d_nodes);
     }
     MerkleTreeGL(const MerkleTreeGL&) = delete;
     MerkleTreeGL& operator=(const MerkleTreeGL&) = delete;
     void copySource(Goldilocks::Element* _source) { std::memcpy(source, _source, height * width * sizeof(Goldilocks::Element)); }
-    void merkelize() { PoseidonGoldilocks::merkletree_avx(nodes, source, width, height); }
+    void merkelize()
+    {
+        if (d_nodes) { XLP_CHECK(xlp_dev_merkle(d_nodes, d_source, width, height)); return; }
+        PoseidonGoldilocks::merkletree_avx(nodes, source, width, height);
+    }
     uint64_t getTreeNumElements() { return height * HASH_SIZE + (height - 1) * HASH_SIZE; }
-    void getRoot(Goldilocks::Element* root) { std::memcpy(root, &nodes[getTreeNumElements() - HASH_SIZE], HASH_SIZE * sizeof(Goldilocks::Element)); }
+    void getRoot(Goldilocks::Element* root)
+    {
+        if (d_nodes) { XLP_CHECK(xlp_copy_d2h(root, d_nodes + getTreeNumElements() - HASH_SIZE, HASH_SIZE * sizeof(Goldilocks::Element))); return; }
+        std::memcpy(root, &nodes[getTreeNumElements() - HASH_SIZE], HASH_SIZE * sizeof(Goldilocks::Element));
+    }
     uint64_t MerkleProofSize()
     {
         uint64_t n = 0;
@@ -228,6 +247,16 @@ public:
     // proof = row || siblings bottom-up (merkleTreeGL.cpp:12-35)
     void getGroupProof(Goldilocks::Element* proof, uint64_t idx)
     {
+        if (d_nodes) {
+            if (width) XLP_CHECK(xlp_copy_d2h(proof, d_source + idx * width, width * sizeof(Goldilocks::Element)));
+            Goldilocks::Element* o = &proof[width];
+            uint64_t off_ = 0, cnt_ = height;
+            while (cnt_ > 1) {
+                XLP_CHECK(xlp_copy_d2h(o, d_nodes + off_ + (idx ^ 1) * HASH_SIZE, HASH_SIZE * sizeof(Goldilocks::Element)));
+                o += HASH_SIZE; off_ += cnt_ * HASH_SIZE; cnt_ >>= 1; idx >>= 1;
+            }
+            return;
+        }
         for (uint64_t i = 0; i < width; i++) proof[i] = source[idx * width + i];
         Goldilocks::Element* out = &proof[width];
         uint64_t off = 0, cnt = height;
@@ -699,7 +728,8 @@ class FRIProve
 public:
     // friProve.cpp:5-190.  The polynomial is uploaded once; fold / transpose / Merkle run on
     // the GPU per step; only roots, the final polynomial and the opened rows come back.
-    static void prove(FRIProof& fproof, MerkleTreeGL** treesGL, Transcript transcript, Polinomial& friPol, uint64_t polBits, StarkInfo starkInfo)
+    // d_friPol != NULL: the FRI polynomial already lives in HBM (GPU-resident Starks); friPol then only receives the final polynomial
+    static void prove(FRIProof& fproof, MerkleTreeGL** treesGL, Transcript transcript, Polinomial& friPol, uint64_t polBits, StarkInfo starkInfo, const uint64_t* d_friPol = NULL)
     {
         const std::vector<StepStruct>& steps = starkInfo.starkStruct.steps;
         const uint64_t nSteps = steps.size();
@@ -713,7 +743,8 @@ public:
         XLP_CHECK(xlp_dev_alloc((void**)&d_aux, n0 * 3 * 8));
         XLP_CHECK(xlp_dev_alloc((void**)&d_nodes, n0 * 2 * HASH_SIZE * 8));
         if (friPol.offset() != FIELD_EXTENSION) xlp_exit_process("FRIProve::prove: friPol must be dense (offset == 3)");
-        XLP_CHECK(xlp_copy_h2d(d_pol, friPol.address(), n0 * 3 * 8));
+        if (d_friPol) XLP_CHECK(xlp_dev_copy_cols(d_pol, 3, d_friPol, 3, n0, 3));
+        else XLP_CHECK(xlp_copy_h2d(d_pol, friPol.address(), n0 * 3 * 8));
 
         uint64_t pol2N = 0;
         for (uint64_t si = 0; si < nSteps; si++) {
