@@ -98,6 +98,10 @@ int xlp_dev_perm_batch(uint64_t* out, const uint64_t* in, uint64_t count);
 int xlp_dev_linear_hash(uint64_t* out, const uint64_t* src, uint64_t w, uint64_t h);
 int xlp_dev_fri_fold(uint64_t* pol2, const uint64_t* pol, uint32_t bits, uint32_t red, const uint64_t x[3], uint64_t shift_inv);
 int xlp_dev_transpose3(uint64_t* dst, const uint64_t* src, uint64_t n, uint32_t tbits);
+/* MerkleTreeGL::getGroupProof (merkleTreeGL.cpp:12-35) for nq indices in one call: out (HOST, nq x (w + 4 log2 h) words)
+ * receives, per index (HOST array idxs), the row followed by the sibling nodes bottom-up; src / nodes are the device
+ * buffers of xlp_dev_merkle.  Used by the query phase of FRIProve::prove (friProve.cpp:150-177). */
+int xlp_dev_merkle_proofs(uint64_t* out, const uint64_t* src, const uint64_t* nodes, uint64_t w, uint64_t h, const uint64_t* idxs, uint64_t nq);
 /* Synthetic trace: dst[i] = splitmix64(seed ^ (start + i)) mod p. */
 int xlp_dev_fill(uint64_t* dst, uint64_t n, uint64_t seed, uint64_t start);
 

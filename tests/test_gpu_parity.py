@@ -473,3 +473,17 @@ def test_q_split_vs_oracle(xlp, orc, nbits, ebits, qdeg, qdim):
     out = xlp.from_np(np.full(ne * qdeg * qdim, 7, np.uint64))
     xlp.dev_q_split(out, xlp.from_np(qq1), n, ne, qdeg, qdim, shift_in); xlp.sync()
     assert (xlp.to_np(out) == orc.q_split(qq1, n, ne, qdeg, qdim, shift_in)).all()
+
+
+@pytest.mark.parametrize("w,h", [(0, 8), (3, 1), (5, 2), (18, 64), (751, 1 << 10)])
+def test_merkle_proofs_batched_vs_oracle(xlp, orc, w, h):
+    """xlp_dev_merkle_proofs (getGroupProof for many indices in one call) against the oracle's proof walk"""
+    src = orc.fill(max(w * h, 1), 0x5EED0B00 + w)[: w * h]
+    nodes = orc.merkletree(src, w, h)
+    d_src = xlp.from_np(src if w * h else np.zeros(1, np.uint64)); d_nodes = xlp.from_np(nodes)
+    idxs = sorted({0, h - 1, h // 2, (h * 3) // 7})
+    got = xlp.dev_merkle_proofs(d_src, d_nodes, w, h, idxs)
+    for row, idx in zip(got, idxs):
+        assert (row == orc.merkle_proof(nodes, src, w, h, idx)).all()
+    with pytest.raises(xlp.XlpError, match="out of range"):
+        xlp.dev_merkle_proofs(d_src, d_nodes, w, h, [h])

@@ -47,6 +47,7 @@ SIGNATURES = {
     "xlp_dev_geometric": [_pu, _u64, _u32, _pu, _pu],
     "xlp_dev_q_split": [_pu, _pu, _u64, _u64, _u32, _u32, _u64],
     "xlp_dev_copy_cols": [_pu, _u64, _pu, _u64, _u64, _u32],
+    "xlp_dev_merkle_proofs": [_pu, _pu, _pu, _u64, _u64, _pu, _u64],
     "xlp_dev_x_div_x_sub_xi": [_pu, _pu, _pu, _u64],
     "xlp_dev_calculate_h1h2": [_pu, _pu, _pu, _pu, _u64, _u32],
     "xlp_expr_create": [C.POINTER(C.c_void_p), _pu, _u64, _u64, _u64],
@@ -265,6 +266,15 @@ def dev_calculate_z(z, num, den, n):
 
 def dev_calculate_h1h2(h1, h2, f, t, n, dim=1):
     _ck(load().xlp_dev_calculate_h1h2(_dp(h1), _dp(h2), _dp(f), _dp(t), n, dim), "xlp_dev_calculate_h1h2")
+
+
+def dev_merkle_proofs(src, nodes, w, h, idxs):
+    """-> ndarray [nq][w + 4 log2 h]: row then sibling nodes bottom-up, for every index"""
+    ix = np.ascontiguousarray(idxs, dtype=np.uint64)
+    levels = max(h.bit_length() - 1, 0)
+    out = np.zeros((ix.size, w + 4 * levels), np.uint64)
+    _ck(load().xlp_dev_merkle_proofs(out.ctypes.data_as(C.c_void_p), _dp(src), _dp(nodes), w, h, ix.ctypes.data_as(C.c_void_p), ix.size), "xlp_dev_merkle_proofs")
+    return out
 
 
 def dev_q_split(qq2, qq1, n, n_ext, q_deg, q_dim, shift_in):

@@ -178,4 +178,32 @@ int dev_merkle(Ctx* ctx, u64* nodes, const u64* src, u64 w, u64 h)
     return 0;
 }
 
+// MerkleTreeGL::getGroupProof (merkleTreeGL.cpp:12-35) for many indices at once: out[q] = row idx_q (w words) followed by
+// the sibling nodes bottom-up (4 words per level); one block per query, so a proof with hundreds of queries costs one
+// kernel and one copy instead of (1 + log2 h) small copies per query.
+__global__ __launch_bounds__(128) void merkle_proofs_kernel(u64* out, const u64* src, const u64* nodes, u64 w, u64 h, const u64* idxs, u32 levels)
+{
+    const u64 idx = idxs[blockIdx.x];
+    u64* o = out + (u64)blockIdx.x * (w + 4ull * levels);
+    for (u64 i = threadIdx.x; i < w; i += blockDim.x) o[i] = src[idx * w + i];
+    if (threadIdx.x < 4 * levels) {
+        const u32 l = threadIdx.x >> 2, c = threadIdx.x & 3;
+        u64 off = 0, cnt = h;
+        for (u32 k = 0; k < l; k++) { off += cnt * 4; cnt >>= 1; }
+        o[w + 4 * l + c] = nodes[off + (((idx >> l) ^ 1) * 4) + c];
+    }
+}
+
+int dev_merkle_proofs(Ctx* ctx, u64* out, const u64* src, const u64* nodes, u64 w, u64 h, const u64* d_idxs, u64 nq)
+{
+    if (!nq) return 0;
+    if (h == 0 || (h & (h - 1))) return xlp_fail("merkle proofs: number of rows is not a power of two");
+    u32 levels = 0;
+    while ((1ull << levels) < h) levels++;
+    if (levels > 32) return xlp_fail("merkle proofs: tree too tall");
+    hipLaunchKernelGGL(merkle_proofs_kernel, dim3((unsigned)nq), dim3(128), 0, ctx->stream, out, src, nodes, w, h, d_idxs, levels);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace xlp

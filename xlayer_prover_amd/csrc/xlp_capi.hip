@@ -69,6 +69,9 @@ struct DevBuf {
 
 using namespace xlp;
 
+#define H2D(buf, host, bytes) do { if (xlp_copy_h2d((buf).p, (host), (bytes))) return -1; } while (0)
+#define D2H(host, buf, bytes) do { if (xlp_copy_d2h((host), (buf).p, (bytes))) return -1; } while (0)
+
 extern "C" {
 
 int xlp_version(void) { return 0x000100; }
@@ -201,6 +204,23 @@ int xlp_dev_expr_run(const xlp_expr_program* prog, const xlp_steps_params* param
     if (ensure_init()) return -1;
     return dev_expr_run(&g_ctx, prog, params, row0, nrows);
 }
+int xlp_dev_merkle_proofs(uint64_t* out, const uint64_t* src, const uint64_t* nodes, uint64_t w, uint64_t h, const uint64_t* idxs, uint64_t nq)
+{
+    if (ensure_init()) return -1;
+    if (nq == 0) return 0;
+    if (!out || !nodes || !idxs || (w && !src)) return xlp_fail("xlp_dev_merkle_proofs: null pointer");
+    for (uint64_t q = 0; q < nq; q++) if (idxs[q] >= h) return xlp_fail("xlp_dev_merkle_proofs: index out of range");
+    uint32_t levels = 0;
+    while ((1ull << levels) < h) levels++;
+    const size_t per = w + 4ull * levels;
+    DevBuf di, dout;
+    if (di.alloc(nq * sizeof(u64)) || dout.alloc(nq * per * sizeof(u64))) return -1;
+    H2D(di, idxs, nq * sizeof(u64));
+    if (dev_merkle_proofs(&g_ctx, dout.u(), src, nodes, w, h, di.u(), nq)) return -1;
+    XLP_HIP(hipStreamSynchronize(g_ctx.stream));
+    D2H(out, dout, nq * per * sizeof(u64));
+    return 0;
+}
 int xlp_dev_copy_cols(uint64_t* dst, uint64_t dst_stride, const uint64_t* src, uint64_t src_stride, uint64_t n, uint32_t dim)
 {
     if (ensure_init()) return -1;
@@ -287,8 +307,6 @@ int xlp_copy_d2h(void* dst_host, const void* src_dev, size_t bytes)
 }
 
 // --------------------------------------------------------------- host layer
-#define H2D(buf, host, bytes) do { if (xlp_copy_h2d((buf).p, (host), (bytes))) return -1; } while (0)
-#define D2H(host, buf, bytes) do { if (xlp_copy_d2h((host), (buf).p, (bytes))) return -1; } while (0)
 
 int xlp_ntt(uint64_t* dst, const uint64_t* src, uint64_t n, uint64_t ncols, int inverse)
 {

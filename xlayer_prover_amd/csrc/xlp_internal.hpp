@@ -73,6 +73,7 @@ int poseidon_init(Ctx* ctx);
 int dev_perm(Ctx* ctx, u64* out, const u64* in, u64 count);
 int dev_linear_hash(Ctx* ctx, u64* out, const u64* src, u64 w, u64 h);
 int dev_merkle(Ctx* ctx, u64* nodes, const u64* src, u64 w, u64 h);
+int dev_merkle_proofs(Ctx* ctx, u64* out, const u64* src, const u64* nodes, u64 w, u64 h, const u64* d_idxs, u64 nq);
 
 // fri.hip
 int dev_fri_fold(Ctx* ctx, u64* pol2, const u64* pol, u32 bits, u32 red, const u64 x[3], u64 shift_inv);

@@ -244,6 +244,15 @@ public:
         while ((1ULL << n) < height) n++;
         return height > 1 ? n : 0;
     }
+    // getGroupProof for many indices: proofs[q] = row || siblings (width + MerkleProofSize() * HASH_SIZE elements each);
+    // one kernel + one copy when the tree lives on the GPU
+    void getGroupProofs(std::vector<Goldilocks::Element>& proofs, const std::vector<uint64_t>& idxs)
+    {
+        const uint64_t per = width + MerkleProofSize() * HASH_SIZE;
+        proofs.assign(idxs.size() * per + 1, Goldilocks::zero());
+        if (d_nodes) { XLP_CHECK(xlp_dev_merkle_proofs(xlp_raw(proofs.data()), d_source, d_nodes, width, height, idxs.data(), idxs.size())); return; }
+        for (size_t q = 0; q < idxs.size(); q++) getGroupProof(&proofs[q * per], idxs[q]);
+    }
     // proof = row || siblings bottom-up (merkleTreeGL.cpp:12-35)
     void getGroupProof(Goldilocks::Element* proof, uint64_t idx)
     {
@@ -735,13 +744,12 @@ public:
         const uint64_t nSteps = steps.size();
         Goldilocks::Element polShiftInv = Goldilocks::inv(Goldilocks::shift());
         std::vector<MerkleTreeGL*> treesFRIGL(nSteps, NULL);
+        std::vector<uint64_t*> friSources;
 
-        uint64_t* d_pol = NULL; uint64_t* d_pol2 = NULL; uint64_t* d_aux = NULL; uint64_t* d_nodes = NULL;
+        uint64_t* d_pol = NULL; uint64_t* d_pol2 = NULL;
         const uint64_t n0 = 1ULL << polBits;
         XLP_CHECK(xlp_dev_alloc((void**)&d_pol, n0 * 3 * 8));
         XLP_CHECK(xlp_dev_alloc((void**)&d_pol2, n0 * 3 * 8));
-        XLP_CHECK(xlp_dev_alloc((void**)&d_aux, n0 * 3 * 8));
-        XLP_CHECK(xlp_dev_alloc((void**)&d_nodes, n0 * 2 * HASH_SIZE * 8));
         if (friPol.offset() != FIELD_EXTENSION) xlp_exit_process("FRIProve::prove: friPol must be dense (offset == 3)");
         if (d_friPol) XLP_CHECK(xlp_dev_copy_cols(d_pol, 3, d_friPol, 3, n0, 3));
         else XLP_CHECK(xlp_copy_h2d(d_pol, friPol.address(), n0 * 3 * 8));
@@ -756,12 +764,15 @@ public:
             if (si < nSteps - 1) {
                 const uint64_t nGroups = 1ULL << steps[si + 1].nBits;
                 const uint64_t groupSize = (1ULL << steps[si].nBits) / nGroups;
-                XLP_CHECK(xlp_dev_transpose3(d_aux, d_pol2, pol2N, (uint32_t)steps[si + 1].nBits));
-                XLP_CHECK(xlp_dev_merkle(d_nodes, d_aux, groupSize * FIELD_EXTENSION, nGroups));
-                treesFRIGL[si + 1] = new MerkleTreeGL(nGroups, groupSize * FIELD_EXTENSION, NULL);
+                // the step's tree stays in HBM (source = the transposed groups, nodes): only its root and, at the end, the
+                // queried rows + sibling paths come back
+                uint64_t* d_src = NULL;
+                XLP_CHECK(xlp_dev_alloc((void**)&d_src, pol2N * 3 * 8));
+                friSources.push_back(d_src);
+                XLP_CHECK(xlp_dev_transpose3(d_src, d_pol2, pol2N, (uint32_t)steps[si + 1].nBits));
+                treesFRIGL[si + 1] = new MerkleTreeGL(nGroups, groupSize * FIELD_EXTENSION, d_src, true);
                 MerkleTreeGL* t = treesFRIGL[si + 1];
-                XLP_CHECK(xlp_copy_d2h(t->source, d_aux, pol2N * 3 * 8));
-                XLP_CHECK(xlp_copy_d2h(t->nodes, d_nodes, t->getTreeNumElements() * 8));
+                t->merkelize();
                 Goldilocks::Element rootGL[HASH_SIZE];
                 t->getRoot(rootGL);
                 transcript.put(rootGL, HASH_SIZE);
@@ -783,15 +794,27 @@ public:
         std::vector<uint64_t> ys(nQueries);
         transcript.getPermutations(ys.data(), nQueries, steps[0].nBits);
         for (uint64_t si = 0; si < nSteps; si++) {
+            // friProve.cpp:155-177, batched per tree: one getGroupProofs call covers every query
+            std::vector<MerkleTreeGL*> trees;
+            if (si == 0) for (unsigned i = 0; i < 5; i++) trees.push_back(treesGL[i]);
+            else trees.push_back(treesFRIGL[si]);
+            std::vector<std::vector<Goldilocks::Element>> bufs(trees.size());
+            for (size_t k = 0; k < trees.size(); k++) trees[k]->getGroupProofs(bufs[k], ys);
             for (uint64_t i = 0; i < nQueries; i++) {
-                if (si == 0) queryPol(fproof, treesGL, ys[i], si);
-                else queryPol(fproof, treesFRIGL[si], ys[i], si);
+                std::vector<MerkleProof> vMkProof;
+                for (size_t k = 0; k < trees.size(); k++) {
+                    MerkleTreeGL* t = trees[k];
+                    const uint64_t per = t->width + t->MerkleProofSize() * HASH_SIZE;
+                    vMkProof.push_back(MerkleProof(t->width, t->MerkleProofSize(), &bufs[k][i * per]));
+                }
+                fproof.proofs.fri.trees[si].polQueries.push_back(vMkProof);
             }
             if (si < nSteps - 1)
                 for (uint64_t i = 0; i < nQueries; i++) ys[i] = ys[i] % (1ULL << steps[si + 1].nBits);
         }
         for (MerkleTreeGL* t : treesFRIGL) delete t;
-        XLP_CHECK(xlp_dev_free(d_pol)); XLP_CHECK(xlp_dev_free(d_pol2)); XLP_CHECK(xlp_dev_free(d_aux)); XLP_CHECK(xlp_dev_free(d_nodes));
+        for (uint64_t* p_ : friSources) XLP_CHECK(xlp_dev_free(p_));
+        XLP_CHECK(xlp_dev_free(d_pol)); XLP_CHECK(xlp_dev_free(d_pol2));
     }
     static void queryPol(FRIProof& fproof, MerkleTreeGL* treesGL[5], uint64_t idx, uint64_t treeIdx)
     {
