@@ -9,7 +9,7 @@ import numpy as np
 from xlayer_prover_amd import expr as E
 
 
-def random_program(seed, n, ninstr, nin=24, ntmp1=12, ntmp3=6, nconst=5, nconst2=4, nch=4, npub=3, nev=5, nstore=40):
+def random_program(seed, n, ninstr, nin=24, ntmp1=12, ntmp3=6, nconst=5, nconst2=4, nch=4, npub=3, nev=5, nstore=40, prime_dst=True):
     rng = np.random.default_rng(seed)
     width = nin + 3 * nstore
     prog = E.Program()
@@ -59,7 +59,7 @@ def random_program(seed, n, ninstr, nin=24, ntmp1=12, ntmp3=6, nconst=5, nconst2
                 i = int(rng.integers(0, ntmp3)); dst = E.tmp3(i); live3.add(i)
         elif r == 7:
             dst = E.pols(next_store[0], width, dd); next_store[0] += 3
-        elif r == 8:
+        elif r == 8 and prime_dst:
             dst = E.pols_prime(next_store[0], int(rng.integers(1, 3)), n, width, dd); next_store[0] += 3
         else:
             if dd == 3:

@@ -548,3 +548,43 @@ def test_golden_proof_fri_polynomial_all_queries(orc, golden_dir, src, fixture, 
         orc.expr_run(code, ntmp1, ntmp3, bufs, 0, 1, 1, len(J["s0_valsC"][q]))
         k = idx >> F["steps_nBits"][1]
         assert [int(v) for v in bufs["f_2ns"]] == ints(J["s1_vals"][q])[3 * k: 3 * k + 3], q
+
+
+@pytest.mark.gpu
+def test_expr_row_windows_equal_full_domain(xlp, orc):
+    """Row sharding (xlayer_prover_amd/shard.py): the HIP VM on two row WINDOWS of a domain (own rows + halo rows of the
+    next shard, local row numbers, global modulus) reproduces the run over the whole domain.  Also: a window shorter than
+    the highest next-row read is rejected."""
+    import torch
+    from xlayer_prover_amd import shard
+    n, ninstr, halo = 4096, 200, 3
+    prog, width = random_program(51, n, ninstr, prime_dst=False)
+    full = make_buffers(orc, 0x5EED0D00, n, width, zi_size=4)
+    widths = {"pols": width, "const_pols": 5, "const_pols_2ns": 4, "x_n": 1, "x_2ns": 1, "x_div_x_sub_xi": 3, "x_div_x_sub_wxi": 3, "q_2ns": 3, "f_2ns": 3}
+    exp = {k: v.copy() for k, v in full.items()}
+    orc.expr_run(prog.code, prog.ntmp1, prog.ntmp3, exp, 0, n, 5, 4)
+    p = xlp.ExprProgram(prog.code, prog.ntmp1, prog.ntmp3)
+    half = n // 2
+    for s in range(2):
+        r0 = s * half
+        dev = {}
+        for name, arr in full.items():
+            if name in widths:
+                w = widths[name]
+                a2 = arr.reshape(n, w)
+                win = np.concatenate([a2[r0:r0 + half], a2[(r0 + half) % n:(r0 + half) % n + halo]])     # what halo_exchange assembles
+                dev[name] = xlp.from_np(np.ascontiguousarray(win).reshape(-1))
+            else:
+                dev[name] = xlp.from_np(arr)
+        p.run(xlp.steps_params(n_const_pols=5, n_const_pols_2ns=4, **dev), 0, half); xlp.sync()
+        for k in ("pols", "q_2ns", "f_2ns"):
+            got = xlp.to_np(dev[k]).reshape(half + halo, widths[k])[:half]
+            assert (got == exp[k].reshape(n, widths[k])[r0:r0 + half]).all(), (s, k)
+        if s == 0:
+            short = dict(dev); short["pols"] = dev["pols"][: (half + 0) * width]                            # no halo rows
+            with pytest.raises(xlp.XlpError, match="past the end"):
+                p.run(xlp.steps_params(n_const_pols=5, n_const_pols_2ns=4, **short), 0, half)
+    p.close()
+    # world-1 halo exchange = wrap-around copy
+    t = torch.arange(12, dtype=torch.int64)
+    assert shard.halo_exchange(t, 3, 1).tolist() == list(range(12)) + [0, 1, 2]

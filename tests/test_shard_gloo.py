@@ -76,3 +76,70 @@ def test_partitions():
         sizes = [b - a for a, b in spans]
         assert max(sizes) - min(sizes) <= 1
     assert [shard.col_range(751, 8, g)[1] - shard.col_range(751, 8, g)[0] for g in range(8)] == [94] * 7 + [93]
+
+
+ROW_BUFFERS = {"pols": None, "const_pols": 5, "const_pols_2ns": 4, "x_n": 1, "x_2ns": 1, "x_div_x_sub_xi": 3, "x_div_x_sub_wxi": 3, "q_2ns": 3, "f_2ns": 3}
+
+
+def _expr_worker(rank, world, port, seed, n, ninstr, q):
+    """one rank of a row-sharded constraint step: windows = own rows + halo rows of the next rank; the oracle interpreter
+    stands in for the HIP VM (injected here, the product module never imports it)"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import gl_oracle as orc
+    from tests.expr_programs import make_buffers, random_program
+    from xlayer_prover_amd import shard
+    prog, width = random_program(seed, n, ninstr, prime_dst=True)
+    full = make_buffers(orc, 0x5EED0C00 + seed, n, width, zi_size=4)
+    r0, r1 = shard.row_range(n, world, rank)
+    rows, halo = r1 - r0, 3
+    widths = dict(ROW_BUFFERS); widths["pols"] = width
+    win = {}
+    for name, arr in full.items():
+        if name in widths:
+            w = widths[name]
+            local = torch.from_numpy(arr.reshape(n, w)[r0:r1].copy().view(np.int64).reshape(-1))
+            win[name] = np.ascontiguousarray(shard.halo_exchange(local, w, halo).numpy().view(np.uint64))
+        else:
+            win[name] = arr.copy()
+    orc.expr_run(prog.code, prog.ntmp1, prog.ntmp3, win, 0, rows, 5, 4)       # local row numbers, global modulus in the program
+    # next-row stores landed in the halo rows: hand them to the owner (columns written by pols_prime destinations)
+    from xlayer_prover_amd import expr as E
+    from tests import expr_real as R
+    cols = sorted({(int(prog.code[qq]), dim, int(prog.code[qq + 1])) for k, s, kind, dim, qq in R.operands(prog.code) if s == 0 and kind == E.K_POLS_PRIME})
+    if cols:
+        t = torch.from_numpy(win["pols"].view(np.int64))
+        shard.halo_writeback(t, width, rows, halo, cols)
+        win["pols"] = t.numpy().view(np.uint64)
+    q.put((rank, r0, r1, {k: win[k].reshape(rows + halo, widths[k])[:rows].copy() for k in ("pols", "q_2ns", "f_2ns")}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,seed", [(2, 1), (4, 2)])
+def test_row_sharded_constraint_step_equals_single_process(world, seed, orc):
+    """constraint steps shard by rows with a halo for the next-row operands (and the reverse exchange for
+    next-row stores); the assembled result equals the single-process run over the whole domain"""
+    from tests.expr_programs import make_buffers, random_program
+    n, ninstr = 256, 150
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + world * 13 + seed
+    procs = [ctx.Process(target=_expr_worker, args=(r, world, port, seed, n, ninstr, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    prog, width = random_program(seed, n, ninstr, prime_dst=True)
+    exp = make_buffers(orc, 0x5EED0C00 + seed, n, width, zi_size=4)
+    before = exp["pols"].copy()
+    orc.expr_run(prog.code, prog.ntmp1, prog.ntmp3, exp, 0, n, 5, 4)
+    assert (exp["pols"] != before).any()
+    widths = {"pols": width, "q_2ns": 3, "f_2ns": 3}
+    for rank, r0, r1, out in res:
+        for k, w in widths.items():
+            assert (out[k] == exp[k].reshape(n, w)[r0:r1]).all(), (rank, k)

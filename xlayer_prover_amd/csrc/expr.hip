@@ -30,7 +30,8 @@
 struct xlp_expr_column {            // one staged column: element (row) = buffer[off + row * stride]
     uint32_t buf;                   // 0 pols, 1 const_pols (stride = n_const_pols), 2 const_pols_2ns
     uint64_t off, stride;
-    bool halo, written;
+    uint64_t halo;                  // rows past the slab this column is read at (largest next-row distance of its operands)
+    bool written;
 };
 struct xlp_expr_program {
     std::vector<uint64_t> code;   // validated user program (numbers canonical): bounds checks run on this
@@ -119,6 +120,13 @@ static int check_bounds(const xlp_expr_program* prog, const xlp_steps_params& P,
     const uint64_t* code = prog->code.data();
     const uint64_t ncode = prog->code.size();
     const uint64_t last = row0 + nrows - 1;
+    // highest row a next-row operand (distance nx, modulus md) reads: the whole domain if the range wraps, else last + nx.
+    // A run over a row WINDOW of a larger domain (one rank's shard + its halo rows, shard.py) therefore only needs the
+    // window to be resident.
+    auto top_row = [&](uint64_t nx, uint64_t md) -> unsigned __int128 {
+        const unsigned __int128 t = (unsigned __int128)last + nx;
+        return t < md ? t : (unsigned __int128)(md - 1);
+    };
     std::string msg;
     uint64_t pc = 0, k = 0;
     while (pc < ncode) {
@@ -132,14 +140,14 @@ static int check_bounds(const xlp_expr_program* prog, const xlp_steps_params& P,
             const uint64_t* p = o->p;
             switch (o->kind) {
             case XLP_K_POLS: hi = (unsigned __int128)p[0] + (unsigned __int128)last * p[1] + o->dim - 1; size = P.pols_size; base = P.pols; break;
-            case XLP_K_POLS_PRIME: hi = (unsigned __int128)p[0] + (unsigned __int128)(p[2] - 1) * p[3] + o->dim - 1; size = P.pols_size; base = P.pols; break;
+            case XLP_K_POLS_PRIME: hi = (unsigned __int128)p[0] + top_row(p[1], p[2]) * p[3] + o->dim - 1; size = P.pols_size; base = P.pols; break;
             case XLP_K_CONST:
                 if (p[0] >= P.n_const_pols) { hi = ~(unsigned __int128)0; }
                 else hi = (unsigned __int128)p[0] + (unsigned __int128)last * P.n_const_pols;
                 size = P.const_pols_size; base = P.const_pols; break;
             case XLP_K_CONST_PRIME:
                 if (p[0] >= P.n_const_pols) { hi = ~(unsigned __int128)0; }
-                else hi = (unsigned __int128)p[0] + (unsigned __int128)(p[2] - 1) * P.n_const_pols;
+                else hi = (unsigned __int128)p[0] + top_row(p[1], p[2]) * P.n_const_pols;
                 size = P.const_pols_size; base = P.const_pols; break;
             case XLP_K_CONST2NS:
                 if (p[0] >= P.n_const_pols_2ns) { hi = ~(unsigned __int128)0; }
@@ -147,7 +155,7 @@ static int check_bounds(const xlp_expr_program* prog, const xlp_steps_params& P,
                 size = P.const_pols_2ns_size; base = P.const_pols_2ns; break;
             case XLP_K_CONST2NS_PRIME:
                 if (p[0] >= P.n_const_pols_2ns) { hi = ~(unsigned __int128)0; }
-                else hi = (unsigned __int128)p[0] + (unsigned __int128)(p[2] - 1) * P.n_const_pols_2ns;
+                else hi = (unsigned __int128)p[0] + top_row(p[1], p[2]) * P.n_const_pols_2ns;
                 size = P.const_pols_2ns_size; base = P.const_pols_2ns; break;
             case XLP_K_CHALLENGE: hi = (unsigned __int128)p[0] * 3 + 2; size = P.challenges_size; base = P.challenges; break;
             case XLP_K_EVAL: hi = (unsigned __int128)p[0] * 3 + 2; size = P.evals_size; base = P.evals; break;
@@ -252,7 +260,7 @@ static void compile(xlp_expr_program* P)
 
     // ---- staging decisions
     const bool stage = env_int("XLP_EXPR_STAGE", 1) != 0;
-    std::map<ColKey, int> colset;          // key -> flags (1 halo, 2 written)
+    std::map<ColKey, std::pair<u64, bool>> colset;   // key -> (halo rows, written)
     std::set<ColKey> blocked;
     u64 modulus = 0, halo = 0;
     if (stage) {
@@ -296,9 +304,9 @@ static void compile(xlp_expr_program* P)
                 if (!rowmajor(*ops[s], k, next, mod)) continue;
                 if (blocked.count({k.buf, k.stride, k.off})) continue;
                 for (u32 c = 0; c < ops[s]->dim; c++) {
-                    int& f = colset[{k.buf, k.stride, k.off + c}];
-                    if (mod && next) { f |= 1; if (next > halo) halo = next; }
-                    if (s == 0) f |= 2;
+                    std::pair<u64, bool>& f = colset[{k.buf, k.stride, k.off + c}];
+                    if (mod && next) { if (next > f.first) f.first = next; if (next > halo) halo = next; }
+                    if (s == 0) f.second = true;
                 }
             }
             pc = nx;
@@ -307,8 +315,8 @@ static void compile(xlp_expr_program* P)
     std::map<ColKey, u32> colidx;
     for (const auto& kv : colset) {
         colidx[kv.first] = (u32)P->cols.size();
-        if (kv.second & 2) P->wcols.push_back((u32)P->cols.size());
-        P->cols.push_back({kv.first.buf, kv.first.off, kv.first.stride, (kv.second & 1) != 0, (kv.second & 2) != 0});
+        if (kv.second.second) P->wcols.push_back((u32)P->cols.size());
+        P->cols.push_back({kv.first.buf, kv.first.off, kv.first.stride, kv.second.first, kv.second.second});
     }
     P->halo = halo; P->modulus = modulus;
 
@@ -349,7 +357,7 @@ struct ExprArgs {
     u64 row0, nrows;                          // absolute first row, rows of this launch
     xlp_steps_params P;
 };
-struct ColDesc { u64* base; u64 stride; u64 flags; };   // flags bit0: halo rows wanted
+struct ColDesc { u64* base; u64 stride; u64 halo; };    // halo: rows past the slab to stage for this column
 
 __device__ __forceinline__ u64 uni(u64 v)   // value is wave-uniform: keep it in SGPRs
 {
@@ -582,7 +590,7 @@ __global__ __launch_bounds__(256) void expr_gather_kernel(u64* cols, const ColDe
     for (u32 r = wv; r < 64; r += 4) {
         const u64 j = j0 + r;
         u64 v = 0;
-        if (c < ncols && (j < rows || (j < rows + halo && (d.flags & 1)))) {
+        if (c < ncols && j < rows + d.halo) {
             u64 ar = row0 + j;
             if (modulus) ar = wrap(ar, modulus);
             v = gl::canon(d.base[ar * d.stride]);
@@ -842,7 +850,7 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
     os << "extern \"C\" { extern const u64_ xlpjit_info[4]; extern const u64_ xlpjit_cols[][4]; }\n";
     os << "const u64_ xlpjit_info[4] = {" << P->cols.size() << "ULL, " << P->halo << "ULL, " << P->modulus << "ULL, " << P->tmp_words << "ULL};\n";
     os << "const u64_ xlpjit_cols[][4] = {";
-    for (const xlp_expr_column& c : P->cols) os << "{" << c.buf << ", " << c.off << "ULL, " << c.stride << "ULL, " << ((c.halo ? 1 : 0) | (c.written ? 2 : 0)) << "},";
+    for (const xlp_expr_column& c : P->cols) os << "{" << c.buf << ", " << c.off << "ULL, " << c.stride << "ULL, " << ((c.halo ? 1 : 0) | (c.written ? 2 : 0)) /* harness: stages the global halo for flagged columns */ << "},";
     os << "{0, 0, 0, 0}};\n";
     return write_file(path, os.str()) ? 0 : xlp_fail("expr codegen: cannot write the output file");
 }
@@ -901,7 +909,7 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
             const xlp_expr_column& k = prog->cols[c];
             u64* base = k.buf == 0 ? P.pols : k.buf == 1 ? const_cast<u64*>(P.const_pols) : const_cast<u64*>(P.const_pols_2ns);
             const u64 stride = k.buf == 0 ? k.stride : k.buf == 1 ? P.n_const_pols : P.n_const_pols_2ns;
-            tab[c] = {base + k.off, stride, k.halo ? 1ull : 0ull};
+            tab[c] = {base + k.off, stride, k.halo};
         }
         XLP_HIP(hipMemcpyAsync(d_tab, tab.data(), ncols * sizeof(ColDesc), hipMemcpyHostToDevice, ctx->stream));
         if (nw) XLP_HIP(hipMemcpyAsync(d_wl, prog->wcols.data(), nw * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));

@@ -111,3 +111,52 @@ def sharded_commit(trace_local, n, n_ext, ncols, group=None, lde=None, merkle=No
     nodes = merkle(ext_rows)
     root, _ = assemble_root(nodes[-4:].clone(), hash_pairs, group)
     return root, nodes, ext_rows
+
+
+# ---------------------------------------------------------------------------------------- constraint steps across ranks
+# expression evaluation is row-local except the next-row ("prime") operands -> row partition with a halo.
+# Each rank keeps a WINDOW of every row-indexed buffer: its rows followed by `halo` rows of the next rank (wrapping to
+# rank 0).  The step program is evaluated on local row numbers 0 .. rows_local-1 with the GLOBAL modulus in its next-row
+# operands: (i + next) % N never wraps inside a window, so the reads land in the halo rows, and xlp_dev_expr_run only
+# asks for the window to be resident (csrc/expr.hip check_bounds).  Shard boundaries must be multiples of the ZhInv
+# period 2^extendBits (they are for power-of-two shards).  Programs that STORE to the next row (a few zkEVM step3prev
+# operations) also need the reverse exchange of the halo rows they wrote; halo_writeback does that.
+def halo_exchange(local, width, halo_rows, group=None):
+    """local: [rows_local * width] tensor of one row-major section.  Returns [(rows_local + halo_rows) * width]: the local
+    rows followed by the first halo_rows rows of rank+1 (ring).  One small point-to-point exchange per section."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rows = local.numel() // width
+    out = torch.empty((rows + halo_rows) * width, dtype=local.dtype, device=local.device)
+    out[: rows * width] = local
+    head = local[: halo_rows * width].contiguous()
+    if world == 1:
+        out[rows * width:] = head
+        return out
+    rank = dist.get_rank(group)
+    recv = torch.empty_like(head)
+    reqs = [dist.isend(head, dst=(rank - 1) % world, group=group), dist.irecv(recv, src=(rank + 1) % world, group=group)]
+    for r in reqs:
+        r.wait()
+    out[rows * width:] = recv
+    return out
+
+
+def halo_writeback(window, width, rows_local, halo_rows, cols, group=None):
+    """After a program that stores to next rows: for each (first column, column count, next distance) in `cols` the first
+    `next` halo rows of `window` hold values that belong to rank+1's first rows.  Sends them forward and overwrites the same
+    columns of the local first `next` rows with what rank-1 computed (rows beyond `next` are the owner's own results)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    w2 = window.view(rows_local + halo_rows, width)
+    halo = torch.cat([w2[rows_local:rows_local + nx, a:a + c].reshape(-1) for a, c, nx in cols]).contiguous()
+    if world == 1:
+        recv = halo
+    else:
+        rank = dist.get_rank(group)
+        recv = torch.empty_like(halo)
+        reqs = [dist.isend(halo, dst=(rank + 1) % world, group=group), dist.irecv(recv, src=(rank - 1) % world, group=group)]
+        for r in reqs:
+            r.wait()
+    o = 0
+    for a, c, nx in cols:
+        w2[:nx, a:a + c] = recv[o:o + nx * c].view(nx, c); o += nx * c
+    return window
