@@ -588,3 +588,33 @@ def test_expr_row_windows_equal_full_domain(xlp, orc):
     # world-1 halo exchange = wrap-around copy
     t = torch.arange(12, dtype=torch.int64)
     assert shard.halo_exchange(t, 3, 1).tolist() == list(range(12)) + [0, 1, 2]
+
+
+def test_expr_create_survives_malformed_programs():
+    """xlp_expr_create is host-only (validation + compilation): mutated programs are either accepted or rejected with an
+    error, never a crash; accepted ones also survive code generation"""
+    import tempfile
+    from xlayer_prover_amd import capi
+    rng = np.random.default_rng(77)
+    prog, _ = random_program(5, 64, 60)
+    base = prog.code
+    accepted = rejected = 0
+    with tempfile.TemporaryDirectory() as d:
+        for it in range(400):
+            c = base.copy()
+            for _ in range(int(rng.integers(1, 4))):
+                k = int(rng.integers(0, c.size))
+                mode = int(rng.integers(0, 3))
+                c[k] = np.uint64(rng.integers(0, 1 << 63)) if mode == 0 else c[k] ^ np.uint64(1 << int(rng.integers(0, 40))) if mode == 1 else np.uint64(rng.integers(0, 64))
+            if it % 7 == 0:
+                c = c[: int(rng.integers(1, c.size))]
+            try:
+                p = capi.ExprProgram(c, prog.ntmp1, prog.ntmp3)
+            except capi.XlpError:
+                rejected += 1
+                continue
+            accepted += 1
+            if accepted <= 20:
+                p.codegen(os.path.join(d, "m.hip"))
+            p.close()
+    assert rejected > 50 and accepted > 10
