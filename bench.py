@@ -26,6 +26,7 @@ EXT_BITS = 1
 SEED = 0x5EED0002
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 LDE_KERNELS = ["xlp::lde_top_dif<11>", "xlp::lde_mid", "xlp::lde_top_dit<11>"]   # one launch of each per extendPol
+VALU_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1", "lde_valu.json")
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1", "lde_traffic.json")          # PMC passes of tools/traffic_probe.py
 
 
@@ -143,6 +144,13 @@ def main():
         traffic = None
         if os.path.exists(TRAFFIC_FILE) and args.log_n == LOG_N and ncols == NCOLS:
             traffic = json.load(open(TRAFFIC_FILE))["hbm_bytes_per_lde"]
+        # the resource that actually binds: VALU issue slots (measured instruction count of one LDE / measured kernel time)
+        valu_issue = None
+        if os.path.exists(VALU_FILE) and args.log_n == LOG_N and ncols == NCOLS:
+            vj = json.load(open(VALU_FILE))
+            rate = vj["valu_wave_instructions_per_lde"] / (lde_kernel_ms * 1e-3)
+            valu_issue = {"achieved": round(rate / 1e9, 1), "peak": round(vj["issue_peak_wave_instructions_per_s"] / 1e9, 1), "unit": "G wave-instr/s",
+                          "frac": round(rate / vj["issue_peak_wave_instructions_per_s"], 3)}
         roofline = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -151,6 +159,7 @@ def main():
             "avg_launch_ms": {k: round(v, 4) for k, v in zip(LDE_KERNELS, per_kernel_ms)} if kern_cnt else None,
             "alg_bytes_per_step": alg_bytes_lde,
             "note": "integer-VALU co-bound (Goldilocks mul = 4 v_mad_u64_u32 + carry chains): see DESIGN.md",
+            "valu_issue": valu_issue,
         }
         line = {
             "metric": "Goldilocks NTT GFE/s (LDE 2^%d x %d, blow-up 2)" % (args.log_n, ncols),
