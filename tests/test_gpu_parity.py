@@ -487,3 +487,29 @@ def test_merkle_proofs_batched_vs_oracle(xlp, orc, w, h):
         assert (row == orc.merkle_proof(nodes, src, w, h, idx)).all()
     with pytest.raises(xlp.XlpError, match="out of range"):
         xlp.dev_merkle_proofs(d_src, d_nodes, w, h, [h])
+
+
+@pytest.mark.parametrize("nbits,eb,width,nev,seed", [(3, 1, 5, 7, 1), (12, 1, 37, 300, 2), (13, 3, 21, 64, 3), (14, 1, 751, 900, 4)])
+def test_evmap_many_entries_vs_oracle(xlp, orc, nbits, eb, width, nev, seed):
+    """the entry-per-lane evmap kernel: more entries than one block, rows not a multiple of the staged sub-chunk, mixed
+    dimensions and prime flags, duplicate columns, non-canonical inputs, a second (narrow) section"""
+    rng = np.random.default_rng(seed)
+    n, ne = 1 << nbits, 1 << (nbits + eb)
+    LEv = orc.fill(3 * n, 0x5EED0E00 + seed).reshape(n, 3)
+    LpEv = orc.fill(3 * n, 0x5EED0E10 + seed).reshape(n, 3)
+    secA = rng.integers(0, 2**64, size=(ne, width), dtype=np.uint64)          # any 64-bit words
+    secB = orc.fill(ne * 6, 0x5EED0E20 + seed).reshape(ne, 6)
+    ents = []
+    for _ in range(nev):
+        if rng.integers(0, 5) == 0:
+            ents.append((secB, int(rng.integers(0, 2)) * 3, 3, bool(rng.integers(0, 2))))
+        elif width >= 3 and rng.integers(0, 6) == 0:
+            ents.append((secA, int(rng.integers(0, width - 2)), 3, bool(rng.integers(0, 2))))
+        else:
+            ents.append((secA, int(rng.integers(0, width)), 1, bool(rng.integers(0, 2))))
+    exp = orc.evmap(LEv, LpEv, n, eb, ents)
+    tA, tB = xlp.from_np(secA.reshape(-1)), xlp.from_np(secB.reshape(-1))
+    dev_ents = xlp.evmap_entries([((tA if e[0] is secA else tB), e[0].shape[1], e[1], e[2], e[3]) for e in ents])
+    ev = xlp.from_np(np.zeros(3 * len(ents), np.uint64))
+    xlp.dev_evmap(ev, xlp.from_np(LEv.reshape(-1)), xlp.from_np(LpEv.reshape(-1)), n, eb, dev_ents); xlp.sync()
+    assert (xlp.to_np(ev).reshape(-1, 3) == exp).all()
