@@ -424,7 +424,7 @@ def _plookup_inputs(orc, n, dim, seed, distinct):
     return np.ascontiguousarray(f), np.ascontiguousarray(t)
 
 
-@pytest.mark.parametrize("n,dim,distinct", [(1, 1, 1), (8, 1, 3), (8, 3, 8), (1000, 1, 37), (4096, 3, 500), (1 << 16, 1, 1 << 12), (1 << 16, 3, 1 << 16)])
+@pytest.mark.parametrize("n,dim,distinct", [(1, 1, 1), (8, 1, 3), (8, 3, 8), (1000, 1, 37), (4096, 3, 500), (1 << 16, 1, 1 << 12), (1 << 16, 3, 1 << 16), (1 << 20, 1, 1 << 19), (1 << 20, 3, 50)])
 def test_calculate_h1h2_vs_oracle(xlp, orc, n, dim, distinct):
     f, t = _plookup_inputs(orc, n, dim, 0x5EED0090 + n, distinct)
     exp1, exp2 = orc.calculate_h1h2(f, t, dim)
