@@ -143,3 +143,57 @@ def test_row_sharded_constraint_step_equals_single_process(world, seed, orc):
     for rank, r0, r1, out in res:
         for k, w in widths.items():
             assert (out[k] == exp[k].reshape(n, w)[r0:r1]).all(), (rank, k)
+
+
+def _z_ev_worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import gl_oracle as orc
+    from xlayer_prover_amd import shard
+    as_u = lambda t: t.numpy().view(np.uint64)
+    to_t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64).reshape(-1))
+    num = orc.fill(3 * n, 0x5EED0F01).reshape(n, 3); den = orc.fill(3 * n, 0x5EED0F02).reshape(n, 3)
+    r0, r1 = shard.row_range(n, world, rank)
+    calc_z = lambda a, b: to_t(orc.calculate_z(as_u(a), as_u(b)))
+
+    def scale3(z, s):
+        v = as_u(z).reshape(-1, 3)
+        for i in range(v.shape[0]):
+            v[i] = orc.mul3(v[i], s)
+    z = shard.sharded_calculate_z(to_t(num[r0:r1]), to_t(den[r0:r1]), calc_z, scale3)
+    # evmap: rows of LEv / LpEv and of a 2x extended section, local windows
+    eb, w = 1, 7
+    LEv = orc.fill(3 * n, 0x5EED0F03).reshape(n, 3); LpEv = orc.fill(3 * n, 0x5EED0F04).reshape(n, 3)
+    sec = orc.fill((n << eb) * w, 0x5EED0F05).reshape(n << eb, w)
+    ents = [(0, 1, False), (3, 1, True), (4, 3, False), (6, 1, True)]
+    part = orc.evmap(LEv[r0:r1].copy(), LpEv[r0:r1].copy(), r1 - r0, eb, [(sec[r0 << eb: r1 << eb].copy(), c, d, pr) for c, d, pr in ents])
+    ev = shard.sharded_evmap(to_t(part))
+    q.put((rank, r0, r1, as_u(z).reshape(-1, 3).copy(), ev))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_row_sharded_z_and_evmap_equal_single_process(world, orc):
+    n = 96 * world
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000) + world * 11
+    procs = [ctx.Process(target=_z_ev_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    num = orc.fill(3 * n, 0x5EED0F01).reshape(n, 3); den = orc.fill(3 * n, 0x5EED0F02).reshape(n, 3)
+    z = orc.calculate_z(num, den)
+    eb, w = 1, 7
+    LEv = orc.fill(3 * n, 0x5EED0F03).reshape(n, 3); LpEv = orc.fill(3 * n, 0x5EED0F04).reshape(n, 3)
+    sec = orc.fill((n << eb) * w, 0x5EED0F05).reshape(n << eb, w)
+    ev = orc.evmap(LEv, LpEv, n, eb, [(sec, c, d, pr) for c, d, pr in [(0, 1, False), (3, 1, True), (4, 3, False), (6, 1, True)]])
+    for rank, r0, r1, zl, evl in res:
+        assert (zl == z[r0:r1]).all(), rank
+        assert evl == [[int(v) for v in e] for e in ev], rank

@@ -160,3 +160,70 @@ def halo_writeback(window, width, rows_local, halo_rows, cols, group=None):
     for a, c, nx in cols:
         w2[:nx, a:a + c] = recv[o:o + nx * c].view(nx, c); o += nx * c
     return window
+
+
+# ------------------------------------------------------------------------------------------ grand products and evaluations
+# calculateZ (polinomial.hpp:586-607) is an exclusive prefix product over the rows; row-sharded it is a local scan plus ONE
+# all-gather of a single Fp^3 element per rank.  evmap (starks.cpp:556-669) is a sum over the rows: local partial sums plus
+# one all-gather of nev x 3 words.  Field arithmetic on the handful of exchanged elements is done on the host (Python ints).
+P = 0xFFFFFFFF00000001
+
+
+def _mul3(a, b):
+    a0, a1, a2 = a; b0, b1, b2 = b
+    return [(a0 * b0 + a1 * b2 + a2 * b1) % P, (a0 * b1 + a1 * b0 + a1 * b2 + a2 * b1 + a2 * b2) % P, (a0 * b2 + a2 * b0 + a1 * b1 + a2 * b2) % P]
+
+
+def _inv3(a):
+    # solve a * x = 1: multiplication by a is a 3x3 matrix over Fp in the basis 1, x, x^2 (x^3 = x + 1)
+    a0, a1, a2 = a
+    m = [[a0, a2, a1], [a1, (a0 + a2) % P, (a1 + a2) % P], [a2, a1, (a0 + a2) % P]]
+    rhs = [1, 0, 0]
+    for c in range(3):                                   # Gauss-Jordan mod p
+        piv = next(r for r in range(c, 3) if m[r][c] % P)
+        m[c], m[piv] = m[piv], m[c]; rhs[c], rhs[piv] = rhs[piv], rhs[c]
+        iv = pow(m[c][c], P - 2, P)
+        m[c] = [v * iv % P for v in m[c]]; rhs[c] = rhs[c] * iv % P
+        for r in range(3):
+            if r != c and m[r][c]:
+                f = m[r][c]
+                m[r] = [(v - f * w) % P for v, w in zip(m[r], m[c])]; rhs[r] = (rhs[r] - f * rhs[c]) % P
+    return rhs
+
+
+def sharded_calculate_z(num_local, den_local, calc_z, scale3, group=None):
+    """num_local / den_local: this rank's rows of the Fp^3 polynomials ([rows*3] tensors).  calc_z(num, den) -> local
+    exclusive product scan starting at 1 (xlp_dev_calculate_z); scale3(z, s) multiplies every element of z by the Fp^3
+    constant s in place (one expression-program launch).  Returns the rank's rows of the global z."""
+    z = calc_z(num_local, den_local)
+    rows = z.numel() // 3
+    as_int = lambda t: [int(v) & 0xFFFFFFFFFFFFFFFF for v in t.cpu().tolist()]
+    last_z, last_n, last_d = as_int(z[-3:]), as_int(num_local[-3:]), as_int(den_local[-3:])
+    total = _mul3(_mul3(last_z, last_n), _inv3(last_d))            # product of this rank's ratios
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return z
+    mine = torch.tensor([v if v < (1 << 63) else v - (1 << 64) for v in total], dtype=torch.int64)
+    allt = [torch.empty(3, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(allt, mine, group=group)
+    prefix = [1, 0, 0]
+    for r in range(dist.get_rank(group)):
+        prefix = _mul3(prefix, [int(v) & 0xFFFFFFFFFFFFFFFF for v in allt[r].tolist()])
+    if prefix != [1, 0, 0]:
+        scale3(z, prefix)
+    return z
+
+
+def sharded_evmap(partial_evals, group=None):
+    """partial_evals: [nev*3] tensor = this rank's evmap over ITS rows (xlp_dev_evmap on the local windows of LEv / LpEv and
+    of the extended sections).  Returns the evaluations (list of nev [3]-lists): the field sum over ranks."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    parts = [partial_evals.cpu()]
+    if world > 1:
+        parts = [torch.empty_like(parts[0]) for _ in range(world)]
+        dist.all_gather(parts, partial_evals.cpu().contiguous(), group=group)
+    acc = [0] * partial_evals.numel()
+    for t in parts:
+        for i, v in enumerate(t.tolist()):
+            acc[i] = (acc[i] + (int(v) & 0xFFFFFFFFFFFFFFFF)) % P
+    return [acc[i:i + 3] for i in range(0, len(acc), 3)]
