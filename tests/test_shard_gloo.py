@@ -197,3 +197,48 @@ def test_row_sharded_z_and_evmap_equal_single_process(world, orc):
     for rank, r0, r1, zl, evl in res:
         assert (zl == z[r0:r1]).all(), rank
         assert evl == [[int(v) for v in e] for e in ev], rank
+
+
+def _h1h2_worker(rank, world, port, n, dim, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import gl_oracle as orc
+    from xlayer_prover_amd import shard
+    as_u = lambda t: t.numpy().view(np.uint64)
+    to_t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64).reshape(-1))
+    base = orc.fill(40 * dim, 3).reshape(40, dim)
+    rng = np.random.default_rng(5)
+    t = base[np.sort(rng.integers(0, 40, n))]; f = t[rng.integers(0, n, n)]
+    r0, r1 = shard.row_range(n, world, rank)
+
+    def h1h2(ff, tt):
+        a, b = orc.calculate_h1h2(as_u(ff), as_u(tt), dim)
+        return to_t(a), to_t(b)
+    h1, h2 = shard.sharded_h1h2(to_t(f[r0:r1]), to_t(t[r0:r1]), dim, h1h2)
+    q.put((rank, r0, r1, as_u(h1).copy(), as_u(h2).copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dim", [(2, 1), (4, 3)])
+def test_row_sharded_h1h2_equals_single_process(world, dim, orc):
+    n = 64 * world
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000) + world * 17 + dim
+    procs = [ctx.Process(target=_h1h2_worker, args=(r, world, port, n, dim, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    base = orc.fill(40 * dim, 3).reshape(40, dim)
+    rng = np.random.default_rng(5)
+    t = base[np.sort(rng.integers(0, 40, n))]; f = t[rng.integers(0, n, n)]
+    h1, h2 = orc.calculate_h1h2(f, t, dim)
+    h1, h2 = np.asarray(h1).reshape(n, dim), np.asarray(h2).reshape(n, dim)
+    for rank, r0, r1, a, b in res:
+        assert (a.reshape(-1, dim) == h1[r0:r1]).all() and (b.reshape(-1, dim) == h2[r0:r1]).all(), rank

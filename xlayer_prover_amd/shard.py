@@ -227,3 +227,21 @@ def sharded_evmap(partial_evals, group=None):
         for i, v in enumerate(t.tolist()):
             acc[i] = (acc[i] + (int(v) & 0xFFFFFFFFFFFFFFFF)) % P
     return [acc[i:i + 3] for i in range(0, len(acc), 3)]
+
+
+def sharded_h1h2(f_local, t_local, dim, h1h2, group=None):
+    """calculateH1H2 (polinomial.hpp:349-585) is a global sort-merge of f into t; its inputs are small next to the trace
+    (2 x N x dim words per lookup: 400 MB for an ext-3 lookup at N = 2^23), so every rank all-gathers f and t, runs the
+    full xlp_dev_calculate_h1h2 (2.5 ms at that size) and keeps its own rows of h1 / h2: two all-gathers per lookup
+    instead of a distributed sort.  h1h2(f, t) -> (h1, h2) on the full vectors."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return h1h2(f_local, t_local)
+    rank = dist.get_rank(group)
+    fs = [torch.empty_like(f_local) for _ in range(world)]
+    ts = [torch.empty_like(t_local) for _ in range(world)]
+    dist.all_gather(fs, f_local.contiguous(), group=group)
+    dist.all_gather(ts, t_local.contiguous(), group=group)
+    h1, h2 = h1h2(torch.cat(fs), torch.cat(ts))
+    rows = f_local.numel() // dim
+    return h1[rank * rows * dim:(rank + 1) * rows * dim].clone(), h2[rank * rows * dim:(rank + 1) * rows * dim].clone()
