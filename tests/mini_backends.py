@@ -51,6 +51,10 @@ class OracleBackend:
     def transpose3(self, pol2, n, tbits): return self.o.transpose3(pol2, n, tbits).reshape(-1)
     def perm(self, st): return self.o.perm(np.array(st, np.uint64))
     def proof(self, src, nodes, w, h, idx): return _merkle_proof_host(src, nodes, w, h, idx)
+    def to_torch(self, a):
+        import torch
+        return torch.from_numpy(a.view(np.int64))
+    def from_torch(self, t): return t.contiguous().numpy().view(np.uint64)
 
 
 class GpuBackend:
@@ -73,9 +77,9 @@ class GpuBackend:
     def h1h2(self, h1, h2, f, t, n, dim): self.x.dev_calculate_h1h2(h1, h2, f, t, n, dim)
     def calc_z(self, z, num, den, n): self.x.dev_calculate_z(z, num, den, n)
     def expr_run(self, prog, bufs, nc, nc2, row0, nrows):
-        if id(prog) not in self.progs:
-            self.progs[id(prog)] = self.x.ExprProgram(prog.code, prog.ntmp1, prog.ntmp3)
-        self.progs[id(prog)].run(self.x.steps_params(n_const_pols=nc, n_const_pols_2ns=nc2, **bufs), row0, nrows)
+        if id(prog) not in self.progs or self.progs[id(prog)][0] is not prog:
+            self.progs[id(prog)] = (prog, self.x.ExprProgram(prog.code, prog.ntmp1, prog.ntmp3))
+        self.progs[id(prog)][1].run(self.x.steps_params(n_const_pols=nc, n_const_pols_2ns=nc2, **bufs), row0, nrows)
     def geometric(self, n, dim, first, ratio):
         out = self.zeros(n * dim); self.x.dev_geometric(out, n, dim, np.array(first, np.uint64), np.array(ratio, np.uint64)); return out
     def x_div(self, x, xi, n):
@@ -89,6 +93,8 @@ class GpuBackend:
     def transpose3(self, pol2, n, tbits):
         out = self.zeros(3 * n); self.x.dev_transpose3(out, pol2, n, tbits); return out
     def perm(self, st): return self.x.perm(np.array(st, np.uint64))
+    def to_torch(self, a): return a
+    def from_torch(self, t): return t.contiguous()
     def proof(self, src, nodes, w, h, idx):
         # MerkleTreeGL::getGroupProof (merkleTreeGL.cpp:12-35): only the row and log2(h) sibling nodes leave the GPU
         row = [int(v) for v in self.x.to_np(src[idx * w:(idx + 1) * w])]

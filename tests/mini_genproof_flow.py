@@ -207,6 +207,39 @@ def _inv(a): return pow(a, P - 2, P)
 def _mul3s(a, s): return [x * s % P for x in a]
 
 
+def fri_prove(B, tr, f_2ns, fri_steps, nqueries, shift, open_step0):
+    """FRIProve::prove (friProve.cpp:5-190) on the full FRI polynomial; open_step0(ys) returns, per query, the opened rows +
+    sibling paths of the five step-0 trees (friProve.cpp:150-177)."""
+    res = {"roots": [], "queries": None}
+    pol = f_2ns; bits = fri_steps[0]; sinv = _inv(shift)
+    trees = []
+    for si, nb in enumerate(fri_steps):
+        red = bits - nb
+        x = tr.get_field()
+        pol2 = B.fri_fold(pol, bits, red, x, sinv)
+        if si < len(fri_steps) - 1:
+            ng = 1 << fri_steps[si + 1]; gs = (1 << nb) // ng
+            aux = B.transpose3(pol2, 1 << nb, fri_steps[si + 1])
+            nodes = B.merkle(aux, gs * 3, ng)
+            trees.append((aux, nodes, gs * 3, ng))
+            r = B.root(nodes, ng); res["roots"].append(r); tr.put(r)
+        else:
+            fin = B.to_host(pol2)[: 3 << nb]
+            res["finalPol"] = [int(v) for v in fin]; tr.put(res["finalPol"])
+        pol = pol2; bits = nb
+        for _ in range(red):
+            sinv = sinv * sinv % P
+    ys = tr.get_permutations(nqueries, fri_steps[0])
+    res["queries"] = ys
+    res["s0"] = open_step0(ys)
+    res["si"] = []
+    idx = ys
+    for si, (aux, nodes, w, ng) in enumerate(trees):
+        idx = [y % ng for y in idx]
+        res["si"].append([B.proof(aux, nodes, w, ng, y) for y in idx])
+    return res
+
+
 def prove(B, nbits, fri_steps, nqueries, seed=1, timers=None, debug=False):
     """B: backend (see tests/test_mini_genproof.py).  Returns a dict of everything a verifier would read."""
     import time
@@ -319,37 +352,9 @@ def prove(B, nbits, fri_steps, nqueries, seed=1, timers=None, debug=False):
     timed("STEP_5_XDIVXSUB", xdiv)
     timed("STEP_5_CALCULATE_EXPS", lambda: run("step52ns", NE))
     # ---- FRI (friProve.cpp:5-190)
-    def fri():
-        res = {"roots": [], "queries": None}
-        pol = f_2ns; bits = fri_steps[0]; sinv = _inv(shift)
-        trees = []
-        for si, nb in enumerate(fri_steps):
-            red = bits - nb
-            x = tr.get_field()
-            pol2 = B.fri_fold(pol, bits, red, x, sinv)
-            if si < len(fri_steps) - 1:
-                ng = 1 << fri_steps[si + 1]; gs = (1 << nb) // ng
-                aux = B.transpose3(pol2, 1 << nb, fri_steps[si + 1])
-                nodes = B.merkle(aux, gs * 3, ng)
-                trees.append((aux, nodes, gs * 3, ng))
-                r = B.root(nodes, ng); res["roots"].append(r); tr.put(r)
-            else:
-                fin = B.to_host(pol2)[: 3 << nb]
-                res["finalPol"] = [int(v) for v in fin]; tr.put(res["finalPol"])
-            pol = pol2; bits = nb
-            for _ in range(red):
-                sinv = sinv * sinv % P
-        ys = tr.get_permutations(nqueries, fri_steps[0])
-        res["queries"] = ys
-        # opened rows + sibling paths of the 5 step-0 trees and of every FRI tree (friProve.cpp:150-177)
-        step0 = [(sec("cm1_2ns"), nodes1, W1), (sec("cm2_2ns"), nodes2, W2), (sec("cm3_2ns"), nodes3, W3), (sec("cm4_2ns"), nodes4, W4), (const_2ns, nodesC, WC)]
-        res["s0"] = [[B.proof(src, nd, w, NE, y) for (src, nd, w) in step0] for y in ys]
-        res["si"] = []
-        idx = ys
-        for si, (aux, nodes, w, ng) in enumerate(trees):
-            idx = [y % ng for y in idx]
-            res["si"].append([B.proof(aux, nodes, w, ng, y) for y in idx])
-        return res
+    step0 = [(sec("cm1_2ns"), nodes1, W1), (sec("cm2_2ns"), nodes2, W2), (sec("cm3_2ns"), nodes3, W3), (sec("cm4_2ns"), nodes4, W4), (const_2ns, nodesC, WC)]
+    open_step0 = lambda ys: [[B.proof(src, nd, w, NE, y) for (src, nd, w) in step0] for y in ys]
+    fri = lambda: fri_prove(B, tr, f_2ns, fri_steps, nqueries, shift, open_step0)
     out["fri"] = timed("STEP_FRI", fri)
     out["verkey"] = verkey
     if debug:

@@ -51,6 +51,35 @@ def test_mini_genproof_gpu_equals_oracle(orc, nbits, steps, nq):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nbits,steps,nq,coll", [(6, [7, 4], 5, False), (10, [11, 7, 4], 12, True)])
+def test_sharded_genproof_on_one_gpu_equals_oracle(orc, nbits, steps, nq, coll):
+    """the multi-GPU form of the flow (tests/mini_genproof_sharded.py: windows with halo rows, rows<->columns exchanges,
+    cap tree, partial evmap ...) on one GPU; with coll=True the exchanges go through RCCL in a world of one rank.
+    The world-2 / world-4 runs of the same code are in tests/test_shard_gloo.py (CPU, gloo)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from xlayer_prover_amd import capi
+    from tests import mini_genproof_sharded as sh
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    capi.init(0); capi.use_torch_stream()
+    exp = flow.prove(OracleBackend(orc), nbits, steps, nq, seed=nbits)
+    if coll:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29637")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        got = sh.prove_sharded(GpuBackend(capi), nbits, steps, nq, seed=nbits, collectives=coll)
+    finally:
+        if coll:
+            dist.destroy_process_group()
+    for k in exp:
+        assert got[k] == exp[k], k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nbits,steps,nq", [(6, [7, 4], 5), (10, [11, 7, 4], 12)])
 def test_cpp_starks_genproof_equals_flow_and_verifies(orc, tmp_path, nbits, steps, nq):
     """The C++ GPU-resident `Starks::genProof` mirror (host/starks.hpp: StarkInfo-driven, starks.cpp:9-404 stage for stage)

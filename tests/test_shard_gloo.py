@@ -242,3 +242,41 @@ def test_row_sharded_h1h2_equals_single_process(world, dim, orc):
     h1, h2 = np.asarray(h1).reshape(n, dim), np.asarray(h2).reshape(n, dim)
     for rank, r0, r1, a, b in res:
         assert (a.reshape(-1, dim) == h1[r0:r1]).all() and (b.reshape(-1, dim) == h2[r0:r1]).all(), rank
+
+
+def _genproof_worker(rank, world, port, nbits, fri_steps, nq, seed, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import gl_oracle as orc
+    from tests import mini_backends as mb, mini_genproof_sharded as sh
+    out = sh.prove_sharded(mb.OracleBackend(orc), nbits, fri_steps, nq, seed=seed)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_genproof_equals_single_process_proof(world, orc):
+    """the whole toy genProof (commit, lookup, grand product, quotient, evaluations, FRI, queries) row-sharded over `world`
+    ranks yields the single-process proof bit for bit, on every rank, and the independent verifier accepts it"""
+    from tests import mini_backends as mb, mini_genproof_flow as flow, mini_verifier
+    nbits, fri_steps, nq, seed = 7, [8, 5, 3], 8, 11
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000) + world * 13
+    procs = [ctx.Process(target=_genproof_worker, args=(r, world, port, nbits, fri_steps, nq, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    exp = flow.prove(mb.OracleBackend(orc), nbits, fri_steps, nq, seed=seed)
+    owners = {y // ((1 << (nbits + 1)) // world) for y in exp["fri"]["queries"]}
+    assert len(owners) > 1                                             # queries really are opened by different ranks
+    for rank, out in res:
+        for k in exp:
+            assert out[k] == exp[k], (rank, k)
+    mini_verifier.verify(orc, res[0][1], nbits, fri_steps, nq, mb.gl_w)

@@ -62,17 +62,54 @@ def _all_to_all_gloo(recv, send, group):
         r.wait()
 
 
-def assemble_root(sub_root, hash_pairs, group=None):
-    """sub_root: int64 tensor [4] = root of this rank's row range.  Returns (root[4], caps[G,4]).
-    hash_pairs(nodes[2k,4]) -> [k,4] computes perm(left|right|0^4)[0..3] per pair."""
+def rows_to_columns(local, nrows, group=None):
+    """inverse of columns_to_rows.  local: [h / G, ncols] (all columns of this rank's rows) -> [h, wc_local] (this rank's
+    columns of all rows): the layout the per-column LDE wants.  One all-to-all."""
     world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    per, ncols = local.shape
+    assert per * world == nrows
+    c0, c1 = col_range(ncols, world, rank)
+    send = [local[:, col_range(ncols, world, p)[0]:col_range(ncols, world, p)[1]].contiguous() for p in range(world)]
+    recv = [torch.empty((per, c1 - c0), dtype=local.dtype, device=local.device) for _ in range(world)]
+    dist.all_to_all(recv, send, group=group) if dist.get_backend(group) != "gloo" else _all_to_all_gloo(recv, send, group)
+    return torch.cat(recv, dim=0).contiguous()
+
+
+def cap_tree(sub_root, hash_pairs, group=None):
+    """sub_root: int64 tensor [4] = root of this rank's row range.  Returns the levels of the tree over the G sub-roots,
+    [caps[G,4], [G/2,4], ..., root[1,4]]; every rank holds all of them (32 bytes per rank exchanged).
+    hash_pairs(nodes[2k,4]) -> [k,4] computes perm(left|right|0^4)[0..3] per pair."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return [sub_root.view(1, 4).clone()]
     caps = [torch.empty_like(sub_root) for _ in range(world)]
     dist.all_gather(caps, sub_root.contiguous(), group=group)
-    level = torch.stack(caps)                       # [G, 4] in rank order == node order
-    top = level
-    while top.shape[0] > 1:
-        top = hash_pairs(top)
-    return top[0], level
+    levels = [torch.stack(caps)]                    # [G, 4] in rank order == node order
+    while levels[-1].shape[0] > 1:
+        levels.append(hash_pairs(levels[-1]))
+    return levels
+
+
+def assemble_root(sub_root, hash_pairs, group=None):
+    """Returns (root[4], caps[G,4]) of cap_tree."""
+    levels = cap_tree(sub_root, hash_pairs, group)
+    return levels[-1][0], levels[0]
+
+
+def sharded_merkle_proof(idx, rows_local, local_proof, levels, rank):
+    """Sibling path of global row idx in a row-sharded tree.  The owner (idx // rows_local) returns (row, siblings):
+    local_proof(idx % rows_local) -> (row, siblings inside the rank's sub-tree), followed by the siblings on the cap tree
+    (cap_tree levels, replicated).  Other ranks return None.  MerkleTreeGL::getGroupProof (merkleTreeGL.cpp:12-35)."""
+    owner = idx // rows_local
+    if owner != rank:
+        return None
+    row, sib = local_proof(idx % rows_local)
+    i = owner
+    for lvl in levels[:-1]:
+        sib = sib + [[int(v) & 0xFFFFFFFFFFFFFFFF for v in lvl[i ^ 1].tolist()]]
+        i //= 2
+    return row, sib
 
 
 def gpu_hash_pairs(nodes):
@@ -191,6 +228,20 @@ def _inv3(a):
     return rhs
 
 
+def _all_gather_small(t_cpu, group=None):
+    """all-gather of a few words held on the host: RCCL moves device memory only, so the words take a round trip through
+    the rank's GPU under the nccl backend (gloo sends them as they are)."""
+    world = dist.get_world_size(group)
+    if dist.get_backend(group) == "nccl":
+        t = t_cpu.cuda()
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t, group=group)
+        return [p.cpu() for p in parts]
+    parts = [torch.empty_like(t_cpu) for _ in range(world)]
+    dist.all_gather(parts, t_cpu.contiguous(), group=group)
+    return parts
+
+
 def sharded_calculate_z(num_local, den_local, calc_z, scale3, group=None):
     """num_local / den_local: this rank's rows of the Fp^3 polynomials ([rows*3] tensors).  calc_z(num, den) -> local
     exclusive product scan starting at 1 (xlp_dev_calculate_z); scale3(z, s) multiplies every element of z by the Fp^3
@@ -204,8 +255,7 @@ def sharded_calculate_z(num_local, den_local, calc_z, scale3, group=None):
     if world == 1:
         return z
     mine = torch.tensor([v if v < (1 << 63) else v - (1 << 64) for v in total], dtype=torch.int64)
-    allt = [torch.empty(3, dtype=torch.int64) for _ in range(world)]
-    dist.all_gather(allt, mine, group=group)
+    allt = _all_gather_small(mine, group)
     prefix = [1, 0, 0]
     for r in range(dist.get_rank(group)):
         prefix = _mul3(prefix, [int(v) & 0xFFFFFFFFFFFFFFFF for v in allt[r].tolist()])
@@ -220,8 +270,7 @@ def sharded_evmap(partial_evals, group=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     parts = [partial_evals.cpu()]
     if world > 1:
-        parts = [torch.empty_like(parts[0]) for _ in range(world)]
-        dist.all_gather(parts, partial_evals.cpu().contiguous(), group=group)
+        parts = _all_gather_small(partial_evals.cpu().contiguous(), group)
     acc = [0] * partial_evals.numel()
     for t in parts:
         for i, v in enumerate(t.tolist()):
