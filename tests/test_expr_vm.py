@@ -618,3 +618,26 @@ def test_expr_create_survives_malformed_programs():
                 p.codegen(os.path.join(d, "m.hip"))
             p.close()
     assert rejected > 50 and accepted > 10
+
+
+def test_zkevm_geometry_relocation_is_consistent():
+    """tools/zkevm_geometry.py: the packing rule reproduces the 11 section offsets recovered from the reference's step tables
+    (SURVEY 8a9), and the five converted programs relocated to a 2^10-row slab address only their own sections"""
+    from tests import expr_real as R
+    from tools import zkevm_geometry as G
+    G._check_real()
+    if not os.path.exists(os.path.join(R.REF_DIR, "zkevm.step42ns.xlpexpr")):
+        pytest.skip("converted reference programs not built (needs the reference tree at build time)")
+    progs, info = G.load(10)
+    L = G.layout(10)
+    assert info["nev"] == 1973 and info["npub"] == 44 and max(info["n_const"], info["n_const2"]) == 234
+    for step, (code, _, _) in progs.items():
+        n_dom = 1 << (11 if step.endswith("2ns") else 10)
+        for _, _, kind, dim, q in R.operands(code):
+            if kind in (E.K_POLS, E.K_POLS_PRIME):
+                off = int(code[q]); stride = int(code[q + (1 if kind == E.K_POLS else 3)])
+                name = [s for s, _, _ in G.SECTIONS if L[s][0] <= off][-1]
+                assert stride == L[name][1] and off - L[name][0] + dim <= stride, (step, name)
+                assert L[name][2] >= n_dom                       # a base-domain step never reads an extended section and vice versa
+            if kind in (E.K_POLS_PRIME, E.K_CONST_PRIME, E.K_CONST2NS_PRIME):
+                assert int(code[q + 2]) == n_dom, step

@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""ALL stages of Starks::genProof (src/starkpil/starks.cpp:9-404) in ONE run at the fork-9 zkEVM geometry, GPU-resident on
+one MI355X: the five converted reference step programs (oracle/_ref/chelpers/zkevm.*.xlpexpr, relocated to a slab of
+2^log_n rows by tools/zkevm_geometry.py -- the real 2^23-row slab is 295 GB and does not fit one GPU, 2^22 rows is 148 GB),
+committed widths 751 / 168 / 408 / 6, 234 constant polynomials, 1973 evaluations, the reference's stage order and timer
+names.  BASELINE.json configs[3] stand-in: the witness is synthetic (no executor / input archive offline), and so are the
+things only the missing starkinfo would tell (which tmpExp columns feed H1H2 / Z: --lookups, --zs; FRI steps; nQueries).
+    python tools/build_expr_plugins.py --geometry 22      # once, needs hipcc (here), plugins travel to the GPU box
+    python tools/bench_zkevm_genproof.py [--log-n 22] [--no-jit]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from tests import expr_real as R
+from tests.mini_genproof_flow import HostTranscript
+from tools import zkevm_geometry as G
+from xlayer_prover_amd import capi
+from xlayer_prover_amd import expr as E
+
+P = 0xFFFFFFFF00000001
+W32 = 7277203076849721926
+
+
+def gl_w(n):
+    w = W32
+    for _ in range(32 - n):
+        w = w * w % P
+    return w
+
+
+def inv(a): return pow(a, P - 2, P)
+
+
+def evmap_from_step52ns(code, L, const_2ns, nconst, pols):
+    """which column each evals[k] belongs to: the `col - evals[k]` subtractions of the FRI-polynomial program
+    (starks.cpp:556-669 reads the same list from starkinfo.evMap).  A column's second evaluation is its next-row one."""
+    ents, seen = {}, {}
+    for op, slots in decode(code):
+        (dk, dd, dp), (ak, ad, apar), (bk, bd, bpar) = slots
+        if op != E.SUB or bk != E.K_EVAL:
+            continue
+        if ak == E.K_POLS:
+            off = apar[0]
+            name = [s for s, _, _ in G.SECTIONS if L[s][0] <= off][-1]
+            t = (pols[L[name][0]:L[name][0] + L[name][1] * L[name][2]], L[name][1], off - L[name][0], ad)
+            key = ("p", off)
+        elif ak == E.K_CONST2NS:
+            t = (const_2ns, nconst, apar[0], ad); key = ("c", apar[0])
+        else:
+            continue
+        seen[key] = seen.get(key, 0) + 1
+        ents[bpar[0]] = t + (seen[key] > 1,)
+    return [ents[k] for k in sorted(ents)], sorted(ents)
+
+
+def decode(code):
+    """-> (op, [(kind, dim, params) for dst, a, b]) per instruction"""
+    ops = list(R.operands(code))
+    for i in range(0, len(ops), 3):
+        slots = [(kind, dim, [int(v) for v in code[q:q + E.KIND_PARAMS[kind]]]) for _, _, kind, dim, q in ops[i:i + 3]]
+        yield int(code[ops[i][4] - 1]) & 255, slots
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log-n", type=int, default=22)
+    ap.add_argument("--fri-steps", default="")
+    ap.add_argument("--queries", type=int, default=128)
+    ap.add_argument("--lookups", type=int, default=28, help="H1H2 computations (cm2 = 168 columns = 28 x (h1, h2) in Fp^3)")
+    ap.add_argument("--zs", type=int, default=40, help="grand products (calculateZ calls); their z columns land in cm3")
+    ap.add_argument("--no-jit", action="store_true")
+    a = ap.parse_args()
+    ln = a.log_n
+    N, NE = 1 << ln, 1 << (ln + 1)
+    steps = [int(x) for x in a.fri_steps.split(",")] if a.fri_steps else [ln + 1] + [b for b in (ln - 4, ln - 9, ln - 13, ln - 17) if b >= 3]
+    capi.init(0); capi.use_torch_stream()
+    progs, info = G.load(ln)
+    L = G.layout(ln)
+    nconst = max(info["n_const"], info["n_const2"])
+    dev = "cuda"
+    i64 = torch.int64
+
+    def fill(cnt, seed):
+        t = torch.empty(cnt, dtype=i64, device=dev); capi.dev_fill(t, seed, 0); return t
+    pols = torch.empty(L["end"][0], dtype=i64, device=dev)
+
+    def sec(name):
+        o, w, rows = L[name]
+        return pols[o:o + w * rows]
+    W = {name: w for name, w, _ in G.SECTIONS}
+    # ---- setup (Starks ctor: constant polynomials, their extension and tree, x tables, ZhInv) -- not part of a proof
+    capi.dev_fill(sec("cm1_n"), 0x5EED0401, 0)                                      # the witness, resident
+    const_n = fill(N * nconst, 0x5EED0402)
+    const_2ns = torch.empty(NE * nconst, dtype=i64, device=dev)
+    capi.dev_extend(const_2ns, const_n, NE, N, nconst)
+    nodesC = torch.empty((2 * NE - 1) * 4, dtype=i64, device=dev)
+    capi.dev_merkle(nodesC, const_2ns, nconst, NE)
+    w_n, w_ne, shift = gl_w(ln), gl_w(ln + 1), 7
+    x_n = torch.empty(N, dtype=i64, device=dev); capi.dev_geometric(x_n, N, 1, [1], [w_n])
+    x_2ns = torch.empty(NE, dtype=i64, device=dev); capi.dev_geometric(x_2ns, NE, 1, [shift], [w_ne])
+    sn = pow(shift, N, P)
+    zi = capi.from_np(np.array([inv((sn * pow(gl_w(1), i, P) - 1) % P) for i in range(2)], np.uint64))
+    xdx = torch.empty(NE * 3, dtype=i64, device=dev); xdwx = torch.empty(NE * 3, dtype=i64, device=dev)
+    challenges = np.zeros(8 * 3, np.uint64)
+    publics = np.arange(1, info["npub"] + 1, dtype=np.uint64)
+    nev = info["nev"]
+    evals_d = torch.zeros(3 * nev, dtype=i64, device=dev)
+    vm, mode = {}, {}
+    for s, (code, n1, n3) in progs.items():
+        vm[s] = capi.ExprProgram(code, n1, n3)
+        so = os.path.join(R.REF_DIR, f"zkevm.{s}.geo{ln}.so")
+        mode[s] = "interpreter"
+        if not a.no_jit and os.path.exists(so):
+            vm[s].attach(so); mode[s] = "compiled"
+    ents, ev_ids = evmap_from_step52ns(progs["step52ns"][0], L, const_2ns, nconst, pols)
+    ev_arr = capi.evmap_entries(ents)
+    ev_out = torch.zeros(3 * len(ents), dtype=i64, device=dev)
+    ev_index = torch.tensor([3 * k + j for k in ev_ids for j in range(3)], device=dev)
+    # plookup inputs the missing starkinfo would select from tmpExp_n: every f value must occur in t
+    t_pl = fill(3 * N, 0x5EED0403)
+    f_pl = t_pl.view(N, 3)[torch.randint(0, N, (N,), device=dev, generator=torch.Generator(device=dev).manual_seed(1))].contiguous().view(-1)
+    h1 = torch.empty(3 * N, dtype=i64, device=dev); h2 = torch.empty(3 * N, dtype=i64, device=dev)
+    num = torch.empty(3 * N, dtype=i64, device=dev); den = torch.empty(3 * N, dtype=i64, device=dev); z = torch.empty(3 * N, dtype=i64, device=dev)
+    trees = {k: torch.empty((2 * NE - 1) * 4, dtype=i64, device=dev) for k in ("cm1_2ns", "cm2_2ns", "cm3_2ns", "cm4_2ns")}
+    LEv = torch.empty(3 * N, dtype=i64, device=dev); LpEv = torch.empty(3 * N, dtype=i64, device=dev)
+    qq1 = torch.empty(3 * NE, dtype=i64, device=dev); qq2 = torch.empty(6 * NE, dtype=i64, device=dev)
+    torch.cuda.synchronize()
+    print(f"resident: {torch.cuda.memory_allocated() / 1e9:.1f} GB (torch) ; modes {mode}", flush=True)
+
+    def run(step, nrows):
+        sp = capi.steps_params(n_const_pols=nconst, n_const_pols_2ns=nconst, pols=pols, const_pols=const_n, const_pols_2ns=const_2ns,
+                               challenges=capi.from_np(challenges), public_inputs=capi.from_np(publics), evals=evals_d, x_n=x_n, x_2ns=x_2ns,
+                               zi=zi, x_div_x_sub_xi=xdx, x_div_x_sub_wxi=xdwx, q_2ns=sec("q_2ns"), f_2ns=sec("f_2ns"))
+        vm[step].run(sp, 0, nrows)
+
+    timers = {}
+    fri_roots = []
+
+    def timed(name, fn):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize()
+        timers[name] = timers.get(name, 0.0) + time.perf_counter() - t0
+        return r
+
+    def commit(i, a_n, a_2ns):
+        timed(f"STARK_STEP_{i}_LDE", lambda: capi.dev_extend(sec(a_2ns), sec(a_n), NE, N, W[a_n]))
+        timed(f"STARK_STEP_{i}_MERKLETREE", lambda: capi.dev_merkle(trees[a_2ns], sec(a_2ns), W[a_2ns], NE))
+        root = [int(v) for v in capi.to_np(trees[a_2ns][-4:])]
+        tr.put(root)
+        return root
+
+    for rep in range(2):                                       # pass 0 warms allocators / code objects; pass 1 is reported
+        timers.clear()
+        tr = HostTranscript(capi.perm)
+        tr.put([int(v) for v in capi.to_np(nodesC[-4:])]); tr.put(publics)
+        torch.cuda.synchronize(); t_proof = time.perf_counter()
+        roots = [commit(1, "cm1_n", "cm1_2ns")]
+        # ---- 2
+        challenges[0:3] = tr.get_field(); challenges[3:6] = tr.get_field()
+        timed("STARK_STEP_2_CALCULATE_EXPS", lambda: run("step2prev", N))
+        cm2 = sec("cm2_n").view(N, W["cm2_n"])
+
+        def lookups():
+            for k in range(a.lookups):
+                capi.dev_calculate_h1h2(h1, h2, f_pl, t_pl, N, 3)
+                cm2[:, 6 * k:6 * k + 3] = h1.view(N, 3); cm2[:, 6 * k + 3:6 * k + 6] = h2.view(N, 3)
+        timed("STARK_STEP_2_CALCULATEH1H2", lookups)
+        roots.append(commit(2, "cm2_n", "cm2_2ns"))
+        # ---- 3
+        challenges[6:9] = tr.get_field(); challenges[9:12] = tr.get_field()
+        timed("STARK_STEP_3_CALCULATE_EXPS", lambda: run("step3prev", N))
+        tmpx = sec("tmpExp_n").view(N, W["tmpExp_n"]); cm3 = sec("cm3_n").view(N, W["cm3_n"])
+
+        def zs():
+            for k in range(a.zs):
+                c = (6 * k) % (W["tmpExp_n"] - 6)
+                num.view(N, 3).copy_(tmpx[:, c:c + 3]); den.view(N, 3).copy_(tmpx[:, c + 3:c + 6])
+                capi.dev_calculate_z(z, num, den, N)
+                cm3[:, 3 * k:3 * k + 3] = z.view(N, 3)
+        timed("STARK_STEP_3_CALCULATE_Z", zs)
+        timed("STARK_STEP_3_CALCULATE_EXPS_2", lambda: run("step3", N))
+        roots.append(commit(3, "cm3_n", "cm3_2ns"))
+        # ---- 4
+        challenges[12:15] = tr.get_field()
+        timed("STARK_STEP_4_CALCULATE_EXPS_2NS", lambda: run("step42ns", NE))
+
+        def q_poly():
+            capi.dev_ntt(qq1, sec("q_2ns"), NE, 3, inverse=True)
+            capi.dev_q_split(qq2, qq1, N, NE, 2, 3, pow(inv(shift), N, P))
+            capi.dev_ntt(sec("cm4_2ns"), qq2, NE, 6)
+        timed("STARK_STEP_4_CALCULATE_EXPS_2NS_INTT_MUL_NTT", q_poly)
+        timed("STARK_STEP_4_MERKLETREE", lambda: capi.dev_merkle(trees["cm4_2ns"], sec("cm4_2ns"), 6, NE))
+        roots.append([int(v) for v in capi.to_np(trees["cm4_2ns"][-4:])]); tr.put(roots[-1])
+        # ---- 5
+        xi = tr.get_field(); challenges[21:24] = xi
+        mul3s = lambda v, s: [x * s % P for x in v]
+
+        def lev():
+            capi.dev_geometric(LEv, N, 3, [1, 0, 0], mul3s(xi, inv(shift))); capi.dev_geometric(LpEv, N, 3, [1, 0, 0], mul3s(mul3s(xi, w_n), inv(shift)))
+            capi.dev_ntt(LEv, LEv, N, 3, inverse=True); capi.dev_ntt(LpEv, LpEv, N, 3, inverse=True)
+        timed("STARK_STEP_5_LEv_LpEv", lev)
+
+        def evmap():
+            capi.dev_evmap(ev_out, LEv, LpEv, N, 1, ev_arr)
+            evals_d[ev_index] = ev_out
+            return capi.to_np(ev_out)
+        ev = timed("STARK_STEP_5_EVMAP", evmap)
+        tr.put([int(v) for v in ev])
+        challenges[15:18] = tr.get_field(); challenges[18:21] = tr.get_field()
+
+        def xdiv():
+            capi.dev_x_div_x_sub_xi(xdx, x_2ns, xi, NE); capi.dev_x_div_x_sub_xi(xdwx, x_2ns, mul3s(xi, w_n), NE)
+        timed("STARK_STEP_5_XDIVXSUBXI", xdiv)
+        timed("STARK_STEP_5_CALCULATE_EXPS", lambda: run("step52ns", NE))
+
+        def fri():
+            pol = sec("f_2ns"); bits = steps[0]; sinv = inv(shift)
+            ftrees = []; fri_roots.clear()
+            for si, nb in enumerate(steps):
+                red = bits - nb
+                x = tr.get_field()
+                pol2 = torch.empty(3 << nb, dtype=i64, device=dev)
+                capi.dev_fri_fold(pol2, pol, bits, red, x, sinv)
+                if si < len(steps) - 1:
+                    ng = 1 << steps[si + 1]; gs = (1 << nb) // ng
+                    aux = torch.empty(3 << nb, dtype=i64, device=dev)
+                    capi.dev_transpose3(aux, pol2, 1 << nb, steps[si + 1])
+                    nodes = torch.empty((2 * ng - 1) * 4, dtype=i64, device=dev)
+                    capi.dev_merkle(nodes, aux, gs * 3, ng)
+                    ftrees.append((aux, nodes, gs * 3, ng))
+                    fri_roots.append([int(v) for v in capi.to_np(nodes[-4:])]); tr.put(fri_roots[-1])
+                else:
+                    fri_roots.append([int(v) for v in capi.to_np(pol2)][:6]); tr.put([int(v) for v in capi.to_np(pol2)])
+                pol = pol2; bits = nb
+                for _ in range(red):
+                    sinv = sinv * sinv % P
+            ys = tr.get_permutations(a.queries, steps[0])
+            opened = 0
+            for name in ("cm1_2ns", "cm2_2ns", "cm3_2ns", "cm4_2ns"):
+                opened += capi.dev_merkle_proofs(sec(name), trees[name], W[name], NE, ys).size
+            opened += capi.dev_merkle_proofs(const_2ns, nodesC, nconst, NE, ys).size
+            idx = ys
+            for aux, nodes, w, ng in ftrees:
+                idx = [y % ng for y in idx]
+                opened += capi.dev_merkle_proofs(aux, nodes, w, ng, idx).size
+            return opened
+        opened = timed("STARK_STEP_FRI", fri)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t_proof
+    out = {"workload": f"genProof, all stages, one run, zkEVM geometry at N=2^{ln} (widths 751/168/408/6, {nconst} const pols, {len(ents)} evaluations, "
+                       f"{a.lookups} lookups, {a.zs} grand products, FRI steps {steps}, {a.queries} queries), 1 GPU, synthetic witness",
+           "programs": mode, "resident_GB_torch": round(torch.cuda.memory_allocated() / 1e9, 1),
+           "timers_s": {k: round(v, 4) for k, v in timers.items()}, "sum_timed_s": round(sum(timers.values()), 4),
+           "genproof_wall_s": round(wall, 4), "proof_elements_opened": int(opened), "roots": roots,
+           "fri_roots_and_head_of_final_pol": fri_roots}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -20,18 +20,28 @@ def main():
     ap.add_argument("--parts", type=int, default=8)
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--full", action="store_true", help="full zkEVM domains instead of --log-rows: 2^23 rows for the *prev/step3 programs, 2^24 for the 2ns ones")
+    ap.add_argument("--geometry", type=int, default=0, help="log2 N: the five programs relocated to ONE zkEVM-geometry slab of 2^N rows "
+                    "(tools/zkevm_geometry.py, used by tools/bench_zkevm_genproof.py) -> zkevm.<step>.geo<N>.so")
     a = ap.parse_args()
     sizes = ["full"] if a.full else [int(x) for x in a.log_rows.split(",")]
+    geo = None
+    if a.geometry:
+        from tools import zkevm_geometry as G
+        geo, _ = G.load(a.geometry)
+        sizes = ["geo"]
     for size in sizes:
         for step in a.steps.split(","):
-            lr = (24 if step.endswith("2ns") else 23) if size == "full" else size
+            lr = (24 if step.endswith("2ns") else 23) if size in ("full", "geo") else size
             src = os.path.join(R.REF_DIR, f"zkevm.{step}.xlpexpr")
-            name = f"zkevm.{step}.n{lr}"
+            name = f"zkevm.{step}.geo{a.geometry}" if geo else f"zkevm.{step}.n{lr}"
             so = os.path.join(R.REF_DIR, name + ".so")
             if not os.path.exists(src):
                 print("missing", src); continue
             code, ntmp1, ntmp3 = R.read_program(src)
-            code, _ = R.shrink(code, 1 << lr)
+            if geo:
+                code = geo[step][0]
+            else:
+                code, _ = R.shrink(code, 1 << lr)
             p = capi.ExprProgram(code, ntmp1, ntmp3)
             # regenerate the launcher text (cheap) and rebuild only if it changed: its signature covers the whole
             # compiled program, so a change of the library's compile step invalidates the plugin too

@@ -1,0 +1,81 @@
+"""The fork-9 zkEVM slab geometry (section offsets recovered from the arguments of the reference's generated
+step tables, src/starkpil/zkevm/chelpers/zkevm.chelpers.step*.parser.hpp) and a relocation of the converted programs to the
+same layout with fewer rows -- so that all five steps address ONE consistent slab that fits a single GPU.
+Benchmarks / tests only."""
+import numpy as np
+
+from tests import expr_real as R
+from xlayer_prover_amd import expr as E
+
+LOG_N_REAL = 23
+# (section, width, on the extended domain?) in slab order (stark_info.cpp mapOffsets order)
+SECTIONS = [("cm1_n", 751, 0), ("cm2_n", 168, 0), ("cm3_n", 408, 0), ("cm4_n", 6, 0), ("tmpExp_n", 389, 0),
+            ("cm1_2ns", 751, 1), ("cm2_2ns", 168, 1), ("cm3_2ns", 408, 1), ("cm4_2ns", 6, 1), ("q_2ns", 3, 1), ("f_2ns", 3, 1)]
+REAL_OFFSETS = {"cm1_n": 0, "cm2_n": 6299844608, "cm3_n": 7709130752, "cm4_n": 11131682816, "tmpExp_n": 11182014464,
+                "cm1_2ns": 14445182976, "cm2_2ns": 27044872192, "cm3_2ns": 29863444480, "cm4_2ns": 36708548608,
+                "q_2ns": 36809211904, "f_2ns": 36859543552, "end": 36909875200}
+
+
+def layout(log_n):
+    """section -> (offset, width, rows) for N = 2^log_n, same packing rule as the real slab"""
+    o, out = 0, {}
+    for name, w, ext in SECTIONS:
+        rows = 1 << (log_n + ext)
+        out[name] = (o, w, rows)
+        o += w * rows
+    out["end"] = (o, 0, 0)
+    return out
+
+
+def _check_real():
+    L = layout(LOG_N_REAL)
+    for k, v in REAL_OFFSETS.items():
+        assert L[k][0] == v, (k, L[k][0], v)
+
+
+def relocate(codes, log_n):
+    """codes: converted zkEVM programs (real 2^23-row addressing) -> ([codes for N = 2^log_n], info)"""
+    _check_real()
+    real, new = layout(LOG_N_REAL), layout(log_n)
+    bases = sorted((real[name][0], name) for name, _, _ in SECTIONS)
+
+    def move(off, stride):
+        name = [n for b, n in bases if b <= off][-1]
+        b, w, rows = real[name]
+        col = off - b
+        assert col < w and stride == w, (name, off, stride)
+        return new[name][0] + col
+
+    codes = [c.copy() for c in codes]
+    info = {"n_const": 1, "n_const2": 1, "nch": 1, "npub": 1, "nev": 1}
+    for code in codes:
+        for _, _, kind, dim, q in R.operands(code):
+            if kind == E.K_POLS:
+                code[q] = move(int(code[q]), int(code[q + 1]))
+            elif kind == E.K_POLS_PRIME:
+                code[q] = move(int(code[q]), int(code[q + 3]))
+            if kind in (E.K_POLS_PRIME, E.K_CONST_PRIME, E.K_CONST2NS_PRIME):
+                n_real = int(code[q + 2])
+                assert n_real in (1 << LOG_N_REAL, 1 << (LOG_N_REAL + 1)), n_real
+                code[q + 2] = n_real >> (LOG_N_REAL - log_n)
+            if kind in (E.K_CONST, E.K_CONST_PRIME):
+                info["n_const"] = max(info["n_const"], int(code[q]) + 1)
+            elif kind in (E.K_CONST2NS, E.K_CONST2NS_PRIME):
+                info["n_const2"] = max(info["n_const2"], int(code[q]) + 1)
+            elif kind == E.K_CHALLENGE:
+                info["nch"] = max(info["nch"], int(code[q]) + 1)
+            elif kind == E.K_PUBLIC:
+                info["npub"] = max(info["npub"], int(code[q]) + 1)
+            elif kind == E.K_EVAL:
+                info["nev"] = max(info["nev"], int(code[q]) + 1)
+    return codes, info
+
+
+STEPS = ("step2prev", "step3prev", "step3", "step42ns", "step52ns")
+
+
+def load(log_n):
+    import os
+    progs = [R.read_program(os.path.join(R.REF_DIR, f"zkevm.{s}.xlpexpr")) for s in STEPS]
+    codes, info = relocate([p[0] for p in progs], log_n)
+    return {s: (c, p[1], p[2]) for s, c, p in zip(STEPS, codes, progs)}, info
