@@ -641,3 +641,56 @@ def test_zkevm_geometry_relocation_is_consistent():
                 assert L[name][2] >= n_dom                       # a base-domain step never reads an extended section and vice versa
             if kind in (E.K_POLS_PRIME, E.K_CONST_PRIME, E.K_CONST2NS_PRIME):
                 assert int(code[q + 2]) == n_dom, step
+
+
+# ------------------------------------------------------------------------------- Horner chains -> dot products (expr_opt.py)
+OPT_PROGS = ["zkevm", "recursive1", "recursive2", "c12a", "recursivef"]
+
+
+def _opt52_case(orc, prog, n):
+    """-> (original code + temporaries, optimised row program, table program, n_ext, buffers, info) for <prog>.step52ns"""
+    from tests import expr_real as R
+    from xlayer_prover_amd import expr_opt
+    path = os.path.join(R.REF_DIR, f"{prog}.step52ns.xlpexpr")
+    if not os.path.exists(path):
+        pytest.skip("converted reference programs not built (needs the reference tree at build time)")
+    code, n1, n3 = R.read_program(path)
+    nch = 8
+    row, tab, n_ext, stats = expr_opt.horner_to_dot(code, n1, n3, nch)
+    assert stats["ext_mul_removed"] > 40 and row.ninstr < sum(1 for _ in E.decode(code))
+    (c0, c1), info = R.shrink_many([code, row.code], n)
+    bufs = R.buffers(lambda cnt, seed: orc.fill(cnt, seed), 11, n, info)
+    bufs["challenges"] = orc.fill(3 * nch, 99)
+    return (c0, n1, n3), (c1, row.ntmp1, row.ntmp3), tab, n_ext, nch, bufs, info
+
+
+@pytest.mark.parametrize("prog", OPT_PROGS)
+def test_horner_to_dot_equals_original_on_the_oracle(orc, prog):
+    """the rewritten FRI-polynomial program (powers of the challenges and the evaluation constants from a one-row table
+    program, base-field columns multiplied by extension constants) gives the values of the reference's program, bit for bit"""
+    n = 64
+    (c0, n1, n3), (c1, m1, m3), tab, n_ext, nch, b0, info = _opt52_case(orc, prog, n)
+    b1 = {k: v.copy() for k, v in b0.items()}
+    orc.expr_run(c0, n1, n3, b0, 0, n, info["n_const"], info["n_const2"])
+    ext = np.zeros(3 * n_ext, np.uint64); ext[:3 * nch] = b1["challenges"]
+    orc.expr_run(tab.code, tab.ntmp1, tab.ntmp3, {**b1, "pols": ext}, 0, 1)
+    b1["challenges"] = ext
+    orc.expr_run(c1, m1, m3, b1, 0, n, info["n_const"], info["n_const2"])
+    assert (b0["f_2ns"] == b1["f_2ns"]).all() and (b0["f_2ns"] != 0).all()
+    assert (b0["pols"] == b1["pols"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog,n", [("zkevm", 1 << 12), ("recursive2", 1000)])
+def test_horner_to_dot_on_the_gpu_equals_original_on_the_oracle(xlp, orc, prog, n):
+    (c0, n1, n3), (c1, m1, m3), tab, n_ext, nch, b0, info = _opt52_case(orc, prog, n)
+    dev = {k: xlp.from_np(v) for k, v in b0.items()}
+    ext = xlp.from_np(np.concatenate([b0["challenges"], np.zeros(3 * (n_ext - nch), np.uint64)]))
+    pt = xlp.ExprProgram(tab.code, tab.ntmp1, tab.ntmp3)
+    pt.run(xlp.steps_params(pols=ext, challenges=dev["challenges"], evals=dev["evals"]), 0, 1)
+    pr = xlp.ExprProgram(c1, m1, m3)
+    pr.run(xlp.steps_params(n_const_pols=info["n_const"], n_const_pols_2ns=info["n_const2"], **{**dev, "challenges": ext}), 0, n)
+    xlp.sync()
+    orc.expr_run(c0, n1, n3, b0, 0, n, info["n_const"], info["n_const2"])
+    assert (xlp.to_np(dev["f_2ns"]) == b0["f_2ns"]).all()
+    pt.close(); pr.close()

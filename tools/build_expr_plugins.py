@@ -28,18 +28,21 @@ def main():
     if a.geometry:
         from tools import zkevm_geometry as G
         geo, _ = G.load(a.geometry)
+        geo["step52ns_opt"] = G.load_opt52(a.geometry)[0]
         sizes = ["geo"]
+        if "step52ns" in a.steps.split(","):
+            a.steps += ",step52ns_opt"
     for size in sizes:
         for step in a.steps.split(","):
             lr = (24 if step.endswith("2ns") else 23) if size in ("full", "geo") else size
-            src = os.path.join(R.REF_DIR, f"zkevm.{step}.xlpexpr")
+            src = os.path.join(R.REF_DIR, f"zkevm.{step.replace('_opt', '')}.xlpexpr")
             name = f"zkevm.{step}.geo{a.geometry}" if geo else f"zkevm.{step}.n{lr}"
             so = os.path.join(R.REF_DIR, name + ".so")
             if not os.path.exists(src):
                 print("missing", src); continue
             code, ntmp1, ntmp3 = R.read_program(src)
             if geo:
-                code = geo[step][0]
+                code, ntmp1, ntmp3 = geo[step]
             else:
                 code, _ = R.shrink(code, 1 << lr)
             p = capi.ExprProgram(code, ntmp1, ntmp3)

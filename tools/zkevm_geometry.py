@@ -79,3 +79,16 @@ def load(log_n):
     progs = [R.read_program(os.path.join(R.REF_DIR, f"zkevm.{s}.xlpexpr")) for s in STEPS]
     codes, info = relocate([p[0] for p in progs], log_n)
     return {s: (c, p[1], p[2]) for s, c, p in zip(STEPS, codes, progs)}, info
+
+
+NCH = 8                                             # challenges of a STARK proof (starks.cpp: 0..7)
+
+
+def load_opt52(log_n):
+    """step52ns with its Horner chains turned into dot products (xlayer_prover_amd/expr_opt.py):
+    -> ((row code, ntmp1, ntmp3), table Program, number of extended-challenge entries)"""
+    from xlayer_prover_amd import expr_opt
+    progs, _ = load(log_n)
+    code, n1, n3 = progs["step52ns"]
+    row, tab, n_ext, _ = expr_opt.horner_to_dot(code, n1, n3, NCH)
+    return (row.code, row.ntmp1, row.ntmp3), tab, n_ext

@@ -77,3 +77,19 @@ class Program:
     @property
     def code(self):
         return np.array(self.words, dtype=np.uint64)
+
+
+def decode(code):
+    """uint64 program -> iterator of (op, dst, a, b) with Operand objects (b is None for COPY)"""
+    pc, n = 0, len(code)
+    while pc < n:
+        h = int(code[pc])
+        q = pc + 1
+        ops = []
+        for s in range(3):
+            kind, dim = (h >> (8 + 8 * s)) & 255, (h >> (32 + 2 * s)) & 3
+            cnt = KIND_PARAMS[kind]
+            ops.append(None if kind == K_NONE else Operand(kind, [int(v) for v in code[q:q + cnt]], dim))
+            q += cnt
+        yield h & 255, ops[0], ops[1], ops[2]
+        pc = q
