@@ -103,7 +103,7 @@ def programs(L):
     return {"step2prev": s2, "step3prev": s3p, "step3": s3, "step42ns": s4, "step52ns": s5}, evmap
 
 
-def toy_stark_files(outdir, name, nbits, fri_steps, nqueries, seed):
+def toy_stark_files(outdir, name, nbits, fri_steps, nqueries, seed, optimise=False):
     """Everything the C++ `Starks` mirror (xlayer_prover_amd/host/starks.hpp) needs to prove the mini PIL: a starkinfo.json
     in the reference's schema (stark_info.cpp:21-520), the five step programs, the constant and committed polynomials
     and the publics -- so the C++ genProof can be compared with this module's flow."""
@@ -147,6 +147,10 @@ def toy_stark_files(outdir, name, nbits, fri_steps, nqueries, seed):
         with open(os.path.join(outdir, f"{name}.{stepname}.xlpexpr"), "wb") as f:
             code = prog.code
             f.write(struct.pack("<4Q", magic, prog.ntmp1, prog.ntmp3, code.size)); f.write(code.astype("<u8").tobytes())
+    if optimise:                                          # dot-product forms next to the programs (tools/optimize_programs.py)
+        from tools.optimize_programs import optimise_file
+        wrote = [optimise_file(os.path.join(outdir, f"{name}.{stepname}.xlpexpr"))[1] for stepname in progs]
+        assert any(wrote)
     cm1, const, publics = witness(L, seed)
     cm1.astype("<u8").tofile(os.path.join(outdir, name + ".commit"))
     const.astype("<u8").tofile(os.path.join(outdir, name + ".const"))

@@ -644,53 +644,153 @@ def test_zkevm_geometry_relocation_is_consistent():
 
 
 # ------------------------------------------------------------------------------- Horner chains -> dot products (expr_opt.py)
-OPT_PROGS = ["zkevm", "recursive1", "recursive2", "c12a", "recursivef"]
+OPT_PROGS = [f"{stark}.{step}" for stark in ("zkevm", "recursive1", "recursive2", "c12a", "recursivef")
+             for step in ("step2prev", "step3prev", "step3", "step42ns", "step52ns") if not (step == "step2prev" and stark != "zkevm")]
 
 
-def _opt52_case(orc, prog, n):
-    """-> (original code + temporaries, optimised row program, table program, n_ext, buffers, info) for <prog>.step52ns"""
+def _opt_case(orc, name, n):
+    """-> (original code + temporaries, optimised row program, table program, n_ext, nch, buffers, info, stats) for a converted program"""
     from tests import expr_real as R
     from xlayer_prover_amd import expr_opt
-    path = os.path.join(R.REF_DIR, f"{prog}.step52ns.xlpexpr")
+    path = os.path.join(R.REF_DIR, f"{name}.xlpexpr")
     if not os.path.exists(path):
         pytest.skip("converted reference programs not built (needs the reference tree at build time)")
     code, n1, n3 = R.read_program(path)
     nch = 8
     row, tab, n_ext, stats = expr_opt.horner_to_dot(code, n1, n3, nch)
-    assert stats["ext_mul_removed"] > 40 and row.ninstr < sum(1 for _ in E.decode(code))
     (c0, c1), info = R.shrink_many([code, row.code], n)
     bufs = R.buffers(lambda cnt, seed: orc.fill(cnt, seed), 11, n, info)
     bufs["challenges"] = orc.fill(3 * nch, 99)
-    return (c0, n1, n3), (c1, row.ntmp1, row.ntmp3), tab, n_ext, nch, bufs, info
+    return (c0, n1, n3), (c1, row.ntmp1, row.ntmp3), tab, n_ext, nch, bufs, info, stats
 
 
-@pytest.mark.parametrize("prog", OPT_PROGS)
-def test_horner_to_dot_equals_original_on_the_oracle(orc, prog):
-    """the rewritten FRI-polynomial program (powers of the challenges and the evaluation constants from a one-row table
-    program, base-field columns multiplied by extension constants) gives the values of the reference's program, bit for bit"""
+@pytest.mark.parametrize("name", OPT_PROGS)
+def test_horner_to_dot_equals_original_on_the_oracle(orc, name):
+    """the rewritten step programs (powers of the challenges and the evaluation constants from a one-row table program,
+    base-field columns multiplied by extension constants) give the values of the reference's programs, bit for bit"""
     n = 64
-    (c0, n1, n3), (c1, m1, m3), tab, n_ext, nch, b0, info = _opt52_case(orc, prog, n)
+    (c0, n1, n3), (c1, m1, m3), tab, n_ext, nch, b0, info, stats = _opt_case(orc, name, n)
+    if name.endswith("step52ns"):
+        assert stats["ext_mul_after"] * 4 < stats["ext_mul_before"]
     b1 = {k: v.copy() for k, v in b0.items()}
     orc.expr_run(c0, n1, n3, b0, 0, n, info["n_const"], info["n_const2"])
     ext = np.zeros(3 * n_ext, np.uint64); ext[:3 * nch] = b1["challenges"]
-    orc.expr_run(tab.code, tab.ntmp1, tab.ntmp3, {**b1, "pols": ext}, 0, 1)
+    if tab.ninstr:
+        orc.expr_run(tab.code, tab.ntmp1, tab.ntmp3, {**b1, "pols": ext}, 0, 1)
     b1["challenges"] = ext
     orc.expr_run(c1, m1, m3, b1, 0, n, info["n_const"], info["n_const2"])
-    assert (b0["f_2ns"] == b1["f_2ns"]).all() and (b0["f_2ns"] != 0).all()
-    assert (b0["pols"] == b1["pols"]).all()
+    for k in ("pols", "q_2ns", "f_2ns"):
+        assert (b0[k] == b1[k]).all(), k
+
+
+def test_horner_to_dot_removes_most_extension_products_of_the_zkevm_steps(orc):
+    from tests import expr_real as R
+    from xlayer_prover_amd import expr_opt
+    if not os.path.exists(os.path.join(R.REF_DIR, "zkevm.step42ns.xlpexpr")):
+        pytest.skip("converted reference programs not built (needs the reference tree at build time)")
+    before = after = 0
+    for step in ("step2prev", "step3prev", "step3", "step42ns", "step52ns"):
+        code, n1, n3 = R.read_program(os.path.join(R.REF_DIR, f"zkevm.{step}.xlpexpr"))
+        st = expr_opt.horner_to_dot(code, n1, n3, 8)[3]
+        before += st["ext_mul_before"]; after += st["ext_mul_after"]
+    assert before == 8243 and after < 1500
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prog,n", [("zkevm", 1 << 12), ("recursive2", 1000)])
-def test_horner_to_dot_on_the_gpu_equals_original_on_the_oracle(xlp, orc, prog, n):
-    (c0, n1, n3), (c1, m1, m3), tab, n_ext, nch, b0, info = _opt52_case(orc, prog, n)
+@pytest.mark.parametrize("name,n", [("zkevm.step52ns", 1 << 12), ("zkevm.step42ns", 1 << 10), ("zkevm.step3prev", 3000), ("recursive2.step42ns", 1000)])
+def test_horner_to_dot_on_the_gpu_equals_original_on_the_oracle(xlp, orc, name, n):
+    (c0, n1, n3), (c1, m1, m3), tab, n_ext, nch, b0, info, _ = _opt_case(orc, name, n)
     dev = {k: xlp.from_np(v) for k, v in b0.items()}
     ext = xlp.from_np(np.concatenate([b0["challenges"], np.zeros(3 * (n_ext - nch), np.uint64)]))
-    pt = xlp.ExprProgram(tab.code, tab.ntmp1, tab.ntmp3)
-    pt.run(xlp.steps_params(pols=ext, challenges=dev["challenges"], evals=dev["evals"]), 0, 1)
+    if tab.ninstr:
+        pt = xlp.ExprProgram(tab.code, tab.ntmp1, tab.ntmp3)
+        pt.run(xlp.steps_params(pols=ext, challenges=dev["challenges"], evals=dev["evals"]), 0, 1)
+        pt.close()
     pr = xlp.ExprProgram(c1, m1, m3)
     pr.run(xlp.steps_params(n_const_pols=info["n_const"], n_const_pols_2ns=info["n_const2"], **{**dev, "challenges": ext}), 0, n)
     xlp.sync()
     orc.expr_run(c0, n1, n3, b0, 0, n, info["n_const"], info["n_const2"])
-    assert (xlp.to_np(dev["f_2ns"]) == b0["f_2ns"]).all()
-    pt.close(); pr.close()
+    for k in ("pols", "q_2ns", "f_2ns"):
+        assert (xlp.to_np(dev[k]) == b0[k]).all(), k
+    pr.close()
+
+
+def _chainy_program(seed, n, ninstr, nin=10, nstore=30):
+    """random programs made of the shapes horner_to_dot reasons about -- shifts by a challenge, sums / differences of
+    columns, `col - evals[e]`, temporaries that are copies of columns or computed, constants -- mixed with the things that
+    must stop it: extension products of temporaries, stores to columns that are read back later, recycled temporaries"""
+    rng = np.random.default_rng(seed)
+    width = nin + 3 * nstore
+    p = E.Program()
+    written = []                                             # (first column, dim) stored so far: readable on the same row
+    nxt = [nin]
+    t3 = lambda: E.tmp3(int(rng.integers(0, 3)))
+    t1 = lambda: E.tmp1(int(rng.integers(0, 4)))
+    ch = lambda: E.challenge(int(rng.integers(0, 3)))
+
+    def col(dim=None):
+        dim = dim or (1 if rng.integers(0, 3) else 3)
+        k = int(rng.integers(0, 6))
+        if k == 0 and written:
+            c, d = written[int(rng.integers(0, len(written)))]
+            if d >= dim: return E.pols(c, width, dim)
+        if k == 1: return E.pols_prime(int(rng.integers(0, nin - 2)), 1, n, width, dim)
+        if k == 2 and dim == 1: return E.const2ns(int(rng.integers(0, 4)))
+        if k == 3 and dim == 1: return E.const(int(rng.integers(0, 5)))
+        return E.pols(int(rng.integers(0, nin - 2)), width, dim)
+
+    def term():
+        k = int(rng.integers(0, 8))
+        if k <= 2: return col()
+        if k == 3: return t1()
+        if k == 4: return E.number(int(rng.integers(0, 1 << 62)))
+        return t3()
+    # every temporary starts defined
+    for i in range(4): p.copy(E.tmp1(i), col(1))
+    for i in range(3): p.mul(E.tmp3(i), col(), ch())
+    for _ in range(ninstr):
+        k = int(rng.integers(0, 14))
+        if k <= 2: p.mul(t3(), term(), ch())
+        elif k == 3: p.mul(t3(), ch(), term())
+        elif k <= 6:
+            a, b = t3(), term()
+            if rng.integers(0, 2): a, b = b, a
+            (p.add if rng.integers(0, 3) else p.sub)(t3(), a, b)
+        elif k == 7: p.sub(t3(), col(), E.evaluation(int(rng.integers(0, 5))))
+        elif k == 8: p.copy(t1(), col(1))
+        elif k == 9: p.mul(t1(), col(1), t1())
+        elif k == 10: p.mul(t3(), t3(), t3())
+        elif k == 11 and nxt[0] + 3 <= width:
+            d = 1 if rng.integers(0, 2) else 3
+            if d == 3: p.add(E.pols(nxt[0], width, 3), t3(), term())
+            else: p.add(E.pols(nxt[0], width, 1), t1(), col(1))
+            written.append((nxt[0], d)); nxt[0] += 3
+        elif k == 12: p.copy(E.f_2ns() if rng.integers(0, 2) else E.q_2ns(), t3())
+        else: p.mul(t3(), t3(), E.x_div_x_sub_xi())
+    for i in range(3):
+        if nxt[0] + 3 <= width:
+            p.copy(E.pols(nxt[0], width, 3), E.tmp3(i)); nxt[0] += 3
+    return p, width
+
+
+@pytest.mark.parametrize("block", range(8))
+def test_horner_to_dot_fuzz_on_the_oracle(orc, block):
+    """400 random chain-shaped programs: the rewritten program + its table program give the original's outputs"""
+    from xlayer_prover_amd import expr_opt
+    n, nch, removed = 6, 4, 0
+    for seed in range(50 * block, 50 * block + 50):
+        prog, width = _chainy_program(seed, n, 30 + seed % 40)
+        row, tab, n_ext, st = expr_opt.horner_to_dot(prog.code, prog.ntmp1, prog.ntmp3, nch)
+        removed += st["ext_mul_before"] - st["ext_mul_after"]
+        b0 = make_buffers(orc, seed, n, width, nch=nch)
+        b0["pols"] = orc.fill(n * width, seed + 77)          # canonical inputs, as the prover's sections are
+        b1 = {k: v.copy() for k, v in b0.items()}
+        orc.expr_run(prog.code, prog.ntmp1, prog.ntmp3, b0, 0, n, 5, 4)
+        ext = np.zeros(3 * n_ext, np.uint64); ext[:3 * nch] = b1["challenges"]
+        if tab.ninstr:
+            orc.expr_run(tab.code, tab.ntmp1, tab.ntmp3, {**b1, "pols": ext}, 0, 1, 5, 4)
+        b1["challenges"] = ext
+        orc.expr_run(row.code, row.ntmp1, row.ntmp3, b1, 0, n, 5, 4)
+        for k in ("pols", "q_2ns", "f_2ns"):
+            assert (b0[k] == b1[k]).all(), (seed, k)
+    assert removed > 0

@@ -80,17 +80,19 @@ def test_sharded_genproof_on_one_gpu_equals_oracle(orc, nbits, steps, nq, coll):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nbits,steps,nq", [(6, [7, 4], 5), (10, [11, 7, 4], 12)])
-def test_cpp_starks_genproof_equals_flow_and_verifies(orc, tmp_path, nbits, steps, nq):
+@pytest.mark.parametrize("nbits,steps,nq,optimise", [(6, [7, 4], 5, False), (10, [11, 7, 4], 12, False), (9, [10, 6, 3], 9, True)])
+def test_cpp_starks_genproof_equals_flow_and_verifies(orc, tmp_path, nbits, steps, nq, optimise):
     """The C++ GPU-resident `Starks::genProof` mirror (host/starks.hpp: StarkInfo-driven, starks.cpp:9-404 stage for stage)
-    on the mini PIL: its zkin proof equals what the Python flow computes on the oracle, and passes the verifier."""
+    on the mini PIL: its zkin proof equals what the Python flow computes on the oracle, and passes the verifier.
+    optimise: the step programs run in their dot-product form (tools/optimize_programs.py pairs picked up by XlpSteps)."""
     import json
     import os
     import subprocess
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xlayer_prover_amd", "host", "test_host_shim")
-    flow.toy_stark_files(str(tmp_path), "toy", nbits, steps, nq, seed=nbits)
+    flow.toy_stark_files(str(tmp_path), "toy", nbits, steps, nq, seed=nbits, optimise=optimise)
     r = subprocess.run([exe, "genproof", str(tmp_path), "toy"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+    assert ("dot-product form" in r.stderr) == optimise
     Z = json.loads(r.stdout)
     exp = flow.prove(OracleBackend(orc), nbits, steps, nq, seed=nbits)
     ints = lambda v: [int(x) for x in v]

@@ -75,8 +75,9 @@ def main():
     ap.add_argument("--lookups", type=int, default=28, help="H1H2 computations (cm2 = 168 columns = 28 x (h1, h2) in Fp^3)")
     ap.add_argument("--zs", type=int, default=40, help="grand products (calculateZ calls); their z columns land in cm3")
     ap.add_argument("--no-jit", action="store_true")
-    ap.add_argument("--no-opt52", action="store_true", help="run step52ns as converted (Horner chains) instead of its dot-product form "
-                    "(xlayer_prover_amd/expr_opt.py: same values, 2 989 fewer Fp^3 x Fp^3 products per row)")
+    ap.add_argument("--vm-only", default="", help="comma-separated steps: only run these programs (twice each) on a random slab and print their times")
+    ap.add_argument("--no-opt", action="store_true", help="run the step programs as converted (Horner chains) instead of their dot-product "
+                    "form (xlayer_prover_amd/expr_opt.py: same values, ~6 800 fewer Fp^3 x Fp^3 products per row over the five steps)")
     a = ap.parse_args()
     ln = a.log_n
     N, NE = 1 << ln, 1 << (ln + 1)
@@ -120,15 +121,15 @@ def main():
         mode[s] = "interpreter"
         if not a.no_jit and os.path.exists(so):
             vm[s].attach(so); mode[s] = "compiled"
-    opt52 = None
-    if not a.no_opt52:
-        (rc, r1, r3), tabp, n_ext = G.load_opt52(ln)
-        opt52 = {"row": capi.ExprProgram(rc, r1, r3), "tab": capi.ExprProgram(tabp.code, tabp.ntmp1, tabp.ntmp3),
-                 "ext": torch.zeros(3 * n_ext, dtype=i64, device=dev)}
-        so = os.path.join(R.REF_DIR, f"zkevm.step52ns_opt.geo{ln}.so")
-        mode["step52ns"] = "dot-product form, interpreter"
-        if not a.no_jit and os.path.exists(so):
-            opt52["row"].attach(so); mode["step52ns"] = "dot-product form, compiled"
+    opt = {}
+    if not a.no_opt:
+        for st, ((rc, r1, r3), tabp, n_ext, stats) in G.load_opt(ln).items():
+            opt[st] = {"row": capi.ExprProgram(rc, r1, r3), "tab": capi.ExprProgram(tabp.code, tabp.ntmp1, tabp.ntmp3) if tabp.ninstr else None,
+                       "ext": torch.zeros(3 * n_ext, dtype=i64, device=dev)}
+            so = os.path.join(R.REF_DIR, f"zkevm.{st}_opt.geo{ln}.so")
+            mode[st] = "dot-product form, interpreter"
+            if not a.no_jit and os.path.exists(so):
+                opt[st]["row"].attach(so); mode[st] = "dot-product form, compiled"
     ents, ev_ids = evmap_from_step52ns(progs["step52ns"][0], L, const_2ns, nconst, pols)
     ev_arr = capi.evmap_entries(ents)
     ev_out = torch.zeros(3 * len(ents), dtype=i64, device=dev)
@@ -148,17 +149,29 @@ def main():
         sp = capi.steps_params(n_const_pols=nconst, n_const_pols_2ns=nconst, pols=pols, const_pols=const_n, const_pols_2ns=const_2ns,
                                challenges=capi.from_np(challenges), public_inputs=capi.from_np(publics), evals=evals_d, x_n=x_n, x_2ns=x_2ns,
                                zi=zi, x_div_x_sub_xi=xdx, x_div_x_sub_wxi=xdwx, q_2ns=sec("q_2ns"), f_2ns=sec("f_2ns"))
-        if step == "step52ns" and opt52 is not None:
-            # powers of the two FRI challenges and the evaluation constants: one row of work, once per proof
-            ext = opt52["ext"]
-            ext[:3 * G.NCH] = sp._keep["challenges"][:3 * G.NCH]
-            tp = capi.steps_params(pols=ext, challenges=sp._keep["challenges"], evals=evals_d)
-            opt52["tab"].run(tp, 0, 1)
-            sp2 = capi.steps_params(n_const_pols=nconst, n_const_pols_2ns=nconst, **{**sp._keep, "challenges": ext})
-            opt52["row"].run(sp2, 0, nrows)
+        if step in opt:
+            # powers of the challenges and the evaluation constants: one row of work, once per proof
+            o = opt[step]
+            o["ext"][:3 * G.NCH] = sp._keep["challenges"][:3 * G.NCH]
+            if o["tab"] is not None:
+                o["tab"].run(capi.steps_params(pols=o["ext"], challenges=sp._keep["challenges"], evals=evals_d), 0, 1)
+            sp2 = capi.steps_params(n_const_pols=nconst, n_const_pols_2ns=nconst, **{**sp._keep, "challenges": o["ext"]})
+            o["row"].run(sp2, 0, nrows)
             return
         vm[step].run(sp, 0, nrows)
 
+    if a.vm_only:
+        capi.dev_fill(pols, 0x5EED0499, 0)
+        challenges[:] = np.arange(1, 25, dtype=np.uint64) * 0x9E3779B97F4A7C15 % P
+        capi.dev_fill(evals_d, 0x5EED049A, 0); capi.dev_fill(xdx, 0x5EED049B, 0); capi.dev_fill(xdwx, 0x5EED049C, 0)
+        res = {}
+        for st in a.vm_only.split(","):
+            nr = NE if st.endswith("2ns") else N
+            run(st, nr); torch.cuda.synchronize()
+            t0 = time.perf_counter(); run(st, nr); torch.cuda.synchronize()
+            res[st] = round(time.perf_counter() - t0, 4)
+        print(json.dumps({"vm_only_s": res, "modes": {k: mode[k] for k in res}}))
+        return
     timers = {}
     fri_roots = []
 

@@ -28,10 +28,10 @@ def main():
     if a.geometry:
         from tools import zkevm_geometry as G
         geo, _ = G.load(a.geometry)
-        geo["step52ns_opt"] = G.load_opt52(a.geometry)[0]
+        for st, v in G.load_opt(a.geometry).items():
+            geo[st + "_opt"] = v[0]
         sizes = ["geo"]
-        if "step52ns" in a.steps.split(","):
-            a.steps += ",step52ns_opt"
+        a.steps = ",".join(x for st in a.steps.split(",") for x in (st, st + "_opt"))
     for size in sizes:
         for step in a.steps.split(","):
             lr = (24 if step.endswith("2ns") else 23) if size in ("full", "geo") else size

@@ -84,11 +84,13 @@ def load(log_n):
 NCH = 8                                             # challenges of a STARK proof (starks.cpp: 0..7)
 
 
-def load_opt52(log_n):
-    """step52ns with its Horner chains turned into dot products (xlayer_prover_amd/expr_opt.py):
-    -> ((row code, ntmp1, ntmp3), table Program, number of extended-challenge entries)"""
+def load_opt(log_n):
+    """every step with its Horner chains turned into dot products (xlayer_prover_amd/expr_opt.py):
+    step -> ((row code, ntmp1, ntmp3), table Program, number of extended-challenge entries, statistics)"""
     from xlayer_prover_amd import expr_opt
     progs, _ = load(log_n)
-    code, n1, n3 = progs["step52ns"]
-    row, tab, n_ext, _ = expr_opt.horner_to_dot(code, n1, n3, NCH)
-    return (row.code, row.ntmp1, row.ntmp3), tab, n_ext
+    res = {}
+    for step, (code, n1, n3) in progs.items():
+        row, tab, n_ext, stats = expr_opt.horner_to_dot(code, n1, n3, NCH)
+        res[step] = ((row.code, row.ntmp1, row.ntmp3), tab, n_ext, stats)
+    return res

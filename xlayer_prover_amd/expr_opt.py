@@ -1,14 +1,16 @@
 """Program-level optimisation for the constraint-expression VM: Horner chains -> dot products.
 
-The FRI-polynomial program of a STARK (step52ns; starks.cpp:374-380, generated code in
-src/starkpil/zkevm/chelpers/zkevm.chelpers.step52ns.parser.cpp) is a few long Horner chains in a challenge v,
+The generated step programs of a STARK (src/starkpil/zkevm/chelpers/zkevm.chelpers.step*.parser.cpp) contain long Horner
+chains in a challenge v over COLUMNS:
 
-    acc = (...((Y0 v + Y1) v + Y2) v + ...) ,   Y_k = col_k  or  col_k - evals[e_k],
+    acc = (...((Y0 v + Y1) v + Y2) v + ...) ,   Y_k = col_k  or  col_k - evals[e_k]
 
-i.e. one Fp^3 x Fp^3 multiplication per committed column and row (2 990 of them for the zkEVM, ~75 % of the program).
-Since v and the evaluations do not depend on the row, the same value is
+-- the FRI polynomial (step52ns: 2 990 of them for the zkEVM, 75 % of the program) and the plookup / permutation
+compressions `a0 + u (a1 + u (a2 + ...))` of step3prev / step3 / step42ns (1 291 more).  Each link is an
+Fp^3 x Fp^3 product per row although most columns are base field.  Since v and the evaluations do not depend on the
+row, the same value is
 
-    acc = sum_k col_k * v^(K-k)  -  D ,      D = sum_k evals[e_k] * v^(K-k) ,
+    acc = sum_k (+-) col_k * v^(p_k)  -  D ,      D = sum_k (+-) evals[e_k] * v^(p_k) ,
 
 with the powers of v and D computed ONCE per proof: a base-field column then costs 3 base multiplications instead of a
 9-multiplication (Karatsuba 6) extension product.  Field arithmetic is exact, so the rewritten program produces the same
@@ -18,34 +20,51 @@ canonical values as the original.
     row program   -- reads the table as CHALLENGE operands with indices >= nch,
     table program -- row independent; run it on ONE row with `pols` = the extended challenge buffer
                      (3 * n_ext words, the first 3 * nch hold the proof's challenges); it fills entries nch .. n_ext-1,
-    n_ext.
-Both are ordinary VM programs: nothing changes in the interpreter or the code generator."""
+    n_ext, statistics.
+Both are ordinary VM programs: nothing changes in the interpreter or the code generator.
+
+How: every extension temporary is tracked symbolically as  base v^b + sum (+-) col v^p - sum (+-) evals[e] v^p  for as long
+as the program only shifts it (multiplies by the chain's challenge) or adds / subtracts columns, `col - evals[e]` values
+values, constants, other temporaries or other such values; base-field temporaries that are plain copies of a column stand
+for that column.  Only when another instruction needs the value is it emitted, in dot-product form.  A symbolic value
+never outlives a write to something it reads: before a column is written every symbolic value is evaluated (the programs
+of steps 2-3 write tmpExp / cm3 columns), before a temporary is overwritten those that read it are.  Instructions left
+without a reader are dropped."""
 from . import expr as E
 
 _COL = (E.K_POLS, E.K_POLS_PRIME, E.K_CONST, E.K_CONST_PRIME, E.K_CONST2NS, E.K_CONST2NS_PRIME)
 
 
 class _Lin:
-    """value of a tmp3 slot kept symbolic: base * v^bpw + sum X * v^pw - sum evals[e] * v^pw   (v = challenge c)"""
+    """base * v^bpw + sum sign * X * v^pw - sum sign * evals[e] * v^pw   (v = challenge c; base = the slot's own register)"""
     __slots__ = ("c", "terms", "evals", "bpw")
 
     def __init__(self, c=None, terms=(), evals=(), bpw=None):
         self.c, self.terms, self.evals, self.bpw = c, list(terms), list(evals), bpw
 
     def shifted(self, c):
-        return _Lin(c, [(x, p + 1) for x, p in self.terms], [(e, p + 1) for e, p in self.evals], None if self.bpw is None else self.bpw + 1)
+        return _Lin(c, [(x, p + 1, s) for x, p, s in self.terms], [(e, p + 1, s) for e, p, s in self.evals], None if self.bpw is None else self.bpw + 1)
+
+    def negated(self):
+        assert self.bpw is None
+        return _Lin(self.c, [(x, p, -s) for x, p, s in self.terms], [(e, p, -s) for e, p, s in self.evals])
 
     def plus(self, o):
+        assert o.bpw is None
         return _Lin(self.c if self.c is not None else o.c, self.terms + o.terms, self.evals + o.evals, self.bpw)
+
+    def compatible(self, o):
+        return self.c is None or o.c is None or self.c == o.c
 
 
 def horner_to_dot(code, ntmp1, ntmp3, nch):
     out, tab = E.Program(), E.Program()
     scratch = E.tmp3(ntmp3)                                  # one more extension temporary for the products
-    state = {}                                               # tmp3 slot -> _Lin (not yet materialised)
+    state = {}                                               # tmp3 slot -> _Lin (value not in its register yet)
+    alias = {}                                               # tmp1 slot -> the column it is a copy of
     powers = {}                                              # (c, j) -> table index of v_c^j
     n_ext = [nch]
-    stats = {"chains": 0, "ext_mul_removed": 0}
+    stats = {"dot_products": 0, "ext_mul_before": 0, "ext_mul_after": 0}
 
     def entry():
         n_ext[0] += 1
@@ -53,106 +72,214 @@ def horner_to_dot(code, ntmp1, ntmp3, nch):
 
     def tab_pols(idx): return E.pols(3 * idx, 3, 3)
 
-    def power(c, j):
-        """CHALLENGE operand holding v_c^j (j >= 1); table entries are created in increasing j"""
-        if j == 1:
-            return E.challenge(c)
-        if (c, j) not in powers:
-            prev = E.challenge(c) if j == 2 else (power(c, j - 1), tab_pols(powers[(c, j - 1)]))[1]
-            idx = entry()
-            tab.mul(tab_pols(idx), prev, E.challenge(c))
-            powers[(c, j)] = idx
-        return E.challenge(powers[(c, j)])
+    def need_power(c, j):
+        for k in range(2, j + 1):
+            if (c, k) not in powers:
+                prev = E.challenge(c) if k == 2 else tab_pols(powers[(c, k - 1)])
+                idx = entry()
+                tab.mul(tab_pols(idx), prev, E.challenge(c))
+                powers[(c, k)] = idx
 
-    def tab_power(c, j):
-        power(c, j)
+    def power(c, j):                                         # operand of the row program
+        need_power(c, j)
+        return E.challenge(c if j == 1 else powers[(c, j)])
+
+    def tab_power(c, j):                                     # operand of the table program
+        need_power(c, j)
         return E.challenge(c) if j == 1 else tab_pols(powers[(c, j)])
 
     def materialise(slot):
-        lin = state.pop(slot, None)
-        if lin is None:
+        if slot not in state:
             return
+        barrier(E.K_TMP3, slot, exclude=slot)                # others that read this register's present value go first
+        lin = state.pop(slot)
         dst = E.tmp3(slot)
-        hi_t = [(x, p) for x, p in lin.terms if p >= 1]
-        lo_t = [x for x, p in lin.terms if p == 0]
-        hi_e = [(e, p) for e, p in lin.evals if p >= 1]
-        lo_e = [e for e, p in lin.evals if p == 0]
-        for p in sorted({p for _, p in hi_t} | {p for _, p in hi_e} | ({lin.bpw} if lin.bpw else set())):
-            for j in range(2, p + 1):
-                power(lin.c, j)                              # fill the table in order
+        hi_t = sorted([t for t in lin.terms if t[1] >= 1], key=lambda t: -t[2])          # positive terms first
+        lo_t = sorted([t for t in lin.terms if t[1] == 0], key=lambda t: -t[2])
+        hi_e = [t for t in lin.evals if t[1] >= 1]
+        lo_e = [t for t in lin.evals if t[1] == 0]
         started = False
         if lin.bpw is not None:
             if lin.bpw >= 1:
                 out.mul(dst, dst, power(lin.c, lin.bpw))
             started = True
-        for x, p in hi_t:
+        for x, p, s in hi_t:
             if not started:
                 out.mul(dst, x, power(lin.c, p)); started = True
+                if s < 0:
+                    out.sub(dst, E.number(0), dst)
             else:
-                out.mul(scratch, x, power(lin.c, p)).add(dst, dst, scratch)
-        if not started:                                      # only row-0-power terms: the original `col - eval` form
-            assert lo_t and lo_e, "unexpected symbolic value"
-            out.sub(dst, lo_t.pop(0), E.evaluation(lo_e.pop(0)))
-        for x in lo_t:
-            out.add(dst, dst, x)
-        for e in lo_e:
-            out.sub(dst, dst, E.evaluation(e))
+                out.mul(scratch, x, power(lin.c, p))
+                (out.add if s > 0 else out.sub)(dst, dst, scratch)
+        for x, p, s in lo_t:
+            if not started:
+                pos_e = [t for t in lo_e if t[2] > 0]
+                if s > 0 and pos_e:                          # the original `col - evals[e]` form
+                    lo_e.remove(pos_e[0])
+                    out.sub(dst, x, E.evaluation(pos_e[0][0]))
+                else:                                        # rare: widen through a multiplication by one
+                    out.mul(dst, x, E.challenge(one_entry()))
+                    if s < 0:
+                        out.sub(dst, E.number(0), dst)
+                started = True
+            else:
+                (out.add if s > 0 else out.sub)(dst, dst, x)
+        assert started, "empty symbolic value"
+        for e, p, s in lo_e:
+            (out.sub if s > 0 else out.add)(dst, dst, E.evaluation(e))
         if hi_e:                                             # D = sum evals[e] * v^p, one table entry
             t0, t1 = E.tmp3(0), E.tmp3(1)
-            for k, (e, p) in enumerate(hi_e):
+            for k, (e, p, s) in enumerate(hi_e):
                 if k == 0:
                     tab.mul(t0, E.evaluation(e), tab_power(lin.c, p))
+                    if s < 0:
+                        tab.sub(t0, E.number(0), t0)
                 else:
-                    tab.mul(t1, E.evaluation(e), tab_power(lin.c, p)).add(t0, t0, t1)
+                    tab.mul(t1, E.evaluation(e), tab_power(lin.c, p))
+                    (tab.add if s > 0 else tab.sub)(t0, t0, t1)
             idx = entry()
             tab.copy(tab_pols(idx), t0)
             out.sub(dst, dst, E.challenge(idx))
         if len(hi_t) > 1:
-            stats["chains"] += 1
+            stats["dot_products"] += 1
 
-    def is_t3(o, slot=None): return o is not None and o.kind == E.K_TMP3 and (slot is None or o.params[0] == slot)
-    def is_col(o): return o is not None and o.kind in _COL
+    one = []
+
+    def one_entry():                                         # (1, 0, 0) in the table
+        if not one:
+            one.append(entry())
+            tab.sub(E.tmp3(0), E.challenge(0), E.challenge(0)).add(tab_pols(one[0]), E.number(1), E.tmp3(0))
+        return one[0]
+
+    def is_t3(o): return o is not None and o.kind == E.K_TMP3
+    def is_ch(o): return o is not None and o.kind == E.K_CHALLENGE and o.params[0] < nch
+
+    def column(o):
+        if o is None:
+            return None
+        if o.kind in _COL:
+            return o
+        if o.kind == E.K_TMP1:
+            return alias.get(o.params[0])
+        return None
+
+    def lin_of(o, d_slot):
+        """symbolic value of a source operand, or None if it cannot be part of a chain"""
+        if o is None:
+            return None
+        if is_t3(o):
+            k = o.params[0]
+            if k in state:
+                return state[k]
+            return _Lin(bpw=0) if k == d_slot else _Lin(None, [(o, 0, 1)])     # a real value: the base / a term
+        x = column(o)
+        if x is not None:
+            return _Lin(None, [(x, 0, 1)])
+        if o.kind in (E.K_TMP1, E.K_NUMBER):
+            return _Lin(None, [(o, 0, 1)])
+        return None
+
+    def refs(lin):
+        return {(x.kind, x.params[0]) for x, _, _ in lin.terms if x.kind in (E.K_TMP1, E.K_TMP3)}
+
+    def barrier(kind, slot, exclude=None):
+        """the register (kind, slot) is about to change: evaluate every symbolic value that still reads it"""
+        for k in list(state):
+            if k != exclude and k in state and (kind, slot) in refs(state[k]):
+                materialise(k)
+
+    def flush_all():
+        for k in list(state):
+            materialise(k)
+
+    def acceptable(lin, slot):
+        """may `lin` become the symbolic value of tmp3 `slot`?  It must not read, as a term, the register it will be written to,
+        neither directly nor through the symbolic values of the registers it reads (evaluation order would be circular)."""
+        todo, seen = [k for kind, k in refs(lin) if kind == E.K_TMP3], set()
+        while todo:
+            k = todo.pop()
+            if k == slot:
+                return False
+            if k in seen:
+                continue
+            seen.add(k)
+            if k in state:
+                todo += [j for kind, j in refs(state[k]) if kind == E.K_TMP3]
+        return True
 
     for op, d, a, b in E.decode(code):
+        if op == E.MUL and a.dim == 3 and b.dim == 3:
+            stats["ext_mul_before"] += 1
         if is_t3(d):
             s = d.params[0]
-            # T = col - evals[e]
-            if op == E.SUB and is_col(a) and b.kind == E.K_EVAL:
-                state[s] = _Lin(None, [(a, 0)], [(b.params[0], 0)])
+            if op == E.SUB and column(a) is not None and b.kind == E.K_EVAL:
+                state[s] = _Lin(None, [(column(a), 0, 1)], [(b.params[0], 0, 1)])
                 continue
-            if op == E.MUL and b is not None and b.kind == E.K_CHALLENGE and b.params[0] < nch:
-                c = b.params[0]
-                if is_col(a):                                # A = col * v
-                    state[s] = _Lin(c, [(a, 1)])
+            if op == E.MUL and (is_ch(a) or is_ch(b)):
+                ch, x = (a, b) if is_ch(a) else (b, a)
+                c = ch.params[0]
+                lin = lin_of(x, s)
+                if lin is not None and is_t3(x) and x.params[0] in state and \
+                        ((lin.bpw is not None and x.params[0] != s) or lin.c not in (None, c)):
+                    materialise(x.params[0])                 # base in another register, or a chain in another challenge:
+                    lin = lin_of(x, s)                       # take its real value
+                if lin is not None and lin.c in (None, c) and acceptable(lin, s):
+                    state[s] = lin.shifted(c)
                     continue
-                if is_t3(a):
-                    src = a.params[0]
-                    lin = state.get(src)
-                    if lin is not None and lin.c in (None, c):
-                        state[s] = lin.shifted(c); stats["ext_mul_removed"] += 1
-                        continue
-                    if src == s:                             # materialised accumulator: keep it as the base of a new chain
-                        materialise(s)
-                        state[s] = _Lin(c, bpw=1)
-                        continue
-            if op == E.ADD and is_t3(a, s) and s in state:
-                lin = state[s]
-                if is_col(b):
-                    state[s] = lin.plus(_Lin(None, [(b, 0)]))
-                    continue
-                if is_t3(b) and b.params[0] in state and b.params[0] != s:
-                    o = state[b.params[0]]
-                    if o.bpw is None and (o.c is None or lin.c is None or o.c == lin.c):
-                        state[s] = lin.plus(o)
-                        continue
+            if op in (E.ADD, E.SUB):
+                la, lb = lin_of(a, s), lin_of(b, s)
+                one_is_chain = (is_t3(a) and a.params[0] in state) or (is_t3(b) and b.params[0] in state)
+                if la is not None and lb is not None and one_is_chain and la.compatible(lb):
+                    if op == E.ADD and la.bpw is None and lb.bpw is not None:
+                        la, lb, a, b = lb, la, b, a                      # x + acc == acc + x
+                    if lb.bpw is None and (la.bpw is None or (is_t3(a) and a.params[0] == s)):
+                        cand = la.plus(lb if op == E.ADD else lb.negated())
+                        if acceptable(cand, s):
+                            state[s] = cand
+                            continue
         # anything else: its tmp3 sources must hold real values; its destination becomes a real value
+        if d.kind in (E.K_POLS, E.K_POLS_PRIME):
+            flush_all()                                      # a column is about to change: nothing symbolic may outlive it
+            alias.clear()
         for o in (a, b):
             if is_t3(o):
                 materialise(o.params[0])
+        if d.kind in (E.K_TMP1, E.K_TMP3):
+            barrier(d.kind, d.params[0])
         if is_t3(d):
             state.pop(d.params[0], None)
+        if d.kind == E.K_TMP1:
+            alias.pop(d.params[0], None)
+            if op == E.COPY and a.kind in _COL:
+                alias[d.params[0]] = a
         out.emit(op, d, a, b)
+    out = _drop_dead(out)
+    for op, d, a, b in E.decode(out.code):
+        if op == E.MUL and a.dim == 3 and b.dim == 3:
+            stats["ext_mul_after"] += 1
     out.ntmp1 = max(out.ntmp1, ntmp1)
     out.ntmp3 = max(out.ntmp3, ntmp3 + 1)
     tab.ntmp3 = max(tab.ntmp3, 2)
     return out, tab, n_ext[0], stats
+
+
+def _drop_dead(prog):
+    """remove instructions whose destination is a temporary nobody reads (backward liveness over the straight-line code)"""
+    ins = list(E.decode(prog.code))
+    live, keep = set(), [False] * len(ins)
+    for i in range(len(ins) - 1, -1, -1):
+        op, d, a, b = ins[i]
+        key = (d.kind, d.params[0]) if d.kind in (E.K_TMP1, E.K_TMP3) else None
+        if key is not None and key not in live:
+            continue
+        keep[i] = True
+        if key is not None:
+            live.discard(key)
+        for o in (a, b):
+            if o is not None and o.kind in (E.K_TMP1, E.K_TMP3):
+                live.add((o.kind, o.params[0]))
+    res = E.Program()
+    for k, (op, d, a, b) in zip(keep, ins):
+        if k:
+            res.emit(op, d, a, b)
+    return res

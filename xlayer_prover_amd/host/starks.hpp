@@ -26,6 +26,9 @@ public:
     Goldilocks::Element constRoot[HASH_SIZE];
     bool logTimers = false;
 
+    // true if step k (0 step2prev .. 4 step52ns) runs in its dot-product form (tools/optimize_programs.py)
+    bool stepOptimised(int k) const { return steps.optimised(k); }
+
 private:
     XlpSteps steps;
     uint64_t *d_mem = NULL, *d_const_n = NULL, *d_const_2ns = NULL, *d_x_n = NULL, *d_x_2ns = NULL, *d_zi = NULL, *d_xdx = NULL, *d_xdwx = NULL;

@@ -91,6 +91,9 @@ static int genproof_mode(const std::string& dir, const std::string& name, bool t
                                      publics = read_u64_file(dir + "/" + name + ".publics");
     Starks starks(dir + "/" + name + ".starkinfo.json", constPols.data(), dir, name);
     starks.logTimers = timers;
+    static const char* stepNames[5] = {"step2prev", "step3prev", "step3", "step42ns", "step52ns"};
+    for (int k = 0; k < 5; k++)
+        if (starks.stepOptimised(k)) fprintf(stderr, "%s: dot-product form\n", stepNames[k]);
     const StarkStruct& ss = starks.starkInfo.starkStruct;
     FRIProof proof(1ULL << ss.steps.back().nBits, FIELD_EXTENSION, ss.steps.size(), starks.starkInfo.evMap.size(), starks.starkInfo.nPublics);
     for (uint64_t i = 0; i < starks.starkInfo.nPublics; i++) proof.publics[i] = publics[i];
