@@ -668,7 +668,7 @@ def _opt_case(orc, name, n):
 def test_horner_to_dot_equals_original_on_the_oracle(orc, name):
     """the rewritten step programs (powers of the challenges and the evaluation constants from a one-row table program,
     base-field columns multiplied by extension constants) give the values of the reference's programs, bit for bit"""
-    n = 16
+    n = 32
     (c0, n1, n3), (c1, m1, m3), tab, n_ext, nch, b0, info, stats = _opt_case(orc, name, n)
     if name.endswith("step52ns"):
         assert stats["ext_mul_after"] * 4 < stats["ext_mul_before"]
