@@ -139,6 +139,17 @@ typedef struct xlp_evmap_entry { const uint64_t* pol; uint64_t row_stride; uint3
 int xlp_dev_evmap(uint64_t* evals, const uint64_t* LEv, const uint64_t* LpEv, uint64_t n, uint32_t extend_bits, uint32_t nev,
                   const xlp_evmap_entry* entries);
 
+/* Row-wise linear combinations of columns with row-independent Fp^3 coefficients -- the linear part of the FRI
+ * polynomial (Starks::genProof step 5, starks.cpp:371-380 / zkevm.chelpers.step52ns.parser.cpp: Horner chains in the
+ * challenges over every committed column) once the chains are written as dot products (xlayer_prover_amd/expr_opt.py):
+ *   out[row * 3 * ngroups + 3 * g + c] = ( sum_{e : group_e == g} coefs[coef_e] * pol_e[row * row_stride_e .. + dim_e) )_c
+ * for row < nrows; coefficient coef_e = the three words coefs[3 * coef_e ..].  `entries` is a HOST array; `pol` are device
+ * pointers to (row 0, column) of row-major sections; dim 1 or 3; ngroups <= 4; results canonical.  The sections are
+ * read once, coalesced, and transposed through LDS; products are accumulated unreduced (one reduction per row and sum). */
+typedef struct xlp_dot_entry { const uint64_t* pol; uint64_t row_stride; uint32_t dim; uint32_t group; uint64_t coef; } xlp_dot_entry;
+int xlp_dev_dot_columns(uint64_t* out, const xlp_dot_entry* entries, uint64_t nentries, uint32_t ngroups,
+                        const uint64_t* coefs, uint64_t coefs_size, uint64_t nrows);
+
 /* ---- constraint-expression VM, device pointers ------------------------------------
  * Replaces ZkevmSteps::step{2prev,3prev,3,42ns,52ns}_parser_first_avx(StepsParams &params, nrows, nrowsBatch)
  * (src/starkpil/zkevm/chelpers/zkevm.chelpers.*.parser.cpp; called at starks.cpp:73,155,193,241,371): one

@@ -513,3 +513,49 @@ def test_evmap_many_entries_vs_oracle(xlp, orc, nbits, eb, width, nev, seed):
     ev = xlp.from_np(np.zeros(3 * len(ents), np.uint64))
     xlp.dev_evmap(ev, xlp.from_np(LEv.reshape(-1)), xlp.from_np(LpEv.reshape(-1)), n, eb, dev_ents); xlp.sync()
     assert (xlp.to_np(ev).reshape(-1, 3) == exp).all()
+
+
+# ---------------------------------------------------------------- dot_columns (linear part of the FRI polynomial)
+@pytest.mark.parametrize("nrows,ngroups,seed", [(1, 1, 1), (255, 2, 2), (256, 3, 3), (1000, 4, 4), (5000, 3, 5)])
+def test_dot_columns_vs_bigint(xlp, orc, nrows, ngroups, seed):
+    """xlp_dev_dot_columns against Python integers (the extension product restated as in oracle mul3): several sections of
+    different widths, base and extension columns, repeated columns, arbitrary 64-bit words as inputs"""
+    import torch
+    rng = np.random.default_rng(seed)
+    Pm = 0xFFFFFFFF00000001
+    widths = [37, 3, 130, 18]
+    secs_h = [rng.integers(0, 2**64, size=nrows * w, dtype=np.uint64) for w in widths]      # non-canonical words included
+    secs = [xlp.from_np(a) for a in secs_h]
+    ncoef = 50
+    coefs_h = orc.fill(3 * ncoef, 0x5EED0D07 + seed)
+    coefs_h[0:3] = [2**64 - 1, Pm, Pm + 5]                                                  # non-canonical coefficient words
+    ents = []
+    for si, w in enumerate(widths):
+        for _ in range(max(2, w // 2)):
+            dim = 3 if (w >= 3 and rng.integers(0, 4) == 0) else 1
+            ents.append((si, w, int(rng.integers(0, w - dim + 1)), dim, int(rng.integers(0, ngroups)), int(rng.integers(0, ncoef))))
+    out = torch.zeros(nrows * 3 * ngroups, dtype=torch.int64, device="cuda")
+    xlp.dev_dot_columns(out, [(secs[si], w, c, d, g, k) for si, w, c, d, g, k in ents], ngroups, xlp.from_np(coefs_h), nrows)
+    xlp.sync()
+    got = xlp.to_np(out).reshape(nrows, ngroups, 3)
+
+    def mul3(a, b):
+        a0, a1, a2 = a; b0, b1, b2 = b
+        return [(a0 * b0 + a1 * b2 + a2 * b1) % Pm, (a0 * b1 + a1 * b0 + a1 * b2 + a2 * b1 + a2 * b2) % Pm, (a0 * b2 + a2 * b0 + a1 * b1 + a2 * b2) % Pm]
+    for row in list(range(min(nrows, 3))) + [nrows - 1] + [int(r) for r in rng.integers(0, nrows, 6)]:
+        exp = [[0, 0, 0] for _ in range(ngroups)]
+        for si, w, c, d, g, k in ents:
+            x = [int(v) for v in secs_h[si][row * w + c: row * w + c + d]] + [0] * (3 - d)
+            m = mul3([int(v) for v in coefs_h[3 * k:3 * k + 3]], x)
+            exp[g] = [(u + v) % Pm for u, v in zip(exp[g], m)]
+        assert [[int(v) for v in r] for r in got[row]] == exp, row
+
+
+def test_dot_columns_rejections(xlp):
+    import torch
+    sec = torch.zeros(64, dtype=torch.int64, device="cuda"); co = torch.zeros(6, dtype=torch.int64, device="cuda")
+    out = torch.zeros(8 * 3, dtype=torch.int64, device="cuda")
+    for ent, ng, msg in [((sec, 8, 0, 2, 0, 0), 1, "dim must be 1 or 3"), ((sec, 8, 0, 1, 1, 0), 1, "group out of range"),
+                         ((sec, 8, 0, 1, 0, 2), 1, "coefficient index"), ((sec, 8, 0, 1, 0, 0), 5, "at most 4 groups")]:
+        with pytest.raises(xlp.XlpError, match=msg):
+            xlp.dev_dot_columns(out, [ent], ng, co, 8)

@@ -47,6 +47,7 @@ SIGNATURES = {
     "xlp_dev_geometric": [_pu, _u64, _u32, _pu, _pu],
     "xlp_dev_q_split": [_pu, _pu, _u64, _u64, _u32, _u32, _u64],
     "xlp_dev_copy_cols": [_pu, _u64, _pu, _u64, _u64, _u32],
+    "xlp_dev_dot_columns": [_pu, _pu, _u64, _u32, _pu, _u64, _u64],
     "xlp_dev_merkle_proofs": [_pu, _pu, _pu, _u64, _u64, _pu, _u64],
     "xlp_dev_x_div_x_sub_xi": [_pu, _pu, _pu, _u64],
     "xlp_dev_calculate_h1h2": [_pu, _pu, _pu, _pu, _u64, _u32],
@@ -386,6 +387,25 @@ def dev_evmap(evals, LEv, LpEv, n, extend_bits, entries):
     """entries: the list evmap_entries() takes, or its result (build it once when the call is repeated)"""
     arr = entries if isinstance(entries, C.Array) else evmap_entries(entries)
     _ck(load().xlp_dev_evmap(_dp(evals), _dp(LEv), _dp(LpEv), n, extend_bits, len(arr), C.cast(arr, C.c_void_p)), "xlp_dev_evmap")
+
+
+class DotEntry(C.Structure):
+    _fields_ = [("pol", C.c_void_p), ("row_stride", C.c_uint64), ("dim", C.c_uint32), ("group", C.c_uint32), ("coef", C.c_uint64)]
+
+
+def dot_entries(entries):
+    """entries: list of (section tensor on device, width, column, dim, group, coefficient index) -> reusable descriptor array"""
+    arr = (DotEntry * len(entries))()
+    for i, (t, width, col, dim, group, coef) in enumerate(entries):
+        arr[i] = DotEntry(t.data_ptr() + 8 * col, width, dim, group, coef)
+    arr._keep = [e[0] for e in entries]
+    return arr
+
+
+def dev_dot_columns(out, entries, ngroups, coefs, nrows):
+    """out[row][g] = sum of coefs[coef_e] * column_e[row] over the entries of group g (xlp_dev_dot_columns)"""
+    arr = entries if isinstance(entries, C.Array) else dot_entries(entries)
+    _ck(load().xlp_dev_dot_columns(_dp(out), C.cast(arr, C.c_void_p), len(arr), ngroups, _dp(coefs), coefs.numel(), nrows), "xlp_dev_dot_columns")
 
 
 def to_np(t):

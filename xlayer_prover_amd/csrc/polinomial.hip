@@ -438,6 +438,129 @@ int dev_evmap(Ctx* ctx, u64* evals, const u64* LEv, const u64* LpEv, u64 n, u32 
 }
 
 
+// ------------------------------------------------------------------ dot_columns
+// out[row][g] = sum_e coefs[coef_e] * pol_e[row]  (Fp^3 coefficient x column of dimension 1 or 3), e over the entries of group g.
+// The linear part of the FRI polynomial (starks.cpp:371-380) once its Horner chains are dot products (expr_opt.py).
+// One workgroup = DC_RT rows.  The host cuts every section into windows of <= DC_CB consecutive words that cover the
+// requested columns; per window the workgroup loads a DC_RT x DC_CB tile with row-contiguous (coalesced) reads, stores it
+// transposed in LDS, and every lane (= one row) walks the window's items: the coefficient is wave-uniform (scalar loads),
+// the value comes from LDS, base-field products are accumulated unreduced in 128 bits + overflow count (2^128 = -2^32).
+constexpr int DC_RT = 256, DC_CB = 16;
+
+template <int G>
+__global__ __launch_bounds__(DC_RT) void dot_columns_kernel(u64* out, const u64* plan, u32 nwindows, const u64* coefs, u64 nrows)
+{
+    __shared__ u64 tile[DC_CB][DC_RT + 1];
+    const u32 t = threadIdx.x;
+    const u64 row0 = (u64)blockIdx.x * DC_RT;
+    unsigned __int128 s128[G][3];
+    u32 ovf[G][3];
+    e3 acc3[G];
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) { s128[g][c] = 0; ovf[g][c] = 0; acc3[g].c[c] = 0; }
+    const u64* p = plan;
+    for (u32 w = 0; w < nwindows; w++) {
+        gptr_t base = (gptr_t)p[0];
+        const u64 stride = p[1];
+        const u32 ncols = (u32)p[2], nitems = (u32)(p[2] >> 32);
+        p += 3;
+        __syncthreads();                                   // previous window fully consumed
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            const u32 r = pass * (DC_RT / 2) + (t >> 1), c0 = (t & 1) * (DC_CB / 2);
+            if (row0 + r < nrows) {
+                gptr_t src = base + (row0 + r) * stride + c0;
+#pragma unroll
+                for (int j = 0; j < DC_CB / 2; j++)
+                    if (c0 + j < ncols) tile[c0 + j][r] = src[j];
+            }
+        }
+        __syncthreads();
+        for (u32 i = 0; i < nitems; i++) {
+            const u64 it = p[i];                           // wave-uniform
+            const u32 c = (u32)it & 255, dim = ((u32)it >> 8) & 255, g = ((u32)it >> 16) & 255;
+            const u64* k = coefs + 3 * (it >> 32);
+            const u64 k0 = k[0], k1 = k[1], k2 = k[2];
+            if (dim == 1) {
+                const u64 v = tile[c][t];
+#pragma unroll
+                for (int gg = 0; gg < G; gg++)
+                    if (g == (u32)gg) {
+                        unsigned __int128 pr = (unsigned __int128)k0 * v; s128[gg][0] += pr; ovf[gg][0] += s128[gg][0] < pr;
+                        pr = (unsigned __int128)k1 * v; s128[gg][1] += pr; ovf[gg][1] += s128[gg][1] < pr;
+                        pr = (unsigned __int128)k2 * v; s128[gg][2] += pr; ovf[gg][2] += s128[gg][2] < pr;
+                    }
+            } else {
+                e3 a, x;
+                a.c[0] = gl::canon(k0); a.c[1] = gl::canon(k1); a.c[2] = gl::canon(k2);
+                x.c[0] = gl::canon(tile[c][t]); x.c[1] = gl::canon(tile[c + 1][t]); x.c[2] = gl::canon(tile[c + 2][t]);
+                const e3 m = gl::mul3(a, x);
+#pragma unroll
+                for (int gg = 0; gg < G; gg++)
+                    if (g == (u32)gg) acc3[gg] = gl::add3(acc3[gg], m);
+            }
+        }
+        p += nitems;
+    }
+    if (row0 + t >= nrows) return;
+    u64* dst = out + (row0 + t) * (3 * G);
+#pragma unroll
+    for (int g = 0; g < G; g++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const u64 r = gl::canon(gl::reduce128((u64)s128[g][c], (u64)(s128[g][c] >> 64)));
+            dst[3 * g + c] = gl::addc(acc3[g].c[c], gl::subc(r, gl::mulc((u64)ovf[g][c], 1ULL << 32)));
+        }
+}
+
+int dev_dot_columns(Ctx* ctx, u64* out, const xlp_dot_entry* entries, u64 nentries, u32 ngroups, const u64* coefs, u64 coefs_size, u64 nrows)
+{
+    if (ngroups > 4) return xlp_fail("dot columns: at most 4 groups");
+    std::vector<xlp_dot_entry> e(entries, entries + nentries);
+    for (const auto& x : e) {
+        if (x.dim != 1 && x.dim != 3) return xlp_fail("dot columns: dim must be 1 or 3");
+        if (x.group >= ngroups) return xlp_fail("dot columns: group out of range");
+        if (x.coef * 3 + 3 > coefs_size) return xlp_fail("dot columns: coefficient index out of range");
+        if (x.row_stride < x.dim) return xlp_fail("dot columns: stride smaller than dim");
+    }
+    std::stable_sort(e.begin(), e.end(), [](const xlp_dot_entry& a, const xlp_dot_entry& b) { return a.pol < b.pol; });
+    // windows: runs of entries of one row span (same stride, < DC_CB words from the window's first word, inside one row)
+    std::vector<u64> plan;
+    u32 nwindows = 0;
+    for (size_t i = 0; i < e.size();) {
+        const u64* w0 = e[i].pol;
+        size_t j = i;
+        u32 ncols = 0;
+        while (j < e.size() && e[j].row_stride == e[i].row_stride && (u64)(e[j].pol - w0) + e[j].dim <= (u64)DC_CB &&
+               (u64)(e[j].pol - w0) + e[j].dim <= e[i].row_stride) {
+            ncols = std::max<u32>(ncols, (u32)(e[j].pol - w0) + e[j].dim);
+            j++;
+        }
+        plan.push_back((u64)(uintptr_t)w0);
+        plan.push_back(e[i].row_stride);
+        plan.push_back((u64)ncols | ((u64)(j - i) << 32));
+        for (size_t k = i; k < j; k++)
+            plan.push_back((u64)(e[k].pol - w0) | ((u64)e[k].dim << 8) | ((u64)e[k].group << 16) | (e[k].coef << 32));
+        nwindows++;
+        i = j;
+    }
+    u64* dplan = nullptr;
+    if (ctx_scratch(ctx, std::max<size_t>(plan.size() * 8, 8), 2, &dplan)) return -1;
+    if (!plan.empty()) XLP_HIP(hipMemcpyAsync(dplan, plan.data(), plan.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    XLP_HIP(hipStreamSynchronize(ctx->stream));            // plan goes out of scope
+    const dim3 grid((unsigned)((nrows + DC_RT - 1) / DC_RT)), block(DC_RT);
+    switch (ngroups) {
+    case 1: hipLaunchKernelGGL(dot_columns_kernel<1>, grid, block, 0, ctx->stream, out, dplan, nwindows, coefs, nrows); break;
+    case 2: hipLaunchKernelGGL(dot_columns_kernel<2>, grid, block, 0, ctx->stream, out, dplan, nwindows, coefs, nrows); break;
+    case 3: hipLaunchKernelGGL(dot_columns_kernel<3>, grid, block, 0, ctx->stream, out, dplan, nwindows, coefs, nrows); break;
+    default: hipLaunchKernelGGL(dot_columns_kernel<4>, grid, block, 0, ctx->stream, out, dplan, nwindows, coefs, nrows); break;
+    }
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------ calculateH1H2
 // Polinomial::calculateH1H2_opt1 / _opt3 (polinomial.hpp:349-585; called starks.cpp:108-125).
 // The reference walks hash chains sequentially; the observable result only depends on

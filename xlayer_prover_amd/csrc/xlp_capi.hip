@@ -243,6 +243,15 @@ int xlp_dev_x_div_x_sub_xi(uint64_t* out, const uint64_t* x, const uint64_t* xi,
     if (!xi) return xlp_fail("xlp_dev_x_div_x_sub_xi: null xi");
     return dev_x_div_x_sub_xi(&g_ctx, out, x, xi, n);
 }
+int xlp_dev_dot_columns(uint64_t* out, const xlp_dot_entry* entries, uint64_t nentries, uint32_t ngroups,
+                        const uint64_t* coefs, uint64_t coefs_size, uint64_t nrows)
+{
+    if (ensure_init()) return -1;
+    if (!nrows || !ngroups) return 0;
+    if (!out || (nentries && (!entries || !coefs))) return xlp_fail("xlp_dev_dot_columns: null pointer");
+    return dev_dot_columns(&g_ctx, out, entries, nentries, ngroups, coefs, coefs_size, nrows);
+}
+
 int xlp_dev_evmap(uint64_t* evals, const uint64_t* LEv, const uint64_t* LpEv, uint64_t n, uint32_t extend_bits, uint32_t nev,
                   const xlp_evmap_entry* entries)
 {
