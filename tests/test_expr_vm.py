@@ -794,3 +794,88 @@ def test_horner_to_dot_fuzz_on_the_oracle(orc, block):
         for k in ("pols", "q_2ns", "f_2ns"):
             assert (b0[k] == b1[k]).all(), (seed, k)
     assert removed > 0
+
+
+def _dots_on_host(orc, dots, bufs, ext, n):
+    """xlp_dev_dot_columns restated with Python integers on the buffers of tests/expr_real.py: -> uint64 [n][3 * ngroups]"""
+    Pm = 0xFFFFFFFF00000001
+    G = dots["ngroups"]
+    out = np.zeros((n, 3 * G), np.uint64)
+    nconst2 = bufs["const_pols_2ns"].size // n
+    for row in range(n):
+        acc = [[0, 0, 0] for _ in range(G)]
+        for x, g, k in dots["entries"]:
+            if x.kind == E.K_POLS:
+                v = bufs["pols"][x.params[0] + row * x.params[1]: x.params[0] + row * x.params[1] + x.dim]
+            else:
+                assert x.kind == E.K_CONST2NS
+                v = bufs["const_pols_2ns"][x.params[0] + row * nconst2: x.params[0] + row * nconst2 + 1]
+            v = [int(t) for t in v] + [0] * (3 - len(v))
+            m = orc.mul3(np.array([int(t) for t in ext[3 * k:3 * k + 3]], np.uint64), np.array(v, np.uint64))
+            acc[g] = [(a + int(b)) % Pm for a, b in zip(acc[g], m)]
+        out[row] = [c for a in acc for c in a]
+    return out
+
+
+@pytest.mark.parametrize("prog", ["zkevm", "recursive1", "recursive2", "c12a", "recursivef"])
+def test_fri_polynomial_as_dot_columns_equals_original_on_the_oracle(orc, prog):
+    """step52ns with its three big sums handed to the dot-columns kernel (restated on the host here) and a 12-instruction
+    row program on the kernel's output: same f_2ns as the reference's program"""
+    from tests import expr_real as R
+    from xlayer_prover_amd import expr_opt
+    path = os.path.join(R.REF_DIR, f"{prog}.step52ns.xlpexpr")
+    if not os.path.exists(path):
+        pytest.skip("converted reference programs not built (needs the reference tree at build time)")
+    code, n1, n3 = R.read_program(path)
+    n, nch = 32, 8
+    (c0,), info = R.shrink_many([code], n)
+    row, tab, n_ext, st, dots = expr_opt.horner_to_dot(c0, n1, n3, nch, outsource_min_terms=8)
+    if dots is None:            # a sum with a non-column term keeps the program reading real columns: the inline form is returned
+        assert prog in ("c12a", "recursivef") and row.ninstr > 100
+        return
+    assert row.ninstr < 40 and st["ext_mul_after"] <= 4
+    b0 = R.buffers(lambda cnt, seed: orc.fill(cnt, seed), 11, n, info)
+    b0["challenges"] = orc.fill(3 * nch, 99)
+    b1 = {k: v.copy() for k, v in b0.items()}
+    orc.expr_run(c0, n1, n3, b0, 0, n, info["n_const"], info["n_const2"])
+    ext = np.zeros(3 * n_ext, np.uint64); ext[:3 * nch] = b1["challenges"]
+    orc.expr_run(tab.code, tab.ntmp1, tab.ntmp3, {**b1, "pols": ext}, 0, 1)
+    dots_out = _dots_on_host(orc, dots, b1, ext, n)
+    b2 = {**b1, "pols": dots_out.reshape(-1).copy(), "challenges": ext}
+    orc.expr_run(row.code, row.ntmp1, row.ntmp3, b2, 0, n, info["n_const"], info["n_const2"])
+    assert (b2["f_2ns"] == b0["f_2ns"]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prog,n", [("zkevm", 3000), ("recursive2", 1 << 12)])
+def test_fri_polynomial_as_dot_columns_on_the_gpu(xlp, orc, prog, n):
+    """table program (VM, one row) -> xlp_dev_dot_columns over the sections -> 12-instruction row program (VM), all on the GPU,
+    against the reference's step52ns on the oracle"""
+    import torch
+    from tests import expr_real as R
+    from xlayer_prover_amd import expr_opt
+    path = os.path.join(R.REF_DIR, f"{prog}.step52ns.xlpexpr")
+    if not os.path.exists(path):
+        pytest.skip("converted reference programs not built (needs the reference tree at build time)")
+    code, n1, n3 = R.read_program(path)
+    nch = 8
+    (c0,), info = R.shrink_many([code], n)
+    row, tab, n_ext, st, dots = expr_opt.horner_to_dot(c0, n1, n3, nch, outsource_min_terms=8)
+    b0 = R.buffers(lambda cnt, seed: orc.fill(cnt, seed), 11, n, info)
+    b0["challenges"] = orc.fill(3 * nch, 99)
+    dev = {k: xlp.from_np(v) for k, v in b0.items()}
+    ext = xlp.from_np(np.concatenate([b0["challenges"], np.zeros(3 * (n_ext - nch), np.uint64)]))
+    pt = xlp.ExprProgram(tab.code, tab.ntmp1, tab.ntmp3)
+    pt.run(xlp.steps_params(pols=ext, challenges=dev["challenges"], evals=dev["evals"]), 0, 1)
+    G = dots["ngroups"]
+    nconst2 = info["n_const2"]
+    ents = [(dev["pols"], x.params[1], x.params[0], x.dim, g, k) if x.kind == E.K_POLS else (dev["const_pols_2ns"], nconst2, x.params[0], 1, g, k)
+            for x, g, k in dots["entries"]]
+    dots_out = torch.zeros(n * 3 * G, dtype=torch.int64, device="cuda")
+    xlp.dev_dot_columns(dots_out, ents, G, ext, n)
+    pr = xlp.ExprProgram(row.code, row.ntmp1, row.ntmp3)
+    pr.run(xlp.steps_params(n_const_pols=info["n_const"], n_const_pols_2ns=nconst2, **{**dev, "pols": dots_out, "challenges": ext}), 0, n)
+    xlp.sync()
+    orc.expr_run(c0, n1, n3, b0, 0, n, info["n_const"], info["n_const2"])
+    assert (xlp.to_np(dev["f_2ns"]) == b0["f_2ns"]).all()
+    pt.close(); pr.close()

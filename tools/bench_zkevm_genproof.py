@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--lookups", type=int, default=28, help="H1H2 computations (cm2 = 168 columns = 28 x (h1, h2) in Fp^3)")
     ap.add_argument("--zs", type=int, default=40, help="grand products (calculateZ calls); their z columns land in cm3")
     ap.add_argument("--no-jit", action="store_true")
+    ap.add_argument("--no-dots", action="store_true", help="keep the FRI polynomial (step52ns) entirely in the expression VM instead of "
+                    "table program + xlp_dev_dot_columns + a 12-instruction row program")
     ap.add_argument("--vm-only", default="", help="comma-separated steps: only run these programs (twice each) on a random slab and print their times")
     ap.add_argument("--no-opt", action="store_true", help="run the step programs as converted (Horner chains) instead of their dot-product "
                     "form (xlayer_prover_amd/expr_opt.py: same values, ~6 800 fewer Fp^3 x Fp^3 products per row over the five steps)")
@@ -130,6 +132,26 @@ def main():
             mode[st] = "dot-product form, interpreter"
             if not a.no_jit and os.path.exists(so):
                 opt[st]["row"].attach(so); mode[st] = "dot-product form, compiled"
+    fri_dots = None
+    if not a.no_opt and not a.no_dots:
+        tabp, dots, rowp, n_ext = G.load_fri_dots(ln)
+        from xlayer_prover_amd import expr as EX
+        dents = []
+        for x, g, k in dots["entries"]:
+            if x.kind == EX.K_POLS:
+                dents.append((pols, x.params[1], x.params[0], x.dim, g, k))
+            else:
+                dents.append((const_2ns, nconst, x.params[0], 1, g, k))
+        fri_dots = {"tab": capi.ExprProgram(tabp.code, tabp.ntmp1, tabp.ntmp3), "row": capi.ExprProgram(rowp.code, rowp.ntmp1, rowp.ntmp3),
+                    "ext": torch.zeros(3 * n_ext, dtype=i64, device=dev), "G": dots["ngroups"], "entries": capi.dot_entries(dents),
+                    "out": torch.empty(NE * 3 * dots["ngroups"], dtype=i64, device=dev)}
+        so = os.path.join(R.REF_DIR, f"zkevm.step52ns_tab.geo{ln}.so")
+        if not a.no_jit and os.path.exists(so):
+            try:
+                fri_dots["tab"].attach(so)
+            except capi.XlpError as e:                     # built from another version of the table program
+                print("table program plugin not attached:", e, file=sys.stderr)
+        mode["step52ns"] = f"table program + dot_columns ({len(dents)} entries, {dots['ngroups']} groups) + {rowp.ninstr}-instruction row program"
     ents, ev_ids = evmap_from_step52ns(progs["step52ns"][0], L, const_2ns, nconst, pols)
     ev_arr = capi.evmap_entries(ents)
     ev_out = torch.zeros(3 * len(ents), dtype=i64, device=dev)
@@ -149,6 +171,14 @@ def main():
         sp = capi.steps_params(n_const_pols=nconst, n_const_pols_2ns=nconst, pols=pols, const_pols=const_n, const_pols_2ns=const_2ns,
                                challenges=capi.from_np(challenges), public_inputs=capi.from_np(publics), evals=evals_d, x_n=x_n, x_2ns=x_2ns,
                                zi=zi, x_div_x_sub_xi=xdx, x_div_x_sub_wxi=xdwx, q_2ns=sec("q_2ns"), f_2ns=sec("f_2ns"))
+        if step == "step52ns" and fri_dots is not None:
+            o = fri_dots
+            o["ext"][:3 * G.NCH] = sp._keep["challenges"][:3 * G.NCH]
+            o["tab"].run(capi.steps_params(pols=o["ext"], challenges=sp._keep["challenges"], evals=evals_d), 0, 1)
+            capi.dev_dot_columns(o["out"], o["entries"], o["G"], o["ext"], nrows)
+            sp2 = capi.steps_params(n_const_pols=nconst, n_const_pols_2ns=nconst, **{**sp._keep, "pols": o["out"], "challenges": o["ext"]})
+            o["row"].run(sp2, 0, nrows)
+            return
         if step in opt:
             # powers of the challenges and the evaluation constants: one row of work, once per proof
             o = opt[step]

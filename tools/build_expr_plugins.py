@@ -31,11 +31,16 @@ def main():
         for st, v in G.load_opt(a.geometry).items():
             geo[st + "_opt"] = v[0]
         sizes = ["geo"]
+        want52 = "step52ns" in a.steps.split(",")
         a.steps = ",".join(x for st in a.steps.split(",") for x in (st, st + "_opt"))
+        if want52:                                        # the one-row table program of the dot-columns form of step52ns
+            tabp = G.load_fri_dots(a.geometry)[0]
+            geo["step52ns_tab"] = (tabp.code, tabp.ntmp1, tabp.ntmp3)
+            a.steps += ",step52ns_tab"
     for size in sizes:
         for step in a.steps.split(","):
             lr = (24 if step.endswith("2ns") else 23) if size in ("full", "geo") else size
-            src = os.path.join(R.REF_DIR, f"zkevm.{step.replace('_opt', '')}.xlpexpr")
+            src = os.path.join(R.REF_DIR, f"zkevm.{step.replace('_opt', '').replace('_tab', '')}.xlpexpr")
             name = f"zkevm.{step}.geo{a.geometry}" if geo else f"zkevm.{step}.n{lr}"
             so = os.path.join(R.REF_DIR, name + ".so")
             if not os.path.exists(src):

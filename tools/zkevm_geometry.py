@@ -94,3 +94,14 @@ def load_opt(log_n):
         row, tab, n_ext, stats = expr_opt.horner_to_dot(code, n1, n3, NCH)
         res[step] = ((row.code, row.ntmp1, row.ntmp3), tab, n_ext, stats)
     return res
+
+
+def load_fri_dots(log_n):
+    """step52ns as (table Program, dot-columns groups, 12-instruction row Program, n_ext): xlayer_prover_amd/expr_opt.py with
+    its big sums handed to xlp_dev_dot_columns"""
+    from xlayer_prover_amd import expr_opt
+    progs, _ = load(log_n)
+    code, n1, n3 = progs["step52ns"]
+    row, tab, n_ext, stats, dots = expr_opt.horner_to_dot(code, n1, n3, NCH, outsource_min_terms=8)
+    assert dots is not None
+    return tab, dots, row, n_ext

@@ -445,7 +445,22 @@ int dev_evmap(Ctx* ctx, u64* evals, const u64* LEv, const u64* LpEv, u64 n, u32 
 // requested columns; per window the workgroup loads a DC_RT x DC_CB tile with row-contiguous (coalesced) reads, stores it
 // transposed in LDS, and every lane (= one row) walks the window's items: the coefficient is wave-uniform (scalar loads),
 // the value comes from LDS, base-field products are accumulated unreduced in 128 bits + overflow count (2^128 = -2^32).
-constexpr int DC_RT = 256, DC_CB = 16;
+constexpr int DC_RT = 256, DC_CB = 16, DC_IB = 4;   // rows per workgroup, words per window, items per scalar-load batch
+
+// (ovf : hi : lo) += a * b with explicit 32-bit carry chains (a 128-bit compare per product costs more than the product)
+__device__ __forceinline__ void dc_mac(u64& lo, u64& hi, u32& ovf, u64 a, u64 b)
+{
+    const unsigned __int128 pr = (unsigned __int128)a * b;
+    const u64 pl = (u64)pr, ph = (u64)(pr >> 64);
+    u32 c0, c1, c2, c3, c4;
+    const u32 l0 = __builtin_addc((u32)lo, (u32)pl, 0u, &c0);
+    const u32 l1 = __builtin_addc((u32)(lo >> 32), (u32)(pl >> 32), c0, &c1);
+    const u32 h0 = __builtin_addc((u32)hi, (u32)ph, c1, &c2);
+    const u32 h1 = __builtin_addc((u32)(hi >> 32), (u32)(ph >> 32), c2, &c3);
+    ovf = __builtin_addc(ovf, 0u, c3, &c4);
+    lo = gl::pack(l0, l1);
+    hi = gl::pack(h0, h1);
+}
 
 template <int G>
 __global__ __launch_bounds__(DC_RT) void dot_columns_kernel(u64* out, const u64* plan, u32 nwindows, const u64* coefs, u64 nrows)
@@ -453,56 +468,68 @@ __global__ __launch_bounds__(DC_RT) void dot_columns_kernel(u64* out, const u64*
     __shared__ u64 tile[DC_CB][DC_RT + 1];
     const u32 t = threadIdx.x;
     const u64 row0 = (u64)blockIdx.x * DC_RT;
-    unsigned __int128 s128[G][3];
+    u64 lo[G][3], hi[G][3];                                // 192-bit unreduced sums: (ovf : hi : lo)
     u32 ovf[G][3];
     e3 acc3[G];
 #pragma unroll
     for (int g = 0; g < G; g++)
 #pragma unroll
-        for (int c = 0; c < 3; c++) { s128[g][c] = 0; ovf[g][c] = 0; acc3[g].c[c] = 0; }
+        for (int c = 0; c < 3; c++) { lo[g][c] = 0; hi[g][c] = 0; ovf[g][c] = 0; acc3[g].c[c] = 0; }
+    // lane -> (row t / 16 of a pass, word t % 16): one wave instruction reads 4 rows x 128 contiguous bytes.  The words of the
+    // NEXT window are fetched into registers while the current one is consumed from LDS.
+    const u32 lc = t & (DC_CB - 1), rs = t >> 4;
+    u64 pre[DC_CB];
+    auto fetch = [&](const u64* hdr) {
+        gptr_t src = (gptr_t)hdr[0] + (row0 + rs) * hdr[1] + lc;
+        const u32 ncols = (u32)hdr[2];
+        const u64 step = (u64)(DC_RT / DC_CB) * hdr[1];
+#pragma unroll
+        for (int pass = 0; pass < DC_CB; pass++)
+            pre[pass] = (lc < ncols && row0 + pass * (DC_RT / DC_CB) + rs < nrows) ? src[(u64)pass * step] : 0;
+    };
+    auto item = [&](u64 it, u64 k0, u64 k1, u64 k2) {
+        const u32 c = (u32)it & 255, dim = ((u32)it >> 8) & 255, g = ((u32)it >> 16) & 255;
+        if (dim == 1) {
+            const u64 v = tile[c][t];
+#pragma unroll
+            for (int gg = 0; gg < G; gg++)
+                if (g == (u32)gg) {
+                    dc_mac(lo[gg][0], hi[gg][0], ovf[gg][0], k0, v);
+                    dc_mac(lo[gg][1], hi[gg][1], ovf[gg][1], k1, v);
+                    dc_mac(lo[gg][2], hi[gg][2], ovf[gg][2], k2, v);
+                }
+        } else if (dim == 3) {
+            e3 a, x;
+            a.c[0] = gl::canon(k0); a.c[1] = gl::canon(k1); a.c[2] = gl::canon(k2);
+            x.c[0] = gl::canon(tile[c][t]); x.c[1] = gl::canon(tile[c + 1][t]); x.c[2] = gl::canon(tile[c + 2][t]);
+            const e3 m = gl::mul3(a, x);
+#pragma unroll
+            for (int gg = 0; gg < G; gg++)
+                if (g == (u32)gg) acc3[gg] = gl::add3(acc3[gg], m);
+        }                                                  // dim 0: padding
+    };
     const u64* p = plan;
+    if (nwindows) fetch(p);
     for (u32 w = 0; w < nwindows; w++) {
-        gptr_t base = (gptr_t)p[0];
-        const u64 stride = p[1];
-        const u32 ncols = (u32)p[2], nitems = (u32)(p[2] >> 32);
-        p += 3;
+        const u32 nitems = (u32)(p[2] >> 32);              // a multiple of DC_IB (padded on the host)
+        p += 4;
         __syncthreads();                                   // previous window fully consumed
 #pragma unroll
-        for (int pass = 0; pass < 2; pass++) {
-            const u32 r = pass * (DC_RT / 2) + (t >> 1), c0 = (t & 1) * (DC_CB / 2);
-            if (row0 + r < nrows) {
-                gptr_t src = base + (row0 + r) * stride + c0;
-#pragma unroll
-                for (int j = 0; j < DC_CB / 2; j++)
-                    if (c0 + j < ncols) tile[c0 + j][r] = src[j];
-            }
-        }
+        for (int pass = 0; pass < DC_CB; pass++) tile[lc][pass * (DC_RT / DC_CB) + rs] = pre[pass];
         __syncthreads();
-        for (u32 i = 0; i < nitems; i++) {
-            const u64 it = p[i];                           // wave-uniform
-            const u32 c = (u32)it & 255, dim = ((u32)it >> 8) & 255, g = ((u32)it >> 16) & 255;
-            const u64* k = coefs + 3 * (it >> 32);
-            const u64 k0 = k[0], k1 = k[1], k2 = k[2];
-            if (dim == 1) {
-                const u64 v = tile[c][t];
+        if (w + 1 < nwindows) fetch(p + 4 * nitems);
+        // items are wave-uniform records {meta, k0, k1, k2} (coefficients copied in by dot_expand_kernel): a batch of DC_IB is
+        // read with independent scalar loads before any of it is used, so their latency is paid once per batch
+        for (u32 i = 0; i < nitems; i += DC_IB) {
+            u64 r[DC_IB][4];
 #pragma unroll
-                for (int gg = 0; gg < G; gg++)
-                    if (g == (u32)gg) {
-                        unsigned __int128 pr = (unsigned __int128)k0 * v; s128[gg][0] += pr; ovf[gg][0] += s128[gg][0] < pr;
-                        pr = (unsigned __int128)k1 * v; s128[gg][1] += pr; ovf[gg][1] += s128[gg][1] < pr;
-                        pr = (unsigned __int128)k2 * v; s128[gg][2] += pr; ovf[gg][2] += s128[gg][2] < pr;
-                    }
-            } else {
-                e3 a, x;
-                a.c[0] = gl::canon(k0); a.c[1] = gl::canon(k1); a.c[2] = gl::canon(k2);
-                x.c[0] = gl::canon(tile[c][t]); x.c[1] = gl::canon(tile[c + 1][t]); x.c[2] = gl::canon(tile[c + 2][t]);
-                const e3 m = gl::mul3(a, x);
+            for (int j = 0; j < DC_IB; j++)
 #pragma unroll
-                for (int gg = 0; gg < G; gg++)
-                    if (g == (u32)gg) acc3[gg] = gl::add3(acc3[gg], m);
-            }
+                for (int q = 0; q < 4; q++) r[j][q] = p[4 * (i + j) + q];
+#pragma unroll
+            for (int j = 0; j < DC_IB; j++) item(r[j][0], r[j][1], r[j][2], r[j][3]);
         }
-        p += nitems;
+        p += 4 * nitems;
     }
     if (row0 + t >= nrows) return;
     u64* dst = out + (row0 + t) * (3 * G);
@@ -510,9 +537,21 @@ __global__ __launch_bounds__(DC_RT) void dot_columns_kernel(u64* out, const u64*
     for (int g = 0; g < G; g++)
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const u64 r = gl::canon(gl::reduce128((u64)s128[g][c], (u64)(s128[g][c] >> 64)));
+            const u64 r = gl::canon(gl::reduce128(lo[g][c], hi[g][c]));
             dst[3 * g + c] = gl::addc(acc3[g].c[c], gl::subc(r, gl::mulc((u64)ovf[g][c], 1ULL << 32)));
         }
+}
+
+// plan records are 4 words; item records {meta, coefficient index, -, -} become {meta, k0, k1, k2}
+__global__ void dot_expand_kernel(u64* plan, u64 nrecords, const u64* coefs)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrecords) return;
+    u64* r = plan + 4 * i;
+    if (r[3] != ~0ULL) return;                             // a window header
+    const u64* k = coefs + 3 * r[1];
+    const u64 k0 = k[0], k1 = k[1], k2 = k[2];
+    r[1] = k0; r[2] = k1; r[3] = k2;
 }
 
 int dev_dot_columns(Ctx* ctx, u64* out, const xlp_dot_entry* entries, u64 nentries, u32 ngroups, const u64* coefs, u64 coefs_size, u64 nrows)
@@ -538,11 +577,16 @@ int dev_dot_columns(Ctx* ctx, u64* out, const xlp_dot_entry* entries, u64 nentri
             ncols = std::max<u32>(ncols, (u32)(e[j].pol - w0) + e[j].dim);
             j++;
         }
+        const u32 nitems = (u32)((j - i + DC_IB - 1) / DC_IB * DC_IB);
         plan.push_back((u64)(uintptr_t)w0);
         plan.push_back(e[i].row_stride);
-        plan.push_back((u64)ncols | ((u64)(j - i) << 32));
-        for (size_t k = i; k < j; k++)
-            plan.push_back((u64)(e[k].pol - w0) | ((u64)e[k].dim << 8) | ((u64)e[k].group << 16) | (e[k].coef << 32));
+        plan.push_back((u64)ncols | ((u64)nitems << 32));
+        plan.push_back(0);
+        for (size_t k = i; k < j; k++) {
+            plan.push_back((u64)(e[k].pol - w0) | ((u64)e[k].dim << 8) | ((u64)e[k].group << 16));
+            plan.push_back(e[k].coef); plan.push_back(0); plan.push_back(~0ULL);
+        }
+        for (size_t k = j - i; k < nitems; k++) { plan.push_back(0); plan.push_back(0); plan.push_back(0); plan.push_back(0); }   // dim 0
         nwindows++;
         i = j;
     }
@@ -550,6 +594,8 @@ int dev_dot_columns(Ctx* ctx, u64* out, const xlp_dot_entry* entries, u64 nentri
     if (ctx_scratch(ctx, std::max<size_t>(plan.size() * 8, 8), 2, &dplan)) return -1;
     if (!plan.empty()) XLP_HIP(hipMemcpyAsync(dplan, plan.data(), plan.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     XLP_HIP(hipStreamSynchronize(ctx->stream));            // plan goes out of scope
+    if (!plan.empty())
+        hipLaunchKernelGGL(dot_expand_kernel, dim3((unsigned)((plan.size() / 4 + 255) / 256)), dim3(256), 0, ctx->stream, dplan, (u64)(plan.size() / 4), coefs);
     const dim3 grid((unsigned)((nrows + DC_RT - 1) / DC_RT)), block(DC_RT);
     switch (ngroups) {
     case 1: hipLaunchKernelGGL(dot_columns_kernel<1>, grid, block, 0, ctx->stream, out, dplan, nwindows, coefs, nrows); break;

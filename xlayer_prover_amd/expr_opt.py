@@ -23,6 +23,14 @@ canonical values as the original.
     n_ext, statistics.
 Both are ordinary VM programs: nothing changes in the interpreter or the code generator.
 
+With `outsource_min_terms=k` every sum of >= k terms whose terms are all plain columns becomes one GROUP of
+`xlp_dev_dot_columns` (csrc/polinomial.hip: sections read once, coalesced, products accumulated unreduced) instead of VM
+instructions; a fifth value describes the groups (`{"ngroups", "entries": [(column operand, group, coefficient index)]}`)
+and the row program then reads group g as the Fp^3 column 3g of ITS `pols` buffer = the kernel's output (rows x 3 ngroups).
+This is only offered when the row program is left without any read of a real column (the FRI-polynomial programs are:
+zkEVM step52ns becomes 3 groups of 2 992 entries + 12 instructions); otherwise the fifth value is None and the inline form
+is returned.
+
 How: every extension temporary is tracked symbolically as  base v^b + sum (+-) col v^p - sum (+-) evals[e] v^p  for as long
 as the program only shifts it (multiplies by the chain's challenge) or adds / subtracts columns, `col - evals[e]` values
 values, constants, other temporaries or other such values; base-field temporaries that are plain copies of a column stand
@@ -57,7 +65,12 @@ class _Lin:
         return self.c is None or o.c is None or self.c == o.c
 
 
-def horner_to_dot(code, ntmp1, ntmp3, nch):
+def horner_to_dot(code, ntmp1, ntmp3, nch, outsource_min_terms=0, _ngroups=None):
+    if outsource_min_terms and _ngroups is None:          # first pass counts the dot-product groups (their row stride)
+        probe = horner_to_dot(code, ntmp1, ntmp3, nch, outsource_min_terms, _ngroups=1)
+        if probe[4] is None:
+            return horner_to_dot(code, ntmp1, ntmp3, nch) + (None,)
+        return horner_to_dot(code, ntmp1, ntmp3, nch, outsource_min_terms, _ngroups=probe[4]["ngroups"])
     out, tab = E.Program(), E.Program()
     scratch = E.tmp3(ntmp3)                                  # one more extension temporary for the products
     state = {}                                               # tmp3 slot -> _Lin (value not in its register yet)
@@ -65,6 +78,8 @@ def horner_to_dot(code, ntmp1, ntmp3, nch):
     powers = {}                                              # (c, j) -> table index of v_c^j
     n_ext = [nch]
     stats = {"dot_products": 0, "ext_mul_before": 0, "ext_mul_after": 0}
+    dots = {"ngroups": 0, "entries": []}                     # big all-column sums handed to xlp_dev_dot_columns
+    negs = {}
 
     def entry():
         n_ext[0] += 1
@@ -88,12 +103,84 @@ def horner_to_dot(code, ntmp1, ntmp3, nch):
         need_power(c, j)
         return E.challenge(c) if j == 1 else tab_pols(powers[(c, j)])
 
+    alphas = {}
+
+    def alpha_times(idx):
+        """table entry holding k * a for the entry / challenge k = idx (a: the generator of Fp^3, a^3 = a + 1):
+        (k0, k1, k2) a = (k2, k0 + k2, k1)"""
+        if idx not in alphas:
+            src = idx
+            if idx < nch:                                    # a challenge: its components are only addressable from the table
+                src = entry()
+                tab.copy(tab_pols(src), E.challenge(idx))
+            j = entry()
+            w = lambda e, c: E.pols(3 * e + c, 3, 1)
+            tab.copy(w(j, 0), w(src, 2)).add(w(j, 1), w(src, 0), w(src, 2)).copy(w(j, 2), w(src, 1))
+            alphas[idx] = j
+        return alphas[idx]
+
+    def emit_eval_constant(lin, dst):
+        """dst -= D,  D = sum (+-) evals[e] * v^p over the evaluation terms with p >= 1: one table entry"""
+        hi_e = [t for t in lin.evals if t[1] >= 1]
+        if not hi_e:
+            return
+        t0, t1 = E.tmp3(0), E.tmp3(1)
+        for k, (e, p, s) in enumerate(hi_e):
+            if k == 0:
+                tab.mul(t0, E.evaluation(e), tab_power(lin.c, p))
+                if s < 0:
+                    tab.sub(t0, E.number(0), t0)
+            else:
+                tab.mul(t1, E.evaluation(e), tab_power(lin.c, p))
+                (tab.add if s > 0 else tab.sub)(t0, t0, t1)
+        idx = entry()
+        tab.copy(tab_pols(idx), t0)
+        out.sub(dst, dst, E.challenge(idx))
+
     def materialise(slot):
         if slot not in state:
             return
         barrier(E.K_TMP3, slot, exclude=slot)                # others that read this register's present value go first
         lin = state.pop(slot)
         dst = E.tmp3(slot)
+        if outsource_min_terms and len(lin.terms) >= outsource_min_terms and \
+                all(x.kind in (E.K_POLS, E.K_CONST, E.K_CONST2NS) for x, _, _ in lin.terms):
+            # the whole sum over columns is one group of the dot-columns kernel; its result is column g of the buffer the row
+            # program gets as `pols`
+            g = dots["ngroups"]; dots["ngroups"] += 1
+            for x, p, sg in lin.terms:
+                if p >= 2:
+                    need_power(lin.c, p)
+                idx = one_entry() if p == 0 else (lin.c if p == 1 else powers[(lin.c, p)])
+                if sg < 0:
+                    if idx not in negs:
+                        negs[idx] = entry()
+                        tab.sub(E.tmp3(0), E.challenge(0), E.challenge(0)).sub(tab_pols(negs[idx]), E.tmp3(0),
+                                                                                E.challenge(idx) if idx < nch else tab_pols(idx))
+                    idx = negs[idx]
+                if x.dim == 1:
+                    dots["entries"].append((x, g, idx))
+                else:
+                    # k * (x0 + x1 a + x2 a^2) = x0 * k + x1 * (k a) + x2 * (k a^2): three base-field entries, so the kernel's
+                    # cheap unreduced path serves extension columns too
+                    ka = alpha_times(idx)
+                    kaa = alpha_times(ka)
+                    for w, ci in enumerate((idx, ka, kaa)):
+                        xw = E.pols(x.params[0] + w, x.params[1], 1) if x.kind == E.K_POLS else None
+                        assert xw is not None, "extension column outside pols"
+                        dots["entries"].append((xw, g, ci))
+            res = E.pols(3 * g, 3 * (_ngroups or 1), 3)
+            if lin.bpw is None:
+                out.copy(dst, res)
+            else:                                            # base * v^b + the sum
+                if lin.bpw >= 1:
+                    out.mul(dst, dst, power(lin.c, lin.bpw))
+                out.add(dst, dst, res)
+            for e, p, sg in [t for t in lin.evals if t[1] == 0]:
+                (out.sub if sg > 0 else out.add)(dst, dst, E.evaluation(e))
+            emit_eval_constant(lin, dst)
+            stats["dot_products"] += 1
+            return
         hi_t = sorted([t for t in lin.terms if t[1] >= 1], key=lambda t: -t[2])          # positive terms first
         lo_t = sorted([t for t in lin.terms if t[1] == 0], key=lambda t: -t[2])
         hi_e = [t for t in lin.evals if t[1] >= 1]
@@ -127,19 +214,7 @@ def horner_to_dot(code, ntmp1, ntmp3, nch):
         assert started, "empty symbolic value"
         for e, p, s in lo_e:
             (out.sub if s > 0 else out.add)(dst, dst, E.evaluation(e))
-        if hi_e:                                             # D = sum evals[e] * v^p, one table entry
-            t0, t1 = E.tmp3(0), E.tmp3(1)
-            for k, (e, p, s) in enumerate(hi_e):
-                if k == 0:
-                    tab.mul(t0, E.evaluation(e), tab_power(lin.c, p))
-                    if s < 0:
-                        tab.sub(t0, E.number(0), t0)
-                else:
-                    tab.mul(t1, E.evaluation(e), tab_power(lin.c, p))
-                    (tab.add if s > 0 else tab.sub)(t0, t0, t1)
-            idx = entry()
-            tab.copy(tab_pols(idx), t0)
-            out.sub(dst, dst, E.challenge(idx))
+        emit_eval_constant(lin, dst)
         if len(hi_t) > 1:
             stats["dot_products"] += 1
 
@@ -260,6 +335,11 @@ def horner_to_dot(code, ntmp1, ntmp3, nch):
     out.ntmp1 = max(out.ntmp1, ntmp1)
     out.ntmp3 = max(out.ntmp3, ntmp3 + 1)
     tab.ntmp3 = max(tab.ntmp3, 2)
+    if outsource_min_terms:
+        # the row program's `pols` will be the dot-columns result: it must not read real columns any more
+        clean = dots["ngroups"] and all(o is None or o.kind not in _COL or (o.kind == E.K_POLS and o.params[1] == 3 * (_ngroups or 1))
+                                        for _, d, a, b in E.decode(out.code) for o in (d, a, b))
+        return out, tab, n_ext[0], stats, (dots if clean else None)
     return out, tab, n_ext[0], stats
 
 
