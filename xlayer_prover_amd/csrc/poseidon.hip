@@ -30,13 +30,26 @@ __device__ __forceinline__ u64 pow7(u64 a)
     return gl::mul(a3, a4);
 }
 
+// The circulant constants, laundered into SGPRs once per kernel: as literals the compiler strength-reduces products like
+// x * 17 into shift-add pairs (v_lshl_add_u64, half rate like the multiply-add they replace, but two of them) -- 364
+// operations for the 288 multiply-adds of one MDS.  mc[12] = M[0][0] = 17 + 8.
+struct MdsConsts { u32 mc[13]; };
+__device__ __forceinline__ MdsConsts mds_consts()
+{
+    constexpr u32 MC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+    MdsConsts k;
+#pragma unroll
+    for (int i = 0; i < 12; i++) { k.mc[i] = MC[i]; asm volatile("" : "+s"(k.mc[i])); }
+    k.mc[12] = MC[0] + 8; asm volatile("" : "+s"(k.mc[12]));
+    return k;
+}
+
 // st <- M * st + c, M[i][j] = MCIRC[(j-i) mod 12] (+8 on [0][0]); inputs "any", outputs "any".
 // `c` (12 canonical words, wave-uniform -> SGPRs) is the NEXT round's constant vector: it is the
 // initial value of the multiply-add chains, so the per-round constant addition costs no instruction.
 template <bool ADDC>
-__device__ __forceinline__ void mds(u64 (&st)[12], const u64* __restrict__ c)
+__device__ __forceinline__ void mds(u64 (&st)[12], const u64* __restrict__ c, const MdsConsts& k)
 {
-    constexpr u32 MC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
     u32 lo[12], hi[12];
 #pragma unroll
     for (int j = 0; j < 12; j++) { lo[j] = (u32)st[j]; hi[j] = (u32)(st[j] >> 32); }
@@ -46,23 +59,31 @@ __device__ __forceinline__ void mds(u64 (&st)[12], const u64* __restrict__ c)
         if constexpr (ADDC) { L = (u32)c[i]; H = c[i] >> 32; }
 #pragma unroll
         for (int j = 0; j < 12; j++) {
-            const u32 m = MC[(j - i + 12) % 12] + ((i == 0 && j == 0) ? 8u : 0u);
+            const u32 m = (i == 0 && j == 0) ? k.mc[12] : k.mc[(j - i + 12) % 12];
             L += (u64)lo[j] * m;   // < 2^32 * 49 * 12 + 2^32 < 2^43
             H += (u64)hi[j] * m;
         }
-        // value = L + H*2^32 = L + Hl*2^32 + Hh*2^64 ; Hh < 2^11
-        const u64 Hl = (u64)(u32)H << 32, Hh = H >> 32;
-        u64 lo64 = L + Hl;
-        const u64 cy = lo64 < Hl;            // carry into 2^64
-        lo64 += (Hh + cy) * gl::EPS;         // (Hh+cy)*EPS < 2^44: may wrap once more
-        if (lo64 < (Hh + cy) * gl::EPS) lo64 += gl::EPS;
-        st[i] = lo64;
+        // value = L + H * 2^32 = L + Hh * 2^64 + Hl * 2^32 = (L + Hh * EPS) + Hl * 2^32 (mod p), Hh < 2^11:
+        // one multiply-add (no overflow: < 2^44), one 32-bit add into the high word, and + EPS if that carried
+        // (the wrapped value is < 2^44, so the correction cannot carry again).
+        const u32 Hl = (u32)H, Hh = (u32)(H >> 32);
+        const u64 t = (u64)Hh * 0xFFFFFFFFu + L;
+        u32 c1, c2, c3;
+        u32 rhi = __builtin_addc((u32)(t >> 32), Hl, 0u, &c1);
+        u32 rlo = (u32)t;
+        gl::opaque(rhi);
+        const u32 fix = c1 ? 0xFFFFFFFFu : 0u;
+        rlo = __builtin_addc(rlo, fix, 0u, &c2);
+        rhi = __builtin_addc(rhi, 0u, c2, &c3);
+        gl::opaque(rlo); gl::opaque(rhi);
+        st[i] = gl::pack(rlo, rhi);
     }
 }
 
 // Round r: state already holds + C[r] (added by the previous round's linear layer).
 __device__ __forceinline__ void permute(u64 (&st)[12])
 {
+    const MdsConsts k = mds_consts();
 #pragma unroll
     for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], POSEIDON_C[i]);  // any + canon
 #pragma unroll 1
@@ -73,11 +94,11 @@ __device__ __forceinline__ void permute(u64 (&st)[12])
         } else {
             st[0] = pow7(st[0]);
         }
-        mds<true>(st, &POSEIDON_C[12 * (r + 1)]);
+        mds<true>(st, &POSEIDON_C[12 * (r + 1)], k);
     }
 #pragma unroll
     for (int i = 0; i < 12; i++) st[i] = pow7(st[i]);
-    mds<false>(st, nullptr);
+    mds<false>(st, nullptr, k);
 #pragma unroll
     for (int i = 0; i < 12; i++) st[i] = gl::canon(st[i]);
 }
