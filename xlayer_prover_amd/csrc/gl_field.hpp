@@ -89,25 +89,25 @@ __device__ __forceinline__ u64 sub(u64 a, u64 b) { return subc(a, b); }  // same
 __device__ __forceinline__ u64 neg(u64 a) { return a ? P - a : 0; }  // canon -> canon
 
 // lo + hl*EPS - hh  (mod p) -> any, where (hh:hl) = hi.   This is (hi:lo) mod p.
+// Both wrap-arounds are settled together: l = lo - hh may borrow (b: the true value is l - 2^64), s = l + hl*EPS may
+// carry (c: the true value is s + 2^64); net (c - b) * 2^64 = (c - b) * EPS.  c = 1, b = 0: s < 2^64 - 2^33 + 1, adding
+// EPS cannot carry.  b = 1, c = 0: l >= 2^64 - 2^32 and so is s, subtracting EPS cannot borrow.  b = c: nothing to do.
 __device__ __forceinline__ u64 reduce128(u64 lo, u64 hi)
 {
     const u32 hh = (u32)(hi >> 32), hl = (u32)hi;
-    u32 b1, b2, b3, b4;
+    u32 b1, b2;
     u32 l0 = __builtin_subc((u32)lo, hh, 0u, &b1);
     u32 l1 = __builtin_subc((u32)(lo >> 32), 0u, b1, &b2);
     opaque(l0); opaque(l1);
-    u32 m = b2 ? 0xFFFFFFFFu : 0u;            // borrow: +p (no second borrow: lo - hh > -2^32)
-    l0 = __builtin_subc(l0, m, 0u, &b3);
-    l1 = __builtin_subc(l1, 0u, b3, &b4);
-    opaque(l0); opaque(l1);
-    const u64 t1 = (u64)hl * 0xFFFFFFFFu;     // hl * EPS <= 2^64 - 2^33 + 1
-    u32 c1, c2, c3, c4;
-    u32 r0 = __builtin_addc(l0, (u32)t1, 0u, &c1);
-    u32 r1 = __builtin_addc(l1, (u32)(t1 >> 32), c1, &c2);
-    opaque(r0); opaque(r1);
-    u32 m2 = c2 ? 0xFFFFFFFFu : 0u;           // carry: 2^64 = EPS (no second carry)
-    r0 = __builtin_addc(r0, m2, 0u, &c3);
-    r1 = __builtin_addc(r1, 0u, c3, &c4);
+    const u64 l = pack(l0, l1);
+    const u64 s = (u64)hl * 0xFFFFFFFFu + l;  // one v_mad_u64_u32
+    const bool c = s < l;
+    // delta = (c - b) * EPS as a 64-bit two's complement word: +EPS = (0, FFFFFFFF), -EPS = (FFFFFFFF, 00000001)
+    const u32 dlo = c ? (b2 ? 0u : 0xFFFFFFFFu) : (b2 ? 1u : 0u);
+    const u32 dhi = (b2 && !c) ? 0xFFFFFFFFu : 0u;
+    u32 c1, c2;
+    u32 r0 = __builtin_addc((u32)s, dlo, 0u, &c1);
+    u32 r1 = __builtin_addc((u32)(s >> 32), dhi, c1, &c2);
     opaque(r0); opaque(r1);
     return pack(r0, r1);
 }
