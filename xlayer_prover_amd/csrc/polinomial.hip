@@ -335,81 +335,82 @@ int dev_copy_cols(Ctx* ctx, u64* dst, u64 dst_stride, const u64* src, u64 src_st
 // neighbouring entries are neighbouring columns of one row-major section, so a wave reads contiguous bytes of a
 // row (a column-per-block layout gathers 8 bytes per 128-byte line: 15x slower at zkEVM widths).  L[k] is
 // wave-uniform per prime flag (one broadcast line).  Blocks cover EV_ROWS rows x EV_T entries and write partial sums
-// partial[chunk][original entry][3]; evmap_final_kernel adds the chunks.
+// partial[chunk][sub-entry][3]; evmap_final_kernel adds the chunks.
+// An extension column (x0, x1, x2) is entered as THREE base-field sub-entries: L * (x0 + x1 a + x2 a^2) =
+// x0 * L + x1 * (a L) + x2 * (a^2 L) with a L = (l2, l0 + l2, l1), a^2 L = (l1, l1 + l2, l0 + l2) -- so every lane runs the
+// same unreduced multiply-accumulate (a wave with one extension lane used to drag all 64 through a full Fp^3 product per row).
 constexpr int EV_T = 256, EV_ROWS = 4096, EV_SUB = 512;   // rows per block / rows of L staged in LDS at a time
-struct EvEntryDev { const u64* pol; u64 stride; u32 dim; u32 prime; u32 orig; u32 pad; };
+struct EvEntryDev { const u64* pol; u64 stride; u32 variant; u32 prime; u32 sub; u32 pad; };
 typedef const __attribute__((address_space(1))) u64* gptr_t;   // entry pointers come from memory: tell the compiler they are global
 
-__global__ __launch_bounds__(EV_T) void evmap_partial_kernel(u64* partial, const u64* LEv, const u64* LpEv, u64 n, u32 eb, const EvEntryDev* ents, u32 nev)
+__global__ __launch_bounds__(EV_T) void evmap_partial_kernel(u64* partial, const u64* LEv, const u64* LpEv, u64 n, u32 eb, const EvEntryDev* ents, u32 nsub)
 {
-    __shared__ u64 sL[2][EV_SUB * 3];                      // LEv / LpEv rows of the current sub-chunk (24 KiB)
+    __shared__ u64 sL[2][EV_SUB * 5];                      // per row of LEv / LpEv: l0, l1, l2, l0 + l2, l1 + l2 (40 KiB)
     const u32 ei = blockIdx.x * EV_T + threadIdx.x;          // entry blocks fastest: the blocks of one row range run together
-    const bool live = ei < nev;
+    const bool live = ei < nsub;
     EvEntryDev e = ents[live ? ei : 0];
     const u64 k0 = (u64)blockIdx.y * EV_ROWS;
     const u64 k1 = k0 + EV_ROWS < n ? k0 + EV_ROWS : n;
     const u64 rstep = e.stride << eb;
     gptr_t b = (gptr_t)e.pol + k0 * rstep;
     const u64* l = sL[e.prime ? 1 : 0];
+    // the multiplier's components for this lane: L -> (0, 1, 2), a L -> (2, 3, 1), a^2 L -> (1, 4, 3)
+    const u32 i0 = e.variant == 0 ? 0 : (e.variant == 1 ? 2 : 1), i1 = e.variant == 0 ? 1 : (e.variant == 1 ? 3 : 4), i2 = e.variant == 0 ? 2 : (e.variant == 1 ? 1 : 3);
     // lazy accumulation: the 128-bit products of a row are added unreduced into (lo, hi, overflow count); one
     // reduction per block (2^128 = -2^32 mod p) instead of a multiply-reduce and an add-reduce per term
     unsigned __int128 s128[3] = {0, 0, 0};
     u32 ovf[3] = {0, 0, 0};
-    e3 acc3; acc3.c[0] = acc3.c[1] = acc3.c[2] = 0;         // dim-3 entries: plain extension arithmetic
     constexpr int U = 8;                                   // rows in flight per lane
     for (u64 s0 = k0; s0 < k1; s0 += EV_SUB) {
         const u32 rows = (u32)(k1 - s0 < EV_SUB ? k1 - s0 : EV_SUB);
         __syncthreads();                                   // previous sub-chunk fully consumed
-        for (u32 i = threadIdx.x; i < rows * 3; i += EV_T) { sL[0][i] = gl::canon(LEv[3 * s0 + i]); sL[1][i] = gl::canon(LpEv[3 * s0 + i]); }
+        for (u32 i = threadIdx.x; i < rows * 2; i += EV_T) {
+            const u32 r = i >> 1;
+            const u64* src = (i & 1) ? LpEv : LEv;
+            u64* d = &sL[i & 1][5 * r];
+            const u64 a0 = gl::canon(src[3 * (s0 + r)]), a1 = gl::canon(src[3 * (s0 + r) + 1]), a2 = gl::canon(src[3 * (s0 + r) + 2]);
+            d[0] = a0; d[1] = a1; d[2] = a2; d[3] = gl::addc(a0, a2); d[4] = gl::addc(a1, a2);
+        }
         __syncthreads();
         if (!live) continue;
-        if (e.dim == 1) {
-            u32 k = 0;
-            for (; k + U <= rows; k += U, b += U * rstep) {
-                u64 v[U];
+        u32 k = 0;
+        for (; k + U <= rows; k += U, b += U * rstep) {
+            u64 v[U];
 #pragma unroll
-                for (int j = 0; j < U; j++) v[j] = b[j * rstep];
+            for (int j = 0; j < U; j++) v[j] = b[j * rstep];
 #pragma unroll
-                for (int j = 0; j < U; j++)
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        const unsigned __int128 pr = (unsigned __int128)l[3 * (k + j) + c] * v[j];
-                        s128[c] += pr;
-                        ovf[c] += s128[c] < pr;
-                    }
+            for (int j = 0; j < U; j++) {
+                const u64* lr = l + 5 * (k + j);
+                unsigned __int128 pr = (unsigned __int128)lr[i0] * v[j]; s128[0] += pr; ovf[0] += s128[0] < pr;
+                pr = (unsigned __int128)lr[i1] * v[j]; s128[1] += pr; ovf[1] += s128[1] < pr;
+                pr = (unsigned __int128)lr[i2] * v[j]; s128[2] += pr; ovf[2] += s128[2] < pr;
             }
-            for (; k < rows; k++, b += rstep)
-                for (int c = 0; c < 3; c++) {
-                    const unsigned __int128 pr = (unsigned __int128)l[3 * k + c] * b[0];
-                    s128[c] += pr;
-                    ovf[c] += s128[c] < pr;
-                }
-        } else {
-            for (u32 k = 0; k < rows; k++, b += rstep) {
-                e3 a, x;
-                a.c[0] = l[3 * k]; a.c[1] = l[3 * k + 1]; a.c[2] = l[3 * k + 2];
-                x.c[0] = gl::canon(b[0]); x.c[1] = gl::canon(b[1]); x.c[2] = gl::canon(b[2]);
-                acc3 = gl::add3(acc3, gl::mul3(a, x));
-            }
+        }
+        for (; k < rows; k++, b += rstep) {
+            const u64* lr = l + 5 * k;
+            const u64 v = b[0];
+            unsigned __int128 pr = (unsigned __int128)lr[i0] * v; s128[0] += pr; ovf[0] += s128[0] < pr;
+            pr = (unsigned __int128)lr[i1] * v; s128[1] += pr; ovf[1] += s128[1] < pr;
+            pr = (unsigned __int128)lr[i2] * v; s128[2] += pr; ovf[2] += s128[2] < pr;
         }
     }
     if (!live) return;
-    e3 acc = acc3;
-    if (e.dim == 1)
-        for (int c = 0; c < 3; c++) {
-            const u64 r = gl::canon(gl::reduce128((u64)s128[c], (u64)(s128[c] >> 64)));
-            acc.c[c] = gl::subc(r, gl::mulc((u64)ovf[c], 1ULL << 32));
-        }
-    u64* dst = partial + ((u64)blockIdx.y * nev + e.orig) * 3;
-    dst[0] = acc.c[0]; dst[1] = acc.c[1]; dst[2] = acc.c[2];
+    u64* dst = partial + ((u64)blockIdx.y * nsub + e.sub) * 3;
+    for (int c = 0; c < 3; c++) {
+        const u64 r = gl::canon(gl::reduce128((u64)s128[c], (u64)(s128[c] >> 64)));
+        dst[c] = gl::subc(r, gl::mulc((u64)ovf[c], 1ULL << 32));
+    }
 }
 
-__global__ void evmap_final_kernel(u64* evals, const u64* partial, u64 nchunks, u32 nev)
+// evals[i] = sum over the chunks and over the sub-entries first[i] .. first[i + 1] - 1 of entry i
+__global__ void evmap_final_kernel(u64* evals, const u64* partial, u64 nchunks, u32 nev, u32 nsub, const u32* first)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nev * 3) return;
+    const u32 i = t / 3, c = t % 3;
     u64 s = 0;
-    for (u64 c = 0; c < nchunks; c++) s = gl::addc(s, partial[c * nev * 3 + t]);
+    for (u32 q = first[i]; q < first[i + 1]; q++)
+        for (u64 ch = 0; ch < nchunks; ch++) s = gl::addc(s, partial[(ch * nsub + q) * 3 + c]);
     evals[t] = s;
 }
 
@@ -418,21 +419,29 @@ int dev_evmap(Ctx* ctx, u64* evals, const u64* LEv, const u64* LpEv, u64 n, u32 
     if (!nev) return 0;
     if (!n) { XLP_HIP(hipMemsetAsync(evals, 0, (size_t)nev * 24, ctx->stream)); return 0; }
     const u64 nchunks = (n + EV_ROWS - 1) / EV_ROWS;
-    u64* scratch = nullptr;
-    const size_t ent_bytes = ((size_t)nev * sizeof(EvEntryDev) + 255) / 256 * 256;
-    if (ctx_scratch(ctx, ent_bytes + nchunks * nev * 24, 2, &scratch)) return -1;
-    std::vector<EvEntryDev> h(nev);
+    std::vector<EvEntryDev> h;
+    std::vector<u32> first(nev + 1);
     for (u32 i = 0; i < nev; i++) {
         if (entries[i].dim != 1 && entries[i].dim != 3) return xlp_fail("evmap: dim must be 1 or 3");
-        h[i] = EvEntryDev{entries[i].pol, entries[i].row_stride, entries[i].dim, entries[i].prime, i, 0};
+        first[i] = (u32)h.size();
+        for (u32 v = 0; v < entries[i].dim; v++)
+            h.push_back(EvEntryDev{entries[i].pol + v, entries[i].row_stride, v, entries[i].prime, (u32)h.size(), 0});
     }
+    const u32 nsub = (u32)h.size();
+    first[nev] = nsub;
     std::stable_sort(h.begin(), h.end(), [](const EvEntryDev& x, const EvEntryDev& y) { return x.pol < y.pol; });   // lanes = neighbouring columns
-    XLP_HIP(hipMemcpyAsync(scratch, h.data(), nev * sizeof(EvEntryDev), hipMemcpyHostToDevice, ctx->stream));
-    XLP_HIP(hipStreamSynchronize(ctx->stream));   // h goes out of scope
-    u64* partial = (u64*)((char*)scratch + ent_bytes);
-    hipLaunchKernelGGL(evmap_partial_kernel, dim3((nev + EV_T - 1) / EV_T, (unsigned)nchunks), dim3(EV_T), 0, ctx->stream, partial, LEv, LpEv, n, eb,
-                       (const EvEntryDev*)scratch, nev);
-    hipLaunchKernelGGL(evmap_final_kernel, dim3((nev * 3 + 63) / 64), dim3(64), 0, ctx->stream, evals, partial, nchunks, nev);
+    u64* scratch = nullptr;
+    const size_t ent_bytes = ((size_t)nsub * sizeof(EvEntryDev) + 255) / 256 * 256;
+    const size_t first_bytes = ((size_t)(nev + 1) * 4 + 255) / 256 * 256;
+    if (ctx_scratch(ctx, ent_bytes + first_bytes + nchunks * nsub * 24, 2, &scratch)) return -1;
+    XLP_HIP(hipMemcpyAsync(scratch, h.data(), nsub * sizeof(EvEntryDev), hipMemcpyHostToDevice, ctx->stream));
+    u32* dfirst = (u32*)((char*)scratch + ent_bytes);
+    XLP_HIP(hipMemcpyAsync(dfirst, first.data(), (nev + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    XLP_HIP(hipStreamSynchronize(ctx->stream));   // h, first go out of scope
+    u64* partial = (u64*)((char*)scratch + ent_bytes + first_bytes);
+    hipLaunchKernelGGL(evmap_partial_kernel, dim3((nsub + EV_T - 1) / EV_T, (unsigned)nchunks), dim3(EV_T), 0, ctx->stream, partial, LEv, LpEv, n, eb,
+                       (const EvEntryDev*)scratch, nsub);
+    hipLaunchKernelGGL(evmap_final_kernel, dim3((nev * 3 + 63) / 64), dim3(64), 0, ctx->stream, evals, partial, nchunks, nev, nsub, dfirst);
     XLP_HIP(hipGetLastError());
     return 0;
 }
