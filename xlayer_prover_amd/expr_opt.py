@@ -23,7 +23,7 @@ canonical values as the original.
     n_ext, statistics.
 Both are ordinary VM programs: nothing changes in the interpreter or the code generator.
 
-With `outsource_min_terms=k` every sum of >= k terms whose terms are all plain columns becomes one GROUP of
+With `outsource_min_terms=k` the plain-column part (>= k terms) of every sum of columns, temporaries and constants becomes one GROUP of
 `xlp_dev_dot_columns` (csrc/polinomial.hip: sections read once, coalesced, products accumulated unreduced) instead of VM
 instructions; a fifth value describes the groups (`{"ngroups", "entries": [(column operand, group, coefficient index)]}`)
 and the row program then reads group g as the Fp^3 column 3g of ITS `pols` buffer = the kernel's output (rows x 3 ngroups).
@@ -143,12 +143,15 @@ def horner_to_dot(code, ntmp1, ntmp3, nch, outsource_min_terms=0, _ngroups=None)
         barrier(E.K_TMP3, slot, exclude=slot)                # others that read this register's present value go first
         lin = state.pop(slot)
         dst = E.tmp3(slot)
-        if outsource_min_terms and len(lin.terms) >= outsource_min_terms and \
-                all(x.kind in (E.K_POLS, E.K_CONST, E.K_CONST2NS) for x, _, _ in lin.terms):
-            # the whole sum over columns is one group of the dot-columns kernel; its result is column g of the buffer the row
-            # program gets as `pols`
+        plain = [t for t in lin.terms if t[0].kind in (E.K_POLS, E.K_CONST, E.K_CONST2NS) and (t[0].dim == 1 or t[0].kind == E.K_POLS)]
+        if outsource_min_terms and len(plain) >= outsource_min_terms and \
+                all(x.kind in (E.K_POLS, E.K_CONST, E.K_CONST2NS, E.K_TMP1, E.K_TMP3, E.K_NUMBER) for x, _, _ in lin.terms):
+            # the sum over the plain columns is one group of the dot-columns kernel; its result is column g of the buffer the
+            # row program gets as `pols`.  Terms that are temporaries or constants (e.g. the recursive STARKs add an already
+            # evaluated partial sum) stay in the row program.
+            rest = [t for t in lin.terms if not any(t is q for q in plain)]
             g = dots["ngroups"]; dots["ngroups"] += 1
-            for x, p, sg in lin.terms:
+            for x, p, sg in plain:
                 if p >= 2:
                     need_power(lin.c, p)
                 idx = one_entry() if p == 0 else (lin.c if p == 1 else powers[(lin.c, p)])
@@ -176,6 +179,12 @@ def horner_to_dot(code, ntmp1, ntmp3, nch, outsource_min_terms=0, _ngroups=None)
                 if lin.bpw >= 1:
                     out.mul(dst, dst, power(lin.c, lin.bpw))
                 out.add(dst, dst, res)
+            for x, p, sg in rest:
+                if p == 0:
+                    (out.add if sg > 0 else out.sub)(dst, dst, x)
+                else:
+                    out.mul(scratch, x, power(lin.c, p))
+                    (out.add if sg > 0 else out.sub)(dst, dst, scratch)
             for e, p, sg in [t for t in lin.evals if t[1] == 0]:
                 (out.sub if sg > 0 else out.add)(dst, dst, E.evaluation(e))
             emit_eval_constant(lin, dst)
