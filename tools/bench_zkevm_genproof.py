@@ -47,7 +47,7 @@ def evmap_from_step52ns(code, L, const_2ns, nconst, pols):
             continue
         if ak == E.K_POLS:
             off = apar[0]
-            name = [s for s, _, _ in G.SECTIONS if L[s][0] <= off][-1]
+            name = [s for s, _, ext in G.SECTIONS if ext and L[s][0] <= off < L[s][0] + L[s][1] * L[s][2]][-1]   # (sections may overlap: --aliased)
             t = (pols[L[name][0]:L[name][0] + L[name][1] * L[name][2]], L[name][1], off - L[name][0], ad)
             key = ("p", off)
         elif ak == E.K_CONST2NS:
@@ -80,14 +80,20 @@ def main():
     ap.add_argument("--vm-only", default="", help="comma-separated steps: only run these programs (twice each) on a random slab and print their times")
     ap.add_argument("--no-opt", action="store_true", help="run the step programs as converted (Horner chains) instead of their dot-product "
                     "form (xlayer_prover_amd/expr_opt.py: same values, ~6 800 fewer Fp^3 x Fp^3 products per row over the five steps)")
+    ap.add_argument("--aliased", type=int, default=-1, help="1: the one-GPU slab of tools/zkevm_geometry.py layout(aliased=True) -- cm3_2ns over the dead "
+                    "cm1_n / cm2_n, const_2ns re-extended per proof over the dead cm3_n, cm4_2ns / q / f inside tmpExp_n: 239 GB instead of 295 GB "
+                    "+ 31 GB at N = 2^23.  Default: on from --log-n 23")
     a = ap.parse_args()
     ln = a.log_n
+    aliased = (ln >= 23) if a.aliased < 0 else bool(a.aliased)
+    geo = f"geo{ln}a" if aliased else f"geo{ln}"
     N, NE = 1 << ln, 1 << (ln + 1)
     steps = [int(x) for x in a.fri_steps.split(",")] if a.fri_steps else [ln + 1] + [b for b in (ln - 4, ln - 9, ln - 13, ln - 17) if b >= 3]
     capi.init(0); capi.use_torch_stream()
-    progs, info = G.load(ln)
-    L = G.layout(ln)
+    progs, info = G.load(ln, aliased)
+    L = G.layout(ln, aliased)
     nconst = max(info["n_const"], info["n_const2"])
+    assert nconst == G.N_CONST
     dev = "cuda"
     i64 = torch.int64
 
@@ -102,7 +108,8 @@ def main():
     # ---- setup (Starks ctor: constant polynomials, their extension and tree, x tables, ZhInv) -- not part of a proof
     capi.dev_fill(sec("cm1_n"), 0x5EED0401, 0)                                      # the witness, resident
     const_n = fill(N * nconst, 0x5EED0402)
-    const_2ns = torch.empty(NE * nconst, dtype=i64, device=dev)
+    # aliased: the extended constants live over cm3_n (dead once cm3 is committed) and are re-extended in step 4 of every proof
+    const_2ns = pols[L["const_2ns"][0]:L["const_2ns"][0] + NE * nconst] if aliased else torch.empty(NE * nconst, dtype=i64, device=dev)
     capi.dev_extend(const_2ns, const_n, NE, N, nconst)
     nodesC = torch.empty((2 * NE - 1) * 4, dtype=i64, device=dev)
     capi.dev_merkle(nodesC, const_2ns, nconst, NE)
@@ -119,22 +126,22 @@ def main():
     vm, mode = {}, {}
     for s, (code, n1, n3) in progs.items():
         vm[s] = capi.ExprProgram(code, n1, n3)
-        so = os.path.join(R.REF_DIR, f"zkevm.{s}.geo{ln}.so")
+        so = os.path.join(R.REF_DIR, f"zkevm.{s}.{geo}.so")
         mode[s] = "interpreter"
         if not a.no_jit and os.path.exists(so):
             vm[s].attach(so); mode[s] = "compiled"
     opt = {}
     if not a.no_opt:
-        for st, ((rc, r1, r3), tabp, n_ext, stats) in G.load_opt(ln).items():
+        for st, ((rc, r1, r3), tabp, n_ext, stats) in G.load_opt(ln, aliased).items():
             opt[st] = {"row": capi.ExprProgram(rc, r1, r3), "tab": capi.ExprProgram(tabp.code, tabp.ntmp1, tabp.ntmp3) if tabp.ninstr else None,
                        "ext": torch.zeros(3 * n_ext, dtype=i64, device=dev)}
-            so = os.path.join(R.REF_DIR, f"zkevm.{st}_opt.geo{ln}.so")
+            so = os.path.join(R.REF_DIR, f"zkevm.{st}_opt.{geo}.so")
             mode[st] = "dot-product form, interpreter"
             if not a.no_jit and os.path.exists(so):
                 opt[st]["row"].attach(so); mode[st] = "dot-product form, compiled"
     fri_dots = None
     if not a.no_opt and not a.no_dots:
-        tabp, dots, rowp, n_ext = G.load_fri_dots(ln)
+        tabp, dots, rowp, n_ext = G.load_fri_dots(ln, aliased)
         from xlayer_prover_amd import expr as EX
         dents = []
         for x, g, k in dots["entries"]:
@@ -145,7 +152,7 @@ def main():
         fri_dots = {"tab": capi.ExprProgram(tabp.code, tabp.ntmp1, tabp.ntmp3), "row": capi.ExprProgram(rowp.code, rowp.ntmp1, rowp.ntmp3),
                     "ext": torch.zeros(3 * n_ext, dtype=i64, device=dev), "G": dots["ngroups"], "entries": capi.dot_entries(dents),
                     "out": torch.empty(NE * 3 * dots["ngroups"], dtype=i64, device=dev)}
-        so = os.path.join(R.REF_DIR, f"zkevm.step52ns_tab.geo{ln}.so")
+        so = os.path.join(R.REF_DIR, f"zkevm.step52ns_tab.{geo}.so")
         if not a.no_jit and os.path.exists(so):
             try:
                 fri_dots["tab"].attach(so)
@@ -165,7 +172,9 @@ def main():
     LEv = torch.empty(3 * N, dtype=i64, device=dev); LpEv = torch.empty(3 * N, dtype=i64, device=dev)
     qq1 = torch.empty(3 * NE, dtype=i64, device=dev); qq2 = torch.empty(6 * NE, dtype=i64, device=dev)
     torch.cuda.synchronize()
-    print(f"resident: {torch.cuda.memory_allocated() / 1e9:.1f} GB (torch) ; modes {mode}", flush=True)
+    free_b, total_b = torch.cuda.mem_get_info()
+    print(f"resident: {torch.cuda.memory_allocated() / 1e9:.1f} GB (torch), device {total_b / 1e9:.1f} GB of which {free_b / 1e9:.1f} GB free ; "
+          f"slab {L['end'][0] * 8 / 1e9:.1f} GB ({'aliased' if aliased else 'reference'} layout) ; modes {mode}", flush=True)
 
     def run(step, nrows):
         sp = capi.steps_params(n_const_pols=nconst, n_const_pols_2ns=nconst, pols=pols, const_pols=const_n, const_pols_2ns=const_2ns,
@@ -219,6 +228,10 @@ def main():
 
     for rep in range(2):                                       # pass 0 warms allocators / code objects; pass 1 is reported
         timers.clear()
+        # the witness arrives resident; everything else on the base domain starts from zero (aliased: the previous proof's
+        # cm3_2ns / const_2ns / q / f lie there)
+        pols[:L["cm1_2ns"][0]].zero_()
+        capi.dev_fill(sec("cm1_n"), 0x5EED0401, 0)
         tr = HostTranscript(capi.perm)
         tr.put([int(v) for v in capi.to_np(nodesC[-4:])]); tr.put(publics)
         torch.cuda.synchronize(); t_proof = time.perf_counter()
@@ -250,6 +263,8 @@ def main():
         roots.append(commit(3, "cm3_n", "cm3_2ns"))
         # ---- 4
         challenges[12:15] = tr.get_field()
+        if aliased:                                            # the one-GPU memory trade: 234 columns re-extended per proof
+            timed("STARK_STEP_4_CONST_LDE", lambda: capi.dev_extend(const_2ns, const_n, NE, N, nconst))
         timed("STARK_STEP_4_CALCULATE_EXPS_2NS", lambda: run("step42ns", NE))
 
         def q_poly():
@@ -317,6 +332,8 @@ def main():
         wall = time.perf_counter() - t_proof
     out = {"workload": f"genProof, all stages, one run, zkEVM geometry at N=2^{ln} (widths 751/168/408/6, {nconst} const pols, {len(ents)} evaluations, "
                        f"{a.lookups} lookups, {a.zs} grand products, FRI steps {steps}, {a.queries} queries), 1 GPU, synthetic witness",
+           "layout": "one-GPU aliased slab (tools/zkevm_geometry.py)" if aliased else "reference slab", "slab_GB": round(L["end"][0] * 8 / 1e9, 1),
+           "peak_GB_torch": round(torch.cuda.max_memory_allocated() / 1e9, 1), "device_GB": round(total_b / 1e9, 1),
            "programs": mode, "resident_GB_torch": round(torch.cuda.memory_allocated() / 1e9, 1),
            "timers_s": {k: round(v, 4) for k, v in timers.items()}, "sum_timed_s": round(sum(timers.values()), 4),
            "genproof_wall_s": round(wall, 4), "proof_elements_opened": int(opened), "roots": roots,

@@ -16,15 +16,46 @@ REAL_OFFSETS = {"cm1_n": 0, "cm2_n": 6299844608, "cm3_n": 7709130752, "cm4_n": 1
                 "q_2ns": 36809211904, "f_2ns": 36859543552, "end": 36909875200}
 
 
-def layout(log_n):
-    """section -> (offset, width, rows) for N = 2^log_n, same packing rule as the real slab"""
+def layout(log_n, aliased=False):
+    """section -> (offset, width, rows) for N = 2^log_n, same packing rule as the real slab.
+
+    aliased=True: the ONE-GPU layout.  The reference keeps all eleven sections apart in one 295 GB slab (and already lets
+    dead regions double as scratch: starks.cpp:53,102-105); a 288 GB GPU cannot, but the sections are never all alive at once:
+    the `_n` sections die with the last base-domain program (step3; only cm3_n lives on until its extension), so
+        cm3_2ns                 lies over cm1_n + the head of cm2_n     (written by the step-3 LDE, when both are dead)
+        cm4_2ns, q_2ns, f_2ns   lie inside tmpExp_n                     (written in step 4)
+        "const_2ns"             (not a slab section in the reference; 234 x 2N words) lies over cm3_n .. head of tmpExp_n and is
+                                re-extended from const_n per proof once cm3 is committed -- its tree stays resident
+    which brings the slab from 4 609 N to 3 560 N words (239 GB at N = 2^23).  Offsets are in words, like the reference's."""
     o, out = 0, {}
-    for name, w, ext in SECTIONS:
-        rows = 1 << (log_n + ext)
-        out[name] = (o, w, rows)
-        o += w * rows
+    if not aliased:
+        for name, w, ext in SECTIONS:
+            rows = 1 << (log_n + ext)
+            out[name] = (o, w, rows)
+            o += w * rows
+        out["end"] = (o, 0, 0)
+        return out
+    n = 1 << log_n
+    width = {name: w for name, w, _ in SECTIONS}
+    for name in ("cm1_n", "cm2_n", "cm3_n", "cm4_n", "tmpExp_n"):
+        out[name] = (o, width[name], n); o += width[name] * n
+    for name in ("cm1_2ns", "cm2_2ns"):
+        out[name] = (o, width[name], 2 * n); o += width[name] * 2 * n
     out["end"] = (o, 0, 0)
+    out["cm3_2ns"] = (0, width["cm3_2ns"], 2 * n)
+    assert width["cm3_2ns"] * 2 * n <= out["cm3_n"][0]
+    c2 = out["cm3_n"][0]
+    out["const_2ns"] = (c2, N_CONST, 2 * n)
+    q = c2 + N_CONST * 2 * n
+    assert q >= out["tmpExp_n"][0]
+    for name in ("cm4_2ns", "q_2ns", "f_2ns"):
+        out[name] = (q, width[name], 2 * n); q += width[name] * 2 * n
+    assert q <= out["cm1_2ns"][0]
+    out["free"] = (q, 0, 0)                       # tmpExp_n's tail: dead from step 4 on
     return out
+
+
+N_CONST = 234                                      # constant polynomials of the fork-9 zkEVM (highest const_2ns column of the step programs + 1)
 
 
 def _check_real():
@@ -33,10 +64,10 @@ def _check_real():
         assert L[k][0] == v, (k, L[k][0], v)
 
 
-def relocate(codes, log_n):
+def relocate(codes, log_n, aliased=False):
     """codes: converted zkEVM programs (real 2^23-row addressing) -> ([codes for N = 2^log_n], info)"""
     _check_real()
-    real, new = layout(LOG_N_REAL), layout(log_n)
+    real, new = layout(LOG_N_REAL), layout(log_n, aliased)
     bases = sorted((real[name][0], name) for name, _, _ in SECTIONS)
 
     def move(off, stride):
@@ -74,21 +105,21 @@ def relocate(codes, log_n):
 STEPS = ("step2prev", "step3prev", "step3", "step42ns", "step52ns")
 
 
-def load(log_n):
+def load(log_n, aliased=False):
     import os
     progs = [R.read_program(os.path.join(R.REF_DIR, f"zkevm.{s}.xlpexpr")) for s in STEPS]
-    codes, info = relocate([p[0] for p in progs], log_n)
+    codes, info = relocate([p[0] for p in progs], log_n, aliased)
     return {s: (c, p[1], p[2]) for s, c, p in zip(STEPS, codes, progs)}, info
 
 
 NCH = 8                                             # challenges of a STARK proof (starks.cpp: 0..7)
 
 
-def load_opt(log_n):
+def load_opt(log_n, aliased=False):
     """every step with its Horner chains turned into dot products (xlayer_prover_amd/expr_opt.py):
     step -> ((row code, ntmp1, ntmp3), table Program, number of extended-challenge entries, statistics)"""
     from xlayer_prover_amd import expr_opt
-    progs, _ = load(log_n)
+    progs, _ = load(log_n, aliased)
     res = {}
     for step, (code, n1, n3) in progs.items():
         row, tab, n_ext, stats = expr_opt.horner_to_dot(code, n1, n3, NCH)
@@ -96,11 +127,11 @@ def load_opt(log_n):
     return res
 
 
-def load_fri_dots(log_n):
+def load_fri_dots(log_n, aliased=False):
     """step52ns as (table Program, dot-columns groups, 12-instruction row Program, n_ext): xlayer_prover_amd/expr_opt.py with
     its big sums handed to xlp_dev_dot_columns"""
     from xlayer_prover_amd import expr_opt
-    progs, _ = load(log_n)
+    progs, _ = load(log_n, aliased)
     code, n1, n3 = progs["step52ns"]
     row, tab, n_ext, stats, dots = expr_opt.horner_to_dot(code, n1, n3, NCH, outsource_min_terms=8)
     assert dots is not None
