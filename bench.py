@@ -57,12 +57,43 @@ def cpu_baseline(log_n, ncols, budget_s=20.0):
     }
 
 
+def genproof_leg(timeout_s=420):
+    """The other half of BASELINE.json's metric: wall-clock of one whole Starks::genProof (starks.cpp:9-404, every stage, the
+    reference's converted step programs) at the fork-9 zkEVM geometry, N = 2^23, GPU-resident on this one GPU, synthetic
+    witness -- tools/bench_zkevm_genproof.py run as a child process (it needs ~293 of the 309 GB).  Reported next to the
+    headline value, never as it; any failure is reported as such and does not touch the main line."""
+    import subprocess
+    import torch
+    free_b, total_b = torch.cuda.mem_get_info()
+    log_n = 23 if free_b > 296e9 else 22
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_zkevm_genproof.py"), "--log-n", str(log_n)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+        if r.returncode != 0:
+            return {"error": (r.stderr or r.stdout)[-300:]}
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:                                   # missing converted programs, timeout, ...
+        return {"error": repr(e)[:300]}
+    t = j["timers_s"]
+    grp = lambda key: round(sum(v for k, v in t.items() if key(k)), 4)
+    return {
+        "metric": "genProof wall-clock (zkEVM STARK of genBatchProof), one GPU", "wall_s": j["genproof_wall_s"], "log_n": log_n,
+        "sum_timed_s": j["sum_timed_s"],
+        "stages_s": {"merkle": grp(lambda k: "MERKLETREE" in k), "lde": grp(lambda k: k.endswith("_LDE")),
+                     "step_programs": grp(lambda k: "CALCULATE_EXPS" in k and "INTT" not in k),
+                     "h1h2_z": grp(lambda k: "H1H2" in k or k.endswith("_Z")), "evmap_lev_xdiv": grp(lambda k: "STEP_5" in k and "EXPS" not in k),
+                     "q_intt_ntt": grp(lambda k: "INTT" in k), "fri_and_openings": grp(lambda k: k.endswith("_FRI"))},
+        "peak_GB": j.get("peak_GB_torch"), "layout": j.get("layout"), "programs": j["programs"], "workload": j["workload"],
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-genproof", action="store_true", help="skip the whole-genProof leg (N=1 only; ~25 s)")
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--ncols", type=int, default=NCOLS)
     args = ap.parse_args()
@@ -171,6 +202,10 @@ def main():
                        "columns_total": ncols * world, "sharding": "independent columns per rank, no collective"},
             "roofline": roofline,
         }
+        if world == 1 and not args.no_genproof and args.log_n == LOG_N:
+            del src, out, scratch
+            torch.cuda.empty_cache()
+            line["genproof"] = genproof_leg()
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.log_n, ncols)
         else:
