@@ -22,7 +22,8 @@ def main():
     ap.add_argument("--full", action="store_true", help="full zkEVM domains instead of --log-rows: 2^23 rows for the *prev/step3 programs, 2^24 for the 2ns ones")
     ap.add_argument("--geometry", type=int, default=0, help="log2 N: the five programs relocated to ONE zkEVM-geometry slab of 2^N rows "
                     "(tools/zkevm_geometry.py, used by tools/bench_zkevm_genproof.py) -> zkevm.<step>.geo<N>.so")
-    ap.add_argument("--opt-only", action="store_true", help="with --geometry: only the dot-product forms (what the genProof bench runs by default)")
+    ap.add_argument("--opt-only", action="store_true", help="with --geometry: only the dot-product forms of steps 2-4 (what the genProof bench runs by default; the one-row table "
+                    "program of step52ns costs the same few ms interpreted and the longest build)")
     ap.add_argument("--aliased", action="store_true", help="with --geometry: the one-GPU aliased slab layout -> zkevm.<step>.geo<N>a.so")
     a = ap.parse_args()
     sizes = ["full"] if a.full else [int(x) for x in a.log_rows.split(",")]
@@ -35,7 +36,7 @@ def main():
         sizes = ["geo"]
         want52 = "step52ns" in a.steps.split(",")
         a.steps = ",".join(x for st in a.steps.split(",") for x in ((st + "_opt",) if a.opt_only else (st, st + "_opt")) if x != "step52ns_opt" or not a.opt_only)
-        if want52:                                        # the one-row table program of the dot-columns form of step52ns
+        if want52 and not a.opt_only:                     # the one-row table program of the dot-columns form of step52ns
             tabp = G.load_fri_dots(a.geometry, a.aliased)[0]
             geo["step52ns_tab"] = (tabp.code, tabp.ntmp1, tabp.ntmp3)
             a.steps += ",step52ns_tab"
