@@ -144,9 +144,7 @@ def prove_sharded(B, nbits, fri_steps, nqueries, seed=1, group=None, collectives
     def all_rows(t_local):
         if world == 1 and not collectives:
             return t_local
-        parts = [torch.empty_like(t_local) for _ in range(world)]
-        dist.all_gather(parts, t_local.contiguous(), group=group)
-        return torch.cat(parts)
+        return torch.cat(shard._all_gather(t_local, group))
 
     out = {"publics": [int(v) for v in publics]}
     tr = flow.HostTranscript(B.perm)

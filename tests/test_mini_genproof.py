@@ -79,6 +79,70 @@ def test_sharded_genproof_on_one_gpu_equals_oracle(orc, nbits, steps, nq, coll):
         assert got[k] == exp[k], k
 
 
+def _two_rank_gpu_worker(rank, world, port, nbits, steps, nq, q):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from xlayer_prover_amd import capi
+    from tests import mini_genproof_sharded as sh
+    from tests.mini_backends import GpuBackend
+    torch.cuda.set_device(0)
+    capi.init(0); capi.use_torch_stream()
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = sh.prove_sharded(GpuBackend(capi), nbits, steps, nq, seed=nbits)
+        q.put((rank, out))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_genproof_ranks_on_one_gpu_equal_oracle(orc, world):
+    """the row-sharded genProof with EVERY kernel on the HIP library and a real exchange between `world` processes: the ranks
+    share the one GPU of the test box, so the transport is gloo with the device tensors staged through the host
+    (shard._host_staged) -- RCCL wants one GPU per rank; its world-of-one run is the test above.  Every rank's proof equals the
+    single-process oracle proof bit for bit."""
+    import multiprocessing as mp
+    import os
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    nbits, steps, nq = 9, [10, 6, 3], 9
+    exp = flow.prove(OracleBackend(orc), nbits, steps, nq, seed=nbits)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36100 + (os.getpid() % 1500) + world
+    procs = [ctx.Process(target=_two_rank_gpu_worker, args=(r, world, port, nbits, steps, nq, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue
+    import time
+    res, t0 = [], time.time()
+    while len(res) < world:
+        try:
+            res.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > 240:
+                for p in procs:
+                    p.kill()
+                pytest.fail(f"rank processes failed: exit codes {dead}")
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    owners = {y // ((1 << (nbits + 1)) // world) for y in exp["fri"]["queries"]}
+    assert len(owners) > 1
+    for rank, out in res:
+        for k in exp:
+            assert out[k] == exp[k], (rank, k)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("nbits,steps,nq,optimise", [(6, [7, 4], 5, False), (10, [11, 7, 4], 12, False), (9, [10, 6, 3], 9, True)])
 def test_cpp_starks_genproof_equals_flow_and_verifies(orc, tmp_path, nbits, steps, nq, optimise):

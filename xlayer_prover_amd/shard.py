@@ -49,17 +49,55 @@ def columns_to_rows(local, ncols, group=None):
 
 
 def _all_to_all_gloo(recv, send, group):
-    # gloo has no all_to_all for CPU tensors: pairwise exchange (tests only)
+    # gloo has no all_to_all for CPU tensors: pairwise exchange (tests only); device tensors go through the host
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     recv[rank].copy_(send[rank])
-    reqs = []
+    reqs, back = [], []
     for p in range(world):
         if p == rank:
             continue
-        reqs.append(dist.isend(send[p], p, group=group))
-        reqs.append(dist.irecv(recv[p], p, group=group))
+        r_h = torch.empty(recv[p].shape, dtype=recv[p].dtype) if recv[p].is_cuda else recv[p]
+        reqs.append(dist.isend(send[p].cpu(), p, group=group))
+        reqs.append(dist.irecv(r_h, p, group=group))
+        back.append((recv[p], r_h))
     for r in reqs:
         r.wait()
+    for d, h in back:
+        if d is not h:
+            d.copy_(h)
+
+
+def _host_staged(t, group):
+    """gloo moves host memory only: under it device tensors take a round trip through the host (tests: several ranks on one GPU)"""
+    return dist.get_backend(group) == "gloo" and t.is_cuda
+
+
+def _all_gather(t, group=None):
+    """-> list of every rank's t (same shape everywhere), on t's device"""
+    world = dist.get_world_size(group)
+    src = t.contiguous()
+    if _host_staged(t, group):
+        parts = [torch.empty(src.shape, dtype=src.dtype) for _ in range(world)]
+        dist.all_gather(parts, src.cpu(), group=group)
+        return [q.to(t.device) for q in parts]
+    parts = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(parts, src, group=group)
+    return parts
+
+
+def _sendrecv(send, dst, src, group=None):
+    """send `send` to rank dst, receive a tensor of the same shape from rank src"""
+    if _host_staged(send, group):
+        r_h = torch.empty(send.shape, dtype=send.dtype)
+        reqs = [dist.isend(send.cpu(), dst=dst, group=group), dist.irecv(r_h, src=src, group=group)]
+        for r in reqs:
+            r.wait()
+        return r_h.to(send.device)
+    recv = torch.empty_like(send)
+    reqs = [dist.isend(send, dst=dst, group=group), dist.irecv(recv, src=src, group=group)]
+    for r in reqs:
+        r.wait()
+    return recv
 
 
 def rows_to_columns(local, nrows, group=None):
@@ -83,9 +121,7 @@ def cap_tree(sub_root, hash_pairs, group=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return [sub_root.view(1, 4).clone()]
-    caps = [torch.empty_like(sub_root) for _ in range(world)]
-    dist.all_gather(caps, sub_root.contiguous(), group=group)
-    levels = [torch.stack(caps)]                    # [G, 4] in rank order == node order
+    levels = [torch.stack(_all_gather(sub_root, group))]                    # [G, 4] in rank order == node order
     while levels[-1].shape[0] > 1:
         levels.append(hash_pairs(levels[-1]))
     return levels
@@ -170,11 +206,7 @@ def halo_exchange(local, width, halo_rows, group=None):
         out[rows * width:] = head
         return out
     rank = dist.get_rank(group)
-    recv = torch.empty_like(head)
-    reqs = [dist.isend(head, dst=(rank - 1) % world, group=group), dist.irecv(recv, src=(rank + 1) % world, group=group)]
-    for r in reqs:
-        r.wait()
-    out[rows * width:] = recv
+    out[rows * width:] = _sendrecv(head, (rank - 1) % world, (rank + 1) % world, group)
     return out
 
 
@@ -189,10 +221,7 @@ def halo_writeback(window, width, rows_local, halo_rows, cols, group=None):
         recv = halo
     else:
         rank = dist.get_rank(group)
-        recv = torch.empty_like(halo)
-        reqs = [dist.isend(halo, dst=(rank + 1) % world, group=group), dist.irecv(recv, src=(rank - 1) % world, group=group)]
-        for r in reqs:
-            r.wait()
+        recv = _sendrecv(halo, (rank + 1) % world, (rank - 1) % world, group)
     o = 0
     for a, c, nx in cols:
         w2[:nx, a:a + c] = recv[o:o + nx * c].view(nx, c); o += nx * c
@@ -287,10 +316,6 @@ def sharded_h1h2(f_local, t_local, dim, h1h2, group=None):
     if world == 1:
         return h1h2(f_local, t_local)
     rank = dist.get_rank(group)
-    fs = [torch.empty_like(f_local) for _ in range(world)]
-    ts = [torch.empty_like(t_local) for _ in range(world)]
-    dist.all_gather(fs, f_local.contiguous(), group=group)
-    dist.all_gather(ts, t_local.contiguous(), group=group)
-    h1, h2 = h1h2(torch.cat(fs), torch.cat(ts))
+    h1, h2 = h1h2(torch.cat(_all_gather(f_local, group)), torch.cat(_all_gather(t_local, group)))
     rows = f_local.numel() // dim
     return h1[rank * rows * dim:(rank + 1) * rows * dim].clone(), h2[rank * rows * dim:(rank + 1) * rows * dim].clone()
