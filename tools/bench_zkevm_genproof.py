@@ -37,7 +37,7 @@ def gl_w(n):
 def inv(a): return pow(a, P - 2, P)
 
 
-def evmap_from_step52ns(code, L, const_2ns, nconst, pols):
+def evmap_from_step52ns(code, L, const_2ns, nconst, pols, secs):
     """which column each evals[k] belongs to: the `col - evals[k]` subtractions of the FRI-polynomial program
     (starks.cpp:556-669 reads the same list from starkinfo.evMap).  A column's second evaluation is its next-row one."""
     ents, seen = {}, {}
@@ -47,7 +47,7 @@ def evmap_from_step52ns(code, L, const_2ns, nconst, pols):
             continue
         if ak == E.K_POLS:
             off = apar[0]
-            name = [s for s, _, ext in G.SECTIONS if ext and L[s][0] <= off < L[s][0] + L[s][1] * L[s][2]][-1]   # (sections may overlap: --aliased)
+            name = [s for s, _, ext in secs if ext and L[s][1] and L[s][0] <= off < L[s][0] + L[s][1] * L[s][2]][-1]   # (sections may overlap: --aliased)
             t = (pols[L[name][0]:L[name][0] + L[name][1] * L[name][2]], L[name][1], off - L[name][0], ad)
             key = ("p", off)
         elif ak == E.K_CONST2NS:
@@ -69,11 +69,14 @@ def decode(code):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--log-n", type=int, default=22)
+    ap.add_argument("--log-n", type=int, default=0, help="zkevm: 2^log_n rows (default 22; 23 = the real size, one-GPU aliased slab)")
+    ap.add_argument("--circuit", default="zkevm", choices=sorted(G.CIRCUITS), help="which STARK of Prover::genBatchProof (prover.cpp:577,610,644); "
+                    "c12a and recursive1 run at their real geometry with their converted reference step programs")
+    ap.add_argument("--batch", action="store_true", help="the three STARKs of genBatchProof one after the other: zkevm (--log-n, default 23), c12a, recursive1")
     ap.add_argument("--fri-steps", default="")
-    ap.add_argument("--queries", type=int, default=128)
-    ap.add_argument("--lookups", type=int, default=28, help="H1H2 computations (cm2 = 168 columns = 28 x (h1, h2) in Fp^3)")
-    ap.add_argument("--zs", type=int, default=40, help="grand products (calculateZ calls); their z columns land in cm3")
+    ap.add_argument("--queries", type=int, default=0)
+    ap.add_argument("--lookups", type=int, default=-1, help="H1H2 computations (zkevm: cm2 = 168 columns = 28 x (h1, h2) in Fp^3)")
+    ap.add_argument("--zs", type=int, default=-1, help="grand products (calculateZ calls); their z columns land in cm3 (zkevm: 40)")
     ap.add_argument("--no-jit", action="store_true")
     ap.add_argument("--no-dots", action="store_true", help="keep the FRI polynomial (step52ns) entirely in the expression VM instead of "
                     "table program + xlp_dev_dot_columns + a 12-instruction row program")
@@ -84,16 +87,39 @@ def main():
                     "cm1_n / cm2_n, const_2ns re-extended per proof over the dead cm3_n, cm4_2ns / q / f inside tmpExp_n: 239 GB instead of 295 GB "
                     "+ 31 GB at N = 2^23.  Default: on from --log-n 23")
     a = ap.parse_args()
-    ln = a.log_n
-    aliased = (ln >= 23) if a.aliased < 0 else bool(a.aliased)
-    geo = f"geo{ln}a" if aliased else f"geo{ln}"
-    N, NE = 1 << ln, 1 << (ln + 1)
-    steps = [int(x) for x in a.fri_steps.split(",")] if a.fri_steps else [ln + 1] + [b for b in (ln - 4, ln - 9, ln - 13, ln - 17) if b >= 3]
     capi.init(0); capi.use_torch_stream()
-    progs, info = G.load(ln, aliased)
-    L = G.layout(ln, aliased)
+    if a.batch:
+        res, total = {}, 0.0
+        for circ, tag in (("zkevm", "STARK_PROOF_BATCH_PROOF"), ("c12a", "STARK_C12_A_PROOF_BATCH_PROOF"), ("recursive1", "STARK_RECURSIVE_1_PROOF_BATCH_PROOF")):
+            o = prove(a, circ, (a.log_n or 23) if circ == "zkevm" else G.CIRCUITS[circ]["log_n"])
+            res[tag] = o; total += o["genproof_wall_s"]
+            torch.cuda.empty_cache()
+        print(json.dumps({"workload": "the three STARKs of Prover::genBatchProof (prover.cpp:572-645) back to back on one GPU, synthetic witnesses; the "
+                                      "executor and the circom witness computations between them are CPU work outside the hot path",
+                          "genbatchproof_starks_wall_s": round(total, 4), "wall_s": {k: v["genproof_wall_s"] for k, v in res.items()}, "proofs": res}))
+        return
+    out = prove(a, a.circuit, a.log_n or (22 if a.circuit == "zkevm" else G.CIRCUITS[a.circuit]["log_n"]))
+    if out is not None:
+        print(json.dumps(out))
+
+
+def prove(a, circ, ln):
+    C = G.CIRCUITS[circ]
+    ext = C["ext"]
+    secs = G.sections(circ)
+    lookups = C["lookups"] if a.lookups < 0 else a.lookups
+    nzs = C["zs"] if a.zs < 0 else a.zs
+    queries = a.queries or C["queries"]
+    aliased = (circ == "zkevm" and ln >= 23) if a.aliased < 0 else bool(a.aliased)
+    geo = f"geo{ln}a" if aliased else f"geo{ln}"
+    N, NE = 1 << ln, 1 << (ln + ext)
+    lne = ln + ext
+    steps = [int(x) for x in a.fri_steps.split(",")] if a.fri_steps else (C["fri"] if C["fri"] and ln == C["log_n"] else
+                                                                         [lne] + [b for b in (lne - 5, lne - 10, lne - 14, lne - 18) if b >= 3])
+    progs, info = G.load(ln, aliased, circ)
+    L = G.layout(ln, aliased, circ)
     nconst = max(info["n_const"], info["n_const2"])
-    assert nconst == G.N_CONST
+    assert circ != "zkevm" or nconst == G.N_CONST
     dev = "cuda"
     i64 = torch.int64
 
@@ -104,7 +130,7 @@ def main():
     def sec(name):
         o, w, rows = L[name]
         return pols[o:o + w * rows]
-    W = {name: w for name, w, _ in G.SECTIONS}
+    W = {name: w for name, w, _ in secs}
     # ---- setup (Starks ctor: constant polynomials, their extension and tree, x tables, ZhInv) -- not part of a proof
     capi.dev_fill(sec("cm1_n"), 0x5EED0401, 0)                                      # the witness, resident
     const_n = fill(N * nconst, 0x5EED0402)
@@ -113,11 +139,11 @@ def main():
     capi.dev_extend(const_2ns, const_n, NE, N, nconst)
     nodesC = torch.empty((2 * NE - 1) * 4, dtype=i64, device=dev)
     capi.dev_merkle(nodesC, const_2ns, nconst, NE)
-    w_n, w_ne, shift = gl_w(ln), gl_w(ln + 1), 7
+    w_n, w_ne, shift = gl_w(ln), gl_w(lne), 7
     x_n = torch.empty(N, dtype=i64, device=dev); capi.dev_geometric(x_n, N, 1, [1], [w_n])
     x_2ns = torch.empty(NE, dtype=i64, device=dev); capi.dev_geometric(x_2ns, NE, 1, [shift], [w_ne])
     sn = pow(shift, N, P)
-    zi = capi.from_np(np.array([inv((sn * pow(gl_w(1), i, P) - 1) % P) for i in range(2)], np.uint64))
+    zi = capi.from_np(np.array([inv((sn * pow(gl_w(ext), i, P) - 1) % P) for i in range(1 << ext)], np.uint64))   # 1 / Zh on the coset: period 2^extendBits
     xdx = torch.empty(NE * 3, dtype=i64, device=dev); xdwx = torch.empty(NE * 3, dtype=i64, device=dev)
     challenges = np.zeros(8 * 3, np.uint64)
     publics = np.arange(1, info["npub"] + 1, dtype=np.uint64)
@@ -126,22 +152,22 @@ def main():
     vm, mode = {}, {}
     for s, (code, n1, n3) in progs.items():
         vm[s] = capi.ExprProgram(code, n1, n3)
-        so = os.path.join(R.REF_DIR, f"zkevm.{s}.{geo}.so")
+        so = os.path.join(R.REF_DIR, f"{circ}.{s}.{geo}.so")
         mode[s] = "interpreter"
         if not a.no_jit and os.path.exists(so):
             vm[s].attach(so); mode[s] = "compiled"
     opt = {}
     if not a.no_opt:
-        for st, ((rc, r1, r3), tabp, n_ext, stats) in G.load_opt(ln, aliased).items():
+        for st, ((rc, r1, r3), tabp, n_ext, stats) in G.load_opt(ln, aliased, circ).items():
             opt[st] = {"row": capi.ExprProgram(rc, r1, r3), "tab": capi.ExprProgram(tabp.code, tabp.ntmp1, tabp.ntmp3) if tabp.ninstr else None,
                        "ext": torch.zeros(3 * n_ext, dtype=i64, device=dev)}
-            so = os.path.join(R.REF_DIR, f"zkevm.{st}_opt.{geo}.so")
+            so = os.path.join(R.REF_DIR, f"{circ}.{st}_opt.{geo}.so")
             mode[st] = "dot-product form, interpreter"
             if not a.no_jit and os.path.exists(so):
                 opt[st]["row"].attach(so); mode[st] = "dot-product form, compiled"
     fri_dots = None
     if not a.no_opt and not a.no_dots:
-        tabp, dots, rowp, n_ext = G.load_fri_dots(ln, aliased)
+        tabp, dots, rowp, n_ext = G.load_fri_dots(ln, aliased, circ)
         from xlayer_prover_amd import expr as EX
         dents = []
         for x, g, k in dots["entries"]:
@@ -152,14 +178,14 @@ def main():
         fri_dots = {"tab": capi.ExprProgram(tabp.code, tabp.ntmp1, tabp.ntmp3), "row": capi.ExprProgram(rowp.code, rowp.ntmp1, rowp.ntmp3),
                     "ext": torch.zeros(3 * n_ext, dtype=i64, device=dev), "G": dots["ngroups"], "entries": capi.dot_entries(dents),
                     "out": torch.empty(NE * 3 * dots["ngroups"], dtype=i64, device=dev)}
-        so = os.path.join(R.REF_DIR, f"zkevm.step52ns_tab.{geo}.so")
+        so = os.path.join(R.REF_DIR, f"{circ}.step52ns_tab.{geo}.so")
         if not a.no_jit and os.path.exists(so):
             try:
                 fri_dots["tab"].attach(so)
             except capi.XlpError as e:                     # built from another version of the table program
                 print("table program plugin not attached:", e, file=sys.stderr)
         mode["step52ns"] = f"table program + dot_columns ({len(dents)} entries, {dots['ngroups']} groups) + {rowp.ninstr}-instruction row program"
-    ents, ev_ids = evmap_from_step52ns(progs["step52ns"][0], L, const_2ns, nconst, pols)
+    ents, ev_ids = evmap_from_step52ns(progs["step52ns"][0], L, const_2ns, nconst, pols, secs)
     ev_arr = capi.evmap_entries(ents)
     ev_out = torch.zeros(3 * len(ents), dtype=i64, device=dev)
     ev_index = torch.tensor([3 * k + j for k in ev_ids for j in range(3)], device=dev)
@@ -170,7 +196,8 @@ def main():
     num = torch.empty(3 * N, dtype=i64, device=dev); den = torch.empty(3 * N, dtype=i64, device=dev); z = torch.empty(3 * N, dtype=i64, device=dev)
     trees = {k: torch.empty((2 * NE - 1) * 4, dtype=i64, device=dev) for k in ("cm1_2ns", "cm2_2ns", "cm3_2ns", "cm4_2ns")}
     LEv = torch.empty(3 * N, dtype=i64, device=dev); LpEv = torch.empty(3 * N, dtype=i64, device=dev)
-    qq1 = torch.empty(3 * NE, dtype=i64, device=dev); qq2 = torch.empty(6 * NE, dtype=i64, device=dev)
+    qdeg = W["cm4_n"] // 3                                     # the quotient is committed as qDeg polynomials of degree < N
+    qq1 = torch.empty(3 * NE, dtype=i64, device=dev); qq2 = torch.empty(3 * qdeg * NE, dtype=i64, device=dev)
     torch.cuda.synchronize()
     free_b, total_b = torch.cuda.mem_get_info()
     print(f"resident: {torch.cuda.memory_allocated() / 1e9:.1f} GB (torch), device {total_b / 1e9:.1f} GB of which {free_b / 1e9:.1f} GB free ; "
@@ -210,7 +237,7 @@ def main():
             t0 = time.perf_counter(); run(st, nr); torch.cuda.synchronize()
             res[st] = round(time.perf_counter() - t0, 4)
         print(json.dumps({"vm_only_s": res, "modes": {k: mode[k] for k in res}}))
-        return
+        return None
     timers = {}
     fri_roots = []
 
@@ -220,7 +247,8 @@ def main():
         return r
 
     def commit(i, a_n, a_2ns):
-        timed(f"STARK_STEP_{i}_LDE", lambda: capi.dev_extend(sec(a_2ns), sec(a_n), NE, N, W[a_n]))
+        if W[a_n]:                                             # a STARK without lookups commits an empty cm2: no columns to extend, the tree is still built
+            timed(f"STARK_STEP_{i}_LDE", lambda: capi.dev_extend(sec(a_2ns), sec(a_n), NE, N, W[a_n]))
         timed(f"STARK_STEP_{i}_MERKLETREE", lambda: capi.dev_merkle(trees[a_2ns], sec(a_2ns), W[a_2ns], NE))
         root = [int(v) for v in capi.to_np(trees[a_2ns][-4:])]
         tr.put(root)
@@ -238,14 +266,15 @@ def main():
         roots = [commit(1, "cm1_n", "cm1_2ns")]
         # ---- 2
         challenges[0:3] = tr.get_field(); challenges[3:6] = tr.get_field()
-        timed("STARK_STEP_2_CALCULATE_EXPS", lambda: run("step2prev", N))
+        if "step2prev" in progs:
+            timed("STARK_STEP_2_CALCULATE_EXPS", lambda: run("step2prev", N))
         cm2 = sec("cm2_n").view(N, W["cm2_n"])
 
-        def lookups():
-            for k in range(a.lookups):
+        def lookups_():
+            for k in range(lookups):
                 capi.dev_calculate_h1h2(h1, h2, f_pl, t_pl, N, 3)
                 cm2[:, 6 * k:6 * k + 3] = h1.view(N, 3); cm2[:, 6 * k + 3:6 * k + 6] = h2.view(N, 3)
-        timed("STARK_STEP_2_CALCULATEH1H2", lookups)
+        timed("STARK_STEP_2_CALCULATEH1H2", lookups_)
         roots.append(commit(2, "cm2_n", "cm2_2ns"))
         # ---- 3
         challenges[6:9] = tr.get_field(); challenges[9:12] = tr.get_field()
@@ -253,8 +282,8 @@ def main():
         tmpx = sec("tmpExp_n").view(N, W["tmpExp_n"]); cm3 = sec("cm3_n").view(N, W["cm3_n"])
 
         def zs():
-            for k in range(a.zs):
-                c = (6 * k) % (W["tmpExp_n"] - 6)
+            for k in range(nzs):
+                c = (6 * k) % max(W["tmpExp_n"] - 6, 1)
                 num.view(N, 3).copy_(tmpx[:, c:c + 3]); den.view(N, 3).copy_(tmpx[:, c + 3:c + 6])
                 capi.dev_calculate_z(z, num, den, N)
                 cm3[:, 3 * k:3 * k + 3] = z.view(N, 3)
@@ -269,10 +298,10 @@ def main():
 
         def q_poly():
             capi.dev_ntt(qq1, sec("q_2ns"), NE, 3, inverse=True)
-            capi.dev_q_split(qq2, qq1, N, NE, 2, 3, pow(inv(shift), N, P))
-            capi.dev_ntt(sec("cm4_2ns"), qq2, NE, 6)
+            capi.dev_q_split(qq2, qq1, N, NE, qdeg, 3, pow(inv(shift), N, P))
+            capi.dev_ntt(sec("cm4_2ns"), qq2, NE, 3 * qdeg)
         timed("STARK_STEP_4_CALCULATE_EXPS_2NS_INTT_MUL_NTT", q_poly)
-        timed("STARK_STEP_4_MERKLETREE", lambda: capi.dev_merkle(trees["cm4_2ns"], sec("cm4_2ns"), 6, NE))
+        timed("STARK_STEP_4_MERKLETREE", lambda: capi.dev_merkle(trees["cm4_2ns"], sec("cm4_2ns"), 3 * qdeg, NE))
         roots.append([int(v) for v in capi.to_np(trees["cm4_2ns"][-4:])]); tr.put(roots[-1])
         # ---- 5
         xi = tr.get_field(); challenges[21:24] = xi
@@ -284,7 +313,7 @@ def main():
         timed("STARK_STEP_5_LEv_LpEv", lev)
 
         def evmap():
-            capi.dev_evmap(ev_out, LEv, LpEv, N, 1, ev_arr)
+            capi.dev_evmap(ev_out, LEv, LpEv, N, ext, ev_arr)
             evals_d[ev_index] = ev_out
             return capi.to_np(ev_out)
         ev = timed("STARK_STEP_5_EVMAP", evmap)
@@ -317,10 +346,11 @@ def main():
                 pol = pol2; bits = nb
                 for _ in range(red):
                     sinv = sinv * sinv % P
-            ys = tr.get_permutations(a.queries, steps[0])
+            ys = tr.get_permutations(queries, steps[0])
             opened = 0
             for name in ("cm1_2ns", "cm2_2ns", "cm3_2ns", "cm4_2ns"):
-                opened += capi.dev_merkle_proofs(sec(name), trees[name], W[name], NE, ys).size
+                if W[name]:                                    # (the zkin proof has no s0_vals2 when cm2 is empty)
+                    opened += capi.dev_merkle_proofs(sec(name), trees[name], W[name], NE, ys).size
             opened += capi.dev_merkle_proofs(const_2ns, nodesC, nconst, NE, ys).size
             idx = ys
             for aux, nodes, w, ng in ftrees:
@@ -330,15 +360,18 @@ def main():
         opened = timed("STARK_STEP_FRI", fri)
         torch.cuda.synchronize()
         wall = time.perf_counter() - t_proof
-    out = {"workload": f"genProof, all stages, one run, zkEVM geometry at N=2^{ln} (widths 751/168/408/6, {nconst} const pols, {len(ents)} evaluations, "
-                       f"{a.lookups} lookups, {a.zs} grand products, FRI steps {steps}, {a.queries} queries), 1 GPU, synthetic witness",
+    out = {"workload": f"genProof, all stages, one run, {circ} geometry at N=2^{ln}, extended 2^{lne} (widths {'/'.join(str(W[k]) for k in ('cm1_n', 'cm2_n', 'cm3_n', 'cm4_n'))}, "
+                       f"{nconst} const pols, {len(ents)} evaluations, "
+                       f"{lookups} lookups, {nzs} grand products, FRI steps {steps}, {queries} queries), 1 GPU, synthetic witness",
            "layout": "one-GPU aliased slab (tools/zkevm_geometry.py)" if aliased else "reference slab", "slab_GB": round(L["end"][0] * 8 / 1e9, 1),
            "peak_GB_torch": round(torch.cuda.max_memory_allocated() / 1e9, 1), "device_GB": round(total_b / 1e9, 1),
            "programs": mode, "resident_GB_torch": round(torch.cuda.memory_allocated() / 1e9, 1),
            "timers_s": {k: round(v, 4) for k, v in timers.items()}, "sum_timed_s": round(sum(timers.values()), 4),
            "genproof_wall_s": round(wall, 4), "proof_elements_opened": int(opened), "roots": roots,
            "fri_roots_and_head_of_final_pol": fri_roots}
-    print(json.dumps(out))
+    for o in list(vm.values()) + [x["row"] for x in opt.values()] + [x["tab"] for x in opt.values() if x["tab"] is not None]:
+        o.close()
+    return out
 
 
 if __name__ == "__main__":

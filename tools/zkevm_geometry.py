@@ -11,12 +11,29 @@ LOG_N_REAL = 23
 # (section, width, on the extended domain?) in slab order (stark_info.cpp mapOffsets order)
 SECTIONS = [("cm1_n", 751, 0), ("cm2_n", 168, 0), ("cm3_n", 408, 0), ("cm4_n", 6, 0), ("tmpExp_n", 389, 0),
             ("cm1_2ns", 751, 1), ("cm2_2ns", 168, 1), ("cm3_2ns", 408, 1), ("cm4_2ns", 6, 1), ("q_2ns", 3, 1), ("f_2ns", 3, 1)]
+# The three STARKs of Prover::genBatchProof (prover.cpp:577,610,644).  The other two are small and keep their real geometry
+# (the widths are the strides of their converted step programs, the tmpExp width follows from the offset of
+# cm1_2ns).  steps / queries of c12a and lookups / zs of all three are what the absent starkinfo would say: defaults only.
+CIRCUITS = {
+    "zkevm": {"log_n": 23, "ext": 1, "widths": (751, 168, 408, 6, 389), "steps": ("step2prev", "step3prev", "step3", "step42ns", "step52ns"),
+              "lookups": 28, "zs": 40, "queries": 128, "fri": None},
+    "c12a": {"log_n": 20, "ext": 2, "widths": (18, 0, 78, 12, 6), "steps": ("step3prev", "step3", "step42ns", "step52ns"),
+             "lookups": 0, "zs": 2, "queries": 64, "fri": [22, 18, 14, 10, 6]},
+    "recursive1": {"log_n": 17, "ext": 3, "widths": (18, 0, 39, 21, 6), "steps": ("step3prev", "step3", "step42ns", "step52ns"),
+                   "lookups": 0, "zs": 2, "queries": 43, "fri": [20, 16, 12, 9, 6]},      # FRI steps / queries of the golden recursive proofs
+}
+
+
+def sections(circ="zkevm"):
+    w1, w2, w3, w4, wt = CIRCUITS[circ]["widths"]
+    return [("cm1_n", w1, 0), ("cm2_n", w2, 0), ("cm3_n", w3, 0), ("cm4_n", w4, 0), ("tmpExp_n", wt, 0),
+            ("cm1_2ns", w1, 1), ("cm2_2ns", w2, 1), ("cm3_2ns", w3, 1), ("cm4_2ns", w4, 1), ("q_2ns", 3, 1), ("f_2ns", 3, 1)]
 REAL_OFFSETS = {"cm1_n": 0, "cm2_n": 6299844608, "cm3_n": 7709130752, "cm4_n": 11131682816, "tmpExp_n": 11182014464,
                 "cm1_2ns": 14445182976, "cm2_2ns": 27044872192, "cm3_2ns": 29863444480, "cm4_2ns": 36708548608,
                 "q_2ns": 36809211904, "f_2ns": 36859543552, "end": 36909875200}
 
 
-def layout(log_n, aliased=False):
+def layout(log_n, aliased=False, circ="zkevm"):
     """section -> (offset, width, rows) for N = 2^log_n, same packing rule as the real slab.
 
     aliased=True: the ONE-GPU layout.  The reference keeps all eleven sections apart in one 295 GB slab (and already lets
@@ -29,12 +46,13 @@ def layout(log_n, aliased=False):
     which brings the slab from 4 609 N to 3 560 N words (239 GB at N = 2^23).  Offsets are in words, like the reference's."""
     o, out = 0, {}
     if not aliased:
-        for name, w, ext in SECTIONS:
-            rows = 1 << (log_n + ext)
+        for name, w, ext in sections(circ):
+            rows = 1 << (log_n + ext * CIRCUITS[circ]["ext"])
             out[name] = (o, w, rows)
             o += w * rows
         out["end"] = (o, 0, 0)
         return out
+    assert circ == "zkevm"
     n = 1 << log_n
     width = {name: w for name, w, _ in SECTIONS}
     for name in ("cm1_n", "cm2_n", "cm3_n", "cm4_n", "tmpExp_n"):
@@ -105,21 +123,51 @@ def relocate(codes, log_n, aliased=False):
 STEPS = ("step2prev", "step3prev", "step3", "step42ns", "step52ns")
 
 
-def load(log_n, aliased=False):
+def scan_info(codes):
+    """highest constant / challenge / public / evaluation index the programs name, + 1"""
+    info = {"n_const": 1, "n_const2": 1, "nch": 1, "npub": 1, "nev": 1}
+    for code in codes:
+        for _, _, kind, dim, q in R.operands(code):
+            if kind in (E.K_CONST, E.K_CONST_PRIME):
+                info["n_const"] = max(info["n_const"], int(code[q]) + 1)
+            elif kind in (E.K_CONST2NS, E.K_CONST2NS_PRIME):
+                info["n_const2"] = max(info["n_const2"], int(code[q]) + 1)
+            elif kind == E.K_CHALLENGE:
+                info["nch"] = max(info["nch"], int(code[q]) + 1)
+            elif kind == E.K_PUBLIC:
+                info["npub"] = max(info["npub"], int(code[q]) + 1)
+            elif kind == E.K_EVAL:
+                info["nev"] = max(info["nev"], int(code[q]) + 1)
+    return info
+
+
+def load(log_n, aliased=False, circ="zkevm"):
     import os
-    progs = [R.read_program(os.path.join(R.REF_DIR, f"zkevm.{s}.xlpexpr")) for s in STEPS]
-    codes, info = relocate([p[0] for p in progs], log_n, aliased)
-    return {s: (c, p[1], p[2]) for s, c, p in zip(STEPS, codes, progs)}, info
+    steps = CIRCUITS[circ]["steps"]
+    progs = [R.read_program(os.path.join(R.REF_DIR, f"{circ}.{s}.xlpexpr")) for s in steps]
+    if circ == "zkevm":
+        codes, info = relocate([p[0] for p in progs], log_n, aliased)
+    else:                                           # small STARKs run at their real geometry: the programs as converted
+        assert log_n == CIRCUITS[circ]["log_n"] and not aliased
+        codes = [p[0] for p in progs]
+        info = scan_info(codes)
+        L = layout(log_n, False, circ)
+        for code in codes:                          # every column operand must fall inside the section its stride names
+            for _, _, kind, dim, q in R.operands(code):
+                if kind in (E.K_POLS, E.K_POLS_PRIME):
+                    off, stride = int(code[q]), int(code[q + 1] if kind == E.K_POLS else code[q + 3])
+                    assert any(w == stride and o <= off < o + w for name, (o, w, rows) in L.items() if w), (circ, off, stride)
+    return {s: (c, p[1], p[2]) for s, c, p in zip(steps, codes, progs)}, info
 
 
 NCH = 8                                             # challenges of a STARK proof (starks.cpp: 0..7)
 
 
-def load_opt(log_n, aliased=False):
+def load_opt(log_n, aliased=False, circ="zkevm"):
     """every step with its Horner chains turned into dot products (xlayer_prover_amd/expr_opt.py):
     step -> ((row code, ntmp1, ntmp3), table Program, number of extended-challenge entries, statistics)"""
     from xlayer_prover_amd import expr_opt
-    progs, _ = load(log_n, aliased)
+    progs, _ = load(log_n, aliased, circ)
     res = {}
     for step, (code, n1, n3) in progs.items():
         row, tab, n_ext, stats = expr_opt.horner_to_dot(code, n1, n3, NCH)
@@ -127,11 +175,11 @@ def load_opt(log_n, aliased=False):
     return res
 
 
-def load_fri_dots(log_n, aliased=False):
+def load_fri_dots(log_n, aliased=False, circ="zkevm"):
     """step52ns as (table Program, dot-columns groups, 12-instruction row Program, n_ext): xlayer_prover_amd/expr_opt.py with
     its big sums handed to xlp_dev_dot_columns"""
     from xlayer_prover_amd import expr_opt
-    progs, _ = load(log_n, aliased)
+    progs, _ = load(log_n, aliased, circ)
     code, n1, n3 = progs["step52ns"]
     row, tab, n_ext, stats, dots = expr_opt.horner_to_dot(code, n1, n3, NCH, outsource_min_terms=8)
     assert dots is not None
