@@ -4,38 +4,14 @@ The checked-in zkEVM tables address a 2^23-row slab (section bases and `% N` mod
 arguments); `shrink` relocates every pols section to a packed slab of `n` rows and rewrites the prime moduli,
 keeping columns, strides, next-row distances and everything else as they are.  Tests / benchmarks only."""
 import os
-import struct
 
-import numpy as np
+import numpy as np  # noqa: F401
 
 from xlayer_prover_amd import expr as E
 
+from xlayer_prover_amd.programs import MAGIC, REF_DIR, operands, read_program  # noqa: F401  (re-exported for the tests)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF_DIR = os.path.join(ROOT, "oracle", "_ref", "chelpers")
-MAGIC = int.from_bytes(b"XLPEXPR1", "little")
-
-
-def read_program(path):
-    raw = open(path, "rb").read()
-    magic, ntmp1, ntmp3, ncode = struct.unpack("<4Q", raw[:32])
-    assert magic == MAGIC and len(raw) == 32 + 8 * ncode
-    return np.frombuffer(raw, dtype="<u8", offset=32).astype(np.uint64), ntmp1, ntmp3
-
-
-def operands(code):
-    """yield (instruction index, slot 0/1/2, kind, dim, position of first parameter word)"""
-    pc, k = 0, 0
-    n = len(code)
-    while pc < n:
-        h = int(code[pc])
-        kinds = [(h >> 8) & 255, (h >> 16) & 255, (h >> 24) & 255]
-        dims = [(h >> 32) & 3, (h >> 34) & 3, (h >> 36) & 3]
-        q = pc + 1
-        for s in range(3):
-            yield k, s, kinds[s], dims[s], q
-            q += E.KIND_PARAMS[kinds[s]]
-        pc = q
-        k += 1
 
 
 def shrink_many(codes, n):

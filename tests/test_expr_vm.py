@@ -131,7 +131,7 @@ def test_expr_reference_recursive_programs(xlp, orc, name):
 @pytest.mark.parametrize("step", REAL_STEPS)
 def test_expr_reference_zkevm_programs(xlp, orc, step):
     """The reference's checked-in zkEVM (fork 9) constraint programs, converted by tools/chelpers_to_xlp.py at
-    build time (oracle/_ref/chelpers, not in the repo), on a 256-row synthetic trace: HIP VM == oracle,
+    build time (xlayer_prover_amd/chelpers, not in the repo), on a 256-row synthetic trace: HIP VM == oracle,
     interpreted and compiled."""
     import os
     from tests import expr_real as R

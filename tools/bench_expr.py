@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time the expression VM on the converted zkEVM programs (oracle/_ref/chelpers/*.xlpexpr, built by
+"""Time the expression VM on the converted zkEVM programs (xlayer_prover_amd/chelpers/*.xlpexpr, built by
 __graft_entry__.build() where the reference tree is mounted) or, without them, on a seeded random program.
 Rows are processed in slabs of --rows (the packed synthetic slab replaces the 2^23-row one, tests/expr_real.py);
 reports ms per slab and the extrapolation to the step's full domain (2^23 rows for *prev/step3, 2^24 for *2ns)."""
@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--steps", default="step2prev,step3prev,step3,step42ns,step52ns")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--full", action="store_true", help="run every step on its full zkEVM domain (2^23 / 2^24 rows): measured, not extrapolated")
-    ap.add_argument("--jit", action="store_true", help="attach the ahead-of-time plugin oracle/_ref/chelpers/zkevm.<step>.so if present")
+    ap.add_argument("--jit", action="store_true", help="attach the ahead-of-time plugin xlayer_prover_amd/chelpers/zkevm.<step>.so if present")
     a = ap.parse_args()
     capi.init(0); capi.use_torch_stream()
     out = {}

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """ALL stages of Starks::genProof (src/starkpil/starks.cpp:9-404) in ONE run at the fork-9 zkEVM geometry, GPU-resident on
-one MI355X: the five converted reference step programs (oracle/_ref/chelpers/zkevm.*.xlpexpr, relocated to a slab of
+one MI355X: the five converted reference step programs (xlayer_prover_amd/chelpers/zkevm.*.xlpexpr, relocated to a slab of
 2^log_n rows by tools/zkevm_geometry.py -- the real 2^23-row slab is 295 GB and does not fit one GPU, 2^22 rows is 148 GB),
 committed widths 751 / 168 / 408 / 6, 234 constant polynomials, 1973 evaluations, the reference's stage order and timer
 names.  BASELINE.json configs[3] stand-in: the witness is synthetic (no executor / input archive offline), and so are the
@@ -17,8 +17,8 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
-from tests import expr_real as R
-from tests.mini_genproof_flow import HostTranscript
+from xlayer_prover_amd import programs as R
+from xlayer_prover_amd.transcript import HostTranscript
 from tools import zkevm_geometry as G
 from xlayer_prover_amd import capi
 from xlayer_prover_amd import expr as E

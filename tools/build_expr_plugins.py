@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Ahead-of-time plugins for the converted zkEVM programs on the synthetic slab the tests / benchmarks use
-(tests/expr_real.py: sections packed for n rows).  Writes oracle/_ref/chelpers/zkevm.<step>.n<log2 n>.so next to
+(tests/expr_real.py: sections packed for n rows).  Writes xlayer_prover_amd/chelpers/zkevm.<step>.n<log2 n>.so next to
 the converted programs (git-ignored, travels to the GPU box).  Needs hipcc, no GPU.
     python tools/build_expr_plugins.py --log-rows 8,19 [--steps step3,...] [--parts 8]"""
 import argparse

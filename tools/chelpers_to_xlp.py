@@ -16,7 +16,7 @@ operand parameters refer to `args[i_args + j]`; the op table is then replayed th
 A case the grammar below does not recognise aborts the conversion (nothing is guessed), and the totals are
 checked against NOPS_ / NARGS_.
 
-    python tools/chelpers_to_xlp.py --ref /root/reference --out oracle/_ref/chelpers [--pil zkevm --name zkevm]
+    python tools/chelpers_to_xlp.py --ref /root/reference --out xlayer_prover_amd/chelpers [--pil zkevm --name zkevm]
 """
 import argparse
 import os

@@ -4,7 +4,7 @@ same layout with fewer rows -- so that all five steps address ONE consistent sla
 Benchmarks / tests only."""
 import numpy as np
 
-from tests import expr_real as R
+from xlayer_prover_amd import programs as R
 from xlayer_prover_amd import expr as E
 
 LOG_N_REAL = 23
