@@ -114,3 +114,52 @@ def test_starkinfo_mirror_loads_zkevm_geometry(tmp_path):
     bad = tmp_path / "bad.json"; bad.write_text('{"starkStruct": {"nBits": 3}}')
     r = subprocess.run([EXE, "starkinfo", str(bad)], capture_output=True, text=True)
     assert r.returncode != 0 and "missing member" in r.stderr
+
+
+def _joinzkin_expected(z1, z2, vk, steps):
+    """plain restatement of joinzkin (src/starkpil/fri/proof2zkinStark.cpp:84-175) on Python dicts (insertion-ordered)"""
+    out = {"publics": z1["publics"][:19] + z2["publics"][19:44]}
+    fixed = ["publics", "root1", "root2", "root3", "root4", "evals", "s0_vals1", "s0_vals3", "s0_vals4", "s0_valsC",
+             "s0_siblings1", "s0_siblings3", "s0_siblings4", "s0_siblingsC"]
+    for pre, z in (("a_", z1), ("b_", z2)):
+        for k in fixed:
+            out[pre + k] = z[k]
+        for i in range(1, steps):
+            for suf in ("_root", "_siblings", "_vals"):
+                out[f"{pre}s{i}{suf}"] = z[f"s{i}{suf}"]
+        out[pre + "finalPol"] = z["finalPol"]
+    out["rootC"] = [str(v) for v in vk["constRoot"]]
+    return out
+
+
+def test_joinzkin_mirror(tmp_path):
+    """joinzkin of the C++ mirror (host/xlp_host.hpp) on two synthetic zkin objects with the golden proofs' member set:
+    same members, same order, same values as the reference's function"""
+    import random
+    rng = random.Random(7)
+    steps, nq = 4, 3
+    fe = lambda: str(rng.randrange(0xFFFFFFFF00000001))
+
+    def zkin():
+        z = {"root1": [fe() for _ in range(4)], "root2": [fe() for _ in range(4)], "root3": [fe() for _ in range(4)], "root4": [fe() for _ in range(4)],
+             "evals": [[fe(), fe(), fe()] for _ in range(5)]}
+        for i in range(1, steps):
+            z[f"s{i}_root"] = [fe() for _ in range(4)]
+            z[f"s{i}_vals"] = [[fe() for _ in range(6)] for _ in range(nq)]
+            z[f"s{i}_siblings"] = [[[fe() for _ in range(4)] for _ in range(3)] for _ in range(nq)]
+        for t in ("1", "3", "4", "C"):
+            z[f"s0_vals{t}"] = [[fe() for _ in range(2)] for _ in range(nq)]
+            z[f"s0_siblings{t}"] = [[[fe() for _ in range(4)] for _ in range(5)] for _ in range(nq)]
+        z["finalPol"] = [[fe(), fe(), fe()] for _ in range(4)]
+        z["publics"] = [fe() for _ in range(44)]
+        return z
+    z1, z2 = zkin(), zkin()
+    vk = {"constRoot": [rng.randrange(0xFFFFFFFF00000001) for _ in range(4)]}
+    for name, obj in (("a.json", z1), ("b.json", z2), ("vk.json", vk)):
+        (tmp_path / name).write_text(json.dumps(obj))
+    r = subprocess.run([EXE, "joinzkin", str(tmp_path / "a.json"), str(tmp_path / "b.json"), str(tmp_path / "vk.json"), str(steps)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-500:]
+    got = json.loads(r.stdout)
+    exp = _joinzkin_expected(z1, z2, vk, steps)
+    assert list(got.keys()) == list(exp.keys())
+    assert got == exp

@@ -115,6 +115,21 @@ int main(int argc, char** argv)
 {
     if ((argc == 4 || argc == 5) && std::string(argv[1]) == "genproof") { const int r = genproof_mode(argv[2], argv[3], argc == 5); xlp_shutdown(); return r; }
     if (argc == 3 && std::string(argv[1]) == "starkinfo") return starkinfo_mode(argv[2]);
+    if (argc == 6 && std::string(argv[1]) == "joinzkin") {      // joinzkin a.json b.json verkey.json steps  (host only)
+        std::string t[3];
+        for (int i = 0; i < 3; i++) {
+            FILE* f = fopen(argv[2 + i], "rb");
+            if (!f) { fprintf(stderr, "cannot open %s\n", argv[2 + i]); return 2; }
+            char buf[65536]; size_t n;
+            while ((n = fread(buf, 1, sizeof buf, f)) > 0) t[i].append(buf, n);
+            fclose(f);
+        }
+        const xlp_json::Value z1 = xlp_json::Parser(t[0]).value(), z2 = xlp_json::Parser(t[1]).value(), vk = xlp_json::Parser(t[2]).value();
+        const std::string out = joinzkin(z1, z2, vk, strtoull(argv[5], 0, 10));
+        fwrite(out.data(), 1, out.size(), stdout);
+        printf("\n");
+        return 0;
+    }
     if (argc == 4 && std::string(argv[1]) == "polinomial") return polinomial_mode(strtoull(argv[2], 0, 10), strtoull(argv[3], 0, 10));
     if (argc < 5) { fprintf(stderr, "usage: %s nBits nBitsExt nQueries step0 [step1 ...]\n", argv[0]); return 2; }
     MiniStarkConfig cfg;

@@ -15,6 +15,7 @@
 //   MerkleProof/ProofTree/Fri/Proofs/FRIProof     fri/friProof.hpp:11-235
 //   FRIProve::prove                    fri/friProve.cpp:5-190
 //   proof2zkinStark (as a JSON string) fri/proof2zkinStark.cpp:8-82
+//   joinzkin (JSON values in, text out) fri/proof2zkinStark.cpp:84-175
 //
 // All field arithmetic on data buffers runs on the GPU; the scalar helpers in
 // class Goldilocks exist only because the reference's drivers use them for a
@@ -890,6 +891,71 @@ inline std::string proof2zkinStark(FRIProof& proof)
         os << "]";
     }
     os << ",\"finalPol\":"; arr2(os, p.fri.pol);
+    os << "}";
+    return os.str();
+}
+
+// ------------------------------------------------------------------ joinzkin
+// The input of the recursive2 verifier circuit from two recursive1 / recursive2 proofs (proof2zkinStark.cpp:84-175, called by
+// Prover::genAggregatedProof, prover.cpp:728): the publics are stitched (old state of the first proof, new state of the
+// second), every member of the two zkin objects reappears under an "a_" / "b_" prefix and rootC is the verification key's
+// constRoot as decimal strings.  Host-only; works on the JSON reader's values and returns the JSON text (member order = the
+// reference's insertion order, as its ordered_json keeps it).
+namespace xlp_json {
+inline void dump(std::ostringstream& os, const Value& v)
+{
+    switch (v.kind) {
+    case Value::Null: os << "null"; break;
+    case Value::Bool: os << (v.b ? "true" : "false"); break;
+    case Value::Number: os << v.s; break;
+    case Value::String:
+        os << '"';
+        for (char c : v.s) { if (c == '"' || c == '\\') os << '\\'; os << c; }
+        os << '"';
+        break;
+    case Value::Array:
+        os << '[';
+        for (size_t i = 0; i < v.a.size(); i++) { if (i) os << ','; dump(os, v.a[i]); }
+        os << ']';
+        break;
+    case Value::Object:
+        os << '{';
+        for (size_t i = 0; i < v.o.size(); i++) { if (i) os << ','; os << '"' << v.o[i].first << "\":"; dump(os, v.o[i].second); }
+        os << '}';
+        break;
+    }
+}
+}  // namespace xlp_json
+
+inline std::string joinzkin(const xlp_json::Value& zkin1, const xlp_json::Value& zkin2, const xlp_json::Value& verKey, uint64_t steps)
+{
+    using xlp_json::Value;
+    std::ostringstream os;
+    bool first = true;
+    auto member = [&](const std::string& name, const Value& v) { os << (first ? "{" : ",") << '"' << name << "\":"; xlp_json::dump(os, v); first = false; };
+    // publics 0..18 (oldStateRoot, oldAccInputHash, oldBatchNum, chainId, forkId) from the first proof, 19..43 (newStateRoot,
+    // newAccInputHash, newLocalExitRoot, newBatchNum) from the second
+    Value pub; pub.kind = Value::Array;
+    for (size_t i = 0; i < 19; i++) pub.a.push_back(zkin1["publics"][i]);
+    for (size_t i = 19; i < 44; i++) pub.a.push_back(zkin2["publics"][i]);
+    member("publics", pub);
+    static const char* fixed[] = {"publics", "root1", "root2", "root3", "root4", "evals", "s0_vals1", "s0_vals3", "s0_vals4", "s0_valsC",
+                                  "s0_siblings1", "s0_siblings3", "s0_siblings4", "s0_siblingsC"};
+    const Value* zk[2] = {&zkin1, &zkin2};
+    for (int w = 0; w < 2; w++) {
+        const std::string pre = w == 0 ? "a_" : "b_";
+        for (const char* k : fixed) member(pre + k, (*zk[w])[k]);
+        for (uint64_t i = 1; i < steps; i++) {
+            const std::string si = "s" + std::to_string(i);
+            member(pre + si + "_root", (*zk[w])[si + "_root"]);
+            member(pre + si + "_siblings", (*zk[w])[si + "_siblings"]);
+            member(pre + si + "_vals", (*zk[w])[si + "_vals"]);
+        }
+        member(pre + "finalPol", (*zk[w])["finalPol"]);
+    }
+    Value rc; rc.kind = Value::Array;
+    for (size_t i = 0; i < 4; i++) { Value e; e.kind = Value::String; e.s = verKey["constRoot"][i].str(); rc.a.push_back(e); }
+    member("rootC", rc);
     os << "}";
     return os.str();
 }
