@@ -100,3 +100,38 @@ def test_small_starks_keep_their_real_geometry(circ):
     assert L["cm1_2ns"][2] == 1 << (C["log_n"] + C["ext"])
     tab, dots, row, n_ext = G.load_fri_dots(C["log_n"], False, circ)
     assert dots["ngroups"] == 3 and row.ninstr < 20
+
+
+def _run_bench(*args):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_zkevm_genproof.py"), "--no-jit", *args], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-1500:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_aliased_slab_gives_the_reference_layouts_proof():
+    """every stage of genProof at the zkEVM geometry (2^12 rows, the five converted reference programs) on the one-GPU slab
+    (cm3_2ns over cm1_n / cm2_n, const_2ns re-extended over cm3_n, ...) == the same run on the reference's slab layout:
+    the four roots, every FRI root and the final polynomial"""
+    a = _run_bench("--log-n", "12", "--aliased", "0")
+    b = _run_bench("--log-n", "12", "--aliased", "1")
+    assert a["roots"] == b["roots"] and a["fri_roots_and_head_of_final_pol"] == b["fri_roots_and_head_of_final_pol"]
+    assert b["layout"].startswith("one-GPU") and "STARK_STEP_4_CONST_LDE" in b["timers_s"]
+
+
+@needs_ref
+@pytest.mark.gpu
+def test_recursive1_geometry_run_commits_the_golden_empty_tree(golden_dir):
+    """recursive1 has no lookups: its cm2 tree is the tree over 2^20 zero-width rows, and the genProof run at recursive1's real
+    geometry (converted reference programs, golden FRI steps / queries) must commit exactly the root2 of the reference's
+    recursive1 proof (testvectors/aggregatedProof/recursive1.zkin.proof_0.json, fixture tests/golden/proof_recursive1_0.json)"""
+    import json
+    g = json.load(open(os.path.join(golden_dir, "proof_recursive1_0.json")))
+    o = _run_bench("--circuit", "recursive1")
+    assert [str(v) for v in o["roots"][1]] == g["root2"]
+    assert len(o["fri_roots_and_head_of_final_pol"]) == len(g["steps_nBits"])
