@@ -796,6 +796,47 @@ def test_horner_to_dot_fuzz_on_the_oracle(orc, block):
     assert removed > 0
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_hoist_sum_terms_fuzz_on_the_oracle(orc, seed):
+    """expr_opt.hoist_sum_terms on programs shaped like the optimiser's output: temporaries produced early (some overwritten
+    again, some shared by two sums, some extension-valued), unrelated work in between, then runs of `mul S, x, K; add|sub D, D, S`.
+    The hoisted program gives the same outputs, and the pairs really moved."""
+    from xlayer_prover_amd import expr_opt
+    rng = np.random.default_rng(1000 + seed)
+    n, nch, width, nt1, nt3 = 5, 6, 40, 24, 6
+    p = E.Program()
+    col = lambda d=1: E.pols(int(rng.integers(0, 30)), width, d)
+    ch = lambda: E.challenge(int(rng.integers(0, nch)))
+    for i in range(nt1):
+        p.mul(E.tmp1(i), col(), col()) if rng.integers(0, 2) else p.add(E.tmp1(i), col(), E.number(int(rng.integers(1, 99))))
+    for i in range(nt3):
+        p.mul(E.tmp3(i), col(3), ch())
+    for _ in range(int(rng.integers(5, 40))):                  # filler: rewrites some temporaries after their first definition
+        k = int(rng.integers(0, 4))
+        if k == 0: p.mul(E.tmp1(int(rng.integers(0, nt1))), col(), col())
+        elif k == 1: p.add(E.tmp3(int(rng.integers(2, nt3))), E.tmp3(int(rng.integers(2, nt3))), col(3))
+        else: p.sub(E.tmp1(int(rng.integers(0, nt1))), E.tmp1(int(rng.integers(0, nt1))), col())
+    S = E.tmp3(nt3)
+    for D in (E.tmp3(0), E.tmp3(1)):                           # two sums; D starts from a real value
+        for _ in range(int(rng.integers(3, 30))):
+            x = E.tmp1(int(rng.integers(0, nt1))) if rng.integers(0, 4) else E.tmp3(int(rng.integers(2, nt3)))
+            if rng.integers(0, 2): p.mul(S, x, ch())
+            else: p.mul(S, ch(), x)
+            (p.add if rng.integers(0, 3) else p.sub)(D, D, S)
+        p.mul(D, D, ch())                                      # the sum is consumed by something that is not part of a run
+    p.copy(E.q_2ns(), E.tmp3(0)); p.copy(E.f_2ns(), E.tmp3(1)); p.copy(E.pols(33, width, 3), E.tmp3(2))
+    q = expr_opt.hoist_sum_terms(p, min_distance=1, min_terms=1)
+    assert q.ninstr > p.ninstr                                 # zeroing + the `add D, D, A` that stays
+    b0 = make_buffers(orc, seed, n, width, nch=nch)
+    b0["pols"] = orc.fill(n * width, seed + 5)
+    b1 = {k: v.copy() for k, v in b0.items()}
+    orc.expr_run(p.code, p.ntmp1, p.ntmp3, b0, 0, n, 5, 4)
+    orc.expr_run(q.code, q.ntmp1, q.ntmp3, b1, 0, n, 5, 4)
+    for k in ("pols", "q_2ns", "f_2ns"):
+        assert (b0[k] == b1[k]).all(), k
+    assert expr_opt.hoist_sum_terms(p, min_distance=10 ** 6) is p          # nothing far enough: the program comes back as it is
+
+
 def _dots_on_host(orc, dots, bufs, ext, n):
     """xlp_dev_dot_columns restated with Python integers on the buffers of tests/expr_real.py: -> uint64 [n][3 * ngroups]"""
     Pm = 0xFFFFFFFF00000001

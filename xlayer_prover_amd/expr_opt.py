@@ -65,12 +65,12 @@ class _Lin:
         return self.c is None or o.c is None or self.c == o.c
 
 
-def horner_to_dot(code, ntmp1, ntmp3, nch, outsource_min_terms=0, _ngroups=None):
+def horner_to_dot(code, ntmp1, ntmp3, nch, outsource_min_terms=0, _ngroups=None, hoist=True):
     if outsource_min_terms and _ngroups is None:          # first pass counts the dot-product groups (their row stride)
-        probe = horner_to_dot(code, ntmp1, ntmp3, nch, outsource_min_terms, _ngroups=1)
+        probe = horner_to_dot(code, ntmp1, ntmp3, nch, outsource_min_terms, _ngroups=1, hoist=False)
         if probe[4] is None:
-            return horner_to_dot(code, ntmp1, ntmp3, nch) + (None,)
-        return horner_to_dot(code, ntmp1, ntmp3, nch, outsource_min_terms, _ngroups=probe[4]["ngroups"])
+            return horner_to_dot(code, ntmp1, ntmp3, nch, hoist=hoist) + (None,)
+        return horner_to_dot(code, ntmp1, ntmp3, nch, outsource_min_terms, _ngroups=probe[4]["ngroups"], hoist=hoist)
     out, tab = E.Program(), E.Program()
     scratch = E.tmp3(ntmp3)                                  # one more extension temporary for the products
     state = {}                                               # tmp3 slot -> _Lin (value not in its register yet)
@@ -344,6 +344,8 @@ def horner_to_dot(code, ntmp1, ntmp3, nch, outsource_min_terms=0, _ngroups=None)
     out.ntmp1 = max(out.ntmp1, ntmp1)
     out.ntmp3 = max(out.ntmp3, ntmp3 + 1)
     tab.ntmp3 = max(tab.ntmp3, 2)
+    if hoist:
+        out = hoist_sum_terms(out)                           # the terms of the sums go where their operands are produced
     if outsource_min_terms:
         # the row program's `pols` will be the dot-columns result: it must not read real columns any more
         clean = dots["ngroups"] and all(o is None or o.kind not in _COL or (o.kind == E.K_POLS and o.params[1] == 3 * (_ngroups or 1))
@@ -372,3 +374,112 @@ def _drop_dead(prog):
         if k:
             res.emit(op, d, a, b)
     return res
+
+
+def hoist_sum_terms(prog, min_distance=64, min_terms=8):
+    """Move the terms of the big sums next to where their operands are produced.
+
+    After horner_to_dot a sum over temporaries is emitted where its value is needed: a run of
+        mul S, x_k, K_k ; add|sub D, D, S          (S: the scratch register, K_k: a row-independent table entry)
+    whose x_k were often computed thousands of instructions earlier (zkEVM step42ns: 1 600 temporaries wait for the final sum).
+    In the ahead-of-time form every such value crosses segment boundaries through HBM (one store + one load per row).  Field
+    addition is associative and commutative and exact, so each pair may run right after the last write of x_k instead,
+    accumulating into a fresh register A (zeroed at the start of the program); the run keeps one `add D, D, A` in place of the
+    pairs that left.  Same value in D bit for bit; x_k dies where it is born.  Returns a new Program (prog if nothing moved)."""
+    ins = list(E.decode(prog.code))
+    n = len(ins)
+    tkey = lambda o: (o.kind, o.params[0]) if o is not None and o.kind in (E.K_TMP1, E.K_TMP3) else None
+    # position of the last write of every temporary before each instruction: one forward pass
+    last_write = {}                                           # temp -> sorted positions where it is written
+    reads_after = {}                                          # temp -> sorted positions where it is read (for the scratch check)
+    for i, (op, d, a, b) in enumerate(ins):
+        for o in (a, b):
+            k = tkey(o)
+            if k is not None:
+                reads_after.setdefault(k, []).append(i)
+        k = tkey(d)
+        if k is not None:
+            last_write.setdefault(k, []).append(i)
+    import bisect
+
+    def last_def_before(k, i):
+        w = last_write.get(k, [])
+        j = bisect.bisect_left(w, i) - 1
+        return w[j] if j >= 0 else None
+
+    def is_pair(i):
+        if i + 1 >= n:
+            return None
+        op, d, a, b = ins[i]
+        op2, d2, a2, b2 = ins[i + 1]
+        if op != E.MUL or d.kind != E.K_TMP3 or op2 not in (E.ADD, E.SUB) or d2.kind != E.K_TMP3:
+            return None
+        S, D = tkey(d), tkey(d2)
+        if S == D or tkey(a2) != D or tkey(b2) != S:
+            return None
+        x, K = (a, b) if tkey(a) is not None else (b, a)
+        if tkey(x) is None or tkey(x) in (S, D) or K is None or K.kind != E.K_CHALLENGE:
+            return None
+        # S must be dead after the pair: its next access is a write (or none)
+        r = reads_after.get(S, [])
+        nr = bisect.bisect_right(r, i + 1)
+        nw = last_write.get(S, [])
+        nwi = bisect.bisect_right(nw, i + 1)
+        next_read = r[nr] if nr < len(r) else n + 1
+        next_write = nw[nwi] if nwi < len(nw) else n + 2
+        if next_read < next_write:
+            return None
+        return (x, K, op2, D)
+
+    # runs of consecutive pairs on the same D
+    runs, i = [], 0
+    while i < n:
+        p = is_pair(i)
+        if p is None:
+            i += 1
+            continue
+        run = [(i, p)]
+        j = i + 2
+        while True:
+            q = is_pair(j)
+            if q is None or q[3] != p[3]:
+                break
+            run.append((j, q)); j += 2
+        runs.append(run)
+        i = j
+    ntmp3 = prog.ntmp3
+    S2 = E.tmp3(ntmp3); ntmp3 += 1
+    inserts, removed, replace_first, zero_acc = {}, set(), {}, []
+    for run in runs:
+        start = run[0][0]
+        moved = []
+        for pos, (x, K, op2, D) in run:
+            j = last_def_before(tkey(x), pos)
+            if j is None or start - j < min_distance:
+                continue
+            moved.append((pos, j, x, K, op2))
+        if len(moved) < min_terms:
+            continue
+        A = E.tmp3(ntmp3); ntmp3 += 1
+        zero_acc.append(A)
+        for pos, j, x, K, op2 in moved:
+            inserts.setdefault(j, []).append((E.MUL, S2, x, K))
+            inserts[j].append((op2, A, A, S2))
+            removed.add(pos); removed.add(pos + 1)
+        D = run[0][1][3]
+        replace_first[moved[0][0]] = (E.ADD, E.tmp3(D[1]), E.tmp3(D[1]), A)
+    if not zero_acc:
+        return prog
+    out = E.Program()
+    for A in zero_acc:                                          # A = 0 (challenge 0 minus itself: an Fp^3 zero without a constant pool)
+        out.sub(A, E.challenge(0), E.challenge(0))
+    for i, (op, d, a, b) in enumerate(ins):
+        if i in replace_first:
+            out.emit(*replace_first[i])
+        if i not in removed:
+            out.emit(op, d, a, b)
+        for t in inserts.get(i, ()):
+            out.emit(*t)
+    out.ntmp1 = max(out.ntmp1, prog.ntmp1)
+    out.ntmp3 = max(out.ntmp3, ntmp3)
+    return out
