@@ -888,7 +888,7 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
     int R = env_int("XLP_EXPR_ROWS", 2);
     if (R != 1 && R != 2 && R != 4) R = 2;
     if (jit) R = 1;
-    const u64 chunk_max = (u64)ctx->ncu * 8 * 256;
+    const u64 chunk_max = (u64)ctx->ncu * (u64)(env_int("XLP_EXPR_SLAB_WGS", 8) > 0 ? env_int("XLP_EXPR_SLAB_WGS", 8) : 8) * 256;   // rows per slab: workgroups per CU x 256 (experiment knob)
     const u64 chunk = nrows < chunk_max ? nrows : chunk_max;
     const u64 threads_max = ((chunk + R - 1) / R + 255) / 256 * 256;     // lanes of the largest launch
     const u32 ncols = (u32)prog->cols.size(), nw = (u32)prog->wcols.size();
