@@ -88,14 +88,14 @@ def test_zkevm_programs_respect_the_section_lifetimes(aliased):
 
 
 @needs_ref
-@pytest.mark.parametrize("circ", ["c12a", "recursive1"])
+@pytest.mark.parametrize("circ", ["c12a", "recursive1", "recursive2"])
 def test_small_starks_keep_their_real_geometry(circ):
     """every column operand of the converted c12a / recursive1 programs falls inside the section its stride names
     (load() asserts it), and the evaluation counts are the golden proofs' (recursive1: evals [118][3])"""
     C = G.CIRCUITS[circ]
     progs, info = G.load(C["log_n"], False, circ)
     assert set(progs) == set(C["steps"])
-    assert info["nev"] == {"c12a": 146, "recursive1": 118}[circ] and info["n_const2"] == 52
+    assert info["nev"] == {"c12a": 146, "recursive1": 118, "recursive2": 118}[circ] and info["n_const2"] == 52
     L = G.layout(C["log_n"], False, circ)
     assert L["cm1_2ns"][2] == 1 << (C["log_n"] + C["ext"])
     tab, dots, row, n_ext = G.load_fri_dots(C["log_n"], False, circ)

@@ -21,6 +21,9 @@ CIRCUITS = {
              "lookups": 0, "zs": 2, "queries": 64, "fri": [22, 18, 14, 10, 6]},
     "recursive1": {"log_n": 17, "ext": 3, "widths": (18, 0, 39, 21, 6), "steps": ("step3prev", "step3", "step42ns", "step52ns"),
                    "lookups": 0, "zs": 2, "queries": 43, "fri": [20, 16, 12, 9, 6]},      # FRI steps / queries of the golden recursive proofs
+    # the STARK of Prover::genAggregatedProof (prover.cpp:782): same geometry as recursive1, its own constraint programs
+    "recursive2": {"log_n": 17, "ext": 3, "widths": (18, 0, 39, 21, 6), "steps": ("step3prev", "step3", "step42ns", "step52ns"),
+                   "lookups": 0, "zs": 2, "queries": 43, "fri": [20, 16, 12, 9, 6]},
 }
 
 
