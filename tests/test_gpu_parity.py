@@ -559,3 +559,21 @@ def test_dot_columns_rejections(xlp):
                          ((sec, 8, 0, 1, 0, 2), 1, "coefficient index"), ((sec, 8, 0, 1, 0, 0), 5, "at most 4 groups")]:
         with pytest.raises(xlp.XlpError, match=msg):
             xlp.dev_dot_columns(out, [ent], ng, co, 8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,ws,wd,dim", [(1, 3, 3, 3), (1000, 7, 3, 3), (4097, 389, 3, 3), (1 << 12, 3, 168, 3), (513, 5, 9, 1)])
+def test_copy_cols_strided_views(xlp, n, ws, wd, dim):
+    """xlp_dev_copy_cols = Polinomial::copy between strided views (the transposeH1H2 / transposeZ helpers, starks.cpp:406-555):
+    only the addressed columns of the destination change"""
+    import torch
+    rng = np.random.default_rng(n + ws)
+    src = rng.integers(0, 1 << 63, size=n * ws, dtype=np.int64)
+    dst = rng.integers(0, 1 << 63, size=n * wd, dtype=np.int64)
+    cs, cd = int(rng.integers(0, ws - dim + 1)), int(rng.integers(0, wd - dim + 1))
+    d_src, d_dst = torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda()
+    xlp.dev_copy_cols(d_dst[cd:], wd, d_src[cs:], ws, n, dim)
+    xlp.sync()
+    exp = dst.reshape(n, wd).copy()
+    exp[:, cd:cd + dim] = src.reshape(n, ws)[:, cs:cs + dim]
+    assert (d_dst.cpu().numpy().reshape(n, wd) == exp).all()

@@ -273,7 +273,8 @@ def prove(a, circ, ln):
         def lookups_():
             for k in range(lookups):
                 capi.dev_calculate_h1h2(h1, h2, f_pl, t_pl, N, 3)
-                cm2[:, 6 * k:6 * k + 3] = h1.view(N, 3); cm2[:, 6 * k + 3:6 * k + 6] = h2.view(N, 3)
+                w2 = W["cm2_n"]                                # transposeH1H2Rows (starks.cpp:433-470): the strided-view copy of the library
+                capi.dev_copy_cols(sec("cm2_n")[6 * k:], w2, h1, 3, N, 3); capi.dev_copy_cols(sec("cm2_n")[6 * k + 3:], w2, h2, 3, N, 3)
         timed("STARK_STEP_2_CALCULATEH1H2", lookups_)
         roots.append(commit(2, "cm2_n", "cm2_2ns"))
         # ---- 3
@@ -284,9 +285,10 @@ def prove(a, circ, ln):
         def zs():
             for k in range(nzs):
                 c = (6 * k) % max(W["tmpExp_n"] - 6, 1)
-                num.view(N, 3).copy_(tmpx[:, c:c + 3]); den.view(N, 3).copy_(tmpx[:, c + 3:c + 6])
+                wt, w3 = W["tmpExp_n"], W["cm3_n"]             # transposeZColumns / transposeZRows (starks.cpp:472-555)
+                capi.dev_copy_cols(num, 3, sec("tmpExp_n")[c:], wt, N, 3); capi.dev_copy_cols(den, 3, sec("tmpExp_n")[c + 3:], wt, N, 3)
                 capi.dev_calculate_z(z, num, den, N)
-                cm3[:, 3 * k:3 * k + 3] = z.view(N, 3)
+                capi.dev_copy_cols(sec("cm3_n")[3 * k:], w3, z, 3, N, 3)
         timed("STARK_STEP_3_CALCULATE_Z", zs)
         timed("STARK_STEP_3_CALCULATE_EXPS_2", lambda: run("step3", N))
         roots.append(commit(3, "cm3_n", "cm3_2ns"))

@@ -278,6 +278,12 @@ def dev_merkle_proofs(src, nodes, w, h, idxs):
     return out
 
 
+def dev_copy_cols(dst, dst_stride, src, src_stride, n, dim):
+    """dst[i * dst_stride + c] = src[i * src_stride + c], i < n, c < dim (Polinomial::copy between strided views: the
+    transposeH1H2Columns / transposeZColumns helpers of starks.cpp:406-555); dst / src point at the first column"""
+    _ck(load().xlp_dev_copy_cols(_dp(dst), dst_stride, _dp(src), src_stride, n, dim), "xlp_dev_copy_cols")
+
+
 def dev_q_split(qq2, qq1, n, n_ext, q_deg, q_dim, shift_in):
     _ck(load().xlp_dev_q_split(_dp(qq2), _dp(qq1), n, n_ext, q_deg, q_dim, shift_in), "xlp_dev_q_split")
 
