@@ -364,6 +364,15 @@ int xlp_perm_batch(uint64_t* out, const uint64_t* in, uint64_t count)
     if (ensure_init()) return -1;
     if (count == 0) return 0;
     if (!out || !in) return xlp_fail("xlp_perm: null pointer");
+    if (count <= 64) {                                        // the transcript's one-at-a-time calls: a staging buffer that stays allocated
+        u64* d = nullptr;
+        if (ctx_scratch(&g_ctx, 2 * 64 * 12 * sizeof(u64), 6, &d)) return -1;
+        XLP_HIP(hipMemcpyAsync(d, in, count * 12 * sizeof(u64), hipMemcpyHostToDevice, g_ctx.stream));
+        if (dev_perm(&g_ctx, d + 64 * 12, d, count)) return -1;
+        XLP_HIP(hipMemcpyAsync(out, d + 64 * 12, count * 12 * sizeof(u64), hipMemcpyDeviceToHost, g_ctx.stream));
+        XLP_HIP(hipStreamSynchronize(g_ctx.stream));
+        return 0;
+    }
     DevBuf a;
     if (a.alloc(count * 12 * sizeof(u64))) return -1;
     H2D(a, in, count * 12 * sizeof(u64));
