@@ -149,13 +149,34 @@ __device__ __forceinline__ void fast_round(const u64* __restrict__ tw, Load load
 #ifndef XLP_WGT
 #define XLP_WGT 1024     // threads per workgroup of the LDE kernels (experiment knob)
 #endif
+// XLP_PF (0 = off): the workgroup that will follow this one on its CU -- block id + XLP_PF resident workgroups, i.e. tile +
+// XLP_PF / 8 under xcd_tile -- finds its first-round input in this XCD's L2 / the memory-side cache.  One dword per 64-byte
+// segment of that tile is fetched with the LDS-direct form of the load (global_load_lds_dword) into a 256-byte dummy area
+// in front of the tile (LDS offset 0, so M0 = 0): no VGPR receives data behind the compiler's back (a plain asm load into a register did, and corrupted
+// registers the allocator had reused; a volatile load is issued system-scope and waited for on the spot), and the
+// compiler inserts no wait for it.  Issued before the last round, whose arithmetic covers the latency.
+#ifndef XLP_PF
+#define XLP_PF 256
+#endif
+constexpr u32 LDE_PF_LDS = 256;                              // bytes of dummy LDS in front of the tile (one wave instruction = 64 x 4 B)
+__device__ __forceinline__ void prefetch_touch(const u64* q, u32 lds_off)
+{
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" :: "v"(q), "s"(lds_off) : "m0", "memory");
+}
+template <int BT>
+__device__ __forceinline__ void prefetch_rows(const u64* base, u64 ld, u32 lo, u32 lds_off)
+{
+    for (u32 tpos = threadIdx.x; tpos < (1u << BT); tpos += blockDim.x)
+        prefetch_touch(base + (((u64)tpos << 12) | lo) * ld, lds_off);
+}
+
 template <int BT, bool INV = true>
 __global__ __launch_bounds__(XLP_WGT) void lde_top_dif(const LdeParams p)
 {
     constexpr int V = XLP_TOPV, m = (BT + 3) / 4, dtop = BT - 4 * (m - 1);
     extern __shared__ u64 smem[];
-    u64* sm = smem;                                        // tile
-    u64* cross = smem + ((1u << BT) + (1u << BT) / 16 + 1) * V;  // cross[k1], natural k1
+    u64* sm = smem + (XLP_PF ? LDE_PF_LDS / 8 : 0);        // tile (the first 256 bytes: the prefetch's dummy target, LDS offset 0)
+    u64* cross = sm + ((1u << BT) + (1u << BT) / 16 + 1) * V;  // cross[k1], natural k1
     const u32 ncc = (p.wc + V - 1) / V;
     const u32 tile = xcd_tile();
     const u32 cc = tile % ncc, lo = tile / ncc;
@@ -199,6 +220,12 @@ __global__ __launch_bounds__(XLP_WGT) void lde_top_dif(const LdeParams p)
         XLP_SYNC();
         fast_round<BT, V, 4, 4, false, INV>(p.twi_bt, lload, lstore);
         XLP_SYNC();
+#if XLP_PF
+        if (gridDim.x >= 16 && (gridDim.x & 7) == 0 && blockIdx.x + XLP_PF < gridDim.x) {
+            const u32 nt = tile + (XLP_PF >> 3);
+            prefetch_rows<BT>(p.in + p.col0 + (nt % ncc) * V, p.ld_in, nt / ncc, 0u);
+        }
+#endif
         fast_round<BT, V, 0, 4, false, INV, false, true>(p.twi_bt, lload, gstore, NoFactor{}, crossf);
     }
 }
@@ -400,7 +427,7 @@ static int launch_top(Ctx* ctx, const LdeParams& p, bool dit)
     const u32 ncc = (p.wc + V - 1) / V;
     u32 threads = (1u << (BT - 4)) * V < 64 ? 64 : (1u << (BT - 4)) * V;
     if (threads > XLP_WGT) threads = XLP_WGT;
-    const size_t lds = ((size_t)((1u << BT) + (1u << BT) / 16 + 1) * V + (1u << BT)) * sizeof(u64);
+    const size_t lds = ((size_t)((1u << BT) + (1u << BT) / 16 + 1) * V + (1u << BT)) * sizeof(u64) + (XLP_PF ? LDE_PF_LDS : 0);
     static bool attr_done = false;
     if (!attr_done) {
         XLP_HIP(hipFuncSetAttribute((const void*)lde_top_dif<BT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -439,7 +466,7 @@ static int launch_top_fwd(Ctx* ctx, const LdeParams& p)
     const u32 ncc = (p.wc + V - 1) / V;
     u32 threads = (1u << (BT - 4)) * V < 64 ? 64 : (1u << (BT - 4)) * V;
     if (threads > XLP_WGT) threads = XLP_WGT;
-    const size_t lds = ((size_t)((1u << BT) + (1u << BT) / 16 + 1) * V + (1u << BT)) * sizeof(u64);
+    const size_t lds = ((size_t)((1u << BT) + (1u << BT) / 16 + 1) * V + (1u << BT)) * sizeof(u64) + (XLP_PF ? LDE_PF_LDS : 0);
     static bool attr_done = false;
     if (!attr_done) {
         XLP_HIP(hipFuncSetAttribute((const void*)lde_top_dif<BT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
