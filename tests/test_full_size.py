@@ -1,0 +1,97 @@
+"""BASELINE.json configs[2] and configs[3] AT SIZE, checked against the CPU oracle through size-independent properties:
+
+  cfg3  Poseidon-Goldilocks Merkle commit of a 2^24-row extended trace, 751 columns (the real cm1 width) and 670 columns
+        (the width BASELINE's text quotes): PoseidonGoldilocks::merkletree_avx (merkleTreeGL.cpp:37-44), 100.8 / 89.9 GB of rows
+  cfg4  Starks::genProof (starks.cpp:9-404) at the fork-9 zkEVM geometry, N = 2^23: see test_zkevm_genproof_2p23_checked
+
+Bit-exact: integer field."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def xlp():
+    from xlayer_prover_amd import capi
+    capi.init(0)
+    return capi
+
+
+def _path(h_nodes_levels, idx):
+    """sibling nodes bottom-up from a list of per-level host arrays (merkleTreeGL.cpp:24-35)"""
+    sib = []
+    for lvl in h_nodes_levels:
+        sib.append(lvl[4 * (idx ^ 1):4 * (idx ^ 1) + 4])
+        idx >>= 1
+    return np.concatenate(sib) if sib else np.zeros(0, np.uint64)
+
+
+@pytest.mark.parametrize("w", [751, 670])
+def test_merkle_config3_full_size(xlp, orc, w):
+    """2^24 x w rows resident in HBM (dev_fill: the synthetic trace of SURVEY 8d, regenerated row by row on the oracle side):
+    (a) root == cap tree (oracle permutations) over the roots of the 8 sub-trees of 2^21 rows each, built by separate launches
+        -- the perfect-binary-tree property the 8-GPU cap assembly of SURVEY 8e relies on;
+    (b) 24 sampled leaves == orc.linear_hash of the same rows (incl. first / last row, sub-tree boundaries);
+    (c) their sibling paths, read from the node buffer, verify against the root with the oracle;
+    (d) xlp_dev_merkle_proofs (the batched getGroupProof) returns the same rows and paths."""
+    import torch
+    h = 1 << 24
+    seed = 0x5EED0003
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < (h * w + 3 * h * 4) * 8 + (8 << 30):
+        pytest.skip("not enough free HBM for the configs[2] section")
+    src = torch.empty(h * w, dtype=torch.int64, device="cuda")
+    xlp.dev_fill(src, seed, 0)
+    nodes = torch.empty((2 * h - 1) * 4, dtype=torch.int64, device="cuda")
+    xlp.dev_merkle(nodes, src, w, h)
+    xlp.sync()
+    root = xlp.to_np(nodes[-4:])
+    # (a)
+    G, q = 8, h // 8
+    sub = torch.empty((2 * q - 1) * 4, dtype=torch.int64, device="cuda")
+    caps = []
+    for g in range(G):
+        xlp.dev_merkle(sub, src[g * q * w:(g + 1) * q * w], w, q)
+        xlp.sync()
+        caps.append(xlp.to_np(sub[-4:]).copy())
+    lvl = caps
+    while len(lvl) > 1:
+        lvl = [orc.perm(list(lvl[2 * i]) + list(lvl[2 * i + 1]) + [0] * 4)[:4] for i in range(len(lvl) // 2)]
+    assert [int(x) for x in lvl[0]] == [int(x) for x in root]
+    # the sub-roots are also where the perfect tree puts them: level log2(q), index g
+    off, cnt = 0, h
+    level_off = []
+    while cnt >= 1:
+        level_off.append((off, cnt)); off += 4 * cnt; cnt //= 2
+    lo, lc = level_off[21]
+    assert lc == G
+    got_caps = xlp.to_np(nodes[lo:lo + 4 * G]).reshape(G, 4)
+    assert (got_caps == np.array(caps)).all()
+    # (b) + (c): pull only the nodes each path needs
+    rng = np.random.default_rng(w)
+    idxs = [0, 1, h - 1, q - 1, q, 5 * q + 12345] + [int(x) for x in rng.integers(0, h, 18)]
+    for idx in idxs:
+        row = orc.fill(w, seed, idx * w)
+        assert (xlp.to_np(src[idx * w:(idx + 1) * w]) == row).all()
+        leaf = xlp.to_np(nodes[4 * idx:4 * idx + 4])
+        assert [int(x) for x in leaf] == [int(x) for x in orc.linear_hash(row)], idx
+        sib, i = [], idx
+        for o, c in level_off[:-1]:
+            s = (i ^ 1) * 4
+            sib.append(xlp.to_np(nodes[o + s:o + s + 4])); i >>= 1
+        assert [int(x) for x in orc.merkle_root_from_path(row, np.concatenate(sib), idx)] == [int(x) for x in root], idx
+    # (d)
+    proofs = xlp.dev_merkle_proofs(src, nodes, w, h, idxs).reshape(len(idxs), -1)
+    assert proofs.shape[1] == w + 4 * 24
+    for p, idx in zip(proofs, idxs):
+        assert (p[:w] == orc.fill(w, seed, idx * w)).all()
+        assert [int(x) for x in orc.merkle_root_from_path(p[:w], p[w:], idx)] == [int(x) for x in root]
+    del src, nodes, sub
+    torch.cuda.empty_cache()

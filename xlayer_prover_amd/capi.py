@@ -113,8 +113,20 @@ def _ck(rc, what):
         raise XlpError(f"{what} failed: {load().xlp_last_error().decode()}")
 
 
-def init(device=0):
+def init(device=0, bind_torch_stream=True):
+    """Bind the library to HIP device `device`.  When torch is importable and sees a GPU, the library's work is put on torch's
+    current stream (xlp_set_stream), so that torch-side readers of the same buffers (to_np, from_np, .clone(), the caching
+    allocator's reuse of a freed tensor) are ordered after the kernels by stream order -- without that the library runs on its
+    own non-blocking stream and every caller has to remember xlp_sync()."""
     _ck(load().xlp_init(device), "xlp_init")
+    if bind_torch_stream:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.set_device(device)
+                use_torch_stream()
+        except ImportError:
+            pass
 
 
 def sync():
