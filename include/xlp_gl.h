@@ -231,6 +231,35 @@ int xlp_field_op(uint64_t* out, const uint64_t* a, const uint64_t* b, uint64_t n
 int xlp_profile_enable(int on);
 int xlp_profile_read(double ms_sum[3], uint64_t* count);
 
+/* ---- band-pipelined commit of a section (device pointers) ------------------------------------------
+ * A Merkle leaf is a sponge over the row in column order, so the leaf state (4 words per row = level 0 of the node buffer)
+ * can absorb a section band by band, right behind the LDE of each band.  These three are the pieces; the two commit calls
+ * below string them together.
+ *   xlp_dev_extend_cols         extendPol (starks.cpp:53,134,215) of the columns [col0, col0 + ncols) of row-major sections of
+ *                               row stride ld (in: n rows, out: n_ext rows);
+ *   xlp_dev_linear_hash_absorb  continue PoseidonGoldilocks::linear_hash of every row over the band [col0, col0 + ncols) of src
+ *                               (row stride ld): state (h x 4) holds the capacity between calls and the leaf after the last;
+ *                               col0 % 8 == 0; ncols % 8 == 0 unless `last`; `first` starts from capacity 0;
+ *   xlp_dev_merkle_levels       the levels above the leaves of merkletree (nodes[0 .. 4h) already holds level 0). */
+int xlp_dev_extend_cols(uint64_t* out, const uint64_t* in, uint64_t n_ext, uint64_t n, uint64_t ld, uint64_t col0, uint64_t ncols);
+int xlp_dev_linear_hash_absorb(uint64_t* state, const uint64_t* src, uint64_t ld, uint64_t col0, uint64_t ncols, uint64_t h, int first, int last);
+int xlp_dev_merkle_levels(uint64_t* nodes, uint64_t h);
+/* ntt.extendPol(cmX_2ns, cmX_n, ...) followed by treesGL[i]->merkelize() (starks.cpp:53-56,134-137,215-218) as one call:
+ * sec_2ns (n_ext x ncols) and nodes ((2 n_ext - 1) * 4) from sec_n (n x ncols), in 64-column bands. */
+int xlp_dev_commit(uint64_t* sec_2ns, uint64_t* nodes, const uint64_t* sec_n, uint64_t n_ext, uint64_t n, uint64_t ncols);
+/* The same for a section whose base-domain rows are still in HOST memory -- the witness the executor leaves at pAddress
+ * (prover.cpp:435 -> starks.cpp:53): h_src (n x ncols, row-major; pinned with xlp_host_alloc / xlp_host_register for full PCIe
+ * rate) is uploaded into sec_n band by band on a second stream while the previous band is extended and absorbed, so the
+ * 50.4 GB of the zkEVM witness cross PCIe behind the LDE and the leaf hashing instead of in front of them.  *upload_ms (may be
+ * NULL) receives the time the copy stream was busy; asking for it synchronises. */
+int xlp_dev_commit_from_host(uint64_t* sec_n, uint64_t* sec_2ns, uint64_t* nodes, const uint64_t* h_src, uint64_t n_ext, uint64_t n, uint64_t ncols,
+                             double* upload_ms);
+/* Page-locked host memory for the witness slab (hipHostMalloc / hipHostRegister behind a HIP-free signature). */
+int xlp_host_alloc(void** ptr, size_t bytes);
+int xlp_host_free(void* ptr);
+int xlp_host_register(void* ptr, size_t bytes);
+int xlp_host_unregister(void* ptr);
+
 /* Plain device memory helpers so a C++/cgo/ctypes host needs no HIP headers. */
 int xlp_dev_alloc(void** ptr, size_t bytes);
 int xlp_dev_free(void* ptr);

@@ -69,7 +69,19 @@ lib = _load()
 
 
 def _a(x):
+    if isinstance(x, (list, tuple)) and x and isinstance(x[0], (int, np.integer)):
+        return np.array([int(v) for v in x], dtype=np.uint64)          # exact (a dtype-less conversion of mixed magnitudes goes through float64)
     return np.ascontiguousarray(np.asarray(x, dtype=np.uint64))
+
+
+def _vec(x):
+    """a few field elements -> exact uint64 vector"""
+    if isinstance(x, np.ndarray):
+        assert x.dtype.kind in "ui"
+        return np.ascontiguousarray(x, dtype=np.uint64).ravel()
+    if isinstance(x, (int, np.integer)):
+        x = [x]
+    return np.array([int(v) for v in x], dtype=np.uint64)
 
 
 def add(a, b): return lib.orc_add(a, b)
@@ -226,7 +238,7 @@ def q_split(qq1, n, n_ext, qdeg, qdim, shift_in):
 
 def geometric(n, dim, first, ratio):
     out = np.zeros(max(n * dim, 1), np.uint64)
-    lib.orc_geometric(out, n, dim, _a(np.atleast_1d(first)), _a(np.atleast_1d(ratio)))
+    lib.orc_geometric(out, n, dim, _vec(first), _vec(ratio))
     return out[: n * dim].reshape(n, dim) if dim == 3 else out[:n]
 
 

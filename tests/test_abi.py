@@ -48,3 +48,21 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 src = open(os.path.join(dp, f), errors="ignore").read()
                 assert "gl_oracle" not in src and "oracle/" not in src.replace("the oracle", ""), f"{f} references the oracle"
+
+
+def test_field_element_vectors_are_converted_exactly(orc):
+    """a list mixing values below and above 2^63 becomes float64 under np.atleast_1d / np.asarray without a dtype and loses its
+    low bits (found by the low-degree check of tests/zkevm_checks.py: LEv was built from a rounded xi / shift): the bindings
+    convert with an explicit uint64 dtype"""
+    import numpy as np
+    from xlayer_prover_amd import capi
+    P = 0xFFFFFFFF00000001
+    v = [2**63 + 5, 3, P - 1]
+    assert [int(x) for x in capi._u64vec(v)] == v and [int(x) for x in capi._u64vec(np.array(v, np.uint64))] == v
+    assert [int(x) for x in capi._u64vec(7)] == [7]
+    g = orc.geometric(4, 3, [1, 0, 0], v)
+    assert [int(x) for x in g[1]] == v
+    assert [int(x) for x in g[2]] == [int(x) for x in orc.mul3(v, v)]
+    x = orc.x_div_x_sub_xi(np.array([11], np.uint64), v)[0]
+    den = [orc.sub(11, v[0]), orc.sub(0, v[1]), orc.sub(0, v[2])]
+    assert [int(t) for t in orc.mul3(x, den)] == [11, 0, 0]

@@ -24,15 +24,6 @@ def xlp():
     return capi
 
 
-def _path(h_nodes_levels, idx):
-    """sibling nodes bottom-up from a list of per-level host arrays (merkleTreeGL.cpp:24-35)"""
-    sib = []
-    for lvl in h_nodes_levels:
-        sib.append(lvl[4 * (idx ^ 1):4 * (idx ^ 1) + 4])
-        idx >>= 1
-    return np.concatenate(sib) if sib else np.zeros(0, np.uint64)
-
-
 @pytest.mark.parametrize("w", [751, 670])
 def test_merkle_config3_full_size(xlp, orc, w):
     """2^24 x w rows resident in HBM (dev_fill: the synthetic trace of SURVEY 8d, regenerated row by row on the oracle side):
@@ -95,3 +86,55 @@ def test_merkle_config3_full_size(xlp, orc, w):
         assert [int(x) for x in orc.merkle_root_from_path(p[:w], p[w:], idx)] == [int(x) for x in root]
     del src, nodes, sub
     torch.cuda.empty_cache()
+
+
+def _checked_run(xlp, args, timeout):
+    """tests/zkevm_genproof_checked.py in its own process (this one first gives its HBM back: the 2^23 run needs ~293 GB)"""
+    import torch
+    torch.cuda.empty_cache()
+    xlp.shutdown()
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "zkevm_genproof_checked.py")] + args, capture_output=True, text=True, timeout=timeout)
+    finally:
+        xlp.init(0)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def _programs_built(circ):
+    from xlayer_prover_amd import programs as R
+    return os.path.exists(os.path.join(R.REF_DIR, f"{circ}.step52ns.xlpexpr"))
+
+
+@pytest.mark.parametrize("circ,args", [("recursive1", []), ("c12a", []), ("zkevm", ["--log-n", "14", "--aliased", "1"]), ("zkevm", ["--log-n", "16", "--aliased", "0"])])
+def test_genproof_small_geometries_checked(xlp, circ, args):
+    """the checked run on the two small STARKs of genBatchProof at their real geometry (prover.cpp:610,644) and on the zkEVM
+    programs at reduced row counts, both slab layouts: every check of tests/zkevm_checks.py"""
+    if not _programs_built(circ):
+        pytest.skip("converted reference programs not built (needs the reference tree at build time)")
+    out = _checked_run(xlp, ["--circuit", circ] + args, 900)
+    c = out["checks"]
+    assert c["transcript_replayed"] and c["evals_checked"] >= 8 and c["fri_folds"] > 0 and c["merkle_paths"] > 0
+    assert all(v >= 64 for v in c["step_program_rows"].values()) and len(c["step_program_rows"]) >= 4
+
+
+def test_zkevm_genproof_2p23_checked(xlp):
+    """BASELINE configs[3] at the real size on one GPU: Starks::genProof at the fork-9 zkEVM geometry, N = 2^23 (aliased 239 GB
+    slab), with the step-program forms that bench.py times (dot-product rewrite + ahead-of-time plugins, FRI polynomial as
+    table program + xlp_dev_dot_columns), CHECKED against the CPU oracle: for each of the five programs >= 64 sampled rows equal
+    the as-converted reference program run on the oracle; >= 8 evaluations recomputed from the resident columns; all
+    128 x 5 Merkle openings and every FRI tree path verify; the fold chain of all 128 queries down to the final polynomial; the
+    transcript replays.  The checked pass has the same roots as the timed pass."""
+    import torch
+    if not _programs_built("zkevm"):
+        pytest.skip("converted reference programs not built (needs the reference tree at build time)")
+    _, total = torch.cuda.mem_get_info()
+    if total < 300e9:
+        pytest.skip("needs the 288 GB of an MI355X")
+    out = _checked_run(xlp, ["--circuit", "zkevm", "--log-n", "23"], 1100)
+    c = out["checks"]
+    assert set(c["step_program_rows"]) == {"step2prev", "step3prev", "step3", "step42ns", "step52ns"}
+    assert all(v >= 64 for v in c["step_program_rows"].values())
+    assert c["evals_checked"] >= 8 and c["transcript_replayed"]
+    assert c["merkle_paths"] == 128 * 5 + 128 * 4 and c["fri_folds"] == 128 * 4 and c["fri_first_tree_vs_f"] == 128
+    assert "compiled" in out["programs"]["step42ns"] and "dot_columns" in out["programs"]["step52ns"]

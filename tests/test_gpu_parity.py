@@ -577,3 +577,104 @@ def test_copy_cols_strided_views(xlp, n, ws, wd, dim):
     exp = dst.reshape(n, wd).copy()
     exp[:, cd:cd + dim] = src.reshape(n, ws)[:, cs:cs + dim]
     assert (d_dst.cpu().numpy().reshape(n, wd) == exp).all()
+
+
+# ---------------------------------------------------------------- band-pipelined commit (xlp_dev_commit / xlp_dev_commit_from_host)
+@pytest.mark.parametrize("w,bands", [(5, [5]), (8, [8]), (9, [8, 1]), (70, [64, 6]), (751, [64] * 11 + [47]), (168, [8, 16, 24, 120]), (23, [16, 7])])
+def test_linear_hash_absorbed_in_bands_equals_linear_hash(xlp, orc, w, bands):
+    """the leaf sponge continued band by band (xlp_dev_linear_hash_absorb) == PoseidonGoldilocks::linear_hash of the whole row"""
+    import torch
+    h = 300
+    src = edge_matrix(orc, h, w, 0x5EED00B1)
+    d = xlp.from_np(src.reshape(-1))
+    st = torch.empty(4 * h, dtype=torch.int64, device="cuda"); st.fill_(-1)
+    c0 = 0
+    for i, wc in enumerate(bands):
+        xlp.dev_linear_hash_absorb(st, d, w, c0, wc, h, i == 0, i == len(bands) - 1); c0 += wc
+    xlp.sync()
+    exp = np.array([orc.linear_hash(r) for r in src])
+    assert (xlp.to_np(st).reshape(h, 4) == exp).all()
+    with pytest.raises(xlp.XlpError):
+        xlp.dev_linear_hash_absorb(st, d, w, 4, 4, h, True, False)            # a band may not start inside a sponge block
+
+
+@pytest.mark.parametrize("lg,ext,w,first,wc", [(10, 1, 70, 8, 40), (12, 2, 17, 5, 12), (17, 1, 75, 64, 11), (17, 1, 130, 0, 64), (18, 1, 9, 3, 5)])
+def test_extend_column_window_vs_oracle(xlp, orc, lg, ext, w, first, wc):
+    """extendPol of a window of columns inside row-major sections (xlp_dev_extend_cols): the window equals the oracle's LDE of
+    those columns, everything outside it is untouched"""
+    import torch
+    n, n_ext = 1 << lg, 1 << (lg + ext)
+    src = orc.fill(n * w, 0x5EED00B2 + lg).reshape(n, w)
+    d_in = xlp.from_np(src.reshape(-1))
+    d_out = torch.full((n_ext * w,), 7, dtype=torch.int64, device="cuda")
+    xlp.dev_extend_cols(d_out, d_in, n_ext, n, w, first, wc)
+    xlp.sync()
+    got = xlp.to_np(d_out).reshape(n_ext, w)
+    exp = orc.extend_pol(np.ascontiguousarray(src[:, first:first + wc]), n_ext, n, wc)
+    assert (got[:, first:first + wc] == exp).all()
+    assert (got[:, :first] == 7).all() and (got[:, first + wc:] == 7).all()
+
+
+@pytest.mark.parametrize("lg,ext,w", [(9, 1, 3), (10, 1, 70), (12, 1, 751), (17, 1, 75), (17, 2, 130), (11, 3, 64), (18, 1, 200)])
+def test_band_pipelined_commit_from_host_vs_oracle(xlp, orc, lg, ext, w):
+    """starks.cpp:53-60 as ONE pipelined call on a witness that lives in host memory (prover.cpp:435): column bands are uploaded
+    on a second stream while the previous band is extended and absorbed into the leaf hashes.  The uploaded section, its
+    extension and the whole node buffer equal the oracle's extendPol + merkletree; the device-resident form (xlp_dev_commit)
+    and a pageable (not page-locked) source give the same."""
+    import torch
+    n, n_ext = 1 << lg, 1 << (lg + ext)
+    host = xlp.HostBuffer(n * w)
+    host.array[:] = edge_matrix(orc, n, w, 0x5EED00B3 + lg).reshape(-1)
+    src = host.array.reshape(n, w).copy()
+    sec_n = torch.zeros(n * w, dtype=torch.int64, device="cuda"); sec_2ns = torch.zeros(n_ext * w, dtype=torch.int64, device="cuda")
+    nodes = torch.zeros((2 * n_ext - 1) * 4, dtype=torch.int64, device="cuda")
+    ms = xlp.dev_commit_from_host(sec_n, sec_2ns, nodes, host, n_ext, n, w, want_upload_ms=True)
+    xlp.sync()
+    assert ms >= 0.0
+    exp_ext = orc.extend_pol(src, n_ext, n, w)
+    exp_nodes = orc.merkletree(exp_ext, w, n_ext)
+    assert (xlp.to_np(sec_n).reshape(n, w) == src).all()
+    assert (xlp.to_np(sec_2ns).reshape(n_ext, w) == exp_ext).all()
+    assert (xlp.to_np(nodes) == exp_nodes).all()
+    # device-resident form
+    sec_2ns.zero_(); nodes.zero_()
+    xlp.dev_commit(sec_2ns, nodes, sec_n, n_ext, n, w); xlp.sync()
+    assert (xlp.to_np(sec_2ns).reshape(n_ext, w) == exp_ext).all() and (xlp.to_np(nodes) == exp_nodes).all()
+    # pageable source
+    sec_n.zero_(); nodes.zero_()
+    xlp.dev_commit_from_host(sec_n, sec_2ns, nodes, np.ascontiguousarray(src.reshape(-1)), n_ext, n, w); xlp.sync()
+    assert (xlp.to_np(nodes) == exp_nodes).all() and (xlp.to_np(sec_n).reshape(n, w) == src).all()
+    host.close()
+
+
+def test_band_pipelined_commit_2p22_x_751_equals_plain_commit(xlp, orc):
+    """a zkEVM-width section, 2^22 rows (25 GB of witness in page-locked memory, 12 bands in flight): the pipelined commit equals
+    upload + xlp_dev_extend + xlp_dev_merkle on the same data bit for bit (both checked against the oracle at small sizes above),
+    the uploaded section equals the host rows, and the upload ran at a PCIe-like rate"""
+    import torch
+    lg, w = 22, 751
+    n, n_ext = 1 << lg, 1 << (lg + 1)
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 120e9:
+        pytest.skip("needs ~110 GB of free HBM")
+    seed = 0x5EED00B4
+    tmp = torch.empty(n * w, dtype=torch.int64, device="cuda")
+    xlp.dev_fill(tmp, seed, 0)
+    host = xlp.HostBuffer(n * w)
+    xlp.copy_d2h(host, tmp)                                     # the "executor" leaves the witness in host memory
+    assert (host.array[:8] == orc.fill(8, seed)).all() and (host.array[-8:] == orc.fill(8, seed, n * w - 8)).all()
+    ref_2ns = torch.empty(n_ext * w, dtype=torch.int64, device="cuda"); ref_nodes = torch.empty((2 * n_ext - 1) * 4, dtype=torch.int64, device="cuda")
+    xlp.dev_extend(ref_2ns, tmp, n_ext, n, w); xlp.dev_merkle(ref_nodes, ref_2ns, w, n_ext); xlp.sync()
+    ref_root = xlp.to_np(ref_nodes[-4:]).copy()
+    del ref_2ns
+    torch.cuda.empty_cache()
+    sec_n = torch.zeros(n * w, dtype=torch.int64, device="cuda"); sec_2ns = torch.empty(n_ext * w, dtype=torch.int64, device="cuda")
+    nodes = torch.zeros((2 * n_ext - 1) * 4, dtype=torch.int64, device="cuda")
+    ms = xlp.dev_commit_from_host(sec_n, sec_2ns, nodes, host, n_ext, n, w, want_upload_ms=True)
+    xlp.sync()
+    assert torch.equal(sec_n, tmp)
+    assert torch.equal(nodes, ref_nodes)
+    assert [int(v) for v in xlp.to_np(nodes[-4:])] == [int(v) for v in ref_root]
+    gbs = n * w * 8 / ms / 1e6
+    assert gbs > 20.0, f"upload ran at {gbs:.1f} GB/s"
+    host.close()

@@ -38,25 +38,35 @@ def inv(a): return pow(a, P - 2, P)
 
 
 def evmap_from_step52ns(code, L, const_2ns, nconst, pols, secs):
-    """which column each evals[k] belongs to: the `col - evals[k]` subtractions of the FRI-polynomial program
-    (starks.cpp:556-669 reads the same list from starkinfo.evMap).  A column's second evaluation is its next-row one."""
-    ents, seen = {}, {}
+    """which column each evals[k] belongs to, and at which point: the `col - evals[k]` subtractions of the FRI-polynomial program
+    (starks.cpp:556-669 reads the same list from starkinfo.evMap).  Whether evals[k] is the value at xi or at w xi follows the
+    data flow: the difference is accumulated into a chain that is finally multiplied by xDivXSubXi (-> xi) or xDivXSubWXi
+    (-> w xi), exactly how the verifier tells them apart."""
+    ents, tags, prime = {}, {}, {}
     for op, slots in decode(code):
         (dk, dd, dp), (ak, ad, apar), (bk, bd, bpar) = slots
-        if op != E.SUB or bk != E.K_EVAL:
-            continue
-        if ak == E.K_POLS:
-            off = apar[0]
-            name = [s for s, _, ext in secs if ext and L[s][1] and L[s][0] <= off < L[s][0] + L[s][1] * L[s][2]][-1]   # (sections may overlap: --aliased)
-            t = (pols[L[name][0]:L[name][0] + L[name][1] * L[name][2]], L[name][1], off - L[name][0], ad)
-            key = ("p", off)
-        elif ak == E.K_CONST2NS:
-            t = (const_2ns, nconst, apar[0], ad); key = ("c", apar[0])
-        else:
-            continue
-        seen[key] = seen.get(key, 0) + 1
-        ents[bpar[0]] = t + (seen[key] > 1,)
-    return [ents[k] for k in sorted(ents)], sorted(ents)
+        srcs = [(ak, ad, apar)] + ([(bk, bd, bpar)] if bk != E.K_NONE else [])
+        s = set()
+        for kind, dim, prm in srcs:
+            if kind == E.K_TMP3:
+                s |= tags.get(prm[0], set())
+        if op == E.SUB and bk == E.K_EVAL and ak in (E.K_POLS, E.K_CONST2NS):
+            if ak == E.K_POLS:
+                off = apar[0]
+                name = [sn for sn, _, ext in secs if ext and L[sn][1] and L[sn][0] <= off < L[sn][0] + L[sn][1] * L[sn][2]][-1]   # (sections may overlap: --aliased)
+                ents[bpar[0]] = (pols[L[name][0]:L[name][0] + L[name][1] * L[name][2]], L[name][1], off - L[name][0], ad)
+            else:
+                ents[bpar[0]] = (const_2ns, nconst, apar[0], ad)
+            s.add(bpar[0])
+        for kind, dim, prm in srcs:
+            if kind in (E.K_XDIVXSUBXI, E.K_XDIVXSUBWXI):
+                for k in s:
+                    prime[k] = kind == E.K_XDIVXSUBWXI
+                s = set()
+        if dk == E.K_TMP3:
+            tags[dp[0]] = s
+    assert set(prime) == set(ents), "an evaluation's chain never meets xDivXSubXi / xDivXSubWXi"
+    return [ents[k] + (prime[k],) for k in sorted(ents)], sorted(ents)
 
 
 def decode(code):
@@ -103,7 +113,14 @@ def main():
         print(json.dumps(out))
 
 
-def prove(a, circ, ln):
+class _Env:
+    """what a checker (tests/zkevm_checks.py) may look at: the resident buffers of the run"""
+
+
+def prove(a, circ, ln, hooks=None):
+    """hooks: optional object with begin(env) / pre_step(step, nrows) / post_step(step, nrows) / evals(ents, ev, xi, w_n) / fri(data),
+    called in an extra, untimed third pass whose roots must equal the reported pass's (tests/zkevm_checks.py checks the run
+    against the CPU oracle through it; this tool never imports the oracle)"""
     C = G.CIRCUITS[circ]
     ext = C["ext"]
     secs = G.sections(circ)
@@ -203,7 +220,16 @@ def prove(a, circ, ln):
     print(f"resident: {torch.cuda.memory_allocated() / 1e9:.1f} GB (torch), device {total_b / 1e9:.1f} GB of which {free_b / 1e9:.1f} GB free ; "
           f"slab {L['end'][0] * 8 / 1e9:.1f} GB ({'aliased' if aliased else 'reference'} layout) ; modes {mode}", flush=True)
 
+    checking = [False]
+
     def run(step, nrows):
+        if checking[0]:
+            hooks.pre_step(step, nrows)
+        run_(step, nrows)
+        if checking[0]:
+            torch.cuda.synchronize(); hooks.post_step(step, nrows)
+
+    def run_(step, nrows):
         sp = capi.steps_params(n_const_pols=nconst, n_const_pols_2ns=nconst, pols=pols, const_pols=const_n, const_pols_2ns=const_2ns,
                                challenges=capi.from_np(challenges), public_inputs=capi.from_np(publics), evals=evals_d, x_n=x_n, x_2ns=x_2ns,
                                zi=zi, x_div_x_sub_xi=xdx, x_div_x_sub_wxi=xdwx, q_2ns=sec("q_2ns"), f_2ns=sec("f_2ns"))
@@ -254,7 +280,21 @@ def prove(a, circ, ln):
         tr.put(root)
         return root
 
-    for rep in range(2):                                       # pass 0 warms allocators / code objects; pass 1 is reported
+    if hooks is not None:
+        env = _Env()
+        env.circ, env.ln, env.ext, env.N, env.NE, env.aliased, env.L, env.secs, env.nconst = circ, ln, ext, N, NE, aliased, L, secs, nconst
+        env.pols, env.sec, env.const_n, env.const_2ns, env.x_n, env.x_2ns, env.xdx, env.xdwx, env.evals_d = pols, sec, const_n, const_2ns, x_n, x_2ns, xdx, xdwx, evals_d
+        env.zi_host = [int(v) for v in capi.to_np(zi)]
+        env.challenges, env.publics = challenges, publics
+        env.to_np = capi.to_np
+        env.capi = capi
+        env.index = lambda rows: torch.tensor(rows, dtype=torch.int64, device=dev)
+        hooks.begin(env)
+    reported = None
+    for rep in range(3 if hooks is not None else 2):           # pass 0 warms allocators / code objects; pass 1 is reported; pass 2 (hooks) is checked
+        checking[0] = rep == 2
+        if rep == 2:
+            reported = (dict(timers), wall, [list(r) for r in roots], [list(r) for r in fri_roots])
         timers.clear()
         # the witness arrives resident; everything else on the base domain starts from zero (aliased: the previous proof's
         # cm3_2ns / const_2ns / q / f lie there)
@@ -319,6 +359,8 @@ def prove(a, circ, ln):
             evals_d[ev_index] = ev_out
             return capi.to_np(ev_out)
         ev = timed("STARK_STEP_5_EVMAP", evmap)
+        if checking[0]:
+            hooks.evals(ents, ev, [int(v) for v in xi], w_n)
         tr.put([int(v) for v in ev])
         challenges[15:18] = tr.get_field(); challenges[18:21] = tr.get_field()
 
@@ -330,9 +372,11 @@ def prove(a, circ, ln):
         def fri():
             pol = sec("f_2ns"); bits = steps[0]; sinv = inv(shift)
             ftrees = []; fri_roots.clear()
+            special = []
             for si, nb in enumerate(steps):
                 red = bits - nb
                 x = tr.get_field()
+                special.append([int(v) for v in x])
                 pol2 = torch.empty(3 << nb, dtype=i64, device=dev)
                 capi.dev_fri_fold(pol2, pol, bits, red, x, sinv)
                 if si < len(steps) - 1:
@@ -344,24 +388,39 @@ def prove(a, circ, ln):
                     ftrees.append((aux, nodes, gs * 3, ng))
                     fri_roots.append([int(v) for v in capi.to_np(nodes[-4:])]); tr.put(fri_roots[-1])
                 else:
-                    fri_roots.append([int(v) for v in capi.to_np(pol2)][:6]); tr.put([int(v) for v in capi.to_np(pol2)])
+                    final_pol = [int(v) for v in capi.to_np(pol2)]
+                    fri_roots.append(final_pol[:6]); tr.put(final_pol)
                 pol = pol2; bits = nb
                 for _ in range(red):
                     sinv = sinv * sinv % P
             ys = tr.get_permutations(queries, steps[0])
             opened = 0
-            for name in ("cm1_2ns", "cm2_2ns", "cm3_2ns", "cm4_2ns"):
+            s0, ft = [], []
+            for k, name in enumerate(("cm1_2ns", "cm2_2ns", "cm3_2ns", "cm4_2ns")):
                 if W[name]:                                    # (the zkin proof has no s0_vals2 when cm2 is empty)
-                    opened += capi.dev_merkle_proofs(sec(name), trees[name], W[name], NE, ys).size
-            opened += capi.dev_merkle_proofs(const_2ns, nodesC, nconst, NE, ys).size
+                    pr = capi.dev_merkle_proofs(sec(name), trees[name], W[name], NE, ys)
+                    opened += pr.size; s0.append((name, roots[k], W[name], pr))
+            pr = capi.dev_merkle_proofs(const_2ns, nodesC, nconst, NE, ys)
+            opened += pr.size; s0.append(("const", [int(v) for v in capi.to_np(nodesC[-4:])], nconst, pr))
             idx = ys
-            for aux, nodes, w, ng in ftrees:
+            for k, (aux, nodes, w, ng) in enumerate(ftrees):
                 idx = [y % ng for y in idx]
-                opened += capi.dev_merkle_proofs(aux, nodes, w, ng, idx).size
+                pr = capi.dev_merkle_proofs(aux, nodes, w, ng, idx)
+                opened += pr.size; ft.append((fri_roots[k], w, ng, pr))
+            if checking[0]:
+                ng1 = 1 << steps[1]
+                f3 = sec("f_2ns").view(-1, 3)
+                f_at = [capi.to_np(f3[torch.arange(0, NE, ng1, device=dev) + (int(y) % ng1)]).reshape(-1) for y in ys]
+                hooks.fri({"steps": steps, "ys": [int(y) for y in ys], "s0": s0, "fri_trees": ft, "special_x": special, "final_pol": final_pol,
+                           "f_at_queries": f_at, "roots": roots, "evals": [int(v) for v in ev], "challenges": [int(v) for v in challenges],
+                           "verkey": [int(v) for v in capi.to_np(nodesC[-4:])], "publics": [int(v) for v in publics]})
             return opened
         opened = timed("STARK_STEP_FRI", fri)
         torch.cuda.synchronize()
         wall = time.perf_counter() - t_proof
+    if reported is not None:                                   # the checked pass must be the reported pass again
+        assert reported[2] == roots and reported[3] == fri_roots, "checked pass differs from the reported pass"
+        timers.clear(); timers.update(reported[0]); wall = reported[1]
     out = {"workload": f"genProof, all stages, one run, {circ} geometry at N=2^{ln}, extended 2^{lne} (widths {'/'.join(str(W[k]) for k in ('cm1_n', 'cm2_n', 'cm3_n', 'cm4_n'))}, "
                        f"{nconst} const pols, {len(ents)} evaluations, "
                        f"{lookups} lookups, {nzs} grand products, FRI steps {steps}, {queries} queries), 1 GPU, synthetic witness",

@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Runs ON THE GPU BOX.  Collects the hardware counters bench.py quotes, each group in its own rocprofv3 pass (--pmc alone: no
+trace domains next to it), over tools/counter_workload.py, and writes ONE summary stamped with the hash of the kernel sources
+it was measured on:
+    python3 tools/collect_counters.py gpurun_out/r2/counters.json       # then copy it to profiles/rN/counters.json
+HBM bytes follow MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE in separate passes, KiB units, FETCH_SIZE x 2 on
+gfx950 (128-byte requests tallied as 64 B) -- the factor is re-derived here from the calibration copy (1 GiB in, 1 GiB out at
+8 B per lane, the access width of these kernels) and recorded."""
+import csv
+import glob
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from xlayer_prover_amd.srchash import csrc_hash      # noqa: E402
+
+PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU"]]
+KERNELS = {"lde_top_dif": "lde_top_dif", "lde_mid": "lde_mid", "lde_top_dit": "lde_top_dit", "linear_hash_kernel": "linear_hash",
+           "merkle_level_kernel": "merkle_level", "copy_canon_kernel": "calibration_copy"}
+
+
+def short(name):
+    for k, v in KERNELS.items():
+        if k in name:
+            return v
+    return None
+
+
+def run_pass(counters):
+    d = tempfile.mkdtemp(prefix="xlp_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = ["rocprofv3", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "tools", "counter_workload.py")]
+    r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        raise SystemExit(f"rocprofv3 failed: {r.stderr[-2000:]}")
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    acc = {}
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            k = short(row["Kernel_Name"])
+            if k is None:
+                continue
+            a = acc.setdefault(k, {}).setdefault(row["Counter_Name"], {})
+            a[row["Dispatch_Id"]] = a.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+    # average per dispatch
+    return {k: {c: sum(v.values()) / len(v) for c, v in cs.items()} | {"dispatches": len(next(iter(cs.values())))} for k, cs in acc.items()}
+
+
+def main():
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "counters.json")
+    per = {}
+    for p in PASSES:
+        for k, cs in run_pass(p).items():
+            per.setdefault(k, {}).update(cs)
+    cal = per.get("calibration_copy", {})
+    gib = float(1 << 20)                                            # 1 GiB in KiB
+    fetch_factor = gib / cal["FETCH_SIZE"] if cal.get("FETCH_SIZE") else 2.0
+    write_factor = gib / cal["WRITE_SIZE"] if cal.get("WRITE_SIZE") else 1.0
+    for k, cs in per.items():
+        if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            cs["hbm_bytes"] = int((cs["FETCH_SIZE"] * round(fetch_factor) + cs["WRITE_SIZE"] * round(write_factor)) * 1024)
+    lde = [per[k] for k in ("lde_top_dif", "lde_mid", "lde_top_dit")]
+    n, ncols = 1 << 23, 8
+    h, w = 1 << 20, 751
+    perms_leaf = h * ((w + 7) // 8)
+    res = {
+        "csrc_sha256": csrc_hash(),
+        "source": "rocprofv3 --pmc <group> -- python3 tools/counter_workload.py, one pass per group: " + " | ".join(" ".join(p) for p in PASSES),
+        "correction": {"fetch_factor_measured": round(fetch_factor, 4), "write_factor_measured": round(write_factor, 4),
+                       "applied": "FETCH_SIZE x 2, WRITE_SIZE x 1 (KiB), per MI355X_MICROARCH.md; the measured factors are the calibration copy's (1 GiB each way, 8 B per lane)"},
+        "per_kernel": per,
+        "lde": {"workload": "extendPol 2^23 x 8 -> 2^24 x 8", "hbm_bytes_per_lde": sum(x["hbm_bytes"] for x in lde),
+                "algorithmic_bytes_per_lde": 8 * n * ncols * 3, "valu_wave_instructions_per_lde": sum(x["SQ_INSTS_VALU"] for x in lde)},
+        "merkle": {"workload": "merkletree 2^20 x 751", "leaf_permutations": perms_leaf, "hbm_bytes_linear_hash": per["linear_hash"]["hbm_bytes"],
+                   "algorithmic_bytes_linear_hash": 8 * h * w + 32 * h,
+                   "valu_wave_instructions_linear_hash": per["linear_hash"]["SQ_INSTS_VALU"],
+                   "valu_lane_instructions_per_permutation": per["linear_hash"]["SQ_INSTS_VALU"] * 64 / perms_leaf},
+        "issue_peak_wave_instructions_per_s": 610e9,
+        "issue_peak_basis": "1024 SIMDs x 2.4 GHz / 4.2 cycles per half-rate wave64 instruction (carry adds, v_mad_u64_u32, v_cndmask: "
+                            "profiles/r1/ubench_instruction_rates.txt), ~10% full-rate moves",
+    }
+    os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
+    json.dump(res, open(out_path, "w"), indent=1)
+    print(json.dumps({k: res[k] for k in ("csrc_sha256", "correction", "lde", "merkle")}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

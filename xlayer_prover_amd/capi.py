@@ -58,6 +58,15 @@ SIGNATURES = {
     "xlp_dev_expr_run": [_pu, _pu, _u64, _u64],
     "xlp_profile_enable": [C.c_int],
     "xlp_profile_read": [C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
+    "xlp_dev_extend_cols": [_pu, _pu, _u64, _u64, _u64, _u64, _u64],
+    "xlp_dev_linear_hash_absorb": [_pu, _pu, _u64, _u64, _u64, _u64, C.c_int, C.c_int],
+    "xlp_dev_merkle_levels": [_pu, _u64],
+    "xlp_dev_commit": [_pu, _pu, _pu, _u64, _u64, _u64],
+    "xlp_dev_commit_from_host": [_pu, _pu, _pu, _pu, _u64, _u64, _u64, C.POINTER(C.c_double)],
+    "xlp_host_alloc": [C.POINTER(C.c_void_p), C.c_size_t],
+    "xlp_host_free": [_pu],
+    "xlp_host_register": [_pu, C.c_size_t],
+    "xlp_host_unregister": [_pu],
     "xlp_dev_alloc": [C.POINTER(C.c_void_p), C.c_size_t],
     "xlp_dev_free": [_pu],
     "xlp_copy_h2d": [_pu, _pu, C.c_size_t],
@@ -133,6 +142,11 @@ def sync():
     _ck(load().xlp_sync(), "xlp_sync")
 
 
+def shutdown():
+    """release the context (tables, scratch slots, stream); a later init() binds again"""
+    load().xlp_shutdown()
+
+
 def profile_enable(on=True):
     _ck(load().xlp_profile_enable(1 if on else 0), "xlp_profile_enable")
 
@@ -154,6 +168,17 @@ def use_torch_stream():
 # ----------------------------------------------------------------- host layer
 def _np(a):
     return np.ascontiguousarray(np.asarray(a, dtype=np.uint64))
+
+
+def _u64vec(x):
+    """a few field elements (Python ints, a list, an ndarray) -> exact uint64 vector.  NOT via np.atleast_1d / np.asarray
+    without a dtype: a list mixing values below and above 2^63 becomes float64 there and loses its low bits."""
+    if isinstance(x, np.ndarray):
+        assert x.dtype.kind in "ui", "field elements as floating point"
+        return np.ascontiguousarray(x, dtype=np.uint64).ravel()
+    if isinstance(x, (int, np.integer)):
+        x = [x]
+    return np.array([int(v) for v in x], dtype=np.uint64)
 
 
 def _p(a):
@@ -252,6 +277,59 @@ def dev_merkle(nodes, src, w, h):
     _ck(load().xlp_dev_merkle(_dp(nodes), _dp(src), w, h), "xlp_dev_merkle")
 
 
+def dev_extend_cols(out, src, n_ext, n, ld, col0, ncols):
+    _ck(load().xlp_dev_extend_cols(_dp(out), _dp(src), n_ext, n, ld, col0, ncols), "xlp_dev_extend_cols")
+
+
+def dev_linear_hash_absorb(state, src, ld, col0, ncols, h, first, last):
+    _ck(load().xlp_dev_linear_hash_absorb(_dp(state), _dp(src), ld, col0, ncols, h, 1 if first else 0, 1 if last else 0), "xlp_dev_linear_hash_absorb")
+
+
+def dev_merkle_levels(nodes, h):
+    _ck(load().xlp_dev_merkle_levels(_dp(nodes), h), "xlp_dev_merkle_levels")
+
+
+def dev_commit(sec_2ns, nodes, sec_n, n_ext, n, ncols):
+    """extendPol + merkelize of one section in 64-column bands (xlp_dev_commit)"""
+    _ck(load().xlp_dev_commit(_dp(sec_2ns), _dp(nodes), _dp(sec_n), n_ext, n, ncols), "xlp_dev_commit")
+
+
+def dev_commit_from_host(sec_n, sec_2ns, nodes, host, n_ext, n, ncols, want_upload_ms=False):
+    """host: HostBuffer (pinned) or a C-contiguous uint64 ndarray holding the n x ncols base-domain rows"""
+    ptr = host.ptr if isinstance(host, HostBuffer) else host.ctypes.data_as(C.c_void_p)
+    ms = C.c_double(0.0)
+    _ck(load().xlp_dev_commit_from_host(_dp(sec_n), _dp(sec_2ns), _dp(nodes), ptr, n_ext, n, ncols, C.byref(ms) if want_upload_ms else None), "xlp_dev_commit_from_host")
+    return ms.value
+
+
+class HostBuffer:
+    """page-locked host memory (xlp_host_alloc); .array is a uint64 ndarray view of it"""
+
+    def __init__(self, words):
+        self.ptr = C.c_void_p(None)
+        _ck(load().xlp_host_alloc(C.byref(self.ptr), 8 * max(words, 1)), "xlp_host_alloc")
+        self.words = words
+        self.array = np.ctypeslib.as_array(C.cast(self.ptr, C.POINTER(C.c_uint64)), shape=(max(words, 1),))[:words]
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            load().xlp_host_free(self.ptr)
+            self.ptr = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def copy_d2h(host, dev_tensor):
+    """device tensor -> HostBuffer / ndarray (synchronous)"""
+    ptr = host.ptr if isinstance(host, HostBuffer) else host.ctypes.data_as(C.c_void_p)
+    _ck(load().xlp_copy_d2h(ptr, _dp(dev_tensor), 8 * dev_tensor.numel()), "xlp_copy_d2h")
+
+
 def dev_perm_batch(out, src, count):
     _ck(load().xlp_dev_perm_batch(_dp(out), _dp(src), count), "xlp_dev_perm_batch")
 
@@ -261,7 +339,7 @@ def dev_linear_hash(out, src, w, h):
 
 
 def dev_fri_fold(pol2, pol, bits, red, x, shift_inv):
-    x = _np(x)
+    x = _u64vec(x)
     _ck(load().xlp_dev_fri_fold(_dp(pol2), _dp(pol), bits, red, _p(x), int(shift_inv)), "xlp_dev_fri_fold")
 
 
@@ -301,13 +379,13 @@ def dev_q_split(qq2, qq1, n, n_ext, q_deg, q_dim, shift_in):
 
 
 def dev_geometric(out, n, dim, first, ratio):
-    f = np.ascontiguousarray(np.atleast_1d(first), dtype=np.uint64); r = np.ascontiguousarray(np.atleast_1d(ratio), dtype=np.uint64)
+    f = _u64vec(first); r = _u64vec(ratio)
     assert f.size == dim and r.size == dim
     _ck(load().xlp_dev_geometric(_dp(out), n, dim, f.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p)), "xlp_dev_geometric")
 
 
 def dev_x_div_x_sub_xi(out, x, xi, n):
-    v = np.ascontiguousarray(xi, dtype=np.uint64)
+    v = _u64vec(xi)
     assert v.size == 3
     _ck(load().xlp_dev_x_div_x_sub_xi(_dp(out), _dp(x), v.ctypes.data_as(C.c_void_p), n), "xlp_dev_x_div_x_sub_xi")
 

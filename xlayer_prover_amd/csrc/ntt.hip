@@ -496,4 +496,25 @@ int dev_extend(Ctx* ctx, u64* out, const u64* in, u64 n_ext, u64 n, u64 ncols, u
     return 0;
 }
 
+// extendPol restricted to the columns [first, first + ncols) of row-major sections of row stride ld (in: n rows, out: n_ext
+// rows): the unit of the band-pipelined commit (xlp_dev_commit_from_host) -- a section is uploaded, extended and absorbed
+// into its leaf hashes band by band.  Sizes outside the three-kernel fast path go through a dense copy of the band.
+int dev_extend_cols(Ctx* ctx, u64* out, const u64* in, u64 n_ext, u64 n, u64 ld, u64 first, u64 ncols)
+{
+    if (n == 0 || ncols == 0) return 0;
+    if (first + ncols > ld) return xlp_fail("extendPol (column window): window exceeds the row stride");
+    if ((n & (n - 1)) || (n_ext & (n_ext - 1)) || n_ext < n) return xlp_fail("extendPol: sizes must be powers of two, n_ext >= n");
+    u32 L = 0, Le = 0;
+    while ((1ull << L) < n) L++;
+    while ((1ull << Le) < n_ext) Le++;
+    if (Le > 32) return xlp_fail("extendPol: size exceeds 2^32");
+    if (lde_fast_supported(L, Le - L, ncols)) return dev_extend_fast_cols(ctx, out, in, L, Le - L, ld, first, ncols);
+    if (first == 0 && ncols == ld) return dev_extend(ctx, out, in, n_ext, n, ncols, nullptr);
+    u64* dense = nullptr;
+    if (ctx_scratch(ctx, (n + n_ext) * ncols * sizeof(u64), 2, &dense)) return -1;
+    if (dev_copy_cols(ctx, dense, ncols, in + first, ld, n, (u32)ncols)) return -1;
+    if (dev_extend(ctx, dense + n * ncols, dense, n_ext, n, ncols, nullptr)) return -1;
+    return dev_copy_cols(ctx, out + first, ld, dense + n * ncols, ncols, n_ext, (u32)ncols);
+}
+
 }  // namespace xlp

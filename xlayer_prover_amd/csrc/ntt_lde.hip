@@ -550,11 +550,17 @@ bool lde_fast_supported(u32 L, u32 e, u64 ncols)
 
 int dev_extend_fast(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ncols)
 {
+    return dev_extend_fast_cols(ctx, out, in, L, e, ncols, 0, ncols);
+}
+
+// columns [first, first + ncols) of row-major matrices with row stride ld (in: n rows, out: n << e rows)
+int dev_extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld, u64 first, u64 ncols)
+{
     const u32 BT = L - 12;
     const u64 n = 1ull << L;
     const u32 ncos = 1u << e;
     LdeParams p{};
-    p.in = in; p.ld_in = ncols; p.out = out; p.ld_out = ncols; p.L = L; p.e = e;
+    p.in = in; p.ld_in = ld; p.out = out; p.ld_out = ld; p.L = L; p.e = e;
     const u64 wn = host_w(L), wbt = host_w(BT), w12 = host_w(12), wext = host_w(L + e);
     const u64* dummy;
     if (get_pow_tables(ctx, BT, hgl::inv(wbt), 1, &p.twi_bt, &dummy)) return -1;
@@ -602,7 +608,7 @@ int dev_extend_fast(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ncols)
         mid_attr = true;
     }
     for (u64 col0 = 0; col0 < ncols; col0 += wc_max) {
-        p.col0 = (u32)col0;
+        p.col0 = (u32)(first + col0);
         p.wc = (u32)(ncols - col0 < wc_max ? ncols - col0 : wc_max);
         p.B = p.A + n * p.wc;
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};

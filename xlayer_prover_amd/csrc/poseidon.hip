@@ -191,6 +191,40 @@ __global__ __launch_bounds__(256) void linear_hash_kernel(u64* out, const u64* s
     for (int k = 0; k < 4; k++) out[4 * row + k] = st[k];
 }
 
+// The same sponge continued over a band of columns: state[4*row..] carries the capacity between calls (it IS the leaf once the
+// last band is absorbed).  Band = columns [first, first + wc) of a row-major matrix of row stride ld; first is a multiple of
+// 8 (a sponge block never straddles two bands) and only the last band may have wc % 8 != 0 (zero-padded like the tail of
+// linear_hash).  Absorbing the bands of a row in order gives exactly linear_hash(row): capacity 0^4 before the first block,
+// out[0..3] of the previous block afterwards.
+__global__ __launch_bounds__(256) void linear_hash_absorb_kernel(u64* state, const u64* src, u64 ld, u64 first, u64 wc, u64 h, int is_first)
+{
+    u64 row = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= h) return;
+    const u64* in = src + row * ld + first;
+    u64 st[12];
+    if (is_first) { st[8] = st[9] = st[10] = st[11] = 0; }
+    else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) st[8 + k] = state[4 * row + k];
+    }
+    u64 rem = wc;
+    while (rem) {
+        if (rem >= 8) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) st[k] = in[k];
+            in += 8; rem -= 8;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) st[k] = (u64)k < rem ? in[k] : 0;
+            rem = 0;
+        }
+        permute(st);
+        st[8] = st[0]; st[9] = st[1]; st[10] = st[2]; st[11] = st[3];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) state[4 * row + k] = st[k];
+}
+
 // One tree level: nxt[j] = perm(cur[2j] | cur[2j+1] | 0^4)[0..3].
 __global__ __launch_bounds__(256) void merkle_level_kernel(u64* nxt, const u64* cur, u64 count)
 {
@@ -229,6 +263,18 @@ int dev_linear_hash(Ctx* ctx, u64* out, const u64* src, u64 w, u64 h)
     return 0;
 }
 
+int dev_linear_hash_absorb(Ctx* ctx, u64* state, const u64* src, u64 ld, u64 first, u64 ncols, u64 h, int is_first, int is_last)
+{
+    if (!h || !ncols) return 0;
+    if (first % 8) return xlp_fail("linear hash (band): the band must start at a multiple of 8 columns");
+    if (!is_last && ncols % 8) return xlp_fail("linear hash (band): only the last band may end inside a sponge block");
+    if (first + ncols > ld) return xlp_fail("linear hash (band): band exceeds the row stride");
+    if (is_first && is_last && ncols <= 4) return xlp_fail("linear hash (band): rows of <= 4 columns are not hashed (use xlp_dev_linear_hash)");
+    hipLaunchKernelGGL(linear_hash_absorb_kernel, dim3((unsigned)((h + 255) / 256)), dim3(256), 0, ctx->stream, state, src, ld, first, ncols, h, is_first);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
 // PoseidonGoldilocks::merkletree_avx(tree, input, ncols, nrows): nodes =
 // level0 | level1 | ... | root, (2h-1)*4 elements (merkleTreeGL.hpp:61-68).
 int dev_merkle(Ctx* ctx, u64* nodes, const u64* src, u64 w, u64 h)
@@ -236,6 +282,14 @@ int dev_merkle(Ctx* ctx, u64* nodes, const u64* src, u64 w, u64 h)
     if (!h) return 0;
     if (h & (h - 1)) return xlp_fail("merkletree: number of rows is not a power of two");
     if (dev_linear_hash(ctx, nodes, src, w, h)) return -1;
+    return dev_merkle_levels(ctx, nodes, h);
+}
+
+// the levels above the leaves: nodes[0 .. 4h) already holds level 0
+int dev_merkle_levels(Ctx* ctx, u64* nodes, u64 h)
+{
+    if (!h) return 0;
+    if (h & (h - 1)) return xlp_fail("merkletree: number of rows is not a power of two");
     u64 off = 0, cnt = h;
     while (cnt > 1) {
         u64 half = cnt / 2;

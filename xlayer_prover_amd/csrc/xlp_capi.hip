@@ -7,6 +7,8 @@
 #include <stdio.h>
 #include <mutex>
 #include <string>
+#include <vector>
+#include <stdlib.h>
 #include "../../include/xlp_gl.h"
 #include "xlp_internal.hpp"
 
@@ -130,6 +132,7 @@ void xlp_shutdown(void)
         g_ctx.scratch_bytes[i] = 0;
     }
     if (g_ctx.own_stream) (void)hipStreamDestroy(g_ctx.stream);
+    if (g_ctx.copy_stream) { (void)hipStreamSynchronize(g_ctx.copy_stream); (void)hipStreamDestroy(g_ctx.copy_stream); g_ctx.copy_stream = nullptr; }
     g_ctx.stream = nullptr;
     g_ctx.own_stream = false;
     g_ctx.inited = false;
@@ -313,6 +316,119 @@ int xlp_copy_d2h(void* dst_host, const void* src_dev, size_t bytes)
     XLP_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, g_ctx.stream));
     XLP_HIP(hipStreamSynchronize(g_ctx.stream));
     return 0;
+}
+
+int xlp_host_alloc(void** ptr, size_t bytes)
+{
+    if (ensure_init()) return -1;
+    XLP_HIP(hipHostMalloc(ptr, bytes ? bytes : 8, hipHostMallocDefault));
+    return 0;
+}
+int xlp_host_free(void* ptr)
+{
+    if (!ptr) return 0;
+    XLP_HIP(hipHostFree(ptr));
+    return 0;
+}
+int xlp_host_register(void* ptr, size_t bytes)
+{
+    if (ensure_init()) return -1;
+    if (!ptr || !bytes) return xlp_fail("xlp_host_register: empty range");
+    XLP_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return 0;
+}
+int xlp_host_unregister(void* ptr)
+{
+    if (!ptr) return 0;
+    XLP_HIP(hipHostUnregister(ptr));
+    return 0;
+}
+
+int xlp_dev_extend_cols(uint64_t* out, const uint64_t* in, uint64_t n_ext, uint64_t n, uint64_t ld, uint64_t col0, uint64_t ncols)
+{
+    if (ensure_init()) return -1;
+    return dev_extend_cols(&g_ctx, out, in, n_ext, n, ld, col0, ncols);
+}
+int xlp_dev_linear_hash_absorb(uint64_t* state, const uint64_t* src, uint64_t ld, uint64_t col0, uint64_t ncols, uint64_t h, int first, int last)
+{
+    if (ensure_init()) return -1;
+    return dev_linear_hash_absorb(&g_ctx, state, src, ld, col0, ncols, h, first, last);
+}
+int xlp_dev_merkle_levels(uint64_t* nodes, uint64_t h)
+{
+    if (ensure_init()) return -1;
+    return dev_merkle_levels(&g_ctx, nodes, h);
+}
+
+// extendPol + merkelize of one section, band by band (starks.cpp:53-60 / :134-141 / :215-222 as ONE pipeline): the leaf sponge of
+// a row absorbs its columns in order, so a band of columns can be hashed into the 4-word leaf state as soon as it is extended.
+// With h_src the bands are first uploaded on the copy stream -- band b+1 crosses PCIe while band b is extended and absorbed.
+static int commit_bands(uint64_t* sec_n, uint64_t* sec_2ns, uint64_t* nodes, const uint64_t* h_src, uint64_t n_ext, uint64_t n, uint64_t ncols, double* upload_ms)
+{
+    if (upload_ms) *upload_ms = 0.0;
+    if (n == 0 || n_ext == 0) return 0;
+    if ((n & (n - 1)) || (n_ext & (n_ext - 1)) || n_ext < n) return xlp_fail("commit: sizes must be powers of two, n_ext >= n");
+    Ctx* ctx = &g_ctx;
+    u64 band = 64;
+    if (const char* e = getenv("XLP_COMMIT_BAND")) { const u64 v = strtoull(e, nullptr, 10); if (v >= 8 && v % 8 == 0) band = v; }
+    if (ncols <= 4 || ncols <= band) {                       // one band (or the no-hash rule of narrow rows): nothing to pipeline
+        if (h_src && ncols) {
+            XLP_HIP(hipMemcpyAsync(sec_n, h_src, n * ncols * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+        }
+        if (ncols && dev_extend(ctx, sec_2ns, sec_n, n_ext, n, ncols, nullptr)) return -1;
+        return dev_merkle(ctx, nodes, sec_2ns, ncols, n_ext);
+    }
+    const u64 nb = (ncols + band - 1) / band;
+    std::vector<hipEvent_t> ev;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (h_src) {
+        if (!ctx->copy_stream) XLP_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        // the copies may not start before earlier work on the compute stream (a previous proof still reading sec_n) is done
+        hipEvent_t start;
+        XLP_HIP(hipEventCreateWithFlags(&start, hipEventDisableTiming));
+        XLP_HIP(hipEventRecord(start, ctx->stream));
+        XLP_HIP(hipStreamWaitEvent(ctx->copy_stream, start, 0));
+        XLP_HIP(hipEventDestroy(start));
+        if (upload_ms) { XLP_HIP(hipEventCreate(&t0)); XLP_HIP(hipEventCreate(&t1)); XLP_HIP(hipEventRecord(t0, ctx->copy_stream)); }
+        ev.resize(nb);
+        for (u64 b = 0; b < nb; b++) {
+            const u64 c0 = b * band, wc = ncols - c0 < band ? ncols - c0 : band;
+            XLP_HIP(hipMemcpy2DAsync(sec_n + c0, ncols * sizeof(u64), h_src + c0, ncols * sizeof(u64), wc * sizeof(u64), n, hipMemcpyHostToDevice, ctx->copy_stream));
+            XLP_HIP(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
+            XLP_HIP(hipEventRecord(ev[b], ctx->copy_stream));
+        }
+        if (upload_ms) XLP_HIP(hipEventRecord(t1, ctx->copy_stream));
+    }
+    int rc = 0;
+    for (u64 b = 0; b < nb && !rc; b++) {
+        const u64 c0 = b * band, wc = ncols - c0 < band ? ncols - c0 : band;
+        if (h_src) XLP_HIP(hipStreamWaitEvent(ctx->stream, ev[b], 0));
+        rc = dev_extend_cols(ctx, sec_2ns, sec_n, n_ext, n, ncols, c0, wc);
+        if (!rc) rc = dev_linear_hash_absorb(ctx, nodes, sec_2ns, ncols, c0, wc, n_ext, b == 0, b == nb - 1);
+    }
+    if (!rc) rc = dev_merkle_levels(ctx, nodes, n_ext);
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    if (t0) {
+        if (!rc) {
+            float ms = 0.f;
+            XLP_HIP(hipEventSynchronize(t1));
+            XLP_HIP(hipEventElapsedTime(&ms, t0, t1));
+            *upload_ms = ms;
+        }
+        (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+    }
+    return rc;
+}
+int xlp_dev_commit_from_host(uint64_t* sec_n, uint64_t* sec_2ns, uint64_t* nodes, const uint64_t* h_src, uint64_t n_ext, uint64_t n, uint64_t ncols, double* upload_ms)
+{
+    if (ensure_init()) return -1;
+    if (ncols && n && !h_src) return xlp_fail("xlp_dev_commit_from_host: null host pointer");
+    return commit_bands(sec_n, sec_2ns, nodes, h_src, n_ext, n, ncols, upload_ms);
+}
+int xlp_dev_commit(uint64_t* sec_2ns, uint64_t* nodes, const uint64_t* sec_n, uint64_t n_ext, uint64_t n, uint64_t ncols)
+{
+    if (ensure_init()) return -1;
+    return commit_bands(const_cast<uint64_t*>(sec_n), sec_2ns, nodes, nullptr, n_ext, n, ncols, nullptr);
 }
 
 // --------------------------------------------------------------- host layer

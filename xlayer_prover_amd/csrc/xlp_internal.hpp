@@ -42,6 +42,7 @@ struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t copy_stream = nullptr;      // host <-> device transfers that overlap kernels on `stream` (xlp_dev_commit_from_host)
     std::map<std::tuple<u32, u64, u64>, u64*> tables;  // (L, root, mult) -> device power tables
     void* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -61,18 +62,22 @@ u64 host_w(unsigned n);  // Goldilocks::w(n)
 int ntt_init(Ctx* ctx);
 int dev_ntt(Ctx* ctx, u64* dst, const u64* src, u64 n, u64 ncols, int inverse);
 int dev_extend(Ctx* ctx, u64* out, const u64* in, u64 n_ext, u64 n, u64 ncols, u64* scratch);
+int dev_extend_cols(Ctx* ctx, u64* out, const u64* in, u64 n_ext, u64 n, u64 ld, u64 first, u64 ncols);
 
 // ntt_lde.hip (three-kernel fast path of extendPol)
 bool lde_fast_supported(u32 L, u32 e, u64 ncols);
 bool ntt_fast_supported(u32 L, u64 ncols);
 int dev_ntt_fast(Ctx* ctx, u64* dst, const u64* src, u32 L, u64 ncols, int inverse);
 int dev_extend_fast(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ncols);
+int dev_extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld, u64 first, u64 ncols);
 
 // poseidon.hip
 int poseidon_init(Ctx* ctx);
 int dev_perm(Ctx* ctx, u64* out, const u64* in, u64 count);
 int dev_linear_hash(Ctx* ctx, u64* out, const u64* src, u64 w, u64 h);
 int dev_merkle(Ctx* ctx, u64* nodes, const u64* src, u64 w, u64 h);
+int dev_linear_hash_absorb(Ctx* ctx, u64* state, const u64* src, u64 ld, u64 first, u64 ncols, u64 h, int is_first, int is_last);
+int dev_merkle_levels(Ctx* ctx, u64* nodes, u64 h);
 int dev_merkle_proofs(Ctx* ctx, u64* out, const u64* src, const u64* nodes, u64 w, u64 h, const u64* d_idxs, u64 nq);
 
 // fri.hip
