@@ -105,6 +105,10 @@ int xlp_dev_merkle_proofs(uint64_t* out, const uint64_t* src, const uint64_t* no
 /* Synthetic trace: dst[i] = splitmix64(seed ^ (start + i)) mod p. */
 int xlp_dev_fill(uint64_t* dst, uint64_t n, uint64_t seed, uint64_t start);
 
+/* Synthetic plookup selector for runs on a synthetic witness (benchmarks / tests): dst[i][0..dim) = src row (splitmix64(seed ^ i) mod n),
+ * src of row stride src_stride, dst dense -- an f polynomial all of whose values occur in the table. */
+int xlp_dev_gather_rows(uint64_t* dst, const uint64_t* src, uint64_t src_stride, uint64_t n, uint32_t dim, uint64_t seed);
+
 /* ---- row-scale helpers between the commit stages, device pointers ------------ */
 /* Polinomial::batchInverse / batchInverseParallel(res, src) -- polinomial.hpp:635-720, starks.cpp:358-359.
  * n elements of dimension dim (1 or 3); res may equal src.  Inputs must be non-zero as in the
@@ -263,6 +267,7 @@ int xlp_host_unregister(void* ptr);
 /* Plain device memory helpers so a C++/cgo/ctypes host needs no HIP headers. */
 int xlp_dev_alloc(void** ptr, size_t bytes);
 int xlp_dev_free(void* ptr);
+int xlp_dev_memset(void* dst_dev, int value, size_t bytes);          /* asynchronous on the context's stream */
 int xlp_copy_h2d(void* dst_dev, const void* src_host, size_t bytes);
 int xlp_copy_d2h(void* dst_host, const void* src_dev, size_t bytes);
 

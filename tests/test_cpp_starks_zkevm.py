@@ -1,0 +1,176 @@
+"""The C++ entry points with the reference's shape -- Starks(config, StarkFiles, pAddress) + genProof(proof, publics, verkey, Steps*)
+(host/starks.hpp; src/starkpil/starks.hpp:74,225) and Prover::genBatchProof (host/prover.hpp; src/prover/prover.cpp:392-669) --
+driven at the zkEVM-family geometries from bundles (tools/make_stark_bundle.py: synthesized starkinfo + the converted reference
+step programs).  Two independent orchestrations of the same kernels must print the same proof: the C++ Starks (witness in
+page-locked host memory, band-pipelined step 1, StarkInfo-driven H1H2 / Z / evmap) and the Python flow of
+tools/bench_zkevm_genproof.py (which tests/test_full_size.py checks against the oracle stage by stage); and the C++ proof is
+verified on the oracle: transcript, all Merkle paths, all folds, final degree."""
+import argparse
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "xlayer_prover_amd", "host")
+EXE = os.path.join(HOST, "test_host_shim")
+WSEED, CSEED = 0x5EED0401, 0x5EED0402
+
+
+def _programs_built(circ):
+    from xlayer_prover_amd import programs as R
+    return os.path.exists(os.path.join(R.REF_DIR, f"{circ}.step52ns.xlpexpr"))
+
+
+def test_bundle_starkinfo_is_consistent(tmp_path):
+    """no GPU: the synthesized starkinfo of every circuit -- evaluation map entries name views that exist, the views lie inside their
+    sections, cm_n lists the commit order (cm1 | h1, h2 per lookup | z per grand product | ...), offsets equal the slab layout"""
+    from tools import zkevm_geometry as G
+    for circ, ln, al in (("zkevm", 14, True), ("zkevm", 15, False), ("c12a", 20, False), ("recursive1", 17, False)):
+        if not _programs_built(circ):
+            pytest.skip("converted reference programs not built")
+        j = G.synth_starkinfo(circ, ln, al)
+        L = G.layout(ln, al, circ)
+        W = j["mapSectionsN"]
+        for v in j["varPolMap"]:
+            assert v["sectionPos"] + v["dim"] <= W[v["section"]]
+        for name, off in j["mapOffsets"].items():
+            assert off == L[name][0]
+        assert j["mapTotalN"] == L["end"][0]
+        for e in j["evMap"]:
+            if e["type"] == "cm":
+                v = j["varPolMap"][j["cm_2ns"][e["id"]]]
+                assert v["section"].endswith("_2ns")
+            elif e["type"] == "q":
+                assert j["varPolMap"][j["qs"][e["id"]]]["section"] == "cm4_2ns"
+            else:
+                assert e["id"] < j["nConstants"]
+        n1, npu = j["nCm1"], len(j["puCtx"])
+        for i, c in enumerate(j["puCtx"]):
+            assert j["cm_n"][n1 + 2 * i] == c["h1Id"] and j["varPolMap"][c["h1Id"]] == {"section": "cm2_n", "dim": 3, "sectionPos": 6 * i}
+        zs = [c["zId"] for c in j["puCtx"]] + [c["zId"] for c in j["peCtx"]]
+        for k, z in enumerate(zs):
+            assert j["cm_n"][n1 + 2 * npu + k] == z and j["varPolMap"][z] == {"section": "cm3_n", "dim": 3, "sectionPos": 3 * k}
+        assert (j["xlp"]["const2nsOffset"] is not None) == al
+        if circ == "recursive1":
+            assert len(j["evMap"]) == 118 and j["nPublics"] == 48 and j["nConstants"] == 52      # the golden recursive1 proofs' shape
+
+
+def _flow(circ, ln, aliased):
+    import torch
+    from tools import bench_zkevm_genproof as T
+    from xlayer_prover_amd import capi
+    capi.init(0)
+    a = argparse.Namespace(log_n=ln, circuit=circ, batch=False, fri_steps="", queries=0, lookups=-1, zs=-1, no_jit=False, no_dots=False, vm_only="", no_opt=False,
+                           aliased=int(aliased))
+    out = T.prove(a, circ, ln)
+    torch.cuda.empty_cache()
+    return out
+
+
+def _cpp_bundle(bundle, circ, timeout=600):
+    r = subprocess.run([EXE, "bundle", bundle, circ, str(WSEED), str(CSEED)], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout), r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("circ,ln,aliased", [("zkevm", 14, True), ("zkevm", 14, False), ("recursive1", 17, False), ("c12a", 20, False)])
+def test_cpp_starks_equals_python_flow_and_verifies(orc, tmp_path, circ, ln, aliased):
+    import torch
+    from tools import make_stark_bundle as B
+    from tools import zkevm_geometry as G
+    from tests.zkin_verify import verify_zkin, ints
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    if not _programs_built(circ):
+        pytest.skip("converted reference programs not built (needs the reference tree at build time)")
+    bundle = B.make(circ, ln, aliased, out=str(tmp_path / "bundle"))
+    Z, log = _cpp_bundle(bundle, circ)
+    assert "dot_columns" in log                                   # the FRI polynomial ran as table program + dot_columns + row program
+    exp = _flow(circ, ln, aliased)
+    # ---- same proof as the Python orchestration
+    assert [ints(Z[k]) for k in ("root1", "root2", "root3", "root4")] == exp["roots"]
+    fr = exp["fri_roots_and_head_of_final_pol"]
+    si = G.synth_starkinfo(circ, ln, aliased)
+    steps = [s["nBits"] for s in si["starkStruct"]["steps"]]
+    for k in range(1, len(steps)):
+        assert ints(Z[f"s{k}_root"]) == fr[k - 1]
+    assert [x for e in Z["finalPol"] for x in ints(e)][:6] == fr[-1]
+    # ---- and a valid one
+    W = si["mapSectionsN"]
+    widths = {"1": W["cm1_2ns"], "2": W["cm2_2ns"], "3": W["cm3_2ns"], "4": W["cm4_2ns"], "C": si["nConstants"]}
+    rep = verify_zkin(orc, Z, ln, ln + G.CIRCUITS[circ]["ext"], steps, si["starkStruct"]["nQueries"], widths)
+    assert rep["paths"] > 0 and rep["folds"] == si["starkStruct"]["nQueries"] * (len(steps) - 1)
+    assert len(Z["evals"]) == len(si["evMap"])
+
+
+def _batch_config(tmp_path, bundles):
+    cfg = {"runFileGenBatchProof": True, "saveOutputToFile": True, "saveProofToFile": True, "outputPath": str(tmp_path), "xlpSyntheticLookups": True}
+    for name, b in bundles.items():
+        cfg[name + "StarkInfo"] = os.path.join(b, f"{name}.starkinfo.json")
+        cfg[name + "ConstPols"] = f"synthetic:{CSEED + len(name)}"
+        cfg[name + "ConstantsTree"] = ""
+        cfg[name + "Verkey"] = ""
+    f = tmp_path / "config.json"
+    f.write_text(json.dumps(cfg))
+    return str(f)
+
+
+@pytest.mark.gpu
+def test_genbatchproof_chains_three_starks(orc, tmp_path):
+    """Prover::genBatchProof (host/prover.hpp) on small bundles: zkEVM programs at 2^13 rows, c12a and recursive1 at their real
+    geometry.  The recursive1 proof it returns verifies; its publics are the zkEVM witness's first / last rows at the fork-9 Main
+    register columns; both upload modes give the same proof; another executor seed changes every proof down the chain."""
+    import torch
+    from tools import make_stark_bundle as B
+    from tools import zkevm_geometry as G
+    from tests.zkin_verify import verify_zkin, ints
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    for c in ("zkevm", "c12a", "recursive1"):
+        if not _programs_built(c):
+            pytest.skip("converted reference programs not built (needs the reference tree at build time)")
+    bundles = {"zkevm": B.make("zkevm", 13, True, out=str(tmp_path / "zkevm")), "c12a": B.make("c12a", 20, False, out=str(tmp_path / "c12a")),
+               "recursive1": B.make("recursive1", 17, False, out=str(tmp_path / "recursive1"))}
+    cfg = _batch_config(tmp_path, bundles)
+    exe = os.path.join(HOST, "zkprover_batch")
+
+    def run(*extra):
+        r = subprocess.run([exe, "-c", cfg, "--proofs", "1"] + list(extra), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads(r.stdout.strip().splitlines()[-1]), json.load(open(tmp_path / "batch_proof.output.json")), json.load(open(tmp_path / "batch_proof.public.json"))
+    line, Z, pub = run()
+    assert line["three_starks_s"] > 0 and line["zkevm_witness_upload_ms"] > 0
+    for k in ("STARK_PROOF_BATCH_PROOF", "STARK_C12_A_PROOF_BATCH_PROOF", "STARK_RECURSIVE_1_PROOF_BATCH_PROOF", "zkevm.STARK_STEP_1_LDE_AND_MERKLETREE", "recursive1.STARK_STEP_FRI"):
+        assert k in line["timers_s"]
+    # publics: rows 0 and N-1 of the synthetic zkEVM witness at the Main register columns (prover.cpp:494-559)
+    N, Wz = 1 << 13, 751
+    at = lambda row, col: int(orc.fill(1, WSEED, row * Wz + col)[0])
+    assert ints(pub[:8]) == [at(0, 581 - k) for k in range(8)] and ints(pub[19:27]) == [at(N - 1, 613 - k) for k in range(8)]
+    assert int(pub[16]) == at(0, 615) and int(pub[43]) == at(N - 1, 616) and ints(pub[44:48]) == [0, 0, 0, 0]
+    assert Z["publics"] == pub
+    si = G.synth_starkinfo("recursive1", 17, False)
+    steps = [s["nBits"] for s in si["starkStruct"]["steps"]]
+    W = si["mapSectionsN"]
+    # the verification key is not in the zkin; the recursive1 Starks printed none -> recompute it the way the transcript needs it: replay with
+    # each candidate is not possible, so take it from a bundle run of the same constants
+    ZZ, _ = _cpp_bundle_verkey(bundles["recursive1"], cfg)
+    Z["verkey"] = ZZ
+    rep = verify_zkin(orc, Z, 17, 20, steps, 43, {"1": W["cm1_2ns"], "2": 0, "3": W["cm3_2ns"], "4": W["cm4_2ns"], "C": si["nConstants"]})
+    assert rep["folds"] == 43 * 4
+    line2, Z2, _ = run("--sequential-upload")
+    assert line2["batch_proof_fnv"] == line["batch_proof_fnv"] and "zkevm.STARK_STEP_1_WITNESS_UPLOAD" in line2["timers_s"]
+    line3, Z3, pub3 = run("--seed", "77")
+    assert line3["batch_proof_fnv"] != line["batch_proof_fnv"] and Z3["root1"] != Z2["root1"] and pub3 != pub
+
+
+def _cpp_bundle_verkey(bundle, cfg_file):
+    """constRoot of the recursive1 constants named by the batch config (synthetic:<seed>): a bundle run with that seed prints it"""
+    cfg = json.load(open(cfg_file))
+    seed = int(cfg["recursive1ConstPols"].split(":")[1])
+    r = subprocess.run([EXE, "bundle", bundle, "recursive1", "1", str(seed)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout)["verkey"], None

@@ -206,9 +206,15 @@ def prove(a, circ, ln, hooks=None):
     ev_arr = capi.evmap_entries(ents)
     ev_out = torch.zeros(3 * len(ents), dtype=i64, device=dev)
     ev_index = torch.tensor([3 * k + j for k in ev_ids for j in range(3)], device=dev)
-    # plookup inputs the missing starkinfo would select from tmpExp_n: every f value must occur in t
-    t_pl = fill(3 * N, 0x5EED0403)
-    f_pl = t_pl.view(N, 3)[torch.randint(0, N, (N,), device=dev, generator=torch.Generator(device=dev).manual_seed(1))].contiguous().view(-1)
+    # plookup inputs: the table t of lookup k is the tmpExp_n polynomial tools/zkevm_geometry.py lookup_picks() names (the missing
+    # starkinfo would say which), f a selection of rows of t (xlp_dev_gather_rows: on a synthetic witness "f in t" has to be made)
+    lk_picks, z_picks = G.lookup_picks(circ)
+    if a.lookups >= 0:
+        lk_picks = lk_picks[:a.lookups]
+    if a.zs >= 0:
+        z_picks = z_picks[:a.zs]
+    lookups, nzs = len(lk_picks), len(z_picks)
+    t_pl = torch.empty(3 * N, dtype=i64, device=dev); f_pl = torch.empty(3 * N, dtype=i64, device=dev)
     h1 = torch.empty(3 * N, dtype=i64, device=dev); h2 = torch.empty(3 * N, dtype=i64, device=dev)
     num = torch.empty(3 * N, dtype=i64, device=dev); den = torch.empty(3 * N, dtype=i64, device=dev); z = torch.empty(3 * N, dtype=i64, device=dev)
     trees = {k: torch.empty((2 * NE - 1) * 4, dtype=i64, device=dev) for k in ("cm1_2ns", "cm2_2ns", "cm3_2ns", "cm4_2ns")}
@@ -311,7 +317,9 @@ def prove(a, circ, ln, hooks=None):
         cm2 = sec("cm2_n").view(N, W["cm2_n"])
 
         def lookups_():
-            for k in range(lookups):
+            for k, c in enumerate(lk_picks):
+                capi.dev_copy_cols(t_pl, 3, sec("tmpExp_n")[c:], W["tmpExp_n"], N, 3)          # transposeH1H2Columns (starks.cpp:406-431)
+                capi.dev_gather_rows(f_pl, t_pl, 3, N, 3, 0x5EED0500 + k)
                 capi.dev_calculate_h1h2(h1, h2, f_pl, t_pl, N, 3)
                 w2 = W["cm2_n"]                                # transposeH1H2Rows (starks.cpp:433-470): the strided-view copy of the library
                 capi.dev_copy_cols(sec("cm2_n")[6 * k:], w2, h1, 3, N, 3); capi.dev_copy_cols(sec("cm2_n")[6 * k + 3:], w2, h2, 3, N, 3)
@@ -323,8 +331,7 @@ def prove(a, circ, ln, hooks=None):
         tmpx = sec("tmpExp_n").view(N, W["tmpExp_n"]); cm3 = sec("cm3_n").view(N, W["cm3_n"])
 
         def zs():
-            for k in range(nzs):
-                c = (6 * k) % max(W["tmpExp_n"] - 6, 1)
+            for k, c in enumerate(z_picks):
                 wt, w3 = W["tmpExp_n"], W["cm3_n"]             # transposeZColumns / transposeZRows (starks.cpp:472-555)
                 capi.dev_copy_cols(num, 3, sec("tmpExp_n")[c:], wt, N, 3); capi.dev_copy_cols(den, 3, sec("tmpExp_n")[c + 3:], wt, N, 3)
                 capi.dev_calculate_z(z, num, den, N)

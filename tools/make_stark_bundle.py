@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Everything host/starks.hpp needs to run one STARK of genBatchProof, in one directory ("bundle"): the counterpart of the
+reference's config/<stark>/ directory (starkinfo.json + chelpers), for the geometries of tools/zkevm_geometry.py:
+    <out>/<circ>.starkinfo.json          stark_info.cpp schema (synthesized: tools/zkevm_geometry.py synth_starkinfo)
+    <out>/<circ>.<step>.xlpexpr          the converted reference program relocated to this slab
+    <out>/<circ>.<step>.opt.xlpexpr, .tab.xlpexpr        its dot-product form (xlayer_prover_amd/expr_opt.py)
+    <out>/<circ>.step52ns.dots, .drow.xlpexpr, .dtab.xlpexpr   the FRI polynomial as table program + xlp_dev_dot_columns + row program
+    <out>/<circ>.steps.json              which of these XlpSteps runs per step, and the ahead-of-time plugin of each
+Needs the converted programs (xlayer_prover_amd/chelpers/*.xlpexpr); no GPU.
+    python tools/make_stark_bundle.py --circuit zkevm --log-n 23 --aliased"""
+import argparse
+import json
+import os
+import struct
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from tools import zkevm_geometry as G
+from xlayer_prover_amd import expr as E
+from xlayer_prover_amd import programs as R
+
+MAGIC = int.from_bytes(b"XLPEXPR1", "little")
+MAGIC_TAB = int.from_bytes(b"XLPTAB01", "little")
+MAGIC_DOTS = int.from_bytes(b"XLPDOTS1", "little")
+
+
+def write_prog(path, code, n1, n3):
+    code = np.ascontiguousarray(code, dtype="<u8")
+    with open(path, "wb") as f:
+        f.write(struct.pack("<4Q", MAGIC, n1, n3, code.size)); f.write(code.tobytes())
+
+
+def write_tab(path, prog, n_ext):
+    code = np.ascontiguousarray(prog.code, dtype="<u8")
+    with open(path, "wb") as f:
+        f.write(struct.pack("<5Q", MAGIC_TAB, prog.ntmp1, prog.ntmp3, code.size, n_ext)); f.write(code.tobytes())
+
+
+def bundle_dir(circ, log_n, aliased):
+    return os.path.join(R.REF_DIR, "bundles", f"{circ}.geo{log_n}{'a' if aliased else ''}")
+
+
+def make(circ, log_n, aliased, out=None, fri_steps=None, queries=None, use_opt=True, use_dots=True):
+    out = out or bundle_dir(circ, log_n, aliased)
+    os.makedirs(out, exist_ok=True)
+    geo = f"geo{log_n}{'a' if aliased else ''}"
+    progs, info = G.load(log_n, aliased, circ)
+    json.dump(G.synth_starkinfo(circ, log_n, aliased, fri_steps, queries), open(os.path.join(out, f"{circ}.starkinfo.json"), "w"))
+    man = {}
+    rel = lambda p: os.path.relpath(p, out)
+
+    def plugin(name):
+        so = os.path.join(R.REF_DIR, name)
+        return rel(so) if os.path.exists(so) else None
+    for st, (code, n1, n3) in progs.items():
+        write_prog(os.path.join(out, f"{circ}.{st}.xlpexpr"), code, n1, n3)
+        man[st] = {"prog": f"{circ}.{st}.xlpexpr", "plugin": plugin(f"{circ}.{st}.{geo}.so")}
+    if use_opt:
+        for st, ((rc, r1, r3), tabp, n_ext, stats) in G.load_opt(log_n, aliased, circ).items():
+            write_prog(os.path.join(out, f"{circ}.{st}.opt.xlpexpr"), rc, r1, r3)
+            e = {"prog": f"{circ}.{st}.opt.xlpexpr", "plugin": plugin(f"{circ}.{st}_opt.{geo}.so"), "n_ext": n_ext}
+            if tabp.ninstr:
+                write_tab(os.path.join(out, f"{circ}.{st}.tab.xlpexpr"), tabp, n_ext)
+                e["tab"] = f"{circ}.{st}.tab.xlpexpr"
+            man[st] = e
+    if use_opt and use_dots:
+        tabp, dots, rowp, n_ext = G.load_fri_dots(log_n, aliased, circ)
+        write_tab(os.path.join(out, f"{circ}.step52ns.dtab.xlpexpr"), tabp, n_ext)
+        write_prog(os.path.join(out, f"{circ}.step52ns.drow.xlpexpr"), rowp.code, rowp.ntmp1, rowp.ntmp3)
+        ents = []
+        for x, g, k in dots["entries"]:
+            if x.kind == E.K_POLS:
+                ents += [0, x.params[0], x.params[1], x.dim, g, k]
+            else:
+                assert x.kind == E.K_CONST2NS
+                ents += [1, x.params[0], 0, 1, g, k]
+        with open(os.path.join(out, f"{circ}.step52ns.dots"), "wb") as f:
+            f.write(struct.pack("<3Q", MAGIC_DOTS, dots["ngroups"], len(dots["entries"]))); f.write(np.array(ents, dtype="<u8").tobytes())
+        man["step52ns"] = {"prog": f"{circ}.step52ns.drow.xlpexpr", "tab": f"{circ}.step52ns.dtab.xlpexpr", "n_ext": n_ext, "dots": f"{circ}.step52ns.dots",
+                           "tab_plugin": plugin(f"{circ}.step52ns_tab.{geo}.so"), "plugin": None}
+    json.dump({"steps": man}, open(os.path.join(out, f"{circ}.steps.json"), "w"), indent=1)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--circuit", default="zkevm")
+    ap.add_argument("--log-n", type=int, default=0)
+    ap.add_argument("--aliased", action="store_true")
+    ap.add_argument("--out", default="")
+    ap.add_argument("--no-opt", action="store_true")
+    ap.add_argument("--no-dots", action="store_true")
+    a = ap.parse_args()
+    ln = a.log_n or G.CIRCUITS[a.circuit]["log_n"]
+    print(make(a.circuit, ln, a.aliased, a.out or None, use_opt=not a.no_opt, use_dots=not a.no_dots))
+
+
+if __name__ == "__main__":
+    main()

@@ -187,3 +187,147 @@ def load_fri_dots(log_n, aliased=False, circ="zkevm"):
     row, tab, n_ext, stats, dots = expr_opt.horner_to_dot(code, n1, n3, NCH, outsource_min_terms=8)
     assert dots is not None
     return tab, dots, row, n_ext
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# A starkinfo.json for these geometries (src/starkpil/stark_info.cpp schema).  The reference's files are in the missing
+# archive; what the step programs fix is reproduced exactly (section widths and offsets, the evaluation map read off
+# step52ns, nConstants, nPublics, qDeg), what only the PIL would tell is chosen here and shared by every driver
+# (tools/bench_zkevm_genproof.py, host/starks.hpp through the bundle): which tmpExp_n columns are the plookup tables and the
+# grand-product numerators / denominators.
+def lookup_picks(circ):
+    """-> (lookups, zs): lookup k reads its table t from tmpExp_n columns [c, c+3) (f is a synthetic selection of t, see
+    xlp_dev_gather_rows) and writes h1 / h2 to cm2_n columns [6k, 6k+3) / [6k+3, 6k+6); grand product k reads num / den from
+    tmpExp_n columns [c, c+3) / [c+3, c+6) and writes z to cm3_n columns [3k, 3k+3); c = 6k mod (W_tmpExp - 6)"""
+    C = CIRCUITS[circ]
+    wt = C["widths"][4]
+    pick = lambda k: (6 * k) % max(wt - 6, 1)
+    return [pick(k) for k in range(C["lookups"])], [pick(k) for k in range(C["zs"])]
+
+
+def evmap_of(code52, L, secs, nconst):
+    """[(kind 'cm' | 'const', section name | None, column, dim, prime)] in evals order, from the FRI-polynomial program: each
+    `column - evals[k]` difference, and whether its chain is finally multiplied by xDivXSubXi or xDivXSubWXi"""
+    ents, tags, prime = {}, {}, {}
+    ops = list(R.operands(code52))
+    for i in range(0, len(ops), 3):
+        slots = [(kind, dim, [int(v) for v in code52[q:q + E.KIND_PARAMS[kind]]]) for _, _, kind, dim, q in ops[i:i + 3]]
+        op = int(code52[ops[i][4] - 1]) & 255
+        (dk, dd, dp), (ak, ad, apar), (bk, bd, bpar) = slots
+        srcs = [(ak, ad, apar)] + ([(bk, bd, bpar)] if bk != E.K_NONE else [])
+        s = set()
+        for kind, dim, prm in srcs:
+            if kind == E.K_TMP3:
+                s |= tags.get(prm[0], set())
+        if op == E.SUB and bk == E.K_EVAL and ak in (E.K_POLS, E.K_CONST2NS):
+            if ak == E.K_POLS:
+                off = apar[0]
+                name = [sn for sn, _, ext in secs if ext and L[sn][1] and L[sn][0] <= off < L[sn][0] + L[sn][1] * L[sn][2]][-1]
+                ents[bpar[0]] = ("cm", name, off - L[name][0], ad)
+            else:
+                ents[bpar[0]] = ("const", None, apar[0], 1)
+            s.add(bpar[0])
+        for kind, dim, prm in srcs:
+            if kind in (E.K_XDIVXSUBXI, E.K_XDIVXSUBWXI):
+                for k in s:
+                    prime[k] = kind == E.K_XDIVXSUBWXI
+                s = set()
+        if dk == E.K_TMP3:
+            tags[dp[0]] = s
+    assert set(prime) == set(ents) and sorted(ents) == list(range(len(ents)))
+    return [ents[k] + (prime[k],) for k in sorted(ents)]
+
+
+def synth_starkinfo(circ, log_n, aliased=False, fri_steps=None, queries=None):
+    C = CIRCUITS[circ]
+    ext = C["ext"]
+    L = layout(log_n, aliased, circ)
+    secs = sections(circ)
+    progs, info = load(log_n, aliased, circ)
+    nconst = max(info["n_const"], info["n_const2"])
+    W = {name: w for name, w, _ in secs}
+    lne = log_n + ext
+    if fri_steps is None:
+        fri_steps = C["fri"] if C["fri"] and log_n == C["log_n"] else [lne] + [b for b in (lne - 5, lne - 10, lne - 14, lne - 18) if b >= 3]
+    lookups, zs = lookup_picks(circ)
+    evm = evmap_of(progs["step52ns"][0], L, secs, nconst)
+    # ---- polynomials: base sections first (cm_n order = commit order), then their extended twins, then the tmpExp operands
+    var, cm_n = [], []
+    dims3 = {}                                               # the picks above decide where h1 / h2 / z go; everything else is a column
+
+    def cols_of(base):
+        """[(pos, dim)] of a base section"""
+        w, twin = W[base], base.replace("_n", "_2ns")
+        out, c = [], 0
+        if base == "cm2_n":
+            for k in range(len(lookups)):
+                out += [(6 * k, 3), (6 * k + 3, 3)]
+            c = 6 * len(lookups)
+        elif base == "cm3_n":
+            out += [(3 * k, 3) for k in range(len(zs))]
+            c = 3 * len(zs)
+        elif base == "cm4_n":
+            out += [(3 * p, 3) for p in range(w // 3)]
+            c = 3 * (w // 3)
+        while c < w:
+            d = 3 if (twin, c) in dims3 and c + 3 <= w else 1
+            out.append((c, d)); c += d
+        return out
+    counts = {}
+    for base in ("cm1_n", "cm2_n", "cm3_n", "cm4_n"):
+        cs = cols_of(base)
+        counts[base] = len(cs)
+        for pos, d in cs:
+            cm_n.append(len(var)); var.append({"section": base, "dim": d, "sectionPos": pos})
+    cm_2ns, twin_id = [], {}
+    for i in cm_n:
+        v = var[i]
+        sec2 = v["section"].replace("_n", "_2ns")
+        twin_id[(sec2, v["sectionPos"], v["dim"])] = len(var)
+        cm_2ns.append(len(var)); var.append({"section": sec2, "dim": v["dim"], "sectionPos": v["sectionPos"]})
+    # the evaluation map names (column, dimension) views of the extended sections as the PIL really lays them out; where that differs
+    # from the views the picks above created (varPolMap entries are views, they may overlap), the view is added
+    for kind, name, col, dim, prime in evm:
+        if kind == "cm" and (name, col, dim) not in twin_id:
+            twin_id[(name, col, dim)] = len(var)
+            cm_2ns.append(len(var)); var.append({"section": name, "dim": dim, "sectionPos": col})
+    qs = [twin_id[("cm4_2ns", 3 * p, 3)] for p in range(W["cm4_n"] // 3)]
+    exp2pol, pu, pe = {}, [], []
+
+    def tmp_pol(pos):
+        eid = 1000 + len(exp2pol)
+        exp2pol[str(eid)] = len(var); var.append({"section": "tmpExp_n", "dim": 3, "sectionPos": pos})
+        return eid
+    for k, c in enumerate(lookups):
+        t = tmp_pol(c)
+        pu.append({"tExpId": t, "fExpId": t, "h1Id": cm_n[counts["cm1_n"] + 2 * k], "h2Id": cm_n[counts["cm1_n"] + 2 * k + 1], "zId": 0, "c1Id": 0, "numId": 0, "denId": 0, "c2Id": 0})
+    z0 = counts["cm1_n"] + counts["cm2_n"]
+    for k, c in enumerate(zs):
+        num, den = tmp_pol(c), tmp_pol(c + 3)
+        ctx = {"zId": cm_n[z0 + k], "numId": num, "denId": den, "c1Id": 0, "c2Id": 0}
+        if k < len(pu):
+            pu[k].update(ctx)
+        else:
+            pe.append({"tExpId": 0, "fExpId": 0, **ctx})
+    ev = []
+    for kind, name, col, dim, prime in evm:
+        if kind == "const":
+            ev.append({"type": "const", "id": col, "prime": prime})
+        elif name == "cm4_2ns" and dim == 3 and col % 3 == 0:
+            ev.append({"type": "q", "id": col // 3, "prime": prime})
+        else:
+            ev.append({"type": "cm", "id": cm_2ns.index(twin_id[(name, col, dim)]), "prime": prime})
+    order = [name for name, _, _ in secs]
+    rows = {name: 1 << (log_n + (ext if e else 0)) for name, _, e in secs}
+    step = {"tmpUsed": 0, "first": [], "i": [], "last": []}
+    j = {"starkStruct": {"nBits": log_n, "nBitsExt": lne, "nQueries": queries or C["queries"], "verificationHashType": "GL", "steps": [{"nBits": b} for b in fri_steps]},
+         "mapTotalN": L["end"][0], "nConstants": nconst, "nPublics": info["npub"], "nCm1": counts["cm1_n"], "nCm2": counts["cm2_n"], "nCm3": counts["cm3_n"],
+         "nCm4": counts["cm4_n"], "friExpId": 0, "nExps": len(exp2pol), "qDim": 3, "qDeg": W["cm4_n"] // 3,
+         "mapDeg": rows, "mapOffsets": {name: L[name][0] for name in order}, "mapSections": {name: [] for name in order}, "mapSectionsN": {name: W[name] for name in order},
+         "mapSectionsN1": {name: W[name] for name in order}, "mapSectionsN3": {name: 0 for name in order}, "varPolMap": var, "qs": qs, "cm_n": cm_n, "cm_2ns": cm_2ns,
+         "peCtx": pe, "puCtx": pu, "ciCtx": [], "evMap": ev, "step2prev": step, "step3prev": step, "step3": step, "step42ns": step, "step52ns": step,
+         "exps_n": [], "q_2ns": [], "cm4_n": [], "cm4_2ns": [], "tmpExp_n": [], "exp2pol": exp2pol,
+         # not in the reference's schema: where the extended constants live when they share the slab (one-GPU aliased layout), and that
+         # the lookups of this STARK run on a synthetic witness (f is then selected from t, see xlp_dev_gather_rows)
+         "xlp": {"aliased": bool(aliased), "const2nsOffset": L["const_2ns"][0] if aliased else None, "circuit": circ, "steps": list(C["steps"])}}
+    return j

@@ -40,6 +40,7 @@ SIGNATURES = {
     "xlp_dev_fri_fold": [_pu, _pu, _u32, _u32, _pu, _u64],
     "xlp_dev_transpose3": [_pu, _pu, _u64, _u32],
     "xlp_dev_fill": [_pu, _u64, _u64, _u64],
+    "xlp_dev_gather_rows": [_pu, _pu, _u64, _u64, _u32, _u64],
     "xlp_field_op": [_pu, _pu, _pu, _u64, C.c_int],
     "xlp_dev_batch_inverse": [_pu, _pu, _u64, _u32],
     "xlp_dev_calculate_z": [_pu, _pu, _pu, _u64],
@@ -69,6 +70,7 @@ SIGNATURES = {
     "xlp_host_unregister": [_pu],
     "xlp_dev_alloc": [C.POINTER(C.c_void_p), C.c_size_t],
     "xlp_dev_free": [_pu],
+    "xlp_dev_memset": [_pu, C.c_int, C.c_size_t],
     "xlp_copy_h2d": [_pu, _pu, C.c_size_t],
     "xlp_copy_d2h": [_pu, _pu, C.c_size_t],
 }
@@ -263,6 +265,10 @@ def _dp(t):
 
 def dev_fill(t, seed, start=0):
     _ck(load().xlp_dev_fill(_dp(t), t.numel(), seed, start), "xlp_dev_fill")
+
+
+def dev_gather_rows(dst, src, src_stride, n, dim, seed):
+    _ck(load().xlp_dev_gather_rows(_dp(dst), _dp(src), src_stride, n, dim, seed), "xlp_dev_gather_rows")
 
 
 def dev_ntt(dst, src, n, ncols, inverse=False):

@@ -133,6 +133,25 @@ __global__ void fill_kernel(u64* dst, u64 n, u64 seed, u64 start)
     for (; i < n; i += stride) dst[i] = gl::canon(splitmix64(seed ^ (start + i)));
 }
 
+// Synthetic plookup selector (benchmarks on a synthetic witness only): dst[i][0..dim) = src[(splitmix64(seed ^ i) mod n)][0..dim),
+// i.e. an `f` polynomial whose every value occurs in the table `src` -- what a satisfying witness guarantees and a random one
+// does not (Polinomial::calculateH1H2 exits on "Number not included", polinomial.hpp:413-414).
+__global__ void gather_rows_kernel(u64* dst, const u64* src, u64 src_stride, u64 n, u32 dim, u64 seed)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * dim) return;
+    const u64 i = t / dim;
+    const u32 c = (u32)(t % dim);
+    dst[t] = src[(splitmix64(seed ^ i) % n) * src_stride + c];
+}
+int dev_gather_rows(Ctx* ctx, u64* dst, const u64* src, u64 src_stride, u64 n, u32 dim, u64 seed)
+{
+    if (!n || !dim) return 0;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((n * dim + 255) / 256)), dim3(256), 0, ctx->stream, dst, src, src_stride, n, dim, seed);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
 // Field-layer self-test hook (tests/ only): out[i] = op(a[i], b[i]) with the exact device
 // functions the kernels use.  op: 0 addc, 1 subc, 2 mulc, 3 canon(a), 4 add(any,canon), 5 sub(any,canon),
 // 100+K: canon(mul_pow2c<K>(a)) for the shifts a radix-16 butterfly uses.

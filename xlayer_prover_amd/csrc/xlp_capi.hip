@@ -224,6 +224,11 @@ int xlp_dev_merkle_proofs(uint64_t* out, const uint64_t* src, const uint64_t* no
     D2H(out, dout, nq * per * sizeof(u64));
     return 0;
 }
+int xlp_dev_gather_rows(uint64_t* dst, const uint64_t* src, uint64_t src_stride, uint64_t n, uint32_t dim, uint64_t seed)
+{
+    if (ensure_init()) return -1;
+    return dev_gather_rows(&g_ctx, dst, src, src_stride, n, dim, seed);
+}
 int xlp_dev_copy_cols(uint64_t* dst, uint64_t dst_stride, const uint64_t* src, uint64_t src_stride, uint64_t n, uint32_t dim)
 {
     if (ensure_init()) return -1;
@@ -299,6 +304,13 @@ int xlp_dev_free(void* ptr)
 {
     if (!ptr) return 0;
     XLP_HIP(hipFree(ptr));
+    return 0;
+}
+int xlp_dev_memset(void* dst_dev, int value, size_t bytes)
+{
+    if (ensure_init()) return -1;
+    if (!bytes) return 0;
+    XLP_HIP(hipMemsetAsync(dst_dev, value, bytes, g_ctx.stream));
     return 0;
 }
 int xlp_copy_h2d(void* dst_dev, const void* src_host, size_t bytes)

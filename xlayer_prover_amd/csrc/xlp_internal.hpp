@@ -84,6 +84,7 @@ int dev_merkle_proofs(Ctx* ctx, u64* out, const u64* src, const u64* nodes, u64 
 int dev_fri_fold(Ctx* ctx, u64* pol2, const u64* pol, u32 bits, u32 red, const u64 x[3], u64 shift_inv);
 int dev_transpose3(Ctx* ctx, u64* dst, const u64* src, u64 n, u32 tbits);
 int dev_fill(Ctx* ctx, u64* dst, u64 n, u64 seed, u64 start);
+int dev_gather_rows(Ctx* ctx, u64* dst, const u64* src, u64 src_stride, u64 n, u32 dim, u64 seed);
 int dev_field_op(Ctx* ctx, u64* out, const u64* a, const u64* b, u64 n, int op);
 
 // polinomial.hip

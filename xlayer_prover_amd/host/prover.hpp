@@ -1,0 +1,212 @@
+// `Prover::genBatchProof` (src/prover/prover.cpp:392-669) over the GPU-resident Starks: the three STARKs of a batch proof --
+// zkEVM (2^23 rows), c12a, recursive1 -- chained through proof2zkinStark exactly as prover.cpp:572-651 chains them.  What the
+// reference does on the CPU between and before them is injected by the caller, because it is outside this path:
+//   * the executor that fills the committed polynomials at pAddress (prover.cpp:435)            -> ProverRequest::executor
+//   * the circom witness calculators that turn a zkin proof into the next STARK's committed polynomials
+//     (Circom::getCommitedPols prover.cpp:593, CircomRecursive1::getCommitedPols prover.cpp:630)  -> ProverRequest::c12aWitness / recursive1Witness
+// Timer names are the reference's.  pAddress is page-locked host memory (xlp_host_alloc) sized for the widest witness.
+#pragma once
+#include <functional>
+#include <sys/stat.h>
+#include "starks.hpp"
+
+class ProverRequest
+{
+public:
+    typedef std::function<void(Goldilocks::Element* cmPols, uint64_t degree, uint64_t nCols)> Executor;
+    typedef std::function<void(const std::string& zkin, Goldilocks::Element* cmPols, uint64_t degree, uint64_t nCols)> WitnessCalculator;
+    std::string uuid = "00000000-0000-0000-0000-000000000000", timestamp = "0", filePrefix;
+    Executor executor;
+    WitnessCalculator c12aWitness, recursive1Witness;
+    int result = 0;                                  // ZKR_SUCCESS
+    std::string batchProofOutput;                    // zkin of the recursive1 proof + publics: the input of genAggregatedProof (prover.cpp:653)
+    std::string publicsJson, proofJson;
+    std::vector<std::pair<std::string, double>> timers;
+    double witnessUploadMs = 0.0;
+    std::string publicsOutputFile() const { return filePrefix + "batch_proof.public.json"; }
+};
+
+class Prover
+{
+    Goldilocks& fr;
+    PoseidonGoldilocks& poseidon;
+    const Config& config;
+    void* pAddress = NULL;
+    uint64_t polsSize = 0;
+    struct Tm {
+        ProverRequest* r; const char* name; std::chrono::steady_clock::time_point t0;
+        Tm(ProverRequest* r_, const char* n) : r(r_), name(n), t0(std::chrono::steady_clock::now()) {}
+        ~Tm() { r->timers.emplace_back(name, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); }
+    };
+    static std::string dirOf(const std::string& f) { const size_t p = f.rfind('/'); return p == std::string::npos ? "." : f.substr(0, p); }
+    static bool fileExists(const std::string& f) { struct stat st; return stat(f.c_str(), &st) == 0; }
+    static void verkey(const std::string& file, Starks* stark, Goldilocks::Element out[4])
+    {
+        // <stark>.verkey.json {"constRoot": [..4..]} (prover.cpp:466-491); the GPU build computes the constant tree itself when the
+        // file is absent, and then its root is the key
+        if (fileExists(file)) {
+            const xlp_json::Value j = xlp_json::Parser(Config::xlp_read_file(file)).value();
+            for (int i = 0; i < 4; i++) out[i] = Goldilocks::fromU64(j["constRoot"][i]);
+        } else for (int i = 0; i < 4; i++) out[i] = stark->constRoot[i];
+    }
+    static std::string withMembers(const std::string& zkin, const std::string& extra) { return zkin.substr(0, zkin.size() - 1) + extra + "}"; }
+    static void json2file(const std::string& text, const std::string& file)
+    {
+        FILE* f = fopen(file.c_str(), "wb");
+        if (!f) xlp_exit_process(("cannot write " + file).c_str());
+        fwrite(text.data(), 1, text.size(), f); fclose(f);
+    }
+
+public:
+    Starks *starkZkevm = NULL, *starksC12a = NULL, *starksRecursive1 = NULL;
+    ZkevmSteps* zkevmSteps = NULL;
+    C12aSteps* c12aSteps = NULL;
+    Recursive1Steps* recursive1Steps = NULL;
+
+    Prover(Goldilocks& fr, PoseidonGoldilocks& poseidon, const Config& config) : fr(fr), poseidon(poseidon), config(config)
+    {
+        if (!config.generateProof()) return;
+        XLP_CHECK(xlp_init((int)config.xlpDevice));
+        // the host slab: only the committed polynomials of the STARK being proven live on the host (prover.cpp:94-115 allocates the
+        // whole 350 GB slab there; here everything past cm1_n is HBM)
+        StarkInfo z(config.zkevmStarkInfo), c(config.c12aStarkInfo), r(config.recursive1StarkInfo);
+        auto cm1Bytes = [](const StarkInfo& s) { return (s.mapOffsets.section[cm1_n] + (1ULL << s.starkStruct.nBits) * s.mapSectionsN.section[cm1_n]) * sizeof(Goldilocks::Element); };
+        polsSize = std::max(cm1Bytes(z), std::max(cm1Bytes(c), cm1Bytes(r)));
+        XLP_CHECK(xlp_host_alloc(&pAddress, polsSize));
+        starkZkevm = new Starks(config, {config.zkevmConstPols, config.mapConstPolsFile, config.zkevmConstantsTree, config.zkevmStarkInfo}, pAddress);
+        starksC12a = new Starks(config, {config.c12aConstPols, config.mapConstPolsFile, config.c12aConstantsTree, config.c12aStarkInfo}, pAddress);
+        starksRecursive1 = new Starks(config, {config.recursive1ConstPols, config.mapConstPolsFile, config.recursive1ConstantsTree, config.recursive1StarkInfo}, pAddress);
+        zkevmSteps = new ZkevmSteps(dirOf(config.zkevmStarkInfo));
+        c12aSteps = new C12aSteps(dirOf(config.c12aStarkInfo));
+        recursive1Steps = new Recursive1Steps(dirOf(config.recursive1StarkInfo));
+    }
+    ~Prover()
+    {
+        delete zkevmSteps; delete c12aSteps; delete recursive1Steps;
+        delete starkZkevm; delete starksC12a; delete starksRecursive1;
+        if (pAddress) xlp_host_free(pAddress);
+        XlpDeviceSlab::get().release();
+    }
+    Prover(const Prover&) = delete;
+    Prover& operator=(const Prover&) = delete;
+    void* address() { return pAddress; }
+
+    void genBatchProof(ProverRequest* pProverRequest)
+    {
+        if (!config.generateProof() || pProverRequest == NULL) xlp_exit_process("Prover::genBatchProof: not configured to generate proofs");
+        ProverRequest& req = *pProverRequest;
+        req.timers.clear();
+        Tm total(&req, "PROVER_BATCH_PROOF");
+        Goldilocks::Element* cmPols = (Goldilocks::Element*)pAddress;
+        const uint64_t Nz = starkZkevm->domainSize(), Wz = starkZkevm->starkInfo.mapSectionsN.section[cm1_n];
+        {
+            Tm t(&req, "EXECUTOR_EXECUTE_BATCH_PROOF");
+            if (!req.executor) xlp_exit_process("Prover::genBatchProof: no executor");
+            req.executor(cmPols, Nz, Wz);                    // executor.execute(*pProverRequest, cmPols), prover.cpp:435
+        }
+        if (req.result != 0) return;
+        // ---- publics (prover.cpp:494-559): first / last row of Main's registers; recursive2's verification key behind them
+        const uint64_t nPublics = starksRecursive1->starkInfo.nPublics;
+        std::vector<Goldilocks::Element> publics(nPublics, Goldilocks::zero());
+        Goldilocks::Element zkevmVerkey[4], c12aVerkey[4], recursive1Verkey[4], recursive2Verkey[4] = {{0}, {0}, {0}, {0}};
+        std::string publicStarkJson;
+        {
+            Tm t(&req, "SAVE_PUBLICS_JSON_BATCH_PROOF");
+            verkey(config.zkevmVerkey, starkZkevm, zkevmVerkey);
+            verkey(config.c12aVerkey, starksC12a, c12aVerkey);
+            verkey(config.recursive1Verkey, starksRecursive1, recursive1Verkey);
+            if (fileExists(config.recursive2Verkey)) {
+                const xlp_json::Value j = xlp_json::Parser(Config::xlp_read_file(config.recursive2Verkey)).value();
+                for (int i = 0; i < 4; i++) recursive2Verkey[i] = Goldilocks::fromU64(j["constRoot"][i]);
+            }
+            const uint64_t lastN = Nz - 1;
+            auto at = [&](uint64_t row, uint64_t col) { return cmPols[row * Wz + col]; };
+            if (Wz > 617 && nPublics >= 48) {
+                // column ids of the fork-9 Main state machine (src/main_sm/fork_9/pols_generated/commit_pols.hpp:1480-1540):
+                // B_k = 581 - k, C_k = 589 - k, D_k = 597 - k, E_k = 605 - k, SR_k = 613 - k, CTX 614, SP 615, PC 616, GAS 617
+                for (uint64_t k = 0; k < 8; k++) {
+                    publics[k] = at(0, 581 - k);             // oldStateRoot      = B[0]
+                    publics[8 + k] = at(0, 589 - k);         // oldAccInputHash   = C[0]
+                    publics[19 + k] = at(lastN, 613 - k);    // newStateRoot      = SR[lastN]
+                    publics[27 + k] = at(lastN, 597 - k);    // newAccInputHash   = D[lastN]
+                    publics[35 + k] = at(lastN, 605 - k);    // localExitRoot     = E[lastN]
+                }
+                publics[16] = at(0, 615);                    // oldBatchNum = SP[0]
+                publics[17] = at(0, 617);                    // chainId     = GAS[0]
+                publics[18] = at(0, 614);                    // forkid      = CTX[0]
+                publics[43] = at(lastN, 616);                // newBatchNum = PC[lastN]
+                for (int i = 0; i < 4; i++) publics[44 + i] = recursive2Verkey[i];
+            } else {
+                for (uint64_t i = 0; i < nPublics && i < Wz; i++) publics[i] = at(0, i);      // not the zkEVM PIL: first row
+            }
+            for (Goldilocks::Element& p : publics) p = Goldilocks::fromU64(Goldilocks::toU64(p));
+            std::ostringstream os;
+            xlp_json::arr(os, publics);
+            publicStarkJson = os.str();
+        }
+        auto newProof = [](Starks* s) {
+            const StarkStruct& ss = s->starkInfo.starkStruct;
+            return new FRIProof(1ULL << ss.steps.back().nBits, FIELD_EXTENSION, ss.steps.size(), s->starkInfo.evMap.size(), s->starkInfo.nPublics);
+        };
+        auto collect = [&](Starks* s, const char* tag) {
+            for (const auto& kv : s->lastTimers) req.timers.emplace_back(std::string(tag) + "." + kv.first, kv.second);
+        };
+        // ---- zkEVM STARK (prover.cpp:572-579)
+        std::string zkin;
+        {
+            FRIProof* fproof = newProof(starkZkevm);
+            {
+                Tm t(&req, "STARK_PROOF_BATCH_PROOF");
+                starkZkevm->genProof(*fproof, publics.data(), zkevmVerkey, zkevmSteps);
+            }
+            req.witnessUploadMs = starkZkevm->lastUploadMs;
+            collect(starkZkevm, "zkevm");
+            Tm t(&req, "STARK_JSON_GENERATION_BATCH_PROOF");
+            zkin = withMembers(proof2zkinStark(*fproof), ",\"publics\":" + publicStarkJson);
+            delete fproof;
+        }
+        // ---- c12a (prover.cpp:581-612)
+        std::string zkinC12a;
+        {
+            {
+                Tm t(&req, "STARK_GEN_AND_CALC_WITNESS_C12A");
+                if (!req.c12aWitness) xlp_exit_process("Prover::genBatchProof: no c12a witness calculator");
+                req.c12aWitness(zkin, cmPols, starksC12a->domainSize(), starksC12a->starkInfo.nCm1);
+            }
+            FRIProof* fproof = newProof(starksC12a);
+            {
+                Tm t(&req, "STARK_C12_A_PROOF_BATCH_PROOF");
+                starksC12a->genProof(*fproof, publics.data(), c12aVerkey, c12aSteps);
+            }
+            collect(starksC12a, "c12a");
+            Tm t(&req, "STARK_JSON_GENERATION_BATCH_PROOF_C12A");
+            std::ostringstream rc;
+            rc << ",\"publics\":" << publicStarkJson << ",\"rootC\":[";
+            for (int i = 0; i < 4; i++) rc << (i ? "," : "") << "\"" << Goldilocks::toString(recursive2Verkey[i]) << "\"";
+            rc << "]";
+            zkinC12a = withMembers(proof2zkinStark(*fproof), rc.str());
+            delete fproof;
+        }
+        // ---- recursive1 (prover.cpp:629-645)
+        {
+            {
+                Tm t(&req, "STARK_GEN_AND_CALC_WITNESS_RECURSIVE1");
+                if (!req.recursive1Witness) xlp_exit_process("Prover::genBatchProof: no recursive1 witness calculator");
+                req.recursive1Witness(zkinC12a, cmPols, starksRecursive1->domainSize(), starksRecursive1->starkInfo.nCm1);
+            }
+            FRIProof* fproof = newProof(starksRecursive1);
+            {
+                Tm t(&req, "STARK_RECURSIVE_1_PROOF_BATCH_PROOF");
+                starksRecursive1->genProof(*fproof, publics.data(), recursive1Verkey, recursive1Steps);
+            }
+            collect(starksRecursive1, "recursive1");
+            Tm t(&req, "SAVE_PROOF");
+            req.batchProofOutput = withMembers(proof2zkinStark(*fproof), ",\"publics\":" + publicStarkJson);
+            req.publicsJson = publicStarkJson;
+            if (config.saveOutputToFile) json2file(req.batchProofOutput, req.filePrefix + "batch_proof.output.json");
+            if (config.saveProofToFile) json2file(req.batchProofOutput, req.filePrefix + "batch_proof.proof.json");
+            if (config.saveOutputToFile || config.saveProofToFile) json2file(publicStarkJson, req.publicsOutputFile());
+            delete fproof;
+        }
+    }
+};

@@ -1,53 +1,99 @@
-// GPU-resident mirror of `class Starks` (src/starkpil/starks.hpp:29-232) and `Starks::genProof`
-// (src/starkpil/starks.cpp:9-404): the same stage order, timer names and transcript sequence, driven by a StarkInfo
-// (stark_info.hpp) and the step programs of the PIL (XlpSteps: tools/chelpers_to_xlp.py / chelpers_cpp_to_xlp.py
-// output), with the whole slab, the constant polynomials, the trees and every intermediate resident in HBM.  Only the
-// witness (cm1_n) goes up and roots / evaluations / final polynomial / opened rows come down.
-//
-// What differs from the reference, by construction:
-//  * transposeH1H2Columns / transposeZColumns / ...Rows (starks.cpp:406-555) become strided device copies
-//    (xlp_dev_copy_cols) around xlp_dev_calculate_h1h2 / xlp_dev_calculate_z;
-//  * the constant tree is computed in the constructor (the reference maps a .consttree file built by bctree;
-//    host/bctree writes that file with the same kernels);
+// GPU-resident `class Starks` with the reference's interface (src/starkpil/starks.hpp:29-232, starks.cpp:9-404):
+//     Starks(const Config& config, StarkFiles starkFiles, void* pAddress)
+//     void genProof(FRIProof& proof, Goldilocks::Element* publicInputs, Goldilocks::Element verkey[4], Steps* steps)
+// Same stage order, timer names and transcript sequence.  What differs, by construction:
+//  * pAddress is still the HOST slab the executor (or the previous STARK's witness calculator) writes the committed polynomials
+//    into (prover.cpp:94-115,435,593,630); only its cm1_n section is read.  Everything else of the slab lives in HBM: one device
+//    slab shared by all Starks of the process, as the reference shares pAddress (prover.cpp:123-127).  Step 1 uploads the witness
+//    in column bands on a second stream while the previous band is extended and absorbed into the leaf hashes
+//    (xlp_dev_commit_from_host); pin pAddress (xlp_host_alloc / xlp_host_register) for the full PCIe rate.
+//  * transposeH1H2Columns / transposeZColumns / ...Rows (starks.cpp:406-555) are strided device copies (xlp_dev_copy_cols)
+//    around xlp_dev_calculate_h1h2 / xlp_dev_calculate_z.
+//  * The constant tree comes from starkFiles.zkevmConstantsTree when that file exists (the bctree layout the reference maps,
+//    starks.hpp:117-136) and is computed from the constant polynomials otherwise.  "synthetic:<seed>" as zkevmConstPols fills the
+//    constants on the device (benchmarks at sizes whose 15 GB .const file does not exist on the box).
+//  * A starkinfo may place the extended constants inside the slab ("xlp": {"const2nsOffset": ...}: the one-GPU aliased layout of
+//    tools/zkevm_geometry.py); they are then re-extended in step 4 of every proof, only their tree stays resident.
 //  * nrowsStepBatch is irrelevant (one row per lane).
 #pragma once
 #include <chrono>
 #include <string>
 #include <vector>
 #include "xlp_host.hpp"
+#include "config.hpp"
+#include "steps.hpp"
 
+#define STARK_C12_A_NUM_TREES 5
 #define NUM_CHALLENGES 8
+
+struct StarkFiles
+{
+    std::string zkevmConstPols;
+    bool mapConstPolsFile;
+    std::string zkevmConstantsTree;
+    std::string zkevmStarkInfo;
+};
+
+// One device slab for all Starks of the process (the reference's shared pAddress, prover.cpp:94-127)
+class XlpDeviceSlab
+{
+    uint64_t* p = NULL;
+    uint64_t words = 0;
+    XlpDeviceSlab() {}
+public:
+    static XlpDeviceSlab& get() { static XlpDeviceSlab s; return s; }
+    uint64_t* reserve(uint64_t w)
+    {
+        if (w > words) {
+            if (p) XLP_CHECK(xlp_dev_free(p));
+            void* d = NULL;
+            XLP_CHECK(xlp_dev_alloc(&d, w * sizeof(uint64_t)));
+            p = (uint64_t*)d; words = w;
+        }
+        return p;
+    }
+    uint64_t* address() { return p; }
+    void release() { if (p) xlp_dev_free(p); p = NULL; words = 0; }
+};
 
 class Starks
 {
 public:
+    const Config& config;
     StarkInfo starkInfo;
-    uint64_t N, NExtended, extendBits;
-    Goldilocks::Element constRoot[HASH_SIZE];
+    uint64_t nrowsStepBatch;
+    Goldilocks::Element constRoot[HASH_SIZE];       // root of the constant tree (= the verification key)
     bool logTimers = false;
-
-    // true if step k (0 step2prev .. 4 step52ns) runs in its dot-product form (tools/optimize_programs.py)
-    bool stepOptimised(int k) const { return steps.optimised(k); }
+    double lastUploadMs = 0.0;                      // time the copy stream was busy with the witness in the last genProof
+    bool pipelineWitness = true;                    // false: upload the witness in one piece first, then commit it (the measurement of what the pipeline hides)
+    std::vector<std::pair<std::string, double>> lastTimers;
 
 private:
-    XlpSteps steps;
-    uint64_t *d_mem = NULL, *d_const_n = NULL, *d_const_2ns = NULL, *d_x_n = NULL, *d_x_2ns = NULL, *d_zi = NULL, *d_xdx = NULL, *d_xdwx = NULL;
+    StarkFiles starkFiles;
+    uint64_t N, NExtended, extendBits;
+    void* pAddress;
+    uint64_t slabWords = 0;
+    bool const2nsInSlab = false;
+    uint64_t const2nsOffset = 0;
+    uint64_t *d_const_n = NULL, *d_const_2ns_own = NULL, *d_x_n = NULL, *d_x_2ns = NULL, *d_zi = NULL, *d_xdx = NULL, *d_xdwx = NULL;
     uint64_t *d_challenges = NULL, *d_publics = NULL, *d_evals = NULL, *d_work = NULL;
-    MerkleTreeGL* treesGL[5] = {NULL, NULL, NULL, NULL, NULL};
+    MerkleTreeGL* treesGL[STARK_C12_A_NUM_TREES] = {NULL, NULL, NULL, NULL, NULL};
 
     static uint64_t* dalloc(uint64_t elems)
     {
-        uint64_t* p = NULL;
-        XLP_CHECK(xlp_dev_alloc((void**)&p, (elems ? elems : 1) * sizeof(uint64_t)));
-        return p;
+        void* p = NULL;
+        XLP_CHECK(xlp_dev_alloc(&p, (elems ? elems : 1) * sizeof(uint64_t)));
+        return (uint64_t*)p;
     }
-    uint64_t* section(eSection s) { return d_mem + starkInfo.mapOffsets.section[s]; }
+    uint64_t* mem() { return XlpDeviceSlab::get().address(); }
+    uint64_t* section(eSection s) { return mem() + starkInfo.mapOffsets.section[s]; }
+    uint64_t* constPols2ns() { return const2nsInSlab ? mem() + const2nsOffset : d_const_2ns_own; }
     struct PolRef { uint64_t* p; uint64_t n, dim, stride; };
     PolRef pol(uint64_t id)          // StarkInfo::getPolinomial on the device slab
     {
         if (id >= starkInfo.varPolMap.size()) xlp_exit_process("Starks: polynomial id out of range");
         const VarPolMap& m = starkInfo.varPolMap[id];
-        return {d_mem + starkInfo.mapOffsets.section[m.section] + m.sectionPos, starkInfo.mapDeg.section[m.section], m.dim, starkInfo.mapSectionsN.section[m.section]};
+        return {mem() + starkInfo.mapOffsets.section[m.section] + m.sectionPos, starkInfo.mapDeg.section[m.section], m.dim, starkInfo.mapSectionsN.section[m.section]};
     }
     uint64_t exp2pol(uint64_t expId)
     {
@@ -56,18 +102,24 @@ private:
         xlp_exit_process(("Starks: expression " + k + " has no polynomial (exp2pol)").c_str());
         return 0;
     }
-    struct Timer {
-        const char* name; bool on; std::chrono::steady_clock::time_point t0;
-        Timer(const char* n, bool o) : name(n), on(o), t0(std::chrono::steady_clock::now()) {}
-        ~Timer() { if (on) { xlp_sync(); fprintf(stderr, "<-- %s done: %.6f s\n", name, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count()); } }
+    struct Timer {           // TimerStart / TimerStopAndLog (src/utils/timer.hpp:17-27)
+        Starks* s; const char* name; std::chrono::steady_clock::time_point t0;
+        Timer(Starks* s_, const char* n) : s(s_), name(n) { xlp_sync(); t0 = std::chrono::steady_clock::now(); }
+        ~Timer()
+        {
+            xlp_sync();
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            s->lastTimers.emplace_back(name, dt);
+            if (s->logTimers) fprintf(stderr, "<-- %s done: %.6f s\n", name, dt);
+        }
     };
-    xlp_steps_params params()
+    StepsParams params()
     {
-        xlp_steps_params P;
+        StepsParams P;
         memset(&P, 0, sizeof P);
-        P.pols = d_mem; P.pols_size = starkInfo.mapTotalN;
+        P.pols = mem(); P.pols_size = starkInfo.mapTotalN;
         P.const_pols = d_const_n; P.n_const_pols = starkInfo.nConstants; P.const_pols_size = N * starkInfo.nConstants;
-        P.const_pols_2ns = d_const_2ns; P.n_const_pols_2ns = starkInfo.nConstants; P.const_pols_2ns_size = NExtended * starkInfo.nConstants;
+        P.const_pols_2ns = constPols2ns(); P.n_const_pols_2ns = starkInfo.nConstants; P.const_pols_2ns_size = NExtended * starkInfo.nConstants;
         P.challenges = d_challenges; P.challenges_size = NUM_CHALLENGES * FIELD_EXTENSION;
         P.public_inputs = d_publics; P.public_inputs_size = starkInfo.nPublics;
         P.evals = d_evals; P.evals_size = starkInfo.evMap.size() * FIELD_EXTENSION;
@@ -80,25 +132,62 @@ private:
         P.f_2ns = section(f_2ns); P.f_2ns_size = NExtended * starkInfo.mapSectionsN.section[f_2ns];
         return P;
     }
+    static bool fileExists(const std::string& f) { FILE* fp = fopen(f.c_str(), "rb"); if (fp) fclose(fp); return fp != NULL; }
+    // copyFile() of the reference (src/utils/utils.cpp) straight into HBM, through a bounded host buffer
+    static void fileToDevice(uint64_t* dst, const std::string& file, uint64_t offsetBytes, uint64_t bytes)
+    {
+        FILE* fp = fopen(file.c_str(), "rb");
+        if (!fp) xlp_exit_process(("Starks: cannot open " + file).c_str());
+        if (fseek(fp, (long)offsetBytes, SEEK_SET)) xlp_exit_process(("Starks: cannot seek in " + file).c_str());
+        const uint64_t chunk = 256ULL << 20;
+        std::vector<char> buf(bytes < chunk ? bytes : chunk);
+        for (uint64_t o = 0; o < bytes; o += chunk) {
+            const uint64_t n = bytes - o < chunk ? bytes - o : chunk;
+            if (fread(buf.data(), 1, n, fp) != n) xlp_exit_process(("Starks: short read on " + file).c_str());
+            XLP_CHECK(xlp_copy_h2d((char*)dst + o, buf.data(), n));
+        }
+        fclose(fp);
+    }
 
 public:
-    // constPols: host, N rows x nConstants (the .const file, starks.hpp:102-115); stepsDir/<name>.<step>.xlpexpr
-    Starks(const std::string& starkInfoFile, const Goldilocks::Element* constPols, const std::string& stepsDir, const std::string& name)
-        : starkInfo(starkInfoFile), steps(stepsDir, name)
+    Starks(const Config& config, StarkFiles starkFiles, void* _pAddress)
+        : config(config), starkInfo(starkFiles.zkevmStarkInfo), nrowsStepBatch(1), starkFiles(starkFiles), N(0), NExtended(0), extendBits(0), pAddress(_pAddress)
     {
+        if (!config.generateProof()) return;      // starks.hpp:91-93: nothing is initialised if no proof will be generated
         N = 1ULL << starkInfo.starkStruct.nBits;
         NExtended = 1ULL << starkInfo.starkStruct.nBitsExt;
         extendBits = starkInfo.starkStruct.nBitsExt - starkInfo.starkStruct.nBits;
         if (starkInfo.mapSectionsN.section[q_2ns] != starkInfo.qDim || starkInfo.mapSectionsN.section[f_2ns] != FIELD_EXTENSION)
             xlp_exit_process("Starks: q_2ns / f_2ns sections must be qDim / 3 wide");
         if (starkInfo.mapSectionsN.section[cm4_2ns] != starkInfo.qDim * starkInfo.qDeg) xlp_exit_process("Starks: cm4_2ns must hold qDeg x qDim columns");
-        XLP_CHECK(xlp_init(0));
-        d_mem = dalloc(starkInfo.mapTotalN);
+        XLP_CHECK(xlp_init((int)config.xlpDevice));
+        const2nsInSlab = starkInfo.xlpConst2nsInSlab; const2nsOffset = starkInfo.xlpConst2nsOffset;
+        slabWords = starkInfo.mapTotalN;
+        XlpDeviceSlab::get().reserve(slabWords);
+        // ---- constant polynomials (LOAD_CONST_POLS_TO_MEMORY, starks.hpp:96-115)
+        if (starkFiles.zkevmConstPols.size() == 0) xlp_exit_process("Starks::Starks() received an empty config.zkevmConstPols");
         d_const_n = dalloc(N * starkInfo.nConstants);
-        d_const_2ns = dalloc(NExtended * starkInfo.nConstants);
-        XLP_CHECK(xlp_copy_h2d(d_const_n, constPols, N * starkInfo.nConstants * sizeof(uint64_t)));
-        XLP_CHECK(xlp_dev_extend(d_const_2ns, d_const_n, NExtended, N, starkInfo.nConstants, NULL));
-        // x_n, x_2ns (starks.hpp:149-160), ZhInv (zhInv.cpp:7-32)
+        if (starkFiles.zkevmConstPols.rfind("synthetic:", 0) == 0)
+            XLP_CHECK(xlp_dev_fill(d_const_n, N * starkInfo.nConstants, strtoull(starkFiles.zkevmConstPols.c_str() + 10, NULL, 0), 0));
+        else fileToDevice(d_const_n, starkFiles.zkevmConstPols, 0, N * starkInfo.nConstants * sizeof(uint64_t));
+        // ---- constant tree (LOAD_CONST_TREE_TO_MEMORY / LOAD_CONST_POLS_2NS_TO_MEMORY, starks.hpp:117-146)
+        if (!const2nsInSlab) d_const_2ns_own = dalloc(NExtended * starkInfo.nConstants);
+        treesGL[4] = new MerkleTreeGL(NExtended, starkInfo.nConstants, constPols2ns(), true);
+        if (starkFiles.zkevmConstantsTree.size() && fileExists(starkFiles.zkevmConstantsTree)) {
+            // [width, height, source (height x width), nodes] -- build_const_tree.cpp:566-603, MerkleTreeGL(Goldilocks::Element*) merkleTreeGL.hpp:24-32
+            uint64_t hdr[2] = {0, 0};
+            FILE* fp = fopen(starkFiles.zkevmConstantsTree.c_str(), "rb");
+            if (!fp || fread(hdr, 8, 2, fp) != 2) xlp_exit_process("Starks: cannot read the constant tree header");
+            fclose(fp);
+            if (hdr[0] != starkInfo.nConstants || hdr[1] != NExtended) xlp_exit_process("Starks: constant tree does not match the starkinfo");
+            fileToDevice(constPols2ns(), starkFiles.zkevmConstantsTree, 16, NExtended * starkInfo.nConstants * 8);
+            fileToDevice(treesGL[4]->d_nodes, starkFiles.zkevmConstantsTree, 16 + NExtended * starkInfo.nConstants * 8, treesGL[4]->getTreeNumElements() * 8);
+        } else {
+            XLP_CHECK(xlp_dev_extend(constPols2ns(), d_const_n, NExtended, N, starkInfo.nConstants, NULL));
+            treesGL[4]->merkelize();
+        }
+        treesGL[4]->getRoot(constRoot);
+        // ---- x_n, x_2ns (COMPUTE_X_N_AND_X_2_NS, starks.hpp:149-160), ZhInv (zhInv.cpp:7-32)
         d_x_n = dalloc(N); d_x_2ns = dalloc(NExtended);
         const uint64_t one = 1, wn = Goldilocks::toU64(Goldilocks::w(starkInfo.starkStruct.nBits)), sh = Goldilocks::toU64(Goldilocks::shift()),
                        wne = Goldilocks::toU64(Goldilocks::w(starkInfo.starkStruct.nBitsExt));
@@ -120,25 +209,28 @@ public:
         d_publics = dalloc(starkInfo.nPublics);
         d_evals = dalloc(starkInfo.evMap.size() * FIELD_EXTENSION);
         d_work = dalloc(NExtended * (uint64_t)std::max<uint64_t>(4 * FIELD_EXTENSION, starkInfo.qDim * (starkInfo.qDeg + 1)));
-        // trees: cm1..cm4 over the extended sections + the constant tree (starks.hpp:186-190)
+        // ---- trees over the extended sections (MERKLE_TREE_ALLOCATION, starks.hpp:185-191): sources are offsets into the shared slab
         const eSection secs[4] = {cm1_2ns, cm2_2ns, cm3_2ns, cm4_2ns};
-        for (int i = 0; i < 4; i++) treesGL[i] = new MerkleTreeGL(NExtended, starkInfo.mapSectionsN.section[secs[i]], section(secs[i]), true);
-        treesGL[4] = new MerkleTreeGL(NExtended, starkInfo.nConstants, d_const_2ns, true);
-        treesGL[4]->merkelize();
-        treesGL[4]->getRoot(constRoot);
+        for (int i = 0; i < 4; i++) treesGL[i] = new MerkleTreeGL(NExtended, starkInfo.mapSectionsN.section[secs[i]], NULL, true);
     }
     ~Starks()
     {
+        if (!config.generateProof()) return;
         for (int i = 0; i < 5; i++) delete treesGL[i];
-        uint64_t* all[] = {d_mem, d_const_n, d_const_2ns, d_x_n, d_x_2ns, d_zi, d_xdx, d_xdwx, d_challenges, d_publics, d_evals, d_work};
+        uint64_t* all[] = {d_const_n, d_const_2ns_own, d_x_n, d_x_2ns, d_zi, d_xdx, d_xdwx, d_challenges, d_publics, d_evals, d_work};
         for (uint64_t* p : all) xlp_dev_free(p);
     }
     Starks(const Starks&) = delete;
     Starks& operator=(const Starks&) = delete;
+    uint64_t domainSize() const { return N; }
 
-    // cm1_n: the committed witness, N rows x mapSectionsN[cm1_n] (what the executor leaves at pAddress + mapOffsets[cm1_n])
-    void genProof(FRIProof& proof, Goldilocks::Element* publicInputs, Goldilocks::Element verkey[4], const Goldilocks::Element* cm1_n_host)
+    void genProof(FRIProof& proof, Goldilocks::Element* publicInputs, Goldilocks::Element verkey[4], Steps* steps)
     {
+        lastTimers.clear();
+        if (XlpDeviceSlab::get().reserve(slabWords) == NULL) xlp_exit_process("Starks: no device slab");
+        const eSection secs2ns[4] = {cm1_2ns, cm2_2ns, cm3_2ns, cm4_2ns};
+        for (int i = 0; i < 4; i++) treesGL[i]->d_source = section(secs2ns[i]);        // the slab may have been re-reserved by a larger Starks
+        treesGL[4]->d_source = constPols2ns();
         const uint64_t W1 = starkInfo.mapSectionsN.section[cm1_n];
         uint64_t numCommited = starkInfo.nCm1;
         Transcript transcript;
@@ -149,16 +241,26 @@ public:
             transcript.getField(&challenges[k * FIELD_EXTENSION]);
             XLP_CHECK(xlp_copy_h2d(d_challenges, challenges.data(), challenges.size() * sizeof(uint64_t)));
         };
-        XLP_CHECK(xlp_copy_h2d(section(cm1_n), cm1_n_host, N * W1 * sizeof(uint64_t)));
+        // the base-domain sections other than the witness start from zero (prover.cpp:426-430 clears the committed polynomials; in the
+        // aliased layout the previous proof's extended sections lie there)
+        {
+            const uint64_t from = starkInfo.mapOffsets.section[cm2_n], to = starkInfo.mapOffsets.section[tmpExp_n] + N * starkInfo.mapSectionsN.section[tmpExp_n];
+            if (to > from && to <= slabWords) XLP_CHECK(xlp_dev_memset(mem() + from, 0, (to - from) * sizeof(uint64_t)));
+        }
         XLP_CHECK(xlp_copy_h2d(d_publics, publicInputs, starkInfo.nPublics * sizeof(uint64_t)));
         transcript.put(&verkey[0], 4);
         transcript.put(&publicInputs[0], starkInfo.nPublics);
-        xlp_steps_params P = params();
+        StepsParams P = params();
         //-------------------------------- 1.- Calculate p_cm1_2ns
         {
-            Timer t("STARK_STEP_1_LDE_AND_MERKLETREE", logTimers);
-            XLP_CHECK(xlp_dev_extend(section(cm1_2ns), section(cm1_n), NExtended, N, W1, NULL));
-            treesGL[0]->merkelize();
+            const uint64_t* h_cm1 = (const uint64_t*)pAddress + starkInfo.mapOffsets.section[cm1_n];
+            if (!pipelineWitness) {
+                Timer t(this, "STARK_STEP_1_WITNESS_UPLOAD");
+                XLP_CHECK(xlp_copy_h2d(section(cm1_n), h_cm1, N * W1 * sizeof(uint64_t)));
+            }
+            Timer t(this, "STARK_STEP_1_LDE_AND_MERKLETREE");
+            if (pipelineWitness) XLP_CHECK(xlp_dev_commit_from_host(section(cm1_n), section(cm1_2ns), treesGL[0]->d_nodes, h_cm1, NExtended, N, W1, &lastUploadMs));
+            else XLP_CHECK(xlp_dev_commit(section(cm1_2ns), treesGL[0]->d_nodes, section(cm1_n), NExtended, N, W1));
             treesGL[0]->getRoot(root0);
             transcript.put(root0, HASH_SIZE);
         }
@@ -166,18 +268,19 @@ public:
         challenge(0);   // u
         challenge(1);   // defVal
         {
-            Timer t("STARK_STEP_2_CALCULATE_EXPS", logTimers);
-            steps.step2prev_parser_first_avx(P, N, 1);
+            Timer t(this, "STARK_STEP_2_CALCULATE_EXPS");
+            steps->step2prev_parser_first_avx(P, N, nrowsStepBatch);
         }
         {
-            Timer t("STARK_STEP_2_CALCULATEH1H2", logTimers);
+            Timer t(this, "STARK_STEP_2_CALCULATEH1H2");
             for (uint64_t i = 0; i < starkInfo.puCtx.size(); i++) {
                 const PolRef f = pol(exp2pol(starkInfo.puCtx[i].fExpId)), tt = pol(exp2pol(starkInfo.puCtx[i].tExpId));
                 const PolRef h1 = pol(starkInfo.cm_n[numCommited + i * 2]), h2 = pol(starkInfo.cm_n[numCommited + i * 2 + 1]);
                 if (f.dim != tt.dim || h1.dim != f.dim || h2.dim != f.dim) xlp_exit_process("Starks: plookup polynomials of different dimensions");
                 uint64_t *df = d_work, *dt = d_work + N * 3, *dh1 = d_work + 2 * N * 3, *dh2 = d_work + 3 * N * 3;
-                XLP_CHECK(xlp_dev_copy_cols(df, f.dim, f.p, f.stride, N, (uint32_t)f.dim));          // transposeH1H2Columns
-                XLP_CHECK(xlp_dev_copy_cols(dt, f.dim, tt.p, tt.stride, N, (uint32_t)f.dim));
+                XLP_CHECK(xlp_dev_copy_cols(dt, f.dim, tt.p, tt.stride, N, (uint32_t)f.dim));          // transposeH1H2Columns
+                if (config.xlpSyntheticLookups) XLP_CHECK(xlp_dev_gather_rows(df, dt, f.dim, N, (uint32_t)f.dim, 0x5EED0500ULL + i));
+                else XLP_CHECK(xlp_dev_copy_cols(df, f.dim, f.p, f.stride, N, (uint32_t)f.dim));
                 XLP_CHECK(xlp_dev_calculate_h1h2(dh1, dh2, df, dt, N, (uint32_t)f.dim));
                 XLP_CHECK(xlp_dev_copy_cols(h1.p, h1.stride, dh1, f.dim, N, (uint32_t)f.dim));       // transposeH1H2Rows
                 XLP_CHECK(xlp_dev_copy_cols(h2.p, h2.stride, dh2, f.dim, N, (uint32_t)f.dim));
@@ -185,9 +288,8 @@ public:
             numCommited += starkInfo.puCtx.size() * 2;
         }
         {
-            Timer t("STARK_STEP_2_LDE_AND_MERKLETREE", logTimers);
-            XLP_CHECK(xlp_dev_extend(section(cm2_2ns), section(cm2_n), NExtended, N, starkInfo.mapSectionsN.section[cm2_n], NULL));
-            treesGL[1]->merkelize();
+            Timer t(this, "STARK_STEP_2_LDE_AND_MERKLETREE");
+            XLP_CHECK(xlp_dev_commit(section(cm2_2ns), treesGL[1]->d_nodes, section(cm2_n), NExtended, N, starkInfo.mapSectionsN.section[cm2_n]));
             treesGL[1]->getRoot(root1);
             transcript.put(root1, HASH_SIZE);
         }
@@ -195,11 +297,11 @@ public:
         challenge(2);   // gamma
         challenge(3);   // betta
         {
-            Timer t("STARK_STEP_3_CALCULATE_EXPS", logTimers);
-            steps.step3prev_parser_first_avx(P, N, 1);
+            Timer t(this, "STARK_STEP_3_CALCULATE_EXPS");
+            steps->step3prev_parser_first_avx(P, N, nrowsStepBatch);
         }
         {
-            Timer t("STARK_STEP_3_CALCULATE_Z", logTimers);
+            Timer t(this, "STARK_STEP_3_CALCULATE_Z");
             std::vector<std::pair<uint64_t, uint64_t>> nd;       // (numId, denId) of puCtx, peCtx, ciCtx in the reference's order
             for (const PuCtx& c : starkInfo.puCtx) nd.emplace_back(c.numId, c.denId);
             for (const PeCtx& c : starkInfo.peCtx) nd.emplace_back(c.numId, c.denId);
@@ -215,24 +317,27 @@ public:
             }
         }
         {
-            Timer t("STARK_STEP_3_CALCULATE_EXPS_2", logTimers);
-            steps.step3_parser_first_avx(P, N, 1);
+            Timer t(this, "STARK_STEP_3_CALCULATE_EXPS_2");
+            steps->step3_parser_first_avx(P, N, nrowsStepBatch);
         }
         {
-            Timer t("STARK_STEP_3_LDE_AND_MERKLETREE", logTimers);
-            XLP_CHECK(xlp_dev_extend(section(cm3_2ns), section(cm3_n), NExtended, N, starkInfo.mapSectionsN.section[cm3_n], NULL));
-            treesGL[2]->merkelize();
+            Timer t(this, "STARK_STEP_3_LDE_AND_MERKLETREE");
+            XLP_CHECK(xlp_dev_commit(section(cm3_2ns), treesGL[2]->d_nodes, section(cm3_n), NExtended, N, starkInfo.mapSectionsN.section[cm3_n]));
             treesGL[2]->getRoot(root2);
             transcript.put(root2, HASH_SIZE);
         }
         //-------------------------------- 4. Compute C Polynomial
         challenge(4);
-        {
-            Timer t("STARK_STEP_4_CALCULATE_EXPS_2NS", logTimers);
-            steps.step42ns_parser_first_avx(P, NExtended, 1);
+        if (const2nsInSlab) {          // the one-GPU memory trade: the extended constants lie over the now dead cm3_n
+            Timer t(this, "STARK_STEP_4_CONST_LDE");
+            XLP_CHECK(xlp_dev_extend(constPols2ns(), d_const_n, NExtended, N, starkInfo.nConstants, NULL));
         }
         {
-            Timer t("STARK_STEP_4_CALCULATE_EXPS_2NS_INTT_MUL_NTT", logTimers);
+            Timer t(this, "STARK_STEP_4_CALCULATE_EXPS_2NS");
+            steps->step42ns_parser_first_avx(P, NExtended, nrowsStepBatch);
+        }
+        {
+            Timer t(this, "STARK_STEP_4_CALCULATE_EXPS_2NS_INTT_MUL_NTT");
             uint64_t *qq1 = d_work, *qq2 = d_work + NExtended * starkInfo.qDim;
             XLP_CHECK(xlp_dev_ntt(qq1, section(q_2ns), NExtended, starkInfo.qDim, 1));
             const Goldilocks::Element shiftIn = Goldilocks::exp(Goldilocks::inv(Goldilocks::shift()), N);
@@ -240,7 +345,7 @@ public:
             XLP_CHECK(xlp_dev_ntt(section(cm4_2ns), qq2, NExtended, starkInfo.qDim * starkInfo.qDeg, 0));
         }
         {
-            Timer t("STARK_STEP_4_MERKLETREE", logTimers);
+            Timer t(this, "STARK_STEP_4_MERKLETREE");
             treesGL[3]->merkelize();
             treesGL[3]->getRoot(root3);
             transcript.put(root3, HASH_SIZE);
@@ -250,7 +355,7 @@ public:
         const Goldilocks::Element* xi = &challenges[7 * FIELD_EXTENSION];
         uint64_t wxi[3];
         {
-            Timer t("STARK_STEP_5_LEv_LpEv", logTimers);
+            Timer t(this, "STARK_STEP_5_LEv_LpEv");
             const Goldilocks::Element sinv = Goldilocks::inv(Goldilocks::shift()), wN = Goldilocks::w(starkInfo.starkStruct.nBits);
             uint64_t xis[3], wxis[3];
             const uint64_t first[3] = {1, 0, 0};
@@ -266,11 +371,11 @@ public:
             XLP_CHECK(xlp_dev_ntt(LpEv, LpEv, N, 3, 1));
         }
         {
-            Timer t("STARK_STEP_5_EVMAP", logTimers);
+            Timer t(this, "STARK_STEP_5_EVMAP");
             std::vector<xlp_evmap_entry> ents(starkInfo.evMap.size());
             for (size_t i = 0; i < ents.size(); i++) {
                 const EvMap& ev = starkInfo.evMap[i];
-                if (ev.type == EvMap::_const) ents[i] = {d_const_2ns + ev.id, starkInfo.nConstants, 1, ev.prime ? 1u : 0u};
+                if (ev.type == EvMap::_const) ents[i] = {constPols2ns() + ev.id, starkInfo.nConstants, 1, ev.prime ? 1u : 0u};
                 else {
                     const PolRef p = pol(ev.type == EvMap::cm ? starkInfo.cm_2ns[ev.id] : starkInfo.qs[ev.id]);
                     ents[i] = {p.p, p.stride, (uint32_t)p.dim, ev.prime ? 1u : 0u};
@@ -283,16 +388,16 @@ public:
         challenge(5);   // v1
         challenge(6);   // v2
         {
-            Timer t("STARK_STEP_5_XDIVXSUB", logTimers);
+            Timer t(this, "STARK_STEP_5_XDIVXSUB");
             XLP_CHECK(xlp_dev_x_div_x_sub_xi(d_xdx, d_x_2ns, xlp_raw(xi), NExtended));
             XLP_CHECK(xlp_dev_x_div_x_sub_xi(d_xdwx, d_x_2ns, wxi, NExtended));
         }
         {
-            Timer t("STARK_STEP_5_CALCULATE_EXPS", logTimers);
-            steps.step52ns_parser_first_avx(P, NExtended, 1);
+            Timer t(this, "STARK_STEP_5_CALCULATE_EXPS");
+            steps->step52ns_parser_first_avx(P, NExtended, nrowsStepBatch);
         }
         {
-            Timer t("STARK_STEP_FRI", logTimers);
+            Timer t(this, "STARK_STEP_FRI");
             Polinomial friPol(NExtended >> (starkInfo.starkStruct.nBitsExt - starkInfo.starkStruct.steps.back().nBits), FIELD_EXTENSION, "friPol");
             FRIProve::prove(proof, treesGL, transcript, friPol, starkInfo.starkStruct.nBitsExt, starkInfo, section(f_2ns));
         }

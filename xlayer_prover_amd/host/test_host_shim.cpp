@@ -85,19 +85,8 @@ static std::vector<Goldilocks::Element> read_u64_file(const std::string& f)
     fclose(fp);
     return v;
 }
-static int genproof_mode(const std::string& dir, const std::string& name, bool timers)
+static std::string zkinWithPublics(Starks& starks, FRIProof& proof)
 {
-    std::vector<Goldilocks::Element> constPols = read_u64_file(dir + "/" + name + ".const"), cm1 = read_u64_file(dir + "/" + name + ".commit"),
-                                     publics = read_u64_file(dir + "/" + name + ".publics");
-    Starks starks(dir + "/" + name + ".starkinfo.json", constPols.data(), dir, name);
-    starks.logTimers = timers;
-    static const char* stepNames[5] = {"step2prev", "step3prev", "step3", "step42ns", "step52ns"};
-    for (int k = 0; k < 5; k++)
-        if (starks.stepOptimised(k)) fprintf(stderr, "%s: dot-product form\n", stepNames[k]);
-    const StarkStruct& ss = starks.starkInfo.starkStruct;
-    FRIProof proof(1ULL << ss.steps.back().nBits, FIELD_EXTENSION, ss.steps.size(), starks.starkInfo.evMap.size(), starks.starkInfo.nPublics);
-    for (uint64_t i = 0; i < starks.starkInfo.nPublics; i++) proof.publics[i] = publics[i];
-    starks.genProof(proof, publics.data(), starks.constRoot, cm1.data());
     std::string zkin = proof2zkinStark(proof);
     std::ostringstream os;
     os << zkin.substr(0, zkin.size() - 1) << ",\"publics\":";
@@ -105,15 +94,81 @@ static int genproof_mode(const std::string& dir, const std::string& name, bool t
     os << ",\"verkey\":[";
     for (int i = 0; i < HASH_SIZE; i++) os << (i ? "," : "") << "\"" << Goldilocks::toString(starks.constRoot[i]) << "\"";
     os << "]}";
-    const std::string out = os.str();
+    return os.str();
+}
+static int genproof_mode(const std::string& dir, const std::string& name, bool timers)
+{
+    std::vector<Goldilocks::Element> cm1 = read_u64_file(dir + "/" + name + ".commit"), publics = read_u64_file(dir + "/" + name + ".publics");
+    Config config;
+    config.runFileGenBatchProof = true;
+    // pAddress: the host slab the executor would have filled; only cm1_n (offset mapOffsets[cm1_n]) is read from it
+    Starks starks(config, {dir + "/" + name + ".const", false, dir + "/" + name + ".consttree", dir + "/" + name + ".starkinfo.json"}, cm1.data());
+    XlpSteps steps(dir, name);
+    starks.logTimers = timers;
+    static const char* stepNames[5] = {"step2prev", "step3prev", "step3", "step42ns", "step52ns"};
+    for (int k = 0; k < 5; k++)
+        if (steps.optimised(k)) fprintf(stderr, "%s: dot-product form\n", stepNames[k]);
+    const StarkStruct& ss = starks.starkInfo.starkStruct;
+    FRIProof proof(1ULL << ss.steps.back().nBits, FIELD_EXTENSION, ss.steps.size(), starks.starkInfo.evMap.size(), starks.starkInfo.nPublics);
+    for (uint64_t i = 0; i < starks.starkInfo.nPublics; i++) proof.publics[i] = publics[i];
+    starks.genProof(proof, publics.data(), starks.constRoot, &steps);
+    const std::string out = zkinWithPublics(starks, proof);
     fwrite(out.data(), 1, out.size(), stdout);
     printf("\n");
     return 0;
 }
 
+// `bundle <dir> <name> <witness seed> <const seed> [timers]`: one STARK from a bundle of tools/make_stark_bundle.py (synthesized
+// starkinfo + relocated reference programs) on a synthetic witness left in page-locked host memory, synthetic constants and
+// synthetic plookup selectors -- the inputs of tools/bench_zkevm_genproof.py, so that the two drivers must print the same proof
+static int bundle_mode(const std::string& dir, const std::string& name, uint64_t wseed, uint64_t cseed, bool timers)
+{
+    Config config;
+    config.runFileGenBatchProof = true;
+    config.xlpSyntheticLookups = true;
+    char cs[64];
+    snprintf(cs, sizeof cs, "synthetic:%llu", (unsigned long long)cseed);
+    StarkInfo si(dir + "/" + name + ".starkinfo.json");
+    const uint64_t N = 1ULL << si.starkStruct.nBits, W = si.mapSectionsN.section[cm1_n];
+    void* host = NULL;
+    XLP_CHECK(xlp_init(0));
+    XLP_CHECK(xlp_host_alloc(&host, (N * W > 0 ? N * W : 1) * 8));
+    {
+        void* d = NULL;
+        XLP_CHECK(xlp_dev_alloc(&d, N * W * 8));
+        XLP_CHECK(xlp_dev_fill((uint64_t*)d, N * W, wseed, 0));
+        XLP_CHECK(xlp_copy_d2h(host, d, N * W * 8));
+        XLP_CHECK(xlp_dev_free(d));
+    }
+    {
+        Starks starks(config, {cs, false, "", dir + "/" + name + ".starkinfo.json"}, host);
+        XlpSteps steps(dir, name);
+        starks.logTimers = timers;
+        for (int k = 0; k < 5; k++) fprintf(stderr, "step %d: %s\n", k, steps.mode(k).c_str());
+        const StarkStruct& ss = starks.starkInfo.starkStruct;
+        FRIProof proof(1ULL << ss.steps.back().nBits, FIELD_EXTENSION, ss.steps.size(), starks.starkInfo.evMap.size(), starks.starkInfo.nPublics);
+        std::vector<Goldilocks::Element> publics(starks.starkInfo.nPublics);
+        for (uint64_t i = 0; i < publics.size(); i++) publics[i] = Goldilocks::fromU64(i + 1);
+        for (uint64_t i = 0; i < publics.size(); i++) proof.publics[i] = publics[i];
+        starks.genProof(proof, publics.data(), starks.constRoot, &steps);
+        fprintf(stderr, "witness upload busy %.3f ms\n", starks.lastUploadMs);
+        const std::string out = zkinWithPublics(starks, proof);
+        fwrite(out.data(), 1, out.size(), stdout);
+        printf("\n");
+    }
+    XlpDeviceSlab::get().release();
+    XLP_CHECK(xlp_host_free(host));
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
-    if ((argc == 4 || argc == 5) && std::string(argv[1]) == "genproof") { const int r = genproof_mode(argv[2], argv[3], argc == 5); xlp_shutdown(); return r; }
+    if ((argc == 4 || argc == 5) && std::string(argv[1]) == "genproof") { const int r = genproof_mode(argv[2], argv[3], argc == 5); XlpDeviceSlab::get().release(); xlp_shutdown(); return r; }
+    if ((argc == 6 || argc == 7) && std::string(argv[1]) == "bundle") {
+        const int r = bundle_mode(argv[2], argv[3], strtoull(argv[4], 0, 0), strtoull(argv[5], 0, 0), argc == 7);
+        xlp_shutdown();
+        return r;
+    }
     if (argc == 3 && std::string(argv[1]) == "starkinfo") return starkinfo_mode(argv[2]);
     if (argc == 6 && std::string(argv[1]) == "joinzkin") {      // joinzkin a.json b.json verkey.json steps  (host only)
         std::string t[3];

@@ -638,6 +638,10 @@ public:
     Step step2prev, step3prev, step3, step42ns, step52ns;
     std::vector<uint64_t> exps_n, q_2nsVector, cm4_nVector, cm4_2nsVector, tmpExp_n;
     std::vector<std::pair<std::string, uint64_t>> exp2pol;
+    // not in the reference's schema ("xlp" member, optional): the extended constants live inside the slab at this offset (one-GPU
+    // aliased layout, tools/zkevm_geometry.py) instead of in a buffer of their own
+    bool xlpConst2nsInSlab = false;
+    uint64_t xlpConst2nsOffset = 0;
 
     StarkInfo() {}                                   // synthetic runs fill starkStruct by hand
     explicit StarkInfo(const std::string& file)      // StarkInfo(config, file), stark_info.cpp:7-19
@@ -709,6 +713,10 @@ public:
         step("step2prev", step2prev); step("step3prev", step3prev); step("step3", step3); step("step42ns", step42ns); step("step52ns", step52ns);
         u64s("exps_n", exps_n); u64s("q_2ns", q_2nsVector); u64s("cm4_n", cm4_nVector); u64s("cm4_2ns", cm4_2nsVector); u64s("tmpExp_n", tmpExp_n);
         for (const auto& kv : j["exp2pol"].o) exp2pol.emplace_back(kv.first, (uint64_t)kv.second);
+        if (j.contains("xlp") && j["xlp"].contains("const2nsOffset") && !j["xlp"]["const2nsOffset"].is_null()) {
+            xlpConst2nsInSlab = true;
+            xlpConst2nsOffset = j["xlp"]["const2nsOffset"];
+        }
     }
     void getPol(void* pAddress, uint64_t idPol, PolInfo& polInfo)     // stark_info.cpp:456-464
     {
@@ -959,91 +967,3 @@ inline std::string joinzkin(const xlp_json::Value& zkin1, const xlp_json::Value&
     os << "}";
     return os.str();
 }
-
-// ------------------------------------------------------------------ constraint steps
-// GPU counterpart of `class ZkevmSteps : public Steps` (src/starkpil/zkevm/chelpers/zkevmSteps.hpp:10-59,
-// src/starkpil/steps.hpp:21-70).  The five parser programs are loaded from the files tools/chelpers_to_xlp.py
-// writes (one per step, converted from the generated *.parser.{cpp,hpp}); the method names and the
-// (params, nrows, nrowsBatch) signature are the reference's, with StepsParams replaced by its device-pointer
-// form xlp_steps_params (include/xlp_gl.h) because the sections stay resident in HBM between the stages.
-class XlpSteps
-{
-    // Per step: the program as converted, or -- when tools/optimize_programs.py left <step>.opt.xlpexpr / <step>.tab.xlpexpr next
-    // to it -- its dot-product form: a row program that reads powers of the challenges and evaluation constants from an
-    // extended challenge array, and a one-row table program that fills that array once per call (xlayer_prover_amd/expr_opt.py).
-    struct Step {
-        xlp_expr_program* prog = NULL;       // as converted, or the row program of the pair
-        xlp_expr_program* tab = NULL;        // table program (pair only)
-        uint64_t* ext = NULL;                // device, 3 * n_ext words: challenges 0..7, then the table
-        uint64_t n_ext = 0;
-    };
-    Step step_[5];
-    static const uint64_t NCH = 8;           // challenges of a proof (starks.cpp)
-    static bool exists(const std::string& path) { FILE* f = fopen(path.c_str(), "rb"); if (f) fclose(f); return f != NULL; }
-    static xlp_expr_program* load(const std::string& path, uint64_t magic, uint64_t* extra)
-    {
-        FILE* f = fopen(path.c_str(), "rb");
-        if (!f) xlp_exit_process(("XlpSteps: cannot open " + path).c_str());
-        uint64_t hdr[5];
-        const size_t nh = extra ? 5 : 4;
-        if (fread(hdr, 8, nh, f) != nh || hdr[0] != magic) { fclose(f); xlp_exit_process(("XlpSteps: bad header in " + path).c_str()); }
-        std::vector<uint64_t> code(hdr[3]);
-        if (hdr[3] && fread(code.data(), 8, hdr[3], f) != hdr[3]) { fclose(f); xlp_exit_process(("XlpSteps: short read on " + path).c_str()); }
-        fclose(f);
-        if (extra) *extra = hdr[4];
-        xlp_expr_program* p = NULL;
-        XLP_CHECK(xlp_expr_create(&p, code.data(), code.size(), hdr[1], hdr[2]));
-        return p;
-    }
-    void run(int k, const xlp_steps_params& params, uint64_t nrows)
-    {
-        Step& s = step_[k];
-        if (!s.tab) { XLP_CHECK(xlp_dev_expr_run(s.prog, &params, 0, nrows)); return; }
-        if (params.challenges_size < 3 * NCH) xlp_exit_process("XlpSteps: fewer than 8 challenges");
-        XLP_CHECK(xlp_dev_copy_cols(s.ext, 3, params.challenges, 3, NCH, 3));
-        xlp_steps_params t = {};
-        t.pols = s.ext; t.pols_size = 3 * s.n_ext;
-        t.challenges = params.challenges; t.challenges_size = params.challenges_size;
-        t.evals = params.evals; t.evals_size = params.evals_size;
-        XLP_CHECK(xlp_dev_expr_run(s.tab, &t, 0, 1));
-        xlp_steps_params r = params;
-        r.challenges = s.ext; r.challenges_size = 3 * s.n_ext;
-        XLP_CHECK(xlp_dev_expr_run(s.prog, &r, 0, nrows));
-    }
-
-public:
-    // dir/<name>.step2prev.xlpexpr ... dir/<name>.step52ns.xlpexpr  (+ optional .opt / .tab pairs)
-    XlpSteps(const std::string& dir, const std::string& name, bool use_optimised = true)
-    {
-        static const char* steps[5] = {"step2prev", "step3prev", "step3", "step42ns", "step52ns"};
-        for (int k = 0; k < 5; k++) {
-            const std::string base = dir + "/" + name + "." + steps[k];
-            if (use_optimised && exists(base + ".opt.xlpexpr") && exists(base + ".tab.xlpexpr")) {
-                step_[k].prog = load(base + ".opt.xlpexpr", 0x3152505845504c58ULL /* "XLPEXPR1" */, NULL);
-                step_[k].tab = load(base + ".tab.xlpexpr", 0x3130424154504c58ULL /* "XLPTAB01" */, &step_[k].n_ext);
-                void* d = NULL;
-                XLP_CHECK(xlp_dev_alloc(&d, 3 * step_[k].n_ext * sizeof(uint64_t)));
-                step_[k].ext = (uint64_t*)d;
-            } else {
-                step_[k].prog = load(base + ".xlpexpr", 0x3152505845504c58ULL, NULL);
-            }
-        }
-    }
-    ~XlpSteps()
-    {
-        for (int k = 0; k < 5; k++) {
-            xlp_expr_destroy(step_[k].prog);
-            if (step_[k].tab) xlp_expr_destroy(step_[k].tab);
-            if (step_[k].ext) xlp_dev_free(step_[k].ext);
-        }
-    }
-    bool optimised(int k) const { return step_[k].tab != NULL; }
-    XlpSteps(const XlpSteps&) = delete;
-    XlpSteps& operator=(const XlpSteps&) = delete;
-    // nrowsBatch is the reference's SIMD batch (4 / 8, starks.cpp:70-80); one row per lane here, so it is ignored
-    void step2prev_parser_first_avx(const xlp_steps_params& params, uint64_t nrows, uint64_t) { run(0, params, nrows); }
-    void step3prev_parser_first_avx(const xlp_steps_params& params, uint64_t nrows, uint64_t) { run(1, params, nrows); }
-    void step3_parser_first_avx(const xlp_steps_params& params, uint64_t nrows, uint64_t) { run(2, params, nrows); }
-    void step42ns_parser_first_avx(const xlp_steps_params& params, uint64_t nrows, uint64_t) { run(3, params, nrows); }
-    void step52ns_parser_first_avx(const xlp_steps_params& params, uint64_t nrows, uint64_t) { run(4, params, nrows); }
-};

@@ -1,0 +1,91 @@
+// zkProver in file mode for a batch proof (src/main.cpp:83-112 runFileGenBatchProof -> Prover::genBatchProof) on the GPU build:
+//     zkprover_batch -c config.json [--proofs K] [--seed S] [--sequential-upload] [--timers]
+// The executor and the two circom witness calculators are CPU subsystems outside this path and their inputs
+// (the 75 GB archive) are absent: they are replaced by stand-ins that leave a synthetic witness in host memory where the real
+// ones would -- the executor's from --seed, the calculators' from a hash of the zkin proof they are given, so that every STARK
+// depends on the previous one's proof as in prover.cpp:584-630.  Prints one JSON line per run and a summary.
+#include <cstdio>
+#include <cstring>
+#include "prover.hpp"
+
+static uint64_t fnv1a(const std::string& s)
+{
+    uint64_t h = 0xcbf29ce484222325ULL;
+    for (unsigned char c : s) { h ^= c; h *= 0x100000001b3ULL; }
+    return h;
+}
+// a synthetic committed-polynomial matrix, generated on the GPU (xlp_dev_fill) and left in host memory at cmPols
+static void syntheticWitness(Goldilocks::Element* cmPols, uint64_t degree, uint64_t nCols, uint64_t seed)
+{
+    const uint64_t total = degree * nCols, chunk = 1ULL << 28;
+    void* d = NULL;
+    XLP_CHECK(xlp_dev_alloc(&d, (total < chunk ? total : chunk) * 8));
+    for (uint64_t o = 0; o < total; o += chunk) {
+        const uint64_t n = total - o < chunk ? total - o : chunk;
+        XLP_CHECK(xlp_dev_fill((uint64_t*)d, n, seed, o));
+        XLP_CHECK(xlp_copy_d2h(cmPols + o, d, n * 8));
+    }
+    XLP_CHECK(xlp_dev_free(d));
+}
+
+int main(int argc, char** argv)
+{
+    std::string cfg;
+    int proofs = 2;
+    uint64_t seed = 0x5EED0401;
+    bool sequential = false, timers = false;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        if (a == "-c" && i + 1 < argc) cfg = argv[++i];
+        else if (a == "--proofs" && i + 1 < argc) proofs = atoi(argv[++i]);
+        else if (a == "--seed" && i + 1 < argc) seed = strtoull(argv[++i], NULL, 0);
+        else if (a == "--sequential-upload") sequential = true;
+        else if (a == "--timers") timers = true;
+        else { fprintf(stderr, "usage: %s -c config.json [--proofs K] [--seed S] [--sequential-upload] [--timers]\n", argv[0]); return 2; }
+    }
+    if (cfg.empty()) { fprintf(stderr, "missing -c config.json\n"); return 2; }
+    Config config;
+    config.load(cfg);
+    if (!config.runFileGenBatchProof) { fprintf(stderr, "config: runFileGenBatchProof is not set\n"); return 2; }
+    Goldilocks fr;
+    PoseidonGoldilocks poseidon;
+    {
+    const auto t0 = std::chrono::steady_clock::now();
+    Prover prover(fr, poseidon, config);
+    const double tSetup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    prover.starkZkevm->pipelineWitness = !sequential;
+    prover.starkZkevm->logTimers = prover.starksC12a->logTimers = prover.starksRecursive1->logTimers = timers;
+    fprintf(stderr, "setup %.2f s ; steps: zkevm", tSetup);
+    for (int k = 0; k < 5; k++) fprintf(stderr, " [%s]", prover.zkevmSteps->mode(k).c_str());
+    fprintf(stderr, "\n");
+    ProverRequest req;
+    req.filePrefix = config.outputPath + "/";
+    req.executor = [&](Goldilocks::Element* p, uint64_t n, uint64_t w) { syntheticWitness(p, n, w, seed); };
+    req.c12aWitness = [&](const std::string& zkin, Goldilocks::Element* p, uint64_t n, uint64_t w) { syntheticWitness(p, n, w, fnv1a(zkin)); };
+    req.recursive1Witness = req.c12aWitness;
+    for (int it = 0; it < proofs; it++) {
+        prover.genBatchProof(&req);
+        double starks = 0, exec = 0, total = 0, wit = 0;
+        std::ostringstream os;
+        os << "{\"run\":" << it << ",\"witness_upload\":\"" << (sequential ? "sequential" : "pipelined with step 1") << "\",\"timers_s\":{";
+        bool first = true;
+        for (const auto& kv : req.timers) {
+            os << (first ? "" : ",") << "\"" << kv.first << "\":" << kv.second; first = false;
+            if (kv.first == "STARK_PROOF_BATCH_PROOF" || kv.first == "STARK_C12_A_PROOF_BATCH_PROOF" || kv.first == "STARK_RECURSIVE_1_PROOF_BATCH_PROOF") starks += kv.second;
+            if (kv.first == "EXECUTOR_EXECUTE_BATCH_PROOF") exec = kv.second;
+            if (kv.first == "STARK_GEN_AND_CALC_WITNESS_C12A" || kv.first == "STARK_GEN_AND_CALC_WITNESS_RECURSIVE1") wit += kv.second;
+            if (kv.first == "PROVER_BATCH_PROOF") total = kv.second;
+        }
+        // req.timers is appended when a scope closes: PROVER_BATCH_PROOF is still open here -> take it from the parts
+        os << "},\"three_starks_s\":" << starks << ",\"executor_standin_s\":" << exec << ",\"witness_standins_s\":" << wit << ",\"zkevm_witness_upload_ms\":" << req.witnessUploadMs;
+        const std::string& z = req.batchProofOutput;
+        const size_t r1 = z.find("\"root1\":"), r1e = z.find("]", r1);
+        os << ",\"recursive1_root1\":" << z.substr(r1 + 8, r1e - r1 - 7) << ",\"batch_proof_bytes\":" << z.size() << ",\"batch_proof_fnv\":\"" << std::hex << fnv1a(z) << std::dec << "\"}";
+        (void)total;
+        printf("%s\n", os.str().c_str());
+        fflush(stdout);
+    }
+    }
+    xlp_shutdown();
+    return 0;
+}
