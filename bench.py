@@ -26,8 +26,6 @@ EXT_BITS = 1
 SEED = 0x5EED0002
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 LDE_KERNELS = ["xlp::lde_top_dif<11>", "xlp::lde_mid", "xlp::lde_top_dit<11>"]   # one launch of each per extendPol
-VALU_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1", "lde_valu.json")
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r1", "lde_traffic.json")          # PMC passes of tools/traffic_probe.py
 
 
 def cpu_baseline(log_n, ncols, budget_s=20.0):
@@ -57,39 +55,178 @@ def cpu_baseline(log_n, ncols, budget_s=20.0):
     }
 
 
-def genproof_leg(timeout_s=420):
-    """The other half of BASELINE.json's metric: wall-clock of the three STARKs of Prover::genBatchProof (prover.cpp:572-645:
-    zkEVM 2^23 rows, c12a 2^20, recursive1 2^17), each a whole Starks::genProof (starks.cpp:9-404, every stage, the reference's
-    converted step programs) GPU-resident on this one GPU, synthetic witnesses -- tools/bench_zkevm_genproof.py --batch run as a
-    child process (the zkEVM proof needs ~293 of the 309 GB).  Reported next to the headline value, never as it; any failure
-    is reported as such and does not touch the main line."""
+def counters():
+    """newest profiles/r*/counters.json (tools/collect_counters.py: rocprofv3 --pmc passes), with a staleness verdict: the file is
+    stamped with the hash of the kernel sources it was measured on"""
+    import glob
+    from xlayer_prover_amd.srchash import csrc_hash
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "counters.json")), key=lambda f: int(os.path.basename(os.path.dirname(f))[1:]))
+    if not files:
+        return None, True, None
+    c = json.load(open(files[-1]))
+    return c, c.get("csrc_sha256") != csrc_hash(), os.path.relpath(files[-1], ROOT)
+
+
+def merkle_leg(capi, torch, dev):
+    """The kernel that is the largest share of a proof: the leaf sponge of PoseidonGoldilocks::merkletree (linear_hash_kernel),
+    timed live with HIP events on the library's stream on 2^20 x 751 rows; the counter-derived figures come from
+    profiles/rN/counters.json measured on the same shape."""
+    h, w = 1 << 20, 751
+    rows = torch.empty(h * w, dtype=torch.int64, device=dev); nodes = torch.empty((2 * h - 1) * 4, dtype=torch.int64, device=dev)
+    capi.dev_fill(rows, 0x5EED0003, 0)
+    capi.dev_linear_hash(nodes, rows, w, h)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 3
+    e0.record()
+    for _ in range(reps):
+        capi.dev_linear_hash(nodes, rows, w, h)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    perms = h * ((w + 7) // 8)
+    alg = 8 * h * w + 32 * h
+    c, stale, src = counters()
+    out = {"kernel": "xlp::linear_hash_kernel (leaf sponge of merkletree, 2^20 x 751 rows)", "bound": "valu", "avg_launch_ms": round(ms, 4),
+           "permutations_per_s": round(perms / ms * 1e3, 0), "hbm": {"achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
+                                                                     "alg_bytes_per_launch": alg}}
+    if c and "merkle" in c:
+        m = c["merkle"]
+        rate = m["valu_wave_instructions_linear_hash"] / (ms * 1e-3)
+        out["valu_issue"] = {"achieved": round(rate / 1e9, 1), "peak": round(c["issue_peak_wave_instructions_per_s"] / 1e9, 1), "unit": "G wave-instr/s",
+                             "frac": round(rate / c["issue_peak_wave_instructions_per_s"], 3), "lane_instructions_per_permutation": round(m["valu_lane_instructions_per_permutation"], 0)}
+        out["hbm"]["traffic"] = m["hbm_bytes_linear_hash"]
+        out["counters"] = src; out["counters_stale"] = stale
+    del rows, nodes
+    return out
+
+
+def sharded_commit_leg(capi, torch, dist, dev, world, rank, log_n=23, ncols=751, check=True):
+    """SURVEY.md 8e / BASELINE north_star: ONE zkEVM-width section (2^23 x 751, the committed trace cm1) committed by all ranks
+    together -- rank g extends its ~751/G columns, one all-to-all over RCCL/xGMI turns column shards into row shards, each rank
+    hashes the sub-tree over its rows, a 32-byte-per-rank all-gather assembles the caps and every rank hashes the top log2 G
+    levels.  Strong scaling (the section is fixed).  Rank 0 then commits the same section alone and the roots must agree."""
+    import time
+    from xlayer_prover_amd import shard
+    n, n_ext, W = 1 << log_n, 2 << log_n, ncols
+    c0, c1 = shard.col_range(W, world, rank)
+    wc = c1 - c0
+    seed = 0x5EED0003
+    full = torch.empty(n * W, dtype=torch.int64, device=dev)
+    capi.dev_fill(full, seed, 0)                              # element (row, col) = fill(seed, row * W + col), the same on every rank
+    trace = full.view(n, W)[:, c0:c1].contiguous()
+    del full
+    torch.cuda.empty_cache()
+    t = [0.0, 0.0, 0.0, 0.0]
+
+    def once(record):
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ext = torch.empty((n_ext, wc), dtype=torch.int64, device=dev)
+        capi.dev_extend(ext.view(-1), trace.view(-1), n_ext, n, wc)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        rows = shard.columns_to_rows(ext, W)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        del ext
+        h = rows.shape[0]
+        nodes = torch.empty((2 * h - 1) * 4, dtype=torch.int64, device=dev)
+        capi.dev_merkle(nodes, rows.view(-1), W, h)
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        root, _ = shard.assemble_root(nodes[-4:].clone(), shard.gpu_hash_pairs)
+        torch.cuda.synchronize(); t4 = time.perf_counter()
+        if record:
+            for i, v in enumerate((t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                t[i] += v
+        return root
+    once(False)
+    reps = 2
+    for _ in range(reps):
+        root = once(True)
+    tt = torch.tensor([v / reps for v in t], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    lde, a2a, mk, caps = [float(x) for x in tt.tolist()]
+    ok = None
+    del trace
+    torch.cuda.empty_cache()
+    if check and rank == 0:
+        full = torch.empty(n * W, dtype=torch.int64, device=dev); capi.dev_fill(full, seed, 0)
+        ext = torch.empty(n_ext * W, dtype=torch.int64, device=dev); nodes = torch.empty((2 * n_ext - 1) * 4, dtype=torch.int64, device=dev)
+        capi.dev_commit(ext, nodes, full, n_ext, n, W)
+        torch.cuda.synchronize()
+        ok = bool((nodes[-4:] == root.to(dev)).all().item())
+        del full, ext, nodes
+        torch.cuda.empty_cache()
+    dist.barrier()
+    sent = 8 * n_ext * wc * (world - 1) / world
+    return {"workload": f"one section 2^{log_n} x {W} -> 2^{log_n + 1} x {W} + Merkle root, columns sharded over {world} ranks (strong scaling)",
+            "stage_s": {"lde": round(lde, 5), "all_to_all_and_unpack": round(a2a, 5), "merkle_subtree": round(mk, 5), "caps_all_gather_and_top": round(caps, 5)},
+            "commit_s": round(lde + a2a + mk + caps, 5), "bytes_sent_per_rank": int(sent),
+            "all_to_all_GBps_per_rank": round(sent / a2a / 1e9, 1) if a2a > 0 and world > 1 else None,
+            "root": [int(v) & 0xFFFFFFFFFFFFFFFF for v in root.tolist()], "root_equals_single_gpu_commit": ok}
+
+
+def genproof_leg(timeout_s=300):
+    """The other half of BASELINE.json's metric: wall-clock of Prover::genBatchProof's three STARKs (prover.cpp:572-645: zkEVM 2^23
+    rows, c12a 2^20, recursive1 2^17), each a whole Starks::genProof (starks.cpp:9-404, every stage, the reference's converted step
+    programs), through the C++ entry points with the reference's shape (host/prover.hpp, host/starks.hpp; binary
+    host/zkprover_batch), GPU-resident on this one GPU, the 50.4 GB zkEVM witness uploaded from page-locked host memory inside
+    the wall.  Run twice: witness upload pipelined with step 1 (the product path) and uploaded in one piece first (what the
+    pipeline hides).  Reported next to the headline value, never as it; a failure is reported as such."""
     import subprocess
-    import torch
-    free_b, total_b = torch.cuda.mem_get_info()
-    log_n = 23 if free_b > 296e9 else 22
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_zkevm_genproof.py"), "--batch", "--log-n", str(log_n)]
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+    exe = os.path.join(ROOT, "xlayer_prover_amd", "host", "zkprover_batch")
+    cfg = os.path.join(ROOT, "tools", "config_runFile_BatchProof_synthetic.json")
+    starks = ("STARK_PROOF_BATCH_PROOF", "STARK_C12_A_PROOF_BATCH_PROOF", "STARK_RECURSIVE_1_PROOF_BATCH_PROOF")
+
+    def run(*extra):
+        r = subprocess.run([exe, "-c", cfg, "--proofs", "2"] + list(extra), capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
         if r.returncode != 0:
-            return {"error": (r.stderr or r.stdout)[-300:]}
-        b = json.loads(r.stdout.strip().splitlines()[-1])
-        j = b["proofs"]["STARK_PROOF_BATCH_PROOF"]
-    except Exception as e:                                   # missing converted programs, timeout, ...
+            raise RuntimeError((r.stderr or r.stdout)[-300:])
+        return json.loads(r.stdout.strip().splitlines()[-1]), r.stderr
+    try:
+        pip, log = run()
+        seq, _ = run("--sequential-upload")
+    except Exception as e:                                   # missing bundles / binary, timeout, ...
         return {"error": repr(e)[:300]}
-    t = j["timers_s"]
-    grp = lambda key: round(sum(v for k, v in t.items() if key(k)), 4)
-    return {
-        "metric": "genBatchProof STARK wall-clock (s): the three genProof calls of Prover::genBatchProof, one GPU",
-        "wall_s": b["genbatchproof_starks_wall_s"], "per_stark_s": b["wall_s"],
-        "zkevm": {"log_n": log_n, "wall_s": j["genproof_wall_s"], "sum_timed_s": j["sum_timed_s"],
-                  "stages_s": {"merkle": grp(lambda k: "MERKLETREE" in k), "lde": grp(lambda k: k.endswith("_LDE")),
+    t = pip["timers_s"]
+    z = {k[len("zkevm."):]: v for k, v in t.items() if k.startswith("zkevm.")}
+    grp = lambda key: round(sum(v for k, v in z.items() if key(k)), 4)
+    up = seq["timers_s"]["zkevm.STARK_STEP_1_WITNESS_UPLOAD"]
+    modes = [m.strip("[] ") for m in log.split("steps: zkevm", 1)[1].splitlines()[0].split("] [")] if "steps: zkevm" in log else None
+    out = {
+        "metric": "genBatchProof STARK wall-clock (s): the three genProof calls of Prover::genBatchProof (C++: host/zkprover_batch), one GPU, "
+                  "zkEVM witness (50.4 GB) uploaded from page-locked host memory inside the wall",
+        "wall_s": round(pip["three_starks_s"], 4), "per_stark_s": {k: round(t[k], 4) for k in starks},
+        "wall_sequential_upload_s": round(seq["three_starks_s"], 4), "wall_without_upload_s": round(seq["three_starks_s"] - up, 4),
+        "witness_upload": {"GB": 50.4, "one_piece_s": round(up, 4), "copy_stream_busy_s_when_pipelined": round(pip["zkevm_witness_upload_ms"] / 1e3, 4),
+                           "exposed_s_when_pipelined": round(pip["three_starks_s"] - (seq["three_starks_s"] - up), 4)},
+        "same_proof_both_ways": pip["batch_proof_fnv"] == seq["batch_proof_fnv"],
+        "zkevm": {"log_n": 23, "wall_s": round(t["STARK_PROOF_BATCH_PROOF"], 4),
+                  "stages_s": {"step1_upload_lde_merkle": grp(lambda k: "STEP_1" in k), "lde_merkle_2_3": grp(lambda k: k in ("STARK_STEP_2_LDE_AND_MERKLETREE", "STARK_STEP_3_LDE_AND_MERKLETREE")),
+                               "const_lde": grp(lambda k: "CONST_LDE" in k), "merkle_4": grp(lambda k: k == "STARK_STEP_4_MERKLETREE"),
                                "step_programs": grp(lambda k: "CALCULATE_EXPS" in k and "INTT" not in k),
-                               "h1h2_z": grp(lambda k: "H1H2" in k or k.endswith("_Z")),
-                               "evmap_lev_xdiv": grp(lambda k: "STEP_5" in k and "EXPS" not in k),
+                               "h1h2_z": grp(lambda k: "H1H2" in k or k.endswith("_Z")), "evmap_lev_xdiv": grp(lambda k: "STEP_5" in k and "EXPS" not in k),
                                "q_intt_ntt": grp(lambda k: "INTT" in k), "fri_and_openings": grp(lambda k: k.endswith("_FRI"))},
-                  "peak_GB": j.get("peak_GB_torch"), "layout": j.get("layout"), "programs": j["programs"], "workload": j["workload"]},
-        "note": "synthetic witnesses; executor and circom witness computation between the STARKs are CPU work outside the hot path",
+                  "timers_s": {k: round(v, 4) for k, v in z.items()}, "programs": modes, "layout": "one-GPU aliased slab (239 GB)"},
+        "note": "synthetic witnesses and constants (the archive is absent); the executor and the circom witness calculators between the STARKs are "
+                "CPU work outside the hot path, replaced by stand-ins outside the timed STARKs",
     }
+    # roofline of the step-program leg: algorithmic bytes = every column / table word a program names, once, per row
+    try:
+        from tools import zkevm_geometry as G
+        progs, _ = G.load(23, True, "zkevm")
+        names = {"step2prev": "STARK_STEP_2_CALCULATE_EXPS", "step3prev": "STARK_STEP_3_CALCULATE_EXPS", "step3": "STARK_STEP_3_CALCULATE_EXPS_2",
+                 "step42ns": "STARK_STEP_4_CALCULATE_EXPS_2NS", "step52ns": "STARK_STEP_5_CALCULATE_EXPS"}
+        per, tot_b, tot_t = {}, 0, 0.0
+        for st, (code, _, _) in progs.items():
+            rd, wr = G.program_io_words(code)
+            rows = 1 << (24 if st.endswith("2ns") else 23)
+            b = (rd + wr) * 8 * rows
+            per[st] = {"words_read_per_row": rd, "words_written_per_row": wr, "alg_GB": round(b / 1e9, 1), "s": round(z[names[st]], 4), "GBs": round(b / z[names[st]] / 1e9, 1)}
+            tot_b += b; tot_t += z[names[st]]
+        out["roofline_steps"] = {"bound": "hbm", "achieved": round(tot_b / tot_t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(tot_b / tot_t / 1e9 / HBM_PEAK_GBS, 4),
+                                 "alg_bytes": tot_b, "seconds": round(tot_t, 4), "per_program": per,
+                                 "note": "algorithmic bytes: each column / table word a program reads or writes, once per row (temporaries are not traffic); measured inside the C++ genProof"}
+    except Exception as e:
+        out["roofline_steps"] = {"error": repr(e)[:200]}
+    return out
 
 
 def main():
@@ -99,6 +236,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-genproof", action="store_true", help="skip the whole-genProof leg (N=1 only; ~25 s)")
+    ap.add_argument("--sharded-commit", type=int, default=-1, help="time the section commit sharded over the ranks (default: on for --gpus > 1; 1 forces it at N=1 "
+                    "through RCCL in a world of one)")
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--ncols", type=int, default=NCOLS)
     args = ap.parse_args()
@@ -117,21 +256,20 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        import datetime
+        dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(seconds=600))
 
     capi.init(local_rank)
-    capi.use_torch_stream()
 
     n, ncols = 1 << args.log_n, args.ncols
     n_ext = n << EXT_BITS
     src = torch.empty(n * ncols, dtype=torch.int64, device=dev)
     out = torch.empty(n_ext * ncols, dtype=torch.int64, device=dev)
-    scratch = torch.empty(2 * n * ncols, dtype=torch.int64, device=dev)
     # rank r owns columns [8r, 8r+8) of the synthetic trace: element index = row*(8*world) + col
     capi.dev_fill(src, SEED, rank * n * ncols)
 
     def step():
-        capi.dev_extend(out, src, n_ext, n, ncols, scratch)
+        capi.dev_extend(out, src, n_ext, n, ncols)
 
     for _ in range(args.warmup):
         step()
@@ -165,6 +303,18 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    sharded = None
+    if (world > 1 and args.sharded_commit != 0) or args.sharded_commit == 1:
+        if world == 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29641")
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+        del src, out
+        torch.cuda.empty_cache()
+        try:
+            sharded = sharded_commit_leg(capi, torch, dist, dev, world, rank, log_n=args.log_n, ncols=751 if args.log_n == LOG_N else 64)
+        except Exception as e:                               # reported, never fatal for the headline line
+            sharded = {"error": repr(e)[:300]}
+        src = out = None
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         fe_per_step = n_ext * ncols * world
@@ -177,19 +327,20 @@ def main():
         per_kernel_ms = [x / kern_cnt for x in kern_ms_sum] if kern_cnt else [None] * 3
         lde_kernel_ms = sum(per_kernel_ms) if kern_cnt else dev_ms / args.steps
         achieved = alg_bytes_lde / (lde_kernel_ms * 1e-3) / 1e9
-        traffic = None
-        if os.path.exists(TRAFFIC_FILE) and args.log_n == LOG_N and ncols == NCOLS:
-            traffic = json.load(open(TRAFFIC_FILE))["hbm_bytes_per_lde"]
-        # the resource that actually binds: VALU issue slots (measured instruction count of one LDE / measured kernel time)
-        valu_issue = None
-        if os.path.exists(VALU_FILE) and args.log_n == LOG_N and ncols == NCOLS:
-            vj = json.load(open(VALU_FILE))
-            rate = vj["valu_wave_instructions_per_lde"] / (lde_kernel_ms * 1e-3)
-            valu_issue = {"achieved": round(rate / 1e9, 1), "peak": round(vj["issue_peak_wave_instructions_per_s"] / 1e9, 1), "unit": "G wave-instr/s",
-                          "frac": round(rate / vj["issue_peak_wave_instructions_per_s"], 3)}
+        # counter-derived figures: HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE) and VALU instructions of one LDE, from the newest
+        # profiles/rN/counters.json; stale = measured on other kernel sources than the ones in the tree
+        traffic, valu_issue, traffic_stale, counters_file = None, None, None, None
+        cj, stale, counters_file = counters()
+        if cj and args.log_n == LOG_N and ncols == NCOLS:
+            traffic = cj["lde"]["hbm_bytes_per_lde"]
+            traffic_stale = stale
+            rate = cj["lde"]["valu_wave_instructions_per_lde"] / (lde_kernel_ms * 1e-3)
+            valu_issue = {"achieved": round(rate / 1e9, 1), "peak": round(cj["issue_peak_wave_instructions_per_s"] / 1e9, 1), "unit": "G wave-instr/s",
+                          "frac": round(rate / cj["issue_peak_wave_instructions_per_s"], 3)}
         roofline = {
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_stale": traffic_stale, "counters": counters_file,
+            "achieved_from": "sum of the three kernels' average launch durations over 3 event-instrumented steps (the timed region's ms_per_step is the unbracketed figure)",
             "kernel": "xlp::lde_mid (dominant) + lde_top_dif + lde_top_dit = one extendPol",
             "launches_per_step": 3,
             "avg_launch_ms": {k: round(v, 4) for k, v in zip(LDE_KERNELS, per_kernel_ms)} if kern_cnt else None,
@@ -207,9 +358,14 @@ def main():
                        "columns_total": ncols * world, "sharding": "independent columns per rank, no collective"},
             "roofline": roofline,
         }
+        if sharded is not None:
+            line["sharded_commit"] = sharded
+        if world == 1:
+            line["roofline_merkle"] = merkle_leg(capi, torch, dev)
         if world == 1 and not args.no_genproof and args.log_n == LOG_N:
-            del src, out, scratch
+            del src, out
             torch.cuda.empty_cache()
+            capi.shutdown()                                   # the child needs ~300 of the 309 GB: give the library's scratch back too
             line["genproof"] = genproof_leg()
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.log_n, ncols)
@@ -217,8 +373,9 @@ def main():
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
 
-    if world > 1:
-        dist.barrier()
+    if dist.is_initialized():
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 

@@ -15,7 +15,15 @@
  *     the C++ shim (xlayer_prover_amd/host/) converts non-zero into that;
  *   - the caller owns every buffer; nothing is retained past return except
  *     caches owned by the process-wide context (twiddle tables, scratch);
- *   - there is NO CPU fallback: without a usable HIP device every call fails.
+ *   - there is NO CPU fallback: without a usable HIP device every call fails;
+ *   - threading: ONE thread at a time per process.  The library keeps one process-wide context (stream, twiddle-table cache,
+ *     grow-only scratch slots) that the entry points mutate without a lock -- like the reference, where one proverThread
+ *     issues every library call (src/prover/prover.cpp:182-255).  Only xlp_init / xlp_shutdown are serialised;
+ *   - xlp_dev_* calls enqueue on the context's stream and return without waiting for the GPU, EXCEPT: a call whose scratch
+ *     slot or table has to be created or grown (hipMalloc, and a stream synchronise when an old slot is freed: first call of a
+ *     shape), xlp_dev_calculate_h1h2 (reads its error flag back), xlp_dev_evmap / xlp_dev_dot_columns (upload their entry
+ *     tables), xlp_dev_expr_run with a plugin (none needed) or a first-time staging plan, xlp_dev_merkle_proofs and every
+ *     xlp_copy_* (synchronous by definition).
  *
  * Two layers:
  *   xlp_*      host pointers  (drop-in for today's call sites: the data lives
@@ -91,7 +99,10 @@ int xlp_calculate_h1h2(uint64_t* h1, uint64_t* h2, const uint64_t* f, const uint
 /* Same semantics as above; pointers are device memory on the bound device;
  * calls enqueue on the context stream and return without synchronising. */
 int xlp_dev_ntt(uint64_t* dst, const uint64_t* src, uint64_t n, uint64_t ncols, int inverse);
-/* scratch: device buffer of >= 2*n*ncols elements, or NULL to use the context's. */
+/* scratch: accepted for signature parity with extendPol's `buffer` (starks.cpp:53,134,215 pass a dead section).  The three-kernel
+ * path (2^17 <= n <= 2^23, blow-up <= 8, ncols >= 4: every production call) ignores it and keeps a context-owned scratch of
+ * (1 + n_ext / n) * n * min(ncols, 64) words -- 12.9 GB at n = 2^23, blow-up 2 -- alive between calls; the generic path uses
+ * `scratch` when given (>= 2 * n * ncols words) and the context's otherwise. */
 int xlp_dev_extend(uint64_t* out, const uint64_t* in, uint64_t n_ext, uint64_t n, uint64_t ncols, uint64_t* scratch);
 int xlp_dev_merkle(uint64_t* nodes, const uint64_t* src, uint64_t w, uint64_t h);
 int xlp_dev_perm_batch(uint64_t* out, const uint64_t* in, uint64_t count);
@@ -105,8 +116,8 @@ int xlp_dev_merkle_proofs(uint64_t* out, const uint64_t* src, const uint64_t* no
 /* Synthetic trace: dst[i] = splitmix64(seed ^ (start + i)) mod p. */
 int xlp_dev_fill(uint64_t* dst, uint64_t n, uint64_t seed, uint64_t start);
 
-/* Synthetic plookup selector for runs on a synthetic witness (benchmarks / tests): dst[i][0..dim) = src row (splitmix64(seed ^ i) mod n),
- * src of row stride src_stride, dst dense -- an f polynomial all of whose values occur in the table. */
+/* Synthetic plookup selector for runs on a synthetic witness (benchmarks / tests): dst[i][0..dim) = src row (splitmix64(seed ^ (i >> 4)) mod n),
+ * src of row stride src_stride, dst dense -- an f polynomial all of whose values occur in the table (runs of 16 rows pick the same row). */
 int xlp_dev_gather_rows(uint64_t* dst, const uint64_t* src, uint64_t src_stride, uint64_t n, uint32_t dim, uint64_t seed);
 
 /* ---- row-scale helpers between the commit stages, device pointers ------------ */

@@ -138,3 +138,39 @@ def test_zkevm_genproof_2p23_checked(xlp):
     assert c["evals_checked"] >= 8 and c["transcript_replayed"]
     assert c["merkle_paths"] == 128 * 5 + 128 * 4 and c["fri_folds"] == 128 * 4 and c["fri_first_tree_vs_f"] == 128
     assert "compiled" in out["programs"]["step42ns"] and "dot_columns" in out["programs"]["step52ns"]
+
+
+def test_cpp_starks_2p23_equals_checked_python_flow(xlp):
+    """the C++ Starks::genProof (host/starks.hpp, reference-shaped entry point; witness in page-locked host memory, upload pipelined with
+    step 1) at the fork-9 zkEVM geometry, N = 2^23, from the bundle build() writes: its zkin proof has the roots, FRI roots and
+    final polynomial of the Python orchestration that test_zkevm_genproof_2p23_checked checks against the oracle stage by stage,
+    and its openings verify against those roots on the oracle"""
+    import torch
+    from xlayer_prover_amd import programs as R
+    from tests.zkin_verify import verify_zkin, ints
+    from oracle import gl_oracle as orc
+    bundle = os.path.join(R.REF_DIR, "bundles", "zkevm.geo23a")
+    if not os.path.exists(os.path.join(bundle, "zkevm.steps.json")):
+        pytest.skip("zkEVM bundle not built (needs the reference tree at build time)")
+    _, total = torch.cuda.mem_get_info()
+    if total < 300e9:
+        pytest.skip("needs the 288 GB of an MI355X")
+    exp = _checked_run(xlp, ["--circuit", "zkevm", "--log-n", "23", "--windows", "3"], 1100)
+    torch.cuda.empty_cache()
+    xlp.shutdown()
+    try:
+        exe = os.path.join(ROOT, "xlayer_prover_amd", "host", "test_host_shim")
+        r = subprocess.run([exe, "bundle", bundle, "zkevm", str(0x5EED0401), str(0x5EED0402)], capture_output=True, text=True, timeout=900)
+    finally:
+        xlp.init(0)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stderr.count("compiled") >= 4 and "dot_columns" in r.stderr
+    Z = json.loads(r.stdout)
+    assert [ints(Z[k]) for k in ("root1", "root2", "root3", "root4")] == exp["roots"]
+    fr = exp["fri_roots_and_head_of_final_pol"]
+    steps = [24, 19, 14, 10, 6]
+    for k in range(1, len(steps)):
+        assert ints(Z[f"s{k}_root"]) == fr[k - 1]
+    assert [x for e in Z["finalPol"] for x in ints(e)][:6] == fr[-1]
+    rep = verify_zkin(orc, Z, 23, 24, steps, 128, {"1": 751, "2": 168, "3": 408, "4": 6, "C": 234})
+    assert rep["folds"] == 128 * 4 and rep["paths"] == 128 * 9

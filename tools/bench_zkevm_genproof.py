@@ -208,7 +208,7 @@ def prove(a, circ, ln, hooks=None):
     ev_index = torch.tensor([3 * k + j for k in ev_ids for j in range(3)], device=dev)
     # plookup inputs: the table t of lookup k is the tmpExp_n polynomial tools/zkevm_geometry.py lookup_picks() names (the missing
     # starkinfo would say which), f a selection of rows of t (xlp_dev_gather_rows: on a synthetic witness "f in t" has to be made)
-    lk_picks, z_picks = G.lookup_picks(circ)
+    lk_picks, z_picks = G.lookup_picks(circ, progs, L)
     if a.lookups >= 0:
         lk_picks = lk_picks[:a.lookups]
     if a.zs >= 0:
@@ -331,9 +331,9 @@ def prove(a, circ, ln, hooks=None):
         tmpx = sec("tmpExp_n").view(N, W["tmpExp_n"]); cm3 = sec("cm3_n").view(N, W["cm3_n"])
 
         def zs():
-            for k, c in enumerate(z_picks):
+            for k, (cn, cd) in enumerate(z_picks):
                 wt, w3 = W["tmpExp_n"], W["cm3_n"]             # transposeZColumns / transposeZRows (starks.cpp:472-555)
-                capi.dev_copy_cols(num, 3, sec("tmpExp_n")[c:], wt, N, 3); capi.dev_copy_cols(den, 3, sec("tmpExp_n")[c + 3:], wt, N, 3)
+                capi.dev_copy_cols(num, 3, sec("tmpExp_n")[cn:], wt, N, 3); capi.dev_copy_cols(den, 3, sec("tmpExp_n")[cd:], wt, N, 3)
                 capi.dev_calculate_z(z, num, den, N)
                 capi.dev_copy_cols(sec("cm3_n")[3 * k:], w3, z, 3, N, 3)
         timed("STARK_STEP_3_CALCULATE_Z", zs)

@@ -195,14 +195,34 @@ def load_fri_dots(log_n, aliased=False, circ="zkevm"):
 # step52ns, nConstants, nPublics, qDeg), what only the PIL would tell is chosen here and shared by every driver
 # (tools/bench_zkevm_genproof.py, host/starks.hpp through the bundle): which tmpExp_n columns are the plookup tables and the
 # grand-product numerators / denominators.
-def lookup_picks(circ):
-    """-> (lookups, zs): lookup k reads its table t from tmpExp_n columns [c, c+3) (f is a synthetic selection of t, see
-    xlp_dev_gather_rows) and writes h1 / h2 to cm2_n columns [6k, 6k+3) / [6k+3, 6k+6); grand product k reads num / den from
-    tmpExp_n columns [c, c+3) / [c+3, c+6) and writes z to cm3_n columns [3k, 3k+3); c = 6k mod (W_tmpExp - 6)"""
+def _tmpexp_dests(code, L):
+    """sorted first columns of the dimension-3 tmpExp_n polynomials a base-domain program writes"""
+    o, w, rows = L["tmpExp_n"]
+    dst = set()
+    ops = list(R.operands(code))
+    for i in range(0, len(ops), 3):
+        _, _, kind, dim, q = ops[i]
+        if kind == E.K_POLS and dim == 3 and o <= int(code[q]) < o + w * rows and int(code[q + 1]) == w:
+            dst.add(int(code[q]) - o)
+    return sorted(dst)
+
+
+def lookup_picks(circ, progs=None, L=None):
+    """-> (lookups, zs).  Lookup k reads its table t from the tmpExp_n polynomial (3 columns from) lookups[k] -- one of the
+    extension-field expressions step2prev computes, as a real plookup's compressed table is -- and writes h1 / h2 to cm2_n columns
+    [6k, 6k+3) / [6k+3, 6k+6); f is a synthetic selection of rows of t (xlp_dev_gather_rows: on a synthetic witness "f in t" has
+    to be made).  Grand product k reads num / den from the tmpExp_n polynomials zs[k] = (num column, den column), two of the
+    expressions step3prev computes, and writes z to cm3_n columns [3k, 3k+3)."""
     C = CIRCUITS[circ]
-    wt = C["widths"][4]
-    pick = lambda k: (6 * k) % max(wt - 6, 1)
-    return [pick(k) for k in range(C["lookups"])], [pick(k) for k in range(C["zs"])]
+    if progs is None:
+        progs, _ = load(C["log_n"] if circ != "zkevm" else 14, circ == "zkevm", circ)
+        L = layout(C["log_n"] if circ != "zkevm" else 14, circ == "zkevm", circ)
+    d2 = _tmpexp_dests(progs["step2prev"][0], L) if "step2prev" in progs else []
+    d3 = _tmpexp_dests(progs["step3prev"][0], L)
+    assert len(d3) >= 2 and (d2 or not C["lookups"])
+    lookups = [d2[(2 * k + 1) % len(d2)] for k in range(C["lookups"])]
+    zs = [(d3[(2 * k) % (len(d3) & ~1)], d3[(2 * k + 1) % (len(d3) & ~1)]) for k in range(C["zs"])]
+    return lookups, zs
 
 
 def evmap_of(code52, L, secs, nconst):
@@ -249,7 +269,7 @@ def synth_starkinfo(circ, log_n, aliased=False, fri_steps=None, queries=None):
     lne = log_n + ext
     if fri_steps is None:
         fri_steps = C["fri"] if C["fri"] and log_n == C["log_n"] else [lne] + [b for b in (lne - 5, lne - 10, lne - 14, lne - 18) if b >= 3]
-    lookups, zs = lookup_picks(circ)
+    lookups, zs = lookup_picks(circ, progs, L)
     evm = evmap_of(progs["step52ns"][0], L, secs, nconst)
     # ---- polynomials: base sections first (cm_n order = commit order), then their extended twins, then the tmpExp operands
     var, cm_n = [], []
@@ -302,8 +322,8 @@ def synth_starkinfo(circ, log_n, aliased=False, fri_steps=None, queries=None):
         t = tmp_pol(c)
         pu.append({"tExpId": t, "fExpId": t, "h1Id": cm_n[counts["cm1_n"] + 2 * k], "h2Id": cm_n[counts["cm1_n"] + 2 * k + 1], "zId": 0, "c1Id": 0, "numId": 0, "denId": 0, "c2Id": 0})
     z0 = counts["cm1_n"] + counts["cm2_n"]
-    for k, c in enumerate(zs):
-        num, den = tmp_pol(c), tmp_pol(c + 3)
+    for k, (cn, cd) in enumerate(zs):
+        num, den = tmp_pol(cn), tmp_pol(cd)
         ctx = {"zId": cm_n[z0 + k], "numId": num, "denId": den, "c1Id": 0, "c2Id": 0}
         if k < len(pu):
             pu[k].update(ctx)
@@ -331,3 +351,25 @@ def synth_starkinfo(circ, log_n, aliased=False, fri_steps=None, queries=None):
          # the lookups of this STARK run on a synthetic witness (f is then selected from t, see xlp_dev_gather_rows)
          "xlp": {"aliased": bool(aliased), "const2nsOffset": L["const_2ns"][0] if aliased else None, "circuit": circ, "steps": list(C["steps"])}}
     return j
+
+
+def program_io_words(code):
+    """(distinct words read per row, distinct words written per row) of a step program: every column / table word it names once --
+    the algorithmic HBM traffic of one evaluation (temporaries, challenges and constants of the program itself are not traffic)"""
+    rd, wr = set(), set()
+    ops = list(R.operands(code))
+    for i in range(0, len(ops), 3):
+        for s, (_, _, kind, dim, q) in enumerate(ops[i:i + 3]):
+            prm = [int(v) for v in code[q:q + E.KIND_PARAMS[kind]]]
+            if kind in (E.K_POLS, E.K_POLS_PRIME):
+                keys = [("p", prm[0] + c, kind == E.K_POLS_PRIME) for c in range(dim)]
+            elif kind in (E.K_CONST, E.K_CONST_PRIME, E.K_CONST2NS, E.K_CONST2NS_PRIME):
+                keys = [("c", kind, prm[0])]
+            elif kind in (E.K_X_N, E.K_X_2NS, E.K_ZI):
+                keys = [("x", kind)]
+            elif kind in (E.K_XDIVXSUBXI, E.K_XDIVXSUBWXI, E.K_Q_2NS, E.K_F_2NS):
+                keys = [("e", kind, c) for c in range(3)]
+            else:
+                continue
+            (wr if s == 0 else rd).update(keys)
+    return len(rd), len(wr)

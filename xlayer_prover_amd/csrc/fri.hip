@@ -133,16 +133,17 @@ __global__ void fill_kernel(u64* dst, u64 n, u64 seed, u64 start)
     for (; i < n; i += stride) dst[i] = gl::canon(splitmix64(seed ^ (start + i)));
 }
 
-// Synthetic plookup selector (benchmarks on a synthetic witness only): dst[i][0..dim) = src[(splitmix64(seed ^ i) mod n)][0..dim),
+// Synthetic plookup selector (benchmarks on a synthetic witness only): dst[i][0..dim) = src[(splitmix64(seed ^ (i >> 4)) mod n)][0..dim),
 // i.e. an `f` polynomial whose every value occurs in the table `src` -- what a satisfying witness guarantees and a random one
-// does not (Polinomial::calculateH1H2 exits on "Number not included", polinomial.hpp:413-414).
+// does not (Polinomial::calculateH1H2 exits on "Number not included", polinomial.hpp:413-414).  Runs of 16 rows select the same
+// table row: multiplicities are skewed as in real lookups, and the selector costs 1/16 of a row-by-row random gather.
 __global__ void gather_rows_kernel(u64* dst, const u64* src, u64 src_stride, u64 n, u32 dim, u64 seed)
 {
     const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n * dim) return;
     const u64 i = t / dim;
     const u32 c = (u32)(t % dim);
-    dst[t] = src[(splitmix64(seed ^ i) % n) * src_stride + c];
+    dst[t] = src[(splitmix64(seed ^ (i >> 4)) % n) * src_stride + c];
 }
 int dev_gather_rows(Ctx* ctx, u64* dst, const u64* src, u64 src_stride, u64 n, u32 dim, u64 seed)
 {

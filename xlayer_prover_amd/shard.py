@@ -32,20 +32,44 @@ def row_range(h, world, rank):
     return rank * per, (rank + 1) * per
 
 
+def _band_copy(dst, dst_col, src, src_col, rows, width):
+    """dst[:, dst_col : dst_col + width] = src[:, src_col : src_col + width] for 2-D row-major tensors: one strided-copy kernel of the
+    library on the GPU (xlp_dev_copy_cols), a slice assignment on the CPU (gloo tests)"""
+    if width == 0 or rows == 0:
+        return
+    if dst.is_cuda:
+        from . import capi
+        capi.dev_copy_cols(dst.view(-1)[dst_col:], dst.shape[1], src.view(-1)[src_col:], src.shape[1], rows, width)
+    else:
+        dst[:, dst_col:dst_col + width] = src[:, src_col:src_col + width]
+
+
 def columns_to_rows(local, ncols, group=None):
     """local: [h, wc_local] (this rank's columns of all rows) -> [h / G, ncols] (all columns of this
-    rank's rows).  One all-to-all; direct peer exchange, every xGMI link busy (no ring)."""
+    rank's rows).  ONE all_to_all_single -- the rows destined to peer p are already contiguous in `local`, so the send side is
+    the tensor itself; direct peer exchange, every xGMI link busy (no ring) -- and one band copy per peer that drops the
+    received [h / G, wc_p] block into its columns of the row-major result (the layout the leaf sponge and the step programs read)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     h, wc = local.shape
-    assert (wc,) == (col_range(ncols, world, rank)[1] - col_range(ncols, world, rank)[0],)
+    spans = [col_range(ncols, world, p) for p in range(world)]
+    assert wc == spans[rank][1] - spans[rank][0]
     per = h // world
-    # send to peer p: rows row_range(p) of my columns
-    send = [local[p * per:(p + 1) * per].contiguous() for p in range(world)]
-    recv = [torch.empty((per, col_range(ncols, world, p)[1] - col_range(ncols, world, p)[0]), dtype=local.dtype, device=local.device)
-            for p in range(world)]
-    dist.all_to_all(recv, send, group=group) if dist.get_backend(group) != "gloo" else _all_to_all_gloo(recv, send, group)
-    return torch.cat(recv, dim=1).contiguous()
+    if dist.get_backend(group) == "gloo":                     # tests: gloo has no all_to_all on CPU tensors
+        send = [local[p * per:(p + 1) * per].contiguous() for p in range(world)]
+        recv = [torch.empty((per, c1 - c0), dtype=local.dtype, device=local.device) for c0, c1 in spans]
+        _all_to_all_gloo(recv, send, group)
+    else:
+        stage = torch.empty(per * ncols, dtype=local.dtype, device=local.device)
+        dist.all_to_all_single(stage, local.contiguous().view(-1), output_split_sizes=[per * (c1 - c0) for c0, c1 in spans],
+                               input_split_sizes=[per * wc] * world, group=group)
+        recv, o = [], 0
+        for c0, c1 in spans:
+            recv.append(stage[o:o + per * (c1 - c0)].view(per, c1 - c0)); o += per * (c1 - c0)
+    out = torch.empty((per, ncols), dtype=local.dtype, device=local.device)
+    for (c0, c1), blk in zip(spans, recv):
+        _band_copy(out, c0, blk, 0, per, c1 - c0)
+    return out
 
 
 def _all_to_all_gloo(recv, send, group):
@@ -102,16 +126,29 @@ def _sendrecv(send, dst, src, group=None):
 
 def rows_to_columns(local, nrows, group=None):
     """inverse of columns_to_rows.  local: [h / G, ncols] (all columns of this rank's rows) -> [h, wc_local] (this rank's
-    columns of all rows): the layout the per-column LDE wants.  One all-to-all."""
+    columns of all rows): the layout the per-column LDE wants.  One band copy per peer packs its columns, ONE
+    all_to_all_single delivers straight into the result (the block of peer p IS rows row_range(p) of the result)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     per, ncols = local.shape
     assert per * world == nrows
-    c0, c1 = col_range(ncols, world, rank)
-    send = [local[:, col_range(ncols, world, p)[0]:col_range(ncols, world, p)[1]].contiguous() for p in range(world)]
-    recv = [torch.empty((per, c1 - c0), dtype=local.dtype, device=local.device) for _ in range(world)]
-    dist.all_to_all(recv, send, group=group) if dist.get_backend(group) != "gloo" else _all_to_all_gloo(recv, send, group)
-    return torch.cat(recv, dim=0).contiguous()
+    spans = [col_range(ncols, world, p) for p in range(world)]
+    c0, c1 = spans[rank]
+    out = torch.empty((nrows, c1 - c0), dtype=local.dtype, device=local.device)
+    if dist.get_backend(group) == "gloo":
+        send = [local[:, a:b].contiguous() for a, b in spans]
+        recv = [out[p * per:(p + 1) * per] for p in range(world)]
+        tmp = [torch.empty((per, c1 - c0), dtype=local.dtype, device=local.device) for _ in range(world)]
+        _all_to_all_gloo(tmp, send, group)
+        for r, t in zip(recv, tmp):
+            r.copy_(t)
+        return out
+    stage = torch.empty(per * ncols, dtype=local.dtype, device=local.device)
+    o = 0
+    for a, b in spans:
+        _band_copy(stage[o:o + per * (b - a)].view(per, b - a), 0, local, a, per, b - a); o += per * (b - a)
+    dist.all_to_all_single(out.view(-1), stage, output_split_sizes=[per * (c1 - c0)] * world, input_split_sizes=[per * (b - a) for a, b in spans], group=group)
+    return out
 
 
 def cap_tree(sub_root, hash_pairs, group=None):
