@@ -241,6 +241,10 @@ def main():
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--ncols", type=int, default=NCOLS)
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON: everything else that writes to fd 1 (RCCL prints a version banner there when its
+    # first communicator is created) goes to stderr
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -371,7 +375,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.log_n, ncols)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
+        json_out.write(json.dumps(line) + "\n"); json_out.flush()
 
     if dist.is_initialized():
         if world > 1:

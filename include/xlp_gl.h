@@ -95,6 +95,19 @@ int xlp_batch_inverse(uint64_t* res, const uint64_t* src, uint64_t n, uint32_t d
 int xlp_calculate_z(uint64_t* z, const uint64_t* num, const uint64_t* den, uint64_t n);
 int xlp_calculate_h1h2(uint64_t* h1, uint64_t* h2, const uint64_t* f, const uint64_t* t, uint64_t n, uint32_t dim);
 
+/* Device copies of host buffers for the host-pointer API above (off by default; max_bytes = 0 turns it off and frees the
+ * copies).  The drop-in call sites name the same slab sections in consecutive calls -- extendPol WRITES p_cm1_2ns, merkelize
+ * READS it (starks.cpp:53-56) -- and staging each call separately would move the 100.8 GB extended section over PCIe three
+ * times.  With the cache on, the device buffer a call produced or uploaded stays registered under its host address range
+ * (least-recently-used eviction beyond max_bytes); a later call that reads exactly that range uses the device copy, a call
+ * that writes into a range drops every copy overlapping it.  Contract: between two xlp_* calls the host does not modify a
+ * range it handed to the library, or tells it so with xlp_cache_invalidate(ptr, bytes) (ptr NULL: everything).
+ * xlp_extend / xlp_merkle on large inputs are pipelines either way: column bands (row chunks) cross PCIe on their own
+ * streams while the previous band is extended (hashed); page-lock the slab (xlp_host_register) for the full PCIe rate. */
+int xlp_cache_enable(size_t max_bytes);
+int xlp_cache_invalidate(const void* host_ptr, size_t bytes);
+size_t xlp_cache_bytes(void);
+
 /* ---- device-pointer API -------------------------------------------------- */
 /* Same semantics as above; pointers are device memory on the bound device;
  * calls enqueue on the context stream and return without synchronising. */

@@ -48,6 +48,7 @@ def prove_sharded(B, nbits, fri_steps, nqueries, seed=1, group=None, collectives
     collectives=True takes the exchange paths even in a world of one rank (GPU test of the RCCL plumbing on one GPU)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    shard.FORCE_EXCHANGE = bool(collectives)
     WL = WindowLayout(nbits, world)
     N, NE, n, ne = WL.N, WL.NE, WL.n, WL.ne
     assert ne % HALO_E == 0 and n >= HALO_N and (world & (world - 1)) == 0

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_python_binding_covers_header():
     from xlayer_prover_amd import capi
-    bound = set(capi.SIGNATURES) | set(capi.VOID_SIGNATURES) | set(capi.STR_SIGNATURES)
+    bound = set(capi.SIGNATURES) | set(capi.VOID_SIGNATURES) | set(capi.STR_SIGNATURES) | set(capi.SIZE_SIGNATURES)
     assert set(header_symbols()) == bound
 
 

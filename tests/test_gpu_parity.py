@@ -678,3 +678,39 @@ def test_band_pipelined_commit_2p22_x_751_equals_plain_commit(xlp, orc):
     gbs = n * w * 8 / ms / 1e6
     assert gbs > 20.0, f"upload ran at {gbs:.1f} GB/s"
     host.close()
+
+
+# ---------------------------------------------------------------- host-pointer drop-in: pipelined + device-copy cache
+@pytest.mark.parametrize("lg,ext,w", [(12, 1, 70), (17, 1, 130), (16, 2, 200)])
+def test_host_pointer_extend_then_merkle_with_cache(xlp, orc, lg, ext, w):
+    """the reference's call pair on HOST pointers -- ntt.extendPol(cm_2ns, cm_n, ...) then merkelize(cm_2ns) (starks.cpp:53-56) --
+    through xlp_extend / xlp_merkle: banded three-stream pipeline, and with the cache on the second call finds the extended
+    section on the device.  Results equal the oracle's with the cache off, on, after an invalidation, and after the host
+    changed the section and said so."""
+    n, n_ext = 1 << lg, 1 << (lg + ext)
+    src = edge_matrix(orc, n, w, 0x5EED00C1 + lg)
+    exp_ext = orc.extend_pol(src, n_ext, n, w)
+    exp_nodes = orc.merkletree(exp_ext, w, n_ext)
+    for cache in (0, 1 << 34):
+        xlp.cache_enable(cache)
+        got = xlp.extend(src, n_ext, n, w)
+        assert (got == exp_ext).all()
+        held = xlp.cache_bytes()
+        assert (held > 0) == bool(cache)
+        nodes = xlp.merkle(got, w, n_ext)                       # same host array object -> same address range
+        assert (nodes == exp_nodes).all()
+        if cache:
+            assert xlp.cache_bytes() >= got.nbytes
+            # the host modifies the section and tells the library: the stale device copy must not be used
+            got[5, 3] ^= np.uint64(1)
+            xlp.cache_invalidate(got)
+            exp2 = orc.merkletree(got, w, n_ext)
+            assert (xlp.merkle(got, w, n_ext) == exp2).all()
+            # an extend INTO a cached range drops the old copy of it
+            got2 = got                                          # reuse the buffer as the output of another extension
+            src2 = orc.fill(n * w, 0x5EED00C2).reshape(n, w)
+            out = xlp.extend_into(got2, src2, n_ext, n, w)
+            assert (out == orc.extend_pol(src2, n_ext, n, w)).all()
+            assert (xlp.merkle(out, w, n_ext) == orc.merkletree(out, w, n_ext)).all()
+    xlp.cache_enable(0)
+    assert xlp.cache_bytes() == 0

@@ -1,3 +1,5 @@
+// MEASUREMENT VARIANT (not built into the product): xlayer_prover_amd/csrc/ntt_lde.hip as of round 1 with its ablation switches
+// (tools/ablate.sh).  Kept so that profiles/r1/ablation_lde_kernels.txt stays reproducible.
 // Fast path of NTT_Goldilocks::extendPol (starks.cpp:53,134,215) for
 // 2^17 <= N <= 2^23: three kernels per column chunk, 72 bytes of HBM traffic
 // per input element (the generic pass engine in ntt.hip needs 96+).
@@ -24,10 +26,39 @@
 #include "ntt_common.hpp"
 #include "ntt_lde_common.hpp"
 
-template <int BIT> __device__ __forceinline__ gl::u64 gld(const gl::u64* q) { return *q; }
-template <int BIT> __device__ __forceinline__ void gst(gl::u64* q, gl::u64 v) { *q = v; }
+#ifndef XLP_ABL
+#define XLP_ABL 0
+#endif
+// Cache policy experiments (tools/ablate.sh 10xx): bit0 input loads, bit1 A stores, bit2 A loads, bit3 B stores,
+// bit4 B loads, bit5 output stores are issued non-temporal.
+#ifndef XLP_NT
+#define XLP_NT 0
+#endif
+template <int BIT> __device__ __forceinline__ gl::u64 gld(const gl::u64* q)
+{
+    if constexpr ((XLP_NT >> BIT) & 1) return __builtin_nontemporal_load(q);
+    else return *q;
+}
+template <int BIT> __device__ __forceinline__ void gst(gl::u64* q, gl::u64 v)
+{
+    if constexpr ((XLP_NT >> BIT) & 1) __builtin_nontemporal_store(v, q);
+    else *q = v;
+}
+#define XLP_NOLOAD (XLP_ABL == 2 || XLP_ABL == 3 || XLP_ABL == 4 || XLP_ABL == 5 || XLP_ABL == 9)
+#define XLP_NOSTORE (XLP_ABL == 2 || XLP_ABL == 3 || XLP_ABL == 4 || XLP_ABL == 5 || XLP_ABL == 8)
+#if 0   // ablation builds (tools/ablate.sh): 1 no twiddle loads, 2 +no global data traffic, 3 +no DFT, 4 +no twiddle muls
+#endif
+#if XLP_ABL == 4
+#define XLP_TWMUL(a, b) ((a) ^ (b))
+#else
 #define XLP_TWMUL(a, b) gl::mulc((a), (b))
+#endif
+
+#if XLP_ABL == 5
+#define XLP_SYNC() ((void)0)
+#else
 #define XLP_SYNC() __syncthreads()
+#endif
 
 namespace xlp {
 
@@ -62,7 +93,11 @@ __device__ __forceinline__ void fast_round(const u64* __restrict__ tw, Load load
         } else if constexpr (TP > 0) {
 #pragma unroll
             for (int j = 1; j < RAD; j++) {
+#if XLP_ABL >= 1 && XLP_ABL != 6 && XLP_ABL != 7
+                twr[j] = 0x123456789ULL + j * low;   // ablation: no twiddle loads
+#else
                 twr[j] = tw[((u32)j * low) << TSHIFT];
+#endif
             }
         }
         u64 x[RAD];
@@ -82,7 +117,9 @@ __device__ __forceinline__ void fast_round(const u64* __restrict__ tw, Load load
 #pragma unroll
             for (int j = 1; j < RAD; j++) x[j] = XLP_TWMUL(x[j], twr[j]);
         }
+#if XLP_ABL != 3
         dft_regs<D>(x);
+#endif
         u64 y[RAD];
 #pragma unroll
         for (int k = 0; k < RAD; k++) y[k] = x[brev<D>(INV ? (RAD - k) % RAD : k)];
@@ -154,13 +191,29 @@ __global__ __launch_bounds__(XLP_WGT) void lde_top_dif(const LdeParams p)
     auto gload = [&](u32 tpos, u32 v, u32) -> u64 {
         const u32 col = c + v < p.wc ? c + v : p.wc - 1;
         const u64 row = ((u64)tpos << 12) | lo;
+#if XLP_NOLOAD
+        return row * 0x9E3779B97F4A7C15ULL + col;
+#else
         return gl::canon(gld<0>(&p.in[row * p.ld_in + p.col0 + col]));
+#endif
     };
+    #if XLP_ABL == 5
+    auto lload = [&](u32 tp_, u32 v, u32 lrow) -> u64 { return (u64)lrow * 0x9E3779B97F4A7C15ULL + v + tp_; };
+#else
     auto lload = [&](u32, u32 v, u32 lrow) -> u64 { return sm[lrow * V + v]; };
+#endif
+    #if XLP_ABL == 5
+    auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { if (val == 0x1234567ULL) sm[lrow * V + v] = val; };
+#else
     auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { sm[lrow * V + v] = val; };
+#endif
     auto gstore = [&](u32 tpos, u32 v, u64 val, u32) {
         const u64 row = ((u64)tpos << 12) | lo;
+#if XLP_NOSTORE
+        if (val == 0x1234567ULL) p.A[row * p.wc + c + v] = val;
+#else
         if (c + v < p.wc) gst<1>(&p.A[row * p.wc + c + v], val);
+#endif
     };
     auto crossf = [&](u32 tpos) -> u64 { return cross[tile_natural_c<BT>(tpos)]; };
     if constexpr (m == 2) {
@@ -197,8 +250,16 @@ __global__ __launch_bounds__(XLP_WGT) void lde_mid(const LdeParams p, u32 BT)
         const u64 row = ((u64)hi << 12) | tpos;
         return gld<2>(&p.A[row * p.wc + col]);
     };
+    #if XLP_ABL == 5
+    auto lload = [&](u32 tp_, u32 v, u32 lrow) -> u64 { return (u64)lrow * 0x9E3779B97F4A7C15ULL + v + tp_; };
+#else
     auto lload = [&](u32, u32 v, u32 lrow) -> u64 { return sm[lrow * V + v]; };
+#endif
+    #if XLP_ABL == 5
+    auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { if (val == 0x1234567ULL) sm[lrow * V + v] = val; };
+#else
     auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { sm[lrow * V + v] = val; };
+#endif
     // ---- inverse NTT over the low 12 bits (DIF); last round keeps its outputs in VGPRs
     fast_round<B, V, 8, 4, false, true>(p.twi_12, gload, lstore);
     XLP_SYNC();
@@ -313,14 +374,30 @@ __global__ __launch_bounds__(XLP_WGT) void lde_top_dit(const LdeParams p)
     auto gload = [&](u32 tpos, u32 v, u32) -> u64 {
         const u32 col = c + v < p.wc ? c + v : p.wc - 1;
         const u64 row = ((u64)tpos << 12) | lo;
+#if XLP_NOLOAD
+        return row * 0x9E3779B97F4A7C15ULL + col;
+#else
         return gld<4>(&Br[row * p.wc + col]);
+#endif
     };
     auto crossf = [&](u32 tpos) -> u64 { return cross[tile_natural_c<BT>(tpos)]; };
+    #if XLP_ABL == 5
+    auto lload = [&](u32 tp_, u32 v, u32 lrow) -> u64 { return (u64)lrow * 0x9E3779B97F4A7C15ULL + v + tp_; };
+#else
     auto lload = [&](u32, u32 v, u32 lrow) -> u64 { return sm[lrow * V + v]; };
+#endif
+    #if XLP_ABL == 5
+    auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { if (val == 0x1234567ULL) sm[lrow * V + v] = val; };
+#else
     auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { sm[lrow * V + v] = val; };
+#endif
     auto gstore = [&](u32 tpos, u32 v, u64 val, u32) {
         const u64 row = (((((u64)tpos << 12) | lo)) << p.e) | r;
+#if XLP_NOSTORE
+        if (val == 0x1234567ULL) p.out[row * p.ld_out + p.col0 + c + v] = val;
+#else
         if (c + v < p.wc) gst<5>(&p.out[row * p.ld_out + p.col0 + c + v], val);
+#endif
     };
     if constexpr (m == 2) {
         fast_round<BT, V, 0, 4, true, false, true, false>(p.twf_bt, gload, lstore, crossf, NoFactor{});

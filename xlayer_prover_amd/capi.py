@@ -64,6 +64,8 @@ SIGNATURES = {
     "xlp_dev_merkle_levels": [_pu, _u64],
     "xlp_dev_commit": [_pu, _pu, _pu, _u64, _u64, _u64],
     "xlp_dev_commit_from_host": [_pu, _pu, _pu, _pu, _u64, _u64, _u64, C.POINTER(C.c_double)],
+    "xlp_cache_enable": [C.c_size_t],
+    "xlp_cache_invalidate": [_pu, C.c_size_t],
     "xlp_host_alloc": [C.POINTER(C.c_void_p), C.c_size_t],
     "xlp_host_free": [_pu],
     "xlp_host_register": [_pu, C.c_size_t],
@@ -75,6 +77,7 @@ SIGNATURES = {
     "xlp_copy_d2h": [_pu, _pu, C.c_size_t],
 }
 VOID_SIGNATURES = {"xlp_shutdown": [], }
+SIZE_SIGNATURES = {"xlp_cache_bytes": []}
 STR_SIGNATURES = {"xlp_last_error": []}
 
 
@@ -113,6 +116,10 @@ def load():
         f = getattr(lib, name)
         f.argtypes = args
         f.restype = None
+    for name, args in SIZE_SIGNATURES.items():
+        f = getattr(lib, name)
+        f.argtypes = args
+        f.restype = C.c_size_t
     lib.xlp_last_error.argtypes = []
     lib.xlp_last_error.restype = C.c_char_p
     _LIB = lib
@@ -142,6 +149,22 @@ def init(device=0, bind_torch_stream=True):
 
 def sync():
     _ck(load().xlp_sync(), "xlp_sync")
+
+
+def cache_enable(max_bytes):
+    """device copies of host buffers for the host-pointer API (xlp_cache_enable); 0 turns it off"""
+    _ck(load().xlp_cache_enable(max_bytes), "xlp_cache_enable")
+
+
+def cache_invalidate(arr=None):
+    if arr is None:
+        _ck(load().xlp_cache_invalidate(None, 0), "xlp_cache_invalidate")
+    else:
+        _ck(load().xlp_cache_invalidate(arr.ctypes.data_as(C.c_void_p), arr.nbytes), "xlp_cache_invalidate")
+
+
+def cache_bytes():
+    return load().xlp_cache_bytes()
 
 
 def shutdown():
@@ -199,6 +222,14 @@ def extend(src, n_ext, n, ncols):
     src = _np(src).reshape(-1)
     assert src.size == n * ncols
     out = np.empty(n_ext * ncols, np.uint64)
+    _ck(load().xlp_extend(_p(out), _p(src), n_ext, n, ncols, None), "xlp_extend")
+    return out.reshape(n_ext, ncols)
+
+
+def extend_into(out, src, n_ext, n, ncols):
+    """xlp_extend into an existing host array (its address range is what the device-copy cache keys on)"""
+    src = _np(src).reshape(-1)
+    assert src.size == n * ncols and out.dtype == np.uint64 and out.size == n_ext * ncols and out.flags["C_CONTIGUOUS"]
     _ck(load().xlp_extend(_p(out), _p(src), n_ext, n, ncols, None), "xlp_extend")
     return out.reshape(n_ext, ncols)
 

@@ -46,20 +46,9 @@ __device__ __forceinline__ void dft_rec(u64 (&x)[1 << D])
         dft_rec<D, T + 1>(x);
     }
 }
-// Hand-scheduled assembly forms of the radix-8 / radix-16 networks (tools/gen_dft_asm.py):
-// same contract, ~half the issue slots (no s_nop padding of the carry chains).
-#ifndef XLP_ASM_DFT
-#define XLP_ASM_DFT 0   // measured: no gain (int carry ops are half-rate regardless of s_nop padding)
-#endif
-#include "dft_asm.inc"
-
 template <int D>
 __device__ __forceinline__ void dft_regs(u64 (&x)[1 << D])
 {
-#if XLP_ASM_DFT
-    if constexpr (D == 4) { dft16_asm(x); return; }
-    else if constexpr (D == 3) { dft8_asm(x); return; }
-#endif
     dft_rec<D, 0>(x);
 }
 

@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <mutex>
+#include <algorithm>
 #include <string>
 #include <vector>
 #include <stdlib.h>
@@ -66,6 +67,68 @@ struct DevBuf {
     }
     u64* u() { return (u64*)p; }
 };
+
+// ---- device copies of host buffers (see xlp_cache_enable below)
+struct CacheEnt { const char* host; size_t bytes; void* dev; uint64_t tick; };
+std::vector<CacheEnt> g_cache;
+size_t g_cache_cap = 0, g_cache_used = 0;
+uint64_t g_cache_tick = 0;
+
+void cache_drop(size_t i)
+{
+    (void)hipFree(g_cache[i].dev);
+    g_cache_used -= g_cache[i].bytes;
+    g_cache.erase(g_cache.begin() + i);
+}
+void cache_drop_overlapping(const void* host, size_t bytes)
+{
+    const char* a = (const char*)host;
+    for (size_t i = g_cache.size(); i-- > 0;)
+        if (a < g_cache[i].host + g_cache[i].bytes && g_cache[i].host < a + bytes) cache_drop(i);
+}
+void* cache_find(const void* host, size_t bytes)
+{
+    for (CacheEnt& e : g_cache)
+        if (e.host == (const char*)host && e.bytes == bytes) { e.tick = ++g_cache_tick; return e.dev; }
+    return nullptr;
+}
+// takes ownership of dev (frees it when the cache is off or too small for it)
+void cache_put(const void* host, size_t bytes, void* dev)
+{
+    cache_drop_overlapping(host, bytes);
+    if (bytes > g_cache_cap) { (void)hipFree(dev); return; }
+    while (g_cache_used + bytes > g_cache_cap && !g_cache.empty()) {
+        size_t lru = 0;
+        for (size_t i = 1; i < g_cache.size(); i++) if (g_cache[i].tick < g_cache[lru].tick) lru = i;
+        cache_drop(lru);
+    }
+    g_cache.push_back({(const char*)host, bytes, dev, ++g_cache_tick});
+    g_cache_used += bytes;
+}
+// a device buffer for the host range: the cached copy, or a fresh allocation (uploaded unless `upload` is false)
+int cache_get(const void* host, size_t bytes, bool upload, void** dev, bool* was_cached)
+{
+    *dev = cache_find(host, bytes);
+    *was_cached = *dev != nullptr;
+    if (*dev) return 0;
+    XLP_HIP(hipMalloc(dev, bytes ? bytes : 8));
+    if (upload && bytes) {
+        XLP_HIP(hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, g_ctx.stream));
+    }
+    return 0;
+}
+// detach the cached copy of exactly this range (the caller becomes the owner), if any
+void* cache_take(const void* host, size_t bytes)
+{
+    for (size_t i = 0; i < g_cache.size(); i++)
+        if (g_cache[i].host == (const char*)host && g_cache[i].bytes == bytes) {
+            void* d = g_cache[i].dev;
+            g_cache_used -= bytes;
+            g_cache.erase(g_cache.begin() + i);
+            return d;
+        }
+    return nullptr;
+}
 
 }  // namespace xlp
 
@@ -133,6 +196,9 @@ void xlp_shutdown(void)
     }
     if (g_ctx.own_stream) (void)hipStreamDestroy(g_ctx.stream);
     if (g_ctx.copy_stream) { (void)hipStreamSynchronize(g_ctx.copy_stream); (void)hipStreamDestroy(g_ctx.copy_stream); g_ctx.copy_stream = nullptr; }
+    if (g_ctx.down_stream) { (void)hipStreamSynchronize(g_ctx.down_stream); (void)hipStreamDestroy(g_ctx.down_stream); g_ctx.down_stream = nullptr; }
+    while (!g_cache.empty()) cache_drop(0);
+    g_cache_cap = 0;
     g_ctx.stream = nullptr;
     g_ctx.own_stream = false;
     g_ctx.inited = false;
@@ -459,17 +525,88 @@ int xlp_ntt(uint64_t* dst, const uint64_t* src, uint64_t n, uint64_t ncols, int 
     return 0;
 }
 
+// ---- device copies of host buffers (opt-in: xlp_cache_enable) -------------------------------------------------------------
+// The drop-in call sites hand over HOST pointers into the prover's slab, and consecutive calls name the same sections:
+// extendPol writes p_cm1_2ns, the next call (merkelize) reads it (starks.cpp:53-56).  Staging every call separately moves the
+// 100.8 GB extended section over PCIe twice more than needed.  With the cache enabled the device buffer a call produced (or
+// uploaded) stays registered under its host address range; a later call that READS exactly that range takes the device copy,
+// a call that WRITES into a range drops every copy overlapping it.  The caller's side of the contract: between two xlp_* calls
+// the host does not modify a range it passed to the library -- or calls xlp_cache_invalidate(ptr) if it did.
+
+int xlp_cache_enable(size_t max_bytes)
+{
+    if (ensure_init()) return -1;
+    XLP_HIP(hipStreamSynchronize(g_ctx.stream));
+    g_cache_cap = max_bytes;
+    while (g_cache_used > g_cache_cap && !g_cache.empty()) cache_drop(0);
+    return 0;
+}
+int xlp_cache_invalidate(const void* host_ptr, size_t bytes)
+{
+    if (!g_ctx.inited) return 0;
+    XLP_HIP(hipStreamSynchronize(g_ctx.stream));
+    if (!host_ptr) { while (!g_cache.empty()) cache_drop(0); return 0; }
+    cache_drop_overlapping(host_ptr, bytes ? bytes : 1);
+    return 0;
+}
+size_t xlp_cache_bytes(void) { return g_cache_used; }
+
+// extendPol on host buffers, as a three-stream pipeline over 64-column bands: band b+1 is uploaded (copy stream) while band b is
+// extended (compute stream) and band b-1 of the result goes back to the host (download stream; PCIe is full duplex).
 int xlp_extend(uint64_t* out, const uint64_t* in, uint64_t n_ext, uint64_t n, uint64_t ncols, uint64_t* scratch)
 {
     (void)scratch;
     if (ensure_init()) return -1;
     if (n == 0 || ncols == 0) return 0;
     if (!out || !in) return xlp_fail("xlp_extend: null pointer");
-    DevBuf a, b;
-    if (a.alloc(n * ncols * sizeof(u64)) || b.alloc(n_ext * ncols * sizeof(u64))) return -1;
-    H2D(a, in, n * ncols * sizeof(u64));
-    if (dev_extend(&g_ctx, b.u(), a.u(), n_ext, n, ncols, nullptr)) return -1;
-    D2H(out, b, n_ext * ncols * sizeof(u64));
+    if ((n & (n - 1)) || (n_ext & (n_ext - 1)) || n_ext < n) return xlp_fail("extendPol: sizes must be powers of two, n_ext >= n");
+    Ctx* ctx = &g_ctx;
+    const size_t in_bytes = n * ncols * sizeof(u64), out_bytes = n_ext * ncols * sizeof(u64);
+    void* d_in = cache_take(in, in_bytes);
+    const bool in_cached = d_in != nullptr;
+    cache_drop_overlapping(out, out_bytes);
+    void* d_out = nullptr;
+    if (!d_in) XLP_HIP(hipMalloc(&d_in, in_bytes));
+    if (hipMalloc(&d_out, out_bytes) != hipSuccess) { (void)hipFree(d_in); return xlp_fail("xlp_extend: out of device memory"); }
+    const u64 band = 64;
+    int rc = 0;
+    if (ncols <= band || n_ext * ncols < (1ull << 22)) {       // small: no pipeline
+        if (!in_cached) rc = hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess ? 0 : xlp_fail("xlp_extend: upload failed");
+        if (!rc) rc = dev_extend(ctx, (u64*)d_out, (const u64*)d_in, n_ext, n, ncols, nullptr);
+        if (!rc) rc = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess ? 0 : xlp_fail("xlp_extend: download failed");
+        if (!rc) rc = hipStreamSynchronize(ctx->stream) == hipSuccess ? 0 : xlp_fail("xlp_extend: synchronise failed");
+    } else {
+        if (!ctx->copy_stream) XLP_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        if (!ctx->down_stream) XLP_HIP(hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
+        XLP_HIP(hipStreamSynchronize(ctx->stream));
+        const u64 nb = (ncols + band - 1) / band;
+        std::vector<hipEvent_t> up(nb, nullptr), done(nb, nullptr);
+        for (u64 b = 0; b < nb && !rc; b++) {
+            const u64 c0 = b * band, wc = ncols - c0 < band ? ncols - c0 : band;
+            if (!in_cached) {
+                if (hipMemcpy2DAsync((u64*)d_in + c0, ncols * 8, in + c0, ncols * 8, wc * 8, n, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess) rc = xlp_fail("xlp_extend: upload failed");
+                (void)hipEventCreateWithFlags(&up[b], hipEventDisableTiming);
+                (void)hipEventRecord(up[b], ctx->copy_stream);
+            }
+        }
+        for (u64 b = 0; b < nb && !rc; b++) {
+            const u64 c0 = b * band, wc = ncols - c0 < band ? ncols - c0 : band;
+            if (up[b]) (void)hipStreamWaitEvent(ctx->stream, up[b], 0);
+            rc = dev_extend_cols(ctx, (u64*)d_out, (const u64*)d_in, n_ext, n, ncols, c0, wc);
+            (void)hipEventCreateWithFlags(&done[b], hipEventDisableTiming);
+            (void)hipEventRecord(done[b], ctx->stream);
+            (void)hipStreamWaitEvent(ctx->down_stream, done[b], 0);
+            if (!rc && hipMemcpy2DAsync(out + c0, ncols * 8, (u64*)d_out + c0, ncols * 8, wc * 8, n_ext, hipMemcpyDeviceToHost, ctx->down_stream) != hipSuccess) rc = xlp_fail("xlp_extend: download failed");
+        }
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (hipStreamSynchronize(ctx->down_stream) != hipSuccess && !rc) rc = xlp_fail("xlp_extend: download failed");
+        for (hipEvent_t e : up) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
+    }
+    if (rc) { (void)hipFree(d_in); (void)hipFree(d_out); return rc; }
+    cache_put(in, in_bytes, d_in);                             // (frees them when the cache is off)
+    cache_put(out, out_bytes, d_out);
     return 0;
 }
 
@@ -479,12 +616,50 @@ int xlp_merkle(uint64_t* nodes, const uint64_t* src, uint64_t w, uint64_t h)
     if (h == 0) return 0;
     if (!nodes || (w && !src)) return xlp_fail("xlp_merkle: null pointer");
     if (h & (h - 1)) return xlp_fail("merkletree: number of rows is not a power of two");
-    DevBuf a, b;
-    if (a.alloc(w * h * sizeof(u64)) || b.alloc((2 * h - 1) * 4 * sizeof(u64))) return -1;
-    H2D(a, src, w * h * sizeof(u64));
-    if (dev_merkle(&g_ctx, b.u(), a.u(), w, h)) return -1;
-    D2H(nodes, b, (2 * h - 1) * 4 * sizeof(u64));
-    return 0;
+    Ctx* ctx = &g_ctx;
+    const size_t src_bytes = w * h * sizeof(u64), node_bytes = (2 * h - 1) * 4 * sizeof(u64);
+    void* d_src = w ? cache_take(src, src_bytes) : nullptr;
+    const bool cached = d_src != nullptr;
+    cache_drop_overlapping(nodes, node_bytes);
+    DevBuf b;
+    if (b.alloc(node_bytes)) { if (d_src) cache_put(src, src_bytes, d_src); return -1; }
+    int rc = 0;
+    if (!cached && w) {
+        XLP_HIP(hipMalloc(&d_src, src_bytes));
+        // rows are hashed independently: upload row chunks on the copy stream while the previous chunk is hashed
+        const u64 chunk_rows = w > 4 && src_bytes > (256ull << 20) ? std::max<u64>(1, (128ull << 20) / (w * 8)) : h;
+        if (chunk_rows >= h) {
+            if (hipMemcpyAsync(d_src, src, src_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = xlp_fail("xlp_merkle: upload failed");
+            if (!rc) rc = dev_linear_hash(ctx, b.u(), (const u64*)d_src, w, h);
+        } else {
+            if (!ctx->copy_stream) XLP_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+            XLP_HIP(hipStreamSynchronize(ctx->stream));
+            std::vector<hipEvent_t> ev;
+            for (u64 r0 = 0; r0 < h && !rc; r0 += chunk_rows) {
+                const u64 nr = h - r0 < chunk_rows ? h - r0 : chunk_rows;
+                if (hipMemcpyAsync((u64*)d_src + r0 * w, src + r0 * w, nr * w * 8, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess) rc = xlp_fail("xlp_merkle: upload failed");
+                hipEvent_t e;
+                (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+                (void)hipEventRecord(e, ctx->copy_stream);
+                ev.push_back(e);
+            }
+            u64 k = 0;
+            for (u64 r0 = 0; r0 < h && !rc; r0 += chunk_rows, k++) {
+                const u64 nr = h - r0 < chunk_rows ? h - r0 : chunk_rows;
+                (void)hipStreamWaitEvent(ctx->stream, ev[k], 0);
+                rc = dev_linear_hash(ctx, b.u() + 4 * r0, (const u64*)d_src + r0 * w, w, nr);
+            }
+            (void)hipStreamSynchronize(ctx->copy_stream);
+            for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        }
+    } else {
+        rc = dev_linear_hash(ctx, b.u(), (const u64*)d_src, w, h);
+    }
+    if (!rc) rc = dev_merkle_levels(ctx, b.u(), h);
+    if (!rc && hipMemcpyAsync(nodes, b.p, node_bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = xlp_fail("xlp_merkle: download failed");
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = xlp_fail("xlp_merkle: synchronise failed");
+    if (d_src) { if (rc) (void)hipFree(d_src); else cache_put(src, src_bytes, d_src); }
+    return rc;
 }
 
 int xlp_perm_batch(uint64_t* out, const uint64_t* in, uint64_t count)

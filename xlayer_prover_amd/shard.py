@@ -19,6 +19,9 @@ import torch
 import torch.distributed as dist
 
 
+FORCE_EXCHANGE = False      # tests: take the all_to_all_single path even in a world of one rank (RCCL plumbing on one GPU)
+
+
 def col_range(ncols, world, rank):
     """contiguous, balanced column shard of rank (first ncols % world ranks get one extra)"""
     base, rem = divmod(ncols, world)
@@ -54,6 +57,8 @@ def columns_to_rows(local, ncols, group=None):
     h, wc = local.shape
     spans = [col_range(ncols, world, p) for p in range(world)]
     assert wc == spans[rank][1] - spans[rank][0]
+    if world == 1 and not FORCE_EXCHANGE:
+        return local                                          # one rank owns every column of every row already
     per = h // world
     if dist.get_backend(group) == "gloo":                     # tests: gloo has no all_to_all on CPU tensors
         send = [local[p * per:(p + 1) * per].contiguous() for p in range(world)]
@@ -132,6 +137,8 @@ def rows_to_columns(local, nrows, group=None):
     rank = dist.get_rank(group)
     per, ncols = local.shape
     assert per * world == nrows
+    if world == 1 and not FORCE_EXCHANGE:
+        return local
     spans = [col_range(ncols, world, p) for p in range(world)]
     c0, c1 = spans[rank]
     out = torch.empty((nrows, c1 - c0), dtype=local.dtype, device=local.device)
