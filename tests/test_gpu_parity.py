@@ -156,6 +156,22 @@ def test_extend_fast_path_vs_oracle(xlp, orc, lg, ext, ncols):
     assert (xlp.extend(src, n_ext, n, ncols) == orc.extend_pol(src, n_ext, n, ncols)).all()
 
 
+@pytest.mark.parametrize("lg,ext,ncols", [(22, 1, 13), (22, 2, 8), (23, 1, 9)])
+@pytest.mark.parametrize("mask", [0, 7])
+def test_extend_2p22_2p23_vs_oracle(xlp, orc, lg, ext, ncols, mask):
+    """N >= 2^22 against the oracle: full 8-column tiles, ragged tiles, non-canonical input words.  mask selects the persistent
+    forms of lde_top_dif / lde_mid / lde_top_dit in experiment builds (tools/experiments/ntt_lde_persistent_dma.hip); the
+    product build ignores it."""
+    n, n_ext = 1 << lg, 1 << (lg + ext)
+    src = edge_matrix(orc, n, ncols, 0x5EED0062 + lg)
+    xlp.tune("lde_persist", mask)
+    try:
+        got = xlp.extend(src, n_ext, n, ncols)
+    finally:
+        xlp.tune("lde_persist", 7)
+    assert (got == orc.extend_pol(src, n_ext, n, ncols)).all()
+
+
 def test_lde_config2_device_resident_properties(xlp, orc):
     """BASELINE config 2 at full size (2^23 x 8 -> 2^24 x 8) through the device API:
     (a) one whole column against the oracle, (b) size-independent properties:

@@ -58,6 +58,7 @@ SIGNATURES = {
     "xlp_expr_attach": [_pu, C.c_char_p],
     "xlp_dev_expr_run": [_pu, _pu, _u64, _u64],
     "xlp_profile_enable": [C.c_int],
+    "xlp_tune": [C.c_char_p, C.c_long],
     "xlp_profile_read": [C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
     "xlp_dev_extend_cols": [_pu, _pu, _u64, _u64, _u64, _u64, _u64],
     "xlp_dev_linear_hash_absorb": [_pu, _pu, _u64, _u64, _u64, _u64, C.c_int, C.c_int],
@@ -174,6 +175,11 @@ def shutdown():
 
 def profile_enable(on=True):
     _ck(load().xlp_profile_enable(1 if on else 0), "xlp_profile_enable")
+
+
+def tune(key, value):
+    """kernel-selection knobs (xlp_tune): results never depend on them"""
+    _ck(load().xlp_tune(key.encode(), int(value)), "xlp_tune")
 
 
 def profile_read():

@@ -3,6 +3,7 @@
 // device-pointer entry points.  No CPU fallback exists: every entry point
 // fails if no HIP device can be bound.
 #include <hip/hip_runtime.h>
+#include <string.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <mutex>
@@ -158,6 +159,7 @@ int xlp_init(int device)
     g_ctx.device = device;
     g_ctx.ncu = (u32)prop.multiProcessorCount / 8 * 8;
     if (g_ctx.ncu == 0) g_ctx.ncu = 8;
+    if (const char* ev = getenv("XLP_LDE_PERSIST")) g_ctx.lde_persist = (u32)strtoul(ev, nullptr, 10) & 7u;
     XLP_HIP(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
     g_ctx.own_stream = true;
     if (ntt_init(&g_ctx)) return -1;
@@ -342,6 +344,13 @@ int xlp_profile_enable(int on)
     g_ctx.prof_events.clear();
     g_ctx.profile = on != 0;
     return 0;
+}
+
+int xlp_tune(const char* key, long value)
+{
+    if (ensure_init()) return -1;
+    if (key && !strcmp(key, "lde_persist")) { g_ctx.lde_persist = (u32)value & 7u; return 0; }
+    return xlp_fail("xlp_tune: unknown key");
 }
 
 int xlp_profile_read(double ms_sum[3], uint64_t* count)

@@ -49,6 +49,7 @@ struct Ctx {
     size_t scratch_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool inited = false;
     u32 ncu = 256;             // compute units of the bound device (persistent-kernel grid size)
+    u32 lde_persist = 0;       // experiment builds only: which extendPol kernels run as persistent workgroups (bit mask: dif, mid, dit)
     // optional per-kernel timing of the LDE fast path (xlp_profile_*): HIP events on ctx->stream
     bool profile = false;
     std::vector<hipEvent_t> prof_events;   // 4 events per recorded LDE chunk
