@@ -247,6 +247,26 @@ int xlp_expr_attach(xlp_expr_program* prog, const char* plugin_so_path);
 /* Evaluate the program on rows row0 .. row0 + nrows - 1 (asynchronous on the context's stream). */
 int xlp_dev_expr_run(const xlp_expr_program* prog, const xlp_steps_params* params, uint64_t row0, uint64_t nrows);
 
+/* ---- BN128 side of StarkRecursiveF ------------------------------------------------------------------
+ * An Fr element (BN254 scalar field) is 4 x uint64_t, little-endian limbs, MONTGOMERY form (R = 2^256): the in-memory
+ * representation of the reference's RawFr::Element (src/ffiasm/fr.hpp), so node buffers are byte-compatible.
+ *   xlp_bn128_init             load the Poseidon-BN128 tables (circomlib's optimized constants for t = 2..17,
+ *                              src/poseidon_opt/constants_opt.hpp as data; tools/gen_poseidon_bn128.py).  NULL = the file
+ *                              chelpers/poseidon_bn128.bin next to the library.  Called implicitly by the entry points below.
+ *   xlp_merkle_bn128_num_nodes MerkleTreeBN128::getNumNodes (merkleTreeBN128.cpp:62-84)
+ *   xlp_[dev_]merkle_bn128     MerkleTreeBN128::merkelize (merkleTreeBN128.cpp:89-186): src = h rows x w Goldilocks words (row-major),
+ *                              nodes = num_nodes(h) Fr elements: leaves (linear hash, 3 Goldilocks words per Fr, 16 Fr per
+ *                              permutation, last chunk hashed with t = pending + 1; w <= 4: the words themselves, no hash), then
+ *                              the 16-ary levels, each padded to 16 slots, root last.  h a power of two.
+ *   xlp_[dev_]poseidon_bn128   Poseidon_opt::hash(vector&) (poseidon_opt.cpp:9-66) on `count` states of t elements, in place
+ *                              (TranscriptBN128::_updateState, transcriptBN128.cpp:82-99, is one t = 17 call). */
+int xlp_bn128_init(const char* constants_path);
+uint64_t xlp_merkle_bn128_num_nodes(uint64_t height);
+int xlp_dev_merkle_bn128(uint64_t* nodes, const uint64_t* src, uint64_t w, uint64_t h);
+int xlp_merkle_bn128(uint64_t* nodes, const uint64_t* src, uint64_t w, uint64_t h);
+int xlp_dev_poseidon_bn128(uint64_t* states, uint32_t t, uint64_t count);
+int xlp_poseidon_bn128(uint64_t* states, uint32_t t, uint64_t count);
+
 /* Test hook: out[i] = op(a[i], b[i]) using the device field functions the kernels are built
  * from (op codes: csrc/fri.hip field_op_kernel).  Host pointers.  Not part of the reference surface. */
 int xlp_field_op(uint64_t* out, const uint64_t* a, const uint64_t* b, uint64_t n, int op);

@@ -1,0 +1,135 @@
+"""BN128 side of StarkRecursiveF: Poseidon over the BN254 scalar field, MerkleTreeBN128, TranscriptBN128.
+
+CPU (`not gpu`): the oracle's permutation against circomlib's published known answers (the only external pin that exists:
+the reference snapshot holds no BN128 golden data), tree-layout arithmetic against the reference's formulas.
+GPU: the HIP kernels against the oracle, through the C ABI, bit-exact on the Montgomery-limb bytes."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bn128_oracle as bo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONST = os.path.join(ROOT, "xlayer_prover_amd", "chelpers", "poseidon_bn128.bin")
+needs_constants = pytest.mark.skipif(not os.path.exists(CONST), reason="poseidon_bn128.bin not generated (needs the reference tree at build time)")
+
+
+@pytest.fixture(scope="module")
+def K():
+    return bo.Constants(CONST)
+
+
+@needs_constants
+def test_oracle_permutation_known_answers(K):
+    """circomlib / circomlibjs poseidon test vectors: poseidon([1, 2]) and poseidon([1, 2, 3, 4]) (state[0] = 0 capacity)"""
+    assert bo.poseidon(K, [0, 1, 2])[0] == 0x115cc0f5e7d690413df64c6b9662e9cf2a3617f2743245519e19607a4417189a
+    assert bo.poseidon(K, [0, 1, 2, 3, 4])[0] == 0x299c867db6c1fdd79dcefa40e4510b9837e60ebb1ce0663dbaa525df65250465
+
+
+def test_montgomery_round_trip():
+    for x in (0, 1, 2, bo.R_MOD - 1, 0x1234567890ABCDEF << 100):
+        assert bo.from_mont_limbs(bo.to_mont_limbs(x)) == x % bo.R_MOD
+    assert bo.to_mont_limbs(1) == [0xac96341c4ffffffb, 0x36fc76959f60cd29, 0x666ea36f7879462e, 0x0e0a77c19a07df2f]   # R mod r (fr.asm's `one`)
+
+
+@pytest.mark.parametrize("h,exp", [(1, 1 * 16 + 0), (16, 16 + 1), (256, 256 + 16 + 1), (1 << 19, (1 << 19) + (1 << 15) + (1 << 11) + 128 + 16 + 1)])
+def test_num_nodes(h, exp):
+    if h == 1:
+        assert bo.get_num_nodes(1) == 16        # n = 1: nextN * ARITY, loop not entered
+    else:
+        assert bo.get_num_nodes(h) == exp
+
+
+@needs_constants
+def test_oracle_tree_and_proof_are_consistent(K):
+    """a proof's groups contain the node of the level below at position idx & 15 and hash (t = 17) to the group's parent"""
+    rng = np.random.default_rng(5)
+    h, w = 64, 7
+    src = rng.integers(0, 0xFFFFFFFF00000001, size=(h, w), dtype=np.uint64)
+    nodes = bo.merkelize(K, src)
+    assert len(nodes) == bo.get_num_nodes(h)
+    for idx in (0, 17, 63):
+        mp = bo.merkle_proof(nodes, idx, h)
+        cur, i = bo.linear_hash_row(K, src[idx]), idx
+        for group in mp:
+            assert group[i & 15] == cur
+            cur = bo.poseidon(K, [0] + list(group))[0]
+            i >>= 4
+        assert cur == nodes[-1]
+
+
+@needs_constants
+def test_oracle_transcript_is_deterministic_and_order_sensitive(K):
+    a, b = bo.TranscriptBN128(K), bo.TranscriptBN128(K)
+    a.put([1, 2, 3]); b.put([1, 3, 2])
+    fa, fb = a.get_field(), b.get_field()
+    assert fa != fb and all(x < (1 << 64) for x in fa)
+    c = bo.TranscriptBN128(K)
+    c.put([1, 2, 3])
+    assert c.get_field() == fa
+    perms = c.get_permutations(43, 20)
+    assert len(perms) == 43 and all(p < (1 << 20) for p in perms)
+
+
+# ------------------------------------------------------------------------------------------------------------- GPU
+@pytest.fixture(scope="module")
+def xlp():
+    from xlayer_prover_amd import capi
+    capi.init(0)
+    return capi
+
+
+@pytest.mark.gpu
+@needs_constants
+@pytest.mark.parametrize("t", [2, 3, 5, 9, 16, 17])
+def test_gpu_permutation_vs_oracle(xlp, K, t):
+    rng = np.random.default_rng(100 + t)
+    count = 70                                     # more than one wave
+    vals = [[int.from_bytes(rng.bytes(32), "little") % bo.R_MOD for _ in range(t)] for _ in range(count)]
+    vals[0] = [0] * t
+    vals[1] = [bo.R_MOD - 1] * t
+    if t == 3:
+        vals[2] = [0, 1, 2]
+    st = np.array([[bo.to_mont_limbs(x) for x in row] for row in vals], dtype=np.uint64)
+    got = xlp.poseidon_bn128(st, t)
+    for i in (0, 1, 2, 3, 63, 64, 69):
+        exp = bo.poseidon(K, vals[i])
+        assert [bo.from_mont_limbs(got[i, j]) for j in range(t)] == exp
+        assert (got[i] == np.array([bo.to_mont_limbs(x) for x in exp], dtype=np.uint64)).all()     # canonical Montgomery limbs
+    if t == 3:
+        assert bo.from_mont_limbs(got[2, 0]) == 0x115cc0f5e7d690413df64c6b9662e9cf2a3617f2743245519e19607a4417189a
+
+
+@pytest.mark.gpu
+@needs_constants
+@pytest.mark.parametrize("h,w", [(16, 12), (256, 3), (256, 4), (64, 5), (32, 48), (16, 49), (32, 51), (512, 18), (1, 12), (2, 9), (8, 100)])
+def test_gpu_merkle_bn128_vs_oracle(xlp, K, h, w):
+    """every leaf rule (w <= 4 raw, one chunk, exactly 16 Fr, 16 + a t = 2 tail, several chunks) and level shapes (single batch of < 16,
+    exact powers of 16, a padded top level)"""
+    rng = np.random.default_rng(h * 1000 + w)
+    src = rng.integers(0, 0xFFFFFFFF00000001, size=(h, w), dtype=np.uint64)
+    src[0, :] = 0xFFFFFFFF00000000
+    got = xlp.merkle_bn128(src, w, h)
+    exp = bo.nodes_to_limbs(bo.merkelize(K, src))
+    assert got.shape == exp.shape
+    assert (got == exp).all()
+
+
+@pytest.mark.gpu
+@needs_constants
+def test_gpu_merkle_bn128_larger_tree_properties(xlp, K):
+    """2^14 x 12 (the recursivef leaf shape): root and sampled paths against the oracle's rules without building the whole oracle tree"""
+    h, w = 1 << 14, 12
+    rng = np.random.default_rng(77)
+    src = rng.integers(0, 0xFFFFFFFF00000001, size=(h, w), dtype=np.uint64)
+    got = xlp.merkle_bn128(src, w, h)
+    nodes = [bo.from_mont_limbs(r) for r in got]
+    for idx in (0, 1, 4097, h - 1):
+        assert nodes[idx] == bo.linear_hash_row(K, src[idx])
+        cur, i = nodes[idx], idx
+        for group in bo.merkle_proof(nodes, idx, h):
+            assert group[i & 15] == cur
+            cur = bo.poseidon(K, [0] + list(group))[0]
+            i >>= 4
+        assert cur == nodes[-1]

@@ -59,6 +59,11 @@ SIGNATURES = {
     "xlp_dev_expr_run": [_pu, _pu, _u64, _u64],
     "xlp_profile_enable": [C.c_int],
     "xlp_tune": [C.c_char_p, C.c_long],
+    "xlp_bn128_init": [C.c_char_p],
+    "xlp_dev_merkle_bn128": [_pu, _pu, _u64, _u64],
+    "xlp_merkle_bn128": [_pu, _pu, _u64, _u64],
+    "xlp_dev_poseidon_bn128": [_pu, C.c_uint32, _u64],
+    "xlp_poseidon_bn128": [_pu, C.c_uint32, _u64],
     "xlp_profile_read": [C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
     "xlp_dev_extend_cols": [_pu, _pu, _u64, _u64, _u64, _u64, _u64],
     "xlp_dev_linear_hash_absorb": [_pu, _pu, _u64, _u64, _u64, _u64, C.c_int, C.c_int],
@@ -78,7 +83,7 @@ SIGNATURES = {
     "xlp_copy_d2h": [_pu, _pu, C.c_size_t],
 }
 VOID_SIGNATURES = {"xlp_shutdown": [], }
-SIZE_SIGNATURES = {"xlp_cache_bytes": []}
+SIZE_SIGNATURES = {"xlp_cache_bytes": [], "xlp_merkle_bn128_num_nodes": [C.c_uint64]}
 STR_SIGNATURES = {"xlp_last_error": []}
 
 
@@ -246,6 +251,23 @@ def merkle(src, w, h):
     nodes = np.empty((2 * h - 1) * 4, np.uint64)
     _ck(load().xlp_merkle(_p(nodes), _p(src) if src.size else None, w, h), "xlp_merkle")
     return nodes
+
+
+def merkle_bn128(src, w, h):
+    """MerkleTreeBN128::merkelize -> (num_nodes, 4) uint64: Fr elements as Montgomery limbs (the reference's RawFr::Element bytes)"""
+    src = _np(src).reshape(-1)
+    assert src.size == w * h
+    nn = load().xlp_merkle_bn128_num_nodes(h)
+    nodes = np.zeros((nn, 4), np.uint64)
+    _ck(load().xlp_merkle_bn128(_p(nodes), _p(src) if src.size else None, w, h), "xlp_merkle_bn128")
+    return nodes
+
+
+def poseidon_bn128(states, t):
+    """Poseidon_opt::hash on (count, t, 4) uint64 Montgomery-limb states -> permuted states"""
+    st = _np(states).reshape(-1, t, 4).copy()
+    _ck(load().xlp_poseidon_bn128(_p(st), t, st.shape[0]), "xlp_poseidon_bn128")
+    return st
 
 
 def perm(state):

@@ -1,0 +1,386 @@
+// BN128 side of StarkRecursiveF for gfx950: Poseidon over the BN254 scalar field (circomlib's optimized
+// form), the 16-ary MerkleTreeBN128 and the permutation TranscriptBN128 sits on.
+//
+// Replaces, on the GPU:
+//   Poseidon_opt::hash                     src/poseidon_opt/poseidon_opt.cpp:3-100   (constants: constants_opt.hpp, as data)
+//   MerkleTreeBN128::linearHash/merkelize  src/starkpil/merkleTree/merkleTreeBN128.cpp:89-186
+//   RawFr (ffiasm fr.asm) mul/add/toMontgomery as those two use them
+//
+// Design.  An Fr element is 8 x 32-bit limbs in Montgomery form (R = 2^256, the reference's in-memory representation, so
+// node buffers are byte-identical).  One hash per lane; a workgroup is ONE wave.  The state (up to 17 elements = 136 words per
+// lane) lives in LDS as st[element][limb][lane] (conflict-free, 34 KiB per wave -> four waves per CU, one per SIMD); on CDNA a
+// single wave keeps its SIMD's integer pipe busy as long as it does not wait for memory, and the round constants and matrices
+// are wave-uniform (scalar loads).  The MDS mix walks the state once (j outer) and keeps all t accumulators in registers (one
+// wave per SIMD has the whole 512-entry register file), so every matrix element and every state word is read once per mix.
+// The state size t (2..17) is a run-time parameter: a leaf's last chunk hashes pending + 1 elements (merkleTreeBN128.cpp:131-137).
+// Integer-VALU bound like the Goldilocks sponge: one Montgomery product = 128 v_mad_u64_u32 + carries.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <dlfcn.h>
+#include <string>
+#include <vector>
+#include "xlp_internal.hpp"
+
+namespace xlp {
+namespace bn {
+
+struct Fr { u32 v[8]; };
+
+// r = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+__device__ __constant__ u32 R_MOD[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+// R^2 mod r (toMontgomery = mul by R^2)
+__device__ __constant__ u32 R2_MOD[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+constexpr u32 N0INV = 0xefffffffu;      // -r^-1 mod 2^32
+
+__device__ __forceinline__ Fr zero() { Fr z; for (int i = 0; i < 8; i++) z.v[i] = 0; return z; }
+
+// a - r if a >= r  (a < 2r, possibly with a 9th limb `hi`)
+__device__ __forceinline__ Fr cond_sub(const u32 (&a)[8], u32 hi)
+{
+    u32 d[8];
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u64 s = (u64)a[i] - R_MOD[i] - borrow;
+        d[i] = (u32)s;
+        borrow = (u32)(s >> 63);
+    }
+    const bool ge = hi != 0 || borrow == 0;
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = ge ? d[i] : a[i];
+    return r;
+}
+
+__device__ __forceinline__ Fr add(const Fr& a, const Fr& b)
+{
+    u32 s[8];
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u64 t = (u64)a.v[i] + b.v[i] + c;
+        s[i] = (u32)t;
+        c = (u32)(t >> 32);
+    }
+    return cond_sub(s, c);      // r < 2^254: c is always 0, kept for the general shape
+}
+
+// Montgomery product a * b / R mod r (CIOS, 32-bit limbs).  b < r; a < 2^256 (toMontgomery of a raw 4-limb word relies on it).
+__device__ __forceinline__ Fr mul(const Fr& a, const Fr& b)
+{
+    u32 t[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const u64 p = (u64)a.v[j] * b.v[i] + t[j] + c;
+            t[j] = (u32)p;
+            c = p >> 32;
+        }
+        u64 s = (u64)t[8] + c;
+        t[8] = (u32)s;
+        t[9] = (u32)(s >> 32);
+        const u32 m = t[0] * N0INV;
+        u64 p = (u64)m * R_MOD[0] + t[0];
+        c = p >> 32;
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+            p = (u64)m * R_MOD[j] + t[j] + c;
+            t[j - 1] = (u32)p;
+            c = p >> 32;
+        }
+        s = (u64)t[8] + c;
+        t[7] = (u32)s;
+        t[8] = t[9] + (u32)(s >> 32);
+    }
+    u32 lo[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) lo[i] = t[i];
+    return cond_sub(lo, t[8]);
+}
+
+__device__ __forceinline__ Fr exp5(const Fr& x)
+{
+    const Fr x2 = mul(x, x);
+    const Fr x4 = mul(x2, x2);
+    return mul(x4, x);
+}
+
+__device__ __forceinline__ Fr to_montgomery(const Fr& raw)
+{
+    Fr r2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r2.v[i] = R2_MOD[i];
+    return mul(raw, r2);
+}
+
+// ----------------------------------------------------------------- constants (device copy of poseidon_bn128.bin)
+struct Tables {
+    const Fr* C[16];
+    const Fr* S[16];
+    const Fr* M[16];
+    const Fr* P[16];
+    u32 nP[16];
+};
+
+constexpr int WAVE = 64;
+constexpr int MAXT = 17;
+
+// state in LDS: st[(j * 8 + l) * WAVE + lane]
+__device__ __forceinline__ Fr ld(const u32* st, int j)
+{
+    Fr e;
+#pragma unroll
+    for (int l = 0; l < 8; l++) e.v[l] = st[(j * 8 + l) * WAVE];
+    return e;
+}
+__device__ __forceinline__ void sst(u32* st, int j, const Fr& e)
+{
+#pragma unroll
+    for (int l = 0; l < 8; l++) st[(j * 8 + l) * WAVE] = e.v[l];
+}
+__device__ __forceinline__ Fr ldc(const Fr* __restrict__ tab, u32 idx)   // wave-uniform table element
+{
+    Fr e;
+#pragma unroll
+    for (int l = 0; l < 8; l++) e.v[l] = tab[idx].v[l];
+    return e;
+}
+
+// new[i] = sum_j mat[j * t + i] * st[j]   (Poseidon_opt::mix, poseidon_opt.cpp:89-100)
+__device__ __forceinline__ void mix(u32* st, const int t, const Fr* __restrict__ mat)
+{
+    Fr acc[MAXT];
+#pragma unroll
+    for (int i = 0; i < MAXT; i++) acc[i] = zero();
+#pragma unroll 1
+    for (int j = 0; j < t; j++) {
+        const Fr s = ld(st, j);
+#pragma unroll
+        for (int i = 0; i < MAXT; i++)
+            if (i < t) acc[i] = add(acc[i], mul(ldc(mat, (u32)(j * t + i)), s));
+    }
+#pragma unroll
+    for (int i = 0; i < MAXT; i++)
+        if (i < t) sst(st, i, acc[i]);
+}
+
+// Poseidon_opt::hash(vector<FrElement>& state) (poseidon_opt.cpp:9-66) on the lane's LDS state, t = 2..17
+__device__ __noinline__ void permute(u32* st, const int t, const Tables& K)
+{
+    const int k = t - 2;
+    const Fr* __restrict__ c = K.C[k];
+    const Fr* __restrict__ s = K.S[k];
+    const int nP = (int)K.nP[k];
+#pragma unroll 1
+    for (int i = 0; i < t; i++) sst(st, i, add(ld(st, i), ldc(c, (u32)i)));
+#pragma unroll 1
+    for (int fr = 0; fr < 8; fr++) {
+        if (fr == 4) {
+#pragma unroll 1
+            for (int r = 0; r < nP; r++) {
+                const Fr x = add(exp5(ld(st, 0)), ldc(c, (u32)(5 * t + r)));
+                const u32 base = (u32)((2 * t - 1) * r);
+                Fr s0 = mul(ldc(s, base), x);
+#pragma unroll 1
+                for (int j = 1; j < t; j++) {
+                    Fr sj = ld(st, j);
+                    s0 = add(s0, mul(ldc(s, base + (u32)j), sj));
+                    sj = add(sj, mul(x, ldc(s, base + (u32)(t + j - 1))));
+                    sst(st, j, sj);
+                }
+                sst(st, 0, s0);
+            }
+        }
+        const u32 cidx = fr < 4 ? (u32)((fr + 1) * t) : (u32)(5 * t + nP + (fr - 4) * t);
+#pragma unroll 1
+        for (int i = 0; i < t; i++) {
+            Fr x = exp5(ld(st, i));
+            if (fr != 7) x = add(x, ldc(c, cidx + (u32)i));
+            sst(st, i, x);
+        }
+        mix(st, t, fr == 3 ? K.P[k] : K.M[k]);
+    }
+}
+
+// ----------------------------------------------------------------- kernels
+// leaves: MerkleTreeBN128::linearHash (merkleTreeBN128.cpp:89-157), one row per lane
+__global__ __launch_bounds__(WAVE) void bn128_leaf_kernel(Fr* __restrict__ nodes, const u64* __restrict__ src, const u64 w, const u64 h, const Tables K)
+{
+    __shared__ u32 lds[MAXT * 8 * WAVE];
+    u32* st = lds + threadIdx.x;
+    const u64 gid = (u64)blockIdx.x * WAVE + threadIdx.x;
+    const u64 row = gid < h ? gid : h - 1;            // idle lanes repeat the last row and do not store
+    const u64* __restrict__ p = src + row * w;
+    if (w <= 4) {
+        Fr raw = zero();
+        for (u64 k = 0; k < w; k++) { raw.v[2 * k] = (u32)p[k]; raw.v[2 * k + 1] = (u32)(p[k] >> 32); }
+        const Fr m = to_montgomery(raw);
+        if (gid < h) nodes[gid] = m;
+        return;
+    }
+    const u64 nfr = (w + 2) / 3;
+    Fr node = zero();
+    u64 done = 0;
+    while (done < nfr) {
+        const u64 take = nfr - done < 16 ? nfr - done : 16;
+        sst(st, 0, node);
+        for (u64 e = 0; e < take; e++) {
+            Fr raw = zero();
+            const u64 c0 = (done + e) * 3;
+            for (u64 q = 0; q < 3 && c0 + q < w; q++) {
+                const u64 x = p[c0 + q];
+                raw.v[2 * q] = (u32)x;
+                raw.v[2 * q + 1] = (u32)(x >> 32);
+            }
+            sst(st, 1 + (int)e, to_montgomery(raw));
+        }
+        permute(st, (int)take + 1, K);
+        node = ld(st, 0);
+        done += take;
+    }
+    if (gid < h) nodes[gid] = node;
+}
+
+// one level of MerkleTreeBN128::merkelize (merkleTreeBN128.cpp:167-185): parent i = hash(0, children[16 i .. 16 i + num))
+__global__ __launch_bounds__(WAVE) void bn128_level_kernel(Fr* __restrict__ next, const Fr* __restrict__ cur, const u64 batches, const u32 num, const Tables K)
+{
+    __shared__ u32 lds[MAXT * 8 * WAVE];
+    u32* st = lds + threadIdx.x;
+    const u64 gid = (u64)blockIdx.x * WAVE + threadIdx.x;
+    const u64 b = gid < batches ? gid : batches - 1;
+    sst(st, 0, zero());
+    for (u32 e = 0; e < 16; e++) {
+        Fr x = zero();
+        if (e < num) x = cur[b * 16 + e];
+        sst(st, 1 + (int)e, x);
+    }
+    permute(st, 17, K);
+    if (gid < batches) next[gid] = ld(st, 0);
+}
+
+// count independent permutations of t-element states (Montgomery limbs in and out): the transcript's and the tests' entry
+__global__ __launch_bounds__(WAVE) void bn128_perm_kernel(Fr* __restrict__ states, const u32 t, const u64 count, const Tables K)
+{
+    __shared__ u32 lds[MAXT * 8 * WAVE];
+    u32* st = lds + threadIdx.x;
+    const u64 gid = (u64)blockIdx.x * WAVE + threadIdx.x;
+    const u64 b = gid < count ? gid : count - 1;
+    for (u32 e = 0; e < t; e++) sst(st, (int)e, states[b * t + e]);
+    permute(st, (int)t, K);
+    if (gid < count)
+        for (u32 e = 0; e < t; e++) states[b * t + e] = ld(st, (int)e);
+}
+
+}  // namespace bn
+
+// ----------------------------------------------------------------- host side
+static bn::Tables g_bn_tables;
+static void* g_bn_blob = nullptr;
+static bool g_bn_ready = false;
+
+static std::string default_constants_path()
+{
+    Dl_info info;
+    if (dladdr((const void*)&default_constants_path, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        const size_t k = p.rfind('/');
+        return (k == std::string::npos ? std::string(".") : p.substr(0, k)) + "/chelpers/poseidon_bn128.bin";
+    }
+    return "chelpers/poseidon_bn128.bin";
+}
+
+int bn128_init(Ctx* ctx, const char* path)
+{
+    (void)ctx;
+    if (g_bn_ready && !path) return 0;
+    const std::string file = path && *path ? std::string(path) : default_constants_path();
+    FILE* f = fopen(file.c_str(), "rb");
+    if (!f) return xlp_fail(("bn128: Poseidon-BN128 constants not found: " + file + " (tools/gen_poseidon_bn128.py writes them)").c_str());
+    std::vector<unsigned char> raw;
+    unsigned char buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) raw.insert(raw.end(), buf, buf + n);
+    fclose(f);
+    if (raw.size() < 16 + 32 * 16 || memcmp(raw.data(), "XLPBN128", 8) != 0) return xlp_fail("bn128: bad constants file");
+    const u64* cnt = (const u64*)(raw.data() + 16);
+    static const u32 nrp[16] = {56, 57, 56, 60, 60, 63, 64, 63, 60, 66, 60, 65, 70, 60, 64, 68};   // poseidon_opt.hpp:18
+    u64 total = 0;
+    for (int k = 0; k < 16; k++) {
+        const u64 t = (u64)k + 2;
+        if (cnt[4 * k] != 8 * t + nrp[k] || cnt[4 * k + 1] != (2 * t - 1) * nrp[k] || cnt[4 * k + 2] != t * t || cnt[4 * k + 3] != t * t)
+            return xlp_fail("bn128: constants file has unexpected table sizes");
+        total += cnt[4 * k] + cnt[4 * k + 1] + cnt[4 * k + 2] + cnt[4 * k + 3];
+    }
+    const size_t body = 16 + 32 * 16;
+    if (raw.size() != body + total * 32) return xlp_fail("bn128: constants file truncated");
+    if (g_bn_blob) { (void)hipFree(g_bn_blob); g_bn_blob = nullptr; }
+    XLP_HIP(hipMalloc(&g_bn_blob, total * 32));
+    XLP_HIP(hipMemcpy(g_bn_blob, raw.data() + body, total * 32, hipMemcpyHostToDevice));
+    const bn::Fr* p = (const bn::Fr*)g_bn_blob;
+    for (int k = 0; k < 16; k++) {
+        g_bn_tables.C[k] = p; p += cnt[4 * k];
+        g_bn_tables.S[k] = p; p += cnt[4 * k + 1];
+        g_bn_tables.M[k] = p; p += cnt[4 * k + 2];
+        g_bn_tables.P[k] = p; p += cnt[4 * k + 3];
+        g_bn_tables.nP[k] = nrp[k];
+    }
+    g_bn_ready = true;
+    return 0;
+}
+
+u64 bn128_num_nodes(u64 n)       // MerkleTreeBN128::getNumNodes (merkleTreeBN128.cpp:62-84)
+{
+    if (n == 0) return 0;
+    u64 n_tmp = n;
+    u64 next = (n_tmp - 1) / 16 + 1;
+    u64 acc = next * 16;
+    while (n_tmp > 1) {
+        n_tmp = next;
+        next = (n_tmp - 1) / 16 + 1;
+        acc += n_tmp > 1 ? next * 16 : 1;
+    }
+    return acc;
+}
+
+int dev_merkle_bn128(Ctx* ctx, u64* nodes, const u64* src, u64 w, u64 h)
+{
+    if (bn128_init(ctx, nullptr)) return -1;
+    if (h == 0) return 0;
+    if (h & (h - 1)) return xlp_fail("merkle_bn128: height must be a power of two");
+    bn::Fr* nd = (bn::Fr*)nodes;
+    XLP_HIP(hipMemsetAsync(nd, 0, bn128_num_nodes(h) * sizeof(bn::Fr), ctx->stream));     // calloc'ed in the reference: padding slots stay zero
+    hipLaunchKernelGGL(bn::bn128_leaf_kernel, dim3((unsigned)((h + bn::WAVE - 1) / bn::WAVE)), dim3(bn::WAVE), 0, ctx->stream, nd, src, w, h, g_bn_tables);
+    XLP_HIP(hipGetLastError());
+    u64 n256 = h, cursor = 0, cursor_next = h;
+    u64 next_n = (n256 - 1) / 16 + 1;
+    while (n256 > 1) {
+        const u64 batches = (n256 + 15) / 16;
+        const u32 num = batches == 1 ? (u32)n256 : 16u;
+        hipLaunchKernelGGL(bn::bn128_level_kernel, dim3((unsigned)((batches + bn::WAVE - 1) / bn::WAVE)), dim3(bn::WAVE), 0, ctx->stream,
+                           nd + cursor_next, nd + cursor, batches, num, g_bn_tables);
+        XLP_HIP(hipGetLastError());
+        n256 = next_n;
+        next_n = (n256 - 1) / 16 + 1;
+        cursor = cursor_next;
+        cursor_next = cursor + (n256 > 16 ? n256 : 16);
+    }
+    return 0;
+}
+
+int dev_poseidon_bn128(Ctx* ctx, u64* states, u32 t, u64 count)
+{
+    if (bn128_init(ctx, nullptr)) return -1;
+    if (t < 2 || t > 17) return xlp_fail("poseidon_bn128: state size must be 2..17");
+    if (count == 0) return 0;
+    hipLaunchKernelGGL(bn::bn128_perm_kernel, dim3((unsigned)((count + bn::WAVE - 1) / bn::WAVE)), dim3(bn::WAVE), 0, ctx->stream, (bn::Fr*)states, t, count, g_bn_tables);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace xlp

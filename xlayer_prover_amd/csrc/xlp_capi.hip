@@ -694,6 +694,52 @@ int xlp_perm_batch(uint64_t* out, const uint64_t* in, uint64_t count)
 }
 int xlp_perm(uint64_t out[12], const uint64_t in[12]) { return xlp_perm_batch(out, in, 1); }
 
+// ---- BN128 (StarkRecursiveF)
+int xlp_bn128_init(const char* constants_path)
+{
+    if (ensure_init()) return -1;
+    return bn128_init(&g_ctx, constants_path);
+}
+uint64_t xlp_merkle_bn128_num_nodes(uint64_t height) { return bn128_num_nodes(height); }
+int xlp_dev_merkle_bn128(uint64_t* nodes, const uint64_t* src, uint64_t w, uint64_t h)
+{
+    if (ensure_init()) return -1;
+    if (h && (!nodes || (!src && w))) return xlp_fail("xlp_dev_merkle_bn128: null pointer");
+    return dev_merkle_bn128(&g_ctx, nodes, src, w, h);
+}
+int xlp_merkle_bn128(uint64_t* nodes, const uint64_t* src, uint64_t w, uint64_t h)
+{
+    if (ensure_init()) return -1;
+    if (h == 0) return 0;
+    if (!nodes || (!src && w)) return xlp_fail("xlp_merkle_bn128: null pointer");
+    DevBuf a, b;
+    const size_t nb = bn128_num_nodes(h) * 4 * sizeof(u64);
+    if (a.alloc((h * w ? h * w : 1) * sizeof(u64)) || b.alloc(nb)) return -1;
+    H2D(a, src, h * w * sizeof(u64));
+    if (dev_merkle_bn128(&g_ctx, b.u(), a.u(), w, h)) return -1;
+    D2H(nodes, b, nb);
+    return 0;
+}
+int xlp_dev_poseidon_bn128(uint64_t* states, uint32_t t, uint64_t count)
+{
+    if (ensure_init()) return -1;
+    if (count && !states) return xlp_fail("xlp_dev_poseidon_bn128: null pointer");
+    return dev_poseidon_bn128(&g_ctx, states, t, count);
+}
+int xlp_poseidon_bn128(uint64_t* states, uint32_t t, uint64_t count)
+{
+    if (ensure_init()) return -1;
+    if (count == 0) return 0;
+    if (!states) return xlp_fail("xlp_poseidon_bn128: null pointer");
+    DevBuf a;
+    const size_t nb = (size_t)count * t * 4 * sizeof(u64);
+    if (a.alloc(nb)) return -1;
+    H2D(a, states, nb);
+    if (dev_poseidon_bn128(&g_ctx, a.u(), t, count)) return -1;
+    D2H(states, a, nb);
+    return 0;
+}
+
 int xlp_linear_hash(uint64_t* out, const uint64_t* src, uint64_t w, uint64_t h)
 {
     if (ensure_init()) return -1;

@@ -101,6 +101,12 @@ int dev_dot_columns(Ctx* ctx, u64* out, const xlp_dot_entry* entries, u64 nentri
 int dev_evmap(Ctx* ctx, u64* evals, const u64* LEv, const u64* LpEv, u64 n, u32 eb, u32 nev, const xlp_evmap_entry* entries);
 
 
+// bn128.hip (Poseidon-BN128, MerkleTreeBN128)
+int bn128_init(Ctx* ctx, const char* path);
+u64 bn128_num_nodes(u64 n);
+int dev_merkle_bn128(Ctx* ctx, u64* nodes, const u64* src, u64 w, u64 h);
+int dev_poseidon_bn128(Ctx* ctx, u64* states, u32 t, u64 count);
+
 // expr.hip
 int expr_create(xlp_expr_program** out, const u64* code, u64 ncode, u64 ntmp1, u64 ntmp3);
 int expr_destroy(xlp_expr_program* prog);
