@@ -133,3 +133,45 @@ def test_gpu_merkle_bn128_larger_tree_properties(xlp, K):
             cur = bo.poseidon(K, [0] + list(group))[0]
             i >>= 4
         assert cur == nodes[-1]
+
+
+# ------------------------------------------------------------------------------------------- C++ host mirror (xlp_host_bn128.hpp)
+def _mini_fill(n, seed):
+    M = (1 << 64) - 1
+    out = np.empty(n, np.uint64)
+    for i in range(n):
+        z = ((seed ^ i) + 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        out[i] = (z ^ (z >> 31)) % 0xFFFFFFFF00000001
+    return out
+
+
+@pytest.mark.gpu
+@needs_constants
+@pytest.mark.parametrize("h,w,seed", [(256, 12, 0x5EED0B01), (4096, 20, 0x5EED0B02), (64, 3, 0x5EED0B03)])
+def test_cpp_merkle_tree_and_transcript_bn128_vs_oracle(K, h, w, seed):
+    """MerkleTreeBN128 (host-pointer and GPU-resident), getGroupProof and TranscriptBN128 of host/xlp_host_bn128.hpp as
+    StarkRecursiveF::genProof drives them, against the oracle"""
+    import json
+    import subprocess
+    exe = os.path.join(ROOT, "xlayer_prover_amd", "host", "test_host_shim")
+    r = subprocess.run([exe, "bn128", str(h), str(w), hex(seed)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = json.loads(r.stdout)
+    src = _mini_fill(h * w, seed).reshape(h, w)
+    nodes = bo.merkelize(K, src)
+    assert got["numNodes"] == len(nodes)
+    assert int(got["root"]) == nodes[-1] and int(got["root_dev"]) == nodes[-1]
+    assert got["proofs_equal"] is True
+    idx = got["idx"]
+    assert idx == (seed * 7 + 3) % h
+    exp = [x for group in bo.merkle_proof(nodes, idx, h) for x in group]
+    assert [int(x) for x in got["proof"]] == exp
+    tr = bo.TranscriptBN128(K)
+    tr.put([nodes[-1]])
+    tr.put([int(x) for x in src.reshape(-1)[:min(w, 5)]])
+    assert got["field1"] == tr.get_field()
+    tr.put([int(src[0, 0])])
+    assert got["field2"] == tr.get_field()
+    assert got["ys"] == tr.get_permutations(8, 10)

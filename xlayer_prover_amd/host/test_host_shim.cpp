@@ -7,6 +7,7 @@
 #include <vector>
 #include "starks_mini.hpp"
 #include "starks.hpp"
+#include "xlp_host_bn128.hpp"
 
 // `polinomial <n> <seed>`: Polinomial::batchInverse / calculateZ / calculateH1H2 through STRIDED views of one slab
 // (offset > dim, as the section views of starks.cpp:108-184 are), results as JSON for the oracle comparison.
@@ -161,8 +162,51 @@ static int bundle_mode(const std::string& dir, const std::string& name, uint64_t
     return 0;
 }
 
+// `bn128 <height> <width> <seed>`: MerkleTreeBN128 (host-pointer and GPU-resident forms), getGroupProof and TranscriptBN128 as
+// StarkRecursiveF::genProof uses them (starkRecursiveF.cpp:150-210); JSON for the comparison with oracle/bn128_oracle.py.
+static int bn128_mode(uint64_t h, uint64_t w, uint64_t seed)
+{
+    std::vector<Goldilocks::Element> src(h * w);
+    mini_fill(src.data(), src.size(), seed);
+    MerkleTreeBN128 tree(h, w, src.data());
+    tree.merkelize();
+    RawFr::Element root;
+    tree.getRoot(&root);
+    // the same tree GPU-resident
+    void* d = NULL;
+    XLP_CHECK(xlp_dev_alloc(&d, ((h * w) != 0 ? h * w : 1) * 8));
+    XLP_CHECK(xlp_copy_h2d(d, src.data(), h * w * 8));
+    MerkleTreeBN128 dtree(h, w, (uint64_t*)d, true);
+    dtree.merkelize();
+    RawFr::Element droot;
+    dtree.getRoot(&droot);
+    const uint64_t idx = (seed * 7 + 3) % h, plen = MerkleTreeBN128::getMerkleProofLength(h);
+    std::vector<uint8_t> pa(w * 8 + plen * 16 * 32 + 8), pb(pa.size());
+    tree.getGroupProof(pa.data(), idx);
+    dtree.getGroupProof(pb.data(), idx);
+    printf("{\"root\":\"%s\",\"root_dev\":\"%s\",\"numNodes\":%llu,\"idx\":%llu,\"proofs_equal\":%s,\"proof\":[", RawFr::field.toString(root, 10).c_str(),
+           RawFr::field.toString(droot, 10).c_str(), (unsigned long long)tree.numNodes, (unsigned long long)idx, pa == pb ? "true" : "false");
+    const RawFr::Element* mp = (const RawFr::Element*)(pa.data() + w * 8);
+    for (uint64_t i = 0; i < plen * 16; i++) printf("%s\"%s\"", i ? "," : "", RawFr::field.toString(mp[i], 10).c_str());
+    TranscriptBN128 tr;
+    tr.put(&root, 1);
+    tr.put(src.data(), w < 5 ? w : 5);
+    uint64_t f1[3], f2[3], ys[8];
+    tr.getField(f1);
+    tr.put(src.data(), 1);
+    tr.getField(f2);
+    tr.getPermutations(ys, 8, 10);
+    printf("],\"field1\":[%llu,%llu,%llu],\"field2\":[%llu,%llu,%llu],\"ys\":[", (unsigned long long)f1[0], (unsigned long long)f1[1], (unsigned long long)f1[2],
+           (unsigned long long)f2[0], (unsigned long long)f2[1], (unsigned long long)f2[2]);
+    for (int i = 0; i < 8; i++) printf("%s%llu", i ? "," : "", (unsigned long long)ys[i]);
+    printf("]}\n");
+    XLP_CHECK(xlp_dev_free(d));
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc == 5 && std::string(argv[1]) == "bn128") { const int r = bn128_mode(strtoull(argv[2], 0, 10), strtoull(argv[3], 0, 10), strtoull(argv[4], 0, 0)); xlp_shutdown(); return r; }
     if ((argc == 4 || argc == 5) && std::string(argv[1]) == "genproof") { const int r = genproof_mode(argv[2], argv[3], argc == 5); XlpDeviceSlab::get().release(); xlp_shutdown(); return r; }
     if ((argc == 6 || argc == 7) && std::string(argv[1]) == "bundle") {
         const int r = bundle_mode(argv[2], argv[3], strtoull(argv[4], 0, 0), strtoull(argv[5], 0, 0), argc == 7);
