@@ -108,3 +108,47 @@ class GpuBackend:
         return row, [[int(v) for v in r] for r in sib]
 
 
+
+
+# ---- StarkRecursiveF shape (starkRecursiveF.cpp:150-175): the same flow with MerkleTreeBN128 trees and TranscriptBN128.
+# Roots are one Fr (an integer mod r), openings are the row + the 16-node groups of merkle_genMerkleProof.
+BN_R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+BN_RINV = pow(1 << 256, -1, BN_R)
+
+
+def _fr_from_limbs(l):
+    return sum(int(l[i]) << (64 * i) for i in range(4)) * BN_RINV % BN_R
+
+
+class OracleBackendBN128(OracleBackend):
+    def __init__(self, orc, bo, K):
+        super().__init__(orc); self.bo, self.K = bo, K
+    def merkle(self, src, w, h): return self.bo.merkelize(self.K, np.asarray(src).reshape(h, w))
+    def root(self, nodes, h): return [nodes[-1]]
+    def proof(self, src, nodes, w, h, idx):
+        return [int(v) for v in np.asarray(src).reshape(h, w)[idx]], [list(g) for g in self.bo.merkle_proof(nodes, idx, h)]
+    def transcript(self): return self.bo.TranscriptBN128(self.K)
+
+
+class GpuBackendBN128(GpuBackend):
+    def merkle(self, src, w, h):
+        nodes = self.zeros(self.x.merkle_bn128_num_nodes(h) * 4); self.x.dev_merkle_bn128(nodes, src, w, h); return nodes
+    def root(self, nodes, h): return [_fr_from_limbs(self.x.to_np(nodes[-4:]))]
+    def proof(self, src, nodes, w, h, idx):
+        row = [int(v) for v in self.x.to_np(src[idx * w:(idx + 1) * w])]
+        groups, off, n, i = [], 0, h, idx
+        while n > 1:
+            si = i & ~0xF
+            g = self.x.to_np(nodes[(off + si) * 4:(off + si + 16) * 4]).reshape(16, 4)
+            groups.append([_fr_from_limbs(r) for r in g])
+            nn = (n - 1) // 16 + 1
+            off += nn * 16; i >>= 4; n = nn
+        return row, groups
+    def transcript(self):
+        from xlayer_prover_amd.transcript import HostTranscriptBN128
+        R = (1 << 256) % BN_R
+        def perm17(st):
+            limbs = np.array([[((x * R % BN_R) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)] for x in st], np.uint64)
+            out = self.x.poseidon_bn128(limbs.reshape(1, 17, 4), 17)[0]
+            return [_fr_from_limbs(r) for r in out]
+        return HostTranscriptBN128(perm17)

@@ -252,7 +252,7 @@ def prove(B, nbits, fri_steps, nqueries, seed=1, timers=None, debug=False):
         B.expr_run(progs[step], bufs, WC, WC, 0, nrows)
 
     out = {"publics": [int(v) for v in publics]}
-    tr = HostTranscript(B.perm)
+    tr = B.transcript() if hasattr(B, "transcript") else HostTranscript(B.perm)     # StarkRecursiveF: TranscriptBN128
     verkey = B.root(nodesC, NE)
     tr.put(verkey); tr.put(publics)
     # ---- 1

@@ -175,3 +175,23 @@ def test_cpp_merkle_tree_and_transcript_bn128_vs_oracle(K, h, w, seed):
     tr.put([int(src[0, 0])])
     assert got["field2"] == tr.get_field()
     assert got["ys"] == tr.get_permutations(8, 10)
+
+
+# --------------------------------------------------------------------------------- StarkRecursiveF-shaped genProof (all stages)
+@pytest.mark.gpu
+@needs_constants
+@pytest.mark.parametrize("nbits,steps,nq", [(5, [6, 3], 4), (9, [10, 6, 3], 8)])
+def test_recursivef_shaped_genproof_gpu_equals_oracle(xlp, orc, K, nbits, steps, nq):
+    """StarkRecursiveF::genProof (starkRecursiveF.cpp:150-650) is Starks::genProof with MerkleTreeBN128 trees (cm1..cm4, constants, FRI
+    layers), TranscriptBN128 and 16-ary openings.  The toy-PIL flow of tests/mini_genproof_flow.py (every stage of genProof) run
+    with the BN128 tree + transcript on the HIP library and on the oracle: identical roots, challenges (evaluations depend on
+    them), FRI layers, query indices and openings."""
+    from tests import mini_genproof_flow as flow
+    from tests.mini_backends import GpuBackendBN128, OracleBackendBN128
+    xlp.use_torch_stream()
+    got = flow.prove(GpuBackendBN128(xlp), nbits, steps, nq, seed=nbits)
+    exp = flow.prove(OracleBackendBN128(orc, bo, K), nbits, steps, nq, seed=nbits)
+    assert got.keys() == exp.keys()
+    for k in exp:
+        assert got[k] == exp[k], k
+    assert len(got["root1"]) == 1 and got["root1"][0] < bo.R_MOD and got["root1"][0] >> 64 != 0      # a BN128 root, not four GL words

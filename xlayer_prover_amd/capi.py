@@ -342,6 +342,15 @@ def dev_merkle(nodes, src, w, h):
     _ck(load().xlp_dev_merkle(_dp(nodes), _dp(src), w, h), "xlp_dev_merkle")
 
 
+def merkle_bn128_num_nodes(h):
+    return int(load().xlp_merkle_bn128_num_nodes(h))
+
+
+def dev_merkle_bn128(nodes, src, w, h):
+    """MerkleTreeBN128::merkelize on device tensors: nodes = merkle_bn128_num_nodes(h) x 4 words (Fr, Montgomery limbs)"""
+    _ck(load().xlp_dev_merkle_bn128(_dp(nodes), _dp(src), w, h), "xlp_dev_merkle_bn128")
+
+
 def dev_extend_cols(out, src, n_ext, n, ld, col0, ncols):
     _ck(load().xlp_dev_extend_cols(_dp(out), _dp(src), n_ext, n, ld, col0, ncols), "xlp_dev_extend_cols")
 
