@@ -266,6 +266,11 @@ int xlp_dev_merkle_bn128(uint64_t* nodes, const uint64_t* src, uint64_t w, uint6
 int xlp_merkle_bn128(uint64_t* nodes, const uint64_t* src, uint64_t w, uint64_t h);
 int xlp_dev_poseidon_bn128(uint64_t* states, uint32_t t, uint64_t count);
 int xlp_poseidon_bn128(uint64_t* states, uint32_t t, uint64_t count);
+/*   xlp_[dev_]fft_bn254        FFT<RawFr>::fft / ifft (src/ffiasm/fft.c.hpp:181-221; the transform of the fflonk prover,
+ *                              src/rapidsnark/fflonk_prover.c.hpp) of n = 2^k <= 2^28 Fr elements in place, natural order in and out:
+ *                              A[k] = sum_i a[i] w^(i k), w = 5^((q - 1) / n); inverse: 1/n sum_k A[k] w^(-i k). */
+int xlp_dev_fft_bn254(uint64_t* data, uint64_t n, int inverse);
+int xlp_fft_bn254(uint64_t* data, uint64_t n, int inverse);
 
 /* Test hook: out[i] = op(a[i], b[i]) using the device field functions the kernels are built
  * from (op codes: csrc/fri.hip field_op_kernel).  Host pointers.  Not part of the reference surface. */

@@ -230,3 +230,40 @@ class TranscriptBN128:
                     cb, cf = 0, cf + 1
             res.append(a)
         return res
+
+
+# ------------------------------------------------------------------------------------------------ FFT over Fr (fflonk prover)
+def fft_root(logn):
+    """w_n of FFT<RawFr> (src/ffiasm/fft.c.hpp:52-84): nqr^((q - 1) / n) with nqr = 5, the smallest quadratic non-residue"""
+    assert pow(2, (R_MOD - 1) // 2, R_MOD) == 1 and pow(3, (R_MOD - 1) // 2, R_MOD) == 1 and pow(4, (R_MOD - 1) // 2, R_MOD) == 1
+    assert pow(5, (R_MOD - 1) // 2, R_MOD) == R_MOD - 1
+    return pow(5, (R_MOD - 1) >> logn, R_MOD)
+
+
+def fft(a):
+    """FFT<Field>::fft (fft.c.hpp:181-202): bit reversal, then log n radix-2 stages; natural order in and out"""
+    n = len(a)
+    logn = n.bit_length() - 1
+    assert 1 << logn == n
+    w = fft_root(logn)
+    a = [a[int(format(i, "0%db" % logn)[::-1], 2)] if logn else a[i] for i in range(n)]
+    for s in range(1, logn + 1):
+        m, half = 1 << s, 1 << (s - 1)
+        ws = pow(w, n >> s, R_MOD)
+        for k in range(0, n, m):
+            x = 1
+            for j in range(half):
+                t = x * a[k + j + half] % R_MOD
+                u = a[k + j]
+                a[k + j] = (u + t) % R_MOD
+                a[k + j + half] = (u - t) % R_MOD
+                x = x * ws % R_MOD
+    return a
+
+
+def ifft(a):
+    """FFT<Field>::ifft (fft.c.hpp:205-221)"""
+    n = len(a)
+    b = fft(a)
+    ninv = pow(n, -1, R_MOD)
+    return [b[(n - i) % n] * ninv % R_MOD for i in range(n)]

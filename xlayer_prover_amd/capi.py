@@ -64,6 +64,8 @@ SIGNATURES = {
     "xlp_merkle_bn128": [_pu, _pu, _u64, _u64],
     "xlp_dev_poseidon_bn128": [_pu, C.c_uint32, _u64],
     "xlp_poseidon_bn128": [_pu, C.c_uint32, _u64],
+    "xlp_dev_fft_bn254": [_pu, _u64, C.c_int],
+    "xlp_fft_bn254": [_pu, _u64, C.c_int],
     "xlp_profile_read": [C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
     "xlp_dev_extend_cols": [_pu, _pu, _u64, _u64, _u64, _u64, _u64],
     "xlp_dev_linear_hash_absorb": [_pu, _pu, _u64, _u64, _u64, _u64, C.c_int, C.c_int],
@@ -268,6 +270,17 @@ def poseidon_bn128(states, t):
     st = _np(states).reshape(-1, t, 4).copy()
     _ck(load().xlp_poseidon_bn128(_p(st), t, st.shape[0]), "xlp_poseidon_bn128")
     return st
+
+
+def fft_bn254(data, inverse=False):
+    """FFT<RawFr>::fft / ifft on (n, 4) uint64 Montgomery-limb elements -> transformed copy"""
+    a = _np(data).reshape(-1, 4).copy()
+    _ck(load().xlp_fft_bn254(_p(a), a.shape[0], 1 if inverse else 0), "xlp_fft_bn254")
+    return a
+
+
+def dev_fft_bn254(data, n, inverse=False):
+    _ck(load().xlp_dev_fft_bn254(_dp(data), n, 1 if inverse else 0), "xlp_dev_fft_bn254")
 
 
 def perm(state):

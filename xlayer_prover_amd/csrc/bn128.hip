@@ -277,6 +277,125 @@ __global__ __launch_bounds__(WAVE) void bn128_perm_kernel(Fr* __restrict__ state
         for (u32 e = 0; e < t; e++) states[b * t + e] = ld(st, (int)e);
 }
 
+// ----------------------------------------------------------------- FFT over Fr (src/ffiasm/fft.c.hpp:181-221, the fflonk prover's transform)
+__device__ __forceinline__ Fr sub(const Fr& a, const Fr& b)
+{
+    u32 d[8];
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u64 s = (u64)a.v[i] - b.v[i] - borrow;
+        d[i] = (u32)s;
+        borrow = (u32)(s >> 63);
+    }
+    // borrow: add r back
+    u32 c = 0;
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u64 t = (u64)d[i] + (borrow ? R_MOD[i] : 0u) + c;
+        r.v[i] = (u32)t;
+        c = (u32)(t >> 32);
+    }
+    return r;
+}
+__device__ __forceinline__ Fr gld(const Fr* p)
+{
+    const uint4* q = (const uint4*)p;
+    const uint4 a = q[0], b = q[1];
+    Fr e;
+    e.v[0] = a.x; e.v[1] = a.y; e.v[2] = a.z; e.v[3] = a.w; e.v[4] = b.x; e.v[5] = b.y; e.v[6] = b.z; e.v[7] = b.w;
+    return e;
+}
+__device__ __forceinline__ void gst(Fr* p, const Fr& e)
+{
+    uint4* q = (uint4*)p;
+    q[0] = make_uint4(e.v[0], e.v[1], e.v[2], e.v[3]);
+    q[1] = make_uint4(e.v[4], e.v[5], e.v[6], e.v[7]);
+}
+
+// tw[j] = w^j, j < count, from wpow[k] = w^(2^k)
+__global__ void fr_twiddle_kernel(Fr* __restrict__ tw, const u64 count, const Fr* __restrict__ wpow, const Fr one)
+{
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    Fr acc = one;
+    for (u32 k = 0; (j >> k) != 0; k++)
+        if ((j >> k) & 1) acc = mul(acc, gld(&wpow[k]));
+    gst(&tw[j], acc);
+}
+
+__device__ __forceinline__ u64 brev_bits(u64 x, u32 bits) { return bits ? __brevll(x) >> (64 - bits) : 0; }
+
+// FFT::reversePermutation (fft.c.hpp:166-178)
+__global__ void fr_bitrev_kernel(Fr* __restrict__ a, const u32 logn)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> logn) return;
+    const u64 r = brev_bits(i, logn);
+    if (i > r) { const Fr x = gld(&a[i]), y = gld(&a[r]); gst(&a[i], y); gst(&a[r], x); }
+}
+
+// stages 1..LB of FFT::fft on one block of 2^LB consecutive elements held in LDS (the butterflies of those stages stay inside the block)
+constexpr int FFT_LB = 8;
+__global__ __launch_bounds__(1 << (FFT_LB - 1)) void fr_fft_low_kernel(Fr* __restrict__ a, const Fr* __restrict__ tw, const u32 logn, const u32 nst)
+{
+    __shared__ u32 sm[8 << FFT_LB];                 // [limb][element]
+    const u32 tid = threadIdx.x, B = 1u << nst;
+    Fr* blk = a + ((u64)blockIdx.x << nst);
+    for (u32 e = tid; e < B; e += blockDim.x) {
+        const Fr x = gld(&blk[e]);
+#pragma unroll
+        for (int l = 0; l < 8; l++) sm[l * (1 << FFT_LB) + e] = x.v[l];
+    }
+    __syncthreads();
+    for (u32 s = 1; s <= nst; s++) {
+        const u32 mdiv2 = 1u << (s - 1);
+        for (u32 i = tid; i < (B >> 1); i += blockDim.x) {
+            const u32 k = (i / mdiv2) << s, j = i % mdiv2;
+            Fr u, v;
+#pragma unroll
+            for (int l = 0; l < 8; l++) { u.v[l] = sm[l * (1 << FFT_LB) + k + j]; v.v[l] = sm[l * (1 << FFT_LB) + k + j + mdiv2]; }
+            const Fr t = mul(gld(&tw[(u64)j << (logn - s)]), v);
+            const Fr x = add(u, t), y = sub(u, t);
+#pragma unroll
+            for (int l = 0; l < 8; l++) { sm[l * (1 << FFT_LB) + k + j] = x.v[l]; sm[l * (1 << FFT_LB) + k + j + mdiv2] = y.v[l]; }
+        }
+        __syncthreads();
+    }
+    for (u32 e = tid; e < B; e += blockDim.x) {
+        Fr x;
+#pragma unroll
+        for (int l = 0; l < 8; l++) x.v[l] = sm[l * (1 << FFT_LB) + e];
+        gst(&blk[e], x);
+    }
+}
+
+// one stage s > LB of FFT::fft (fft.c.hpp:186-201) through HBM
+__global__ void fr_fft_stage_kernel(Fr* __restrict__ a, const Fr* __restrict__ tw, const u32 logn, const u32 s)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> (logn - 1)) return;
+    const u64 mdiv2 = 1ull << (s - 1);
+    const u64 k = (i >> (s - 1)) << s, j = i & (mdiv2 - 1);
+    const Fr t = mul(gld(&tw[j << (logn - s)]), gld(&a[k + j + mdiv2]));
+    const Fr u = gld(&a[k + j]);
+    gst(&a[k + j], add(u, t));
+    gst(&a[k + j + mdiv2], sub(u, t));
+}
+
+// the tail of FFT::ifft (fft.c.hpp:205-221): a[i] <-> a[n - i], everything times 1 / n
+__global__ void fr_ifft_finish_kernel(Fr* __restrict__ a, const u32 logn, const Fr ninv)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 n = 1ull << logn, half = n >> 1;
+    if (i > half) return;
+    if (i == 0 || i == half) { gst(&a[i], mul(gld(&a[i]), ninv)); return; }
+    const Fr x = gld(&a[i]), y = gld(&a[n - i]);
+    gst(&a[i], mul(y, ninv));
+    gst(&a[n - i], mul(x, ninv));
+}
+
 }  // namespace bn
 
 // ----------------------------------------------------------------- host side
@@ -379,6 +498,96 @@ int dev_poseidon_bn128(Ctx* ctx, u64* states, u32 t, u64 count)
     if (t < 2 || t > 17) return xlp_fail("poseidon_bn128: state size must be 2..17");
     if (count == 0) return 0;
     hipLaunchKernelGGL(bn::bn128_perm_kernel, dim3((unsigned)((count + bn::WAVE - 1) / bn::WAVE)), dim3(bn::WAVE), 0, ctx->stream, (bn::Fr*)states, t, count, g_bn_tables);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- host-side scalar Fr arithmetic for launch constants only (root of unity, 1 / n): 4 x 64-bit Montgomery
+namespace hfr {
+typedef unsigned __int128 u128;
+struct E { u64 v[4]; };
+static const u64 Q[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+static const u64 R2[4] = {0x1bb8e645ae216da7ULL, 0x53fe3ab1e35c59e3ULL, 0x8c49833d53bb8085ULL, 0x0216d0b17f4e44a5ULL};
+static const u64 NP = 0xc2e1f593efffffffULL;
+static E mont(const E& a, const E& b)
+{
+    u64 t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) { const u128 p = (u128)a.v[j] * b.v[i] + t[j] + (u64)c; t[j] = (u64)p; c = p >> 64; }
+        u128 s = (u128)t[4] + (u64)c; t[4] = (u64)s; t[5] = (u64)(s >> 64);
+        const u64 m = t[0] * NP;
+        u128 p = (u128)m * Q[0] + t[0]; c = p >> 64;
+        for (int j = 1; j < 4; j++) { p = (u128)m * Q[j] + t[j] + (u64)c; t[j - 1] = (u64)p; c = p >> 64; }
+        s = (u128)t[4] + (u64)c; t[3] = (u64)s; t[4] = t[5] + (u64)(s >> 64);
+    }
+    E r = {{t[0], t[1], t[2], t[3]}};
+    bool ge = t[4] != 0;
+    if (!ge) { ge = true; for (int i = 3; i >= 0; i--) if (r.v[i] != Q[i]) { ge = r.v[i] > Q[i]; break; } }
+    if (ge) { u128 bw = 0; for (int i = 0; i < 4; i++) { const u128 d = (u128)r.v[i] - Q[i] - (u64)bw; r.v[i] = (u64)d; bw = (d >> 64) & 1; } }
+    return r;
+}
+static E from_u64(u64 x) { E raw = {{x, 0, 0, 0}}, r2 = {{R2[0], R2[1], R2[2], R2[3]}}; return mont(raw, r2); }
+static E pow(E base, const u64 e[4])
+{
+    E r = from_u64(1);
+    for (int i = 255; i >= 0; i--) {
+        r = mont(r, r);
+        if ((e[i >> 6] >> (i & 63)) & 1) r = mont(r, base);
+    }
+    return r;
+}
+}  // namespace hfr
+
+static bn::Fr to_dev(const hfr::E& e)
+{
+    bn::Fr f;
+    for (int i = 0; i < 4; i++) { f.v[2 * i] = (u32)e.v[i]; f.v[2 * i + 1] = (u32)(e.v[i] >> 32); }
+    return f;
+}
+
+// FFT<RawFr>::fft / ifft (src/ffiasm/fft.c.hpp:181-221) of n = 2^logn Fr elements (Montgomery limbs) in place on the device:
+// w_n = nqr^((q - 1) / n) with nqr = 5, the smallest quadratic non-residue (fft.c.hpp:52-57,83-84)
+int dev_fft_bn254(Ctx* ctx, u64* data, u64 n, int inverse)
+{
+    if (n == 0) return 0;
+    if (n & (n - 1)) return xlp_fail("fft_bn254: size must be a power of two");
+    u32 logn = 0;
+    while ((1ull << logn) < n) logn++;
+    if (logn > 28) return xlp_fail("fft_bn254: domain too big for the curve (2-adicity 28)");
+    bn::Fr* a = (bn::Fr*)data;
+    if (logn == 0) return 0;
+    // (q - 1) >> logn
+    u64 e[4];
+    {
+        u64 qm1[4] = {hfr::Q[0] - 1, hfr::Q[1], hfr::Q[2], hfr::Q[3]};
+        for (int i = 0; i < 4; i++) e[i] = (qm1[i] >> logn) | (i < 3 && logn ? qm1[i + 1] << (64 - logn) : 0);
+    }
+    hfr::E w = hfr::pow(hfr::from_u64(5), e);
+    std::vector<bn::Fr> wpow(logn);
+    for (u32 k = 0; k < logn; k++) { wpow[k] = to_dev(w); w = hfr::mont(w, w); }
+    const u64 half = n >> 1;
+    u64* scratch = nullptr;
+    if (ctx_scratch(ctx, (half + 32) * sizeof(bn::Fr), 3, &scratch)) return -1;
+    bn::Fr* tw = (bn::Fr*)scratch;
+    bn::Fr* d_wpow = tw + half;
+    XLP_HIP(hipMemcpyAsync(d_wpow, wpow.data(), logn * sizeof(bn::Fr), hipMemcpyHostToDevice, ctx->stream));
+    XLP_HIP(hipStreamSynchronize(ctx->stream));       // wpow is a host temporary
+    hipLaunchKernelGGL(bn::fr_twiddle_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, ctx->stream, tw, half, d_wpow, to_dev(hfr::from_u64(1)));
+    hipLaunchKernelGGL(bn::fr_bitrev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, logn);
+    const u32 nst = logn < (u32)bn::FFT_LB ? logn : (u32)bn::FFT_LB;
+    hipLaunchKernelGGL(bn::fr_fft_low_kernel, dim3((unsigned)(n >> nst)), dim3(1 << (bn::FFT_LB - 1)), 0, ctx->stream, a, tw, logn, nst);
+    for (u32 s = nst + 1; s <= logn; s++)
+        hipLaunchKernelGGL(bn::fr_fft_stage_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, ctx->stream, a, tw, logn, s);
+    if (inverse) {
+        // 1 / n = 2^-logn: (q + 1) / 2 raised to logn
+        hfr::E inv2 = hfr::from_u64(2);
+        u64 qm2[4] = {hfr::Q[0] - 2, hfr::Q[1], hfr::Q[2], hfr::Q[3]};
+        inv2 = hfr::pow(inv2, qm2);
+        hfr::E ninv = hfr::from_u64(1);
+        for (u32 k = 0; k < logn; k++) ninv = hfr::mont(ninv, inv2);
+        hipLaunchKernelGGL(bn::fr_ifft_finish_kernel, dim3((unsigned)((half + 1 + 255) / 256)), dim3(256), 0, ctx->stream, a, logn, to_dev(ninv));
+    }
     XLP_HIP(hipGetLastError());
     return 0;
 }

@@ -740,6 +740,25 @@ int xlp_poseidon_bn128(uint64_t* states, uint32_t t, uint64_t count)
     return 0;
 }
 
+int xlp_dev_fft_bn254(uint64_t* data, uint64_t n, int inverse)
+{
+    if (ensure_init()) return -1;
+    if (n && !data) return xlp_fail("xlp_dev_fft_bn254: null pointer");
+    return dev_fft_bn254(&g_ctx, data, n, inverse);
+}
+int xlp_fft_bn254(uint64_t* data, uint64_t n, int inverse)
+{
+    if (ensure_init()) return -1;
+    if (n == 0) return 0;
+    if (!data) return xlp_fail("xlp_fft_bn254: null pointer");
+    DevBuf a;
+    if (a.alloc(n * 4 * sizeof(u64))) return -1;
+    H2D(a, data, n * 4 * sizeof(u64));
+    if (dev_fft_bn254(&g_ctx, a.u(), n, inverse)) return -1;
+    D2H(data, a, n * 4 * sizeof(u64));
+    return 0;
+}
+
 int xlp_linear_hash(uint64_t* out, const uint64_t* src, uint64_t w, uint64_t h)
 {
     if (ensure_init()) return -1;

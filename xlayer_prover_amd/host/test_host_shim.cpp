@@ -163,7 +163,7 @@ static int bundle_mode(const std::string& dir, const std::string& name, uint64_t
 }
 
 // `bn128 <height> <width> <seed>`: MerkleTreeBN128 (host-pointer and GPU-resident forms), getGroupProof and TranscriptBN128 as
-// StarkRecursiveF::genProof uses them (starkRecursiveF.cpp:150-210); JSON for the comparison with oracle/bn128_oracle.py.
+// StarkRecursiveF::genProof uses them (starkRecursiveF.cpp:150-210); JSON for the comparison in tests/test_bn128.py.
 static int bn128_mode(uint64_t h, uint64_t w, uint64_t seed)
 {
     std::vector<Goldilocks::Element> src(h * w);
