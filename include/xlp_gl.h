@@ -271,6 +271,12 @@ int xlp_poseidon_bn128(uint64_t* states, uint32_t t, uint64_t count);
  *                              A[k] = sum_i a[i] w^(i k), w = 5^((q - 1) / n); inverse: 1/n sum_k A[k] w^(-i k). */
 int xlp_dev_fft_bn254(uint64_t* data, uint64_t n, int inverse);
 int xlp_fft_bn254(uint64_t* data, uint64_t n, int inverse);
+/*   xlp_[dev_]msm_bn254        ParallelMultiexp<G1>::multiexp (src/ffiasm/multiexp.c.hpp:118-164, Curve::multiMulByScalar as called at
+ *                              fflonk_prover.c.hpp:1700): out = sum_i scalars[i] * bases[i] on BN254 G1.  bases: n affine points, 8 words each
+ *                              (x, y as Fq Montgomery limbs; (0, 0) = infinity, skipped); scalars: n x 4 words, raw little-endian 256-bit
+ *                              integers; out: 8 words, the sum as an affine point ((0, 0) = infinity).  n < 2^27. */
+int xlp_dev_msm_bn254(uint64_t* out, const uint64_t* bases, const uint64_t* scalars, uint64_t n);
+int xlp_msm_bn254(uint64_t* out, const uint64_t* bases, const uint64_t* scalars, uint64_t n);
 
 /* Test hook: out[i] = op(a[i], b[i]) using the device field functions the kernels are built
  * from (op codes: csrc/fri.hip field_op_kernel).  Host pointers.  Not part of the reference surface. */

@@ -267,3 +267,100 @@ def ifft(a):
     b = fft(a)
     ninv = pow(n, -1, R_MOD)
     return [b[(n - i) % n] * ninv % R_MOD for i in range(n)]
+
+
+# ------------------------------------------------------------------------------------------------ G1 multi-scalar multiplication
+# ParallelMultiexp<Curve>::multiexp (src/ffiasm/multiexp.c.hpp:118-164) computes sum_i scalars[i] * bases[i] on alt_bn128 G1
+# (y^2 = x^3 + 3 over Fq, src/ffiasm/alt_bn128.cpp); restated here as plain double-and-add per point (a different algorithm from
+# both the reference's and the GPU's bucket methods).  Points are (x, y) integers, None = infinity.
+Q_MOD = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+Q_MONT_R = (1 << 256) % Q_MOD
+Q_MONT_RINV = pow(Q_MONT_R, -1, Q_MOD)
+G1 = (1, 2)
+
+
+def g1_on_curve(p):
+    return p is None or (p[1] * p[1] - (p[0] ** 3 + 3)) % Q_MOD == 0
+
+
+def _jdbl(p):
+    X, Y, Z = p
+    if Z == 0:
+        return p
+    A, B = X * X % Q_MOD, Y * Y % Q_MOD
+    C = B * B % Q_MOD
+    D = 2 * ((X + B) ** 2 - A - C) % Q_MOD
+    E = 3 * A % Q_MOD
+    X3 = (E * E - 2 * D) % Q_MOD
+    return X3, (E * (D - X3) - 8 * C) % Q_MOD, 2 * Y * Z % Q_MOD
+
+
+def _jadd(p, q):
+    if q[2] == 0:
+        return p
+    if p[2] == 0:
+        return q
+    Z1Z1, Z2Z2 = p[2] * p[2] % Q_MOD, q[2] * q[2] % Q_MOD
+    U1, U2 = p[0] * Z2Z2 % Q_MOD, q[0] * Z1Z1 % Q_MOD
+    S1, S2 = p[1] * q[2] * Z2Z2 % Q_MOD, q[1] * p[2] * Z1Z1 % Q_MOD
+    if U1 == U2:
+        return _jdbl(p) if S1 == S2 else (1, 1, 0)
+    H, r = (U2 - U1) % Q_MOD, (S2 - S1) % Q_MOD
+    HH = H * H % Q_MOD
+    HHH = H * HH % Q_MOD
+    V = U1 * HH % Q_MOD
+    X3 = (r * r - HHH - 2 * V) % Q_MOD
+    return X3, (r * (V - X3) - S1 * HHH) % Q_MOD, p[2] * q[2] * H % Q_MOD
+
+
+def _to_affine(p):
+    if p[2] == 0:
+        return None
+    zi = pow(p[2], -1, Q_MOD)
+    return p[0] * zi * zi % Q_MOD, p[1] * zi * zi * zi % Q_MOD
+
+
+def g1_mul(p, k):
+    if p is None or k == 0:
+        return None
+    acc, base = (1, 1, 0), (p[0], p[1], 1)
+    for b in range(k.bit_length() - 1, -1, -1):
+        acc = _jdbl(acc)
+        if (k >> b) & 1:
+            acc = _jadd(acc, base)
+    return _to_affine(acc)
+
+
+def g1_add(p, q):
+    a = (1, 1, 0) if p is None else (p[0], p[1], 1)
+    b = (1, 1, 0) if q is None else (q[0], q[1], 1)
+    return _to_affine(_jadd(a, b))
+
+
+def msm(bases, scalars):
+    """sum_i scalars[i] * bases[i]; scalars are raw integers < 2^256 (not reduced, as getChunk reads them, multiexp.c.hpp:23-35)"""
+    acc = (1, 1, 0)
+    for p, k in zip(bases, scalars):
+        if p is None or k == 0:
+            continue
+        q = g1_mul(p, k)
+        if q is not None:
+            acc = _jadd(acc, (q[0], q[1], 1))
+    return _to_affine(acc)
+
+
+def g1_to_limbs(p):
+    """affine point -> 8 uint64: x, y as Fq Montgomery limbs ((0, 0) = infinity, the reference's zeroAffine)"""
+    if p is None:
+        return [0] * 8
+    out = []
+    for c in p:
+        v = c * Q_MONT_R % Q_MOD
+        out += [(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+    return out
+
+
+def g1_from_limbs(l):
+    x = sum(int(l[i]) << (64 * i) for i in range(4)) * Q_MONT_RINV % Q_MOD
+    y = sum(int(l[4 + i]) << (64 * i) for i in range(4)) * Q_MONT_RINV % Q_MOD
+    return None if x == 0 and y == 0 else (x, y)

@@ -206,7 +206,12 @@ def main():
     json.dump(fx2, open(os.path.join(HERE, "proof_recursive2_01.json"), "w"), separators=(",", ":"))
     fx1, _ = golden_proof(REF + "/aggregatedProof/recursive1.zkin.proof_0.json", const2, "recursive1.proof_0")
     json.dump(fx1, open(os.path.join(HERE, "proof_recursive1_0.json"), "w"), separators=(",", ":"))
-    for f in ["poseidon_kats.json", "proof_recursive2_01.json", "proof_recursive1_0.json"]:
+    # the four G1 commitments of the reference's fflonk proof: real BN254 curve points held by the reference (pin q and b = 3)
+    blob = open(REF + "/finalProof/proof.json").read().strip()[2:]
+    w = [int(blob[64 * i:64 * i + 64], 16) for i in range(8)]
+    json.dump({"source": "testvectors/finalProof/proof.json: the first eight 32-byte words = the G1 commitments C1, C2, W1, W2 of the reference's fflonk proof (affine x, y)",
+               "points": [[str(w[2 * i]), str(w[2 * i + 1])] for i in range(4)]}, open(os.path.join(HERE, "fflonk_proof_g1_points.json"), "w"), indent=1)
+    for f in ["poseidon_kats.json", "proof_recursive2_01.json", "proof_recursive1_0.json", "fflonk_proof_g1_points.json"]:
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

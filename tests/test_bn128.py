@@ -242,3 +242,81 @@ def test_gpu_fft_bn254_2p20_properties(xlp):
     for k in (0, 1, 2, 12345, n - 1):
         assert bo.from_mont_limbs(D[k]) == 7 * pow(w, 3 * k, bo.R_MOD) % bo.R_MOD
     assert len(vals) == 64
+
+
+# ------------------------------------------------------------------------------------------------ G1 MSM (fflonk commitments)
+def _golden_points():
+    import json
+    j = json.load(open(os.path.join(ROOT, "tests", "golden", "fflonk_proof_g1_points.json")))
+    return [(int(x), int(y)) for x, y in j["points"]]
+
+
+def test_oracle_curve_is_pinned_by_reference_held_points():
+    """the G1 commitments of the reference's own fflonk proof (testvectors/finalProof/proof.json) lie on y^2 = x^3 + 3 over the
+    oracle's q; the doubling of the generator is the published 2G (EIP-196 test vectors)"""
+    for p in _golden_points():
+        assert bo.g1_on_curve(p) and p[0] < bo.Q_MOD
+    assert bo.g1_mul(bo.G1, 2) == (1368015179489954701390400359078579693043519447331113978918064868415326638035,
+                                   9918110051302171585080402603319702774565515993150576347155970296011118125764)
+    assert bo.g1_mul(bo.G1, bo.R_MOD) is None                      # the group order is r
+    a, b = _golden_points()[:2]
+    assert bo.g1_add(bo.g1_mul(a, 5), bo.g1_mul(a, 7)) == bo.g1_mul(a, 12)
+    assert bo.msm([a, b, None], [3, 4, 9]) == bo.g1_add(bo.g1_mul(a, 3), bo.g1_mul(b, 4))
+    assert bo.g1_from_limbs(bo.g1_to_limbs(a)) == a and bo.g1_from_limbs([0] * 8) is None
+
+
+def _random_points(rng, n):
+    """n curve points: small multiples of the generator and of the reference-held points, by chained additions (cheap)"""
+    seeds = [bo.G1] + _golden_points()
+    pts, cur = [], None
+    for i in range(n):
+        cur = bo.g1_add(cur, seeds[int(rng.integers(0, len(seeds)))])
+        pts.append(cur)
+    return pts
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 17, 64, 300])
+def test_gpu_msm_bn254_vs_oracle(xlp, n):
+    rng = np.random.default_rng(500 + n)
+    pts = _random_points(rng, n)
+    ks = [int.from_bytes(rng.bytes(32), "little") for _ in range(n)]           # raw 256-bit scalars, not reduced
+    if n >= 3:
+        ks[0] = 0; ks[1] = 1; ks[2] = (1 << 256) - 1
+    if n >= 17:
+        pts[5] = None                                                          # a point at infinity among the bases
+        pts[7] = pts[6]                                                        # equal points (doubling inside a bucket)
+        ks[7] = ks[6]
+        pts[9] = (pts[8][0], bo.Q_MOD - pts[8][1])                             # P and -P with the same scalar: cancels
+        ks[9] = ks[8]
+    bases = np.array([bo.g1_to_limbs(p) for p in pts], dtype=np.uint64).reshape(-1, 8)
+    scal = np.array([[(k >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)] for k in ks], dtype=np.uint64).reshape(-1, 4)
+    got = xlp.msm_bn254(bases, scal)
+    exp = bo.msm(pts, ks)
+    assert bo.g1_from_limbs(got) == exp
+    assert [int(v) for v in got] == bo.g1_to_limbs(exp)
+
+
+@pytest.mark.gpu
+def test_gpu_msm_bn254_large_properties(xlp):
+    """2^16 points (16-bit windows): linearity -- MSM(P, a) + MSM(P, b) == MSM(P, a + b) -- and MSM with all scalars equal to k ==
+    k * MSM(P, 1), checked with the oracle's group law on the (small) results"""
+    n = 1 << 16
+    rng = np.random.default_rng(777)
+    base_pts = _random_points(rng, 256)
+    idx = rng.integers(0, 256, size=n)
+    table = np.array([bo.g1_to_limbs(p) for p in base_pts], dtype=np.uint64)
+    bases = table[idx]
+    a = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64); a[:, 3] &= 0x00FFFFFFFFFFFFFF
+    b = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64); b[:, 3] &= 0x00FFFFFFFFFFFFFF
+    ab = a + b                                                      # limb-wise, no carries (62-bit limbs)
+    Pa, Pb, Pab = (bo.g1_from_limbs(xlp.msm_bn254(bases, s)) for s in (a, b, ab))
+    assert bo.g1_add(Pa, Pb) == Pab
+    ones = np.zeros((n, 4), np.uint64); ones[:, 0] = 1
+    k = 0xDEADBEEFCAFE
+    ks = np.zeros((n, 4), np.uint64); ks[:, 0] = k
+    S1, Sk = bo.g1_from_limbs(xlp.msm_bn254(bases, ones)), bo.g1_from_limbs(xlp.msm_bn254(bases, ks))
+    assert Sk == bo.g1_mul(S1, k)
+    # and against the oracle directly: sum over the 256 distinct points of (count * point)
+    cnt = np.bincount(idx, minlength=256)
+    assert S1 == bo.msm(base_pts, [int(c) for c in cnt])

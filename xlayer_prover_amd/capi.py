@@ -66,6 +66,8 @@ SIGNATURES = {
     "xlp_poseidon_bn128": [_pu, C.c_uint32, _u64],
     "xlp_dev_fft_bn254": [_pu, _u64, C.c_int],
     "xlp_fft_bn254": [_pu, _u64, C.c_int],
+    "xlp_dev_msm_bn254": [_pu, _pu, _pu, _u64],
+    "xlp_msm_bn254": [_pu, _pu, _pu, _u64],
     "xlp_profile_read": [C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
     "xlp_dev_extend_cols": [_pu, _pu, _u64, _u64, _u64, _u64, _u64],
     "xlp_dev_linear_hash_absorb": [_pu, _pu, _u64, _u64, _u64, _u64, C.c_int, C.c_int],
@@ -277,6 +279,20 @@ def fft_bn254(data, inverse=False):
     a = _np(data).reshape(-1, 4).copy()
     _ck(load().xlp_fft_bn254(_p(a), a.shape[0], 1 if inverse else 0), "xlp_fft_bn254")
     return a
+
+
+def msm_bn254(bases, scalars):
+    """sum scalars[i] * bases[i] on BN254 G1: bases (n, 8) uint64 (x, y Montgomery limbs), scalars (n, 4) uint64 raw -> (8,) affine sum"""
+    b = _np(bases).reshape(-1, 8)
+    s = _np(scalars).reshape(-1, 4)
+    assert b.shape[0] == s.shape[0]
+    out = np.zeros(8, np.uint64)
+    _ck(load().xlp_msm_bn254(_p(out), _p(b) if b.size else None, _p(s) if s.size else None, b.shape[0]), "xlp_msm_bn254")
+    return out
+
+
+def dev_msm_bn254(out, bases, scalars, n):
+    _ck(load().xlp_dev_msm_bn254(_dp(out), _dp(bases), _dp(scalars), n), "xlp_dev_msm_bn254")
 
 
 def dev_fft_bn254(data, n, inverse=False):

@@ -1,0 +1,359 @@
+// G1 multi-scalar multiplication over BN254 (alt_bn128) for gfx950 -- the commitment primitive of the fflonk prover
+// (SURVEY.md 8 f4): r = sum_i scalars[i] * bases[i].
+//
+// Replaces  ParallelMultiexp<Curve>::multiexp   src/ffiasm/multiexp.c.hpp:118-164  (as called through
+//           Curve::multiMulByScalar, src/ffiasm/curve.c.hpp, from src/rapidsnark/fflonk_prover.c.hpp:1700,1712)
+// Semantics kept: bases are affine points (x, y) in Fq Montgomery form, (0, 0) = the point at infinity and is skipped
+// (multiexp.c.hpp:41); scalars are raw little-endian integers of 32 bytes (NOT reduced, NOT Montgomery); the result is the
+// group element, returned in affine form (the reference returns a projective representative whose coordinates depend on the
+// thread count; callers normalise it).
+//
+// Design (not the reference's per-thread bucket arrays).  Bucket method with c-bit windows, all windows at once:
+//   1. msm_keys      (window w, point i) -> key = w * 2^c + digit, value = i             one pass over the scalars
+//   2. radix sort of the (key, value) pairs (rocPRIM through hipCUB), bucket start offsets by neighbour comparison
+//   3. msm_buckets   one lane per non-empty-able bucket (w, digit != 0): Jacobian accumulator += its points (mixed addition)
+//   4. msm_groups    per window, 2^c / 256 lanes: running-sum trick on 256 consecutive buckets, then the group's offset * total
+//   5. msm_finish    one lane: sum the groups of each window, Horner over the windows (c doublings each), Jacobian -> affine
+// Fq arithmetic: 8 x 32-bit limbs, Montgomery (R = 2^256), CIOS on v_mad_u64_u32 -- integer-VALU bound like everything else here.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+#include "xlp_internal.hpp"
+
+namespace xlp {
+namespace g1 {
+
+struct Fq { u32 v[8]; };
+// q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+__device__ __constant__ u32 Q_MOD[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+__device__ __constant__ u32 Q_ONE[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u, 0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};   // R mod q
+constexpr u32 Q_N0INV = 0xe4866389u;
+
+__device__ __forceinline__ Fq fzero() { Fq z; for (int i = 0; i < 8; i++) z.v[i] = 0; return z; }
+__device__ __forceinline__ Fq fone() { Fq z; for (int i = 0; i < 8; i++) z.v[i] = Q_ONE[i]; return z; }
+__device__ __forceinline__ bool is_zero(const Fq& a) { u32 o = 0; for (int i = 0; i < 8; i++) o |= a.v[i]; return o == 0; }
+__device__ __forceinline__ bool feq(const Fq& a, const Fq& b) { u32 o = 0; for (int i = 0; i < 8; i++) o |= a.v[i] ^ b.v[i]; return o == 0; }
+
+__device__ __forceinline__ Fq cond_sub(const u32 (&a)[8], u32 hi)
+{
+    u32 d[8];
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u64 s = (u64)a[i] - Q_MOD[i] - borrow;
+        d[i] = (u32)s;
+        borrow = (u32)(s >> 63);
+    }
+    const bool ge = hi != 0 || borrow == 0;
+    Fq r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = ge ? d[i] : a[i];
+    return r;
+}
+__device__ __forceinline__ Fq fadd(const Fq& a, const Fq& b)
+{
+    u32 s[8];
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u64 t = (u64)a.v[i] + b.v[i] + c;
+        s[i] = (u32)t;
+        c = (u32)(t >> 32);
+    }
+    return cond_sub(s, c);
+}
+__device__ __forceinline__ Fq fsub(const Fq& a, const Fq& b)
+{
+    u32 d[8];
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u64 s = (u64)a.v[i] - b.v[i] - borrow;
+        d[i] = (u32)s;
+        borrow = (u32)(s >> 63);
+    }
+    u32 c = 0;
+    Fq r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u64 t = (u64)d[i] + (borrow ? Q_MOD[i] : 0u) + c;
+        r.v[i] = (u32)t;
+        c = (u32)(t >> 32);
+    }
+    return r;
+}
+__device__ __forceinline__ Fq fdbl(const Fq& a) { return fadd(a, a); }
+__device__ __noinline__ Fq fmul(const Fq& a, const Fq& b)
+{
+    u32 t[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const u64 p = (u64)a.v[j] * b.v[i] + t[j] + c;
+            t[j] = (u32)p;
+            c = p >> 32;
+        }
+        u64 s = (u64)t[8] + c;
+        t[8] = (u32)s;
+        t[9] = (u32)(s >> 32);
+        const u32 m = t[0] * Q_N0INV;
+        u64 p = (u64)m * Q_MOD[0] + t[0];
+        c = p >> 32;
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+            p = (u64)m * Q_MOD[j] + t[j] + c;
+            t[j - 1] = (u32)p;
+            c = p >> 32;
+        }
+        s = (u64)t[8] + c;
+        t[7] = (u32)s;
+        t[8] = t[9] + (u32)(s >> 32);
+    }
+    u32 lo[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) lo[i] = t[i];
+    return cond_sub(lo, t[8]);
+}
+__device__ __forceinline__ Fq fsqr(const Fq& a) { return fmul(a, a); }
+
+struct Aff { Fq x, y; };            // (0, 0) = infinity
+struct Jac { Fq x, y, z; };         // z = 0 = infinity
+
+__device__ __forceinline__ Jac jzero() { Jac p; p.x = fone(); p.y = fone(); p.z = fzero(); return p; }
+__device__ __forceinline__ bool jinf(const Jac& p) { return is_zero(p.z); }
+__device__ __forceinline__ bool ainf(const Aff& p) { return is_zero(p.x) && is_zero(p.y); }
+
+// dbl-2009-l (a = 0)
+__device__ __noinline__ Jac jdbl(const Jac& p)
+{
+    if (jinf(p)) return p;
+    const Fq A = fsqr(p.x), B = fsqr(p.y), C = fsqr(B);
+    Fq D = fsub(fsub(fsqr(fadd(p.x, B)), A), C);
+    D = fdbl(D);
+    const Fq E = fadd(fdbl(A), A), F = fsqr(E);
+    Jac r;
+    r.x = fsub(F, fdbl(D));
+    Fq C8 = fdbl(fdbl(fdbl(C)));
+    r.y = fsub(fmul(E, fsub(D, r.x)), C8);
+    r.z = fdbl(fmul(p.y, p.z));
+    return r;
+}
+// madd-2007-bl with the exceptional cases
+__device__ __noinline__ Jac jmadd(const Jac& p, const Aff& q)
+{
+    if (ainf(q)) return p;
+    if (jinf(p)) { Jac r; r.x = q.x; r.y = q.y; r.z = fone(); return r; }
+    const Fq Z1Z1 = fsqr(p.z), U2 = fmul(q.x, Z1Z1), S2 = fmul(fmul(q.y, p.z), Z1Z1);
+    const Fq H = fsub(U2, p.x);
+    Fq rr = fsub(S2, p.y);
+    if (is_zero(H)) {
+        if (is_zero(rr)) { Jac t; t.x = q.x; t.y = q.y; t.z = fone(); return jdbl(t); }
+        return jzero();
+    }
+    rr = fdbl(rr);
+    const Fq HH = fsqr(H), I = fdbl(fdbl(HH)), J = fmul(H, I), V = fmul(p.x, I);
+    Jac r;
+    r.x = fsub(fsub(fsqr(rr), J), fdbl(V));
+    r.y = fsub(fmul(rr, fsub(V, r.x)), fdbl(fmul(p.y, J)));
+    r.z = fsub(fsub(fsqr(fadd(p.z, H)), Z1Z1), HH);
+    return r;
+}
+// add-2007-bl with the exceptional cases
+__device__ __noinline__ Jac jadd(const Jac& p, const Jac& q)
+{
+    if (jinf(q)) return p;
+    if (jinf(p)) return q;
+    const Fq Z1Z1 = fsqr(p.z), Z2Z2 = fsqr(q.z);
+    const Fq U1 = fmul(p.x, Z2Z2), U2 = fmul(q.x, Z1Z1);
+    const Fq S1 = fmul(fmul(p.y, q.z), Z2Z2), S2 = fmul(fmul(q.y, p.z), Z1Z1);
+    const Fq H = fsub(U2, U1);
+    Fq rr = fsub(S2, S1);
+    if (is_zero(H)) {
+        if (is_zero(rr)) return jdbl(p);
+        return jzero();
+    }
+    rr = fdbl(rr);
+    const Fq I = fsqr(fdbl(H)), J = fmul(H, I), V = fmul(U1, I);
+    Jac r;
+    r.x = fsub(fsub(fsqr(rr), J), fdbl(V));
+    r.y = fsub(fmul(rr, fsub(V, r.x)), fdbl(fmul(S1, J)));
+    r.z = fmul(fsub(fsub(fsqr(fadd(p.z, q.z)), Z1Z1), Z2Z2), H);
+    return r;
+}
+// k * p for a small k (<= 16 bits), double-and-add from the top
+__device__ __forceinline__ Jac jmul_small(const Jac& p, u32 k)
+{
+    Jac r = jzero();
+    for (int b = 31 - __clz(k | 1); b >= 0; b--) {
+        r = jdbl(r);
+        if ((k >> b) & 1) r = jadd(r, p);
+    }
+    return k ? r : jzero();
+}
+
+// ----------------------------------------------------------------- kernels
+// digit of scalar i in window w: bits [w * c, w * c + c) of the 256-bit little-endian integer (getChunk, multiexp.c.hpp:23-35)
+__device__ __forceinline__ u32 window_digit(const u32* __restrict__ sc, u32 w, u32 c)
+{
+    const u32 bit = w * c, word = bit >> 5, sh = bit & 31;
+    u64 v = sc[word];
+    if (word + 1 < 8) v |= (u64)sc[word + 1] << 32;
+    return (u32)((v >> sh) & ((1u << c) - 1));
+}
+
+__global__ void msm_keys_kernel(u32* __restrict__ keys, u32* __restrict__ vals, const u32* __restrict__ scalars, const Aff* __restrict__ bases,
+                                const u64 n, const u32 nwin, const u32 c)
+{
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n * nwin) return;
+    const u64 i = gid % n;
+    const u32 w = (u32)(gid / n);
+    u32 d = window_digit(scalars + i * 8, w, c);
+    // points at infinity are skipped: digit 0 is the "no contribution" bucket
+    const Aff b = bases[i];
+    if (ainf(b)) d = 0;
+    keys[gid] = (w << c) | d;
+    vals[gid] = (u32)i;
+}
+
+// start[k] = first sorted position with key k; start[nkeys] = total.  Keys absent from the sorted array inherit the next start.
+__global__ void msm_starts_kernel(u32* __restrict__ start, const u32* __restrict__ sorted_keys, const u64 total, const u32 nkeys)
+{
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid > total) return;
+    const u32 cur = gid < total ? sorted_keys[gid] : nkeys;
+    const u32 prev = gid == 0 ? 0xFFFFFFFFu : sorted_keys[gid - 1];
+    if (gid == 0) { for (u32 k = 0; k <= cur; k++) start[k] = 0; return; }
+    for (u32 k = prev + 1; k <= cur; k++) start[k] = (u32)gid;
+}
+
+__global__ __launch_bounds__(64) void msm_buckets_kernel(Jac* __restrict__ buckets, const u32* __restrict__ start, const u32* __restrict__ sorted_vals,
+                                                          const Aff* __restrict__ bases, const u32 nkeys, const u32 c)
+{
+    const u32 key = blockIdx.x * blockDim.x + threadIdx.x;
+    if (key >= nkeys) return;
+    Jac acc = jzero();
+    if ((key & ((1u << c) - 1)) != 0) {
+        const u32 b = start[key], e = start[key + 1];
+        for (u32 k = b; k < e; k++) acc = jmadd(acc, bases[sorted_vals[k]]);
+    }
+    buckets[key] = acc;
+}
+
+// group g of window w covers digits [g * GS, (g + 1) * GS): out = sum_d d * B_d over the group
+constexpr u32 GS = 256;
+__global__ __launch_bounds__(64) void msm_groups_kernel(Jac* __restrict__ groups, const Jac* __restrict__ buckets, const u32 nwin, const u32 c)
+{
+    const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 nb = 1u << c, gs = nb < GS ? nb : GS, gpw = nb / gs;
+    if (gid >= nwin * gpw) return;
+    const u32 w = gid / gpw, g = gid % gpw;
+    const Jac* __restrict__ B = buckets + ((u64)w << c) + (u64)g * gs;
+    Jac run = jzero(), sum = jzero();
+    for (int d = (int)gs - 1; d >= 0; d--) {          // sum = sum_d (d + 1) * B[d] ... shifted below
+        run = jadd(run, B[d]);
+        sum = jadd(sum, run);
+    }
+    // sum = sum_d (d + 1) B[d]; wanted sum_d (g * gs + d) B[d] = sum + (g * gs - 1) * run  (run = group total); g * gs = 0: sum - run
+    if (g == 0) {
+        Jac neg = run; neg.y = fsub(fzero(), neg.y);
+        groups[gid] = jadd(sum, neg);
+    } else {
+        groups[gid] = jadd(sum, jmul_small(run, g * gs - 1));
+    }
+}
+
+__device__ Fq finv(const Fq& a)          // a^(q - 2)
+{
+    const u32 e[8] = {0xd87cfd45u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    Fq r = fone();
+    for (int i = 255; i >= 0; i--) {
+        r = fsqr(r);
+        if ((e[i >> 5] >> (i & 31)) & 1) r = fmul(r, a);
+    }
+    return r;
+}
+
+__global__ void msm_finish_kernel(Aff* __restrict__ out, const Jac* __restrict__ wsum, const u32 nwin, const u32 c)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    Jac r = jzero();
+    for (int w = (int)nwin - 1; w >= 0; w--) {          // Horner over the windows (multiexp.c.hpp:155-159)
+        for (u32 k = 0; k < c; k++) r = jdbl(r);
+        r = jadd(r, wsum[w]);
+    }
+    Aff a;
+    if (jinf(r)) { a.x = fzero(); a.y = fzero(); }
+    else {
+        const Fq zi = finv(r.z), zi2 = fsqr(zi);
+        a.x = fmul(r.x, zi2);
+        a.y = fmul(r.y, fmul(zi2, zi));
+    }
+    *out = a;
+}
+
+// per-window partial sums of the groups, one lane per window (keeps msm_finish short when 2^c / GS is large)
+__global__ void msm_window_sums_kernel(Jac* __restrict__ wsum, const Jac* __restrict__ groups, const u32 nwin, const u32 gpw)
+{
+    const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwin) return;
+    Jac s = jzero();
+    for (u32 g = 0; g < gpw; g++) s = jadd(s, groups[w * gpw + g]);
+    wsum[w] = s;
+}
+
+}  // namespace g1
+
+// out (device, 8 words: x, y affine Montgomery; (0, 0) = infinity) = sum scalars[i] * bases[i]
+int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 n)
+{
+    using namespace g1;
+    if (n == 0) { XLP_HIP(hipMemsetAsync(out, 0, sizeof(Aff), ctx->stream)); return 0; }
+    if (n >= (1ull << 28)) return xlp_fail("msm_bn254: more than 2^28 points");
+    u32 lg = 0;
+    while ((2ull << lg) <= n) lg++;
+    u32 c = lg > 6 ? lg - 4 : 2;                 // ~16 points per bucket on average
+    if (c > 16) c = 16;
+    if (c < 2) c = 2;
+    const u32 nwin = (256 + c - 1) / c;
+    const u64 total = n * nwin;
+    if (total >= (1ull << 31)) return xlp_fail("msm_bn254: n * windows exceeds 2^31 pairs");
+    const u32 nkeys = nwin << c;
+    const u32 nb = 1u << c, gs = nb < GS ? nb : GS, gpw = nb / gs;
+    // scratch: keys/vals in+out (4 x total u32), starts (nkeys + 1), buckets (nkeys Jac), groups, window sums, sort temp
+    size_t temp_bytes = 0;
+    u32* nul = nullptr;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, nul, nul, nul, nul, (int)total, 0, 32, ctx->stream);
+    const size_t words32 = 4 * total + (nkeys + 2);
+    const size_t jac_count = (size_t)nkeys + (size_t)nwin * gpw + nwin;
+    const size_t bytes = ((words32 * 4 + 255) / 256) * 256 + jac_count * sizeof(Jac) + temp_bytes + 256;
+    u64* scratch = nullptr;
+    if (ctx_scratch(ctx, bytes, 7, &scratch)) return -1;
+    u32* keys = (u32*)scratch;
+    u32* vals = keys + total;
+    u32* keys2 = vals + total;
+    u32* vals2 = keys2 + total;
+    u32* start = vals2 + total;
+    Jac* buckets = (Jac*)((char*)scratch + ((words32 * 4 + 255) / 256) * 256);
+    Jac* groups = buckets + nkeys;
+    Jac* wsum = groups + (size_t)nwin * gpw;
+    void* temp = (void*)(wsum + nwin);
+    const unsigned T = 256;
+    hipLaunchKernelGGL(msm_keys_kernel, dim3((unsigned)((total + T - 1) / T)), dim3(T), 0, ctx->stream, keys, vals, (const u32*)scalars, (const Aff*)bases, n, nwin, c);
+    u32 key_bits = 0;
+    while ((1ull << key_bits) < nkeys) key_bits++;
+    XLP_HIP(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys2, vals, vals2, (int)total, 0, (int)key_bits, ctx->stream));
+    hipLaunchKernelGGL(msm_starts_kernel, dim3((unsigned)((total + 1 + T - 1) / T)), dim3(T), 0, ctx->stream, start, keys2, total, nkeys);
+    hipLaunchKernelGGL(msm_buckets_kernel, dim3((nkeys + 63) / 64), dim3(64), 0, ctx->stream, buckets, start, vals2, (const Aff*)bases, nkeys, c);
+    hipLaunchKernelGGL(msm_groups_kernel, dim3((nwin * gpw + 63) / 64), dim3(64), 0, ctx->stream, groups, buckets, nwin, c);
+    hipLaunchKernelGGL(msm_window_sums_kernel, dim3((nwin + 63) / 64), dim3(64), 0, ctx->stream, wsum, groups, nwin, gpw);
+    hipLaunchKernelGGL(msm_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, (Aff*)out, wsum, nwin, c);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace xlp

@@ -759,6 +759,24 @@ int xlp_fft_bn254(uint64_t* data, uint64_t n, int inverse)
     return 0;
 }
 
+int xlp_dev_msm_bn254(uint64_t* out, const uint64_t* bases, const uint64_t* scalars, uint64_t n)
+{
+    if (ensure_init()) return -1;
+    if (!out || (n && (!bases || !scalars))) return xlp_fail("xlp_dev_msm_bn254: null pointer");
+    return dev_msm_bn254(&g_ctx, out, bases, scalars, n);
+}
+int xlp_msm_bn254(uint64_t* out, const uint64_t* bases, const uint64_t* scalars, uint64_t n)
+{
+    if (ensure_init()) return -1;
+    if (!out || (n && (!bases || !scalars))) return xlp_fail("xlp_msm_bn254: null pointer");
+    DevBuf b, s, o;
+    if (b.alloc((n ? n : 1) * 8 * sizeof(u64)) || s.alloc((n ? n : 1) * 4 * sizeof(u64)) || o.alloc(8 * sizeof(u64))) return -1;
+    if (n) { H2D(b, bases, n * 8 * sizeof(u64)); H2D(s, scalars, n * 4 * sizeof(u64)); }
+    if (dev_msm_bn254(&g_ctx, o.u(), b.u(), s.u(), n)) return -1;
+    D2H(out, o, 8 * sizeof(u64));
+    return 0;
+}
+
 int xlp_linear_hash(uint64_t* out, const uint64_t* src, uint64_t w, uint64_t h)
 {
     if (ensure_init()) return -1;

@@ -107,6 +107,8 @@ u64 bn128_num_nodes(u64 n);
 int dev_merkle_bn128(Ctx* ctx, u64* nodes, const u64* src, u64 w, u64 h);
 int dev_poseidon_bn128(Ctx* ctx, u64* states, u32 t, u64 count);
 int dev_fft_bn254(Ctx* ctx, u64* data, u64 n, int inverse);
+// bn254_msm.hip
+int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 n);
 
 // expr.hip
 int expr_create(xlp_expr_program** out, const u64* code, u64 ncode, u64 ntmp1, u64 ntmp3);
