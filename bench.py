@@ -99,6 +99,60 @@ def merkle_leg(capi, torch, dev):
     return out
 
 
+def bn128_leg(capi, torch, dev):
+    """SURVEY 8 f4 kernels, timed live (HIP events on the library's stream): MerkleTreeBN128::merkelize at the recursivef geometry
+    (2^23 leaves x 12 columns), FFT<RawFr>::fft of 2^24 elements and the G1 multiexp of 2^22 points (the fflonk prover's two
+    primitives).  Synthetic inputs; None when the Poseidon-BN128 tables were not generated."""
+    import numpy as np
+    try:
+        capi.load().xlp_bn128_init(None)
+        if capi.load().xlp_bn128_init(None) != 0:
+            return {"error": capi.load().xlp_last_error().decode()}
+    except Exception as e:     # noqa: BLE001
+        return {"error": str(e)}
+
+    def timed(fn, reps):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    out = {}
+    h, w = 1 << 23, 12
+    src = torch.empty(h * w, dtype=torch.int64, device=dev); capi.dev_fill(src, 0x5EED0F04, 0)
+    nodes = torch.empty(capi.merkle_bn128_num_nodes(h) * 4, dtype=torch.int64, device=dev)
+    ms = timed(lambda: capi.dev_merkle_bn128(nodes, src, w, h), 2)
+    out["merkle_bn128"] = {"workload": "MerkleTreeBN128::merkelize 2^23 x 12 (recursivef cm1)", "ms": round(ms, 2), "leaf_permutations_t5": h, "node_permutations_t17": 559241}
+    del src, nodes
+    n = 1 << 24
+    a = torch.empty(n * 4, dtype=torch.int64, device=dev); capi.dev_fill(a, 0x5EED0F05, 0)
+    a.view(n, 4)[:, 3] &= 0x0FFFFFFFFFFFFFFF
+    ms = timed(lambda: capi.dev_fft_bn254(a, n), 3)
+    out["fft_bn254"] = {"workload": "FFT<RawFr>::fft 2^24", "ms": round(ms, 3), "Melem_per_s": round(n / ms / 1e3, 1)}
+    del a
+    q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    R = (1 << 256) % q
+    pts, cur = [], None                       # 256 multiples of the generator (host integers), replicated
+    for _ in range(256):
+        if cur is None:
+            cur = (1, 2)
+        else:
+            lam = (3 * cur[0] * cur[0] * pow(2 * cur[1], -1, q) if cur == (1, 2) else (2 - cur[1]) * pow(1 - cur[0], -1, q)) % q
+            x = (lam * lam - cur[0] - 1) % q
+            cur = (x, (lam * (cur[0] - x) - cur[1]) % q)
+        pts.append(cur)
+    tab = np.array([[((c * R % q) >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for c in p for i in range(4)] for p in pts], dtype=np.uint64)
+    n = 1 << 22
+    bases = capi.from_np(tab[np.random.default_rng(1).integers(0, 256, size=n)].reshape(-1))
+    sc = torch.empty(n * 4, dtype=torch.int64, device=dev); capi.dev_fill(sc, 0x5EED0F06, 0)
+    res = torch.empty(8, dtype=torch.int64, device=dev)
+    ms = timed(lambda: capi.dev_msm_bn254(res, bases, sc, n), 2)
+    out["msm_bn254"] = {"workload": "G1 multiexp 2^22 points, 256-bit scalars", "ms": round(ms, 2), "Mpoints_per_s": round(n / ms / 1e3, 1)}
+    return out
+
+
 def sharded_commit_leg(capi, torch, dist, dev, world, rank, log_n=23, ncols=751, check=True):
     """SURVEY.md 8e / BASELINE north_star: ONE zkEVM-width section (2^23 x 751, the committed trace cm1) committed by all ranks
     together -- rank g extends its ~751/G columns, one all-to-all over RCCL/xGMI turns column shards into row shards, each rank
@@ -235,6 +289,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bn128", action="store_true", help="skip the BN128 / fflonk kernel leg (N=1 only; a few seconds)")
     ap.add_argument("--no-genproof", action="store_true", help="skip the whole-genProof leg (N=1 only; ~25 s)")
     ap.add_argument("--sharded-commit", type=int, default=-1, help="time the section commit sharded over the ranks (default: on for --gpus > 1; 1 forces it at N=1 "
                     "through RCCL in a world of one)")
@@ -366,6 +421,8 @@ def main():
             line["sharded_commit"] = sharded
         if world == 1:
             line["roofline_merkle"] = merkle_leg(capi, torch, dev)
+            if not args.no_bn128:
+                line["recursivef_fflonk_kernels"] = bn128_leg(capi, torch, dev)
         if world == 1 and not args.no_genproof and args.log_n == LOG_N:
             del src, out
             torch.cuda.empty_cache()
