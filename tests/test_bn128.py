@@ -320,3 +320,37 @@ def test_gpu_msm_bn254_large_properties(xlp):
     # and against the oracle directly: sum over the 256 distinct points of (count * point)
     cnt = np.bincount(idx, minlength=256)
     assert S1 == bo.msm(base_pts, [int(c) for c in cnt])
+
+
+@pytest.mark.gpu
+@needs_constants
+@pytest.mark.parametrize("nbits,steps,nq", [(6, [7, 4], 5), (9, [10, 6, 3], 9)])
+def test_cpp_stark_recursivef_genproof_equals_flow(orc, K, tmp_path, nbits, steps, nq):
+    """The C++ `StarkRecursiveF::genProof` (host/starkRecursiveF.hpp = StarksT<XlpHashBN128>: StarkInfo-driven, starkRecursiveF.cpp:150-650
+    stage for stage) on the mini PIL: its zkin (roots as Fr strings, [query][level][16] sibling groups) equals what the Python flow
+    computes on the oracle with the BN128 trees / transcript"""
+    import json
+    import subprocess
+    from tests import mini_genproof_flow as flow
+    from tests.mini_backends import OracleBackendBN128
+    exe = os.path.join(ROOT, "xlayer_prover_amd", "host", "test_host_shim")
+    flow.toy_stark_files(str(tmp_path), "toy", nbits, steps, nq, seed=nbits)
+    r = subprocess.run([exe, "genproof_bn128", str(tmp_path), "toy"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    Z = json.loads(r.stdout)
+    exp = flow.prove(OracleBackendBN128(orc, bo, K), nbits, steps, nq, seed=nbits)
+    ints = lambda v: [int(x) for x in v]
+    for k in ("root1", "root2", "root3", "root4", "verkey"):
+        assert [int(Z[k])] == exp[k], k
+    assert ints(Z["publics"]) == exp["publics"]
+    assert [ints(e) for e in Z["evals"]] == exp["evals"]
+    assert [x for e in Z["finalPol"] for x in ints(e)] == exp["fri"]["finalPol"]
+    for si in range(1, len(steps)):
+        assert [int(Z[f"s{si}_root"])] == exp["fri"]["roots"][si - 1]
+        for q in range(nq):
+            row, groups = exp["fri"]["si"][si - 1][q]
+            assert ints(Z[f"s{si}_vals"][q]) == row and [ints(g) for g in Z[f"s{si}_siblings"][q]] == groups
+    for q in range(nq):
+        for k, tname in enumerate(["1", "2", "3", "4", "C"]):
+            row, groups = exp["fri"]["s0"][q][k]
+            assert ints(Z[f"s0_vals{tname}"][q]) == row and [ints(g) for g in Z[f"s0_siblings{tname}"][q]] == groups

@@ -56,13 +56,44 @@ public:
     void release() { if (p) xlp_dev_free(p); p = NULL; words = 0; }
 };
 
-class Starks
+// What differs between Starks (Poseidon-Goldilocks trees, Transcript) and StarkRecursiveF (MerkleTreeBN128, TranscriptBN128;
+// starkRecursiveF.cpp:150-650 is starks.cpp:9-404 with those types): the hash policy H of StarksT<H>.
+struct XlpHashGL
+{
+    typedef MerkleTreeGL Tree;
+    typedef Transcript TranscriptT;
+    typedef FRIProof Proof;
+    typedef FRIProve Prove;
+    typedef Goldilocks::Element Root[HASH_SIZE];
+    static constexpr bool kFileTree = true;          // <stark>.consttree in the MerkleTreeGL layout can be mapped instead of computed
+    static void getField(TranscriptT& t, Goldilocks::Element* out) { t.getField(out); }
+    static void putRoot(TranscriptT& t, Goldilocks::Element* r) { t.put(r, HASH_SIZE); }
+    static void putVerkey(TranscriptT& t, Goldilocks::Element* verkey, Goldilocks::Element* /*constRoot*/) { t.put(&verkey[0], 4); }   // starks.cpp:33
+    static void commit(Tree* tree, uint64_t* sec2ns, const uint64_t* secn, uint64_t NExtended, uint64_t N, uint64_t W)
+    {
+        XLP_CHECK(xlp_dev_commit(sec2ns, tree->d_nodes, secn, NExtended, N, W));
+    }
+    static void commitFromHost(Tree* tree, uint64_t* secn, uint64_t* sec2ns, const uint64_t* h_src, uint64_t NExtended, uint64_t N, uint64_t W, double* busyMs)
+    {
+        XLP_CHECK(xlp_dev_commit_from_host(secn, sec2ns, tree->d_nodes, h_src, NExtended, N, W, busyMs));
+    }
+    static void storeRoots(Proof& proof, Goldilocks::Element* r0, Goldilocks::Element* r1, Goldilocks::Element* r2, Goldilocks::Element* r3)
+    {
+        std::memcpy(&proof.proofs.root1[0], r0, HASH_SIZE * sizeof(Goldilocks::Element));
+        std::memcpy(&proof.proofs.root2[0], r1, HASH_SIZE * sizeof(Goldilocks::Element));
+        std::memcpy(&proof.proofs.root3[0], r2, HASH_SIZE * sizeof(Goldilocks::Element));
+        std::memcpy(&proof.proofs.root4[0], r3, HASH_SIZE * sizeof(Goldilocks::Element));
+    }
+};
+
+template <class H>
+class StarksT
 {
 public:
     const Config& config;
     StarkInfo starkInfo;
     uint64_t nrowsStepBatch;
-    Goldilocks::Element constRoot[HASH_SIZE];       // root of the constant tree (= the verification key)
+    typename H::Root constRoot;                     // root of the constant tree (= the verification key)
     bool logTimers = false;
     double lastUploadMs = 0.0;                      // time the copy stream was busy with the witness in the last genProof
     bool pipelineWitness = true;                    // false: upload the witness in one piece first, then commit it (the measurement of what the pipeline hides)
@@ -77,7 +108,7 @@ private:
     uint64_t const2nsOffset = 0;
     uint64_t *d_const_n = NULL, *d_const_2ns_own = NULL, *d_x_n = NULL, *d_x_2ns = NULL, *d_zi = NULL, *d_xdx = NULL, *d_xdwx = NULL;
     uint64_t *d_challenges = NULL, *d_publics = NULL, *d_evals = NULL, *d_work = NULL;
-    MerkleTreeGL* treesGL[STARK_C12_A_NUM_TREES] = {NULL, NULL, NULL, NULL, NULL};
+    typename H::Tree* treesGL[STARK_C12_A_NUM_TREES] = {NULL, NULL, NULL, NULL, NULL};
 
     static uint64_t* dalloc(uint64_t elems)
     {
@@ -103,8 +134,8 @@ private:
         return 0;
     }
     struct Timer {           // TimerStart / TimerStopAndLog (src/utils/timer.hpp:17-27)
-        Starks* s; const char* name; std::chrono::steady_clock::time_point t0;
-        Timer(Starks* s_, const char* n) : s(s_), name(n) { xlp_sync(); t0 = std::chrono::steady_clock::now(); }
+        StarksT* s; const char* name; std::chrono::steady_clock::time_point t0;
+        Timer(StarksT* s_, const char* n) : s(s_), name(n) { xlp_sync(); t0 = std::chrono::steady_clock::now(); }
         ~Timer()
         {
             xlp_sync();
@@ -150,7 +181,7 @@ private:
     }
 
 public:
-    Starks(const Config& config, StarkFiles starkFiles, void* _pAddress)
+    StarksT(const Config& config, StarkFiles starkFiles, void* _pAddress)
         : config(config), starkInfo(starkFiles.zkevmStarkInfo), nrowsStepBatch(1), starkFiles(starkFiles), N(0), NExtended(0), extendBits(0), pAddress(_pAddress)
     {
         if (!config.generateProof()) return;      // starks.hpp:91-93: nothing is initialised if no proof will be generated
@@ -172,8 +203,11 @@ public:
         else fileToDevice(d_const_n, starkFiles.zkevmConstPols, 0, N * starkInfo.nConstants * sizeof(uint64_t));
         // ---- constant tree (LOAD_CONST_TREE_TO_MEMORY / LOAD_CONST_POLS_2NS_TO_MEMORY, starks.hpp:117-146)
         if (!const2nsInSlab) d_const_2ns_own = dalloc(NExtended * starkInfo.nConstants);
-        treesGL[4] = new MerkleTreeGL(NExtended, starkInfo.nConstants, constPols2ns(), true);
-        if (starkFiles.zkevmConstantsTree.size() && fileExists(starkFiles.zkevmConstantsTree)) {
+        treesGL[4] = new typename H::Tree(NExtended, starkInfo.nConstants, constPols2ns(), true);
+        bool treeFromFile = false;
+        if constexpr (H::kFileTree) treeFromFile = starkFiles.zkevmConstantsTree.size() && fileExists(starkFiles.zkevmConstantsTree);
+        if (treeFromFile) {
+          if constexpr (H::kFileTree) {
             // [width, height, source (height x width), nodes] -- build_const_tree.cpp:566-603, MerkleTreeGL(Goldilocks::Element*) merkleTreeGL.hpp:24-32
             uint64_t hdr[2] = {0, 0};
             FILE* fp = fopen(starkFiles.zkevmConstantsTree.c_str(), "rb");
@@ -182,6 +216,7 @@ public:
             if (hdr[0] != starkInfo.nConstants || hdr[1] != NExtended) xlp_exit_process("Starks: constant tree does not match the starkinfo");
             fileToDevice(constPols2ns(), starkFiles.zkevmConstantsTree, 16, NExtended * starkInfo.nConstants * 8);
             fileToDevice(treesGL[4]->d_nodes, starkFiles.zkevmConstantsTree, 16 + NExtended * starkInfo.nConstants * 8, treesGL[4]->getTreeNumElements() * 8);
+          }
         } else {
             XLP_CHECK(xlp_dev_extend(constPols2ns(), d_const_n, NExtended, N, starkInfo.nConstants, NULL));
             treesGL[4]->merkelize();
@@ -211,20 +246,20 @@ public:
         d_work = dalloc(NExtended * (uint64_t)std::max<uint64_t>(4 * FIELD_EXTENSION, starkInfo.qDim * (starkInfo.qDeg + 1)));
         // ---- trees over the extended sections (MERKLE_TREE_ALLOCATION, starks.hpp:185-191): sources are offsets into the shared slab
         const eSection secs[4] = {cm1_2ns, cm2_2ns, cm3_2ns, cm4_2ns};
-        for (int i = 0; i < 4; i++) treesGL[i] = new MerkleTreeGL(NExtended, starkInfo.mapSectionsN.section[secs[i]], NULL, true);
+        for (int i = 0; i < 4; i++) treesGL[i] = new typename H::Tree(NExtended, starkInfo.mapSectionsN.section[secs[i]], NULL, true);
     }
-    ~Starks()
+    ~StarksT()
     {
         if (!config.generateProof()) return;
         for (int i = 0; i < 5; i++) delete treesGL[i];
         uint64_t* all[] = {d_const_n, d_const_2ns_own, d_x_n, d_x_2ns, d_zi, d_xdx, d_xdwx, d_challenges, d_publics, d_evals, d_work};
         for (uint64_t* p : all) xlp_dev_free(p);
     }
-    Starks(const Starks&) = delete;
-    Starks& operator=(const Starks&) = delete;
+    StarksT(const StarksT&) = delete;
+    StarksT& operator=(const StarksT&) = delete;
     uint64_t domainSize() const { return N; }
 
-    void genProof(FRIProof& proof, Goldilocks::Element* publicInputs, Goldilocks::Element verkey[4], Steps* steps)
+    void genProof(typename H::Proof& proof, Goldilocks::Element* publicInputs, Goldilocks::Element verkey[4], Steps* steps)
     {
         lastTimers.clear();
         if (XlpDeviceSlab::get().reserve(slabWords) == NULL) xlp_exit_process("Starks: no device slab");
@@ -233,12 +268,12 @@ public:
         treesGL[4]->d_source = constPols2ns();
         const uint64_t W1 = starkInfo.mapSectionsN.section[cm1_n];
         uint64_t numCommited = starkInfo.nCm1;
-        Transcript transcript;
+        typename H::TranscriptT transcript;
         std::vector<Goldilocks::Element> challenges(NUM_CHALLENGES * FIELD_EXTENSION, Goldilocks::zero());
         std::vector<Goldilocks::Element> evals(starkInfo.evMap.size() * FIELD_EXTENSION, Goldilocks::zero());
-        Goldilocks::Element root0[HASH_SIZE], root1[HASH_SIZE], root2[HASH_SIZE], root3[HASH_SIZE];
+        typename H::Root root0, root1, root2, root3;
         auto challenge = [&](int k) {
-            transcript.getField(&challenges[k * FIELD_EXTENSION]);
+            H::getField(transcript, &challenges[k * FIELD_EXTENSION]);
             XLP_CHECK(xlp_copy_h2d(d_challenges, challenges.data(), challenges.size() * sizeof(uint64_t)));
         };
         // the base-domain sections other than the witness start from zero (prover.cpp:426-430 clears the committed polynomials; in the
@@ -248,7 +283,7 @@ public:
             if (to > from && to <= slabWords) XLP_CHECK(xlp_dev_memset(mem() + from, 0, (to - from) * sizeof(uint64_t)));
         }
         XLP_CHECK(xlp_copy_h2d(d_publics, publicInputs, starkInfo.nPublics * sizeof(uint64_t)));
-        transcript.put(&verkey[0], 4);
+        H::putVerkey(transcript, verkey, constRoot);
         transcript.put(&publicInputs[0], starkInfo.nPublics);
         StepsParams P = params();
         //-------------------------------- 1.- Calculate p_cm1_2ns
@@ -259,10 +294,10 @@ public:
                 XLP_CHECK(xlp_copy_h2d(section(cm1_n), h_cm1, N * W1 * sizeof(uint64_t)));
             }
             Timer t(this, "STARK_STEP_1_LDE_AND_MERKLETREE");
-            if (pipelineWitness) XLP_CHECK(xlp_dev_commit_from_host(section(cm1_n), section(cm1_2ns), treesGL[0]->d_nodes, h_cm1, NExtended, N, W1, &lastUploadMs));
-            else XLP_CHECK(xlp_dev_commit(section(cm1_2ns), treesGL[0]->d_nodes, section(cm1_n), NExtended, N, W1));
+            if (pipelineWitness) H::commitFromHost(treesGL[0], section(cm1_n), section(cm1_2ns), h_cm1, NExtended, N, W1, &lastUploadMs);
+            else H::commit(treesGL[0], section(cm1_2ns), section(cm1_n), NExtended, N, W1);
             treesGL[0]->getRoot(root0);
-            transcript.put(root0, HASH_SIZE);
+            H::putRoot(transcript, root0);
         }
         //-------------------------------- 2.- Calculate plookups h1 and h2
         challenge(0);   // u
@@ -289,9 +324,9 @@ public:
         }
         {
             Timer t(this, "STARK_STEP_2_LDE_AND_MERKLETREE");
-            XLP_CHECK(xlp_dev_commit(section(cm2_2ns), treesGL[1]->d_nodes, section(cm2_n), NExtended, N, starkInfo.mapSectionsN.section[cm2_n]));
+            H::commit(treesGL[1], section(cm2_2ns), section(cm2_n), NExtended, N, starkInfo.mapSectionsN.section[cm2_n]);
             treesGL[1]->getRoot(root1);
-            transcript.put(root1, HASH_SIZE);
+            H::putRoot(transcript, root1);
         }
         //-------------------------------- 3.- Compute Z polynomials
         challenge(2);   // gamma
@@ -322,9 +357,9 @@ public:
         }
         {
             Timer t(this, "STARK_STEP_3_LDE_AND_MERKLETREE");
-            XLP_CHECK(xlp_dev_commit(section(cm3_2ns), treesGL[2]->d_nodes, section(cm3_n), NExtended, N, starkInfo.mapSectionsN.section[cm3_n]));
+            H::commit(treesGL[2], section(cm3_2ns), section(cm3_n), NExtended, N, starkInfo.mapSectionsN.section[cm3_n]);
             treesGL[2]->getRoot(root2);
-            transcript.put(root2, HASH_SIZE);
+            H::putRoot(transcript, root2);
         }
         //-------------------------------- 4. Compute C Polynomial
         challenge(4);
@@ -348,7 +383,7 @@ public:
             Timer t(this, "STARK_STEP_4_MERKLETREE");
             treesGL[3]->merkelize();
             treesGL[3]->getRoot(root3);
-            transcript.put(root3, HASH_SIZE);
+            H::putRoot(transcript, root3);
         }
         //-------------------------------- 5. Compute FRI Polynomial
         challenge(7);   // xi
@@ -399,12 +434,11 @@ public:
         {
             Timer t(this, "STARK_STEP_FRI");
             Polinomial friPol(NExtended >> (starkInfo.starkStruct.nBitsExt - starkInfo.starkStruct.steps.back().nBits), FIELD_EXTENSION, "friPol");
-            FRIProve::prove(proof, treesGL, transcript, friPol, starkInfo.starkStruct.nBitsExt, starkInfo, section(f_2ns));
+            H::Prove::prove(proof, treesGL, transcript, friPol, starkInfo.starkStruct.nBitsExt, starkInfo, section(f_2ns));
         }
         proof.proofs.setEvals(evals.data());
-        std::memcpy(&proof.proofs.root1[0], root0, sizeof root0);
-        std::memcpy(&proof.proofs.root2[0], root1, sizeof root1);
-        std::memcpy(&proof.proofs.root3[0], root2, sizeof root2);
-        std::memcpy(&proof.proofs.root4[0], root3, sizeof root3);
+        H::storeRoots(proof, root0, root1, root2, root3);
     }
 };
+
+typedef StarksT<XlpHashGL> Starks;

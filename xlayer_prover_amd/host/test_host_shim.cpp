@@ -8,6 +8,7 @@
 #include "starks_mini.hpp"
 #include "starks.hpp"
 #include "xlp_host_bn128.hpp"
+#include "starkRecursiveF.hpp"
 
 // `polinomial <n> <seed>`: Polinomial::batchInverse / calculateZ / calculateH1H2 through STRIDED views of one slab
 // (offset > dim, as the section views of starks.cpp:108-184 are), results as JSON for the oracle comparison.
@@ -204,8 +205,33 @@ static int bn128_mode(uint64_t h, uint64_t w, uint64_t seed)
     return 0;
 }
 
+// `genproof_bn128 <dir> <name>`: StarkRecursiveF::genProof (host/starkRecursiveF.hpp: the Starks flow with MerkleTreeBN128 trees,
+// TranscriptBN128 and 16-ary openings) on the files of `genproof`; prints the recursivef-style zkin + publics + the constant root
+static int genproof_bn128_mode(const std::string& dir, const std::string& name)
+{
+    std::vector<Goldilocks::Element> cm1 = read_u64_file(dir + "/" + name + ".commit"), publics = read_u64_file(dir + "/" + name + ".publics");
+    Config config;
+    config.runFileGenFinalProof = true;
+    StarkRecursiveF starks(config, {dir + "/" + name + ".const", false, "", dir + "/" + name + ".starkinfo.json"}, cm1.data());
+    XlpSteps steps(dir, name);
+    const StarkStruct& ss = starks.starkInfo.starkStruct;
+    FRIProofC12 proof(1ULL << ss.steps.back().nBits, FIELD_EXTENSION, ss.steps.size(), starks.starkInfo.evMap.size(), starks.starkInfo.nPublics);
+    for (uint64_t i = 0; i < starks.starkInfo.nPublics; i++) proof.publics[i] = publics[i];
+    starks.genProof(proof, publics.data(), &steps);
+    const std::string zkin = proof2zkinStarkC12(proof);
+    std::ostringstream os;
+    os << zkin.substr(0, zkin.size() - 1) << ",\"publics\":";
+    xlp_json::arr(os, proof.publics);
+    os << ",\"verkey\":\"" << RawFr::field.toString(starks.constRoot[0], 10) << "\"}";
+    const std::string out = os.str();
+    fwrite(out.data(), 1, out.size(), stdout);
+    printf("\n");
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
+    if (argc == 4 && std::string(argv[1]) == "genproof_bn128") { const int r = genproof_bn128_mode(argv[2], argv[3]); XlpDeviceSlab::get().release(); xlp_shutdown(); return r; }
     if (argc == 5 && std::string(argv[1]) == "bn128") { const int r = bn128_mode(strtoull(argv[2], 0, 10), strtoull(argv[3], 0, 10), strtoull(argv[4], 0, 0)); xlp_shutdown(); return r; }
     if ((argc == 4 || argc == 5) && std::string(argv[1]) == "genproof") { const int r = genproof_mode(argv[2], argv[3], argc == 5); XlpDeviceSlab::get().release(); xlp_shutdown(); return r; }
     if ((argc == 6 || argc == 7) && std::string(argv[1]) == "bundle") {
