@@ -174,3 +174,56 @@ def _cpp_bundle_verkey(bundle, cfg_file):
     r = subprocess.run([EXE, "bundle", bundle, "recursive1", "1", str(seed)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     return json.loads(r.stdout)["verkey"], None
+
+
+@pytest.mark.gpu
+def test_e2e_chain_batch_aggregated_final(orc, tmp_path):
+    """BASELINE configs[4] minus the SNARK wrap, in C++ (host/prover.hpp through `zkprover_batch --e2e`): two consecutive batch proofs
+    (zkEVM programs at 2^13 rows; c12a, recursive1 at their real geometry) -> Prover::genAggregatedProof (joinzkin + the recursive2
+    STARK) -> Prover::genFinalProof up to the recursivef STARK (real geometry 2^17 x 16, Poseidon-BN128 trees and transcript).
+    The aggregated proof verifies on the Goldilocks oracle and carries the joined publics; the recursivef proof verifies on the BN128
+    oracle (TranscriptBN128 replay, MerkleTreeBN128 openings, FRI folds, final degree)."""
+    import torch
+    from oracle import bn128_oracle as bo
+    from tools import make_stark_bundle as B
+    from tools import zkevm_geometry as G
+    from tests.zkin_verify import verify_zkin, verify_zkin_bn128, ints
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    const = os.path.join(ROOT, "xlayer_prover_amd", "chelpers", "poseidon_bn128.bin")
+    for c in ("zkevm", "c12a", "recursive1", "recursive2", "recursivef"):
+        if not _programs_built(c):
+            pytest.skip("converted reference programs not built (needs the reference tree at build time)")
+    if not os.path.exists(const):
+        pytest.skip("poseidon_bn128.bin not generated")
+    geo = {"zkevm": (13, True), "c12a": (20, False), "recursive1": (17, False), "recursive2": (17, False), "recursivef": (17, False)}
+    bundles = {c: B.make(c, ln, al, out=str(tmp_path / c)) for c, (ln, al) in geo.items()}
+    cfg = _batch_config(tmp_path, bundles)
+    exe = os.path.join(HOST, "zkprover_batch")
+    r = subprocess.run([exe, "-c", cfg, "--e2e"], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.strip().splitlines()]
+    assert [l["stage"] for l in lines] == ["genBatchProof#1", "genBatchProof#2", "genAggregatedProof", "genFinalProof(recursivef)"]
+    assert lines[0]["output_fnv"] != lines[1]["output_fnv"]
+    assert "STARK_RECURSIVE_2_PROOF_BATCH_PROOF" in lines[2]["timers_s"] and "STARK_RECURSIVE_F_PROOF_BATCH_PROOF" in lines[3]["timers_s"]
+    # ---- the aggregated (recursive2) proof
+    Z = json.load(open(tmp_path / "aggregated_proof.output.json"))
+    Z["verkey"] = lines[2]["verkey"]
+    si = G.synth_starkinfo("recursive2", 17, False)
+    steps = [s["nBits"] for s in si["starkStruct"]["steps"]]
+    W = si["mapSectionsN"]
+    rep = verify_zkin(orc, Z, 17, 20, steps, si["starkStruct"]["nQueries"], {"1": W["cm1_2ns"], "2": 0, "3": W["cm3_2ns"], "4": W["cm4_2ns"], "C": si["nConstants"]})
+    assert rep["folds"] == si["starkStruct"]["nQueries"] * (len(steps) - 1)
+    assert len(Z["publics"]) == 48 and ints(Z["publics"][44:48]) == ints(lines[2]["verkey"])       # joined publics + recursive2's own constRoot
+    # ---- the recursivef proof
+    ZF = json.load(open(tmp_path / "recursivef.zkin.json"))
+    sf = G.synth_starkinfo("recursivef", 17, False)
+    assert sf["starkStruct"]["verificationHashType"] == "BN128"
+    stepsf = [s["nBits"] for s in sf["starkStruct"]["steps"]]
+    Wf = sf["mapSectionsN"]
+    K = bo.Constants(const)
+    repf = verify_zkin_bn128(orc, bo, K, ZF, 17, 21, stepsf, sf["starkStruct"]["nQueries"],
+                             {"1": Wf["cm1_2ns"], "2": 0, "3": Wf["cm3_2ns"], "4": Wf["cm4_2ns"], "C": sf["nConstants"]})
+    assert repf["verkey"] == int(lines[3]["verkey"])                                                 # rebuilt from the first opening == the prover's constant root
+    assert repf["folds"] == sf["starkStruct"]["nQueries"] * (len(stepsf) - 1) and repf["paths"] >= 32 * 8
+    assert ZF["publics"] == Z["publics"][:len(ZF["publics"])] and ZF["aggregatorAddr"] == "0"

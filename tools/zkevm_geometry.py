@@ -24,6 +24,11 @@ CIRCUITS = {
     # the STARK of Prover::genAggregatedProof (prover.cpp:782): same geometry as recursive1, its own constraint programs
     "recursive2": {"log_n": 17, "ext": 3, "widths": (18, 0, 39, 21, 6), "steps": ("step3prev", "step3", "step42ns", "step52ns"),
                    "lookups": 0, "zs": 2, "queries": 43, "fri": [20, 16, 12, 9, 6]},
+    # the STARK of Prover::genFinalProof (StarkRecursiveF, prover.cpp:871): Poseidon-BN128 trees / transcript.  N = 2^17, blow-up 16 and the
+    # widths are read off its converted programs (cm1_2ns at word 60 * 2^17, next-row distance 16); FRI steps and query count are a choice
+    # (its starkstruct is absent from the snapshot)
+    "recursivef": {"log_n": 17, "ext": 4, "widths": (12, 0, 21, 21, 6), "steps": ("step3prev", "step3", "step42ns", "step52ns"),
+                   "lookups": 0, "zs": 2, "queries": 32, "fri": [21, 17, 13, 9, 5], "hash": "BN128"},
 }
 
 
@@ -340,7 +345,7 @@ def synth_starkinfo(circ, log_n, aliased=False, fri_steps=None, queries=None):
     order = [name for name, _, _ in secs]
     rows = {name: 1 << (log_n + (ext if e else 0)) for name, _, e in secs}
     step = {"tmpUsed": 0, "first": [], "i": [], "last": []}
-    j = {"starkStruct": {"nBits": log_n, "nBitsExt": lne, "nQueries": queries or C["queries"], "verificationHashType": "GL", "steps": [{"nBits": b} for b in fri_steps]},
+    j = {"starkStruct": {"nBits": log_n, "nBitsExt": lne, "nQueries": queries or C["queries"], "verificationHashType": C.get("hash", "GL"), "steps": [{"nBits": b} for b in fri_steps]},
          "mapTotalN": L["end"][0], "nConstants": nconst, "nPublics": info["npub"], "nCm1": counts["cm1_n"], "nCm2": counts["cm2_n"], "nCm3": counts["cm3_n"],
          "nCm4": counts["cm4_n"], "friExpId": 0, "nExps": len(exp2pol), "qDim": 3, "qDeg": W["cm4_n"] // 3,
          "mapDeg": rows, "mapOffsets": {name: L[name][0] for name in order}, "mapSections": {name: [] for name in order}, "mapSectionsN": {name: W[name] for name in order},

@@ -21,6 +21,7 @@ public:
     std::string c12aConstPols, c12aConstantsTree, c12aStarkInfo, c12aVerkey;
     std::string recursive1ConstPols, recursive1ConstantsTree, recursive1StarkInfo, recursive1Verkey;
     std::string recursive2ConstPols, recursive2ConstantsTree, recursive2StarkInfo, recursive2Verkey;
+    std::string recursivefConstPols, recursivefConstantsTree, recursivefStarkInfo, recursivefVerkey;
     std::string xlpChelpersPath;
     bool xlpSyntheticLookups = false;
     uint64_t xlpDevice = 0;
@@ -44,10 +45,11 @@ public:
         ParseString(config, "proofFile", "PROOF_FILE", proofFile, "proof.json");
         ParseString(config, "zkevmCmPols", "ZKEVM_CM_POLS", zkevmCmPols, "");
         ParseString(config, "zkevmCmPolsAfterExecutor", "ZKEVM_CM_POLS_AFTER_EXECUTOR", zkevmCmPolsAfterExecutor, "");
-        struct { const char* stark; std::string *c, *t, *s, *v; } S[4] = {{"zkevm", &zkevmConstPols, &zkevmConstantsTree, &zkevmStarkInfo, &zkevmVerkey},
+        struct { const char* stark; std::string *c, *t, *s, *v; } S[5] = {{"zkevm", &zkevmConstPols, &zkevmConstantsTree, &zkevmStarkInfo, &zkevmVerkey},
                                                                           {"c12a", &c12aConstPols, &c12aConstantsTree, &c12aStarkInfo, &c12aVerkey},
                                                                           {"recursive1", &recursive1ConstPols, &recursive1ConstantsTree, &recursive1StarkInfo, &recursive1Verkey},
-                                                                          {"recursive2", &recursive2ConstPols, &recursive2ConstantsTree, &recursive2StarkInfo, &recursive2Verkey}};
+                                                                          {"recursive2", &recursive2ConstPols, &recursive2ConstantsTree, &recursive2StarkInfo, &recursive2Verkey},
+                                                                          {"recursivef", &recursivefConstPols, &recursivefConstantsTree, &recursivefStarkInfo, &recursivefVerkey}};
         for (auto& s : S) {                                        // config.cpp:238-268: <configPath>/<stark>/<stark>.{const,consttree,starkinfo.json,verkey.json}
             const std::string n = s.stark, up = upper(n), dir = configPath + "/" + n + "/" + n;
             ParseString(config, (n + "ConstPols").c_str(), (up + "_CONST_POLS").c_str(), *s.c, dir + ".const");

@@ -9,6 +9,7 @@
 #include <functional>
 #include <sys/stat.h>
 #include "starks.hpp"
+#include "starkRecursiveF.hpp"
 
 class ProverRequest
 {
@@ -17,7 +18,10 @@ public:
     typedef std::function<void(const std::string& zkin, Goldilocks::Element* cmPols, uint64_t degree, uint64_t nCols)> WitnessCalculator;
     std::string uuid = "00000000-0000-0000-0000-000000000000", timestamp = "0", filePrefix;
     Executor executor;
-    WitnessCalculator c12aWitness, recursive1Witness;
+    WitnessCalculator c12aWitness, recursive1Witness, recursive2Witness, recursivefWitness;
+    std::string aggregatedProofInput1, aggregatedProofInput2, aggregatedProofOutput;     // zkin JSON texts (prover.cpp:674-783)
+    std::string finalProofInput, recursivefProofOutput;                                  // prover.cpp:836-885
+    std::string aggregatorAddress = "0";
     int result = 0;                                  // ZKR_SUCCESS
     std::string batchProofOutput;                    // zkin of the recursive1 proof + publics: the input of genAggregatedProof (prover.cpp:653)
     std::string publicsJson, proofJson;
@@ -58,10 +62,13 @@ class Prover
     }
 
 public:
-    Starks *starkZkevm = NULL, *starksC12a = NULL, *starksRecursive1 = NULL;
+    Starks *starkZkevm = NULL, *starksC12a = NULL, *starksRecursive1 = NULL, *starksRecursive2 = NULL;
+    StarkRecursiveF* starksRecursiveF = NULL;
     ZkevmSteps* zkevmSteps = NULL;
     C12aSteps* c12aSteps = NULL;
     Recursive1Steps* recursive1Steps = NULL;
+    Recursive2Steps* recursive2Steps = NULL;
+    StarkRecursiveFSteps* recursivefSteps = NULL;
 
     Prover(Goldilocks& fr, PoseidonGoldilocks& poseidon, const Config& config) : fr(fr), poseidon(poseidon), config(config)
     {
@@ -72,6 +79,11 @@ public:
         StarkInfo z(config.zkevmStarkInfo), c(config.c12aStarkInfo), r(config.recursive1StarkInfo);
         auto cm1Bytes = [](const StarkInfo& s) { return (s.mapOffsets.section[cm1_n] + (1ULL << s.starkStruct.nBits) * s.mapSectionsN.section[cm1_n]) * sizeof(Goldilocks::Element); };
         polsSize = std::max(cm1Bytes(z), std::max(cm1Bytes(c), cm1Bytes(r)));
+        // the aggregation / final STARKs exist when their starkinfo is configured and present (prover.cpp:128-160 creates all five)
+        const bool haveR2 = config.recursive2StarkInfo.size() && fileExists(config.recursive2StarkInfo);
+        const bool haveRF = config.recursivefStarkInfo.size() && fileExists(config.recursivefStarkInfo);
+        if (haveR2) polsSize = std::max<uint64_t>(polsSize, cm1Bytes(StarkInfo(config.recursive2StarkInfo)));
+        if (haveRF) polsSize = std::max<uint64_t>(polsSize, cm1Bytes(StarkInfo(config.recursivefStarkInfo)));
         XLP_CHECK(xlp_host_alloc(&pAddress, polsSize));
         starkZkevm = new Starks(config, {config.zkevmConstPols, config.mapConstPolsFile, config.zkevmConstantsTree, config.zkevmStarkInfo}, pAddress);
         starksC12a = new Starks(config, {config.c12aConstPols, config.mapConstPolsFile, config.c12aConstantsTree, config.c12aStarkInfo}, pAddress);
@@ -79,11 +91,19 @@ public:
         zkevmSteps = new ZkevmSteps(dirOf(config.zkevmStarkInfo));
         c12aSteps = new C12aSteps(dirOf(config.c12aStarkInfo));
         recursive1Steps = new Recursive1Steps(dirOf(config.recursive1StarkInfo));
+        if (haveR2) {
+            starksRecursive2 = new Starks(config, {config.recursive2ConstPols, config.mapConstPolsFile, config.recursive2ConstantsTree, config.recursive2StarkInfo}, pAddress);
+            recursive2Steps = new Recursive2Steps(dirOf(config.recursive2StarkInfo));
+        }
+        if (haveRF) {
+            starksRecursiveF = new StarkRecursiveF(config, {config.recursivefConstPols, config.mapConstPolsFile, "", config.recursivefStarkInfo}, pAddress);
+            recursivefSteps = new StarkRecursiveFSteps(dirOf(config.recursivefStarkInfo));
+        }
     }
     ~Prover()
     {
-        delete zkevmSteps; delete c12aSteps; delete recursive1Steps;
-        delete starkZkevm; delete starksC12a; delete starksRecursive1;
+        delete zkevmSteps; delete c12aSteps; delete recursive1Steps; delete recursive2Steps; delete recursivefSteps;
+        delete starkZkevm; delete starksC12a; delete starksRecursive1; delete starksRecursive2; delete starksRecursiveF;
         if (pAddress) xlp_host_free(pAddress);
         XlpDeviceSlab::get().release();
     }
@@ -208,5 +228,82 @@ public:
             if (config.saveOutputToFile || config.saveProofToFile) json2file(publicStarkJson, req.publicsOutputFile());
             delete fproof;
         }
+    }
+    // Prover::genAggregatedProof (prover.cpp:674-783): two batch (or aggregated) proofs -> joinzkin -> recursive2 STARK
+    void genAggregatedProof(ProverRequest* pProverRequest)
+    {
+        if (!config.generateProof() || pProverRequest == NULL || !starksRecursive2) xlp_exit_process("Prover::genAggregatedProof: recursive2 is not configured");
+        ProverRequest& req = *pProverRequest;
+        req.timers.clear();
+        Tm total(&req, "PROVER_AGGREGATED_PROOF");
+        const xlp_json::Value in1 = xlp_json::Parser(req.aggregatedProofInput1).value(), in2 = xlp_json::Parser(req.aggregatedProofInput2).value();
+        // the second proof must continue the first (prover.cpp:695-728): chainId, forkId, state root, acc input hash, batch number
+        auto same = [&](size_t a, size_t b) { return in1["publics"][a].str() == in2["publics"][b].str(); };
+        bool ok = same(17, 17) && same(18, 18) && same(43, 16);
+        for (size_t i = 0; i < 8; i++) ok = ok && same(19 + i, i) && same(27 + i, 8 + i);
+        if (!ok) { req.result = 1; /* ZKR_AGGREGATED_PROOF_INVALID_INPUT */ return; }
+        Goldilocks::Element recursive2Verkey[4];
+        verkey(config.recursive2Verkey, starksRecursive2, recursive2Verkey);
+        std::string vk = "{\"constRoot\":[";
+        for (int i = 0; i < 4; i++) vk += (i ? "," : "") + Goldilocks::toString(recursive2Verkey[i]);
+        vk += "]}";
+        const std::string zkinInputRecursive2 = joinzkin(in1, in2, xlp_json::Parser(vk).value(), starksRecursive2->starkInfo.starkStruct.steps.size());
+        const xlp_json::Value joined = xlp_json::Parser(zkinInputRecursive2).value();
+        const uint64_t nPublics = starksRecursive2->starkInfo.nPublics;
+        std::vector<Goldilocks::Element> publics(nPublics, Goldilocks::zero());
+        for (uint64_t i = 0; i < 44 && i < nPublics; i++) publics[i] = Goldilocks::fromU64(strtoull(joined["publics"][i].str().c_str(), NULL, 10));
+        for (uint64_t i = 0; i < 4 && 44 + i < nPublics; i++) publics[44 + i] = recursive2Verkey[i];
+        std::ostringstream pj;
+        xlp_json::arr(pj, publics);
+        Goldilocks::Element* cmPols = (Goldilocks::Element*)pAddress;
+        {
+            Tm t(&req, "STARK_GEN_AND_CALC_WITNESS_RECURSIVE2");
+            if (!req.recursive2Witness) xlp_exit_process("Prover::genAggregatedProof: no recursive2 witness calculator");
+            req.recursive2Witness(zkinInputRecursive2, cmPols, starksRecursive2->domainSize(), starksRecursive2->starkInfo.nCm1);
+        }
+        const StarkStruct& ss = starksRecursive2->starkInfo.starkStruct;
+        FRIProof fproof(1ULL << ss.steps.back().nBits, FIELD_EXTENSION, ss.steps.size(), starksRecursive2->starkInfo.evMap.size(), nPublics);
+        {
+            Tm t(&req, "STARK_RECURSIVE_2_PROOF_BATCH_PROOF");
+            starksRecursive2->genProof(fproof, publics.data(), recursive2Verkey, recursive2Steps);
+        }
+        for (const auto& kv : starksRecursive2->lastTimers) req.timers.emplace_back("recursive2." + kv.first, kv.second);
+        req.aggregatedProofOutput = withMembers(proof2zkinStark(fproof), ",\"publics\":" + pj.str());
+        req.publicsJson = pj.str();
+        if (config.saveOutputToFile) json2file(req.aggregatedProofOutput, req.filePrefix + "aggregated_proof.output.json");
+        req.result = 0;
+    }
+
+    // Prover::genFinalProof (prover.cpp:836-885 up to the recursivef proof): aggregated proof -> StarkRecursiveF (BN128 trees and transcript).
+    // The final circom witness and the fflonk prover behind it (prover.cpp:887-960) are not part of this build: the output is the
+    // recursivef zkin the final circuit would consume.
+    void genFinalProof(ProverRequest* pProverRequest)
+    {
+        if (!config.generateProof() || pProverRequest == NULL || !starksRecursiveF) xlp_exit_process("Prover::genFinalProof: recursivef is not configured");
+        ProverRequest& req = *pProverRequest;
+        req.timers.clear();
+        Tm total(&req, "PROVER_FINAL_PROOF");
+        const xlp_json::Value zkinFinal = xlp_json::Parser(req.finalProofInput).value();
+        const uint64_t nPublics = starksRecursiveF->starkInfo.nPublics;
+        std::vector<Goldilocks::Element> publics(nPublics, Goldilocks::zero());
+        for (uint64_t i = 0; i < nPublics; i++) publics[i] = Goldilocks::fromU64(strtoull(zkinFinal["publics"][i].str().c_str(), NULL, 10));
+        Goldilocks::Element* cmPols = (Goldilocks::Element*)pAddress;
+        {
+            Tm t(&req, "STARK_GEN_AND_CALC_WITNESS_RECURSIVEF");
+            if (!req.recursivefWitness) xlp_exit_process("Prover::genFinalProof: no recursivef witness calculator");
+            req.recursivefWitness(req.finalProofInput, cmPols, starksRecursiveF->domainSize(), starksRecursiveF->starkInfo.nCm1);
+        }
+        const StarkStruct& ss = starksRecursiveF->starkInfo.starkStruct;
+        FRIProofC12 fproof(1ULL << ss.steps.back().nBits, FIELD_EXTENSION, ss.steps.size(), starksRecursiveF->starkInfo.evMap.size(), nPublics);
+        {
+            Tm t(&req, "STARK_RECURSIVE_F_PROOF_BATCH_PROOF");
+            starksRecursiveF->genProof(fproof, publics.data(), recursivefSteps);
+        }
+        for (const auto& kv : starksRecursiveF->lastTimers) req.timers.emplace_back("recursivef." + kv.first, kv.second);
+        std::ostringstream pj;
+        xlp_json::arr(pj, publics);
+        req.recursivefProofOutput = withMembers(proof2zkinStarkC12(fproof), ",\"publics\":" + pj.str() + ",\"aggregatorAddr\":\"" + req.aggregatorAddress + "\"");
+        if (config.saveProofToFile) json2file(req.recursivefProofOutput, req.filePrefix + "recursivef.proof.json");
+        req.result = 0;
     }
 };

@@ -190,3 +190,4 @@ struct ZkevmSteps : XlpSteps { ZkevmSteps(const std::string& dir) : XlpSteps(dir
 struct C12aSteps : XlpSteps { C12aSteps(const std::string& dir) : XlpSteps(dir, "c12a") {} };
 struct Recursive1Steps : XlpSteps { Recursive1Steps(const std::string& dir) : XlpSteps(dir, "recursive1") {} };
 struct Recursive2Steps : XlpSteps { Recursive2Steps(const std::string& dir) : XlpSteps(dir, "recursive2") {} };
+struct StarkRecursiveFSteps : XlpSteps { StarkRecursiveFSteps(const std::string& dir) : XlpSteps(dir, "recursivef") {} };   // starkRecursiveFSteps.hpp

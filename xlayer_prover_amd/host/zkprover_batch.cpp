@@ -1,5 +1,7 @@
 // zkProver in file mode for a batch proof (src/main.cpp:83-112 runFileGenBatchProof -> Prover::genBatchProof) on the GPU build:
-//     zkprover_batch -c config.json [--proofs K] [--seed S] [--sequential-upload] [--timers]
+//     zkprover_batch -c config.json [--proofs K] [--seed S] [--sequential-upload] [--timers] [--e2e]
+// --e2e: BASELINE configs[4] minus the SNARK wrap -- two consecutive batch proofs, Prover::genAggregatedProof over them (joinzkin + the recursive2
+// STARK) and Prover::genFinalProof up to the recursivef STARK (Poseidon-BN128 trees / transcript); needs recursive2 / recursivef in the config.
 // The executor and the two circom witness calculators are CPU subsystems outside this path and their inputs
 // (the 75 GB archive) are absent: they are replaced by stand-ins that leave a synthetic witness in host memory where the real
 // ones would -- the executor's from --seed, the calculators' from a hash of the zkin proof they are given, so that every STARK
@@ -33,7 +35,7 @@ int main(int argc, char** argv)
     std::string cfg;
     int proofs = 2;
     uint64_t seed = 0x5EED0401;
-    bool sequential = false, timers = false;
+    bool sequential = false, timers = false, e2e = false;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "-c" && i + 1 < argc) cfg = argv[++i];
@@ -41,6 +43,7 @@ int main(int argc, char** argv)
         else if (a == "--seed" && i + 1 < argc) seed = strtoull(argv[++i], NULL, 0);
         else if (a == "--sequential-upload") sequential = true;
         else if (a == "--timers") timers = true;
+        else if (a == "--e2e") e2e = true;
         else { fprintf(stderr, "usage: %s -c config.json [--proofs K] [--seed S] [--sequential-upload] [--timers]\n", argv[0]); return 2; }
     }
     if (cfg.empty()) { fprintf(stderr, "missing -c config.json\n"); return 2; }
@@ -63,6 +66,52 @@ int main(int argc, char** argv)
     req.executor = [&](Goldilocks::Element* p, uint64_t n, uint64_t w) { syntheticWitness(p, n, w, seed); };
     req.c12aWitness = [&](const std::string& zkin, Goldilocks::Element* p, uint64_t n, uint64_t w) { syntheticWitness(p, n, w, fnv1a(zkin)); };
     req.recursive1Witness = req.c12aWitness;
+    req.recursive2Witness = req.c12aWitness;
+    req.recursivefWitness = req.c12aWitness;
+    if (e2e) {
+        // two CONSECUTIVE batches: the second executor stand-in starts from the state the first one ended in (the registers the publics are
+        // read from, prover.cpp:494-559), so that genAggregatedProof's continuity checks (prover.cpp:695-728) hold as they do for real batches
+        auto stat = [&](const char* what, const ProverRequest& r, const std::string& out, const std::string& verkey = "") {
+            std::ostringstream os;
+            os << "{\"stage\":\"" << what << "\"," << (verkey.size() ? "\"verkey\":" + verkey + "," : std::string()) << "\"timers_s\":{";
+            bool first = true;
+            for (const auto& kv : r.timers) { os << (first ? "" : ",") << "\"" << kv.first << "\":" << kv.second; first = false; }
+            os << "},\"output_bytes\":" << out.size() << ",\"output_fnv\":\"" << std::hex << fnv1a(out) << std::dec << "\"}";
+            printf("%s\n", os.str().c_str()); fflush(stdout);
+        };
+        prover.genBatchProof(&req);
+        const std::string proofA = req.batchProofOutput;
+        stat("genBatchProof#1", req, proofA);
+        const xlp_json::Value pa = xlp_json::Parser(req.publicsJson).value();
+        auto pub = [&](size_t i) { return (uint64_t)strtoull(pa[i].str().c_str(), NULL, 10); };
+        req.executor = [&](Goldilocks::Element* p, uint64_t n, uint64_t w) {
+            syntheticWitness(p, n, w, seed + 1);
+            if (w > 617)
+                for (uint64_t k = 0; k < 8; k++) { p[581 - k] = Goldilocks::fromU64(pub(19 + k)); p[589 - k] = Goldilocks::fromU64(pub(27 + k)); }
+            if (w > 617) { p[615] = Goldilocks::fromU64(pub(43)); p[617] = Goldilocks::fromU64(pub(17)); p[614] = Goldilocks::fromU64(pub(18)); }
+        };
+        prover.genBatchProof(&req);
+        const std::string proofB = req.batchProofOutput;
+        stat("genBatchProof#2", req, proofB);
+        req.aggregatedProofInput1 = proofA; req.aggregatedProofInput2 = proofB;
+        prover.genAggregatedProof(&req);
+        if (req.result != 0) { fprintf(stderr, "genAggregatedProof: invalid input (the two proofs are not consecutive)\n"); return 1; }
+        {
+            std::ostringstream vk;
+            vk << "[";
+            for (int i = 0; i < 4; i++) vk << (i ? "," : "") << "\"" << Goldilocks::toString(prover.starksRecursive2->constRoot[i]) << "\"";
+            vk << "]";
+            stat("genAggregatedProof", req, req.aggregatedProofOutput, vk.str());
+        }
+        req.finalProofInput = req.aggregatedProofOutput;
+        prover.genFinalProof(&req);
+        stat("genFinalProof(recursivef)", req, req.recursivefProofOutput, "\"" + RawFr::field.toString(prover.starksRecursiveF->constRoot[0], 10) + "\"");
+        if (config.saveOutputToFile) {
+            FILE* f = fopen((config.outputPath + "/aggregated_proof.output.json").c_str(), "wb"); if (f) { fwrite(req.aggregatedProofOutput.data(), 1, req.aggregatedProofOutput.size(), f); fclose(f); }
+            f = fopen((config.outputPath + "/recursivef.zkin.json").c_str(), "wb"); if (f) { fwrite(req.recursivefProofOutput.data(), 1, req.recursivefProofOutput.size(), f); fclose(f); }
+        }
+        proofs = 0;
+    }
     for (int it = 0; it < proofs; it++) {
         prover.genBatchProof(&req);
         double starks = 0, exec = 0, total = 0, wit = 0;
