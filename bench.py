@@ -283,6 +283,32 @@ def genproof_leg(timeout_s=300):
     return out
 
 
+def e2e_leg(timeout_s=300):
+    """BASELINE configs[4] minus the SNARK wrap, through the C++ Prover (host/zkprover_batch --e2e): two consecutive batch proofs
+    (each: zkEVM 2^23 + c12a + recursive1), Prover::genAggregatedProof (joinzkin + the recursive2 STARK) and Prover::genFinalProof up
+    to the recursivef STARK (Poseidon-BN128 trees / transcript).  Synthetic witnesses; the circom witness calculators and the fflonk
+    prover around them are CPU / out-of-scope work."""
+    import subprocess
+    exe = os.path.join(ROOT, "xlayer_prover_amd", "host", "zkprover_batch")
+    cfg = os.path.join(ROOT, "tools", "config_runFile_e2e_synthetic.json")
+    try:
+        r = subprocess.run([exe, "-c", cfg, "--e2e"], capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
+        if r.returncode != 0:
+            raise RuntimeError((r.stderr or r.stdout)[-300:])
+        lines = [json.loads(l) for l in r.stdout.strip().splitlines()]
+    except Exception as e:
+        return {"error": repr(e)[:300]}
+    t = {l["stage"]: l["timers_s"] for l in lines}
+    batch = lambda k: round(sum(t[k][n] for n in ("STARK_PROOF_BATCH_PROOF", "STARK_C12_A_PROOF_BATCH_PROOF", "STARK_RECURSIVE_1_PROOF_BATCH_PROOF")), 4)
+    agg, fin = t["genAggregatedProof"], t["genFinalProof(recursivef)"]
+    out = {"metric": "STARK seconds of batch + batch + aggregated + final(recursivef) in the C++ Prover, one GPU",
+           "batch_proof_1_s": batch("genBatchProof#1"), "batch_proof_2_s": batch("genBatchProof#2"),
+           "aggregated_recursive2_s": round(agg["STARK_RECURSIVE_2_PROOF_BATCH_PROOF"], 4), "final_recursivef_s": round(fin["STARK_RECURSIVE_F_PROOF_BATCH_PROOF"], 4),
+           "recursivef_stages_s": {k[len("recursivef."):]: round(v, 4) for k, v in fin.items() if k.startswith("recursivef.")}}
+    out["starks_total_s"] = round(out["batch_proof_1_s"] + out["batch_proof_2_s"] + out["aggregated_recursive2_s"] + out["final_recursivef_s"], 4)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -290,6 +316,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bn128", action="store_true", help="skip the BN128 / fflonk kernel leg (N=1 only; a few seconds)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the batch + batch + aggregated + final(recursivef) chain (N=1 only; ~20 s)")
     ap.add_argument("--no-genproof", action="store_true", help="skip the whole-genProof leg (N=1 only; ~25 s)")
     ap.add_argument("--sharded-commit", type=int, default=-1, help="time the section commit sharded over the ranks (default: on for --gpus > 1; 1 forces it at N=1 "
                     "through RCCL in a world of one)")
@@ -428,6 +455,8 @@ def main():
             torch.cuda.empty_cache()
             capi.shutdown()                                   # the child needs ~300 of the 309 GB: give the library's scratch back too
             line["genproof"] = genproof_leg()
+            if not args.no_e2e:
+                line["e2e"] = e2e_leg()
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.log_n, ncols)
         else:
