@@ -265,6 +265,10 @@ uint64_t xlp_merkle_bn128_num_nodes(uint64_t height);
 int xlp_dev_merkle_bn128(uint64_t* nodes, const uint64_t* src, uint64_t w, uint64_t h);
 int xlp_merkle_bn128(uint64_t* nodes, const uint64_t* src, uint64_t w, uint64_t h);
 int xlp_dev_poseidon_bn128(uint64_t* states, uint32_t t, uint64_t count);
+/* MerkleTreeBN128::getGroupProof (merkleTreeBN128.cpp:210-260) for nq indices in one call: src / nodes are the device buffers of a tree
+ * built by xlp_dev_merkle_bn128; out (HOST, nq x (w + 64 * ceil(log16 h)) words) = the row, then per level the 16-node group (4 words per
+ * node); idxs (HOST) < h. */
+int xlp_dev_merkle_bn128_proofs(uint64_t* out, const uint64_t* src, const uint64_t* nodes, uint64_t w, uint64_t h, const uint64_t* idxs, uint64_t nq);
 int xlp_poseidon_bn128(uint64_t* states, uint32_t t, uint64_t count);
 /*   xlp_[dev_]fft_bn254        FFT<RawFr>::fft / ifft (src/ffiasm/fft.c.hpp:181-221; the transform of the fflonk prover,
  *                              src/rapidsnark/fflonk_prover.c.hpp) of n = 2^k <= 2^28 Fr elements in place, natural order in and out:

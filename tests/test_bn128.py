@@ -354,3 +354,39 @@ def test_cpp_stark_recursivef_genproof_equals_flow(orc, K, tmp_path, nbits, step
         for k, tname in enumerate(["1", "2", "3", "4", "C"]):
             row, groups = exp["fri"]["s0"][q][k]
             assert ints(Z[f"s0_vals{tname}"][q]) == row and [ints(g) for g in Z[f"s0_siblings{tname}"][q]] == groups
+
+
+@pytest.mark.gpu
+@needs_constants
+@pytest.mark.parametrize("h,w", [(4096, 12), (256, 21), (16, 5), (512, 48)])
+def test_gpu_merkle_bn128_batched_openings_vs_oracle(xlp, K, h, w):
+    """xlp_dev_merkle_bn128_proofs: every query's row + 16-node groups in one kernel == the oracle's merkle_genMerkleProof"""
+    import torch
+    rng = np.random.default_rng(h + w)
+    src = rng.integers(0, 0xFFFFFFFF00000001, size=(h, w), dtype=np.uint64)
+    d_src = xlp.from_np(src.reshape(-1))
+    d_nodes = torch.zeros(xlp.merkle_bn128_num_nodes(h) * 4, dtype=torch.int64, device="cuda")
+    xlp.dev_merkle_bn128(d_nodes, d_src, w, h)
+    idxs = [0, h - 1, h // 2 + 1, 7 % h, 7 % h]
+    got = xlp.dev_merkle_bn128_proofs(d_src, d_nodes, w, h, idxs)
+    nodes = bo.merkelize(K, src)
+    for q, idx in enumerate(idxs):
+        assert (got[q, :w] == src[idx]).all()
+        groups = bo.merkle_proof(nodes, idx, h)
+        flat = got[q, w:].reshape(len(groups), 16, 4)
+        assert [[bo.from_mont_limbs(r) for r in g] for g in flat] == [list(g) for g in groups]
+
+
+@pytest.mark.gpu
+@needs_constants
+@pytest.mark.parametrize("t", [2, 3, 6, 16, 17])
+def test_gpu_single_permutation_kernel_vs_oracle(xlp, K, t):
+    """count <= 4 takes the one-wave-per-permutation kernel (lanes across the state: the transcript's path)"""
+    rng = np.random.default_rng(900 + t)
+    for count in (1, 3):
+        vals = [[int.from_bytes(rng.bytes(32), "little") % bo.R_MOD for _ in range(t)] for _ in range(count)]
+        st = np.array([[bo.to_mont_limbs(x) for x in row] for row in vals], dtype=np.uint64)
+        got = xlp.poseidon_bn128(st, t)
+        for i in range(count):
+            exp = bo.poseidon(K, vals[i])
+            assert (got[i] == np.array([bo.to_mont_limbs(x) for x in exp], dtype=np.uint64)).all()

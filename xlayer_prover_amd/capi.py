@@ -64,6 +64,7 @@ SIGNATURES = {
     "xlp_merkle_bn128": [_pu, _pu, _u64, _u64],
     "xlp_dev_poseidon_bn128": [_pu, C.c_uint32, _u64],
     "xlp_poseidon_bn128": [_pu, C.c_uint32, _u64],
+    "xlp_dev_merkle_bn128_proofs": [_pu, _pu, _pu, _u64, _u64, _pu, _u64],
     "xlp_dev_fft_bn254": [_pu, _u64, C.c_int],
     "xlp_fft_bn254": [_pu, _u64, C.c_int],
     "xlp_dev_msm_bn254": [_pu, _pu, _pu, _u64],
@@ -378,6 +379,17 @@ def merkle_bn128_num_nodes(h):
 def dev_merkle_bn128(nodes, src, w, h):
     """MerkleTreeBN128::merkelize on device tensors: nodes = merkle_bn128_num_nodes(h) x 4 words (Fr, Montgomery limbs)"""
     _ck(load().xlp_dev_merkle_bn128(_dp(nodes), _dp(src), w, h), "xlp_dev_merkle_bn128")
+
+
+def dev_merkle_bn128_proofs(src, nodes, w, h, idxs):
+    """-> ndarray [nq][w + 64 ceil(log16 h)]: row, then per level the 16-node group (Montgomery limbs), for every index"""
+    ix = np.ascontiguousarray(idxs, dtype=np.uint64)
+    levels, c = 0, 1
+    while c < h:
+        c *= 16; levels += 1
+    out = np.zeros((ix.size, w + 64 * levels), np.uint64)
+    _ck(load().xlp_dev_merkle_bn128_proofs(out.ctypes.data_as(C.c_void_p), _dp(src), _dp(nodes), w, h, ix.ctypes.data_as(C.c_void_p), ix.size), "xlp_dev_merkle_bn128_proofs")
+    return out
 
 
 def dev_extend_cols(out, src, n_ext, n, ld, col0, ncols):

@@ -22,6 +22,7 @@
 #include <string>
 #include <vector>
 #include "xlp_internal.hpp"
+#include "mont256.hpp"
 
 namespace xlp {
 namespace bn {
@@ -32,7 +33,6 @@ struct Fr { u32 v[8]; };
 __device__ __constant__ u32 R_MOD[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
 // R^2 mod r (toMontgomery = mul by R^2)
 __device__ __constant__ u32 R2_MOD[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
-constexpr u32 N0INV = 0xefffffffu;      // -r^-1 mod 2^32
 
 __device__ __forceinline__ Fr zero() { Fr z; for (int i = 0; i < 8; i++) z.v[i] = 0; return z; }
 
@@ -67,41 +67,23 @@ __device__ __forceinline__ Fr add(const Fr& a, const Fr& b)
     return cond_sub(s, c);      // r < 2^254: c is always 0, kept for the general shape
 }
 
-// Montgomery product a * b / R mod r (CIOS, 32-bit limbs).  b < r; a < 2^256 (toMontgomery of a raw 4-limb word relies on it).
-__device__ __forceinline__ Fr mul(const Fr& a, const Fr& b)
+// Montgomery product a * b / R mod r (mont256.hpp: product scanning, 2 VALU per multiply-accumulate).  b < r; a < 2^256
+// (toMontgomery of a raw 4-limb word relies on it).
+struct FrParams {
+    static constexpr u32 N[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    static constexpr u32 N0INV = 0xefffffffu;
+};
+__device__ __forceinline__ Fr mul(const Fr& a, const Fr& b)          // Poseidon kernels: one wave per SIMD -> split accumulators
 {
-    u32 t[10];
-#pragma unroll
-    for (int i = 0; i < 10; i++) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        u64 c = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const u64 p = (u64)a.v[j] * b.v[i] + t[j] + c;
-            t[j] = (u32)p;
-            c = p >> 32;
-        }
-        u64 s = (u64)t[8] + c;
-        t[8] = (u32)s;
-        t[9] = (u32)(s >> 32);
-        const u32 m = t[0] * N0INV;
-        u64 p = (u64)m * R_MOD[0] + t[0];
-        c = p >> 32;
-#pragma unroll
-        for (int j = 1; j < 8; j++) {
-            p = (u64)m * R_MOD[j] + t[j] + c;
-            t[j - 1] = (u32)p;
-            c = p >> 32;
-        }
-        s = (u64)t[8] + c;
-        t[7] = (u32)s;
-        t[8] = t[9] + (u32)(s >> 32);
-    }
-    u32 lo[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) lo[i] = t[i];
-    return cond_sub(lo, t[8]);
+    Fr r;
+    mont::mul<FrParams, true>(r.v, a.v, b.v);
+    return r;
+}
+__device__ __forceinline__ Fr mul1(const Fr& a, const Fr& b)         // FFT kernels: occupancy hides the latency
+{
+    Fr r;
+    mont::mul<FrParams, false>(r.v, a.v, b.v);
+    return r;
 }
 
 __device__ __forceinline__ Fr exp5(const Fr& x)
@@ -130,6 +112,8 @@ struct Tables {
 
 constexpr int WAVE = 64;
 constexpr int MAXT = 17;
+// kernels are built for two state-size classes: MT = 8 (t <= 8: 40-64 accumulator registers, 16 KiB of LDS per wave -> two waves per
+// SIMD; the leaves of the recursivef trees, t = 5 and t = 8) and MT = 17 (everything)
 
 // state in LDS: st[(j * 8 + l) * WAVE + lane]
 __device__ __forceinline__ Fr ld(const u32* st, int j)
@@ -153,24 +137,26 @@ __device__ __forceinline__ Fr ldc(const Fr* __restrict__ tab, u32 idx)   // wave
 }
 
 // new[i] = sum_j mat[j * t + i] * st[j]   (Poseidon_opt::mix, poseidon_opt.cpp:89-100)
+template <int MT>
 __device__ __forceinline__ void mix(u32* st, const int t, const Fr* __restrict__ mat)
 {
-    Fr acc[MAXT];
+    Fr acc[MT];
 #pragma unroll
-    for (int i = 0; i < MAXT; i++) acc[i] = zero();
+    for (int i = 0; i < MT; i++) acc[i] = zero();
 #pragma unroll 1
     for (int j = 0; j < t; j++) {
         const Fr s = ld(st, j);
 #pragma unroll
-        for (int i = 0; i < MAXT; i++)
+        for (int i = 0; i < MT; i++)
             if (i < t) acc[i] = add(acc[i], mul(ldc(mat, (u32)(j * t + i)), s));
     }
 #pragma unroll
-    for (int i = 0; i < MAXT; i++)
+    for (int i = 0; i < MT; i++)
         if (i < t) sst(st, i, acc[i]);
 }
 
 // Poseidon_opt::hash(vector<FrElement>& state) (poseidon_opt.cpp:9-66) on the lane's LDS state, t = 2..17
+template <int MT>
 __device__ __noinline__ void permute(u32* st, const int t, const Tables& K)
 {
     const int k = t - 2;
@@ -204,15 +190,16 @@ __device__ __noinline__ void permute(u32* st, const int t, const Tables& K)
             if (fr != 7) x = add(x, ldc(c, cidx + (u32)i));
             sst(st, i, x);
         }
-        mix(st, t, fr == 3 ? K.P[k] : K.M[k]);
+        mix<MT>(st, t, fr == 3 ? K.P[k] : K.M[k]);
     }
 }
 
 // ----------------------------------------------------------------- kernels
 // leaves: MerkleTreeBN128::linearHash (merkleTreeBN128.cpp:89-157), one row per lane
-__global__ __launch_bounds__(WAVE) void bn128_leaf_kernel(Fr* __restrict__ nodes, const u64* __restrict__ src, const u64 w, const u64 h, const Tables K)
+template <int MT>
+__global__ __launch_bounds__(WAVE, MT <= 8 ? 2 : 1) void bn128_leaf_kernel(Fr* __restrict__ nodes, const u64* __restrict__ src, const u64 w, const u64 h, const Tables K)
 {
-    __shared__ u32 lds[MAXT * 8 * WAVE];
+    __shared__ u32 lds[MT * 8 * WAVE];
     u32* st = lds + threadIdx.x;
     const u64 gid = (u64)blockIdx.x * WAVE + threadIdx.x;
     const u64 row = gid < h ? gid : h - 1;            // idle lanes repeat the last row and do not store
@@ -240,7 +227,7 @@ __global__ __launch_bounds__(WAVE) void bn128_leaf_kernel(Fr* __restrict__ nodes
             }
             sst(st, 1 + (int)e, to_montgomery(raw));
         }
-        permute(st, (int)take + 1, K);
+        permute<MT>(st, (int)take + 1, K);
         node = ld(st, 0);
         done += take;
     }
@@ -260,19 +247,20 @@ __global__ __launch_bounds__(WAVE) void bn128_level_kernel(Fr* __restrict__ next
         if (e < num) x = cur[b * 16 + e];
         sst(st, 1 + (int)e, x);
     }
-    permute(st, 17, K);
+    permute<MAXT>(st, 17, K);
     if (gid < batches) next[gid] = ld(st, 0);
 }
 
 // count independent permutations of t-element states (Montgomery limbs in and out): the transcript's and the tests' entry
-__global__ __launch_bounds__(WAVE) void bn128_perm_kernel(Fr* __restrict__ states, const u32 t, const u64 count, const Tables K)
+template <int MT>
+__global__ __launch_bounds__(WAVE, MT <= 8 ? 2 : 1) void bn128_perm_kernel(Fr* __restrict__ states, const u32 t, const u64 count, const Tables K)
 {
-    __shared__ u32 lds[MAXT * 8 * WAVE];
+    __shared__ u32 lds[MT * 8 * WAVE];
     u32* st = lds + threadIdx.x;
     const u64 gid = (u64)blockIdx.x * WAVE + threadIdx.x;
     const u64 b = gid < count ? gid : count - 1;
     for (u32 e = 0; e < t; e++) sst(st, (int)e, states[b * t + e]);
-    permute(st, (int)t, K);
+    permute<MT>(st, (int)t, K);
     if (gid < count)
         for (u32 e = 0; e < t; e++) states[b * t + e] = ld(st, (int)e);
 }
@@ -321,7 +309,7 @@ __global__ void fr_twiddle_kernel(Fr* __restrict__ tw, const u64 count, const Fr
     if (j >= count) return;
     Fr acc = one;
     for (u32 k = 0; (j >> k) != 0; k++)
-        if ((j >> k) & 1) acc = mul(acc, gld(&wpow[k]));
+        if ((j >> k) & 1) acc = mul1(acc, gld(&wpow[k]));
     gst(&tw[j], acc);
 }
 
@@ -356,7 +344,7 @@ __global__ __launch_bounds__(1 << (FFT_LB - 1)) void fr_fft_low_kernel(Fr* __res
             Fr u, v;
 #pragma unroll
             for (int l = 0; l < 8; l++) { u.v[l] = sm[l * (1 << FFT_LB) + k + j]; v.v[l] = sm[l * (1 << FFT_LB) + k + j + mdiv2]; }
-            const Fr t = mul(gld(&tw[(u64)j << (logn - s)]), v);
+            const Fr t = mul1(gld(&tw[(u64)j << (logn - s)]), v);
             const Fr x = add(u, t), y = sub(u, t);
 #pragma unroll
             for (int l = 0; l < 8; l++) { sm[l * (1 << FFT_LB) + k + j] = x.v[l]; sm[l * (1 << FFT_LB) + k + j + mdiv2] = y.v[l]; }
@@ -378,7 +366,7 @@ __global__ void fr_fft_stage_kernel(Fr* __restrict__ a, const Fr* __restrict__ t
     if (i >> (logn - 1)) return;
     const u64 mdiv2 = 1ull << (s - 1);
     const u64 k = (i >> (s - 1)) << s, j = i & (mdiv2 - 1);
-    const Fr t = mul(gld(&tw[j << (logn - s)]), gld(&a[k + j + mdiv2]));
+    const Fr t = mul1(gld(&tw[j << (logn - s)]), gld(&a[k + j + mdiv2]));
     const Fr u = gld(&a[k + j]);
     gst(&a[k + j], add(u, t));
     gst(&a[k + j + mdiv2], sub(u, t));
@@ -390,10 +378,82 @@ __global__ void fr_ifft_finish_kernel(Fr* __restrict__ a, const u32 logn, const 
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 n = 1ull << logn, half = n >> 1;
     if (i > half) return;
-    if (i == 0 || i == half) { gst(&a[i], mul(gld(&a[i]), ninv)); return; }
+    if (i == 0 || i == half) { gst(&a[i], mul1(gld(&a[i]), ninv)); return; }
     const Fr x = gld(&a[i]), y = gld(&a[n - i]);
-    gst(&a[i], mul(y, ninv));
-    gst(&a[n - i], mul(x, ninv));
+    gst(&a[i], mul1(y, ninv));
+    gst(&a[n - i], mul1(x, ninv));
+}
+
+// MerkleTreeBN128::getGroupProof (merkleTreeBN128.cpp:210-260) for many indices at once: out[q] = row idx_q (w Goldilocks words)
+// followed, per level, by the 16 nodes of the group idx_q falls in (4 words each); one block per query
+__global__ __launch_bounds__(64) void bn128_proofs_kernel(u64* __restrict__ out, const u64* __restrict__ src, const u64* __restrict__ nodes, const u64 w, const u64 h,
+                                                         const u64* __restrict__ idxs, const u32 levels)
+{
+    u64 idx = idxs[blockIdx.x];
+    u64* o = out + (u64)blockIdx.x * (w + 64ull * levels);
+    for (u64 i = threadIdx.x; i < w; i += blockDim.x) o[i] = src[idx * w + i];
+    u64 offset = 0, n = h;
+    for (u32 l = 0; l < levels; l++) {
+        const u64 si = idx & ~15ull;
+        o[w + 64ull * l + threadIdx.x] = nodes[(offset + si) * 4 + threadIdx.x];     // 16 nodes x 4 words = 64 lanes
+        const u64 next = (n - 1) / 16 + 1;
+        offset += next * 16; idx >>= 4; n = next;
+    }
+}
+
+// ONE permutation spread over the lanes of one wave (lane i owns state element i): the transcript asks for its permutations one at
+// a time (TranscriptBN128::_updateState), and a lane walking a whole t = 17 permutation alone needs ~6 ms (5 457 dependent Montgomery
+// products).  Here the critical path is 8 x (3 + t) + nP x ~5 + t products: ~0.6 ms.  Same arithmetic, same result.
+__global__ __launch_bounds__(WAVE) void bn128_perm_coop_kernel(Fr* __restrict__ state, const u32 t, const Tables K)
+{
+    __shared__ u32 sh[MAXT * 8];            // state / product vector, element-major
+    __shared__ u32 xs[8];                   // broadcast of the S-boxed element 0
+    const u32 lane = threadIdx.x;
+    const bool on = lane < t;
+    const int k = (int)t - 2;
+    const Fr* __restrict__ c = K.C[k];
+    const Fr* __restrict__ s = K.S[k];
+    const u32 nP = K.nP[k];
+    auto put = [&](const Fr& e) { if (on) for (int l = 0; l < 8; l++) sh[lane * 8 + l] = e.v[l]; };
+    auto get = [&](u32 j) { Fr e; for (int l = 0; l < 8; l++) e.v[l] = sh[j * 8 + l]; return e; };
+    auto mixc = [&](const Fr& mine, const Fr* __restrict__ mat) {
+        put(mine);
+        __syncthreads();
+        Fr acc = zero();
+        for (u32 j = 0; j < t; j++) acc = add(acc, mul(gld(&mat[j * t + (on ? lane : 0)]), get(j)));
+        __syncthreads();
+        return acc;
+    };
+    Fr st = on ? gld(&state[lane]) : zero();
+    st = add(st, gld(&c[on ? lane : 0]));
+    for (int fr = 0; fr < 8; fr++) {
+        if (fr == 4) {
+            for (u32 r = 0; r < nP; r++) {
+                const u32 base = (2 * t - 1) * r;
+                if (lane == 0) {
+                    st = add(exp5(st), gld(&c[5 * t + r]));
+                    for (int l = 0; l < 8; l++) xs[l] = st.v[l];
+                }
+                __syncthreads();
+                Fr x;
+                for (int l = 0; l < 8; l++) x.v[l] = xs[l];
+                put(mul(gld(&s[base + (on ? lane : 0)]), st));                       // S[j] * state[j] (lane 0: the S-boxed element)
+                if (on && lane > 0) st = add(st, mul(x, gld(&s[base + t + lane - 1])));
+                __syncthreads();
+                if (lane == 0) {
+                    Fr s0 = get(0);
+                    for (u32 j = 1; j < t; j++) s0 = add(s0, get(j));
+                    st = s0;
+                }
+                __syncthreads();
+            }
+        }
+        const u32 cidx = fr < 4 ? (u32)((fr + 1) * t) : (u32)(5 * t + nP + (fr - 4) * t);
+        st = exp5(st);
+        if (fr != 7) st = add(st, gld(&c[cidx + (on ? lane : 0)]));
+        st = mixc(st, fr == 3 ? K.P[k] : K.M[k]);
+    }
+    if (on) gst(&state[lane], st);
 }
 
 }  // namespace bn
@@ -474,7 +534,9 @@ int dev_merkle_bn128(Ctx* ctx, u64* nodes, const u64* src, u64 w, u64 h)
     if (h & (h - 1)) return xlp_fail("merkle_bn128: height must be a power of two");
     bn::Fr* nd = (bn::Fr*)nodes;
     XLP_HIP(hipMemsetAsync(nd, 0, bn128_num_nodes(h) * sizeof(bn::Fr), ctx->stream));     // calloc'ed in the reference: padding slots stay zero
-    hipLaunchKernelGGL(bn::bn128_leaf_kernel, dim3((unsigned)((h + bn::WAVE - 1) / bn::WAVE)), dim3(bn::WAVE), 0, ctx->stream, nd, src, w, h, g_bn_tables);
+    const u64 nfr = (w + 2) / 3;          // Fr elements per leaf: a leaf hashes min(nfr, 16) + 1 elements at a time
+    if (w > 4 && nfr <= 7) hipLaunchKernelGGL(bn::bn128_leaf_kernel<8>, dim3((unsigned)((h + bn::WAVE - 1) / bn::WAVE)), dim3(bn::WAVE), 0, ctx->stream, nd, src, w, h, g_bn_tables);
+    else hipLaunchKernelGGL(bn::bn128_leaf_kernel<bn::MAXT>, dim3((unsigned)((h + bn::WAVE - 1) / bn::WAVE)), dim3(bn::WAVE), 0, ctx->stream, nd, src, w, h, g_bn_tables);
     XLP_HIP(hipGetLastError());
     u64 n256 = h, cursor = 0, cursor_next = h;
     u64 next_n = (n256 - 1) / 16 + 1;
@@ -492,12 +554,29 @@ int dev_merkle_bn128(Ctx* ctx, u64* nodes, const u64* src, u64 w, u64 h)
     return 0;
 }
 
+int dev_merkle_bn128_proofs(Ctx* ctx, u64* out, const u64* src, const u64* nodes, u64 w, u64 h, const u64* d_idxs, u64 nq)
+{
+    if (!nq) return 0;
+    if (h == 0 || (h & (h - 1))) return xlp_fail("merkle_bn128 proofs: height must be a power of two");
+    u32 levels = 0;
+    for (u64 c = 1; c < h; c *= 16) levels++;
+    hipLaunchKernelGGL(bn::bn128_proofs_kernel, dim3((unsigned)nq), dim3(64), 0, ctx->stream, out, src, nodes, w, h, d_idxs, levels);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
 int dev_poseidon_bn128(Ctx* ctx, u64* states, u32 t, u64 count)
 {
     if (bn128_init(ctx, nullptr)) return -1;
     if (t < 2 || t > 17) return xlp_fail("poseidon_bn128: state size must be 2..17");
     if (count == 0) return 0;
-    hipLaunchKernelGGL(bn::bn128_perm_kernel, dim3((unsigned)((count + bn::WAVE - 1) / bn::WAVE)), dim3(bn::WAVE), 0, ctx->stream, (bn::Fr*)states, t, count, g_bn_tables);
+    if (count <= 4) {          // the transcript's one-at-a-time calls: one wave per permutation, lanes across the state
+        for (u64 q = 0; q < count; q++) hipLaunchKernelGGL(bn::bn128_perm_coop_kernel, dim3(1), dim3(bn::WAVE), 0, ctx->stream, (bn::Fr*)states + q * t, t, g_bn_tables);
+        XLP_HIP(hipGetLastError());
+        return 0;
+    }
+    if (t <= 8) hipLaunchKernelGGL(bn::bn128_perm_kernel<8>, dim3((unsigned)((count + bn::WAVE - 1) / bn::WAVE)), dim3(bn::WAVE), 0, ctx->stream, (bn::Fr*)states, t, count, g_bn_tables);
+    else hipLaunchKernelGGL(bn::bn128_perm_kernel<bn::MAXT>, dim3((unsigned)((count + bn::WAVE - 1) / bn::WAVE)), dim3(bn::WAVE), 0, ctx->stream, (bn::Fr*)states, t, count, g_bn_tables);
     XLP_HIP(hipGetLastError());
     return 0;
 }

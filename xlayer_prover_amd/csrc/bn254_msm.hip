@@ -19,6 +19,7 @@
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
 #include "xlp_internal.hpp"
+#include "mont256.hpp"
 
 namespace xlp {
 namespace g1 {
@@ -83,40 +84,15 @@ __device__ __forceinline__ Fq fsub(const Fq& a, const Fq& b)
     return r;
 }
 __device__ __forceinline__ Fq fdbl(const Fq& a) { return fadd(a, a); }
-__device__ __noinline__ Fq fmul(const Fq& a, const Fq& b)
+struct FqParams {
+    static constexpr u32 N[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+    static constexpr u32 N0INV = 0xe4866389u;
+};
+__device__ __noinline__ Fq fmul(const Fq& a, const Fq& b)      // mont256.hpp: product scanning, 2 VALU per multiply-accumulate
 {
-    u32 t[10];
-#pragma unroll
-    for (int i = 0; i < 10; i++) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        u64 c = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const u64 p = (u64)a.v[j] * b.v[i] + t[j] + c;
-            t[j] = (u32)p;
-            c = p >> 32;
-        }
-        u64 s = (u64)t[8] + c;
-        t[8] = (u32)s;
-        t[9] = (u32)(s >> 32);
-        const u32 m = t[0] * Q_N0INV;
-        u64 p = (u64)m * Q_MOD[0] + t[0];
-        c = p >> 32;
-#pragma unroll
-        for (int j = 1; j < 8; j++) {
-            p = (u64)m * Q_MOD[j] + t[j] + c;
-            t[j - 1] = (u32)p;
-            c = p >> 32;
-        }
-        s = (u64)t[8] + c;
-        t[7] = (u32)s;
-        t[8] = t[9] + (u32)(s >> 32);
-    }
-    u32 lo[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) lo[i] = t[i];
-    return cond_sub(lo, t[8]);
+    Fq r;
+    mont::mul<FqParams>(r.v, a.v, b.v);
+    return r;
 }
 __device__ __forceinline__ Fq fsqr(const Fq& a) { return fmul(a, a); }
 

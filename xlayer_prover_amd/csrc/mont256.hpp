@@ -1,0 +1,99 @@
+// 256-bit Montgomery multiplication for gfx950, shared by the BN254 scalar-field (bn128.hip) and base-field (bn254_msm.hip) code.
+//
+// Finely integrated product scanning (FIPS): the 16 result columns are summed one after the other in a 96-bit accumulator
+// (lo:mid as one 64-bit register pair + hi), every 32 x 32 product is ONE v_mad_u64_u32 whose carry-out (VCC) feeds ONE
+// v_addc_co_u32 on the top word -- two VALU instructions per multiply-accumulate, 128 of them per product -- instead of
+// the compare-and-add sequences hipcc builds for `u64 += (u64)a * b` chains (measured: 668 -> ~350 VALU per Montgomery product;
+// these kernels sit at ~75 % of the VALU issue peak, so instructions are time).  The modulus limbs are compile-time constants
+// and ride in SGPRs (one scalar operand per VOP3 instruction).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace xlp {
+namespace mont {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+// acc (lo64, hi32) += a * b
+__device__ __forceinline__ void mac(u64& lo, u32& hi, u32 a, u32 b)
+{
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(a), "v"(b) : "vcc");
+}
+// acc += a * K, K a compile-time constant (modulus limb) in an SGPR
+__device__ __forceinline__ void mac_k(u64& lo, u32& hi, u32 a, u32 k)
+{
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(a), "s"(k) : "vcc");
+}
+
+// (lo, hi) += (lo2, hi2)
+__device__ __forceinline__ void acc_add(u64& lo, u32& hi, u64 lo2, u32 hi2)
+{
+    const u64 s = lo + lo2;
+    hi += hi2 + (s < lo2 ? 1u : 0u);
+    lo = s;
+}
+
+// P: struct with static constexpr u32 N[8] (modulus, little-endian limbs) and N0INV (-N^-1 mod 2^32).
+// r = a * b / 2^256 mod N;  b < N, a < 2^256;  r < N.
+// SPLIT: two accumulators per column -- the a * b products and the m * N products -- are independent dependency chains (each
+// multiply-accumulate waits for the previous one on the same accumulator).  Pays where a lone wave per SIMD has nothing else to
+// issue meanwhile (the Poseidon-BN128 kernels: 1.24x -> 1.52x on the recursivef tree); costs 5 % where occupancy already hides the
+// latency (FFT, MSM), which therefore use one accumulator.
+template <class P, bool SPLIT = false>
+__device__ __forceinline__ void mul(u32 (&r)[8], const u32 (&a)[8], const u32 (&b)[8])
+{
+    u32 m[8];
+    u64 lo = 0;
+    u32 hi = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 lo2 = 0;
+        u32 hi2 = 0;
+#pragma unroll
+        for (int j = 0; j < i; j++) {
+            mac(lo, hi, a[j], b[i - j]);
+            if constexpr (SPLIT) mac_k(lo2, hi2, m[j], P::N[i - j]);
+            else mac_k(lo, hi, m[j], P::N[i - j]);
+        }
+        mac(lo, hi, a[i], b[0]);
+        if (SPLIT && i > 0) acc_add(lo, hi, lo2, hi2);
+        m[i] = (u32)lo * P::N0INV;
+        mac_k(lo, hi, m[i], P::N[0]);
+        lo = (lo >> 32) | ((u64)hi << 32);
+        hi = 0;
+    }
+    u32 t[9];
+#pragma unroll
+    for (int i = 8; i < 16; i++) {
+        u64 lo2 = 0;
+        u32 hi2 = 0;
+#pragma unroll
+        for (int j = i - 7; j < 8; j++) {
+            mac(lo, hi, a[j], b[i - j]);
+            if constexpr (SPLIT) mac_k(lo2, hi2, m[j], P::N[i - j]);
+            else mac_k(lo, hi, m[j], P::N[i - j]);
+        }
+        if (SPLIT && i < 15) acc_add(lo, hi, lo2, hi2);
+        t[i - 8] = (u32)lo;
+        lo = (lo >> 32) | ((u64)hi << 32);
+        hi = 0;
+    }
+    t[8] = (u32)lo;
+    // t < 2N: one conditional subtraction
+    u32 d[8];
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u64 s = (u64)t[i] - P::N[i] - borrow;
+        d[i] = (u32)s;
+        borrow = (u32)(s >> 63);
+    }
+    const bool ge = t[8] != 0 || borrow == 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r[i] = ge ? d[i] : t[i];
+}
+
+}  // namespace mont
+}  // namespace xlp

@@ -740,6 +740,23 @@ int xlp_poseidon_bn128(uint64_t* states, uint32_t t, uint64_t count)
     return 0;
 }
 
+int xlp_dev_merkle_bn128_proofs(uint64_t* out, const uint64_t* src, const uint64_t* nodes, uint64_t w, uint64_t h, const uint64_t* idxs, uint64_t nq)
+{
+    if (ensure_init()) return -1;
+    if (nq == 0) return 0;
+    if (!out || !nodes || !idxs || (w && !src)) return xlp_fail("xlp_dev_merkle_bn128_proofs: null pointer");
+    for (uint64_t q = 0; q < nq; q++) if (idxs[q] >= h) return xlp_fail("xlp_dev_merkle_bn128_proofs: index out of range");
+    uint32_t levels = 0;
+    for (u64 c = 1; c < h; c *= 16) levels++;
+    const size_t per = w + 64ull * levels;
+    DevBuf di, dout;
+    if (di.alloc(nq * sizeof(u64)) || dout.alloc(nq * per * sizeof(u64))) return -1;
+    H2D(di, idxs, nq * sizeof(u64));
+    if (dev_merkle_bn128_proofs(&g_ctx, dout.u(), src, nodes, w, h, di.u(), nq)) return -1;
+    XLP_HIP(hipStreamSynchronize(g_ctx.stream));
+    D2H(out, dout, nq * per * sizeof(u64));
+    return 0;
+}
 int xlp_dev_fft_bn254(uint64_t* data, uint64_t n, int inverse)
 {
     if (ensure_init()) return -1;

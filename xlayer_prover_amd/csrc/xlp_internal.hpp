@@ -106,6 +106,7 @@ int bn128_init(Ctx* ctx, const char* path);
 u64 bn128_num_nodes(u64 n);
 int dev_merkle_bn128(Ctx* ctx, u64* nodes, const u64* src, u64 w, u64 h);
 int dev_poseidon_bn128(Ctx* ctx, u64* states, u32 t, u64 count);
+int dev_merkle_bn128_proofs(Ctx* ctx, u64* out, const u64* src, const u64* nodes, u64 w, u64 h, const u64* d_idxs, u64 nq);
 int dev_fft_bn254(Ctx* ctx, u64* data, u64 n, int inverse);
 // bn254_msm.hip
 int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 n);

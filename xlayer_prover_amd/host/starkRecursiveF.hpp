@@ -125,9 +125,20 @@ public:
         std::vector<uint64_t> ys(nQueries);
         transcript.getPermutations(ys.data(), nQueries, steps[0].nBits);
         for (uint64_t si = 0; si < nSteps; si++) {
+            // friProveC12.cpp:155-177, batched per tree: one getGroupProofs call covers every query
+            std::vector<MerkleTreeBN128*> trees;
+            if (si == 0) for (unsigned i = 0; i < 5; i++) trees.push_back(treesBN128[i]);
+            else trees.push_back(treesFRI[si]);
+            std::vector<std::vector<uint8_t>> bufs(trees.size());
+            for (size_t k = 0; k < trees.size(); k++) trees[k]->getGroupProofs(bufs[k], ys);
             for (uint64_t i = 0; i < nQueries; i++) {
-                if (si == 0) queryPol(fproof, treesBN128, ys[i], si);
-                else queryPol(fproof, treesFRI[si], ys[i], si);
+                std::vector<MerkleProofC12> vMkProof;
+                for (size_t k = 0; k < trees.size(); k++) {
+                    MerkleTreeBN128* t = trees[k];
+                    const uint64_t per = t->source_width * sizeof(Goldilocks::Element) + MerkleTreeBN128::getMerkleProofSize(t->height);
+                    vMkProof.push_back(MerkleProofC12(t->source_width, MerkleTreeBN128::getMerkleProofLength(t->height), &bufs[k][i * per]));
+                }
+                fproof.proofs.fri.trees[si].polQueries.push_back(vMkProof);
             }
             if (si < nSteps - 1)
                 for (uint64_t i = 0; i < nQueries; i++) ys[i] = ys[i] % (1ULL << steps[si + 1].nBits);

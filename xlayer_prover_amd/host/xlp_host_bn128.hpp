@@ -157,6 +157,15 @@ public:
         RawFr::Element* mp = (RawFr::Element*)((uint8_t*)res + source_width * sizeof(Goldilocks::Element));
         merkle_genMerkleProof(mp, idx, 0, height);
     }
+    // getGroupProof for many indices: proofs[q] = row || groups (source_width * 8 + getMerkleProofSize(height) bytes each); one kernel + one
+    // copy when the tree lives on the GPU
+    void getGroupProofs(std::vector<uint8_t>& proofs, const std::vector<uint64_t>& idxs)
+    {
+        const uint64_t per = source_width * sizeof(Goldilocks::Element) + getMerkleProofSize(height);
+        proofs.assign(idxs.size() * per + 8, 0);
+        if (d_nodes) { XLP_CHECK(xlp_dev_merkle_bn128_proofs((uint64_t*)proofs.data(), d_source, d_nodes, source_width, height, idxs.data(), idxs.size())); return; }
+        for (size_t q = 0; q < idxs.size(); q++) getGroupProof(&proofs[q * per], idxs[q]);
+    }
     void merkle_genMerkleProof(RawFr::Element* proof, uint64_t idx, uint64_t offset, uint64_t n)
     {
         while (n > 1) {
