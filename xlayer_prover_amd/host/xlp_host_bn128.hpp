@@ -87,6 +87,7 @@ public:
     uint64_t* d_source = NULL;
     uint64_t* d_nodes = NULL;
     bool ownsDevNodes = false;
+    bool emptyTreeDone = false;      // source_width == 0: the tree of all-zero leaves depends on the height only; built once per object
 
     MerkleTreeBN128() {}
     MerkleTreeBN128(uint64_t _height, uint64_t _width, Goldilocks::Element* _source) : source(_source), height(_height), source_width(_width)
