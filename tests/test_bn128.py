@@ -390,3 +390,22 @@ def test_gpu_single_permutation_kernel_vs_oracle(xlp, K, t):
         for i in range(count):
             exp = bo.poseidon(K, vals[i])
             assert (got[i] == np.array([bo.to_mont_limbs(x) for x in exp], dtype=np.uint64)).all()
+
+
+@pytest.mark.gpu
+@needs_constants
+def test_bn128_entry_points_reject_bad_arguments(xlp):
+    """error behaviour of the C ABI: non-zero status + a message, nothing computed"""
+    import ctypes as C
+    lib = xlp.load()
+    buf = np.zeros(64, np.uint64)
+    p = buf.ctypes.data_as(C.c_void_p)
+    assert lib.xlp_poseidon_bn128(p, 1, 1) != 0 and b"2..17" in lib.xlp_last_error()
+    assert lib.xlp_poseidon_bn128(p, 18, 1) != 0
+    assert lib.xlp_merkle_bn128(p, p, 3, 3) != 0 and b"power of two" in lib.xlp_last_error()
+    assert lib.xlp_fft_bn254(p, 3, 0) != 0 and b"power of two" in lib.xlp_last_error()
+    assert lib.xlp_msm_bn254(None, p, p, 1) != 0
+    assert lib.xlp_bn128_init(b"/nonexistent/poseidon_bn128.bin") != 0 and b"not found" in lib.xlp_last_error()
+    assert lib.xlp_bn128_init(None) == 0                                     # the tables next to the library still load
+    assert lib.xlp_merkle_bn128(p, p, 3, 0) == 0 and lib.xlp_fft_bn254(p, 0, 0) == 0      # empty inputs are no-ops
+    assert xlp.msm_bn254(np.zeros((0, 8), np.uint64), np.zeros((0, 4), np.uint64)).tolist() == [0] * 8   # the empty sum is the point at infinity
