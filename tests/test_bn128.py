@@ -409,3 +409,21 @@ def test_bn128_entry_points_reject_bad_arguments(xlp):
     assert lib.xlp_bn128_init(None) == 0                                     # the tables next to the library still load
     assert lib.xlp_merkle_bn128(p, p, 3, 0) == 0 and lib.xlp_fft_bn254(p, 0, 0) == 0      # empty inputs are no-ops
     assert xlp.msm_bn254(np.zeros((0, 8), np.uint64), np.zeros((0, 4), np.uint64)).tolist() == [0] * 8   # the empty sum is the point at infinity
+
+
+@pytest.mark.gpu
+def test_gpu_msm_bn254_skewed_scalars_heavy_buckets(xlp):
+    """all scalars equal (one bucket per window holds every point) and scalars with only the top bits set (the short top window):
+    buckets with more than 256 points are summed by a workgroup each; results against the oracle's group law"""
+    rng = np.random.default_rng(31)
+    n = 3000
+    base_pts = _random_points(rng, 64)
+    idx = rng.integers(0, 64, size=n)
+    table = np.array([bo.g1_to_limbs(p) for p in base_pts], dtype=np.uint64)
+    bases = table[idx]
+    cnt = np.bincount(idx, minlength=64)
+    S1 = bo.msm(base_pts, [int(c) for c in cnt])
+    for k in (5, (1 << 255) + 77, (0xF << 252)):
+        sc = np.array([[(k >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]] * n, dtype=np.uint64)
+        got = bo.g1_from_limbs(xlp.msm_bn254(bases, sc))
+        assert got == bo.g1_mul(S1, k % bo.R_MOD)

@@ -12,8 +12,9 @@
 //   1. msm_keys      (window w, point i) -> key = w * 2^c + digit, value = i             one pass over the scalars
 //   2. radix sort of the (key, value) pairs (rocPRIM through hipCUB), bucket start offsets by neighbour comparison
 //   3. msm_buckets   one lane per non-empty-able bucket (w, digit != 0): Jacobian accumulator += its points (mixed addition)
-//   4. msm_groups    per window, 2^c / 256 lanes: running-sum trick on 256 consecutive buckets, then the group's offset * total
-//   5. msm_finish    one lane: sum the groups of each window, Horner over the windows (c doublings each), Jacobian -> affine
+//   4. msm_groups    per window, 2^c / 64 lanes: running-sum trick on 64 consecutive buckets, then the group's offset * total;
+//      msm_window_sums: one workgroup per window folds the groups (LDS tree)
+//   5. msm_finish    one lane: Horner over the windows (c doublings each), Jacobian -> affine
 // Fq arithmetic: 8 x 32-bit limbs, Montgomery (R = 2^256), CIOS on v_mad_u64_u32 -- integer-VALU bound like everything else here.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -207,21 +208,46 @@ __global__ void msm_starts_kernel(u32* __restrict__ start, const u32* __restrict
     for (u32 k = prev + 1; k <= cur; k++) start[k] = (u32)gid;
 }
 
+// A bucket with more than HEAVY points is not walked by one lane: skewed scalars (many equal digits) and the top window (256 mod c
+// bits: few buckets, n / 2^bits points each) would serialise thousands of additions on one lane.  Such buckets are listed and summed by a
+// whole workgroup each (msm_heavy_kernel).
+constexpr u32 HEAVY = 256;
 __global__ __launch_bounds__(64) void msm_buckets_kernel(Jac* __restrict__ buckets, const u32* __restrict__ start, const u32* __restrict__ sorted_vals,
-                                                          const Aff* __restrict__ bases, const u32 nkeys, const u32 c)
+                                                          const Aff* __restrict__ bases, const u32 nkeys, const u32 c, u32* __restrict__ heavy /* [0] = count, then keys */)
 {
     const u32 key = blockIdx.x * blockDim.x + threadIdx.x;
     if (key >= nkeys) return;
     Jac acc = jzero();
     if ((key & ((1u << c) - 1)) != 0) {
         const u32 b = start[key], e = start[key + 1];
+        if (e - b > HEAVY) { heavy[1 + atomicAdd(&heavy[0], 1u)] = key; return; }
         for (u32 k = b; k < e; k++) acc = jmadd(acc, bases[sorted_vals[k]]);
     }
     buckets[key] = acc;
 }
+__global__ __launch_bounds__(256) void msm_heavy_kernel(Jac* __restrict__ buckets, const u32* __restrict__ start, const u32* __restrict__ sorted_vals,
+                                                         const Aff* __restrict__ bases, const u32* __restrict__ heavy)
+{
+    __shared__ Jac sh[256];
+    const u32 t = threadIdx.x;
+    for (u32 hb = blockIdx.x; hb < heavy[0]; hb += gridDim.x) {
+        const u32 key = heavy[1 + hb];
+        const u32 b = start[key], e = start[key + 1];
+        Jac acc = jzero();
+        for (u32 k = b + t; k < e; k += 256) acc = jmadd(acc, bases[sorted_vals[k]]);
+        sh[t] = acc;
+        __syncthreads();
+        for (u32 step = 128; step >= 1; step >>= 1) {
+            if (t < step) sh[t] = jadd(sh[t], sh[t + step]);
+            __syncthreads();
+        }
+        if (t == 0) buckets[key] = sh[0];
+        __syncthreads();
+    }
+}
 
 // group g of window w covers digits [g * GS, (g + 1) * GS): out = sum_d d * B_d over the group
-constexpr u32 GS = 256;
+constexpr u32 GS = 64;       // buckets per running-sum lane: 2^c / 64 lanes per window (a 256-bucket lane was 13 ms of serial additions)
 __global__ __launch_bounds__(64) void msm_groups_kernel(Jac* __restrict__ groups, const Jac* __restrict__ buckets, const u32 nwin, const u32 c)
 {
     const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -272,14 +298,20 @@ __global__ void msm_finish_kernel(Aff* __restrict__ out, const Jac* __restrict__
     *out = a;
 }
 
-// per-window partial sums of the groups, one lane per window (keeps msm_finish short when 2^c / GS is large)
-__global__ void msm_window_sums_kernel(Jac* __restrict__ wsum, const Jac* __restrict__ groups, const u32 nwin, const u32 gpw)
+// per-window sum of the groups: one 256-lane workgroup per window, every lane folds its share, then an LDS tree
+__global__ __launch_bounds__(256) void msm_window_sums_kernel(Jac* __restrict__ wsum, const Jac* __restrict__ groups, const u32 nwin, const u32 gpw)
 {
-    const u32 w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= nwin) return;
+    __shared__ Jac sh[256];
+    const u32 w = blockIdx.x, t = threadIdx.x;
     Jac s = jzero();
-    for (u32 g = 0; g < gpw; g++) s = jadd(s, groups[w * gpw + g]);
-    wsum[w] = s;
+    for (u32 g = t; g < gpw; g += 256) s = jadd(s, groups[w * gpw + g]);
+    sh[t] = s;
+    __syncthreads();
+    for (u32 step = 128; step >= 1; step >>= 1) {
+        if (t < step) sh[t] = jadd(sh[t], sh[t + step]);
+        __syncthreads();
+    }
+    if (t == 0) wsum[w] = sh[0];
 }
 
 }  // namespace g1
@@ -304,7 +336,8 @@ int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 
     size_t temp_bytes = 0;
     u32* nul = nullptr;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, nul, nul, nul, nul, (int)total, 0, 32, ctx->stream);
-    const size_t words32 = 4 * total + (nkeys + 2);
+    const size_t nheavy_max = total / HEAVY + 2;
+    const size_t words32 = 4 * total + (nkeys + 2) + nheavy_max + 1;
     const size_t jac_count = (size_t)nkeys + (size_t)nwin * gpw + nwin;
     const size_t bytes = ((words32 * 4 + 255) / 256) * 256 + jac_count * sizeof(Jac) + temp_bytes + 256;
     u64* scratch = nullptr;
@@ -314,6 +347,7 @@ int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 
     u32* keys2 = vals + total;
     u32* vals2 = keys2 + total;
     u32* start = vals2 + total;
+    u32* heavy = start + (nkeys + 2);
     Jac* buckets = (Jac*)((char*)scratch + ((words32 * 4 + 255) / 256) * 256);
     Jac* groups = buckets + nkeys;
     Jac* wsum = groups + (size_t)nwin * gpw;
@@ -324,9 +358,11 @@ int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 
     while ((1ull << key_bits) < nkeys) key_bits++;
     XLP_HIP(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys2, vals, vals2, (int)total, 0, (int)key_bits, ctx->stream));
     hipLaunchKernelGGL(msm_starts_kernel, dim3((unsigned)((total + 1 + T - 1) / T)), dim3(T), 0, ctx->stream, start, keys2, total, nkeys);
-    hipLaunchKernelGGL(msm_buckets_kernel, dim3((nkeys + 63) / 64), dim3(64), 0, ctx->stream, buckets, start, vals2, (const Aff*)bases, nkeys, c);
+    XLP_HIP(hipMemsetAsync(heavy, 0, sizeof(u32), ctx->stream));
+    hipLaunchKernelGGL(msm_buckets_kernel, dim3((nkeys + 63) / 64), dim3(64), 0, ctx->stream, buckets, start, vals2, (const Aff*)bases, nkeys, c, heavy);
+    hipLaunchKernelGGL(msm_heavy_kernel, dim3((unsigned)(nheavy_max < 2048 ? nheavy_max : 2048)), dim3(256), 0, ctx->stream, buckets, start, vals2, (const Aff*)bases, heavy);
     hipLaunchKernelGGL(msm_groups_kernel, dim3((nwin * gpw + 63) / 64), dim3(64), 0, ctx->stream, groups, buckets, nwin, c);
-    hipLaunchKernelGGL(msm_window_sums_kernel, dim3((nwin + 63) / 64), dim3(64), 0, ctx->stream, wsum, groups, nwin, gpw);
+    hipLaunchKernelGGL(msm_window_sums_kernel, dim3(nwin), dim3(256), 0, ctx->stream, wsum, groups, nwin, gpw);
     hipLaunchKernelGGL(msm_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, (Aff*)out, wsum, nwin, c);
     XLP_HIP(hipGetLastError());
     return 0;
