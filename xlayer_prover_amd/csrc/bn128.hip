@@ -372,6 +372,26 @@ __global__ void fr_fft_stage_kernel(Fr* __restrict__ a, const Fr* __restrict__ t
     gst(&a[k + j + mdiv2], sub(u, t));
 }
 
+// stages s and s + 1 of FFT::fft in one pass through HBM (half the traffic of two radix-2 passes): the four elements
+// k + j + {0, h, 2h, 3h}, h = 2^(s-1), carry both butterflies (same four products)
+__global__ void fr_fft_stage2_kernel(Fr* __restrict__ a, const Fr* __restrict__ tw, const u32 logn, const u32 s)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> (logn - 2)) return;
+    const u64 h = 1ull << (s - 1);
+    const u64 k = (i >> (s - 1)) << (s + 1), j = i & (h - 1);
+    Fr* p = a + k + j;
+    const Fr w1 = gld(&tw[j << (logn - s)]);                         // root(s, j)
+    const Fr x0 = gld(&p[0]), x1 = mul1(w1, gld(&p[h])), x2 = gld(&p[2 * h]), x3 = mul1(w1, gld(&p[3 * h]));
+    const Fr y0 = add(x0, x1), y1 = sub(x0, x1), y2 = add(x2, x3), y3 = sub(x2, x3);
+    const Fr t2 = mul1(gld(&tw[j << (logn - s - 1)]), y2);           // root(s + 1, j)
+    const Fr t3 = mul1(gld(&tw[(j + h) << (logn - s - 1)]), y3);     // root(s + 1, j + h)
+    gst(&p[0], add(y0, t2));
+    gst(&p[2 * h], sub(y0, t2));
+    gst(&p[h], add(y1, t3));
+    gst(&p[3 * h], sub(y1, t3));
+}
+
 // the tail of FFT::ifft (fft.c.hpp:205-221): a[i] <-> a[n - i], everything times 1 / n
 __global__ void fr_ifft_finish_kernel(Fr* __restrict__ a, const u32 logn, const Fr ninv)
 {
@@ -656,7 +676,10 @@ int dev_fft_bn254(Ctx* ctx, u64* data, u64 n, int inverse)
     hipLaunchKernelGGL(bn::fr_bitrev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, logn);
     const u32 nst = logn < (u32)bn::FFT_LB ? logn : (u32)bn::FFT_LB;
     hipLaunchKernelGGL(bn::fr_fft_low_kernel, dim3((unsigned)(n >> nst)), dim3(1 << (bn::FFT_LB - 1)), 0, ctx->stream, a, tw, logn, nst);
-    for (u32 s = nst + 1; s <= logn; s++)
+    u32 s = nst + 1;
+    for (; s + 1 <= logn; s += 2)
+        hipLaunchKernelGGL(bn::fr_fft_stage2_kernel, dim3((unsigned)(((n >> 2) + 255) / 256)), dim3(256), 0, ctx->stream, a, tw, logn, s);
+    if (s <= logn)
         hipLaunchKernelGGL(bn::fr_fft_stage_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, ctx->stream, a, tw, logn, s);
     if (inverse) {
         // 1 / n = 2^-logn: (q + 1) / 2 raised to logn
