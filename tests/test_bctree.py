@@ -30,8 +30,9 @@ def test_bctree_cli_errors(tmp_path):
     assert r.returncode != 0 and "tree ouput file argument not specified" in r.stderr
     r = _run("-c", str(c), "-c", str(c), "-s", str(s), "-t", "y")
     assert r.returncode != 0 and "parameter twice" in r.stderr
+    s.write_text('{"nBits":3,"nBitsExt":4,"verificationHashType":"KECCAK"}')
     r = _run("-c", str(c), "-s", str(s), "-t", str(tmp_path / "t"))
-    assert r.returncode != 0 and "BN128" in r.stderr             # other field: outside the path
+    assert r.returncode != 0 and "Invalid Hash Type" in r.stderr
     s.write_text('{"nBits":3,"nBitsExt":4,"verificationHashType":"GL"}')
     c.write_bytes(b"\0" * 72)
     r = _run("-c", str(c), "-s", str(s), "-t", str(tmp_path / "t"))
@@ -60,3 +61,30 @@ def test_bctree_files_match_oracle(orc, tmp_path, nbits, nbits_ext, npols):
     assert (tree[2 + next_ * npols:] == nodes).all()             # nodes
     vk = json.loads((tmp_path / "x.verkey.json").read_text())
     assert vk == {"constRoot": [int(v) for v in nodes[-4:]]}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nbits,nbits_ext,npols", [(4, 8, 7), (8, 12, 39)])
+def test_bctree_bn128_files_match_oracle(orc, tmp_path, nbits, nbits_ext, npols):
+    """verificationHashType BN128 (build_const_tree.cpp:609-641: the recursivef constants): [source_width, height, source, nodes] with the
+    16-ary MerkleTreeBN128 node buffer, verkey = the root as one decimal string"""
+    from oracle import bn128_oracle as bo
+    const_bin = os.path.join(ROOT, "xlayer_prover_amd", "chelpers", "poseidon_bn128.bin")
+    if not os.path.exists(const_bin):
+        pytest.skip("poseidon_bn128.bin not generated")
+    K = bo.Constants(const_bin)
+    n, next_ = 1 << nbits, 1 << nbits_ext
+    const = orc.fill(n * npols, 0x5EED00D0 + nbits) % np.uint64(orc.P)
+    (tmp_path / "f.const").write_bytes(const.tobytes())
+    (tmp_path / "f.starkstruct.json").write_text(json.dumps({"nBits": nbits, "nBitsExt": nbits_ext, "nQueries": 4, "verificationHashType": "BN128",
+                                                             "steps": [{"nBits": nbits_ext}]}))
+    r = _run("-c", str(tmp_path / "f.const"), "-s", str(tmp_path / "f.starkstruct.json"), "-t", str(tmp_path / "f.consttree"), "-v", str(tmp_path / "f.verkey.json"))
+    assert r.returncode == 0, r.stderr
+    tree = np.fromfile(tmp_path / "f.consttree", dtype=np.uint64)
+    ext = orc.extend_pol(const, next_, n, npols)
+    nodes = bo.merkelize(K, ext.reshape(next_, npols))
+    assert tree.size == 2 + next_ * npols + 4 * len(nodes)
+    assert tree[0] == npols and tree[1] == next_                 # MerkleTreeBN128(void *): source_width, height
+    assert (tree[2:2 + next_ * npols] == ext.reshape(-1)).all()
+    assert (tree[2 + next_ * npols:].reshape(-1, 4) == bo.nodes_to_limbs(nodes)).all()
+    assert json.load(open(tmp_path / "f.verkey.json")) == {"constRoot": str(nodes[-1])}

@@ -93,8 +93,8 @@ inline void buildConstTree(const std::string constFile, const std::string starkS
     const uint64_t nBits = json_u64(st, "nBits"), nBitsExt = json_u64(st, "nBitsExt");
     std::string hashType;
     if (!json_top_level(st, "verificationHashType", hashType)) throw std::runtime_error("starkstruct: missing \"verificationHashType\"");
-    if (hashType == "BN128") throw std::runtime_error("bctree: verificationHashType BN128 is outside this library's path (Goldilocks trees only)");
-    if (hashType != "GL") throw std::runtime_error("Invalid Hash Type: " + hashType);
+    const bool bn128 = hashType == "BN128";
+    if (hashType != "GL" && !bn128) throw std::runtime_error("Invalid Hash Type: " + hashType);
     if (nBitsExt < nBits || nBitsExt > 32) throw std::runtime_error("bctree: need nBits <= nBitsExt <= 32");
     const uint64_t n = 1ULL << nBits, nExt = 1ULL << nBitsExt;
 
@@ -105,7 +105,9 @@ inline void buildConstTree(const std::string constFile, const std::string starkS
     if (nPols == 0 || nPols * n * 8 != constFileSize) throw std::runtime_error("bctree: const file size is not nPols * 2^nBits * 8");
     std::cout << "Pols=" << nPols << "\nnBits=" << nBits << "\nnBitsExt=" << nBitsExt << std::endl;
 
-    const uint64_t numElementsTree = (2 * nExt - 1) * 4, header = 2;
+    // BN128 (build_const_tree.cpp:609-641, the recursivef constants): [source_width, height, source, nodes] with MerkleTreeBN128's 16-ary node
+    // buffer (getNumNodes(height) Fr elements of 4 words) instead of the binary Goldilocks tree
+    const uint64_t numElementsTree = bn128 ? xlp_merkle_bn128_num_nodes(nExt) * 4 : (2 * nExt - 1) * 4, header = 2;
     const uint64_t numElementsCopy = header + nPols * nExt, numElements = numElementsCopy + numElementsTree;
     std::vector<uint64_t> constTree(numElements);
     {
@@ -122,7 +124,8 @@ inline void buildConstTree(const std::string constFile, const std::string starkS
         XLP_BCT(xlp_dev_alloc((void**)&d_nodes, numElementsTree * 8));
         XLP_BCT(xlp_copy_h2d(d_in, stage, n * nPols * 8));
         XLP_BCT(xlp_dev_extend(d_ext, d_in, nExt, n, nPols, NULL));              // Interpolate
-        XLP_BCT(xlp_dev_merkle(d_nodes, d_ext, nPols, nExt));              // MerkleTree_GL
+        if (bn128) XLP_BCT(xlp_dev_merkle_bn128(d_nodes, d_ext, nPols, nExt));  // MerkleTree_BN128
+        else XLP_BCT(xlp_dev_merkle(d_nodes, d_ext, nPols, nExt));              // MerkleTree_GL
         XLP_BCT(xlp_sync());
         constTree[0] = nPols;
         constTree[1] = nExt;
@@ -133,6 +136,30 @@ inline void buildConstTree(const std::string constFile, const std::string starkS
     if (verKeyFile != "") {
         std::ofstream fv(verKeyFile);
         if (!fv) throw std::runtime_error("bctree: cannot write " + verKeyFile);
+        if (bn128) {
+            // rawfr.toString(constRoot): the root out of Montgomery form, in decimal (one JSON string)
+            typedef unsigned __int128 u128;
+            static const uint64_t Q[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+            const uint64_t NP = 0xc2e1f593efffffffULL;
+            uint64_t t[6] = {constTree[numElements - 4], constTree[numElements - 3], constTree[numElements - 2], constTree[numElements - 1], 0, 0};
+            for (int i = 0; i < 4; i++) {                  // Montgomery reduction by 2^256: t <- (t + m q) / 2^64, four times
+                const uint64_t m = t[0] * NP;
+                u128 c = ((u128)m * Q[0] + t[0]) >> 64;
+                for (int j = 1; j < 4; j++) { const u128 p_ = (u128)m * Q[j] + t[j] + (uint64_t)c; t[j - 1] = (uint64_t)p_; c = p_ >> 64; }
+                const u128 s_ = (u128)t[4] + (uint64_t)c; t[3] = (uint64_t)s_; t[4] = (uint64_t)(s_ >> 64);
+            }
+            bool ge = t[4] != 0;
+            if (!ge) { ge = true; for (int i = 3; i >= 0; i--) if (t[i] != Q[i]) { ge = t[i] > Q[i]; break; } }
+            if (ge) { u128 bw = 0; for (int i = 0; i < 4; i++) { const u128 d = (u128)t[i] - Q[i] - (uint64_t)bw; t[i] = (uint64_t)d; bw = (d >> 64) & 1; } }
+            std::string dec;
+            uint64_t w[4] = {t[0], t[1], t[2], t[3]};
+            while (w[0] | w[1] | w[2] | w[3]) {
+                u128 rem = 0;
+                for (int i = 3; i >= 0; i--) { const u128 cur = (rem << 64) | w[i]; w[i] = (uint64_t)(cur / 10); rem = cur % 10; }
+                dec.insert(dec.begin(), (char)('0' + (int)rem));
+            }
+            fv << "{\"constRoot\":\"" << (dec.empty() ? "0" : dec) << "\"}" << std::endl;
+        } else
         fv << "{\"constRoot\":[" << constTree[numElements - 4] << "," << constTree[numElements - 3] << "," << constTree[numElements - 2] << ","
            << constTree[numElements - 1] << "]}" << std::endl;
     }
