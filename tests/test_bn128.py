@@ -427,3 +427,27 @@ def test_gpu_msm_bn254_skewed_scalars_heavy_buckets(xlp):
         sc = np.array([[(k >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]] * n, dtype=np.uint64)
         got = bo.g1_from_limbs(xlp.msm_bn254(bases, sc))
         assert got == bo.g1_mul(S1, k % bo.R_MOD)
+
+
+@pytest.mark.gpu
+@needs_constants
+def test_cpp_stark_recursivef_loads_bctree_bn128_tree(tmp_path):
+    """`bctree` with verificationHashType BN128 writes <name>.consttree; StarkRecursiveF loads it (constants' extension + 16-ary tree) instead
+    of computing them: the proof is the same either way"""
+    import json
+    import subprocess
+    from tests import mini_genproof_flow as flow
+    nbits, steps, nq = 7, [8, 5], 6
+    flow.toy_stark_files(str(tmp_path), "toy", nbits, steps, nq, seed=nbits)
+    shim = os.path.join(ROOT, "xlayer_prover_amd", "host", "test_host_shim")
+    bct = os.path.join(ROOT, "xlayer_prover_amd", "host", "bctree")
+    r0 = subprocess.run([shim, "genproof_bn128", str(tmp_path), "toy"], capture_output=True, text=True)
+    assert r0.returncode == 0, r0.stderr[-2000:]
+    (tmp_path / "ss.json").write_text(json.dumps({"nBits": nbits, "nBitsExt": steps[0], "verificationHashType": "BN128", "steps": [{"nBits": b} for b in steps]}))
+    rb = subprocess.run([bct, "-c", str(tmp_path / "toy.const"), "-s", str(tmp_path / "ss.json"), "-t", str(tmp_path / "toy.consttree_bn128"),
+                         "-v", str(tmp_path / "toy.verkey_bn128.json")], capture_output=True, text=True)
+    assert rb.returncode == 0, rb.stderr
+    r1 = subprocess.run([shim, "genproof_bn128", str(tmp_path), "toy"], capture_output=True, text=True)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    assert r1.stdout == r0.stdout
+    assert json.loads(r1.stdout)["verkey"] == json.load(open(tmp_path / "toy.verkey_bn128.json"))["constRoot"]

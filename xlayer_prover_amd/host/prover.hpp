@@ -96,7 +96,7 @@ public:
             recursive2Steps = new Recursive2Steps(dirOf(config.recursive2StarkInfo));
         }
         if (haveRF) {
-            starksRecursiveF = new StarkRecursiveF(config, {config.recursivefConstPols, config.mapConstPolsFile, "", config.recursivefStarkInfo}, pAddress);
+            starksRecursiveF = new StarkRecursiveF(config, {config.recursivefConstPols, config.mapConstPolsFile, config.recursivefConstantsTree, config.recursivefStarkInfo}, pAddress);
             recursivefSteps = new StarkRecursiveFSteps(dirOf(config.recursivefStarkInfo));
         }
     }

@@ -175,7 +175,8 @@ struct XlpHashBN128
     typedef FRIProofC12 Proof;
     typedef FRIProveC12 Prove;
     typedef RawFr::Element Root[1];
-    static constexpr bool kFileTree = false;         // the constant tree is computed from the constant polynomials (a few hundred ms at recursivef size)
+    static constexpr bool kFileTree = true;          // recursivef.consttree as bctree (verificationHashType BN128) writes it: [width, height, source, nodes]
+    static uint64_t treeWords(Tree* t) { return t->numNodes * 4; }
     static void getField(TranscriptT& t, Goldilocks::Element* out)
     {
         uint64_t f[3];
@@ -207,7 +208,7 @@ struct XlpHashBN128
 class StarkRecursiveF : public StarksT<XlpHashBN128>
 {
 public:
-    // the reference reads config.recursivef{StarkInfo,ConstPols,ConstantsTree}; here the three files are given (the constants tree is not read)
+    // the reference reads config.recursivef{StarkInfo,ConstPols,ConstantsTree}; here the three files are given (an absent tree file: computed)
     StarkRecursiveF(const Config& config, StarkFiles starkFiles, void* _pAddress) : StarksT<XlpHashBN128>(config, starkFiles, _pAddress) {}
     void genProof(FRIProofC12& proof, Goldilocks::Element* publicInputs, Steps* steps) { StarksT<XlpHashBN128>::genProof(proof, publicInputs, NULL, steps); }
 };

@@ -65,7 +65,8 @@ struct XlpHashGL
     typedef FRIProof Proof;
     typedef FRIProve Prove;
     typedef Goldilocks::Element Root[HASH_SIZE];
-    static constexpr bool kFileTree = true;          // <stark>.consttree in the MerkleTreeGL layout can be mapped instead of computed
+    static constexpr bool kFileTree = true;          // <stark>.consttree (bctree's file) can be loaded instead of computed
+    static uint64_t treeWords(Tree* t) { return t->getTreeNumElements(); }
     static void getField(TranscriptT& t, Goldilocks::Element* out) { t.getField(out); }
     static void putRoot(TranscriptT& t, Goldilocks::Element* r) { t.put(r, HASH_SIZE); }
     static void putVerkey(TranscriptT& t, Goldilocks::Element* verkey, Goldilocks::Element* /*constRoot*/) { t.put(&verkey[0], 4); }   // starks.cpp:33
@@ -215,7 +216,7 @@ public:
             fclose(fp);
             if (hdr[0] != starkInfo.nConstants || hdr[1] != NExtended) xlp_exit_process("Starks: constant tree does not match the starkinfo");
             fileToDevice(constPols2ns(), starkFiles.zkevmConstantsTree, 16, NExtended * starkInfo.nConstants * 8);
-            fileToDevice(treesGL[4]->d_nodes, starkFiles.zkevmConstantsTree, 16 + NExtended * starkInfo.nConstants * 8, treesGL[4]->getTreeNumElements() * 8);
+            fileToDevice(treesGL[4]->d_nodes, starkFiles.zkevmConstantsTree, 16 + NExtended * starkInfo.nConstants * 8, H::treeWords(treesGL[4]) * 8);
           }
         } else {
             XLP_CHECK(xlp_dev_extend(constPols2ns(), d_const_n, NExtended, N, starkInfo.nConstants, NULL));

@@ -212,7 +212,7 @@ static int genproof_bn128_mode(const std::string& dir, const std::string& name)
     std::vector<Goldilocks::Element> cm1 = read_u64_file(dir + "/" + name + ".commit"), publics = read_u64_file(dir + "/" + name + ".publics");
     Config config;
     config.runFileGenFinalProof = true;
-    StarkRecursiveF starks(config, {dir + "/" + name + ".const", false, "", dir + "/" + name + ".starkinfo.json"}, cm1.data());
+    StarkRecursiveF starks(config, {dir + "/" + name + ".const", false, dir + "/" + name + ".consttree_bn128", dir + "/" + name + ".starkinfo.json"}, cm1.data());   // the tree file is optional
     XlpSteps steps(dir, name);
     const StarkStruct& ss = starks.starkInfo.starkStruct;
     FRIProofC12 proof(1ULL << ss.steps.back().nBits, FIELD_EXTENSION, ss.steps.size(), starks.starkInfo.evMap.size(), starks.starkInfo.nPublics);
