@@ -483,3 +483,33 @@ def hoist_sum_terms(prog, min_distance=64, min_terms=8):
     out.ntmp1 = max(out.ntmp1, prog.ntmp1)
     out.ntmp3 = max(out.ntmp3, ntmp3)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+def segment_traffic(prog_or_code, seg=256):
+    """offline model of the ahead-of-time form's HBM traffic per row: (column words loaded, summed over segments of `seg` instructions;
+    temporary words live across segment boundaries).  Each segment kernel loads a staged column word once and keeps it in a register."""
+    code = prog_or_code.code if hasattr(prog_or_code, "code") else prog_or_code
+    ins = list(E.decode(code))
+    cols, n = 0, len(ins)
+    width = {E.K_TMP1: 1, E.K_TMP3: 3}
+    last_use, first_def = {}, {}
+    for i, (op, d, a, b) in enumerate(ins):
+        for o in (a, b):
+            if o is not None and o.kind in width:
+                last_use[(o.kind, o.params[0], first_def.get((o.kind, o.params[0]), -1))] = i
+        if d.kind in width:
+            first_def[(d.kind, d.params[0])] = i
+    for s0 in range(0, n, seg):
+        cs = set()
+        for op, d, a, b in ins[s0:s0 + seg]:
+            for o in (a, b):
+                if o is not None and o.kind in _COL:
+                    for c in range(o.dim):
+                        cs.add((o.kind in (E.K_POLS, E.K_POLS_PRIME), o.kind in (E.K_CONST2NS, E.K_CONST2NS_PRIME), tuple(o.params), c))
+        cols += len(cs)
+    tmps = 0
+    for (kind, slot, dpos), lu in last_use.items():
+        if dpos >= 0 and lu // seg != dpos // seg:
+            tmps += width[kind] * (lu // seg - dpos // seg >= 1)
+    return cols, tmps
