@@ -90,10 +90,24 @@ def _check_real():
         assert L[k][0] == v, (k, L[k][0], v)
 
 
-def relocate(codes, log_n, aliased=False):
-    """codes: converted zkEVM programs (real 2^23-row addressing) -> ([codes for N = 2^log_n], info)"""
+def layout_window(log_n, world, circ="zkevm"):
+    """per-rank slab of a proof row-sharded over `world` ranks: every section holds the rank's rows followed by the halo rows of the
+    next rank (1 on the base domain, 2^ext on the extended one: the next-row distances of the step programs)"""
+    ext = CIRCUITS[circ]["ext"]
+    n, ne = (1 << log_n) // world, (1 << (log_n + ext)) // world
+    o, out = 0, {}
+    for name, w, e in sections(circ):
+        rows = ne + (1 << ext) if e else n + 1
+        out[name] = (o, w, rows); o += w * rows
+    out["end"] = (o, 0, 0)
+    return out
+
+
+def relocate(codes, log_n, aliased=False, new_layout=None):
+    """codes: converted zkEVM programs (real 2^23-row addressing) -> ([codes for N = 2^log_n], info); new_layout: another packing of the
+    same sections (layout_window: the next-row operands keep the GLOBAL modulus 2^log_n and never wrap inside a window)"""
     _check_real()
-    real, new = layout(LOG_N_REAL), layout(log_n, aliased)
+    real, new = layout(LOG_N_REAL), (new_layout or layout(log_n, aliased))
     bases = sorted((real[name][0], name) for name, _, _ in SECTIONS)
 
     def move(off, stride):
@@ -149,12 +163,12 @@ def scan_info(codes):
     return info
 
 
-def load(log_n, aliased=False, circ="zkevm"):
+def load(log_n, aliased=False, circ="zkevm", new_layout=None):
     import os
     steps = CIRCUITS[circ]["steps"]
     progs = [R.read_program(os.path.join(R.REF_DIR, f"{circ}.{s}.xlpexpr")) for s in steps]
     if circ == "zkevm":
-        codes, info = relocate([p[0] for p in progs], log_n, aliased)
+        codes, info = relocate([p[0] for p in progs], log_n, aliased, new_layout)
     else:                                           # small STARKs run at their real geometry: the programs as converted
         assert log_n == CIRCUITS[circ]["log_n"] and not aliased
         codes = [p[0] for p in progs]
