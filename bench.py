@@ -283,6 +283,35 @@ def genproof_leg(timeout_s=300):
     return out
 
 
+def sharded_genproof_leg(world, rank, local_rank, log_n, timeout_s=240):
+    """The row-sharded genProof at the zkEVM geometry (tools/zkevm_genproof_sharded.py) over the ranks of this run: every rank starts the
+    tool as a CHILD process on its own GPU (own rendezvous, one port above this run's), so that a failure on ranks that never ran
+    together before (the flow is checked against the one-GPU flow with ranks SHARING a GPU, tests/test_sharded_zkevm.py; this pool has no
+    multi-GPU box) costs this leg, not the bench line.  Rank 0's child reports stage times, the all-to-all volume / rate, the roots,
+    and re-runs the one-GPU flow on the same witness with the same (interpreted) step programs: same roots and FRI layers expected."""
+    import subprocess
+    env = dict(os.environ)
+    env.update(RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 23), PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""))
+    for k in ("TORCHELASTIC_RUN_ID", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_USE_AGENT_STORE"):
+        env.pop(k, None)                                     # the child makes a plain env:// rendezvous of its own
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "zkevm_genproof_sharded.py"), "--log-n", str(log_n), "--collectives", "--check-one-gpu"]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env)
+    try:
+        out, err = p.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        p.kill(); p.communicate()
+        return {"error": f"rank {rank}: no result within {timeout_s} s"}
+    if p.returncode != 0:
+        return {"error": f"rank {rank}: exit {p.returncode}: {err[-300:]}"}
+    if rank != 0:
+        return None
+    try:
+        return json.loads(out.strip().splitlines()[-1])
+    except Exception as e:
+        return {"error": repr(e)[:200] + " / " + out[-200:]}
+
+
 def e2e_leg(timeout_s=300):
     """BASELINE configs[4] minus the SNARK wrap, through the C++ Prover (host/zkprover_batch --e2e): two consecutive batch proofs
     (each: zkEVM 2^23 + c12a + recursive1), Prover::genAggregatedProof (joinzkin + the recursive2 STARK) and Prover::genFinalProof up
@@ -320,6 +349,8 @@ def main():
     ap.add_argument("--no-genproof", action="store_true", help="skip the whole-genProof leg (N=1 only; ~25 s)")
     ap.add_argument("--sharded-commit", type=int, default=-1, help="time the section commit sharded over the ranks (default: on for --gpus > 1; 1 forces it at N=1 "
                     "through RCCL in a world of one)")
+    ap.add_argument("--sharded-genproof", type=int, default=-1, help="log2 N of the row-sharded zkEVM-geometry genProof run over the ranks "
+                    "(tools/zkevm_genproof_sharded.py, one child process per rank); 0 = off; default: 20 when --gpus > 1, off on one GPU")
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--ncols", type=int, default=NCOLS)
     args = ap.parse_args()
@@ -401,6 +432,17 @@ def main():
         except Exception as e:                               # reported, never fatal for the headline line
             sharded = {"error": repr(e)[:300]}
         src = out = None
+    sharded_gp = None
+    gp_log_n = args.sharded_genproof if args.sharded_genproof >= 0 else (20 if world > 1 else 0)
+    if gp_log_n:
+        src = out = None
+        torch.cuda.empty_cache()
+        try:
+            sharded_gp = sharded_genproof_leg(world, rank, local_rank, gp_log_n)
+        except Exception as e:                               # reported, never fatal for the headline line
+            sharded_gp = {"error": repr(e)[:300]}
+        if world > 1:
+            dist.barrier()
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         fe_per_step = n_ext * ncols * world
@@ -446,6 +488,8 @@ def main():
         }
         if sharded is not None:
             line["sharded_commit"] = sharded
+        if sharded_gp is not None:
+            line["sharded_genproof"] = sharded_gp
         if world == 1:
             line["roofline_merkle"] = merkle_leg(capi, torch, dev)
             if not args.no_bn128:

@@ -67,6 +67,40 @@ def test_sharded_commit_equals_single_process_tree(world, ncols, orc):
             assert rows == ext[r0:r1].tolist()                         # exchange delivered all columns of my rows
 
 
+def _exchange_worker(rank, world, port, h, ncols, max_words, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from xlayer_prover_amd import shard
+    shard.MAX_MESSAGE_WORDS = max_words                        # many rounds, ragged tails (the product value is 2^25 words)
+    full = torch.arange(h * ncols, dtype=torch.int64).view(h, ncols) * 7 + 3
+    c0, c1 = shard.col_range(ncols, world, rank)
+    r0, r1 = shard.row_range(h, world, rank)
+    rows = shard.columns_to_rows(full[:, c0:c1].contiguous(), ncols)
+    cols = shard.rows_to_columns(full[r0:r1].contiguous(), h)
+    q.put((rank, bool((rows == full[r0:r1]).all()), bool((cols == full[:, c0:c1]).all())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,ncols,max_words", [(2, 5, 7), (4, 11, 5), (4, 6, 1 << 25), (2, 8, 16)])
+def test_banded_exchange_rounds(world, ncols, max_words):
+    """columns <-> rows in rounds of at most MAX_MESSAGE_WORDS per message: spans of unequal width end in different rounds"""
+    h = 32
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + world * 7 + ncols
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, h, ncols, max_words, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(r, True, True) for r in range(world)]
+
+
 def test_partitions():
     from xlayer_prover_amd import shard
     for W, G in [(751, 8), (168, 8), (408, 8), (6, 4), (8, 2), (5, 2)]:

@@ -124,3 +124,32 @@ def test_sharded_zkevm_genproof_ranks_on_one_gpu(orc, world):
         assert out["roots"] == exp_roots, rank
         assert out["fri_roots_and_head_of_final_pol"] == exp_fri, rank
         _check_openings(orc, out, 1 << (LN + 1))
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_of_a_large_section_world_of_one():
+    """A section of 751 x 2^18 words (1.5 GiB) through the RCCL exchange paths of shard.py: both directions must be the identity in a
+    world of one.  (As ONE all_to_all_single message this size comes back with its second half unwritten from the RCCL of this image;
+    shard._exchange therefore moves sections in rounds of <= 256 MiB per message and copies the own block locally.)"""
+    import torch
+    import torch.distributed as dist
+    from xlayer_prover_amd import capi, shard
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    capi.init(0); capi.use_torch_stream()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29643")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    old = shard.FORCE_EXCHANGE
+    try:
+        shard.FORCE_EXCHANGE = True
+        n, w = 1 << 18, 751
+        x = torch.empty(n * w, dtype=torch.int64, device="cuda"); capi.dev_fill(x, 0x5EED0777, 0)
+        cols = shard.rows_to_columns(x.view(n, w), n)
+        assert bool((cols.reshape(-1) == x).all())
+        rows = shard.columns_to_rows(cols, w)
+        assert bool((rows.reshape(-1) == x).all())
+    finally:
+        shard.FORCE_EXCHANGE = old
+        dist.destroy_process_group()

@@ -318,6 +318,8 @@ def main():
     ap.add_argument("--log-n", type=int, default=16)
     ap.add_argument("--queries", type=int, default=0)
     ap.add_argument("--collectives", action="store_true", help="take the exchange paths even in a world of one rank")
+    ap.add_argument("--check-one-gpu", action="store_true", help="rank 0 then runs the one-GPU flow (tools/bench_zkevm_genproof.py, programs "
+                    "interpreted as here) on the same synthetic witness: same roots / FRI layers expected, its wall reported beside the sharded one")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -328,6 +330,7 @@ def main():
     res, timers = None, {}
     for rep in range(2):                                   # pass 0 warms allocators / code objects
         timers.clear()
+        shard.EXCHANGE_STATS = {} if dist.is_initialized() else None
         torch.cuda.synchronize()
         if dist.is_initialized():
             dist.barrier()
@@ -336,10 +339,27 @@ def main():
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
     if not dist.is_initialized() or dist.get_rank() == 0:
-        print(json.dumps({"workload": f"zkEVM-geometry genProof row-sharded over {world} rank(s), N = 2^{a.log_n}; step programs interpreted "
-                                      "(window-relocated programs have no ahead-of-time plugins yet)",
-                          "wall_s_incl_setup": round(wall, 4), "timers_s": {k: round(v, 4) for k, v in timers.items()},
-                          "roots": res["roots"], "fri_roots_and_head_of_final_pol": res["fri_roots_and_head_of_final_pol"]}))
+        line = {"workload": f"zkEVM-geometry genProof row-sharded over {world} rank(s), N = 2^{a.log_n}; step programs interpreted "
+                            "(window-relocated programs have no ahead-of-time plugins yet)",
+                "wall_s_incl_setup": round(wall, 4), "sum_timed_s": round(sum(timers.values()), 4),
+                "timers_s": {k: round(v, 4) for k, v in timers.items()}, "roots": res["roots"], "fri_roots_and_head_of_final_pol": res["fri_roots_and_head_of_final_pol"]}
+        st = shard.EXCHANGE_STATS
+        if st and st.get("all_to_all_s"):
+            line["exchange_rank0"] = {"all_to_all_calls": st["all_to_all_calls"], "all_to_all_s": round(st["all_to_all_s"], 4),
+                                      "GB_sent_to_peers": round(st["bytes_sent_to_peers"] / 1e9, 3),
+                                      "GBs_sent_per_rank": round(st["bytes_sent_to_peers"] / 1e9 / st["all_to_all_s"], 1)}
+        if a.check_one_gpu:
+            import argparse as _ap
+            from tools import bench_zkevm_genproof as one
+            expect = (res["roots"], res["fri_roots_and_head_of_final_pol"])
+            res = None
+            torch.cuda.empty_cache()
+            o = one.prove(_ap.Namespace(log_n=a.log_n, circuit="zkevm", batch=False, fri_steps="", queries=a.queries, lookups=-1, zs=-1, no_jit=True,
+                                        no_dots=False, vm_only="", no_opt=False, aliased=0), "zkevm", a.log_n)
+            line["one_gpu_same_programs"] = {"genproof_wall_s": o["genproof_wall_s"], "timers_s": o["timers_s"],
+                                             "same_roots_and_fri_layers": (o["roots"], o["fri_roots_and_head_of_final_pol"]) == expect,
+                                             "same_by_tree": [x == y for x, y in zip(o["roots"] + o["fri_roots_and_head_of_final_pol"], expect[0] + expect[1])]}
+        print(json.dumps(line))
     if dist.is_initialized():
         dist.destroy_process_group()
 

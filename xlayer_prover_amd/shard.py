@@ -19,7 +19,64 @@ import torch
 import torch.distributed as dist
 
 
-FORCE_EXCHANGE = False      # tests: take the all_to_all_single path even in a world of one rank (RCCL plumbing on one GPU)
+FORCE_EXCHANGE = False      # tests: take the exchange paths even in a world of one rank (RCCL plumbing on one GPU)
+EXCHANGE_STATS = None       # bench: set to {} to account the all-to-alls (synchronises around each one): calls, bytes sent by this rank, seconds
+
+
+MAX_MESSAGE_WORDS = 1 << 25  # 256 MiB per (sender, receiver) message and round, see _exchange
+
+
+def _run_p2p(ops, group):
+    """one round of sends / receives.  RCCL: one coalesced group (separately enqueued sends would wait for receives that sit behind
+    the peers' own sends).  gloo (CPU tests; device tensors of ranks sharing a GPU go through the host): plain isend / irecv."""
+    if not ops:
+        return
+    if dist.get_backend(group) != "gloo":
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        return
+    reqs, back = [], []
+    for op in ops:
+        if op.op is dist.isend:
+            reqs.append(dist.isend(op.tensor.cpu().contiguous(), op.peer, group=group))
+        else:
+            h = torch.empty(op.tensor.shape, dtype=op.tensor.dtype)
+            reqs.append(dist.irecv(h, op.peer, group=group)); back.append((op.tensor, h))
+    for r in reqs:
+        r.wait()
+    for d, h in back:
+        d.copy_(h)
+
+
+def _exchange(recv, send, max_words, group):
+    """recv[p] <- what rank p holds for me, send[p] -> rank p; 1-D contiguous tensors, len(send[p]) here == len(recv[me]) on p.
+    max_words: the longest message of the whole exchange (every rank derives the same value from the column spans).
+    The own block is a local copy; the rest goes in rounds of <= MAX_MESSAGE_WORDS per message, each round one grouped
+    send / receive (`batch_isend_irecv`: direct peer exchange, all xGMI links at once) over slices of the tensors (no packing).  Why rounds: the RCCL of this image leaves the second half of a self
+    message unwritten from somewhere between 1 and 1.5 GiB on (measured on one MI355X, 2^27 words fine, 751 x 2^18 and 2^28 words
+    not; peer messages of that size could not be tried in this pool), and a zkEVM section at G = 8 is 1.6 GB per message; rounds
+    are also what a copy / LDE / hash pipeline across bands wants."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    st = EXCHANGE_STATS
+    if st is not None:
+        import time
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+    recv[rank].copy_(send[rank])
+    if world > 1:
+        for o in range(0, max_words, MAX_MESSAGE_WORDS):
+            ops = []
+            for d in range(1, world):                         # the same pairing order on every rank; empty tails are left out
+                to, frm = (rank + d) % world, (rank - d) % world
+                if send[to].numel() > o:
+                    ops.append(dist.P2POp(dist.isend, send[to][o:o + MAX_MESSAGE_WORDS], to, group))
+                if recv[frm].numel() > o:
+                    ops.append(dist.P2POp(dist.irecv, recv[frm][o:o + MAX_MESSAGE_WORDS], frm, group))
+            _run_p2p(ops, group)
+    if st is not None:
+        torch.cuda.synchronize()
+        st["all_to_all_calls"] = st.get("all_to_all_calls", 0) + 1
+        st["all_to_all_s"] = st.get("all_to_all_s", 0.0) + time.perf_counter() - t0
+        st["bytes_sent_to_peers"] = st.get("bytes_sent_to_peers", 0) + sum(send[p].numel() for p in range(world) if p != rank) * send[rank].element_size()
 
 
 def col_range(ncols, world, rank):
@@ -49,7 +106,7 @@ def _band_copy(dst, dst_col, src, src_col, rows, width):
 
 def columns_to_rows(local, ncols, group=None):
     """local: [h, wc_local] (this rank's columns of all rows) -> [h / G, ncols] (all columns of this
-    rank's rows).  ONE all_to_all_single -- the rows destined to peer p are already contiguous in `local`, so the send side is
+    rank's rows).  One exchange (`_exchange`) -- the rows destined to peer p are already contiguous in `local`, so the send side is
     the tensor itself; direct peer exchange, every xGMI link busy (no ring) -- and one band copy per peer that drops the
     received [h / G, wc_p] block into its columns of the row-major result (the layout the leaf sponge and the step programs read)."""
     world = dist.get_world_size(group)
@@ -60,40 +117,14 @@ def columns_to_rows(local, ncols, group=None):
     if world == 1 and not FORCE_EXCHANGE:
         return local                                          # one rank owns every column of every row already
     per = h // world
-    if dist.get_backend(group) == "gloo":                     # tests: gloo has no all_to_all on CPU tensors
-        send = [local[p * per:(p + 1) * per].contiguous() for p in range(world)]
-        recv = [torch.empty((per, c1 - c0), dtype=local.dtype, device=local.device) for c0, c1 in spans]
-        _all_to_all_gloo(recv, send, group)
-    else:
-        stage = torch.empty(per * ncols, dtype=local.dtype, device=local.device)
-        dist.all_to_all_single(stage, local.contiguous().view(-1), output_split_sizes=[per * (c1 - c0) for c0, c1 in spans],
-                               input_split_sizes=[per * wc] * world, group=group)
-        recv, o = [], 0
-        for c0, c1 in spans:
-            recv.append(stage[o:o + per * (c1 - c0)].view(per, c1 - c0)); o += per * (c1 - c0)
+    recv = [torch.empty((per, c1 - c0), dtype=local.dtype, device=local.device) for c0, c1 in spans]
+    flat = local.contiguous().view(-1)
+    _exchange([r.view(-1) for r in recv], [flat[p * per * wc:(p + 1) * per * wc] for p in range(world)],
+              per * max(c1 - c0 for c0, c1 in spans), group)
     out = torch.empty((per, ncols), dtype=local.dtype, device=local.device)
     for (c0, c1), blk in zip(spans, recv):
         _band_copy(out, c0, blk, 0, per, c1 - c0)
     return out
-
-
-def _all_to_all_gloo(recv, send, group):
-    # gloo has no all_to_all for CPU tensors: pairwise exchange (tests only); device tensors go through the host
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    recv[rank].copy_(send[rank])
-    reqs, back = [], []
-    for p in range(world):
-        if p == rank:
-            continue
-        r_h = torch.empty(recv[p].shape, dtype=recv[p].dtype) if recv[p].is_cuda else recv[p]
-        reqs.append(dist.isend(send[p].cpu(), p, group=group))
-        reqs.append(dist.irecv(r_h, p, group=group))
-        back.append((recv[p], r_h))
-    for r in reqs:
-        r.wait()
-    for d, h in back:
-        if d is not h:
-            d.copy_(h)
 
 
 def _host_staged(t, group):
@@ -123,7 +154,12 @@ def _sendrecv(send, dst, src, group=None):
             r.wait()
         return r_h.to(send.device)
     recv = torch.empty_like(send)
-    reqs = [dist.isend(send, dst=dst, group=group), dist.irecv(recv, src=src, group=group)]
+    if dist.get_backend(group) == "nccl":
+        # one coalesced group: every rank sends to its ring neighbour and receives from the other one at the same time; separately
+        # enqueued sends would wait for receives that sit behind the peers' own sends
+        reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, send.contiguous(), dst, group), dist.P2POp(dist.irecv, recv, src, group)])
+    else:
+        reqs = [dist.isend(send, dst=dst, group=group), dist.irecv(recv, src=src, group=group)]
     for r in reqs:
         r.wait()
     return recv
@@ -131,8 +167,8 @@ def _sendrecv(send, dst, src, group=None):
 
 def rows_to_columns(local, nrows, group=None):
     """inverse of columns_to_rows.  local: [h / G, ncols] (all columns of this rank's rows) -> [h, wc_local] (this rank's
-    columns of all rows): the layout the per-column LDE wants.  One band copy per peer packs its columns, ONE
-    all_to_all_single delivers straight into the result (the block of peer p IS rows row_range(p) of the result)."""
+    columns of all rows): the layout the per-column LDE wants.  One band copy per peer packs its columns, the
+    exchange (`_exchange`) delivers straight into the result (the block of peer p IS rows row_range(p) of the result)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     per, ncols = local.shape
@@ -142,19 +178,14 @@ def rows_to_columns(local, nrows, group=None):
     spans = [col_range(ncols, world, p) for p in range(world)]
     c0, c1 = spans[rank]
     out = torch.empty((nrows, c1 - c0), dtype=local.dtype, device=local.device)
-    if dist.get_backend(group) == "gloo":
-        send = [local[:, a:b].contiguous() for a, b in spans]
-        recv = [out[p * per:(p + 1) * per] for p in range(world)]
-        tmp = [torch.empty((per, c1 - c0), dtype=local.dtype, device=local.device) for _ in range(world)]
-        _all_to_all_gloo(tmp, send, group)
-        for r, t in zip(recv, tmp):
-            r.copy_(t)
-        return out
-    stage = torch.empty(per * ncols, dtype=local.dtype, device=local.device)
-    o = 0
+    send = []
     for a, b in spans:
-        _band_copy(stage[o:o + per * (b - a)].view(per, b - a), 0, local, a, per, b - a); o += per * (b - a)
-    dist.all_to_all_single(out.view(-1), stage, output_split_sizes=[per * (c1 - c0)] * world, input_split_sizes=[per * (b - a) for a, b in spans], group=group)
+        blk = torch.empty((per, b - a), dtype=local.dtype, device=local.device)
+        _band_copy(blk, 0, local, a, per, b - a)
+        send.append(blk.view(-1))
+    flat = out.view(-1)
+    w_me = c1 - c0
+    _exchange([flat[p * per * w_me:(p + 1) * per * w_me] for p in range(world)], send, per * max(b - a for a, b in spans), group)
     return out
 
 
