@@ -211,9 +211,9 @@ def sharded_commit_leg(capi, torch, dist, dev, world, rank, log_n=23, ncols=751,
     dist.barrier()
     sent = 8 * n_ext * wc * (world - 1) / world
     return {"workload": f"one section 2^{log_n} x {W} -> 2^{log_n + 1} x {W} + Merkle root, columns sharded over {world} ranks (strong scaling)",
-            "stage_s": {"lde": round(lde, 5), "all_to_all_and_unpack": round(a2a, 5), "merkle_subtree": round(mk, 5), "caps_all_gather_and_top": round(caps, 5)},
+            "stage_s": {"lde": round(lde, 5), "exchange_and_unpack": round(a2a, 5), "merkle_subtree": round(mk, 5), "caps_all_gather_and_top": round(caps, 5)},
             "commit_s": round(lde + a2a + mk + caps, 5), "bytes_sent_per_rank": int(sent),
-            "all_to_all_GBps_per_rank": round(sent / a2a / 1e9, 1) if a2a > 0 and world > 1 else None,
+            "exchange_GBps_sent_per_rank": round(sent / a2a / 1e9, 1) if a2a > 0 and world > 1 else None,
             "root": [int(v) & 0xFFFFFFFFFFFFFFFF for v in root.tolist()], "root_equals_single_gpu_commit": ok}
 
 
@@ -283,19 +283,18 @@ def genproof_leg(timeout_s=300):
     return out
 
 
-def sharded_genproof_leg(world, rank, local_rank, log_n, timeout_s=240):
-    """The row-sharded genProof at the zkEVM geometry (tools/zkevm_genproof_sharded.py) over the ranks of this run: every rank starts the
-    tool as a CHILD process on its own GPU (own rendezvous, one port above this run's), so that a failure on ranks that never ran
-    together before (the flow is checked against the one-GPU flow with ranks SHARING a GPU, tests/test_sharded_zkevm.py; this pool has no
-    multi-GPU box) costs this leg, not the bench line.  Rank 0's child reports stage times, the all-to-all volume / rate, the roots,
-    and re-runs the one-GPU flow on the same witness with the same (interpreted) step programs: same roots and FRI layers expected."""
+def child_leg(tool, tool_args, world, rank, local_rank, port_offset, backend, timeout_s=300):
+    """Run tools/<tool> over the ranks of this run as one CHILD process per rank on the rank's GPU, with a rendezvous of its own
+    (port_offset above this run's port) and a hard timeout.  The multi-rank exchanges have run with ranks SHARING a GPU only (this
+    pool has no multi-GPU box): a failure or a hang on hardware they never saw then costs that leg, not the bench line.
+    -> the JSON line rank 0's child printed (rank 0), None (other ranks), or {"error": ...}."""
     import subprocess
     env = dict(os.environ)
     env.update(RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 23), PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""))
+               MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + port_offset), PYTHONPATH=ROOT + os.pathsep + env.get("PYTHONPATH", ""))
     for k in ("TORCHELASTIC_RUN_ID", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_USE_AGENT_STORE"):
         env.pop(k, None)                                     # the child makes a plain env:// rendezvous of its own
-    cmd = [sys.executable, os.path.join(ROOT, "tools", "zkevm_genproof_sharded.py"), "--log-n", str(log_n), "--collectives", "--check-one-gpu"]
+    cmd = [sys.executable, os.path.join(ROOT, "tools", tool)] + tool_args + ["--backend", backend]
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env)
     try:
         out, err = p.communicate(timeout=timeout_s)
@@ -351,6 +350,8 @@ def main():
                     "through RCCL in a world of one)")
     ap.add_argument("--sharded-genproof", type=int, default=-1, help="log2 N of the row-sharded zkEVM-geometry genProof run over the ranks "
                     "(tools/zkevm_genproof_sharded.py, one child process per rank); 0 = off; default: 20 when --gpus > 1, off on one GPU")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the --gpus N path with the ranks SHARING GPU 0 "
+                    "(exchanges staged through the host); its numbers mean nothing")
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--ncols", type=int, default=NCOLS)
     args = ap.parse_args()
@@ -369,12 +370,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if args.backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
-        dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(seconds=600))
+        if args.backend == "gloo":
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=900))
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(seconds=900))
 
     capi.init(local_rank)
 
@@ -416,15 +422,16 @@ def main():
     elapsed = t1 - t0
     dev_ms = ev0.elapsed_time(ev1)           # HIP events on the stream the kernels run on
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    sharded = None
-    if (world > 1 and args.sharded_commit != 0) or args.sharded_commit == 1:
-        if world == 1 and not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29641")
-            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    # ---- the exchange-carrying legs.  On one GPU: in this process (opt-in).  On several: one child process per rank.
+    sharded, sharded_gp = None, None
+    gp_log_n = args.sharded_genproof if args.sharded_genproof >= 0 else (20 if world > 1 else 0)
+    if world == 1 and args.sharded_commit == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29641")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
         del src, out
         torch.cuda.empty_cache()
         try:
@@ -432,17 +439,21 @@ def main():
         except Exception as e:                               # reported, never fatal for the headline line
             sharded = {"error": repr(e)[:300]}
         src = out = None
-    sharded_gp = None
-    gp_log_n = args.sharded_genproof if args.sharded_genproof >= 0 else (20 if world > 1 else 0)
-    if gp_log_n:
+    if world > 1 and (args.sharded_commit != 0 or gp_log_n):
         src = out = None
         torch.cuda.empty_cache()
-        try:
-            sharded_gp = sharded_genproof_leg(world, rank, local_rank, gp_log_n)
-        except Exception as e:                               # reported, never fatal for the headline line
-            sharded_gp = {"error": repr(e)[:300]}
-        if world > 1:
+        capi.shutdown()                                      # the children get the whole GPU
+        if args.sharded_commit != 0:
+            sharded = child_leg("bench_sharded_commit.py", ["--log-n", str(args.log_n), "--ncols", "751" if args.log_n == LOG_N else "64", "--steps", "2",
+                                                            "--check"], world, rank, local_rank, 29, args.backend)
             dist.barrier()
+        if gp_log_n:
+            sharded_gp = child_leg("zkevm_genproof_sharded.py", ["--log-n", str(gp_log_n), "--check-one-gpu"], world, rank, local_rank, 23, args.backend)
+            dist.barrier()
+    elif gp_log_n:
+        src = out = None
+        torch.cuda.empty_cache()
+        sharded_gp = child_leg("zkevm_genproof_sharded.py", ["--log-n", str(gp_log_n), "--collectives", "--check-one-gpu"], 1, 0, local_rank, 23, "nccl")
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         fe_per_step = n_ext * ncols * world

@@ -318,13 +318,16 @@ def main():
     ap.add_argument("--log-n", type=int, default=16)
     ap.add_argument("--queries", type=int, default=0)
     ap.add_argument("--collectives", action="store_true", help="take the exchange paths even in a world of one rank")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: the ranks share GPU 0, exchanges staged through the host (rehearsal)")
     ap.add_argument("--check-one-gpu", action="store_true", help="rank 0 then runs the one-GPU flow (tools/bench_zkevm_genproof.py, programs "
                     "interpreted as here) on the same synthetic witness: same roots / FRI layers expected, its wall reported beside the sharded one")
     a = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or a.collectives:
-        torch.cuda.set_device(local_rank)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if a.backend == "nccl" else 0
+    torch.cuda.set_device(local_rank)
+    if a.backend == "gloo":
+        dist.init_process_group("gloo")
+    elif world > 1 or a.collectives:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     capi.init(local_rank); capi.use_torch_stream()
     res, timers = None, {}
@@ -344,10 +347,10 @@ def main():
                 "wall_s_incl_setup": round(wall, 4), "sum_timed_s": round(sum(timers.values()), 4),
                 "timers_s": {k: round(v, 4) for k, v in timers.items()}, "roots": res["roots"], "fri_roots_and_head_of_final_pol": res["fri_roots_and_head_of_final_pol"]}
         st = shard.EXCHANGE_STATS
-        if st and st.get("all_to_all_s"):
-            line["exchange_rank0"] = {"all_to_all_calls": st["all_to_all_calls"], "all_to_all_s": round(st["all_to_all_s"], 4),
+        if st and st.get("exchange_s"):
+            line["exchange_rank0"] = {"exchange_calls": st["exchange_calls"], "exchange_s": round(st["exchange_s"], 4),
                                       "GB_sent_to_peers": round(st["bytes_sent_to_peers"] / 1e9, 3),
-                                      "GBs_sent_per_rank": round(st["bytes_sent_to_peers"] / 1e9 / st["all_to_all_s"], 1)}
+                                      "GBs_sent_per_rank": round(st["bytes_sent_to_peers"] / 1e9 / st["exchange_s"], 1)}
         if a.check_one_gpu:
             import argparse as _ap
             from tools import bench_zkevm_genproof as one
@@ -359,7 +362,9 @@ def main():
             line["one_gpu_same_programs"] = {"genproof_wall_s": o["genproof_wall_s"], "timers_s": o["timers_s"],
                                              "same_roots_and_fri_layers": (o["roots"], o["fri_roots_and_head_of_final_pol"]) == expect,
                                              "same_by_tree": [x == y for x, y in zip(o["roots"] + o["fri_roots_and_head_of_final_pol"], expect[0] + expect[1])]}
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
+    if dist.is_initialized():
+        dist.barrier()                                     # (the other ranks wait for rank 0's one-GPU re-run)
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -74,8 +74,8 @@ def _exchange(recv, send, max_words, group):
             _run_p2p(ops, group)
     if st is not None:
         torch.cuda.synchronize()
-        st["all_to_all_calls"] = st.get("all_to_all_calls", 0) + 1
-        st["all_to_all_s"] = st.get("all_to_all_s", 0.0) + time.perf_counter() - t0
+        st["exchange_calls"] = st.get("exchange_calls", 0) + 1
+        st["exchange_s"] = st.get("exchange_s", 0.0) + time.perf_counter() - t0
         st["bytes_sent_to_peers"] = st.get("bytes_sent_to_peers", 0) + sum(send[p].numel() for p in range(world) if p != rank) * send[rank].element_size()
 
 
