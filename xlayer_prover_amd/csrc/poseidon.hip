@@ -23,6 +23,7 @@ using gl::u64;
 __constant__ u64 POSEIDON_C[360] = {
 #include "poseidon_constants.inc"
 };
+#include "poseidon_fused.inc"
 
 __device__ __forceinline__ u64 pow7(u64 a)
 {
@@ -44,6 +45,24 @@ __device__ __forceinline__ MdsConsts mds_consts()
     return k;
 }
 
+// L + H * 2^32 (mod p) -> any, for L, H < 2^57 (the sums of the multiply-add chains below).
+// value = L + Hh * 2^64 + Hl * 2^32 = (L + Hh * EPS) + Hl * 2^32 (mod p), Hh < 2^25: one multiply-add (no overflow: < 2^58), one
+// 32-bit add into the high word, and + EPS if that carried (the wrapped value is < 2^58, so the correction cannot carry again).
+__device__ __forceinline__ u64 recombine(u64 L, u64 H)
+{
+    const u32 Hl = (u32)H, Hh = (u32)(H >> 32);
+    const u64 t = (u64)Hh * 0xFFFFFFFFu + L;
+    u32 c1, c2, c3;
+    u32 rhi = __builtin_addc((u32)(t >> 32), Hl, 0u, &c1);
+    u32 rlo = (u32)t;
+    gl::opaque(rhi);
+    const u32 fix = c1 ? 0xFFFFFFFFu : 0u;
+    rlo = __builtin_addc(rlo, fix, 0u, &c2);
+    rhi = __builtin_addc(rhi, 0u, c2, &c3);
+    gl::opaque(rlo); gl::opaque(rhi);
+    return gl::pack(rlo, rhi);
+}
+
 // st <- M * st + c, M[i][j] = MCIRC[(j-i) mod 12] (+8 on [0][0]); inputs "any", outputs "any".
 // `c` (12 canonical words, wave-uniform -> SGPRs) is the NEXT round's constant vector: it is the
 // initial value of the multiply-add chains, so the per-round constant addition costs no instruction.
@@ -60,40 +79,83 @@ __device__ __forceinline__ void mds(u64 (&st)[12], const u64* __restrict__ c, co
 #pragma unroll
         for (int j = 0; j < 12; j++) {
             const u32 m = (i == 0 && j == 0) ? k.mc[12] : k.mc[(j - i + 12) % 12];
-            L += (u64)lo[j] * m;   // < 2^32 * 49 * 12 + 2^32 < 2^43
+            L += (u64)lo[j] * m;   // < 2^32 * 264 + 2^32 < 2^41
             H += (u64)hi[j] * m;
         }
-        // value = L + H * 2^32 = L + Hh * 2^64 + Hl * 2^32 = (L + Hh * EPS) + Hl * 2^32 (mod p), Hh < 2^11:
-        // one multiply-add (no overflow: < 2^44), one 32-bit add into the high word, and + EPS if that carried
-        // (the wrapped value is < 2^44, so the correction cannot carry again).
-        const u32 Hl = (u32)H, Hh = (u32)(H >> 32);
-        const u64 t = (u64)Hh * 0xFFFFFFFFu + L;
-        u32 c1, c2, c3;
-        u32 rhi = __builtin_addc((u32)(t >> 32), Hl, 0u, &c1);
-        u32 rlo = (u32)t;
-        gl::opaque(rhi);
-        const u32 fix = c1 ? 0xFFFFFFFFu : 0u;
-        rlo = __builtin_addc(rlo, fix, 0u, &c2);
-        rhi = __builtin_addc(rhi, 0u, c2, &c3);
-        gl::opaque(rlo); gl::opaque(rhi);
-        st[i] = gl::pack(rlo, rhi);
+        st[i] = recombine(L, H);
     }
 }
 
-// Round r: state already holds + C[r] (added by the previous round's linear layer).
+// Three partial rounds as ONE linear layer (tools/gen_poseidon_fused.py has the algebra).  Only word 0 goes through the S-box, so
+// with Z = diag(0, 1, ..., 1) the state after three rounds is (M Z M Z M) u' + (M Z M e0) y2 + (M e0) y3 + K, where u' = u with
+// word 0 replaced by y1 = u[0]^7 and y2, y3 are the next two S-box outputs, themselves x^7 of one 12-term (13-, 14-term) dot
+// product with row 0 of M (of M Z M).  The integer matrices stay below 2^22, so every product against a 32-bit half of a word
+// still fits the 64-bit multiply-add chains: 14 x 12 x 2 + 54 multiply-adds and 14 recombinations for three rounds instead of
+// 3 x (288 + 12) and 36 -- 20 % fewer instructions per permutation, and the permutation IS the Merkle commit (integer-issue bound).
+// Field arithmetic is exact, so the result is the same element as round-by-round evaluation (every known answer still holds).
+__constant__ u32 POSEIDON_FU32[193] = XLP_POSEIDON_FUSED_U32;
+__constant__ u64 POSEIDON_FU64[98] = XLP_POSEIDON_FUSED_U64;
+
+__device__ __forceinline__ void partial3(u64 (&st)[12], const u64* __restrict__ kc)
+{
+    // The table pointer is laundered per call: as a loop invariant the compiler loads all 193 constants ahead of the loop over the
+    // groups, runs out of SGPRs and parks them in VGPR lanes (311 v_readlane per call, VALU slots); loaded where they are used they
+    // are scalar loads beside the VALU stream.
+    const u32* F = POSEIDON_FU32;
+    asm volatile("" : "+s"(F));
+    const u32* __restrict__ R1 = F;             // row 0 of M
+    const u32* __restrict__ R2 = F + 12;        // row 0 of M Z M
+    const u32 m00 = F[24];
+    const u32* __restrict__ B3 = F + 25;        // M Z M Z M, row-major
+    const u32* __restrict__ B2 = F + 25 + 144;  // M Z M e0
+    const u32* __restrict__ A1 = F + 25 + 156;  // M e0
+    st[0] = pow7(st[0]);
+    u32 lo[12], hi[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) { lo[j] = (u32)st[j]; hi[j] = (u32)(st[j] >> 32); }
+    u64 L = (u32)kc[0], H = kc[0] >> 32;
+#pragma unroll
+    for (int j = 0; j < 12; j++) { L += (u64)lo[j] * R1[j]; H += (u64)hi[j] * R1[j]; }
+    const u64 y2 = pow7(recombine(L, H));
+    const u32 y2l = (u32)y2, y2h = (u32)(y2 >> 32);
+    L = (u32)kc[1]; H = kc[1] >> 32;
+#pragma unroll
+    for (int j = 0; j < 12; j++) { L += (u64)lo[j] * R2[j]; H += (u64)hi[j] * R2[j]; }
+    L += (u64)y2l * m00; H += (u64)y2h * m00;
+    const u64 y3 = pow7(recombine(L, H));
+    const u32 y3l = (u32)y3, y3h = (u32)(y3 >> 32);
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        L = (u32)kc[2 + i]; H = kc[2 + i] >> 32;
+#pragma unroll
+        for (int j = 0; j < 12; j++) { L += (u64)lo[j] * B3[12 * i + j]; H += (u64)hi[j] * B3[12 * i + j]; }
+        L += (u64)y2l * B2[i]; H += (u64)y2h * B2[i];
+        L += (u64)y3l * A1[i]; H += (u64)y3h * A1[i];
+        st[i] = recombine(L, H);
+    }
+}
+
+// Round r: state already holds + C[r] (added by the previous round's linear layer).  Rounds 0-3 and 26-29 are full, 4-25 partial:
+// 4-24 run as seven fused triples, 25 as a plain partial round.
 __device__ __forceinline__ void permute(u64 (&st)[12])
 {
     const MdsConsts k = mds_consts();
 #pragma unroll
     for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], POSEIDON_C[i]);  // any + canon
 #pragma unroll 1
-    for (int r = 0; r < 29; r++) {
-        if (r < 4 || r >= 26) {
+    for (int r = 0; r < 4; r++) {
 #pragma unroll
-            for (int i = 0; i < 12; i++) st[i] = pow7(st[i]);
-        } else {
-            st[0] = pow7(st[0]);
-        }
+        for (int i = 0; i < 12; i++) st[i] = pow7(st[i]);
+        mds<true>(st, &POSEIDON_C[12 * (r + 1)], k);
+    }
+#pragma unroll 1
+    for (int g = 0; g < 7; g++) partial3(st, &POSEIDON_FU64[14 * g]);
+    st[0] = pow7(st[0]);
+    mds<true>(st, &POSEIDON_C[12 * 26], k);
+#pragma unroll 1
+    for (int r = 26; r < 29; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = pow7(st[i]);
         mds<true>(st, &POSEIDON_C[12 * (r + 1)], k);
     }
 #pragma unroll
