@@ -145,6 +145,13 @@ int xlp_dev_calculate_z(uint64_t* z, const uint64_t* num, const uint64_t* den, u
  * n elements of dimension dim (1 or 3) each, dense.  Fails ("number not included") if a value of f does not
  * occur in t (the reference calls exitProcess()). */
 int xlp_dev_calculate_h1h2(uint64_t* h1, uint64_t* h2, const uint64_t* f, const uint64_t* t, uint64_t n, uint32_t dim);
+/* The same two on the reference's Polinomial VIEWS (polinomial.hpp:24-40: Polinomial(address, degree, dim, offset), element i at
+ * address[i * offset]): every polynomial is a column group of a row-major section, addressed by its first word and the section width
+ * (stride >= dim, in words).  This is how Starks::genProof hands them over (starks.cpp:108-125, 150-167 through transposeH1H2Columns /
+ * transposeZColumns, starks.cpp:406-555): with strides the transposed copies around the calls disappear. */
+int xlp_dev_calculate_z_strided(uint64_t* z, uint64_t z_stride, const uint64_t* num, uint64_t num_stride, const uint64_t* den, uint64_t den_stride, uint64_t n);
+int xlp_dev_calculate_h1h2_strided(uint64_t* h1, uint64_t h1_stride, uint64_t* h2, uint64_t h2_stride, const uint64_t* f, uint64_t f_stride,
+                                   const uint64_t* t, uint64_t t_stride, uint64_t n, uint32_t dim);
 /* out[k] = first * ratio^k, k < n, elements of dimension dim (1 or 3; `first`, `ratio`: dim host words each).
  * Replaces the sequential table loops of Starks: x_n, x_2ns, x (starks.hpp:149-183: ratio = w(nBits) / w(nBitsExt),
  * first = 1 / shift) and LEv, LpEv before their INTT (starks.cpp:318-322: ratio = xi/shift, w*xi/shift). */

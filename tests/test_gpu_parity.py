@@ -449,6 +449,35 @@ def test_calculate_h1h2_vs_oracle(xlp, orc, n, dim, distinct):
     assert (xlp.to_np(h1) == exp1.reshape(-1)).all() and (xlp.to_np(h2) == exp2.reshape(-1)).all()
 
 
+@pytest.mark.parametrize("n", [1, 9, 2049, 1 << 16])
+def test_calculate_z_on_section_views_vs_oracle(xlp, orc, n):
+    """Polinomial views (polinomial.hpp:24-40): num, den and z are column groups of row-major sections of different widths; the
+    words around z must stay untouched"""
+    wn, wd, wz = 7, 12, 5
+    secn = orc.fill(n * wn, 0x5EED00A1).reshape(n, wn); secd = orc.fill(n * wd, 0x5EED00A2).reshape(n, wd)
+    secz = orc.fill(n * wz, 0x5EED00A3).reshape(n, wz)
+    tn, td, tz = xlp.from_np(secn.reshape(-1)), xlp.from_np(secd.reshape(-1)), xlp.from_np(secz.reshape(-1))
+    xlp.dev_calculate_z_strided(tz[2:], wz, tn[4:], wn, td[1:], wd, n); xlp.sync()
+    exp = secz.copy(); exp[:, 2:5] = orc.calculate_z(np.ascontiguousarray(secn[:, 4:7]), np.ascontiguousarray(secd[:, 1:4]))
+    assert (xlp.to_np(tz).reshape(n, wz) == exp).all()
+    with pytest.raises(xlp.XlpError, match="stride"):
+        xlp.dev_calculate_z_strided(tz, 2, tn, wn, td, wd, n)
+
+
+@pytest.mark.parametrize("n,dim,distinct", [(8, 1, 3), (4096, 3, 500), (1 << 16, 1, 1 << 12), (1 << 16, 3, 1 << 16)])
+def test_calculate_h1h2_on_section_views_vs_oracle(xlp, orc, n, dim, distinct):
+    f, t = _plookup_inputs(orc, n, dim, 0x5EED00B0 + n, distinct)
+    exp1, exp2 = orc.calculate_h1h2(f, t, dim)
+    wf, wt, wh = dim + 4, dim + 9, 2 * dim + 3
+    secf = orc.fill(n * wf, 0x5EED00B1).reshape(n, wf); secf[:, 2:2 + dim] = f.reshape(n, dim)
+    sect = orc.fill(n * wt, 0x5EED00B2).reshape(n, wt); sect[:, 9:9 + dim] = t.reshape(n, dim)
+    sech = orc.fill(n * wh, 0x5EED00B3).reshape(n, wh)
+    tf, tt, th = xlp.from_np(secf.reshape(-1)), xlp.from_np(sect.reshape(-1)), xlp.from_np(sech.reshape(-1))
+    xlp.dev_calculate_h1h2_strided(th[1:], wh, th[1 + dim:], wh, tf[2:], wf, tt[9:], wt, n, dim); xlp.sync()
+    exp = sech.copy(); exp[:, 1:1 + dim] = exp1.reshape(n, dim); exp[:, 1 + dim:1 + 2 * dim] = exp2.reshape(n, dim)
+    assert (xlp.to_np(th).reshape(n, wh) == exp).all()
+
+
 def test_calculate_h1h2_number_not_included(xlp, orc):
     t = np.arange(1, 65, dtype=np.uint64); f = t.copy(); f[10] = 1000
     h = xlp.from_np(np.zeros(64, np.uint64)); h2 = xlp.from_np(np.zeros(64, np.uint64))

@@ -44,6 +44,8 @@ SIGNATURES = {
     "xlp_field_op": [_pu, _pu, _pu, _u64, C.c_int],
     "xlp_dev_batch_inverse": [_pu, _pu, _u64, _u32],
     "xlp_dev_calculate_z": [_pu, _pu, _pu, _u64],
+    "xlp_dev_calculate_z_strided": [_pu, _u64, _pu, _u64, _pu, _u64, _u64],
+    "xlp_dev_calculate_h1h2_strided": [_pu, _u64, _pu, _u64, _pu, _u64, _pu, _u64, _u64, _u32],
     "xlp_dev_evmap": [_pu, _pu, _pu, _u64, _u32, _u32, _pu],
     "xlp_dev_geometric": [_pu, _u64, _u32, _pu, _pu],
     "xlp_dev_q_split": [_pu, _pu, _u64, _u64, _u32, _u32, _u64],
@@ -468,6 +470,15 @@ def dev_batch_inverse(res, src, n, dim=3):
 
 def dev_calculate_z(z, num, den, n):
     _ck(load().xlp_dev_calculate_z(_dp(z), _dp(num), _dp(den), n), "xlp_dev_calculate_z")
+
+
+def dev_calculate_z_strided(z, zs, num, ns, den, ds, n):
+    """z / num / den: device tensors whose element i sits at [i * stride, i * stride + 3) (views into row-major sections)"""
+    _ck(load().xlp_dev_calculate_z_strided(_dp(z), zs, _dp(num), ns, _dp(den), ds, n), "xlp_dev_calculate_z_strided")
+
+
+def dev_calculate_h1h2_strided(h1, h1s, h2, h2s, f, fs, t, ts, n, dim=1):
+    _ck(load().xlp_dev_calculate_h1h2_strided(_dp(h1), h1s, _dp(h2), h2s, _dp(f), fs, _dp(t), ts, n, dim), "xlp_dev_calculate_h1h2_strided")
 
 
 def dev_calculate_h1h2(h1, h2, f, t, n, dim=1):

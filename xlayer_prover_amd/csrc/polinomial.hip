@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void batch_inverse1_kernel(u64* res, const u64
 constexpr int SCAN_T = 256, SCAN_E = 8, SCAN_PER_BLOCK = SCAN_T * SCAN_E;
 
 // mode 0: v[i] = num[i] / den[i] ; mode 1: v[i] = num[i] (already ratios / block products)
-__global__ __launch_bounds__(SCAN_T) void scan3_block_kernel(u64* out_incl, u64* block_prod, const u64* num, const u64* den, u64 n, int mode)
+__global__ __launch_bounds__(SCAN_T) void scan3_block_kernel(u64* out_incl, u64* block_prod, const u64* num, u64 ns, const u64* den, u64 ds, u64 n, int mode)
 {
     __shared__ u64 sh[SCAN_T][3];
     const u64 base = (u64)blockIdx.x * SCAN_PER_BLOCK + (u64)threadIdx.x * SCAN_E;
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(SCAN_T) void scan3_block_kernel(u64* out_incl, u64*
         const u64 i = base + k;
         e3 x = one3();
         if (i < n) {
-            x = load3(num + 3 * i);
-            if (mode == 0) x = gl::mul3(x, inv3(load3(den + 3 * i)));
+            x = load3(num + ns * i);
+            if (mode == 0) x = gl::mul3(x, inv3(load3(den + ds * i)));
         }
         acc = gl::mul3(acc, x);
         v[k] = acc;                      // inclusive within the thread
@@ -151,40 +151,43 @@ __global__ __launch_bounds__(256) void scan3_apply_kernel(u64* incl, const u64* 
 }
 
 // z[0] = 1, z[i] = incl[i-1]
-__global__ __launch_bounds__(256) void scan3_shift_kernel(u64* z, const u64* incl, u64 n)
+__global__ __launch_bounds__(256) void scan3_shift_kernel(u64* z, u64 zs, const u64* incl, u64 n)
 {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (i == 0) { z[0] = 1; z[1] = 0; z[2] = 0; return; }
-    z[3 * i] = incl[3 * (i - 1)]; z[3 * i + 1] = incl[3 * (i - 1) + 1]; z[3 * i + 2] = incl[3 * (i - 1) + 2];
+    z[zs * i] = incl[3 * (i - 1)]; z[zs * i + 1] = incl[3 * (i - 1) + 1]; z[zs * i + 2] = incl[3 * (i - 1) + 2];
 }
 
-static int scan3_inclusive(Ctx* ctx, u64* incl, const u64* num, const u64* den, u64 n, int mode, u64* scratch, u64 scratch_elems)
+static int scan3_inclusive(Ctx* ctx, u64* incl, const u64* num, u64 ns, const u64* den, u64 ds, u64 n, int mode, u64* scratch, u64 scratch_elems)
 {
     const u64 nb = (n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;
     if (3 * nb > scratch_elems && nb > 1) return xlp_fail("scan: scratch too small");
     u64* bp = nb > 1 ? scratch : nullptr;
-    hipLaunchKernelGGL(scan3_block_kernel, dim3((unsigned)nb), dim3(SCAN_T), 0, ctx->stream, incl, bp, num, den, n, mode);
+    hipLaunchKernelGGL(scan3_block_kernel, dim3((unsigned)nb), dim3(SCAN_T), 0, ctx->stream, incl, bp, num, ns, den, ds, n, mode);
     XLP_HIP(hipGetLastError());
     if (nb > 1) {
         u64* bincl = scratch + 3 * nb;
         if (6 * nb > scratch_elems) return xlp_fail("scan: scratch too small");
-        if (scan3_inclusive(ctx, bincl, bp, nullptr, nb, 1, scratch + 6 * nb, scratch_elems - 6 * nb)) return -1;
+        if (scan3_inclusive(ctx, bincl, bp, 3, nullptr, 3, nb, 1, scratch + 6 * nb, scratch_elems - 6 * nb)) return -1;
         hipLaunchKernelGGL(scan3_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, incl, bincl, n);
         XLP_HIP(hipGetLastError());
     }
     return 0;
 }
 
-int dev_calculate_z(Ctx* ctx, u64* z, const u64* num, const u64* den, u64 n)
+// z, num, den: element i at p[i * stride .. + 3) -- the reference's Polinomial(address, degree, dim, offset) views of a row-major
+// section (polinomial.hpp:24-40), so that a column of a section needs no transposed copy around the call (starks.cpp:406-555).
+int dev_calculate_z(Ctx* ctx, u64* z, u64 zs, const u64* num, u64 ns, const u64* den, u64 ds, u64 n)
 {
     if (!n) return 0;
+    if (zs < 3 || ns < 3 || ds < 3) return xlp_fail("calculateZ: stride below the dimension");
     u64* tmp = nullptr;
     const u64 nb = (n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;
     const u64 aux = 8 * (nb + 64) * 3;
     if (ctx_scratch(ctx, (3 * n + aux) * sizeof(u64), 2, &tmp)) return -1;
-    if (scan3_inclusive(ctx, tmp, num, den, n, 0, tmp + 3 * n, aux)) return -1;
-    hipLaunchKernelGGL(scan3_shift_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, z, tmp, n);
+    if (scan3_inclusive(ctx, tmp, num, ns, den, ds, n, 0, tmp + 3 * n, aux)) return -1;
+    hipLaunchKernelGGL(scan3_shift_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, z, zs, tmp, n);
     XLP_HIP(hipGetLastError());
     return 0;
 }
@@ -627,11 +630,11 @@ int dev_dot_columns(Ctx* ctx, u64* out, const xlp_dot_entry* entries, u64 nentri
 constexpr u32 H_EMPTY = 0xFFFFFFFFu;
 
 template <int DIM>
-__device__ __forceinline__ void load_key(u64 (&k)[3], const u64* p, u64 i)
+__device__ __forceinline__ void load_key(u64 (&k)[3], const u64* p, u64 stride, u64 i)
 {
-    k[0] = gl::canon(p[i * DIM]);
-    k[1] = DIM == 3 ? gl::canon(p[i * DIM + 1]) : 0;
-    k[2] = DIM == 3 ? gl::canon(p[i * DIM + 2]) : 0;
+    k[0] = gl::canon(p[i * stride]);
+    k[1] = DIM == 3 ? gl::canon(p[i * stride + 1]) : 0;
+    k[2] = DIM == 3 ? gl::canon(p[i * stride + 2]) : 0;
 }
 __device__ __forceinline__ u32 hash_key(const u64 (&k)[3], u32 mask)
 {
@@ -641,34 +644,34 @@ __device__ __forceinline__ u32 hash_key(const u64 (&k)[3], u32 mask)
 }
 
 template <int DIM>
-__global__ void h1h2_insert_kernel(u32* owner, u32* last, const u64* t, u64 n, u32 mask)
+__global__ void h1h2_insert_kernel(u32* owner, u32* last, const u64* t, u64 ts, u64 n, u32 mask)
 {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u64 k[3], o[3];
-    load_key<DIM>(k, t, i);
+    load_key<DIM>(k, t, ts, i);
     u32 slot = hash_key(k, mask);
     for (;;) {
         u32 cur = atomicCAS(&owner[slot], H_EMPTY, (u32)i);
         if (cur == H_EMPTY) cur = (u32)i;
-        load_key<DIM>(o, t, cur);
+        load_key<DIM>(o, t, ts, cur);
         if (o[0] == k[0] && o[1] == k[1] && o[2] == k[2]) { atomicMax(&last[slot], (u32)i); return; }
         slot = (slot + 1) & mask;
     }
 }
 
 template <int DIM>
-__global__ void h1h2_count_kernel(u32* count, u32* err, const u32* owner, const u32* last, const u64* f, const u64* t, u64 n, u32 mask)
+__global__ void h1h2_count_kernel(u32* count, u32* err, const u32* owner, const u32* last, const u64* f, u64 fs, const u64* t, u64 ts, u64 n, u32 mask)
 {
     const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     u64 k[3], o[3];
-    load_key<DIM>(k, f, j);
+    load_key<DIM>(k, f, fs, j);
     u32 slot = hash_key(k, mask);
     for (;;) {
         const u32 cur = owner[slot];
         if (cur == H_EMPTY) { atomicExch(err, 1u); return; }     // number not included (reference: exitProcess)
-        load_key<DIM>(o, t, cur);
+        load_key<DIM>(o, t, ts, cur);
         if (o[0] == k[0] && o[1] == k[1] && o[2] == k[2]) { atomicAdd(&count[last[slot]], 1u); return; }
         slot = (slot + 1) & mask;
     }
@@ -721,20 +724,20 @@ static int uscan_exclusive(Ctx* ctx, u32* out, const u32* in, u64 n, u32* scratc
 }
 
 template <int DIM>
-__global__ void h1h2_expand_kernel(u64* h1, u64* h2, const u64* t, const u32* offs, u64 n)
+__global__ void h1h2_expand_kernel(u64* h1, u64 h1s, u64* h2, u64 h2s, const u64* t, u64 ts, const u32* offs, u64 n)
 {
     const u64 pos = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= 2 * n) return;
     // largest i with offs[i] <= pos   (offs ascending, offs[0] = 0, every count >= 1)
     u64 lo = 0, hi = n;
     while (hi - lo > 1) { const u64 m = (lo + hi) >> 1; if (offs[m] <= pos) lo = m; else hi = m; }
-    u64* dst = (pos & 1) ? h2 : h1;
+    u64* dst = (pos & 1) ? h2 + (pos >> 1) * h2s : h1 + (pos >> 1) * h1s;
 #pragma unroll
-    for (int d = 0; d < DIM; d++) dst[(pos >> 1) * DIM + d] = gl::canon(t[lo * DIM + d]);
+    for (int d = 0; d < DIM; d++) dst[d] = gl::canon(t[lo * ts + d]);
 }
 
 template <int DIM>
-static int h1h2_impl(Ctx* ctx, u64* h1, u64* h2, const u64* f, const u64* t, u64 n)
+static int h1h2_impl(Ctx* ctx, u64* h1, u64 h1s, u64* h2, u64 h2s, const u64* f, u64 fs, const u64* t, u64 ts_, u64 n)
 {
     u32 ts = 1;
     while (ts < 2 * n) ts <<= 1;
@@ -750,25 +753,27 @@ static int h1h2_impl(Ctx* ctx, u64* h1, u64* h2, const u64* f, const u64* t, u64
     XLP_HIP(hipMemsetAsync(err, 0, 4, ctx->stream));
     const unsigned g = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(fill_u32_kernel, dim3(g), dim3(256), 0, ctx->stream, count, n, 1u);
-    hipLaunchKernelGGL(h1h2_insert_kernel<DIM>, dim3(g), dim3(256), 0, ctx->stream, owner, last, t, n, mask);
-    hipLaunchKernelGGL(h1h2_count_kernel<DIM>, dim3(g), dim3(256), 0, ctx->stream, count, err, owner, last, f, t, n, mask);
+    hipLaunchKernelGGL(h1h2_insert_kernel<DIM>, dim3(g), dim3(256), 0, ctx->stream, owner, last, t, ts_, n, mask);
+    hipLaunchKernelGGL(h1h2_count_kernel<DIM>, dim3(g), dim3(256), 0, ctx->stream, count, err, owner, last, f, fs, t, ts_, n, mask);
     XLP_HIP(hipGetLastError());
     u32 herr = 0;
     XLP_HIP(hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, ctx->stream));
     XLP_HIP(hipStreamSynchronize(ctx->stream));
     if (herr) return xlp_fail("calculateH1H2: number not included");
     if (uscan_exclusive(ctx, offs, count, n, scan)) return -1;
-    hipLaunchKernelGGL(h1h2_expand_kernel<DIM>, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, ctx->stream, h1, h2, t, offs, n);
+    hipLaunchKernelGGL(h1h2_expand_kernel<DIM>, dim3((unsigned)((2 * n + 255) / 256)), dim3(256), 0, ctx->stream, h1, h1s, h2, h2s, t, ts_, offs, n);
     XLP_HIP(hipGetLastError());
     return 0;
 }
 
-int dev_calculate_h1h2(Ctx* ctx, u64* h1, u64* h2, const u64* f, const u64* t, u64 n, u32 dim)
+// element i of a polynomial at p[i * stride .. + dim): Polinomial views of row-major sections, as for dev_calculate_z
+int dev_calculate_h1h2(Ctx* ctx, u64* h1, u64 h1s, u64* h2, u64 h2s, const u64* f, u64 fs, const u64* t, u64 ts, u64 n, u32 dim)
 {
     if (!n) return 0;
     if (n > (1ull << 30)) return xlp_fail("calculateH1H2: too many rows");
-    if (dim == 1) return h1h2_impl<1>(ctx, h1, h2, f, t, n);
-    if (dim == 3) return h1h2_impl<3>(ctx, h1, h2, f, t, n);
+    if (h1s < dim || h2s < dim || fs < dim || ts < dim) return xlp_fail("calculateH1H2: stride below the dimension");
+    if (dim == 1) return h1h2_impl<1>(ctx, h1, h1s, h2, h2s, f, fs, t, ts, n);
+    if (dim == 3) return h1h2_impl<3>(ctx, h1, h1s, h2, h2s, f, fs, t, ts, n);
     return xlp_fail("calculateH1H2: dim must be 1 or 3");
 }
 

@@ -256,12 +256,23 @@ int xlp_dev_batch_inverse(uint64_t* res, const uint64_t* src, uint64_t n, uint32
 int xlp_dev_calculate_z(uint64_t* z, const uint64_t* num, const uint64_t* den, uint64_t n)
 {
     if (ensure_init()) return -1;
-    return dev_calculate_z(&g_ctx, z, num, den, n);
+    return dev_calculate_z(&g_ctx, z, 3, num, 3, den, 3, n);
+}
+int xlp_dev_calculate_z_strided(uint64_t* z, uint64_t z_stride, const uint64_t* num, uint64_t num_stride, const uint64_t* den, uint64_t den_stride, uint64_t n)
+{
+    if (ensure_init()) return -1;
+    return dev_calculate_z(&g_ctx, z, z_stride, num, num_stride, den, den_stride, n);
 }
 int xlp_dev_calculate_h1h2(uint64_t* h1, uint64_t* h2, const uint64_t* f, const uint64_t* t, uint64_t n, uint32_t dim)
 {
     if (ensure_init()) return -1;
-    return dev_calculate_h1h2(&g_ctx, h1, h2, f, t, n, dim);
+    return dev_calculate_h1h2(&g_ctx, h1, dim, h2, dim, f, dim, t, dim, n, dim);
+}
+int xlp_dev_calculate_h1h2_strided(uint64_t* h1, uint64_t h1_stride, uint64_t* h2, uint64_t h2_stride, const uint64_t* f, uint64_t f_stride,
+                                   const uint64_t* t, uint64_t t_stride, uint64_t n, uint32_t dim)
+{
+    if (ensure_init()) return -1;
+    return dev_calculate_h1h2(&g_ctx, h1, h1_stride, h2, h2_stride, f, f_stride, t, t_stride, n, dim);
 }
 int xlp_expr_create(xlp_expr_program** out, const uint64_t* code, uint64_t ncode, uint64_t ntmp1, uint64_t ntmp3)
 {
@@ -846,7 +857,7 @@ int xlp_calculate_z(uint64_t* z, const uint64_t* num, const uint64_t* den, uint6
     if (a.alloc(bytes) || b.alloc(bytes) || c.alloc(bytes)) return -1;
     H2D(a, num, bytes);
     H2D(b, den, bytes);
-    if (dev_calculate_z(&g_ctx, c.u(), a.u(), b.u(), n)) return -1;
+    if (dev_calculate_z(&g_ctx, c.u(), 3, a.u(), 3, b.u(), 3, n)) return -1;
     D2H(z, c, bytes);
     return 0;
 }
@@ -861,7 +872,7 @@ int xlp_calculate_h1h2(uint64_t* h1, uint64_t* h2, const uint64_t* f, const uint
     if (a.alloc(bytes) || b.alloc(bytes) || c.alloc(bytes) || d.alloc(bytes)) return -1;
     H2D(a, f, bytes);
     H2D(b, t, bytes);
-    if (dev_calculate_h1h2(&g_ctx, c.u(), d.u(), a.u(), b.u(), n, dim)) return -1;
+    if (dev_calculate_h1h2(&g_ctx, c.u(), dim, d.u(), dim, a.u(), dim, b.u(), dim, n, dim)) return -1;
     XLP_HIP(hipStreamSynchronize(g_ctx.stream));
     D2H(h1, c, bytes);
     D2H(h2, d, bytes);

@@ -91,8 +91,8 @@ int dev_field_op(Ctx* ctx, u64* out, const u64* a, const u64* b, u64 n, int op);
 
 // polinomial.hip
 int dev_batch_inverse(Ctx* ctx, u64* res, const u64* src, u64 n, u32 dim);
-int dev_calculate_z(Ctx* ctx, u64* z, const u64* num, const u64* den, u64 n);
-int dev_calculate_h1h2(Ctx* ctx, u64* h1, u64* h2, const u64* f, const u64* t, u64 n, u32 dim);
+int dev_calculate_z(Ctx* ctx, u64* z, u64 zs, const u64* num, u64 ns, const u64* den, u64 ds, u64 n);
+int dev_calculate_h1h2(Ctx* ctx, u64* h1, u64 h1s, u64* h2, u64 h2s, const u64* f, u64 fs, const u64* t, u64 ts, u64 n, u32 dim);
 int dev_copy_cols(Ctx* ctx, u64* dst, u64 dst_stride, const u64* src, u64 src_stride, u64 n, u32 dim);
 int dev_q_split(Ctx* ctx, u64* qq2, const u64* qq1, u64 n, u64 n_ext, u32 qdeg, u32 qdim, u64 shift_in);
 int dev_geometric(Ctx* ctx, u64* out, u64 n, u32 dim, const u64* first, const u64* ratio);

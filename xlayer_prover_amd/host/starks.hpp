@@ -7,8 +7,8 @@
 //    slab shared by all Starks of the process, as the reference shares pAddress (prover.cpp:123-127).  Step 1 uploads the witness
 //    in column bands on a second stream while the previous band is extended and absorbed into the leaf hashes
 //    (xlp_dev_commit_from_host); pin pAddress (xlp_host_alloc / xlp_host_register) for the full PCIe rate.
-//  * transposeH1H2Columns / transposeZColumns / ...Rows (starks.cpp:406-555) are strided device copies (xlp_dev_copy_cols)
-//    around xlp_dev_calculate_h1h2 / xlp_dev_calculate_z.
+//  * transposeH1H2Columns / transposeZColumns / ...Rows (starks.cpp:406-555) are address arithmetic: xlp_dev_calculate_h1h2_strided /
+//    xlp_dev_calculate_z_strided take the polynomials as (first word, section width) views.
 //  * The constant tree comes from starkFiles.zkevmConstantsTree when that file exists (the bctree layout the reference maps,
 //    starks.hpp:117-136) and is computed from the constant polynomials otherwise.  "synthetic:<seed>" as zkevmConstPols fills the
 //    constants on the device (benchmarks at sizes whose 15 GB .const file does not exist on the box).
@@ -313,13 +313,15 @@ public:
                 const PolRef f = pol(exp2pol(starkInfo.puCtx[i].fExpId)), tt = pol(exp2pol(starkInfo.puCtx[i].tExpId));
                 const PolRef h1 = pol(starkInfo.cm_n[numCommited + i * 2]), h2 = pol(starkInfo.cm_n[numCommited + i * 2 + 1]);
                 if (f.dim != tt.dim || h1.dim != f.dim || h2.dim != f.dim) xlp_exit_process("Starks: plookup polynomials of different dimensions");
-                uint64_t *df = d_work, *dt = d_work + N * 3, *dh1 = d_work + 2 * N * 3, *dh2 = d_work + 3 * N * 3;
-                XLP_CHECK(xlp_dev_copy_cols(dt, f.dim, tt.p, tt.stride, N, (uint32_t)f.dim));          // transposeH1H2Columns
-                if (config.xlpSyntheticLookups) XLP_CHECK(xlp_dev_gather_rows(df, dt, f.dim, N, (uint32_t)f.dim, 0x5EED0500ULL + i));
-                else XLP_CHECK(xlp_dev_copy_cols(df, f.dim, f.p, f.stride, N, (uint32_t)f.dim));
-                XLP_CHECK(xlp_dev_calculate_h1h2(dh1, dh2, df, dt, N, (uint32_t)f.dim));
-                XLP_CHECK(xlp_dev_copy_cols(h1.p, h1.stride, dh1, f.dim, N, (uint32_t)f.dim));       // transposeH1H2Rows
-                XLP_CHECK(xlp_dev_copy_cols(h2.p, h2.stride, dh2, f.dim, N, (uint32_t)f.dim));
+                // Polinomial views straight into the sections (transposeH1H2Columns / ...Rows of the reference are address arithmetic here)
+                if (config.xlpSyntheticLookups) {
+                    uint64_t *df = d_work, *dt = d_work + N * 3;
+                    XLP_CHECK(xlp_dev_copy_cols(dt, f.dim, tt.p, tt.stride, N, (uint32_t)f.dim));
+                    XLP_CHECK(xlp_dev_gather_rows(df, dt, f.dim, N, (uint32_t)f.dim, 0x5EED0500ULL + i));
+                    XLP_CHECK(xlp_dev_calculate_h1h2_strided(h1.p, h1.stride, h2.p, h2.stride, df, f.dim, dt, f.dim, N, (uint32_t)f.dim));
+                } else {
+                    XLP_CHECK(xlp_dev_calculate_h1h2_strided(h1.p, h1.stride, h2.p, h2.stride, f.p, f.stride, tt.p, tt.stride, N, (uint32_t)f.dim));
+                }
             }
             numCommited += starkInfo.puCtx.size() * 2;
         }
@@ -345,11 +347,7 @@ public:
             for (uint64_t i = 0; i < nd.size(); i++) {
                 const PolRef num = pol(exp2pol(nd[i].first)), den = pol(exp2pol(nd[i].second)), z = pol(starkInfo.cm_n[numCommited + i]);
                 if (num.dim != 3 || den.dim != 3 || z.dim != 3) xlp_exit_process("Starks: Z polynomials must be ext-3");
-                uint64_t *dn = d_work, *dd = d_work + N * 3, *dz = d_work + 2 * N * 3;
-                XLP_CHECK(xlp_dev_copy_cols(dn, 3, num.p, num.stride, N, 3));
-                XLP_CHECK(xlp_dev_copy_cols(dd, 3, den.p, den.stride, N, 3));
-                XLP_CHECK(xlp_dev_calculate_z(dz, dn, dd, N));
-                XLP_CHECK(xlp_dev_copy_cols(z.p, z.stride, dz, 3, N, 3));
+                XLP_CHECK(xlp_dev_calculate_z_strided(z.p, z.stride, num.p, num.stride, den.p, den.stride, N));   // views, no transposeZColumns copies
             }
         }
         {
