@@ -45,6 +45,7 @@ struct xlp_expr_program {
     std::vector<xlp_expr_column> cols;
     std::vector<uint32_t> wcols;  // indices of the written columns
     uint64_t halo = 0, modulus = 0;
+    bool serial_slabs = false;    // some row-major operand is addressed directly (not staged): slabs must run one after the other
     void* jit_handle = nullptr;   // dlopen'ed plugin (xlp_expr_attach)
     void* jit_launch = nullptr;
 };
@@ -319,6 +320,25 @@ static void compile(xlp_expr_program* P)
         P->cols.push_back({kv.first.buf, kv.first.off, kv.first.stride, kv.second.first, kv.second.second});
     }
     P->halo = halo; P->modulus = modulus;
+    // Direct (unstaged) columns are touched by the program's kernels themselves.  Slabs may run side by side as long as no direct
+    // column is both written and read: a row then writes its own cell (or its neighbour's, for a next-row store) exactly once and
+    // nobody looks at it before the program ends.
+    {
+        std::set<ColKey> dwr, drd;
+        for (u64 pc = 0; pc < ncode;) {
+            Instr in; const u64 nx = decode(code, ncode, pc, in, msg);
+            const Operand* ops[3] = {&in.d, &in.a, &in.b};
+            for (int s = 0; s < 3; s++) {
+                ColKey k; u64 next, mod;
+                if (!rowmajor(*ops[s], k, next, mod)) continue;
+                for (u32 c = 0; c < ops[s]->dim; c++)
+                    if (blocked.count({k.buf, k.stride, k.off + c})) (s == 0 ? dwr : drd).insert({k.buf, k.stride, k.off + c});
+            }
+            pc = nx;
+        }
+        P->serial_slabs = false;
+        for (const ColKey& k : dwr) if (drd.count(k)) P->serial_slabs = true;
+    }
 
     // ---- device program
     for (u64 pc = 0; pc < ncode;) {
@@ -888,7 +908,18 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
     int R = env_int("XLP_EXPR_ROWS", 2);
     if (R != 1 && R != 2 && R != 4) R = 2;
     if (jit) R = 1;
-    const u64 chunk_max = (u64)ctx->ncu * (u64)(env_int("XLP_EXPR_SLAB_WGS", 8) > 0 ? env_int("XLP_EXPR_SLAB_WGS", 8) : 8) * 256;   // rows per slab: workgroups per CU x 256 (experiment knob)
+    // Slabs.  A slab = gather (pure HBM, 4.6 TB/s) -> the program's kernels (integer issue + latency: 56 % of VALU issue, 3.0 TB/s) ->
+    // scatter.  Consecutive slabs are independent except through the halo, so every other slab runs on a second stream with its own
+    // scratch: one slab's gather and kernel tails fill the other's stalls.  The scratch budget stays the same (half-size slabs).
+    // A program whose kernels write a direct column that they also read (a next-row store picked up by the next row: zkEVM step3prev,
+    // step3) keeps one stream: running only its gathers / scatters ahead on the second one measured no gain (0.177 vs 0.179 s).
+    int S = env_int("XLP_EXPR_STREAMS", 2);
+    if (S < 1 || S > 4 || prog->serial_slabs) S = 1;
+    const bool chain = false;
+    const u64 wgs = (u64)(env_int("XLP_EXPR_SLAB_WGS", 8) > 0 ? env_int("XLP_EXPR_SLAB_WGS", 8) : 8);   // workgroups per CU and slab, all streams together
+    u64 chunk_max = (u64)ctx->ncu * wgs * 256;
+    while (S > 1 && (nrows <= chunk_max / S * (S - 1) || wgs < (u64)S)) S--;           // every stream gets a slab
+    chunk_max = chunk_max / S / 256 * 256;
     const u64 chunk = nrows < chunk_max ? nrows : chunk_max;
     const u64 threads_max = ((chunk + R - 1) / R + 255) / 256 * 256;     // lanes of the largest launch
     const u32 ncols = (u32)prog->cols.size(), nw = (u32)prog->wcols.size();
@@ -897,10 +928,11 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
     A.code = prog->d_dcode; A.ncode = prog->dcode.size();
     A.hot_words = prog->hot_words; A.tstride = (u64)R * threads_max; A.tmp = nullptr; A.cols = nullptr; A.cap = cap; A.P = P;
     const u64 spill = jit ? prog->tmp_words : prog->tmp_words - prog->hot_words;
-    if (spill && ctx_scratch(ctx, spill * A.tstride * sizeof(u64), 2, &A.tmp)) return -1;
-    u64* cols = nullptr; ColDesc* d_tab = nullptr; u32* d_wl = nullptr;
+    u64* tmp_all = nullptr;
+    if (spill && ctx_scratch(ctx, (size_t)S * spill * A.tstride * sizeof(u64), 2, &tmp_all)) return -1;
+    u64* cols_all = nullptr; ColDesc* d_tab = nullptr; u32* d_wl = nullptr;
     if (ncols) {
-        if (ctx_scratch(ctx, (size_t)ncols * cap * sizeof(u64), 4, &cols)) return -1;
+        if (ctx_scratch(ctx, (size_t)S * ncols * cap * sizeof(u64), 4, &cols_all)) return -1;
         u64* raw = nullptr;
         if (ctx_scratch(ctx, ncols * sizeof(ColDesc) + (nw ? nw : 1) * sizeof(u32), 5, &raw)) return -1;
         d_tab = (ColDesc*)raw; d_wl = (u32*)(d_tab + ncols);
@@ -914,31 +946,75 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
         XLP_HIP(hipMemcpyAsync(d_tab, tab.data(), ncols * sizeof(ColDesc), hipMemcpyHostToDevice, ctx->stream));
         if (nw) XLP_HIP(hipMemcpyAsync(d_wl, prog->wcols.data(), nw * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
         XLP_HIP(hipStreamSynchronize(ctx->stream));       // `tab` is a stack object
-        A.cols = cols;
+    }
+    hipStream_t streams[4] = {ctx->stream, ctx->stream, ctx->stream, ctx->stream};
+    const u64 nslabs = (nrows + chunk - 1) / chunk;
+    hipEvent_t computed = nullptr;                        // chain: the previous slab's kernels are done
+    std::vector<hipEvent_t> gathered;                     // gathered[i]: slab i's inputs (its rows + halo) have been staged
+    hipEvent_t first_written = nullptr;                   // slab 0's destination columns are back in the sections
+    if (S > 1) {
+        hipEvent_t start;
+        XLP_HIP(hipEventCreateWithFlags(&start, hipEventDisableTiming));
+        XLP_HIP(hipEventRecord(start, ctx->stream));
+        for (int a = 1; a < S; a++) {
+            if (!ctx->aux_stream[a - 1]) XLP_HIP(hipStreamCreateWithFlags(&ctx->aux_stream[a - 1], hipStreamNonBlocking));
+            streams[a] = ctx->aux_stream[a - 1];
+            XLP_HIP(hipStreamWaitEvent(streams[a], start, 0));
+        }
+        XLP_HIP(hipEventDestroy(start));
+        gathered.resize(nslabs, nullptr);
     }
     const size_t lds = (size_t)prog->hot_words * R * 256 * sizeof(u64);
-    for (u64 r0 = 0; r0 < nrows; r0 += chunk) {
+    int rc = 0;
+    for (u64 r0 = 0, i = 0; r0 < nrows && !rc; r0 += chunk, i++) {
         const u64 rows = nrows - r0 < chunk ? nrows - r0 : chunk;
+        const int s = (int)(i % (u64)S);
+        hipStream_t st = streams[s];
+        u64* cols = cols_all ? cols_all + (size_t)s * ncols * cap : nullptr;
+        A.tmp = tmp_all ? tmp_all + (size_t)s * spill * A.tstride : nullptr;
+        A.cols = cols;
+        if (S > 1 && i == nslabs - 1 && i > 0 && first_written) (void)hipStreamWaitEvent(st, first_written, 0);   // its halo wraps to slab 0's rows: the values written there
         if (ncols) {
             const dim3 grid((ncols + 63) / 64, (unsigned)((rows + prog->halo + 63) / 64));
-            hipLaunchKernelGGL(expr_gather_kernel, grid, dim3(256), 0, ctx->stream, cols, d_tab, ncols, cap, row0 + r0, rows, prog->halo, prog->modulus);
+            hipLaunchKernelGGL(expr_gather_kernel, grid, dim3(256), 0, st, cols, d_tab, ncols, cap, row0 + r0, rows, prog->halo, prog->modulus);
+        }
+        if (S > 1) {
+            (void)hipEventCreateWithFlags(&gathered[i], hipEventDisableTiming);
+            (void)hipEventRecord(gathered[i], st);
         }
         A.row0 = row0 + r0; A.nrows = rows;
+        if (S > 1 && chain && computed) { (void)hipStreamWaitEvent(st, computed, 0); (void)hipEventDestroy(computed); computed = nullptr; }
         if (jit) {
             XlpJitArgs J;
             J.cols = cols; J.cap = cap; J.tmp = A.tmp; J.tstride = A.tstride; J.row0 = row0 + r0; J.nrows = rows; J.P = P;
-            if (((xlpjit_launch_fn)prog->jit_launch)(&J, (void*)ctx->stream)) return xlp_fail("expr run: the compiled plugin failed to launch");
+            if (((xlpjit_launch_fn)prog->jit_launch)(&J, (void*)st)) rc = xlp_fail("expr run: the compiled plugin failed to launch");
         } else {
             const dim3 vgrid((unsigned)((((rows + R - 1) / R) + 255) / 256));
-            if (R == 1) hipLaunchKernelGGL(expr_kernel<1>, vgrid, dim3(256), lds, ctx->stream, A);
-            else if (R == 2) hipLaunchKernelGGL(expr_kernel<2>, vgrid, dim3(256), lds, ctx->stream, A);
-            else hipLaunchKernelGGL(expr_kernel<4>, vgrid, dim3(256), lds, ctx->stream, A);
+            if (R == 1) hipLaunchKernelGGL(expr_kernel<1>, vgrid, dim3(256), lds, st, A);
+            else if (R == 2) hipLaunchKernelGGL(expr_kernel<2>, vgrid, dim3(256), lds, st, A);
+            else hipLaunchKernelGGL(expr_kernel<4>, vgrid, dim3(256), lds, st, A);
         }
-        if (nw) {
+        if (S > 1 && chain) { (void)hipEventCreateWithFlags(&computed, hipEventDisableTiming); (void)hipEventRecord(computed, st); }
+        if (nw && !rc) {
+            if (S > 1 && i > 0) (void)hipStreamWaitEvent(st, gathered[i - 1], 0);    // slab i-1 staged its halo (= my first rows) before I overwrite them
             const dim3 grid((nw + 63) / 64, (unsigned)((rows + 63) / 64));
-            hipLaunchKernelGGL(expr_scatter_kernel, grid, dim3(256), 0, ctx->stream, cols, d_tab, d_wl, nw, cap, row0 + r0, rows);
+            hipLaunchKernelGGL(expr_scatter_kernel, grid, dim3(256), 0, st, cols, d_tab, d_wl, nw, cap, row0 + r0, rows);
+            if (S > 1 && i == 0) { (void)hipEventCreateWithFlags(&first_written, hipEventDisableTiming); (void)hipEventRecord(first_written, st); }
         }
     }
+    if (S > 1) {                                          // later work on the library's stream sees every slab
+        for (int a = 1; a < S; a++) {
+            hipEvent_t done;
+            (void)hipEventCreateWithFlags(&done, hipEventDisableTiming);
+            (void)hipEventRecord(done, streams[a]);
+            (void)hipStreamWaitEvent(ctx->stream, done, 0);
+            (void)hipEventDestroy(done);
+        }
+        for (hipEvent_t e : gathered) if (e) (void)hipEventDestroy(e);
+        if (first_written) (void)hipEventDestroy(first_written);
+        if (computed) (void)hipEventDestroy(computed);
+    }
+    if (rc) return rc;
     XLP_HIP(hipGetLastError());
     return 0;
 }

@@ -198,6 +198,7 @@ void xlp_shutdown(void)
     }
     if (g_ctx.own_stream) (void)hipStreamDestroy(g_ctx.stream);
     if (g_ctx.copy_stream) { (void)hipStreamSynchronize(g_ctx.copy_stream); (void)hipStreamDestroy(g_ctx.copy_stream); g_ctx.copy_stream = nullptr; }
+    for (hipStream_t& a : g_ctx.aux_stream) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); a = nullptr; }
     if (g_ctx.down_stream) { (void)hipStreamSynchronize(g_ctx.down_stream); (void)hipStreamDestroy(g_ctx.down_stream); g_ctx.down_stream = nullptr; }
     while (!g_cache.empty()) cache_drop(0);
     g_cache_cap = 0;

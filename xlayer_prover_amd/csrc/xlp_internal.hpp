@@ -43,6 +43,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t down_stream = nullptr;      // device -> host results of the pipelined host-pointer entry points
+    hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};   // more compute streams: the slabs of a step program go round them (dev_expr_run)
     hipStream_t copy_stream = nullptr;      // host <-> device transfers that overlap kernels on `stream` (xlp_dev_commit_from_host)
     std::map<std::tuple<u32, u64, u64>, u64*> tables;  // (L, root, mult) -> device power tables
     void* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
