@@ -914,7 +914,7 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
     // A program whose kernels write a direct column that they also read (a next-row store picked up by the next row: zkEVM step3prev,
     // step3) keeps one stream: running only its gathers / scatters ahead on the second one measured no gain (0.177 vs 0.179 s).
     int S = env_int("XLP_EXPR_STREAMS", 2);
-    if (S < 1 || S > 4 || prog->serial_slabs) S = 1;
+    if (S < 1 || S > 4 || prog->serial_slabs || !jit) S = 1;    // (the interpreter is slower with two half-slabs: zkEVM step42ns at 2^21 rows 0.21 -> 0.30 s)
     const bool chain = false;
     const u64 wgs = (u64)(env_int("XLP_EXPR_SLAB_WGS", 8) > 0 ? env_int("XLP_EXPR_SLAB_WGS", 8) : 8);   // workgroups per CU and slab, all streams together
     u64 chunk_max = (u64)ctx->ncu * wgs * 256;
