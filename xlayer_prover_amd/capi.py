@@ -571,7 +571,7 @@ class ExprProgram:
             self.codegen(src)
         finally:
             del os.environ["XLP_EXPR_PARTS"]
-        flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I", os.path.join(_HERE, "csrc")]
+        flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I", os.path.join(_HERE, "csrc")] + os.environ.get("XLP_JIT_EXTRA_FLAGS", "").split()
         srcs = [src] + [f"{src}.part{k}.hip" for k in range(parts) if os.path.exists(f"{src}.part{k}.hip")]
         procs = [subprocess.Popen(["hipcc"] + flags + ["-c", f, "-o", f + ".o"]) for f in srcs]
         if any(p.wait() != 0 for p in procs):
