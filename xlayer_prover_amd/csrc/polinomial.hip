@@ -100,16 +100,46 @@ __global__ __launch_bounds__(SCAN_T) void scan3_block_kernel(u64* out_incl, u64*
     const u64 base = (u64)blockIdx.x * SCAN_PER_BLOCK + (u64)threadIdx.x * SCAN_E;
     e3 v[SCAN_E];
     e3 acc = one3();
+    // mode 0: the ratios num / den, the denominators inverted four at a time with Montgomery's trick (one field inversion = ~140 base
+    // multiplications per FOUR elements instead of per element; a zero denominator gives a zero ratio, as batch_inverse3_kernel does)
+    constexpr int ZB = 4;
 #pragma unroll
-    for (int k = 0; k < SCAN_E; k++) {
-        const u64 i = base + k;
-        e3 x = one3();
-        if (i < n) {
-            x = load3(num + ns * i);
-            if (mode == 0) x = gl::mul3(x, inv3(load3(den + ds * i)));
+    for (int k0 = 0; k0 < SCAN_E; k0 += ZB) {
+        e3 x[ZB];
+        if (mode == 0) {
+            e3 d[ZB], pre[ZB];
+            bool z[ZB];
+            e3 pacc = one3();
+#pragma unroll
+            for (int k = 0; k < ZB; k++) {
+                const u64 i = base + k0 + k;
+                d[k] = i < n ? load3(den + ds * i) : one3();
+                z[k] = is_zero3(d[k]);
+                if (z[k]) d[k] = one3();
+                pre[k] = pacc;
+                pacc = gl::mul3(pacc, d[k]);
+            }
+            e3 inv = inv3(pacc);
+#pragma unroll
+            for (int k = ZB - 1; k >= 0; k--) {
+                const u64 i = base + k0 + k;
+                e3 r = gl::mul3(inv, pre[k]);
+                inv = gl::mul3(inv, d[k]);
+                if (z[k]) { r.c[0] = 0; r.c[1] = 0; r.c[2] = 0; }
+                x[k] = i < n ? gl::mul3(load3(num + ns * i), r) : one3();
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < ZB; k++) {
+                const u64 i = base + k0 + k;
+                x[k] = i < n ? load3(num + ns * i) : one3();
+            }
         }
-        acc = gl::mul3(acc, x);
-        v[k] = acc;                      // inclusive within the thread
+#pragma unroll
+        for (int k = 0; k < ZB; k++) {
+            acc = gl::mul3(acc, x[k]);
+            v[k0 + k] = acc;             // inclusive within the thread
+        }
     }
     sh[threadIdx.x][0] = acc.c[0]; sh[threadIdx.x][1] = acc.c[1]; sh[threadIdx.x][2] = acc.c[2];
     __syncthreads();
