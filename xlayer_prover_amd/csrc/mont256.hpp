@@ -95,5 +95,70 @@ __device__ __forceinline__ void mul(u32 (&r)[8], const u32 (&a)[8], const u32 (&
     for (int i = 0; i < 8; i++) r[i] = ge ? d[i] : t[i];
 }
 
+// ---- sums of products with ONE Montgomery reduction (the dot products of the Poseidon-BN128 linear layers)
+// acc (16 limbs) += k * b.   k: wave-uniform table element (SGPRs), b: a lane's value.  The caller bounds the sum below 2^512.
+__device__ __forceinline__ void mac512(u32 (&acc)[16], const u32 (&k)[8], const u32 (&b)[8])
+{
+    u64 lo = 0;
+    u32 hi = 0;
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+        mac_k(lo, hi, acc[c], 1u);
+#pragma unroll
+        for (int x = (c > 7 ? c - 7 : 0); x <= (c < 7 ? c : 7); x++) mac_k(lo, hi, b[c - x], k[x]);
+        acc[c] = (u32)lo;
+        lo = (lo >> 32) | ((u64)hi << 32);
+        hi = 0;
+    }
+}
+// r = t / 2^256 mod N for t (16 limbs) < SUBS * N * 2^256 - N * 2^256 + ... : the Montgomery reduction of a sum of products, followed by
+// SUBS conditional subtractions (a sum of n products of values below N needs ceil((n * N / 2^256) + 1) - 1 of them; the result is canonical).
+template <class P, int SUBS>
+__device__ __forceinline__ void redc512(u32 (&r)[8], const u32 (&t)[16])
+{
+    u32 m[8];
+    u64 lo = 0;
+    u32 hi = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        mac_k(lo, hi, t[i], 1u);
+#pragma unroll
+        for (int j = 0; j < i; j++) mac_k(lo, hi, m[j], P::N[i - j]);
+        m[i] = (u32)lo * P::N0INV;
+        mac_k(lo, hi, m[i], P::N[0]);
+        lo = (lo >> 32) | ((u64)hi << 32);
+        hi = 0;
+    }
+    u32 v[9];
+#pragma unroll
+    for (int i = 8; i < 16; i++) {
+        mac_k(lo, hi, t[i], 1u);
+#pragma unroll
+        for (int j = i - 7; j < 8; j++) mac_k(lo, hi, m[j], P::N[i - j]);
+        v[i - 8] = (u32)lo;
+        lo = (lo >> 32) | ((u64)hi << 32);
+        hi = 0;
+    }
+    v[8] = (u32)lo;
+#pragma unroll
+    for (int s = 0; s < SUBS; s++) {
+        u32 d[9];
+        u32 borrow = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const u64 x = (u64)v[i] - P::N[i] - borrow;
+            d[i] = (u32)x;
+            borrow = (u32)(x >> 63);
+        }
+        const u64 x = (u64)v[8] - borrow;
+        d[8] = (u32)x;
+        const bool ge = (x >> 63) == 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) v[i] = ge ? d[i] : v[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) r[i] = v[i];
+}
+
 }  // namespace mont
 }  // namespace xlp
