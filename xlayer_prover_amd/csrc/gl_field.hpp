@@ -95,13 +95,15 @@ __device__ __forceinline__ u64 neg(u64 a) { return a ? P - a : 0; }  // canon ->
 // Written in assembly (round 2): 8 VALU + 2 SALU instead of the 11 VALU hipcc builds from the C form (it materialises the borrow with a
 // v_cndmask instead of v_subbrev, compares s with l instead of taking the multiply-add's carry-out, and spends four selects on the
 // correction word).  Every field multiplication ends here: x^7 79 -> 67 instructions, the Poseidon permutation 16.0k -> 14.6k.
-// The s_nop 1 pairs are the two wait states hipcc itself leaves between a VALU write of a carry and the VALU instruction reading it.
+// No wait states between a carry's producer and its consumer: hipcc leaves two (s_nop 1) in its own code, but the hardware interlocks
+// them -- tools/experiments/reduce128_hazard_probe.hip runs this sequence with ONE wave on the whole GPU (nothing to fill a slot) on edge
+// values and 2^20 random ones against the C formula: no mismatch (and mont256.hpp's multiply-accumulate has relied on it all along).
 __device__ __forceinline__ u64 reduce128(u64 lo, u64 hi)
 {
     const u32 hh = (u32)(hi >> 32), hl = (u32)hi;
     u32 l0, l1;
     u64 b;                                   // lane mask: lo - hh borrowed
-    asm("v_sub_co_u32 %0, %2, %3, %4\n\ts_nop 1\n\tv_subbrev_co_u32 %1, %2, 0, %5, %2"
+    asm("v_sub_co_u32 %0, %2, %3, %4\n\tv_subbrev_co_u32 %1, %2, 0, %5, %2"
         : "=&v"(l0), "=&v"(l1), "=&s"(b) : "v"((u32)lo), "v"(hh), "v"((u32)(lo >> 32)));
     const u64 l = pack(l0, l1);
     u64 s, c;                                // c: lane mask: l + hl * EPS carried out of 64 bits (the multiply-add's own carry-out)
@@ -115,7 +117,6 @@ __device__ __forceinline__ u64 reduce128(u64 lo, u64 hi)
         "v_cndmask_b32 %[t], 0, %[t], %[x]\n\t"
         "v_cndmask_b32 %[r1], 0, -1, %[y]\n\t"
         "v_add_co_u32 %[r0], vcc, %[s0], %[t]\n\t"
-        "s_nop 1\n\t"
         "v_addc_co_u32 %[r1], vcc, %[s1], %[r1], vcc"
         : [r0] "=&v"(r0), [r1] "=&v"(r1), [t] "=&v"(t), [x] "=&s"(x), [y] "=&s"(y)
         : [b] "s"(b), [c] "s"(c), [s0] "v"((u32)s), [s1] "v"((u32)(s >> 32)) : "vcc", "scc");
