@@ -8,6 +8,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# the seven golden proofs of the reference's e2e flow as committed fixtures (tests/golden/make_fixtures.py), with the circuit whose
+# step programs made them
+GOLDEN_PROOFS = [("proof_recursive2_01.json", "recursive2"), ("proof_recursive1_0.json", "recursive1"), ("proof_recursive1_1.json", "recursive1"),
+                 ("proof_recursive1_2.json", "recursive1"), ("proof_recursive1_3.json", "recursive1"), ("proof_recursive2_23.json", "recursive2"),
+                 ("proof_recursive2_03.json", "recursive2")]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

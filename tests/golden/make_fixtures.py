@@ -106,7 +106,8 @@ def replay(J, verkey, extra_publics, steps_nbits, nqueries):
     return ch, special, ys
 
 
-def golden_proof(path, extra_publics, name):
+def golden_proof(path, extra_publics, name, queries_out=None):
+    queries_out = QUERIES_OUT if queries_out is None else queries_out
     J = json.load(open(path))
     nq = len(J["s0_vals1"])
     nbits_ext = len(J["s0_siblings1"][0])
@@ -187,7 +188,7 @@ def golden_proof(path, extra_publics, name):
         "ys": ys,
         "queries": [],
     }
-    for q in QUERIES_OUT:
+    for q in queries_out:
         e = {"q": q, "idx": ys[q]}
         for tname in ["1", "3", "4", "C"]:
             e[f"s0_vals{tname}"] = J[f"s0_vals{tname}"][q]
@@ -199,19 +200,56 @@ def golden_proof(path, extra_publics, name):
     return fx, const_root
 
 
+# The seven golden proofs of the reference's e2e flow (test/service/aggregator/aggregator_service.cpp:31-144): four batch proofs
+# (recursive1.zkin.proof_{0..3} = genBatchProof outputs), aggregated pairwise (recursive2.zkin.proof_{01,23} = genAggregatedProof
+# outputs) and once more (proof_03).  (fixture name, source, is_recursive2, queries kept)
+CHAIN = [
+    ("proof_recursive2_01.json", "/finalProof/recursive2.zkin.proof_01.json", True, QUERIES_OUT),
+    ("proof_recursive1_0.json", "/aggregatedProof/recursive1.zkin.proof_0.json", False, QUERIES_OUT),
+    ("proof_recursive1_1.json", "/aggregatedProof/recursive1.zkin.proof_1.json", False, [0, 42]),
+    ("proof_recursive1_2.json", "/aggregatedProof/recursive1.zkin.proof_2.json", False, [0, 42]),
+    ("proof_recursive1_3.json", "/aggregatedProof/recursive1.zkin.proof_3.json", False, [0, 42]),
+    ("proof_recursive2_23.json", "/finalProof/recursive2.zkin.proof_23.json", True, [0, 42]),
+    ("proof_recursive2_03.json", "/finalProof/recursive2.zkin.proof_03.json", True, [0, 42]),
+]
+# which two proofs the reference joined into which (aggregator_service.cpp:31-144; Prover::genAggregatedProof prover.cpp:674-783)
+JOINS = [("proof_recursive1_0.json", "proof_recursive1_1.json", "proof_recursive2_01.json"),
+         ("proof_recursive1_2.json", "proof_recursive1_3.json", "proof_recursive2_23.json"),
+         ("proof_recursive2_01.json", "proof_recursive2_23.json", "proof_recursive2_03.json")]
+
+
 def main():
     kats = poseidon_kats()
     json.dump(kats, open(os.path.join(HERE, "poseidon_kats.json"), "w"), separators=(",", ":"))
-    fx2, const2 = golden_proof(REF + "/finalProof/recursive2.zkin.proof_01.json", None, "recursive2.proof_01")
-    json.dump(fx2, open(os.path.join(HERE, "proof_recursive2_01.json"), "w"), separators=(",", ":"))
-    fx1, _ = golden_proof(REF + "/aggregatedProof/recursive1.zkin.proof_0.json", const2, "recursive1.proof_0")
-    json.dump(fx1, open(os.path.join(HERE, "proof_recursive1_0.json"), "w"), separators=(",", ":"))
+    const2, const1, pubs = None, None, {}
+    for fname, src, is_r2, qs in CHAIN:
+        fx, const = golden_proof(REF + src, None if is_r2 else const2, src.rsplit("/", 1)[1][:-5].replace(".zkin", ""), qs)
+        if is_r2:      # every recursive2 proof was made with the same constant tree (one circuit), likewise recursive1
+            assert const2 is None or const == const2, (const, const2)
+            const2 = const
+        else:
+            assert const1 is None or const == const1, (const, const1)
+            const1 = const
+        pubs[fname] = fx["publics"][:44]
+        json.dump(fx, open(os.path.join(HERE, fname), "w"), separators=(",", ":"))
+    # the aggregation chain as the reference produced it: publics of the joined proof = joinzkin's stitch of its two inputs
+    # (proof2zkinStark.cpp:84-125) and the inputs pass genAggregatedProof's consistency checks (prover.cpp:695-728)
+    for a, b, out in JOINS:
+        pa, pb, po = pubs[a], pubs[b], pubs[out]
+        assert po == pa[:19] + pb[19:44], (a, b, out)
+        assert pa[17] == pb[17] and pa[18] == pb[18] and pa[19:27] == pb[0:8] and pa[27:35] == pb[8:16] and pa[43] == pb[16], (a, b)
+    print("aggregation chain: 3 joins reproduce the golden aggregated publics; all inputs pass the reference's consistency checks")
+    json.dump({"source": "publics of the seven golden proofs (testvectors/aggregatedProof, testvectors/finalProof) and which pairs the reference "
+                         "aggregated into which (test/service/aggregator/aggregator_service.cpp:31-144)",
+               "recursive1_constRoot": [str(x) for x in const1], "recursive2_constRoot": [str(x) for x in const2],
+               "joins": [{"a": a, "b": b, "out": out} for a, b, out in JOINS]},
+              open(os.path.join(HERE, "aggregation_chain.json"), "w"), indent=1)
     # the four G1 commitments of the reference's fflonk proof: real BN254 curve points held by the reference (pin q and b = 3)
     blob = open(REF + "/finalProof/proof.json").read().strip()[2:]
     w = [int(blob[64 * i:64 * i + 64], 16) for i in range(8)]
     json.dump({"source": "testvectors/finalProof/proof.json: the first eight 32-byte words = the G1 commitments C1, C2, W1, W2 of the reference's fflonk proof (affine x, y)",
                "points": [[str(w[2 * i]), str(w[2 * i + 1])] for i in range(4)]}, open(os.path.join(HERE, "fflonk_proof_g1_points.json"), "w"), indent=1)
-    for f in ["poseidon_kats.json", "proof_recursive2_01.json", "proof_recursive1_0.json", "fflonk_proof_g1_points.json"]:
+    for f in ["poseidon_kats.json", "fflonk_proof_g1_points.json", "aggregation_chain.json"] + [c[0] for c in CHAIN]:
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -7,6 +7,8 @@ import os
 import numpy as np
 import pytest
 
+from tests.conftest import GOLDEN_PROOFS
+
 pytestmark = pytest.mark.gpu
 P = 0xFFFFFFFF00000001
 
@@ -68,10 +70,11 @@ def test_merkle_rejects_non_pow2(xlp):
         xlp.merkle(np.zeros(3 * 5, np.uint64), 5, 3)
 
 
-def test_merkle_golden_paths(xlp, orc, golden_dir):
+@pytest.mark.parametrize("name", [g[0] for g in GOLDEN_PROOFS])
+def test_merkle_golden_paths(xlp, orc, golden_dir, name):
     """leaf rows + sibling paths of the reference's golden proofs hash to the proof's roots
     when the leaf and every node are computed by the HIP kernels"""
-    F = json.load(open(os.path.join(golden_dir, "proof_recursive2_01.json")))
+    F = json.load(open(os.path.join(golden_dir, name)))
     for Q in F["queries"]:
         for tn, root in (("1", F["root1"]), ("3", F["root3"]), ("4", F["root4"]), ("C", F["constRoot"])):
             row = np.array(ints(Q[f"s0_vals{tn}"]), np.uint64)
@@ -231,7 +234,7 @@ def test_fri_fold_vs_oracle(xlp, orc, bits, red):
 def test_fri_fold_golden(xlp, orc, golden_dir):
     """fold relations of the reference's golden proofs, computed by the HIP fold kernel:
     embed the query's group values into an otherwise random polynomial."""
-    for name in ("proof_recursive2_01.json", "proof_recursive1_0.json"):
+    for name, _ in GOLDEN_PROOFS:
         F = json.load(open(os.path.join(golden_dir, name)))
         steps = F["steps_nBits"]
         for Q in F["queries"][:2]:

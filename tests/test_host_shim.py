@@ -163,3 +163,59 @@ def test_joinzkin_mirror(tmp_path):
     exp = _joinzkin_expected(z1, z2, vk, steps)
     assert list(got.keys()) == list(exp.keys())
     assert got == exp
+
+
+def _zkin_from_fixture(F):
+    """a zkin object with the reference's member set made of a golden fixture's content (the queries the fixture keeps)"""
+    z = {k: F[k] for k in ("root1", "root2", "root3", "root4", "evals")}
+    nsteps = len(F["steps_nBits"])
+    for i in range(1, nsteps):
+        z[f"s{i}_root"] = F["fri_roots"][i - 1]
+        z[f"s{i}_vals"] = [Q[f"s{i}_vals"] for Q in F["queries"]]
+        z[f"s{i}_siblings"] = [Q[f"s{i}_siblings"] for Q in F["queries"]]
+    for t in ("1", "3", "4", "C"):
+        z[f"s0_vals{t}"] = [Q[f"s0_vals{t}"] for Q in F["queries"]]
+        z[f"s0_siblings{t}"] = [Q[f"s0_siblings{t}"] for Q in F["queries"]]
+    z["finalPol"] = F["finalPol"]
+    z["publics"] = F["publics"][:44]                 # the zkin files hold 44; the fixture appends recursive2's constRoot (transcript input)
+    return z
+
+
+def _aggregate(tmp_path, za, zb, vk, steps):
+    for name, obj in (("a.json", za), ("b.json", zb), ("vk.json", vk)):
+        (tmp_path / name).write_text(json.dumps(obj))
+    r = subprocess.run([EXE, "aggregate", str(tmp_path / "a.json"), str(tmp_path / "b.json"), str(tmp_path / "vk.json"), str(steps)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-500:]
+    return json.loads(r.stdout)
+
+
+def test_aggregation_chain_of_the_golden_proofs(tmp_path, golden_dir):
+    """REFERENCE-HELD PIN of aggregation: the reference aggregated its four golden batch proofs pairwise and once more
+    (recursive1.zkin.proof_{0..3} -> recursive2.zkin.proof_{01,23} -> proof_03).  Through the C++ mirror -- the input checks of
+    Prover::genAggregatedProof (prover.cpp:695-728) and joinzkin (proof2zkinStark.cpp:84-175) -- every pair the reference joined
+    is accepted, the stitched publics are the golden aggregated proof's publics, `rootC` is recursive2's constant root (which
+    the golden recursive2 proofs open), and every member of the two inputs reappears under a_ / b_."""
+    chain = json.load(open(os.path.join(golden_dir, "aggregation_chain.json")))
+    fx = lambda n: json.load(open(os.path.join(golden_dir, n)))
+    vk = {"constRoot": [int(x) for x in chain["recursive2_constRoot"]]}
+    for J in chain["joins"]:
+        A, B, OUT = fx(J["a"]), fx(J["b"]), fx(J["out"])
+        za, zb = _zkin_from_fixture(A), _zkin_from_fixture(B)
+        steps = len(A["steps_nBits"])
+        got = _aggregate(tmp_path, za, zb, vk, steps)
+        assert "result" not in got, got
+        assert got["publics"] == OUT["publics"][:44]                      # the reference's own aggregated proof carries exactly these
+        assert got["rootC"] == chain["recursive2_constRoot"] == OUT["constRoot"] == OUT["publics"][44:48]
+        assert got == _joinzkin_expected(za, zb, vk, steps) and list(got.keys()) == list(_joinzkin_expected(za, zb, vk, steps).keys())
+        for pre, z in (("a_", za), ("b_", zb)):
+            for k, v in z.items():
+                assert got[pre + k] == v
+    # proofs that do not follow each other are refused with the reference's result code (ZKR_AGGREGATED_PROOF_INVALID_INPUT = 9)
+    p = [_zkin_from_fixture(fx(f"proof_recursive1_{i}.json")) for i in range(4)]
+    for a, b, what in ((1, 0, "newStateRoot"), (0, 2, "newStateRoot"), (0, 3, "newStateRoot"), (2, 1, "newStateRoot")):
+        got = _aggregate(tmp_path, p[a], p[b], vk, 5)
+        assert got["result"] == 9 and what in got["why"], got
+    for idx, what in ((17, "chainId"), (18, "forkId"), (43, "BatchNum"), (30, "AccInputHash")):
+        bad = dict(p[0]); bad["publics"] = list(bad["publics"]); bad["publics"][idx] = str(int(bad["publics"][idx]) + 1)
+        got = _aggregate(tmp_path, bad, p[1], vk, 5)
+        assert got["result"] == 9 and what in got["why"], got

@@ -22,7 +22,7 @@ public:
     std::string aggregatedProofInput1, aggregatedProofInput2, aggregatedProofOutput;     // zkin JSON texts (prover.cpp:674-783)
     std::string finalProofInput, recursivefProofOutput;                                  // prover.cpp:836-885
     std::string aggregatorAddress = "0";
-    int result = 0;                                  // ZKR_SUCCESS
+    int result = 1;                                  // zkresult numbering of src/config/zkresult.hpp:9-19: ZKR_SUCCESS = 1, ZKR_AGGREGATED_PROOF_INVALID_INPUT = 9
     std::string batchProofOutput;                    // zkin of the recursive1 proof + publics: the input of genAggregatedProof (prover.cpp:653)
     std::string publicsJson, proofJson;
     std::vector<std::pair<std::string, double>> timers;
@@ -124,7 +124,7 @@ public:
             if (!req.executor) xlp_exit_process("Prover::genBatchProof: no executor");
             req.executor(cmPols, Nz, Wz);                    // executor.execute(*pProverRequest, cmPols), prover.cpp:435
         }
-        if (req.result != 0) return;
+        if (req.result != ZKR_SUCCESS) return;           // prover.cpp:437: the executor reports through the request
         // ---- publics (prover.cpp:494-559): first / last row of Main's registers; recursive2's verification key behind them
         const uint64_t nPublics = starksRecursive1->starkInfo.nPublics;
         std::vector<Goldilocks::Element> publics(nPublics, Goldilocks::zero());
@@ -229,6 +229,25 @@ public:
             delete fproof;
         }
     }
+    // The input checks of Prover::genAggregatedProof (prover.cpp:695-728): the second proof must continue the first -- same chainId
+    // (publics[17]) and forkId ([18]); the first proof's newStateRoot ([19..26]) and newAccInputHash ([27..34]) are the second's
+    // oldStateRoot ([0..7]) and oldAccInputHash ([8..15]); its newBatchNum ([43]) is the second's oldBatchNum ([16]).  Checked in the
+    // reference's order, `why` names the first failure like its log line does.
+    enum { ZKR_SUCCESS = 1, ZKR_AGGREGATED_PROOF_INVALID_INPUT = 9 };      // src/config/zkresult.hpp:11,19
+    static bool aggregatedInputsAreConsecutive(const xlp_json::Value& in1, const xlp_json::Value& in2, std::string* why = NULL)
+    {
+        auto same = [&](size_t a, size_t b) { return in1["publics"][a].str() == in2["publics"][b].str(); };
+        auto fail = [&](const char* what, size_t a, size_t b) {
+            if (why) *why = std::string(what) + " " + in1["publics"][a].str() + "!=" + in2["publics"][b].str();
+            return false;
+        };
+        if (!same(17, 17)) return fail("Inputs has different chainId", 17, 17);
+        if (!same(18, 18)) return fail("Inputs has different forkId", 18, 18);
+        for (size_t i = 0; i < 8; i++) if (!same(19 + i, i)) return fail("The newStateRoot and the oldStateRoot are not consistent", 19 + i, i);
+        for (size_t i = 0; i < 8; i++) if (!same(27 + i, 8 + i)) return fail("newAccInputHash and oldAccInputHash are not consistent", 27 + i, 8 + i);
+        if (!same(43, 16)) return fail("newBatchNum and oldBatchNum are not consistent", 43, 16);
+        return true;
+    }
     // Prover::genAggregatedProof (prover.cpp:674-783): two batch (or aggregated) proofs -> joinzkin -> recursive2 STARK
     void genAggregatedProof(ProverRequest* pProverRequest)
     {
@@ -237,11 +256,12 @@ public:
         req.timers.clear();
         Tm total(&req, "PROVER_AGGREGATED_PROOF");
         const xlp_json::Value in1 = xlp_json::Parser(req.aggregatedProofInput1).value(), in2 = xlp_json::Parser(req.aggregatedProofInput2).value();
-        // the second proof must continue the first (prover.cpp:695-728): chainId, forkId, state root, acc input hash, batch number
-        auto same = [&](size_t a, size_t b) { return in1["publics"][a].str() == in2["publics"][b].str(); };
-        bool ok = same(17, 17) && same(18, 18) && same(43, 16);
-        for (size_t i = 0; i < 8; i++) ok = ok && same(19 + i, i) && same(27 + i, 8 + i);
-        if (!ok) { req.result = 1; /* ZKR_AGGREGATED_PROOF_INVALID_INPUT */ return; }
+        std::string why;
+        if (!aggregatedInputsAreConsecutive(in1, in2, &why)) {
+            fprintf(stderr, "Prover::genAggregatedProof() %s\n", why.c_str());
+            req.result = ZKR_AGGREGATED_PROOF_INVALID_INPUT;
+            return;
+        }
         Goldilocks::Element recursive2Verkey[4];
         verkey(config.recursive2Verkey, starksRecursive2, recursive2Verkey);
         std::string vk = "{\"constRoot\":[";
@@ -271,7 +291,7 @@ public:
         req.aggregatedProofOutput = withMembers(proof2zkinStark(fproof), ",\"publics\":" + pj.str());
         req.publicsJson = pj.str();
         if (config.saveOutputToFile) json2file(req.aggregatedProofOutput, req.filePrefix + "aggregated_proof.output.json");
-        req.result = 0;
+        req.result = ZKR_SUCCESS;
     }
 
     // Prover::genFinalProof (prover.cpp:836-885 up to the recursivef proof): aggregated proof -> StarkRecursiveF (BN128 trees and transcript).
@@ -304,6 +324,6 @@ public:
         xlp_json::arr(pj, publics);
         req.recursivefProofOutput = withMembers(proof2zkinStarkC12(fproof), ",\"publics\":" + pj.str() + ",\"aggregatorAddr\":\"" + req.aggregatorAddress + "\"");
         if (config.saveProofToFile) json2file(req.recursivefProofOutput, req.filePrefix + "recursivef.proof.json");
-        req.result = 0;
+        req.result = ZKR_SUCCESS;
     }
 };

@@ -9,6 +9,7 @@
 #include "starks.hpp"
 #include "xlp_host_bn128.hpp"
 #include "starkRecursiveF.hpp"
+#include "prover.hpp"
 
 // `polinomial <n> <seed>`: Polinomial::batchInverse / calculateZ / calculateH1H2 through STRIDED views of one slab
 // (offset > dim, as the section views of starks.cpp:108-184 are), results as JSON for the oracle comparison.
@@ -240,7 +241,8 @@ int main(int argc, char** argv)
         return r;
     }
     if (argc == 3 && std::string(argv[1]) == "starkinfo") return starkinfo_mode(argv[2]);
-    if (argc == 6 && std::string(argv[1]) == "joinzkin") {      // joinzkin a.json b.json verkey.json steps  (host only)
+    const bool aggregate = argc == 6 && std::string(argv[1]) == "aggregate";   // aggregate a.json b.json verkey.json steps: genAggregatedProof's input checks, then joinzkin
+    if (aggregate || (argc == 6 && std::string(argv[1]) == "joinzkin")) {      // joinzkin a.json b.json verkey.json steps  (host only)
         std::string t[3];
         for (int i = 0; i < 3; i++) {
             FILE* f = fopen(argv[2 + i], "rb");
@@ -250,6 +252,11 @@ int main(int argc, char** argv)
             fclose(f);
         }
         const xlp_json::Value z1 = xlp_json::Parser(t[0]).value(), z2 = xlp_json::Parser(t[1]).value(), vk = xlp_json::Parser(t[2]).value();
+        std::string why;
+        if (aggregate && !Prover::aggregatedInputsAreConsecutive(z1, z2, &why)) {
+            printf("{\"result\":%d,\"why\":\"%s\"}\n", (int)Prover::ZKR_AGGREGATED_PROOF_INVALID_INPUT, why.c_str());
+            return 0;
+        }
         const std::string out = joinzkin(z1, z2, vk, strtoull(argv[5], 0, 10));
         fwrite(out.data(), 1, out.size(), stdout);
         printf("\n");

@@ -95,7 +95,7 @@ int main(int argc, char** argv)
         stat("genBatchProof#2", req, proofB);
         req.aggregatedProofInput1 = proofA; req.aggregatedProofInput2 = proofB;
         prover.genAggregatedProof(&req);
-        if (req.result != 0) { fprintf(stderr, "genAggregatedProof: invalid input (the two proofs are not consecutive)\n"); return 1; }
+        if (req.result != Prover::ZKR_SUCCESS) { fprintf(stderr, "genAggregatedProof: invalid input (the two proofs are not consecutive)\n"); return 1; }
         {
             std::ostringstream vk;
             vk << "[";
