@@ -300,12 +300,6 @@ int xlp_field_op(uint64_t* out, const uint64_t* a, const uint64_t* b, uint64_t n
  * around STARK_STEP_n_LDE (src/starkpil/starks.cpp:49-55). */
 int xlp_profile_enable(int on);
 int xlp_profile_read(double ms_sum[3], uint64_t* count);
-/* Kernel-selection knobs (measurement / A-B aid; results never depend on them).  Keys:
- *   "lde_persist"  experiment builds only (tools/experiments/ntt_lde_persistent_dma.hip, -DXLP_LDE_PERSISTENT_EXPERIMENT): bit mask of
- *                  the extendPol kernels that run as persistent workgroups with LDS-direct prefetch of the next tile at N = 2^23
- *                  (1 = lde_top_dif, 2 = lde_mid, 4 = lde_top_dit).  Ignored by the product build.
- * Unknown keys fail. */
-int xlp_tune(const char* key, long value);
 
 /* ---- band-pipelined commit of a section (device pointers) ------------------------------------------
  * A Merkle leaf is a sponge over the row in column order, so the leaf state (4 words per row = level 0 of the node buffer)

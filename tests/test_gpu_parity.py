@@ -160,19 +160,11 @@ def test_extend_fast_path_vs_oracle(xlp, orc, lg, ext, ncols):
 
 
 @pytest.mark.parametrize("lg,ext,ncols", [(22, 1, 13), (22, 2, 8), (23, 1, 9)])
-@pytest.mark.parametrize("mask", [0, 7])
-def test_extend_2p22_2p23_vs_oracle(xlp, orc, lg, ext, ncols, mask):
-    """N >= 2^22 against the oracle: full 8-column tiles, ragged tiles, non-canonical input words.  mask selects the persistent
-    forms of lde_top_dif / lde_mid / lde_top_dit in experiment builds (tools/experiments/ntt_lde_persistent_dma.hip); the
-    product build ignores it."""
+def test_extend_2p22_2p23_vs_oracle(xlp, orc, lg, ext, ncols):
+    """N >= 2^22 against the oracle: full 8-column tiles, ragged tiles, non-canonical input words"""
     n, n_ext = 1 << lg, 1 << (lg + ext)
     src = edge_matrix(orc, n, ncols, 0x5EED0062 + lg)
-    xlp.tune("lde_persist", mask)
-    try:
-        got = xlp.extend(src, n_ext, n, ncols)
-    finally:
-        xlp.tune("lde_persist", 7)
-    assert (got == orc.extend_pol(src, n_ext, n, ncols)).all()
+    assert (xlp.extend(src, n_ext, n, ncols) == orc.extend_pol(src, n_ext, n, ncols)).all()
 
 
 def test_lde_config2_device_resident_properties(xlp, orc):
@@ -762,3 +754,28 @@ def test_host_pointer_extend_then_merkle_with_cache(xlp, orc, lg, ext, w):
             assert (xlp.merkle(out, w, n_ext) == orc.merkletree(out, w, n_ext)).all()
     xlp.cache_enable(0)
     assert xlp.cache_bytes() == 0
+
+
+def test_host_pointer_outputs_drop_stale_device_copies(xlp, orc):
+    """every host-pointer entry point that WRITES a host range drops the device copies of it (include/xlp_gl.h, xlp_cache_enable): proof 1
+    commits a section (xlp_merkle caches its device copy), proof 2 rewrites the same host buffer through another call -- xlp_ntt(dst = the
+    section), xlp_batch_inverse, xlp_transpose3 -- and commits it again: the second tree must be the tree of the NEW content."""
+    n, w = 1 << 10, 12
+    xlp.cache_enable(1 << 30)
+    try:
+        for rewrite in ("ntt", "batch_inverse", "transpose3"):
+            sec = np.ascontiguousarray(orc.fill(n * w, 0x5EED00D1).reshape(n, w))
+            assert (xlp.merkle(sec, w, n) == orc.merkletree(sec, w, n)).all()
+            assert xlp.cache_bytes() >= sec.nbytes                          # the section's device copy is now cached under its host range
+            src = orc.fill(n * w, 0x5EED00D2).reshape(n, w)
+            lib = xlp.load()
+            if rewrite == "ntt":
+                xlp._ck(lib.xlp_ntt(xlp._p(sec), xlp._p(src), n, w, 1), "xlp_ntt")
+                assert (sec == orc.ntt(src, n, w, inverse=True)).all()
+            elif rewrite == "batch_inverse":
+                xlp._ck(lib.xlp_batch_inverse(xlp._p(sec), xlp._p(src), n * w // 3, 3), "xlp_batch_inverse")
+            else:
+                xlp._ck(lib.xlp_transpose3(xlp._p(sec), xlp._p(src), n * w // 3, 4), "xlp_transpose3")
+            assert (xlp.merkle(sec, w, n) == orc.merkletree(sec, w, n)).all(), f"stale device copy hashed after {rewrite}"
+    finally:
+        xlp.cache_enable(0)

@@ -6,6 +6,7 @@ import json
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -219,3 +220,20 @@ def test_aggregation_chain_of_the_golden_proofs(tmp_path, golden_dir):
         bad = dict(p[0]); bad["publics"] = list(bad["publics"]); bad["publics"][idx] = str(int(bad["publics"][idx]) + 1)
         got = _aggregate(tmp_path, bad, p[1], vk, 5)
         assert got["result"] == 9 and what in got["why"], got
+
+
+@pytest.mark.gpu
+def test_host_boundary_is_reentrant_from_openmp_threads(orc):
+    """SURVEY 8b: FRIProve::prove calls NTT_Goldilocks(nX, 1).INTT from inside an OpenMP region (friProve.cpp:44-108).  The C++ mirror's
+    INTT (+ a transcript-style hash_full_result) from 8 threads at once over 192 groups: every result equals the oracle's."""
+    nX, groups, seed = 32, 192, 0x5EED00E1
+    env = dict(os.environ, OMP_NUM_THREADS="8")
+    r = subprocess.run([EXE, "omp_intt", str(nX), str(groups), str(seed)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-800:]
+    got = json.loads(r.stdout)
+    assert got["threads"] == 8
+    for g in range(groups):
+        src = orc.fill(nX * 3, seed, start=g * nX * 3).reshape(nX, 3)
+        assert (np.array(got["intt"][g], np.uint64).reshape(nX, 3) == orc.ntt(src, nX, 3, inverse=True)).all(), g
+        st = orc.fill(12, seed + 1, start=g * 12)
+        assert got["perm"][g] == [int(v) for v in orc.perm(st)], g

@@ -13,6 +13,15 @@ from tests import expr_real as R
 from xlayer_prover_amd import capi
 
 
+def headers_hash():
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(os.path.dirname(os.path.abspath(capi.__file__)), "csrc")
+    for f in ("gl_field.hpp", "xlp_expr_jit.h"):
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log-rows", default="8,19")
@@ -64,7 +73,9 @@ def main():
             probe = os.path.join(build, name + ".probe.hip")
             p.codegen(probe)
             stamp = os.path.join(build, name + ".stamp")
-            sig = [l for l in open(probe) if "xlpjit_signature" in l][0]
+            # ... and the generated text is compiled against the library's field arithmetic: a change there (gl_field.hpp,
+            # xlp_expr_jit.h) makes the plugin stale as well
+            sig = [l for l in open(probe) if "xlpjit_signature" in l][0] + "headers " + headers_hash() + "\n"
             if os.path.exists(so) and os.path.exists(stamp) and open(stamp).read() == sig and not a.force:
                 print("up to date", so); continue
             t = time.time()

@@ -60,7 +60,6 @@ SIGNATURES = {
     "xlp_expr_attach": [_pu, C.c_char_p],
     "xlp_dev_expr_run": [_pu, _pu, _u64, _u64],
     "xlp_profile_enable": [C.c_int],
-    "xlp_tune": [C.c_char_p, C.c_long],
     "xlp_bn128_init": [C.c_char_p],
     "xlp_dev_merkle_bn128": [_pu, _pu, _u64, _u64],
     "xlp_merkle_bn128": [_pu, _pu, _u64, _u64],
@@ -187,11 +186,6 @@ def shutdown():
 
 def profile_enable(on=True):
     _ck(load().xlp_profile_enable(1 if on else 0), "xlp_profile_enable")
-
-
-def tune(key, value):
-    """kernel-selection knobs (xlp_tune): results never depend on them"""
-    _ck(load().xlp_tune(key.encode(), int(value)), "xlp_tune")
 
 
 def profile_read():

@@ -522,6 +522,14 @@ static std::string default_constants_path()
     return "chelpers/poseidon_bn128.bin";
 }
 
+// the tables live on the device the context was bound to: they go with it (xlp_shutdown), a later xlp_init loads them again
+void bn128_shutdown()
+{
+    if (g_bn_blob) { (void)hipFree(g_bn_blob); g_bn_blob = nullptr; }
+    g_bn_tables = bn::Tables{};
+    g_bn_ready = false;
+}
+
 int bn128_init(Ctx* ctx, const char* path)
 {
     (void)ctx;

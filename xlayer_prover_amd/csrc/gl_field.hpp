@@ -89,38 +89,35 @@ __device__ __forceinline__ u64 sub(u64 a, u64 b) { return subc(a, b); }  // same
 __device__ __forceinline__ u64 neg(u64 a) { return a ? P - a : 0; }  // canon -> canon
 
 // lo + hl*EPS - hh  (mod p) -> any, where (hh:hl) = hi.   This is (hi:lo) mod p.
-// Both wrap-arounds are settled together: l = lo - hh may borrow (b: the true value is l - 2^64), s = l + hl*EPS may
-// carry (c: the true value is s + 2^64); net (c - b) * 2^64 = (c - b) * EPS.  c = 1, b = 0: s < 2^64 - 2^33 + 1, adding
-// EPS cannot carry.  b = 1, c = 0: l >= 2^64 - 2^32 and so is s, subtracting EPS cannot borrow.  b = c: nothing to do.
-// Written in assembly (round 2): 8 VALU + 2 SALU instead of the 11 VALU hipcc builds from the C form (it materialises the borrow with a
-// v_cndmask instead of v_subbrev, compares s with l instead of taking the multiply-add's carry-out, and spends four selects on the
-// correction word).  Every field multiplication ends here: x^7 79 -> 67 instructions, the Poseidon permutation 16.0k -> 14.6k.
-// No wait states between a carry's producer and its consumer: hipcc leaves two (s_nop 1) in its own code, but the hardware interlocks
-// them -- tools/experiments/reduce128_hazard_probe.hip runs this sequence with ONE wave on the whole GPU (nothing to fill a slot) on edge
-// values and 2^20 random ones against the C formula: no mismatch (and mont256.hpp's multiply-accumulate has relied on it all along).
+// Both wrap-arounds are settled together: s = lo + hl*EPS may carry (c: the true value is s + 2^64), l = s - hh may borrow (b: the true
+// value is l - 2^64); net (c - b) * 2^64 = (c - b) * EPS.  c = 1, b = 0: s < 2^64 - 2^33 + 1 and l <= s, adding EPS cannot carry.  b = 1,
+// c = 0: l >= 2^64 - 2^32 + 1, subtracting EPS cannot borrow.  b = c: nothing to do.
+// Written in assembly: 7 VALU + 2 SALU (hipcc builds 11 VALU from the C form: it materialises the borrow with a v_cndmask instead of
+// v_subbrev, compares instead of taking the multiply-add's carry-out, and spends four selects on the correction word).  Every field
+// multiplication ends here.  Round 3: (1) the correction is ONE 64-bit add (v_lshl_add_u64, left to the compiler so that it can schedule
+// it) instead of a v_add_co / v_addc_co pair; (2) HAZARD-SAFE by construction: on gfx940+ a VALU that reads an SGPR / VCC written by a
+// VALU needs two wait states in between (LLVM's GCNHazardRecognizer, "VALUWriteSGPRVALURead", which cannot see inside an asm blob) --
+// every such producer / consumer pair below is two instructions apart: v_mad (c) .. v_sub_co, s_nop .. v_cndmask (c);
+// v_sub_co (b) .. s_nop, v_cndmask .. v_subbrev (b).  The SALU reads of b and c and the VALU reads of the SALU-written x, y need none.
 __device__ __forceinline__ u64 reduce128(u64 lo, u64 hi)
 {
     const u32 hh = (u32)(hi >> 32), hl = (u32)hi;
-    u32 l0, l1;
-    u64 b;                                   // lane mask: lo - hh borrowed
-    asm("v_sub_co_u32 %0, %2, %3, %4\n\tv_subbrev_co_u32 %1, %2, 0, %5, %2"
-        : "=&v"(l0), "=&v"(l1), "=&s"(b) : "v"((u32)lo), "v"(hh), "v"((u32)(lo >> 32)));
-    const u64 l = pack(l0, l1);
-    u64 s, c;                                // c: lane mask: l + hl * EPS carried out of 64 bits (the multiply-add's own carry-out)
-    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=&v"(s), "=&s"(c) : "v"(hl), "v"(l));
-    // + (c - b) * EPS as a two's complement word: +EPS = (0, FFFFFFFF), -EPS = (FFFFFFFF, 00000001)
-    u32 r0, r1, t;
-    u64 x, y;
-    asm("s_xor_b64 %[x], %[b], %[c]\n\t"
-        "s_andn2_b64 %[y], %[b], %[c]\n\t"
+    u64 s, c;                                // c: lane mask: lo + hl * EPS carried out of 64 bits (the multiply-add's own carry-out)
+    asm("v_mad_u64_u32 %[s], %[c], %[hl], -1, %[lo]" : [s] "=&v"(s), [c] "=&s"(c) : [hl] "v"(hl), [lo] "v"(lo));
+    u32 l0, l1, t, r1;
+    u64 b, x, y;                             // b: lane mask: s - hh borrowed
+    // + (c - b) * EPS as a two's complement word (t, r1): +EPS = (FFFFFFFF, 0), -EPS = (00000001, FFFFFFFF)
+    asm("v_sub_co_u32 %[l0], %[b], %[s0], %[hh]\n\t"
+        "s_nop 0\n\t"
         "v_cndmask_b32 %[t], 1, -1, %[c]\n\t"
+        "v_subbrev_co_u32 %[l1], %[b], 0, %[s1], %[b]\n\t"
+        "s_xor_b64 %[x], %[b], %[c]\n\t"
+        "s_andn2_b64 %[y], %[b], %[c]\n\t"
         "v_cndmask_b32 %[t], 0, %[t], %[x]\n\t"
-        "v_cndmask_b32 %[r1], 0, -1, %[y]\n\t"
-        "v_add_co_u32 %[r0], vcc, %[s0], %[t]\n\t"
-        "v_addc_co_u32 %[r1], vcc, %[s1], %[r1], vcc"
-        : [r0] "=&v"(r0), [r1] "=&v"(r1), [t] "=&v"(t), [x] "=&s"(x), [y] "=&s"(y)
-        : [b] "s"(b), [c] "s"(c), [s0] "v"((u32)s), [s1] "v"((u32)(s >> 32)) : "vcc", "scc");
-    return pack(r0, r1);
+        "v_cndmask_b32 %[r1], 0, -1, %[y]"
+        : [b] "=&s"(b), [l0] "=&v"(l0), [l1] "=&v"(l1), [t] "=&v"(t), [r1] "=&v"(r1), [x] "=&s"(x), [y] "=&s"(y)
+        : [c] "s"(c), [hh] "v"(hh), [s0] "v"((u32)s), [s1] "v"((u32)(s >> 32)) : "scc");
+    return pack(l0, l1) + pack(t, r1);       // no wrap in either direction (see above): v_lshl_add_u64
 }
 
 // any * any -> any

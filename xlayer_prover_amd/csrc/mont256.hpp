@@ -16,15 +16,17 @@ namespace mont {
 typedef uint32_t u32;
 typedef uint64_t u64;
 
-// acc (lo64, hi32) += a * b
+// acc (lo64, hi32) += a * b.  Two wait states between the multiply-add that writes VCC and the add that reads it: gfx940+ does not
+// interlock a VALU-written SGPR / VCC against the next VALU's read (LLVM GCNHazardRecognizer, "VALUWriteSGPRVALURead": 2 wait states),
+// and the compiler cannot see inside an asm blob.
 __device__ __forceinline__ void mac(u64& lo, u32& hi, u32 a, u32 b)
 {
-    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(a), "v"(b) : "vcc");
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(a), "v"(b) : "vcc");
 }
 // acc += a * K, K a compile-time constant (modulus limb) in an SGPR
 __device__ __forceinline__ void mac_k(u64& lo, u32& hi, u32 a, u32 k)
 {
-    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(a), "s"(k) : "vcc");
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(a), "s"(k) : "vcc");
 }
 
 // (lo, hi) += (lo2, hi2)

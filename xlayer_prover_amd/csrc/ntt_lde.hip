@@ -347,17 +347,6 @@ __global__ void lde_tw2_kernel(u64* out, const u64* __restrict__ sk /* G^k2 */, 
 
 // ----------------------------------------------------------------- host side
 int get_pow_tables(Ctx* ctx, u32 L, u64 root, u64 mult, const u64** lo, const u64** hi);  // ntt.hip
-#ifdef XLP_LDE_PERSISTENT_EXPERIMENT
-// tools/experiments/ntt_lde_persistent_dma.hip: persistent workgroups with LDS-direct prefetch of the next tile (N = 2^23).
-// Measured slower than the one-tile-per-workgroup kernels (profiles/r2/lde_persistent_dma_ab.json); not built by default.
-bool lde_persistent_supported(u32 BT);
-int launch_lde_top_p(Ctx* ctx, const LdeParams& p, u32 BT, bool dit);
-int launch_lde_mid_p(Ctx* ctx, const LdeParams& p, u32 BT);
-#else
-static inline bool lde_persistent_supported(u32) { return false; }
-static inline int launch_lde_top_p(Ctx*, const LdeParams&, u32, bool) { return -1; }
-static inline int launch_lde_mid_p(Ctx*, const LdeParams&, u32) { return -1; }
-#endif
 
 template <int BT>
 static int launch_top(Ctx* ctx, const LdeParams& p, bool dit)
@@ -543,8 +532,6 @@ int dev_extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld
         XLP_HIP(hipFuncSetAttribute((const void*)lde_mid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         mid_attr = true;
     }
-    // experiment builds only (-DXLP_LDE_PERSISTENT_EXPERIMENT): bit 0 = lde_top_dif, bit 1 = lde_mid, bit 2 = lde_top_dit as persistent workgroups
-    const u32 persist = lde_persistent_supported(BT) ? ctx->lde_persist : 0;
     for (u64 col0 = 0; col0 < ncols; col0 += wc_max) {
         p.col0 = (u32)(first + col0);
         p.wc = (u32)(ncols - col0 < wc_max ? ncols - col0 : wc_max);
@@ -554,11 +541,9 @@ int dev_extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld
             for (int i = 0; i < 4; i++) { XLP_HIP(hipEventCreate(&ev[i])); ctx->prof_events.push_back(ev[i]); }
             XLP_HIP(hipEventRecord(ev[0], ctx->stream));
         }
-        if ((persist & 1) ? launch_lde_top_p(ctx, p, BT, false) : launch_top_bt(ctx, p, BT, false)) return -1;
+        if (launch_top_bt(ctx, p, BT, false)) return -1;
         if (ctx->profile) XLP_HIP(hipEventRecord(ev[1], ctx->stream));
-        if (persist & 2) {
-            if (launch_lde_mid_p(ctx, p, BT)) return -1;
-        } else {
+        {
             const u32 ncc = (p.wc + 3) / 4;
             const u64 grid = (u64)ncc << BT;
             const size_t lds = (size_t)(4096 + 256 + 1) * 4 * sizeof(u64);
@@ -566,7 +551,7 @@ int dev_extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld
             XLP_HIP(hipGetLastError());
         }
         if (ctx->profile) XLP_HIP(hipEventRecord(ev[2], ctx->stream));
-        if ((persist & 4) ? launch_lde_top_p(ctx, p, BT, true) : launch_top_bt(ctx, p, BT, true)) return -1;
+        if (launch_top_bt(ctx, p, BT, true)) return -1;
         if (ctx->profile) XLP_HIP(hipEventRecord(ev[3], ctx->stream));
     }
     return 0;

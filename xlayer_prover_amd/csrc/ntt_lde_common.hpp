@@ -1,4 +1,4 @@
-// Shared declarations of the extendPol fast-path kernels (ntt_lde.hip, ntt_lde_p.hip).
+// Shared declarations of the extendPol fast-path kernels (ntt_lde.hip).
 #pragma once
 #include "gl_field.hpp"
 #include "xlp_internal.hpp"

@@ -18,7 +18,13 @@ namespace xlp {
 
 static thread_local std::string g_err;
 static Ctx g_ctx;
-static std::mutex g_mu;
+// One lock for the whole C ABI.  Every entry point below takes it: the context (stream, grow-only scratch slots, the twiddle-table map, the
+// device-copy cache) is shared state, and the reference calls this boundary from inside OpenMP regions (FRIProve::prove runs
+// NTT_Goldilocks(nX, 1).INTT per group on all threads, friProve.cpp:44-108).  All work goes to one HIP stream anyway, so serialising the
+// callers costs nothing the GPU would have overlapped.  Recursive, because entry points call each other (xlp_perm -> xlp_perm_batch,
+// the staging copies, ensure_init -> xlp_init).  xlp_last_error() is per thread and takes no lock.
+static std::recursive_mutex g_mu;
+#define XLP_ENTER std::lock_guard<std::recursive_mutex> xlp_api_lock(g_mu)
 
 int xlp_fail(const char* msg)
 {
@@ -69,6 +75,36 @@ struct DevBuf {
     u64* u() { return (u64*)p; }
 };
 
+// Events of one pipelined call: all destroyed when the call returns, whichever way it returns.
+struct EventPool {
+    std::vector<hipEvent_t> all;
+    ~EventPool() { for (hipEvent_t e : all) (void)hipEventDestroy(e); }
+    int make(hipEvent_t* out, bool timing = false)
+    {
+        hipEvent_t e = nullptr;
+        if (timing) XLP_HIP(hipEventCreate(&e)); else XLP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        all.push_back(e);
+        *out = e;
+        return 0;
+    }
+    // record on `from`; `to` (if any) waits for it
+    int mark(hipStream_t from, hipStream_t to, hipEvent_t* out = nullptr)
+    {
+        hipEvent_t e;
+        if (make(&e)) return -1;
+        XLP_HIP(hipEventRecord(e, from));
+        if (to) XLP_HIP(hipStreamWaitEvent(to, e, 0));
+        if (out) *out = e;
+        return 0;
+    }
+};
+// A device allocation that is either handed on (release) or freed on return.
+struct DevOwner {
+    void* p = nullptr;
+    ~DevOwner() { if (p) (void)hipFree(p); }
+    void* release() { void* q = p; p = nullptr; return q; }
+};
+
 // ---- device copies of host buffers (see xlp_cache_enable below)
 struct CacheEnt { const char* host; size_t bytes; void* dev; uint64_t tick; };
 std::vector<CacheEnt> g_cache;
@@ -87,12 +123,6 @@ void cache_drop_overlapping(const void* host, size_t bytes)
     for (size_t i = g_cache.size(); i-- > 0;)
         if (a < g_cache[i].host + g_cache[i].bytes && g_cache[i].host < a + bytes) cache_drop(i);
 }
-void* cache_find(const void* host, size_t bytes)
-{
-    for (CacheEnt& e : g_cache)
-        if (e.host == (const char*)host && e.bytes == bytes) { e.tick = ++g_cache_tick; return e.dev; }
-    return nullptr;
-}
 // takes ownership of dev (frees it when the cache is off or too small for it)
 void cache_put(const void* host, size_t bytes, void* dev)
 {
@@ -105,18 +135,6 @@ void cache_put(const void* host, size_t bytes, void* dev)
     }
     g_cache.push_back({(const char*)host, bytes, dev, ++g_cache_tick});
     g_cache_used += bytes;
-}
-// a device buffer for the host range: the cached copy, or a fresh allocation (uploaded unless `upload` is false)
-int cache_get(const void* host, size_t bytes, bool upload, void** dev, bool* was_cached)
-{
-    *dev = cache_find(host, bytes);
-    *was_cached = *dev != nullptr;
-    if (*dev) return 0;
-    XLP_HIP(hipMalloc(dev, bytes ? bytes : 8));
-    if (upload && bytes) {
-        XLP_HIP(hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, g_ctx.stream));
-    }
-    return 0;
 }
 // detach the cached copy of exactly this range (the caller becomes the owner), if any
 void* cache_take(const void* host, size_t bytes)
@@ -146,7 +164,7 @@ const char* xlp_last_error(void) { return g_err.c_str(); }
 
 int xlp_init(int device)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    XLP_ENTER;
     if (g_ctx.inited && g_ctx.device == device) return 0;
     if (g_ctx.inited) return xlp_fail("xlp_init: already bound to another device");
     int n = 0;
@@ -159,7 +177,6 @@ int xlp_init(int device)
     g_ctx.device = device;
     g_ctx.ncu = (u32)prop.multiProcessorCount / 8 * 8;
     if (g_ctx.ncu == 0) g_ctx.ncu = 8;
-    if (const char* ev = getenv("XLP_LDE_PERSIST")) g_ctx.lde_persist = (u32)strtoul(ev, nullptr, 10) & 7u;
     XLP_HIP(hipStreamCreateWithFlags(&g_ctx.stream, hipStreamNonBlocking));
     g_ctx.own_stream = true;
     if (ntt_init(&g_ctx)) return -1;
@@ -170,6 +187,7 @@ int xlp_init(int device)
 
 int xlp_set_stream(void* hip_stream)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     XLP_HIP(hipStreamSynchronize(g_ctx.stream));
     if (g_ctx.own_stream) { XLP_HIP(hipStreamDestroy(g_ctx.stream)); g_ctx.own_stream = false; }
@@ -179,6 +197,7 @@ int xlp_set_stream(void* hip_stream)
 
 int xlp_sync(void)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     XLP_HIP(hipStreamSynchronize(g_ctx.stream));
     return 0;
@@ -186,7 +205,7 @@ int xlp_sync(void)
 
 void xlp_shutdown(void)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
+    XLP_ENTER;
     if (!g_ctx.inited) return;
     (void)hipStreamSynchronize(g_ctx.stream);
     for (auto& kv : g_ctx.tables) (void)hipFree(kv.second);
@@ -202,6 +221,7 @@ void xlp_shutdown(void)
     if (g_ctx.down_stream) { (void)hipStreamSynchronize(g_ctx.down_stream); (void)hipStreamDestroy(g_ctx.down_stream); g_ctx.down_stream = nullptr; }
     while (!g_cache.empty()) cache_drop(0);
     g_cache_cap = 0;
+    bn128_shutdown();
     g_ctx.stream = nullptr;
     g_ctx.own_stream = false;
     g_ctx.inited = false;
@@ -210,85 +230,101 @@ void xlp_shutdown(void)
 // ------------------------------------------------------------- device layer
 int xlp_dev_ntt(uint64_t* dst, const uint64_t* src, uint64_t n, uint64_t ncols, int inverse)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     return dev_ntt(&g_ctx, dst, src, n, ncols, inverse);
 }
 int xlp_dev_extend(uint64_t* out, const uint64_t* in, uint64_t n_ext, uint64_t n, uint64_t ncols, uint64_t* scratch)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     return dev_extend(&g_ctx, out, in, n_ext, n, ncols, scratch);
 }
 int xlp_dev_merkle(uint64_t* nodes, const uint64_t* src, uint64_t w, uint64_t h)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     return dev_merkle(&g_ctx, nodes, src, w, h);
 }
 int xlp_dev_perm_batch(uint64_t* out, const uint64_t* in, uint64_t count)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     return dev_perm(&g_ctx, out, in, count);
 }
 int xlp_dev_linear_hash(uint64_t* out, const uint64_t* src, uint64_t w, uint64_t h)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     return dev_linear_hash(&g_ctx, out, src, w, h);
 }
 int xlp_dev_fri_fold(uint64_t* pol2, const uint64_t* pol, uint32_t bits, uint32_t red, const uint64_t x[3], uint64_t shift_inv)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     return dev_fri_fold(&g_ctx, pol2, pol, bits, red, x, shift_inv);
 }
 int xlp_dev_transpose3(uint64_t* dst, const uint64_t* src, uint64_t n, uint32_t tbits)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     return dev_transpose3(&g_ctx, dst, src, n, tbits);
 }
 int xlp_dev_fill(uint64_t* dst, uint64_t n, uint64_t seed, uint64_t start)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     return dev_fill(&g_ctx, dst, n, seed, start);
 }
 
 int xlp_dev_batch_inverse(uint64_t* res, const uint64_t* src, uint64_t n, uint32_t dim)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     return dev_batch_inverse(&g_ctx, res, src, n, dim);
 }
 int xlp_dev_calculate_z(uint64_t* z, const uint64_t* num, const uint64_t* den, uint64_t n)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     return dev_calculate_z(&g_ctx, z, 3, num, 3, den, 3, n);
 }
 int xlp_dev_calculate_z_strided(uint64_t* z, uint64_t z_stride, const uint64_t* num, uint64_t num_stride, const uint64_t* den, uint64_t den_stride, uint64_t n)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     return dev_calculate_z(&g_ctx, z, z_stride, num, num_stride, den, den_stride, n);
 }
 int xlp_dev_calculate_h1h2(uint64_t* h1, uint64_t* h2, const uint64_t* f, const uint64_t* t, uint64_t n, uint32_t dim)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     return dev_calculate_h1h2(&g_ctx, h1, dim, h2, dim, f, dim, t, dim, n, dim);
 }
 int xlp_dev_calculate_h1h2_strided(uint64_t* h1, uint64_t h1_stride, uint64_t* h2, uint64_t h2_stride, const uint64_t* f, uint64_t f_stride,
                                    const uint64_t* t, uint64_t t_stride, uint64_t n, uint32_t dim)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     return dev_calculate_h1h2(&g_ctx, h1, h1_stride, h2, h2_stride, f, f_stride, t, t_stride, n, dim);
 }
 int xlp_expr_create(xlp_expr_program** out, const uint64_t* code, uint64_t ncode, uint64_t ntmp1, uint64_t ntmp3)
 {
+    XLP_ENTER;
     return expr_create(out, code, ncode, ntmp1, ntmp3);      // host-only: validation + compilation to the device form
 }
-int xlp_expr_destroy(xlp_expr_program* prog) { return expr_destroy(prog); }
-int xlp_expr_codegen(const xlp_expr_program* prog, const char* path) { return expr_codegen(prog, path); }
-int xlp_expr_attach(xlp_expr_program* prog, const char* path) { return expr_attach(prog, path); }
+int xlp_expr_destroy(xlp_expr_program* prog) { XLP_ENTER; return expr_destroy(prog); }
+int xlp_expr_codegen(const xlp_expr_program* prog, const char* path) { XLP_ENTER; return expr_codegen(prog, path); }
+int xlp_expr_attach(xlp_expr_program* prog, const char* path) { XLP_ENTER; return expr_attach(prog, path); }
 int xlp_dev_expr_run(const xlp_expr_program* prog, const xlp_steps_params* params, uint64_t row0, uint64_t nrows)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     return dev_expr_run(&g_ctx, prog, params, row0, nrows);
 }
 int xlp_dev_merkle_proofs(uint64_t* out, const uint64_t* src, const uint64_t* nodes, uint64_t w, uint64_t h, const uint64_t* idxs, uint64_t nq)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (nq == 0) return 0;
     if (!out || !nodes || !idxs || (w && !src)) return xlp_fail("xlp_dev_merkle_proofs: null pointer");
@@ -306,27 +342,32 @@ int xlp_dev_merkle_proofs(uint64_t* out, const uint64_t* src, const uint64_t* no
 }
 int xlp_dev_gather_rows(uint64_t* dst, const uint64_t* src, uint64_t src_stride, uint64_t n, uint32_t dim, uint64_t seed)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     return dev_gather_rows(&g_ctx, dst, src, src_stride, n, dim, seed);
 }
 int xlp_dev_copy_cols(uint64_t* dst, uint64_t dst_stride, const uint64_t* src, uint64_t src_stride, uint64_t n, uint32_t dim)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     return dev_copy_cols(&g_ctx, dst, dst_stride, src, src_stride, n, dim);
 }
 int xlp_dev_q_split(uint64_t* qq2, const uint64_t* qq1, uint64_t n, uint64_t n_ext, uint32_t q_deg, uint32_t q_dim, uint64_t shift_in)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     return dev_q_split(&g_ctx, qq2, qq1, n, n_ext, q_deg, q_dim, shift_in);
 }
 int xlp_dev_geometric(uint64_t* out, uint64_t n, uint32_t dim, const uint64_t* first, const uint64_t* ratio)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (!first || !ratio) return xlp_fail("xlp_dev_geometric: null first / ratio");
     return dev_geometric(&g_ctx, out, n, dim, first, ratio);
 }
 int xlp_dev_x_div_x_sub_xi(uint64_t* out, const uint64_t* x, const uint64_t* xi, uint64_t n)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (!xi) return xlp_fail("xlp_dev_x_div_x_sub_xi: null xi");
     return dev_x_div_x_sub_xi(&g_ctx, out, x, xi, n);
@@ -334,6 +375,7 @@ int xlp_dev_x_div_x_sub_xi(uint64_t* out, const uint64_t* x, const uint64_t* xi,
 int xlp_dev_dot_columns(uint64_t* out, const xlp_dot_entry* entries, uint64_t nentries, uint32_t ngroups,
                         const uint64_t* coefs, uint64_t coefs_size, uint64_t nrows)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (!nrows || !ngroups) return 0;
     if (!out || (nentries && (!entries || !coefs))) return xlp_fail("xlp_dev_dot_columns: null pointer");
@@ -343,6 +385,7 @@ int xlp_dev_dot_columns(uint64_t* out, const xlp_dot_entry* entries, uint64_t ne
 int xlp_dev_evmap(uint64_t* evals, const uint64_t* LEv, const uint64_t* LpEv, uint64_t n, uint32_t extend_bits, uint32_t nev,
                   const xlp_evmap_entry* entries)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (nev && !entries) return xlp_fail("xlp_dev_evmap: null entries");
     return dev_evmap(&g_ctx, evals, LEv, LpEv, n, extend_bits, nev, entries);
@@ -350,6 +393,7 @@ int xlp_dev_evmap(uint64_t* evals, const uint64_t* LEv, const uint64_t* LpEv, ui
 
 int xlp_profile_enable(int on)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     XLP_HIP(hipStreamSynchronize(g_ctx.stream));
     for (hipEvent_t e : g_ctx.prof_events) (void)hipEventDestroy(e);
@@ -358,15 +402,9 @@ int xlp_profile_enable(int on)
     return 0;
 }
 
-int xlp_tune(const char* key, long value)
-{
-    if (ensure_init()) return -1;
-    if (key && !strcmp(key, "lde_persist")) { g_ctx.lde_persist = (u32)value & 7u; return 0; }
-    return xlp_fail("xlp_tune: unknown key");
-}
-
 int xlp_profile_read(double ms_sum[3], uint64_t* count)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     XLP_HIP(hipStreamSynchronize(g_ctx.stream));
     ms_sum[0] = ms_sum[1] = ms_sum[2] = 0;
@@ -383,18 +421,21 @@ int xlp_profile_read(double ms_sum[3], uint64_t* count)
 
 int xlp_dev_alloc(void** ptr, size_t bytes)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     XLP_HIP(hipMalloc(ptr, bytes ? bytes : 8));
     return 0;
 }
 int xlp_dev_free(void* ptr)
 {
+    XLP_ENTER;
     if (!ptr) return 0;
     XLP_HIP(hipFree(ptr));
     return 0;
 }
 int xlp_dev_memset(void* dst_dev, int value, size_t bytes)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (!bytes) return 0;
     XLP_HIP(hipMemsetAsync(dst_dev, value, bytes, g_ctx.stream));
@@ -402,6 +443,7 @@ int xlp_dev_memset(void* dst_dev, int value, size_t bytes)
 }
 int xlp_copy_h2d(void* dst_dev, const void* src_host, size_t bytes)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (!bytes) return 0;
     XLP_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, g_ctx.stream));
@@ -410,8 +452,12 @@ int xlp_copy_h2d(void* dst_dev, const void* src_host, size_t bytes)
 }
 int xlp_copy_d2h(void* dst_host, const void* src_dev, size_t bytes)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (!bytes) return 0;
+    // the host range is rewritten: device copies of it kept by the host-pointer cache (xlp_cache_enable) are stale from here on.  Every
+    // host-pointer entry point returns its results through this function (the D2H macro), so none of them can leave a stale copy behind.
+    cache_drop_overlapping(dst_host, bytes);
     XLP_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, g_ctx.stream));
     XLP_HIP(hipStreamSynchronize(g_ctx.stream));
     return 0;
@@ -419,18 +465,21 @@ int xlp_copy_d2h(void* dst_host, const void* src_dev, size_t bytes)
 
 int xlp_host_alloc(void** ptr, size_t bytes)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     XLP_HIP(hipHostMalloc(ptr, bytes ? bytes : 8, hipHostMallocDefault));
     return 0;
 }
 int xlp_host_free(void* ptr)
 {
+    XLP_ENTER;
     if (!ptr) return 0;
     XLP_HIP(hipHostFree(ptr));
     return 0;
 }
 int xlp_host_register(void* ptr, size_t bytes)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (!ptr || !bytes) return xlp_fail("xlp_host_register: empty range");
     XLP_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
@@ -438,6 +487,7 @@ int xlp_host_register(void* ptr, size_t bytes)
 }
 int xlp_host_unregister(void* ptr)
 {
+    XLP_ENTER;
     if (!ptr) return 0;
     XLP_HIP(hipHostUnregister(ptr));
     return 0;
@@ -445,16 +495,19 @@ int xlp_host_unregister(void* ptr)
 
 int xlp_dev_extend_cols(uint64_t* out, const uint64_t* in, uint64_t n_ext, uint64_t n, uint64_t ld, uint64_t col0, uint64_t ncols)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     return dev_extend_cols(&g_ctx, out, in, n_ext, n, ld, col0, ncols);
 }
 int xlp_dev_linear_hash_absorb(uint64_t* state, const uint64_t* src, uint64_t ld, uint64_t col0, uint64_t ncols, uint64_t h, int first, int last)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     return dev_linear_hash_absorb(&g_ctx, state, src, ld, col0, ncols, h, first, last);
 }
 int xlp_dev_merkle_levels(uint64_t* nodes, uint64_t h)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     return dev_merkle_levels(&g_ctx, nodes, h);
 }
@@ -478,54 +531,49 @@ static int commit_bands(uint64_t* sec_n, uint64_t* sec_2ns, uint64_t* nodes, con
         return dev_merkle(ctx, nodes, sec_2ns, ncols, n_ext);
     }
     const u64 nb = (ncols + band - 1) / band;
-    std::vector<hipEvent_t> ev;
+    EventPool pool;
+    std::vector<hipEvent_t> ev(nb, nullptr);
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (h_src) {
         if (!ctx->copy_stream) XLP_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
         // the copies may not start before earlier work on the compute stream (a previous proof still reading sec_n) is done
-        hipEvent_t start;
-        XLP_HIP(hipEventCreateWithFlags(&start, hipEventDisableTiming));
-        XLP_HIP(hipEventRecord(start, ctx->stream));
-        XLP_HIP(hipStreamWaitEvent(ctx->copy_stream, start, 0));
-        XLP_HIP(hipEventDestroy(start));
-        if (upload_ms) { XLP_HIP(hipEventCreate(&t0)); XLP_HIP(hipEventCreate(&t1)); XLP_HIP(hipEventRecord(t0, ctx->copy_stream)); }
-        ev.resize(nb);
+        if (pool.mark(ctx->stream, ctx->copy_stream)) return -1;
+        if (upload_ms) {
+            if (pool.make(&t0, true) || pool.make(&t1, true)) return -1;
+            XLP_HIP(hipEventRecord(t0, ctx->copy_stream));
+        }
         for (u64 b = 0; b < nb; b++) {
             const u64 c0 = b * band, wc = ncols - c0 < band ? ncols - c0 : band;
             XLP_HIP(hipMemcpy2DAsync(sec_n + c0, ncols * sizeof(u64), h_src + c0, ncols * sizeof(u64), wc * sizeof(u64), n, hipMemcpyHostToDevice, ctx->copy_stream));
-            XLP_HIP(hipEventCreateWithFlags(&ev[b], hipEventDisableTiming));
-            XLP_HIP(hipEventRecord(ev[b], ctx->copy_stream));
+            if (pool.mark(ctx->copy_stream, nullptr, &ev[b])) return -1;
         }
         if (upload_ms) XLP_HIP(hipEventRecord(t1, ctx->copy_stream));
     }
-    int rc = 0;
-    for (u64 b = 0; b < nb && !rc; b++) {
+    for (u64 b = 0; b < nb; b++) {
         const u64 c0 = b * band, wc = ncols - c0 < band ? ncols - c0 : band;
         if (h_src) XLP_HIP(hipStreamWaitEvent(ctx->stream, ev[b], 0));
-        rc = dev_extend_cols(ctx, sec_2ns, sec_n, n_ext, n, ncols, c0, wc);
-        if (!rc) rc = dev_linear_hash_absorb(ctx, nodes, sec_2ns, ncols, c0, wc, n_ext, b == 0, b == nb - 1);
+        if (dev_extend_cols(ctx, sec_2ns, sec_n, n_ext, n, ncols, c0, wc)) return -1;
+        if (dev_linear_hash_absorb(ctx, nodes, sec_2ns, ncols, c0, wc, n_ext, b == 0, b == nb - 1)) return -1;
     }
-    if (!rc) rc = dev_merkle_levels(ctx, nodes, n_ext);
-    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    if (dev_merkle_levels(ctx, nodes, n_ext)) return -1;
     if (t0) {
-        if (!rc) {
-            float ms = 0.f;
-            XLP_HIP(hipEventSynchronize(t1));
-            XLP_HIP(hipEventElapsedTime(&ms, t0, t1));
-            *upload_ms = ms;
-        }
-        (void)hipEventDestroy(t0); (void)hipEventDestroy(t1);
+        float ms = 0.f;
+        XLP_HIP(hipEventSynchronize(t1));
+        XLP_HIP(hipEventElapsedTime(&ms, t0, t1));
+        *upload_ms = ms;
     }
-    return rc;
+    return 0;
 }
 int xlp_dev_commit_from_host(uint64_t* sec_n, uint64_t* sec_2ns, uint64_t* nodes, const uint64_t* h_src, uint64_t n_ext, uint64_t n, uint64_t ncols, double* upload_ms)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (ncols && n && !h_src) return xlp_fail("xlp_dev_commit_from_host: null host pointer");
     return commit_bands(sec_n, sec_2ns, nodes, h_src, n_ext, n, ncols, upload_ms);
 }
 int xlp_dev_commit(uint64_t* sec_2ns, uint64_t* nodes, const uint64_t* sec_n, uint64_t n_ext, uint64_t n, uint64_t ncols)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     return commit_bands(const_cast<uint64_t*>(sec_n), sec_2ns, nodes, nullptr, n_ext, n, ncols, nullptr);
 }
@@ -534,6 +582,7 @@ int xlp_dev_commit(uint64_t* sec_2ns, uint64_t* nodes, const uint64_t* sec_n, ui
 
 int xlp_ntt(uint64_t* dst, const uint64_t* src, uint64_t n, uint64_t ncols, int inverse)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (n == 0 || ncols == 0) return 0;
     if (!dst || !src) return xlp_fail("xlp_ntt: null pointer");
@@ -556,6 +605,7 @@ int xlp_ntt(uint64_t* dst, const uint64_t* src, uint64_t n, uint64_t ncols, int 
 
 int xlp_cache_enable(size_t max_bytes)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     XLP_HIP(hipStreamSynchronize(g_ctx.stream));
     g_cache_cap = max_bytes;
@@ -564,18 +614,20 @@ int xlp_cache_enable(size_t max_bytes)
 }
 int xlp_cache_invalidate(const void* host_ptr, size_t bytes)
 {
+    XLP_ENTER;
     if (!g_ctx.inited) return 0;
     XLP_HIP(hipStreamSynchronize(g_ctx.stream));
     if (!host_ptr) { while (!g_cache.empty()) cache_drop(0); return 0; }
     cache_drop_overlapping(host_ptr, bytes ? bytes : 1);
     return 0;
 }
-size_t xlp_cache_bytes(void) { return g_cache_used; }
+size_t xlp_cache_bytes(void) { XLP_ENTER; return g_cache_used; }
 
 // extendPol on host buffers, as a three-stream pipeline over 64-column bands: band b+1 is uploaded (copy stream) while band b is
 // extended (compute stream) and band b-1 of the result goes back to the host (download stream; PCIe is full duplex).
 int xlp_extend(uint64_t* out, const uint64_t* in, uint64_t n_ext, uint64_t n, uint64_t ncols, uint64_t* scratch)
 {
+    XLP_ENTER;
     (void)scratch;
     if (ensure_init()) return -1;
     if (n == 0 || ncols == 0) return 0;
@@ -583,108 +635,107 @@ int xlp_extend(uint64_t* out, const uint64_t* in, uint64_t n_ext, uint64_t n, ui
     if ((n & (n - 1)) || (n_ext & (n_ext - 1)) || n_ext < n) return xlp_fail("extendPol: sizes must be powers of two, n_ext >= n");
     Ctx* ctx = &g_ctx;
     const size_t in_bytes = n * ncols * sizeof(u64), out_bytes = n_ext * ncols * sizeof(u64);
-    void* d_in = cache_take(in, in_bytes);
-    const bool in_cached = d_in != nullptr;
+    // the buffers belong to this call until it succeeds (then the cache takes them, or frees them when it is off); on any failure they
+    // are freed -- a cached input copy included: it may have been half overwritten
+    DevOwner d_in, d_out;
+    d_in.p = cache_take(in, in_bytes);
+    const bool in_cached = d_in.p != nullptr;
     cache_drop_overlapping(out, out_bytes);
-    void* d_out = nullptr;
-    if (!d_in) XLP_HIP(hipMalloc(&d_in, in_bytes));
-    if (hipMalloc(&d_out, out_bytes) != hipSuccess) { (void)hipFree(d_in); return xlp_fail("xlp_extend: out of device memory"); }
+    if (!d_in.p) XLP_HIP(hipMalloc(&d_in.p, in_bytes));
+    if (hipMalloc(&d_out.p, out_bytes) != hipSuccess) return xlp_fail("xlp_extend: out of device memory");
     const u64 band = 64;
-    int rc = 0;
     if (ncols <= band || n_ext * ncols < (1ull << 22)) {       // small: no pipeline
-        if (!in_cached) rc = hipMemcpyAsync(d_in, in, in_bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess ? 0 : xlp_fail("xlp_extend: upload failed");
-        if (!rc) rc = dev_extend(ctx, (u64*)d_out, (const u64*)d_in, n_ext, n, ncols, nullptr);
-        if (!rc) rc = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess ? 0 : xlp_fail("xlp_extend: download failed");
-        if (!rc) rc = hipStreamSynchronize(ctx->stream) == hipSuccess ? 0 : xlp_fail("xlp_extend: synchronise failed");
+        if (!in_cached) XLP_HIP(hipMemcpyAsync(d_in.p, in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+        if (dev_extend(ctx, (u64*)d_out.p, (const u64*)d_in.p, n_ext, n, ncols, nullptr)) return -1;
+        XLP_HIP(hipMemcpyAsync(out, d_out.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        XLP_HIP(hipStreamSynchronize(ctx->stream));
     } else {
         if (!ctx->copy_stream) XLP_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
         if (!ctx->down_stream) XLP_HIP(hipStreamCreateWithFlags(&ctx->down_stream, hipStreamNonBlocking));
         XLP_HIP(hipStreamSynchronize(ctx->stream));
         const u64 nb = (ncols + band - 1) / band;
-        std::vector<hipEvent_t> up(nb, nullptr), done(nb, nullptr);
-        for (u64 b = 0; b < nb && !rc; b++) {
+        EventPool pool;
+        std::vector<hipEvent_t> up(nb, nullptr);
+        int rc = 0;
+        for (u64 b = 0; b < nb && !rc && !in_cached; b++) {
             const u64 c0 = b * band, wc = ncols - c0 < band ? ncols - c0 : band;
-            if (!in_cached) {
-                if (hipMemcpy2DAsync((u64*)d_in + c0, ncols * 8, in + c0, ncols * 8, wc * 8, n, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess) rc = xlp_fail("xlp_extend: upload failed");
-                (void)hipEventCreateWithFlags(&up[b], hipEventDisableTiming);
-                (void)hipEventRecord(up[b], ctx->copy_stream);
-            }
+            if (hipMemcpy2DAsync((u64*)d_in.p + c0, ncols * 8, in + c0, ncols * 8, wc * 8, n, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess) rc = xlp_fail("xlp_extend: upload failed");
+            if (!rc) rc = pool.mark(ctx->copy_stream, nullptr, &up[b]);
         }
         for (u64 b = 0; b < nb && !rc; b++) {
             const u64 c0 = b * band, wc = ncols - c0 < band ? ncols - c0 : band;
-            if (up[b]) (void)hipStreamWaitEvent(ctx->stream, up[b], 0);
-            rc = dev_extend_cols(ctx, (u64*)d_out, (const u64*)d_in, n_ext, n, ncols, c0, wc);
-            (void)hipEventCreateWithFlags(&done[b], hipEventDisableTiming);
-            (void)hipEventRecord(done[b], ctx->stream);
-            (void)hipStreamWaitEvent(ctx->down_stream, done[b], 0);
-            if (!rc && hipMemcpy2DAsync(out + c0, ncols * 8, (u64*)d_out + c0, ncols * 8, wc * 8, n_ext, hipMemcpyDeviceToHost, ctx->down_stream) != hipSuccess) rc = xlp_fail("xlp_extend: download failed");
+            if (up[b] && hipStreamWaitEvent(ctx->stream, up[b], 0) != hipSuccess) rc = xlp_fail("xlp_extend: stream wait failed");
+            if (!rc) rc = dev_extend_cols(ctx, (u64*)d_out.p, (const u64*)d_in.p, n_ext, n, ncols, c0, wc);
+            if (!rc) rc = pool.mark(ctx->stream, ctx->down_stream);          // the band's download starts when its kernels are done
+            if (!rc && hipMemcpy2DAsync(out + c0, ncols * 8, (u64*)d_out.p + c0, ncols * 8, wc * 8, n_ext, hipMemcpyDeviceToHost, ctx->down_stream) != hipSuccess) rc = xlp_fail("xlp_extend: download failed");
         }
+        // nothing of this call may still be in flight when the buffers are released, failed or not
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamSynchronize(ctx->stream);
         if (hipStreamSynchronize(ctx->down_stream) != hipSuccess && !rc) rc = xlp_fail("xlp_extend: download failed");
-        for (hipEvent_t e : up) if (e) (void)hipEventDestroy(e);
-        for (hipEvent_t e : done) if (e) (void)hipEventDestroy(e);
+        if (rc) return rc;
     }
-    if (rc) { (void)hipFree(d_in); (void)hipFree(d_out); return rc; }
-    cache_put(in, in_bytes, d_in);                             // (frees them when the cache is off)
-    cache_put(out, out_bytes, d_out);
+    cache_put(in, in_bytes, d_in.release());                   // (frees them when the cache is off)
+    cache_put(out, out_bytes, d_out.release());
     return 0;
 }
 
 int xlp_merkle(uint64_t* nodes, const uint64_t* src, uint64_t w, uint64_t h)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (h == 0) return 0;
     if (!nodes || (w && !src)) return xlp_fail("xlp_merkle: null pointer");
     if (h & (h - 1)) return xlp_fail("merkletree: number of rows is not a power of two");
     Ctx* ctx = &g_ctx;
     const size_t src_bytes = w * h * sizeof(u64), node_bytes = (2 * h - 1) * 4 * sizeof(u64);
-    void* d_src = w ? cache_take(src, src_bytes) : nullptr;
-    const bool cached = d_src != nullptr;
+    DevOwner d_src;                                            // this call's until it succeeds; then the cache's (or freed)
+    d_src.p = w ? cache_take(src, src_bytes) : nullptr;
+    const bool cached = d_src.p != nullptr;
     cache_drop_overlapping(nodes, node_bytes);
     DevBuf b;
-    if (b.alloc(node_bytes)) { if (d_src) cache_put(src, src_bytes, d_src); return -1; }
+    if (b.alloc(node_bytes)) { if (d_src.p) cache_put(src, src_bytes, d_src.release()); return -1; }
     int rc = 0;
     if (!cached && w) {
-        XLP_HIP(hipMalloc(&d_src, src_bytes));
+        XLP_HIP(hipMalloc(&d_src.p, src_bytes));
         // rows are hashed independently: upload row chunks on the copy stream while the previous chunk is hashed
         const u64 chunk_rows = w > 4 && src_bytes > (256ull << 20) ? std::max<u64>(1, (128ull << 20) / (w * 8)) : h;
         if (chunk_rows >= h) {
-            if (hipMemcpyAsync(d_src, src, src_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = xlp_fail("xlp_merkle: upload failed");
-            if (!rc) rc = dev_linear_hash(ctx, b.u(), (const u64*)d_src, w, h);
+            XLP_HIP(hipMemcpyAsync(d_src.p, src, src_bytes, hipMemcpyHostToDevice, ctx->stream));
+            rc = dev_linear_hash(ctx, b.u(), (const u64*)d_src.p, w, h);
         } else {
             if (!ctx->copy_stream) XLP_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
             XLP_HIP(hipStreamSynchronize(ctx->stream));
+            EventPool pool;
             std::vector<hipEvent_t> ev;
             for (u64 r0 = 0; r0 < h && !rc; r0 += chunk_rows) {
                 const u64 nr = h - r0 < chunk_rows ? h - r0 : chunk_rows;
-                if (hipMemcpyAsync((u64*)d_src + r0 * w, src + r0 * w, nr * w * 8, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess) rc = xlp_fail("xlp_merkle: upload failed");
-                hipEvent_t e;
-                (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-                (void)hipEventRecord(e, ctx->copy_stream);
+                if (hipMemcpyAsync((u64*)d_src.p + r0 * w, src + r0 * w, nr * w * 8, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess) rc = xlp_fail("xlp_merkle: upload failed");
+                hipEvent_t e = nullptr;
+                if (!rc) rc = pool.mark(ctx->copy_stream, nullptr, &e);
                 ev.push_back(e);
             }
             u64 k = 0;
             for (u64 r0 = 0; r0 < h && !rc; r0 += chunk_rows, k++) {
                 const u64 nr = h - r0 < chunk_rows ? h - r0 : chunk_rows;
-                (void)hipStreamWaitEvent(ctx->stream, ev[k], 0);
-                rc = dev_linear_hash(ctx, b.u() + 4 * r0, (const u64*)d_src + r0 * w, w, nr);
+                if (hipStreamWaitEvent(ctx->stream, ev[k], 0) != hipSuccess) rc = xlp_fail("xlp_merkle: stream wait failed");
+                if (!rc) rc = dev_linear_hash(ctx, b.u() + 4 * r0, (const u64*)d_src.p + r0 * w, w, nr);
             }
-            (void)hipStreamSynchronize(ctx->copy_stream);
-            for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+            (void)hipStreamSynchronize(ctx->copy_stream);      // no copy into d_src may outlive this call
         }
     } else {
-        rc = dev_linear_hash(ctx, b.u(), (const u64*)d_src, w, h);
+        rc = dev_linear_hash(ctx, b.u(), (const u64*)d_src.p, w, h);
     }
     if (!rc) rc = dev_merkle_levels(ctx, b.u(), h);
     if (!rc && hipMemcpyAsync(nodes, b.p, node_bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = xlp_fail("xlp_merkle: download failed");
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && !rc) rc = xlp_fail("xlp_merkle: synchronise failed");
-    if (d_src) { if (rc) (void)hipFree(d_src); else cache_put(src, src_bytes, d_src); }
+    if (d_src.p && !rc) cache_put(src, src_bytes, d_src.release());
     return rc;
 }
 
 int xlp_perm_batch(uint64_t* out, const uint64_t* in, uint64_t count)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (count == 0) return 0;
     if (!out || !in) return xlp_fail("xlp_perm: null pointer");
@@ -693,6 +744,7 @@ int xlp_perm_batch(uint64_t* out, const uint64_t* in, uint64_t count)
         if (ctx_scratch(&g_ctx, 2 * 64 * 12 * sizeof(u64), 6, &d)) return -1;
         XLP_HIP(hipMemcpyAsync(d, in, count * 12 * sizeof(u64), hipMemcpyHostToDevice, g_ctx.stream));
         if (dev_perm(&g_ctx, d + 64 * 12, d, count)) return -1;
+        cache_drop_overlapping(out, count * 12 * sizeof(u64));
         XLP_HIP(hipMemcpyAsync(out, d + 64 * 12, count * 12 * sizeof(u64), hipMemcpyDeviceToHost, g_ctx.stream));
         XLP_HIP(hipStreamSynchronize(g_ctx.stream));
         return 0;
@@ -709,18 +761,21 @@ int xlp_perm(uint64_t out[12], const uint64_t in[12]) { return xlp_perm_batch(ou
 // ---- BN128 (StarkRecursiveF)
 int xlp_bn128_init(const char* constants_path)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     return bn128_init(&g_ctx, constants_path);
 }
 uint64_t xlp_merkle_bn128_num_nodes(uint64_t height) { return bn128_num_nodes(height); }
 int xlp_dev_merkle_bn128(uint64_t* nodes, const uint64_t* src, uint64_t w, uint64_t h)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (h && (!nodes || (!src && w))) return xlp_fail("xlp_dev_merkle_bn128: null pointer");
     return dev_merkle_bn128(&g_ctx, nodes, src, w, h);
 }
 int xlp_merkle_bn128(uint64_t* nodes, const uint64_t* src, uint64_t w, uint64_t h)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (h == 0) return 0;
     if (!nodes || (!src && w)) return xlp_fail("xlp_merkle_bn128: null pointer");
@@ -734,12 +789,14 @@ int xlp_merkle_bn128(uint64_t* nodes, const uint64_t* src, uint64_t w, uint64_t 
 }
 int xlp_dev_poseidon_bn128(uint64_t* states, uint32_t t, uint64_t count)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (count && !states) return xlp_fail("xlp_dev_poseidon_bn128: null pointer");
     return dev_poseidon_bn128(&g_ctx, states, t, count);
 }
 int xlp_poseidon_bn128(uint64_t* states, uint32_t t, uint64_t count)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (count == 0) return 0;
     if (!states) return xlp_fail("xlp_poseidon_bn128: null pointer");
@@ -754,6 +811,7 @@ int xlp_poseidon_bn128(uint64_t* states, uint32_t t, uint64_t count)
 
 int xlp_dev_merkle_bn128_proofs(uint64_t* out, const uint64_t* src, const uint64_t* nodes, uint64_t w, uint64_t h, const uint64_t* idxs, uint64_t nq)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (nq == 0) return 0;
     if (!out || !nodes || !idxs || (w && !src)) return xlp_fail("xlp_dev_merkle_bn128_proofs: null pointer");
@@ -771,12 +829,14 @@ int xlp_dev_merkle_bn128_proofs(uint64_t* out, const uint64_t* src, const uint64
 }
 int xlp_dev_fft_bn254(uint64_t* data, uint64_t n, int inverse)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (n && !data) return xlp_fail("xlp_dev_fft_bn254: null pointer");
     return dev_fft_bn254(&g_ctx, data, n, inverse);
 }
 int xlp_fft_bn254(uint64_t* data, uint64_t n, int inverse)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (n == 0) return 0;
     if (!data) return xlp_fail("xlp_fft_bn254: null pointer");
@@ -790,12 +850,14 @@ int xlp_fft_bn254(uint64_t* data, uint64_t n, int inverse)
 
 int xlp_dev_msm_bn254(uint64_t* out, const uint64_t* bases, const uint64_t* scalars, uint64_t n)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (!out || (n && (!bases || !scalars))) return xlp_fail("xlp_dev_msm_bn254: null pointer");
     return dev_msm_bn254(&g_ctx, out, bases, scalars, n);
 }
 int xlp_msm_bn254(uint64_t* out, const uint64_t* bases, const uint64_t* scalars, uint64_t n)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (!out || (n && (!bases || !scalars))) return xlp_fail("xlp_msm_bn254: null pointer");
     DevBuf b, s, o;
@@ -808,6 +870,7 @@ int xlp_msm_bn254(uint64_t* out, const uint64_t* bases, const uint64_t* scalars,
 
 int xlp_linear_hash(uint64_t* out, const uint64_t* src, uint64_t w, uint64_t h)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (h == 0) return 0;
     if (!out || (w && !src)) return xlp_fail("xlp_linear_hash: null pointer");
@@ -821,6 +884,7 @@ int xlp_linear_hash(uint64_t* out, const uint64_t* src, uint64_t w, uint64_t h)
 
 int xlp_fri_fold(uint64_t* pol2, const uint64_t* pol, uint32_t bits, uint32_t red, const uint64_t x[3], uint64_t shift_inv)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (!pol2 || !pol || !x) return xlp_fail("xlp_fri_fold: null pointer");
     if (red > bits) return xlp_fail("fri_fold: reduction exceeds polynomial size");
@@ -836,6 +900,7 @@ int xlp_fri_fold(uint64_t* pol2, const uint64_t* pol, uint32_t bits, uint32_t re
 
 int xlp_batch_inverse(uint64_t* res, const uint64_t* src, uint64_t n, uint32_t dim)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (n == 0) return 0;
     if (!res || !src) return xlp_fail("xlp_batch_inverse: null pointer");
@@ -850,6 +915,7 @@ int xlp_batch_inverse(uint64_t* res, const uint64_t* src, uint64_t n, uint32_t d
 }
 int xlp_calculate_z(uint64_t* z, const uint64_t* num, const uint64_t* den, uint64_t n)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (n == 0) return 0;
     if (!z || !num || !den) return xlp_fail("xlp_calculate_z: null pointer");
@@ -864,6 +930,7 @@ int xlp_calculate_z(uint64_t* z, const uint64_t* num, const uint64_t* den, uint6
 }
 int xlp_calculate_h1h2(uint64_t* h1, uint64_t* h2, const uint64_t* f, const uint64_t* t, uint64_t n, uint32_t dim)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (n == 0) return 0;
     if (!h1 || !h2 || !f || !t) return xlp_fail("xlp_calculate_h1h2: null pointer");
@@ -882,6 +949,7 @@ int xlp_calculate_h1h2(uint64_t* h1, uint64_t* h2, const uint64_t* f, const uint
 
 int xlp_field_op(uint64_t* out, const uint64_t* a, const uint64_t* b, uint64_t n, int op)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (n == 0) return 0;
     DevBuf da, db, dc;
@@ -895,6 +963,7 @@ int xlp_field_op(uint64_t* out, const uint64_t* a, const uint64_t* b, uint64_t n
 
 int xlp_transpose3(uint64_t* dst, const uint64_t* src, uint64_t n, uint32_t tbits)
 {
+    XLP_ENTER;
     if (ensure_init()) return -1;
     if (n == 0) return 0;
     if (!dst || !src) return xlp_fail("xlp_transpose3: null pointer");

@@ -50,7 +50,6 @@ struct Ctx {
     size_t scratch_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool inited = false;
     u32 ncu = 256;             // compute units of the bound device (persistent-kernel grid size)
-    u32 lde_persist = 0;       // experiment builds only: which extendPol kernels run as persistent workgroups (bit mask: dif, mid, dit)
     // optional per-kernel timing of the LDE fast path (xlp_profile_*): HIP events on ctx->stream
     bool profile = false;
     std::vector<hipEvent_t> prof_events;   // 4 events per recorded LDE chunk
@@ -104,6 +103,7 @@ int dev_evmap(Ctx* ctx, u64* evals, const u64* LEv, const u64* LpEv, u64 n, u32 
 
 // bn128.hip (Poseidon-BN128, MerkleTreeBN128)
 int bn128_init(Ctx* ctx, const char* path);
+void bn128_shutdown();
 u64 bn128_num_nodes(u64 n);
 int dev_merkle_bn128(Ctx* ctx, u64* nodes, const u64* src, u64 w, u64 h);
 int dev_poseidon_bn128(Ctx* ctx, u64* states, u32 t, u64 count);

@@ -108,6 +108,13 @@ class XlpSteps : public Steps
         }
         XLP_CHECK(xlp_dev_expr_run(s.prog, &r, 0, nrows));
     }
+    // Only step2prev may be missing: a STARK without plookups has no such program (c12a, recursive1/2/f ship none; the reference's
+    // step2prev_first is then an empty function).  Any other step missing means a mis-deployed bundle: a proof made without it would be
+    // complete and invalid, so stop like the reference's loaders do (exitProcess).
+    static void requirePresent(int k, const std::string& what)
+    {
+        if (k != 0) xlp_exit_process(("XlpSteps: " + what).c_str());
+    }
     void allocExt(Step& s)
     {
         void* d = NULL;
@@ -131,7 +138,7 @@ public:
             const xlp_json::Value& S = j["steps"];
             auto str = [&](const xlp_json::Value& e, const char* k) { return e.contains(k) && !e[k].is_null() ? dir + "/" + e[k].str() : std::string(); };
             for (int k = 0; k < 5; k++) {
-                if (!S.contains(steps[k])) continue;
+                if (!S.contains(steps[k])) { requirePresent(k, manifest + " has no " + steps[k]); continue; }
                 const xlp_json::Value& e = S[steps[k]];
                 Step& s = step_[k];
                 s.prog = load(str(e, "prog"), 0x3152505845504c58ULL /* "XLPEXPR1" */, NULL);
@@ -162,7 +169,7 @@ public:
             } else if (exists(base + ".xlpexpr")) {
                 s.prog = load(base + ".xlpexpr", 0x3152505845504c58ULL, NULL);
                 s.mode = "as converted";
-            }
+            } else requirePresent(k, "cannot open " + base + ".xlpexpr");
         }
     }
     ~XlpSteps()

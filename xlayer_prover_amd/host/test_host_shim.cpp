@@ -5,6 +5,7 @@
 //   usage: test_host_shim <nBits> <nBitsExt> <nQueries> <step nBits...>
 #include <cstdio>
 #include <vector>
+#include <omp.h>
 #include "starks_mini.hpp"
 #include "starks.hpp"
 #include "xlp_host_bn128.hpp"
@@ -230,6 +231,59 @@ static int genproof_bn128_mode(const std::string& dir, const std::string& name)
     return 0;
 }
 
+
+// Re-entrancy of the host-pointer boundary (SURVEY 8b "Threading"): FRIProve::prove of the reference runs, inside
+// `#pragma omp parallel` (friProve.cpp:44-108), per group `NTT_Goldilocks ntt(nX, 1); ntt.INTT(ppar_c, ppar, nX, FIELD_EXTENSION)`.
+// The same here on all OpenMP threads at once: group g's input is splitmix-seeded (splitmix64(seed ^ index) mod p: the generator of SURVEY 8d, oracle orc_fill), its INTT is
+// written to stdout as one JSON row.  tests/test_host_shim.py compares every row with the oracle.  Also mixes in the other small
+// host-pointer calls a transcript / Merkle walk makes from a thread (hash_full_result, fri_fold) so that staging slots are shared.
+static uint64_t splitmix_fe(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ULL;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return z % 0xFFFFFFFF00000001ULL;
+}
+static int omp_intt_mode(uint64_t nX, uint64_t groups, uint64_t seed)
+{
+    std::vector<std::vector<uint64_t>> out(groups, std::vector<uint64_t>(nX * 3)), perms(groups, std::vector<uint64_t>(12));
+    int nthreads = 1;
+#pragma omp parallel
+    {
+#pragma omp single
+        nthreads = omp_get_num_threads();
+#pragma omp for schedule(dynamic, 1)
+        for (uint64_t g = 0; g < groups; g++) {
+            Polinomial ppar(nX, FIELD_EXTENSION), ppar_c(nX, FIELD_EXTENSION);
+            for (uint64_t i = 0; i < nX * 3; i++) ppar.address()[i] = Goldilocks::fromU64(splitmix_fe(seed ^ (g * nX * 3 + i)));
+            NTT_Goldilocks ntt(nX, 1);
+            ntt.INTT(ppar_c.address(), ppar.address(), nX, FIELD_EXTENSION);
+            for (uint64_t i = 0; i < nX * 3; i++) out[g][i] = Goldilocks::toU64(ppar_c.address()[i]);
+            Goldilocks::Element st[12], res[12];
+            for (int i = 0; i < 12; i++) st[i] = Goldilocks::fromU64(splitmix_fe((seed + 1) ^ (g * 12 + i)));
+            PoseidonGoldilocks::hash_full_result(res, st);
+            for (int i = 0; i < 12; i++) perms[g][i] = Goldilocks::toU64(res[i]);
+        }
+    }
+    printf("{\"threads\":%d,\"intt\":[", nthreads);
+    for (uint64_t g = 0; g < groups; g++) {
+        printf("%s[", g ? "," : "");
+        for (uint64_t i = 0; i < nX * 3; i++) printf("%s%llu", i ? "," : "", (unsigned long long)out[g][i]);
+        printf("]");
+    }
+    printf("],\"perm\":[");
+    for (uint64_t g = 0; g < groups; g++) {
+        printf("%s[", g ? "," : "");
+        for (int i = 0; i < 12; i++) printf("%s%llu", i ? "," : "", (unsigned long long)perms[g][i]);
+        printf("]");
+    }
+    printf("]}\n");
+    xlp_shutdown();
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc == 4 && std::string(argv[1]) == "genproof_bn128") { const int r = genproof_bn128_mode(argv[2], argv[3]); XlpDeviceSlab::get().release(); xlp_shutdown(); return r; }
@@ -262,6 +316,7 @@ int main(int argc, char** argv)
         printf("\n");
         return 0;
     }
+    if (argc == 5 && std::string(argv[1]) == "omp_intt") return omp_intt_mode(strtoull(argv[2], 0, 10), strtoull(argv[3], 0, 10), strtoull(argv[4], 0, 10));
     if (argc == 4 && std::string(argv[1]) == "polinomial") return polinomial_mode(strtoull(argv[2], 0, 10), strtoull(argv[3], 0, 10));
     if (argc < 5) { fprintf(stderr, "usage: %s nBits nBitsExt nQueries step0 [step1 ...]\n", argv[0]); return 2; }
     MiniStarkConfig cfg;
