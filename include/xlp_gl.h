@@ -16,9 +16,12 @@
  *   - the caller owns every buffer; nothing is retained past return except
  *     caches owned by the process-wide context (twiddle tables, scratch);
  *   - there is NO CPU fallback: without a usable HIP device every call fails;
- *   - threading: ONE thread at a time per process.  The library keeps one process-wide context (stream, twiddle-table cache,
- *     grow-only scratch slots) that the entry points mutate without a lock -- like the reference, where one proverThread
- *     issues every library call (src/prover/prover.cpp:182-255).  Only xlp_init / xlp_shutdown are serialised;
+ *   - threading: every entry point may be called from any thread, concurrently.  The library keeps one process-wide context (stream,
+ *     twiddle-table cache, grow-only scratch slots, the host-range device-copy cache) and ONE recursive lock that every entry point holds
+ *     for its duration: callers are serialised, which costs nothing the GPU would have overlapped (all work goes to one stream).  This is
+ *     what the reference needs: its proverThread issues the big calls one at a time (src/prover/prover.cpp:182-255), but FRIProve::prove
+ *     calls NTT_Goldilocks(nX, 1).INTT from inside an OpenMP region (src/starkpil/fri/friProve.cpp:44,100).  xlp_last_error() is per
+ *     thread.  tests/test_host_shim.py::test_host_boundary_is_reentrant_from_openmp_threads;
  *   - xlp_dev_* calls enqueue on the context's stream and return without waiting for the GPU, EXCEPT: a call whose scratch
  *     slot or table has to be created or grown (hipMalloc, and a stream synchronise when an old slot is freed: first call of a
  *     shape), xlp_dev_calculate_h1h2 (reads its error flag back), xlp_dev_evmap / xlp_dev_dot_columns (upload their entry
@@ -150,6 +153,10 @@ int xlp_dev_calculate_h1h2(uint64_t* h1, uint64_t* h2, const uint64_t* f, const 
  * (stride >= dim, in words).  This is how Starks::genProof hands them over (starks.cpp:108-125, 150-167 through transposeH1H2Columns /
  * transposeZColumns, starks.cpp:406-555): with strides the transposed copies around the calls disappear. */
 int xlp_dev_calculate_z_strided(uint64_t* z, uint64_t z_stride, const uint64_t* num, uint64_t num_stride, const uint64_t* den, uint64_t den_stride, uint64_t n);
+/* z[i] *= s (Fp^3, strided view): the second half of a ROW-SHARDED calculateZ (polinomial.hpp:586-607 is a prefix product over the rows) --
+ * every rank scans its own rows with xlp_dev_calculate_z_strided, the ranks all-gather their total products (three words each) and
+ * scale their rows by the product of the ranks before them. */
+int xlp_dev_scale3_strided(uint64_t* z, uint64_t z_stride, uint64_t n, const uint64_t s[3]);
 int xlp_dev_calculate_h1h2_strided(uint64_t* h1, uint64_t h1_stride, uint64_t* h2, uint64_t h2_stride, const uint64_t* f, uint64_t f_stride,
                                    const uint64_t* t, uint64_t t_stride, uint64_t n, uint32_t dim);
 /* out[k] = first * ratio^k, k < n, elements of dimension dim (1 or 3; `first`, `ratio`: dim host words each).
@@ -300,6 +307,34 @@ int xlp_field_op(uint64_t* out, const uint64_t* a, const uint64_t* b, uint64_t n
  * around STARK_STEP_n_LDE (src/starkpil/starks.cpp:49-55). */
 int xlp_profile_enable(int on);
 int xlp_profile_read(double ms_sum[3], uint64_t* count);
+
+/* ---- transport between the ranks of a row-sharded proof: one process per GPU -----------------------------------------
+ * The reference commits a section with ntt.extendPol + treesGL[i]->merkelize() on one host (starks.cpp:53-60,134-141,215-222) and runs
+ * the step programs over all rows (starks.cpp:73,155,193,241,371).  Over G ranks the rows are partitioned; these entry points are the
+ * exchanges that partition needs (host/starks.hpp drives them): two all-to-alls per committed section (rows -> columns for the
+ * per-column LDE, columns -> rows for the row-wise leaf sponge), ring halo rows for the next-row operands, all-gathers of the 3-column
+ * quotient / FRI polynomials and plookup tables, and a few host words per rank (sub-tree roots: the G x 32-byte "cap" all-gather of
+ * BASELINE's north_star, grand-product totals, partial evaluations).  Device buffers; everything is enqueued on the library's stream.
+ *   backend "rccl": RCCL over xGMI (librccl.so.1 loaded on first use); `rendezvous` = a file path through which rank 0 publishes the
+ *                   ncclUniqueId.  Call xlp_init(device) first: one process per GPU, no GPU call of another kind before it is needed.
+ *   backend "shm":  ranks sharing one GPU or without a peer path (test box, rehearsal): POSIX shared memory named `rendezvous`, host-staged.
+ *   backend NULL / "self": world must be 1; exchanges are device copies.
+ * xlp_comm_exchange: recv[p] (recv_words[p] words) <- the block rank p sends me; send[p] (send_words[p] words) -> rank p; arrays of
+ *   `world` entries; my own block is copied on the device.  Messages travel in rounds of <= 256 MiB per (sender, receiver).
+ * xlp_comm_all_gather: out[p * words ..] <- rank p's `in`.   xlp_comm_sendrecv: one ring step (halo rows).
+ * xlp_comm_all_gather_host: the same for a few HOST words (synchronises the stream).
+ * xlp_comm_stats: seconds / bytes sent to peers / calls of the exchanges so far; mode bit 0 resets, bit 1 turns the timing on (each
+ *   exchange then synchronises the stream before and after), bit 2 turns it off. */
+int xlp_comm_init(int rank, int world, const char* backend, const char* rendezvous);
+void xlp_comm_shutdown(void);
+int xlp_comm_rank(void);
+int xlp_comm_world(void);
+int xlp_comm_exchange(uint64_t* const* recv, const uint64_t* recv_words, const uint64_t* const* send, const uint64_t* send_words);
+int xlp_comm_all_gather(uint64_t* out, const uint64_t* in, uint64_t words);
+int xlp_comm_sendrecv(uint64_t* recv, int from, const uint64_t* send, int to, uint64_t words);
+int xlp_comm_all_gather_host(uint64_t* out, const uint64_t* in, uint64_t words);
+int xlp_comm_barrier(void);
+int xlp_comm_stats(double* seconds, uint64_t* bytes_sent, uint64_t* calls, int mode);
 
 /* ---- band-pipelined commit of a section (device pointers) ------------------------------------------
  * A Merkle leaf is a sponge over the row in column order, so the leaf state (4 words per row = level 0 of the node buffer)

@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--opt-only", action="store_true", help="with --geometry: only the dot-product forms of steps 2-4 (what the genProof bench runs by default; the one-row table "
                     "program of step52ns costs the same few ms interpreted and the longest build)")
     ap.add_argument("--aliased", action="store_true", help="with --geometry: the one-GPU aliased slab layout -> zkevm.<step>.geo<N>a.so")
+    ap.add_argument("--world", type=int, default=0, help="with --geometry: the window layout of one rank of a proof row-sharded over this many ranks "
+                    "(tools/zkevm_geometry.py layout_window) -> zkevm.<step>.geo<N>w<G>.so")
     a = ap.parse_args()
     sizes = ["full"] if a.full else [int(x) for x in a.log_rows.split(",")]
     geo = None
@@ -42,21 +44,22 @@ def main():
         from tools import zkevm_geometry as G
         if a.steps == ap.get_default("steps"):
             a.steps = ",".join(G.CIRCUITS[a.circuit]["steps"])
-        geo, _ = G.load(a.geometry, a.aliased, a.circuit)
-        for st, v in G.load_opt(a.geometry, a.aliased, a.circuit).items():
+        LW = G.layout_window(a.geometry, a.world, a.circuit) if a.world else None
+        geo, _ = G.load(a.geometry, a.aliased, a.circuit, LW)
+        for st, v in G.load_opt(a.geometry, a.aliased, a.circuit, LW).items():
             geo[st + "_opt"] = v[0]
         sizes = ["geo"]
         want52 = "step52ns" in a.steps.split(",")
         a.steps = ",".join(x for st in a.steps.split(",") for x in ((st + "_opt",) if a.opt_only else (st, st + "_opt")) if x != "step52ns_opt" or not a.opt_only)
         if want52 and not a.opt_only:                     # the one-row table program of the dot-columns form of step52ns
-            tabp = G.load_fri_dots(a.geometry, a.aliased, a.circuit)[0]
+            tabp = G.load_fri_dots(a.geometry, a.aliased, a.circuit, LW)[0]
             geo["step52ns_tab"] = (tabp.code, tabp.ntmp1, tabp.ntmp3)
             a.steps += ",step52ns_tab"
     for size in sizes:
         for step in a.steps.split(","):
             lr = (24 if step.endswith("2ns") else 23) if size in ("full", "geo") else size
             src = os.path.join(R.REF_DIR, f"{a.circuit if geo else 'zkevm'}.{step.replace('_opt', '').replace('_tab', '')}.xlpexpr")
-            name = f"{a.circuit}.{step}.geo{a.geometry}{'a' if a.aliased else ''}" if geo else f"zkevm.{step}.n{lr}"
+            name = f"{a.circuit}.{step}.geo{a.geometry}{'a' if a.aliased else ''}{f'w{a.world}' if a.world else ''}" if geo else f"zkevm.{step}.n{lr}"
             so = os.path.join(R.REF_DIR, name + ".so")
             if not os.path.exists(src):
                 print("missing", src); continue

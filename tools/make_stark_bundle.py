@@ -37,16 +37,24 @@ def write_tab(path, prog, n_ext):
         f.write(struct.pack("<5Q", MAGIC_TAB, prog.ntmp1, prog.ntmp3, code.size, n_ext)); f.write(code.tobytes())
 
 
-def bundle_dir(circ, log_n, aliased):
-    return os.path.join(R.REF_DIR, "bundles", f"{circ}.geo{log_n}{'a' if aliased else ''}")
+def geo_tag(log_n, aliased=False, world=0):
+    return f"geo{log_n}{'a' if aliased else ''}{f'w{world}' if world else ''}"
 
 
-def make(circ, log_n, aliased, out=None, fri_steps=None, queries=None, use_opt=True, use_dots=True):
-    out = out or bundle_dir(circ, log_n, aliased)
+def bundle_dir(circ, log_n, aliased, world=0):
+    return os.path.join(R.REF_DIR, "bundles", f"{circ}.{geo_tag(log_n, aliased, world)}")
+
+
+def make(circ, log_n, aliased, out=None, fri_steps=None, queries=None, use_opt=True, use_dots=True, world=0):
+    """world > 0: the bundle of ONE RANK of a proof row-sharded over `world` ranks (every rank uses the same files): window starkinfo,
+    programs relocated to the window slab (tools/zkevm_geometry.py layout_window), and per step the next-row stores whose halo rows go
+    back to their owner"""
+    out = out or bundle_dir(circ, log_n, aliased, world)
     os.makedirs(out, exist_ok=True)
-    geo = f"geo{log_n}{'a' if aliased else ''}"
-    progs, info = G.load(log_n, aliased, circ)
-    json.dump(G.synth_starkinfo(circ, log_n, aliased, fri_steps, queries), open(os.path.join(out, f"{circ}.starkinfo.json"), "w"))
+    geo = geo_tag(log_n, aliased, world)
+    LW = G.layout_window(log_n, world, circ) if world else None
+    progs, info = G.load(log_n, aliased, circ, LW)
+    json.dump(G.synth_starkinfo(circ, log_n, aliased, fri_steps, queries, world), open(os.path.join(out, f"{circ}.starkinfo.json"), "w"))
     man = {}
     rel = lambda p: os.path.relpath(p, out)
 
@@ -57,7 +65,7 @@ def make(circ, log_n, aliased, out=None, fri_steps=None, queries=None, use_opt=T
         write_prog(os.path.join(out, f"{circ}.{st}.xlpexpr"), code, n1, n3)
         man[st] = {"prog": f"{circ}.{st}.xlpexpr", "plugin": plugin(f"{circ}.{st}.{geo}.so")}
     if use_opt:
-        for st, ((rc, r1, r3), tabp, n_ext, stats) in G.load_opt(log_n, aliased, circ).items():
+        for st, ((rc, r1, r3), tabp, n_ext, stats) in G.load_opt(log_n, aliased, circ, LW).items():
             write_prog(os.path.join(out, f"{circ}.{st}.opt.xlpexpr"), rc, r1, r3)
             e = {"prog": f"{circ}.{st}.opt.xlpexpr", "plugin": plugin(f"{circ}.{st}_opt.{geo}.so"), "n_ext": n_ext}
             if tabp.ninstr:
@@ -65,7 +73,7 @@ def make(circ, log_n, aliased, out=None, fri_steps=None, queries=None, use_opt=T
                 e["tab"] = f"{circ}.{st}.tab.xlpexpr"
             man[st] = e
     if use_opt and use_dots:
-        tabp, dots, rowp, n_ext = G.load_fri_dots(log_n, aliased, circ)
+        tabp, dots, rowp, n_ext = G.load_fri_dots(log_n, aliased, circ, LW)
         write_tab(os.path.join(out, f"{circ}.step52ns.dtab.xlpexpr"), tabp, n_ext)
         write_prog(os.path.join(out, f"{circ}.step52ns.drow.xlpexpr"), rowp.code, rowp.ntmp1, rowp.ntmp3)
         ents = []
@@ -79,6 +87,9 @@ def make(circ, log_n, aliased, out=None, fri_steps=None, queries=None, use_opt=T
             f.write(struct.pack("<3Q", MAGIC_DOTS, dots["ngroups"], len(dots["entries"]))); f.write(np.array(ents, dtype="<u8").tobytes())
         man["step52ns"] = {"prog": f"{circ}.step52ns.drow.xlpexpr", "tab": f"{circ}.step52ns.dtab.xlpexpr", "n_ext": n_ext, "dots": f"{circ}.step52ns.dots",
                            "tab_plugin": plugin(f"{circ}.step52ns_tab.{geo}.so"), "plugin": None}
+    if world:
+        for st, (code, n1, n3) in progs.items():               # (the rewritten forms store to the same places)
+            man[st]["nextRowStores"] = [list(x) for x in G.next_row_stores(code, LW)]
     json.dump({"steps": man}, open(os.path.join(out, f"{circ}.steps.json"), "w"), indent=1)
     return out
 
@@ -91,9 +102,10 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--no-opt", action="store_true")
     ap.add_argument("--no-dots", action="store_true")
+    ap.add_argument("--world", type=int, default=0, help="the per-rank bundle of a proof row-sharded over this many ranks (window layout)")
     a = ap.parse_args()
     ln = a.log_n or G.CIRCUITS[a.circuit]["log_n"]
-    print(make(a.circuit, ln, a.aliased, a.out or None, use_opt=not a.no_opt, use_dots=not a.no_dots))
+    print(make(a.circuit, ln, a.aliased, a.out or None, use_opt=not a.no_opt, use_dots=not a.no_dots, world=a.world))
 
 
 if __name__ == "__main__":

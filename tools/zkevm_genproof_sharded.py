@@ -42,12 +42,9 @@ from xlayer_prover_amd.transcript import HostTranscript
 def _next_row_stores(code, L):
     """{section: [(first column, columns, next distance)]} of the program's stores to next rows"""
     out = {}
-    for op, d, a, b in E.decode(code):
-        if d.kind == E.K_POLS_PRIME:
-            off, nxt, _, stride = d.params
-            name = [nm for nm, (o, w, r) in L.items() if w and o <= off < o + w * r and w == stride][-1]
-            out.setdefault(name, set()).add((off - L[name][0], d.dim, nxt))
-    return {k: sorted(v) for k, v in out.items()}
+    for name, col, dim, nxt in G.next_row_stores(code, L):
+        out.setdefault(name, []).append((col, dim, nxt))
+    return out
 
 
 def prove_sharded(ln, group=None, collectives=False, queries=0, fri_steps=None, lookups=-1, zs=-1, device="cuda", timers=None):

@@ -185,11 +185,11 @@ def load(log_n, aliased=False, circ="zkevm", new_layout=None):
 NCH = 8                                             # challenges of a STARK proof (starks.cpp: 0..7)
 
 
-def load_opt(log_n, aliased=False, circ="zkevm"):
+def load_opt(log_n, aliased=False, circ="zkevm", new_layout=None):
     """every step with its Horner chains turned into dot products (xlayer_prover_amd/expr_opt.py):
     step -> ((row code, ntmp1, ntmp3), table Program, number of extended-challenge entries, statistics)"""
     from xlayer_prover_amd import expr_opt
-    progs, _ = load(log_n, aliased, circ)
+    progs, _ = load(log_n, aliased, circ, new_layout)
     res = {}
     for step, (code, n1, n3) in progs.items():
         row, tab, n_ext, stats = expr_opt.horner_to_dot(code, n1, n3, NCH)
@@ -197,11 +197,11 @@ def load_opt(log_n, aliased=False, circ="zkevm"):
     return res
 
 
-def load_fri_dots(log_n, aliased=False, circ="zkevm"):
+def load_fri_dots(log_n, aliased=False, circ="zkevm", new_layout=None):
     """step52ns as (table Program, dot-columns groups, 12-instruction row Program, n_ext): xlayer_prover_amd/expr_opt.py with
     its big sums handed to xlp_dev_dot_columns"""
     from xlayer_prover_amd import expr_opt
-    progs, _ = load(log_n, aliased, circ)
+    progs, _ = load(log_n, aliased, circ, new_layout)
     code, n1, n3 = progs["step52ns"]
     row, tab, n_ext, stats, dots = expr_opt.horner_to_dot(code, n1, n3, NCH, outsource_min_terms=8)
     assert dots is not None
@@ -277,12 +277,28 @@ def evmap_of(code52, L, secs, nconst):
     return [ents[k] + (prime[k],) for k in sorted(ents)]
 
 
-def synth_starkinfo(circ, log_n, aliased=False, fri_steps=None, queries=None):
+def next_row_stores(code, L):
+    """[(section, first column, columns, next distance)] of a program's stores to NEXT rows (zkEVM step3prev / step3 have a few): in a
+    row-sharded run the rows they write past a rank's last row belong to the next rank (xlayer_prover_amd/shard.py halo_writeback)"""
+    out = set()
+    for op, d, a, b in E.decode(code):
+        if d.kind == E.K_POLS_PRIME:
+            off, nxt, _, stride = d.params
+            name = [nm for nm, (o, w, r) in L.items() if w and o <= off < o + w * r and w == stride][-1]
+            out.add((name, int(off - L[name][0]), int(d.dim), int(nxt)))
+    return sorted(out)
+
+
+def synth_starkinfo(circ, log_n, aliased=False, fri_steps=None, queries=None, world=0):
+    """world > 0: the per-rank WINDOW layout of a proof row-sharded over `world` ranks (layout_window): every section holds the rank's
+    N / world rows followed by the halo rows of the next rank; offsets, mapDeg and mapTotalN describe that window slab, nBits / nBitsExt
+    stay the global ones.  host/starks.hpp runs such a starkinfo in its sharded mode (world must equal the number of ranks)."""
     C = CIRCUITS[circ]
     ext = C["ext"]
-    L = layout(log_n, aliased, circ)
+    assert not (world and aliased)
+    L = layout_window(log_n, world, circ) if world else layout(log_n, aliased, circ)
     secs = sections(circ)
-    progs, info = load(log_n, aliased, circ)
+    progs, info = load(log_n, aliased, circ, L if world else None)
     nconst = max(info["n_const"], info["n_const2"])
     W = {name: w for name, w, _ in secs}
     lne = log_n + ext
@@ -357,7 +373,7 @@ def synth_starkinfo(circ, log_n, aliased=False, fri_steps=None, queries=None):
         else:
             ev.append({"type": "cm", "id": cm_2ns.index(twin_id[(name, col, dim)]), "prime": prime})
     order = [name for name, _, _ in secs]
-    rows = {name: 1 << (log_n + (ext if e else 0)) for name, _, e in secs}
+    rows = {name: (L[name][2] if world else 1 << (log_n + (ext if e else 0))) for name, _, e in secs}
     step = {"tmpUsed": 0, "first": [], "i": [], "last": []}
     j = {"starkStruct": {"nBits": log_n, "nBitsExt": lne, "nQueries": queries or C["queries"], "verificationHashType": C.get("hash", "GL"), "steps": [{"nBits": b} for b in fri_steps]},
          "mapTotalN": L["end"][0], "nConstants": nconst, "nPublics": info["npub"], "nCm1": counts["cm1_n"], "nCm2": counts["cm2_n"], "nCm3": counts["cm3_n"],
@@ -369,6 +385,8 @@ def synth_starkinfo(circ, log_n, aliased=False, fri_steps=None, queries=None):
          # not in the reference's schema: where the extended constants live when they share the slab (one-GPU aliased layout), and that
          # the lookups of this STARK run on a synthetic witness (f is then selected from t, see xlp_dev_gather_rows)
          "xlp": {"aliased": bool(aliased), "const2nsOffset": L["const_2ns"][0] if aliased else None, "circuit": circ, "steps": list(C["steps"])}}
+    if world:
+        j["xlp"].update({"world": world, "haloN": 1, "haloExt": 1 << ext})
     return j
 
 

@@ -87,8 +87,18 @@ SIGNATURES = {
     "xlp_dev_memset": [_pu, C.c_int, C.c_size_t],
     "xlp_copy_h2d": [_pu, _pu, C.c_size_t],
     "xlp_copy_d2h": [_pu, _pu, C.c_size_t],
+    "xlp_dev_scale3_strided": [_pu, _u64, _u64, _pu],
+    "xlp_comm_init": [C.c_int, C.c_int, C.c_char_p, C.c_char_p],
+    "xlp_comm_rank": [],
+    "xlp_comm_world": [],
+    "xlp_comm_exchange": [_pu, _pu, _pu, _pu],
+    "xlp_comm_all_gather": [_pu, _pu, _u64],
+    "xlp_comm_sendrecv": [_pu, C.c_int, _pu, C.c_int, _u64],
+    "xlp_comm_all_gather_host": [_pu, _pu, _u64],
+    "xlp_comm_barrier": [],
+    "xlp_comm_stats": [C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int],
 }
-VOID_SIGNATURES = {"xlp_shutdown": [], }
+VOID_SIGNATURES = {"xlp_shutdown": [], "xlp_comm_shutdown": []}
 SIZE_SIGNATURES = {"xlp_cache_bytes": [], "xlp_merkle_bn128_num_nodes": [C.c_uint64]}
 STR_SIGNATURES = {"xlp_last_error": []}
 

@@ -222,6 +222,23 @@ int dev_calculate_z(Ctx* ctx, u64* z, u64 zs, const u64* num, u64 ns, const u64*
     return 0;
 }
 
+// z[i] <- z[i] * s for the Fp^3 elements of a strided view (row-sharded calculateZ: a rank's local scan times the product of the ranks before it)
+__global__ __launch_bounds__(256) void scale3_kernel(u64* z, u64 zs, u64 n, e3 s)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    store3(z + i * zs, gl::mul3(load3(z + i * zs), s));
+}
+int dev_scale3(Ctx* ctx, u64* z, u64 zs, u64 n, const u64 s[3])
+{
+    if (!n) return 0;
+    if (zs < 3) return xlp_fail("scale3: stride below the dimension");
+    e3 k; k.c[0] = s[0] % hgl::P; k.c[1] = s[1] % hgl::P; k.c[2] = s[2] % hgl::P;
+    hipLaunchKernelGGL(scale3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, z, zs, n, k);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
 int dev_batch_inverse(Ctx* ctx, u64* res, const u64* src, u64 n, u32 dim)
 {
     if (!n) return 0;

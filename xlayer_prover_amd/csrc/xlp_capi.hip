@@ -222,6 +222,7 @@ void xlp_shutdown(void)
     while (!g_cache.empty()) cache_drop(0);
     g_cache_cap = 0;
     bn128_shutdown();
+    comm_shutdown();
     g_ctx.stream = nullptr;
     g_ctx.own_stream = false;
     g_ctx.inited = false;
@@ -294,6 +295,13 @@ int xlp_dev_calculate_z_strided(uint64_t* z, uint64_t z_stride, const uint64_t* 
     XLP_ENTER;
     if (ensure_init()) return -1;
     return dev_calculate_z(&g_ctx, z, z_stride, num, num_stride, den, den_stride, n);
+}
+int xlp_dev_scale3_strided(uint64_t* z, uint64_t z_stride, uint64_t n, const uint64_t s[3])
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if (n && (!z || !s)) return xlp_fail("xlp_dev_scale3_strided: null pointer");
+    return dev_scale3(&g_ctx, z, z_stride, n, s);
 }
 int xlp_dev_calculate_h1h2(uint64_t* h1, uint64_t* h2, const uint64_t* f, const uint64_t* t, uint64_t n, uint32_t dim)
 {
@@ -757,6 +765,52 @@ int xlp_perm_batch(uint64_t* out, const uint64_t* in, uint64_t count)
     return 0;
 }
 int xlp_perm(uint64_t out[12], const uint64_t in[12]) { return xlp_perm_batch(out, in, 1); }
+
+// ---- transport between the ranks of a row-sharded proof (comm.hip)
+int xlp_comm_init(int rank, int world, const char* backend, const char* rendezvous)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    return comm_init(&g_ctx, rank, world, backend, rendezvous);
+}
+void xlp_comm_shutdown(void) { XLP_ENTER; comm_shutdown(); }
+int xlp_comm_rank(void) { return comm_rank(); }
+int xlp_comm_world(void) { return comm_world(); }
+int xlp_comm_exchange(uint64_t* const* recv, const uint64_t* recv_words, const uint64_t* const* send, const uint64_t* send_words)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if (!recv || !recv_words || !send || !send_words) return xlp_fail("xlp_comm_exchange: null pointer");
+    return comm_exchange(&g_ctx, recv, recv_words, send, send_words);
+}
+int xlp_comm_all_gather(uint64_t* out, const uint64_t* in, uint64_t words)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if (words && (!out || !in)) return xlp_fail("xlp_comm_all_gather: null pointer");
+    return comm_all_gather(&g_ctx, out, in, words);
+}
+int xlp_comm_sendrecv(uint64_t* recv, int from, const uint64_t* send, int to, uint64_t words)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if (words && (!recv || !send)) return xlp_fail("xlp_comm_sendrecv: null pointer");
+    return comm_sendrecv(&g_ctx, recv, from, send, to, words);
+}
+int xlp_comm_all_gather_host(uint64_t* out, const uint64_t* in, uint64_t words)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if (words && (!out || !in)) return xlp_fail("xlp_comm_all_gather_host: null pointer");
+    return comm_all_gather_host(&g_ctx, out, in, words);
+}
+int xlp_comm_barrier(void)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    return comm_barrier(&g_ctx);
+}
+int xlp_comm_stats(double* seconds, uint64_t* bytes_sent, uint64_t* calls, int mode) { XLP_ENTER; return comm_stats(seconds, bytes_sent, calls, mode); }
 
 // ---- BN128 (StarkRecursiveF)
 int xlp_bn128_init(const char* constants_path)

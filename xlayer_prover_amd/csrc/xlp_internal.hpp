@@ -93,6 +93,7 @@ int dev_field_op(Ctx* ctx, u64* out, const u64* a, const u64* b, u64 n, int op);
 int dev_batch_inverse(Ctx* ctx, u64* res, const u64* src, u64 n, u32 dim);
 int dev_calculate_z(Ctx* ctx, u64* z, u64 zs, const u64* num, u64 ns, const u64* den, u64 ds, u64 n);
 int dev_calculate_h1h2(Ctx* ctx, u64* h1, u64 h1s, u64* h2, u64 h2s, const u64* f, u64 fs, const u64* t, u64 ts, u64 n, u32 dim);
+int dev_scale3(Ctx* ctx, u64* z, u64 zs, u64 n, const u64 s[3]);
 int dev_copy_cols(Ctx* ctx, u64* dst, u64 dst_stride, const u64* src, u64 src_stride, u64 n, u32 dim);
 int dev_q_split(Ctx* ctx, u64* qq2, const u64* qq1, u64 n, u64 n_ext, u32 qdeg, u32 qdim, u64 shift_in);
 int dev_geometric(Ctx* ctx, u64* out, u64 n, u32 dim, const u64* first, const u64* ratio);
@@ -111,6 +112,18 @@ int dev_merkle_bn128_proofs(Ctx* ctx, u64* out, const u64* src, const u64* nodes
 int dev_fft_bn254(Ctx* ctx, u64* data, u64 n, int inverse);
 // bn254_msm.hip
 int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 n);
+
+// comm.hip (transport between the ranks of a row-sharded proof)
+int comm_init(Ctx* ctx, int rank, int world, const char* backend, const char* rendezvous);
+void comm_shutdown();
+int comm_rank();
+int comm_world();
+int comm_exchange(Ctx* ctx, u64* const* recv, const u64* recv_words, const u64* const* send, const u64* send_words);
+int comm_all_gather(Ctx* ctx, u64* out, const u64* in, u64 words);
+int comm_sendrecv(Ctx* ctx, u64* recv, int from, const u64* send, int to, u64 words);
+int comm_all_gather_host(Ctx* ctx, u64* out, const u64* in, u64 words);
+int comm_barrier(Ctx* ctx);
+int comm_stats(double* seconds, u64* bytes_sent, u64* calls, int mode);
 
 // expr.hip
 int expr_create(xlp_expr_program** out, const u64* code, u64 ncode, u64 ntmp1, u64 ntmp3);

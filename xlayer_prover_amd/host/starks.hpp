@@ -15,6 +15,14 @@
 //  * A starkinfo may place the extended constants inside the slab ("xlp": {"const2nsOffset": ...}: the one-GPU aliased layout of
 //    tools/zkevm_geometry.py); they are then re-extended in step 4 of every proof, only their tree stays resident.
 //  * nrowsStepBatch is irrelevant (one row per lane).
+//  * ROW-SHARDED MODE (BASELINE north_star: "columns shard across the 8 GPUs ... a single RCCL all-gather ... to assemble
+//    Merkle caps"): one process per GPU, xlp_comm_init(rank, world, ...) before the Starks is built, and a starkinfo laid out for that
+//    world ("xlp": {"world": G}: every section is the rank's WINDOW = its N / G rows + the halo rows of the next rank).  genProof then
+//    runs the same stages on the rank's rows: a section commit is rows -> columns (all-to-all), per-column extendPol, columns -> rows
+//    (all-to-all), sub-tree, 32-byte cap all-gather; step programs run on the window with ring halo exchanges around them; H1H2 on the
+//    all-gathered table; calculateZ = local scan + 3 words per rank; the 3-column quotient / FRI polynomials are all-gathered and
+//    transformed on every rank; evmap = local sums + one all-gather; openings come from the owning rank.  Every rank runs the transcript
+//    and ends with the complete proof.  pAddress then holds the rank's ROWS of the witness.  See genProofSharded below.
 #pragma once
 #include <chrono>
 #include <string>
@@ -66,6 +74,7 @@ struct XlpHashGL
     typedef FRIProve Prove;
     typedef Goldilocks::Element Root[HASH_SIZE];
     static constexpr bool kFileTree = true;          // <stark>.consttree (bctree's file) can be loaded instead of computed
+    static constexpr bool kShardable = true;         // MerkleTreeGL has a row-sharded form (binary tree: a rank's sub-root is a node of the global tree)
     static uint64_t treeWords(Tree* t) { return t->getTreeNumElements(); }
     static void getField(TranscriptT& t, Goldilocks::Element* out) { t.getField(out); }
     static void putRoot(TranscriptT& t, Goldilocks::Element* r) { t.put(r, HASH_SIZE); }
@@ -110,6 +119,12 @@ private:
     uint64_t *d_const_n = NULL, *d_const_2ns_own = NULL, *d_x_n = NULL, *d_x_2ns = NULL, *d_zi = NULL, *d_xdx = NULL, *d_xdwx = NULL;
     uint64_t *d_challenges = NULL, *d_publics = NULL, *d_evals = NULL, *d_work = NULL;
     typename H::Tree* treesGL[STARK_C12_A_NUM_TREES] = {NULL, NULL, NULL, NULL, NULL};
+    // row-sharded mode
+    bool sharded = false;
+    int rank = 0, world = 1;
+    uint64_t nLoc = 0, neLoc = 0, haloN = 0, haloExt = 0, row0 = 0, ext0 = 0;     // my rows of the base / extended domain, halo rows, my first rows
+    uint64_t *d_const_n_full = NULL, *d_const_2ns_win = NULL, *d_shard = NULL;
+    uint64_t shardWords = 0;
 
     static uint64_t* dalloc(uint64_t elems)
     {
@@ -149,19 +164,22 @@ private:
     {
         StepsParams P;
         memset(&P, 0, sizeof P);
+        // sharded: the buffers are this rank's windows (its rows + the halo rows) and the programs run on local row numbers
+        const uint64_t rowsN = sharded ? nLoc + haloN : N, rowsE = sharded ? neLoc + haloExt : NExtended;
+        const uint64_t ownN = sharded ? nLoc : N, ownE = sharded ? neLoc : NExtended;
         P.pols = mem(); P.pols_size = starkInfo.mapTotalN;
-        P.const_pols = d_const_n; P.n_const_pols = starkInfo.nConstants; P.const_pols_size = N * starkInfo.nConstants;
-        P.const_pols_2ns = constPols2ns(); P.n_const_pols_2ns = starkInfo.nConstants; P.const_pols_2ns_size = NExtended * starkInfo.nConstants;
+        P.const_pols = d_const_n; P.n_const_pols = starkInfo.nConstants; P.const_pols_size = rowsN * starkInfo.nConstants;
+        P.const_pols_2ns = sharded ? d_const_2ns_win : constPols2ns(); P.n_const_pols_2ns = starkInfo.nConstants; P.const_pols_2ns_size = rowsE * starkInfo.nConstants;
         P.challenges = d_challenges; P.challenges_size = NUM_CHALLENGES * FIELD_EXTENSION;
         P.public_inputs = d_publics; P.public_inputs_size = starkInfo.nPublics;
         P.evals = d_evals; P.evals_size = starkInfo.evMap.size() * FIELD_EXTENSION;
-        P.x_n = d_x_n; P.x_n_size = N;
-        P.x_2ns = d_x_2ns; P.x_2ns_size = NExtended;
+        P.x_n = d_x_n; P.x_n_size = ownN;
+        P.x_2ns = d_x_2ns; P.x_2ns_size = ownE;
         P.zi = d_zi; P.zi_size = 1ULL << extendBits;
-        P.x_div_x_sub_xi = d_xdx; P.x_div_x_sub_xi_size = NExtended * FIELD_EXTENSION;
-        P.x_div_x_sub_wxi = d_xdwx; P.x_div_x_sub_wxi_size = NExtended * FIELD_EXTENSION;
-        P.q_2ns = section(q_2ns); P.q_2ns_size = NExtended * starkInfo.mapSectionsN.section[q_2ns];
-        P.f_2ns = section(f_2ns); P.f_2ns_size = NExtended * starkInfo.mapSectionsN.section[f_2ns];
+        P.x_div_x_sub_xi = d_xdx; P.x_div_x_sub_xi_size = ownE * FIELD_EXTENSION;
+        P.x_div_x_sub_wxi = d_xdwx; P.x_div_x_sub_wxi_size = ownE * FIELD_EXTENSION;
+        P.q_2ns = section(q_2ns); P.q_2ns_size = rowsE * starkInfo.mapSectionsN.section[q_2ns];
+        P.f_2ns = section(f_2ns); P.f_2ns_size = rowsE * starkInfo.mapSectionsN.section[f_2ns];
         return P;
     }
     static bool fileExists(const std::string& f) { FILE* fp = fopen(f.c_str(), "rb"); if (fp) fclose(fp); return fp != NULL; }
@@ -181,6 +199,336 @@ private:
         fclose(fp);
     }
 
+    // ------------------------------------------------------------------------------------------------ row-sharded mode
+    // dst (rows x width, dense) <- rows (first + i) % total of src (total x width): a rank's window of a replicated table
+    static void windowRows(uint64_t* dst, const uint64_t* src, uint64_t width, uint64_t first, uint64_t rows, uint64_t total)
+    {
+        if (!width || !rows) return;
+        const uint64_t a = first % total, head = rows < total - a ? rows : total - a;
+        XLP_CHECK(xlp_dev_copy_cols(dst, width, src + a * width, width, head, (uint32_t)width));
+        for (uint64_t done = head; done < rows;) {          // (the halo of the last rank wraps to row 0)
+            const uint64_t k = rows - done < total ? rows - done : total;
+            XLP_CHECK(xlp_dev_copy_cols(dst + done * width, width, src, width, k, (uint32_t)width));
+            done += k;
+        }
+    }
+    static bool isExtSection(eSection s) { return s == cm1_2ns || s == cm2_2ns || s == cm3_2ns || s == cm4_2ns || s == q_2ns || s == f_2ns; }
+    uint64_t ownRows(eSection s) const { return isExtSection(s) ? neLoc : nLoc; }
+    uint64_t haloRows(eSection s) const { return isExtSection(s) ? haloExt : haloN; }
+    // contiguous, balanced column shard of a rank (the first W % G ranks own one column more)
+    void colSpan(uint64_t W, int r, uint64_t& c0, uint64_t& c1) const
+    {
+        const uint64_t base = W / world, rem = W % world;
+        c0 = r * base + ((uint64_t)r < rem ? (uint64_t)r : rem);
+        c1 = c0 + base + ((uint64_t)r < rem ? 1 : 0);
+    }
+    uint64_t* shardScratch(uint64_t words)
+    {
+        if (words > shardWords) {
+            if (d_shard) XLP_CHECK(xlp_dev_free(d_shard));
+            d_shard = dalloc(words); shardWords = words;
+        }
+        return d_shard;
+    }
+    // the window's halo rows <- the first rows of the next rank (ring): my first rows go to the previous rank
+    void fillHalo(eSection s)
+    {
+        const uint64_t W = starkInfo.mapSectionsN.section[s];
+        if (!W) return;
+        XLP_CHECK(xlp_comm_sendrecv(section(s) + ownRows(s) * W, (rank + 1) % world, section(s), (rank + world - 1) % world, haloRows(s) * W));
+    }
+    // after a program with next-row stores: the halo rows it wrote belong to the next rank's first rows; mine come from the previous rank
+    void haloWriteback(const std::vector<NextRowStore>& stores)
+    {
+        if (stores.empty()) return;
+        uint64_t total = 0;
+        for (const NextRowStore& st : stores) total += st.next * st.cols;
+        uint64_t *pack = shardScratch(2 * total), *recv = pack + total, o = 0;
+        for (const NextRowStore& st : stores) {
+            const eSection sec = (eSection)st.section;
+            const uint64_t W = starkInfo.mapSectionsN.section[sec];
+            if (st.next > haloRows(sec) || st.col + st.cols > W) xlp_exit_process("Starks: next-row store outside the halo");
+            XLP_CHECK(xlp_dev_copy_cols(pack + o, st.cols, section(sec) + ownRows(sec) * W + st.col, W, st.next, (uint32_t)st.cols));
+            o += st.next * st.cols;
+        }
+        XLP_CHECK(xlp_comm_sendrecv(recv, (rank + world - 1) % world, pack, (rank + 1) % world, total));
+        o = 0;
+        for (const NextRowStore& st : stores) {
+            const eSection sec = (eSection)st.section;
+            const uint64_t W = starkInfo.mapSectionsN.section[sec];
+            XLP_CHECK(xlp_dev_copy_cols(section(sec) + st.col, W, recv + o, st.cols, st.next, (uint32_t)st.cols));
+            o += st.next * st.cols;
+        }
+    }
+    // ntt.extendPol(cmX_2ns, cmX_n, ...) + treesGL[i]->merkelize() (starks.cpp:53-60,134-141,215-222) over the ranks: the LDE runs per
+    // COLUMN (all N rows of my W / G columns), the leaf sponge per ROW (all W columns of my NExtended / G rows):
+    //   rows -> columns all-to-all | extendPol of my columns | columns -> rows all-to-all | sub-tree | cap (32 bytes per rank)
+    void commitSharded(typename H::Tree* tree, eSection sn, eSection s2)
+    {
+        const uint64_t W = starkInfo.mapSectionsN.section[sn];
+        tree->d_source = section(s2);
+        if (W) {
+            uint64_t c0, c1;
+            colSpan(W, rank, c0, c1);
+            const uint64_t wc = c1 - c0, wcMax = (W + world - 1) / world;
+            uint64_t* pack = shardScratch(nLoc * W + N * wcMax + NExtended * wcMax + neLoc * W);
+            uint64_t *colb = pack + nLoc * W, *extb = colb + N * wcMax, *rowb = extb + NExtended * wcMax;
+            std::vector<uint64_t*> rp(world), sp(world);
+            std::vector<const uint64_t*> spc(world);
+            std::vector<uint64_t> rw(world), sw(world);
+            // rows -> columns: block p = my rows of rank p's columns, packed; what arrives from p is rows [p nLoc, (p + 1) nLoc) of my columns
+            uint64_t o = 0;
+            for (int p_ = 0; p_ < world; p_++) {
+                uint64_t a, b; colSpan(W, p_, a, b);
+                sp[p_] = pack + o; sw[p_] = nLoc * (b - a);
+                if (b > a) XLP_CHECK(xlp_dev_copy_cols(sp[p_], b - a, section(sn) + a, W, nLoc, (uint32_t)(b - a)));
+                o += sw[p_];
+                rp[p_] = colb + (uint64_t)p_ * nLoc * wc; rw[p_] = nLoc * wc;
+            }
+            for (int p_ = 0; p_ < world; p_++) spc[p_] = sp[p_];
+            XLP_CHECK(xlp_comm_exchange(rp.data(), rw.data(), spc.data(), sw.data()));
+            if (wc) XLP_CHECK(xlp_dev_extend(extb, colb, NExtended, N, wc, NULL));
+            // columns -> rows: the rows destined to rank p are contiguous in extb; what arrives from p is its columns of my rows
+            o = 0;
+            for (int p_ = 0; p_ < world; p_++) {
+                uint64_t a, b; colSpan(W, p_, a, b);
+                spc[p_] = extb + (uint64_t)p_ * neLoc * wc; sw[p_] = neLoc * wc;
+                rp[p_] = rowb + o; rw[p_] = neLoc * (b - a);
+                o += rw[p_];
+            }
+            XLP_CHECK(xlp_comm_exchange(rp.data(), rw.data(), spc.data(), sw.data()));
+            for (int p_ = 0; p_ < world; p_++) {
+                uint64_t a, b; colSpan(W, p_, a, b);
+                if (b > a) XLP_CHECK(xlp_dev_copy_cols(section(s2) + a, W, rp[p_], b - a, neLoc, (uint32_t)(b - a)));
+            }
+        }
+        tree->merkelize();                                    // my sub-tree + the cap
+        fillHalo(s2);
+    }
+    void runStep(Steps* steps, int k, StepsParams& P, uint64_t rows)
+    {
+        switch (k) {
+        case 0: steps->step2prev_parser_first_avx(P, rows, nrowsStepBatch); break;
+        case 1: steps->step3prev_parser_first_avx(P, rows, nrowsStepBatch); break;
+        case 2: steps->step3_parser_first_avx(P, rows, nrowsStepBatch); break;
+        case 3: steps->step42ns_parser_first_avx(P, rows, nrowsStepBatch); break;
+        default: steps->step52ns_parser_first_avx(P, rows, nrowsStepBatch); break;
+        }
+        haloWriteback(steps->nextRowStores(k));
+    }
+
+    // Starks::genProof (starks.cpp:9-404) on this rank's rows; the stage order, timer names and transcript sequence are genProof's.
+    void genProofSharded(typename H::Proof& proof, Goldilocks::Element* publicInputs, Goldilocks::Element verkey[4], Steps* steps)
+    {
+        lastTimers.clear();
+        if (XlpDeviceSlab::get().reserve(slabWords) == NULL) xlp_exit_process("Starks: no device slab");
+        const eSection secs2ns[4] = {cm1_2ns, cm2_2ns, cm3_2ns, cm4_2ns};
+        for (int i = 0; i < 4; i++) treesGL[i]->d_source = section(secs2ns[i]);
+        treesGL[4]->d_source = constPols2ns();
+        const uint64_t W1 = starkInfo.mapSectionsN.section[cm1_n];
+        uint64_t numCommited = starkInfo.nCm1;
+        typename H::TranscriptT transcript;
+        std::vector<Goldilocks::Element> challenges(NUM_CHALLENGES * FIELD_EXTENSION, Goldilocks::zero());
+        std::vector<Goldilocks::Element> evals(starkInfo.evMap.size() * FIELD_EXTENSION, Goldilocks::zero());
+        typename H::Root root0, root1, root2, root3;
+        auto challenge = [&](int k) {
+            H::getField(transcript, &challenges[k * FIELD_EXTENSION]);
+            XLP_CHECK(xlp_copy_h2d(d_challenges, challenges.data(), challenges.size() * sizeof(uint64_t)));
+        };
+        {
+            const uint64_t from = starkInfo.mapOffsets.section[cm2_n], to = starkInfo.mapOffsets.section[tmpExp_n] + (nLoc + haloN) * starkInfo.mapSectionsN.section[tmpExp_n];
+            if (to > from && to <= slabWords) XLP_CHECK(xlp_dev_memset(mem() + from, 0, (to - from) * sizeof(uint64_t)));
+        }
+        XLP_CHECK(xlp_copy_h2d(d_publics, publicInputs, starkInfo.nPublics * sizeof(uint64_t)));
+        H::putVerkey(transcript, verkey, constRoot);
+        transcript.put(&publicInputs[0], starkInfo.nPublics);
+        StepsParams P = params();
+        //-------------------------------- 1.- my rows of the witness (pAddress holds THEM), halo, commit
+        {
+            Timer t(this, "STARK_STEP_1_LDE_AND_MERKLETREE");
+            const uint64_t* h_cm1 = (const uint64_t*)pAddress + starkInfo.mapOffsets.section[cm1_n];
+            XLP_CHECK(xlp_copy_h2d(section(cm1_n), h_cm1, nLoc * W1 * sizeof(uint64_t)));
+            fillHalo(cm1_n);
+            commitSharded(treesGL[0], cm1_n, cm1_2ns);
+            treesGL[0]->getRoot(root0);
+            H::putRoot(transcript, root0);
+        }
+        //-------------------------------- 2.- plookups
+        challenge(0);
+        challenge(1);
+        {
+            Timer t(this, "STARK_STEP_2_CALCULATE_EXPS");
+            runStep(steps, 0, P, nLoc);
+        }
+        {
+            // calculateH1H2 is a global sort-merge of f into t; both are small next to the trace (2 x N x dim words per lookup), so the
+            // table is all-gathered and every rank computes the whole h1 / h2 and keeps its rows
+            Timer t(this, "STARK_STEP_2_CALCULATEH1H2");
+            for (uint64_t i = 0; i < starkInfo.puCtx.size(); i++) {
+                const PolRef f = pol(exp2pol(starkInfo.puCtx[i].fExpId)), tt = pol(exp2pol(starkInfo.puCtx[i].tExpId));
+                const PolRef h1 = pol(starkInfo.cm_n[numCommited + i * 2]), h2 = pol(starkInfo.cm_n[numCommited + i * 2 + 1]);
+                if (f.dim != tt.dim || h1.dim != f.dim || h2.dim != f.dim) xlp_exit_process("Starks: plookup polynomials of different dimensions");
+                const uint64_t d = f.dim;
+                uint64_t *tLoc = d_work, *tFull = d_work + N * 3, *fFull = d_work + 2 * N * 3, *hh1 = d_work + 3 * N * 3, *hh2 = d_work + 4 * N * 3, *fLoc = d_work + 5 * N * 3;
+                XLP_CHECK(xlp_dev_copy_cols(tLoc, d, tt.p, tt.stride, nLoc, (uint32_t)d));
+                XLP_CHECK(xlp_comm_all_gather(tFull, tLoc, nLoc * d));
+                if (config.xlpSyntheticLookups) XLP_CHECK(xlp_dev_gather_rows(fFull, tFull, d, N, (uint32_t)d, 0x5EED0500ULL + i));
+                else {
+                    XLP_CHECK(xlp_dev_copy_cols(fLoc, d, f.p, f.stride, nLoc, (uint32_t)d));
+                    XLP_CHECK(xlp_comm_all_gather(fFull, fLoc, nLoc * d));
+                }
+                XLP_CHECK(xlp_dev_calculate_h1h2(hh1, hh2, fFull, tFull, N, (uint32_t)d));
+                XLP_CHECK(xlp_dev_copy_cols(h1.p, h1.stride, hh1 + row0 * d, d, nLoc, (uint32_t)d));
+                XLP_CHECK(xlp_dev_copy_cols(h2.p, h2.stride, hh2 + row0 * d, d, nLoc, (uint32_t)d));
+            }
+            numCommited += starkInfo.puCtx.size() * 2;
+        }
+        fillHalo(tmpExp_n); fillHalo(cm2_n); fillHalo(cm3_n);
+        {
+            Timer t(this, "STARK_STEP_2_LDE_AND_MERKLETREE");
+            commitSharded(treesGL[1], cm2_n, cm2_2ns);
+            treesGL[1]->getRoot(root1);
+            H::putRoot(transcript, root1);
+        }
+        //-------------------------------- 3.- grand products
+        challenge(2);
+        challenge(3);
+        {
+            Timer t(this, "STARK_STEP_3_CALCULATE_EXPS");
+            runStep(steps, 1, P, nLoc);
+        }
+        {
+            // calculateZ (polinomial.hpp:586-607) is an exclusive prefix product over the rows: a local scan over my rows AND one more (the
+            // extra output, in the halo row, is the product of all my ratios; what is read there does not enter it), one all-gather of
+            // that Fp^3 element, and a scaling of my rows by the product of the ranks before me
+            Timer t(this, "STARK_STEP_3_CALCULATE_Z");
+            std::vector<std::pair<uint64_t, uint64_t>> nd;
+            for (const PuCtx& c : starkInfo.puCtx) nd.emplace_back(c.numId, c.denId);
+            for (const PeCtx& c : starkInfo.peCtx) nd.emplace_back(c.numId, c.denId);
+            for (const CiCtx& c : starkInfo.ciCtx) nd.emplace_back(c.numId, c.denId);
+            std::vector<uint64_t> totals(3 * nd.size()), allTotals((size_t)world * 3 * nd.size());
+            for (uint64_t i = 0; i < nd.size(); i++) {
+                const PolRef num = pol(exp2pol(nd[i].first)), den = pol(exp2pol(nd[i].second)), z = pol(starkInfo.cm_n[numCommited + i]);
+                if (num.dim != 3 || den.dim != 3 || z.dim != 3) xlp_exit_process("Starks: Z polynomials must be ext-3");
+                XLP_CHECK(xlp_dev_calculate_z_strided(z.p, z.stride, num.p, num.stride, den.p, den.stride, nLoc + 1));
+                XLP_CHECK(xlp_copy_d2h(&totals[3 * i], z.p + nLoc * z.stride, 3 * sizeof(uint64_t)));
+            }
+            if (!nd.empty()) XLP_CHECK(xlp_comm_all_gather_host(allTotals.data(), totals.data(), totals.size()));
+            for (uint64_t i = 0; i < nd.size() && rank > 0; i++) {
+                Goldilocks3::Element prefix;
+                Goldilocks3::one(prefix);
+                for (int r = 0; r < rank; r++) {
+                    Goldilocks3::Element tr_ = {Goldilocks::fromU64(allTotals[(size_t)r * totals.size() + 3 * i]), Goldilocks::fromU64(allTotals[(size_t)r * totals.size() + 3 * i + 1]),
+                                                Goldilocks::fromU64(allTotals[(size_t)r * totals.size() + 3 * i + 2])};
+                    Goldilocks3::mul(prefix, prefix, tr_);
+                }
+                const uint64_t pw[3] = {Goldilocks::toU64(prefix[0]), Goldilocks::toU64(prefix[1]), Goldilocks::toU64(prefix[2])};
+                const PolRef z = pol(starkInfo.cm_n[numCommited + i]);
+                XLP_CHECK(xlp_dev_scale3_strided(z.p, z.stride, nLoc, pw));
+            }
+        }
+        fillHalo(tmpExp_n); fillHalo(cm3_n);
+        {
+            Timer t(this, "STARK_STEP_3_CALCULATE_EXPS_2");
+            runStep(steps, 2, P, nLoc);
+        }
+        {
+            Timer t(this, "STARK_STEP_3_LDE_AND_MERKLETREE");
+            commitSharded(treesGL[2], cm3_n, cm3_2ns);
+            treesGL[2]->getRoot(root2);
+            H::putRoot(transcript, root2);
+        }
+        //-------------------------------- 4. the quotient: qDim columns, all-gathered and transformed on every rank; my rows of cm4_2ns kept
+        challenge(4);
+        {
+            Timer t(this, "STARK_STEP_4_CALCULATE_EXPS_2NS");
+            runStep(steps, 3, P, neLoc);
+        }
+        const uint64_t W4 = starkInfo.qDim * starkInfo.qDeg;
+        {
+            Timer t(this, "STARK_STEP_4_CALCULATE_EXPS_2NS_INTT_MUL_NTT");
+            uint64_t *qfull = d_work, *qq2 = d_work + NExtended * starkInfo.qDim;
+            XLP_CHECK(xlp_comm_all_gather(qfull, section(q_2ns), neLoc * starkInfo.qDim));
+            XLP_CHECK(xlp_dev_ntt(qfull, qfull, NExtended, starkInfo.qDim, 1));
+            const Goldilocks::Element shiftIn = Goldilocks::exp(Goldilocks::inv(Goldilocks::shift()), N);
+            XLP_CHECK(xlp_dev_q_split(qq2, qfull, N, NExtended, (uint32_t)starkInfo.qDeg, (uint32_t)starkInfo.qDim, Goldilocks::toU64(shiftIn)));
+            XLP_CHECK(xlp_dev_ntt(qq2, qq2, NExtended, W4, 0));
+            XLP_CHECK(xlp_dev_copy_cols(section(cm4_2ns), W4, qq2 + ext0 * W4, W4, neLoc, (uint32_t)W4));
+        }
+        {
+            Timer t(this, "STARK_STEP_4_MERKLETREE");
+            treesGL[3]->merkelize();
+            fillHalo(cm4_2ns);
+            treesGL[3]->getRoot(root3);
+            H::putRoot(transcript, root3);
+        }
+        //-------------------------------- 5. evaluations and the FRI polynomial
+        challenge(7);
+        const Goldilocks::Element* xi = &challenges[7 * FIELD_EXTENSION];
+        uint64_t wxi[3];
+        {
+            Timer t(this, "STARK_STEP_5_LEv_LpEv");        // replicated: N x 3 words each
+            const Goldilocks::Element sinv = Goldilocks::inv(Goldilocks::shift()), wN = Goldilocks::w(starkInfo.starkStruct.nBits);
+            uint64_t xis[3], wxis[3];
+            const uint64_t first[3] = {1, 0, 0};
+            for (int c = 0; c < 3; c++) {
+                xis[c] = Goldilocks::toU64(Goldilocks::mul(xi[c], sinv));
+                wxi[c] = Goldilocks::toU64(Goldilocks::mul(xi[c], wN));
+                wxis[c] = Goldilocks::toU64(Goldilocks::mul(Goldilocks::mul(xi[c], wN), sinv));
+            }
+            uint64_t *LEv = d_work, *LpEv = d_work + N * 3;
+            XLP_CHECK(xlp_dev_geometric(LEv, N, 3, first, xis));
+            XLP_CHECK(xlp_dev_geometric(LpEv, N, 3, first, wxis));
+            XLP_CHECK(xlp_dev_ntt(LEv, LEv, N, 3, 1));
+            XLP_CHECK(xlp_dev_ntt(LpEv, LpEv, N, 3, 1));
+        }
+        {
+            // evmap (starks.cpp:556-669) is a sum over the rows: my rows' partial sums, one all-gather of nev x 3 words, the field sum on the host
+            Timer t(this, "STARK_STEP_5_EVMAP");
+            std::vector<xlp_evmap_entry> ents(starkInfo.evMap.size());
+            for (size_t i = 0; i < ents.size(); i++) {
+                const EvMap& ev = starkInfo.evMap[i];
+                if (ev.type == EvMap::_const) ents[i] = {d_const_2ns_win + ev.id, starkInfo.nConstants, 1, ev.prime ? 1u : 0u};
+                else {
+                    const PolRef p = pol(ev.type == EvMap::cm ? starkInfo.cm_2ns[ev.id] : starkInfo.qs[ev.id]);
+                    ents[i] = {p.p, p.stride, (uint32_t)p.dim, ev.prime ? 1u : 0u};
+                }
+            }
+            XLP_CHECK(xlp_dev_evmap(d_evals, d_work + 3 * row0, d_work + N * 3 + 3 * row0, nLoc, (uint32_t)extendBits, (uint32_t)ents.size(), ents.data()));
+            std::vector<uint64_t> part(evals.size()), all((size_t)world * evals.size());
+            XLP_CHECK(xlp_copy_d2h(part.data(), d_evals, part.size() * sizeof(uint64_t)));
+            XLP_CHECK(xlp_comm_all_gather_host(all.data(), part.data(), part.size()));
+            for (size_t k = 0; k < evals.size(); k++) {
+                Goldilocks::Element acc = Goldilocks::zero();
+                for (int r = 0; r < world; r++) acc = Goldilocks::add(acc, Goldilocks::fromU64(all[(size_t)r * evals.size() + k]));
+                evals[k] = acc;
+            }
+            XLP_CHECK(xlp_copy_h2d(d_evals, evals.data(), evals.size() * sizeof(uint64_t)));
+        }
+        for (uint64_t i = 0; i < starkInfo.evMap.size(); i++) transcript.put(&evals[i * FIELD_EXTENSION], 3);
+        challenge(5);
+        challenge(6);
+        {
+            Timer t(this, "STARK_STEP_5_XDIVXSUB");
+            XLP_CHECK(xlp_dev_x_div_x_sub_xi(d_xdx, d_x_2ns, xlp_raw(xi), neLoc));
+            XLP_CHECK(xlp_dev_x_div_x_sub_xi(d_xdwx, d_x_2ns, wxi, neLoc));
+        }
+        {
+            Timer t(this, "STARK_STEP_5_CALCULATE_EXPS");
+            runStep(steps, 4, P, neLoc);
+        }
+        {
+            // FRI on the gathered polynomial (3 columns), on every rank: every rank follows the transcript and ends with the whole proof;
+            // the step-0 openings of the four sharded trees come from the ranks that own the rows (MerkleTreeGL::getGroupProofs)
+            Timer t(this, "STARK_STEP_FRI");
+            XLP_CHECK(xlp_comm_all_gather(d_work, section(f_2ns), neLoc * FIELD_EXTENSION));
+            Polinomial friPol(NExtended >> (starkInfo.starkStruct.nBitsExt - starkInfo.starkStruct.steps.back().nBits), FIELD_EXTENSION, "friPol");
+            H::Prove::prove(proof, treesGL, transcript, friPol, starkInfo.starkStruct.nBitsExt, starkInfo, d_work);
+        }
+        proof.proofs.setEvals(evals.data());
+        H::storeRoots(proof, root0, root1, root2, root3);
+    }
+
 public:
     StarksT(const Config& config, StarkFiles starkFiles, void* _pAddress)
         : config(config), starkInfo(starkFiles.zkevmStarkInfo), nrowsStepBatch(1), starkFiles(starkFiles), N(0), NExtended(0), extendBits(0), pAddress(_pAddress)
@@ -196,12 +544,26 @@ public:
         const2nsInSlab = starkInfo.xlpConst2nsInSlab; const2nsOffset = starkInfo.xlpConst2nsOffset;
         slabWords = starkInfo.mapTotalN;
         XlpDeviceSlab::get().reserve(slabWords);
-        // ---- constant polynomials (LOAD_CONST_POLS_TO_MEMORY, starks.hpp:96-115)
+        if (starkInfo.xlpWorld) {                         // a window starkinfo: this Starks is one rank of a row-sharded proof
+            if constexpr (!H::kShardable) xlp_exit_process("Starks: this hash policy has no row-sharded tree");
+            world = xlp_comm_world(); rank = xlp_comm_rank();
+            if ((uint64_t)world != starkInfo.xlpWorld) xlp_exit_process("Starks: the starkinfo is laid out for another number of ranks (xlp_comm_init first; \"xlp\".world)");
+            sharded = true;
+            nLoc = N / world; neLoc = NExtended / world; haloN = starkInfo.xlpHaloN; haloExt = starkInfo.xlpHaloExt;
+            row0 = (uint64_t)rank * nLoc; ext0 = (uint64_t)rank * neLoc;
+            if (nLoc < haloN || haloExt != (haloN << extendBits)) xlp_exit_process("Starks: shard smaller than its halo");
+        }
+        // ---- constant polynomials (LOAD_CONST_POLS_TO_MEMORY, starks.hpp:96-115); sharded: replicated, the programs read a window of them
         if (starkFiles.zkevmConstPols.size() == 0) xlp_exit_process("Starks::Starks() received an empty config.zkevmConstPols");
-        d_const_n = dalloc(N * starkInfo.nConstants);
+        uint64_t* constFull = dalloc(N * starkInfo.nConstants);
         if (starkFiles.zkevmConstPols.rfind("synthetic:", 0) == 0)
-            XLP_CHECK(xlp_dev_fill(d_const_n, N * starkInfo.nConstants, strtoull(starkFiles.zkevmConstPols.c_str() + 10, NULL, 0), 0));
-        else fileToDevice(d_const_n, starkFiles.zkevmConstPols, 0, N * starkInfo.nConstants * sizeof(uint64_t));
+            XLP_CHECK(xlp_dev_fill(constFull, N * starkInfo.nConstants, strtoull(starkFiles.zkevmConstPols.c_str() + 10, NULL, 0), 0));
+        else fileToDevice(constFull, starkFiles.zkevmConstPols, 0, N * starkInfo.nConstants * sizeof(uint64_t));
+        if (sharded) {
+            d_const_n_full = constFull;
+            d_const_n = dalloc((nLoc + haloN) * starkInfo.nConstants);
+            windowRows(d_const_n, constFull, starkInfo.nConstants, row0, nLoc + haloN, N);
+        } else d_const_n = constFull;
         // ---- constant tree (LOAD_CONST_TREE_TO_MEMORY / LOAD_CONST_POLS_2NS_TO_MEMORY, starks.hpp:117-146)
         if (!const2nsInSlab) d_const_2ns_own = dalloc(NExtended * starkInfo.nConstants);
         treesGL[4] = new typename H::Tree(NExtended, starkInfo.nConstants, constPols2ns(), true);
@@ -223,12 +585,18 @@ public:
             treesGL[4]->merkelize();
         }
         treesGL[4]->getRoot(constRoot);
-        // ---- x_n, x_2ns (COMPUTE_X_N_AND_X_2_NS, starks.hpp:149-160), ZhInv (zhInv.cpp:7-32)
-        d_x_n = dalloc(N); d_x_2ns = dalloc(NExtended);
-        const uint64_t one = 1, wn = Goldilocks::toU64(Goldilocks::w(starkInfo.starkStruct.nBits)), sh = Goldilocks::toU64(Goldilocks::shift()),
-                       wne = Goldilocks::toU64(Goldilocks::w(starkInfo.starkStruct.nBitsExt));
-        XLP_CHECK(xlp_dev_geometric(d_x_n, N, 1, &one, &wn));
-        XLP_CHECK(xlp_dev_geometric(d_x_2ns, NExtended, 1, &sh, &wne));
+        if (sharded) {                                    // the extended constants and their tree are replicated; the 2ns programs read my window
+            d_const_2ns_win = dalloc((neLoc + haloExt) * starkInfo.nConstants);
+            windowRows(d_const_2ns_win, constPols2ns(), starkInfo.nConstants, ext0, neLoc + haloExt, NExtended);
+        }
+        // ---- x_n, x_2ns (COMPUTE_X_N_AND_X_2_NS, starks.hpp:149-160), ZhInv (zhInv.cpp:7-32); sharded: my rows of them
+        const uint64_t ownN = sharded ? nLoc : N, ownE = sharded ? neLoc : NExtended;
+        d_x_n = dalloc(ownN); d_x_2ns = dalloc(ownE);
+        const Goldilocks::Element wnE = Goldilocks::w(starkInfo.starkStruct.nBits), wneE = Goldilocks::w(starkInfo.starkStruct.nBitsExt);
+        const uint64_t one = Goldilocks::toU64(Goldilocks::exp(wnE, row0)), wn = Goldilocks::toU64(wnE),
+                       sh = Goldilocks::toU64(Goldilocks::mul(Goldilocks::shift(), Goldilocks::exp(wneE, ext0))), wne = Goldilocks::toU64(wneE);
+        XLP_CHECK(xlp_dev_geometric(d_x_n, ownN, 1, &one, &wn));
+        XLP_CHECK(xlp_dev_geometric(d_x_2ns, ownE, 1, &sh, &wne));
         {
             std::vector<uint64_t> zh(1ULL << extendBits);
             Goldilocks::Element sn = Goldilocks::shift(), w = Goldilocks::one();
@@ -240,20 +608,23 @@ public:
             d_zi = dalloc(zh.size());
             XLP_CHECK(xlp_copy_h2d(d_zi, zh.data(), zh.size() * sizeof(uint64_t)));
         }
-        d_xdx = dalloc(NExtended * FIELD_EXTENSION); d_xdwx = dalloc(NExtended * FIELD_EXTENSION);
+        d_xdx = dalloc(ownE * FIELD_EXTENSION); d_xdwx = dalloc(ownE * FIELD_EXTENSION);
         d_challenges = dalloc(NUM_CHALLENGES * FIELD_EXTENSION);
         d_publics = dalloc(starkInfo.nPublics);
         d_evals = dalloc(starkInfo.evMap.size() * FIELD_EXTENSION);
         d_work = dalloc(NExtended * (uint64_t)std::max<uint64_t>(4 * FIELD_EXTENSION, starkInfo.qDim * (starkInfo.qDeg + 1)));
         // ---- trees over the extended sections (MERKLE_TREE_ALLOCATION, starks.hpp:185-191): sources are offsets into the shared slab
         const eSection secs[4] = {cm1_2ns, cm2_2ns, cm3_2ns, cm4_2ns};
-        for (int i = 0; i < 4; i++) treesGL[i] = new typename H::Tree(NExtended, starkInfo.mapSectionsN.section[secs[i]], NULL, true);
+        for (int i = 0; i < 4; i++) {
+            if constexpr (H::kShardable) treesGL[i] = new typename H::Tree(NExtended, starkInfo.mapSectionsN.section[secs[i]], NULL, true, sharded ? world : 0, rank);
+            else treesGL[i] = new typename H::Tree(NExtended, starkInfo.mapSectionsN.section[secs[i]], NULL, true);
+        }
     }
     ~StarksT()
     {
         if (!config.generateProof()) return;
         for (int i = 0; i < 5; i++) delete treesGL[i];
-        uint64_t* all[] = {d_const_n, d_const_2ns_own, d_x_n, d_x_2ns, d_zi, d_xdx, d_xdwx, d_challenges, d_publics, d_evals, d_work};
+        uint64_t* all[] = {d_const_n, d_const_2ns_own, d_x_n, d_x_2ns, d_zi, d_xdx, d_xdwx, d_challenges, d_publics, d_evals, d_work, d_const_n_full, d_const_2ns_win, d_shard};
         for (uint64_t* p : all) xlp_dev_free(p);
     }
     StarksT(const StarksT&) = delete;
@@ -262,6 +633,10 @@ public:
 
     void genProof(typename H::Proof& proof, Goldilocks::Element* publicInputs, Goldilocks::Element verkey[4], Steps* steps)
     {
+        if (sharded) {
+            if constexpr (H::kShardable) genProofSharded(proof, publicInputs, verkey, steps);
+            return;
+        }
         lastTimers.clear();
         if (XlpDeviceSlab::get().reserve(slabWords) == NULL) xlp_exit_process("Starks: no device slab");
         const eSection secs2ns[4] = {cm1_2ns, cm2_2ns, cm3_2ns, cm4_2ns};

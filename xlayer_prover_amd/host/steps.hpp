@@ -11,10 +11,15 @@
 
 typedef xlp_steps_params StepsParams;
 
+// a program's stores to NEXT rows (zkEVM step3prev / step3 have a few): in a row-sharded run the rows written past a rank's last row belong
+// to the next rank (host/starks.hpp haloWriteback).  section: eSection; columns [col, col + cols); next: the row distance
+struct NextRowStore { int section; uint64_t col, cols, next; };
+
 class Steps
 {
 public:
     virtual ~Steps() {}
+    virtual const std::vector<NextRowStore>& nextRowStores(int /*0 step2prev .. 4 step52ns*/) const { static const std::vector<NextRowStore> none; return none; }
     // nrowsBatch is the reference's SIMD batch (4 / 8 rows, starks.cpp:70-80); one row per lane here, so it is ignored
     virtual void step2prev_parser_first_avx(StepsParams& params, uint64_t nrows, uint64_t nrowsBatch) = 0;
     virtual void step3prev_parser_first_avx(StepsParams& params, uint64_t nrows, uint64_t nrowsBatch) = 0;
@@ -38,6 +43,7 @@ class XlpSteps : public Steps
         uint64_t* ext = NULL;                // device, 3 * n_ext words: challenges 0..7, then the table
         uint64_t n_ext = 0;
         std::vector<DotSpec> dots;
+        std::vector<NextRowStore> stores;    // manifest "nextRowStores" (bundles of a row-sharded proof)
         uint64_t ngroups = 0;
         uint64_t* dotOut = NULL;             // device, nrows x 3 x ngroups (allocated at the first run)
         uint64_t dotOutWords = 0;
@@ -152,6 +158,12 @@ public:
                     for (uint64_t i = 0; i < w[2]; i++) s.dots.push_back({w[3 + 6 * i], w[4 + 6 * i], w[5 + 6 * i], w[6 + 6 * i], w[7 + 6 * i], w[8 + 6 * i]});
                     s.mode = "table program + dot_columns (" + std::to_string(s.dots.size()) + " entries) + row program";
                 }
+                if (e.contains("nextRowStores"))
+                    for (const xlp_json::Value& v : e["nextRowStores"].a) {
+                        NextRowStore st;
+                        st.section = (int)string2section(v[(size_t)0].str()); st.col = v[(size_t)1]; st.cols = v[(size_t)2]; st.next = v[(size_t)3];
+                        s.stores.push_back(st);
+                    }
                 if (s.n_ext) allocExt(s);
                 attach(s.prog, str(e, "plugin"), s.mode);
                 if (s.tab) { std::string m; attach(s.tab, str(e, "tab_plugin"), m); }
@@ -181,6 +193,7 @@ public:
             if (step_[k].dotOut) xlp_dev_free(step_[k].dotOut);
         }
     }
+    const std::vector<NextRowStore>& nextRowStores(int k) const override { return step_[k].stores; }
     bool optimised(int k) const { return step_[k].n_ext != 0; }
     const std::string& mode(int k) const { return step_[k].mode; }
     XlpSteps(const XlpSteps&) = delete;

@@ -122,10 +122,14 @@ static int genproof_mode(const std::string& dir, const std::string& name, bool t
     return 0;
 }
 
-// `bundle <dir> <name> <witness seed> <const seed> [timers]`: one STARK from a bundle of tools/make_stark_bundle.py (synthesized
-// starkinfo + relocated reference programs) on a synthetic witness left in page-locked host memory, synthetic constants and
-// synthetic plookup selectors -- the inputs of tools/bench_zkevm_genproof.py, so that the two drivers must print the same proof
-static int bundle_mode(const std::string& dir, const std::string& name, uint64_t wseed, uint64_t cseed, bool timers)
+// `bundle <dir> <name> <witness seed> <const seed> [timers] [--world G --rank r --backend rccl|shm --rendezvous <file | name>]`: one STARK from a
+// bundle of tools/make_stark_bundle.py (synthesized starkinfo + relocated reference programs) on a synthetic witness left in page-locked
+// host memory, synthetic constants and synthetic plookup selectors -- the inputs of tools/bench_zkevm_genproof.py, so that the two drivers
+// must print the same proof.  With --world the bundle must be the per-rank window bundle of that world (make_stark_bundle.py --world G):
+// this process is rank r of a row-sharded proof (host/starks.hpp), its host slab holds ITS rows of the same synthetic witness, and rank 0
+// prints the proof, which must equal the one-GPU proof bit for bit.
+static int bundle_mode(const std::string& dir, const std::string& name, uint64_t wseed, uint64_t cseed, bool timers, int world, int rank,
+                       const std::string& backend, const std::string& rendezvous)
 {
     Config config;
     config.runFileGenBatchProof = true;
@@ -136,12 +140,14 @@ static int bundle_mode(const std::string& dir, const std::string& name, uint64_t
     const uint64_t N = 1ULL << si.starkStruct.nBits, W = si.mapSectionsN.section[cm1_n];
     void* host = NULL;
     XLP_CHECK(xlp_init(0));
-    XLP_CHECK(xlp_host_alloc(&host, (N * W > 0 ? N * W : 1) * 8));
+    if (world) XLP_CHECK(xlp_comm_init(rank, world, backend.empty() ? NULL : backend.c_str(), rendezvous.empty() ? NULL : rendezvous.c_str()));
+    const uint64_t rows = world ? N / world : N, first = world ? rows * rank : 0;     // my rows of the witness
+    XLP_CHECK(xlp_host_alloc(&host, (rows * W > 0 ? rows * W : 1) * 8));
     {
         void* d = NULL;
-        XLP_CHECK(xlp_dev_alloc(&d, N * W * 8));
-        XLP_CHECK(xlp_dev_fill((uint64_t*)d, N * W, wseed, 0));
-        XLP_CHECK(xlp_copy_d2h(host, d, N * W * 8));
+        XLP_CHECK(xlp_dev_alloc(&d, rows * W * 8));
+        XLP_CHECK(xlp_dev_fill((uint64_t*)d, rows * W, wseed, first * W));
+        XLP_CHECK(xlp_copy_d2h(host, d, rows * W * 8));
         XLP_CHECK(xlp_dev_free(d));
     }
     {
@@ -154,11 +160,20 @@ static int bundle_mode(const std::string& dir, const std::string& name, uint64_t
         std::vector<Goldilocks::Element> publics(starks.starkInfo.nPublics);
         for (uint64_t i = 0; i < publics.size(); i++) publics[i] = Goldilocks::fromU64(i + 1);
         for (uint64_t i = 0; i < publics.size(); i++) proof.publics[i] = publics[i];
+        if (world) XLP_CHECK(xlp_comm_stats(NULL, NULL, NULL, 1 | 2));
         starks.genProof(proof, publics.data(), starks.constRoot, &steps);
         fprintf(stderr, "witness upload busy %.3f ms\n", starks.lastUploadMs);
-        const std::string out = zkinWithPublics(starks, proof);
-        fwrite(out.data(), 1, out.size(), stdout);
-        printf("\n");
+        if (world) {
+            double sec = 0; uint64_t bytes = 0, calls = 0;
+            XLP_CHECK(xlp_comm_stats(&sec, &bytes, &calls, 4));
+            fprintf(stderr, "rank %d of %d: %llu exchanges, %.3f GB sent to peers in %.4f s\n", rank, world, (unsigned long long)calls, bytes / 1e9, sec);
+        }
+        if (!world || rank == 0) {
+            const std::string out = zkinWithPublics(starks, proof);
+            fwrite(out.data(), 1, out.size(), stdout);
+            printf("\n");
+        }
+        if (world) XLP_CHECK(xlp_comm_barrier());
     }
     XlpDeviceSlab::get().release();
     XLP_CHECK(xlp_host_free(host));
@@ -289,8 +304,19 @@ int main(int argc, char** argv)
     if (argc == 4 && std::string(argv[1]) == "genproof_bn128") { const int r = genproof_bn128_mode(argv[2], argv[3]); XlpDeviceSlab::get().release(); xlp_shutdown(); return r; }
     if (argc == 5 && std::string(argv[1]) == "bn128") { const int r = bn128_mode(strtoull(argv[2], 0, 10), strtoull(argv[3], 0, 10), strtoull(argv[4], 0, 0)); xlp_shutdown(); return r; }
     if ((argc == 4 || argc == 5) && std::string(argv[1]) == "genproof") { const int r = genproof_mode(argv[2], argv[3], argc == 5); XlpDeviceSlab::get().release(); xlp_shutdown(); return r; }
-    if ((argc == 6 || argc == 7) && std::string(argv[1]) == "bundle") {
-        const int r = bundle_mode(argv[2], argv[3], strtoull(argv[4], 0, 0), strtoull(argv[5], 0, 0), argc == 7);
+    if (argc >= 6 && std::string(argv[1]) == "bundle") {
+        bool timers = false;
+        int world = 0, rank = 0;
+        std::string backend, rendezvous;
+        for (int i = 6; i < argc; i++) {
+            const std::string a = argv[i];
+            if (a == "--world" && i + 1 < argc) world = atoi(argv[++i]);
+            else if (a == "--rank" && i + 1 < argc) rank = atoi(argv[++i]);
+            else if (a == "--backend" && i + 1 < argc) backend = argv[++i];
+            else if (a == "--rendezvous" && i + 1 < argc) rendezvous = argv[++i];
+            else timers = true;
+        }
+        const int r = bundle_mode(argv[2], argv[3], strtoull(argv[4], 0, 0), strtoull(argv[5], 0, 0), timers, world, rank, backend, rendezvous);
         xlp_shutdown();
         return r;
     }

@@ -196,10 +196,43 @@ public:
     uint64_t* d_source = NULL;
     uint64_t* d_nodes = NULL;
     bool ownsDevNodes = false;
-    MerkleTreeGL(uint64_t _height, uint64_t _width, uint64_t* dSource, bool /*deviceTag*/) : height(_height), width(_width), source(NULL), nodes(NULL), d_source(dSource)
+    // Row-sharded form (host/starks.hpp, sharded mode): `height` stays the GLOBAL number of rows; this rank holds the
+    // sub-tree over ITS height / shardWorld rows (d_source, d_nodes) -- its root is node (level log2(height / world), rank) of the
+    // reference's tree -- and every rank holds the cap: the levels over the `world` sub-roots (32 bytes per rank all-gathered).
+    // getRoot / getGroupProofs answer for the GLOBAL tree on every rank (an opening is made by the rank that owns the row and shared).
+    int shardRank = 0, shardWorld = 0;                         // shardWorld == 0: an ordinary tree
+    std::vector<std::vector<uint64_t>> capLevels;              // [sub-roots (world x 4)], ..., [root (4)]
+    MerkleTreeGL(uint64_t _height, uint64_t _width, uint64_t* dSource, bool /*deviceTag*/, int world = 0, int rank = 0)
+        : height(_height), width(_width), source(NULL), nodes(NULL), d_source(dSource), shardRank(rank), shardWorld(world)
     {
-        XLP_CHECK(xlp_dev_alloc((void**)&d_nodes, (getTreeNumElements() ? getTreeNumElements() : 1) * sizeof(uint64_t)));
+        if (world && (_height % (uint64_t)world || rank < 0 || rank >= world)) xlp_exit_process("MerkleTreeGL: rows do not divide over the ranks");
+        const uint64_t words = MerklehashGoldilocks::getTreeNumElements(localHeight());
+        XLP_CHECK(xlp_dev_alloc((void**)&d_nodes, (localHeight() ? words : 1) * sizeof(uint64_t)));
         ownsDevNodes = true;
+    }
+    uint64_t localHeight() const { return shardWorld ? height / (uint64_t)shardWorld : height; }
+    // the cap over the sub-roots: one all-gather of 4 words per rank, then world - 1 node hashes on every rank
+    void assembleCap()
+    {
+        const uint64_t lh = localHeight(), words = MerklehashGoldilocks::getTreeNumElements(lh);
+        uint64_t sub[HASH_SIZE];
+        XLP_CHECK(xlp_copy_d2h(sub, d_nodes + words - HASH_SIZE, sizeof sub));
+        std::vector<uint64_t> lvl((size_t)shardWorld * HASH_SIZE);
+        XLP_CHECK(xlp_comm_all_gather_host(lvl.data(), sub, HASH_SIZE));
+        capLevels.clear();
+        capLevels.push_back(lvl);
+        while (capLevels.back().size() > HASH_SIZE) {
+            const std::vector<uint64_t>& cur = capLevels.back();
+            std::vector<uint64_t> nxt(cur.size() / 2);
+            for (size_t k = 0; k < nxt.size() / HASH_SIZE; k++) {
+                uint64_t in[12], out[12];
+                for (int i = 0; i < 8; i++) in[i] = cur[8 * k + i];
+                in[8] = in[9] = in[10] = in[11] = 0;
+                XLP_CHECK(xlp_perm(out, in));
+                for (int i = 0; i < HASH_SIZE; i++) nxt[HASH_SIZE * k + i] = out[i];
+            }
+            capLevels.push_back(nxt);
+        }
     }
     MerkleTreeGL() : height(0), width(0), source(NULL), nodes(NULL) {}
     // file-backed layout [width, height, source(height*width), nodes] (build_const_tree.cpp:566-603)
@@ -230,12 +263,18 @@ public:
     void copySource(Goldilocks::Element* _source) { std::memcpy(source, _source, height * width * sizeof(Goldilocks::Element)); }
     void merkelize()
     {
+        if (d_nodes && shardWorld) { XLP_CHECK(xlp_dev_merkle(d_nodes, d_source, width, localHeight())); assembleCap(); return; }
         if (d_nodes) { XLP_CHECK(xlp_dev_merkle(d_nodes, d_source, width, height)); return; }
         PoseidonGoldilocks::merkletree_avx(nodes, source, width, height);
     }
     uint64_t getTreeNumElements() { return height * HASH_SIZE + (height - 1) * HASH_SIZE; }
     void getRoot(Goldilocks::Element* root)
     {
+        if (shardWorld) {
+            if (capLevels.empty()) xlp_exit_process("MerkleTreeGL::getRoot: sharded tree not merkelized");
+            std::memcpy(root, capLevels.back().data(), HASH_SIZE * sizeof(Goldilocks::Element));
+            return;
+        }
         if (d_nodes) { XLP_CHECK(xlp_copy_d2h(root, d_nodes + getTreeNumElements() - HASH_SIZE, HASH_SIZE * sizeof(Goldilocks::Element))); return; }
         std::memcpy(root, &nodes[getTreeNumElements() - HASH_SIZE], HASH_SIZE * sizeof(Goldilocks::Element));
     }
@@ -251,12 +290,48 @@ public:
     {
         const uint64_t per = width + MerkleProofSize() * HASH_SIZE;
         proofs.assign(idxs.size() * per + 1, Goldilocks::zero());
+        if (shardWorld) {
+            // the owner of row idx (idx / localHeight) opens it inside its sub-tree and appends the cap siblings; one all-gather shares them
+            const uint64_t lh = localHeight();
+            uint64_t lbits = 0;
+            while ((1ULL << lbits) < lh) lbits++;
+            const uint64_t perLocal = width + lbits * HASH_SIZE;
+            std::vector<uint64_t> mine, pos;
+            for (size_t q = 0; q < idxs.size(); q++) {
+                if (idxs[q] >= height) xlp_exit_process("MerkleTreeGL::getGroupProofs: index out of range");
+                if (idxs[q] / lh == (uint64_t)shardRank) { mine.push_back(idxs[q] % lh); pos.push_back(q); }
+            }
+            if (!mine.empty()) {
+                std::vector<uint64_t> loc(mine.size() * perLocal);
+                XLP_CHECK(xlp_dev_merkle_proofs(loc.data(), d_source, d_nodes, width, lh, mine.data(), mine.size()));
+                for (size_t k = 0; k < mine.size(); k++) {
+                    uint64_t* o = xlp_raw(&proofs[pos[k] * per]);
+                    std::memcpy(o, &loc[k * perLocal], perLocal * sizeof(uint64_t));
+                    o += perLocal;
+                    uint64_t i = (uint64_t)shardRank;
+                    for (size_t l = 0; l + 1 < capLevels.size(); l++) { std::memcpy(o, &capLevels[l][(i ^ 1) * HASH_SIZE], HASH_SIZE * sizeof(uint64_t)); o += HASH_SIZE; i >>= 1; }
+                }
+            }
+            if (shardWorld > 1) {
+                const uint64_t words = idxs.size() * per;
+                std::vector<uint64_t> all((size_t)shardWorld * words);
+                XLP_CHECK(xlp_comm_all_gather_host(all.data(), xlp_raw(proofs.data()), words));
+                for (size_t q = 0; q < idxs.size(); q++) std::memcpy(xlp_raw(&proofs[q * per]), &all[(idxs[q] / lh) * words + q * per], per * sizeof(uint64_t));
+            }
+            return;
+        }
         if (d_nodes) { XLP_CHECK(xlp_dev_merkle_proofs(xlp_raw(proofs.data()), d_source, d_nodes, width, height, idxs.data(), idxs.size())); return; }
         for (size_t q = 0; q < idxs.size(); q++) getGroupProof(&proofs[q * per], idxs[q]);
     }
     // proof = row || siblings bottom-up (merkleTreeGL.cpp:12-35)
     void getGroupProof(Goldilocks::Element* proof, uint64_t idx)
     {
+        if (shardWorld) {
+            std::vector<Goldilocks::Element> one;
+            getGroupProofs(one, std::vector<uint64_t>(1, idx));
+            std::memcpy(proof, one.data(), (width + MerkleProofSize() * HASH_SIZE) * sizeof(Goldilocks::Element));
+            return;
+        }
         if (d_nodes) {
             if (width) XLP_CHECK(xlp_copy_d2h(proof, d_source + idx * width, width * sizeof(Goldilocks::Element)));
             Goldilocks::Element* o = &proof[width];
@@ -642,6 +717,10 @@ public:
     // aliased layout, tools/zkevm_geometry.py) instead of in a buffer of their own
     bool xlpConst2nsInSlab = false;
     uint64_t xlpConst2nsOffset = 0;
+    // "xlp": {"world": G, "haloN": 1, "haloExt": 2^ext}: the sections are the per-rank WINDOWS of a proof row-sharded over G ranks
+    // (tools/zkevm_geometry.py layout_window): N / G (NExtended / G) rows followed by haloN (haloExt) rows of the next rank; mapOffsets,
+    // mapDeg and mapTotalN describe that window slab, starkStruct stays global.  0: the reference's whole-domain layout.
+    uint64_t xlpWorld = 0, xlpHaloN = 0, xlpHaloExt = 0;
 
     StarkInfo() {}                                   // synthetic runs fill starkStruct by hand
     explicit StarkInfo(const std::string& file)      // StarkInfo(config, file), stark_info.cpp:7-19
@@ -716,6 +795,10 @@ public:
         if (j.contains("xlp") && j["xlp"].contains("const2nsOffset") && !j["xlp"]["const2nsOffset"].is_null()) {
             xlpConst2nsInSlab = true;
             xlpConst2nsOffset = j["xlp"]["const2nsOffset"];
+        }
+        if (j.contains("xlp") && j["xlp"].contains("world")) {
+            xlpWorld = j["xlp"]["world"]; xlpHaloN = j["xlp"]["haloN"]; xlpHaloExt = j["xlp"]["haloExt"];
+            if (!xlpWorld || (xlpWorld & (xlpWorld - 1)) || xlpConst2nsInSlab) xlp_exit_process("StarkInfo: bad sharded (\"xlp\") layout");
         }
     }
     void getPol(void* pAddress, uint64_t idPol, PolInfo& polInfo)     // stark_info.cpp:456-464
