@@ -311,6 +311,63 @@ def child_leg(tool, tool_args, world, rank, local_rank, port_offset, backend, ti
         return {"error": repr(e)[:200] + " / " + out[-200:]}
 
 
+def genproof_sharded_cpp_leg(world, rank, local_rank, backend, log_n=23, timeout_s=600):
+    """The batch proof with the zkEVM STARK ROW-SHARDED over the ranks, through the C++ product path (BASELINE north_star):
+    one CHILD process per rank runs host/zkprover_batch --world N --rank r on the rank's GPU -- xlp_comm_init (RCCL over xGMI; "shm" =
+    host-staged for ranks sharing a GPU in rehearsals) before any other GPU work, host/starks.hpp genProofSharded on the per-rank window
+    bundle (ahead-of-time step programs), c12a / recursive1 on rank 0.  Rank 0's child prints the line; a hard timeout: no multi-GPU node
+    has ever been available to this build, so a failure on hardware it never saw costs this leg, not the bench line."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "xlayer_prover_amd", "host", "zkprover_batch")
+    bundle = os.path.join(ROOT, "xlayer_prover_amd", "chelpers", "bundles", f"zkevm.geo{log_n}w{world}")
+    built_here = False
+    if not os.path.exists(os.path.join(bundle, "zkevm.starkinfo.json")):
+        if rank == 0:                                        # (no reference tree needed: the converted programs travel with the repo)
+            try:
+                from tools import make_stark_bundle as B
+                B.make("zkevm", log_n, False, world=world)
+                built_here = True
+            except Exception as e:
+                return {"error": "no window bundle: " + repr(e)[:200]}
+    base = json.load(open(os.path.join(ROOT, "tools", "config_runFile_BatchProof_synthetic.json")))
+    base["zkevmStarkInfo"] = os.path.join(bundle, "zkevm.starkinfo.json")
+    port = int(os.environ.get("MASTER_PORT", "29500"))
+    cfg = os.path.join(tempfile.gettempdir(), f"xlp_sharded_cfg_{port}_{world}.json")
+    rdv = os.path.join(tempfile.gettempdir(), f"xlp_rccl_id_{port}_{world}_{os.getppid()}") if backend == "rccl" else f"xlp_bench_{port}_{world}"
+    if rank == 0:
+        json.dump(base, open(cfg + ".tmp", "w")); os.replace(cfg + ".tmp", cfg)
+        if backend == "rccl" and os.path.exists(rdv):
+            os.remove(rdv)
+    import torch.distributed as dist
+    if dist.is_initialized():
+        dist.barrier()                                       # config (and a bundle built just now) in place before the children start
+    cmd = [exe, "-c", cfg, "--proofs", "2", "--timers", "--world", str(world), "--rank", str(rank), "--device", str(local_rank), "--backend", backend, "--rendezvous", rdv]
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT)
+    try:
+        out, err = p.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        p.kill(); p.communicate()
+        return {"error": f"rank {rank}: no result within {timeout_s} s"}
+    if p.returncode != 0:
+        return {"error": f"rank {rank}: exit {p.returncode}: {err[-300:]}"}
+    if rank != 0:
+        return None
+    try:
+        j = json.loads(out.strip().splitlines()[-1])
+        t = j["timers_s"]
+        z = {k[len("zkevm."):]: round(v, 4) for k, v in t.items() if k.startswith("zkevm.")}
+        modes = [m.strip("[] ") for m in err.split("steps: zkevm", 1)[1].splitlines()[0].split("] [")] if "steps: zkevm" in err else None
+        return {"metric": f"genBatchProof STARK wall-clock (s), zkEVM STARK row-sharded over {world} rank(s) in the C++ Prover (host/zkprover_batch --world {world}), "
+                          "witness rows uploaded per rank inside the wall; c12a / recursive1 on rank 0",
+                "wall_s": round(j["three_starks_s"], 4), "zkevm_sharded_s": round(t["STARK_PROOF_BATCH_PROOF"], 4), "c12a_s": round(t["STARK_C12_A_PROOF_BATCH_PROOF"], 4),
+                "recursive1_s": round(t["STARK_RECURSIVE_1_PROOF_BATCH_PROOF"], 4), "zkevm_stage_timers_s_rank0": z, "sharded": j.get("sharded"), "programs": modes,
+                "window_bundle_built_in_this_run": built_here, "log_n": log_n, "recursive1_root1": j.get("recursive1_root1"),
+                "note": "no run on more than one GPU exists yet: correctness of the multi-rank path is covered by tests/test_cpp_sharded.py (ranks sharing one GPU)"}
+    except Exception as e:
+        return {"error": repr(e)[:200] + " / " + out[-200:]}
+
+
 def e2e_leg(timeout_s=300):
     """BASELINE configs[4] minus the SNARK wrap, through the C++ Prover (host/zkprover_batch --e2e): two consecutive batch proofs
     (each: zkEVM 2^23 + c12a + recursive1), Prover::genAggregatedProof (joinzkin + the recursive2 STARK) and Prover::genFinalProof up
@@ -350,6 +407,8 @@ def main():
                     "through RCCL in a world of one)")
     ap.add_argument("--sharded-genproof", type=int, default=-1, help="log2 N of the row-sharded zkEVM-geometry genProof run over the ranks "
                     "(tools/zkevm_genproof_sharded.py, one child process per rank); 0 = off; default: 20 when --gpus > 1, off on one GPU")
+    ap.add_argument("--sharded-batchproof", type=int, default=-1, help="log2 N of the batch proof with the zkEVM STARK row-sharded over the ranks through the C++ "
+                    "Prover (host/zkprover_batch --world N); 0 = off; default: 23 when --gpus > 1, off on one GPU (opt-in there: a world of one through RCCL)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the --gpus N path with the ranks SHARING GPU 0 "
                     "(exchanges staged through the host); its numbers mean nothing")
     ap.add_argument("--log-n", type=int, default=LOG_N)
@@ -427,7 +486,7 @@ def main():
         elapsed = float(tt.item())
 
     # ---- the exchange-carrying legs.  On one GPU: in this process (opt-in).  On several: one child process per rank.
-    sharded, sharded_gp = None, None
+    sharded, sharded_gp, sharded_bp = None, None, None
     gp_log_n = args.sharded_genproof if args.sharded_genproof >= 0 else (20 if world > 1 else 0)
     if world == 1 and args.sharded_commit == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29641")
@@ -450,10 +509,19 @@ def main():
         if gp_log_n:
             sharded_gp = child_leg("zkevm_genproof_sharded.py", ["--log-n", str(gp_log_n), "--check-one-gpu"], world, rank, local_rank, 23, args.backend)
             dist.barrier()
+        bp_log_n = args.sharded_batchproof if args.sharded_batchproof >= 0 else 23
+        if bp_log_n:
+            sharded_bp = genproof_sharded_cpp_leg(world, rank, local_rank, "rccl" if args.backend == "nccl" else "shm", bp_log_n)
+            dist.barrier()
     elif gp_log_n:
         src = out = None
         torch.cuda.empty_cache()
         sharded_gp = child_leg("zkevm_genproof_sharded.py", ["--log-n", str(gp_log_n), "--collectives", "--check-one-gpu"], 1, 0, local_rank, 23, "nccl")
+    if world == 1 and args.sharded_batchproof > 0:           # opt-in on one GPU: a world of one through RCCL (2^23 does not fit one GPU unaliased: pick <= 22)
+        src = out = None
+        torch.cuda.empty_cache()
+        capi.shutdown()
+        sharded_bp = genproof_sharded_cpp_leg(1, 0, local_rank, "rccl", args.sharded_batchproof)
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         fe_per_step = n_ext * ncols * world
@@ -501,6 +569,8 @@ def main():
             line["sharded_commit"] = sharded
         if sharded_gp is not None:
             line["sharded_genproof"] = sharded_gp
+        if sharded_bp is not None:
+            line["genproof_sharded_cpp"] = sharded_bp
         if world == 1:
             line["roofline_merkle"] = merkle_leg(capi, torch, dev)
             if not args.no_bn128:

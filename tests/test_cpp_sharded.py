@@ -47,14 +47,14 @@ def test_window_bundle_is_consistent(tmp_path):
     assert all(s[1] + s[2] <= W[s[0]] for s in st)
 
 
-def _run_ranks(bundle, world, backend, tmp_path, timeout=900):
-    rdv = str(tmp_path / "rccl.id") if backend == "rccl" else f"xlp_test_{os.getpid()}_{world}"
+def _run_ranks(bundle, world, backend, tmp_path, timeout=900, env=None):
+    rdv = str(tmp_path / "rccl.id") if backend == "rccl" else f"xlp_test_{os.getpid()}_{world}_{abs(hash(str(tmp_path))) % 10**8}"    # a name of its own per launch
     procs = []
     for r in range(world):
         cmd = [EXE, "bundle", bundle, "zkevm", str(WSEED), str(CSEED), "--world", str(world), "--rank", str(r)]
         if backend != "self":
             cmd += ["--backend", backend, "--rendezvous", rdv]
-        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
     outs = []
     try:
         for p in procs:
@@ -65,12 +65,14 @@ def _run_ranks(bundle, world, backend, tmp_path, timeout=900):
                 p.kill()
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r}: {se[-3000:]}"
-    return json.loads(outs[0][0]), [se for _, se in outs]
+    return json.loads(outs[0][0].strip().splitlines()[-1]), [se for _, se in outs]      # (RCCL prints a banner on stdout first)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,backend", [(1, "self"), (1, "rccl"), (2, "shm"), (4, "shm")])
-def test_cpp_sharded_starks_proof_equals_one_gpu_proof(tmp_path, world, backend):
+@pytest.mark.parametrize("world,backend,scratch_mb", [(1, "self", 0), (1, "rccl", 0), (2, "shm", 0), (4, "shm", 0), (2, "shm", 1)])
+def test_cpp_sharded_starks_proof_equals_one_gpu_proof(tmp_path, world, backend, scratch_mb):
+    """scratch_mb: the staging budget of the sharded commit (XLP_SHARD_SCRATCH_MB); 1 MiB forces the exchanges / LDE of a section into many
+    column bands (at the real size a 2-rank zkEVM section needs 7 bands to stay below 24 GB)"""
     from tools import make_stark_bundle as B
     if not _programs_built():
         pytest.skip("converted reference programs not built (needs the reference tree at build time)")
@@ -80,9 +82,56 @@ def test_cpp_sharded_starks_proof_equals_one_gpu_proof(tmp_path, world, backend)
     assert r.returncode == 0, r.stderr[-3000:]
     expect = json.loads(r.stdout)
     win = B.make("zkevm", ln, False, out=str(tmp_path / "win"), world=world)
-    got, logs = _run_ranks(win, world, backend, tmp_path)
+    env = dict(os.environ, XLP_SHARD_SCRATCH_MB=str(scratch_mb)) if scratch_mb else None
+    got, logs = _run_ranks(win, world, backend, tmp_path, env=env)
     assert "exchanges" in logs[0]
     for k in ("root1", "root2", "root3", "root4"):
         assert got[k] == expect[k], k
     assert got["evals"] == expect["evals"]
     assert got == expect                                              # every FRI tree, every opened row and sibling path, the final polynomial
+
+
+@pytest.mark.gpu
+def test_genbatchproof_with_the_zkevm_stark_sharded_equals_one_gpu(tmp_path):
+    """Prover::genBatchProof (host/prover.hpp, binary host/zkprover_batch) with --world 2: both ranks prove their rows of the zkEVM STARK
+    (window bundle, 2^13 rows), the publics come from rank 0's first and rank 1's last witness row, rank 0 goes on with c12a and
+    recursive1 at their real geometry -- the batch proof it prints is the one-GPU run's, byte for byte (FNV of the zkin text)."""
+    from tools import make_stark_bundle as B
+    if not _programs_built():
+        pytest.skip("converted reference programs not built (needs the reference tree at build time)")
+    exe = os.path.join(ROOT, "xlayer_prover_amd", "host", "zkprover_batch")
+    small = {"c12a": B.make("c12a", 20, False, out=str(tmp_path / "c12a")), "recursive1": B.make("recursive1", 17, False, out=str(tmp_path / "recursive1"))}
+
+    def config(name, zk):
+        cfg = {"runFileGenBatchProof": True, "saveOutputToFile": False, "saveProofToFile": False, "outputPath": str(tmp_path), "xlpSyntheticLookups": True}
+        for n, b in dict(small, zkevm=zk).items():
+            cfg[n + "StarkInfo"] = os.path.join(b, f"{n}.starkinfo.json")
+            cfg[n + "ConstPols"] = f"synthetic:{CSEED + len(n)}"
+            cfg[n + "ConstantsTree"] = ""
+            cfg[n + "Verkey"] = ""
+        f = tmp_path / name
+        f.write_text(json.dumps(cfg))
+        return str(f)
+    one = config("one.json", B.make("zkevm", 13, False, out=str(tmp_path / "zk1")))
+    r = subprocess.run([exe, "-c", one, "--proofs", "1"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    expect = json.loads(r.stdout.strip().splitlines()[-1])
+    two = config("two.json", B.make("zkevm", 13, False, out=str(tmp_path / "zk2"), world=2))
+    name = f"xlp_test_bp_{os.getpid()}"
+    procs = [subprocess.Popen([exe, "-c", two, "--proofs", "1", "--world", "2", "--rank", str(k), "--backend", "shm", "--rendezvous", name],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=900))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for k, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {k}: {se[-3000:]}"
+    got = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert outs[1][0].strip() == ""                                   # only rank 0 reports
+    assert got["sharded"]["world"] == 2 and got["sharded"]["exchanges"] > 0
+    assert got["recursive1_root1"] == expect["recursive1_root1"]
+    assert got["batch_proof_fnv"] == expect["batch_proof_fnv"] and got["batch_proof_bytes"] == expect["batch_proof_bytes"]

@@ -68,6 +68,8 @@ struct Comm {
     size_t shm_bytes = 0;
     uint64_t slot_bytes = 0;
     bool shm_owner = false;
+    char* bounce = nullptr;                      // page-locked staging buffer of one slot: HIP never sees the shared mapping itself (a copy
+                                                 // engine writing straight into a MAP_SHARED /dev/shm mapping faulted on MI355X, XNACK off)
     u64* small = nullptr;                        // device staging for the host-word all-gather (rccl)
     size_t small_words = 0;
     // accounting (bench): exchanges only
@@ -117,6 +119,19 @@ static bool wait_for(const std::function<bool()>& cond, double seconds)
 }
 
 static ShmHeader* shm_hdr() { return (ShmHeader*)g_comm.shm; }
+// device <-> shared-memory slot, through the page-locked bounce buffer
+static int shm_put(char* slot, const u64* dev, size_t bytes)
+{
+    XLP_HIP(hipMemcpy(g_comm.bounce, dev, bytes, hipMemcpyDeviceToHost));
+    memcpy(slot, g_comm.bounce, bytes);
+    return 0;
+}
+static int shm_get(u64* dev, const char* slot, size_t bytes)
+{
+    memcpy(g_comm.bounce, slot, bytes);
+    XLP_HIP(hipMemcpy(dev, g_comm.bounce, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
 static char* shm_slot(int from, int to) { return g_comm.shm + 4096 + ((size_t)from * g_comm.world + to) * g_comm.slot_bytes; }
 
 static int shm_barrier()
@@ -201,6 +216,7 @@ int comm_init(Ctx* ctx, int rank, int world, const char* backend, const char* re
         h->attached.fetch_add(1, std::memory_order_acq_rel);
         if (!wait_for([&] { return h->attached.load(std::memory_order_acquire) >= (uint32_t)world; }, 300.0)) return xlp_fail("xlp_comm_init: not every rank attached within 300 s");
         if (h->world != (uint32_t)world || h->slot_bytes != slot) return xlp_fail("xlp_comm_init: ranks disagree on world size / slot size");
+        XLP_HIP(hipHostMalloc((void**)&c.bounce, slot, hipHostMallocDefault));
         c.kind = Comm::SHM;
         return shm_barrier();
     }
@@ -212,6 +228,7 @@ void comm_shutdown()
     Comm& c = g_comm;
     if (c.kind == Comm::RCCL && c.nccl) { (void)c.rccl.CommDestroy(c.nccl); c.nccl = nullptr; }
     if (c.small) { (void)hipFree(c.small); c.small = nullptr; c.small_words = 0; }
+    if (c.bounce) { (void)hipHostFree(c.bounce); c.bounce = nullptr; }
     if (c.shm) { munmap(c.shm, c.shm_bytes); c.shm = nullptr; if (c.shm_owner) shm_unlink(c.shm_name.c_str()); c.shm_owner = false; }
     c.kind = Comm::NONE; c.rank = 0; c.world = 1;
 }
@@ -263,19 +280,19 @@ int comm_exchange(Ctx* ctx, u64* const* recv, const u64* recv_words, const u64* 
         for (u64 o = 0; o < all_max; o += slot_words) {
             for (int p = 0; p < G; p++)
                 if (p != me && send_words[p] > o)
-                    XLP_HIP(hipMemcpy(shm_slot(me, p), send[p] + o, (size_t)std::min(slot_words, send_words[p] - o) * sizeof(u64), hipMemcpyDeviceToHost));
+                    if (shm_put(shm_slot(me, p), send[p] + o, (size_t)std::min(slot_words, send_words[p] - o) * sizeof(u64))) return -1;
             if (shm_barrier()) return -1;
             for (int p = 0; p < G; p++)
                 if (p != me && recv_words[p] > o)
-                    XLP_HIP(hipMemcpy(recv[p] + o, shm_slot(p, me), (size_t)std::min(slot_words, recv_words[p] - o) * sizeof(u64), hipMemcpyHostToDevice));
+                    if (shm_get(recv[p] + o, shm_slot(p, me), (size_t)std::min(slot_words, recv_words[p] - o) * sizeof(u64))) return -1;
             if (shm_barrier()) return -1;                          // nobody overwrites a slot that is still being read
         }
     }
+    c.calls++;
+    for (int p = 0; p < G; p++) if (p != me) c.bytes_sent += send_words[p] * sizeof(u64);
     if (c.timing) {
         XLP_HIP(hipStreamSynchronize(ctx->stream));
         c.seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        c.calls++;
-        for (int p = 0; p < G; p++) if (p != me) c.bytes_sent += send_words[p] * sizeof(u64);
     }
     return 0;
 }
@@ -308,9 +325,9 @@ int comm_all_gather(Ctx* ctx, u64* out, const u64* in, u64 words)
     const u64 slot_words = c.slot_bytes / sizeof(u64);
     for (u64 o = 0; o < words; o += slot_words) {
         const u64 k = std::min(slot_words, words - o);
-        XLP_HIP(hipMemcpy(shm_slot(c.rank, 0), in + o, (size_t)k * sizeof(u64), hipMemcpyDeviceToHost));
+        if (shm_put(shm_slot(c.rank, 0), in + o, (size_t)k * sizeof(u64))) return -1;
         if (shm_barrier()) return -1;
-        for (int p = 0; p < c.world; p++) XLP_HIP(hipMemcpy(out + (u64)p * words + o, shm_slot(p, 0), (size_t)k * sizeof(u64), hipMemcpyHostToDevice));
+        for (int p = 0; p < c.world; p++) if (shm_get(out + (u64)p * words + o, shm_slot(p, 0), (size_t)k * sizeof(u64))) return -1;
         if (shm_barrier()) return -1;
     }
     return 0;
@@ -337,9 +354,9 @@ int comm_sendrecv(Ctx* ctx, u64* recv, int from, const u64* send, int to, u64 wo
     }
     if (words * sizeof(u64) > c.slot_bytes) return xlp_fail("xlp_comm_sendrecv: message longer than a shared-memory slot");
     XLP_HIP(hipStreamSynchronize(ctx->stream));
-    XLP_HIP(hipMemcpy(shm_slot(c.rank, to), send, (size_t)words * sizeof(u64), hipMemcpyDeviceToHost));
+    if (shm_put(shm_slot(c.rank, to), send, (size_t)words * sizeof(u64))) return -1;
     if (shm_barrier()) return -1;
-    XLP_HIP(hipMemcpy(recv, shm_slot(from, c.rank), (size_t)words * sizeof(u64), hipMemcpyHostToDevice));
+    if (shm_get(recv, shm_slot(from, c.rank), (size_t)words * sizeof(u64))) return -1;
     return shm_barrier();
 }
 

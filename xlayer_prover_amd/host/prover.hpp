@@ -5,6 +5,10 @@
 //   * the circom witness calculators that turn a zkin proof into the next STARK's committed polynomials
 //     (Circom::getCommitedPols prover.cpp:593, CircomRecursive1::getCommitedPols prover.cpp:630)  -> ProverRequest::c12aWitness / recursive1Witness
 // Timer names are the reference's.  pAddress is page-locked host memory (xlp_host_alloc) sized for the widest witness.
+// ROW-SHARDED (one process per GPU, xlp_comm_init before the Prover is built, a window bundle for the zkEVM STARK): every rank proves its rows
+// of the zkEVM STARK (98 % of a batch proof's GPU time; host/starks.hpp genProofSharded) and ends with the same proof; the executor fills
+// ProverRequest::firstRow .. + degree of the witness on each rank; the publics come from the first row (rank 0) and the last row (last rank);
+// c12a and recursive1 (2^20 / 2^17 rows, 0.1 s together) run on rank 0 alone, which is the rank that returns the batch proof.
 #pragma once
 #include <functional>
 #include <sys/stat.h>
@@ -27,6 +31,7 @@ public:
     std::string publicsJson, proofJson;
     std::vector<std::pair<std::string, double>> timers;
     double witnessUploadMs = 0.0;
+    uint64_t firstRow = 0;                           // row-sharded: the global row the executor's `degree` rows start at (set by genBatchProof)
     std::string publicsOutputFile() const { return filePrefix + "batch_proof.public.json"; }
 };
 
@@ -37,6 +42,7 @@ class Prover
     const Config& config;
     void* pAddress = NULL;
     uint64_t polsSize = 0;
+    int rank = 0;
     struct Tm {
         ProverRequest* r; const char* name; std::chrono::steady_clock::time_point t0;
         Tm(ProverRequest* r_, const char* n) : r(r_), name(n), t0(std::chrono::steady_clock::now()) {}
@@ -77,7 +83,9 @@ public:
         // the host slab: only the committed polynomials of the STARK being proven live on the host (prover.cpp:94-115 allocates the
         // whole 350 GB slab there; here everything past cm1_n is HBM)
         StarkInfo z(config.zkevmStarkInfo), c(config.c12aStarkInfo), r(config.recursive1StarkInfo);
-        auto cm1Bytes = [](const StarkInfo& s) { return (s.mapOffsets.section[cm1_n] + (1ULL << s.starkStruct.nBits) * s.mapSectionsN.section[cm1_n]) * sizeof(Goldilocks::Element); };
+        // (a window starkinfo: the rank's rows only)
+        auto cm1Bytes = [](const StarkInfo& s) { return (s.mapOffsets.section[cm1_n] + ((1ULL << s.starkStruct.nBits) / (s.xlpWorld ? s.xlpWorld : 1)) * s.mapSectionsN.section[cm1_n]) * sizeof(Goldilocks::Element); };
+        rank = xlp_comm_rank();
         polsSize = std::max(cm1Bytes(z), std::max(cm1Bytes(c), cm1Bytes(r)));
         // the aggregation / final STARKs exist when their starkinfo is configured and present (prover.cpp:128-160 creates all five)
         const bool haveR2 = config.recursive2StarkInfo.size() && fileExists(config.recursive2StarkInfo);
@@ -86,9 +94,10 @@ public:
         if (haveRF) polsSize = std::max<uint64_t>(polsSize, cm1Bytes(StarkInfo(config.recursivefStarkInfo)));
         XLP_CHECK(xlp_host_alloc(&pAddress, polsSize));
         starkZkevm = new Starks(config, {config.zkevmConstPols, config.mapConstPolsFile, config.zkevmConstantsTree, config.zkevmStarkInfo}, pAddress);
+        zkevmSteps = new ZkevmSteps(dirOf(config.zkevmStarkInfo));
+        if (rank != 0) return;                             // the small STARKs run on rank 0 alone
         starksC12a = new Starks(config, {config.c12aConstPols, config.mapConstPolsFile, config.c12aConstantsTree, config.c12aStarkInfo}, pAddress);
         starksRecursive1 = new Starks(config, {config.recursive1ConstPols, config.mapConstPolsFile, config.recursive1ConstantsTree, config.recursive1StarkInfo}, pAddress);
-        zkevmSteps = new ZkevmSteps(dirOf(config.zkevmStarkInfo));
         c12aSteps = new C12aSteps(dirOf(config.c12aStarkInfo));
         recursive1Steps = new Recursive1Steps(dirOf(config.recursive1StarkInfo));
         if (haveR2) {
@@ -118,23 +127,26 @@ public:
         req.timers.clear();
         Tm total(&req, "PROVER_BATCH_PROOF");
         Goldilocks::Element* cmPols = (Goldilocks::Element*)pAddress;
-        const uint64_t Nz = starkZkevm->domainSize(), Wz = starkZkevm->starkInfo.mapSectionsN.section[cm1_n];
+        const uint64_t Nz = starkZkevm->localRows(), Wz = starkZkevm->starkInfo.mapSectionsN.section[cm1_n];      // (sharded: my rows)
+        const bool shardedZ = starkZkevm->isSharded();
+        const int world = shardedZ ? xlp_comm_world() : 1;
         {
             Tm t(&req, "EXECUTOR_EXECUTE_BATCH_PROOF");
             if (!req.executor) xlp_exit_process("Prover::genBatchProof: no executor");
+            req.firstRow = starkZkevm->firstRow();
             req.executor(cmPols, Nz, Wz);                    // executor.execute(*pProverRequest, cmPols), prover.cpp:435
         }
         if (req.result != ZKR_SUCCESS) return;           // prover.cpp:437: the executor reports through the request
         // ---- publics (prover.cpp:494-559): first / last row of Main's registers; recursive2's verification key behind them
-        const uint64_t nPublics = starksRecursive1->starkInfo.nPublics;
+        const uint64_t nPublics = starkZkevm->starkInfo.nPublics;       // (= recursive1's: the publics travel unchanged through the three STARKs)
         std::vector<Goldilocks::Element> publics(nPublics, Goldilocks::zero());
         Goldilocks::Element zkevmVerkey[4], c12aVerkey[4], recursive1Verkey[4], recursive2Verkey[4] = {{0}, {0}, {0}, {0}};
         std::string publicStarkJson;
         {
             Tm t(&req, "SAVE_PUBLICS_JSON_BATCH_PROOF");
             verkey(config.zkevmVerkey, starkZkevm, zkevmVerkey);
-            verkey(config.c12aVerkey, starksC12a, c12aVerkey);
-            verkey(config.recursive1Verkey, starksRecursive1, recursive1Verkey);
+            if (starksC12a) verkey(config.c12aVerkey, starksC12a, c12aVerkey);
+            if (starksRecursive1) verkey(config.recursive1Verkey, starksRecursive1, recursive1Verkey);
             if (fileExists(config.recursive2Verkey)) {
                 const xlp_json::Value j = xlp_json::Parser(Config::xlp_read_file(config.recursive2Verkey)).value();
                 for (int i = 0; i < 4; i++) recursive2Verkey[i] = Goldilocks::fromU64(j["constRoot"][i]);
@@ -160,6 +172,17 @@ public:
                 for (uint64_t i = 0; i < nPublics && i < Wz; i++) publics[i] = at(0, i);      // not the zkEVM PIL: first row
             }
             for (Goldilocks::Element& p : publics) p = Goldilocks::fromU64(Goldilocks::toU64(p));
+            if (shardedZ && world > 1) {
+                // the first row lives on rank 0, the last one on the last rank: publics 0..18 are first-row registers, 19..43 last-row ones
+                std::vector<uint64_t> mine(nPublics), all((size_t)world * nPublics);
+                for (uint64_t i = 0; i < nPublics; i++) mine[i] = Goldilocks::toU64(publics[i]);
+                XLP_CHECK(xlp_comm_all_gather_host(all.data(), mine.data(), nPublics));
+                const bool zkevmPil = Wz > 617 && nPublics >= 48;
+                for (uint64_t i = 0; i < nPublics; i++) {
+                    const int from = zkevmPil && i >= 19 && i < 44 ? world - 1 : 0;
+                    publics[i] = Goldilocks::fromU64(all[(size_t)from * nPublics + i]);
+                }
+            }
             std::ostringstream os;
             xlp_json::arr(os, publics);
             publicStarkJson = os.str();
@@ -184,6 +207,11 @@ public:
             Tm t(&req, "STARK_JSON_GENERATION_BATCH_PROOF");
             zkin = withMembers(proof2zkinStark(*fproof), ",\"publics\":" + publicStarkJson);
             delete fproof;
+        }
+        if (rank != 0) {                                     // row-sharded: c12a / recursive1 are rank 0's (0.1 s); the others are done
+            req.publicsJson = publicStarkJson;
+            req.batchProofOutput.clear();
+            return;
         }
         // ---- c12a (prover.cpp:581-612)
         std::string zkinC12a;

@@ -240,7 +240,8 @@ private:
     // after a program with next-row stores: the halo rows it wrote belong to the next rank's first rows; mine come from the previous rank
     void haloWriteback(const std::vector<NextRowStore>& stores)
     {
-        if (stores.empty()) return;
+        // (one rank: the window is the whole domain, the operand's own modulus wraps the store of the last row to row 0 -- nothing lands in the halo)
+        if (stores.empty() || world == 1) return;
         uint64_t total = 0;
         for (const NextRowStore& st : stores) total += st.next * st.cols;
         uint64_t *pack = shardScratch(2 * total), *recv = pack + total, o = 0;
@@ -263,43 +264,65 @@ private:
     // ntt.extendPol(cmX_2ns, cmX_n, ...) + treesGL[i]->merkelize() (starks.cpp:53-60,134-141,215-222) over the ranks: the LDE runs per
     // COLUMN (all N rows of my W / G columns), the leaf sponge per ROW (all W columns of my NExtended / G rows):
     //   rows -> columns all-to-all | extendPol of my columns | columns -> rows all-to-all | sub-tree | cap (32 bytes per rank)
+    // The two exchanges and the LDE between them run in BANDS of columns (every rank's span is cut into the same number of bands) so that
+    // the staging buffers stay below XLP_SHARD_SCRATCH_MB (default 24576) whatever the section: (2 + 2 * 2^ext) x rows x columns words in all.
     void commitSharded(typename H::Tree* tree, eSection sn, eSection s2)
     {
         const uint64_t W = starkInfo.mapSectionsN.section[sn];
         tree->d_source = section(s2);
         if (W) {
-            uint64_t c0, c1;
-            colSpan(W, rank, c0, c1);
-            const uint64_t wc = c1 - c0, wcMax = (W + world - 1) / world;
-            uint64_t* pack = shardScratch(nLoc * W + N * wcMax + NExtended * wcMax + neLoc * W);
-            uint64_t *colb = pack + nLoc * W, *extb = colb + N * wcMax, *rowb = extb + NExtended * wcMax;
-            std::vector<uint64_t*> rp(world), sp(world);
+            const uint64_t wcMax = (W + world - 1) / world;
+            const uint64_t allWords = nLoc * W + N * wcMax + NExtended * wcMax + neLoc * W;
+            uint64_t budget = 24ULL << 30;
+            if (const char* e = getenv("XLP_SHARD_SCRATCH_MB")) { const uint64_t v = strtoull(e, NULL, 10); if (v) budget = v << 20; }
+            uint64_t nb = (allWords * sizeof(uint64_t) + budget - 1) / budget;
+            if (nb < 1) nb = 1;
+            if (nb > W / world && W / world) nb = W / world;            // at least one column per rank and band
+            if (W < (uint64_t)world) nb = 1;
+            // band k of a rank's span [a, b): [a + (b - a) k / nb, a + (b - a) (k + 1) / nb)
+            auto band = [&](int r, uint64_t k, uint64_t& a, uint64_t& b) {
+                uint64_t c0, c1; colSpan(W, r, c0, c1);
+                a = c0 + (c1 - c0) * k / nb; b = c0 + (c1 - c0) * (k + 1) / nb;
+            };
+            uint64_t bandTotalMax = 0, wcbMax = 0;
+            for (uint64_t k = 0; k < nb; k++) {
+                uint64_t tot = 0;
+                for (int p_ = 0; p_ < world; p_++) { uint64_t a, b; band(p_, k, a, b); tot += b - a; if (b - a > wcbMax) wcbMax = b - a; }
+                if (tot > bandTotalMax) bandTotalMax = tot;
+            }
+            uint64_t* pack = shardScratch(nLoc * bandTotalMax + N * wcbMax + NExtended * wcbMax + neLoc * bandTotalMax);
+            uint64_t *colb = pack + nLoc * bandTotalMax, *extb = colb + N * wcbMax, *rowb = extb + NExtended * wcbMax;
+            std::vector<uint64_t*> rp(world);
             std::vector<const uint64_t*> spc(world);
             std::vector<uint64_t> rw(world), sw(world);
-            // rows -> columns: block p = my rows of rank p's columns, packed; what arrives from p is rows [p nLoc, (p + 1) nLoc) of my columns
-            uint64_t o = 0;
-            for (int p_ = 0; p_ < world; p_++) {
-                uint64_t a, b; colSpan(W, p_, a, b);
-                sp[p_] = pack + o; sw[p_] = nLoc * (b - a);
-                if (b > a) XLP_CHECK(xlp_dev_copy_cols(sp[p_], b - a, section(sn) + a, W, nLoc, (uint32_t)(b - a)));
-                o += sw[p_];
-                rp[p_] = colb + (uint64_t)p_ * nLoc * wc; rw[p_] = nLoc * wc;
-            }
-            for (int p_ = 0; p_ < world; p_++) spc[p_] = sp[p_];
-            XLP_CHECK(xlp_comm_exchange(rp.data(), rw.data(), spc.data(), sw.data()));
-            if (wc) XLP_CHECK(xlp_dev_extend(extb, colb, NExtended, N, wc, NULL));
-            // columns -> rows: the rows destined to rank p are contiguous in extb; what arrives from p is its columns of my rows
-            o = 0;
-            for (int p_ = 0; p_ < world; p_++) {
-                uint64_t a, b; colSpan(W, p_, a, b);
-                spc[p_] = extb + (uint64_t)p_ * neLoc * wc; sw[p_] = neLoc * wc;
-                rp[p_] = rowb + o; rw[p_] = neLoc * (b - a);
-                o += rw[p_];
-            }
-            XLP_CHECK(xlp_comm_exchange(rp.data(), rw.data(), spc.data(), sw.data()));
-            for (int p_ = 0; p_ < world; p_++) {
-                uint64_t a, b; colSpan(W, p_, a, b);
-                if (b > a) XLP_CHECK(xlp_dev_copy_cols(section(s2) + a, W, rp[p_], b - a, neLoc, (uint32_t)(b - a)));
+            for (uint64_t k = 0; k < nb; k++) {
+                uint64_t ma, mb; band(rank, k, ma, mb);
+                const uint64_t wc = mb - ma;                              // my columns of this band
+                // rows -> columns: block p = my rows of rank p's band columns, packed; what arrives from p is rows [p nLoc, (p + 1) nLoc) of mine
+                uint64_t o = 0;
+                for (int p_ = 0; p_ < world; p_++) {
+                    uint64_t a, b; band(p_, k, a, b);
+                    uint64_t* blk = pack + o;
+                    spc[p_] = blk; sw[p_] = nLoc * (b - a);
+                    if (b > a) XLP_CHECK(xlp_dev_copy_cols(blk, b - a, section(sn) + a, W, nLoc, (uint32_t)(b - a)));
+                    o += sw[p_];
+                    rp[p_] = colb + (uint64_t)p_ * nLoc * wc; rw[p_] = nLoc * wc;
+                }
+                XLP_CHECK(xlp_comm_exchange(rp.data(), rw.data(), spc.data(), sw.data()));
+                if (wc) XLP_CHECK(xlp_dev_extend(extb, colb, NExtended, N, wc, NULL));
+                // columns -> rows: the rows destined to rank p are contiguous in extb; what arrives from p is its band columns of my rows
+                o = 0;
+                for (int p_ = 0; p_ < world; p_++) {
+                    uint64_t a, b; band(p_, k, a, b);
+                    spc[p_] = extb + (uint64_t)p_ * neLoc * wc; sw[p_] = neLoc * wc;
+                    rp[p_] = rowb + o; rw[p_] = neLoc * (b - a);
+                    o += rw[p_];
+                }
+                XLP_CHECK(xlp_comm_exchange(rp.data(), rw.data(), spc.data(), sw.data()));
+                for (int p_ = 0; p_ < world; p_++) {
+                    uint64_t a, b; band(p_, k, a, b);
+                    if (b > a) XLP_CHECK(xlp_dev_copy_cols(section(s2) + a, W, rp[p_], b - a, neLoc, (uint32_t)(b - a)));
+                }
             }
         }
         tree->merkelize();                                    // my sub-tree + the cap
@@ -630,6 +653,10 @@ public:
     StarksT(const StarksT&) = delete;
     StarksT& operator=(const StarksT&) = delete;
     uint64_t domainSize() const { return N; }
+    // row-sharded mode: this rank holds rows [firstRow(), firstRow() + localRows()) of the witness (pAddress holds exactly them)
+    bool isSharded() const { return sharded; }
+    uint64_t localRows() const { return sharded ? nLoc : N; }
+    uint64_t firstRow() const { return row0; }
 
     void genProof(typename H::Proof& proof, Goldilocks::Element* publicInputs, Goldilocks::Element verkey[4], Steps* steps)
     {

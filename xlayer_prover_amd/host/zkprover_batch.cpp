@@ -1,5 +1,9 @@
 // zkProver in file mode for a batch proof (src/main.cpp:83-112 runFileGenBatchProof -> Prover::genBatchProof) on the GPU build:
 //     zkprover_batch -c config.json [--proofs K] [--seed S] [--sequential-upload] [--timers] [--e2e]
+//                    [--world G --rank r --backend rccl|shm --rendezvous <file | name> [--device d]]
+// --world: this process is rank r of G (one process per GPU): the transport is set up before any other GPU work, the zkEVM
+// STARK runs row-sharded (the config's zkevmStarkInfo must be the window bundle of that world, tools/make_stark_bundle.py --world G), rank 0
+// runs c12a / recursive1 and prints the lines; every rank's executor stand-in fills ITS rows of the same synthetic witness.
 // --e2e: BASELINE configs[4] minus the SNARK wrap -- two consecutive batch proofs, Prover::genAggregatedProof over them (joinzkin + the recursive2
 // STARK) and Prover::genFinalProof up to the recursivef STARK (Poseidon-BN128 trees / transcript); needs recursive2 / recursivef in the config.
 // The executor and the two circom witness calculators are CPU subsystems outside this path and their inputs
@@ -17,14 +21,14 @@ static uint64_t fnv1a(const std::string& s)
     return h;
 }
 // a synthetic committed-polynomial matrix, generated on the GPU (xlp_dev_fill) and left in host memory at cmPols
-static void syntheticWitness(Goldilocks::Element* cmPols, uint64_t degree, uint64_t nCols, uint64_t seed)
+static void syntheticWitness(Goldilocks::Element* cmPols, uint64_t degree, uint64_t nCols, uint64_t seed, uint64_t firstRow = 0)
 {
-    const uint64_t total = degree * nCols, chunk = 1ULL << 28;
+    const uint64_t total = degree * nCols, chunk = 1ULL << 28, start = firstRow * nCols;
     void* d = NULL;
     XLP_CHECK(xlp_dev_alloc(&d, (total < chunk ? total : chunk) * 8));
     for (uint64_t o = 0; o < total; o += chunk) {
         const uint64_t n = total - o < chunk ? total - o : chunk;
-        XLP_CHECK(xlp_dev_fill((uint64_t*)d, n, seed, o));
+        XLP_CHECK(xlp_dev_fill((uint64_t*)d, n, seed, start + o));
         XLP_CHECK(xlp_copy_d2h(cmPols + o, d, n * 8));
     }
     XLP_CHECK(xlp_dev_free(d));
@@ -36,6 +40,8 @@ int main(int argc, char** argv)
     int proofs = 2;
     uint64_t seed = 0x5EED0401;
     bool sequential = false, timers = false, e2e = false;
+    int world = 0, rank = 0, device = -1;
+    std::string backend, rendezvous;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "-c" && i + 1 < argc) cfg = argv[++i];
@@ -44,12 +50,23 @@ int main(int argc, char** argv)
         else if (a == "--sequential-upload") sequential = true;
         else if (a == "--timers") timers = true;
         else if (a == "--e2e") e2e = true;
+        else if (a == "--world" && i + 1 < argc) world = atoi(argv[++i]);
+        else if (a == "--rank" && i + 1 < argc) rank = atoi(argv[++i]);
+        else if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
+        else if (a == "--backend" && i + 1 < argc) backend = argv[++i];
+        else if (a == "--rendezvous" && i + 1 < argc) rendezvous = argv[++i];
         else { fprintf(stderr, "usage: %s -c config.json [--proofs K] [--seed S] [--sequential-upload] [--timers]\n", argv[0]); return 2; }
     }
     if (cfg.empty()) { fprintf(stderr, "missing -c config.json\n"); return 2; }
     Config config;
     config.load(cfg);
     if (!config.runFileGenBatchProof) { fprintf(stderr, "config: runFileGenBatchProof is not set\n"); return 2; }
+    if (device >= 0) config.xlpDevice = (uint64_t)device;
+    if (world) {
+        if (e2e) { fprintf(stderr, "--e2e runs on one GPU\n"); return 2; }
+        XLP_CHECK(xlp_init((int)config.xlpDevice));           // one process per GPU: bind it, then the transport, before anything else
+        XLP_CHECK(xlp_comm_init(rank, world, backend.empty() ? NULL : backend.c_str(), rendezvous.empty() ? NULL : rendezvous.c_str()));
+    }
     Goldilocks fr;
     PoseidonGoldilocks poseidon;
     {
@@ -57,13 +74,14 @@ int main(int argc, char** argv)
     Prover prover(fr, poseidon, config);
     const double tSetup = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     prover.starkZkevm->pipelineWitness = !sequential;
-    prover.starkZkevm->logTimers = prover.starksC12a->logTimers = prover.starksRecursive1->logTimers = timers;
+    prover.starkZkevm->logTimers = timers;
+    if (prover.starksC12a) prover.starksC12a->logTimers = prover.starksRecursive1->logTimers = timers;
     fprintf(stderr, "setup %.2f s ; steps: zkevm", tSetup);
     for (int k = 0; k < 5; k++) fprintf(stderr, " [%s]", prover.zkevmSteps->mode(k).c_str());
     fprintf(stderr, "\n");
     ProverRequest req;
     req.filePrefix = config.outputPath + "/";
-    req.executor = [&](Goldilocks::Element* p, uint64_t n, uint64_t w) { syntheticWitness(p, n, w, seed); };
+    req.executor = [&](Goldilocks::Element* p, uint64_t n, uint64_t w) { syntheticWitness(p, n, w, seed, req.firstRow); };
     req.c12aWitness = [&](const std::string& zkin, Goldilocks::Element* p, uint64_t n, uint64_t w) { syntheticWitness(p, n, w, fnv1a(zkin)); };
     req.recursive1Witness = req.c12aWitness;
     req.recursive2Witness = req.c12aWitness;
@@ -113,7 +131,12 @@ int main(int argc, char** argv)
         proofs = 0;
     }
     for (int it = 0; it < proofs; it++) {
+        if (world) XLP_CHECK(xlp_comm_stats(NULL, NULL, NULL, 1 | (timers ? 2 : 0)));
         prover.genBatchProof(&req);
+        if (world) {
+            XLP_CHECK(xlp_comm_barrier());
+            if (rank != 0) continue;
+        }
         double starks = 0, exec = 0, total = 0, wit = 0;
         std::ostringstream os;
         os << "{\"run\":" << it << ",\"witness_upload\":\"" << (sequential ? "sequential" : "pipelined with step 1") << "\",\"timers_s\":{";
@@ -126,6 +149,12 @@ int main(int argc, char** argv)
             if (kv.first == "PROVER_BATCH_PROOF") total = kv.second;
         }
         // req.timers is appended when a scope closes: PROVER_BATCH_PROOF is still open here -> take it from the parts
+        if (world) {
+            double sec = 0; uint64_t bytes = 0, calls = 0;
+            XLP_CHECK(xlp_comm_stats(&sec, &bytes, &calls, 0));
+            os << "},\"sharded\":{\"world\":" << world << ",\"backend\":\"" << (backend.empty() ? "self" : backend) << "\",\"exchanges\":" << calls << ",\"GB_sent_to_peers_rank0\":" << bytes / 1e9
+               << ",\"exchange_s_rank0\":" << sec;
+        }
         os << "},\"three_starks_s\":" << starks << ",\"executor_standin_s\":" << exec << ",\"witness_standins_s\":" << wit << ",\"zkevm_witness_upload_ms\":" << req.witnessUploadMs;
         const std::string& z = req.batchProofOutput;
         const size_t r1 = z.find("\"root1\":"), r1e = z.find("]", r1);
