@@ -48,11 +48,54 @@ def cpu_baseline(log_n, ncols, budget_s=20.0):
     t0 = time.perf_counter()
     orc.extend_pol(src, n << EXT_BITS, n, ncols)
     t = time.perf_counter() - t0
-    return {
+    out = {
         "value": (n << EXT_BITS) * ncols / t / 1e9, "unit": "GFE/s", "cores": min(threads, ncols), "kind": "port",
         "sample": f"oracle extendPol 2^{lg} x {ncols} -> 2^{lg + EXT_BITS} x {ncols} ({t:.2f} s, OpenMP over columns, "
                   f"scalar u128 arithmetic; restated CPU path, not the reference's AVX2 binary)",
     }
+    # the other two legs of the path on the same host cores (bounded samples): the Merkle leaf sponge + tree, and one small complete genProof
+    legs = {}
+    try:
+        h, w = 1 << 14, 751
+        rows = orc.fill(h * w, SEED + 1).reshape(h, w)
+        t0 = time.perf_counter()
+        orc.merkletree(rows, w, h)
+        tm = time.perf_counter() - t0
+        perms = h * ((w + 7) // 8) + h - 1
+        legs["merkle"] = {"value": round(perms / tm, 1), "unit": "Poseidon permutations/s", "cores": threads, "kind": "port",
+                          "sample": f"oracle merkletree 2^14 x 751 ({perms} permutations, {tm:.2f} s, OpenMP over rows); the GPU figure beside it is roofline_merkle.permutations_per_s"}
+    except Exception as e:
+        legs["merkle"] = {"error": repr(e)[:200]}
+    try:
+        from tests import mini_genproof_flow as flow
+        from tests.mini_backends import OracleBackend
+        nb = 14
+        steps = [nb + 1, 10, 5]
+        t0 = time.perf_counter()
+        res = flow.prove(OracleBackend(orc), nb, steps, 16, seed=7)
+        tg = time.perf_counter() - t0
+        legs["genproof_toy"] = {"value": round(tg, 3), "unit": "s", "cores": threads, "kind": "port", "root1": res["root1"],
+                                "sample": f"the complete stage sequence of Starks::genProof on the toy PIL (tests/mini_genproof_flow.py: 17 committed columns, N = 2^{nb}, "
+                                          f"FRI {steps}, 16 queries) on the oracle; the same flow on the GPU: genproof_toy_gpu_s"}
+    except Exception as e:
+        legs["genproof_toy"] = {"error": repr(e)[:200]}
+    out["legs"] = legs
+    return out
+
+
+def genproof_toy_gpu(capi):
+    """the toy-PIL genProof of cpu_baseline.legs.genproof_toy on the GPU (same sizes), for the ratio only"""
+    try:
+        from tests import mini_genproof_flow as flow
+        from tests.mini_backends import GpuBackend
+        capi.init(0); capi.use_torch_stream()
+        B = GpuBackend(capi)
+        flow.prove(B, 10, [11, 6], 4)
+        t0 = time.perf_counter()
+        res = flow.prove(B, 14, [15, 10, 5], 16, seed=7)
+        return {"s": round(time.perf_counter() - t0, 4), "root1": res["root1"]}
+    except Exception as e:
+        return {"error": repr(e)[:200]}
 
 
 def counters():
@@ -584,6 +627,11 @@ def main():
                 line["e2e"] = e2e_leg()
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.log_n, ncols)
+            g = genproof_toy_gpu(capi)
+            line["cpu_baseline"]["legs"]["genproof_toy_gpu"] = g
+            tg = line["cpu_baseline"]["legs"].get("genproof_toy", {})
+            if "root1" in g and "root1" in tg:
+                line["cpu_baseline"]["legs"]["genproof_toy_same_root"] = g["root1"] == tg["root1"]
         else:
             line["cpu_baseline"] = None
         json_out.write(json.dumps(line) + "\n"); json_out.flush()

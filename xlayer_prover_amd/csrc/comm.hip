@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <fcntl.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -236,6 +238,11 @@ void comm_shutdown()
 int comm_rank() { return g_comm.rank; }
 int comm_world() { return g_comm.world; }
 
+static void trace(const char* what, u64 words)
+{
+    static const bool on = getenv("XLP_COMM_TRACE") != nullptr;
+    if (on) { fprintf(stderr, "[xlp_comm rank %d] %s %llu words\n", g_comm.rank, what, (unsigned long long)words); fflush(stderr); }
+}
 static int need_comm(const char* what)
 {
     if (g_comm.kind == Comm::NONE) return xlp_fail((std::string(what) + ": xlp_comm_init has not been called").c_str());
@@ -249,6 +256,7 @@ int comm_exchange(Ctx* ctx, u64* const* recv, const u64* recv_words, const u64* 
     Comm& c = g_comm;
     const int me = c.rank, G = c.world;
     if (send_words[me] != recv_words[me]) return xlp_fail("xlp_comm_exchange: own block sizes differ");
+    trace("exchange (own block)", send_words[me]);
     std::chrono::steady_clock::time_point t0;
     if (c.timing) { XLP_HIP(hipStreamSynchronize(ctx->stream)); t0 = std::chrono::steady_clock::now(); }
     if (send_words[me] && recv[me] != send[me])
@@ -303,6 +311,7 @@ int comm_all_gather(Ctx* ctx, u64* out, const u64* in, u64 words)
     if (need_comm("xlp_comm_all_gather")) return -1;
     Comm& c = g_comm;
     if (!words) return 0;
+    trace("all_gather", words);
     if (c.world == 1 && c.kind != Comm::RCCL) {
         if (out != in) XLP_HIP(hipMemcpyAsync(out, in, words * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
         return 0;
@@ -340,6 +349,7 @@ int comm_sendrecv(Ctx* ctx, u64* recv, int from, const u64* send, int to, u64 wo
     Comm& c = g_comm;
     if (from < 0 || from >= c.world || to < 0 || to >= c.world) return xlp_fail("xlp_comm_sendrecv: peer out of range");
     if (!words) return 0;
+    trace("sendrecv", words);
     if (c.kind == Comm::SELF || (c.world == 1 && c.kind == Comm::SHM)) {
         XLP_HIP(hipMemcpyAsync(recv, send, words * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
         return 0;
@@ -366,6 +376,7 @@ int comm_all_gather_host(Ctx* ctx, u64* out, const u64* in, u64 words)
     if (need_comm("xlp_comm_all_gather_host")) return -1;
     Comm& c = g_comm;
     if (!words) return 0;
+    trace("all_gather_host", words);
     if (c.world == 1 && c.kind != Comm::RCCL) { memmove(out, in, words * sizeof(u64)); return 0; }
     if (c.kind == Comm::RCCL) {                                   // RCCL moves device memory: a round trip through a small device buffer
         const size_t need = (size_t)words * (c.world + 1);

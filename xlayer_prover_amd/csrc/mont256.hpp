@@ -29,6 +29,32 @@ __device__ __forceinline__ void mac_k(u64& lo, u32& hi, u32 a, u32 k)
     asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(a), "s"(k) : "vcc");
 }
 
+// Two multiply-accumulates at once: acc1 += a1 * b1 (VGPR x VGPR), acc2 += a2 * k2 (VGPR x SGPR constant); acc1 and acc2 may be the SAME
+// accumulator (then the second multiply-add simply continues the first).  The two carries live in different registers (VCC and an SGPR
+// pair) and each is consumed two instructions after it is produced -- M1 M2 nop A1 A2 -- so the pair costs five issue slots instead of the
+// six of two separate mac() calls with their own wait states.
+__device__ __forceinline__ void mac2(u64& lo1, u32& hi1, u32 a1, u32 b1, u64& lo2, u32& hi2, u32 a2, u32 k2)
+{
+    u64 c2;
+    asm("v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+        "v_mad_u64_u32 %2, %4, %7, %8, %2\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+        "v_addc_co_u32 %3, %4, 0, %3, %4"
+        : "+v"(lo1), "+v"(hi1), "+v"(lo2), "+v"(hi2), "=&s"(c2) : "v"(a1), "v"(b1), "v"(a2), "s"(k2) : "vcc");
+}
+// the same on ONE accumulator: acc += a1 * b1 + a2 * k2
+__device__ __forceinline__ void mac2s(u64& lo, u32& hi, u32 a1, u32 b1, u32 a2, u32 k2)
+{
+    u64 c2;
+    asm("v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+        "v_mad_u64_u32 %0, %2, %5, %6, %0\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+        "v_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+v"(lo), "+v"(hi), "=&s"(c2) : "v"(a1), "v"(b1), "v"(a2), "s"(k2) : "vcc");
+}
+
 // (lo, hi) += (lo2, hi2)
 __device__ __forceinline__ void acc_add(u64& lo, u32& hi, u64 lo2, u32 hi2)
 {
@@ -55,9 +81,8 @@ __device__ __forceinline__ void mul(u32 (&r)[8], const u32 (&a)[8], const u32 (&
         u32 hi2 = 0;
 #pragma unroll
         for (int j = 0; j < i; j++) {
-            mac(lo, hi, a[j], b[i - j]);
-            if constexpr (SPLIT) mac_k(lo2, hi2, m[j], P::N[i - j]);
-            else mac_k(lo, hi, m[j], P::N[i - j]);
+            if constexpr (SPLIT) mac2(lo, hi, a[j], b[i - j], lo2, hi2, m[j], P::N[i - j]);
+            else mac2s(lo, hi, a[j], b[i - j], m[j], P::N[i - j]);
         }
         mac(lo, hi, a[i], b[0]);
         if (SPLIT && i > 0) acc_add(lo, hi, lo2, hi2);
@@ -73,9 +98,8 @@ __device__ __forceinline__ void mul(u32 (&r)[8], const u32 (&a)[8], const u32 (&
         u32 hi2 = 0;
 #pragma unroll
         for (int j = i - 7; j < 8; j++) {
-            mac(lo, hi, a[j], b[i - j]);
-            if constexpr (SPLIT) mac_k(lo2, hi2, m[j], P::N[i - j]);
-            else mac_k(lo, hi, m[j], P::N[i - j]);
+            if constexpr (SPLIT) mac2(lo, hi, a[j], b[i - j], lo2, hi2, m[j], P::N[i - j]);
+            else mac2s(lo, hi, a[j], b[i - j], m[j], P::N[i - j]);
         }
         if (SPLIT && i < 15) acc_add(lo, hi, lo2, hi2);
         t[i - 8] = (u32)lo;

@@ -604,7 +604,7 @@ public:
             fileToDevice(treesGL[4]->d_nodes, starkFiles.zkevmConstantsTree, 16 + NExtended * starkInfo.nConstants * 8, H::treeWords(treesGL[4]) * 8);
           }
         } else {
-            XLP_CHECK(xlp_dev_extend(constPols2ns(), d_const_n, NExtended, N, starkInfo.nConstants, NULL));
+            XLP_CHECK(xlp_dev_extend(constPols2ns(), constFull, NExtended, N, starkInfo.nConstants, NULL));      // (sharded: d_const_n is only my window)
             treesGL[4]->merkelize();
         }
         treesGL[4]->getRoot(constRoot);
