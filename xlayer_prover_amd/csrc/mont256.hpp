@@ -55,6 +55,27 @@ __device__ __forceinline__ void mac2s(u64& lo, u32& hi, u32 a1, u32 b1, u32 a2, 
         : "+v"(lo), "+v"(hi), "=&s"(c2) : "v"(a1), "v"(b1), "v"(a2), "s"(k2) : "vcc");
 }
 
+// acc += a1 * k1 + a2 * k2 with both multipliers wave-uniform (SGPRs: table entries, modulus limbs)
+__device__ __forceinline__ void mac2kk(u64& lo, u32& hi, u32 a1, u32 k1, u32 a2, u32 k2)
+{
+    u64 c2;
+    asm("v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+        "v_mad_u64_u32 %0, %2, %5, %6, %0\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+        "v_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+v"(lo), "+v"(hi), "=&s"(c2) : "v"(a1), "s"(k1), "v"(a2), "s"(k2) : "vcc");
+}
+// a run of n multiply-accumulates acc += a(i) * k(i), i = 0 .. n - 1 (n a compile-time constant after unrolling), two at a time
+template <class FA, class FK>
+__device__ __forceinline__ void mac_run_k(u64& lo, u32& hi, int n, FA a, FK k)
+{
+    int i = 0;
+#pragma unroll
+    for (; i + 1 < n; i += 2) mac2kk(lo, hi, a(i), k(i), a(i + 1), k(i + 1));
+    if (i < n) mac_k(lo, hi, a(i), k(i));
+}
+
 // (lo, hi) += (lo2, hi2)
 __device__ __forceinline__ void acc_add(u64& lo, u32& hi, u64 lo2, u32 hi2)
 {
@@ -129,9 +150,11 @@ __device__ __forceinline__ void mac512(u32 (&acc)[16], const u32 (&k)[8], const 
     u32 hi = 0;
 #pragma unroll
     for (int c = 0; c < 16; c++) {
-        mac_k(lo, hi, acc[c], 1u);
-#pragma unroll
-        for (int x = (c > 7 ? c - 7 : 0); x <= (c < 7 ? c : 7); x++) mac_k(lo, hi, b[c - x], k[x]);
+        {
+            // terms of column c: acc[c] * 1 and b[c - x] * k[x] for x0 <= x <= x1
+            const int x0 = c > 7 ? c - 7 : 0, x1 = c < 7 ? c : 7;
+            mac_run_k(lo, hi, x1 - x0 + 2, [&](int i) { return i == 0 ? acc[c] : b[c - (x0 + i - 1)]; }, [&](int i) { return i == 0 ? 1u : k[x0 + i - 1]; });
+        }
         acc[c] = (u32)lo;
         lo = (lo >> 32) | ((u64)hi << 32);
         hi = 0;
@@ -147,9 +170,7 @@ __device__ __forceinline__ void redc512(u32 (&r)[8], const u32 (&t)[16])
     u32 hi = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        mac_k(lo, hi, t[i], 1u);
-#pragma unroll
-        for (int j = 0; j < i; j++) mac_k(lo, hi, m[j], P::N[i - j]);
+        mac_run_k(lo, hi, i + 1, [&](int q) { return q == 0 ? t[i] : m[q - 1]; }, [&](int q) { return q == 0 ? 1u : P::N[i - (q - 1)]; });
         m[i] = (u32)lo * P::N0INV;
         mac_k(lo, hi, m[i], P::N[0]);
         lo = (lo >> 32) | ((u64)hi << 32);
@@ -158,9 +179,7 @@ __device__ __forceinline__ void redc512(u32 (&r)[8], const u32 (&t)[16])
     u32 v[9];
 #pragma unroll
     for (int i = 8; i < 16; i++) {
-        mac_k(lo, hi, t[i], 1u);
-#pragma unroll
-        for (int j = i - 7; j < 8; j++) mac_k(lo, hi, m[j], P::N[i - j]);
+        mac_run_k(lo, hi, 16 - i, [&](int q) { return q == 0 ? t[i] : m[i - 7 + q - 1]; }, [&](int q) { return q == 0 ? 1u : P::N[i - (i - 7 + q - 1)]; });
         v[i - 8] = (u32)lo;
         lo = (lo >> 32) | ((u64)hi << 32);
         hi = 0;

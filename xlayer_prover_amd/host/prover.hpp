@@ -43,6 +43,7 @@ class Prover
     void* pAddress = NULL;
     uint64_t polsSize = 0;
     int rank = 0;
+    uint64_t nPublicsBatch = 0;
     struct Tm {
         ProverRequest* r; const char* name; std::chrono::steady_clock::time_point t0;
         Tm(ProverRequest* r_, const char* n) : r(r_), name(n), t0(std::chrono::steady_clock::now()) {}
@@ -86,6 +87,7 @@ public:
         // (a window starkinfo: the rank's rows only)
         auto cm1Bytes = [](const StarkInfo& s) { return (s.mapOffsets.section[cm1_n] + ((1ULL << s.starkStruct.nBits) / (s.xlpWorld ? s.xlpWorld : 1)) * s.mapSectionsN.section[cm1_n]) * sizeof(Goldilocks::Element); };
         rank = xlp_comm_rank();
+        nPublicsBatch = std::max(r.nPublics, z.nPublics);
         polsSize = std::max(cm1Bytes(z), std::max(cm1Bytes(c), cm1Bytes(r)));
         // the aggregation / final STARKs exist when their starkinfo is configured and present (prover.cpp:128-160 creates all five)
         const bool haveR2 = config.recursive2StarkInfo.size() && fileExists(config.recursive2StarkInfo);
@@ -138,7 +140,7 @@ public:
         }
         if (req.result != ZKR_SUCCESS) return;           // prover.cpp:437: the executor reports through the request
         // ---- publics (prover.cpp:494-559): first / last row of Main's registers; recursive2's verification key behind them
-        const uint64_t nPublics = starkZkevm->starkInfo.nPublics;       // (= recursive1's: the publics travel unchanged through the three STARKs)
+        const uint64_t nPublics = nPublicsBatch;              // recursive1's count (prover.cpp:494: the publics of the batch proof; known on every rank)
         std::vector<Goldilocks::Element> publics(nPublics, Goldilocks::zero());
         Goldilocks::Element zkevmVerkey[4], c12aVerkey[4], recursive1Verkey[4], recursive2Verkey[4] = {{0}, {0}, {0}, {0}};
         std::string publicStarkJson;
