@@ -8,9 +8,11 @@ Each function cites the reference lines it follows (paths relative to /root/refe
 The field library (ffiasm `RawFr`, generated from src/ffiasm/fr.asm) is standard 4 x 64-bit Montgomery arithmetic with R = 2^256;
 elements are kept here as ordinary integers mod r and converted to / from Montgomery limbs only at the byte boundary.
 
-Pinning: the reference snapshot holds no BN128 golden data (no recursivef proof, no BN128 tree).  The permutation is pinned by
-circomlib's published known answers for t = 3 and t = 5 (tests/test_bn128.py); the 16-ary tree layout, the leaf rule and the
-transcript are restatement-only -- "parity unpinned" for those, stated in DESIGN.md.
+Pinning: the reference snapshot holds no BN128 golden data (no recursivef proof, no BN128 tree).  What it does hold pins the ELEMENT
+REPRESENTATION: the field constants of src/ffiasm/fr.asm / fq.asm (q, R^2, R^3, np -> tests/golden/bn254_field_constants.json) fix RawFr / RawFq as
+4 x 64-bit Montgomery residues with R = 2^256, and the four G1 commitments of testvectors/finalProof/proof.json fix the curve.  The permutation is
+pinned by circomlib's published known answers for t = 3 and t = 5 (tests/test_bn128.py); the 16-ary tree layout, the leaf rule and the
+transcript are restatement-only -- "parity unpinned" for those, stated in DESIGN.md (a recursivef proof or .consttree would pin them).
 """
 import struct
 

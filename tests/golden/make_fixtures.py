@@ -249,7 +249,23 @@ def main():
     w = [int(blob[64 * i:64 * i + 64], 16) for i in range(8)]
     json.dump({"source": "testvectors/finalProof/proof.json: the first eight 32-byte words = the G1 commitments C1, C2, W1, W2 of the reference's fflonk proof (affine x, y)",
                "points": [[str(w[2 * i]), str(w[2 * i + 1])] for i in range(4)]}, open(os.path.join(HERE, "fflonk_proof_g1_points.json"), "w"), indent=1)
-    for f in ["poseidon_kats.json", "fflonk_proof_g1_points.json", "aggregation_chain.json"] + [c[0] for c in CHAIN]:
+    # BN254 field constants the reference's generated field code holds as DATA (src/ffiasm/fr.asm / fq.asm, section .data): modulus, R^2, R^3 and
+    # np = -q^-1 mod 2^64 of the 4 x 64-bit Montgomery form.  They pin the element representation (R = 2^256) of RawFr / RawFq -- what "the bytes of
+    # a RawFr::Element" means -- for the oracle (oracle/bn128_oracle.py) and for the limbs / N0INV the kernels are built with.
+    import re
+
+    def asm_consts(path):
+        text = open(path).read()
+        data = text[text.index("section .data"):]
+        out = {}
+        for name in ("q", "half", "R2", "R3", "np"):
+            m = re.search(r"^%s\s+dq\s+([0-9a-fx, ]+)$" % name, data, re.M)
+            out[name] = [v.strip() for v in m.group(1).split(",")]
+        return out
+    json.dump({"source": "src/ffiasm/fr.asm and src/ffiasm/fq.asm, `section .data`: little-endian 64-bit limbs as written there",
+               "Fr": asm_consts("/root/reference/src/ffiasm/fr.asm"), "Fq": asm_consts("/root/reference/src/ffiasm/fq.asm")},
+              open(os.path.join(HERE, "bn254_field_constants.json"), "w"), indent=1)
+    for f in ["poseidon_kats.json", "fflonk_proof_g1_points.json", "aggregation_chain.json", "bn254_field_constants.json"] + [c[0] for c in CHAIN]:
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

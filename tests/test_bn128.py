@@ -265,6 +265,36 @@ def test_oracle_curve_is_pinned_by_reference_held_points():
     assert bo.g1_from_limbs(bo.g1_to_limbs(a)) == a and bo.g1_from_limbs([0] * 8) is None
 
 
+def test_field_representation_is_pinned_by_the_reference_field_constants():
+    """REFERENCE-HELD PIN of the element bytes: the reference's generated field code carries its constants as data (src/ffiasm/fr.asm / fq.asm:
+    modulus q, R^2, R^3, np = -q^-1 mod 2^64; fixture tests/golden/bn254_field_constants.json).  R^2 there is (2^256)^2 mod q, so RawFr / RawFq elements
+    are 4 x 64-bit Montgomery residues with R = 2^256 -- the representation the oracle converts to at its byte boundary and the kernels compute in.
+    Checked: the oracle's moduli and Montgomery radix reproduce every constant; its encoding of 1 is R mod q; and the 32-bit limbs / N0INV the HIP
+    kernels are compiled with (csrc/bn128.hip, csrc/bn254_msm.hip) are these numbers."""
+    import json
+    import re
+    J = json.load(open(os.path.join(ROOT, "tests", "golden", "bn254_field_constants.json")))
+    num = lambda limbs: sum(int(v, 16) << (64 * i) for i, v in enumerate(limbs))
+    for name, q, mont_r in (("Fr", bo.R_MOD, bo.MONT_R), ("Fq", bo.Q_MOD, bo.Q_MONT_R)):
+        c = J[name]
+        assert num(c["q"]) == q
+        assert num(c["half"]) == q >> 1
+        assert mont_r == (1 << 256) % q
+        assert num(c["R2"]) == mont_r * mont_r % q and num(c["R3"]) == pow(mont_r, 3, q)
+        assert (int(c["np"][0], 16) * q + 1) % (1 << 64) == 0                      # np = -q^-1 mod 2^64
+    assert bo.to_mont_limbs(1) == [(bo.MONT_R >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+    assert bo.from_mont_limbs([int(v, 16) for v in J["Fr"]["R2"]]) == bo.MONT_R      # R^2 read as an element is R
+    assert bo.g1_to_limbs((1, 2))[:4] == [(bo.Q_MONT_R >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
+    # the kernels' compile-time constants
+    csrc = os.path.join(ROOT, "xlayer_prover_amd", "csrc")
+    for fn, name in (("bn128.hip", "Fr"), ("bn254_msm.hip", "Fq")):
+        src = open(os.path.join(csrc, fn)).read()
+        limbs = [int(x, 16) for x in re.search(r"static constexpr u32 N\[8\] = \{([^}]*)\}", src).group(1).replace("u", "").split(",")]
+        assert sum(v << (32 * i) for i, v in enumerate(limbs)) == num(J[name]["q"])
+        n0inv = int(re.search(r"static constexpr u32 N0INV = (0x[0-9a-f]+)u", src).group(1), 16)
+        assert n0inv == int(J[name]["np"][0], 16) & 0xFFFFFFFF
+
+
 def _random_points(rng, n):
     """n curve points: small multiples of the generator and of the reference-held points, by chained additions (cheap)"""
     seeds = [bo.G1] + _golden_points()

@@ -261,6 +261,30 @@ private:
             o += st.next * st.cols;
         }
     }
+    // how the sharded commit of a W-column section is cut into column bands (see commitSharded): number of bands, and per band the most
+    // columns all ranks together / one rank can hold; -> words of staging scratch it needs
+    uint64_t commitBandPlan(uint64_t W, uint64_t& nb, uint64_t& bandTotalMax, uint64_t& wcbMax) const
+    {
+        const uint64_t wcMax = (W + world - 1) / world;
+        const uint64_t allWords = nLoc * W + N * wcMax + NExtended * wcMax + neLoc * W;
+        uint64_t budget = 24ULL << 30;
+        if (const char* e = getenv("XLP_SHARD_SCRATCH_MB")) { const uint64_t v = strtoull(e, NULL, 10); if (v) budget = v << 20; }
+        nb = (allWords * sizeof(uint64_t) + budget - 1) / budget;
+        if (nb < 1) nb = 1;
+        if (nb > W / world && W / world) nb = W / world;            // at least one column per rank and band
+        if (W < (uint64_t)world) nb = 1;
+        bandTotalMax = 0; wcbMax = 0;
+        for (uint64_t k = 0; k < nb; k++) {
+            uint64_t tot = 0;
+            for (int p_ = 0; p_ < world; p_++) {
+                uint64_t c0, c1; colSpan(W, p_, c0, c1);
+                const uint64_t a = c0 + (c1 - c0) * k / nb, b = c0 + (c1 - c0) * (k + 1) / nb;
+                tot += b - a; if (b - a > wcbMax) wcbMax = b - a;
+            }
+            if (tot > bandTotalMax) bandTotalMax = tot;
+        }
+        return nLoc * bandTotalMax + N * wcbMax + NExtended * wcbMax + neLoc * bandTotalMax;
+    }
     // ntt.extendPol(cmX_2ns, cmX_n, ...) + treesGL[i]->merkelize() (starks.cpp:53-60,134-141,215-222) over the ranks: the LDE runs per
     // COLUMN (all N rows of my W / G columns), the leaf sponge per ROW (all W columns of my NExtended / G rows):
     //   rows -> columns all-to-all | extendPol of my columns | columns -> rows all-to-all | sub-tree | cap (32 bytes per rank)
@@ -271,25 +295,13 @@ private:
         const uint64_t W = starkInfo.mapSectionsN.section[sn];
         tree->d_source = section(s2);
         if (W) {
-            const uint64_t wcMax = (W + world - 1) / world;
-            const uint64_t allWords = nLoc * W + N * wcMax + NExtended * wcMax + neLoc * W;
-            uint64_t budget = 24ULL << 30;
-            if (const char* e = getenv("XLP_SHARD_SCRATCH_MB")) { const uint64_t v = strtoull(e, NULL, 10); if (v) budget = v << 20; }
-            uint64_t nb = (allWords * sizeof(uint64_t) + budget - 1) / budget;
-            if (nb < 1) nb = 1;
-            if (nb > W / world && W / world) nb = W / world;            // at least one column per rank and band
-            if (W < (uint64_t)world) nb = 1;
+            uint64_t nb, bandTotalMax, wcbMax;
+            commitBandPlan(W, nb, bandTotalMax, wcbMax);
             // band k of a rank's span [a, b): [a + (b - a) k / nb, a + (b - a) (k + 1) / nb)
             auto band = [&](int r, uint64_t k, uint64_t& a, uint64_t& b) {
                 uint64_t c0, c1; colSpan(W, r, c0, c1);
                 a = c0 + (c1 - c0) * k / nb; b = c0 + (c1 - c0) * (k + 1) / nb;
             };
-            uint64_t bandTotalMax = 0, wcbMax = 0;
-            for (uint64_t k = 0; k < nb; k++) {
-                uint64_t tot = 0;
-                for (int p_ = 0; p_ < world; p_++) { uint64_t a, b; band(p_, k, a, b); tot += b - a; if (b - a > wcbMax) wcbMax = b - a; }
-                if (tot > bandTotalMax) bandTotalMax = tot;
-            }
             uint64_t* pack = shardScratch(nLoc * bandTotalMax + N * wcbMax + NExtended * wcbMax + neLoc * bandTotalMax);
             uint64_t *colb = pack + nLoc * bandTotalMax, *extb = colb + N * wcbMax, *rowb = extb + NExtended * wcbMax;
             std::vector<uint64_t*> rp(world);
@@ -638,6 +650,12 @@ public:
         d_work = dalloc(NExtended * (uint64_t)std::max<uint64_t>(4 * FIELD_EXTENSION, starkInfo.qDim * (starkInfo.qDeg + 1)));
         // ---- trees over the extended sections (MERKLE_TREE_ALLOCATION, starks.hpp:185-191): sources are offsets into the shared slab
         const eSection secs[4] = {cm1_2ns, cm2_2ns, cm3_2ns, cm4_2ns};
+        if (sharded) {                                    // the staging scratch of the sharded commits, once, for the section that needs most
+            uint64_t need = 0, nb, bt, wm;                // (growing it between sections costs a free + malloc of tens of GB: 1 s at 2^20 rows)
+            const eSection cs[3] = {cm1_n, cm2_n, cm3_n};
+            for (eSection c_ : cs) if (starkInfo.mapSectionsN.section[c_]) need = std::max(need, commitBandPlan(starkInfo.mapSectionsN.section[c_], nb, bt, wm));
+            shardScratch(need);
+        }
         for (int i = 0; i < 4; i++) {
             if constexpr (H::kShardable) treesGL[i] = new typename H::Tree(NExtended, starkInfo.mapSectionsN.section[secs[i]], NULL, true, sharded ? world : 0, rank);
             else treesGL[i] = new typename H::Tree(NExtended, starkInfo.mapSectionsN.section[secs[i]], NULL, true);
