@@ -354,7 +354,7 @@ def child_leg(tool, tool_args, world, rank, local_rank, port_offset, backend, ti
         return {"error": repr(e)[:200] + " / " + out[-200:]}
 
 
-def genproof_sharded_cpp_leg(world, rank, local_rank, backend, log_n=23, timeout_s=600):
+def genproof_sharded_cpp_leg(world, rank, local_rank, backend, log_n=23, timeout_s=420):
     """The batch proof with the zkEVM STARK ROW-SHARDED over the ranks, through the C++ product path (BASELINE north_star):
     one CHILD process per rank runs host/zkprover_batch --world N --rank r on the rank's GPU -- xlp_comm_init (RCCL over xGMI; "shm" =
     host-staged for ranks sharing a GPU in rehearsals) before any other GPU work, host/starks.hpp genProofSharded on the per-rank window

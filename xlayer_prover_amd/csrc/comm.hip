@@ -122,14 +122,21 @@ static bool wait_for(const std::function<bool()>& cond, double seconds)
 
 static ShmHeader* shm_hdr() { return (ShmHeader*)g_comm.shm; }
 // device <-> shared-memory slot, through the page-locked bounce buffer
+static int shm_bounce()
+{
+    if (!g_comm.bounce) XLP_HIP(hipHostMalloc((void**)&g_comm.bounce, g_comm.slot_bytes, hipHostMallocDefault));
+    return 0;
+}
 static int shm_put(char* slot, const u64* dev, size_t bytes)
 {
+    if (shm_bounce()) return -1;
     XLP_HIP(hipMemcpy(g_comm.bounce, dev, bytes, hipMemcpyDeviceToHost));
     memcpy(slot, g_comm.bounce, bytes);
     return 0;
 }
 static int shm_get(u64* dev, const char* slot, size_t bytes)
 {
+    if (shm_bounce()) return -1;
     memcpy(g_comm.bounce, slot, bytes);
     XLP_HIP(hipMemcpy(dev, g_comm.bounce, bytes, hipMemcpyHostToDevice));
     return 0;
@@ -218,8 +225,7 @@ int comm_init(Ctx* ctx, int rank, int world, const char* backend, const char* re
         h->attached.fetch_add(1, std::memory_order_acq_rel);
         if (!wait_for([&] { return h->attached.load(std::memory_order_acquire) >= (uint32_t)world; }, 300.0)) return xlp_fail("xlp_comm_init: not every rank attached within 300 s");
         if (h->world != (uint32_t)world || h->slot_bytes != slot) return xlp_fail("xlp_comm_init: ranks disagree on world size / slot size");
-        XLP_HIP(hipHostMalloc((void**)&c.bounce, slot, hipHostMallocDefault));
-        c.kind = Comm::SHM;
+        c.kind = Comm::SHM;                                   // (the bounce buffer is allocated by the first device transfer)
         return shm_barrier();
     }
     return xlp_fail("xlp_comm_init: unknown backend (\"rccl\", \"shm\", \"self\")");
@@ -401,7 +407,7 @@ int comm_all_gather_host(Ctx* ctx, u64* out, const u64* in, u64 words)
 int comm_barrier(Ctx* ctx)
 {
     if (need_comm("xlp_comm_barrier")) return -1;
-    XLP_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->inited) XLP_HIP(hipStreamSynchronize(ctx->stream));
     if (g_comm.world == 1 && g_comm.kind != Comm::RCCL) return 0;
     if (g_comm.kind == Comm::SHM) return shm_barrier();
     u64 one = 1;

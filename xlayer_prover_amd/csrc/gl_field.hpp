@@ -92,19 +92,21 @@ __device__ __forceinline__ u64 neg(u64 a) { return a ? P - a : 0; }  // canon ->
 // Both wrap-arounds are settled together: s = lo + hl*EPS may carry (c: the true value is s + 2^64), l = s - hh may borrow (b: the true
 // value is l - 2^64); net (c - b) * 2^64 = (c - b) * EPS.  c = 1, b = 0: s < 2^64 - 2^33 + 1 and l <= s, adding EPS cannot carry.  b = 1,
 // c = 0: l >= 2^64 - 2^32 + 1, subtracting EPS cannot borrow.  b = c: nothing to do.
-// Written in assembly: 7 VALU + 2 SALU (hipcc builds 11 VALU from the C form: it materialises the borrow with a v_cndmask instead of
+// Written in assembly: 8 VALU + 2 SALU (hipcc builds 11 VALU from the C form: it materialises the borrow with a v_cndmask instead of
 // v_subbrev, compares instead of taking the multiply-add's carry-out, and spends four selects on the correction word).  Every field
-// multiplication ends here.  Round 3: (1) the correction is ONE 64-bit add (v_lshl_add_u64, left to the compiler so that it can schedule
-// it) instead of a v_add_co / v_addc_co pair; (2) HAZARD-SAFE by construction: on gfx940+ a VALU that reads an SGPR / VCC written by a
-// VALU needs two wait states in between (LLVM's GCNHazardRecognizer, "VALUWriteSGPRVALURead", which cannot see inside an asm blob) --
-// every such producer / consumer pair below is two instructions apart: v_mad (c) .. v_sub_co, s_nop .. v_cndmask (c);
-// v_sub_co (b) .. s_nop, v_cndmask .. v_subbrev (b).  The SALU reads of b and c and the VALU reads of the SALU-written x, y need none.
+// multiplication ends here.  HAZARD-SAFE by construction (round 3): on gfx940+ a VALU that reads an SGPR / VCC written by a VALU needs two
+// wait states in between (LLVM's GCNHazardRecognizer, "VALUWriteSGPRVALURead", which cannot see inside an asm blob) -- every such producer /
+// consumer pair below is two instructions apart: v_mad (c) .. v_sub_co, s_nop .. v_cndmask (c);  v_sub_co (b) .. s_nop, v_cndmask ..
+// v_subbrev (b);  v_add_co (vcc) .. v_cndmask, s_nop .. v_addc_co (vcc).  The SALU reads of b and c and the VALU reads of the SALU-written
+// x, y need none.  The result leaves as two 32-bit halves (what the next multiplication reads anyway): a 64-bit v_lshl_add_u64 for the
+// correction was one instruction shorter on paper and 2 v_mov longer in the kernels (aligned register pairs), 14.6k -> 15.6k VALU per
+// Poseidon permutation (profiles/r3/counters_lshl_add_variant.json).
 __device__ __forceinline__ u64 reduce128(u64 lo, u64 hi)
 {
     const u32 hh = (u32)(hi >> 32), hl = (u32)hi;
     u64 s, c;                                // c: lane mask: lo + hl * EPS carried out of 64 bits (the multiply-add's own carry-out)
     asm("v_mad_u64_u32 %[s], %[c], %[hl], -1, %[lo]" : [s] "=&v"(s), [c] "=&s"(c) : [hl] "v"(hl), [lo] "v"(lo));
-    u32 l0, l1, t, r1;
+    u32 l0, l1, t, r0, r1;
     u64 b, x, y;                             // b: lane mask: s - hh borrowed
     // + (c - b) * EPS as a two's complement word (t, r1): +EPS = (FFFFFFFF, 0), -EPS = (00000001, FFFFFFFF)
     asm("v_sub_co_u32 %[l0], %[b], %[s0], %[hh]\n\t"
@@ -114,10 +116,13 @@ __device__ __forceinline__ u64 reduce128(u64 lo, u64 hi)
         "s_xor_b64 %[x], %[b], %[c]\n\t"
         "s_andn2_b64 %[y], %[b], %[c]\n\t"
         "v_cndmask_b32 %[t], 0, %[t], %[x]\n\t"
-        "v_cndmask_b32 %[r1], 0, -1, %[y]"
-        : [b] "=&s"(b), [l0] "=&v"(l0), [l1] "=&v"(l1), [t] "=&v"(t), [r1] "=&v"(r1), [x] "=&s"(x), [y] "=&s"(y)
-        : [c] "s"(c), [hh] "v"(hh), [s0] "v"((u32)s), [s1] "v"((u32)(s >> 32)) : "scc");
-    return pack(l0, l1) + pack(t, r1);       // no wrap in either direction (see above): v_lshl_add_u64
+        "v_add_co_u32 %[r0], vcc, %[l0], %[t]\n\t"
+        "v_cndmask_b32 %[r1], 0, -1, %[y]\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32 %[r1], vcc, %[l1], %[r1], vcc"
+        : [b] "=&s"(b), [l0] "=&v"(l0), [l1] "=&v"(l1), [t] "=&v"(t), [r0] "=&v"(r0), [r1] "=&v"(r1), [x] "=&s"(x), [y] "=&s"(y)
+        : [c] "s"(c), [hh] "v"(hh), [s0] "v"((u32)s), [s1] "v"((u32)(s >> 32)) : "vcc", "scc");
+    return pack(r0, r1);
 }
 
 // any * any -> any
