@@ -1,15 +1,16 @@
-"""Hash of the kernel sources (xlayer_prover_amd/csrc): rocprof summaries under profiles/ are stamped with it, and bench.py
-marks a counter-derived figure stale when the kernels it was measured on are no longer the ones in the tree."""
+"""Hash of the sources of the kernels whose hardware counters bench.py quotes (the extendPol kernels and the Poseidon leaf sponge):
+rocprof summaries under profiles/ are stamped with it, and bench.py marks a counter-derived figure stale when the kernels it was
+measured on are no longer the ones in the tree.  Host-side files of csrc/ (the C ABI, the transport) do not enter it."""
 import hashlib
 import os
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+MEASURED = ("gl_field.hpp", "ntt.hip", "ntt_common.hpp", "ntt_lde.hip", "ntt_lde_common.hpp", "poseidon.hip", "poseidon_constants.inc", "poseidon_fused.inc")
 
 
 def csrc_hash():
     h = hashlib.sha256()
-    for name in sorted(os.listdir(CSRC)):
-        if name.endswith((".hip", ".hpp", ".h", ".inc")):
-            h.update(name.encode()); h.update(b"\0")
-            h.update(open(os.path.join(CSRC, name), "rb").read())
+    for name in MEASURED:
+        h.update(name.encode()); h.update(b"\0")
+        h.update(open(os.path.join(CSRC, name), "rb").read())
     return h.hexdigest()[:16]
