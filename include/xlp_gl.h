@@ -352,6 +352,14 @@ int xlp_dev_merkle_levels(uint64_t* nodes, uint64_t h);
 /* ntt.extendPol(cmX_2ns, cmX_n, ...) followed by treesGL[i]->merkelize() (starks.cpp:53-56,134-137,215-218) as one call:
  * sec_2ns (n_ext x ncols) and nodes ((2 n_ext - 1) * 4) from sec_n (n x ncols), in 64-column bands. */
 int xlp_dev_commit(uint64_t* sec_2ns, uint64_t* nodes, const uint64_t* sec_n, uint64_t n_ext, uint64_t n, uint64_t ncols);
+/* The witness upload of step 1 (the executor's committed polynomials, prover.cpp:435 -> starks.cpp:49-60) in column bands on the copy stream, for a
+ * caller that interleaves it with stages of its own (host/starks.hpp, row-sharded commit: band k + 1 crosses PCIe while band k is exchanged and
+ * extended).  begin: the copy stream waits for the work enqueued so far on the compute stream (it may still read the target).  cols_async: columns
+ * [col0, col0 + ncols) of `rows` rows of a row-major host matrix of row stride ld -> the same place of the device matrix (page-locked host memory for
+ * the full rate).  fence: work enqueued on the compute stream from now on waits for every upload enqueued so far. */
+int xlp_dev_upload_begin(void);
+int xlp_dev_upload_cols_async(uint64_t* dst, const uint64_t* src_host, uint64_t ld, uint64_t col0, uint64_t ncols, uint64_t rows);
+int xlp_dev_upload_fence(void);
 /* The same for a section whose base-domain rows are still in HOST memory -- the witness the executor leaves at pAddress
  * (prover.cpp:435 -> starks.cpp:53): h_src (n x ncols, row-major; pinned with xlp_host_alloc / xlp_host_register for full PCIe
  * rate) is uploaded into sec_n band by band on a second stream while the previous band is extended and absorbed, so the

@@ -88,6 +88,9 @@ SIGNATURES = {
     "xlp_copy_h2d": [_pu, _pu, C.c_size_t],
     "xlp_copy_d2h": [_pu, _pu, C.c_size_t],
     "xlp_dev_scale3_strided": [_pu, _u64, _u64, _pu],
+    "xlp_dev_upload_begin": [],
+    "xlp_dev_upload_cols_async": [_pu, _pu, _u64, _u64, _u64, _u64],
+    "xlp_dev_upload_fence": [],
     "xlp_comm_init": [C.c_int, C.c_int, C.c_char_p, C.c_char_p],
     "xlp_comm_rank": [],
     "xlp_comm_world": [],

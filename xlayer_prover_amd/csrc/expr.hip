@@ -911,6 +911,8 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
     // Slabs.  A slab = gather (pure HBM, 4.6 TB/s) -> the program's kernels (integer issue + latency: 56 % of VALU issue, 3.0 TB/s) ->
     // scatter.  Consecutive slabs are independent except through the halo, so every other slab runs on a second stream with its own
     // scratch: one slab's gather and kernel tails fill the other's stalls.  The scratch budget stays the same (half-size slabs).
+    // (Round 3: confining the two streams to half of the CUs each -- hipExtStreamCreateWithCUMask, by XCD halves or by halves of every XCD -- so that
+    // the slabs run side by side for their whole length was measured SLOWER: zkEVM step42ns 0.444 -> 0.489 / 0.561 s, profiles/r3/expr_cumask_ab.json.)
     // A program whose kernels write a direct column that they also read (a next-row store picked up by the next row: zkEVM step3prev,
     // step3) keeps one stream: running only its gathers / scatters ahead on the second one measured no gain (0.177 vs 0.179 s).
     int S = env_int("XLP_EXPR_STREAMS", 2);
@@ -952,34 +954,13 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
     hipEvent_t computed = nullptr;                        // chain: the previous slab's kernels are done
     std::vector<hipEvent_t> gathered;                     // gathered[i]: slab i's inputs (its rows + halo) have been staged
     hipEvent_t first_written = nullptr;                   // slab 0's destination columns are back in the sections
-    // EXPERIMENT (XLP_EXPR_CUMASK, round 3; measured, see profiles/r3): the two slab streams each confined to HALF of the CUs, so that the two
-    // slabs' kernels really run side by side (one loading while the other computes) instead of meeting only at launch tails.
-    // 1: half of every XCD's CUs per stream (bit i of the mask = CU i, XCD = i % 8);  2: XCDs 0-3 / XCDs 4-7.
-    const int cumask = S == 2 ? env_int("XLP_EXPR_CUMASK", 0) : 0;
-    static hipStream_t masked[2] = {nullptr, nullptr};
-    static int masked_mode = 0;
-    if (cumask && masked_mode != cumask) {
-        for (int a = 0; a < 2; a++) {
-            if (masked[a]) { XLP_HIP(hipStreamSynchronize(masked[a])); XLP_HIP(hipStreamDestroy(masked[a])); masked[a] = nullptr; }
-            uint32_t bits[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (u32 i = 0; i < 256 && i < ctx->ncu; i++) {
-                const bool mine = cumask == 1 ? (int)((i >> 3) & 1) == a : (int)((i & 7) >> 2) == a;
-                if (mine) bits[i >> 5] |= 1u << (i & 31);
-            }
-            XLP_HIP(hipExtStreamCreateWithCUMask(&masked[a], 8, bits));
-        }
-        masked_mode = cumask;
-    }
     if (S > 1) {
         hipEvent_t start;
         XLP_HIP(hipEventCreateWithFlags(&start, hipEventDisableTiming));
         XLP_HIP(hipEventRecord(start, ctx->stream));
-        for (int a = cumask ? 0 : 1; a < S; a++) {
-            if (cumask) streams[a] = masked[a];
-            else {
-                if (!ctx->aux_stream[a - 1]) XLP_HIP(hipStreamCreateWithFlags(&ctx->aux_stream[a - 1], hipStreamNonBlocking));
-                streams[a] = ctx->aux_stream[a - 1];
-            }
+        for (int a = 1; a < S; a++) {
+            if (!ctx->aux_stream[a - 1]) XLP_HIP(hipStreamCreateWithFlags(&ctx->aux_stream[a - 1], hipStreamNonBlocking));
+            streams[a] = ctx->aux_stream[a - 1];
             XLP_HIP(hipStreamWaitEvent(streams[a], start, 0));
         }
         XLP_HIP(hipEventDestroy(start));
@@ -1024,7 +1005,7 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
         }
     }
     if (S > 1) {                                          // later work on the library's stream sees every slab
-        for (int a = cumask ? 0 : 1; a < S; a++) {
+        for (int a = 1; a < S; a++) {
             hipEvent_t done;
             (void)hipEventCreateWithFlags(&done, hipEventDisableTiming);
             (void)hipEventRecord(done, streams[a]);

@@ -579,6 +579,38 @@ int xlp_dev_commit_from_host(uint64_t* sec_n, uint64_t* sec_2ns, uint64_t* nodes
     if (ncols && n && !h_src) return xlp_fail("xlp_dev_commit_from_host: null host pointer");
     return commit_bands(sec_n, sec_2ns, nodes, h_src, n_ext, n, ncols, upload_ms);
 }
+// ---- witness upload in column bands beside the compute stream, for callers that interleave it with their own stages (the row-sharded
+// commit of host/starks.hpp: band k + 1 crosses PCIe while band k is exchanged and extended)
+int xlp_dev_upload_begin(void)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    Ctx* ctx = &g_ctx;
+    if (!ctx->copy_stream) XLP_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    EventPool pool;
+    return pool.mark(ctx->stream, ctx->copy_stream);          // the copies may not overtake earlier work on the compute stream (it may still read the target)
+}
+int xlp_dev_upload_cols_async(uint64_t* dst, const uint64_t* src_host, uint64_t ld, uint64_t col0, uint64_t ncols, uint64_t rows)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if (!rows || !ncols) return 0;
+    if (!dst || !src_host) return xlp_fail("xlp_dev_upload_cols_async: null pointer");
+    if (col0 + ncols > ld) return xlp_fail("xlp_dev_upload_cols_async: columns exceed the row stride");
+    Ctx* ctx = &g_ctx;
+    if (!ctx->copy_stream) XLP_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    XLP_HIP(hipMemcpy2DAsync(dst + col0, ld * sizeof(u64), src_host + col0, ld * sizeof(u64), ncols * sizeof(u64), rows, hipMemcpyHostToDevice, ctx->copy_stream));
+    return 0;
+}
+int xlp_dev_upload_fence(void)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    Ctx* ctx = &g_ctx;
+    if (!ctx->copy_stream) return 0;
+    EventPool pool;
+    return pool.mark(ctx->copy_stream, ctx->stream);          // later work on the compute stream sees every upload enqueued so far
+}
 int xlp_dev_commit(uint64_t* sec_2ns, uint64_t* nodes, const uint64_t* sec_n, uint64_t n_ext, uint64_t n, uint64_t ncols)
 {
     XLP_ENTER;

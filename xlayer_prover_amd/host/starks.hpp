@@ -263,14 +263,14 @@ private:
     }
     // how the sharded commit of a W-column section is cut into column bands (see commitSharded): number of bands, and per band the most
     // columns all ranks together / one rank can hold; -> words of staging scratch it needs
-    uint64_t commitBandPlan(uint64_t W, uint64_t& nb, uint64_t& bandTotalMax, uint64_t& wcbMax) const
+    uint64_t commitBandPlan(uint64_t W, uint64_t& nb, uint64_t& bandTotalMax, uint64_t& wcbMax, uint64_t minBands = 1) const
     {
         const uint64_t wcMax = (W + world - 1) / world;
         const uint64_t allWords = nLoc * W + N * wcMax + NExtended * wcMax + neLoc * W;
         uint64_t budget = 24ULL << 30;
         if (const char* e = getenv("XLP_SHARD_SCRATCH_MB")) { const uint64_t v = strtoull(e, NULL, 10); if (v) budget = v << 20; }
         nb = (allWords * sizeof(uint64_t) + budget - 1) / budget;
-        if (nb < 1) nb = 1;
+        if (nb < minBands) nb = minBands;
         if (nb > W / world && W / world) nb = W / world;            // at least one column per rank and band
         if (W < (uint64_t)world) nb = 1;
         bandTotalMax = 0; wcbMax = 0;
@@ -290,13 +290,15 @@ private:
     //   rows -> columns all-to-all | extendPol of my columns | columns -> rows all-to-all | sub-tree | cap (32 bytes per rank)
     // The two exchanges and the LDE between them run in BANDS of columns (every rank's span is cut into the same number of bands) so that
     // the staging buffers stay below XLP_SHARD_SCRATCH_MB (default 24576) whatever the section: (2 + 2 * 2^ext) x rows x columns words in all.
-    void commitSharded(typename H::Tree* tree, eSection sn, eSection s2)
+    // h_src != NULL (step 1): my rows of the section are still in HOST memory (the executor's output): their columns are uploaded band by band
+    // on the copy stream, band k + 1 crossing PCIe while band k is exchanged and extended (at least 4 bands then)
+    void commitSharded(typename H::Tree* tree, eSection sn, eSection s2, const uint64_t* h_src = NULL)
     {
         const uint64_t W = starkInfo.mapSectionsN.section[sn];
         tree->d_source = section(s2);
         if (W) {
             uint64_t nb, bandTotalMax, wcbMax;
-            commitBandPlan(W, nb, bandTotalMax, wcbMax);
+            commitBandPlan(W, nb, bandTotalMax, wcbMax, h_src ? 4 : 1);
             // band k of a rank's span [a, b): [a + (b - a) k / nb, a + (b - a) (k + 1) / nb)
             auto band = [&](int r, uint64_t k, uint64_t& a, uint64_t& b) {
                 uint64_t c0, c1; colSpan(W, r, c0, c1);
@@ -307,7 +309,18 @@ private:
             std::vector<uint64_t*> rp(world);
             std::vector<const uint64_t*> spc(world);
             std::vector<uint64_t> rw(world), sw(world);
+            auto upload = [&](uint64_t k) {                              // band k's columns (of every rank's span) of my rows: host -> section
+                for (int p_ = 0; p_ < world; p_++) {
+                    uint64_t a, b; band(p_, k, a, b);
+                    if (b > a) XLP_CHECK(xlp_dev_upload_cols_async(section(sn), h_src, W, a, b - a, nLoc));
+                }
+            };
+            if (h_src) { XLP_CHECK(xlp_dev_upload_begin()); upload(0); }
             for (uint64_t k = 0; k < nb; k++) {
+                if (h_src) {
+                    XLP_CHECK(xlp_dev_upload_fence());                   // band k (and everything before it) is there ...
+                    if (k + 1 < nb) upload(k + 1);                        // ... and the next one starts while this one is worked on
+                }
                 uint64_t ma, mb; band(rank, k, ma, mb);
                 const uint64_t wc = mb - ma;                              // my columns of this band
                 // rows -> columns: block p = my rows of rank p's band columns, packed; what arrives from p is rows [p nLoc, (p + 1) nLoc) of mine
@@ -382,9 +395,12 @@ private:
         {
             Timer t(this, "STARK_STEP_1_LDE_AND_MERKLETREE");
             const uint64_t* h_cm1 = (const uint64_t*)pAddress + starkInfo.mapOffsets.section[cm1_n];
-            XLP_CHECK(xlp_copy_h2d(section(cm1_n), h_cm1, nLoc * W1 * sizeof(uint64_t)));
+            if (W1 && pipelineWitness) commitSharded(treesGL[0], cm1_n, cm1_2ns, h_cm1);
+            else {
+                XLP_CHECK(xlp_copy_h2d(section(cm1_n), h_cm1, nLoc * W1 * sizeof(uint64_t)));
+                commitSharded(treesGL[0], cm1_n, cm1_2ns);
+            }
             fillHalo(cm1_n);
-            commitSharded(treesGL[0], cm1_n, cm1_2ns);
             treesGL[0]->getRoot(root0);
             H::putRoot(transcript, root0);
         }
