@@ -24,95 +24,11 @@
 #include "ntt_common.hpp"
 #include "ntt_lde_common.hpp"
 
-template <int BIT> __device__ __forceinline__ gl::u64 gld(const gl::u64* q) { return *q; }
-template <int BIT> __device__ __forceinline__ void gst(gl::u64* q, gl::u64 v) { *q = v; }
-#define XLP_TWMUL(a, b) gl::mulc((a), (b))
-#define XLP_SYNC() __syncthreads()
-
 namespace xlp {
-
-// One radix-2^D round over the tile digit at bit offset TP (compile-time geometry).
-// Written in explicit phases -- (1) all twiddle loads, (2) all data loads, (3) arithmetic,
-// (4) all stores -- because hipcc otherwise serialises "load; s_waitcnt vmcnt(0); use" per
-// element (a full L2 round trip each).  pre/post return per-position factors (LDS cross
-// twiddles) and are only evaluated when HAS_PRE / HAS_POST.
-template <int B, int V, int TP, int D, bool DIT, bool INV, bool HAS_PRE, bool HAS_POST, class Load, class Store, class Pre, class Post, bool POSTW = false>
-__device__ __forceinline__ void fast_round(const u64* __restrict__ tw, Load load, Store store, Pre pre, Post post)
-{
-    constexpr int RAD = 1 << D;
-    constexpr u32 VB = V == 8 ? 3 : 2;
-    constexpr u32 NG = (1u << (B - D)) * V;
-    constexpr u32 TSHIFT = B - TP - D;
-    for (u32 g = threadIdx.x; g < NG; g += blockDim.x) {
-        const u32 v = g & (V - 1);
-        const u32 rest = g >> VB;
-        const u32 low = rest & ((1u << TP) - 1);
-        const u32 high = rest >> TP;
-        const u32 base = (high << (TP + D)) | low;
-        // LDS row of input/output j is affine in j (no carries between the digit fields):
-        // lds_row(base + (j << TP)) = lds_row(base) + j * RS  -> one address register + immediates
-        constexpr u32 RS = TP >= 4 ? (1u << TP) + ((1u << TP) >> 4) : (1u << TP);
-        static_assert(TP == 0 || TP >= 4, "digit offsets are multiples of 4");
-        const u32 r0 = lds_row(base);
-        u64 twr[RAD];
-        if constexpr (POSTW) {
-            // position-indexed twiddles (scale folded in): one factor per input, j = 0 included
-#pragma unroll
-            for (int j = 0; j < RAD; j++) twr[j] = tw[base + ((u32)j << TP)];
-        } else if constexpr (TP > 0) {
-#pragma unroll
-            for (int j = 1; j < RAD; j++) {
-                twr[j] = tw[((u32)j * low) << TSHIFT];
-            }
-        }
-        u64 x[RAD];
-#pragma unroll
-        for (int j = 0; j < RAD; j++) x[j] = load(base + ((u32)j << TP), v, r0 + (u32)j * RS);
-        if constexpr (HAS_PRE) {
-            u64 f[RAD];
-#pragma unroll
-            for (int j = 0; j < RAD; j++) f[j] = pre(base + ((u32)j << TP));
-#pragma unroll
-            for (int j = 0; j < RAD; j++) x[j] = XLP_TWMUL(x[j], f[j]);
-        }
-        if constexpr (POSTW) {
-#pragma unroll
-            for (int j = 0; j < RAD; j++) x[j] = XLP_TWMUL(x[j], twr[j]);
-        } else if constexpr (DIT && TP > 0) {
-#pragma unroll
-            for (int j = 1; j < RAD; j++) x[j] = XLP_TWMUL(x[j], twr[j]);
-        }
-        dft_regs<D>(x);
-        u64 y[RAD];
-#pragma unroll
-        for (int k = 0; k < RAD; k++) y[k] = x[brev<D>(INV ? (RAD - k) % RAD : k)];
-        if constexpr (!DIT && TP > 0) {
-#pragma unroll
-            for (int k = 1; k < RAD; k++) y[k] = XLP_TWMUL(y[k], twr[k]);
-        }
-        if constexpr (HAS_POST) {
-            u64 f[RAD];
-#pragma unroll
-            for (int k = 0; k < RAD; k++) f[k] = post(base + ((u32)k << TP));
-#pragma unroll
-            for (int k = 0; k < RAD; k++) y[k] = XLP_TWMUL(y[k], f[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < RAD; k++) store(base + ((u32)k << TP), v, y[k], r0 + (u32)k * RS);
-    }
-}
-template <int B, int V, int TP, int D, bool DIT, bool INV, class Load, class Store>
-__device__ __forceinline__ void fast_round(const u64* __restrict__ tw, Load load, Store store)
-{
-    fast_round<B, V, TP, D, DIT, INV, false, false>(tw, load, store, NoFactor{}, NoFactor{});
-}
 
 // ------------------------------------------------------------------------ K1
 #ifndef XLP_TOPV
 #define XLP_TOPV 8
-#endif
-#ifndef XLP_WGT
-#define XLP_WGT 1024     // threads per workgroup of the LDE kernels (experiment knob)
 #endif
 // XLP_PF (0 = off): the workgroup that will follow this one on its CU -- block id + XLP_PF resident workgroups, i.e. tile +
 // XLP_PF / 8 under xcd_tile -- finds its first-round input in this XCD's L2 / the memory-side cache.  One dword per 64-byte
@@ -182,76 +98,8 @@ __global__ __launch_bounds__(XLP_WGT) void lde_top_dif(const LdeParams p)
     }
 }
 
-// ------------------------------------------------------------------------ K2
-__global__ __launch_bounds__(XLP_WGT) void lde_mid(const LdeParams p, u32 BT)
-{
-    constexpr int V = 4, B = 12;
-    extern __shared__ u64 sm[];
-    const u32 ncc = (p.wc + V - 1) / V;
-    const u32 tile = xcd_tile();
-    const u32 cc = tile % ncc, hi = tile / ncc;
-    const u32 c = cc * V;
-    const u64 n = 1ull << p.L;
-    auto gload = [&](u32 tpos, u32 v, u32) -> u64 {
-        const u32 col = c + v < p.wc ? c + v : p.wc - 1;
-        const u64 row = ((u64)hi << 12) | tpos;
-        return gld<2>(&p.A[row * p.wc + col]);
-    };
-    auto lload = [&](u32, u32 v, u32 lrow) -> u64 { return sm[lrow * V + v]; };
-    auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { sm[lrow * V + v] = val; };
-    // ---- inverse NTT over the low 12 bits (DIF); last round keeps its outputs in VGPRs
-    fast_round<B, V, 8, 4, false, true>(p.twi_12, gload, lstore);
-    XLP_SYNC();
-    fast_round<B, V, 4, 4, false, true>(p.twi_12, lload, lstore);
-    XLP_SYNC();
-    // a thread's groups in a TP = 0 round: g = tid + i * T -> base = (g >> 2) << 4, v = g & 3  (T % 4 == 0)
-    constexpr int NGT = 1024 / XLP_WGT;
-    const u32 v = threadIdx.x & 3;
-    u32 base_[NGT];
-    u64 X[NGT][16];
-#pragma unroll
-    for (int i = 0; i < NGT; i++) {
-        base_[i] = ((threadIdx.x + i * XLP_WGT) >> 2) << 4;
-        const u32 base = base_[i];
-        u64 x[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = sm[(lds_row(base) + j) * V + v];
-        dft_regs<4>(x);
-#pragma unroll
-        for (int k = 0; k < 16; k++) X[i][k] = x[brev<4>((16 - k) % 16)];   // coefficient at tile position base + k
-    }
-    const bool valid = c + v < p.wc;
-    // ---- every coset: scale, forward NTT over the same 12 bits (DIT), -> B_r
-    // Coset scale S_r[k2] = G^k2 (G = g_r^(2^BT), k2 = natural index of the tile position):
-    // for the 16 inputs of one thread k2 = nb + 256 j, so S = G^nb * H[j], H[j] = G^(256 j)
-    // workgroup-uniform.  H[j] is applied here; G^nb is constant over a thread's DFT16, commutes
-    // with it, and is folded into the position-indexed twiddle table tw2[r] of the next round.
-    for (u32 r = 0; r < (1u << p.e); r++) {
-        const u64* __restrict__ hk = p.hk[r];
-        u64* __restrict__ Br = p.B + (u64)r * n * p.wc;
-        XLP_SYNC();   // previous users of the LDS tile are done
-#pragma unroll
-        for (int i = 0; i < NGT; i++) {
-            const u32 base = base_[i];
-            u64 x[16];
-            x[0] = X[i][0];
-#pragma unroll
-            for (int j = 1; j < 16; j++) x[j] = gl::mulc(X[i][j], hk[j]);
-            dft_regs<4>(x);
-#pragma unroll
-            for (int k = 0; k < 16; k++) sm[(lds_row(base) + k) * V + v] = x[brev<4>(k)];
-        }
-        XLP_SYNC();
-        fast_round<B, V, 4, 4, true, false, false, false, decltype(lload), decltype(lstore), NoFactor, NoFactor, true>(p.tw2[r], lload, lstore, NoFactor{}, NoFactor{});
-        XLP_SYNC();
-        auto gstore = [&](u32 tpos, u32 vv, u64 val, u32) {
-            const u64 row = ((u64)hi << 12) | tpos;
-            if (c + vv < p.wc) gst<3>(&Br[row * p.wc + c + vv], val);
-        };
-        fast_round<B, V, 8, 4, true, false>(p.twf_12, lload, gstore);
-    }
-    (void)valid; (void)BT;
-}
+// K2 (lde_mid) lives in ntt_lde_mid.hip: it is compiled with another instruction-scheduling strategy (see csrc/Makefile)
+int launch_lde_mid(Ctx* ctx, const LdeParams& p, u32 BT);
 
 // ---------------------------------------------------------- stand-alone NTT, bottom pass
 // Second pass of a natural-order NTT / INTT of size 2^(BT+12): DIF over the low 12 bits of one
@@ -527,11 +375,6 @@ int dev_extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld
     if (ctx_scratch(ctx, (size_t)(1 + ncos) * n * wc_max * sizeof(u64), 1, &scratch)) return -1;
     p.A = scratch;
     p.B = scratch + n * wc_max;
-    static bool mid_attr = false;
-    if (!mid_attr) {
-        XLP_HIP(hipFuncSetAttribute((const void*)lde_mid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        mid_attr = true;
-    }
     for (u64 col0 = 0; col0 < ncols; col0 += wc_max) {
         p.col0 = (u32)(first + col0);
         p.wc = (u32)(ncols - col0 < wc_max ? ncols - col0 : wc_max);
@@ -543,13 +386,7 @@ int dev_extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld
         }
         if (launch_top_bt(ctx, p, BT, false)) return -1;
         if (ctx->profile) XLP_HIP(hipEventRecord(ev[1], ctx->stream));
-        {
-            const u32 ncc = (p.wc + 3) / 4;
-            const u64 grid = (u64)ncc << BT;
-            const size_t lds = (size_t)(4096 + 256 + 1) * 4 * sizeof(u64);
-            hipLaunchKernelGGL(lde_mid, dim3((unsigned)grid), dim3(XLP_WGT), lds, ctx->stream, p, BT);
-            XLP_HIP(hipGetLastError());
-        }
+        if (launch_lde_mid(ctx, p, BT)) return -1;
         if (ctx->profile) XLP_HIP(hipEventRecord(ev[2], ctx->stream));
         if (launch_top_bt(ctx, p, BT, true)) return -1;
         if (ctx->profile) XLP_HIP(hipEventRecord(ev[3], ctx->stream));

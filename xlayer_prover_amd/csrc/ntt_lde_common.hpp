@@ -1,8 +1,17 @@
-// Shared declarations of the extendPol fast-path kernels (ntt_lde.hip).
+// Shared declarations and the radix-16 round of the extendPol fast-path kernels (ntt_lde.hip, ntt_lde_mid.hip).
 #pragma once
 #include "gl_field.hpp"
 #include "xlp_internal.hpp"
 #include "ntt_common.hpp"
+
+template <int BIT> __device__ __forceinline__ gl::u64 gld(const gl::u64* q) { return *q; }
+template <int BIT> __device__ __forceinline__ void gst(gl::u64* q, gl::u64 v) { *q = v; }
+#define XLP_TWMUL(a, b) gl::mulc((a), (b))
+#define XLP_SYNC() __syncthreads()
+
+#ifndef XLP_WGT
+#define XLP_WGT 1024     // threads per workgroup of the LDE kernels (experiment knob)
+#endif
 
 namespace xlp {
 
@@ -48,6 +57,83 @@ __device__ __forceinline__ u64 two_level12(const u64* __restrict__ lo, const u64
     const u64 t = lo[e & 4095];
     const u64 eh = e >> 12;
     return eh ? gl::mul(t, hi[eh]) : t;
+}
+
+
+// One radix-2^D round over the tile digit at bit offset TP (compile-time geometry).
+// Written in explicit phases -- (1) all twiddle loads, (2) all data loads, (3) arithmetic,
+// (4) all stores -- because hipcc otherwise serialises "load; s_waitcnt vmcnt(0); use" per
+// element (a full L2 round trip each).  pre/post return per-position factors (LDS cross
+// twiddles) and are only evaluated when HAS_PRE / HAS_POST.
+template <int B, int V, int TP, int D, bool DIT, bool INV, bool HAS_PRE, bool HAS_POST, class Load, class Store, class Pre, class Post, bool POSTW = false>
+__device__ __forceinline__ void fast_round(const u64* __restrict__ tw, Load load, Store store, Pre pre, Post post)
+{
+    constexpr int RAD = 1 << D;
+    constexpr u32 VB = V == 8 ? 3 : 2;
+    constexpr u32 NG = (1u << (B - D)) * V;
+    constexpr u32 TSHIFT = B - TP - D;
+    for (u32 g = threadIdx.x; g < NG; g += blockDim.x) {
+        const u32 v = g & (V - 1);
+        const u32 rest = g >> VB;
+        const u32 low = rest & ((1u << TP) - 1);
+        const u32 high = rest >> TP;
+        const u32 base = (high << (TP + D)) | low;
+        // LDS row of input/output j is affine in j (no carries between the digit fields):
+        // lds_row(base + (j << TP)) = lds_row(base) + j * RS  -> one address register + immediates
+        constexpr u32 RS = TP >= 4 ? (1u << TP) + ((1u << TP) >> 4) : (1u << TP);
+        static_assert(TP == 0 || TP >= 4, "digit offsets are multiples of 4");
+        const u32 r0 = lds_row(base);
+        u64 twr[RAD];
+        if constexpr (POSTW) {
+            // position-indexed twiddles (scale folded in): one factor per input, j = 0 included
+#pragma unroll
+            for (int j = 0; j < RAD; j++) twr[j] = tw[base + ((u32)j << TP)];
+        } else if constexpr (TP > 0) {
+#pragma unroll
+            for (int j = 1; j < RAD; j++) {
+                twr[j] = tw[((u32)j * low) << TSHIFT];
+            }
+        }
+        u64 x[RAD];
+#pragma unroll
+        for (int j = 0; j < RAD; j++) x[j] = load(base + ((u32)j << TP), v, r0 + (u32)j * RS);
+        if constexpr (HAS_PRE) {
+            u64 f[RAD];
+#pragma unroll
+            for (int j = 0; j < RAD; j++) f[j] = pre(base + ((u32)j << TP));
+#pragma unroll
+            for (int j = 0; j < RAD; j++) x[j] = XLP_TWMUL(x[j], f[j]);
+        }
+        if constexpr (POSTW) {
+#pragma unroll
+            for (int j = 0; j < RAD; j++) x[j] = XLP_TWMUL(x[j], twr[j]);
+        } else if constexpr (DIT && TP > 0) {
+#pragma unroll
+            for (int j = 1; j < RAD; j++) x[j] = XLP_TWMUL(x[j], twr[j]);
+        }
+        dft_regs<D>(x);
+        u64 y[RAD];
+#pragma unroll
+        for (int k = 0; k < RAD; k++) y[k] = x[brev<D>(INV ? (RAD - k) % RAD : k)];
+        if constexpr (!DIT && TP > 0) {
+#pragma unroll
+            for (int k = 1; k < RAD; k++) y[k] = XLP_TWMUL(y[k], twr[k]);
+        }
+        if constexpr (HAS_POST) {
+            u64 f[RAD];
+#pragma unroll
+            for (int k = 0; k < RAD; k++) f[k] = post(base + ((u32)k << TP));
+#pragma unroll
+            for (int k = 0; k < RAD; k++) y[k] = XLP_TWMUL(y[k], f[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < RAD; k++) store(base + ((u32)k << TP), v, y[k], r0 + (u32)k * RS);
+    }
+}
+template <int B, int V, int TP, int D, bool DIT, bool INV, class Load, class Store>
+__device__ __forceinline__ void fast_round(const u64* __restrict__ tw, Load load, Store store)
+{
+    fast_round<B, V, TP, D, DIT, INV, false, false>(tw, load, store, NoFactor{}, NoFactor{});
 }
 
 
