@@ -135,3 +135,26 @@ def test_genbatchproof_with_the_zkevm_stark_sharded_equals_one_gpu(tmp_path):
     assert got["sharded"]["world"] == 2 and got["sharded"]["exchanges"] > 0
     assert got["recursive1_root1"] == expect["recursive1_root1"]
     assert got["batch_proof_fnv"] == expect["batch_proof_fnv"] and got["batch_proof_bytes"] == expect["batch_proof_bytes"]
+
+
+@pytest.mark.gpu
+def test_cpp_sharded_starks_on_compiled_window_programs(tmp_path):
+    """two ranks on the AHEAD-OF-TIME kernels of the window-relocated step programs (the prebuilt bundle chelpers/bundles/zkevm.geo12w2, made by
+    `make -C xlayer_prover_amd/chelpers bundles` like the 2^23 bundles bench.py --gpus N uses): every rank reports its four step programs as compiled,
+    and the proof equals the one-GPU proof of the INTERPRETED programs"""
+    from tools import make_stark_bundle as B
+    from xlayer_prover_amd import programs as R
+    win = os.path.join(R.REF_DIR, "bundles", "zkevm.geo12w2")
+    if not os.path.exists(os.path.join(win, "zkevm.steps.json")):
+        pytest.skip("prebuilt window bundle not present (make -C xlayer_prover_amd/chelpers bundles)")
+    man = json.load(open(os.path.join(win, "zkevm.steps.json")))["steps"]
+    assert all(man[st]["plugin"] for st in ("step2prev", "step3prev", "step3", "step42ns")), "window plugins not built"
+    one = B.make("zkevm", 12, False, out=str(tmp_path / "one"), use_opt=False, use_dots=False)       # the programs as converted, interpreted
+    r = subprocess.run([EXE, "bundle", one, "zkevm", str(WSEED), str(CSEED)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "compiled" not in r.stderr
+    expect = json.loads(r.stdout)
+    got, logs = _run_ranks(win, 2, "shm", tmp_path)
+    for log in logs:
+        assert log.count("compiled") >= 4, log[-1500:]
+    assert got == expect
