@@ -556,24 +556,29 @@ def test_evmap_many_entries_vs_oracle(xlp, orc, nbits, eb, width, nev, seed):
 
 
 # ---------------------------------------------------------------- dot_columns (linear part of the FRI polynomial)
-@pytest.mark.parametrize("nrows,ngroups,seed", [(1, 1, 1), (255, 2, 2), (256, 3, 3), (1000, 4, 4), (5000, 3, 5)])
-def test_dot_columns_vs_bigint(xlp, orc, nrows, ngroups, seed):
+@pytest.mark.parametrize("nrows,ngroups,seed,reps", [(1, 1, 1, 1), (255, 2, 2, 1), (256, 3, 3, 1), (1000, 4, 4, 1), (5000, 3, 5, 1), (300, 2, 6, 40), (70, 1, 7, 60)])
+def test_dot_columns_vs_bigint(xlp, orc, nrows, ngroups, seed, reps):
     """xlp_dev_dot_columns against Python integers (the extension product restated as in oracle mul3): several sections of
-    different widths, base and extension columns, repeated columns, arbitrary 64-bit words as inputs"""
+    different widths, base and extension columns, repeated columns, arbitrary 64-bit words as inputs.  reps > 1: thousands of entries
+    per group -- more than one carry-free accumulator takes (1 024 products), and more per 64-word window than the plan allows a
+    group (512), so the accumulators are folded mid-way and windows are split; the all-ones rows make every partial product maximal"""
     import torch
     rng = np.random.default_rng(seed)
     Pm = 0xFFFFFFFF00000001
     widths = [37, 3, 130, 18]
     secs_h = [rng.integers(0, 2**64, size=nrows * w, dtype=np.uint64) for w in widths]      # non-canonical words included
+    if reps > 1:
+        for a, w in zip(secs_h, widths):
+            a[:w] = 2**64 - 1                                                                   # row 0: every word all ones
     secs = [xlp.from_np(a) for a in secs_h]
     ncoef = 50
     coefs_h = orc.fill(3 * ncoef, 0x5EED0D07 + seed)
     coefs_h[0:3] = [2**64 - 1, Pm, Pm + 5]                                                  # non-canonical coefficient words
     ents = []
     for si, w in enumerate(widths):
-        for _ in range(max(2, w // 2)):
+        for _ in range(max(2, w // 2) * reps):
             dim = 3 if (w >= 3 and rng.integers(0, 4) == 0) else 1
-            ents.append((si, w, int(rng.integers(0, w - dim + 1)), dim, int(rng.integers(0, ngroups)), int(rng.integers(0, ncoef))))
+            ents.append((si, w, int(rng.integers(0, w - dim + 1)), dim, int(rng.integers(0, ngroups)), int(rng.integers(0, ncoef)) if reps == 1 else int(rng.integers(0, 3))))
     out = torch.zeros(nrows * 3 * ngroups, dtype=torch.int64, device="cuda")
     xlp.dev_dot_columns(out, [(secs[si], w, c, d, g, k) for si, w, c, d, g, k in ents], ngroups, xlp.from_np(coefs_h), nrows)
     xlp.sync()

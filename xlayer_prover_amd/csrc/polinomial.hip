@@ -499,123 +499,227 @@ int dev_evmap(Ctx* ctx, u64* evals, const u64* LEv, const u64* LpEv, u64 n, u32 
 
 // ------------------------------------------------------------------ dot_columns
 // out[row][g] = sum_e coefs[coef_e] * pol_e[row]  (Fp^3 coefficient x column of dimension 1 or 3), e over the entries of group g.
-// The linear part of the FRI polynomial (starks.cpp:371-380) once its Horner chains are dot products (expr_opt.py).
-// One workgroup = DC_RT rows.  The host cuts every section into windows of <= DC_CB consecutive words that cover the
-// requested columns; per window the workgroup loads a DC_RT x DC_CB tile with row-contiguous (coalesced) reads, stores it
-// transposed in LDS, and every lane (= one row) walks the window's items: the coefficient is wave-uniform (scalar loads),
-// the value comes from LDS, base-field products are accumulated unreduced in 128 bits + overflow count (2^128 = -2^32).
-constexpr int DC_RT = 256, DC_CB = 16, DC_IB = 4;   // rows per workgroup, words per window, items per scalar-load batch
+// The linear part of the FRI polynomial (starks.cpp:371-380) once its Horner chains are dot products (expr_opt.py): at the zkEVM
+// geometry 3 788 (coefficient, column) pairs per row over 1 556 columns, 2^24 rows -- 188 GB read once, and 3 x 3 788 base-field
+// products per row, which is what bounds it (VALU).
+// One workgroup = DC_ROWS rows, three waves: lane = row, WAVE = COMPONENT of the Fp^3 sums (each wave multiplies the same column
+// words by its own word of the coefficients: a lane keeps 6 accumulators per group instead of 18).  The host cuts every section into
+// windows of <= DC_CB consecutive words that cover the requested columns; per window the workgroup loads a DC_ROWS x DC_CB tile (one
+// wave instruction = 512 contiguous bytes of one row), stores it transposed in LDS, and every wave walks ITS stream of the window's
+// items: one 16-byte record per item.
+// PRODUCTS WITHOUT CARRIES (round 3): a coefficient word is cut into limbs of 22 + 21 + 21 bits (once, by dot_expand_kernel), the
+// column value into its two 32-bit halves; the six partial products (< 2^54) each have an accumulator of their own, one v_mad_u64_u32
+// apiece and nothing else -- 6 vector instructions per base-field product where the 128-bit product with its carry chain into a 192-bit
+// sum took 14.  An accumulator holds 1 024 such products before it can overflow: the host orders a window's items by group and counts
+// them, and a group's accumulators are folded into its field-element sum (DcSum::flush) before the count would pass that.  The items of
+// a group run in a loop of their own, so which accumulators a product goes to is static (the first version selected them per item: a
+// third of its instructions were register moves and selects).
+// THE RECORDS GO THROUGH LDS TOO: read with scalar loads (they are wave-uniform) every batch of four cost a scalar-cache miss of ~450
+// cycles that three waves per SIMD do not cover, prefetched one batch ahead or not (SQ_WAIT_ANY 45 % of the wave cycles, VALU 38 % busy:
+// profiles/r3/dot_columns_ab.txt).  The workgroup now copies a window's three streams into LDS beside the tile (prefetched with it) and a
+// wave reads its records back as broadcast ds_read_b128 -- in-order returns, so the loop (DcPipe) keeps records two batches and column
+// words one batch ahead of the multiply-adds with counted waits; the limbs are then vector operands, which v_mad_u64_u32 takes as well.
+constexpr int DC_ROWS = 64, DC_CB = 64, DC_T = 192, DC_IB = 4;   // rows per workgroup, words per window, threads, records per batch
+constexpr int DC_PRE = (DC_ROWS + 2) / 3;             // rows of a tile each wave loads (wave w: rows w, w + 3, ...)
+constexpr u32 DC_HDR = 4;                             // records of a window header
+constexpr u32 DC_SMAX = 144;                          // records of one stream of a window (host); three streams + the tile = 40 192 bytes of LDS: four workgroups per CU
+constexpr int DC_PREREC = (3 * DC_SMAX + DC_T - 1) / DC_T;
+constexpr u32 DC_UNITS = 1024;                        // products one accumulator takes: 1024 * (2^32 - 1) * (2^22 - 1) < 2^64
+constexpr u32 DC_DIM3_UNITS = 3;                      // an extension column puts 3 products into a component's accumulators
+constexpr u32 DC_COLB = (DC_ROWS + 1) * 8;            // bytes between two columns of the LDS tile
+typedef u32 dc_u4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) dc_u4* dc_hdr_t;   // window headers: constant address space = scalar loads
+typedef const __attribute__((address_space(1))) dc_u4* dc_rec_t;
 
-// (ovf : hi : lo) += a * b with explicit 32-bit carry chains (a 128-bit compare per product costs more than the product)
-__device__ __forceinline__ void dc_mac(u64& lo, u64& hi, u32& ovf, u64 a, u64 b)
-{
-    const unsigned __int128 pr = (unsigned __int128)a * b;
-    const u64 pl = (u64)pr, ph = (u64)(pr >> 64);
-    u32 c0, c1, c2, c3, c4;
-    const u32 l0 = __builtin_addc((u32)lo, (u32)pl, 0u, &c0);
-    const u32 l1 = __builtin_addc((u32)(lo >> 32), (u32)(pl >> 32), c0, &c1);
-    const u32 h0 = __builtin_addc((u32)hi, (u32)ph, c1, &c2);
-    const u32 h1 = __builtin_addc((u32)(hi >> 32), (u32)(ph >> 32), c2, &c3);
-    ovf = __builtin_addc(ovf, 0u, c3, &c4);
-    lo = gl::pack(l0, l1);
-    hi = gl::pack(h0, h1);
-}
+struct DcSum {
+    u64 a[6];                                         // partial products of weight 2^0, 2^22, 2^43, 2^32, 2^54, 2^75
+    u64 r;                                            // what has been folded so far (canonical)
+    __device__ __forceinline__ void clear()
+    {
+        r = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) a[i] = 0;
+    }
+    // a += (l0 + l1 2^22 + l2 2^43) * v, v any 64-bit word
+    __device__ __forceinline__ void mac(u32 l0, u32 l1, u32 l2, u64 v)
+    {
+        const u32 v0 = (u32)v, v1 = (u32)(v >> 32);
+        a[0] += (u64)v0 * l0; a[1] += (u64)v0 * l1; a[2] += (u64)v0 * l2;
+        a[3] += (u64)v1 * l0; a[4] += (u64)v1 * l1; a[5] += (u64)v1 * l2;
+    }
+    __device__ __forceinline__ void flush()
+    {
+        constexpr u64 W[6] = {1ULL, 1ULL << 22, 1ULL << 43, 1ULL << 32, 1ULL << 54, (1ULL << 43) - (1ULL << 11)};   // 2^75 = 2^11 (2^32 - 1)
+#pragma unroll
+        for (int i = 0; i < 6; i++) { r = gl::addc(r, gl::mulc(a[i], W[i])); a[i] = 0; }
+    }
+};
+
+// a record: {byte offset of the column in the LDS tile, l0, l1, l2 | group << 24}; in LDS the offsets and the limbs are two arrays.
+// Every array of the pipeline is double-buffered with period two -- sent for in one step, used in the next -- so two steps with the
+// buffer names swapped (step2) need no register moves; a lone step rotates.
+typedef u32 dc_u3 __attribute__((ext_vector_type(3)));
+struct DcHalf { u32 m[DC_IB]; dc_u3 l[DC_IB]; u64 v[DC_IB]; };   // m: offsets of the batch AFTER the one l and v belong to
+struct DcPipe {
+    DcHalf A, B;                                      // between steps: A.l, A.v = batch j (A.v maybe still in flight), B.m = offsets of batch j + 1
+    u32 at;                                           // record index of batch j + 2 within the LDS arrays (wave-uniform)
+    const u32* metas;
+    const u32* limbs;
+    const char* tl;                                   // this lane's row of the tile
+    __device__ __forceinline__ void load_m(DcHalf& h, u32 rec) const
+    {
+        const dc_u4 t = *(const dc_u4*)(metas + rec);
+        h.m[0] = t.x; h.m[1] = t.y; h.m[2] = t.z; h.m[3] = t.w;
+    }
+    __device__ __forceinline__ void load_l(DcHalf& h, u32 rec) const
+    {
+        const dc_u4* q = (const dc_u4*)(limbs + 3 * rec);
+        const dc_u4 t0 = q[0], t1 = q[1], t2 = q[2];
+        h.l[0] = dc_u3{t0.x, t0.y, t0.z}; h.l[1] = dc_u3{t0.w, t1.x, t1.y}; h.l[2] = dc_u3{t1.z, t1.w, t2.x}; h.l[3] = dc_u3{t2.y, t2.z, t2.w};
+    }
+    __device__ __forceinline__ void load_v(DcHalf& h, const u32 (&m)[DC_IB]) const
+    {
+#pragma unroll
+        for (int j = 0; j < DC_IB; j++) h.v[j] = *(const u64*)(tl + m[j]);
+    }
+    __device__ __forceinline__ void start(u32 first, const u32* metas_, const u32* limbs_, const char* tile_lane)
+    {
+        metas = metas_; limbs = limbs_; tl = tile_lane;
+        DcHalf t;
+        load_m(t, first);
+        load_l(A, first);
+        load_m(B, first + DC_IB);
+        load_v(A, t.m);
+        at = first + 2 * DC_IB;
+    }
+    // multiplies batch j (in `cur`), sends for the words and limbs of batch j + 1 (into `nxt`, whose offsets it holds) and the offsets of batch j + 2
+    __device__ __forceinline__ void half(DcSum& s, DcHalf& cur, DcHalf& nxt)
+    {
+        load_v(nxt, nxt.m);
+        load_l(nxt, at - DC_IB);
+        load_m(cur, at);
+        at += DC_IB;
+#pragma unroll
+        for (int j = 0; j < DC_IB; j++) s.mac(cur.l[j].x, cur.l[j].y, cur.l[j].z, cur.v[j]);
+    }
+    __device__ __forceinline__ void step2(DcSum& s) { half(s, A, B); half(s, B, A); }
+    __device__ __forceinline__ void step1(DcSum& s)
+    {
+        half(s, A, B);
+#pragma unroll
+        for (int j = 0; j < DC_IB; j++) { const u32 m = A.m[j]; A.l[j] = B.l[j]; A.v[j] = B.v[j]; B.m[j] = m; }
+    }
+};
 
 template <int G>
-__global__ __launch_bounds__(DC_RT) void dot_columns_kernel(u64* out, const u64* plan, u32 nwindows, const u64* coefs, u64 nrows)
+__global__ __launch_bounds__(DC_T, 3) void dot_columns_kernel(u64* out, const dc_u4* plan, u32 nwindows, u64 nrows)
 {
-    __shared__ u64 tile[DC_CB][DC_RT + 1];
-    const u32 t = threadIdx.x;
-    const u64 row0 = (u64)blockIdx.x * DC_RT;
-    u64 lo[G][3], hi[G][3];                                // 192-bit unreduced sums: (ovf : hi : lo)
-    u32 ovf[G][3];
-    e3 acc3[G];
+    constexpr u32 NREC = 3 * DC_SMAX + 2 * DC_IB;         // the three streams back to back; the pipeline reads up to two batches past a stream
+    __shared__ u64 tile[DC_CB][DC_ROWS + 1];
+    __shared__ __attribute__((aligned(16))) u32 metas[NREC];
+    __shared__ __attribute__((aligned(16))) u32 limbs[3 * NREC];
+    static_assert(sizeof(tile) == DC_CB * DC_COLB, "tile layout");
+    const u32 lane = threadIdx.x & 63;
+    const u32 comp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: which word of the Fp^3 sums this wave computes
+    const u64 row0 = (u64)blockIdx.x * DC_ROWS;
+    DcSum S[G];
+    u32 units[G];                                          // wave-uniform: products in S[g]'s accumulators since its last flush
 #pragma unroll
-    for (int g = 0; g < G; g++)
+    for (int g = 0; g < G; g++) { S[g].clear(); units[g] = 0; }
+    for (u32 i = threadIdx.x; i < NREC; i += DC_T) metas[i] = 0;   // whatever the pipeline picks up past a stream is then a valid offset: an older record's, or 0
+    // The column words and the records of the NEXT window are fetched into registers while the current one is consumed from LDS.
+    u64 pre[DC_PRE];
+    dc_u4 prerec[DC_PREREC];
+    auto fetch = [&](dc_hdr_t hdr) {
+        const dc_u4 h0 = hdr[0], h1 = hdr[1];
+        const u64 stride = gl::pack(h0.z, h0.w);
+        gptr_t src = (gptr_t)gl::pack(h0.x, h0.y) + (row0 + comp) * stride + lane;
+        const u32 ncols = h1.x, nrec3 = 3 * h1.y;
 #pragma unroll
-        for (int c = 0; c < 3; c++) { lo[g][c] = 0; hi[g][c] = 0; ovf[g][c] = 0; acc3[g].c[c] = 0; }
-    // lane -> (row t / 16 of a pass, word t % 16): one wave instruction reads 4 rows x 128 contiguous bytes.  The words of the
-    // NEXT window are fetched into registers while the current one is consumed from LDS.
-    const u32 lc = t & (DC_CB - 1), rs = t >> 4;
-    u64 pre[DC_CB];
-    auto fetch = [&](const u64* hdr) {
-        gptr_t src = (gptr_t)hdr[0] + (row0 + rs) * hdr[1] + lc;
-        const u32 ncols = (u32)hdr[2];
-        const u64 step = (u64)(DC_RT / DC_CB) * hdr[1];
+        for (int i = 0; i < DC_PRE; i++)
+            pre[i] = (lane < ncols && comp + 3 * i < (u32)DC_ROWS && row0 + comp + 3 * i < nrows) ? src[(u64)(3 * i) * stride] : 0;
+        dc_rec_t rsrc = (dc_rec_t)(const dc_u4*)(hdr + DC_HDR);
 #pragma unroll
-        for (int pass = 0; pass < DC_CB; pass++)
-            pre[pass] = (lc < ncols && row0 + pass * (DC_RT / DC_CB) + rs < nrows) ? src[(u64)pass * step] : 0;
+        for (int i = 0; i < DC_PREREC; i++)
+            prerec[i] = threadIdx.x + i * DC_T < nrec3 ? rsrc[threadIdx.x + i * DC_T] : dc_u4{0, 0, 0, 0};
     };
-    auto item = [&](u64 it, u64 k0, u64 k1, u64 k2) {
-        const u32 c = (u32)it & 255, dim = ((u32)it >> 8) & 255, g = ((u32)it >> 16) & 255;
-        if (dim == 1) {
-            const u64 v = tile[c][t];
+    dc_hdr_t p = (dc_hdr_t)plan;
+    if (nwindows) fetch(p);
+    for (u32 w = 0; w < nwindows; w++) {
+        const dc_u4 h1 = p[1];
+        const u32 nrec = h1.y, n3 = h1.w >> 16, wunits = n3 * DC_DIM3_UNITS;   // records per stream; items of dimension 3
+        const u64 counts = gl::pack(h1.z, h1.w);           // items of dimension 1 per group, padded to DC_IB (4 x 12 bits)
+        p += DC_HDR + 3 * nrec;
+        __syncthreads();                                   // previous window fully consumed
+#pragma unroll
+        for (int i = 0; i < DC_PRE; i++)
+            if (comp + 3 * i < (u32)DC_ROWS) tile[lane][comp + 3 * i] = pre[i];
+#pragma unroll
+        for (int i = 0; i < DC_PREREC; i++) {
+            const u32 k = threadIdx.x + i * DC_T;
+            if (k < 3 * DC_SMAX) { metas[k] = prerec[i].x; limbs[3 * k] = prerec[i].y; limbs[3 * k + 1] = prerec[i].z; limbs[3 * k + 2] = prerec[i].w; }
+        }
+        __syncthreads();
+        if (w + 1 < nwindows) fetch(p);
+        DcPipe pipe;
+        pipe.start(comp * nrec, metas, limbs, (const char*)&tile[0][lane]);
+        u32 n1all = 0;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const u32 n1 = (u32)(counts >> (12 * g)) & 0xFFF;
+            if (units[g] + n1 + wunits > DC_UNITS) { S[g].flush(); units[g] = 0; }
+            units[g] += n1 + wunits;
+            u32 i = 0;
+            for (; i + 2 * DC_IB <= n1; i += 2 * DC_IB) pipe.step2(S[g]);
+            if (i < n1) pipe.step1(S[g]);
+            n1all += n1;
+        }
+        // extension columns: (k0, k1, k2) * (x0, x1, x2) in Fp[X] / (X^3 - X - 1), the nine products regrouped as
+        // c0 = k0 x0 + k1 x2 + k2 x1, c1 = k0 x1 + k1 (x0 + x2) + k2 (x1 + x2), c2 = k0 x2 + k1 x1 + k2 (x0 + x2) (the two sums of column
+        // words taken in the field): three records (k0, k1, k2) and three products per component.  No real FRI polynomial has such an
+        // item (expr_opt.py splits extension columns into their words and folds X, X^2 into the coefficient table); the entry point
+        // accepts them, and they take this plain loop behind the pipelined one
+        const u32 q3 = comp * nrec + n1all;
+        for (u32 i = 0; i < n3; i++) {
+            const u32 k = q3 + 3 * i;
+            const char* tc = (const char*)&tile[0][lane] + metas[k];
+            const u32 g = __builtin_amdgcn_readfirstlane(limbs[3 * k + 2] >> 24);
+            const u64 x0 = gl::canon(*(const u64*)tc), x1 = gl::canon(*(const u64*)(tc + DC_COLB)), x2 = gl::canon(*(const u64*)(tc + 2 * DC_COLB));
+            const u64 x02 = gl::addc(x0, x2), x12 = gl::addc(x1, x2);
+            const u64 xa = comp == 0 ? x0 : comp == 1 ? x1 : x2, xb = comp == 0 ? x2 : comp == 1 ? x02 : x1, xc = comp == 0 ? x1 : comp == 1 ? x12 : x02;
 #pragma unroll
             for (int gg = 0; gg < G; gg++)
                 if (g == (u32)gg) {
-                    dc_mac(lo[gg][0], hi[gg][0], ovf[gg][0], k0, v);
-                    dc_mac(lo[gg][1], hi[gg][1], ovf[gg][1], k1, v);
-                    dc_mac(lo[gg][2], hi[gg][2], ovf[gg][2], k2, v);
+                    S[gg].mac(limbs[3 * k], limbs[3 * k + 1], limbs[3 * k + 2] & 0x1FFFFFu, xa);
+                    S[gg].mac(limbs[3 * k + 3], limbs[3 * k + 4], limbs[3 * k + 5] & 0x1FFFFFu, xb);
+                    S[gg].mac(limbs[3 * k + 6], limbs[3 * k + 7], limbs[3 * k + 8] & 0x1FFFFFu, xc);
                 }
-        } else if (dim == 3) {
-            e3 a, x;
-            a.c[0] = gl::canon(k0); a.c[1] = gl::canon(k1); a.c[2] = gl::canon(k2);
-            x.c[0] = gl::canon(tile[c][t]); x.c[1] = gl::canon(tile[c + 1][t]); x.c[2] = gl::canon(tile[c + 2][t]);
-            const e3 m = gl::mul3(a, x);
-#pragma unroll
-            for (int gg = 0; gg < G; gg++)
-                if (g == (u32)gg) acc3[gg] = gl::add3(acc3[gg], m);
-        }                                                  // dim 0: padding
-    };
-    const u64* p = plan;
-    if (nwindows) fetch(p);
-    for (u32 w = 0; w < nwindows; w++) {
-        const u32 nitems = (u32)(p[2] >> 32);              // a multiple of DC_IB (padded on the host)
-        p += 4;
-        __syncthreads();                                   // previous window fully consumed
-#pragma unroll
-        for (int pass = 0; pass < DC_CB; pass++) tile[lc][pass * (DC_RT / DC_CB) + rs] = pre[pass];
-        __syncthreads();
-        if (w + 1 < nwindows) fetch(p + 4 * nitems);
-        // items are wave-uniform records {meta, k0, k1, k2} (coefficients copied in by dot_expand_kernel): a batch of DC_IB is
-        // read with independent scalar loads before any of it is used, so their latency is paid once per batch
-        for (u32 i = 0; i < nitems; i += DC_IB) {
-            u64 r[DC_IB][4];
-#pragma unroll
-            for (int j = 0; j < DC_IB; j++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) r[j][q] = p[4 * (i + j) + q];
-#pragma unroll
-            for (int j = 0; j < DC_IB; j++) item(r[j][0], r[j][1], r[j][2], r[j][3]);
         }
-        p += 4 * nitems;
     }
-    if (row0 + t >= nrows) return;
-    u64* dst = out + (row0 + t) * (3 * G);
+    if (row0 + lane >= nrows) return;
+    u64* dst = out + (row0 + lane) * (3 * G) + comp;
 #pragma unroll
-    for (int g = 0; g < G; g++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const u64 r = gl::canon(gl::reduce128(lo[g][c], hi[g][c]));
-            dst[3 * g + c] = gl::addc(acc3[g].c[c], gl::subc(r, gl::mulc((u64)ovf[g][c], 1ULL << 32)));
-        }
+    for (int g = 0; g < G; g++) {
+        S[g].flush();
+        dst[3 * g] = S[g].r;
+    }
 }
 
-// plan records are 4 words; item records {meta, coefficient index, -, -} become {meta, k0, k1, k2}
-__global__ void dot_expand_kernel(u64* plan, u64 nrecords, const u64* coefs)
+// item records {meta, coefficient index, word of the coefficient, ~0} become {meta, l0, l1, l2}: the limbs of that word
+__global__ void dot_expand_kernel(dc_u4* plan, u64 nrecords, const u64* coefs)
 {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nrecords) return;
-    u64* r = plan + 4 * i;
-    if (r[3] != ~0ULL) return;                             // a window header
-    const u64* k = coefs + 3 * r[1];
-    const u64 k0 = k[0], k1 = k[1], k2 = k[2];
-    r[1] = k0; r[2] = k1; r[3] = k2;
+    const dc_u4 r = plan[i];
+    if (r.w != 0xFFFFFFFFu) return;                        // a window header or padding (a third limb has 21 bits, a header's last word 28)
+    const u64 k = coefs[3 * (u64)r.y + (r.z & 3)];         // r.z: word of the coefficient | group << 24 (records of dimension-3 items)
+    plan[i] = dc_u4{r.x, (u32)k & 0x3FFFFFu, (u32)(k >> 22) & 0x1FFFFFu, (u32)(k >> 43) | (r.z & 0xFF000000u)};
 }
 
 int dev_dot_columns(Ctx* ctx, u64* out, const xlp_dot_entry* entries, u64 nentries, u32 ngroups, const u64* coefs, u64 coefs_size, u64 nrows)
 {
     if (ngroups > 4) return xlp_fail("dot columns: at most 4 groups");
+    if (coefs_size >> 32) return xlp_fail("dot columns: coefficient table too large");
     std::vector<xlp_dot_entry> e(entries, entries + nentries);
     for (const auto& x : e) {
         if (x.dim != 1 && x.dim != 3) return xlp_fail("dot columns: dim must be 1 or 3");
@@ -624,43 +728,60 @@ int dev_dot_columns(Ctx* ctx, u64* out, const xlp_dot_entry* entries, u64 nentri
         if (x.row_stride < x.dim) return xlp_fail("dot columns: stride smaller than dim");
     }
     std::stable_sort(e.begin(), e.end(), [](const xlp_dot_entry& a, const xlp_dot_entry& b) { return a.pol < b.pol; });
-    // windows: runs of entries of one row span (same stride, < DC_CB words from the window's first word, inside one row)
-    std::vector<u64> plan;
+    // windows: runs of entries of one row span (same stride, < DC_CB words from the window's first word, inside one row), closed early
+    // when a stream would get longer than DC_SMAX records.  A window = header, then one record stream per component: the
+    // dimension-1 items group by group, each run padded to DC_IB records (zero limbs), then three records per dimension-3 item.
+    struct Rec { u32 x, y, z, w; };
+    std::vector<Rec> plan;
     u32 nwindows = 0;
     for (size_t i = 0; i < e.size();) {
         const u64* w0 = e[i].pol;
         size_t j = i;
-        u32 ncols = 0;
+        u32 ncols = 0, n3 = 0, n1[4] = {0, 0, 0, 0};
+        auto stream_len = [&](const u32* c1, u32 c3) { u32 r = 3 * c3; for (u32 g = 0; g < 4; g++) r += (c1[g] + DC_IB - 1) / DC_IB * DC_IB; return r; };
         while (j < e.size() && e[j].row_stride == e[i].row_stride && (u64)(e[j].pol - w0) + e[j].dim <= (u64)DC_CB &&
                (u64)(e[j].pol - w0) + e[j].dim <= e[i].row_stride) {
+            u32 t1[4] = {n1[0], n1[1], n1[2], n1[3]}, t3 = n3;
+            if (e[j].dim == 3) t3++; else t1[e[j].group]++;
+            if (j > i && stream_len(t1, t3) > DC_SMAX) break;
+            n3 = t3;
+            for (u32 g = 0; g < 4; g++) n1[g] = t1[g];
             ncols = std::max<u32>(ncols, (u32)(e[j].pol - w0) + e[j].dim);
             j++;
         }
-        const u32 nitems = (u32)((j - i + DC_IB - 1) / DC_IB * DC_IB);
-        plan.push_back((u64)(uintptr_t)w0);
-        plan.push_back(e[i].row_stride);
-        plan.push_back((u64)ncols | ((u64)nitems << 32));
-        plan.push_back(0);
-        for (size_t k = i; k < j; k++) {
-            plan.push_back((u64)(e[k].pol - w0) | ((u64)e[k].dim << 8) | ((u64)e[k].group << 16));
-            plan.push_back(e[k].coef); plan.push_back(0); plan.push_back(~0ULL);
+        u32 padded[4], nrec = 3 * n3;
+        for (u32 g = 0; g < 4; g++) { padded[g] = (n1[g] + DC_IB - 1) / DC_IB * DC_IB; nrec += padded[g]; }
+        const u64 base = (u64)(uintptr_t)w0, stride = e[i].row_stride;
+        const u64 counts = (u64)padded[0] | ((u64)padded[1] << 12) | ((u64)padded[2] << 24) | ((u64)padded[3] << 36) | ((u64)n3 << 48);
+        plan.push_back({(u32)base, (u32)(base >> 32), (u32)stride, (u32)(stride >> 32)});
+        plan.push_back({ncols, nrec, (u32)counts, (u32)(counts >> 32)});
+        for (u32 k = 2; k < DC_HDR; k++) plan.push_back({0, 0, 0, 0});
+        for (u32 comp = 0; comp < 3; comp++) {
+            for (u32 g = 0; g < 4; g++) {
+                u32 put = 0;
+                for (size_t k = i; k < j; k++)
+                    if (e[k].dim == 1 && e[k].group == g) { plan.push_back({(u32)(e[k].pol - w0) * DC_COLB, (u32)e[k].coef, comp, 0xFFFFFFFFu}); put++; }
+                for (; put < padded[g]; put++) plan.push_back({0, 0, 0, 0});          // 0 * word 0 of the window
+            }
+            for (size_t k = i; k < j; k++)
+                if (e[k].dim == 3)
+                    for (u32 word = 0; word < 3; word++) plan.push_back({(u32)(e[k].pol - w0) * DC_COLB, (u32)e[k].coef, word | (e[k].group << 24), 0xFFFFFFFFu});
         }
-        for (size_t k = j - i; k < nitems; k++) { plan.push_back(0); plan.push_back(0); plan.push_back(0); plan.push_back(0); }   // dim 0
         nwindows++;
         i = j;
     }
     u64* dplan = nullptr;
-    if (ctx_scratch(ctx, std::max<size_t>(plan.size() * 8, 8), 2, &dplan)) return -1;
-    if (!plan.empty()) XLP_HIP(hipMemcpyAsync(dplan, plan.data(), plan.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (ctx_scratch(ctx, plan.size() * sizeof(Rec), 2, &dplan)) return -1;
+    XLP_HIP(hipMemcpyAsync(dplan, plan.data(), plan.size() * sizeof(Rec), hipMemcpyHostToDevice, ctx->stream));
     XLP_HIP(hipStreamSynchronize(ctx->stream));            // plan goes out of scope
-    if (!plan.empty())
-        hipLaunchKernelGGL(dot_expand_kernel, dim3((unsigned)((plan.size() / 4 + 255) / 256)), dim3(256), 0, ctx->stream, dplan, (u64)(plan.size() / 4), coefs);
-    const dim3 grid((unsigned)((nrows + DC_RT - 1) / DC_RT)), block(DC_RT);
+    hipLaunchKernelGGL(dot_expand_kernel, dim3((unsigned)((plan.size() + 255) / 256)), dim3(256), 0, ctx->stream, (dc_u4*)dplan, (u64)plan.size(), coefs);
+    const dim3 grid((unsigned)((nrows + DC_ROWS - 1) / DC_ROWS)), block(DC_T);
+    const dc_u4* dp = (const dc_u4*)dplan;
     switch (ngroups) {
-    case 1: hipLaunchKernelGGL(dot_columns_kernel<1>, grid, block, 0, ctx->stream, out, dplan, nwindows, coefs, nrows); break;
-    case 2: hipLaunchKernelGGL(dot_columns_kernel<2>, grid, block, 0, ctx->stream, out, dplan, nwindows, coefs, nrows); break;
-    case 3: hipLaunchKernelGGL(dot_columns_kernel<3>, grid, block, 0, ctx->stream, out, dplan, nwindows, coefs, nrows); break;
-    default: hipLaunchKernelGGL(dot_columns_kernel<4>, grid, block, 0, ctx->stream, out, dplan, nwindows, coefs, nrows); break;
+    case 1: hipLaunchKernelGGL(dot_columns_kernel<1>, grid, block, 0, ctx->stream, out, dp, nwindows, nrows); break;
+    case 2: hipLaunchKernelGGL(dot_columns_kernel<2>, grid, block, 0, ctx->stream, out, dp, nwindows, nrows); break;
+    case 3: hipLaunchKernelGGL(dot_columns_kernel<3>, grid, block, 0, ctx->stream, out, dp, nwindows, nrows); break;
+    default: hipLaunchKernelGGL(dot_columns_kernel<4>, grid, block, 0, ctx->stream, out, dp, nwindows, nrows); break;
     }
     XLP_HIP(hipGetLastError());
     return 0;
