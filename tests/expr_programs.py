@@ -80,3 +80,65 @@ def make_buffers(orc, seed, n, width, nconst=5, nconst2=4, nch=4, npub=3, nev=5,
         "public_inputs": f(npub, 4), "evals": f(3 * nev, 5), "x_n": f(n, 6), "x_2ns": f(n, 7), "zi": f(zi_size, 8),
         "x_div_x_sub_xi": f(3 * n, 9), "x_div_x_sub_wxi": f(3 * n, 10), "q_2ns": f(3 * n, 11), "f_2ns": f(3 * n, 12),
     }
+
+
+def accumulation_program(seed, n, nterms, nin=24, ntmp1=8, ntmp3=6, nch=4, nev=5, nstore=40):
+    """Chains of acc (+|-)= (challenge | evaluation) x base-field value -- what the ahead-of-time generator turns into carry-free
+    accumulators (csrc/expr.hip, "lazy accumulation") -- with everything that makes that hard: values in the base field and in Fp^3 (the accumulators themselves included), an accumulator hopping between temporaries,
+    an old state read after the accumulator moved on, copies of a state, products read twice or never added, sums of two products,
+    accumulators stored or multiplied mid-chain, several chains interleaved (more than the generator keeps alive), base-field bases."""
+    rng = np.random.default_rng(seed)
+    width = nin + 3 * nstore
+    prog = E.Program()
+    next_store = [nin]
+
+    def coef():
+        return E.challenge(int(rng.integers(0, nch))) if rng.integers(0, 3) else E.evaluation(int(rng.integers(0, nev)))
+
+    def value():
+        k = rng.integers(0, 5)
+        if k == 0: return E.pols(int(rng.integers(0, nin)), width)
+        if k == 1: return E.pols_prime(int(rng.integers(0, nin)), 1, n, width)
+        if k == 2: return E.number(int(rng.integers(0, 2**63)) * 2 + 1)
+        if k == 3: return E.x_n()
+        return E.tmp1(int(rng.integers(0, ntmp1)))
+    for i in range(ntmp1):
+        prog.emit(E.MUL, E.tmp1(i), E.pols(int(rng.integers(0, nin)), width), E.pols(int(rng.integers(0, nin)), width))
+    for i in range(ntmp3):
+        prog.emit(E.COPY, E.tmp3(i), E.pols(int(rng.integers(0, nin - 2)), width, 3))
+    for it in range(nterms):
+        acc = int(rng.integers(0, ntmp3 - 1))
+        prodt = ntmp3 - 1                                   # the temporary the products go through
+        val = value() if rng.integers(0, 3) else (E.pols(int(rng.integers(0, nin - 2)), width, 3) if rng.integers(0, 2) else E.tmp3(int(rng.integers(0, ntmp3 - 1))))
+        prog.emit(E.MUL, E.tmp3(prodt), coef(), val) if rng.integers(0, 2) else prog.emit(E.MUL, E.tmp3(prodt), val, coef())
+        r = rng.integers(0, 20)
+        if r < 11:                                          # in place
+            prog.emit(E.ADD, E.tmp3(acc), E.tmp3(acc), E.tmp3(prodt)) if rng.integers(0, 2) else prog.emit(E.ADD, E.tmp3(acc), E.tmp3(prodt), E.tmp3(acc))
+        elif r < 13:
+            prog.emit(E.SUB, E.tmp3(acc), E.tmp3(acc), E.tmp3(prodt))
+        elif r == 13:                                       # product - accumulator: stays plain
+            prog.emit(E.SUB, E.tmp3(acc), E.tmp3(prodt), E.tmp3(acc))
+        elif r == 14:                                       # hop: the old temporary keeps the old state and is read later
+            other = (acc + 1) % (ntmp3 - 1)
+            prog.emit(E.ADD, E.tmp3(other), E.tmp3(acc), E.tmp3(prodt))
+        elif r == 15:                                       # the product is read again, and two products are added
+            prog.emit(E.ADD, E.tmp3(acc), E.tmp3(prodt), E.tmp3(prodt))
+            prog.emit(E.MUL, E.tmp3(acc), E.tmp3(acc), E.tmp3(prodt))
+        elif r == 16:                                       # a copy of a state, then the accumulator moves on
+            other = (acc + 2) % (ntmp3 - 1)
+            prog.emit(E.COPY, E.tmp3(other), E.tmp3(acc))
+            prog.emit(E.ADD, E.tmp3(acc), E.tmp3(acc), E.tmp3(prodt))
+        elif r == 17:                                       # base-field base
+            prog.emit(E.ADD, E.tmp3(acc), value(), E.tmp3(prodt))
+        elif r == 18 and next_store[0] + 3 <= width:        # a state is stored mid-chain
+            prog.emit(E.ADD, E.tmp3(acc), E.tmp3(acc), E.tmp3(prodt))
+            prog.emit(E.COPY, E.pols(next_store[0], width, 3), E.tmp3(acc)); next_store[0] += 3
+        else:                                               # a product nobody adds
+            if next_store[0] + 3 <= width:
+                prog.emit(E.COPY, E.pols(next_store[0], width, 3), E.tmp3(prodt)); next_store[0] += 3
+    for i in range(ntmp3 - 1):
+        if next_store[0] + 3 <= width:
+            prog.emit(E.COPY, E.pols(next_store[0], width, 3), E.tmp3(i)); next_store[0] += 3
+    prog.emit(E.COPY, E.q_2ns(), E.tmp3(0))
+    prog.emit(E.COPY, E.f_2ns(), E.tmp3(1))
+    return prog, width

@@ -7,7 +7,7 @@ import pytest
 
 from tests.conftest import GOLDEN_PROOFS
 
-from tests.expr_programs import make_buffers, random_program
+from tests.expr_programs import accumulation_program, make_buffers, random_program
 from xlayer_prover_amd import expr as E
 
 
@@ -251,6 +251,29 @@ def test_expr_generated_code_on_cpu(orc, tmp_path, seed, n, ninstr, row0, nrows)
         del os.environ["XLP_EXPR_SEG"]
     exp = {k: v.copy() for k, v in bufs.items()}
     orc.expr_run(prog.code, prog.ntmp1, prog.ntmp3, exp, row0, nrows, 5, 4)
+    for k in ("pols", "q_2ns", "f_2ns"):
+        assert (got[k] == exp[k]).all(), f"{k}: {np.flatnonzero(got[k] != exp[k])[:5]}"
+
+
+@pytest.mark.parametrize("seed,n,nterms,seg,accs", [(61, 64, 120, 64, 3), (62, 100, 400, 256, 3), (63, 64, 1500, 100000, 1), (64, 64, 200, 32, 2)])
+def test_expr_generated_lazy_accumulation_on_cpu(orc, tmp_path, seed, n, nterms, seg, accs):
+    """The generator's carry-free accumulators (acc += challenge x value as gl::lazy3::mac, csrc/expr.hip) against the oracle, on the
+    CPU stand-in that traps on any 64-bit overflow of a partial sum: chains that hop between temporaries, states read after the
+    accumulator moved on, more chains than accumulators, one segment of 1 500 terms (past the 1 000 an accumulator is given), and
+    challenge words that are not canonical."""
+    os.environ["XLP_EXPR_SEG"] = str(seg); os.environ["XLP_EXPR_LAZY_ACCS"] = str(accs)
+    try:
+        prog, width = accumulation_program(seed, n, nterms)
+        bufs = make_buffers(orc, 0x5EED0700 + seed, n, width)
+        bufs["challenges"][:3] = [2**64 - 1, 0xFFFFFFFF00000001, 0xFFFFFFFF00000006]     # any 64-bit word
+        bufs["pols"][:width] = 2**64 - 1                                                  # row 0: every value all ones
+        got = _run_generated_on_cpu(tmp_path, prog.code, prog.ntmp1, prog.ntmp3, bufs, 0, n, 5, 4)
+        text = open(tmp_path / "prog.hip").read()
+        assert ".mac(" in text and ".mac3(" in text and ".fold(" in text and "neg_any" in text
+    finally:
+        del os.environ["XLP_EXPR_SEG"]; del os.environ["XLP_EXPR_LAZY_ACCS"]
+    exp = {k: v.copy() for k, v in bufs.items()}
+    orc.expr_run(prog.code, prog.ntmp1, prog.ntmp3, exp, 0, n, 5, 4)
     for k in ("pols", "q_2ns", "f_2ns"):
         assert (got[k] == exp[k]).all(), f"{k}: {np.flatnonzero(got[k] != exp[k])[:5]}"
 

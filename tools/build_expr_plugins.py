@@ -78,7 +78,9 @@ def main():
             stamp = os.path.join(build, name + ".stamp")
             # ... and the generated text is compiled against the library's field arithmetic: a change there (gl_field.hpp,
             # xlp_expr_jit.h) makes the plugin stale as well
-            sig = [l for l in open(probe) if "xlpjit_signature" in l][0] + "headers " + headers_hash() + "\n"
+            # ... and so does a change of the generator itself (segment size, lazy accumulation): the stamp covers the generated text
+            import hashlib
+            sig = [l for l in open(probe) if "xlpjit_signature" in l][0] + "headers " + headers_hash() + "\ntext " + hashlib.sha256(open(probe, "rb").read()).hexdigest()[:16] + "\n"
             if os.path.exists(so) and os.path.exists(stamp) and open(stamp).read() == sig and not a.force:
                 print("up to date", so); continue
             t = time.time()

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <sstream>
 #include <algorithm>
+#include <array>
 #include <map>
 #include <set>
 #include <string>
@@ -712,6 +713,36 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
             if (i % SEG == 0) live_in[i / SEG] = live;
         }
     }
+    // dies[i][o]: the temporary operand o of instruction i is not read again (its words are overwritten first, or never touched)
+    std::vector<std::array<bool, 3>> dies(ins.size());
+    {
+        std::vector<bool> live(W, false);
+        for (size_t i = ins.size(); i-- > 0;) {
+            const DInstr& in = ins[i];
+            dies[i] = {false, false, false};
+            for (int o = 1; o < 3; o++) {
+                if (in.k[o] != XD_TMP) continue;
+                bool d = true;
+                for (u32 c = 0; c < in.dim[o]; c++) {
+                    const u64 w = in.prm[o][0] + c;
+                    const bool overwritten = in.k[0] == XD_TMP && w >= in.prm[0][0] && w < in.prm[0][0] + in.dim[0];
+                    if (live[w] && !overwritten) d = false;
+                }
+                dies[i][o] = d;
+            }
+            if (in.k[0] == XD_TMP) for (u32 c = 0; c < in.dim[0]; c++) live[in.prm[0][0] + c] = false;
+            for (int o = 1; o < 3; o++) if (in.k[o] == XD_TMP) for (u32 c = 0; c < in.dim[o]; c++) live[in.prm[o][0] + c] = true;
+        }
+    }
+    // LAZY ACCUMULATION (round 3).  Most of a step program is "acc += challenge power x value" (the constraint sum in dot-product form:
+    // 6 774 of the 15 891 multiplications of the zkEVM step42ns, 4 383 of 5 172 in step3prev).  The coefficient is wave-uniform, so the
+    // product needs no reduction of its own: a MUL of a challenge / evaluation (dimension 3) by a base-field value is kept as a symbol
+    // ("@P"), an ADD / SUB of such a symbol becomes gl::lazy3::mac on an accumulator ("@A", 18 vector instructions instead of ~63), and
+    // the three canonical words are only computed (fold) where something else reads them or at the end of the segment.  Results are the
+    // same field elements.  XLP_EXPR_LAZY=0 generates the plain form; XLP_EXPR_LAZY_ACCS bounds the accumulators alive at once
+    // (42 registers each).
+    const bool lazy_on = env_int("XLP_EXPR_LAZY", 1) != 0;
+    const size_t lazy_max = (size_t)env_int("XLP_EXPR_LAZY_ACCS", 3);
     const std::string prologue =
         "// generated by xlp_expr_codegen -- do not edit\n#include <hip/hip_runtime.h>\n#include \"gl_field.hpp\"\n#include \"xlp_expr_jit.h\"\n"
         "typedef unsigned long long u64_;\nusing gl::u64;\n"
@@ -743,6 +774,59 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
             return n;
         };
         auto num = [&](u64 v) { snprintf(buf, sizeof buf, "0x%llxULL", (unsigned long long)v); return std::string(buf); };
+        // symbols of the lazy accumulation: "@P<id>.<c>" a product not multiplied yet, "@A<id>:<version>.<c>" a state of an accumulator
+        struct Prod { std::string k[3], v, x[3], mat[3]; bool ext = false, done = false; };   // ext: the value is an Fp^3 element x (canonical words)
+        struct Acc { std::string var; u32 ver = 0, count = 0; bool retired = false; size_t last = 0; std::map<u32, std::array<std::string, 3>> folded; };
+        std::vector<Prod> prods;
+        std::vector<Acc> accs;
+        std::map<std::string, std::string> rawval;       // uniform words as loaded (no canon): coefficients of the products
+        auto raw = [&](const std::string& expr) {
+            auto it = rawval.find(expr);
+            if (it != rawval.end()) return it->second;
+            const std::string n = fresh();
+            os << "    const u64 " << n << " = " << expr << ";\n";
+            rawval[expr] = n;
+            return n;
+        };
+        auto sym = [&](char kind, u32 id, u32 ver, u32 c) {
+            if (kind == 'P') snprintf(buf, sizeof buf, "@P%u.%u", id, c); else snprintf(buf, sizeof buf, "@A%u:%u.%u", id, ver, c);
+            return std::string(buf);
+        };
+        auto parse = [](const std::string& t, char& kind, u32& id, u32& ver, u32& c) {
+            if (t.size() < 2 || t[0] != '@') return false;
+            kind = t[1]; ver = 0;
+            if (kind == 'P') return sscanf(t.c_str() + 2, "%u.%u", &id, &c) == 2;
+            return sscanf(t.c_str() + 2, "%u:%u.%u", &id, &ver, &c) == 3;
+        };
+        // the SSA name of a value: multiplies a product / folds an accumulator state on first use
+        auto real = [&](const std::string& t) -> std::string {
+            char kind; u32 id, ver, c;
+            if (!parse(t, kind, id, ver, c)) return t;
+            if (kind == 'P') {
+                Prod& p = prods[id];
+                if (!p.done && p.ext) {
+                    const std::string e = fresh();
+                    os << "    const gl::e3 " << e << " = gl::mul3(gl::e3{{gl::canon(" << p.k[0] << "), gl::canon(" << p.k[1] << "), gl::canon(" << p.k[2] << ")}}, gl::e3{{"
+                       << p.x[0] << ", " << p.x[1] << ", " << p.x[2] << "}});\n";
+                    for (u32 q = 0; q < 3; q++) p.mat[q] = e + ".c[" + std::to_string(q) + "]";
+                    p.done = true;
+                }
+                if (!p.done) {
+                    for (u32 q = 0; q < 3; q++) { p.mat[q] = fresh(); os << "    const u64 " << p.mat[q] << " = gl::mulc(" << p.k[q] << ", " << p.v << ");\n"; }
+                    p.done = true;
+                }
+                return p.mat[c];
+            }
+            Acc& a = accs[id];
+            auto it = a.folded.find(ver);
+            if (it == a.folded.end()) {                  // only the current state can be unfolded: older ones are folded before the accumulator moves on
+                if (ver != a.ver) os << "#error xlp_expr_codegen: stale accumulator state\n";
+                std::array<std::string, 3> f = {fresh(), fresh(), fresh()};
+                os << "    u64 " << f[0] << ", " << f[1] << ", " << f[2] << "; " << a.var << ".fold(" << f[0] << ", " << f[1] << ", " << f[2] << ");\n";
+                it = a.folded.emplace(ver, f).first;
+            }
+            return it->second[c];
+        };
         // value of component c of a source operand
         auto src = [&](const DInstr& in, int o, u32 c) -> std::string {
             const u64* p = in.prm[o];
@@ -791,10 +875,97 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
             const DInstr& in = ins[i];
             const u32 dd = in.dim[0], ad = in.dim[1], bd = in.dim[2];
             std::string a[3], b[3], r[3];
+            auto uniform3 = [&](int o) { return in.dim[o] == 3 && (in.k[o] == XLP_K_CHALLENGE || in.k[o] == XLP_K_EVAL); };
+            const int ko = (lazy_on && in.op == XLP_OP_MUL) ? (uniform3(1) ? 1 : uniform3(2) ? 2 : 0) : 0;
+            if (ko) {                                    // (uniform Fp^3) x (value of the row): a symbol, multiplied where it is read
+                Prod p;
+                const char* arr = in.k[ko] == XLP_K_CHALLENGE ? "A.P.challenges[" : "A.P.evals[";
+                for (u32 c = 0; c < 3; c++) p.k[c] = raw(arr + num(3 * in.prm[ko][0] + c) + "]");
+                const int vo = ko == 1 ? 2 : 1;
+                p.ext = in.dim[vo] == 3;
+                if (p.ext) for (u32 c = 0; c < 3; c++) p.x[c] = real(src(in, vo, c));
+                else p.v = real(src(in, vo, 0));
+                prods.push_back(p);
+                for (u32 c = 0; c < 3; c++) r[c] = sym('P', (u32)prods.size() - 1, 0, c);
+            } else {
             for (u32 c = 0; c < 3; c++) a[c] = src(in, 1, c);
             if (in.op != XLP_OP_COPY) for (u32 c = 0; c < 3; c++) b[c] = src(in, 2, c);
-            if (in.op == XLP_OP_COPY) { for (u32 c = 0; c < dd; c++) r[c] = a[c]; }
+            // an ADD / SUB that takes a product symbol goes to an accumulator
+            bool accumulated = false;
+            if (lazy_on && dd == 3 && (in.op == XLP_OP_ADD || in.op == XLP_OP_SUB)) {
+                auto prod_of = [&](const std::string* x, u32 dim) -> int {
+                    char kind; u32 id, ver, c;
+                    if (dim != 3 || !parse(x[0], kind, id, ver, c) || kind != 'P' || c != 0) return -1;
+                    return (x[1] == sym('P', id, 0, 1) && x[2] == sym('P', id, 0, 2)) ? (int)id : -1;
+                };
+                auto acc_of = [&](const std::string* x, u32 dim) -> int {    // the CURRENT state of an accumulator still in use
+                    char kind; u32 id, ver, c;
+                    if (dim != 3 || !parse(x[0], kind, id, ver, c) || kind != 'A' || c != 0) return -1;
+                    if (x[1] != sym('A', id, ver, 1) || x[2] != sym('A', id, ver, 2)) return -1;
+                    return (!accs[id].retired && accs[id].ver == ver) ? (int)id : -1;
+                };
+                const int pa = in.op == XLP_OP_ADD ? prod_of(a, ad) : -1, pb = prod_of(b, bd);   // a - k v = a + (-k) v; (k v) - b stays plain
+                if (pa >= 0 || pb >= 0) {
+                    accumulated = true;
+                    const std::string* X = (pa >= 0 && pb >= 0) ? nullptr : (pb >= 0 ? a : b);
+                    const u32 xd = X == a ? ad : bd;
+                    const int xo = X == a ? 1 : 2;
+                    const size_t nprod = (pa >= 0 ? (prods[pa].ext ? 3 : 1) : 0) + (pb >= 0 ? (prods[pb].ext ? 3 : 1) : 0);   // products per accumulator
+                    int aid = X ? acc_of(X, xd) : -1;
+                    if (aid >= 0 && accs[aid].count + nprod > 1000) aid = -1;   // an accumulator takes 1 024 products (gl::lazy3)
+                    const bool created = aid < 0;
+                    if (aid >= 0) {
+                        // somebody else still holds this state (a temporary that is neither this operand on its last read nor the destination):
+                        // fold it now, the holders then resolve to the folded words, and the accumulator moves on
+                        Acc& A = accs[aid];
+                        bool others = false;
+                        for (const auto& kv : tval) {
+                            char kind; u32 id, ver, c;
+                            if (!parse(kv.second, kind, id, ver, c) || kind != 'A' || (int)id != aid || ver != A.ver) continue;
+                            const u64 w = kv.first;
+                            const bool is_dst = in.k[0] == XD_TMP && w >= in.prm[0][0] && w < in.prm[0][0] + dd;
+                            const bool is_x = in.k[xo] == XD_TMP && w >= in.prm[xo][0] && w < in.prm[xo][0] + xd && dies[i][xo];
+                            if (!is_dst && !is_x) others = true;
+                        }
+                        if (others) (void)real(X[0]);
+                    } else {
+                        std::string base[3] = {"0ULL", "0ULL", "0ULL"};
+                        if (X) for (u32 c = 0; c < xd; c++) base[c] = real(X[c]);
+                        size_t alive = 0;
+                        for (const Acc& A : accs) alive += !A.retired;
+                        while (alive >= lazy_max && alive) {                     // retire the accumulator touched longest ago
+                            size_t victim = accs.size();
+                            for (size_t q = 0; q < accs.size(); q++) if (!accs[q].retired && (victim == accs.size() || accs[q].last < accs[victim].last)) victim = q;
+                            (void)real(sym('A', (u32)victim, accs[victim].ver, 0));
+                            accs[victim].retired = true;
+                            alive--;
+                        }
+                        Acc A;
+                        A.var = "acc" + std::to_string(sg) + "_" + std::to_string(accs.size());
+                        os << "    gl::lazy3 " << A.var << "; " << A.var << ".init(" << base[0] << ", " << base[1] << ", " << base[2] << ");\n";
+                        accs.push_back(A);
+                        aid = (int)accs.size() - 1;
+                    }
+                    Acc& A = accs[aid];
+                    auto mac = [&](int pid, bool negate) {
+                        const Prod& p = prods[pid];
+                        os << "    " << A.var << (p.ext ? ".mac3(" : ".mac(");
+                        for (u32 c = 0; c < 3; c++) os << (negate ? "gl::neg_any(" + p.k[c] + ")" : p.k[c]) << ", ";
+                        if (p.ext) os << p.x[0] << ", " << p.x[1] << ", " << p.x[2] << ");\n";
+                        else os << p.v << ");\n";
+                    };
+                    if (pa >= 0) mac(pa, false);
+                    if (pb >= 0) mac(pb, in.op == XLP_OP_SUB);
+                    if (!created) A.ver++;                                       // the state handed out before this instruction is history
+                    A.count += (u32)nprod;
+                    A.last = i;
+                    for (u32 c = 0; c < 3; c++) r[c] = sym('A', (u32)aid, A.ver, c);
+                }
+            }
+            if (accumulated) {}
+            else if (in.op == XLP_OP_COPY) { for (u32 c = 0; c < dd; c++) r[c] = a[c]; }
             else if (in.op == XLP_OP_ADD || in.op == XLP_OP_SUB) {
+                for (u32 c = 0; c < 3; c++) { a[c] = real(a[c]); b[c] = real(b[c]); }
                 const char* f = in.op == XLP_OP_ADD ? "gl::addc" : "gl::subc";
                 for (u32 c = 0; c < dd; c++) {
                     const bool ha = c < ad, hb = c < bd;
@@ -804,6 +975,7 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
                     else { r[c] = fresh(); os << "    const u64 " << r[c] << " = gl::neg(" << b[c] << ");\n"; }
                 }
             } else {
+                for (u32 c = 0; c < 3; c++) { a[c] = real(a[c]); b[c] = real(b[c]); }
                 if (ad == 3 && bd == 3) {
                     const std::string e = fresh();
                     os << "    const gl::e3 " << e << " = gl::mul3(gl::e3{{" << a[0] << ", " << a[1] << ", " << a[2] << "}}, gl::e3{{" << b[0] << ", " << b[1] << ", " << b[2] << "}});\n";
@@ -814,7 +986,9 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
                     for (u32 c = 0; c < 3; c++) { r[c] = fresh(); os << "    const u64 " << r[c] << " = gl::mulc(" << x[c] << ", " << s << ");\n"; }
                 } else { r[0] = fresh(); os << "    const u64 " << r[0] << " = gl::mulc(" << a[0] << ", " << b[0] << ");\n"; }
             }
-            // destination
+            }
+            // destination (a temporary may hold a symbol; anything stored is a word)
+            if (in.k[0] != XD_TMP) for (u32 c = 0; c < dd; c++) r[c] = real(r[c]);
             const u64* p = in.prm[0];
             switch (in.k[0]) {
             case XD_TMP: for (u32 c = 0; c < dd; c++) { tval[p[0] + c] = r[c]; tdef[p[0] + c] = true; } break;
@@ -836,7 +1010,7 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
             }
         }
         for (const auto& kv : tval)
-            if (tdef[kv.first] && live_in[sg + 1][kv.first]) os << "    T[" << kv.first << "ULL * TS] = " << kv.second << ";\n";
+            if (tdef[kv.first] && live_in[sg + 1][kv.first]) { const std::string v = real(kv.second); os << "    T[" << kv.first << "ULL * TS] = " << v << ";\n"; }
         os << "}\n";
         segsrc[sg] = os.str();
     }

@@ -220,4 +220,63 @@ __device__ __forceinline__ e3 mul3s(const e3& a, u64 s)  // ext * base, s any
     e3 r; for (int i = 0; i < 3; i++) r.c[i] = mulc(a.c[i], s); return r;
 }
 
+// ---------------------------------------------------------------- sums of (uniform Fp^3 coefficient) x (base-field value)
+// What a step program's constraint accumulation is once its Horner chain is a dot product (tools/expr_opt.py): acc += k * v with k a
+// challenge power (the same in every lane) and v the row's value of a constraint.  PRODUCTS WITHOUT CARRIES: the coefficient word is cut
+// into limbs of 22 + 21 + 21 bits (scalar ALU: it is wave-uniform), the value into its 32-bit halves, and each of the six partial
+// products (< 2^54) has an accumulator of its own: one v_mad_u64_u32 apiece -- 18 vector instructions for the Fp^3 x Fp multiply-add
+// that three mulc + three addc spend ~63 on.  An accumulator takes 1 024 products before it can overflow (the code generator counts);
+// fold() brings the sum back to three canonical words and leaves the accumulators as they are.
+struct lazy3 {
+    u64 a[3][6];                                      // per component: weights 2^0, 2^22, 2^43, 2^32, 2^54, 2^75
+    u64 b[3];                                         // canonical words added at fold()
+    __device__ __forceinline__ void init(u64 b0, u64 b1, u64 b2)
+    {
+        b[0] = b0; b[1] = b1; b[2] = b2;
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int i = 0; i < 6; i++) a[c][i] = 0;
+    }
+    __device__ __forceinline__ void mac1(int c, u64 k, u32 v0, u32 v1)
+    {
+        const u32 l0 = (u32)k & 0x3FFFFFu, l1 = (u32)(k >> 22) & 0x1FFFFFu, l2 = (u32)(k >> 43);
+        a[c][0] += (u64)v0 * l0; a[c][1] += (u64)v0 * l1; a[c][2] += (u64)v0 * l2;
+        a[c][3] += (u64)v1 * l0; a[c][4] += (u64)v1 * l1; a[c][5] += (u64)v1 * l2;
+    }
+    // += (k0, k1, k2) * v: any 64-bit words
+    __device__ __forceinline__ void mac(u64 k0, u64 k1, u64 k2, u64 v)
+    {
+        const u32 v0 = (u32)v, v1 = (u32)(v >> 32);
+        mac1(0, k0, v0, v1); mac1(1, k1, v0, v1); mac1(2, k2, v0, v1);
+    }
+    // += (k0, k1, k2) * (x0, x1, x2) in Fp[X] / (X^3 - X - 1), k any words, x CANONICAL: the nine products regrouped per component,
+    // c0 = k0 x0 + k1 x2 + k2 x1, c1 = k0 x1 + k1 (x0 + x2) + k2 (x1 + x2), c2 = k0 x2 + k1 x1 + k2 (x0 + x2): three products per
+    // accumulator (the code generator counts them as three), 54 multiply-adds and two field additions where mul3 + add3 spend ~180
+    __device__ __forceinline__ void mac3(u64 k0, u64 k1, u64 k2, u64 x0, u64 x1, u64 x2)
+    {
+        const u64 x02 = addc(x0, x2), x12 = addc(x1, x2);
+        mac1(0, k0, (u32)x0, (u32)(x0 >> 32)); mac1(0, k1, (u32)x2, (u32)(x2 >> 32)); mac1(0, k2, (u32)x1, (u32)(x1 >> 32));
+        mac1(1, k0, (u32)x1, (u32)(x1 >> 32)); mac1(1, k1, (u32)x02, (u32)(x02 >> 32)); mac1(1, k2, (u32)x12, (u32)(x12 >> 32));
+        mac1(2, k0, (u32)x2, (u32)(x2 >> 32)); mac1(2, k1, (u32)x1, (u32)(x1 >> 32)); mac1(2, k2, (u32)x02, (u32)(x02 >> 32));
+    }
+    // sum of a[c][i] 2^w[i] = X + Y 2^32, X = a0 + a1 2^22 + a2 2^43 < 2^108, Y likewise; Y is reduced first so that X + y 2^32 < 2^109
+    __device__ __forceinline__ u64 fold1(int c) const
+    {
+        typedef unsigned __int128 u128;
+        const u128 X = (u128)a[c][0] + ((u128)a[c][1] << 22) + ((u128)a[c][2] << 43);
+        const u128 Y = (u128)a[c][3] + ((u128)a[c][4] << 22) + ((u128)a[c][5] << 43);
+        const u64 y = reduce128((u64)Y, (u64)(Y >> 64));
+        const u128 Z = X + ((u128)y << 32);
+        return addc(canon(reduce128((u64)Z, (u64)(Z >> 64))), b[c]);
+    }
+    __device__ __forceinline__ void fold(u64& r0, u64& r1, u64& r2) const { r0 = fold1(0); r1 = fold1(1); r2 = fold1(2); }
+};
+// -(a mod p) for a wave-uniform word, in plain C so that it stays on the scalar ALU (canon() / neg() pin their operands to vector registers)
+__device__ __forceinline__ u64 neg_any(u64 a)
+{
+    const u64 c = a >= P ? a - P : a;
+    return c ? P - c : 0;
+}
+
 }  // namespace gl
