@@ -538,7 +538,30 @@ static int commit_bands(uint64_t* sec_n, uint64_t* sec_2ns, uint64_t* nodes, con
         if (ncols && dev_extend(ctx, sec_2ns, sec_n, n_ext, n, ncols, nullptr)) return -1;
         return dev_merkle(ctx, nodes, sec_2ns, ncols, n_ext);
     }
-    const u64 nb = (ncols + band - 1) / band;
+    // Band plan.  From device memory: uniform bands.  From the host (step 1) the copy stream and the extension + hashing run at nearly the
+    // same rate per column (PCIe 1.2-1.4 ms, compute 1.1 ms per column of 2^23 rows); the DMA engine moves wide row pieces faster (2 KB
+    // pieces: 55 GB/s, 512 B: 49 GB/s, 256 B: 36 GB/s), but a band is only worked on once it has arrived, and what the pipeline cannot hide is
+    // the work on the LAST band: bands that start wide and narrow by 15 % each, so the compute stream keeps up and ends on a small one
+    // (751 columns: 168, 128, 112, 88, 80, 64, 56, 55 -- profiles/r3/commit_band_ab.txt).
+    // XLP_COMMIT_BAND forces uniform bands.
+    std::vector<u64> starts, widths;
+    if (h_src && !getenv("XLP_COMMIT_BAND") && ncols >= 320) {
+        std::vector<u64> rev;                                 // built from the end: 48, then wider by 1 / 0.85 each, at most 160
+        double w = 48.0;
+        for (u64 rem = ncols / 8 * 8; rem;) {                 // every band starts on a multiple of 8 columns (one sponge block)
+            u64 ww = ((u64)(w + 4.0)) / 8 * 8;
+            if (ww > rem) ww = rem;
+            rev.push_back(ww); rem -= ww;
+            w = w / 0.85 < 160.0 ? w / 0.85 : 160.0;
+        }
+        rev[0] += ncols % 8;                                  // the odd columns go with the last band
+        if (rev.size() > 1 && rev.back() < 64) { rev[rev.size() - 2] += rev.back(); rev.pop_back(); }   // no sliver in front
+        u64 c0 = 0;
+        for (size_t k = rev.size(); k-- > 0;) { starts.push_back(c0); widths.push_back(rev[k]); c0 += rev[k]; }
+    } else {
+        for (u64 c0 = 0; c0 < ncols; c0 += band) { starts.push_back(c0); widths.push_back(ncols - c0 < band ? ncols - c0 : band); }
+    }
+    const u64 nb = starts.size();
     EventPool pool;
     std::vector<hipEvent_t> ev(nb, nullptr);
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -551,14 +574,14 @@ static int commit_bands(uint64_t* sec_n, uint64_t* sec_2ns, uint64_t* nodes, con
             XLP_HIP(hipEventRecord(t0, ctx->copy_stream));
         }
         for (u64 b = 0; b < nb; b++) {
-            const u64 c0 = b * band, wc = ncols - c0 < band ? ncols - c0 : band;
+            const u64 c0 = starts[b], wc = widths[b];
             XLP_HIP(hipMemcpy2DAsync(sec_n + c0, ncols * sizeof(u64), h_src + c0, ncols * sizeof(u64), wc * sizeof(u64), n, hipMemcpyHostToDevice, ctx->copy_stream));
             if (pool.mark(ctx->copy_stream, nullptr, &ev[b])) return -1;
         }
         if (upload_ms) XLP_HIP(hipEventRecord(t1, ctx->copy_stream));
     }
     for (u64 b = 0; b < nb; b++) {
-        const u64 c0 = b * band, wc = ncols - c0 < band ? ncols - c0 : band;
+        const u64 c0 = starts[b], wc = widths[b];
         if (h_src) XLP_HIP(hipStreamWaitEvent(ctx->stream, ev[b], 0));
         if (dev_extend_cols(ctx, sec_2ns, sec_n, n_ext, n, ncols, c0, wc)) return -1;
         if (dev_linear_hash_absorb(ctx, nodes, sec_2ns, ncols, c0, wc, n_ext, b == 0, b == nb - 1)) return -1;
