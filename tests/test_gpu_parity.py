@@ -660,7 +660,7 @@ def test_extend_column_window_vs_oracle(xlp, orc, lg, ext, w, first, wc):
     assert (got[:, :first] == 7).all() and (got[:, first + wc:] == 7).all()
 
 
-@pytest.mark.parametrize("lg,ext,w", [(9, 1, 3), (10, 1, 70), (12, 1, 751), (17, 1, 75), (17, 2, 130), (11, 3, 64), (18, 1, 200)])
+@pytest.mark.parametrize("lg,ext,w", [(9, 1, 3), (10, 1, 70), (12, 1, 751), (17, 1, 75), (17, 2, 130), (11, 3, 64), (18, 1, 200), (10, 1, 320), (10, 1, 327), (9, 2, 408), (8, 1, 1003)])
 def test_band_pipelined_commit_from_host_vs_oracle(xlp, orc, lg, ext, w):
     """starks.cpp:53-60 as ONE pipelined call on a witness that lives in host memory (prover.cpp:435): column bands are uploaded
     on a second stream while the previous band is extended and absorbed into the leaf hashes.  The uploaded section, its
