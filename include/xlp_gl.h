@@ -375,6 +375,9 @@ int xlp_host_unregister(void* ptr);
 
 /* Plain device memory helpers so a C++/cgo/ctypes host needs no HIP headers. */
 int xlp_dev_alloc(void** ptr, size_t bytes);
+/* Free / total bytes of the bound device's memory (hipMemGetInfo), for callers that decide at run time what stays resident
+ * (host/starks.hpp: the extended constant polynomials, 31 GB at the zkEVM geometry -- starks.hpp:138-146 keeps them loaded). */
+int xlp_dev_mem_info(size_t* free_bytes, size_t* total_bytes);
 int xlp_dev_free(void* ptr);
 int xlp_dev_memset(void* dst_dev, int value, size_t bytes);          /* asynchronous on the context's stream */
 int xlp_copy_h2d(void* dst_dev, const void* src_host, size_t bytes);

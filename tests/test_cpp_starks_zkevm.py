@@ -165,6 +165,15 @@ def test_genbatchproof_chains_three_starks(orc, tmp_path):
     assert line2["batch_proof_fnv"] == line["batch_proof_fnv"] and "zkevm.STARK_STEP_1_WITNESS_UPLOAD" in line2["timers_s"]
     line3, Z3, pub3 = run("--seed", "77")
     assert line3["batch_proof_fnv"] != line["batch_proof_fnv"] and Z3["root1"] != Z2["root1"] and pub3 != pub
+    # three proofs in one process: in the aliased layout the extended constants are recomputed in step 4 of a proof; from the second proof
+    # on a resident copy is taken when the memory is there (here it is; at 2^23 rows on 288 GB it is not: 10.5 GB free at that point) and
+    # the third proof no longer extends them -- the proofs stay the same
+    r = subprocess.run([exe, "-c", cfg, "--proofs", "3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.strip().splitlines() if l.startswith("{") and "timers_s" in l]
+    assert len(lines) == 3 and all(l["batch_proof_fnv"] == line["batch_proof_fnv"] for l in lines)
+    assert "zkevm.STARK_STEP_4_CONST_LDE" in lines[0]["timers_s"] and "zkevm.STARK_STEP_4_CONST_LDE" in lines[1]["timers_s"]
+    assert "zkevm.STARK_STEP_4_CONST_LDE" not in lines[2]["timers_s"]
 
 
 def _cpp_bundle_verkey(bundle, cfg_file):

@@ -83,6 +83,7 @@ SIGNATURES = {
     "xlp_host_register": [_pu, C.c_size_t],
     "xlp_host_unregister": [_pu],
     "xlp_dev_alloc": [C.POINTER(C.c_void_p), C.c_size_t],
+    "xlp_dev_mem_info": [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)],
     "xlp_dev_free": [_pu],
     "xlp_dev_memset": [_pu, C.c_int, C.c_size_t],
     "xlp_copy_h2d": [_pu, _pu, C.c_size_t],

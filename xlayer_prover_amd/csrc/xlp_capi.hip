@@ -434,6 +434,16 @@ int xlp_dev_alloc(void** ptr, size_t bytes)
     XLP_HIP(hipMalloc(ptr, bytes ? bytes : 8));
     return 0;
 }
+int xlp_dev_mem_info(size_t* free_bytes, size_t* total_bytes)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    size_t f = 0, t = 0;
+    XLP_HIP(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return 0;
+}
 int xlp_dev_free(void* ptr)
 {
     XLP_ENTER;

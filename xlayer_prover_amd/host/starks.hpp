@@ -134,7 +134,14 @@ private:
     }
     uint64_t* mem() { return XlpDeviceSlab::get().address(); }
     uint64_t* section(eSection s) { return mem() + starkInfo.mapOffsets.section[s]; }
-    uint64_t* constPols2ns() { return const2nsInSlab ? mem() + const2nsOffset : d_const_2ns_own; }
+    // In the aliased layout the extended constants are recomputed in step 4 of a proof (0.083 s of the zkEVM STARK) because they lie over
+    // a dead section of the slab.  From the second proof on -- when the grow-only scratch of the first one exists and the free memory is
+    // what it will stay -- a RESIDENT copy is taken instead if 8 GB remain free beside it (the reference keeps constPols2ns loaded,
+    // starks.hpp:138-146); `residentConstants = false` keeps the trade as it was.
+    bool residentConstants = true;
+    uint64_t* d_const_2ns_res = NULL;
+    uint64_t proofsDone = 0;
+    uint64_t* constPols2ns() { return d_const_2ns_res ? d_const_2ns_res : const2nsInSlab ? mem() + const2nsOffset : d_const_2ns_own; }
     struct PolRef { uint64_t* p; uint64_t n, dim, stride; };
     PolRef pol(uint64_t id)          // StarkInfo::getPolinomial on the device slab
     {
@@ -681,7 +688,7 @@ public:
     {
         if (!config.generateProof()) return;
         for (int i = 0; i < 5; i++) delete treesGL[i];
-        uint64_t* all[] = {d_const_n, d_const_2ns_own, d_x_n, d_x_2ns, d_zi, d_xdx, d_xdwx, d_challenges, d_publics, d_evals, d_work, d_const_n_full, d_const_2ns_win, d_shard};
+        uint64_t* all[] = {d_const_2ns_res, d_const_n, d_const_2ns_own, d_x_n, d_x_2ns, d_zi, d_xdx, d_xdwx, d_challenges, d_publics, d_evals, d_work, d_const_n_full, d_const_2ns_win, d_shard};
         for (uint64_t* p : all) xlp_dev_free(p);
     }
     StarksT(const StarksT&) = delete;
@@ -798,8 +805,20 @@ public:
         }
         //-------------------------------- 4. Compute C Polynomial
         challenge(4);
-        if (const2nsInSlab) {          // the one-GPU memory trade: the extended constants lie over the now dead cm3_n
+        if (const2nsInSlab && !d_const_2ns_res) {          // the one-GPU memory trade: the extended constants lie over the now dead cm3_n
             Timer t(this, "STARK_STEP_4_CONST_LDE");
+            if (residentConstants && proofsDone >= 1) {
+                const size_t need = (size_t)NExtended * starkInfo.nConstants * sizeof(uint64_t);
+                size_t fr = 0, tot = 0;
+                void* d = NULL;
+                if (xlp_dev_mem_info(&fr, &tot) == 0 && getenv("XLP_MEMINFO")) fprintf(stderr, "Starks: step 4 of proof %llu: %.1f GB free of %.1f GB, resident constants need %.1f GB\n", (unsigned long long)proofsDone, fr / 1e9, tot / 1e9, need / 1e9);
+                if (fr >= need + (8ULL << 30) && xlp_dev_alloc(&d, need) == 0) {
+                    d_const_2ns_res = (uint64_t*)d;
+                    treesGL[4]->d_source = d_const_2ns_res;
+                    P.const_pols_2ns = d_const_2ns_res;
+                    if (logTimers) fprintf(stderr, "Starks: extended constants now resident (%.1f GB; %.1f GB were free)\n", need / 1e9, fr / 1e9);
+                }
+            }
             XLP_CHECK(xlp_dev_extend(constPols2ns(), d_const_n, NExtended, N, starkInfo.nConstants, NULL));
         }
         {
@@ -873,6 +892,7 @@ public:
         }
         proof.proofs.setEvals(evals.data());
         H::storeRoots(proof, root0, root1, root2, root3);
+        proofsDone++;
     }
 };
 
