@@ -142,3 +142,17 @@ def accumulation_program(seed, n, nterms, nin=24, ntmp1=8, ntmp3=6, nch=4, nev=5
     prog.emit(E.COPY, E.q_2ns(), E.tmp3(0))
     prog.emit(E.COPY, E.f_2ns(), E.tmp3(1))
     return prog, width
+
+
+def long_chain_program(seed, n, nterms, nin=24, nstore=4):
+    """ONE accumulator taking nterms products in place: more than the 1 000 the generator gives a carry-free accumulator before it folds it
+    and starts a new one with the folded words as its base"""
+    rng = np.random.default_rng(seed)
+    width = nin + 3 * nstore
+    prog = E.Program()
+    prog.emit(E.COPY, E.tmp3(0), E.pols(0, width, 3))
+    for it in range(nterms):
+        prog.emit(E.MUL, E.tmp3(1), E.challenge(int(rng.integers(0, 4))), E.pols(int(rng.integers(0, nin)), width))
+        prog.emit(E.SUB if it % 7 == 3 else E.ADD, E.tmp3(0), E.tmp3(0), E.tmp3(1))
+    prog.emit(E.COPY, E.q_2ns(), E.tmp3(0))
+    return prog, width

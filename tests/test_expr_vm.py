@@ -7,7 +7,7 @@ import pytest
 
 from tests.conftest import GOLDEN_PROOFS
 
-from tests.expr_programs import accumulation_program, make_buffers, random_program
+from tests.expr_programs import accumulation_program, long_chain_program, make_buffers, random_program
 from xlayer_prover_amd import expr as E
 
 
@@ -194,6 +194,41 @@ def test_expr_compiled_random_programs_vs_oracle(xlp, orc, tmp_path, seed, n, ni
     p.close(); q.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,nterms", [(71, 1 << 12, 300), (72, 777, 1300)])
+def test_expr_compiled_lazy_accumulation_vs_oracle(xlp, orc, tmp_path, seed, n, nterms):
+    """the generator's carry-free accumulators (gl::lazy3: mac, mac3, neg_any, fold) compiled by hipcc and run on the GPU against the oracle:
+    accumulation chains with hops, stale states, copies, Fp^3 values; all-ones rows and non-canonical challenge words; the second case puts
+    ONE chain of 1 300 products with every coefficient limb and the first row's values maximal into one segment (the accumulator is folded and restarted
+    after 1 000 products: the sums stay below 2^64)"""
+    import shutil
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    if nterms > 1000:
+        os.environ["XLP_EXPR_SEG"] = "100000"
+    try:
+        prog, width = long_chain_program(seed, n, nterms) if nterms > 1000 else accumulation_program(seed, n, nterms)
+        bufs = make_buffers(orc, 0x5EED0800 + seed, n, width)
+        if nterms > 1000:
+            bufs["challenges"][:] = 2**64 - 1
+        bufs["challenges"][:3] = [2**64 - 1, 0xFFFFFFFF00000001, 0xFFFFFFFF00000006]
+        bufs["pols"][:width] = 2**64 - 1
+        dev = {k: xlp.from_np(v) for k, v in bufs.items()}
+        sp = xlp.steps_params(n_const_pols=5, n_const_pols_2ns=4, **dev)
+        p = xlp.ExprProgram(prog.code, prog.ntmp1, prog.ntmp3)
+        p.compile(str(tmp_path), "lazy", parts=4)
+    finally:
+        os.environ.pop("XLP_EXPR_SEG", None)
+    text = open(tmp_path / "lazy.hip").read() + "".join(open(f).read() for f in sorted(map(str, tmp_path.glob("lazy.hip.part*.hip"))))
+    assert ".mac(" in text and ".fold(" in text and (nterms > 1000 or ".mac3(" in text)
+    p.run(sp, 0, n); xlp.sync(); p.close()
+    exp = {k: v.copy() for k, v in bufs.items()}
+    orc.expr_run(prog.code, prog.ntmp1, prog.ntmp3, exp, 0, n, 5, 4)
+    for k in ("pols", "q_2ns", "f_2ns"):
+        got = xlp.to_np(dev[k])
+        assert (got == exp[k]).all(), f"{k}: {np.flatnonzero(got != exp[k])[:5]}"
+
+
 def test_converter_covers_reference_tables():
     """Every case of the five zkEVM parsers is recognised and the op/arg tables are consumed exactly
     (NOPS_ / NARGS_); runs only where the reference tree is mounted."""
@@ -255,7 +290,7 @@ def test_expr_generated_code_on_cpu(orc, tmp_path, seed, n, ninstr, row0, nrows)
         assert (got[k] == exp[k]).all(), f"{k}: {np.flatnonzero(got[k] != exp[k])[:5]}"
 
 
-@pytest.mark.parametrize("seed,n,nterms,seg,accs", [(61, 64, 120, 64, 3), (62, 100, 400, 256, 3), (63, 64, 1500, 100000, 1), (64, 64, 200, 32, 2)])
+@pytest.mark.parametrize("seed,n,nterms,seg,accs", [(61, 64, 120, 64, 3), (62, 100, 400, 256, 3), (63, 64, 1500, 100000, 1), (64, 64, 200, 32, 2), (65, 64, 1300, 100000, -1)])
 def test_expr_generated_lazy_accumulation_on_cpu(orc, tmp_path, seed, n, nterms, seg, accs):
     """The generator's carry-free accumulators (acc += challenge x value as gl::lazy3::mac, csrc/expr.hip) against the oracle, on the
     CPU stand-in that traps on any 64-bit overflow of a partial sum: chains that hop between temporaries, states read after the
@@ -263,13 +298,20 @@ def test_expr_generated_lazy_accumulation_on_cpu(orc, tmp_path, seed, n, nterms,
     challenge words that are not canonical."""
     os.environ["XLP_EXPR_SEG"] = str(seg); os.environ["XLP_EXPR_LAZY_ACCS"] = str(accs)
     try:
-        prog, width = accumulation_program(seed, n, nterms)
+        long_chain = accs < 0                                                             # accs = -1: ONE chain of nterms products (the 1 000-product limit)
+        if long_chain:
+            os.environ["XLP_EXPR_LAZY_ACCS"] = "3"
+        prog, width = long_chain_program(seed, n, nterms) if long_chain else accumulation_program(seed, n, nterms)
         bufs = make_buffers(orc, 0x5EED0700 + seed, n, width)
+        bufs["challenges"][:] = 2**64 - 1 if long_chain else bufs["challenges"]          # every coefficient limb maximal
         bufs["challenges"][:3] = [2**64 - 1, 0xFFFFFFFF00000001, 0xFFFFFFFF00000006]     # any 64-bit word
         bufs["pols"][:width] = 2**64 - 1                                                  # row 0: every value all ones
         got = _run_generated_on_cpu(tmp_path, prog.code, prog.ntmp1, prog.ntmp3, bufs, 0, n, 5, 4)
         text = open(tmp_path / "prog.hip").read()
-        assert ".mac(" in text and ".mac3(" in text and ".fold(" in text and "neg_any" in text
+        if long_chain:
+            assert text.count(".mac(") == nterms and text.count("gl::lazy3") == 2 and text.count(".fold(") == 2 and "neg_any" in text
+        else:
+            assert ".mac(" in text and ".mac3(" in text and ".fold(" in text and "neg_any" in text
     finally:
         del os.environ["XLP_EXPR_SEG"]; del os.environ["XLP_EXPR_LAZY_ACCS"]
     exp = {k: v.copy() for k, v in bufs.items()}
