@@ -74,9 +74,10 @@ __global__ __launch_bounds__(XLP_WGT) void lde_top_dif(const LdeParams p)
     };
     auto lload = [&](u32, u32 v, u32 lrow) -> u64 { return sm[lrow * V + v]; };
     auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { sm[lrow * V + v] = val; };
+    u64* __restrict__ Ag = p.A + (((u64)cc << p.L) << 3);     // this workgroup's 8-column group of the scratch (lde_sidx)
     auto gstore = [&](u32 tpos, u32 v, u64 val, u32) {
         const u64 row = ((u64)tpos << 12) | lo;
-        if (c + v < p.wc) gst<1>(&p.A[row * p.wc + c + v], val);
+        if (c + v < p.wc) gst<1>(&Ag[row * 8 + v], val);
     };
     auto crossf = [&](u32 tpos) -> u64 { return cross[tile_natural_c<BT>(tpos)]; };
     if constexpr (m == 2) {
@@ -120,10 +121,11 @@ __global__ __launch_bounds__(XLP_WGT) void ntt_bot_dif(const LdeParams p, u32 BT
         u32 shift = dtop;
         for (u32 r = 1; r < m; r++) { k1 |= ((hi >> (4 * (m - 1 - r))) & 15) << shift; shift += 4; }
     }
+    const u64* __restrict__ Ag = p.A + (((u64)(cc >> 1) << p.L) << 3) + (cc & 1) * 4;   // my 4 columns inside their 8-column group (lde_sidx)
     auto gload = [&](u32 tpos, u32 v, u32) -> u64 {
-        const u32 col = c + v < p.wc ? c + v : p.wc - 1;
+        const u32 vv = c + v < p.wc ? v : p.wc - 1 - c;
         const u64 row = ((u64)hi << 12) | tpos;
-        return gld<2>(&p.A[row * p.wc + col]);
+        return gld<2>(&Ag[row * 8 + vv]);
     };
     auto lload = [&](u32, u32 v, u32 lrow) -> u64 { return sm[lrow * V + v]; };
     auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { sm[lrow * V + v] = val; };
@@ -157,11 +159,11 @@ __global__ __launch_bounds__(XLP_WGT) void lde_top_dit(const LdeParams p)
     XLP_SYNC();
     const u32 c = cc * V;
     const u64 n = 1ull << p.L;
-    const u64* __restrict__ Br = p.B + (u64)r * n * p.wc;
+    const u64* __restrict__ Br = p.B + (u64)r * lde_swords(p.wc, p.L) + (((u64)cc << p.L) << 3);   // coset r, this workgroup's 8-column group (lde_sidx)
     auto gload = [&](u32 tpos, u32 v, u32) -> u64 {
-        const u32 col = c + v < p.wc ? c + v : p.wc - 1;
+        const u32 vv = c + v < p.wc ? v : p.wc - 1 - c;
         const u64 row = ((u64)tpos << 12) | lo;
-        return gld<4>(&Br[row * p.wc + col]);
+        return gld<4>(&Br[row * 8 + vv]);
     };
     auto crossf = [&](u32 tpos) -> u64 { return cross[tile_natural_c<BT>(tpos)]; };
     auto lload = [&](u32, u32 v, u32 lrow) -> u64 { return sm[lrow * V + v]; };
@@ -275,7 +277,7 @@ int dev_ntt_fast(Ctx* ctx, u64* dst, const u64* src, u32 L, u64 ncols, int inver
     // and every chunk's top pass must have read src before any bottom pass writes dst -> two sweeps.
     u64* scratch = nullptr;
     const u64 nchunks = (ncols + wc_max - 1) / wc_max;
-    if (ctx_scratch(ctx, (size_t)n * wc_max * nchunks * sizeof(u64), 1, &scratch)) return -1;
+    if (ctx_scratch(ctx, (size_t)lde_swords(wc_max, L) * nchunks * sizeof(u64), 1, &scratch)) return -1;
     static bool attr = false;
     if (!attr) {
         XLP_HIP(hipFuncSetAttribute((const void*)ntt_bot_dif<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -286,7 +288,7 @@ int dev_ntt_fast(Ctx* ctx, u64* dst, const u64* src, u32 L, u64 ncols, int inver
         for (u64 ci = 0; ci < nchunks; ci++) {
             p.col0 = (u32)(ci * wc_max);
             p.wc = (u32)(ncols - p.col0 < wc_max ? ncols - p.col0 : wc_max);
-            p.A = scratch + ci * n * wc_max;
+            p.A = scratch + ci * lde_swords(wc_max, L);
             if (sweep == 0) {
                 int rc;
                 if (inverse) rc = launch_top_bt(ctx, p, BT, false);
@@ -372,13 +374,13 @@ int dev_extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld
     // column chunks: scratch = (1 + 2^e) * n * wc elements
     const u32 wc_max = ncols < 64 ? (u32)ncols : 64;
     u64* scratch = nullptr;
-    if (ctx_scratch(ctx, (size_t)(1 + ncos) * n * wc_max * sizeof(u64), 1, &scratch)) return -1;
+    if (ctx_scratch(ctx, (size_t)(1 + ncos) * lde_swords(wc_max, L) * sizeof(u64), 1, &scratch)) return -1;
     p.A = scratch;
-    p.B = scratch + n * wc_max;
+    p.B = scratch + lde_swords(wc_max, L);
     for (u64 col0 = 0; col0 < ncols; col0 += wc_max) {
         p.col0 = (u32)(first + col0);
         p.wc = (u32)(ncols - col0 < wc_max ? ncols - col0 : wc_max);
-        p.B = p.A + n * p.wc;
+        p.B = p.A + lde_swords(p.wc, L);
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
         if (ctx->profile) {
             for (int i = 0; i < 4; i++) { XLP_HIP(hipEventCreate(&ev[i])); ctx->prof_events.push_back(ev[i]); }

@@ -33,6 +33,13 @@ struct LdeParams {
     const u64* ur[LDE_MAX_COSETS];   // ur[r][j]   = g_r^j / N,       j  < 2^BT
 };
 
+// Scratch element (row, col) of a column chunk: the chunk's columns in groups of 8, every group a contiguous [2^L][8] matrix -- whatever the
+// chunk's width (64 in a proof, 8 in the bench), a top-pass workgroup's 8 columns of a row are one 64-byte line and the middle pass's two
+// 4-column workgroups share the lines of one group, exactly as in the 8-column bench (with [row][chunk width] rows of 512 bytes the middle
+// pass ran 21 % slower inside a proof than in the bench: profiles/r3/lde_scratch_layout_ab.txt).
+__host__ __device__ __forceinline__ u64 lde_sidx(u64 row, u32 col, u32 L) { return ((((u64)(col >> 3)) << L) + row) * 8 + (col & 7); }
+__host__ __device__ __forceinline__ u64 lde_swords(u32 wc, u32 L) { return ((u64)((wc + 7) >> 3) << L) * 8; }   // words of one scratch matrix of wc columns
+
 template <int B>
 __device__ __forceinline__ u32 tile_natural_c(u32 tpos)
 {

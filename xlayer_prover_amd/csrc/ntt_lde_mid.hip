@@ -22,10 +22,12 @@ __global__ __launch_bounds__(XLP_WGT) void lde_mid(const LdeParams p, u32 BT)
     const u32 cc = tile % ncc, hi = tile / ncc;
     const u32 c = cc * V;
     const u64 n = 1ull << p.L;
+    const u64 goff = (((u64)(cc >> 1) << p.L) << 3) + (cc & 1) * 4;        // my 4 columns inside their 8-column group of a scratch matrix (lde_sidx)
+    const u64* __restrict__ Ag = p.A + goff;
     auto gload = [&](u32 tpos, u32 v, u32) -> u64 {
-        const u32 col = c + v < p.wc ? c + v : p.wc - 1;
+        const u32 vv = c + v < p.wc ? v : p.wc - 1 - c;
         const u64 row = ((u64)hi << 12) | tpos;
-        return gld<2>(&p.A[row * p.wc + col]);
+        return gld<2>(&Ag[row * 8 + vv]);
     };
     auto lload = [&](u32, u32 v, u32 lrow) -> u64 { return sm[lrow * V + v]; };
     auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { sm[lrow * V + v] = val; };
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(XLP_WGT) void lde_mid(const LdeParams p, u32 BT)
     // with it, and is folded into the position-indexed twiddle table tw2[r] of the next round.
     for (u32 r = 0; r < (1u << p.e); r++) {
         const u64* __restrict__ hk = p.hk[r];
-        u64* __restrict__ Br = p.B + (u64)r * n * p.wc;
+        u64* __restrict__ Br = p.B + (u64)r * lde_swords(p.wc, p.L) + goff;
         XLP_SYNC();   // previous users of the LDS tile are done
 #pragma unroll
         for (int i = 0; i < NGT; i++) {
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(XLP_WGT) void lde_mid(const LdeParams p, u32 BT)
         XLP_SYNC();
         auto gstore = [&](u32 tpos, u32 vv, u64 val, u32) {
             const u64 row = ((u64)hi << 12) | tpos;
-            if (c + vv < p.wc) gst<3>(&Br[row * p.wc + c + vv], val);
+            if (c + vv < p.wc) gst<3>(&Br[row * 8 + vv], val);
         };
         fast_round<B, V, 8, 4, true, false>(p.twf_12, lload, gstore);
     }
