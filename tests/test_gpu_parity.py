@@ -596,6 +596,15 @@ def test_dot_columns_vs_bigint(xlp, orc, nrows, ngroups, seed, reps):
         assert [[int(v) for v in r] for r in got[row]] == exp, row
 
 
+def test_dot_columns_without_entries_gives_zeros(xlp):
+    import torch
+    co = torch.zeros(6, dtype=torch.int64, device="cuda")
+    out = torch.full((100 * 3 * 2,), 7, dtype=torch.int64, device="cuda")
+    xlp.dev_dot_columns(out, [], 2, co, 100); xlp.sync()
+    assert int(out.abs().sum().item()) == 0
+    xlp.dev_dot_columns(out, [], 2, co, 0); xlp.sync()                 # no rows: nothing to do
+
+
 def test_dot_columns_rejections(xlp):
     import torch
     sec = torch.zeros(64, dtype=torch.int64, device="cuda"); co = torch.zeros(6, dtype=torch.int64, device="cuda")

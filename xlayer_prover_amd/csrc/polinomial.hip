@@ -771,10 +771,13 @@ int dev_dot_columns(Ctx* ctx, u64* out, const xlp_dot_entry* entries, u64 nentri
         i = j;
     }
     u64* dplan = nullptr;
-    if (ctx_scratch(ctx, plan.size() * sizeof(Rec), 2, &dplan)) return -1;
-    XLP_HIP(hipMemcpyAsync(dplan, plan.data(), plan.size() * sizeof(Rec), hipMemcpyHostToDevice, ctx->stream));
-    XLP_HIP(hipStreamSynchronize(ctx->stream));            // plan goes out of scope
-    hipLaunchKernelGGL(dot_expand_kernel, dim3((unsigned)((plan.size() + 255) / 256)), dim3(256), 0, ctx->stream, (dc_u4*)dplan, (u64)plan.size(), coefs);
+    if (!nrows) return 0;
+    if (ctx_scratch(ctx, std::max<size_t>(plan.size() * sizeof(Rec), 16), 2, &dplan)) return -1;
+    if (!plan.empty()) {                                   // no entries: every sum is zero (the kernel below writes them)
+        XLP_HIP(hipMemcpyAsync(dplan, plan.data(), plan.size() * sizeof(Rec), hipMemcpyHostToDevice, ctx->stream));
+        XLP_HIP(hipStreamSynchronize(ctx->stream));        // plan goes out of scope
+        hipLaunchKernelGGL(dot_expand_kernel, dim3((unsigned)((plan.size() + 255) / 256)), dim3(256), 0, ctx->stream, (dc_u4*)dplan, (u64)plan.size(), coefs);
+    }
     const dim3 grid((unsigned)((nrows + DC_ROWS - 1) / DC_ROWS)), block(DC_T);
     const dc_u4* dp = (const dc_u4*)dplan;
     switch (ngroups) {
