@@ -380,6 +380,34 @@ int dev_copy_cols(Ctx* ctx, u64* dst, u64 dst_stride, const u64* src, u64 src_st
     return 0;
 }
 
+// ------------------------------------------------------------------ sums of products without carries (evmap, dot_columns)
+// One factor is cut into limbs of 22 + 21 + 21 bits, the other into its 32-bit halves; the six partial products (< 2^54) each have an
+// accumulator of their own: one v_mad_u64_u32 apiece and no carry chain.  An accumulator takes 1 024 such products (1024 * (2^32 - 1) * (2^22 - 1)
+// < 2^64); flush() folds the six into the canonical running sum r and clears them.
+struct DcSum {
+    u64 a[6];                                         // partial products of weight 2^0, 2^22, 2^43, 2^32, 2^54, 2^75
+    u64 r;                                            // what has been folded so far (canonical)
+    __device__ __forceinline__ void clear()
+    {
+        r = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) a[i] = 0;
+    }
+    // a += (l0 + l1 2^22 + l2 2^43) * v, v any 64-bit word
+    __device__ __forceinline__ void mac(u32 l0, u32 l1, u32 l2, u64 v)
+    {
+        const u32 v0 = (u32)v, v1 = (u32)(v >> 32);
+        a[0] += (u64)v0 * l0; a[1] += (u64)v0 * l1; a[2] += (u64)v0 * l2;
+        a[3] += (u64)v1 * l0; a[4] += (u64)v1 * l1; a[5] += (u64)v1 * l2;
+    }
+    __device__ __forceinline__ void flush()
+    {
+        constexpr u64 W[6] = {1ULL, 1ULL << 22, 1ULL << 43, 1ULL << 32, 1ULL << 54, (1ULL << 43) - (1ULL << 11)};   // 2^75 = 2^11 (2^32 - 1)
+#pragma unroll
+        for (int i = 0; i < 6; i++) { r = gl::addc(r, gl::mulc(a[i], W[i])); a[i] = 0; }
+    }
+};
+
 // ------------------------------------------------------------------ evmap
 // evals[i] = sum_k L_i[k] * pol_i[(k << eb) * stride_i].  Lanes run along the ENTRIES, sorted by address on the host:
 // neighbouring entries are neighbouring columns of one row-major section, so a wave reads contiguous bytes of a
@@ -389,13 +417,16 @@ int dev_copy_cols(Ctx* ctx, u64* dst, u64 dst_stride, const u64* src, u64 src_st
 // An extension column (x0, x1, x2) is entered as THREE base-field sub-entries: L * (x0 + x1 a + x2 a^2) =
 // x0 * L + x1 * (a L) + x2 * (a^2 L) with a L = (l2, l0 + l2, l1), a^2 L = (l1, l1 + l2, l0 + l2) -- so every lane runs the
 // same unreduced multiply-accumulate (a wave with one extension lane used to drag all 64 through a full Fp^3 product per row).
-constexpr int EV_T = 256, EV_ROWS = 4096, EV_SUB = 512;   // rows per block / rows of L staged in LDS at a time
+constexpr int EV_T = 256, EV_ROWS = 4096, EV_SUB = 256, EV_FOLD = 1024;   // rows per block / rows of L staged in LDS at a time / products per accumulator
 struct EvEntryDev { const u64* pol; u64 stride; u32 variant; u32 prime; u32 sub; u32 pad; };
 typedef const __attribute__((address_space(1))) u64* gptr_t;   // entry pointers come from memory: tell the compiler they are global
 
+// Round 3: the products without carries of DcSum.  The multiplier words of a row (l0, l1, l2, l0 + l2, l1 + l2 of LEv / LpEv) are staged in LDS
+// already cut into their three limbs, a lane reads the nine limbs of its three multipliers and its column word and issues 18 multiply-adds --
+// the 128-bit products with a compare per addition took ~45 vector instructions per row and lane, as long as the rows take to arrive.
 __global__ __launch_bounds__(EV_T) void evmap_partial_kernel(u64* partial, const u64* LEv, const u64* LpEv, u64 n, u32 eb, const EvEntryDev* ents, u32 nsub)
 {
-    __shared__ u64 sL[2][EV_SUB * 5];                      // per row of LEv / LpEv: l0, l1, l2, l0 + l2, l1 + l2 (40 KiB)
+    __shared__ u32 sL[2][EV_SUB * 15];                     // per row of LEv / LpEv: five multiplier words x three limbs (30 KiB)
     const u32 ei = blockIdx.x * EV_T + threadIdx.x;          // entry blocks fastest: the blocks of one row range run together
     const bool live = ei < nsub;
     EvEntryDev e = ents[live ? ei : 0];
@@ -403,13 +434,12 @@ __global__ __launch_bounds__(EV_T) void evmap_partial_kernel(u64* partial, const
     const u64 k1 = k0 + EV_ROWS < n ? k0 + EV_ROWS : n;
     const u64 rstep = e.stride << eb;
     gptr_t b = (gptr_t)e.pol + k0 * rstep;
-    const u64* l = sL[e.prime ? 1 : 0];
-    // the multiplier's components for this lane: L -> (0, 1, 2), a L -> (2, 3, 1), a^2 L -> (1, 4, 3)
-    const u32 i0 = e.variant == 0 ? 0 : (e.variant == 1 ? 2 : 1), i1 = e.variant == 0 ? 1 : (e.variant == 1 ? 3 : 4), i2 = e.variant == 0 ? 2 : (e.variant == 1 ? 1 : 3);
-    // lazy accumulation: the 128-bit products of a row are added unreduced into (lo, hi, overflow count); one
-    // reduction per block (2^128 = -2^32 mod p) instead of a multiply-reduce and an add-reduce per term
-    unsigned __int128 s128[3] = {0, 0, 0};
-    u32 ovf[3] = {0, 0, 0};
+    // the multiplier's components for this lane: L -> (0, 1, 2), a L -> (2, 3, 1), a^2 L -> (1, 4, 3); as dword offsets into a row's 15
+    const u32 i0 = 3 * (e.variant == 0 ? 0 : (e.variant == 1 ? 2 : 1)), i1 = 3 * (e.variant == 0 ? 1 : (e.variant == 1 ? 3 : 4)), i2 = 3 * (e.variant == 0 ? 2 : (e.variant == 1 ? 1 : 3));
+    const u32* l = sL[e.prime ? 1 : 0];
+    DcSum S[3];
+    S[0].clear(); S[1].clear(); S[2].clear();
+    u32 since = 0;                                          // rows accumulated since the last fold (block-uniform)
     constexpr int U = 8;                                   // rows in flight per lane
     for (u64 s0 = k0; s0 < k1; s0 += EV_SUB) {
         const u32 rows = (u32)(k1 - s0 < EV_SUB ? k1 - s0 : EV_SUB);
@@ -417,39 +447,35 @@ __global__ __launch_bounds__(EV_T) void evmap_partial_kernel(u64* partial, const
         for (u32 i = threadIdx.x; i < rows * 2; i += EV_T) {
             const u32 r = i >> 1;
             const u64* src = (i & 1) ? LpEv : LEv;
-            u64* d = &sL[i & 1][5 * r];
+            u32* d = &sL[i & 1][15 * r];
             const u64 a0 = gl::canon(src[3 * (s0 + r)]), a1 = gl::canon(src[3 * (s0 + r) + 1]), a2 = gl::canon(src[3 * (s0 + r) + 2]);
-            d[0] = a0; d[1] = a1; d[2] = a2; d[3] = gl::addc(a0, a2); d[4] = gl::addc(a1, a2);
+            const u64 m[5] = {a0, a1, a2, gl::addc(a0, a2), gl::addc(a1, a2)};
+#pragma unroll
+            for (int q = 0; q < 5; q++) { d[3 * q] = (u32)m[q] & 0x3FFFFFu; d[3 * q + 1] = (u32)(m[q] >> 22) & 0x1FFFFFu; d[3 * q + 2] = (u32)(m[q] >> 43); }
         }
         __syncthreads();
+        if (since + rows > EV_FOLD) { S[0].flush(); S[1].flush(); S[2].flush(); since = 0; }
+        since += rows;
         if (!live) continue;
+        auto row = [&](u32 k, u64 v) {
+            const u32* lr = l + 15 * k;
+            S[0].mac(lr[i0], lr[i0 + 1], lr[i0 + 2], v);
+            S[1].mac(lr[i1], lr[i1 + 1], lr[i1 + 2], v);
+            S[2].mac(lr[i2], lr[i2 + 1], lr[i2 + 2], v);
+        };
         u32 k = 0;
         for (; k + U <= rows; k += U, b += U * rstep) {
             u64 v[U];
 #pragma unroll
             for (int j = 0; j < U; j++) v[j] = b[j * rstep];
 #pragma unroll
-            for (int j = 0; j < U; j++) {
-                const u64* lr = l + 5 * (k + j);
-                unsigned __int128 pr = (unsigned __int128)lr[i0] * v[j]; s128[0] += pr; ovf[0] += s128[0] < pr;
-                pr = (unsigned __int128)lr[i1] * v[j]; s128[1] += pr; ovf[1] += s128[1] < pr;
-                pr = (unsigned __int128)lr[i2] * v[j]; s128[2] += pr; ovf[2] += s128[2] < pr;
-            }
+            for (int j = 0; j < U; j++) row(k + j, v[j]);
         }
-        for (; k < rows; k++, b += rstep) {
-            const u64* lr = l + 5 * k;
-            const u64 v = b[0];
-            unsigned __int128 pr = (unsigned __int128)lr[i0] * v; s128[0] += pr; ovf[0] += s128[0] < pr;
-            pr = (unsigned __int128)lr[i1] * v; s128[1] += pr; ovf[1] += s128[1] < pr;
-            pr = (unsigned __int128)lr[i2] * v; s128[2] += pr; ovf[2] += s128[2] < pr;
-        }
+        for (; k < rows; k++, b += rstep) row(k, b[0]);
     }
     if (!live) return;
     u64* dst = partial + ((u64)blockIdx.y * nsub + e.sub) * 3;
-    for (int c = 0; c < 3; c++) {
-        const u64 r = gl::canon(gl::reduce128((u64)s128[c], (u64)(s128[c] >> 64)));
-        dst[c] = gl::subc(r, gl::mulc((u64)ovf[c], 1ULL << 32));
-    }
+    for (int c = 0; c < 3; c++) { S[c].flush(); dst[c] = S[c].r; }
 }
 
 // evals[i] = sum over the chunks and over the sub-entries first[i] .. first[i + 1] - 1 of entry i
@@ -531,29 +557,6 @@ typedef u32 dc_u4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) dc_u4* dc_hdr_t;   // window headers: constant address space = scalar loads
 typedef const __attribute__((address_space(1))) dc_u4* dc_rec_t;
 
-struct DcSum {
-    u64 a[6];                                         // partial products of weight 2^0, 2^22, 2^43, 2^32, 2^54, 2^75
-    u64 r;                                            // what has been folded so far (canonical)
-    __device__ __forceinline__ void clear()
-    {
-        r = 0;
-#pragma unroll
-        for (int i = 0; i < 6; i++) a[i] = 0;
-    }
-    // a += (l0 + l1 2^22 + l2 2^43) * v, v any 64-bit word
-    __device__ __forceinline__ void mac(u32 l0, u32 l1, u32 l2, u64 v)
-    {
-        const u32 v0 = (u32)v, v1 = (u32)(v >> 32);
-        a[0] += (u64)v0 * l0; a[1] += (u64)v0 * l1; a[2] += (u64)v0 * l2;
-        a[3] += (u64)v1 * l0; a[4] += (u64)v1 * l1; a[5] += (u64)v1 * l2;
-    }
-    __device__ __forceinline__ void flush()
-    {
-        constexpr u64 W[6] = {1ULL, 1ULL << 22, 1ULL << 43, 1ULL << 32, 1ULL << 54, (1ULL << 43) - (1ULL << 11)};   // 2^75 = 2^11 (2^32 - 1)
-#pragma unroll
-        for (int i = 0; i < 6; i++) { r = gl::addc(r, gl::mulc(a[i], W[i])); a[i] = 0; }
-    }
-};
 
 // a record: {byte offset of the column in the LDS tile, l0, l1, l2 | group << 24}; in LDS the offsets and the limbs are two arrays.
 // Every array of the pipeline is double-buffered with period two -- sent for in one step, used in the next -- so two steps with the
