@@ -76,6 +76,11 @@ int xlp_merkle(uint64_t* nodes, const uint64_t* src, uint64_t w, uint64_t h);
 
 /* PoseidonGoldilocks::hash_full_result(out12, in12) -- transcript.cpp:23,46. */
 int xlp_perm(uint64_t out[12], const uint64_t in[12]);
+/* Transcript::put of a long message (src/starkpil/transcript/transcript.cpp:12-29: every 8th element triggers _updateState = one
+ * hash_full_result on pending[8] | state[4]): nblocks FULL blocks absorbed in one call.  out = the last permutation's 12 words (the transcript's
+ * `out`, whose words 0..3 are its new `state`); block b = elems[8b .. 8b + 8) | capacity, capacity = state for b = 0, then words 0..3 of the
+ * previous output.  Host pointers; one launch instead of nblocks round trips (739 for the evaluations of a zkEVM proof). */
+int xlp_perm_chain(uint64_t out[12], const uint64_t state[4], const uint64_t* elems, uint64_t nblocks);
 /* Batched form of the above: `count` independent 12-word states. */
 int xlp_perm_batch(uint64_t* out, const uint64_t* in, uint64_t count);
 

@@ -596,6 +596,22 @@ def test_dot_columns_vs_bigint(xlp, orc, nrows, ngroups, seed, reps):
         assert [[int(v) for v in r] for r in got[row]] == exp, row
 
 
+@pytest.mark.parametrize("nblocks,seed", [(1, 1), (2, 2), (7, 3), (739, 4)])
+def test_perm_chain_equals_sequential_permutations(xlp, orc, nblocks, seed):
+    """xlp_perm_chain (Transcript::put of a long message as one call, transcript.cpp:12-29) against block-by-block hash_full_result on the
+    oracle: elements and the starting state are arbitrary 64-bit words; 739 blocks = the evaluations of a zkEVM proof"""
+    rng = np.random.default_rng(seed)
+    elems = rng.integers(0, 2**64, size=8 * nblocks, dtype=np.uint64)
+    state = rng.integers(0, 2**64, size=4, dtype=np.uint64)
+    got = xlp.perm_chain(state, elems)
+    cap = state.copy()
+    out = None
+    for b in range(nblocks):
+        out = orc.perm(np.concatenate([elems[8 * b:8 * b + 8], cap]))
+        cap = out[:4]
+    assert [int(v) for v in got] == [int(v) for v in out]
+
+
 def test_dot_columns_without_entries_gives_zeros(xlp):
     import torch
     co = torch.zeros(6, dtype=torch.int64, device="cuda")

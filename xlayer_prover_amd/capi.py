@@ -25,6 +25,7 @@ SIGNATURES = {
     "xlp_extend": [_pu, _pu, _u64, _u64, _u64, _pu],
     "xlp_merkle": [_pu, _pu, _u64, _u64],
     "xlp_perm": [_pu, _pu],
+    "xlp_perm_chain": [_pu, _pu, _pu, _u64],
     "xlp_perm_batch": [_pu, _pu, _u64],
     "xlp_linear_hash": [_pu, _pu, _u64, _u64],
     "xlp_fri_fold": [_pu, _pu, _u32, _u32, _pu, _u64],
@@ -315,6 +316,15 @@ def perm(state):
     assert s.size == 12
     out = np.empty(12, np.uint64)
     _ck(load().xlp_perm(_p(out), _p(s)), "xlp_perm")
+    return out
+
+
+def perm_chain(state4, elems):
+    """xlp_perm_chain: the full blocks of a long Transcript::put in one call -> the last permutation's 12 words"""
+    st, e = _np(state4).reshape(-1), _np(elems).reshape(-1)
+    assert st.size == 4 and e.size % 8 == 0 and e.size
+    out = np.empty(12, np.uint64)
+    _ck(load().xlp_perm_chain(_p(out), _p(st), _p(e), e.size // 8), "xlp_perm_chain")
     return out
 
 

@@ -185,6 +185,37 @@ __global__ __launch_bounds__(256) void perm_kernel(u64* out, const u64* in, u64 
 // lane's row of the circulant), ~6x fewer instructions on the critical path.  One wave per permutation; lanes 12..63 mirror
 // lanes 0..11 (i = lane % 12) so that no lane diverges outside the partial rounds.
 __constant__ u32 MDS_CIRC[12] = {17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20};
+// one permutation, the state distributed over the lanes (word i = lane % 12 in every lane): in = that lane's word, any 64-bit value
+__device__ __forceinline__ u64 perm_coop_lanes(u64 in, const u32 (&m)[12], u32 i)
+{
+    u64 x = gl::add(in, POSEIDON_C[i]);                    // any + canon
+#pragma unroll 1
+    for (int r = 0; r < 30; r++) {
+        if (r < 4 || r >= 26 || i == 0) x = pow7(x);
+        u64 L = 0, H = 0;
+        if (r < 29) { const u64 c = POSEIDON_C[12 * (r + 1) + i]; L = (u32)c; H = c >> 32; }
+        const u32 xl = (u32)x, xh = (u32)(x >> 32);
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const u32 bl = (u32)__builtin_amdgcn_readlane((int)xl, j), bh = (u32)__builtin_amdgcn_readlane((int)xh, j);
+            L += (u64)bl * m[j];
+            H += (u64)bh * m[j];
+        }
+        // L + H * 2^32 (mod p), as in mds()
+        const u32 Hl = (u32)H, Hh = (u32)(H >> 32);
+        const u64 t = (u64)Hh * 0xFFFFFFFFu + L;
+        u32 c1, c2, c3;
+        u32 rhi = __builtin_addc((u32)(t >> 32), Hl, 0u, &c1);
+        u32 rlo = (u32)t;
+        gl::opaque(rhi);
+        const u32 fix = c1 ? 0xFFFFFFFFu : 0u;
+        rlo = __builtin_addc(rlo, fix, 0u, &c2);
+        rhi = __builtin_addc(rhi, 0u, c2, &c3);
+        gl::opaque(rlo); gl::opaque(rhi);
+        x = gl::pack(rlo, rhi);
+    }
+    return x;
+}
 __global__ __launch_bounds__(64) void perm_coop_kernel(u64* out, const u64* in, u64 count)
 {
     const u32 lane = threadIdx.x, i = lane % 12;
@@ -192,34 +223,28 @@ __global__ __launch_bounds__(64) void perm_coop_kernel(u64* out, const u64* in, 
 #pragma unroll
     for (int j = 0; j < 12; j++) m[j] = MDS_CIRC[(j + 12 - i) % 12] + ((i == 0 && j == 0) ? 8u : 0u);
     for (u64 p = blockIdx.x; p < count; p += gridDim.x) {
-        u64 x = gl::add(in[12 * p + i], POSEIDON_C[i]);     // any + canon
-#pragma unroll 1
-        for (int r = 0; r < 30; r++) {
-            if (r < 4 || r >= 26 || i == 0) x = pow7(x);
-            u64 L = 0, H = 0;
-            if (r < 29) { const u64 c = POSEIDON_C[12 * (r + 1) + i]; L = (u32)c; H = c >> 32; }
-            const u32 xl = (u32)x, xh = (u32)(x >> 32);
-#pragma unroll
-            for (int j = 0; j < 12; j++) {
-                const u32 bl = (u32)__builtin_amdgcn_readlane((int)xl, j), bh = (u32)__builtin_amdgcn_readlane((int)xh, j);
-                L += (u64)bl * m[j];
-                H += (u64)bh * m[j];
-            }
-            // L + H * 2^32 (mod p), as in mds()
-            const u32 Hl = (u32)H, Hh = (u32)(H >> 32);
-            const u64 t = (u64)Hh * 0xFFFFFFFFu + L;
-            u32 c1, c2, c3;
-            u32 rhi = __builtin_addc((u32)(t >> 32), Hl, 0u, &c1);
-            u32 rlo = (u32)t;
-            gl::opaque(rhi);
-            const u32 fix = c1 ? 0xFFFFFFFFu : 0u;
-            rlo = __builtin_addc(rlo, fix, 0u, &c2);
-            rhi = __builtin_addc(rhi, 0u, c2, &c3);
-            gl::opaque(rlo); gl::opaque(rhi);
-            x = gl::pack(rlo, rhi);
-        }
+        const u64 x = perm_coop_lanes(in[12 * p + i], m, i);
         if (lane < 12) out[12 * p + i] = gl::canon(x);
     }
+}
+
+// The transcript absorbing a long message (Transcript::put of the 3 x 1 973 evaluation words of a zkEVM proof, transcript.cpp:12-29): nblocks
+// dependent permutations, block b = perm(elems[8b .. 8b + 8) | capacity), capacity = words 0..3 of the previous output.  One wave walks the
+// whole chain (739 permutations: ~4 ms) instead of one launch, two copies and a host wait per permutation.
+__global__ __launch_bounds__(64) void perm_chain_kernel(u64* out, const u64* state, const u64* elems, u64 nblocks)
+{
+    const u32 lane = threadIdx.x, i = lane % 12;
+    u32 m[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) m[j] = MDS_CIRC[(j + 12 - i) % 12] + ((i == 0 && j == 0) ? 8u : 0u);
+    u64 cap = i >= 8 ? state[i - 8] : 0, x = 0;
+    const u32 from = i >= 8 ? i - 8 : i;                     // lanes 8..11 take words 0..3 of the output as the next capacity
+    for (u64 b = 0; b < nblocks; b++) {
+        x = perm_coop_lanes(i < 8 ? elems[8 * b + i] : cap, m, i);
+        const u32 lo = (u32)__shfl((int)(u32)x, (int)from), hi = (u32)__shfl((int)(u32)(x >> 32), (int)from);
+        cap = gl::pack(lo, hi);
+    }
+    if (lane < 12) out[i] = gl::canon(x);
 }
 
 // Leaf level: out[4*row..] = linear_hash(src[row][0..w)).
@@ -312,6 +337,14 @@ int dev_perm(Ctx* ctx, u64* out, const u64* in, u64 count)
         return 0;
     }
     hipLaunchKernelGGL(perm_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, out, in, count);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
+int dev_perm_chain(Ctx* ctx, u64* out, const u64* state, const u64* elems, u64 nblocks)
+{
+    if (!nblocks) return 0;
+    hipLaunchKernelGGL(perm_chain_kernel, dim3(1), dim3(64), 0, ctx->stream, out, state, elems, nblocks);
     XLP_HIP(hipGetLastError());
     return 0;
 }

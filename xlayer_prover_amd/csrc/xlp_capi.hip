@@ -830,6 +830,22 @@ int xlp_perm_batch(uint64_t* out, const uint64_t* in, uint64_t count)
     return 0;
 }
 int xlp_perm(uint64_t out[12], const uint64_t in[12]) { return xlp_perm_batch(out, in, 1); }
+int xlp_perm_chain(uint64_t out[12], const uint64_t state[4], const uint64_t* elems, uint64_t nblocks)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if (!out || !state || (nblocks && !elems)) return xlp_fail("xlp_perm_chain: null pointer");
+    if (nblocks == 0) return xlp_fail("xlp_perm_chain: no block");
+    u64* d = nullptr;                                         // [out 12 | state 4 | elems 8 * nblocks]
+    if (ctx_scratch(&g_ctx, std::max<size_t>((16 + 8 * nblocks) * sizeof(u64), 2 * 64 * 12 * sizeof(u64)), 6, &d)) return -1;   // the transcript's staging slot (xlp_perm_batch)
+    XLP_HIP(hipMemcpyAsync(d + 12, state, 4 * sizeof(u64), hipMemcpyHostToDevice, g_ctx.stream));
+    XLP_HIP(hipMemcpyAsync(d + 16, elems, 8 * nblocks * sizeof(u64), hipMemcpyHostToDevice, g_ctx.stream));
+    if (dev_perm_chain(&g_ctx, d, d + 12, d + 16, nblocks)) return -1;
+    cache_drop_overlapping(out, 12 * sizeof(u64));
+    XLP_HIP(hipMemcpyAsync(out, d, 12 * sizeof(u64), hipMemcpyDeviceToHost, g_ctx.stream));
+    XLP_HIP(hipStreamSynchronize(g_ctx.stream));
+    return 0;
+}
 
 // ---- transport between the ranks of a row-sharded proof (comm.hip)
 int xlp_comm_init(int rank, int world, const char* backend, const char* rendezvous)

@@ -76,6 +76,7 @@ int dev_extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld
 // poseidon.hip
 int poseidon_init(Ctx* ctx);
 int dev_perm(Ctx* ctx, u64* out, const u64* in, u64 count);
+int dev_perm_chain(Ctx* ctx, u64* out, const u64* state, const u64* elems, u64 nblocks);
 int dev_linear_hash(Ctx* ctx, u64* out, const u64* src, u64 w, u64 h);
 int dev_merkle(Ctx* ctx, u64* nodes, const u64* src, u64 w, u64 h);
 int dev_linear_hash_absorb(Ctx* ctx, u64* state, const u64* src, u64 ld, u64 first, u64 ncols, u64 h, int is_first, int is_last);

@@ -563,7 +563,7 @@ private:
             }
             XLP_CHECK(xlp_copy_h2d(d_evals, evals.data(), evals.size() * sizeof(uint64_t)));
         }
-        for (uint64_t i = 0; i < starkInfo.evMap.size(); i++) transcript.put(&evals[i * FIELD_EXTENSION], 3);
+        transcript.put(evals.data(), starkInfo.evMap.size() * FIELD_EXTENSION);   // (starks.cpp:336-339 puts them three at a time: the same element sequence; one call lets the sponge take its full blocks in one launch)
         challenge(5);
         challenge(6);
         {
@@ -873,7 +873,7 @@ public:
             XLP_CHECK(xlp_dev_evmap(d_evals, d_work, d_work + N * 3, N, (uint32_t)extendBits, (uint32_t)ents.size(), ents.data()));
             XLP_CHECK(xlp_copy_d2h(evals.data(), d_evals, evals.size() * sizeof(uint64_t)));
         }
-        for (uint64_t i = 0; i < starkInfo.evMap.size(); i++) transcript.put(&evals[i * FIELD_EXTENSION], 3);
+        transcript.put(evals.data(), starkInfo.evMap.size() * FIELD_EXTENSION);   // (starks.cpp:336-339 puts them three at a time: the same element sequence; one call lets the sponge take its full blocks in one launch)
         challenge(5);   // v1
         challenge(6);   // v2
         {

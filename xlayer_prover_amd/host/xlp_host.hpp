@@ -146,6 +146,12 @@ public:
     {
         XLP_CHECK(xlp_perm(xlp_raw(state), xlp_raw(input)));
     }
+    // nblocks dependent hash_full_result calls on input[8b .. 8b + 8) | capacity (capacity: `state`, then words 0..3 of the previous result): what
+    // Transcript::put does element by element (transcript.cpp:12-29), as ONE call
+    static void hash_chain(Goldilocks::Element* out12, const Goldilocks::Element* state4, const Goldilocks::Element* input, uint64_t nblocks)
+    {
+        XLP_CHECK(xlp_perm_chain(xlp_raw(out12), xlp_raw(state4), xlp_raw(input), nblocks));
+    }
     static void hash(Goldilocks::Element (&state)[CAPACITY], const Goldilocks::Element (&input)[SPONGE_WIDTH])
     {
         Goldilocks::Element full[SPONGE_WIDTH];
@@ -389,7 +395,21 @@ public:
         std::memset(pending, 0, sizeof(pending));
         std::memset(out, 0, sizeof(out));
     }
-    void put(Goldilocks::Element* input, uint64_t size) { for (uint64_t i = 0; i < size; i++) _add1(input[i]); }
+    // transcript.cpp:12-29 adds element by element, one permutation per 8; a long message (the evaluations: 3 x 1 973 words at the zkEVM) goes
+    // through its full blocks in one call once the pending block is empty -- the same sequence of permutations, the same members afterwards
+    void put(Goldilocks::Element* input, uint64_t size)
+    {
+        uint64_t i = 0;
+        while (i < size && pending_cursor != 0) _add1(input[i++]);
+        const uint64_t nblocks = (size - i) / TRANSCRIPT_PENDING_SIZE;
+        if (nblocks >= 2) {
+            PoseidonGoldilocks::hash_chain(out, state, &input[i], nblocks);
+            out_cursor = TRANSCRIPT_OUT_SIZE;
+            std::memcpy(state, out, sizeof(state));
+            i += nblocks * TRANSCRIPT_PENDING_SIZE;
+        }
+        for (; i < size; i++) _add1(input[i]);
+    }
     Goldilocks::Element getFields1()
     {
         if (out_cursor == 0) _updateState();
