@@ -29,28 +29,28 @@ LDE_KERNELS = ["xlp::lde_top_dif<11>", "xlp::lde_mid", "xlp::lde_top_dit<11>"]  
 
 
 def cpu_baseline(log_n, ncols, budget_s=20.0):
-    """Oracle (restated CPU path, OpenMP over columns) timed on this host, bounded sample."""
+    """Oracle (restated CPU path) timed on this host, bounded sample, EVERY host core: orc_extend_pol_team puts the whole OpenMP team on
+    one column at a time (the butterflies of a stage are independent), so an 8-column trace uses all 128 cores of the GPU box."""
     from oracle import gl_oracle as orc
     threads = orc.num_threads()
     # pick a sample size whose run time is ~10-30 s: calibrate on 2^16
     n = 1 << 16
     src = orc.fill(n * ncols, SEED).reshape(n, ncols)
     t0 = time.perf_counter()
-    orc.extend_pol(src, n << EXT_BITS, n, ncols)
+    orc.extend_pol_team(src, n << EXT_BITS, n, ncols)
     t = time.perf_counter() - t0
-    par = min(threads, ncols)
-    per_fe_log = t / (n * 17) * (1 if par >= ncols else ncols / par)   # ~ n log n per column-batch model
+    per_fe_log = t / (n * 17)                                  # ~ n log n model (small sizes parallelise worse: the estimate is an upper bound)
     lg = 16
     while lg < log_n and per_fe_log * (1 << (lg + 1)) * (lg + 2) < budget_s:
         lg += 1
     n = 1 << lg
     src = orc.fill(n * ncols, SEED).reshape(n, ncols)
     t0 = time.perf_counter()
-    orc.extend_pol(src, n << EXT_BITS, n, ncols)
+    orc.extend_pol_team(src, n << EXT_BITS, n, ncols)
     t = time.perf_counter() - t0
     out = {
-        "value": (n << EXT_BITS) * ncols / t / 1e9, "unit": "GFE/s", "cores": min(threads, ncols), "kind": "port",
-        "sample": f"oracle extendPol 2^{lg} x {ncols} -> 2^{lg + EXT_BITS} x {ncols} ({t:.2f} s, OpenMP over columns, "
+        "value": (n << EXT_BITS) * ncols / t / 1e9, "unit": "GFE/s", "cores": threads, "kind": "port",
+        "sample": f"oracle extendPol 2^{lg} x {ncols} -> 2^{lg + EXT_BITS} x {ncols} ({t:.2f} s, OpenMP team of {threads} threads on one column at a time, "
                   f"scalar u128 arithmetic; restated CPU path, not the reference's AVX2 binary)",
     }
     # the other two legs of the path on the same host cores (bounded samples): the Merkle leaf sponge + tree, and one small complete genProof
@@ -377,11 +377,13 @@ def genproof_sharded_cpp_leg(world, rank, local_rank, backend, log_n=23, timeout
     base["zkevmStarkInfo"] = os.path.join(bundle, "zkevm.starkinfo.json")
     port = int(os.environ.get("MASTER_PORT", "29500"))
     cfg = os.path.join(tempfile.gettempdir(), f"xlp_sharded_cfg_{port}_{world}.json")
-    rdv = os.path.join(tempfile.gettempdir(), f"xlp_rccl_id_{port}_{world}_{os.getppid()}") if backend == "rccl" else f"xlp_bench_{port}_{world}"
+    tag = os.environ.get("XLP_BENCH_LAUNCH_TAG", str(os.getppid()))     # the same on every rank of this run, different between runs
+    rdv = os.path.join(tempfile.gettempdir(), f"xlp_rccl_id_{port}_{world}_{tag}") if backend == "rccl" else f"xlp_bench_{port}_{world}_{tag}"
     if rank == 0:
         json.dump(base, open(cfg + ".tmp", "w")); os.replace(cfg + ".tmp", cfg)
-        if backend == "rccl" and os.path.exists(rdv):
-            os.remove(rdv)
+        for stale in ((rdv, rdv + ".tmp") if backend == "rccl" else ("/dev/shm/" + rdv, "/dev/shm/" + rdv + ".ctl")):
+            if os.path.exists(stale):                        # (the library does not trust leftovers either: comm.hip)
+                os.remove(stale)
     import torch.distributed as dist
     if dist.is_initialized():
         dist.barrier()                                       # config (and a bundle built just now) in place before the children start
@@ -437,6 +439,66 @@ def e2e_leg(timeout_s=300):
     return out
 
 
+def self_launch(gpus, budget_s):
+    """`python3 bench.py --gpus N` started PLAINLY (no torch.distributed.run around it): before anything touches the GPU, start one child per
+    rank -- this same script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment -- relay rank 0's single JSON line, and leave
+    with rank 0's exit code.  (Children, never an exec: a process that has initialised the GPU must not be replaced.)"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    t0 = time.time()
+    procs = []
+    for r in range(gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   XLP_BENCH_T0=repr(t0), XLP_BENCH_LAUNCH_TAG=f"{os.getpid()}_{int(t0)}")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=ROOT,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    line, rc = "", 1
+    try:
+        out, _ = procs[0].communicate(timeout=budget_s + 150)          # the ranks keep to budget_s themselves; this is the backstop
+        rc = procs[0].returncode
+        line = out.strip().splitlines()[-1] if out.strip() else ""
+    except subprocess.TimeoutExpired:
+        line = ""
+    for p_ in procs:                                                     # the exact processes started above
+        try:
+            p_.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            p_.kill()
+    if not line:
+        line = json.dumps({"metric": "Goldilocks NTT GFE/s (LDE 2^%d x %d, blow-up 2)" % (LOG_N, NCOLS), "value": None, "unit": "GFE/s", "n_gpus": gpus,
+                           "error": f"rank 0 printed no line (exit {rc}) within {budget_s + 150} s of the self-launched run"})
+        rc = rc or 1
+    print(line, flush=True)
+    return rc
+
+
+class Budget:
+    """ONE deadline for the whole run (the driver gives a bench command 600 s): every leg gets min(its cap, what is left minus what the legs after
+    it and the final line need) and is skipped -- named as skipped in the line -- when that is not enough to be worth starting."""
+
+    def __init__(self, seconds):
+        self.t0 = float(os.environ.get("XLP_BENCH_T0", time.time()))
+        self.seconds = seconds
+
+    def left(self):
+        return self.t0 + self.seconds - time.time()
+
+    def grant(self, cap, need, reserve=10.0, dist=None, dev=None, torch=None):
+        """seconds this leg may take (0 = skip).  With dist: the SAME answer on every rank (the smallest `left`)."""
+        left = self.left()
+        if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+            t = torch.tensor([left], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            left = float(t.item())
+        g = min(cap, left - reserve)
+        return g if g >= need else 0.0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -454,9 +516,14 @@ def main():
                     "Prover (host/zkprover_batch --world N); 0 = off; default: 23 when --gpus > 1, off on one GPU (opt-in there: a world of one through RCCL)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the --gpus N path with the ranks SHARING GPU 0 "
                     "(exchanges staged through the host); its numbers mean nothing")
+    ap.add_argument("--budget", type=float, default=420.0, help="seconds the whole run may take (one global deadline; legs that no longer fit are skipped and "
+                    "named in the line)")
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--ncols", type=int, default=NCOLS)
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        sys.exit(self_launch(args.gpus, args.budget))                    # plain `python3 bench.py --gpus N`: be the launcher (no GPU call before this)
+    budget = Budget(args.budget)
     # stdout carries exactly ONE line, the JSON: everything else that writes to fd 1 (RCCL prints a version banner there when its
     # first communicator is created) goes to stderr
     json_out = os.fdopen(os.dup(1), "w")
@@ -470,8 +537,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.backend == "gloo":
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -528,9 +594,14 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # ---- the exchange-carrying legs.  On one GPU: in this process (opt-in).  On several: one child process per rank.
+    # ---- the exchange-carrying legs.  On one GPU: in this process (opt-in).  On several: one child process per rank, in the order
+    # headline (above) -> sharded_commit -> genproof_sharded_cpp, each inside what is left of the ONE budget (a slow first contact with
+    # hardware this code has never seen costs the later legs, not the line).  The interpreted Python form of the sharded genProof
+    # (tools/zkevm_genproof_sharded.py) is opt-in (--sharded-genproof L): the C++ product path supersedes it.
     sharded, sharded_gp, sharded_bp = None, None, None
-    gp_log_n = args.sharded_genproof if args.sharded_genproof >= 0 else (20 if world > 1 else 0)
+    skipped = {}
+    gp_log_n = args.sharded_genproof if args.sharded_genproof > 0 else 0
+    grant = lambda cap, need, reserve: budget.grant(cap, need, reserve, dist, dev, torch)
     if world == 1 and args.sharded_commit == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29641")
         dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
@@ -541,20 +612,32 @@ def main():
         except Exception as e:                               # reported, never fatal for the headline line
             sharded = {"error": repr(e)[:300]}
         src = out = None
-    if world > 1 and (args.sharded_commit != 0 or gp_log_n):
+    bp_log_n = args.sharded_batchproof if args.sharded_batchproof >= 0 else (23 if world > 1 else 0)
+    if world > 1 and (args.sharded_commit != 0 or gp_log_n or bp_log_n):
         src = out = None
         torch.cuda.empty_cache()
         capi.shutdown()                                      # the children get the whole GPU
         if args.sharded_commit != 0:
-            sharded = child_leg("bench_sharded_commit.py", ["--log-n", str(args.log_n), "--ncols", "751" if args.log_n == LOG_N else "64", "--steps", "2",
-                                                            "--check"], world, rank, local_rank, 29, args.backend)
+            g = grant(150.0, 45.0, 150.0 if bp_log_n else 10.0)          # (leave the batch proof, the leg that matters more, its share)
+            if g:
+                sharded = child_leg("bench_sharded_commit.py", ["--log-n", str(args.log_n), "--ncols", "751" if args.log_n == LOG_N else "64", "--steps", "2",
+                                                                "--check"], world, rank, local_rank, 29, args.backend, timeout_s=g)
+            else:
+                skipped["sharded_commit"] = f"{budget.left():.0f} s left of the {args.budget:.0f} s budget"
+            dist.barrier()
+        if bp_log_n:
+            g = grant(330.0, 90.0, 10.0)
+            if g:
+                sharded_bp = genproof_sharded_cpp_leg(world, rank, local_rank, "rccl" if args.backend == "nccl" else "shm", bp_log_n, timeout_s=g)
+            else:
+                skipped["genproof_sharded_cpp"] = f"{budget.left():.0f} s left of the {args.budget:.0f} s budget"
             dist.barrier()
         if gp_log_n:
-            sharded_gp = child_leg("zkevm_genproof_sharded.py", ["--log-n", str(gp_log_n), "--check-one-gpu"], world, rank, local_rank, 23, args.backend)
-            dist.barrier()
-        bp_log_n = args.sharded_batchproof if args.sharded_batchproof >= 0 else 23
-        if bp_log_n:
-            sharded_bp = genproof_sharded_cpp_leg(world, rank, local_rank, "rccl" if args.backend == "nccl" else "shm", bp_log_n)
+            g = grant(200.0, 60.0, 10.0)
+            if g:
+                sharded_gp = child_leg("zkevm_genproof_sharded.py", ["--log-n", str(gp_log_n), "--check-one-gpu"], world, rank, local_rank, 23, args.backend, timeout_s=g)
+            else:
+                skipped["sharded_genproof"] = f"{budget.left():.0f} s left of the {args.budget:.0f} s budget"
             dist.barrier()
     elif gp_log_n:
         src = out = None
@@ -614,6 +697,9 @@ def main():
             line["sharded_genproof"] = sharded_gp
         if sharded_bp is not None:
             line["genproof_sharded_cpp"] = sharded_bp
+        if world > 1:
+            line["multi_gpu_evidence"] = ("no run of this code on more than one GPU existed when it was written (none in the build pool): ranks_seen inside "
+                                          "genproof_sharded_cpp.sharded is what the transport itself counted in THIS run")
         if world == 1:
             line["roofline_merkle"] = merkle_leg(capi, torch, dev)
             if not args.no_bn128:
@@ -622,11 +708,19 @@ def main():
             del src, out
             torch.cuda.empty_cache()
             capi.shutdown()                                   # the child needs ~300 of the 309 GB: give the library's scratch back too
-            line["genproof"] = genproof_leg()
+            g = budget.grant(300.0, 120.0, 60.0)              # (two runs of the binary; the CPU baseline after it needs ~45 s)
+            if g:
+                line["genproof"] = genproof_leg(timeout_s=g / 2)
+            else:
+                skipped["genproof"] = f"{budget.left():.0f} s left of the {args.budget:.0f} s budget"
             if not args.no_e2e:
-                line["e2e"] = e2e_leg()
+                g = budget.grant(200.0, 60.0, 60.0)
+                if g:
+                    line["e2e"] = e2e_leg(timeout_s=g)
+                else:
+                    skipped["e2e"] = f"{budget.left():.0f} s left of the {args.budget:.0f} s budget"
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.log_n, ncols)
+            line["cpu_baseline"] = cpu_baseline(args.log_n, ncols, budget_s=max(3.0, min(20.0, budget.left() / 3)))
             g = genproof_toy_gpu(capi)
             line["cpu_baseline"]["legs"]["genproof_toy_gpu"] = g
             tg = line["cpu_baseline"]["legs"].get("genproof_toy", {})
@@ -634,6 +728,9 @@ def main():
                 line["cpu_baseline"]["legs"]["genproof_toy_same_root"] = g["root1"] == tg["root1"]
         else:
             line["cpu_baseline"] = None
+        if skipped:
+            line["skipped"] = skipped
+        line["seconds_used"] = round(time.time() - budget.t0, 1)
         json_out.write(json.dumps(line) + "\n"); json_out.flush()
 
     if dist.is_initialized():

@@ -52,6 +52,16 @@ int xlp_init(int device);
 /* Use an existing hipStream_t (e.g. torch's current stream) for all xlp_dev_* work. */
 int xlp_set_stream(void* hip_stream);
 int xlp_sync(void);
+/* Two streams for a caller that overlaps exchanges (and the copies around them) with kernels -- host/starks.hpp, the row-sharded commit:
+ * band k + 1's all-to-all runs beside band k's extendPol (the split of starks.cpp:53-60).  Stream 0 is the context's stream, stream 1 a second
+ * one created on first use.  xlp_stream_select(s): every later xlp_dev_* / xlp_comm_* call enqueues on stream s.  xlp_stream_wait(a, b): work
+ * enqueued on stream a from now on starts after everything enqueued on stream b so far.  xlp_sync with stream 0 selected waits for both. */
+int xlp_stream_select(int which);
+int xlp_stream_wait(int waiter, int signaller);
+/* Finer ordering: xlp_stream_mark(s, m) records "everything enqueued on stream s so far" in mark m (0..7, reusable);
+ * xlp_stream_wait_mark(s, m): later work of stream s waits for what mark m recorded (never recorded: no wait). */
+int xlp_stream_mark(int stream, int mark);
+int xlp_stream_wait_mark(int stream, int mark);
 void xlp_shutdown(void);
 const char* xlp_last_error(void);
 /* 0xMMmmpp */
@@ -325,16 +335,27 @@ int xlp_profile_read(double ms_sum[3], uint64_t* count);
  *   backend "shm":  ranks sharing one GPU or without a peer path (test box, rehearsal): POSIX shared memory named `rendezvous`, host-staged.
  *   backend NULL / "self": world must be 1; exchanges are device copies.
  * xlp_comm_exchange: recv[p] (recv_words[p] words) <- the block rank p sends me; send[p] (send_words[p] words) -> rank p; arrays of
- *   `world` entries; my own block is copied on the device.  Messages travel in rounds of <= 256 MiB per (sender, receiver).
+ *   `world` entries; my own block is copied on the device.  Messages travel in rounds of <= 256 MiB per (sender, receiver); all_max_words =
+ *   the longest (sender, receiver) message of the whole exchange, the SAME number on every rank (it fixes the number of rounds): a caller that
+ *   knows every rank's sizes passes it and the exchange is enqueued without waiting for the GPU; 0 = unknown, the ranks agree on it through
+ *   one host word each (synchronises the stream).
+ * xlp_comm_ranks_seen: the number of ranks the transport itself reports (ncclCommCount / processes attached to the segment); 0 before init.
+ * xlp_comm_abort: tell the other ranks that this one is giving up (the host's exit path calls it): their pending and later xlp_comm_* calls
+ *   fail with the reason instead of waiting for a peer that is gone; ranks inside RCCL (no timeout there) are ended by a watchdog thread.
+ *   A rank that dies without calling it is found by its heartbeat (20 s).  No-op in a world of one.
  * xlp_comm_all_gather: out[p * words ..] <- rank p's `in`.   xlp_comm_sendrecv: one ring step (halo rows).
  * xlp_comm_all_gather_host: the same for a few HOST words (synchronises the stream).
+ * Everything is enqueued on the CURRENT stream (xlp_stream_select).  Environment (tests): XLP_COMM_MAX_MESSAGE_WORDS = words per message
+ * and round; XLP_COMM_SELF_VIA_RCCL = the own block of an exchange travels through ncclSend / ncclRecv too (the multi-round path in a world of one).
  * xlp_comm_stats: seconds / bytes sent to peers / calls of the exchanges so far; mode bit 0 resets, bit 1 turns the timing on (each
  *   exchange then synchronises the stream before and after), bit 2 turns it off. */
 int xlp_comm_init(int rank, int world, const char* backend, const char* rendezvous);
 void xlp_comm_shutdown(void);
 int xlp_comm_rank(void);
 int xlp_comm_world(void);
-int xlp_comm_exchange(uint64_t* const* recv, const uint64_t* recv_words, const uint64_t* const* send, const uint64_t* send_words);
+int xlp_comm_ranks_seen(void);
+void xlp_comm_abort(const char* why);
+int xlp_comm_exchange(uint64_t* const* recv, const uint64_t* recv_words, const uint64_t* const* send, const uint64_t* send_words, uint64_t all_max_words);
 int xlp_comm_all_gather(uint64_t* out, const uint64_t* in, uint64_t words);
 int xlp_comm_sendrecv(uint64_t* recv, int from, const uint64_t* send, int to, uint64_t words);
 int xlp_comm_all_gather_host(uint64_t* out, const uint64_t* in, uint64_t words);

@@ -360,6 +360,67 @@ void orc_extend_pol(u64 *out, const u64 *in, u64 n_ext, u64 n, u64 ncols)
     }
 }
 
+/* The same extension with EVERY host thread at work (bench.py's cpu_baseline on the GPU box's cores): orc_extend_pol above runs one thread
+ * per column, which leaves 120 of 128 cores idle on an 8-column trace.  Here the team shares one column at a time: the butterflies of a stage
+ * are independent, twiddles come from a table w(log2 n)^i built in parallel chunks.  Same arithmetic, same results as orc_extend_pol
+ * (tests/test_oracle_golden.py compares the two). */
+static void ntt_col_team(u64 *a, u64 n, int inverse, const u64 *tw /* w(log2 n)^(+-i), i < n/2 */)
+{
+    const unsigned lg = ilog2(n);
+#pragma omp for schedule(static)
+    for (u64 i = 0; i < n; i++) {
+        u64 j = bitrev(i, lg);
+        if (i < j) { u64 t = a[i]; a[i] = a[j]; a[j] = t; }
+    }
+    for (unsigned s = 1; s <= lg; s++) {
+        const u64 h = 1ULL << (s - 1), step = n >> s;
+#pragma omp for schedule(static)
+        for (u64 i = 0; i < n / 2; i++) {
+            const u64 j = i & (h - 1), k = (i >> (s - 1)) << s;
+            const u64 t = gl_mul(tw[j * step], a[k + j + h]);
+            const u64 u = a[k + j];
+            a[k + j] = gl_add(u, t);
+            a[k + j + h] = gl_sub(u, t);
+        }
+    }
+    if (inverse) {
+        const u64 ninv = gl_inv(n % GL_P);
+#pragma omp for schedule(static)
+        for (u64 i = 0; i < n; i++) a[i] = gl_mul(a[i], ninv);
+    }
+}
+static void pow_table_team(u64 *t, u64 count, u64 base)       /* t[i] = base^i */
+{
+#pragma omp for schedule(static)
+    for (u64 c = 0; c < (count + 4095) / 4096; c++) {
+        u64 v = gl_pow(base, c * 4096);
+        for (u64 i = c * 4096; i < count && i < (c + 1) * 4096; i++) { t[i] = v; v = gl_mul(v, base); }
+    }
+}
+void orc_extend_pol_team(u64 *out, const u64 *in, u64 n_ext, u64 n, u64 ncols)
+{
+    if (n == 0 || ncols == 0) return;
+    u64 *col = (u64 *)malloc(n_ext * sizeof(u64));
+    u64 *twi = (u64 *)malloc((n / 2 + 1) * sizeof(u64)), *twf = (u64 *)malloc((n_ext / 2 + 1) * sizeof(u64)), *sh = (u64 *)malloc(n * sizeof(u64));
+#pragma omp parallel
+    {
+        pow_table_team(twi, n / 2, gl_inv(orc_w(ilog2(n))));
+        pow_table_team(twf, n_ext / 2, orc_w(ilog2(n_ext)));
+        pow_table_team(sh, n, GL_SHIFT);
+        for (u64 c = 0; c < ncols; c++) {
+#pragma omp for schedule(static)
+            for (u64 i = 0; i < n; i++) col[i] = gl_canon(in[i * ncols + c]);
+            ntt_col_team(col, n, 1, twi);
+#pragma omp for schedule(static)
+            for (u64 i = 0; i < n_ext; i++) col[i] = i < n ? gl_mul(col[i], sh[i]) : 0;
+            ntt_col_team(col, n_ext, 0, twf);
+#pragma omp for schedule(static)
+            for (u64 i = 0; i < n_ext; i++) out[i * ncols + c] = col[i];
+        }
+    }
+    free(col); free(twi); free(twf); free(sh);
+}
+
 /* Naive evaluation: out[k] = P(shift*w_ext^k) by Horner over INTT coefficients
  * computed with the naive DFT.  Independent check of orc_extend_pol. */
 void orc_extend_naive(u64 *out, const u64 *in, u64 n_ext, u64 n)

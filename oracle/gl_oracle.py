@@ -40,6 +40,7 @@ def _load():
         "orc_ntt": (None, [_pu64, _pu64, u64, u64, C.c_int]),
         "orc_dft_naive": (None, [_pu64, _pu64, u64, C.c_int]),
         "orc_extend_pol": (None, [_pu64, _pu64, u64, u64, u64]),
+        "orc_extend_pol_team": (None, [_pu64, _pu64, u64, u64, u64]),
         "orc_extend_naive": (None, [_pu64, _pu64, u64, u64]),
         "orc_fri_fold": (None, [_pu64, _pu64, C.c_uint, C.c_uint, _pu64, u64]),
         "orc_fri_fold_one": (None, [_pu64, _pu64, C.c_uint, C.c_uint, u64, _pu64, u64]),
@@ -162,6 +163,15 @@ def extend_pol(src, n_ext, n, ncols):
     out = np.zeros(n_ext * ncols, np.uint64)
     if n * ncols:
         lib.orc_extend_pol(out, src, n_ext, n, ncols)
+    return out.reshape(n_ext, ncols)
+
+
+def extend_pol_team(src, n_ext, n, ncols):
+    """extend_pol with all host threads on one column at a time (the CPU-baseline form: a narrow trace still uses every core)"""
+    src = _a(src).ravel()
+    out = np.zeros(n_ext * ncols, np.uint64)
+    if n * ncols:
+        lib.orc_extend_pol_team(out, src, n_ext, n, ncols)
     return out.reshape(n_ext, ncols)
 
 

@@ -111,6 +111,112 @@ def test_comm_shared_memory_backend_between_processes(tmp_path, world):
         assert p.returncode == 0 and so.strip() == f"ok {r}", se[-1500:]
 
 
+_COMM_WORKER_FAIL = r"""
+import ctypes, os, sys, time
+sys.path.insert(0, sys.argv[1])
+from xlayer_prover_amd import capi
+rank, world, name, mode = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+if rank == 0 and mode == "late0":
+    time.sleep(1.0)                                    # the others meet the leftover segment first
+lib = capi.load()
+assert lib.xlp_comm_init(rank, world, b"shm", name.encode()) == 0, lib.xlp_last_error()
+U = ctypes.c_uint64
+mine, out = (U * 1)(rank), (U * world)()
+assert lib.xlp_comm_all_gather_host(out, mine, 1) == 0, lib.xlp_last_error()
+assert list(out) == list(range(world))
+if mode in ("abort", "die") and rank == world - 1:
+    if mode == "abort":
+        lib.xlp_comm_abort(b"boom from the last rank")
+    os._exit(3)                                        # no shutdown: the way a crashed rank goes
+t0 = time.time()
+rc = lib.xlp_comm_all_gather_host(out, mine, 1)
+if mode in ("abort", "die"):
+    assert rc != 0, "the gather must fail when a rank is gone"
+    msg = lib.xlp_last_error().decode()
+    assert ("boom from the last rank" in msg) if mode == "abort" else ("stopped responding" in msg), msg
+    assert time.time() - t0 < 30
+    lib.xlp_comm_shutdown()
+    print("failed-fast", rank, round(time.time() - t0, 2))
+else:
+    assert rc == 0, lib.xlp_last_error()
+    lib.xlp_comm_shutdown()
+    print("ok", rank)
+"""
+
+
+def _run_ranks(tmp_path, script, world, name, mode, env=None, timeout=120):
+    import subprocess
+    import sys
+    w = tmp_path / "worker.py"
+    w.write_text(script)
+    e = dict(os.environ)
+    e.update(env or {})
+    procs = [subprocess.Popen([sys.executable, str(w), ROOT, str(r), str(world), name, mode], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=e) for r in range(world)]
+    try:
+        outs = [p.communicate(timeout=timeout) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return procs, outs
+
+
+def _leftover_segment(name, world, slot_mb=16, pid=None):
+    """what a killed run leaves in /dev/shm: a segment of the right size, marked ready, every rank attached, barrier counters mid-way;
+    its creator's pid is dead (or, pid given, a live process that is not the creator: a recycled pid)"""
+    import struct
+    size = 4096 + world * world * (slot_mb << 20)
+    if pid is None:
+        pid, start = 2 ** 22 + 12345, 1                  # above pid_max's default: no such process
+    else:                                                # a live process with its real start time: the liveness test passes
+        stat = open(f"/proc/{pid}/stat").read()
+        start = int(stat[stat.rindex(")") + 2:].split()[19])
+    hdr = struct.pack("<IIQQQ", 0x584c5031, world, pid, start, size) + struct.pack("<III", 1, 7, world) + b"\0" * 4 + struct.pack("<Q", slot_mb << 20)
+    for n, sz, h in ((name, size, hdr), (name + ".ctl", None, None)):
+        path = "/dev/shm/" + n
+        if h is None:
+            if os.path.exists(path):
+                os.remove(path)
+            continue
+        with open(path, "wb") as f:
+            f.write(h)
+            f.truncate(sz)
+
+
+@pytest.mark.parametrize("mode", ["ok", "late0", "late0-live-owner"])
+def test_comm_rendezvous_ignores_the_segment_a_killed_run_left_behind(tmp_path, mode):
+    """a rank > 0 used to accept any existing segment of the right size, and then sat on the stale counters of a dead run
+    until the 300 s / 600 s waits gave up.  Now a segment is only taken when its creator is alive, and a rank that did pick up a leftover
+    moves over when rank 0 replaces it (here rank 0 arrives a second late)."""
+    name = f"xlp_abi_stale_{os.getpid()}_{mode}"
+    # "live-owner": the leftover names a live process as its creator (this one), so rank 1 DOES attach to it first -- and must find out
+    # that the name has moved to rank 0's fresh segment
+    _leftover_segment(name, 2, pid=os.getpid() if mode.endswith("live-owner") else None)
+    try:
+        procs, outs = _run_ranks(tmp_path, _COMM_WORKER_FAIL, 2, name, mode.split("-")[0])
+        for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+            assert p.returncode == 0 and so.strip() == f"ok {r}", se[-1500:]
+    finally:
+        for n in (name, name + ".ctl"):
+            if os.path.exists("/dev/shm/" + n):
+                os.remove("/dev/shm/" + n)
+
+
+@pytest.mark.parametrize("mode", ["abort", "die"])
+def test_comm_failure_of_one_rank_ends_the_others(tmp_path, mode):
+    """a dead rank used to leave the others in a 600 s barrier wait.  xlp_comm_abort (the host's exit path calls it) raises
+    a flag in the control segment that every wait checks; a rank that just dies is found by its heartbeat (shortened here)."""
+    name = f"xlp_abi_fail_{os.getpid()}_{mode}"
+    try:
+        procs, outs = _run_ranks(tmp_path, _COMM_WORKER_FAIL, 2, name, mode, env={"XLP_COMM_HEARTBEAT_STALE_MS": "1500"})
+        assert procs[1].returncode == 3
+        assert procs[0].returncode == 0 and outs[0][0].startswith("failed-fast 0"), outs[0][1][-1500:]
+    finally:
+        for n in (name, name + ".ctl"):
+            if os.path.exists("/dev/shm/" + n):
+                os.remove("/dev/shm/" + n)
+
+
 def test_comm_rejects_bad_worlds():
     from xlayer_prover_amd import capi
     lib = capi.load()

@@ -69,10 +69,14 @@ def _run_ranks(bundle, world, backend, tmp_path, timeout=900, env=None):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,backend,scratch_mb", [(1, "self", 0), (1, "rccl", 0), (2, "shm", 0), (4, "shm", 0), (2, "shm", 1)])
-def test_cpp_sharded_starks_proof_equals_one_gpu_proof(tmp_path, world, backend, scratch_mb):
+@pytest.mark.parametrize("world,backend,scratch_mb,msg_words", [(1, "self", 0, 0), (1, "rccl", 0, 0), (2, "shm", 0, 0), (4, "shm", 0, 0), (2, "shm", 1, 0),
+                                                                (1, "rccl", 1, 1000), (2, "shm", 0, 777), (1, "self", 1, 0)])
+def test_cpp_sharded_starks_proof_equals_one_gpu_proof(tmp_path, world, backend, scratch_mb, msg_words):
     """scratch_mb: the staging budget of the sharded commit (XLP_SHARD_SCRATCH_MB); 1 MiB forces the exchanges / LDE of a section into many
-    column bands (at the real size a 2-rank zkEVM section needs 7 bands to stay below 24 GB)"""
+    column bands, i.e. the two-stream pipeline of commitSharded with both staging sets in use (at the real size a 2-rank zkEVM section needs
+    14 bands to stay below 24 GB).  msg_words: XLP_COMM_MAX_MESSAGE_WORDS -- messages of an exchange / all-gather travel in ROUNDS of that many
+    words (256 MiB in production, never reached at test sizes); with rccl in a world of one the rank's own block is sent through
+    ncclSend / ncclRecv too (XLP_COMM_SELF_VIA_RCCL), so the grouped multi-round loop runs on RCCL itself."""
     from tools import make_stark_bundle as B
     if not _programs_built():
         pytest.skip("converted reference programs not built (needs the reference tree at build time)")
@@ -82,7 +86,13 @@ def test_cpp_sharded_starks_proof_equals_one_gpu_proof(tmp_path, world, backend,
     assert r.returncode == 0, r.stderr[-3000:]
     expect = json.loads(r.stdout)
     win = B.make("zkevm", ln, False, out=str(tmp_path / "win"), world=world)
-    env = dict(os.environ, XLP_SHARD_SCRATCH_MB=str(scratch_mb)) if scratch_mb else None
+    env = dict(os.environ)
+    if scratch_mb:
+        env["XLP_SHARD_SCRATCH_MB"] = str(scratch_mb)
+    if msg_words:
+        env["XLP_COMM_MAX_MESSAGE_WORDS"] = str(msg_words)
+        if backend == "rccl":
+            env["XLP_COMM_SELF_VIA_RCCL"] = "1"
     got, logs = _run_ranks(win, world, backend, tmp_path, env=env)
     assert "exchanges" in logs[0]
     for k in ("root1", "root2", "root3", "root4"):
@@ -134,6 +144,58 @@ def test_genbatchproof_with_the_zkevm_stark_sharded_equals_one_gpu(tmp_path):
     assert outs[1][0].strip() == ""                                   # only rank 0 reports
     assert got["sharded"]["world"] == 2 and got["sharded"]["exchanges"] > 0
     assert got["recursive1_root1"] == expect["recursive1_root1"]
+    assert got["batch_proof_fnv"] == expect["batch_proof_fnv"] and got["batch_proof_bytes"] == expect["batch_proof_bytes"]
+
+
+@pytest.mark.gpu
+def test_genbatchproof_two_ranks_at_2p18_with_the_default_staging_budget(tmp_path):
+    """the multi-rank product path at a size where the exchanges are hundreds of MB (2^18 rows: 0.8 GB of witness per rank, sections
+    of 751 / 168 / 408 columns), through host/zkprover_batch with the DEFAULT staging budget and message size, ranks sharing the box's GPU (shm).
+    Rank 0's line must name 2 ranks seen by the transport, the same zkEVM proof on both ranks, per-stage exchange volumes -- and the batch proof
+    of the one-GPU run."""
+    from tools import make_stark_bundle as B
+    if not _programs_built():
+        pytest.skip("converted reference programs not built (needs the reference tree at build time)")
+    exe = os.path.join(ROOT, "xlayer_prover_amd", "host", "zkprover_batch")
+    small = {"c12a": B.make("c12a", 20, False, out=str(tmp_path / "c12a")), "recursive1": B.make("recursive1", 17, False, out=str(tmp_path / "recursive1"))}
+
+    def config(name, zk):
+        cfg = {"runFileGenBatchProof": True, "saveOutputToFile": False, "saveProofToFile": False, "outputPath": str(tmp_path), "xlpSyntheticLookups": True}
+        for n, b in dict(small, zkevm=zk).items():
+            cfg[n + "StarkInfo"] = os.path.join(b, f"{n}.starkinfo.json")
+            cfg[n + "ConstPols"] = f"synthetic:{CSEED + len(n)}"
+            cfg[n + "ConstantsTree"] = ""
+            cfg[n + "Verkey"] = ""
+        f = tmp_path / name
+        f.write_text(json.dumps(cfg))
+        return str(f)
+    ln = 18
+    one = config("one.json", B.make("zkevm", ln, False, out=str(tmp_path / "zk1")))
+    r = subprocess.run([exe, "-c", one, "--proofs", "1"], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    expect = json.loads(r.stdout.strip().splitlines()[-1])
+    two = config("two.json", B.make("zkevm", ln, False, out=str(tmp_path / "zk2"), world=2))
+    name = f"xlp_test_bp18_{os.getpid()}"
+    procs = [subprocess.Popen([exe, "-c", two, "--proofs", "1", "--timers", "--world", "2", "--rank", str(k), "--backend", "shm", "--rendezvous", name],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=1200))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for k, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {k}: {se[-3000:]}"
+    got = json.loads(outs[0][0].strip().splitlines()[-1])
+    sh = got["sharded"]
+    assert sh["world"] == 2 and sh["ranks_seen"] == 2 and sh["same_zkevm_proof_on_all_ranks"] is True
+    st = sh["exchange_by_stage_rank0"]
+    assert set(st) >= {"STARK_STEP_1_LDE_AND_MERKLETREE", "STARK_STEP_2_LDE_AND_MERKLETREE", "STARK_STEP_3_LDE_AND_MERKLETREE"}
+    n = 1 << ln
+    # step 1: my rows of the peer's columns out (n/2 x ~375 words), my columns of the peer's extended rows out (n x ~375 words): ~0.59 GB
+    assert 0.9 * 8 * (n // 2 + n) * 375 < st["STARK_STEP_1_LDE_AND_MERKLETREE"]["GB_sent"] * 1e9 < 1.1 * 8 * (n // 2 + n) * 376
     assert got["batch_proof_fnv"] == expect["batch_proof_fnv"] and got["batch_proof_bytes"] == expect["batch_proof_bytes"]
 
 

@@ -96,14 +96,19 @@ SIGNATURES = {
     "xlp_comm_init": [C.c_int, C.c_int, C.c_char_p, C.c_char_p],
     "xlp_comm_rank": [],
     "xlp_comm_world": [],
-    "xlp_comm_exchange": [_pu, _pu, _pu, _pu],
+    "xlp_comm_exchange": [_pu, _pu, _pu, _pu, _u64],
+    "xlp_comm_ranks_seen": [],
+    "xlp_stream_select": [C.c_int],
+    "xlp_stream_wait": [C.c_int, C.c_int],
+    "xlp_stream_mark": [C.c_int, C.c_int],
+    "xlp_stream_wait_mark": [C.c_int, C.c_int],
     "xlp_comm_all_gather": [_pu, _pu, _u64],
     "xlp_comm_sendrecv": [_pu, C.c_int, _pu, C.c_int, _u64],
     "xlp_comm_all_gather_host": [_pu, _pu, _u64],
     "xlp_comm_barrier": [],
     "xlp_comm_stats": [C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int],
 }
-VOID_SIGNATURES = {"xlp_shutdown": [], "xlp_comm_shutdown": []}
+VOID_SIGNATURES = {"xlp_shutdown": [], "xlp_comm_shutdown": [], "xlp_comm_abort": [C.c_char_p]}
 SIZE_SIGNATURES = {"xlp_cache_bytes": [], "xlp_merkle_bn128_num_nodes": [C.c_uint64]}
 STR_SIGNATURES = {"xlp_last_error": []}
 

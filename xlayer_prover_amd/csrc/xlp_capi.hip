@@ -24,6 +24,8 @@ static Ctx g_ctx;
 // callers costs nothing the GPU would have overlapped.  Recursive, because entry points call each other (xlp_perm -> xlp_perm_batch,
 // the staging copies, ensure_init -> xlp_init).  xlp_last_error() is per thread and takes no lock.
 static std::recursive_mutex g_mu;
+static hipEvent_t g_marks[8];
+static bool g_marked[8];
 #define XLP_ENTER std::lock_guard<std::recursive_mutex> xlp_api_lock(g_mu)
 
 int xlp_fail(const char* msg)
@@ -189,6 +191,7 @@ int xlp_set_stream(void* hip_stream)
 {
     XLP_ENTER;
     if (ensure_init()) return -1;
+    if (g_ctx.selected != 0) return xlp_fail("xlp_set_stream: stream 1 is selected (xlp_stream_select(0) first)");
     XLP_HIP(hipStreamSynchronize(g_ctx.stream));
     if (g_ctx.own_stream) { XLP_HIP(hipStreamDestroy(g_ctx.stream)); g_ctx.own_stream = false; }
     g_ctx.stream = (hipStream_t)hip_stream;
@@ -200,7 +203,60 @@ int xlp_sync(void)
     XLP_ENTER;
     if (ensure_init()) return -1;
     XLP_HIP(hipStreamSynchronize(g_ctx.stream));
+    if (g_ctx.side_stream && g_ctx.selected == 0) XLP_HIP(hipStreamSynchronize(g_ctx.side_stream));
     return 0;
+}
+
+// ---- two streams for a caller that overlaps exchanges with kernels (host/starks.hpp, row-sharded commit).  Stream 0 is the library's
+// stream (or the one given to xlp_set_stream), stream 1 a second one created on first use.  select: every later xlp_dev_* / xlp_comm_* call
+// enqueues on that stream.  wait(a, b): work enqueued on stream a from now on starts after everything enqueued on stream b so far.
+static hipStream_t stream_of(int which) { return which == 0 ? (g_ctx.selected == 0 ? g_ctx.stream : g_ctx.main_stream) : g_ctx.side_stream; }
+int xlp_stream_select(int which)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if (which != 0 && which != 1) return xlp_fail("xlp_stream_select: stream 0 or 1");
+    if (which == g_ctx.selected) return 0;
+    if (which == 1) {
+        if (!g_ctx.side_stream) XLP_HIP(hipStreamCreateWithFlags(&g_ctx.side_stream, hipStreamNonBlocking));
+        g_ctx.main_stream = g_ctx.stream;
+        g_ctx.stream = g_ctx.side_stream;
+    } else g_ctx.stream = g_ctx.main_stream;
+    g_ctx.selected = which;
+    return 0;
+}
+// finer than xlp_stream_wait: mark(s, slot) records "everything enqueued on stream s so far" in one of 8 reusable marks, wait_mark(s, slot)
+// makes later work of stream s wait for what that mark recorded (a mark never recorded: no wait)
+int xlp_stream_mark(int stream, int slot)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if ((stream != 0 && stream != 1) || slot < 0 || slot >= 8) return xlp_fail("xlp_stream_mark: stream 0 or 1, mark 0..7");
+    if (stream == 1 && !g_ctx.side_stream) XLP_HIP(hipStreamCreateWithFlags(&g_ctx.side_stream, hipStreamNonBlocking));
+    if (!g_marks[slot]) XLP_HIP(hipEventCreateWithFlags(&g_marks[slot], hipEventDisableTiming));
+    XLP_HIP(hipEventRecord(g_marks[slot], stream_of(stream)));
+    g_marked[slot] = true;
+    return 0;
+}
+int xlp_stream_wait_mark(int stream, int slot)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if ((stream != 0 && stream != 1) || slot < 0 || slot >= 8) return xlp_fail("xlp_stream_wait_mark: stream 0 or 1, mark 0..7");
+    if (!g_marked[slot]) return 0;
+    if (stream == 1 && !g_ctx.side_stream) XLP_HIP(hipStreamCreateWithFlags(&g_ctx.side_stream, hipStreamNonBlocking));
+    XLP_HIP(hipStreamWaitEvent(stream_of(stream), g_marks[slot], 0));
+    return 0;
+}
+int xlp_stream_wait(int waiter, int signaller)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if ((waiter != 0 && waiter != 1) || (signaller != 0 && signaller != 1)) return xlp_fail("xlp_stream_wait: stream 0 or 1");
+    if (waiter == signaller) return 0;
+    if (!g_ctx.side_stream) XLP_HIP(hipStreamCreateWithFlags(&g_ctx.side_stream, hipStreamNonBlocking));
+    EventPool pool;
+    return pool.mark(stream_of(signaller), stream_of(waiter));
 }
 
 void xlp_shutdown(void)
@@ -215,6 +271,9 @@ void xlp_shutdown(void)
         g_ctx.scratch[i] = nullptr;
         g_ctx.scratch_bytes[i] = 0;
     }
+    if (g_ctx.selected != 0) { g_ctx.stream = g_ctx.main_stream; g_ctx.selected = 0; }
+    for (int i = 0; i < 8; i++) { if (g_marks[i]) (void)hipEventDestroy(g_marks[i]); g_marks[i] = nullptr; g_marked[i] = false; }
+    if (g_ctx.side_stream) { (void)hipStreamSynchronize(g_ctx.side_stream); (void)hipStreamDestroy(g_ctx.side_stream); g_ctx.side_stream = nullptr; }
     if (g_ctx.own_stream) (void)hipStreamDestroy(g_ctx.stream);
     if (g_ctx.copy_stream) { (void)hipStreamSynchronize(g_ctx.copy_stream); (void)hipStreamDestroy(g_ctx.copy_stream); g_ctx.copy_stream = nullptr; }
     for (hipStream_t& a : g_ctx.aux_stream) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); a = nullptr; }
@@ -859,12 +918,14 @@ int xlp_comm_init(int rank, int world, const char* backend, const char* rendezvo
 void xlp_comm_shutdown(void) { XLP_ENTER; comm_shutdown(); }
 int xlp_comm_rank(void) { return comm_rank(); }
 int xlp_comm_world(void) { return comm_world(); }
-int xlp_comm_exchange(uint64_t* const* recv, const uint64_t* recv_words, const uint64_t* const* send, const uint64_t* send_words)
+int xlp_comm_ranks_seen(void) { return comm_ranks_seen(); }
+void xlp_comm_abort(const char* why) { comm_abort(why); }    // (no lock: the caller may be on its way out of a failed call of another thread)
+int xlp_comm_exchange(uint64_t* const* recv, const uint64_t* recv_words, const uint64_t* const* send, const uint64_t* send_words, uint64_t all_max_words)
 {
     XLP_ENTER;
     if (ensure_init()) return -1;
     if (!recv || !recv_words || !send || !send_words) return xlp_fail("xlp_comm_exchange: null pointer");
-    return comm_exchange(&g_ctx, recv, recv_words, send, send_words);
+    return comm_exchange(&g_ctx, recv, recv_words, send, send_words, all_max_words);
 }
 int xlp_comm_all_gather(uint64_t* out, const uint64_t* in, uint64_t words)
 {

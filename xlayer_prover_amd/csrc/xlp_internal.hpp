@@ -40,8 +40,11 @@ int xlp_fail_hip(hipError_t e, const char* file, int line);
 
 struct Ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;           // the CURRENT stream: every xlp_dev_* / xlp_comm_* call enqueues here (xlp_stream_select)
     bool own_stream = false;
+    hipStream_t main_stream = nullptr;      // stream 0 of xlp_stream_select (what `stream` is unless stream 1 is selected)
+    hipStream_t side_stream = nullptr;      // stream 1: exchanges and their pack / unpack copies beside the kernels of stream 0 (host/starks.hpp)
+    int selected = 0;
     hipStream_t down_stream = nullptr;      // device -> host results of the pipelined host-pointer entry points
     hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};   // more compute streams: the slabs of a step program go round them (dev_expr_run)
     hipStream_t copy_stream = nullptr;      // host <-> device transfers that overlap kernels on `stream` (xlp_dev_commit_from_host)
@@ -119,7 +122,9 @@ int comm_init(Ctx* ctx, int rank, int world, const char* backend, const char* re
 void comm_shutdown();
 int comm_rank();
 int comm_world();
-int comm_exchange(Ctx* ctx, u64* const* recv, const u64* recv_words, const u64* const* send, const u64* send_words);
+int comm_ranks_seen();
+void comm_abort(const char* why);
+int comm_exchange(Ctx* ctx, u64* const* recv, const u64* recv_words, const u64* const* send, const u64* send_words, u64 all_max_words);
 int comm_all_gather(Ctx* ctx, u64* out, const u64* in, u64 words);
 int comm_sendrecv(Ctx* ctx, u64* recv, int from, const u64* send, int to, u64 words);
 int comm_all_gather_host(Ctx* ctx, u64* out, const u64* in, u64 words);

@@ -5,6 +5,8 @@
 //   "xlpChelpersPath"        directory of the converted step programs / bundles (default: next to the library: xlayer_prover_amd/chelpers)
 //   "xlpSyntheticLookups"    run plookups on a synthetic witness: f is a selection of rows of t (xlp_dev_gather_rows)
 //   "xlpDevice"              HIP device index (default 0)
+//   "xlpResidentConstants"   keep a resident copy of the extended constant polynomials from the second proof on when the device has
+//                            room beside everything else (default true; the reference keeps constPols2ns loaded, starks.hpp:138-146)
 #pragma once
 #include <cstdlib>
 #include <string>
@@ -23,7 +25,7 @@ public:
     std::string recursive2ConstPols, recursive2ConstantsTree, recursive2StarkInfo, recursive2Verkey;
     std::string recursivefConstPols, recursivefConstantsTree, recursivefStarkInfo, recursivefVerkey;
     std::string xlpChelpersPath;
-    bool xlpSyntheticLookups = false;
+    bool xlpSyntheticLookups = false, xlpResidentConstants = true;
     uint64_t xlpDevice = 0;
 
     bool generateProof(void) const { return runFileGenBatchProof || runFileGenAggregatedProof || runFileGenFinalProof || runAggregatorClient; }
@@ -59,6 +61,7 @@ public:
         }
         ParseString(config, "xlpChelpersPath", "XLP_CHELPERS_PATH", xlpChelpersPath, "");
         ParseBool(config, "xlpSyntheticLookups", "XLP_SYNTHETIC_LOOKUPS", xlpSyntheticLookups, false);
+        ParseBool(config, "xlpResidentConstants", "XLP_RESIDENT_CONSTANTS", xlpResidentConstants, true);
         if (config.contains("xlpDevice")) xlpDevice = config["xlpDevice"];
     }
     void load(const std::string& file) { load(xlp_json::Parser(xlp_read_file(file)).value()); }

@@ -31,6 +31,10 @@ public:
     std::string publicsJson, proofJson;
     std::vector<std::pair<std::string, double>> timers;
     double witnessUploadMs = 0.0;
+    // row-sharded zkEVM STARK: what each timed stage spent in xlp_comm_exchange (when xlp_comm_stats timing is on), and whether every rank
+    // ended with the same zkEVM proof text (an all-gather of its FNV-1a hash): -1 not sharded, 0 no, 1 yes
+    std::vector<Starks::StageExchange> exchanges;
+    int zkevmProofSameOnAllRanks = -1;
     uint64_t firstRow = 0;                           // row-sharded: the global row the executor's `degree` rows start at (set by genBatchProof)
     std::string publicsOutputFile() const { return filePrefix + "batch_proof.public.json"; }
 };
@@ -209,6 +213,16 @@ public:
             Tm t(&req, "STARK_JSON_GENERATION_BATCH_PROOF");
             zkin = withMembers(proof2zkinStark(*fproof), ",\"publics\":" + publicStarkJson);
             delete fproof;
+            req.exchanges = starkZkevm->lastExchanges;
+            req.zkevmProofSameOnAllRanks = -1;
+            if (starkZkevm->isSharded()) {
+                uint64_t h = 0xcbf29ce484222325ULL;
+                for (unsigned char c : zkin) { h ^= c; h *= 0x100000001b3ULL; }
+                std::vector<uint64_t> all((size_t)xlp_comm_world());
+                XLP_CHECK(xlp_comm_all_gather_host(all.data(), &h, 1));
+                req.zkevmProofSameOnAllRanks = 1;
+                for (uint64_t v : all) if (v != h) req.zkevmProofSameOnAllRanks = 0;
+            }
         }
         if (rank != 0) {                                     // row-sharded: c12a / recursive1 are rank 0's (0.1 s); the others are done
             req.publicsJson = publicStarkJson;

@@ -108,6 +108,8 @@ public:
     double lastUploadMs = 0.0;                      // time the copy stream was busy with the witness in the last genProof
     bool pipelineWitness = true;                    // false: upload the witness in one piece first, then commit it (the measurement of what the pipeline hides)
     std::vector<std::pair<std::string, double>> lastTimers;
+    struct StageExchange { std::string stage; double seconds, GB; uint64_t calls; };
+    std::vector<StageExchange> lastExchanges;       // row-sharded mode with xlp_comm_stats timing on: what each timed stage spent in xlp_comm_exchange
 
 private:
     StarkFiles starkFiles;
@@ -125,6 +127,7 @@ private:
     uint64_t nLoc = 0, neLoc = 0, haloN = 0, haloExt = 0, row0 = 0, ext0 = 0;     // my rows of the base / extended domain, halo rows, my first rows
     uint64_t *d_const_n_full = NULL, *d_const_2ns_win = NULL, *d_shard = NULL;
     uint64_t shardWords = 0;
+    double commSeconds = 0; uint64_t commBytes = 0, commCalls = 0;   // xlp_comm_stats at the end of the last timed stage
 
     static uint64_t* dalloc(uint64_t elems)
     {
@@ -138,7 +141,7 @@ private:
     // a dead section of the slab.  From the second proof on -- when the grow-only scratch of the first one exists and the free memory is
     // what it will stay -- a RESIDENT copy is taken instead if 8 GB remain free beside it (the reference keeps constPols2ns loaded,
     // starks.hpp:138-146); `residentConstants = false` keeps the trade as it was.
-    bool residentConstants = true;
+    bool residentConstants = true;                  // Config::xlpResidentConstants
     uint64_t* d_const_2ns_res = NULL;
     uint64_t proofsDone = 0;
     uint64_t* constPols2ns() { return d_const_2ns_res ? d_const_2ns_res : const2nsInSlab ? mem() + const2nsOffset : d_const_2ns_own; }
@@ -164,6 +167,13 @@ private:
             xlp_sync();
             const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             s->lastTimers.emplace_back(name, dt);
+            if (s->sharded) {
+                double sec = 0; uint64_t bytes = 0, calls = 0;
+                if (xlp_comm_stats(&sec, &bytes, &calls, 0) == 0 && calls > s->commCalls) {
+                    s->lastExchanges.push_back({name, sec - s->commSeconds, (bytes - s->commBytes) / 1e9, calls - s->commCalls});
+                    s->commSeconds = sec; s->commBytes = bytes; s->commCalls = calls;
+                }
+            }
             if (s->logTimers) fprintf(stderr, "<-- %s done: %.6f s\n", name, dt);
         }
     };
@@ -269,13 +279,14 @@ private:
         }
     }
     // how the sharded commit of a W-column section is cut into column bands (see commitSharded): number of bands, and per band the most
-    // columns all ranks together / one rank can hold; -> words of staging scratch it needs
+    // columns all ranks together / one rank can hold; -> words of ONE of the two staging sets it needs
     uint64_t commitBandPlan(uint64_t W, uint64_t& nb, uint64_t& bandTotalMax, uint64_t& wcbMax, uint64_t minBands = 1) const
     {
         const uint64_t wcMax = (W + world - 1) / world;
         const uint64_t allWords = nLoc * W + N * wcMax + NExtended * wcMax + neLoc * W;
         uint64_t budget = 24ULL << 30;
         if (const char* e = getenv("XLP_SHARD_SCRATCH_MB")) { const uint64_t v = strtoull(e, NULL, 10); if (v) budget = v << 20; }
+        budget /= 2;                                                // two sets: band k + 1 is exchanged while band k is extended
         nb = (allWords * sizeof(uint64_t) + budget - 1) / budget;
         if (nb < minBands) nb = minBands;
         if (nb > W / world && W / world) nb = W / world;            // at least one column per rank and band
@@ -296,7 +307,11 @@ private:
     // COLUMN (all N rows of my W / G columns), the leaf sponge per ROW (all W columns of my NExtended / G rows):
     //   rows -> columns all-to-all | extendPol of my columns | columns -> rows all-to-all | sub-tree | cap (32 bytes per rank)
     // The two exchanges and the LDE between them run in BANDS of columns (every rank's span is cut into the same number of bands) so that
-    // the staging buffers stay below XLP_SHARD_SCRATCH_MB (default 24576) whatever the section: (2 + 2 * 2^ext) x rows x columns words in all.
+    // the staging buffers stay below XLP_SHARD_SCRATCH_MB (default 24576) whatever the section: two sets of (2 + 2 * 2^ext) x rows x columns
+    // words.  The exchanges and the pack / unpack copies around them are enqueued on the library's stream 1, extendPol on stream 0
+    // (xlp_stream_select), ordered by marks: band k + 1 travels to its column owners while band k is extended, band k's extended columns
+    // travel back to their row owners while band k + 1 is extended.  Every rank knows every rank's band widths, so the exchanges are given
+    // their longest message and never wait for the host.
     // h_src != NULL (step 1): my rows of the section are still in HOST memory (the executor's output): their columns are uploaded band by band
     // on the copy stream, band k + 1 crossing PCIe while band k is exchanged and extended (at least 4 bands then)
     void commitSharded(typename H::Tree* tree, eSection sn, eSection s2, const uint64_t* h_src = NULL)
@@ -305,57 +320,88 @@ private:
         tree->d_source = section(s2);
         if (W) {
             uint64_t nb, bandTotalMax, wcbMax;
-            commitBandPlan(W, nb, bandTotalMax, wcbMax, h_src ? 4 : 1);
+            const uint64_t setWords = commitBandPlan(W, nb, bandTotalMax, wcbMax, h_src ? 4 : 1);
             // band k of a rank's span [a, b): [a + (b - a) k / nb, a + (b - a) (k + 1) / nb)
             auto band = [&](int r, uint64_t k, uint64_t& a, uint64_t& b) {
                 uint64_t c0, c1; colSpan(W, r, c0, c1);
                 a = c0 + (c1 - c0) * k / nb; b = c0 + (c1 - c0) * (k + 1) / nb;
             };
-            uint64_t* pack = shardScratch(nLoc * bandTotalMax + N * wcbMax + NExtended * wcbMax + neLoc * bandTotalMax);
-            uint64_t *colb = pack + nLoc * bandTotalMax, *extb = colb + N * wcbMax, *rowb = extb + NExtended * wcbMax;
+            auto widest = [&](uint64_t k) { uint64_t m = 0; for (int p_ = 0; p_ < world; p_++) { uint64_t a, b; band(p_, k, a, b); if (b - a > m) m = b - a; } return m; };
+            uint64_t* base = shardScratch(2 * setWords);
+            struct Set { uint64_t *pack, *colb, *extb, *rowb; } S[2];
+            for (int i = 0; i < 2; i++) {
+                S[i].pack = base + (uint64_t)i * setWords;
+                S[i].colb = S[i].pack + nLoc * bandTotalMax; S[i].extb = S[i].colb + N * wcbMax; S[i].rowb = S[i].extb + NExtended * wcbMax;
+            }
             std::vector<uint64_t*> rp(world);
             std::vector<const uint64_t*> spc(world);
             std::vector<uint64_t> rw(world), sw(world);
+            enum { M_FRONT = 0, M_EXT = 2, M_BACK = 4 };                 // marks (+ set): band exchanged to columns / extended / exchanged back
             auto upload = [&](uint64_t k) {                              // band k's columns (of every rank's span) of my rows: host -> section
                 for (int p_ = 0; p_ < world; p_++) {
                     uint64_t a, b; band(p_, k, a, b);
                     if (b > a) XLP_CHECK(xlp_dev_upload_cols_async(section(sn), h_src, W, a, b - a, nLoc));
                 }
             };
-            if (h_src) { XLP_CHECK(xlp_dev_upload_begin()); upload(0); }
-            for (uint64_t k = 0; k < nb; k++) {
+            // stream 1: rows -> columns.  Block p = my rows of rank p's band columns, packed; what arrives from p is rows [p nLoc, (p + 1) nLoc) of mine
+            auto front = [&](uint64_t k) {
+                Set& B = S[k & 1];
                 if (h_src) {
                     XLP_CHECK(xlp_dev_upload_fence());                   // band k (and everything before it) is there ...
                     if (k + 1 < nb) upload(k + 1);                        // ... and the next one starts while this one is worked on
                 }
+                if (k >= 2) XLP_CHECK(xlp_stream_wait_mark(1, M_EXT + (int)(k & 1)));      // extendPol of band k - 2 has read this set's columns
                 uint64_t ma, mb; band(rank, k, ma, mb);
                 const uint64_t wc = mb - ma;                              // my columns of this band
-                // rows -> columns: block p = my rows of rank p's band columns, packed; what arrives from p is rows [p nLoc, (p + 1) nLoc) of mine
                 uint64_t o = 0;
                 for (int p_ = 0; p_ < world; p_++) {
                     uint64_t a, b; band(p_, k, a, b);
-                    uint64_t* blk = pack + o;
+                    uint64_t* blk = B.pack + o;
                     spc[p_] = blk; sw[p_] = nLoc * (b - a);
                     if (b > a) XLP_CHECK(xlp_dev_copy_cols(blk, b - a, section(sn) + a, W, nLoc, (uint32_t)(b - a)));
                     o += sw[p_];
-                    rp[p_] = colb + (uint64_t)p_ * nLoc * wc; rw[p_] = nLoc * wc;
+                    rp[p_] = B.colb + (uint64_t)p_ * nLoc * wc; rw[p_] = nLoc * wc;
                 }
-                XLP_CHECK(xlp_comm_exchange(rp.data(), rw.data(), spc.data(), sw.data()));
-                if (wc) XLP_CHECK(xlp_dev_extend(extb, colb, NExtended, N, wc, NULL));
-                // columns -> rows: the rows destined to rank p are contiguous in extb; what arrives from p is its band columns of my rows
-                o = 0;
+                XLP_CHECK(xlp_comm_exchange(rp.data(), rw.data(), spc.data(), sw.data(), nLoc * widest(k)));
+                XLP_CHECK(xlp_stream_mark(1, M_FRONT + (int)(k & 1)));
+            };
+            // stream 1: columns -> rows.  The rows destined to rank p are contiguous in extb; what arrives from p is its band columns of my rows
+            auto back = [&](uint64_t k) {
+                Set& B = S[k & 1];
+                XLP_CHECK(xlp_stream_wait_mark(1, M_EXT + (int)(k & 1)));
+                uint64_t ma, mb; band(rank, k, ma, mb);
+                const uint64_t wc = mb - ma;
+                uint64_t o = 0;
                 for (int p_ = 0; p_ < world; p_++) {
                     uint64_t a, b; band(p_, k, a, b);
-                    spc[p_] = extb + (uint64_t)p_ * neLoc * wc; sw[p_] = neLoc * wc;
-                    rp[p_] = rowb + o; rw[p_] = neLoc * (b - a);
+                    spc[p_] = B.extb + (uint64_t)p_ * neLoc * wc; sw[p_] = neLoc * wc;
+                    rp[p_] = B.rowb + o; rw[p_] = neLoc * (b - a);
                     o += rw[p_];
                 }
-                XLP_CHECK(xlp_comm_exchange(rp.data(), rw.data(), spc.data(), sw.data()));
+                XLP_CHECK(xlp_comm_exchange(rp.data(), rw.data(), spc.data(), sw.data(), neLoc * widest(k)));
                 for (int p_ = 0; p_ < world; p_++) {
                     uint64_t a, b; band(p_, k, a, b);
                     if (b > a) XLP_CHECK(xlp_dev_copy_cols(section(s2) + a, W, rp[p_], b - a, neLoc, (uint32_t)(b - a)));
                 }
+                XLP_CHECK(xlp_stream_mark(1, M_BACK + (int)(k & 1)));
+            };
+            XLP_CHECK(xlp_stream_wait(1, 0));                             // the section is what stream 0 has made of it so far
+            XLP_CHECK(xlp_stream_select(1));
+            if (h_src) { XLP_CHECK(xlp_dev_upload_begin()); upload(0); }
+            front(0);
+            for (uint64_t k = 0; k < nb; k++) {
+                uint64_t ma, mb; band(rank, k, ma, mb);
+                XLP_CHECK(xlp_stream_select(0));
+                XLP_CHECK(xlp_stream_wait_mark(0, M_FRONT + (int)(k & 1)));               // my columns of band k have arrived
+                if (k >= 2) XLP_CHECK(xlp_stream_wait_mark(0, M_BACK + (int)(k & 1)));    // band k - 2's extended columns have left this set
+                if (mb > ma) XLP_CHECK(xlp_dev_extend(S[k & 1].extb, S[k & 1].colb, NExtended, N, mb - ma, NULL));
+                XLP_CHECK(xlp_stream_mark(0, M_EXT + (int)(k & 1)));
+                XLP_CHECK(xlp_stream_select(1));
+                if (k + 1 < nb) front(k + 1);
+                back(k);
             }
+            XLP_CHECK(xlp_stream_select(0));
+            XLP_CHECK(xlp_stream_wait(0, 1));
         }
         tree->merkelize();                                    // my sub-tree + the cap
         fillHalo(s2);
@@ -376,6 +422,8 @@ private:
     void genProofSharded(typename H::Proof& proof, Goldilocks::Element* publicInputs, Goldilocks::Element verkey[4], Steps* steps)
     {
         lastTimers.clear();
+        lastExchanges.clear();
+        XLP_CHECK(xlp_comm_stats(&commSeconds, &commBytes, &commCalls, 0));
         if (XlpDeviceSlab::get().reserve(slabWords) == NULL) xlp_exit_process("Starks: no device slab");
         const eSection secs2ns[4] = {cm1_2ns, cm2_2ns, cm3_2ns, cm4_2ns};
         for (int i = 0; i < 4; i++) treesGL[i]->d_source = section(secs2ns[i]);
@@ -592,6 +640,7 @@ public:
         : config(config), starkInfo(starkFiles.zkevmStarkInfo), nrowsStepBatch(1), starkFiles(starkFiles), N(0), NExtended(0), extendBits(0), pAddress(_pAddress)
     {
         if (!config.generateProof()) return;      // starks.hpp:91-93: nothing is initialised if no proof will be generated
+        residentConstants = config.xlpResidentConstants;
         N = 1ULL << starkInfo.starkStruct.nBits;
         NExtended = 1ULL << starkInfo.starkStruct.nBitsExt;
         extendBits = starkInfo.starkStruct.nBitsExt - starkInfo.starkStruct.nBits;
@@ -610,6 +659,8 @@ public:
             nLoc = N / world; neLoc = NExtended / world; haloN = starkInfo.xlpHaloN; haloExt = starkInfo.xlpHaloExt;
             row0 = (uint64_t)rank * nLoc; ext0 = (uint64_t)rank * neLoc;
             if (nLoc < haloN || haloExt != (haloN << extendBits)) xlp_exit_process("Starks: shard smaller than its halo");
+            // the sharded calculateZ scans one row past the rank's last and reads its total there: that row must be a halo row of the window
+            if (haloN < 1 && (starkInfo.puCtx.size() || starkInfo.peCtx.size() || starkInfo.ciCtx.size())) xlp_exit_process("Starks: a window starkinfo with grand products needs a halo of at least one row");
         }
         // ---- constant polynomials (LOAD_CONST_POLS_TO_MEMORY, starks.hpp:96-115); sharded: replicated, the programs read a window of them
         if (starkFiles.zkevmConstPols.size() == 0) xlp_exit_process("Starks::Starks() received an empty config.zkevmConstPols");
@@ -676,7 +727,7 @@ public:
         if (sharded) {                                    // the staging scratch of the sharded commits, once, for the section that needs most
             uint64_t need = 0, nb, bt, wm;                // (growing it between sections costs a free + malloc of tens of GB: 1 s at 2^20 rows)
             const eSection cs[3] = {cm1_n, cm2_n, cm3_n};
-            for (eSection c_ : cs) if (starkInfo.mapSectionsN.section[c_]) need = std::max(need, commitBandPlan(starkInfo.mapSectionsN.section[c_], nb, bt, wm));
+            for (eSection c_ : cs) if (starkInfo.mapSectionsN.section[c_]) need = std::max(need, 2 * commitBandPlan(starkInfo.mapSectionsN.section[c_], nb, bt, wm, c_ == cm1_n ? 4 : 1));
             shardScratch(need);
         }
         for (int i = 0; i < 4; i++) {

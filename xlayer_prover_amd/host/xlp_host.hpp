@@ -45,6 +45,7 @@
 inline void xlp_exit_process(const char* what)
 {
     fprintf(stderr, "xlp_gl error in %s: %s\n", what, xlp_last_error());
+    xlp_comm_abort(what);                          // one rank of a row-sharded proof giving up ends the others (no-op otherwise)
     exit(-1);
 }
 #define XLP_CHECK(call)                         \

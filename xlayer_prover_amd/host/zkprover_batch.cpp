@@ -152,8 +152,15 @@ int main(int argc, char** argv)
         if (world) {
             double sec = 0; uint64_t bytes = 0, calls = 0;
             XLP_CHECK(xlp_comm_stats(&sec, &bytes, &calls, 0));
-            os << "},\"sharded\":{\"world\":" << world << ",\"backend\":\"" << (backend.empty() ? "self" : backend) << "\",\"exchanges\":" << calls << ",\"GB_sent_to_peers_rank0\":" << bytes / 1e9
-               << ",\"exchange_s_rank0\":" << sec;
+            os << "},\"sharded\":{\"world\":" << world << ",\"ranks_seen\":" << xlp_comm_ranks_seen() << ",\"backend\":\"" << (backend.empty() ? "self" : backend)
+               << "\",\"same_zkevm_proof_on_all_ranks\":" << (req.zkevmProofSameOnAllRanks == 1 ? "true" : req.zkevmProofSameOnAllRanks == 0 ? "false" : "null")
+               << ",\"exchanges\":" << calls << ",\"GB_sent_to_peers_rank0\":" << bytes / 1e9 << ",\"exchange_s_rank0\":" << sec << ",\"exchange_by_stage_rank0\":{";
+            for (size_t i = 0; i < req.exchanges.size(); i++) {
+                const auto& e = req.exchanges[i];
+                os << (i ? "," : "") << "\"" << e.stage << "\":{\"calls\":" << e.calls << ",\"GB_sent\":" << e.GB << ",\"exchange_s\":" << e.seconds
+                   << ",\"GBps_sent\":" << (e.seconds > 0 ? e.GB / e.seconds : 0.0) << "}";
+            }
+            os << "}";
         }
         os << "},\"three_starks_s\":" << starks << ",\"executor_standin_s\":" << exec << ",\"witness_standins_s\":" << wit << ",\"zkevm_witness_upload_ms\":" << req.witnessUploadMs;
         const std::string& z = req.batchProofOutput;
