@@ -296,7 +296,9 @@ def genproof_leg(timeout_s=300):
                            "exposed_s_when_pipelined": round(pip["three_starks_s"] - (seq["three_starks_s"] - up), 4)},
         "same_proof_both_ways": pip["batch_proof_fnv"] == seq["batch_proof_fnv"],
         "zkevm": {"log_n": 23, "wall_s": round(t["STARK_PROOF_BATCH_PROOF"], 4),
-                  "stages_s": {"step1_upload_lde_merkle": grp(lambda k: "STEP_1" in k), "lde_merkle_2_3": grp(lambda k: k in ("STARK_STEP_2_LDE_AND_MERKLETREE", "STARK_STEP_3_LDE_AND_MERKLETREE")),
+                  "stages_s": {"step1_upload_lde_merkle": grp(lambda k: k in ("STARK_STEP_1_LDE_AND_MERKLETREE", "STARK_STEP_1_WITNESS_UPLOAD")), "lde_merkle_2_3": grp(lambda k: k in ("STARK_STEP_2_LDE_AND_MERKLETREE", "STARK_STEP_3_LDE_AND_MERKLETREE")),
+                               "lde_kernels_1_2_3": grp(lambda k: k in ("STARK_STEP_1_LDE", "STARK_STEP_2_LDE", "STARK_STEP_3_LDE")),
+                               "merkle_kernels_1_2_3": grp(lambda k: k in ("STARK_STEP_1_MERKLETREE", "STARK_STEP_2_MERKLETREE", "STARK_STEP_3_MERKLETREE")),
                                "const_lde": grp(lambda k: "CONST_LDE" in k), "merkle_4": grp(lambda k: k == "STARK_STEP_4_MERKLETREE"),
                                "step_programs": grp(lambda k: "CALCULATE_EXPS" in k and "INTT" not in k),
                                "h1h2_z": grp(lambda k: "H1H2" in k or k.endswith("_Z")), "evmap_lev_xdiv": grp(lambda k: "STEP_5" in k and "EXPS" not in k),
@@ -612,7 +614,10 @@ def main():
         except Exception as e:                               # reported, never fatal for the headline line
             sharded = {"error": repr(e)[:300]}
         src = out = None
-    bp_log_n = args.sharded_batchproof if args.sharded_batchproof >= 0 else (23 if world > 1 else 0)
+    # gloo = a rehearsal with the ranks SHARING one GPU: the exchange-carrying legs run at 2^20 rows (two ranks' 2^23-row windows do not fit one GPU)
+    rehearsal = args.backend == "gloo" and world > 1
+    bp_log_n = args.sharded_batchproof if args.sharded_batchproof >= 0 else ((20 if rehearsal else 23) if world > 1 else 0)
+    sc_log_n = 20 if rehearsal and args.log_n == LOG_N else args.log_n
     if world > 1 and (args.sharded_commit != 0 or gp_log_n or bp_log_n):
         src = out = None
         torch.cuda.empty_cache()
@@ -620,7 +625,7 @@ def main():
         if args.sharded_commit != 0:
             g = grant(150.0, 45.0, 150.0 if bp_log_n else 10.0)          # (leave the batch proof, the leg that matters more, its share)
             if g:
-                sharded = child_leg("bench_sharded_commit.py", ["--log-n", str(args.log_n), "--ncols", "751" if args.log_n == LOG_N else "64", "--steps", "2",
+                sharded = child_leg("bench_sharded_commit.py", ["--log-n", str(sc_log_n), "--ncols", "751" if sc_log_n == LOG_N else "64", "--steps", "2",
                                                                 "--check"], world, rank, local_rank, 29, args.backend, timeout_s=g)
             else:
                 skipped["sharded_commit"] = f"{budget.left():.0f} s left of the {args.budget:.0f} s budget"
@@ -698,6 +703,8 @@ def main():
         if sharded_bp is not None:
             line["genproof_sharded_cpp"] = sharded_bp
         if world > 1:
+            if rehearsal:
+                line["rehearsal"] = "ranks share ONE GPU, exchanges staged through the host (gloo / shm): plumbing evidence, the rates mean nothing"
             line["multi_gpu_evidence"] = ("no run of this code on more than one GPU existed when it was written (none in the build pool): ranks_seen inside "
                                           "genproof_sharded_cpp.sharded is what the transport itself counted in THIS run")
         if world == 1:

@@ -378,6 +378,10 @@ int xlp_dev_merkle_levels(uint64_t* nodes, uint64_t h);
 /* ntt.extendPol(cmX_2ns, cmX_n, ...) followed by treesGL[i]->merkelize() (starks.cpp:53-56,134-137,215-218) as one call:
  * sec_2ns (n_ext x ncols) and nodes ((2 n_ext - 1) * 4) from sec_n (n x ncols), in 64-column bands. */
 int xlp_dev_commit(uint64_t* sec_2ns, uint64_t* nodes, const uint64_t* sec_n, uint64_t n_ext, uint64_t n, uint64_t ncols);
+/* The two halves of the last xlp_dev_commit / xlp_dev_commit_from_host, which the reference times apart (TimerStart(STARK_STEP_n_LDE) and
+ * (STARK_STEP_n_MERKLETREE), starks.cpp:51-58,133-139): summed HIP-event times of the extendPol kernels and of the leaf sponge + tree
+ * levels on the compute stream (the bands interleave them).  Synchronises. */
+int xlp_dev_commit_last_times(double* lde_ms, double* merkle_ms);
 /* The witness upload of step 1 (the executor's committed polynomials, prover.cpp:435 -> starks.cpp:49-60) in column bands on the copy stream, for a
  * caller that interleaves it with stages of its own (host/starks.hpp, row-sharded commit: band k + 1 crosses PCIe while band k is exchanged and
  * extended).  begin: the copy stream waits for the work enqueued so far on the compute stream (it may still read the target).  cols_async: columns

@@ -76,6 +76,7 @@ SIGNATURES = {
     "xlp_dev_linear_hash_absorb": [_pu, _pu, _u64, _u64, _u64, _u64, C.c_int, C.c_int],
     "xlp_dev_merkle_levels": [_pu, _u64],
     "xlp_dev_commit": [_pu, _pu, _pu, _u64, _u64, _u64],
+    "xlp_dev_commit_last_times": [C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "xlp_dev_commit_from_host": [_pu, _pu, _pu, _pu, _u64, _u64, _u64, C.POINTER(C.c_double)],
     "xlp_cache_enable": [C.c_size_t],
     "xlp_cache_invalidate": [_pu, C.c_size_t],

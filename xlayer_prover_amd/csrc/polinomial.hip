@@ -741,7 +741,7 @@ int dev_dot_columns(Ctx* ctx, u64* out, const xlp_dot_entry* entries, u64 nentri
         const u64* w0 = e[i].pol;
         size_t j = i;
         u32 ncols = 0, n3 = 0, n1[4] = {0, 0, 0, 0};
-        auto stream_len = [&](const u32* c1, u32 c3) { u32 r = 3 * c3; for (u32 g = 0; g < 4; g++) r += (c1[g] + DC_IB - 1) / DC_IB * DC_IB; return r; };
+        auto stream_len = [&](const u32* c1, u32 c3) { u32 r = (3 * c3 + DC_IB - 1) / DC_IB * DC_IB; for (u32 g = 0; g < 4; g++) r += (c1[g] + DC_IB - 1) / DC_IB * DC_IB; return r; };
         while (j < e.size() && e[j].row_stride == e[i].row_stride && (u64)(e[j].pol - w0) + e[j].dim <= (u64)DC_CB &&
                (u64)(e[j].pol - w0) + e[j].dim <= e[i].row_stride) {
             u32 t1[4] = {n1[0], n1[1], n1[2], n1[3]}, t3 = n3;
@@ -752,7 +752,8 @@ int dev_dot_columns(Ctx* ctx, u64* out, const xlp_dot_entry* entries, u64 nentri
             ncols = std::max<u32>(ncols, (u32)(e[j].pol - w0) + e[j].dim);
             j++;
         }
-        u32 padded[4], nrec = 3 * n3;
+        // every stream is a whole number of batches, the dimension-3 tail included: the streams start at comp * nrec and are read as 16-byte vectors
+        u32 padded[4], nrec = (3 * n3 + DC_IB - 1) / DC_IB * DC_IB;
         for (u32 g = 0; g < 4; g++) { padded[g] = (n1[g] + DC_IB - 1) / DC_IB * DC_IB; nrec += padded[g]; }
         const u64 base = (u64)(uintptr_t)w0, stride = e[i].row_stride;
         const u64 counts = (u64)padded[0] | ((u64)padded[1] << 12) | ((u64)padded[2] << 24) | ((u64)padded[3] << 36) | ((u64)n3 << 48);
@@ -769,6 +770,7 @@ int dev_dot_columns(Ctx* ctx, u64* out, const xlp_dot_entry* entries, u64 nentri
             for (size_t k = i; k < j; k++)
                 if (e[k].dim == 3)
                     for (u32 word = 0; word < 3; word++) plan.push_back({(u32)(e[k].pol - w0) * DC_COLB, (u32)e[k].coef, word | (e[k].group << 24), 0xFFFFFFFFu});
+            for (u32 put = 3 * n3; put % DC_IB; put++) plan.push_back({0, 0, 0, 0});   // (never read: the kernel walks n3 items)
         }
         nwindows++;
         i = j;

@@ -154,6 +154,7 @@ void* cache_take(const void* host, size_t bytes)
 }  // namespace xlp
 
 using namespace xlp;
+static void commit_times_clear();
 
 #define H2D(buf, host, bytes) do { if (xlp_copy_h2d((buf).p, (host), (bytes))) return -1; } while (0)
 #define D2H(host, buf, bytes) do { if (xlp_copy_d2h((host), (buf).p, (bytes))) return -1; } while (0)
@@ -273,6 +274,7 @@ void xlp_shutdown(void)
     }
     if (g_ctx.selected != 0) { g_ctx.stream = g_ctx.main_stream; g_ctx.selected = 0; }
     for (int i = 0; i < 8; i++) { if (g_marks[i]) (void)hipEventDestroy(g_marks[i]); g_marks[i] = nullptr; g_marked[i] = false; }
+    commit_times_clear();
     if (g_ctx.side_stream) { (void)hipStreamSynchronize(g_ctx.side_stream); (void)hipStreamDestroy(g_ctx.side_stream); g_ctx.side_stream = nullptr; }
     if (g_ctx.own_stream) (void)hipStreamDestroy(g_ctx.stream);
     if (g_ctx.copy_stream) { (void)hipStreamSynchronize(g_ctx.copy_stream); (void)hipStreamDestroy(g_ctx.copy_stream); g_ctx.copy_stream = nullptr; }
@@ -592,8 +594,31 @@ int xlp_dev_merkle_levels(uint64_t* nodes, uint64_t h)
 // extendPol + merkelize of one section, band by band (starks.cpp:53-60 / :134-141 / :215-222 as ONE pipeline): the leaf sponge of
 // a row absorbs its columns in order, so a band of columns can be hashed into the 4-word leaf state as soon as it is extended.
 // With h_src the bands are first uploaded on the copy stream -- band b+1 crosses PCIe while band b is extended and absorbed.
+// the reference times the two halves of a commit apart (TimerStart(STARK_STEP_n_LDE) / (STARK_STEP_n_MERKLETREE), starks.cpp:51-58,133-139);
+// here the bands interleave them, so each half is the sum of its kernels' event times on the compute stream (xlp_dev_commit_last_times)
+struct CommitTimes {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> lde, merkle;
+    void clear()
+    {
+        for (auto* v : {&lde, &merkle}) { for (auto& pr : *v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); } v->clear(); }
+    }
+    int begin(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, hipStream_t st)
+    {
+        hipEvent_t a = nullptr, b = nullptr;
+        XLP_HIP(hipEventCreate(&a)); XLP_HIP(hipEventCreate(&b));
+        v.emplace_back(a, b);
+        XLP_HIP(hipEventRecord(a, st));
+        return 0;
+    }
+    int end(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, hipStream_t st) { XLP_HIP(hipEventRecord(v.back().second, st)); return 0; }
+};
+static CommitTimes g_commit_times;
+static void commit_times_clear() { g_commit_times.clear(); }
+
 static int commit_bands(uint64_t* sec_n, uint64_t* sec_2ns, uint64_t* nodes, const uint64_t* h_src, uint64_t n_ext, uint64_t n, uint64_t ncols, double* upload_ms)
 {
+    CommitTimes& T = g_commit_times;
+    T.clear();
     if (upload_ms) *upload_ms = 0.0;
     if (n == 0 || n_ext == 0) return 0;
     if ((n & (n - 1)) || (n_ext & (n_ext - 1)) || n_ext < n) return xlp_fail("commit: sizes must be powers of two, n_ext >= n");
@@ -604,8 +629,11 @@ static int commit_bands(uint64_t* sec_n, uint64_t* sec_2ns, uint64_t* nodes, con
         if (h_src && ncols) {
             XLP_HIP(hipMemcpyAsync(sec_n, h_src, n * ncols * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
         }
-        if (ncols && dev_extend(ctx, sec_2ns, sec_n, n_ext, n, ncols, nullptr)) return -1;
-        return dev_merkle(ctx, nodes, sec_2ns, ncols, n_ext);
+        if (ncols) {
+            if (T.begin(T.lde, ctx->stream) || dev_extend(ctx, sec_2ns, sec_n, n_ext, n, ncols, nullptr) || T.end(T.lde, ctx->stream)) return -1;
+        }
+        if (T.begin(T.merkle, ctx->stream) || dev_merkle(ctx, nodes, sec_2ns, ncols, n_ext) || T.end(T.merkle, ctx->stream)) return -1;
+        return 0;
     }
     // Band plan.  From device memory: uniform bands.  From the host (step 1) the copy stream and the extension + hashing run at nearly the
     // same rate per column (PCIe 1.2-1.4 ms, compute 1.1 ms per column of 2^23 rows); the DMA engine moves wide row pieces faster (2 KB
@@ -652,16 +680,36 @@ static int commit_bands(uint64_t* sec_n, uint64_t* sec_2ns, uint64_t* nodes, con
     for (u64 b = 0; b < nb; b++) {
         const u64 c0 = starts[b], wc = widths[b];
         if (h_src) XLP_HIP(hipStreamWaitEvent(ctx->stream, ev[b], 0));
-        if (dev_extend_cols(ctx, sec_2ns, sec_n, n_ext, n, ncols, c0, wc)) return -1;
-        if (dev_linear_hash_absorb(ctx, nodes, sec_2ns, ncols, c0, wc, n_ext, b == 0, b == nb - 1)) return -1;
+        if (T.begin(T.lde, ctx->stream) || dev_extend_cols(ctx, sec_2ns, sec_n, n_ext, n, ncols, c0, wc) || T.end(T.lde, ctx->stream)) return -1;
+        if (T.begin(T.merkle, ctx->stream) || dev_linear_hash_absorb(ctx, nodes, sec_2ns, ncols, c0, wc, n_ext, b == 0, b == nb - 1)) return -1;
+        if (b == nb - 1 && dev_merkle_levels(ctx, nodes, n_ext)) return -1;
+        if (T.end(T.merkle, ctx->stream)) return -1;
     }
-    if (dev_merkle_levels(ctx, nodes, n_ext)) return -1;
     if (t0) {
         float ms = 0.f;
         XLP_HIP(hipEventSynchronize(t1));
         XLP_HIP(hipEventElapsedTime(&ms, t0, t1));
         *upload_ms = ms;
     }
+    return 0;
+}
+int xlp_dev_commit_last_times(double* lde_ms, double* merkle_ms)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    double sum[2] = {0.0, 0.0};
+    int k = 0;
+    for (auto* v : {&g_commit_times.lde, &g_commit_times.merkle}) {
+        for (auto& pr : *v) {
+            float ms = 0.f;
+            XLP_HIP(hipEventSynchronize(pr.second));
+            XLP_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+            sum[k] += ms;
+        }
+        k++;
+    }
+    if (lde_ms) *lde_ms = sum[0];
+    if (merkle_ms) *merkle_ms = sum[1];
     return 0;
 }
 int xlp_dev_commit_from_host(uint64_t* sec_n, uint64_t* sec_2ns, uint64_t* nodes, const uint64_t* h_src, uint64_t n_ext, uint64_t n, uint64_t ncols, double* upload_ms)

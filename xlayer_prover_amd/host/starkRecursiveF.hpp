@@ -175,6 +175,7 @@ struct XlpHashBN128
     typedef FRIProofC12 Proof;
     typedef FRIProveC12 Prove;
     typedef RawFr::Element Root[1];
+    static constexpr bool kCommitTimes = false;
     static constexpr bool kShardable = false;        // the 16-ary BN128 tree has no row-sharded form here (recursivef is 2^17 rows: one GPU)
     static constexpr bool kFileTree = true;          // recursivef.consttree as bctree (verificationHashType BN128) writes it: [width, height, source, nodes]
     static uint64_t treeWords(Tree* t) { return t->numNodes * 4; }
