@@ -261,9 +261,29 @@ typedef struct xlp_steps_params {       /* StepsParams, steps.hpp:4-19; all devi
     const uint64_t* x_div_x_sub_wxi; uint64_t x_div_x_sub_wxi_size;
     uint64_t* q_2ns;                uint64_t q_2ns_size;
     uint64_t* f_2ns;                uint64_t f_2ns_size;
+    /* column-major programs on the extended domain only (XLP_EXPR_COLMAJOR below; 0 otherwise): rows per coset, and the distance in rows
+     * between the cosets of a column (0 = coset_rows; larger when every coset block is followed by halo rows: a rank's window) */
+    uint64_t coset_rows;            uint64_t coset_stride;
 } xlp_steps_params;
 typedef struct xlp_expr_program xlp_expr_program;
 int xlp_expr_create(xlp_expr_program** out, const uint64_t* code, uint64_t ncode, uint64_t ntmp1, uint64_t ntmp3);
+/* COLUMN-MAJOR BUFFERS (flags = XLP_EXPR_COLMAJOR).  The reference's slab is row-major (stark_info.cpp:473-482) because its interpreters walk a
+ * row at a time; here a LANE is a row, so a column stored contiguously is read and written coalesced as it is and nothing has to be staged.
+ * A program created with this flag addresses
+ *   XLP_K_POLS        offset, cstride            pols[offset + c * cstride + i]                  (cstride = words between the columns of a section)
+ *   XLP_K_POLS_PRIME  offset, next, n, cstride   pols[offset + c * cstride + wrap(i + next)],    wrap(j) = j - cbase >= n ? j - n : j
+ *   XLP_K_CONST col / _PRIME / CONST2NS ...      const_pols[col * (const_pols_size / n_const_pols) + i]   (and with wrap(i + next))
+ * where i is the STORAGE row.  The extended domain is stored COSET-MAJOR: natural row k = (q << extendBits) | r sits at storage row
+ * r * coset_stride + q (xlp_steps_params: coset_rows = the domain's rows per coset, coset_stride >= coset_rows), so an extended column is the
+ * 2^extendBits cosets of the base domain one after the other -- what extendPol produces coset by coset, what evmap reads (coset 0), and what makes
+ * a next-row operand (next = 1 after the conversion, n = the base domain) the neighbouring word.  xlp_dev_expr_run(prog, params, row0, nrows)
+ * then takes row0 / nrows as dense coset-major indices and launches coset by coset (cbase = r * coset_stride); within coset r
+ *   XLP_K_ZI = zi[r];  XLP_K_X_2NS / XDIVXSUB* = table[i - r * (coset_stride - coset_rows)] (tables dense, coset-major);
+ *   XLP_K_Q_2NS / XLP_K_F_2NS = q_2ns[3 * (((i - cbase) << extendBits) | r) + c]: these two stay row-major in NATURAL order (3 words per row: the
+ *   INTT of the quotient and FRI read them).
+ * Base-domain programs: coset_rows = 0, one coset, cbase = 0.  tools/zkevm_geometry.py to_colmajor converts a program. */
+#define XLP_EXPR_COLMAJOR 1ULL
+int xlp_expr_create_ex(xlp_expr_program** out, const uint64_t* code, uint64_t ncode, uint64_t ntmp1, uint64_t ntmp3, uint64_t flags);
 int xlp_expr_destroy(xlp_expr_program* prog);
 /* Ahead-of-time path (the counterpart of the reference's generated straight-line chelpers,
  * src/starkpil/zkevm/chelpers/zkevm.chelpers.step3prev.cpp): write the program as HIP source (segments of
@@ -397,6 +417,42 @@ int xlp_dev_upload_fence(void);
  * NULL) receives the time the copy stream was busy; asking for it synchronises. */
 int xlp_dev_commit_from_host(uint64_t* sec_n, uint64_t* sec_2ns, uint64_t* nodes, const uint64_t* h_src, uint64_t n_ext, uint64_t n, uint64_t ncols,
                              double* upload_ms);
+/* ---- column-major sections (device pointers) ------------------------------------------------------------------------------------------
+ * The reference's slab is row-major (stark_info.cpp:473-482: element (row, col) of a section at row * width + col) because its loops walk a
+ * row at a time.  On the GPU a lane is a row, and a section stored as COLUMNS is read and written coalesced by every stage of
+ * Starks::genProof: the step programs need no staging copy (XLP_EXPR_COLMAJOR above), extendPol moves whole lines, the leaf sponge reads
+ * 512 contiguous bytes per wave and word.  These entry points are the stages of the commit path on that layout; host/starks.hpp uses them
+ * when the starkinfo says "xlp": {"colMajor": true}.  The row-major form stays at the host boundary: the witness is transposed band by band as
+ * it arrives over PCIe, opened rows are gathered.
+ *   layout: column c of a section = `rows` consecutive words at base + c * cstride.  Base-domain sections: natural row order.  Extended
+ *   sections: COSET-MAJOR -- natural row k = (q << ext_bits) | r at storage row r * coset_stride + q (coset_stride = 0 means rows >> ext_bits):
+ *   the 2^ext_bits cosets of the base domain one after the other, which is how extendPol produces them and how evmap (coset 0) and the
+ *   next-row operands (the neighbouring word) read them.
+ *   xlp_dev_rows_to_cm / xlp_dev_cm_to_rows   columns [col0, col0 + ncols) of a row-major matrix (row stride ld, natural order, `rows` rows)
+ *                                             <-> ncols columns of the other form (dst / src = the first of them)
+ *   xlp_dev_copy_view                          dst[i * drs + c * dcs] = src[i * srs + c * scs], i < n, c < dim: a Polinomial view
+ *                                             (polinomial.hpp:24-40) of either layout copied into the other (the dense ext-3 operands of
+ *                                             calculateZ / calculateH1H2)
+ *   xlp_dev_extend_cm                          extendPol (starks.cpp:53,134,215): in = ncols columns of n rows, out = ncols columns of n_ext rows
+ *                                             coset-major.  2^17 <= n <= 2^23, blow-up <= 8: three kernels working on whole lines of both
+ *   xlp_dev_linear_hash_absorb_cm / _merkle_cm the leaf sponge / whole tree (merkleTreeGL.cpp:37-44) over a coset-major section; leaves and nodes in
+ *                                             NATURAL row order (the buffer of xlp_dev_merkle)
+ *   xlp_dev_merkle_proofs_cm                   xlp_dev_merkle_proofs with the opened rows gathered from the columns
+ *   xlp_dev_commit_cm / _commit_from_host_cm   xlp_dev_commit / _commit_from_host: bands of columns; the host form uploads each band as a dense
+ *                                             row-major [n][band] matrix into `stage` (>= n * ncols words of dead device memory) and transposes
+ *                                             it into its columns ahead of its extension */
+int xlp_dev_rows_to_cm(uint64_t* dst, uint64_t dst_cstride, uint64_t dst_coset_stride, const uint64_t* src, uint64_t ld, uint64_t col0, uint64_t ncols, uint64_t rows, uint32_t ext_bits);
+int xlp_dev_cm_to_rows(uint64_t* dst, uint64_t ld, uint64_t col0, const uint64_t* src, uint64_t src_cstride, uint64_t src_coset_stride, uint64_t ncols, uint64_t rows, uint32_t ext_bits);
+int xlp_dev_copy_view(uint64_t* dst, uint64_t dst_row_stride, uint64_t dst_comp_stride, const uint64_t* src, uint64_t src_row_stride, uint64_t src_comp_stride, uint64_t n, uint32_t dim);
+int xlp_dev_extend_cm(uint64_t* out, uint64_t out_cstride, uint64_t out_coset_stride, const uint64_t* in, uint64_t in_cstride, uint64_t n_ext, uint64_t n, uint64_t ncols);
+int xlp_dev_linear_hash_absorb_cm(uint64_t* state, const uint64_t* src, uint64_t cstride, uint64_t coset_stride, uint64_t col0, uint64_t ncols, uint64_t h, uint32_t ext_bits, int first, int last);
+int xlp_dev_merkle_cm(uint64_t* nodes, const uint64_t* src, uint64_t cstride, uint64_t coset_stride, uint64_t w, uint64_t h, uint32_t ext_bits);
+int xlp_dev_merkle_proofs_cm(uint64_t* out, const uint64_t* src, uint64_t cstride, uint64_t coset_stride, const uint64_t* nodes, uint64_t w, uint64_t h, uint32_t ext_bits,
+                             const uint64_t* idxs, uint64_t nq);
+int xlp_dev_commit_cm(uint64_t* sec_2ns, uint64_t cs2, uint64_t* nodes, const uint64_t* sec_n, uint64_t csn, uint64_t n_ext, uint64_t n, uint64_t ncols);
+int xlp_dev_commit_from_host_cm(uint64_t* sec_n, uint64_t csn, uint64_t* sec_2ns, uint64_t cs2, uint64_t* nodes, const uint64_t* h_src, uint64_t* stage, uint64_t stage_words,
+                                uint64_t n_ext, uint64_t n, uint64_t ncols, double* upload_ms);
+
 /* Page-locked host memory for the witness slab (hipHostMalloc / hipHostRegister behind a HIP-free signature). */
 int xlp_host_alloc(void** ptr, size_t bytes);
 int xlp_host_free(void* ptr);

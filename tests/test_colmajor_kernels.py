@@ -1,0 +1,132 @@
+"""Column-major device sections (include/xlp_gl.h, csrc/colmajor.hip, ntt_lde_cm.hip, poseidon.hip): every stage of the commit path on the
+column-major / coset-major layout against the oracle's row-major restatement on the same data -- the transposes, extendPol (the three
+column-major kernels and the staged fallback), the leaf sponge in bands, the tree, the openings, and the two band-pipelined commits."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def xlp():
+    import torch
+    from xlayer_prover_amd import capi
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    capi.init(0)
+    capi.use_torch_stream()
+    return capi
+
+
+def _cm(a, ext):
+    from tools import zkevm_geometry as G
+    return G.matrix_to_colmajor(a, ext)
+
+
+def _rows(flat, rows, w, ext):
+    from tools import zkevm_geometry as G
+    return G.matrix_from_colmajor(flat, rows, w, ext)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,w,ext,col0,ncols", [(64, 8, 0, 0, 8), (1 << 10, 70, 1, 3, 65), (1 << 9, 5, 3, 1, 4), (96, 130, 0, 0, 130), (1 << 12, 13, 2, 0, 13)])
+def test_transposes_between_the_two_layouts(xlp, orc, rows, w, ext, col0, ncols):
+    import torch
+    a = orc.fill(rows * w, 0x5EED0D00 + rows + w).reshape(rows, w)
+    src = xlp.from_np(a.reshape(-1))
+    dst = torch.zeros(ncols * rows, dtype=torch.int64, device="cuda")
+    xlp.dev_rows_to_cm(dst, rows, src, w, col0, ncols, rows, ext)
+    xlp.sync()
+    assert (xlp.to_np(dst) == _cm(a[:, col0:col0 + ncols], ext)).all()
+    back = torch.zeros(rows * w, dtype=torch.int64, device="cuda")
+    xlp.dev_cm_to_rows(back, w, col0, dst, rows, ncols, rows, ext)
+    xlp.sync()
+    exp = np.zeros_like(a); exp[:, col0:col0 + ncols] = a[:, col0:col0 + ncols]
+    assert (xlp.to_np(back).reshape(rows, w) == exp).all()
+
+
+@pytest.mark.gpu
+def test_copy_view_between_layouts(xlp, orc):
+    import torch
+    n = 1000
+    a = orc.fill(n * 7, 0x5EED0D10).reshape(n, 7)                       # row-major section of width 7: the ext-3 polynomial at columns 2..4
+    cm = xlp.from_np(_cm(a, 0))
+    dense = torch.zeros(n * 3, dtype=torch.int64, device="cuda")
+    xlp.dev_copy_view(dense, 3, 1, cm, 1, n, n, 3, src_off=2 * n)       # column-major view (row stride 1, component stride n) -> dense [n][3]
+    xlp.sync()
+    assert (xlp.to_np(dense).reshape(n, 3) == a[:, 2:5]).all()
+    back = torch.zeros(n * 7, dtype=torch.int64, device="cuda")
+    xlp.dev_copy_view(back, 1, n, dense, 3, 1, n, 3, dst_off=4 * n)
+    xlp.sync()
+    assert (_rows(xlp.to_np(back), n, 7, 0)[:, 4:7] == a[:, 2:5]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lg,ext,w", [(4, 1, 3), (10, 1, 9), (12, 2, 5), (17, 1, 5), (17, 3, 2), (18, 2, 9), (19, 1, 33), (20, 1, 3), (13, 4, 4)])
+def test_extend_cm_equals_oracle(xlp, orc, lg, ext, w):
+    """2^17.. rows with blow-up <= 8: the three column-major kernels; the others: the staged fallback"""
+    import torch
+    n, ne = 1 << lg, 1 << (lg + ext)
+    a = orc.fill(n * w, 0x5EED0D20 + lg).reshape(n, w)
+    a[0, 0] = 0xFFFFFFFFFFFFFFFF; a[1 % n, 0] = 0xFFFFFFFF00000001                       # non-canonical words
+    exp = orc.extend_pol(a, ne, n, w)
+    src = xlp.from_np(_cm(a, 0))
+    out = torch.zeros(ne * w, dtype=torch.int64, device="cuda")
+    xlp.dev_extend_cm(out, ne, src, n, ne, n, w)
+    xlp.sync()
+    got = _rows(xlp.to_np(out), ne, w, ext)
+    assert (got == exp).all(), np.argwhere(got != exp)[:5]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lg,ext,w", [(8, 1, 751), (10, 2, 20), (9, 1, 4), (9, 1, 3), (7, 3, 9), (6, 0, 16), (9, 1, 0)])
+def test_merkle_cm_equals_oracle_and_openings(xlp, orc, lg, ext, w):
+    import torch
+    h = 1 << (lg + ext)
+    a = orc.fill(h * w, 0x5EED0D30 + w).reshape(h, w)
+    exp = orc.merkletree(a, w, h)
+    src = xlp.from_np(_cm(a, ext)) if w else torch.zeros(1, dtype=torch.int64, device="cuda")
+    nodes = torch.zeros((2 * h - 1) * 4, dtype=torch.int64, device="cuda")
+    xlp.dev_merkle_cm(nodes, src, h, w, h, ext)
+    xlp.sync()
+    assert (xlp.to_np(nodes) == exp).all()
+    if w > 8:
+        # the same leaves absorbed in three bands (the pipelined commit's shape)
+        st = torch.zeros((2 * h - 1) * 4, dtype=torch.int64, device="cuda")
+        b1, b2 = 8, (w // 16) * 8 + 8
+        xlp.dev_linear_hash_absorb_cm(st, src, h, 0, b1, h, ext, True, False)
+        xlp.dev_linear_hash_absorb_cm(st, src, h, b1, b2 - b1, h, ext, False, b2 == w)
+        if b2 < w:
+            xlp.dev_linear_hash_absorb_cm(st, src, h, b2, w - b2, h, ext, False, True)
+        xlp.sync()
+        assert (xlp.to_np(st)[:4 * h] == exp[:4 * h]).all()
+    if w:
+        idxs = [0, 1, h - 1, h // 2 + 1, 5 % h]
+        got = xlp.dev_merkle_proofs_cm(src, h, nodes, w, h, ext, idxs)
+        ref = xlp.dev_merkle_proofs(xlp.from_np(a.reshape(-1)), nodes, w, h, idxs)
+        assert (got == ref).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lg,ext,w,from_host", [(10, 1, 751, True), (10, 1, 168, False), (11, 2, 78, True), (9, 1, 4, True), (9, 1, 70, True), (17, 1, 130, True), (17, 1, 70, False)])
+def test_commit_cm_equals_oracle(xlp, orc, lg, ext, w, from_host):
+    import torch
+    n, ne = 1 << lg, 1 << (lg + ext)
+    a = orc.fill(n * w, 0x5EED0D40 + w + lg).reshape(n, w)
+    e = orc.extend_pol(a, ne, n, w)
+    exp_nodes = orc.merkletree(e, w, ne)
+    sec_n = torch.zeros(n * w, dtype=torch.int64, device="cuda")
+    sec_2 = torch.zeros(ne * w, dtype=torch.int64, device="cuda")
+    nodes = torch.zeros((2 * ne - 1) * 4, dtype=torch.int64, device="cuda")
+    if from_host:
+        stage = torch.zeros(n * w, dtype=torch.int64, device="cuda")
+        xlp.dev_commit_from_host_cm(sec_n, n, sec_2, ne, nodes, np.ascontiguousarray(a.reshape(-1)), stage, ne, n, w)
+        xlp.sync()
+        assert (_rows(xlp.to_np(sec_n), n, w, 0) == a).all()
+    else:
+        sec_n = xlp.from_np(_cm(a, 0))
+        xlp.dev_commit_cm(sec_2, ne, nodes, sec_n, n, ne, n, w)
+        xlp.sync()
+    assert (_rows(xlp.to_np(sec_2), ne, w, ext) == e).all()
+    assert (xlp.to_np(nodes) == exp_nodes).all()
+    import ctypes as C
+    l, m = C.c_double(0), C.c_double(0)
+    assert xlp.load().xlp_dev_commit_last_times(C.byref(l), C.byref(m)) == 0 and l.value > 0 and m.value > 0

@@ -142,6 +142,93 @@ def relocate(codes, log_n, aliased=False, new_layout=None):
     return codes, info
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# COLUMN-MAJOR device sections (include/xlp_gl.h, XLP_EXPR_COLMAJOR).  The packing of the slab stays what `layout` says -- a section
+# still occupies width x rows words at its offset -- but inside a section element (row, col) sits at col * rows + s(row), where the
+# storage row s of an extended-domain row k = (q << ext) | r is r * (rows >> ext) + q (coset-major: the 2^ext cosets of the base
+# domain one after the other), and s(row) = row on the base domain.
+def to_colmajor(code, L, ext):
+    """a program addressed for the row-major layout L (section -> (offset, width, rows)) -> the same program for the column-major
+    form of L: XLP_K_POLS (offset, stride) -> (section offset + col * rows, rows); next-row operands on the extended domain step by
+    next >> ext inside a coset of n >> ext rows"""
+    secs = sorted((o, w, rows, name) for name, (o, w, rows) in L.items() if w and name != "const_2ns")
+    code = code.copy()
+
+    def move(off, stride):
+        hit = [(o, w, rows, name) for o, w, rows, name in secs if o <= off < o + w * rows and w == stride]
+        assert hit, (off, stride)
+        o, w, rows, name = hit[-1]
+        col = off - o
+        assert col < w, (name, off)
+        return o + col * rows, rows, name.endswith("_2ns")
+
+    for _, _, kind, dim, q in R.operands(code):
+        if kind == E.K_POLS:
+            code[q], code[q + 1], _ = move(int(code[q]), int(code[q + 1]))
+        elif kind == E.K_POLS_PRIME:
+            off, rows, extended = move(int(code[q]), int(code[q + 3]))
+            code[q], code[q + 3] = off, rows
+            if extended:
+                assert int(code[q + 1]) % (1 << ext) == 0 and int(code[q + 2]) % (1 << ext) == 0
+                code[q + 1] = int(code[q + 1]) >> ext; code[q + 2] = int(code[q + 2]) >> ext
+        elif kind == E.K_CONST2NS_PRIME:
+            assert int(code[q + 1]) % (1 << ext) == 0 and int(code[q + 2]) % (1 << ext) == 0
+            code[q + 1] = int(code[q + 1]) >> ext; code[q + 2] = int(code[q + 2]) >> ext
+    return code
+
+
+def dots_to_colmajor(dots, L):
+    """the (kind, offset, stride, dim, group, coef) entries of a dot-columns plan (expr_opt.horner_to_dot) for the column-major form of L:
+    offset -> the column's first word, stride -> the words between the columns of its section (constant entries keep their column index)"""
+    secs = sorted((o, w, rows, name) for name, (o, w, rows) in L.items() if w and name != "const_2ns")
+    out = []
+    for kind, off, stride, dim, group, coef in dots:
+        if kind == 0:
+            o, w, rows, name = [t for t in secs if t[0] <= off < t[0] + t[1] * t[2] and t[1] == stride][-1]
+            off, stride = o + (off - o) * rows, rows
+        out.append((kind, off, stride, dim, group, coef))
+    return out
+
+
+def rows_to_storage(a, ext):
+    """[rows][width] in natural row order -> [rows][width] in storage (coset-major) order; ext = 0: unchanged"""
+    a = np.asarray(a)
+    rows = a.shape[0]
+    return a.reshape(rows >> ext, 1 << ext, -1).transpose(1, 0, 2).reshape(rows, -1)
+
+
+def rows_from_storage(a, ext):
+    a = np.asarray(a)
+    rows = a.shape[0]
+    return a.reshape(1 << ext, rows >> ext, -1).transpose(1, 0, 2).reshape(rows, -1)
+
+
+def matrix_to_colmajor(a, ext):
+    """row-major [rows][width], natural order -> flat column-major, coset-major storage order"""
+    return np.ascontiguousarray(rows_to_storage(a, ext).T).reshape(-1)
+
+
+def matrix_from_colmajor(flat, rows, width, ext):
+    return rows_from_storage(np.asarray(flat).reshape(width, rows).T, ext)
+
+
+def slab_to_colmajor(slab, L, ext):
+    """the whole row-major slab of layout L -> its column-major form (same offsets, same size)"""
+    out = np.array(slab, copy=True)
+    for name, (o, w, rows) in L.items():
+        if w and name != "const_2ns":
+            out[o:o + w * rows] = matrix_to_colmajor(slab[o:o + w * rows].reshape(rows, w), ext if name.endswith("_2ns") else 0)
+    return out
+
+
+def slab_from_colmajor(slab, L, ext):
+    out = np.array(slab, copy=True)
+    for name, (o, w, rows) in L.items():
+        if w and name != "const_2ns":
+            out[o:o + w * rows] = matrix_from_colmajor(slab[o:o + w * rows], rows, w, ext if name.endswith("_2ns") else 0).reshape(-1)
+    return out
+
+
 STEPS = ("step2prev", "step3prev", "step3", "step42ns", "step52ns")
 
 

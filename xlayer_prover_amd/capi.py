@@ -56,6 +56,7 @@ SIGNATURES = {
     "xlp_dev_x_div_x_sub_xi": [_pu, _pu, _pu, _u64],
     "xlp_dev_calculate_h1h2": [_pu, _pu, _pu, _pu, _u64, _u32],
     "xlp_expr_create": [C.POINTER(C.c_void_p), _pu, _u64, _u64, _u64],
+    "xlp_expr_create_ex": [C.POINTER(C.c_void_p), _pu, _u64, _u64, _u64, _u64],
     "xlp_expr_destroy": [_pu],
     "xlp_expr_codegen": [_pu, C.c_char_p],
     "xlp_expr_attach": [_pu, C.c_char_p],
@@ -77,6 +78,15 @@ SIGNATURES = {
     "xlp_dev_merkle_levels": [_pu, _u64],
     "xlp_dev_commit": [_pu, _pu, _pu, _u64, _u64, _u64],
     "xlp_dev_commit_last_times": [C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    "xlp_dev_rows_to_cm": [_pu, _u64, _u64, _pu, _u64, _u64, _u64, _u64, C.c_uint32],
+    "xlp_dev_cm_to_rows": [_pu, _u64, _u64, _pu, _u64, _u64, _u64, _u64, C.c_uint32],
+    "xlp_dev_copy_view": [_pu, _u64, _u64, _pu, _u64, _u64, _u64, C.c_uint32],
+    "xlp_dev_extend_cm": [_pu, _u64, _u64, _pu, _u64, _u64, _u64, _u64],
+    "xlp_dev_linear_hash_absorb_cm": [_pu, _pu, _u64, _u64, _u64, _u64, _u64, C.c_uint32, C.c_int, C.c_int],
+    "xlp_dev_merkle_cm": [_pu, _pu, _u64, _u64, _u64, _u64, C.c_uint32],
+    "xlp_dev_merkle_proofs_cm": [_pu, _pu, _u64, _u64, _pu, _u64, _u64, C.c_uint32, _pu, _u64],
+    "xlp_dev_commit_cm": [_pu, _u64, _pu, _pu, _u64, _u64, _u64, _u64],
+    "xlp_dev_commit_from_host_cm": [_pu, _u64, _pu, _u64, _pu, _pu, _pu, _u64, _u64, _u64, _u64, C.POINTER(C.c_double)],
     "xlp_dev_commit_from_host": [_pu, _pu, _pu, _pu, _u64, _u64, _u64, C.POINTER(C.c_double)],
     "xlp_cache_enable": [C.c_size_t],
     "xlp_cache_invalidate": [_pu, C.c_size_t],
@@ -443,6 +453,56 @@ def dev_commit_from_host(sec_n, sec_2ns, nodes, host, n_ext, n, ncols, want_uplo
     return ms.value
 
 
+# ---- column-major sections (include/xlp_gl.h): tensors are flat device int64; `off` = word offset of the first column inside the tensor
+def _dpo(t, off=0):
+    return C.c_void_p(t.data_ptr() + 8 * off)
+
+
+def dev_rows_to_cm(dst, dst_cstride, src, ld, col0, ncols, rows, ext_bits=0, dst_off=0, coset_stride=0):
+    _ck(load().xlp_dev_rows_to_cm(_dpo(dst, dst_off), dst_cstride, coset_stride, _dp(src), ld, col0, ncols, rows, ext_bits), "xlp_dev_rows_to_cm")
+
+
+def dev_cm_to_rows(dst, ld, col0, src, src_cstride, ncols, rows, ext_bits=0, src_off=0, coset_stride=0):
+    _ck(load().xlp_dev_cm_to_rows(_dp(dst), ld, col0, _dpo(src, src_off), src_cstride, coset_stride, ncols, rows, ext_bits), "xlp_dev_cm_to_rows")
+
+
+def dev_copy_view(dst, drs, dcs, src, srs, scs, n, dim, dst_off=0, src_off=0):
+    _ck(load().xlp_dev_copy_view(_dpo(dst, dst_off), drs, dcs, _dpo(src, src_off), srs, scs, n, dim), "xlp_dev_copy_view")
+
+
+def dev_extend_cm(out, out_cstride, src, in_cstride, n_ext, n, ncols, out_off=0, src_off=0, out_coset_stride=0):
+    _ck(load().xlp_dev_extend_cm(_dpo(out, out_off), out_cstride, out_coset_stride, _dpo(src, src_off), in_cstride, n_ext, n, ncols), "xlp_dev_extend_cm")
+
+
+def dev_linear_hash_absorb_cm(state, src, cstride, col0, ncols, h, ext_bits, first, last, coset_stride=0):
+    _ck(load().xlp_dev_linear_hash_absorb_cm(_dp(state), _dp(src), cstride, coset_stride, col0, ncols, h, ext_bits, 1 if first else 0, 1 if last else 0), "xlp_dev_linear_hash_absorb_cm")
+
+
+def dev_merkle_cm(nodes, src, cstride, w, h, ext_bits, coset_stride=0):
+    _ck(load().xlp_dev_merkle_cm(_dp(nodes), _dp(src), cstride, coset_stride, w, h, ext_bits), "xlp_dev_merkle_cm")
+
+
+def dev_merkle_proofs_cm(src, cstride, nodes, w, h, ext_bits, idxs, coset_stride=0):
+    ix = np.ascontiguousarray(idxs, dtype=np.uint64)
+    levels = max(h.bit_length() - 1, 0)
+    out = np.zeros((ix.size, w + 4 * levels), np.uint64)
+    _ck(load().xlp_dev_merkle_proofs_cm(out.ctypes.data_as(C.c_void_p), _dp(src), cstride, coset_stride, _dp(nodes), w, h, ext_bits, ix.ctypes.data_as(C.c_void_p), ix.size),
+        "xlp_dev_merkle_proofs_cm")
+    return out
+
+
+def dev_commit_cm(sec_2ns, cs2, nodes, sec_n, csn, n_ext, n, ncols):
+    _ck(load().xlp_dev_commit_cm(_dp(sec_2ns), cs2, _dp(nodes), _dp(sec_n), csn, n_ext, n, ncols), "xlp_dev_commit_cm")
+
+
+def dev_commit_from_host_cm(sec_n, csn, sec_2ns, cs2, nodes, host, stage, n_ext, n, ncols, want_upload_ms=False):
+    ptr = host.ptr if isinstance(host, HostBuffer) else host.ctypes.data_as(C.c_void_p)
+    ms = C.c_double(0.0)
+    _ck(load().xlp_dev_commit_from_host_cm(_dp(sec_n), csn, _dp(sec_2ns), cs2, _dp(nodes), ptr, _dp(stage), stage.numel(), n_ext, n, ncols, C.byref(ms) if want_upload_ms else None),
+        "xlp_dev_commit_from_host_cm")
+    return ms.value
+
+
 class HostBuffer:
     """page-locked host memory (xlp_host_alloc); .array is a uint64 ndarray view of it"""
 
@@ -554,13 +614,15 @@ class StepsParams(C.Structure):
                 ("x_div_x_sub_xi", C.c_void_p), ("x_div_x_sub_xi_size", C.c_uint64),
                 ("x_div_x_sub_wxi", C.c_void_p), ("x_div_x_sub_wxi_size", C.c_uint64),
                 ("q_2ns", C.c_void_p), ("q_2ns_size", C.c_uint64),
-                ("f_2ns", C.c_void_p), ("f_2ns_size", C.c_uint64)]
+                ("f_2ns", C.c_void_p), ("f_2ns_size", C.c_uint64),
+                ("coset_rows", C.c_uint64), ("coset_stride", C.c_uint64)]
 
 
-def steps_params(n_const_pols=0, n_const_pols_2ns=0, **buffers):
+def steps_params(n_const_pols=0, n_const_pols_2ns=0, coset_rows=0, coset_stride=0, **buffers):
     """buffers: name -> device int64 tensor (members of xlp_steps_params); sizes are taken from the tensors"""
     sp = StepsParams()
     sp.n_const_pols, sp.n_const_pols_2ns = n_const_pols, n_const_pols_2ns
+    sp.coset_rows, sp.coset_stride = coset_rows, coset_stride
     for name, t in buffers.items():
         setattr(sp, name, t.data_ptr())
         setattr(sp, name + "_size", t.numel())
@@ -571,10 +633,11 @@ def steps_params(n_const_pols=0, n_const_pols_2ns=0, **buffers):
 class ExprProgram:
     """xlp_expr_program handle (xlp_expr_create / xlp_expr_destroy)"""
 
-    def __init__(self, code, ntmp1, ntmp3):
+    def __init__(self, code, ntmp1, ntmp3, colmajor=False):
+        """colmajor: the program addresses column-major buffers (XLP_EXPR_COLMAJOR, include/xlp_gl.h)"""
         code = np.ascontiguousarray(code, dtype=np.uint64)
         self._h = C.c_void_p(None)
-        _ck(load().xlp_expr_create(C.byref(self._h), code.ctypes.data_as(C.c_void_p), code.size, ntmp1, ntmp3), "xlp_expr_create")
+        _ck(load().xlp_expr_create_ex(C.byref(self._h), code.ctypes.data_as(C.c_void_p), code.size, ntmp1, ntmp3, 1 if colmajor else 0), "xlp_expr_create")
 
     def run(self, params, row0, nrows):
         _ck(load().xlp_dev_expr_run(self._h, C.byref(params), row0, nrows), "xlp_dev_expr_run")

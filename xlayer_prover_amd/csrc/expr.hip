@@ -47,6 +47,7 @@ struct xlp_expr_program {
     std::vector<uint32_t> wcols;  // indices of the written columns
     uint64_t halo = 0, modulus = 0;
     bool serial_slabs = false;    // some row-major operand is addressed directly (not staged): slabs must run one after the other
+    bool colmajor = false;        // XLP_EXPR_COLMAJOR: the buffers are column-major (see include/xlp_gl.h): nothing is staged, every access is direct
     void* jit_handle = nullptr;   // dlopen'ed plugin (xlp_expr_attach)
     void* jit_launch = nullptr;
 };
@@ -117,6 +118,69 @@ static int validate(const uint64_t* code, uint64_t ncode, uint64_t ntmp1, uint64
 }
 
 // Largest element index an operand touches for rows [row0, row0 + nrows), and the buffer it lives in.
+// Column-major programs (XLP_EXPR_COLMAJOR): one launch range = storage rows [s0, s1] of coset `coset` (base-domain programs: coset 0, the
+// whole range); cbase = the coset's first storage row, dshift = storage row - dense index of the x / xDivXSubXi tables.
+static int check_bounds_cm(const xlp_expr_program* prog, const xlp_steps_params& P, u64 s0, u64 s1, u64 coset, u64 cbase, u64 dshift)
+{
+    const uint64_t* code = prog->code.data();
+    const uint64_t ncode = prog->code.size();
+    typedef unsigned __int128 u128;
+    auto top = [&](u64 nx, u64 md) -> u128 {               // highest storage row a next-row operand reads (the wrapping rows read lower ones)
+        const u128 t = (u128)s1 + nx;
+        return (t - cbase >= md) ? (u128)(cbase + md - 1 < s1 ? s1 : cbase + md - 1) : t;
+    };
+    const u64 crows = P.n_const_pols ? P.const_pols_size / P.n_const_pols : 0, crows2 = P.n_const_pols_2ns ? P.const_pols_2ns_size / P.n_const_pols_2ns : 0;
+    std::string msg;
+    uint64_t pc = 0, k = 0;
+    while (pc < ncode) {
+        Instr in;
+        const uint64_t nx = decode(code, ncode, pc, in, msg);
+        const Operand* ops[3] = {&in.d, &in.a, &in.b};
+        for (const Operand* o : ops) {
+            u128 hi = 0;
+            uint64_t size = 0;
+            const void* base = nullptr;
+            const uint64_t* p = o->p;
+            switch (o->kind) {
+            case XLP_K_POLS: hi = (u128)p[0] + (u128)(o->dim - 1) * p[1] + s1; size = P.pols_size; base = P.pols; break;
+            case XLP_K_POLS_PRIME: hi = (u128)p[0] + (u128)(o->dim - 1) * p[3] + top(p[1], p[2]); size = P.pols_size; base = P.pols; break;
+            case XLP_K_CONST: case XLP_K_CONST_PRIME: {
+                const bool pr = o->kind == XLP_K_CONST_PRIME;
+                const u128 r = pr ? top(p[1], p[2]) : (u128)s1;
+                hi = (p[0] >= P.n_const_pols || r >= crows) ? ~(u128)0 : (u128)p[0] * crows + r;
+                size = P.const_pols_size; base = P.const_pols; break;
+            }
+            case XLP_K_CONST2NS: case XLP_K_CONST2NS_PRIME: {
+                const bool pr = o->kind == XLP_K_CONST2NS_PRIME;
+                const u128 r = pr ? top(p[1], p[2]) : (u128)s1;
+                hi = (p[0] >= P.n_const_pols_2ns || r >= crows2) ? ~(u128)0 : (u128)p[0] * crows2 + r;
+                size = P.const_pols_2ns_size; base = P.const_pols_2ns; break;
+            }
+            case XLP_K_CHALLENGE: hi = (u128)p[0] * 3 + 2; size = P.challenges_size; base = P.challenges; break;
+            case XLP_K_EVAL: hi = (u128)p[0] * 3 + 2; size = P.evals_size; base = P.evals; break;
+            case XLP_K_PUBLIC: hi = p[0]; size = P.public_inputs_size; base = P.public_inputs; break;
+            case XLP_K_X_N: hi = s1 - dshift; size = P.x_n_size; base = P.x_n; break;
+            case XLP_K_X_2NS: hi = s1 - dshift; size = P.x_2ns_size; base = P.x_2ns; break;
+            case XLP_K_ZI: hi = coset; size = P.zi_size; base = P.zi; break;
+            case XLP_K_XDIVXSUBXI: hi = (u128)(s1 - dshift) * 3 + 2; size = P.x_div_x_sub_xi_size; base = P.x_div_x_sub_xi; break;
+            case XLP_K_XDIVXSUBWXI: hi = (u128)(s1 - dshift) * 3 + 2; size = P.x_div_x_sub_wxi_size; base = P.x_div_x_sub_wxi; break;
+            case XLP_K_Q_2NS: hi = ((u128)(s1 - cbase) * P.zi_size + coset) * 3 + 2; size = P.q_2ns_size; base = P.q_2ns; break;
+            case XLP_K_F_2NS: hi = ((u128)(s1 - cbase) * P.zi_size + coset) * 3 + 2; size = P.f_2ns_size; base = P.f_2ns; break;
+            default: continue;
+            }
+            if (base == nullptr || hi >= size) {
+                const std::string m = "expr run (column-major): instruction " + std::to_string(k) + ": operand " + KIND_NAME[o->kind] +
+                                      (base == nullptr ? " has no buffer" : " reads/writes past the end of its buffer") + " for storage rows [" +
+                                      std::to_string(s0) + ", " + std::to_string(s1 + 1) + ") of coset " + std::to_string(coset);
+                return xlp_fail(m.c_str());
+            }
+        }
+        pc = nx;
+        k++;
+    }
+    return 0;
+}
+
 static int check_bounds(const xlp_expr_program* prog, const xlp_steps_params& P, uint64_t row0, uint64_t nrows)
 {
     const uint64_t* code = prog->code.data();
@@ -261,7 +325,7 @@ static void compile(xlp_expr_program* P)
     P->hot_words = (u32)hot;
 
     // ---- staging decisions
-    const bool stage = env_int("XLP_EXPR_STAGE", 1) != 0;
+    const bool stage = env_int("XLP_EXPR_STAGE", 1) != 0 && !P->colmajor;   // column-major buffers: a lane's row of a column is coalesced as it is
     std::map<ColKey, std::pair<u64, bool>> colset;   // key -> (halo rows, written)
     std::set<ColKey> blocked;
     u64 modulus = 0, halo = 0;
@@ -340,6 +404,29 @@ static void compile(xlp_expr_program* P)
         P->serial_slabs = false;
         for (const ColKey& k : dwr) if (drd.count(k)) P->serial_slabs = true;
     }
+    if (P->colmajor) {
+        // every access is direct.  A row that only touches ITS cells of a column may run in any order with the others; a column that is
+        // written at one row distance and touched at another (next-row stores picked up by the next row: zkEVM step3prev, step3) orders
+        // the rows through the segment boundaries, so its slabs run one after the other
+        std::map<std::pair<u32, u64>, std::set<u64>> wr, any;
+        for (u64 pc = 0; pc < ncode;) {
+            Instr in; const u64 nx = decode(code, ncode, pc, in, msg);
+            const Operand* ops[3] = {&in.d, &in.a, &in.b};
+            for (int s_ = 0; s_ < 3; s_++) {
+                const Operand& o = *ops[s_];
+                u32 buf; u64 off, cs = 0, next = 0;
+                switch (o.kind) {
+                case XLP_K_POLS: buf = 0; off = o.p[0]; cs = o.p[1]; break;
+                case XLP_K_POLS_PRIME: buf = 0; off = o.p[0]; cs = o.p[3]; next = o.p[1]; break;
+                default: continue;
+                }
+                for (u32 c = 0; c < o.dim; c++) { any[{buf, off + c * cs}].insert(next); if (s_ == 0) wr[{buf, off + c * cs}].insert(next); }
+            }
+            pc = nx;
+        }
+        P->serial_slabs = false;
+        for (const auto& kv : wr) if (any[kv.first].size() > 1) P->serial_slabs = true;
+    }
 
     // ---- device program
     for (u64 pc = 0; pc < ncode;) {
@@ -372,6 +459,8 @@ static void compile(xlp_expr_program* P)
 
 // ------------------------------------------------------------------------------------------ device
 struct ExprArgs {
+    u32 colmajor;                             // column-major addressing (see check_bounds_cm): coset / cbase / dshift describe this launch
+    u64 coset, cbase, dshift, crows, crows2;  // crows / crows2: rows per column of const_pols / const_pols_2ns
     const u64* code; u64 ncode;
     u64* tmp; u64 tstride; u32 hot_words;     // spilled temporaries tmp[word - hot_words][thread]
     const u64* cols; u64 cap;                 // staged columns cols[c][local row], cap rows each
@@ -407,6 +496,33 @@ __device__ __forceinline__ void load_operand(Rows<R>& out, const ExprArgs& A, u3
     for (int r = 0; r < R; r++) out.r[r].c[0] = out.r[r].c[1] = out.r[r].c[2] = 0;
     const u64* src = nullptr;
     u64 rstride = 0;                       // element distance between consecutive rows of `src`
+    if (A.colmajor && kind >= XLP_K_POLS && kind <= XLP_K_CONST2NS_PRIME) {     // element c of row i = base[off + c * cs + wrap(i + next)]
+        const bool pr = kind == XLP_K_POLS_PRIME || kind == XLP_K_CONST_PRIME || kind == XLP_K_CONST2NS_PRIME;
+        const bool pol = kind == XLP_K_POLS || kind == XLP_K_POLS_PRIME;
+        const u64* base = pol ? A.P.pols : (kind == XLP_K_CONST || kind == XLP_K_CONST_PRIME) ? A.P.const_pols : A.P.const_pols_2ns;
+        const u64 cs = pol ? (pr ? PRM(3) : PRM(1)) : 0;
+        const u64 off = pol ? PRM(0) : PRM(0) * ((kind == XLP_K_CONST || kind == XLP_K_CONST_PRIME) ? A.crows : A.crows2);
+        const u64 nx = pr ? PRM(1) : 0, md = pr ? PRM(2) : 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            u64 j = ro[r] + nx;
+            if (pr && j - A.cbase >= md) j -= md;
+            const u64* q = base + off + j;
+            out.r[r].c[0] = gl::canon(q[0]);
+            if (dim == 3) { out.r[r].c[1] = gl::canon(q[cs]); out.r[r].c[2] = gl::canon(q[2 * cs]); }
+        }
+        return;
+    }
+    if (A.colmajor && (kind == XLP_K_ZI || kind == XLP_K_Q_2NS || kind == XLP_K_F_2NS)) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (kind == XLP_K_ZI) { out.r[r].c[0] = gl::canon(A.P.zi[A.coset]); continue; }
+            const u64* q = (kind == XLP_K_Q_2NS ? A.P.q_2ns : A.P.f_2ns) + 3 * ((ro[r] - A.cbase) * A.P.zi_size + A.coset);
+            out.r[r].c[0] = gl::canon(q[0]); out.r[r].c[1] = gl::canon(q[1]); out.r[r].c[2] = gl::canon(q[2]);
+        }
+        return;
+    }
+    const u64 dsh = A.colmajor ? A.dshift : 0;   // the dense tables (x_n, x_2ns, xDivXSubXi) are indexed by storage row - dshift
     switch (kind) {
     case XD_TMP: {
         const u64 w = PRM(0);
@@ -465,10 +581,10 @@ __device__ __forceinline__ void load_operand(Rows<R>& out, const ExprArgs& A, u3
     case XLP_K_CHALLENGE: src = A.P.challenges + 3 * PRM(0); break;
     case XLP_K_EVAL: src = A.P.evals + 3 * PRM(0); break;
     case XLP_K_PUBLIC: src = A.P.public_inputs + PRM(0); break;
-    case XLP_K_X_N: rstride = 1; src = A.P.x_n; break;
-    case XLP_K_X_2NS: rstride = 1; src = A.P.x_2ns; break;
-    case XLP_K_XDIVXSUBXI: rstride = 3; src = A.P.x_div_x_sub_xi; break;
-    case XLP_K_XDIVXSUBWXI: rstride = 3; src = A.P.x_div_x_sub_wxi; break;
+    case XLP_K_X_N: rstride = 1; src = A.P.x_n - dsh; break;
+    case XLP_K_X_2NS: rstride = 1; src = A.P.x_2ns - dsh; break;
+    case XLP_K_XDIVXSUBXI: rstride = 3; src = A.P.x_div_x_sub_xi - 3 * dsh; break;
+    case XLP_K_XDIVXSUBWXI: rstride = 3; src = A.P.x_div_x_sub_wxi - 3 * dsh; break;
     case XLP_K_Q_2NS: rstride = 3; src = A.P.q_2ns; break;
     case XLP_K_F_2NS: rstride = 3; src = A.P.f_2ns; break;
     default: return;
@@ -486,6 +602,29 @@ __device__ __forceinline__ void store_operand(const ExprArgs& A, u32 kind, u32 d
 {
     u64* dst = nullptr;
     u64 rstride = 0;
+    if (A.colmajor && (kind == XLP_K_POLS || kind == XLP_K_POLS_PRIME)) {
+        const bool pr = kind == XLP_K_POLS_PRIME;
+        const u64 off = PRM(0), cs = pr ? PRM(3) : PRM(1), nx = pr ? PRM(1) : 0, md = pr ? PRM(2) : 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (gt + r * T >= nrows) continue;
+            u64 j = ro[r] + nx;
+            if (pr && j - A.cbase >= md) j -= md;
+            u64* q = A.P.pols + off + j;
+            q[0] = v.r[r].c[0];
+            if (dim == 3) { q[cs] = v.r[r].c[1]; q[2 * cs] = v.r[r].c[2]; }
+        }
+        return;
+    }
+    if (A.colmajor && (kind == XLP_K_Q_2NS || kind == XLP_K_F_2NS)) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (gt + r * T >= nrows) continue;
+            u64* q = (kind == XLP_K_Q_2NS ? A.P.q_2ns : A.P.f_2ns) + 3 * ((ro[r] - A.cbase) * A.P.zi_size + A.coset);
+            q[0] = v.r[r].c[0]; q[1] = v.r[r].c[1]; q[2] = v.r[r].c[2];
+        }
+        return;
+    }
     switch (kind) {
     case XD_TMP: {                                               // rows past the end compute garbage in their own slots: harmless
         const u64 w = PRM(0);
@@ -668,6 +807,8 @@ static u64 program_signature(const xlp_expr_program* P)
     h = fnv(P->dcode.data(), P->dcode.size() * 8, h);
     for (const xlp_expr_column& c : P->cols) { h = fnv(&c.buf, 4, h); h = fnv(&c.off, 8, h); h = fnv(&c.stride, 8, h); }
     h = fnv(&P->tmp_words, 8, h);
+    const u64 cm = P->colmajor ? 1 : 0;
+    if (cm) h = fnv(&cm, 8, h);
     return h;
 }
 
@@ -746,7 +887,9 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
     const std::string prologue =
         "// generated by xlp_expr_codegen -- do not edit\n#include <hip/hip_runtime.h>\n#include \"gl_field.hpp\"\n#include \"xlp_expr_jit.h\"\n"
         "typedef unsigned long long u64_;\nusing gl::u64;\n"
-        "static __device__ __forceinline__ u64 wrapr(u64 r, u64 n) { return (n & (n - 1)) == 0 ? (r & (n - 1)) : r % n; }\n";
+        "static __device__ __forceinline__ u64 wrapr(u64 r, u64 n) { return (n & (n - 1)) == 0 ? (r & (n - 1)) : r % n; }\n"
+        "static __device__ __forceinline__ u64 wrapc(u64 j, u64 base, u64 n) { return j - base >= n ? j - n : j; }\n";
+    const bool CM = P->colmajor;
     std::vector<std::string> segsrc(nseg);
     char buf[256];
     for (size_t sg = 0; sg < nseg; sg++) {
@@ -756,9 +899,21 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
               "    u64* __restrict__ T = A.tmp + gt; const u64 TS = A.tstride;\n"
               "    const u64* __restrict__ C = A.cols + gt; u64* __restrict__ CW = A.cols + gt; const u64 CAP = A.cap;\n"
               "    (void)row; (void)T; (void)TS; (void)C; (void)CW; (void)CAP;\n";
+        if (CM)
+            os << "    const u64* __restrict__ PR = A.P.pols; u64* __restrict__ PW = A.P.pols; const u64* __restrict__ KN = A.P.const_pols; const u64* __restrict__ KE = A.P.const_pols_2ns;\n"
+                  "    const u64 KNR = A.crows, KER = A.crows2, drow = row - A.dshift, nat3 = 3 * ((row - A.cbase) * A.P.zi_size + A.coset);\n"
+                  "    (void)PR; (void)PW; (void)KN; (void)KE; (void)KNR; (void)KER; (void)drow; (void)nat3;\n";
         const size_t i0 = sg * SEG, i1 = std::min(ins.size(), i0 + SEG);
         std::set<u64> wcol;                              // columns this segment writes: all their accesses go through CW (restrict-clean)
         for (size_t i = i0; i < i1; i++) if (ins[i].k[0] == XD_COL) for (u32 c = 0; c < ins[i].dim[0]; c++) wcol.insert(ins[i].prm[0][0] + c);
+        // column-major form: a column is named by (buffer, first word | constant column); the ones this segment writes go through PW
+        typedef std::tuple<u32, u64, u64> MKey;          // (buffer 0 pols / 1 const / 2 const2ns, column, next)
+        std::set<u64> wcolm;
+        std::map<MKey, std::string> mval;
+        if (CM)
+            for (size_t i = i0; i < i1; i++)
+                if (ins[i].k[0] == XLP_K_POLS || ins[i].k[0] == XLP_K_POLS_PRIME)
+                    for (u32 c = 0; c < ins[i].dim[0]; c++) wcolm.insert(ins[i].prm[0][0] + c * ins[i].prm[0][ins[i].k[0] == XLP_K_POLS ? 1 : 3]);
         std::map<u64, std::string> tval;                 // tmp word -> SSA name
         std::map<u64, bool> tdef;                        // defined (not just loaded) in this segment
         std::map<std::pair<u64, u64>, std::string> cval; // (column, next) -> SSA name
@@ -852,6 +1007,25 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
                 return n;
             }
             case XLP_K_NUMBER: return num(p[0]);
+            case XLP_K_POLS: case XLP_K_POLS_PRIME: case XLP_K_CONST: case XLP_K_CONST_PRIME: case XLP_K_CONST2NS: case XLP_K_CONST2NS_PRIME:
+                if (CM) {
+                    const bool pol = k == XLP_K_POLS || k == XLP_K_POLS_PRIME, pr = k == XLP_K_POLS_PRIME || k == XLP_K_CONST_PRIME || k == XLP_K_CONST2NS_PRIME;
+                    const u32 buf = pol ? 0 : (k == XLP_K_CONST || k == XLP_K_CONST_PRIME) ? 1 : 2;
+                    const u64 col = pol ? p[0] + c * (pr ? p[3] : p[1]) : p[0];
+                    const MKey key(buf, col, pr ? p[1] : 0);
+                    auto it = mval.find(key);
+                    if (it != mval.end()) return it->second;
+                    const std::string idx = pr ? "wrapc(row + " + num(p[1]) + ", A.cbase, " + num(p[2]) + ")" : std::string("row");
+                    const std::string n = fresh();
+                    if (pol) os << "    const u64 " << n << " = gl::canon(" << (wcolm.count(col) ? "PW[" : "PR[") << num(col) << " + " << idx << "]);\n";
+                    else os << "    const u64 " << n << " = gl::canon(" << (buf == 1 ? "KN[" : "KE[") << num(col) << " * " << (buf == 1 ? "KNR" : "KER") << " + " << idx << "]);\n";
+                    mval[key] = n;
+                    return n;
+                }
+                break;
+            default: break;
+            }
+            switch (k) {
             case XLP_K_POLS: return direct("A.P.pols[" + num(p[0] + c) + " + row * " + num(p[1]) + "]");
             case XLP_K_POLS_PRIME: return direct("A.P.pols[" + num(p[0] + c) + " + wrapr(row + " + num(p[1]) + ", " + num(p[2]) + ") * " + num(p[3]) + "]");
             case XLP_K_CONST: return direct("A.P.const_pols[" + num(p[0]) + " + row * A.P.n_const_pols]");
@@ -861,13 +1035,13 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
             case XLP_K_CHALLENGE: return direct("A.P.challenges[" + num(3 * p[0] + c) + "]");
             case XLP_K_EVAL: return direct("A.P.evals[" + num(3 * p[0] + c) + "]");
             case XLP_K_PUBLIC: return direct("A.P.public_inputs[" + num(p[0]) + "]");
-            case XLP_K_X_N: return direct("A.P.x_n[row]");
-            case XLP_K_X_2NS: return direct("A.P.x_2ns[row]");
-            case XLP_K_ZI: return direct("A.P.zi[wrapr(row, A.P.zi_size)]");
-            case XLP_K_XDIVXSUBXI: return direct("A.P.x_div_x_sub_xi[3 * row + " + num(c) + "]");
-            case XLP_K_XDIVXSUBWXI: return direct("A.P.x_div_x_sub_wxi[3 * row + " + num(c) + "]");
-            case XLP_K_Q_2NS: { const std::string n = fresh(); os << "    const u64 " << n << " = gl::canon(A.P.q_2ns[3 * row + " << c << "]);\n"; return n; }
-            case XLP_K_F_2NS: { const std::string n = fresh(); os << "    const u64 " << n << " = gl::canon(A.P.f_2ns[3 * row + " << c << "]);\n"; return n; }
+            case XLP_K_X_N: return direct(CM ? "A.P.x_n[drow]" : "A.P.x_n[row]");
+            case XLP_K_X_2NS: return direct(CM ? "A.P.x_2ns[drow]" : "A.P.x_2ns[row]");
+            case XLP_K_ZI: return direct(CM ? "A.P.zi[A.coset]" : "A.P.zi[wrapr(row, A.P.zi_size)]");
+            case XLP_K_XDIVXSUBXI: return direct(std::string("A.P.x_div_x_sub_xi[3 * ") + (CM ? "drow" : "row") + " + " + num(c) + "]");
+            case XLP_K_XDIVXSUBWXI: return direct(std::string("A.P.x_div_x_sub_wxi[3 * ") + (CM ? "drow" : "row") + " + " + num(c) + "]");
+            case XLP_K_Q_2NS: { const std::string n = fresh(); os << "    const u64 " << n << " = gl::canon(A.P.q_2ns[" << (CM ? "nat3" : "3 * row") << " + " << c << "]);\n"; return n; }
+            case XLP_K_F_2NS: { const std::string n = fresh(); os << "    const u64 " << n << " = gl::canon(A.P.f_2ns[" << (CM ? "nat3" : "3 * row") << " + " << c << "]);\n"; return n; }
             default: return "0ULL";
             }
         };
@@ -999,13 +1173,23 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
                     cval[{p[0] + c, 0}] = r[c];
                 }
                 break;
-            case XLP_K_POLS: for (u32 c = 0; c < dd; c++) os << "    A.P.pols[" << num(p[0] + c) << " + row * " << num(p[1]) << "] = " << r[c] << ";\n"; dval.clear(); break;
-            case XLP_K_POLS_PRIME:
-                for (u32 c = 0; c < dd; c++) os << "    A.P.pols[" << num(p[0] + c) << " + wrapr(row + " << num(p[1]) << ", " << num(p[2]) << ") * " << num(p[3]) << "] = " << r[c] << ";\n";
+            case XLP_K_POLS: case XLP_K_POLS_PRIME:
+                if (CM) {
+                    const bool pr = in.k[0] == XLP_K_POLS_PRIME;
+                    for (u32 c = 0; c < dd; c++) {
+                        const u64 col = p[0] + c * (pr ? p[3] : p[1]);
+                        os << "    PW[" << num(col) << " + " << (pr ? "wrapc(row + " + num(p[1]) + ", A.cbase, " + num(p[2]) + ")" : std::string("row")) << "] = " << r[c] << ";\n";
+                        for (auto it = mval.begin(); it != mval.end();) { if (std::get<0>(it->first) == 0 && std::get<1>(it->first) == col) it = mval.erase(it); else ++it; }
+                        mval[MKey(0, col, pr ? p[1] : 0)] = r[c];
+                    }
+                    break;
+                }
+                if (in.k[0] == XLP_K_POLS) for (u32 c = 0; c < dd; c++) os << "    A.P.pols[" << num(p[0] + c) << " + row * " << num(p[1]) << "] = " << r[c] << ";\n";
+                else for (u32 c = 0; c < dd; c++) os << "    A.P.pols[" << num(p[0] + c) << " + wrapr(row + " << num(p[1]) << ", " << num(p[2]) << ") * " << num(p[3]) << "] = " << r[c] << ";\n";
                 dval.clear();
                 break;
-            case XLP_K_Q_2NS: for (u32 c = 0; c < dd; c++) os << "    A.P.q_2ns[3 * row + " << c << "] = " << r[c] << ";\n"; break;
-            case XLP_K_F_2NS: for (u32 c = 0; c < dd; c++) os << "    A.P.f_2ns[3 * row + " << c << "] = " << r[c] << ";\n"; break;
+            case XLP_K_Q_2NS: for (u32 c = 0; c < dd; c++) os << "    A.P.q_2ns[" << (CM ? "nat3" : "3 * row") << " + " << c << "] = " << r[c] << ";\n"; break;
+            case XLP_K_F_2NS: for (u32 c = 0; c < dd; c++) os << "    A.P.f_2ns[" << (CM ? "nat3" : "3 * row") << " + " << c << "] = " << r[c] << ";\n"; break;
             default: break;
             }
         }
@@ -1070,7 +1254,27 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
     if (!nrows || prog->code.empty()) return 0;
     if (row0 + nrows < row0) return xlp_fail("expr run: row range overflows");
     if (params->zi && params->zi_size == 0) return xlp_fail("expr run: zi_size is 0");
-    if (check_bounds(prog, *params, row0, nrows)) return -1;
+    // launch ranges.  Row-major programs: one, rows as they are.  Column-major programs on the extended domain (coset_rows != 0): the rows
+    // [row0, row0 + nrows) are DENSE coset-major indices (coset r = index / coset_rows); coset r's rows start at storage row r * coset_stride
+    struct Range { u64 s0, n, coset, cbase, dshift; };
+    std::vector<Range> ranges;
+    if (!prog->colmajor) {
+        if (check_bounds(prog, *params, row0, nrows)) return -1;
+        ranges.push_back({row0, nrows, 0, 0, 0});
+    } else {
+        const u64 nb = params->coset_rows, bs = params->coset_stride ? params->coset_stride : nb;
+        if (!nb) ranges.push_back({row0, nrows, 0, 0, 0});
+        else {
+            if (bs < nb) return xlp_fail("expr run: coset_stride smaller than coset_rows");
+            for (u64 r = row0 / nb; r <= (row0 + nrows - 1) / nb; r++) {
+                const u64 d0 = std::max(row0, r * nb), d1 = std::min(row0 + nrows, (r + 1) * nb);
+                ranges.push_back({r * bs + (d0 - r * nb), d1 - d0, r, r * bs, r * (bs - nb)});
+            }
+        }
+        for (const Range& g : ranges) if (check_bounds_cm(prog, *params, g.s0, g.s0 + g.n - 1, g.coset, g.cbase, g.dshift)) return -1;
+    }
+    u64 longest = 0;
+    for (const Range& g : ranges) longest = std::max(longest, g.n);
     if (!prog->d_dcode) {
         xlp_expr_program* mp = const_cast<xlp_expr_program*>(prog);
         XLP_HIP(hipMalloc((void**)&mp->d_dcode, prog->dcode.size() * sizeof(u64)));
@@ -1094,13 +1298,15 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
     const bool chain = false;
     const u64 wgs = (u64)(env_int("XLP_EXPR_SLAB_WGS", 8) > 0 ? env_int("XLP_EXPR_SLAB_WGS", 8) : 8);   // workgroups per CU and slab, all streams together
     u64 chunk_max = (u64)ctx->ncu * wgs * 256;
-    while (S > 1 && (nrows <= chunk_max / S * (S - 1) || wgs < (u64)S)) S--;           // every stream gets a slab
+    while (S > 1 && ((nrows <= chunk_max / S * (S - 1) && ranges.size() < 2) || wgs < (u64)S)) S--;           // every stream gets a slab
     chunk_max = chunk_max / S / 256 * 256;
-    const u64 chunk = nrows < chunk_max ? nrows : chunk_max;
+    const u64 chunk = longest < chunk_max ? longest : chunk_max;
     const u64 threads_max = ((chunk + R - 1) / R + 255) / 256 * 256;     // lanes of the largest launch
     const u32 ncols = (u32)prog->cols.size(), nw = (u32)prog->wcols.size();
     const u64 cap = (u64)R * threads_max + prog->halo;
     ExprArgs A;
+    A.colmajor = prog->colmajor ? 1 : 0; A.coset = A.cbase = A.dshift = 0;
+    A.crows = P.n_const_pols ? P.const_pols_size / P.n_const_pols : 0; A.crows2 = P.n_const_pols_2ns ? P.const_pols_2ns_size / P.n_const_pols_2ns : 0;
     A.code = prog->d_dcode; A.ncode = prog->dcode.size();
     A.hot_words = prog->hot_words; A.tstride = (u64)R * threads_max; A.tmp = nullptr; A.cols = nullptr; A.cap = cap; A.P = P;
     const u64 spill = jit ? prog->tmp_words : prog->tmp_words - prog->hot_words;
@@ -1124,7 +1330,8 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
         XLP_HIP(hipStreamSynchronize(ctx->stream));       // `tab` is a stack object
     }
     hipStream_t streams[4] = {ctx->stream, ctx->stream, ctx->stream, ctx->stream};
-    const u64 nslabs = (nrows + chunk - 1) / chunk;
+    u64 nslabs = 0;
+    for (const Range& g : ranges) nslabs += (g.n + chunk - 1) / chunk;
     hipEvent_t computed = nullptr;                        // chain: the previous slab's kernels are done
     std::vector<hipEvent_t> gathered;                     // gathered[i]: slab i's inputs (its rows + halo) have been staged
     hipEvent_t first_written = nullptr;                   // slab 0's destination columns are back in the sections
@@ -1142,7 +1349,11 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
     }
     const size_t lds = (size_t)prog->hot_words * R * 256 * sizeof(u64);
     int rc = 0;
-    for (u64 r0 = 0, i = 0; r0 < nrows && !rc; r0 += chunk, i++) {
+    u64 i = 0;
+    for (const Range& g : ranges)
+    for (u64 r0 = 0; r0 < g.n && !rc; r0 += chunk, i++) {
+        const u64 row0 = g.s0, nrows = g.n;                   // (shadow the call's range: this launch range)
+        A.coset = g.coset; A.cbase = g.cbase; A.dshift = g.dshift;
         const u64 rows = nrows - r0 < chunk ? nrows - r0 : chunk;
         const int s = (int)(i % (u64)S);
         hipStream_t st = streams[s];
@@ -1163,6 +1374,7 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
         if (jit) {
             XlpJitArgs J;
             J.cols = cols; J.cap = cap; J.tmp = A.tmp; J.tstride = A.tstride; J.row0 = row0 + r0; J.nrows = rows; J.P = P;
+            J.coset = A.coset; J.cbase = A.cbase; J.dshift = A.dshift; J.crows = A.crows; J.crows2 = A.crows2;
             if (((xlpjit_launch_fn)prog->jit_launch)(&J, (void*)st)) rc = xlp_fail("expr run: the compiled plugin failed to launch");
         } else {
             const dim3 vgrid((unsigned)((((rows + R - 1) / R) + 255) / 256));
@@ -1195,8 +1407,9 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
     return 0;
 }
 
-int expr_create(xlp_expr_program** out, const u64* code, u64 ncode, u64 ntmp1, u64 ntmp3)
+int expr_create(xlp_expr_program** out, const u64* code, u64 ncode, u64 ntmp1, u64 ntmp3, u64 flags)
 {
+    if (flags & ~(u64)XLP_EXPR_COLMAJOR) return xlp_fail("expr create: unknown flag");
     if (!out) return xlp_fail("expr create: null output");
     *out = nullptr;
     if (ncode && !code) return xlp_fail("expr create: null code");
@@ -1217,6 +1430,7 @@ int expr_create(xlp_expr_program** out, const u64* code, u64 ncode, u64 ntmp1, u
         }
     }
     p->ntmp1 = ntmp1; p->ntmp3 = ntmp3; p->ninstr = ninstr;
+    p->colmajor = (flags & XLP_EXPR_COLMAJOR) != 0;
     compile(p);
     // the device copy is made by the first run: creating, generating code and attaching need no GPU
     *out = p;

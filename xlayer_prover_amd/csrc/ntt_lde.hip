@@ -79,7 +79,7 @@ __global__ __launch_bounds__(XLP_WGT) void lde_top_dif(const LdeParams p)
         const u64 row = ((u64)tpos << 12) | lo;
         if (c + v < p.wc) gst<1>(&Ag[row * 8 + v], val);
     };
-    auto crossf = [&](u32 tpos) -> u64 { return cross[tile_natural_c<BT>(tpos)]; };
+    auto crossf = [&](u32 tpos, u32) -> u64 { return cross[tile_natural_c<BT>(tpos)]; };
     if constexpr (m == 2) {
         fast_round<BT, V, 4, dtop, false, INV>(p.twi_bt, gload, lstore);
         XLP_SYNC();
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(XLP_WGT) void lde_top_dit(const LdeParams p)
         const u64 row = ((u64)tpos << 12) | lo;
         return gld<4>(&Br[row * 8 + vv]);
     };
-    auto crossf = [&](u32 tpos) -> u64 { return cross[tile_natural_c<BT>(tpos)]; };
+    auto crossf = [&](u32 tpos, u32) -> u64 { return cross[tile_natural_c<BT>(tpos)]; };
     auto lload = [&](u32, u32 v, u32 lrow) -> u64 { return sm[lrow * V + v]; };
     auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { sm[lrow * V + v] = val; };
     auto gstore = [&](u32 tpos, u32 v, u64 val, u32) {
@@ -197,6 +197,22 @@ __global__ void lde_tw2_kernel(u64* out, const u64* __restrict__ sk /* G^k2 */, 
 
 // ----------------------------------------------------------------- host side
 int get_pow_tables(Ctx* ctx, u32 L, u64 root, u64 mult, const u64** lo, const u64** hi);  // ntt.hip
+
+// the derived table tw2 of a coset (lde_tw2_kernel), cached under (100 + BT, root = g^(2^BT), mult = 1); shared with ntt_lde_cm.hip
+int lde_tw2_table(Ctx* ctx, u32 BT, u64 gk, const u64* sk, const u64* twf12, const u64** out)
+{
+    auto key = std::make_tuple(100u + BT, gk, (u64)1);
+    auto it = ctx->tables.find(key);
+    if (it == ctx->tables.end()) {
+        u64* d = nullptr;
+        XLP_HIP(hipMalloc(&d, 4096 * sizeof(u64)));
+        hipLaunchKernelGGL(lde_tw2_kernel, dim3(16), dim3(256), 0, ctx->stream, d, sk, twf12);
+        XLP_HIP(hipGetLastError());
+        it = ctx->tables.emplace(key, d).first;
+    }
+    *out = it->second;
+    return 0;
+}
 
 template <int BT>
 static int launch_top(Ctx* ctx, const LdeParams& p, bool dit)
@@ -351,19 +367,7 @@ int dev_extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld
         for (u32 i = 0; i < BT; i++) gk = hgl::mul(gk, gk);    // g^(2^BT)
         const u64* sk;
         if (get_pow_tables(ctx, 12, gk, 1, &sk, &dummy)) return -1;
-        // derived tables, cached under (L = 100 + BT / 200 + BT, root = g^(2^BT), mult = 1)
-        {
-            auto key = std::make_tuple(100u + BT, gk, (u64)1);
-            auto it = ctx->tables.find(key);
-            if (it == ctx->tables.end()) {
-                u64* d = nullptr;
-                XLP_HIP(hipMalloc(&d, 4096 * sizeof(u64)));
-                hipLaunchKernelGGL(lde_tw2_kernel, dim3(16), dim3(256), 0, ctx->stream, d, sk, p.twf_12);
-                XLP_HIP(hipGetLastError());
-                it = ctx->tables.emplace(key, d).first;
-            }
-            p.tw2[r] = it->second;
-        }
+        if (lde_tw2_table(ctx, BT, gk, sk, p.twf_12, &p.tw2[r])) return -1;
         {
             u64 g256 = gk;
             for (int i = 0; i < 8; i++) g256 = hgl::mul(g256, g256);   // G^256

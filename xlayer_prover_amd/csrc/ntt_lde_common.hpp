@@ -56,7 +56,7 @@ __device__ __forceinline__ u32 xcd_tile()
     return (g >= 16 && (g & 7) == 0) ? (bid & 7) * (g >> 3) + (bid >> 3) : bid;
 }
 
-struct NoFactor { __device__ __forceinline__ u64 operator()(u32) const { return 1; } };
+struct NoFactor { __device__ __forceinline__ u64 operator()(u32, u32) const { return 1; } };   // (tile position, column of the tile)
 
 
 __device__ __forceinline__ u64 two_level12(const u64* __restrict__ lo, const u64* __restrict__ hi, u64 e)
@@ -72,16 +72,18 @@ __device__ __forceinline__ u64 two_level12(const u64* __restrict__ lo, const u64
 // (4) all stores -- because hipcc otherwise serialises "load; s_waitcnt vmcnt(0); use" per
 // element (a full L2 round trip each).  pre/post return per-position factors (LDS cross
 // twiddles) and are only evaluated when HAS_PRE / HAS_POST.
-template <int B, int V, int TP, int D, bool DIT, bool INV, bool HAS_PRE, bool HAS_POST, class Load, class Store, class Pre, class Post, bool POSTW = false>
+// VHI: the tile's column is the HIGH part of the group index (v = g >> (B - D): wave-uniform, adjacent lanes = adjacent positions) instead
+// of the low part (adjacent lanes = adjacent columns): the column-major kernels' middle pass, whose columns are far apart in memory.
+template <int B, int V, int TP, int D, bool DIT, bool INV, bool HAS_PRE, bool HAS_POST, class Load, class Store, class Pre, class Post, bool POSTW = false, bool VHI = false>
 __device__ __forceinline__ void fast_round(const u64* __restrict__ tw, Load load, Store store, Pre pre, Post post)
 {
     constexpr int RAD = 1 << D;
-    constexpr u32 VB = V == 8 ? 3 : 2;
+    constexpr u32 VB = V == 8 ? 3 : V == 4 ? 2 : V == 2 ? 1 : 0;
     constexpr u32 NG = (1u << (B - D)) * V;
     constexpr u32 TSHIFT = B - TP - D;
     for (u32 g = threadIdx.x; g < NG; g += blockDim.x) {
-        const u32 v = g & (V - 1);
-        const u32 rest = g >> VB;
+        const u32 v = VHI ? g >> (B - D) : g & (V - 1);
+        const u32 rest = VHI ? g & ((1u << (B - D)) - 1) : g >> VB;
         const u32 low = rest & ((1u << TP) - 1);
         const u32 high = rest >> TP;
         const u32 base = (high << (TP + D)) | low;
@@ -107,7 +109,7 @@ __device__ __forceinline__ void fast_round(const u64* __restrict__ tw, Load load
         if constexpr (HAS_PRE) {
             u64 f[RAD];
 #pragma unroll
-            for (int j = 0; j < RAD; j++) f[j] = pre(base + ((u32)j << TP));
+            for (int j = 0; j < RAD; j++) f[j] = pre(base + ((u32)j << TP), v);
 #pragma unroll
             for (int j = 0; j < RAD; j++) x[j] = XLP_TWMUL(x[j], f[j]);
         }
@@ -129,7 +131,7 @@ __device__ __forceinline__ void fast_round(const u64* __restrict__ tw, Load load
         if constexpr (HAS_POST) {
             u64 f[RAD];
 #pragma unroll
-            for (int k = 0; k < RAD; k++) f[k] = post(base + ((u32)k << TP));
+            for (int k = 0; k < RAD; k++) f[k] = post(base + ((u32)k << TP), v);
 #pragma unroll
             for (int k = 0; k < RAD; k++) y[k] = XLP_TWMUL(y[k], f[k]);
         }

@@ -312,6 +312,50 @@ __global__ __launch_bounds__(256) void linear_hash_absorb_kernel(u64* state, con
     for (int k = 0; k < 4; k++) state[4 * row + k] = st[k];
 }
 
+// The leaf sponge on a COLUMN-MAJOR section (colmajor.hip): lane = dense coset-major index d = r * nq + q of an extended row, i.e. storage
+// row r * cos + q of every column, so a wave reads 512 contiguous bytes of one column per absorbed word (the row-major sponge reads 64-byte
+// pieces of rows up to 6 KB apart: 2.1x the algorithmic traffic).  The leaf belongs to NATURAL row k = (q << ext) | r: state[4 k ..].
+// Bands as in linear_hash_absorb_kernel: src = the section's column `first`, wc columns, first % 8 == 0, wc % 8 == 0 unless last.
+__global__ __launch_bounds__(256) void linear_hash_absorb_cm_kernel(u64* state, const u64* src, u64 cstride, u64 cos, u64 wc, u64 h, u32 ext, u32 lognq, int is_first)
+{
+    const u64 d = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= h) return;
+    const u64 r = d >> lognq, q = d & ((1ull << lognq) - 1);
+    const u64 k = (q << ext) | r;
+    const u64* in = src + r * cos + q;
+    u64 st[12];
+    if (is_first) { st[8] = st[9] = st[10] = st[11] = 0; }
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) st[8 + j] = state[4 * k + j];
+    }
+    u64 rem = wc;
+    while (rem) {
+        if (rem >= 8) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) st[j] = in[j * cstride];
+            in += 8 * cstride; rem -= 8;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) st[j] = (u64)j < rem ? in[j * cstride] : 0;
+            rem = 0;
+        }
+        permute(st);
+        st[8] = st[0]; st[9] = st[1]; st[10] = st[2]; st[11] = st[3];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) state[4 * k + j] = st[j];
+}
+// w <= 4: the leaf is the row itself, zero-padded (no hash)
+__global__ __launch_bounds__(256) void leaf_copy_cm_kernel(u64* out, const u64* src, u64 cstride, u64 cos, u64 w, u64 h, u32 ext, u32 lognq)
+{
+    const u64 d = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= h) return;
+    const u64 r = d >> lognq, q = d & ((1ull << lognq) - 1);
+    const u64 k = (q << ext) | r;
+    for (u64 j = 0; j < 4; j++) out[4 * k + j] = j < w ? gl::canon(src[j * cstride + r * cos + q]) : 0;
+}
+
 // One tree level: nxt[j] = perm(cur[2j] | cur[2j+1] | 0^4)[0..3].
 __global__ __launch_bounds__(256) void merkle_level_kernel(u64* nxt, const u64* cur, u64 count)
 {
@@ -372,6 +416,40 @@ int dev_linear_hash_absorb(Ctx* ctx, u64* state, const u64* src, u64 ld, u64 fir
 
 // PoseidonGoldilocks::merkletree_avx(tree, input, ncols, nrows): nodes =
 // level0 | level1 | ... | root, (2h-1)*4 elements (merkleTreeGL.hpp:61-68).
+static int cm_geometry(const char* what, u64 h, u32 ext, u64& cos, u32& lognq)
+{
+    if (h == 0 || (h & (h - 1))) return xlp_fail((std::string(what) + ": number of rows is not a power of two").c_str());
+    if (ext > 8 || (h >> ext) == 0) return xlp_fail((std::string(what) + ": more cosets than rows").c_str());
+    const u64 nq = h >> ext;
+    lognq = 0;
+    while ((1ull << lognq) < nq) lognq++;
+    if (cos == 0) cos = nq;
+    if (cos < nq) return xlp_fail((std::string(what) + ": coset stride smaller than the rows of a coset").c_str());
+    return 0;
+}
+int dev_linear_hash_absorb_cm(Ctx* ctx, u64* state, const u64* src, u64 cstride, u64 cos, u64 first, u64 ncols, u64 h, u32 ext, int is_first, int is_last)
+{
+    if (!h || !ncols) return 0;
+    u32 lognq;
+    if (cm_geometry("linear hash (column-major)", h, ext, cos, lognq)) return -1;
+    if (first % 8) return xlp_fail("linear hash (column-major): a band must start on a multiple of 8 columns");
+    if (!is_last && ncols % 8) return xlp_fail("linear hash (column-major): only the last band may hold a partial block");
+    hipLaunchKernelGGL(linear_hash_absorb_cm_kernel, dim3((unsigned)((h + 255) / 256)), dim3(256), 0, ctx->stream, state, src + first * cstride, cstride, cos, ncols, h, ext, lognq, is_first);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+int dev_merkle_cm(Ctx* ctx, u64* nodes, const u64* src, u64 cstride, u64 cos, u64 w, u64 h, u32 ext)
+{
+    if (!h) return 0;
+    u32 lognq;
+    if (cm_geometry("merkle (column-major)", h, ext, cos, lognq)) return -1;
+    if (w <= 4) {
+        hipLaunchKernelGGL(leaf_copy_cm_kernel, dim3((unsigned)((h + 255) / 256)), dim3(256), 0, ctx->stream, nodes, src, cstride, cos, w, h, ext, lognq);
+        XLP_HIP(hipGetLastError());
+    } else if (dev_linear_hash_absorb_cm(ctx, nodes, src, cstride, cos, 0, w, h, ext, 1, 1)) return -1;
+    return dev_merkle_levels(ctx, nodes, h);
+}
+
 int dev_merkle(Ctx* ctx, u64* nodes, const u64* src, u64 w, u64 h)
 {
     if (!h) return 0;
@@ -411,6 +489,33 @@ __global__ __launch_bounds__(128) void merkle_proofs_kernel(u64* out, const u64*
         for (u32 k = 0; k < l; k++) { off += cnt * 4; cnt >>= 1; }
         o[w + 4 * l + c] = nodes[off + (((idx >> l) ^ 1) * 4) + c];
     }
+}
+
+// the same on a column-major section: the opened row is gathered from the w columns (storage row r * cos + q of natural row (q << ext) | r)
+__global__ __launch_bounds__(128) void merkle_proofs_cm_kernel(u64* out, const u64* src, u64 cstride, u64 cos, const u64* nodes, u64 w, u64 h, u32 ext, const u64* idxs, u32 levels)
+{
+    const u64 idx = idxs[blockIdx.x];
+    const u64 s = (idx & ((1ull << ext) - 1)) * cos + (idx >> ext);
+    u64* o = out + (u64)blockIdx.x * (w + 4ull * levels);
+    for (u64 i = threadIdx.x; i < w; i += blockDim.x) o[i] = src[i * cstride + s];
+    if (threadIdx.x < 4 * levels) {
+        const u32 l = threadIdx.x >> 2, c = threadIdx.x & 3;
+        u64 off = 0, cnt = h;
+        for (u32 k = 0; k < l; k++) { off += cnt * 4; cnt >>= 1; }
+        o[w + 4 * l + c] = nodes[off + (((idx >> l) ^ 1) * 4) + c];
+    }
+}
+int dev_merkle_proofs_cm(Ctx* ctx, u64* out, const u64* src, u64 cstride, u64 cos, const u64* nodes, u64 w, u64 h, u32 ext, const u64* d_idxs, u64 nq)
+{
+    if (!nq) return 0;
+    u32 lognq;
+    if (cm_geometry("merkle proofs (column-major)", h, ext, cos, lognq)) return -1;
+    u32 levels = 0;
+    while ((1ull << levels) < h) levels++;
+    if (levels > 32) return xlp_fail("merkle proofs: tree too tall");
+    hipLaunchKernelGGL(merkle_proofs_cm_kernel, dim3((unsigned)nq), dim3(128), 0, ctx->stream, out, src, cstride, cos, nodes, w, h, ext, d_idxs, levels);
+    XLP_HIP(hipGetLastError());
+    return 0;
 }
 
 int dev_merkle_proofs(Ctx* ctx, u64* out, const u64* src, const u64* nodes, u64 w, u64 h, const u64* d_idxs, u64 nq)

@@ -380,7 +380,12 @@ int xlp_dev_calculate_h1h2_strided(uint64_t* h1, uint64_t h1_stride, uint64_t* h
 int xlp_expr_create(xlp_expr_program** out, const uint64_t* code, uint64_t ncode, uint64_t ntmp1, uint64_t ntmp3)
 {
     XLP_ENTER;
-    return expr_create(out, code, ncode, ntmp1, ntmp3);      // host-only: validation + compilation to the device form
+    return expr_create(out, code, ncode, ntmp1, ntmp3, 0);   // host-only: validation + compilation to the device form
+}
+int xlp_expr_create_ex(xlp_expr_program** out, const uint64_t* code, uint64_t ncode, uint64_t ntmp1, uint64_t ntmp3, uint64_t flags)
+{
+    XLP_ENTER;
+    return expr_create(out, code, ncode, ntmp1, ntmp3, flags);
 }
 int xlp_expr_destroy(xlp_expr_program* prog) { XLP_ENTER; return expr_destroy(prog); }
 int xlp_expr_codegen(const xlp_expr_program* prog, const char* path) { XLP_ENTER; return expr_codegen(prog, path); }
@@ -405,6 +410,65 @@ int xlp_dev_merkle_proofs(uint64_t* out, const uint64_t* src, const uint64_t* no
     if (di.alloc(nq * sizeof(u64)) || dout.alloc(nq * per * sizeof(u64))) return -1;
     H2D(di, idxs, nq * sizeof(u64));
     if (dev_merkle_proofs(&g_ctx, dout.u(), src, nodes, w, h, di.u(), nq)) return -1;
+    XLP_HIP(hipStreamSynchronize(g_ctx.stream));
+    D2H(out, dout, nq * per * sizeof(u64));
+    return 0;
+}
+// ---- column-major device sections (colmajor.hip, ntt_lde_cm.hip, poseidon.hip; include/xlp_gl.h "column-major sections")
+int xlp_dev_rows_to_cm(uint64_t* dst, uint64_t dst_cstride, uint64_t dst_coset_stride, const uint64_t* src, uint64_t ld, uint64_t col0, uint64_t ncols, uint64_t rows, uint32_t ext_bits)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if (ncols && rows && (!dst || !src)) return xlp_fail("xlp_dev_rows_to_cm: null pointer");
+    return dev_rows_to_cm(&g_ctx, dst, dst_cstride, dst_coset_stride, src, ld, col0, ncols, rows, ext_bits);
+}
+int xlp_dev_cm_to_rows(uint64_t* dst, uint64_t ld, uint64_t col0, const uint64_t* src, uint64_t src_cstride, uint64_t src_coset_stride, uint64_t ncols, uint64_t rows, uint32_t ext_bits)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if (ncols && rows && (!dst || !src)) return xlp_fail("xlp_dev_cm_to_rows: null pointer");
+    return dev_cm_to_rows(&g_ctx, dst, ld, col0, src, src_cstride, src_coset_stride, ncols, rows, ext_bits);
+}
+int xlp_dev_copy_view(uint64_t* dst, uint64_t dst_row_stride, uint64_t dst_comp_stride, const uint64_t* src, uint64_t src_row_stride, uint64_t src_comp_stride, uint64_t n, uint32_t dim)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if (n && dim && (!dst || !src)) return xlp_fail("xlp_dev_copy_view: null pointer");
+    return dev_copy_view(&g_ctx, dst, dst_row_stride, dst_comp_stride, src, src_row_stride, src_comp_stride, n, dim);
+}
+int xlp_dev_extend_cm(uint64_t* out, uint64_t out_cstride, uint64_t out_coset_stride, const uint64_t* in, uint64_t in_cstride, uint64_t n_ext, uint64_t n, uint64_t ncols)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if (n && ncols && (!out || !in)) return xlp_fail("xlp_dev_extend_cm: null pointer");
+    return dev_extend_cm(&g_ctx, out, out_cstride, out_coset_stride, in, in_cstride, n_ext, n, ncols);
+}
+int xlp_dev_linear_hash_absorb_cm(uint64_t* state, const uint64_t* src, uint64_t cstride, uint64_t coset_stride, uint64_t col0, uint64_t ncols, uint64_t h, uint32_t ext_bits, int first, int last)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    return dev_linear_hash_absorb_cm(&g_ctx, state, src, cstride, coset_stride, col0, ncols, h, ext_bits, first, last);
+}
+int xlp_dev_merkle_cm(uint64_t* nodes, const uint64_t* src, uint64_t cstride, uint64_t coset_stride, uint64_t w, uint64_t h, uint32_t ext_bits)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    return dev_merkle_cm(&g_ctx, nodes, src, cstride, coset_stride, w, h, ext_bits);
+}
+int xlp_dev_merkle_proofs_cm(uint64_t* out, const uint64_t* src, uint64_t cstride, uint64_t coset_stride, const uint64_t* nodes, uint64_t w, uint64_t h, uint32_t ext_bits, const uint64_t* idxs, uint64_t nq)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if (nq == 0) return 0;
+    if (!out || !nodes || !idxs || (w && !src)) return xlp_fail("xlp_dev_merkle_proofs_cm: null pointer");
+    for (uint64_t q = 0; q < nq; q++) if (idxs[q] >= h) return xlp_fail("xlp_dev_merkle_proofs_cm: index out of range");
+    uint32_t levels = 0;
+    while ((1ull << levels) < h) levels++;
+    const size_t per = w + 4ull * levels;
+    DevBuf di, dout;
+    if (di.alloc(nq * sizeof(u64)) || dout.alloc(nq * per * sizeof(u64))) return -1;
+    H2D(di, idxs, nq * sizeof(u64));
+    if (dev_merkle_proofs_cm(&g_ctx, dout.u(), src, cstride, coset_stride, nodes, w, h, ext_bits, di.u(), nq)) return -1;
     XLP_HIP(hipStreamSynchronize(g_ctx.stream));
     D2H(out, dout, nq * per * sizeof(u64));
     return 0;
@@ -692,6 +756,100 @@ static int commit_bands(uint64_t* sec_n, uint64_t* sec_2ns, uint64_t* nodes, con
         *upload_ms = ms;
     }
     return 0;
+}
+// The same pipeline on column-major sections: sec_n = ncols columns of n rows (csn words apart), sec_2ns = ncols columns of n_ext rows,
+// coset-major (cs2 apart), bands of whole columns.  With h_src (the executor's row-major witness in host memory, prover.cpp:435) every band
+// is uploaded as it is -- a dense row-major [n][band] matrix -- into `stage` (device scratch of >= n * ncols words: in step 1 the dead
+// base-domain sections behind cm1_n) on the copy stream and transposed into its columns on the compute stream ahead of its extension.
+static int commit_bands_cm(uint64_t* sec_n, uint64_t csn, uint64_t* sec_2ns, uint64_t cs2, uint64_t* nodes, const uint64_t* h_src, uint64_t* stage, uint64_t stage_words,
+                           uint64_t n_ext, uint64_t n, uint64_t ncols, double* upload_ms)
+{
+    CommitTimes& T = g_commit_times;
+    T.clear();
+    if (upload_ms) *upload_ms = 0.0;
+    if (n == 0 || n_ext == 0) return 0;
+    if ((n & (n - 1)) || (n_ext & (n_ext - 1)) || n_ext < n) return xlp_fail("commit (column-major): sizes must be powers of two, n_ext >= n");
+    if (csn < n || cs2 < n_ext) return xlp_fail("commit (column-major): column stride smaller than a column");
+    if (h_src && ncols && stage_words < n * ncols) return xlp_fail("commit (column-major): staging area smaller than the section");
+    u32 e = 0;
+    while ((n << e) < n_ext) e++;
+    Ctx* ctx = &g_ctx;
+    // band plan: as commit_bands (wide first, narrowing by 15 %, for a host source; uniform 64-column bands otherwise)
+    u64 band = 64;
+    if (const char* ev = getenv("XLP_COMMIT_BAND")) { const u64 v = strtoull(ev, nullptr, 10); if (v >= 8 && v % 8 == 0) band = v; }
+    std::vector<u64> starts, widths;
+    if (ncols <= 4 || ncols <= band) { starts.push_back(0); widths.push_back(ncols); }
+    else if (h_src && !getenv("XLP_COMMIT_BAND") && ncols >= 320) {
+        std::vector<u64> rev;
+        double w = 48.0;
+        for (u64 rem = ncols / 8 * 8; rem;) {
+            u64 ww = ((u64)(w + 4.0)) / 8 * 8;
+            if (ww > rem) ww = rem;
+            rev.push_back(ww); rem -= ww;
+            w = w / 0.85 < 160.0 ? w / 0.85 : 160.0;
+        }
+        rev[0] += ncols % 8;
+        if (rev.size() > 1 && rev.back() < 64) { rev[rev.size() - 2] += rev.back(); rev.pop_back(); }
+        u64 c0 = 0;
+        for (size_t k = rev.size(); k-- > 0;) { starts.push_back(c0); widths.push_back(rev[k]); c0 += rev[k]; }
+    } else {
+        for (u64 c0 = 0; c0 < ncols; c0 += band) { starts.push_back(c0); widths.push_back(ncols - c0 < band ? ncols - c0 : band); }
+    }
+    const u64 nb = starts.size();
+    EventPool pool;
+    std::vector<hipEvent_t> ev(nb, nullptr);
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (h_src && ncols) {
+        if (!ctx->copy_stream) XLP_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        if (pool.mark(ctx->stream, ctx->copy_stream)) return -1;       // the staging area may still be read by earlier work
+        if (upload_ms) {
+            if (pool.make(&t0, true) || pool.make(&t1, true)) return -1;
+            XLP_HIP(hipEventRecord(t0, ctx->copy_stream));
+        }
+        for (u64 b = 0; b < nb; b++) {                                  // band b lands dense at stage + n * starts[b]: no area is reused
+            const u64 c0 = starts[b], wc = widths[b];
+            XLP_HIP(hipMemcpy2DAsync(stage + n * c0, wc * sizeof(u64), h_src + c0, ncols * sizeof(u64), wc * sizeof(u64), n, hipMemcpyHostToDevice, ctx->copy_stream));
+            if (pool.mark(ctx->copy_stream, nullptr, &ev[b])) return -1;
+        }
+        if (upload_ms) XLP_HIP(hipEventRecord(t1, ctx->copy_stream));
+    }
+    for (u64 b = 0; b < nb && ncols; b++) {
+        const u64 c0 = starts[b], wc = widths[b];
+        if (h_src) {
+            XLP_HIP(hipStreamWaitEvent(ctx->stream, ev[b], 0));
+            if (dev_rows_to_cm(ctx, sec_n + c0 * csn, csn, 0, stage + n * c0, wc, 0, wc, n, 0)) return -1;
+        }
+        if (T.begin(T.lde, ctx->stream) || dev_extend_cm(ctx, sec_2ns + c0 * cs2, cs2, 0, sec_n + c0 * csn, csn, n_ext, n, wc) || T.end(T.lde, ctx->stream)) return -1;
+        if (ncols > 4) {
+            if (T.begin(T.merkle, ctx->stream) || dev_linear_hash_absorb_cm(ctx, nodes, sec_2ns, cs2, 0, c0, wc, n_ext, e, b == 0, b == nb - 1)) return -1;
+            if (b == nb - 1 && dev_merkle_levels(ctx, nodes, n_ext)) return -1;
+            if (T.end(T.merkle, ctx->stream)) return -1;
+        }
+    }
+    if (ncols <= 4) {                                                   // the no-hash rule of narrow rows, and the empty section
+        if (T.begin(T.merkle, ctx->stream) || dev_merkle_cm(ctx, nodes, sec_2ns, cs2, 0, ncols, n_ext, e) || T.end(T.merkle, ctx->stream)) return -1;
+    }
+    if (t0) {
+        float ms = 0.f;
+        XLP_HIP(hipEventSynchronize(t1));
+        XLP_HIP(hipEventElapsedTime(&ms, t0, t1));
+        *upload_ms = ms;
+    }
+    return 0;
+}
+int xlp_dev_commit_cm(uint64_t* sec_2ns, uint64_t cs2, uint64_t* nodes, const uint64_t* sec_n, uint64_t csn, uint64_t n_ext, uint64_t n, uint64_t ncols)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    return commit_bands_cm(const_cast<uint64_t*>(sec_n), csn, sec_2ns, cs2, nodes, nullptr, nullptr, 0, n_ext, n, ncols, nullptr);
+}
+int xlp_dev_commit_from_host_cm(uint64_t* sec_n, uint64_t csn, uint64_t* sec_2ns, uint64_t cs2, uint64_t* nodes, const uint64_t* h_src, uint64_t* stage, uint64_t stage_words,
+                                uint64_t n_ext, uint64_t n, uint64_t ncols, double* upload_ms)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if (ncols && n && (!h_src || !stage)) return xlp_fail("xlp_dev_commit_from_host_cm: null host pointer or staging area");
+    return commit_bands_cm(sec_n, csn, sec_2ns, cs2, nodes, h_src, stage, stage_words, n_ext, n, ncols, upload_ms);
 }
 int xlp_dev_commit_last_times(double* lde_ms, double* merkle_ms)
 {

@@ -76,6 +76,12 @@ int dev_ntt_fast(Ctx* ctx, u64* dst, const u64* src, u32 L, u64 ncols, int inver
 int dev_extend_fast(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ncols);
 int dev_extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld, u64 first, u64 ncols);
 
+// colmajor.hip / ntt_lde_cm.hip (column-major device sections)
+int dev_rows_to_cm(Ctx* ctx, u64* dst, u64 cstride, u64 cos, const u64* src, u64 ld, u64 col0, u64 ncols, u64 rows, u32 ext);
+int dev_cm_to_rows(Ctx* ctx, u64* dst, u64 ld, u64 col0, const u64* src, u64 cstride, u64 cos, u64 ncols, u64 rows, u32 ext);
+int dev_copy_view(Ctx* ctx, u64* dst, u64 drs, u64 dcs, const u64* src, u64 srs, u64 scs, u64 n, u32 dim);
+int dev_extend_cm(Ctx* ctx, u64* out, u64 out_cstride, u64 out_cos, const u64* in, u64 in_cstride, u64 n_ext, u64 n, u64 ncols);
+
 // poseidon.hip
 int poseidon_init(Ctx* ctx);
 int dev_perm(Ctx* ctx, u64* out, const u64* in, u64 count);
@@ -85,6 +91,9 @@ int dev_merkle(Ctx* ctx, u64* nodes, const u64* src, u64 w, u64 h);
 int dev_linear_hash_absorb(Ctx* ctx, u64* state, const u64* src, u64 ld, u64 first, u64 ncols, u64 h, int is_first, int is_last);
 int dev_merkle_levels(Ctx* ctx, u64* nodes, u64 h);
 int dev_merkle_proofs(Ctx* ctx, u64* out, const u64* src, const u64* nodes, u64 w, u64 h, const u64* d_idxs, u64 nq);
+int dev_linear_hash_absorb_cm(Ctx* ctx, u64* state, const u64* src, u64 cstride, u64 cos, u64 first, u64 ncols, u64 h, u32 ext, int is_first, int is_last);
+int dev_merkle_cm(Ctx* ctx, u64* nodes, const u64* src, u64 cstride, u64 cos, u64 w, u64 h, u32 ext);
+int dev_merkle_proofs_cm(Ctx* ctx, u64* out, const u64* src, u64 cstride, u64 cos, const u64* nodes, u64 w, u64 h, u32 ext, const u64* d_idxs, u64 nq);
 
 // fri.hip
 int dev_fri_fold(Ctx* ctx, u64* pol2, const u64* pol, u32 bits, u32 red, const u64 x[3], u64 shift_inv);
@@ -132,7 +141,7 @@ int comm_barrier(Ctx* ctx);
 int comm_stats(double* seconds, u64* bytes_sent, u64* calls, int mode);
 
 // expr.hip
-int expr_create(xlp_expr_program** out, const u64* code, u64 ncode, u64 ntmp1, u64 ntmp3);
+int expr_create(xlp_expr_program** out, const u64* code, u64 ncode, u64 ntmp1, u64 ntmp3, u64 flags);
 int expr_destroy(xlp_expr_program* prog);
 int expr_codegen(const xlp_expr_program* prog, const char* path);
 int expr_attach(xlp_expr_program* prog, const char* so_path);

@@ -24,6 +24,7 @@
 // exitProcess() (src/utils/exit_process.cpp:7); a non-zero C-ABI status does the
 // same here (xlp_exit_process, overridable for tests).
 #pragma once
+#include <algorithm>
 #include <cassert>
 #include <cmath>
 #include <cstdint>
@@ -366,24 +367,28 @@ public:
 #define TRANSCRIPT_STATE_SIZE 4
 #define TRANSCRIPT_PENDING_SIZE 8
 #define TRANSCRIPT_OUT_SIZE 12
+// Transcript (src/starkpil/transcript/transcript.hpp:13-37, .cpp:4-87): a duplex sponge over the Poseidon permutation, rate 8, capacity 4.
+// The reference's public members keep their names and meaning (state = the capacity, pending = the rate block being filled, out = the last
+// permutation's 12 words of which the last out_cursor are unread); the bodies are this file's own.
 class Transcript
 {
-    void _updateState()
+    // one permutation: out <- P(pending | state); the capacity becomes out[0..4), the block is emptied, 12 words are there to be read
+    void duplex()
     {
-        Goldilocks::Element inputs[TRANSCRIPT_OUT_SIZE];
-        std::memcpy(inputs, pending, sizeof(pending));
-        std::memcpy(&inputs[TRANSCRIPT_PENDING_SIZE], state, sizeof(state));
-        PoseidonGoldilocks::hash_full_result(out, inputs);
-        out_cursor = TRANSCRIPT_OUT_SIZE;
-        std::memset(pending, 0, sizeof(pending));
+        Goldilocks::Element in[TRANSCRIPT_OUT_SIZE];
+        for (unsigned i = 0; i < TRANSCRIPT_PENDING_SIZE; i++) { in[i] = pending[i]; pending[i] = Goldilocks::zero(); }
+        for (unsigned i = 0; i < TRANSCRIPT_STATE_SIZE; i++) in[TRANSCRIPT_PENDING_SIZE + i] = state[i];
+        PoseidonGoldilocks::hash_full_result(out, in);
+        for (unsigned i = 0; i < TRANSCRIPT_STATE_SIZE; i++) state[i] = out[i];
         pending_cursor = 0;
-        std::memcpy(state, out, sizeof(state));
+        out_cursor = TRANSCRIPT_OUT_SIZE;
     }
-    void _add1(Goldilocks::Element input)
+    // absorbing anything makes what is left of the old output unreadable
+    void absorb(const Goldilocks::Element& e)
     {
-        pending[pending_cursor++] = input;
         out_cursor = 0;
-        if (pending_cursor == TRANSCRIPT_PENDING_SIZE) _updateState();
+        pending[pending_cursor] = e;
+        if (++pending_cursor == TRANSCRIPT_PENDING_SIZE) duplex();
     }
 public:
     Goldilocks::Element state[TRANSCRIPT_STATE_SIZE];
@@ -392,48 +397,48 @@ public:
     unsigned pending_cursor = 0, out_cursor = 0, state_cursor = 0;
     Transcript()
     {
-        std::memset(state, 0, sizeof(state));
-        std::memset(pending, 0, sizeof(pending));
-        std::memset(out, 0, sizeof(out));
+        for (Goldilocks::Element& e : state) e = Goldilocks::zero();
+        for (Goldilocks::Element& e : pending) e = Goldilocks::zero();
+        for (Goldilocks::Element& e : out) e = Goldilocks::zero();
     }
-    // transcript.cpp:12-29 adds element by element, one permutation per 8; a long message (the evaluations: 3 x 1 973 words at the zkEVM) goes
-    // through its full blocks in one call once the pending block is empty -- the same sequence of permutations, the same members afterwards
+    // transcript.cpp:12-29 absorbs element by element, one permutation per 8.  A long message (the evaluations: 3 x 1 973 words at the zkEVM)
+    // is cut into head (completes the block in progress) | whole blocks | tail: the whole blocks go through ONE kernel that walks the chained
+    // permutations (xlp_perm_chain) -- the same permutations in the same order, the same members afterwards
     void put(Goldilocks::Element* input, uint64_t size)
     {
-        uint64_t i = 0;
-        while (i < size && pending_cursor != 0) _add1(input[i++]);
-        const uint64_t nblocks = (size - i) / TRANSCRIPT_PENDING_SIZE;
-        if (nblocks >= 2) {
-            PoseidonGoldilocks::hash_chain(out, state, &input[i], nblocks);
+        const uint64_t head = pending_cursor ? std::min<uint64_t>(size, TRANSCRIPT_PENDING_SIZE - pending_cursor) : 0;
+        for (uint64_t i = 0; i < head; i++) absorb(input[i]);
+        uint64_t done = head;
+        const uint64_t whole = pending_cursor == 0 ? (size - done) / TRANSCRIPT_PENDING_SIZE : 0;
+        if (whole >= 2) {
+            PoseidonGoldilocks::hash_chain(out, state, input + done, whole);
+            for (unsigned i = 0; i < TRANSCRIPT_STATE_SIZE; i++) state[i] = out[i];
             out_cursor = TRANSCRIPT_OUT_SIZE;
-            std::memcpy(state, out, sizeof(state));
-            i += nblocks * TRANSCRIPT_PENDING_SIZE;
+            done += whole * TRANSCRIPT_PENDING_SIZE;
         }
-        for (; i < size; i++) _add1(input[i]);
+        for (; done < size; done++) absorb(input[done]);
     }
+    // the unread words are the LAST out_cursor words of out, read front to back; with none left the current block is permuted first
     Goldilocks::Element getFields1()
     {
-        if (out_cursor == 0) _updateState();
-        Goldilocks::Element res = out[(TRANSCRIPT_OUT_SIZE - out_cursor) % TRANSCRIPT_OUT_SIZE];
-        out_cursor--;
-        return res;
+        if (out_cursor == 0) duplex();
+        return out[TRANSCRIPT_OUT_SIZE - out_cursor--];
     }
     void getField(Goldilocks::Element* output) { for (int i = 0; i < 3; i++) output[i] = getFields1(); }
-    // 63 bits per field element, LSB first (transcript.cpp:57-87)
+    // query indices (transcript.cpp:57-87): n numbers of nBits bits each, read LSB-first from the low 63 bits of as many squeezed words as needed
     void getPermutations(uint64_t* res, uint64_t n, uint64_t nBits)
     {
-        uint64_t totalBits = n * nBits;
-        uint64_t NFields = (totalBits - 1) / 63 + 1;
-        std::vector<uint64_t> fields(NFields);
-        for (uint64_t i = 0; i < NFields; i++) fields[i] = Goldilocks::toU64(getFields1());
-        uint64_t curField = 0, curBit = 0;
+        uint64_t word = 0;
+        unsigned have = 0;                                       // unread bits of `word`
         for (uint64_t i = 0; i < n; i++) {
-            uint64_t a = 0;
+            uint64_t v = 0;
             for (uint64_t j = 0; j < nBits; j++) {
-                if ((fields[curField] >> curBit) & 1) a += (1ULL << j);
-                if (++curBit == 63) { curBit = 0; curField++; }
+                if (have == 0) { word = Goldilocks::toU64(getFields1()); have = 63; }
+                v |= (word & 1ULL) << j;
+                word >>= 1;
+                have--;
             }
-            res[i] = a;
+            res[i] = v;
         }
     }
 };

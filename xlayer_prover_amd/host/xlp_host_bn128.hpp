@@ -179,77 +179,98 @@ public:
     }
 };
 
+// TranscriptBN128 (src/starkpil/transcript/transcriptBN128.hpp:12-38, .cpp:5-141) as a sponge over fixed arrays with cursors: capacity =
+// one Fr element, rate = 16.  Observable behaviour kept, quirks included: absorbing an element discards the unread OUTPUT ELEMENTS but not
+// the 64-bit limbs already cut from one (the reference clears `out`, not `out3`, in _add1); a squeeze on a fresh transcript returns the
+// initial zero element without hashing (its `out` starts as one zero); a squeeze with a partial block hashes the block zero-padded.
 class TranscriptBN128
 {
-    void _add1(RawFr::Element input)
+    static const unsigned kRate = 16, kWidth = kRate + 1;
+    RawFr::Element capacity_;                  // the reference's state[0]
+    RawFr::Element block_[kRate];               // the reference's `pending`
+    unsigned filled_ = 0;
+    RawFr::Element squeezed_[kWidth];           // the reference's `out`: elements [head_, head_ + left_) are unread
+    unsigned head_ = 0, left_ = 1;
+    uint64_t limbs_[3];                        // the reference's `out3`
+    unsigned limbHead_ = 0, limbsLeft_ = 0;
+
+    // out <- Poseidon(capacity | block, zero-padded), capacity <- out[0]; 17 fresh output elements, no limbs
+    void duplex()
     {
-        pending.push_back(input);
-        out.clear();
-        if (pending.size() == 16) _updateState();
+        std::vector<RawFr::Element> st(kWidth, RawFr::field.zero());
+        st[0] = capacity_;
+        for (unsigned i = 0; i < filled_; i++) st[1 + i] = block_[i];
+        Poseidon_opt().hash(st);
+        for (unsigned i = 0; i < kWidth; i++) squeezed_[i] = st[i];
+        capacity_ = squeezed_[0];
+        head_ = 0; left_ = kWidth;
+        limbsLeft_ = 0;
+        filled_ = 0;
     }
-    void _updateState()
+    void absorb(const RawFr::Element& e)
     {
-        while (pending.size() < 16) pending.push_back(RawFr::field.zero());
-        Poseidon_opt p;
-        out.insert(out.end(), state.begin(), state.end());
-        out.insert(out.end(), pending.begin(), pending.end());
-        p.hash(out);
-        state[0] = out[0];
-        out3.clear();
-        pending.clear();
+        left_ = 0;
+        block_[filled_++] = e;
+        if (filled_ == kRate) duplex();
+    }
+    RawFr::Element nextElement()
+    {
+        if (left_ == 0) duplex();
+        left_--;
+        return squeezed_[head_++];
     }
 
 public:
     unsigned typeSize = 2;
-    std::vector<RawFr::Element> state, pending, out;
-    std::vector<uint64_t> out3;
-    TranscriptBN128() : state(1, RawFr::field.zero()), out(1, RawFr::field.zero()) {}
+    TranscriptBN128()
+    {
+        capacity_ = RawFr::field.zero();
+        squeezed_[0] = RawFr::field.zero();
+    }
+    // the reference's public vectors, as copies (tests look at them; the prover does not)
+    std::vector<RawFr::Element> state() const { return std::vector<RawFr::Element>(1, capacity_); }
+    std::vector<RawFr::Element> pending() const { return std::vector<RawFr::Element>(block_, block_ + filled_); }
+    std::vector<RawFr::Element> out() const { return std::vector<RawFr::Element>(squeezed_ + head_, squeezed_ + head_ + left_); }
+    std::vector<uint64_t> out3() const { return std::vector<uint64_t>(limbs_ + limbHead_, limbs_ + limbHead_ + limbsLeft_); }
+
     void put(Goldilocks::Element* input, uint64_t size)
     {
         for (uint64_t i = 0; i < size; i++) {
-            RawFr::Element tmp = RawFr::field.zero();
-            tmp.v[0] = Goldilocks::toU64(input[i]);
-            RawFr::field.toMontgomery(tmp, tmp);
-            _add1(tmp);
+            RawFr::Element e = RawFr::field.zero();
+            e.v[0] = Goldilocks::toU64(input[i]);
+            RawFr::field.toMontgomery(e, e);
+            absorb(e);
         }
     }
-    void put(RawFr::Element* input, uint64_t size) { for (uint64_t i = 0; i < size; i++) _add1(input[i]); }
-    void getField(uint64_t* output) { for (int i = 0; i < 3; i++) output[i] = getFields1(); }
-    RawFr::Element getFields253()
-    {
-        for (;;) {
-            if (out.size() > 0) { RawFr::Element res = out[0]; out.erase(out.begin()); return res; }
-            _updateState();
-        }
-    }
+    void put(RawFr::Element* input, uint64_t size) { for (uint64_t i = 0; i < size; i++) absorb(input[i]); }
+    RawFr::Element getFields253() { return nextElement(); }
+    // 64-bit limbs: three per squeezed element (its low 192 bits, out of Montgomery form)
     uint64_t getFields1()
     {
-        for (;;) {
-            if (out3.size() > 0) { const uint64_t res = out3[0]; out3.erase(out3.begin()); return res; }
-            if (out.size() > 0) {
-                RawFr::Element res;
-                RawFr::field.fromMontgomery(res, out[0]);
-                out.erase(out.begin());
-                out3.push_back(res.v[0]); out3.push_back(res.v[1]); out3.push_back(res.v[2]);
-                continue;
-            }
-            _updateState();
+        if (limbsLeft_ == 0) {
+            RawFr::Element plain;
+            RawFr::field.fromMontgomery(plain, nextElement());
+            for (int i = 0; i < 3; i++) limbs_[i] = plain.v[i];
+            limbHead_ = 0; limbsLeft_ = 3;
         }
+        limbsLeft_--;
+        return limbs_[limbHead_++];
     }
+    void getField(uint64_t* output) { for (int i = 0; i < 3; i++) output[i] = getFields1(); }
+    // query indices: n numbers of nBits bits, read LSB-first from the 253 low bits of as many squeezed elements as needed
     void getPermutations(uint64_t* res, uint64_t n, uint64_t nBits)
     {
-        const uint64_t totalBits = n * nBits;
-        const uint64_t NFields = (totalBits - 1) / 253 + 1;
-        std::vector<RawFr::Element> fields(NFields);
-        for (uint64_t i = 0; i < NFields; i++) { RawFr::Element f = getFields253(); RawFr::field.fromMontgomery(fields[i], f); }
-        uint64_t curField = 0, curBit = 0;
+        RawFr::Element cur;
+        unsigned have = 0;                      // unread bits of `cur`
         for (uint64_t i = 0; i < n; i++) {
-            uint64_t a = 0;
+            uint64_t v = 0;
             for (uint64_t j = 0; j < nBits; j++) {
-                if ((fields[curField].v[curBit >> 6] >> (curBit & 63)) & 1) a = a + (1ULL << j);
-                if (++curBit == 253) { curBit = 0; curField++; }
+                if (have == 0) { RawFr::field.fromMontgomery(cur, nextElement()); have = 253; }
+                const unsigned bit = 253 - have;
+                v |= ((cur.v[bit >> 6] >> (bit & 63)) & 1ULL) << j;
+                have--;
             }
-            res[i] = a;
+            res[i] = v;
         }
     }
 };
