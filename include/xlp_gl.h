@@ -441,6 +441,14 @@ int xlp_dev_commit_from_host(uint64_t* sec_n, uint64_t* sec_2ns, uint64_t* nodes
  *   xlp_dev_commit_cm / _commit_from_host_cm   xlp_dev_commit / _commit_from_host: bands of columns; the host form uploads each band as a dense
  *                                             row-major [n][band] matrix into `stage` (>= n * ncols words of dead device memory) and transposes
  *                                             it into its columns ahead of its extension */
+/*   xlp_dev_evmap_cm                           Starks::evmap (starks.cpp:556-669) with the polynomials as columns: entries[i].pol = the column's first
+ *                                             word (coset 0 of an extended column holds its values at the rows k << extendBits), .row_stride = the
+ *                                             words between the components of an extension column; prime entries read word (k + 1) % n
+ *   xlp_dev_dot_columns_cm                     xlp_dev_dot_columns on columns: out column 3 g + c (out_cstride words apart) = component c of group
+ *                                             g's sum over the storage rows [0, nrows); entries as above; results canonical */
+int xlp_dev_evmap_cm(uint64_t* evals, const uint64_t* LEv, const uint64_t* LpEv, uint64_t n, uint32_t nev, const xlp_evmap_entry* entries);
+int xlp_dev_dot_columns_cm(uint64_t* out, uint64_t out_cstride, const xlp_dot_entry* entries, uint64_t nentries, uint32_t ngroups,
+                           const uint64_t* coefs, uint64_t coefs_size, uint64_t nrows);
 int xlp_dev_rows_to_cm(uint64_t* dst, uint64_t dst_cstride, uint64_t dst_coset_stride, const uint64_t* src, uint64_t ld, uint64_t col0, uint64_t ncols, uint64_t rows, uint32_t ext_bits);
 int xlp_dev_cm_to_rows(uint64_t* dst, uint64_t ld, uint64_t col0, const uint64_t* src, uint64_t src_cstride, uint64_t src_coset_stride, uint64_t ncols, uint64_t rows, uint32_t ext_bits);
 int xlp_dev_copy_view(uint64_t* dst, uint64_t dst_row_stride, uint64_t dst_comp_stride, const uint64_t* src, uint64_t src_row_stride, uint64_t src_comp_stride, uint64_t n, uint32_t dim);

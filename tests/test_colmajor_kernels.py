@@ -130,3 +130,66 @@ def test_commit_cm_equals_oracle(xlp, orc, lg, ext, w, from_host):
     import ctypes as C
     l, m = C.c_double(0), C.c_double(0)
     assert xlp.load().xlp_dev_commit_last_times(C.byref(l), C.byref(m)) == 0 and l.value > 0 and m.value > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nbits,eb,width,nev,seed", [(3, 1, 5, 7, 1), (12, 1, 37, 300, 2), (13, 3, 21, 64, 3), (14, 1, 751, 900, 4)])
+def test_evmap_cm_equals_oracle(xlp, orc, nbits, eb, width, nev, seed):
+    """Starks::evmap on column-major / coset-major sections against the oracle on the row-major ones: more entries than a block holds, rows not a
+    multiple of the staged sub-chunk, mixed dimensions and prime flags, duplicate columns, arbitrary 64-bit words, two sections"""
+    rng = np.random.default_rng(seed)
+    n, ne = 1 << nbits, 1 << (nbits + eb)
+    LEv = orc.fill(3 * n, 0x5EED0E00 + seed).reshape(n, 3)
+    LpEv = orc.fill(3 * n, 0x5EED0E10 + seed).reshape(n, 3)
+    secA = rng.integers(0, 2**64, size=(ne, width), dtype=np.uint64)
+    secB = orc.fill(ne * 6, 0x5EED0E20 + seed).reshape(ne, 6)
+    ents = []
+    for _ in range(nev):
+        if rng.integers(0, 5) == 0:
+            ents.append((secB, int(rng.integers(0, 2)) * 3, 3, bool(rng.integers(0, 2))))
+        elif width >= 3 and rng.integers(0, 6) == 0:
+            ents.append((secA, int(rng.integers(0, width - 2)), 3, bool(rng.integers(0, 2))))
+        else:
+            ents.append((secA, int(rng.integers(0, width)), 1, bool(rng.integers(0, 2))))
+    exp = orc.evmap(LEv, LpEv, n, eb, ents)
+    tA, tB = xlp.from_np(_cm(secA, eb)), xlp.from_np(_cm(secB, eb))
+    dev_ents = xlp.evmap_entries_cm([((tA if e[0] is secA else tB), ne, e[1], e[2], e[3]) for e in ents])
+    ev = xlp.from_np(np.zeros(3 * len(ents), np.uint64))
+    xlp.dev_evmap_cm(ev, xlp.from_np(LEv.reshape(-1)), xlp.from_np(LpEv.reshape(-1)), n, dev_ents); xlp.sync()
+    assert (xlp.to_np(ev).reshape(-1, 3) == exp).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nrows,ngroups,seed,reps", [(1, 1, 1, 1), (255, 2, 2, 1), (256, 3, 3, 1), (1000, 4, 4, 1), (5000, 3, 5, 1), (300, 2, 6, 40)])
+def test_dot_columns_cm_equals_the_row_major_kernel(xlp, orc, nrows, ngroups, seed, reps):
+    """xlp_dev_dot_columns_cm on the transposed sections == xlp_dev_dot_columns (itself checked against Python integers in test_gpu_parity.py):
+    base and extension columns, repeated columns and repeated (column, group) pairs, arbitrary 64-bit words, > 1 024 columns per run"""
+    import torch
+    rng = np.random.default_rng(seed)
+    Pm = 0xFFFFFFFF00000001
+    widths = [37, 3, 130, 18] if reps == 1 else [37, 3, 1300, 18]
+    secs_h = [rng.integers(0, 2**64, size=nrows * w, dtype=np.uint64) for w in widths]
+    if reps > 1:
+        for a, w in zip(secs_h, widths):
+            a[:w] = 2**64 - 1
+    secs = [xlp.from_np(a) for a in secs_h]
+    secs_cm = [xlp.from_np(_cm(a.reshape(nrows, w), 0)) for a, w in zip(secs_h, widths)]
+    ncoef = 50
+    coefs_h = orc.fill(3 * ncoef, 0x5EED0D07 + seed)
+    coefs_h[0:3] = [2**64 - 1, Pm, Pm + 5]
+    ents = []
+    for si, w in enumerate(widths):
+        for _ in range(max(2, w // 2) * (reps if w < 1000 else 1)):
+            dim = 3 if (w >= 3 and rng.integers(0, 4) == 0) else 1
+            ents.append((si, w, int(rng.integers(0, w - dim + 1)), dim, int(rng.integers(0, ngroups)), int(rng.integers(0, ncoef)) if reps == 1 else int(rng.integers(0, 3))))
+    if reps > 1:
+        ents += [(2, 1300, c, 1, int(rng.integers(0, ngroups)), int(rng.integers(0, 3))) for c in range(1300)]       # every column once more: > 1 024 distinct columns
+    co = xlp.from_np(coefs_h)
+    ref = torch.zeros(nrows * 3 * ngroups, dtype=torch.int64, device="cuda")
+    xlp.dev_dot_columns(ref, [(secs[si], w, c, d, g, k) for si, w, c, d, g, k in ents], ngroups, co, nrows)
+    out = torch.full((nrows * 3 * ngroups + 5,), 7, dtype=torch.int64, device="cuda")
+    xlp.dev_dot_columns_cm(out, nrows, [(secs_cm[si], nrows, c, d, g, k) for si, w, c, d, g, k in ents], ngroups, co, nrows)
+    xlp.sync()
+    got = xlp.to_np(out)
+    assert (got[nrows * 3 * ngroups:] == 7).all()
+    assert (got[:nrows * 3 * ngroups].reshape(3 * ngroups, nrows).T == xlp.to_np(ref).reshape(nrows, 3 * ngroups)).all()

@@ -1,0 +1,99 @@
+"""COLUMN-MAJOR device sections in the C++ product path (host/starks.hpp with a "colMajor" starkinfo; include/xlp_gl.h): the proof must be the
+row-major run's proof, bit for bit -- the same witness, constants and plookup selections, every stage on the other layout (witness bands
+transposed on arrival, step programs addressing columns and cosets, extendPol / leaf sponge / evmap / FRI-polynomial sums on columns, opened rows
+gathered).  One process per run (host/test_host_shim `bundle ...`, host/zkprover_batch)."""
+import json
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "xlayer_prover_amd", "host", "test_host_shim")
+WSEED, CSEED = 0x5EED0401, 0x5EED0402
+
+
+def _programs_built():
+    from xlayer_prover_amd import programs as R
+    return os.path.exists(os.path.join(R.REF_DIR, "zkevm.step52ns.xlpexpr"))
+
+
+def _proof(bundle, circ="zkevm"):
+    r = subprocess.run([EXE, "bundle", bundle, circ, str(WSEED), str(CSEED)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads(r.stdout), r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ln,aliased,use_opt,use_dots", [(12, False, True, True), (12, False, False, False), (13, False, True, False), (13, True, True, True)])
+def test_colmajor_zkevm_proof_equals_rowmajor_proof(tmp_path, ln, aliased, use_opt, use_dots):
+    """the zkEVM STARK at 2^12 / 2^13 rows: programs as converted, in dot-product form, and with the FRI polynomial on xlp_dev_dot_columns_cm;
+    the one-GPU aliased slab (extended constants inside the slab, re-extended per proof)"""
+    from tools import make_stark_bundle as B
+    if not _programs_built():
+        pytest.skip("converted reference programs not built (needs the reference tree at build time)")
+    row = B.make("zkevm", ln, aliased, out=str(tmp_path / "row"), use_opt=use_opt, use_dots=use_dots)
+    col = B.make("zkevm", ln, aliased, out=str(tmp_path / "col"), use_opt=use_opt, use_dots=use_dots, colmajor=True)
+    assert json.load(open(os.path.join(col, "zkevm.starkinfo.json")))["xlp"]["colMajor"] is True
+    expect, _ = _proof(row)
+    got, _ = _proof(col)
+    for k in ("root1", "root2", "root3", "root4"):
+        assert got[k] == expect[k], k
+    assert got["evals"] == expect["evals"]
+    assert got == expect
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("circ", ["recursive1", "c12a"])
+def test_colmajor_small_starks_at_their_real_geometry(tmp_path, circ):
+    """recursive1 (2^17 rows, blow-up 8) and c12a (2^20 rows, blow-up 4) at their real sizes: the three column-major extendPol kernels inside a
+    proof, prebuilt ahead-of-time kernels of the converted programs when they are there"""
+    from tools import make_stark_bundle as B
+    from tools import zkevm_geometry as G
+    if not _programs_built():
+        pytest.skip("converted reference programs not built (needs the reference tree at build time)")
+    ln = G.CIRCUITS[circ]["log_n"]
+    row = B.make(circ, ln, False, out=str(tmp_path / "row"))
+    col = B.make(circ, ln, False, out=str(tmp_path / "col"), colmajor=True)
+    expect, _ = _proof(row, circ)
+    got, log = _proof(col, circ)
+    assert got == expect
+    man = json.load(open(os.path.join(col, f"{circ}.steps.json")))
+    if man["steps"]["step42ns"].get("plugin"):
+        assert "compiled" in log
+
+
+@pytest.mark.gpu
+def test_genbatchproof_colmajor_equals_rowmajor(tmp_path):
+    """Prover::genBatchProof (host/zkprover_batch): the three STARKs with column-major bundles == with row-major bundles (FNV of the batch proof's
+    zkin text), witness upload pipelined and sequential"""
+    from tools import make_stark_bundle as B
+    if not _programs_built():
+        pytest.skip("converted reference programs not built (needs the reference tree at build time)")
+    exe = os.path.join(ROOT, "xlayer_prover_amd", "host", "zkprover_batch")
+
+    def config(name, cm):
+        bundles = {"zkevm": B.make("zkevm", 14, True, out=str(tmp_path / f"zk{cm}"), colmajor=cm), "c12a": B.make("c12a", 20, False, out=str(tmp_path / f"c12a{cm}"), colmajor=cm),
+                   "recursive1": B.make("recursive1", 17, False, out=str(tmp_path / f"r1{cm}"), colmajor=cm)}
+        cfg = {"runFileGenBatchProof": True, "saveOutputToFile": False, "saveProofToFile": False, "outputPath": str(tmp_path), "xlpSyntheticLookups": True}
+        for n, b in bundles.items():
+            cfg[n + "StarkInfo"] = os.path.join(b, f"{n}.starkinfo.json")
+            cfg[n + "ConstPols"] = f"synthetic:{CSEED + len(n)}"
+            cfg[n + "ConstantsTree"] = ""
+            cfg[n + "Verkey"] = ""
+        f = tmp_path / name
+        f.write_text(json.dumps(cfg))
+        return str(f)
+    outs = {}
+    for cm in (False, True):
+        for extra in ([], ["--sequential-upload"]):
+            r = subprocess.run([exe, "-c", config(f"cfg{cm}.json", cm), "--proofs", "2"] + extra, capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stderr[-3000:]
+            lines = [json.loads(l) for l in r.stdout.strip().splitlines()]
+            assert lines[0]["batch_proof_fnv"] == lines[1]["batch_proof_fnv"]          # the second proof of a process (resident constants, reused scratch)
+            outs[(cm, bool(extra))] = lines[-1]
+    ref = outs[(False, False)]
+    for k, v in outs.items():
+        assert v["batch_proof_fnv"] == ref["batch_proof_fnv"] and v["batch_proof_bytes"] == ref["batch_proof_bytes"], k
+    t = outs[(True, False)]["timers_s"]
+    assert "zkevm.STARK_STEP_1_LDE" in t and "zkevm.STARK_STEP_1_MERKLETREE" in t

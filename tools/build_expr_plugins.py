@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--aliased", action="store_true", help="with --geometry: the one-GPU aliased slab layout -> zkevm.<step>.geo<N>a.so")
     ap.add_argument("--world", type=int, default=0, help="with --geometry: the window layout of one rank of a proof row-sharded over this many ranks "
                     "(tools/zkevm_geometry.py layout_window) -> zkevm.<step>.geo<N>w<G>.so")
+    ap.add_argument("--colmajor", action="store_true", help="with --geometry: column-major device sections (tools/zkevm_geometry.py to_colmajor; XLP_EXPR_COLMAJOR) "
+                    "-> zkevm.<step>.geo<N>[a]c.so")
     a = ap.parse_args()
     sizes = ["full"] if a.full else [int(x) for x in a.log_rows.split(",")]
     geo = None
@@ -55,11 +57,15 @@ def main():
             tabp = G.load_fri_dots(a.geometry, a.aliased, a.circuit, LW)[0]
             geo["step52ns_tab"] = (tabp.code, tabp.ntmp1, tabp.ntmp3)
             a.steps += ",step52ns_tab"
+        if a.colmajor:                                    # (the one-row table programs address their own table: row-major as they are)
+            assert not a.world
+            Lc, ext = G.layout(a.geometry, a.aliased, a.circuit), G.CIRCUITS[a.circuit]["ext"]
+            geo = {st: ((G.to_colmajor(v[0], Lc, ext), v[1], v[2]) if not st.endswith("_tab") else v) for st, v in geo.items()}
     for size in sizes:
         for step in a.steps.split(","):
             lr = (24 if step.endswith("2ns") else 23) if size in ("full", "geo") else size
             src = os.path.join(R.REF_DIR, f"{a.circuit if geo else 'zkevm'}.{step.replace('_opt', '').replace('_tab', '')}.xlpexpr")
-            name = f"{a.circuit}.{step}.geo{a.geometry}{'a' if a.aliased else ''}{f'w{a.world}' if a.world else ''}" if geo else f"zkevm.{step}.n{lr}"
+            name = f"{a.circuit}.{step}.geo{a.geometry}{'a' if a.aliased else ''}{f'w{a.world}' if a.world else ''}{'c' if a.colmajor else ''}" if geo else f"zkevm.{step}.n{lr}"
             so = os.path.join(R.REF_DIR, name + ".so")
             if not os.path.exists(src):
                 print("missing", src); continue
@@ -68,7 +74,7 @@ def main():
                 code, ntmp1, ntmp3 = geo[step]
             else:
                 code, _ = R.shrink(code, 1 << lr)
-            p = capi.ExprProgram(code, ntmp1, ntmp3)
+            p = capi.ExprProgram(code, ntmp1, ntmp3, colmajor=bool(geo) and a.colmajor and not step.endswith("_tab"))
             # regenerate the launcher text (cheap) and rebuild only if it changed: its signature covers the whole
             # compiled program, so a change of the library's compile step invalidates the plugin too
             build = os.path.join(R.REF_DIR, "build")

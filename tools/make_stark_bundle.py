@@ -37,24 +37,34 @@ def write_tab(path, prog, n_ext):
         f.write(struct.pack("<5Q", MAGIC_TAB, prog.ntmp1, prog.ntmp3, code.size, n_ext)); f.write(code.tobytes())
 
 
-def geo_tag(log_n, aliased=False, world=0):
-    return f"geo{log_n}{'a' if aliased else ''}{f'w{world}' if world else ''}"
+def geo_tag(log_n, aliased=False, world=0, colmajor=False):
+    return f"geo{log_n}{'a' if aliased else ''}{f'w{world}' if world else ''}{'c' if colmajor else ''}"
 
 
-def bundle_dir(circ, log_n, aliased, world=0):
-    return os.path.join(R.REF_DIR, "bundles", f"{circ}.{geo_tag(log_n, aliased, world)}")
+def bundle_dir(circ, log_n, aliased, world=0, colmajor=False):
+    return os.path.join(R.REF_DIR, "bundles", f"{circ}.{geo_tag(log_n, aliased, world, colmajor)}")
 
 
-def make(circ, log_n, aliased, out=None, fri_steps=None, queries=None, use_opt=True, use_dots=True, world=0):
+def make(circ, log_n, aliased, out=None, fri_steps=None, queries=None, use_opt=True, use_dots=True, world=0, colmajor=False):
     """world > 0: the bundle of ONE RANK of a proof row-sharded over `world` ranks (every rank uses the same files): window starkinfo,
     programs relocated to the window slab (tools/zkevm_geometry.py layout_window), and per step the next-row stores whose halo rows go
-    back to their owner"""
-    out = out or bundle_dir(circ, log_n, aliased, world)
+    back to their owner.
+    colmajor: COLUMN-MAJOR device sections (include/xlp_gl.h, XLP_EXPR_COLMAJOR): the same slab packing, every section stored as columns
+    (the extended ones coset-major); the programs are converted last (tools/zkevm_geometry.py to_colmajor), the starkinfo and the manifest
+    say "colMajor": true"""
+    assert not (world and colmajor), "the row-sharded windows are row-major"
+    out = out or bundle_dir(circ, log_n, aliased, world, colmajor)
     os.makedirs(out, exist_ok=True)
-    geo = geo_tag(log_n, aliased, world)
+    geo = geo_tag(log_n, aliased, world, colmajor)
     LW = G.layout_window(log_n, world, circ) if world else None
     progs, info = G.load(log_n, aliased, circ, LW)
-    json.dump(G.synth_starkinfo(circ, log_n, aliased, fri_steps, queries, world), open(os.path.join(out, f"{circ}.starkinfo.json"), "w"))
+    si = G.synth_starkinfo(circ, log_n, aliased, fri_steps, queries, world)
+    L = LW or G.layout(log_n, aliased, circ)
+    ext = G.CIRCUITS[circ]["ext"]
+    cm = (lambda code: G.to_colmajor(code, L, ext)) if colmajor else (lambda code: code)
+    if colmajor:
+        si["xlp"]["colMajor"] = True
+    json.dump(si, open(os.path.join(out, f"{circ}.starkinfo.json"), "w"))
     man = {}
     rel = lambda p: os.path.relpath(p, out)
 
@@ -62,11 +72,11 @@ def make(circ, log_n, aliased, out=None, fri_steps=None, queries=None, use_opt=T
         so = os.path.join(R.REF_DIR, name)
         return rel(so) if os.path.exists(so) else None
     for st, (code, n1, n3) in progs.items():
-        write_prog(os.path.join(out, f"{circ}.{st}.xlpexpr"), code, n1, n3)
+        write_prog(os.path.join(out, f"{circ}.{st}.xlpexpr"), cm(code), n1, n3)
         man[st] = {"prog": f"{circ}.{st}.xlpexpr", "plugin": plugin(f"{circ}.{st}.{geo}.so")}
     if use_opt:
         for st, ((rc, r1, r3), tabp, n_ext, stats) in G.load_opt(log_n, aliased, circ, LW).items():
-            write_prog(os.path.join(out, f"{circ}.{st}.opt.xlpexpr"), rc, r1, r3)
+            write_prog(os.path.join(out, f"{circ}.{st}.opt.xlpexpr"), cm(rc), r1, r3)
             e = {"prog": f"{circ}.{st}.opt.xlpexpr", "plugin": plugin(f"{circ}.{st}_opt.{geo}.so"), "n_ext": n_ext}
             if tabp.ninstr:
                 write_tab(os.path.join(out, f"{circ}.{st}.tab.xlpexpr"), tabp, n_ext)
@@ -75,14 +85,21 @@ def make(circ, log_n, aliased, out=None, fri_steps=None, queries=None, use_opt=T
     if use_opt and use_dots:
         tabp, dots, rowp, n_ext = G.load_fri_dots(log_n, aliased, circ, LW)
         write_tab(os.path.join(out, f"{circ}.step52ns.dtab.xlpexpr"), tabp, n_ext)
-        write_prog(os.path.join(out, f"{circ}.step52ns.drow.xlpexpr"), rowp.code, rowp.ntmp1, rowp.ntmp3)
+        rows_ext = 1 << (log_n + ext)
+        drow = rowp.code
+        if colmajor:                                           # the row program reads the kernel's output: 3 * ngroups columns of rows_ext words
+            drow = G.to_colmajor(drow, {"dots": (0, 3 * dots["ngroups"], rows_ext)}, ext)
+        write_prog(os.path.join(out, f"{circ}.step52ns.drow.xlpexpr"), drow, rowp.ntmp1, rowp.ntmp3)
         ents = []
         for x, g, k in dots["entries"]:
             if x.kind == E.K_POLS:
-                ents += [0, x.params[0], x.params[1], x.dim, g, k]
+                ents.append((0, x.params[0], x.params[1], x.dim, g, k))
             else:
                 assert x.kind == E.K_CONST2NS
-                ents += [1, x.params[0], 0, 1, g, k]
+                ents.append((1, x.params[0], 0, 1, g, k))
+        if colmajor:
+            ents = G.dots_to_colmajor(ents, L)
+        ents = [v for e in ents for v in e]
         with open(os.path.join(out, f"{circ}.step52ns.dots"), "wb") as f:
             f.write(struct.pack("<3Q", MAGIC_DOTS, dots["ngroups"], len(dots["entries"]))); f.write(np.array(ents, dtype="<u8").tobytes())
         man["step52ns"] = {"prog": f"{circ}.step52ns.drow.xlpexpr", "tab": f"{circ}.step52ns.dtab.xlpexpr", "n_ext": n_ext, "dots": f"{circ}.step52ns.dots",
@@ -90,7 +107,7 @@ def make(circ, log_n, aliased, out=None, fri_steps=None, queries=None, use_opt=T
     if world:
         for st, (code, n1, n3) in progs.items():               # (the rewritten forms store to the same places)
             man[st]["nextRowStores"] = [list(x) for x in G.next_row_stores(code, LW)]
-    json.dump({"steps": man}, open(os.path.join(out, f"{circ}.steps.json"), "w"), indent=1)
+    json.dump({"steps": man, "colMajor": bool(colmajor)}, open(os.path.join(out, f"{circ}.steps.json"), "w"), indent=1)
     return out
 
 
@@ -103,9 +120,10 @@ def main():
     ap.add_argument("--no-opt", action="store_true")
     ap.add_argument("--no-dots", action="store_true")
     ap.add_argument("--world", type=int, default=0, help="the per-rank bundle of a proof row-sharded over this many ranks (window layout)")
+    ap.add_argument("--colmajor", action="store_true", help="column-major device sections (one-GPU layouts)")
     a = ap.parse_args()
     ln = a.log_n or G.CIRCUITS[a.circuit]["log_n"]
-    print(make(a.circuit, ln, a.aliased, a.out or None, use_opt=not a.no_opt, use_dots=not a.no_dots, world=a.world))
+    print(make(a.circuit, ln, a.aliased, a.out or None, use_opt=not a.no_opt, use_dots=not a.no_dots, world=a.world, colmajor=a.colmajor))
 
 
 if __name__ == "__main__":

@@ -78,6 +78,8 @@ SIGNATURES = {
     "xlp_dev_merkle_levels": [_pu, _u64],
     "xlp_dev_commit": [_pu, _pu, _pu, _u64, _u64, _u64],
     "xlp_dev_commit_last_times": [C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    "xlp_dev_evmap_cm": [_pu, _pu, _pu, _u64, C.c_uint32, _pu],
+    "xlp_dev_dot_columns_cm": [_pu, _u64, _pu, _u64, C.c_uint32, _pu, _u64, _u64],
     "xlp_dev_rows_to_cm": [_pu, _u64, _u64, _pu, _u64, _u64, _u64, _u64, C.c_uint32],
     "xlp_dev_cm_to_rows": [_pu, _u64, _u64, _pu, _u64, _u64, _u64, _u64, C.c_uint32],
     "xlp_dev_copy_view": [_pu, _u64, _u64, _pu, _u64, _u64, _u64, C.c_uint32],
@@ -715,6 +717,34 @@ def dev_dot_columns(out, entries, ngroups, coefs, nrows):
     """out[row][g] = sum of coefs[coef_e] * column_e[row] over the entries of group g (xlp_dev_dot_columns)"""
     arr = entries if isinstance(entries, C.Array) else dot_entries(entries)
     _ck(load().xlp_dev_dot_columns(_dp(out), C.cast(arr, C.c_void_p), len(arr), ngroups, _dp(coefs), coefs.numel(), nrows), "xlp_dev_dot_columns")
+
+
+def evmap_entries_cm(entries):
+    """entries: list of (column-major section tensor, rows per column, column, dim, prime): the columns' first words (coset 0)"""
+    arr = (EvmapEntry * len(entries))()
+    for i, (t, rows, col, dim, prime) in enumerate(entries):
+        arr[i] = EvmapEntry(t.data_ptr() + 8 * col * rows, rows, dim, 1 if prime else 0)
+    arr._keep = [e[0] for e in entries]
+    return arr
+
+
+def dev_evmap_cm(evals, LEv, LpEv, n, entries):
+    arr = entries if isinstance(entries, C.Array) else evmap_entries_cm(entries)
+    _ck(load().xlp_dev_evmap_cm(_dp(evals), _dp(LEv), _dp(LpEv), n, len(arr), C.cast(arr, C.c_void_p)), "xlp_dev_evmap_cm")
+
+
+def dot_entries_cm(entries):
+    """entries: list of (column-major section tensor, rows per column, column, dim, group, coefficient index)"""
+    arr = (DotEntry * len(entries))()
+    for i, (t, rows, col, dim, group, coef) in enumerate(entries):
+        arr[i] = DotEntry(t.data_ptr() + 8 * col * rows, rows, dim, group, coef)
+    arr._keep = [e[0] for e in entries]
+    return arr
+
+
+def dev_dot_columns_cm(out, out_cstride, entries, ngroups, coefs, nrows):
+    arr = entries if isinstance(entries, C.Array) else dot_entries_cm(entries)
+    _ck(load().xlp_dev_dot_columns_cm(_dp(out), out_cstride, C.cast(arr, C.c_void_p), len(arr), ngroups, _dp(coefs), coefs.numel(), nrows), "xlp_dev_dot_columns_cm")
 
 
 def to_np(t):

@@ -523,6 +523,253 @@ int dev_evmap(Ctx* ctx, u64* evals, const u64* LEv, const u64* LpEv, u64 n, u32 
 }
 
 
+// ------------------------------------------------------------------ evmap on column-major sections
+// The same sums with the columns stored contiguously (colmajor.hip): coset 0 of an extended column IS the column at the rows (k << eb), so
+// an entry is the pointer to its first word and the next-row entries read word k + 1 (wrapping at n).  Lanes still run along the ENTRIES in
+// the arithmetic (the multiplier limbs of a row are wave-uniform), but the global reads run along the ROWS: a workgroup takes 64 sub-entries,
+// each wave loads 64 rows of 16 of them (512 contiguous bytes per instruction), the tile is turned through LDS, and wave w accumulates rows
+// 16 w .. 16 w + 15 of the tile for all 64 entries; the four partial sums meet in LDS at the end of the row chunk.
+constexpr int EC_T = 256, EC_E = 64, EC_ROWS = 4096;
+struct EvEntryCm { const u64* col; u32 variant; u32 prime; u32 sub; u32 pad; };
+__global__ __launch_bounds__(EC_T) void evmap_cm_partial_kernel(u64* partial, const u64* LEv, const u64* LpEv, u64 n, const EvEntryCm* ents, u32 nsub)
+{
+    __shared__ u32 sL[2][EV_SUB * 15];
+    __shared__ u64 tile[64][EC_E + 1];
+    const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const u32 e0 = blockIdx.x * EC_E;
+    const u32 ei = e0 + lane;
+    const bool live = ei < nsub;
+    const EvEntryCm e = ents[live ? ei : 0];
+    const u64 k0 = (u64)blockIdx.y * EC_ROWS;
+    const u64 k1 = k0 + EC_ROWS < n ? k0 + EC_ROWS : n;
+    const u32 i0 = 3 * (e.variant == 0 ? 0 : (e.variant == 1 ? 2 : 1)), i1 = 3 * (e.variant == 0 ? 1 : (e.variant == 1 ? 3 : 4)), i2 = 3 * (e.variant == 0 ? 2 : (e.variant == 1 ? 1 : 3));
+    const u32* l = sL[e.prime ? 1 : 0];
+    DcSum S[3];
+    S[0].clear(); S[1].clear(); S[2].clear();
+    u32 since = 0;
+    for (u64 s0 = k0; s0 < k1; s0 += EV_SUB) {
+        const u32 rows = (u32)(k1 - s0 < EV_SUB ? k1 - s0 : EV_SUB);
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < rows * 2; i += EC_T) {
+            const u32 r = i >> 1;
+            const u64* src = (i & 1) ? LpEv : LEv;
+            u32* d = &sL[i & 1][15 * r];
+            const u64 a0 = gl::canon(src[3 * (s0 + r)]), a1 = gl::canon(src[3 * (s0 + r) + 1]), a2 = gl::canon(src[3 * (s0 + r) + 2]);
+            const u64 m[5] = {a0, a1, a2, gl::addc(a0, a2), gl::addc(a1, a2)};
+#pragma unroll
+            for (int q = 0; q < 5; q++) { d[3 * q] = (u32)m[q] & 0x3FFFFFu; d[3 * q + 1] = (u32)(m[q] >> 22) & 0x1FFFFFu; d[3 * q + 2] = (u32)(m[q] >> 43); }
+        }
+        if (since + (rows + 3) / 4 > EV_FOLD) { S[0].flush(); S[1].flush(); S[2].flush(); since = 0; }    // a wave adds a quarter of the rows
+        since += (rows + 3) / 4;
+        for (u32 t0 = 0; t0 < rows; t0 += 64) {
+            const u32 trows = rows - t0 < 64 ? rows - t0 : 64;
+            __syncthreads();                                   // sL staged (first tile) / previous tile consumed
+            // load: this wave's 16 entries, lane = row of the tile
+            u64 v[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const u32 ej = e0 + wv * 16 + j;
+                v[j] = 0;
+                if (ej < nsub && lane < trows) {
+                    const EvEntryCm x = ents[ej];               // wave-uniform
+                    u64 k = s0 + t0 + lane + x.prime;
+                    if (k >= n) k -= n;
+                    v[j] = x.col[k];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) tile[lane][wv * 16 + j] = v[j];
+            __syncthreads();
+            // accumulate: lane = entry, this wave's rows of the tile
+            if (live) {
+#pragma unroll 4
+                for (u32 rr = wv * 16; rr < wv * 16 + 16; rr++) {
+                    if (rr >= trows) break;
+                    const u32* lr = l + 15 * (t0 + rr);
+                    const u64 x = tile[rr][lane];
+                    S[0].mac(lr[i0], lr[i0 + 1], lr[i0 + 2], x);
+                    S[1].mac(lr[i1], lr[i1 + 1], lr[i1 + 2], x);
+                    S[2].mac(lr[i2], lr[i2 + 1], lr[i2 + 2], x);
+                }
+            }
+        }
+    }
+    // the four waves' sums of the same 64 entries
+    __syncthreads();
+    for (int c = 0; c < 3; c++) { S[c].flush(); tile[wv * 3 + c][lane] = S[c].r; }
+    __syncthreads();
+    if (wv == 0 && live) {
+        u64* dst = partial + ((u64)blockIdx.y * nsub + e.sub) * 3;
+        for (int c = 0; c < 3; c++) dst[c] = gl::addc(gl::addc(tile[c][lane], tile[3 + c][lane]), gl::addc(tile[6 + c][lane], tile[9 + c][lane]));
+    }
+}
+
+// entries: pol = the column's first word (coset 0 of an extended column), row_stride = the words between the components of an extension column
+int dev_evmap_cm(Ctx* ctx, u64* evals, const u64* LEv, const u64* LpEv, u64 n, u32 nev, const xlp_evmap_entry* entries)
+{
+    if (!nev) return 0;
+    if (!n) { XLP_HIP(hipMemsetAsync(evals, 0, (size_t)nev * 24, ctx->stream)); return 0; }
+    const u64 nchunks = (n + EC_ROWS - 1) / EC_ROWS;
+    std::vector<EvEntryCm> h;
+    std::vector<u32> first(nev + 1);
+    for (u32 i = 0; i < nev; i++) {
+        if (entries[i].dim != 1 && entries[i].dim != 3) return xlp_fail("evmap: dim must be 1 or 3");
+        first[i] = (u32)h.size();
+        for (u32 v = 0; v < entries[i].dim; v++) h.push_back(EvEntryCm{entries[i].pol + v * entries[i].row_stride, v, entries[i].prime ? 1u : 0u, (u32)h.size(), 0});
+    }
+    const u32 nsub = (u32)h.size();
+    first[nev] = nsub;
+    u64* scratch = nullptr;
+    const size_t ent_bytes = ((size_t)nsub * sizeof(EvEntryCm) + 255) / 256 * 256;
+    const size_t first_bytes = ((size_t)(nev + 1) * 4 + 255) / 256 * 256;
+    if (ctx_scratch(ctx, ent_bytes + first_bytes + nchunks * nsub * 24, 2, &scratch)) return -1;
+    XLP_HIP(hipMemcpyAsync(scratch, h.data(), nsub * sizeof(EvEntryCm), hipMemcpyHostToDevice, ctx->stream));
+    u32* dfirst = (u32*)((char*)scratch + ent_bytes);
+    XLP_HIP(hipMemcpyAsync(dfirst, first.data(), (nev + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    XLP_HIP(hipStreamSynchronize(ctx->stream));   // h, first go out of scope
+    u64* partial = (u64*)((char*)scratch + ent_bytes + first_bytes);
+    hipLaunchKernelGGL(evmap_cm_partial_kernel, dim3((nsub + EC_E - 1) / EC_E, (unsigned)nchunks), dim3(EC_T), 0, ctx->stream, partial, LEv, LpEv, n, (const EvEntryCm*)scratch, nsub);
+    hipLaunchKernelGGL(evmap_final_kernel, dim3((nev * 3 + 63) / 64), dim3(64), 0, ctx->stream, evals, partial, nchunks, nev, nsub, dfirst);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ dot_columns on column-major sections
+// out column 3 g + c (out_cstride words apart) = component c of sum_e coefs[coef_e] * pol_e over the entries of group g, for the storage rows
+// [0, nrows) -- every named column holds at least nrows words.  Lanes are rows here without any transposition: a wave reads 1 KiB of one column
+// per instruction (two rows per lane), the coefficient limbs are wave-uniform scalars.  One workgroup = 128 rows, three waves: WAVE = COMPONENT
+// of the Fp^3 sums, as in the row-major kernel.  The host groups the entries by COLUMN: a column word is loaded once and multiplied into the
+// accumulators of all ngroups groups (limbs zero where a group does not name the column; several entries of one group on one column are summed
+// when the records are expanded), so which accumulator a product goes to is static.
+constexpr int DCM_T = 192, DCM_ROWS = 128;
+struct DcmContrib { u32 col, group, variant, pad; u64 coef; };     // entry -> column record `col`, group, multiplier variant (1, a, a^2), coefficient index
+// rec[col]: {ptr lo, ptr hi, pad, pad} then limbs[comp][g][3] (u32), g < 4: 4 + 36 dwords
+constexpr u32 DCM_REC = 40;
+__global__ void dcm_expand_kernel(u32* rec, const DcmContrib* con, const u32* cfirst, u32 ncol, const u64* coefs)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ncol * 12) return;
+    const u32 col = t / 12, comp = (t % 12) / 4, g = t % 4;
+    u64 k = 0;
+    for (u32 i = cfirst[col]; i < cfirst[col + 1]; i++) {
+        if (con[i].group != g) continue;
+        const u64* c3 = coefs + 3 * con[i].coef;
+        const u64 k0 = gl::canon(c3[0]), k1 = gl::canon(c3[1]), k2 = gl::canon(c3[2]);
+        // the multiplier of this column word: k, a k = (k2, k0 + k2, k1), a^2 k = (k1, k1 + k2, k0 + k2)
+        const u64 m0 = con[i].variant == 0 ? k0 : con[i].variant == 1 ? k2 : k1;
+        const u64 m1 = con[i].variant == 0 ? k1 : con[i].variant == 1 ? gl::addc(k0, k2) : gl::addc(k1, k2);
+        const u64 m2 = con[i].variant == 0 ? k2 : con[i].variant == 1 ? k1 : gl::addc(k0, k2);
+        k = gl::addc(k, comp == 0 ? m0 : comp == 1 ? m1 : m2);
+    }
+    u32* d = rec + (u64)col * DCM_REC + 4 + (comp * 4 + g) * 3;
+    d[0] = (u32)k & 0x3FFFFFu; d[1] = (u32)(k >> 22) & 0x1FFFFFu; d[2] = (u32)(k >> 43);
+}
+
+template <int G>
+__global__ __launch_bounds__(DCM_T) void dot_columns_cm_kernel(u64* out, u64 out_cstride, const u32* __restrict__ rec, u32 ncol, u64 nrows)
+{
+    const u32 lane = threadIdx.x & 63, comp = threadIdx.x >> 6;
+    const u64 row = (u64)blockIdx.x * DCM_ROWS + 2 * lane;
+    const bool ok0 = row < nrows, ok1 = row + 1 < nrows;
+    DcSum S[G][2];
+#pragma unroll
+    for (int g = 0; g < G; g++) { S[g][0].clear(); S[g][1].clear(); }
+    constexpr int U = 4;
+    u32 since = 0;
+    for (u32 c0 = 0; c0 < ncol; c0 += U) {
+        if (since + U > 1024) {
+#pragma unroll
+            for (int g = 0; g < G; g++) { S[g][0].flush(); S[g][1].flush(); }
+            since = 0;
+        }
+        since += U;
+        u64 v0[U], v1[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const u32 c = c0 + j < ncol ? c0 + j : ncol - 1;
+            const u32* r = rec + (u64)c * DCM_REC;
+            const u64* p = (const u64*)(((u64)r[1] << 32) | r[0]);
+            v0[j] = ok0 ? p[row] : 0;
+            v1[j] = ok1 ? p[row + 1] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            if (c0 + j >= ncol) break;
+            const u32* r = rec + (u64)(c0 + j) * DCM_REC + 4 + comp * 12;
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                const u32 l0 = r[3 * g], l1 = r[3 * g + 1], l2 = r[3 * g + 2];
+                S[g][0].mac(l0, l1, l2, v0[j]);
+                S[g][1].mac(l0, l1, l2, v1[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        S[g][0].flush(); S[g][1].flush();
+        u64* dst = out + (u64)(3 * g + comp) * out_cstride + row;
+        if (ok0) dst[0] = S[g][0].r;
+        if (ok1) dst[1] = S[g][1].r;
+    }
+}
+
+// entries: pol = the column's first word, row_stride = the words between the components of an extension column (dim 3)
+int dev_dot_columns_cm(Ctx* ctx, u64* out, u64 out_cstride, const xlp_dot_entry* entries, u64 nentries, u32 ngroups, const u64* coefs, u64 coefs_size, u64 nrows)
+{
+    if (ngroups < 1 || ngroups > 4) return xlp_fail("dot columns: 1..4 groups");
+    if (!nrows) return 0;
+    if (out_cstride < nrows) return xlp_fail("dot columns (column-major): output column stride smaller than the rows");
+    std::vector<std::pair<const u64*, DcmContrib>> all;
+    for (u64 i = 0; i < nentries; i++) {
+        const xlp_dot_entry& x = entries[i];
+        if (x.dim != 1 && x.dim != 3) return xlp_fail("dot columns: dim must be 1 or 3");
+        if (x.group >= ngroups) return xlp_fail("dot columns: group out of range");
+        if (x.coef * 3 + 3 > coefs_size) return xlp_fail("dot columns: coefficient index out of range");
+        for (u32 v = 0; v < x.dim; v++) all.push_back({x.pol + v * x.row_stride, DcmContrib{0, x.group, v, 0, x.coef}});
+    }
+    std::stable_sort(all.begin(), all.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    std::vector<DcmContrib> con;
+    std::vector<u32> cfirst;
+    std::vector<u32> rec;
+    for (size_t i = 0; i < all.size(); i++) {
+        if (i == 0 || all[i].first != all[i - 1].first) {
+            cfirst.push_back((u32)con.size());
+            const u64 ptr = (u64)(uintptr_t)all[i].first;
+            rec.resize(rec.size() + DCM_REC, 0);
+            rec[rec.size() - DCM_REC] = (u32)ptr; rec[rec.size() - DCM_REC + 1] = (u32)(ptr >> 32);
+        }
+        DcmContrib c = all[i].second;
+        c.col = (u32)cfirst.size() - 1;
+        con.push_back(c);
+    }
+    const u32 ncol = (u32)cfirst.size();
+    cfirst.push_back((u32)con.size());
+    if (!ncol) {                                          // no entries: every sum is zero
+        for (u32 k = 0; k < 3 * ngroups; k++) XLP_HIP(hipMemsetAsync(out + (u64)k * out_cstride, 0, nrows * sizeof(u64), ctx->stream));
+        return 0;
+    }
+    u64* scratch = nullptr;
+    const size_t rec_b = ((size_t)rec.size() * 4 + 255) / 256 * 256, con_b = ((size_t)con.size() * sizeof(DcmContrib) + 255) / 256 * 256, cf_b = ((size_t)cfirst.size() * 4 + 255) / 256 * 256;
+    if (ctx_scratch(ctx, rec_b + con_b + cf_b, 2, &scratch)) return -1;
+    u32* drec = (u32*)scratch;
+    DcmContrib* dcon = (DcmContrib*)((char*)scratch + rec_b);
+    u32* dcf = (u32*)((char*)scratch + rec_b + con_b);
+    XLP_HIP(hipMemcpyAsync(drec, rec.data(), rec.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    XLP_HIP(hipMemcpyAsync(dcon, con.data(), con.size() * sizeof(DcmContrib), hipMemcpyHostToDevice, ctx->stream));
+    XLP_HIP(hipMemcpyAsync(dcf, cfirst.data(), cfirst.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    XLP_HIP(hipStreamSynchronize(ctx->stream));            // the host vectors go out of scope
+    hipLaunchKernelGGL(dcm_expand_kernel, dim3((ncol * 12 + 255) / 256), dim3(256), 0, ctx->stream, drec, dcon, dcf, ncol, coefs);
+    const dim3 grid((unsigned)((nrows + DCM_ROWS - 1) / DCM_ROWS)), block(DCM_T);
+    switch (ngroups) {
+    case 1: hipLaunchKernelGGL(dot_columns_cm_kernel<1>, grid, block, 0, ctx->stream, out, out_cstride, drec, ncol, nrows); break;
+    case 2: hipLaunchKernelGGL(dot_columns_cm_kernel<2>, grid, block, 0, ctx->stream, out, out_cstride, drec, ncol, nrows); break;
+    case 3: hipLaunchKernelGGL(dot_columns_cm_kernel<3>, grid, block, 0, ctx->stream, out, out_cstride, drec, ncol, nrows); break;
+    default: hipLaunchKernelGGL(dot_columns_cm_kernel<4>, grid, block, 0, ctx->stream, out, out_cstride, drec, ncol, nrows); break;
+    }
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------ dot_columns
 // out[row][g] = sum_e coefs[coef_e] * pol_e[row]  (Fp^3 coefficient x column of dimension 1 or 3), e over the entries of group g.
 // The linear part of the FRI polynomial (starks.cpp:371-380) once its Horner chains are dot products (expr_opt.py): at the zkEVM

@@ -524,6 +524,23 @@ int xlp_dev_evmap(uint64_t* evals, const uint64_t* LEv, const uint64_t* LpEv, ui
     return dev_evmap(&g_ctx, evals, LEv, LpEv, n, extend_bits, nev, entries);
 }
 
+int xlp_dev_evmap_cm(uint64_t* evals, const uint64_t* LEv, const uint64_t* LpEv, uint64_t n, uint32_t nev, const xlp_evmap_entry* entries)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if (nev && !entries) return xlp_fail("xlp_dev_evmap_cm: null entries");
+    return dev_evmap_cm(&g_ctx, evals, LEv, LpEv, n, nev, entries);
+}
+int xlp_dev_dot_columns_cm(uint64_t* out, uint64_t out_cstride, const xlp_dot_entry* entries, uint64_t nentries, uint32_t ngroups,
+                           const uint64_t* coefs, uint64_t coefs_size, uint64_t nrows)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if (!nrows || !ngroups) return 0;
+    if (!out || (nentries && (!entries || !coefs))) return xlp_fail("xlp_dev_dot_columns_cm: null pointer");
+    return dev_dot_columns_cm(&g_ctx, out, out_cstride, entries, nentries, ngroups, coefs, coefs_size, nrows);
+}
+
 int xlp_profile_enable(int on)
 {
     XLP_ENTER;

@@ -113,6 +113,8 @@ int dev_geometric(Ctx* ctx, u64* out, u64 n, u32 dim, const u64* first, const u6
 int dev_x_div_x_sub_xi(Ctx* ctx, u64* out, const u64* x, const u64* xi, u64 n);
 int dev_dot_columns(Ctx* ctx, u64* out, const xlp_dot_entry* entries, u64 nentries, u32 ngroups, const u64* coefs, u64 coefs_size, u64 nrows);
 int dev_evmap(Ctx* ctx, u64* evals, const u64* LEv, const u64* LpEv, u64 n, u32 eb, u32 nev, const xlp_evmap_entry* entries);
+int dev_evmap_cm(Ctx* ctx, u64* evals, const u64* LEv, const u64* LpEv, u64 n, u32 nev, const xlp_evmap_entry* entries);
+int dev_dot_columns_cm(Ctx* ctx, u64* out, u64 out_cstride, const xlp_dot_entry* entries, u64 nentries, u32 ngroups, const u64* coefs, u64 coefs_size, u64 nrows);
 
 
 // bn128.hip (Poseidon-BN128, MerkleTreeBN128)

@@ -88,6 +88,16 @@ struct XlpHashGL
     {
         XLP_CHECK(xlp_dev_commit_from_host(secn, sec2ns, tree->d_nodes, h_src, NExtended, N, W, busyMs));
     }
+    // the same two on column-major sections (csn / cs2: words between the columns of the base / extended section)
+    static void commitCm(Tree* tree, uint64_t* sec2ns, uint64_t cs2, const uint64_t* secn, uint64_t csn, uint64_t NExtended, uint64_t N, uint64_t W)
+    {
+        XLP_CHECK(xlp_dev_commit_cm(sec2ns, cs2, tree->d_nodes, secn, csn, NExtended, N, W));
+    }
+    static void commitFromHostCm(Tree* tree, uint64_t* secn, uint64_t csn, uint64_t* sec2ns, uint64_t cs2, const uint64_t* h_src, uint64_t* stage, uint64_t stageWords,
+                                 uint64_t NExtended, uint64_t N, uint64_t W, double* busyMs)
+    {
+        XLP_CHECK(xlp_dev_commit_from_host_cm(secn, csn, sec2ns, cs2, tree->d_nodes, h_src, stage, stageWords, NExtended, N, W, busyMs));
+    }
     static void storeRoots(Proof& proof, Goldilocks::Element* r0, Goldilocks::Element* r1, Goldilocks::Element* r2, Goldilocks::Element* r3)
     {
         std::memcpy(&proof.proofs.root1[0], r0, HASH_SIZE * sizeof(Goldilocks::Element));
@@ -119,6 +129,11 @@ private:
     uint64_t slabWords = 0;
     bool const2nsInSlab = false;
     uint64_t const2nsOffset = 0;
+    // COLUMN-MAJOR device sections ("xlp": {"colMajor": true} in the starkinfo; include/xlp_gl.h): every section of the device slab is stored
+    // as columns at the offsets and sizes the starkinfo names (the extended ones coset-major), the constant polynomials likewise; the step
+    // programs of the bundle are converted to match.  The host slab pAddress keeps the reference's row-major form: the witness is transposed
+    // band by band as it arrives, opened rows are gathered.  One-GPU mode only.
+    bool colMajor = false;
     uint64_t *d_const_n = NULL, *d_const_2ns_own = NULL, *d_x_n = NULL, *d_x_2ns = NULL, *d_zi = NULL, *d_xdx = NULL, *d_xdwx = NULL;
     uint64_t *d_challenges = NULL, *d_publics = NULL, *d_evals = NULL, *d_work = NULL;
     typename H::Tree* treesGL[STARK_C12_A_NUM_TREES] = {NULL, NULL, NULL, NULL, NULL};
@@ -146,13 +161,19 @@ private:
     uint64_t* d_const_2ns_res = NULL;
     uint64_t proofsDone = 0;
     uint64_t* constPols2ns() { return d_const_2ns_res ? d_const_2ns_res : const2nsInSlab ? mem() + const2nsOffset : d_const_2ns_own; }
-    struct PolRef { uint64_t* p; uint64_t n, dim, stride; };
+    struct PolRef { uint64_t* p; uint64_t n, dim, stride, cs; };   // element i, component c at p[i * stride + c * cs]
     PolRef pol(uint64_t id)          // StarkInfo::getPolinomial on the device slab
     {
         if (id >= starkInfo.varPolMap.size()) xlp_exit_process("Starks: polynomial id out of range");
         const VarPolMap& m = starkInfo.varPolMap[id];
-        return {mem() + starkInfo.mapOffsets.section[m.section] + m.sectionPos, starkInfo.mapDeg.section[m.section], m.dim, starkInfo.mapSectionsN.section[m.section]};
+        const uint64_t rows = starkInfo.mapDeg.section[m.section];
+        if (colMajor) return {mem() + starkInfo.mapOffsets.section[m.section] + m.sectionPos * rows, rows, m.dim, 1, rows};
+        return {mem() + starkInfo.mapOffsets.section[m.section] + m.sectionPos, rows, m.dim, starkInfo.mapSectionsN.section[m.section], 1};
     }
+    uint64_t colStride(eSection sec) const { return starkInfo.mapDeg.section[sec]; }   // column-major: words between the columns of a section
+    // a polynomial view <-> dense elements (the operands of calculateZ / calculateH1H2 when the sections are column-major)
+    void toDense(uint64_t* dst, const PolRef& r, uint64_t n) { XLP_CHECK(xlp_dev_copy_view(dst, r.dim, 1, r.p, r.stride, r.cs, n, (uint32_t)r.dim)); }
+    void fromDense(const PolRef& r, const uint64_t* src, uint64_t n) { XLP_CHECK(xlp_dev_copy_view(r.p, r.stride, r.cs, src, r.dim, 1, n, (uint32_t)r.dim)); }
     uint64_t exp2pol(uint64_t expId)
     {
         const std::string k = std::to_string(expId);
@@ -663,6 +684,8 @@ public:
         if (starkInfo.mapSectionsN.section[cm4_2ns] != starkInfo.qDim * starkInfo.qDeg) xlp_exit_process("Starks: cm4_2ns must hold qDeg x qDim columns");
         XLP_CHECK(xlp_init((int)config.xlpDevice));
         const2nsInSlab = starkInfo.xlpConst2nsInSlab; const2nsOffset = starkInfo.xlpConst2nsOffset;
+        colMajor = starkInfo.xlpColMajor;
+        if (colMajor && !H::kCommitTimes) xlp_exit_process("Starks: column-major sections need the Goldilocks hash policy");
         slabWords = starkInfo.mapTotalN;
         XlpDeviceSlab::get().reserve(slabWords);
         if (starkInfo.xlpWorld) {                         // a window starkinfo: this Starks is one rank of a row-sharded proof
@@ -679,9 +702,15 @@ public:
         // ---- constant polynomials (LOAD_CONST_POLS_TO_MEMORY, starks.hpp:96-115); sharded: replicated, the programs read a window of them
         if (starkFiles.zkevmConstPols.size() == 0) xlp_exit_process("Starks::Starks() received an empty config.zkevmConstPols");
         uint64_t* constFull = dalloc(N * starkInfo.nConstants);
+        // column-major: the file / the synthetic fill is row-major (the same VALUES in both layouts): it lands in the still unused device slab
+        // and is transposed from there
+        const bool viaSlab = colMajor && slabWords >= NExtended * starkInfo.nConstants;
+        if (colMajor && !viaSlab) xlp_exit_process("Starks: device slab smaller than the extended constants (column-major load)");
+        uint64_t* constLand = colMajor ? mem() : constFull;
         if (starkFiles.zkevmConstPols.rfind("synthetic:", 0) == 0)
-            XLP_CHECK(xlp_dev_fill(constFull, N * starkInfo.nConstants, strtoull(starkFiles.zkevmConstPols.c_str() + 10, NULL, 0), 0));
-        else fileToDevice(constFull, starkFiles.zkevmConstPols, 0, N * starkInfo.nConstants * sizeof(uint64_t));
+            XLP_CHECK(xlp_dev_fill(constLand, N * starkInfo.nConstants, strtoull(starkFiles.zkevmConstPols.c_str() + 10, NULL, 0), 0));
+        else fileToDevice(constLand, starkFiles.zkevmConstPols, 0, N * starkInfo.nConstants * sizeof(uint64_t));
+        if (colMajor) XLP_CHECK(xlp_dev_rows_to_cm(constFull, N, 0, constLand, starkInfo.nConstants, 0, starkInfo.nConstants, N, 0));
         if (sharded) {
             d_const_n_full = constFull;
             d_const_n = dalloc((nLoc + haloN) * starkInfo.nConstants);
@@ -690,6 +719,7 @@ public:
         // ---- constant tree (LOAD_CONST_TREE_TO_MEMORY / LOAD_CONST_POLS_2NS_TO_MEMORY, starks.hpp:117-146)
         if (!const2nsInSlab) d_const_2ns_own = dalloc(NExtended * starkInfo.nConstants);
         treesGL[4] = new typename H::Tree(NExtended, starkInfo.nConstants, constPols2ns(), true);
+        if constexpr (H::kCommitTimes) { if (colMajor) treesGL[4]->setColMajor((uint32_t)extendBits, NExtended); }
         bool treeFromFile = false;
         if constexpr (H::kFileTree) treeFromFile = starkFiles.zkevmConstantsTree.size() && fileExists(starkFiles.zkevmConstantsTree);
         if (treeFromFile) {
@@ -700,11 +730,17 @@ public:
             if (!fp || fread(hdr, 8, 2, fp) != 2) xlp_exit_process("Starks: cannot read the constant tree header");
             fclose(fp);
             if (hdr[0] != starkInfo.nConstants || hdr[1] != NExtended) xlp_exit_process("Starks: constant tree does not match the starkinfo");
-            fileToDevice(constPols2ns(), starkFiles.zkevmConstantsTree, 16, NExtended * starkInfo.nConstants * 8);
+            if (colMajor && !const2nsInSlab) {            // the file's source is row-major, natural order: through the slab, then coset-major columns
+                fileToDevice(mem(), starkFiles.zkevmConstantsTree, 16, NExtended * starkInfo.nConstants * 8);
+                XLP_CHECK(xlp_dev_rows_to_cm(constPols2ns(), NExtended, 0, mem(), starkInfo.nConstants, 0, starkInfo.nConstants, NExtended, (uint32_t)extendBits));
+            } else if (colMajor) {                        // (the extended constants live IN the slab: recomputed from the base ones instead, as in every proof)
+                XLP_CHECK(xlp_dev_extend_cm(constPols2ns(), NExtended, 0, constFull, N, NExtended, N, starkInfo.nConstants));
+            } else fileToDevice(constPols2ns(), starkFiles.zkevmConstantsTree, 16, NExtended * starkInfo.nConstants * 8);
             fileToDevice(treesGL[4]->d_nodes, starkFiles.zkevmConstantsTree, 16 + NExtended * starkInfo.nConstants * 8, H::treeWords(treesGL[4]) * 8);
           }
         } else {
-            XLP_CHECK(xlp_dev_extend(constPols2ns(), constFull, NExtended, N, starkInfo.nConstants, NULL));      // (sharded: d_const_n is only my window)
+            if (colMajor) XLP_CHECK(xlp_dev_extend_cm(constPols2ns(), NExtended, 0, constFull, N, NExtended, N, starkInfo.nConstants));
+            else XLP_CHECK(xlp_dev_extend(constPols2ns(), constFull, NExtended, N, starkInfo.nConstants, NULL));      // (sharded: d_const_n is only my window)
             treesGL[4]->merkelize();
         }
         treesGL[4]->getRoot(constRoot);
@@ -719,7 +755,12 @@ public:
         const uint64_t one = Goldilocks::toU64(Goldilocks::exp(wnE, row0)), wn = Goldilocks::toU64(wnE),
                        sh = Goldilocks::toU64(Goldilocks::mul(Goldilocks::shift(), Goldilocks::exp(wneE, ext0))), wne = Goldilocks::toU64(wneE);
         XLP_CHECK(xlp_dev_geometric(d_x_n, ownN, 1, &one, &wn));
-        XLP_CHECK(xlp_dev_geometric(d_x_2ns, ownE, 1, &sh, &wne));
+        if (colMajor) {                                   // coset-major: x of storage row r N + q = shift w_ext^r (w_N)^q
+            for (uint64_t r = 0; r < (1ULL << extendBits); r++) {
+                const uint64_t first = Goldilocks::toU64(Goldilocks::mul(Goldilocks::shift(), Goldilocks::exp(wneE, r)));
+                XLP_CHECK(xlp_dev_geometric(d_x_2ns + r * N, N, 1, &first, &wn));
+            }
+        } else XLP_CHECK(xlp_dev_geometric(d_x_2ns, ownE, 1, &sh, &wne));
         {
             std::vector<uint64_t> zh(1ULL << extendBits);
             Goldilocks::Element sn = Goldilocks::shift(), w = Goldilocks::one();
@@ -747,6 +788,14 @@ public:
         for (int i = 0; i < 4; i++) {
             if constexpr (H::kShardable) treesGL[i] = new typename H::Tree(NExtended, starkInfo.mapSectionsN.section[secs[i]], NULL, true, sharded ? world : 0, rank);
             else treesGL[i] = new typename H::Tree(NExtended, starkInfo.mapSectionsN.section[secs[i]], NULL, true);
+            if constexpr (H::kCommitTimes) { if (colMajor) treesGL[i]->setColMajor((uint32_t)extendBits, NExtended); }
+        }
+        if (colMajor) {
+            for (int i = 0; i < 11; i++) {
+                const eSection sec = (eSection)i;
+                const uint64_t want = isExtSection(sec) ? NExtended : N;
+                if (starkInfo.mapSectionsN.section[sec] && starkInfo.mapDeg.section[sec] != want) xlp_exit_process("Starks: column-major starkinfo whose sections are not whole domains");
+            }
         }
     }
     ~StarksT()
@@ -771,6 +820,7 @@ public:
             return;
         }
         lastTimers.clear();
+        if (steps->colMajor() != colMajor) xlp_exit_process("Starks: the step programs and the starkinfo disagree on the layout of the sections (colMajor)");
         if (XlpDeviceSlab::get().reserve(slabWords) == NULL) xlp_exit_process("Starks: no device slab");
         const eSection secs2ns[4] = {cm1_2ns, cm2_2ns, cm3_2ns, cm4_2ns};
         for (int i = 0; i < 4; i++) treesGL[i]->d_source = section(secs2ns[i]);        // the slab may have been re-reserved by a larger Starks
@@ -786,11 +836,10 @@ public:
             XLP_CHECK(xlp_copy_h2d(d_challenges, challenges.data(), challenges.size() * sizeof(uint64_t)));
         };
         // the base-domain sections other than the witness start from zero (prover.cpp:426-430 clears the committed polynomials; in the
-        // aliased layout the previous proof's extended sections lie there)
-        {
-            const uint64_t from = starkInfo.mapOffsets.section[cm2_n], to = starkInfo.mapOffsets.section[tmpExp_n] + N * starkInfo.mapSectionsN.section[tmpExp_n];
-            if (to > from && to <= slabWords) XLP_CHECK(xlp_dev_memset(mem() + from, 0, (to - from) * sizeof(uint64_t)));
-        }
+        // aliased layout the previous proof's extended sections lie there).  Column-major: AFTER step 1, whose witness bands land there first
+        const uint64_t zeroFrom = starkInfo.mapOffsets.section[cm2_n], zeroTo = starkInfo.mapOffsets.section[tmpExp_n] + N * starkInfo.mapSectionsN.section[tmpExp_n];
+        auto clearBaseSections = [&]() { if (zeroTo > zeroFrom && zeroTo <= slabWords) XLP_CHECK(xlp_dev_memset(mem() + zeroFrom, 0, (zeroTo - zeroFrom) * sizeof(uint64_t))); };
+        if (!colMajor) clearBaseSections();
         XLP_CHECK(xlp_copy_h2d(d_publics, publicInputs, starkInfo.nPublics * sizeof(uint64_t)));
         H::putVerkey(transcript, verkey, constRoot);
         transcript.put(&publicInputs[0], starkInfo.nPublics);
@@ -798,12 +847,29 @@ public:
         //-------------------------------- 1.- Calculate p_cm1_2ns
         {
             const uint64_t* h_cm1 = (const uint64_t*)pAddress + starkInfo.mapOffsets.section[cm1_n];
+            // column-major: the bands of the row-major witness land in the dead base-domain sections behind cm1_n and are transposed from there
+            uint64_t* stage = mem() + zeroFrom;
+            uint64_t stageWords = zeroTo > zeroFrom && zeroTo <= slabWords ? zeroTo - zeroFrom : 0;
+            uint64_t* ownStage = NULL;
+            if (colMajor && stageWords < N * W1) { ownStage = dalloc(N * W1); stage = ownStage; stageWords = N * W1; }
             if (!pipelineWitness) {
                 Timer t(this, "STARK_STEP_1_WITNESS_UPLOAD");
-                XLP_CHECK(xlp_copy_h2d(section(cm1_n), h_cm1, N * W1 * sizeof(uint64_t)));
+                XLP_CHECK(xlp_copy_h2d(colMajor ? stage : section(cm1_n), h_cm1, N * W1 * sizeof(uint64_t)));
             }
             Timer t(this, "STARK_STEP_1_LDE_AND_MERKLETREE");
-            if (pipelineWitness) H::commitFromHost(treesGL[0], section(cm1_n), section(cm1_2ns), h_cm1, NExtended, N, W1, &lastUploadMs);
+            if constexpr (H::kCommitTimes) {
+              if (colMajor) {
+                if (pipelineWitness) H::commitFromHostCm(treesGL[0], section(cm1_n), N, section(cm1_2ns), NExtended, h_cm1, stage, stageWords, NExtended, N, W1, &lastUploadMs);
+                else {
+                    XLP_CHECK(xlp_dev_rows_to_cm(section(cm1_n), N, 0, stage, W1, 0, W1, N, 0));
+                    H::commitCm(treesGL[0], section(cm1_2ns), NExtended, section(cm1_n), N, NExtended, N, W1);
+                }
+                if (ownStage) { XLP_CHECK(xlp_sync()); xlp_dev_free(ownStage); }
+                clearBaseSections();
+              }
+            }
+            if (colMajor) {}
+            else if (pipelineWitness) H::commitFromHost(treesGL[0], section(cm1_n), section(cm1_2ns), h_cm1, NExtended, N, W1, &lastUploadMs);
             else H::commit(treesGL[0], section(cm1_2ns), section(cm1_n), NExtended, N, W1);
             subTimers("STARK_STEP_1_LDE", "STARK_STEP_1_MERKLETREE");
             treesGL[0]->getRoot(root0);
@@ -823,7 +889,14 @@ public:
                 const PolRef h1 = pol(starkInfo.cm_n[numCommited + i * 2]), h2 = pol(starkInfo.cm_n[numCommited + i * 2 + 1]);
                 if (f.dim != tt.dim || h1.dim != f.dim || h2.dim != f.dim) xlp_exit_process("Starks: plookup polynomials of different dimensions");
                 // Polinomial views straight into the sections (transposeH1H2Columns / ...Rows of the reference are address arithmetic here)
-                if (config.xlpSyntheticLookups) {
+                if (colMajor) {                           // dense elements for the kernel, columns in the sections: four small copies around it
+                    uint64_t *df = d_work, *dt = d_work + N * 3, *dh1 = d_work + 2 * N * 3, *dh2 = d_work + 3 * N * 3;
+                    toDense(dt, tt, N);
+                    if (config.xlpSyntheticLookups) XLP_CHECK(xlp_dev_gather_rows(df, dt, f.dim, N, (uint32_t)f.dim, 0x5EED0500ULL + i));
+                    else toDense(df, f, N);
+                    XLP_CHECK(xlp_dev_calculate_h1h2(dh1, dh2, df, dt, N, (uint32_t)f.dim));
+                    fromDense(h1, dh1, N); fromDense(h2, dh2, N);
+                } else if (config.xlpSyntheticLookups) {
                     uint64_t *df = d_work, *dt = d_work + N * 3;
                     XLP_CHECK(xlp_dev_copy_cols(dt, f.dim, tt.p, tt.stride, N, (uint32_t)f.dim));
                     XLP_CHECK(xlp_dev_gather_rows(df, dt, f.dim, N, (uint32_t)f.dim, 0x5EED0500ULL + i));
@@ -836,7 +909,8 @@ public:
         }
         {
             Timer t(this, "STARK_STEP_2_LDE_AND_MERKLETREE");
-            H::commit(treesGL[1], section(cm2_2ns), section(cm2_n), NExtended, N, starkInfo.mapSectionsN.section[cm2_n]);
+            if constexpr (H::kCommitTimes) { if (colMajor) H::commitCm(treesGL[1], section(cm2_2ns), NExtended, section(cm2_n), N, NExtended, N, starkInfo.mapSectionsN.section[cm2_n]); }
+            if (!colMajor) H::commit(treesGL[1], section(cm2_2ns), section(cm2_n), NExtended, N, starkInfo.mapSectionsN.section[cm2_n]);
             subTimers("STARK_STEP_2_LDE", "STARK_STEP_2_MERKLETREE");
             treesGL[1]->getRoot(root1);
             H::putRoot(transcript, root1);
@@ -857,6 +931,12 @@ public:
             for (uint64_t i = 0; i < nd.size(); i++) {
                 const PolRef num = pol(exp2pol(nd[i].first)), den = pol(exp2pol(nd[i].second)), z = pol(starkInfo.cm_n[numCommited + i]);
                 if (num.dim != 3 || den.dim != 3 || z.dim != 3) xlp_exit_process("Starks: Z polynomials must be ext-3");
+                if (colMajor) {
+                    uint64_t *dn = d_work, *dd = d_work + N * 3, *dz = d_work + 2 * N * 3;
+                    toDense(dn, num, N); toDense(dd, den, N);
+                    XLP_CHECK(xlp_dev_calculate_z(dz, dn, dd, N));
+                    fromDense(z, dz, N);
+                } else
                 XLP_CHECK(xlp_dev_calculate_z_strided(z.p, z.stride, num.p, num.stride, den.p, den.stride, N));   // views, no transposeZColumns copies
             }
         }
@@ -866,7 +946,8 @@ public:
         }
         {
             Timer t(this, "STARK_STEP_3_LDE_AND_MERKLETREE");
-            H::commit(treesGL[2], section(cm3_2ns), section(cm3_n), NExtended, N, starkInfo.mapSectionsN.section[cm3_n]);
+            if constexpr (H::kCommitTimes) { if (colMajor) H::commitCm(treesGL[2], section(cm3_2ns), NExtended, section(cm3_n), N, NExtended, N, starkInfo.mapSectionsN.section[cm3_n]); }
+            if (!colMajor) H::commit(treesGL[2], section(cm3_2ns), section(cm3_n), NExtended, N, starkInfo.mapSectionsN.section[cm3_n]);
             subTimers("STARK_STEP_3_LDE", "STARK_STEP_3_MERKLETREE");
             treesGL[2]->getRoot(root2);
             H::putRoot(transcript, root2);
@@ -887,8 +968,10 @@ public:
                     if (logTimers) fprintf(stderr, "Starks: extended constants now resident (%.1f GB; %.1f GB were free)\n", need / 1e9, fr / 1e9);
                 }
             }
-            XLP_CHECK(xlp_dev_extend(constPols2ns(), d_const_n, NExtended, N, starkInfo.nConstants, NULL));
+            if (colMajor) XLP_CHECK(xlp_dev_extend_cm(constPols2ns(), NExtended, 0, d_const_n, N, NExtended, N, starkInfo.nConstants));
+            else XLP_CHECK(xlp_dev_extend(constPols2ns(), d_const_n, NExtended, N, starkInfo.nConstants, NULL));
         }
+        if (colMajor) { P.coset_rows = N; P.coset_stride = N; }      // the extended-domain programs run coset by coset (XLP_EXPR_COLMAJOR)
         {
             Timer t(this, "STARK_STEP_4_CALCULATE_EXPS_2NS");
             steps->step42ns_parser_first_avx(P, NExtended, nrowsStepBatch);
@@ -899,6 +982,10 @@ public:
             XLP_CHECK(xlp_dev_ntt(qq1, section(q_2ns), NExtended, starkInfo.qDim, 1));
             const Goldilocks::Element shiftIn = Goldilocks::exp(Goldilocks::inv(Goldilocks::shift()), N);
             XLP_CHECK(xlp_dev_q_split(qq2, qq1, N, NExtended, (uint32_t)starkInfo.qDeg, (uint32_t)starkInfo.qDim, Goldilocks::toU64(shiftIn)));
+            if (colMajor) {                                  // natural rows out of the transform -> coset-major columns
+                XLP_CHECK(xlp_dev_ntt(qq2, qq2, NExtended, starkInfo.qDim * starkInfo.qDeg, 0));
+                XLP_CHECK(xlp_dev_rows_to_cm(section(cm4_2ns), NExtended, 0, qq2, starkInfo.qDim * starkInfo.qDeg, 0, starkInfo.qDim * starkInfo.qDeg, NExtended, (uint32_t)extendBits));
+            } else
             XLP_CHECK(xlp_dev_ntt(section(cm4_2ns), qq2, NExtended, starkInfo.qDim * starkInfo.qDeg, 0));
         }
         {
@@ -938,6 +1025,17 @@ public:
                     ents[i] = {p.p, p.stride, (uint32_t)p.dim, ev.prime ? 1u : 0u};
                 }
             }
+            if (colMajor) {                                  // coset 0 of an extended column IS the column at the rows k << extendBits
+                for (size_t i = 0; i < ents.size(); i++) {
+                    const EvMap& ev = starkInfo.evMap[i];
+                    if (ev.type == EvMap::_const) ents[i] = {constPols2ns() + ev.id * NExtended, NExtended, 1, ev.prime ? 1u : 0u};
+                    else {
+                        const PolRef p = pol(ev.type == EvMap::cm ? starkInfo.cm_2ns[ev.id] : starkInfo.qs[ev.id]);
+                        ents[i] = {p.p, p.cs, (uint32_t)p.dim, ev.prime ? 1u : 0u};
+                    }
+                }
+                XLP_CHECK(xlp_dev_evmap_cm(d_evals, d_work, d_work + N * 3, N, (uint32_t)ents.size(), ents.data()));
+            } else
             XLP_CHECK(xlp_dev_evmap(d_evals, d_work, d_work + N * 3, N, (uint32_t)extendBits, (uint32_t)ents.size(), ents.data()));
             XLP_CHECK(xlp_copy_d2h(evals.data(), d_evals, evals.size() * sizeof(uint64_t)));
         }

@@ -20,6 +20,7 @@ class Steps
 public:
     virtual ~Steps() {}
     virtual const std::vector<NextRowStore>& nextRowStores(int /*0 step2prev .. 4 step52ns*/) const { static const std::vector<NextRowStore> none; return none; }
+    virtual bool colMajor() const { return false; }          // the programs address column-major sections (must match the starkinfo's layout)
     // nrowsBatch is the reference's SIMD batch (4 / 8 rows, starks.cpp:70-80); one row per lane here, so it is ignored
     virtual void step2prev_parser_first_avx(StepsParams& params, uint64_t nrows, uint64_t nrowsBatch) = 0;
     virtual void step3prev_parser_first_avx(StepsParams& params, uint64_t nrows, uint64_t nrowsBatch) = 0;
@@ -50,6 +51,7 @@ class XlpSteps : public Steps
         std::string mode = "absent";
     };
     Step step_[5];
+    bool colMajor_ = false;                  // manifest "colMajor": the row programs address column-major sections (XLP_EXPR_COLMAJOR)
     static const uint64_t NCH = 8;           // challenges of a proof (starks.cpp)
     static bool exists(const std::string& path) { FILE* f = fopen(path.c_str(), "rb"); if (f) fclose(f); return f != NULL; }
     static std::vector<uint64_t> readWords(const std::string& path)
@@ -62,14 +64,14 @@ class XlpSteps : public Steps
         fclose(f);
         return v;
     }
-    static xlp_expr_program* load(const std::string& path, uint64_t magic, uint64_t* extra)
+    static xlp_expr_program* load(const std::string& path, uint64_t magic, uint64_t* extra, bool colMajor = false)
     {
         const std::vector<uint64_t> w = readWords(path);
         const size_t nh = extra ? 5 : 4;
         if (w.size() < nh || w[0] != magic || w.size() != nh + w[3]) xlp_exit_process(("XlpSteps: bad header in " + path).c_str());
         if (extra) *extra = w[4];
         xlp_expr_program* p = NULL;
-        XLP_CHECK(xlp_expr_create(&p, w.data() + nh, w[3], w[1], w[2]));
+        XLP_CHECK(xlp_expr_create_ex(&p, w.data() + nh, w[3], w[1], w[2], colMajor ? XLP_EXPR_COLMAJOR : 0));
         return p;
     }
     static void attach(xlp_expr_program* p, const std::string& so, std::string& mode)
@@ -95,7 +97,26 @@ class XlpSteps : public Steps
         }
         StepsParams r = params;
         r.challenges = s.ext; r.challenges_size = 3 * s.n_ext;
-        if (!s.dots.empty()) {
+        if (!s.dots.empty() && colMajor_) {
+            // the sums as 3 * ngroups COLUMNS of nrows words (what the converted row program reads); entries: the columns' first words, constant
+            // polynomials at column * rows of their buffer
+            const uint64_t words = nrows * 3 * s.ngroups;
+            if (s.dotOutWords < words) {
+                if (s.dotOut) XLP_CHECK(xlp_dev_free(s.dotOut));
+                void* d = NULL;
+                XLP_CHECK(xlp_dev_alloc(&d, words * sizeof(uint64_t)));
+                s.dotOut = (uint64_t*)d; s.dotOutWords = words;
+            }
+            const uint64_t crows = params.n_const_pols_2ns ? params.const_pols_2ns_size / params.n_const_pols_2ns : 0;
+            std::vector<xlp_dot_entry> ents(s.dots.size());
+            for (size_t i = 0; i < ents.size(); i++) {
+                const DotSpec& d = s.dots[i];
+                if (d.kind == 0) ents[i] = {params.pols + d.offset, d.stride, (uint32_t)d.dim, (uint32_t)d.group, d.coef};
+                else ents[i] = {params.const_pols_2ns + d.offset * crows, crows, 1u, (uint32_t)d.group, d.coef};
+            }
+            XLP_CHECK(xlp_dev_dot_columns_cm(s.dotOut, nrows, ents.data(), ents.size(), (uint32_t)s.ngroups, s.ext, 3 * s.n_ext, nrows));
+            r.pols = s.dotOut; r.pols_size = words;
+        } else if (!s.dots.empty()) {
             const uint64_t words = nrows * 3 * s.ngroups;
             if (s.dotOutWords < words) {
                 if (s.dotOut) XLP_CHECK(xlp_dev_free(s.dotOut));
@@ -142,12 +163,13 @@ public:
             fclose(f);
             const xlp_json::Value j = xlp_json::Parser(text).value();
             const xlp_json::Value& S = j["steps"];
+            colMajor_ = j.contains("colMajor") && j["colMajor"].kind == xlp_json::Value::Bool && (bool)j["colMajor"];
             auto str = [&](const xlp_json::Value& e, const char* k) { return e.contains(k) && !e[k].is_null() ? dir + "/" + e[k].str() : std::string(); };
             for (int k = 0; k < 5; k++) {
                 if (!S.contains(steps[k])) { requirePresent(k, manifest + " has no " + steps[k]); continue; }
                 const xlp_json::Value& e = S[steps[k]];
                 Step& s = step_[k];
-                s.prog = load(str(e, "prog"), 0x3152505845504c58ULL /* "XLPEXPR1" */, NULL);
+                s.prog = load(str(e, "prog"), 0x3152505845504c58ULL /* "XLPEXPR1" */, NULL, colMajor_);
                 s.mode = "as converted";
                 if (e.contains("n_ext")) { s.n_ext = e["n_ext"]; s.mode = "dot-product form"; }
                 if (e.contains("tab")) { uint64_t n = 0; s.tab = load(str(e, "tab"), 0x3130424154504c58ULL /* "XLPTAB01" */, &n); if (n != s.n_ext) xlp_exit_process("XlpSteps: table size mismatch"); }
@@ -195,6 +217,7 @@ public:
     }
     const std::vector<NextRowStore>& nextRowStores(int k) const override { return step_[k].stores; }
     bool optimised(int k) const { return step_[k].n_ext != 0; }
+    bool colMajor() const override { return colMajor_; }
     const std::string& mode(int k) const { return step_[k].mode; }
     XlpSteps(const XlpSteps&) = delete;
     XlpSteps& operator=(const XlpSteps&) = delete;

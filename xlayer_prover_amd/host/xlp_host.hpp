@@ -209,6 +209,12 @@ public:
     // reference's tree -- and every rank holds the cap: the levels over the `world` sub-roots (32 bytes per rank all-gathered).
     // getRoot / getGroupProofs answer for the GLOBAL tree on every rank (an opening is made by the rank that owns the row and shared).
     int shardRank = 0, shardWorld = 0;                         // shardWorld == 0: an ordinary tree
+    // Column-major source (GPU-resident form; host/starks.hpp with a "colMajor" starkinfo): d_source = `width` columns of `height` words
+    // (cmStride apart), coset-major with 2^cmExtBits cosets; leaves, nodes and openings are the same as over the row-major section
+    bool colMajor = false;
+    uint32_t cmExtBits = 0;
+    uint64_t cmStride = 0;
+    void setColMajor(uint32_t extBits, uint64_t cstride) { colMajor = true; cmExtBits = extBits; cmStride = cstride; }
     std::vector<std::vector<uint64_t>> capLevels;              // [sub-roots (world x 4)], ..., [root (4)]
     MerkleTreeGL(uint64_t _height, uint64_t _width, uint64_t* dSource, bool /*deviceTag*/, int world = 0, int rank = 0)
         : height(_height), width(_width), source(NULL), nodes(NULL), d_source(dSource), shardRank(rank), shardWorld(world)
@@ -272,6 +278,7 @@ public:
     void merkelize()
     {
         if (d_nodes && shardWorld) { XLP_CHECK(xlp_dev_merkle(d_nodes, d_source, width, localHeight())); assembleCap(); return; }
+        if (d_nodes && colMajor) { XLP_CHECK(xlp_dev_merkle_cm(d_nodes, d_source, cmStride, 0, width, height, cmExtBits)); return; }
         if (d_nodes) { XLP_CHECK(xlp_dev_merkle(d_nodes, d_source, width, height)); return; }
         PoseidonGoldilocks::merkletree_avx(nodes, source, width, height);
     }
@@ -328,13 +335,14 @@ public:
             }
             return;
         }
+        if (d_nodes && colMajor) { XLP_CHECK(xlp_dev_merkle_proofs_cm(xlp_raw(proofs.data()), d_source, cmStride, 0, d_nodes, width, height, cmExtBits, idxs.data(), idxs.size())); return; }
         if (d_nodes) { XLP_CHECK(xlp_dev_merkle_proofs(xlp_raw(proofs.data()), d_source, d_nodes, width, height, idxs.data(), idxs.size())); return; }
         for (size_t q = 0; q < idxs.size(); q++) getGroupProof(&proofs[q * per], idxs[q]);
     }
     // proof = row || siblings bottom-up (merkleTreeGL.cpp:12-35)
     void getGroupProof(Goldilocks::Element* proof, uint64_t idx)
     {
-        if (shardWorld) {
+        if (shardWorld || (d_nodes && colMajor)) {
             std::vector<Goldilocks::Element> one;
             getGroupProofs(one, std::vector<uint64_t>(1, idx));
             std::memcpy(proof, one.data(), (width + MerkleProofSize() * HASH_SIZE) * sizeof(Goldilocks::Element));
@@ -747,6 +755,7 @@ public:
     // (tools/zkevm_geometry.py layout_window): N / G (NExtended / G) rows followed by haloN (haloExt) rows of the next rank; mapOffsets,
     // mapDeg and mapTotalN describe that window slab, starkStruct stays global.  0: the reference's whole-domain layout.
     uint64_t xlpWorld = 0, xlpHaloN = 0, xlpHaloExt = 0;
+    bool xlpColMajor = false;                         // "xlp": {"colMajor": true}: the DEVICE sections are column-major (include/xlp_gl.h), same offsets and sizes
 
     StarkInfo() {}                                   // synthetic runs fill starkStruct by hand
     explicit StarkInfo(const std::string& file)      // StarkInfo(config, file), stark_info.cpp:7-19
@@ -822,9 +831,10 @@ public:
             xlpConst2nsInSlab = true;
             xlpConst2nsOffset = j["xlp"]["const2nsOffset"];
         }
+        if (j.contains("xlp") && j["xlp"].contains("colMajor") && j["xlp"]["colMajor"].kind == xlp_json::Value::Bool) xlpColMajor = (bool)j["xlp"]["colMajor"];
         if (j.contains("xlp") && j["xlp"].contains("world")) {
             xlpWorld = j["xlp"]["world"]; xlpHaloN = j["xlp"]["haloN"]; xlpHaloExt = j["xlp"]["haloExt"];
-            if (!xlpWorld || (xlpWorld & (xlpWorld - 1)) || xlpConst2nsInSlab) xlp_exit_process("StarkInfo: bad sharded (\"xlp\") layout");
+            if (!xlpWorld || (xlpWorld & (xlpWorld - 1)) || xlpConst2nsInSlab || xlpColMajor) xlp_exit_process("StarkInfo: bad sharded (\"xlp\") layout");
         }
     }
     void getPol(void* pAddress, uint64_t idPol, PolInfo& polInfo)     // stark_info.cpp:456-464
