@@ -341,6 +341,10 @@ int xlp_field_op(uint64_t* out, const uint64_t* a, const uint64_t* b, uint64_t n
  * column chunks.  Measurement aid for bench.py; the reference's analogue is TimerStart/TimerStopAndLog
  * around STARK_STEP_n_LDE (src/starkpil/starks.cpp:49-55). */
 int xlp_profile_enable(int on);
+/* Measurement aid: the ALU ceiling of the Poseidon leaf sponge -- `count` lanes each walk `iters` chained hash_full_result
+ * permutations of a state that never leaves its registers (no HBM traffic; out[i] = a checksum of lane i's final state so that the work is
+ * kept).  bench.py reports the sponge's permutations/s against what this kernel reaches on the same grid. */
+int xlp_dev_perm_resident(uint64_t* out, uint64_t count, uint64_t iters);
 int xlp_profile_read(double ms_sum[3], uint64_t* count);
 
 /* ---- transport between the ranks of a row-sharded proof: one process per GPU -----------------------------------------
@@ -443,7 +447,7 @@ int xlp_dev_commit_from_host(uint64_t* sec_n, uint64_t* sec_2ns, uint64_t* nodes
  *                                             it into its columns ahead of its extension */
 /*   xlp_dev_evmap_cm                           Starks::evmap (starks.cpp:556-669) with the polynomials as columns: entries[i].pol = the column's first
  *                                             word (coset 0 of an extended column holds its values at the rows k << extendBits), .row_stride = the
- *                                             words between the components of an extension column; prime entries read word (k + 1) % n
+ *                                             words between the components of an extension column
  *   xlp_dev_dot_columns_cm                     xlp_dev_dot_columns on columns: out column 3 g + c (out_cstride words apart) = component c of group
  *                                             g's sum over the storage rows [0, nrows); entries as above; results canonical */
 int xlp_dev_evmap_cm(uint64_t* evals, const uint64_t* LEv, const uint64_t* LpEv, uint64_t n, uint32_t nev, const xlp_evmap_entry* entries);

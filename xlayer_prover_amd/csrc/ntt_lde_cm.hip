@@ -19,23 +19,10 @@
 #include "xlp_internal.hpp"
 #include "ntt_common.hpp"
 #include "ntt_lde_common.hpp"
+#include "ntt_lde_cm_common.hpp"
 
 namespace xlp {
 
-struct LdeCmParams {
-    const u64* in; u64 in_cs;            // input: column c at in + c * in_cs, n words
-    u64* out; u64 out_cs, out_cos;       // output: column c at out + c * out_cs, coset r at + r * out_cos, n words each
-    u64* A;                              // scratch [wc][n]
-    u64* B;                              // scratch [2^e][wc][n]
-    u32 col0, wc;                        // column chunk [col0, col0 + wc)
-    u32 L, e;
-    const u64 *twi_bt, *twf_bt, *twi_12, *twf_12;
-    const u64 *cri_lo, *cri_hi, *crf_lo, *crf_hi;
-    const u64 *ei, *ef;                  // ei[v][k] = w(L)^(-k v), ef[v][k] = w(L)^(k v): v < 8, k < 2^BT
-    const u64* tw2[LDE_MAX_COSETS];
-    const u64* hk[LDE_MAX_COSETS];
-    const u64* ur[LDE_MAX_COSETS];
-};
 
 // e[v * 2^BT + k] = root^(k v) from the two-level power tables of root
 __global__ void lde_cm_etable_kernel(u64* e, const u64* __restrict__ lo, const u64* __restrict__ hi, u32 BT)
@@ -81,62 +68,7 @@ __global__ __launch_bounds__(XLP_WGT) void lde_cm_top_dif(const LdeCmParams p)
     }
 }
 
-// ------------------------------------------------------------------------ K2: the 12-bit middle pass on 4 whole columns
-__global__ __launch_bounds__(1024) void lde_cm_mid(const LdeCmParams p, u32 BT)
-{
-    constexpr int V = 4, B = 12;
-    constexpr u32 LT = 4096 + 256 + 1;                       // padded tile of one column
-    extern __shared__ u64 sm[];
-    const u32 ncc = (p.wc + V - 1) / V;
-    const u32 tile = xcd_tile();
-    const u32 cc = tile % ncc, hi = tile / ncc;
-    const u32 c = cc * V;
-    const u64 n = 1ull << p.L;
-    // columns past the chunk's last read its last column (in bounds) and never store
-    auto colbase = [&](u32 v) -> u64 { return (u64)(c + v < p.wc ? c + v : p.wc - 1) << p.L; };
-    auto gload = [&](u32 tpos, u32 v, u32) -> u64 { return p.A[colbase(v) + (((u64)hi << 12) | tpos)]; };
-    auto lload = [&](u32, u32 v, u32 lrow) -> u64 { return sm[v * LT + lrow]; };
-    auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { sm[v * LT + lrow] = val; };
-    fast_round<B, V, 8, 4, false, true, false, false, decltype(gload), decltype(lstore), NoFactor, NoFactor, false, true>(p.twi_12, gload, lstore, NoFactor{}, NoFactor{});
-    XLP_SYNC();
-    fast_round<B, V, 4, 4, false, true, false, false, decltype(lload), decltype(lstore), NoFactor, NoFactor, false, true>(p.twi_12, lload, lstore, NoFactor{}, NoFactor{});
-    XLP_SYNC();
-    // the last inverse round keeps its outputs in registers: thread -> (column v = tid >> 8, group = tid & 255)
-    const u32 v = threadIdx.x >> 8;
-    const u32 base = (threadIdx.x & 255) << 4;
-    u64 X[16];
-    {
-        u64 x[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) x[j] = sm[v * LT + lds_row(base) + j];
-        dft_regs<4>(x);
-#pragma unroll
-        for (int k = 0; k < 16; k++) X[k] = x[brev<4>((16 - k) % 16)];
-    }
-    const bool valid = c + v < p.wc;
-    for (u32 r = 0; r < (1u << p.e); r++) {
-        const u64* __restrict__ hk = p.hk[r];
-        u64* __restrict__ Br = p.B + (((u64)r * p.wc) << p.L);
-        XLP_SYNC();
-        {
-            u64 x[16];
-            x[0] = X[0];
-#pragma unroll
-            for (int j = 1; j < 16; j++) x[j] = gl::mulc(X[j], hk[j]);
-            dft_regs<4>(x);
-#pragma unroll
-            for (int k = 0; k < 16; k++) sm[v * LT + lds_row(base) + k] = x[brev<4>(k)];
-        }
-        XLP_SYNC();
-        fast_round<B, V, 4, 4, true, false, false, false, decltype(lload), decltype(lstore), NoFactor, NoFactor, true, true>(p.tw2[r], lload, lstore, NoFactor{}, NoFactor{});
-        XLP_SYNC();
-        auto gstore = [&](u32 tpos, u32 vv, u64 val, u32) {
-            if (c + vv < p.wc) Br[((u64)(c + vv) << p.L) + (((u64)hi << 12) | tpos)] = val;
-        };
-        fast_round<B, V, 8, 4, true, false, false, false, decltype(lload), decltype(gstore), NoFactor, NoFactor, false, true>(p.twf_12, lload, gstore, NoFactor{}, NoFactor{});
-    }
-    (void)valid; (void)BT; (void)n;
-}
+// K2 (lde_cm_mid) lives in ntt_lde_cm_mid.hip
 
 // ------------------------------------------------------------------------ K3: forward NTT over t of 8 neighbouring lo of one column of one coset
 template <int BT>
@@ -264,11 +196,6 @@ int dev_extend_cm_fast(Ctx* ctx, u64* out, u64 out_cstride, u64 out_cos, const u
     if (ncols < wc_max) wc_max = ncols;
     u64* scratch = nullptr;
     if (ctx_scratch(ctx, (size_t)(1 + ncos) * wc_max * n * sizeof(u64), 1, &scratch)) return -1;
-    static bool mid_attr = false;
-    if (!mid_attr) {
-        XLP_HIP(hipFuncSetAttribute((const void*)lde_cm_mid, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        mid_attr = true;
-    }
     for (u64 col0 = 0; col0 < ncols; col0 += wc_max) {
         p.col0 = (u32)col0;
         p.wc = (u32)(ncols - col0 < wc_max ? ncols - col0 : wc_max);
@@ -281,12 +208,7 @@ int dev_extend_cm_fast(Ctx* ctx, u64* out, u64 out_cstride, u64 out_cos, const u
         }
         if (launch_cm_top_bt(ctx, p, BT, false)) return -1;
         if (ctx->profile) XLP_HIP(hipEventRecord(ev[1], ctx->stream));
-        {
-            const u32 ncc = (p.wc + 3) / 4;
-            const size_t lds = (size_t)(4096 + 256 + 1) * 4 * sizeof(u64);
-            hipLaunchKernelGGL(lde_cm_mid, dim3((unsigned)((u64)ncc << BT)), dim3(1024), lds, ctx->stream, p, BT);
-            XLP_HIP(hipGetLastError());
-        }
+        if (launch_lde_cm_mid(ctx, p, BT)) return -1;
         if (ctx->profile) XLP_HIP(hipEventRecord(ev[2], ctx->stream));
         if (launch_cm_top_bt(ctx, p, BT, true)) return -1;
         if (ctx->profile) XLP_HIP(hipEventRecord(ev[3], ctx->stream));

@@ -525,16 +525,16 @@ int dev_evmap(Ctx* ctx, u64* evals, const u64* LEv, const u64* LpEv, u64 n, u32 
 
 // ------------------------------------------------------------------ evmap on column-major sections
 // The same sums with the columns stored contiguously (colmajor.hip): coset 0 of an extended column IS the column at the rows (k << eb), so
-// an entry is the pointer to its first word and the next-row entries read word k + 1 (wrapping at n).  Lanes still run along the ENTRIES in
+// an entry is the pointer to its first word (a `prime` entry is multiplied by LpEv instead of LEv, nothing else).  Lanes still run along the ENTRIES in
 // the arithmetic (the multiplier limbs of a row are wave-uniform), but the global reads run along the ROWS: a workgroup takes 64 sub-entries,
 // each wave loads 64 rows of 16 of them (512 contiguous bytes per instruction), the tile is turned through LDS, and wave w accumulates rows
 // 16 w .. 16 w + 15 of the tile for all 64 entries; the four partial sums meet in LDS at the end of the row chunk.
-constexpr int EC_T = 256, EC_E = 64, EC_ROWS = 4096;
+constexpr int EC_T = 256, EC_E = 64, EC_ROWS = 4096, EC_TILE = 64;
 struct EvEntryCm { const u64* col; u32 variant; u32 prime; u32 sub; u32 pad; };
 __global__ __launch_bounds__(EC_T) void evmap_cm_partial_kernel(u64* partial, const u64* LEv, const u64* LpEv, u64 n, const EvEntryCm* ents, u32 nsub)
 {
-    __shared__ u32 sL[2][EV_SUB * 15];
-    __shared__ u64 tile[64][EC_E + 1];
+    __shared__ u32 sL[2][EC_TILE * 15];                    // the multiplier limbs of the tile's rows: [LEv | LpEv][row][5 words x 3 limbs]
+    __shared__ u64 tile[EC_TILE][EC_E + 1];
     const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const u32 e0 = blockIdx.x * EC_E;
     const u32 ei = e0 + lane;
@@ -544,53 +544,49 @@ __global__ __launch_bounds__(EC_T) void evmap_cm_partial_kernel(u64* partial, co
     const u64 k1 = k0 + EC_ROWS < n ? k0 + EC_ROWS : n;
     const u32 i0 = 3 * (e.variant == 0 ? 0 : (e.variant == 1 ? 2 : 1)), i1 = 3 * (e.variant == 0 ? 1 : (e.variant == 1 ? 3 : 4)), i2 = 3 * (e.variant == 0 ? 2 : (e.variant == 1 ? 1 : 3));
     const u32* l = sL[e.prime ? 1 : 0];
+    // this wave's 16 entries of the tile (lane = row) and, for threads 0 .. 127, one row of LEv / LpEv: fetched one tile ahead
+    const u64* mycol[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const u32 ej = e0 + wv * 16 + j; mycol[j] = ents[ej < nsub ? ej : 0].col; }
+    const u64* Lsrc = (threadIdx.x & 1) ? LpEv : LEv;
+    u64 v[16], a[3];
+    auto fetch = [&](u64 t0) {
+        const bool in = t0 + lane < k1;
+#pragma unroll
+        for (int j = 0; j < 16; j++) v[j] = (in && e0 + wv * 16 + j < nsub) ? mycol[j][t0 + lane] : 0;
+        const u64 r = t0 + (threadIdx.x >> 1);
+        if (threadIdx.x < 2 * EC_TILE && r < k1) { a[0] = Lsrc[3 * r]; a[1] = Lsrc[3 * r + 1]; a[2] = Lsrc[3 * r + 2]; }
+        else a[0] = a[1] = a[2] = 0;
+    };
     DcSum S[3];
     S[0].clear(); S[1].clear(); S[2].clear();
     u32 since = 0;
-    for (u64 s0 = k0; s0 < k1; s0 += EV_SUB) {
-        const u32 rows = (u32)(k1 - s0 < EV_SUB ? k1 - s0 : EV_SUB);
-        __syncthreads();
-        for (u32 i = threadIdx.x; i < rows * 2; i += EC_T) {
-            const u32 r = i >> 1;
-            const u64* src = (i & 1) ? LpEv : LEv;
-            u32* d = &sL[i & 1][15 * r];
-            const u64 a0 = gl::canon(src[3 * (s0 + r)]), a1 = gl::canon(src[3 * (s0 + r) + 1]), a2 = gl::canon(src[3 * (s0 + r) + 2]);
+    fetch(k0);
+    for (u64 t0 = k0; t0 < k1; t0 += EC_TILE) {
+        const u32 trows = (u32)(k1 - t0 < EC_TILE ? k1 - t0 : EC_TILE);
+        __syncthreads();                                   // the previous tile has been consumed
+#pragma unroll
+        for (int j = 0; j < 16; j++) tile[lane][wv * 16 + j] = v[j];
+        if (threadIdx.x < 2 * EC_TILE) {
+            u32* d = &sL[threadIdx.x & 1][15 * (threadIdx.x >> 1)];
+            const u64 a0 = gl::canon(a[0]), a1 = gl::canon(a[1]), a2 = gl::canon(a[2]);
             const u64 m[5] = {a0, a1, a2, gl::addc(a0, a2), gl::addc(a1, a2)};
 #pragma unroll
             for (int q = 0; q < 5; q++) { d[3 * q] = (u32)m[q] & 0x3FFFFFu; d[3 * q + 1] = (u32)(m[q] >> 22) & 0x1FFFFFu; d[3 * q + 2] = (u32)(m[q] >> 43); }
         }
-        if (since + (rows + 3) / 4 > EV_FOLD) { S[0].flush(); S[1].flush(); S[2].flush(); since = 0; }    // a wave adds a quarter of the rows
-        since += (rows + 3) / 4;
-        for (u32 t0 = 0; t0 < rows; t0 += 64) {
-            const u32 trows = rows - t0 < 64 ? rows - t0 : 64;
-            __syncthreads();                                   // sL staged (first tile) / previous tile consumed
-            // load: this wave's 16 entries, lane = row of the tile
-            u64 v[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const u32 ej = e0 + wv * 16 + j;
-                v[j] = 0;
-                if (ej < nsub && lane < trows) {
-                    const EvEntryCm x = ents[ej];               // wave-uniform
-                    u64 k = s0 + t0 + lane + x.prime;
-                    if (k >= n) k -= n;
-                    v[j] = x.col[k];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 16; j++) tile[lane][wv * 16 + j] = v[j];
-            __syncthreads();
-            // accumulate: lane = entry, this wave's rows of the tile
-            if (live) {
+        __syncthreads();
+        if (t0 + EC_TILE < k1) fetch(t0 + EC_TILE);          // in flight while this tile is multiplied
+        if (since + 16 > EV_FOLD) { S[0].flush(); S[1].flush(); S[2].flush(); since = 0; }
+        since += 16;
+        if (live) {
+            const u32 r1 = wv * 16 + 16 < trows ? wv * 16 + 16 : trows;
 #pragma unroll 4
-                for (u32 rr = wv * 16; rr < wv * 16 + 16; rr++) {
-                    if (rr >= trows) break;
-                    const u32* lr = l + 15 * (t0 + rr);
-                    const u64 x = tile[rr][lane];
-                    S[0].mac(lr[i0], lr[i0 + 1], lr[i0 + 2], x);
-                    S[1].mac(lr[i1], lr[i1 + 1], lr[i1 + 2], x);
-                    S[2].mac(lr[i2], lr[i2 + 1], lr[i2 + 2], x);
-                }
+            for (u32 rr = wv * 16; rr < r1; rr++) {
+                const u32* lr = l + 15 * rr;
+                const u64 x = tile[rr][lane];
+                S[0].mac(lr[i0], lr[i0 + 1], lr[i0 + 2], x);
+                S[1].mac(lr[i1], lr[i1 + 1], lr[i1 + 2], x);
+                S[2].mac(lr[i2], lr[i2 + 1], lr[i2 + 2], x);
             }
         }
     }
@@ -619,6 +615,7 @@ int dev_evmap_cm(Ctx* ctx, u64* evals, const u64* LEv, const u64* LpEv, u64 n, u
     }
     const u32 nsub = (u32)h.size();
     first[nev] = nsub;
+    std::stable_sort(h.begin(), h.end(), [](const EvEntryCm& x, const EvEntryCm& y) { return x.col < y.col; });   // the two entries of a column (LEv and LpEv) in one tile
     u64* scratch = nullptr;
     const size_t ent_bytes = ((size_t)nsub * sizeof(EvEntryCm) + 255) / 256 * 256;
     const size_t first_bytes = ((size_t)(nev + 1) * 4 + 255) / 256 * 256;
@@ -641,7 +638,7 @@ int dev_evmap_cm(Ctx* ctx, u64* evals, const u64* LEv, const u64* LpEv, u64 n, u
 // of the Fp^3 sums, as in the row-major kernel.  The host groups the entries by COLUMN: a column word is loaded once and multiplied into the
 // accumulators of all ngroups groups (limbs zero where a group does not name the column; several entries of one group on one column are summed
 // when the records are expanded), so which accumulator a product goes to is static.
-constexpr int DCM_T = 192, DCM_ROWS = 128;
+constexpr int DCM_T = 256, DCM_ROWS = 256;
 struct DcmContrib { u32 col, group, variant, pad; u64 coef; };     // entry -> column record `col`, group, multiplier variant (1, a, a^2), coefficient index
 // rec[col]: {ptr lo, ptr hi, pad, pad} then limbs[comp][g][3] (u32), g < 4: 4 + 36 dwords
 constexpr u32 DCM_REC = 40;
@@ -665,52 +662,59 @@ __global__ void dcm_expand_kernel(u32* rec, const DcmContrib* con, const u32* cf
     d[0] = (u32)k & 0x3FFFFFu; d[1] = (u32)(k >> 22) & 0x1FFFFFu; d[2] = (u32)(k >> 43);
 }
 
+// One lane = one row, ALL three components and all G groups of its sums (18 G accumulators): a column word is loaded once per row and
+// meets 3 G wave-uniform multipliers (their limbs arrive by scalar loads: the column index is the loop counter).  The words of the next
+// DCM_U columns are in flight while the current ones are multiplied.
+constexpr int DCM_U = 4;
 template <int G>
 __global__ __launch_bounds__(DCM_T) void dot_columns_cm_kernel(u64* out, u64 out_cstride, const u32* __restrict__ rec, u32 ncol, u64 nrows)
 {
-    const u32 lane = threadIdx.x & 63, comp = threadIdx.x >> 6;
-    const u64 row = (u64)blockIdx.x * DCM_ROWS + 2 * lane;
-    const bool ok0 = row < nrows, ok1 = row + 1 < nrows;
-    DcSum S[G][2];
+    const u64 row = (u64)blockIdx.x * DCM_ROWS + threadIdx.x;
+    const bool ok = row < nrows;
+    const u64 rr = ok ? row : nrows - 1;                      // lanes past the end read the last row (in bounds) and store nothing
+    DcSum S[3][G];
 #pragma unroll
-    for (int g = 0; g < G; g++) { S[g][0].clear(); S[g][1].clear(); }
-    constexpr int U = 4;
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int g = 0; g < G; g++) S[c][g].clear();
+    auto colptr = [&](u32 c) -> const u64* {
+        const u32* r = rec + (u64)(c < ncol ? c : ncol - 1) * DCM_REC;
+        return (const u64*)(((u64)r[1] << 32) | r[0]);
+    };
+    u64 cur[DCM_U], nxt[DCM_U];
+#pragma unroll
+    for (int j = 0; j < DCM_U; j++) cur[j] = colptr(j)[rr];
     u32 since = 0;
-    for (u32 c0 = 0; c0 < ncol; c0 += U) {
-        if (since + U > 1024) {
+    for (u32 c0 = 0; c0 < ncol; c0 += DCM_U) {
 #pragma unroll
-            for (int g = 0; g < G; g++) { S[g][0].flush(); S[g][1].flush(); }
+        for (int j = 0; j < DCM_U; j++) nxt[j] = colptr(c0 + DCM_U + j)[rr];
+        if (since + DCM_U > 1024) {
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int g = 0; g < G; g++) S[c][g].flush();
             since = 0;
         }
-        since += U;
-        u64 v0[U], v1[U];
+        since += DCM_U;
 #pragma unroll
-        for (int j = 0; j < U; j++) {
-            const u32 c = c0 + j < ncol ? c0 + j : ncol - 1;
-            const u32* r = rec + (u64)c * DCM_REC;
-            const u64* p = (const u64*)(((u64)r[1] << 32) | r[0]);
-            v0[j] = ok0 ? p[row] : 0;
-            v1[j] = ok1 ? p[row + 1] : 0;
-        }
-#pragma unroll
-        for (int j = 0; j < U; j++) {
+        for (int j = 0; j < DCM_U; j++) {
             if (c0 + j >= ncol) break;
-            const u32* r = rec + (u64)(c0 + j) * DCM_REC + 4 + comp * 12;
+            const u32* r = rec + (u64)(c0 + j) * DCM_REC + 4;
 #pragma unroll
-            for (int g = 0; g < G; g++) {
-                const u32 l0 = r[3 * g], l1 = r[3 * g + 1], l2 = r[3 * g + 2];
-                S[g][0].mac(l0, l1, l2, v0[j]);
-                S[g][1].mac(l0, l1, l2, v1[j]);
-            }
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int g = 0; g < G; g++) S[c][g].mac(r[(c * 4 + g) * 3], r[(c * 4 + g) * 3 + 1], r[(c * 4 + g) * 3 + 2], cur[j]);
         }
+#pragma unroll
+        for (int j = 0; j < DCM_U; j++) cur[j] = nxt[j];
     }
 #pragma unroll
-    for (int g = 0; g < G; g++) {
-        S[g][0].flush(); S[g][1].flush();
-        u64* dst = out + (u64)(3 * g + comp) * out_cstride + row;
-        if (ok0) dst[0] = S[g][0].r;
-        if (ok1) dst[1] = S[g][1].r;
-    }
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            S[c][g].flush();
+            if (ok) out[(u64)(3 * g + c) * out_cstride + row] = S[c][g].r;
+        }
 }
 
 // entries: pol = the column's first word, row_stride = the words between the components of an extension column (dim 3)

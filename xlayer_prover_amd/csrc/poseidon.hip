@@ -178,6 +178,31 @@ __global__ __launch_bounds__(256) void perm_kernel(u64* out, const u64* in, u64 
     for (int k = 0; k < 12; k++) out[12 * i + k] = st[k];
 }
 
+// MEASUREMENT AID ("perms/s vs an int-ALU ceiling measured by a register-resident microbenchmark"): the leaf sponge's
+// arithmetic with no memory traffic at all -- every lane walks `iters` chained permutations of a state that never leaves its registers
+// (the capacity is fed back as in the sponge, the rate words are rotated out of the previous output), launched with the sponge's own
+// launch bounds and grid.  What this kernel reaches is the ceiling of THIS formulation of the permutation on this chip; the sponge's
+// distance from it is what its loads cost.
+__global__ __launch_bounds__(256) void perm_resident_kernel(u64* out, u64 count, u64 iters)
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    u64 st[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) st[k] = (i + 1) * 0x9E3779B97F4A7C15ULL + (u64)k * 0xBF58476D1CE4E5B9ULL;
+#pragma unroll 1
+    for (u64 it = 0; it < iters; it++) {
+        permute(st);
+        const u64 c0 = st[0], c1 = st[1], c2 = st[2], c3 = st[3];
+        st[0] = st[4]; st[1] = st[5]; st[2] = st[6]; st[3] = st[7]; st[4] = st[8]; st[5] = st[9]; st[6] = st[10]; st[7] = st[11];
+        st[8] = c0; st[9] = c1; st[10] = c2; st[11] = c3;
+    }
+    u64 x = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) x ^= st[k];
+    out[i] = x;
+}
+
 // The same permutation with ONE state word per lane, for the handful of permutations the Fiat-Shamir transcript asks for
 // one at a time (transcript.cpp:23,46 -- ~800 per zkEVM proof, each waited for by the host): a lane that walks the whole
 // permutation alone retires ~21 500 dependent instructions (64 us measured); here the 12 S-boxes of a full round run in 12
@@ -385,6 +410,13 @@ int dev_perm(Ctx* ctx, u64* out, const u64* in, u64 count)
     return 0;
 }
 
+int dev_perm_resident(Ctx* ctx, u64* out, u64 count, u64 iters)
+{
+    if (!count) return 0;
+    hipLaunchKernelGGL(perm_resident_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, ctx->stream, out, count, iters);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
 int dev_perm_chain(Ctx* ctx, u64* out, const u64* state, const u64* elems, u64 nblocks)
 {
     if (!nblocks) return 0;

@@ -541,6 +541,13 @@ int xlp_dev_dot_columns_cm(uint64_t* out, uint64_t out_cstride, const xlp_dot_en
     return dev_dot_columns_cm(&g_ctx, out, out_cstride, entries, nentries, ngroups, coefs, coefs_size, nrows);
 }
 
+int xlp_dev_perm_resident(uint64_t* out, uint64_t count, uint64_t iters)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if (count && !out) return xlp_fail("xlp_dev_perm_resident: null pointer");
+    return dev_perm_resident(&g_ctx, out, count, iters);
+}
 int xlp_profile_enable(int on)
 {
     XLP_ENTER;

@@ -86,6 +86,7 @@ int dev_extend_cm(Ctx* ctx, u64* out, u64 out_cstride, u64 out_cos, const u64* i
 int poseidon_init(Ctx* ctx);
 int dev_perm(Ctx* ctx, u64* out, const u64* in, u64 count);
 int dev_perm_chain(Ctx* ctx, u64* out, const u64* state, const u64* elems, u64 nblocks);
+int dev_perm_resident(Ctx* ctx, u64* out, u64 count, u64 iters);
 int dev_linear_hash(Ctx* ctx, u64* out, const u64* src, u64 w, u64 h);
 int dev_merkle(Ctx* ctx, u64* nodes, const u64* src, u64 w, u64 h);
 int dev_linear_hash_absorb(Ctx* ctx, u64* state, const u64* src, u64 ld, u64 first, u64 ncols, u64 h, int is_first, int is_last);
