@@ -463,7 +463,7 @@ int xlp_dev_merkle_proofs_cm(uint64_t* out, const uint64_t* src, uint64_t cstrid
                              const uint64_t* idxs, uint64_t nq);
 int xlp_dev_commit_cm(uint64_t* sec_2ns, uint64_t cs2, uint64_t* nodes, const uint64_t* sec_n, uint64_t csn, uint64_t n_ext, uint64_t n, uint64_t ncols);
 int xlp_dev_commit_from_host_cm(uint64_t* sec_n, uint64_t csn, uint64_t* sec_2ns, uint64_t cs2, uint64_t* nodes, const uint64_t* h_src, uint64_t* stage, uint64_t stage_words,
-                                uint64_t n_ext, uint64_t n, uint64_t ncols, double* upload_ms);
+                                int clear_stage /* != 0: every band's staging words are zeroed once transposed */, uint64_t n_ext, uint64_t n, uint64_t ncols, double* upload_ms);
 
 /* Page-locked host memory for the witness slab (hipHostMalloc / hipHostRegister behind a HIP-free signature). */
 int xlp_host_alloc(void** ptr, size_t bytes);

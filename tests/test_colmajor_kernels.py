@@ -117,10 +117,12 @@ def test_commit_cm_equals_oracle(xlp, orc, lg, ext, w, from_host):
     sec_2 = torch.zeros(ne * w, dtype=torch.int64, device="cuda")
     nodes = torch.zeros((2 * ne - 1) * 4, dtype=torch.int64, device="cuda")
     if from_host:
-        stage = torch.zeros(n * w, dtype=torch.int64, device="cuda")
-        xlp.dev_commit_from_host_cm(sec_n, n, sec_2, ne, nodes, np.ascontiguousarray(a.reshape(-1)), stage, ne, n, w)
+        stage = torch.full((n * w + 3,), 5, dtype=torch.int64, device="cuda")
+        xlp.dev_commit_from_host_cm(sec_n, n, sec_2, ne, nodes, np.ascontiguousarray(a.reshape(-1)), stage, ne, n, w, clear_stage=(w % 2 == 0))
         xlp.sync()
         assert (_rows(xlp.to_np(sec_n), n, w, 0) == a).all()
+        st = xlp.to_np(stage)
+        assert (st[n * w:] == 5).all() and ((st[:n * w] == 0).all() if w % 2 == 0 else (st[:n * w] == a.reshape(-1)).all())
     else:
         sec_n = xlp.from_np(_cm(a, 0))
         xlp.dev_commit_cm(sec_2, ne, nodes, sec_n, n, ne, n, w)

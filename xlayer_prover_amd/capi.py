@@ -89,7 +89,7 @@ SIGNATURES = {
     "xlp_dev_merkle_cm": [_pu, _pu, _u64, _u64, _u64, _u64, C.c_uint32],
     "xlp_dev_merkle_proofs_cm": [_pu, _pu, _u64, _u64, _pu, _u64, _u64, C.c_uint32, _pu, _u64],
     "xlp_dev_commit_cm": [_pu, _u64, _pu, _pu, _u64, _u64, _u64, _u64],
-    "xlp_dev_commit_from_host_cm": [_pu, _u64, _pu, _u64, _pu, _pu, _pu, _u64, _u64, _u64, _u64, C.POINTER(C.c_double)],
+    "xlp_dev_commit_from_host_cm": [_pu, _u64, _pu, _u64, _pu, _pu, _pu, _u64, C.c_int, _u64, _u64, _u64, C.POINTER(C.c_double)],
     "xlp_dev_commit_from_host": [_pu, _pu, _pu, _pu, _u64, _u64, _u64, C.POINTER(C.c_double)],
     "xlp_cache_enable": [C.c_size_t],
     "xlp_cache_invalidate": [_pu, C.c_size_t],
@@ -498,10 +498,10 @@ def dev_commit_cm(sec_2ns, cs2, nodes, sec_n, csn, n_ext, n, ncols):
     _ck(load().xlp_dev_commit_cm(_dp(sec_2ns), cs2, _dp(nodes), _dp(sec_n), csn, n_ext, n, ncols), "xlp_dev_commit_cm")
 
 
-def dev_commit_from_host_cm(sec_n, csn, sec_2ns, cs2, nodes, host, stage, n_ext, n, ncols, want_upload_ms=False):
+def dev_commit_from_host_cm(sec_n, csn, sec_2ns, cs2, nodes, host, stage, n_ext, n, ncols, want_upload_ms=False, clear_stage=False):
     ptr = host.ptr if isinstance(host, HostBuffer) else host.ctypes.data_as(C.c_void_p)
     ms = C.c_double(0.0)
-    _ck(load().xlp_dev_commit_from_host_cm(_dp(sec_n), csn, _dp(sec_2ns), cs2, _dp(nodes), ptr, _dp(stage), stage.numel(), n_ext, n, ncols, C.byref(ms) if want_upload_ms else None),
+    _ck(load().xlp_dev_commit_from_host_cm(_dp(sec_n), csn, _dp(sec_2ns), cs2, _dp(nodes), ptr, _dp(stage), stage.numel(), 1 if clear_stage else 0, n_ext, n, ncols, C.byref(ms) if want_upload_ms else None),
         "xlp_dev_commit_from_host_cm")
     return ms.value
 

@@ -24,12 +24,13 @@
 namespace xlp {
 
 
-// e[v * 2^BT + k] = root^(k v) from the two-level power tables of root
+// e[k * 8 + v] = root^(k v) from the two-level power tables of root (the eight columns of a position share a 64-byte line: a wave's
+// 64 lanes -- 8 columns x 8 positions -- touch 8 lines per load)
 __global__ void lde_cm_etable_kernel(u64* e, const u64* __restrict__ lo, const u64* __restrict__ hi, u32 BT)
 {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (8u << BT)) return;
-    const u32 v = i >> BT, k = i & ((1u << BT) - 1);
+    const u32 v = i & 7, k = i >> 3;
     e[i] = gl::canon(two_level12(lo, hi, (u64)k * v));
 }
 
@@ -38,7 +39,8 @@ template <int BT>
 __global__ __launch_bounds__(XLP_WGT) void lde_cm_top_dif(const LdeCmParams p)
 {
     constexpr int V = 8, m = (BT + 3) / 4, dtop = BT - 4 * (m - 1);
-    extern __shared__ u64 sm[];
+    extern __shared__ u64 smem[];
+    u64* sm = smem + LDE_PF_LDS / 8;                        // (the first 256 bytes: the dummy target of the successor prefetch, LDS offset 0)
     u64* cross = sm + ((1u << BT) + (1u << BT) / 16 + 1) * V;
     const u32 tile = xcd_tile();
     const u32 lg = tile & 511, c = tile >> 9;               // lo group fastest: co-resident workgroups share 128-byte lines
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(XLP_WGT) void lde_cm_top_dif(const LdeCmParams p)
     auto gstore = [&](u32 tpos, u32 v, u64 val, u32) { Ac[((u64)tpos << 12) + v] = val; };
     auto crossf = [&](u32 tpos, u32 v) -> u64 {
         const u32 k1 = tile_natural_c<BT>(tpos);
-        return v ? gl::mul(cross[k1], ei[((u32)v << BT) + k1]) : cross[k1];
+        return v ? gl::mul(cross[k1], ei[k1 * 8 + v]) : cross[k1];
     };
     if constexpr (m == 2) {
         fast_round<BT, V, 4, dtop, false, true>(p.twi_bt, gload, lstore);
@@ -64,6 +66,12 @@ __global__ __launch_bounds__(XLP_WGT) void lde_cm_top_dif(const LdeCmParams p)
         XLP_SYNC();
         fast_round<BT, V, 4, 4, false, true>(p.twi_bt, lload, lstore);
         XLP_SYNC();
+        // successor prefetch (see ntt_lde.hip): the workgroup that follows this one on its CU is block id + 256 = tile + 32 under xcd_tile
+        if (gridDim.x >= 16 && (gridDim.x & 7) == 0 && blockIdx.x + 256 < gridDim.x) {
+            const u32 nt = tile + 32;
+            const u64* q = p.in + (u64)(p.col0 + (nt >> 9)) * p.in_cs + (nt & 511) * 8;
+            for (u32 tpos = threadIdx.x; tpos < (1u << BT); tpos += blockDim.x) prefetch_touch(q + ((u64)tpos << 12), 0u);
+        }
         fast_round<BT, V, 0, 4, false, true, false, true>(p.twi_bt, lload, gstore, NoFactor{}, crossf);
     }
 }
@@ -90,7 +98,7 @@ __global__ __launch_bounds__(XLP_WGT) void lde_cm_top_dit(const LdeCmParams p)
     auto gload = [&](u32 tpos, u32 v, u32) -> u64 { return Bc[((u64)tpos << 12) + v]; };
     auto crossf = [&](u32 tpos, u32 v) -> u64 {
         const u32 j1 = tile_natural_c<BT>(tpos);
-        return v ? gl::mul(cross[j1], ef[((u32)v << BT) + j1]) : cross[j1];
+        return v ? gl::mul(cross[j1], ef[j1 * 8 + v]) : cross[j1];
     };
     auto lload = [&](u32, u32 v, u32 lrow) -> u64 { return sm[lrow * V + v]; };
     auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { sm[lrow * V + v] = val; };
@@ -118,7 +126,7 @@ static int launch_cm_top(Ctx* ctx, const LdeCmParams& p, bool dit)
     constexpr u32 V = 8;
     u32 threads = (1u << (BT - 4)) * V < 64 ? 64 : (1u << (BT - 4)) * V;
     if (threads > XLP_WGT) threads = XLP_WGT;
-    const size_t lds = ((size_t)((1u << BT) + (1u << BT) / 16 + 1) * V + (1u << BT)) * sizeof(u64);
+    const size_t lds = ((size_t)((1u << BT) + (1u << BT) / 16 + 1) * V + (1u << BT)) * sizeof(u64) + LDE_PF_LDS;
     static bool attr_done = false;
     if (!attr_done) {
         XLP_HIP(hipFuncSetAttribute((const void*)lde_cm_top_dif<BT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -164,7 +172,7 @@ int dev_extend_cm_fast(Ctx* ctx, u64* out, u64 out_cstride, u64 out_cos, const u
     if (get_pow_tables(ctx, L, wn, 1, &p.crf_lo, &p.crf_hi)) return -1;
     for (int dir = 0; dir < 2; dir++) {                     // E tables, cached under (300 + BT | 400 + BT, root, 1)
         const u64 root = dir ? wn : hgl::inv(wn);
-        auto key = std::make_tuple((dir ? 400u : 300u) + BT, root, (u64)1);
+        auto key = std::make_tuple((dir ? 400u : 300u) + BT, root, (u64)8);
         auto it = ctx->tables.find(key);
         if (it == ctx->tables.end()) {
             u64* d = nullptr;

@@ -14,7 +14,7 @@ struct LdeCmParams {
     u32 L, e;
     const u64 *twi_bt, *twf_bt, *twi_12, *twf_12;
     const u64 *cri_lo, *cri_hi, *crf_lo, *crf_hi;
-    const u64 *ei, *ef;                  // ei[v][k] = w(L)^(-k v), ef[v][k] = w(L)^(k v): v < 8, k < 2^BT
+    const u64 *ei, *ef;                  // ei[k][v] = w(L)^(-k v), ef[k][v] = w(L)^(k v): v < 8, k < 2^BT
     const u64* tw2[LDE_MAX_COSETS];
     const u64* hk[LDE_MAX_COSETS];
     const u64* ur[LDE_MAX_COSETS];

@@ -56,6 +56,15 @@ __device__ __forceinline__ u32 xcd_tile()
     return (g >= 16 && (g & 7) == 0) ? (bid & 7) * (g >> 3) + (bid >> 3) : bid;
 }
 
+constexpr u32 LDE_PF_LDS = 256;                              // bytes of dummy LDS in front of the tile (one wave instruction = 64 x 4 B)
+// M0 (reserved by the compiler) is saved and restored around the load; one wait state between its write and the LDS-direct load.
+__device__ __forceinline__ void prefetch_touch(const u64* q, u32 lds_off)
+{
+    u32 m0_saved;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_saved) : "v"(q), "s"(lds_off) : "memory");
+}
+
 struct NoFactor { __device__ __forceinline__ u64 operator()(u32, u32) const { return 1; } };   // (tile position, column of the tile)
 
 

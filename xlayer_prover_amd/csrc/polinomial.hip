@@ -663,12 +663,16 @@ __global__ void dcm_expand_kernel(u32* rec, const DcmContrib* con, const u32* cf
 }
 
 // One lane = one row, ALL three components and all G groups of its sums (18 G accumulators): a column word is loaded once per row and
-// meets 3 G wave-uniform multipliers (their limbs arrive by scalar loads: the column index is the loop counter).  The words of the next
-// DCM_U columns are in flight while the current ones are multiplied.
-constexpr int DCM_U = 4;
+// meets 3 G wave-uniform multipliers.  The column records (pointer + limbs: 160 bytes each) go through LDS in chunks of DCM_CH columns,
+// double-buffered: read with scalar loads they cost a scalar-cache miss per column that three waves per SIMD do not cover (the row-major
+// kernel's lesson, profiles/r3/dot_columns_ab.txt); from LDS they are broadcast reads.  The words of the next DCM_U columns are in flight
+// while the current ones are multiplied.
+constexpr int DCM_U = 4, DCM_CH = 32;
 template <int G>
-__global__ __launch_bounds__(DCM_T) void dot_columns_cm_kernel(u64* out, u64 out_cstride, const u32* __restrict__ rec, u32 ncol, u64 nrows)
+__global__ __launch_bounds__(DCM_T, G <= 3 ? 3 : 2) void dot_columns_cm_kernel(u64* out, u64 out_cstride, const u32* __restrict__ rec, u32 ncol, u64 nrows)
 {
+    __shared__ u32 srec[2][DCM_CH * DCM_REC];
+    static_assert(DCM_CH * DCM_REC == 5 * DCM_T, "a thread moves five dwords of a chunk");
     const u64 row = (u64)blockIdx.x * DCM_ROWS + threadIdx.x;
     const bool ok = row < nrows;
     const u64 rr = ok ? row : nrows - 1;                      // lanes past the end read the last row (in bounds) and store nothing
@@ -677,36 +681,56 @@ __global__ __launch_bounds__(DCM_T) void dot_columns_cm_kernel(u64* out, u64 out
     for (int c = 0; c < 3; c++)
 #pragma unroll
         for (int g = 0; g < G; g++) S[c][g].clear();
-    auto colptr = [&](u32 c) -> const u64* {
-        const u32* r = rec + (u64)(c < ncol ? c : ncol - 1) * DCM_REC;
-        return (const u64*)(((u64)r[1] << 32) | r[0]);
+    const u32 nch = (ncol + DCM_CH - 1) / DCM_CH;
+    const u64 nwords = (u64)ncol * DCM_REC;
+    u32 mv[5];
+    auto gfetch = [&](u32 ch) {
+#pragma unroll
+        for (int i = 0; i < 5; i++) { const u64 w = (u64)ch * DCM_CH * DCM_REC + threadIdx.x + i * DCM_T; mv[i] = w < nwords ? rec[w] : 0; }
     };
-    u64 cur[DCM_U], nxt[DCM_U];
+    auto lput = [&](u32 buf) {
 #pragma unroll
-    for (int j = 0; j < DCM_U; j++) cur[j] = colptr(j)[rr];
+        for (int i = 0; i < 5; i++) srec[buf][threadIdx.x + i * DCM_T] = mv[i];
+    };
+    gfetch(0); lput(0);
+    __syncthreads();
     u32 since = 0;
-    for (u32 c0 = 0; c0 < ncol; c0 += DCM_U) {
+    for (u32 ch = 0; ch < nch; ch++) {
+        if (ch + 1 < nch) gfetch(ch + 1);
+        const u32* R = srec[ch & 1];
+        const u32 ncc = ncol - ch * DCM_CH < (u32)DCM_CH ? ncol - ch * DCM_CH : (u32)DCM_CH;
+        auto colptr = [&](u32 j) -> const u64* {
+            const u32* r = R + (j < ncc ? j : ncc - 1) * DCM_REC;
+            return (const u64*)(((u64)r[1] << 32) | r[0]);
+        };
+        u64 cur[DCM_U], nxt[DCM_U];
 #pragma unroll
-        for (int j = 0; j < DCM_U; j++) nxt[j] = colptr(c0 + DCM_U + j)[rr];
-        if (since + DCM_U > 1024) {
+        for (int j = 0; j < DCM_U; j++) cur[j] = colptr(j)[rr];
+        for (u32 j0 = 0; j0 < ncc; j0 += DCM_U) {
 #pragma unroll
-            for (int c = 0; c < 3; c++)
+            for (int j = 0; j < DCM_U; j++) nxt[j] = colptr(j0 + DCM_U + j)[rr];
+            if (since + DCM_U > 1024) {
 #pragma unroll
-                for (int g = 0; g < G; g++) S[c][g].flush();
-            since = 0;
+                for (int c = 0; c < 3; c++)
+#pragma unroll
+                    for (int g = 0; g < G; g++) S[c][g].flush();
+                since = 0;
+            }
+            since += DCM_U;
+#pragma unroll
+            for (int j = 0; j < DCM_U; j++) {
+                if (j0 + j >= ncc) break;
+                const u32* r = R + (j0 + j) * DCM_REC + 4;
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+#pragma unroll
+                    for (int g = 0; g < G; g++) S[c][g].mac(r[(c * 4 + g) * 3], r[(c * 4 + g) * 3 + 1], r[(c * 4 + g) * 3 + 2], cur[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < DCM_U; j++) cur[j] = nxt[j];
         }
-        since += DCM_U;
-#pragma unroll
-        for (int j = 0; j < DCM_U; j++) {
-            if (c0 + j >= ncol) break;
-            const u32* r = rec + (u64)(c0 + j) * DCM_REC + 4;
-#pragma unroll
-            for (int c = 0; c < 3; c++)
-#pragma unroll
-                for (int g = 0; g < G; g++) S[c][g].mac(r[(c * 4 + g) * 3], r[(c * 4 + g) * 3 + 1], r[(c * 4 + g) * 3 + 2], cur[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < DCM_U; j++) cur[j] = nxt[j];
+        if (ch + 1 < nch) lput((ch + 1) & 1);
+        __syncthreads();
     }
 #pragma unroll
     for (int c = 0; c < 3; c++)

@@ -786,7 +786,7 @@ static int commit_bands(uint64_t* sec_n, uint64_t* sec_2ns, uint64_t* nodes, con
 // is uploaded as it is -- a dense row-major [n][band] matrix -- into `stage` (device scratch of >= n * ncols words: in step 1 the dead
 // base-domain sections behind cm1_n) on the copy stream and transposed into its columns on the compute stream ahead of its extension.
 static int commit_bands_cm(uint64_t* sec_n, uint64_t csn, uint64_t* sec_2ns, uint64_t cs2, uint64_t* nodes, const uint64_t* h_src, uint64_t* stage, uint64_t stage_words,
-                           uint64_t n_ext, uint64_t n, uint64_t ncols, double* upload_ms)
+                           uint64_t n_ext, uint64_t n, uint64_t ncols, double* upload_ms, int clear_stage = 0)
 {
     CommitTimes& T = g_commit_times;
     T.clear();
@@ -842,6 +842,8 @@ static int commit_bands_cm(uint64_t* sec_n, uint64_t csn, uint64_t* sec_2ns, uin
         if (h_src) {
             XLP_HIP(hipStreamWaitEvent(ctx->stream, ev[b], 0));
             if (dev_rows_to_cm(ctx, sec_n + c0 * csn, csn, 0, stage + n * c0, wc, 0, wc, n, 0)) return -1;
+            // the staging area is somebody's section again afterwards: hand it back zeroed, band by band (the compute stream waits for PCIe anyway)
+            if (clear_stage) XLP_HIP(hipMemsetAsync(stage + n * c0, 0, n * wc * sizeof(u64), ctx->stream));
         }
         if (T.begin(T.lde, ctx->stream) || dev_extend_cm(ctx, sec_2ns + c0 * cs2, cs2, 0, sec_n + c0 * csn, csn, n_ext, n, wc) || T.end(T.lde, ctx->stream)) return -1;
         if (ncols > 4) {
@@ -868,12 +870,12 @@ int xlp_dev_commit_cm(uint64_t* sec_2ns, uint64_t cs2, uint64_t* nodes, const ui
     return commit_bands_cm(const_cast<uint64_t*>(sec_n), csn, sec_2ns, cs2, nodes, nullptr, nullptr, 0, n_ext, n, ncols, nullptr);
 }
 int xlp_dev_commit_from_host_cm(uint64_t* sec_n, uint64_t csn, uint64_t* sec_2ns, uint64_t cs2, uint64_t* nodes, const uint64_t* h_src, uint64_t* stage, uint64_t stage_words,
-                                uint64_t n_ext, uint64_t n, uint64_t ncols, double* upload_ms)
+                                int clear_stage, uint64_t n_ext, uint64_t n, uint64_t ncols, double* upload_ms)
 {
     XLP_ENTER;
     if (ensure_init()) return -1;
     if (ncols && n && (!h_src || !stage)) return xlp_fail("xlp_dev_commit_from_host_cm: null host pointer or staging area");
-    return commit_bands_cm(sec_n, csn, sec_2ns, cs2, nodes, h_src, stage, stage_words, n_ext, n, ncols, upload_ms);
+    return commit_bands_cm(sec_n, csn, sec_2ns, cs2, nodes, h_src, stage, stage_words, n_ext, n, ncols, upload_ms, clear_stage);
 }
 int xlp_dev_commit_last_times(double* lde_ms, double* merkle_ms)
 {

@@ -94,9 +94,9 @@ struct XlpHashGL
         XLP_CHECK(xlp_dev_commit_cm(sec2ns, cs2, tree->d_nodes, secn, csn, NExtended, N, W));
     }
     static void commitFromHostCm(Tree* tree, uint64_t* secn, uint64_t csn, uint64_t* sec2ns, uint64_t cs2, const uint64_t* h_src, uint64_t* stage, uint64_t stageWords,
-                                 uint64_t NExtended, uint64_t N, uint64_t W, double* busyMs)
+                                 bool clearStage, uint64_t NExtended, uint64_t N, uint64_t W, double* busyMs)
     {
-        XLP_CHECK(xlp_dev_commit_from_host_cm(secn, csn, sec2ns, cs2, tree->d_nodes, h_src, stage, stageWords, NExtended, N, W, busyMs));
+        XLP_CHECK(xlp_dev_commit_from_host_cm(secn, csn, sec2ns, cs2, tree->d_nodes, h_src, stage, stageWords, clearStage ? 1 : 0, NExtended, N, W, busyMs));
     }
     static void storeRoots(Proof& proof, Goldilocks::Element* r0, Goldilocks::Element* r1, Goldilocks::Element* r2, Goldilocks::Element* r3)
     {
@@ -838,8 +838,12 @@ public:
         // the base-domain sections other than the witness start from zero (prover.cpp:426-430 clears the committed polynomials; in the
         // aliased layout the previous proof's extended sections lie there).  Column-major: AFTER step 1, whose witness bands land there first
         const uint64_t zeroFrom = starkInfo.mapOffsets.section[cm2_n], zeroTo = starkInfo.mapOffsets.section[tmpExp_n] + N * starkInfo.mapSectionsN.section[tmpExp_n];
-        auto clearBaseSections = [&]() { if (zeroTo > zeroFrom && zeroTo <= slabWords) XLP_CHECK(xlp_dev_memset(mem() + zeroFrom, 0, (zeroTo - zeroFrom) * sizeof(uint64_t))); };
-        if (!colMajor) clearBaseSections();
+        auto clearBaseSections = [&](uint64_t skipWords) {      // [zeroFrom + skipWords, zeroTo)
+            if (zeroTo > zeroFrom + skipWords && zeroTo <= slabWords) XLP_CHECK(xlp_dev_memset(mem() + zeroFrom + skipWords, 0, (zeroTo - zeroFrom - skipWords) * sizeof(uint64_t)));
+        };
+        // (column-major, pipelined upload: the first N x W1 words are the staging area of step 1, zeroed there band by band once transposed)
+        const bool stageInSections = colMajor && zeroTo > zeroFrom && zeroTo <= slabWords && zeroTo - zeroFrom >= N * starkInfo.mapSectionsN.section[cm1_n];
+        clearBaseSections(stageInSections ? N * starkInfo.mapSectionsN.section[cm1_n] : 0);
         XLP_CHECK(xlp_copy_h2d(d_publics, publicInputs, starkInfo.nPublics * sizeof(uint64_t)));
         H::putVerkey(transcript, verkey, constRoot);
         transcript.put(&publicInputs[0], starkInfo.nPublics);
@@ -859,13 +863,13 @@ public:
             Timer t(this, "STARK_STEP_1_LDE_AND_MERKLETREE");
             if constexpr (H::kCommitTimes) {
               if (colMajor) {
-                if (pipelineWitness) H::commitFromHostCm(treesGL[0], section(cm1_n), N, section(cm1_2ns), NExtended, h_cm1, stage, stageWords, NExtended, N, W1, &lastUploadMs);
+                if (pipelineWitness) H::commitFromHostCm(treesGL[0], section(cm1_n), N, section(cm1_2ns), NExtended, h_cm1, stage, stageWords, stageInSections, NExtended, N, W1, &lastUploadMs);
                 else {
                     XLP_CHECK(xlp_dev_rows_to_cm(section(cm1_n), N, 0, stage, W1, 0, W1, N, 0));
+                    if (stageInSections) XLP_CHECK(xlp_dev_memset(stage, 0, N * W1 * sizeof(uint64_t)));
                     H::commitCm(treesGL[0], section(cm1_2ns), NExtended, section(cm1_n), N, NExtended, N, W1);
                 }
                 if (ownStage) { XLP_CHECK(xlp_sync()); xlp_dev_free(ownStage); }
-                clearBaseSections();
               }
             }
             if (colMajor) {}
