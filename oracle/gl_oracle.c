@@ -361,32 +361,49 @@ void orc_extend_pol(u64 *out, const u64 *in, u64 n_ext, u64 n, u64 ncols)
 }
 
 /* The same extension with EVERY host thread at work (bench.py's cpu_baseline on the GPU box's cores): orc_extend_pol above runs one thread
- * per column, which leaves 120 of 128 cores idle on an 8-column trace.  Here the team shares one column at a time: the butterflies of a stage
- * are independent, twiddles come from a table w(log2 n)^i built in parallel chunks.  Same arithmetic, same results as orc_extend_pol
- * (tests/test_oracle_golden.py compares the two). */
-static void ntt_col_team(u64 *a, u64 n, int inverse, const u64 *tw /* w(log2 n)^(+-i), i < n/2 */)
+ * per column, which leaves 120 of 128 cores idle on an 8-column trace.  Here all columns are transformed together by the whole team:
+ * the first 16 stages of a transform stay inside blocks of 2^16 points (one block = one task, in cache), the remaining stages run over
+ * all butterflies of all columns; twiddles come from a table w(log2 n)^i built in parallel chunks.  Same arithmetic, same results as
+ * orc_extend_pol (tests/test_oracle_golden.py compares the two). */
+#define TEAM_BLOCK_LOG 16
+static void ntt_cols_team(u64 *a /* [ncols][n] */, u64 ncols, u64 n, int inverse, const u64 *tw /* w(log2 n)^(+-i), i < n/2 */)
 {
     const unsigned lg = ilog2(n);
+    const unsigned lb = lg < TEAM_BLOCK_LOG ? lg : TEAM_BLOCK_LOG;
+    const u64 nblk = n >> lb;
 #pragma omp for schedule(static)
-    for (u64 i = 0; i < n; i++) {
-        u64 j = bitrev(i, lg);
-        if (i < j) { u64 t = a[i]; a[i] = a[j]; a[j] = t; }
+    for (u64 t = 0; t < ncols * n; t++) {
+        const u64 c = t / n, i = t % n, j = bitrev(i, lg);
+        if (i < j) { u64 *col = a + c * n; u64 x = col[i]; col[i] = col[j]; col[j] = x; }
     }
-    for (unsigned s = 1; s <= lg; s++) {
+#pragma omp for schedule(dynamic, 1)
+    for (u64 t = 0; t < ncols * nblk; t++) {
+        u64 *b = a + (t / nblk) * n + ((t % nblk) << lb);
+        for (unsigned s = 1; s <= lb; s++) {
+            const u64 h = 1ULL << (s - 1), step = n >> s;
+            for (u64 k = 0; k < (1ULL << lb); k += 2 * h)
+                for (u64 j = 0; j < h; j++) {
+                    const u64 x = gl_mul(tw[j * step], b[k + j + h]), u = b[k + j];
+                    b[k + j] = gl_add(u, x);
+                    b[k + j + h] = gl_sub(u, x);
+                }
+        }
+    }
+    for (unsigned s = lb + 1; s <= lg; s++) {
         const u64 h = 1ULL << (s - 1), step = n >> s;
 #pragma omp for schedule(static)
-        for (u64 i = 0; i < n / 2; i++) {
-            const u64 j = i & (h - 1), k = (i >> (s - 1)) << s;
-            const u64 t = gl_mul(tw[j * step], a[k + j + h]);
-            const u64 u = a[k + j];
-            a[k + j] = gl_add(u, t);
-            a[k + j + h] = gl_sub(u, t);
+        for (u64 t = 0; t < ncols * (n / 2); t++) {
+            u64 *col = a + (t / (n / 2)) * n;
+            const u64 i = t % (n / 2), j = i & (h - 1), k = (i >> (s - 1)) << s;
+            const u64 x = gl_mul(tw[j * step], col[k + j + h]), u = col[k + j];
+            col[k + j] = gl_add(u, x);
+            col[k + j + h] = gl_sub(u, x);
         }
     }
     if (inverse) {
         const u64 ninv = gl_inv(n % GL_P);
 #pragma omp for schedule(static)
-        for (u64 i = 0; i < n; i++) a[i] = gl_mul(a[i], ninv);
+        for (u64 t = 0; t < ncols * n; t++) a[t] = gl_mul(a[t], ninv);
     }
 }
 static void pow_table_team(u64 *t, u64 count, u64 base)       /* t[i] = base^i */
@@ -400,25 +417,29 @@ static void pow_table_team(u64 *t, u64 count, u64 base)       /* t[i] = base^i *
 void orc_extend_pol_team(u64 *out, const u64 *in, u64 n_ext, u64 n, u64 ncols)
 {
     if (n == 0 || ncols == 0) return;
-    u64 *col = (u64 *)malloc(n_ext * sizeof(u64));
+    u64 *cols = (u64 *)malloc(n_ext * ncols * sizeof(u64));           /* [ncols][n_ext]: the base transform uses the first n words of a column */
     u64 *twi = (u64 *)malloc((n / 2 + 1) * sizeof(u64)), *twf = (u64 *)malloc((n_ext / 2 + 1) * sizeof(u64)), *sh = (u64 *)malloc(n * sizeof(u64));
+    u64 *base = (u64 *)malloc(n * ncols * sizeof(u64));               /* [ncols][n] */
 #pragma omp parallel
     {
         pow_table_team(twi, n / 2, gl_inv(orc_w(ilog2(n))));
         pow_table_team(twf, n_ext / 2, orc_w(ilog2(n_ext)));
         pow_table_team(sh, n, GL_SHIFT);
-        for (u64 c = 0; c < ncols; c++) {
 #pragma omp for schedule(static)
-            for (u64 i = 0; i < n; i++) col[i] = gl_canon(in[i * ncols + c]);
-            ntt_col_team(col, n, 1, twi);
+        for (u64 i = 0; i < n; i++)
+            for (u64 c = 0; c < ncols; c++) base[c * n + i] = gl_canon(in[i * ncols + c]);
+        ntt_cols_team(base, ncols, n, 1, twi);
 #pragma omp for schedule(static)
-            for (u64 i = 0; i < n_ext; i++) col[i] = i < n ? gl_mul(col[i], sh[i]) : 0;
-            ntt_col_team(col, n_ext, 0, twf);
-#pragma omp for schedule(static)
-            for (u64 i = 0; i < n_ext; i++) out[i * ncols + c] = col[i];
+        for (u64 t = 0; t < ncols * n_ext; t++) {
+            const u64 c = t / n_ext, i = t % n_ext;
+            cols[t] = i < n ? gl_mul(base[c * n + i], sh[i]) : 0;
         }
+        ntt_cols_team(cols, ncols, n_ext, 0, twf);
+#pragma omp for schedule(static)
+        for (u64 i = 0; i < n_ext; i++)
+            for (u64 c = 0; c < ncols; c++) out[i * ncols + c] = cols[c * n_ext + i];
     }
-    free(col); free(twi); free(twf); free(sh);
+    free(cols); free(twi); free(twf); free(sh); free(base);
 }
 
 /* Naive evaluation: out[k] = P(shift*w_ext^k) by Horner over INTT coefficients

@@ -804,9 +804,15 @@ static int commit_bands_cm(uint64_t* sec_n, uint64_t csn, uint64_t* sec_2ns, uin
     std::vector<u64> starts, widths;
     if (ncols <= 4 || ncols <= band) { starts.push_back(0); widths.push_back(ncols); }
     else if (h_src && !getenv("XLP_COMMIT_BAND") && ncols >= 320) {
+        // On this layout a band costs the GPU about as long as PCIe takes to deliver it (extendPol + leaf sponge + the transposition: 1.15 ms per
+        // column of 2^23 rows against 1.3), so with the row-major plan (widest band first) the step took first upload + ALL of the compute:
+        // the stream never waited again after band 0.  Here the FIRST band is small (the compute starts after 64 columns instead of 168), the
+        // middle ones wide (PCIe rate), the last ones narrow (what is left to do when the last byte has arrived).  XLP_COMMIT_PLAN=0: the row-major plan.
+        const bool small_first = !(getenv("XLP_COMMIT_PLAN") && atoi(getenv("XLP_COMMIT_PLAN")) == 0);
         std::vector<u64> rev;
-        double w = 48.0;
-        for (u64 rem = ncols / 8 * 8; rem;) {
+        double w = small_first ? 32.0 : 48.0;
+        const u64 head = small_first ? 64 : 0;
+        for (u64 rem = ncols / 8 * 8 - head; rem;) {
             u64 ww = ((u64)(w + 4.0)) / 8 * 8;
             if (ww > rem) ww = rem;
             rev.push_back(ww); rem -= ww;
@@ -814,6 +820,14 @@ static int commit_bands_cm(uint64_t* sec_n, uint64_t csn, uint64_t* sec_2ns, uin
         }
         rev[0] += ncols % 8;
         if (rev.size() > 1 && rev.back() < 64) { rev[rev.size() - 2] += rev.back(); rev.pop_back(); }
+        if (head) rev.push_back(head);
+        if (const char* ev = getenv("XLP_COMMIT_PLAN_WIDTHS")) {          // experiments: an explicit plan "w0,w1,..." (multiples of 8 but the last, summing to ncols)
+            std::vector<u64> ws;
+            u64 sum = 0; bool ok = true;
+            for (const char* q = ev; *q;) { char* e2; const u64 v = strtoull(q, &e2, 10); if (e2 == q || !v) { ok = false; break; } ws.push_back(v); sum += v; q = *e2 == ',' ? e2 + 1 : e2; }
+            for (size_t k = 0; k + 1 < ws.size(); k++) if (ws[k] % 8) ok = false;
+            if (ok && sum == ncols) { rev.assign(ws.rbegin(), ws.rend()); }
+        }
         u64 c0 = 0;
         for (size_t k = rev.size(); k-- > 0;) { starts.push_back(c0); widths.push_back(rev[k]); c0 += rev[k]; }
     } else {
