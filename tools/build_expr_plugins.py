@@ -74,6 +74,10 @@ def main():
                 code, ntmp1, ntmp3 = geo[step]
             else:
                 code, _ = R.shrink(code, 1 << lr)
+            if geo and not step.endswith("_tab"):             # what the segment form moves per row (offline model of the generated kernels)
+                from xlayer_prover_amd import expr_opt
+                cw, tw = expr_opt.segment_traffic(code, int(os.environ.get("XLP_EXPR_SEG", "256")))
+                print(f"{name}: segment model: {cw} column words loaded per row, {tw} temporary words across segment boundaries", flush=True)
             p = capi.ExprProgram(code, ntmp1, ntmp3, colmajor=bool(geo) and a.colmajor and not step.endswith("_tab"))
             # regenerate the launcher text (cheap) and rebuild only if it changed: its signature covers the whole
             # compiled program, so a change of the library's compile step invalidates the plugin too

@@ -804,11 +804,10 @@ static int commit_bands_cm(uint64_t* sec_n, uint64_t csn, uint64_t* sec_2ns, uin
     std::vector<u64> starts, widths;
     if (ncols <= 4 || ncols <= band) { starts.push_back(0); widths.push_back(ncols); }
     else if (h_src && !getenv("XLP_COMMIT_BAND") && ncols >= 320) {
-        // On this layout a band costs the GPU about as long as PCIe takes to deliver it (extendPol + leaf sponge + the transposition: 1.15 ms per
-        // column of 2^23 rows against 1.3), so with the row-major plan (widest band first) the step took first upload + ALL of the compute:
-        // the stream never waited again after band 0.  Here the FIRST band is small (the compute starts after 64 columns instead of 168), the
-        // middle ones wide (PCIe rate), the last ones narrow (what is left to do when the last byte has arrived).  XLP_COMMIT_PLAN=0: the row-major plan.
-        const bool small_first = !(getenv("XLP_COMMIT_PLAN") && atoi(getenv("XLP_COMMIT_PLAN")) == 0);
+        // The row-major plan (wide first, narrowing by 15 %) stays: plans with a small first band, or with uniform wide bands, measured within
+        // +-1 % of it and none better (profiles/r4/commit_band_plan_ab.txt: step 1 1.069-1.110 s over eight plans).  XLP_COMMIT_PLAN=1: small first band;
+        // XLP_COMMIT_PLAN_WIDTHS: an explicit plan.
+        const bool small_first = getenv("XLP_COMMIT_PLAN") && atoi(getenv("XLP_COMMIT_PLAN")) == 1;
         std::vector<u64> rev;
         double w = small_first ? 32.0 : 48.0;
         const u64 head = small_first ? 64 : 0;
