@@ -117,18 +117,24 @@ def merkle_leg(capi, torch, dev):
     h, w = 1 << 20, 751
     rows = torch.empty(h * w, dtype=torch.int64, device=dev); nodes = torch.empty((2 * h - 1) * 4, dtype=torch.int64, device=dev)
     capi.dev_fill(rows, 0x5EED0003, 0)
-    capi.dev_linear_hash(nodes, rows, w, h)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 3
-    e0.record()
-    for _ in range(reps):
-        capi.dev_linear_hash(nodes, rows, w, h)
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+
+    def timed(fn):
+        fn()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    ms_row = timed(lambda: capi.dev_linear_hash(nodes, rows, w, h))
+    # the product path (round 4): the same words read as COLUMNS (the buffer taken as 751 columns of 2^20 words: timing does not depend on the values)
+    ms = timed(lambda: capi.dev_linear_hash_absorb_cm(nodes, rows, h, 0, w, h, 0, True, True))
     perms = h * ((w + 7) // 8)
     alg = 8 * h * w + 32 * h
     c, stale, src = counters()
-    out = {"kernel": "xlp::linear_hash_kernel (leaf sponge of merkletree, 2^20 x 751 rows)", "bound": "valu", "avg_launch_ms": round(ms, 4),
+    out = {"kernel": "xlp::linear_hash_absorb_cm_kernel (leaf sponge of merkletree over a column-major section, 2^20 x 751 rows; the product path)", "bound": "valu", "avg_launch_ms": round(ms, 4),
+           "row_major_sections": {"kernel": "xlp::linear_hash_kernel", "avg_launch_ms": round(ms_row, 4), "permutations_per_s": round(h * ((w + 7) // 8) / ms_row * 1e3, 0)},
            "permutations_per_s": round(perms / ms * 1e3, 0), "hbm": {"achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4),
                                                                      "alg_bytes_per_launch": alg}}
     # the ceiling SURVEY 8d asks for: the same permutations per lane on the same grid with the state resident in registers (no HBM traffic at all)
@@ -146,8 +152,8 @@ def merkle_leg(capi, torch, dev):
                               "frac": round(ms_res / ms, 4), "note": "frac = sponge rate / this ceiling: what is missing is what the sponge's loads cost"}
     except Exception as e:                                   # noqa: BLE001
         out["alu_ceiling"] = {"error": repr(e)[:200]}
-    if c and "merkle" in c:
-        m = c["merkle"]
+    if c and (c.get("merkle_colmajor") or "merkle" in c):
+        m = c.get("merkle_colmajor") or c["merkle"]
         rate = m["valu_wave_instructions_linear_hash"] / (ms * 1e-3)
         out["valu_issue"] = {"achieved": round(rate / 1e9, 1), "unit": "G wave-instr/s", "lane_instructions_per_permutation": round(m["valu_lane_instructions_per_permutation"], 0),
                              "note": "instructions retired per second (counter-derived); the ceiling of this kernel is alu_ceiling above, measured, not a model of issue rates"}

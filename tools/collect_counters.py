@@ -19,7 +19,8 @@ sys.path.insert(0, ROOT)
 from xlayer_prover_amd.srchash import csrc_hash      # noqa: E402
 
 PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU"]]
-KERNELS = {"lde_top_dif": "lde_top_dif", "lde_mid": "lde_mid", "lde_top_dit": "lde_top_dit", "linear_hash_kernel": "linear_hash",
+KERNELS = {"lde_cm_top_dif": "lde_cm_top_dif", "lde_cm_mid": "lde_cm_mid", "lde_cm_top_dit": "lde_cm_top_dit", "linear_hash_absorb_cm_kernel": "linear_hash_cm",
+           "lde_top_dif": "lde_top_dif", "lde_mid": "lde_mid", "lde_top_dit": "lde_top_dit", "linear_hash_kernel": "linear_hash",
            "merkle_level_kernel": "merkle_level", "copy_canon_kernel": "calibration_copy"}
 
 
@@ -79,13 +80,21 @@ def main():
                    "algorithmic_bytes_linear_hash": 8 * h * w + 32 * h,
                    "valu_wave_instructions_linear_hash": per["linear_hash"]["SQ_INSTS_VALU"],
                    "valu_lane_instructions_per_permutation": per["linear_hash"]["SQ_INSTS_VALU"] * 64 / perms_leaf},
+        "merkle_colmajor": ({"workload": "merkletree 2^20 x 751 on a column-major section (xlp_dev_merkle_cm)", "leaf_permutations": perms_leaf,
+                             "hbm_bytes_linear_hash": per["linear_hash_cm"]["hbm_bytes"], "algorithmic_bytes_linear_hash": 8 * h * w + 32 * h,
+                             "valu_wave_instructions_linear_hash": per["linear_hash_cm"]["SQ_INSTS_VALU"],
+                             "valu_lane_instructions_per_permutation": per["linear_hash_cm"]["SQ_INSTS_VALU"] * 64 / perms_leaf} if "linear_hash_cm" in per else None),
+        "lde_colmajor": ({"workload": "extendPol 2^23 x 8 -> 2^24 x 8 on column-major sections (xlp_dev_extend_cm)",
+                          "hbm_bytes_per_lde": sum(per[k]["hbm_bytes"] for k in ("lde_cm_top_dif", "lde_cm_mid", "lde_cm_top_dit")), "algorithmic_bytes_per_lde": 8 * n * ncols * 3,
+                          "valu_wave_instructions_per_lde": sum(per[k]["SQ_INSTS_VALU"] for k in ("lde_cm_top_dif", "lde_cm_mid", "lde_cm_top_dit"))}
+                         if all(k in per for k in ("lde_cm_top_dif", "lde_cm_mid", "lde_cm_top_dit")) else None),
         "issue_peak_wave_instructions_per_s": 610e9,
         "issue_peak_basis": "1024 SIMDs x 2.4 GHz / 4.2 cycles per half-rate wave64 instruction (carry adds, v_mad_u64_u32, v_cndmask: "
                             "profiles/r1/ubench_instruction_rates.txt), ~10% full-rate moves",
     }
     os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
     json.dump(res, open(out_path, "w"), indent=1)
-    print(json.dumps({k: res[k] for k in ("csrc_sha256", "correction", "lde", "merkle")}, indent=1))
+    print(json.dumps({k: res[k] for k in ("csrc_sha256", "correction", "lde", "merkle", "merkle_colmajor", "lde_colmajor")}, indent=1))
 
 
 if __name__ == "__main__":

@@ -16,8 +16,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_WAVES"]]
 CLASSES = [("seg_", "step-program segments (ahead-of-time)"), ("expr_gather", "column staging: gather"), ("expr_scatter", "column staging: scatter"),
            ("dot_columns", "dot_columns"), ("expr_kernel", "step-program interpreter"), ("linear_hash_absorb", "leaf sponge (banded)"),
-           ("linear_hash_kernel", "leaf sponge"), ("merkle_level", "tree levels"), ("lde_top_dif", "lde_top_dif"), ("lde_mid", "lde_mid"),
-           ("lde_top_dit", "lde_top_dit"), ("copy_cols", "copy_cols"), ("scan3", "calculateZ scans"), ("h1h2", "calculateH1H2"), ("evmap", "evmap")]
+           ("linear_hash_kernel", "leaf sponge"), ("merkle_level", "tree levels"),
+           ("lde_cm_top_dif", "lde_cm_top_dif"), ("lde_cm_mid", "lde_cm_mid"), ("lde_cm_top_dit", "lde_cm_top_dit"),
+           ("lde_top_dif", "lde_top_dif"), ("lde_mid", "lde_mid"), ("lde_top_dit", "lde_top_dit"),
+           ("rows_to_cm", "transposes (witness bands, quotient)"), ("cm_to_rows", "transposes (witness bands, quotient)"), ("copy_view", "view copies (H1H2 / Z operands)"),
+           ("copy_cols", "copy_cols"), ("scan3", "calculateZ scans"), ("h1h2", "calculateH1H2"), ("evmap", "evmap")]
+CONFIG = os.environ.get("XLP_COUNTERS_CONFIG", os.path.join("tools", "config_runFile_BatchProof_synthetic_colmajor.json"))   # the product path: column-major sections
 
 
 def cls(name):
@@ -31,7 +35,7 @@ def run_pass(counters):
     d = tempfile.mkdtemp(prefix="xlp_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "--", os.path.join(ROOT, "xlayer_prover_amd", "host", "zkprover_batch"),
-           "-c", os.path.join("tools", "config_runFile_BatchProof_synthetic.json"), "--proofs", "1"]
+           "-c", CONFIG, "--proofs", "1"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     if r.returncode != 0:
         raise SystemExit(f"rocprofv3 failed: {r.stderr[-2000:]}")
@@ -69,7 +73,7 @@ def main():
             if e["valu_wave_instructions"]:
                 e["valu_G_wave_instr_per_s"] = round(e["valu_wave_instructions"] / dur[k] / 1e9, 1)
         res[k] = e
-    json.dump({"source": "rocprofv3 --pmc <group> -- host/zkprover_batch --proofs 1 (the three STARKs of genBatchProof), summed per kernel class; "
+    json.dump({"config": CONFIG, "source": "rocprofv3 --pmc <group> -- host/zkprover_batch --proofs 1 (the three STARKs of genBatchProof), summed per kernel class; "
                          "FETCH_SIZE x 2, WRITE_SIZE x 1, KiB", "per_class": res}, open(out_path, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

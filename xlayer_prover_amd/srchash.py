@@ -6,7 +6,8 @@ import hashlib
 import os
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-MEASURED = ("gl_field.hpp", "ntt.hip", "ntt_common.hpp", "ntt_lde.hip", "ntt_lde_mid.hip", "ntt_lde_common.hpp", "poseidon.hip", "poseidon_constants.inc", "poseidon_fused.inc")
+MEASURED = ("gl_field.hpp", "ntt.hip", "ntt_common.hpp", "ntt_lde.hip", "ntt_lde_mid.hip", "ntt_lde_common.hpp", "ntt_lde_cm.hip", "ntt_lde_cm_mid.hip", "ntt_lde_cm_common.hpp",
+            "poseidon.hip", "poseidon_constants.inc", "poseidon_fused.inc")
 
 
 def csrc_hash():
