@@ -86,7 +86,7 @@ def test_genbatchproof_colmajor_equals_rowmajor(tmp_path):
         return str(f)
     outs = {}
     for cm in (False, True):
-        for extra in ([], ["--sequential-upload"]):
+        for extra in ([], ["--sequential-upload"]) if cm else ([],):
             r = subprocess.run([exe, "-c", config(f"cfg{cm}.json", cm), "--proofs", "2"] + extra, capture_output=True, text=True, timeout=900)
             assert r.returncode == 0, r.stderr[-3000:]
             lines = [json.loads(l) for l in r.stdout.strip().splitlines()]

@@ -50,20 +50,15 @@ def _to_colmajor_buffers(G, bufs, L, n, ext, nc):
     return {k: np.ascontiguousarray(v) for k, v in cm.items()}      # q_2ns / f_2ns / zi / x_n / challenges ...: as they are
 
 
-CASES = [("zkevm", "step2prev"), ("zkevm", "step3prev"), ("zkevm", "step3"), ("zkevm", "step42ns"), ("zkevm", "step52ns"),
-         ("recursive1", "step3prev"), ("recursive1", "step42ns"), ("recursive1", "step52ns"), ("c12a", "step3"), ("c12a", "step42ns")]
+# (the small STARKs run at their real geometry, 2^17+ rows: their column-major programs are covered by the C++ proofs of tests/test_cpp_colmajor.py)
+CASES = [("zkevm", "step2prev"), ("zkevm", "step3prev"), ("zkevm", "step3"), ("zkevm", "step42ns"), ("zkevm", "step52ns")]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("circ,step", CASES)
 def test_colmajor_program_on_the_gpu_equals_the_rowmajor_program_on_the_oracle(xlp, orc, tmp_path, circ, step):
-    from tools import zkevm_geometry as Gm
-    ln = 8 if circ == "zkevm" else Gm.CIRCUITS[circ]["log_n"]
-    if circ != "zkevm" and ln > 17:
-        ln = Gm.CIRCUITS[circ]["log_n"]
+    ln = 8
     G, progs, info, L, ext = _programs(circ, ln)
-    if circ != "zkevm":
-        pytest.skip("the small STARKs run at their real geometry (2^17+ rows): covered by the C++ proofs")
     code, n1, n3 = progs[step]
     n = 1 << ln
     rows = n << ext if step.endswith("2ns") else n

@@ -10,3 +10,5 @@ cp $(ls $O/prof_bench/*/*kernel_stats.csv | head -1) $O/bench_kernel_stats.csv
 cp $(ls $O/prof_batch/*/*kernel_stats.csv | head -1) $O/genbatchproof_cpp_kernel_stats.csv
 python3 tools/collect_step_counters.py $O/genbatchproof_class_counters.json $O/genbatchproof_cpp_kernel_stats.csv > $O/collect_step_counters.log 2>&1
 tail -3 $O/collect_step_counters.log
+XLP_MEMINFO=1 $R/xlayer_prover_amd/host/zkprover_batch -c tools/config_runFile_BatchProof_synthetic_colmajor.json --proofs 2 > $O/meminfo_colmajor.out 2> $O/meminfo_colmajor.err
+grep "free of" $O/meminfo_colmajor.err | tail -3
