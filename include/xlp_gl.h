@@ -456,6 +456,9 @@ int xlp_dev_dot_columns_cm(uint64_t* out, uint64_t out_cstride, const xlp_dot_en
 int xlp_dev_rows_to_cm(uint64_t* dst, uint64_t dst_cstride, uint64_t dst_coset_stride, const uint64_t* src, uint64_t ld, uint64_t col0, uint64_t ncols, uint64_t rows, uint32_t ext_bits);
 int xlp_dev_cm_to_rows(uint64_t* dst, uint64_t ld, uint64_t col0, const uint64_t* src, uint64_t src_cstride, uint64_t src_coset_stride, uint64_t ncols, uint64_t rows, uint32_t ext_bits);
 int xlp_dev_copy_view(uint64_t* dst, uint64_t dst_row_stride, uint64_t dst_comp_stride, const uint64_t* src, uint64_t src_row_stride, uint64_t src_comp_stride, uint64_t n, uint32_t dim);
+/*   xlp_dev_copy_3d                            dst[a * ds0 + b * ds1 + i] = src[a * ss0 + b * ss1 + i], a < n0, b < n1, i < n: runs of contiguous words regrouped (the packing
+ *                                             around the exchanges of a row-sharded proof on column-major windows, halo rows, windows of replicated tables) */
+int xlp_dev_copy_3d(uint64_t* dst, uint64_t dst_stride0, uint64_t dst_stride1, const uint64_t* src, uint64_t src_stride0, uint64_t src_stride1, uint64_t n0, uint64_t n1, uint64_t n);
 int xlp_dev_extend_cm(uint64_t* out, uint64_t out_cstride, uint64_t out_coset_stride, const uint64_t* in, uint64_t in_cstride, uint64_t n_ext, uint64_t n, uint64_t ncols);
 int xlp_dev_linear_hash_absorb_cm(uint64_t* state, const uint64_t* src, uint64_t cstride, uint64_t coset_stride, uint64_t col0, uint64_t ncols, uint64_t h, uint32_t ext_bits, int first, int last);
 int xlp_dev_merkle_cm(uint64_t* nodes, const uint64_t* src, uint64_t cstride, uint64_t coset_stride, uint64_t w, uint64_t h, uint32_t ext_bits);

@@ -69,10 +69,14 @@ def _run_ranks(bundle, world, backend, tmp_path, timeout=900, env=None):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,backend,scratch_mb,msg_words", [(1, "self", 0, 0), (1, "rccl", 0, 0), (2, "shm", 0, 0), (4, "shm", 0, 0), (2, "shm", 1, 0),
-                                                                (1, "rccl", 1, 1000), (2, "shm", 0, 777), (1, "self", 1, 0)])
-def test_cpp_sharded_starks_proof_equals_one_gpu_proof(tmp_path, world, backend, scratch_mb, msg_words):
-    """scratch_mb: the staging budget of the sharded commit (XLP_SHARD_SCRATCH_MB); 1 MiB forces the exchanges / LDE of a section into many
+@pytest.mark.parametrize("world,backend,scratch_mb,msg_words,colmajor", [
+    (1, "self", 0, 0, False), (1, "rccl", 0, 0, False), (2, "shm", 0, 0, False), (4, "shm", 0, 0, False), (2, "shm", 1, 0, False),
+    (1, "rccl", 1, 1000, False), (2, "shm", 0, 777, False), (1, "self", 1, 0, False),
+    (1, "self", 0, 0, True), (1, "self", 1, 0, True), (2, "shm", 0, 0, True), (2, "shm", 1, 0, True), (4, "shm", 1, 777, True), (1, "rccl", 1, 1000, True)])
+def test_cpp_sharded_starks_proof_equals_one_gpu_proof(tmp_path, world, backend, scratch_mb, msg_words, colmajor):
+    """colmajor: the windows as COLUMNS (a column of a section = the rank's rows + halo; the extended ones as 2^ext coset blocks): what
+    travels in the exchanges is regrouped runs of a rank's rows, the halo of a section is one row per column and coset.
+    scratch_mb: the staging budget of the sharded commit (XLP_SHARD_SCRATCH_MB); 1 MiB forces the exchanges / LDE of a section into many
     column bands, i.e. the two-stream pipeline of commitSharded with both staging sets in use (at the real size a 2-rank zkEVM section needs
     14 bands to stay below 24 GB).  msg_words: XLP_COMM_MAX_MESSAGE_WORDS -- messages of an exchange / all-gather travel in ROUNDS of that many
     words (256 MiB in production, never reached at test sizes); with rccl in a world of one the rank's own block is sent through
@@ -85,7 +89,7 @@ def test_cpp_sharded_starks_proof_equals_one_gpu_proof(tmp_path, world, backend,
     r = subprocess.run([EXE, "bundle", one, "zkevm", str(WSEED), str(CSEED)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     expect = json.loads(r.stdout)
-    win = B.make("zkevm", ln, False, out=str(tmp_path / "win"), world=world)
+    win = B.make("zkevm", ln, False, out=str(tmp_path / "win"), world=world, colmajor=colmajor)
     env = dict(os.environ)
     if scratch_mb:
         env["XLP_SHARD_SCRATCH_MB"] = str(scratch_mb)
@@ -102,7 +106,8 @@ def test_cpp_sharded_starks_proof_equals_one_gpu_proof(tmp_path, world, backend,
 
 
 @pytest.mark.gpu
-def test_genbatchproof_with_the_zkevm_stark_sharded_equals_one_gpu(tmp_path):
+@pytest.mark.parametrize("colmajor", [False, True])
+def test_genbatchproof_with_the_zkevm_stark_sharded_equals_one_gpu(tmp_path, colmajor):
     """Prover::genBatchProof (host/prover.hpp, binary host/zkprover_batch) with --world 2: both ranks prove their rows of the zkEVM STARK
     (window bundle, 2^13 rows), the publics come from rank 0's first and rank 1's last witness row, rank 0 goes on with c12a and
     recursive1 at their real geometry -- the batch proof it prints is the one-GPU run's, byte for byte (FNV of the zkin text)."""
@@ -126,7 +131,7 @@ def test_genbatchproof_with_the_zkevm_stark_sharded_equals_one_gpu(tmp_path):
     r = subprocess.run([exe, "-c", one, "--proofs", "1"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     expect = json.loads(r.stdout.strip().splitlines()[-1])
-    two = config("two.json", B.make("zkevm", 13, False, out=str(tmp_path / "zk2"), world=2))
+    two = config("two.json", B.make("zkevm", 13, False, out=str(tmp_path / "zk2"), world=2, colmajor=colmajor))
     name = f"xlp_test_bp_{os.getpid()}"
     procs = [subprocess.Popen([exe, "-c", two, "--proofs", "1", "--world", "2", "--rank", str(k), "--backend", "shm", "--rendezvous", name],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in range(2)]
@@ -200,13 +205,14 @@ def test_genbatchproof_two_ranks_at_2p18_with_the_default_staging_budget(tmp_pat
 
 
 @pytest.mark.gpu
-def test_cpp_sharded_starks_on_compiled_window_programs(tmp_path):
+@pytest.mark.parametrize("tag", ["geo12w2", "geo12w2c"])
+def test_cpp_sharded_starks_on_compiled_window_programs(tmp_path, tag):
     """two ranks on the AHEAD-OF-TIME kernels of the window-relocated step programs (the prebuilt bundle chelpers/bundles/zkevm.geo12w2, made by
     `make -C xlayer_prover_amd/chelpers bundles` like the 2^23 bundles bench.py --gpus N uses): every rank reports its four step programs as compiled,
     and the proof equals the one-GPU proof of the INTERPRETED programs"""
     from tools import make_stark_bundle as B
     from xlayer_prover_amd import programs as R
-    win = os.path.join(R.REF_DIR, "bundles", "zkevm.geo12w2")
+    win = os.path.join(R.REF_DIR, "bundles", "zkevm." + tag)        # (...c: the windows as columns)
     if not os.path.exists(os.path.join(win, "zkevm.steps.json")):
         pytest.skip("prebuilt window bundle not present (make -C xlayer_prover_amd/chelpers bundles)")
     man = json.load(open(os.path.join(win, "zkevm.steps.json")))["steps"]

@@ -58,8 +58,7 @@ def main():
             geo["step52ns_tab"] = (tabp.code, tabp.ntmp1, tabp.ntmp3)
             a.steps += ",step52ns_tab"
         if a.colmajor:                                    # (the one-row table programs address their own table: row-major as they are)
-            assert not a.world
-            Lc, ext = G.layout(a.geometry, a.aliased, a.circuit), G.CIRCUITS[a.circuit]["ext"]
+            Lc, ext = LW or G.layout(a.geometry, a.aliased, a.circuit), G.CIRCUITS[a.circuit]["ext"]
             geo = {st: ((G.to_colmajor(v[0], Lc, ext), v[1], v[2]) if not st.endswith("_tab") else v) for st, v in geo.items()}
     for size in sizes:
         for step in a.steps.split(","):

@@ -51,8 +51,8 @@ def make(circ, log_n, aliased, out=None, fri_steps=None, queries=None, use_opt=T
     back to their owner.
     colmajor: COLUMN-MAJOR device sections (include/xlp_gl.h, XLP_EXPR_COLMAJOR): the same slab packing, every section stored as columns
     (the extended ones coset-major); the programs are converted last (tools/zkevm_geometry.py to_colmajor), the starkinfo and the manifest
-    say "colMajor": true"""
-    assert not (world and colmajor), "the row-sharded windows are row-major"
+    say "colMajor": true.  With world > 0: the window slab as columns -- a column of a base-domain section = the rank's rows + the halo row,
+    of an extended one = 2^ext coset blocks of (the rank's rows + the halo row)"""
     out = out or bundle_dir(circ, log_n, aliased, world, colmajor)
     os.makedirs(out, exist_ok=True)
     geo = geo_tag(log_n, aliased, world, colmajor)
@@ -85,7 +85,7 @@ def make(circ, log_n, aliased, out=None, fri_steps=None, queries=None, use_opt=T
     if use_opt and use_dots:
         tabp, dots, rowp, n_ext = G.load_fri_dots(log_n, aliased, circ, LW)
         write_tab(os.path.join(out, f"{circ}.step52ns.dtab.xlpexpr"), tabp, n_ext)
-        rows_ext = 1 << (log_n + ext)
+        rows_ext = L["cm1_2ns"][2]                              # (a window: the rank's extended rows + halo)
         drow = rowp.code
         if colmajor:                                           # the row program reads the kernel's output: 3 * ngroups columns of rows_ext words
             drow = G.to_colmajor(drow, {"dots": (0, 3 * dots["ngroups"], rows_ext)}, ext)
@@ -120,7 +120,7 @@ def main():
     ap.add_argument("--no-opt", action="store_true")
     ap.add_argument("--no-dots", action="store_true")
     ap.add_argument("--world", type=int, default=0, help="the per-rank bundle of a proof row-sharded over this many ranks (window layout)")
-    ap.add_argument("--colmajor", action="store_true", help="column-major device sections (one-GPU layouts)")
+    ap.add_argument("--colmajor", action="store_true", help="column-major device sections")
     a = ap.parse_args()
     ln = a.log_n or G.CIRCUITS[a.circuit]["log_n"]
     print(make(a.circuit, ln, a.aliased, a.out or None, use_opt=not a.no_opt, use_dots=not a.no_dots, world=a.world, colmajor=a.colmajor))

@@ -85,6 +85,7 @@ SIGNATURES = {
     "xlp_dev_cm_to_rows": [_pu, _u64, _u64, _pu, _u64, _u64, _u64, _u64, C.c_uint32],
     "xlp_dev_copy_view": [_pu, _u64, _u64, _pu, _u64, _u64, _u64, C.c_uint32],
     "xlp_dev_extend_cm": [_pu, _u64, _u64, _pu, _u64, _u64, _u64, _u64],
+    "xlp_dev_copy_3d": [_pu, _u64, _u64, _pu, _u64, _u64, _u64, _u64, _u64],
     "xlp_dev_linear_hash_absorb_cm": [_pu, _pu, _u64, _u64, _u64, _u64, _u64, C.c_uint32, C.c_int, C.c_int],
     "xlp_dev_merkle_cm": [_pu, _pu, _u64, _u64, _u64, _u64, C.c_uint32],
     "xlp_dev_merkle_proofs_cm": [_pu, _pu, _u64, _u64, _pu, _u64, _u64, C.c_uint32, _pu, _u64],

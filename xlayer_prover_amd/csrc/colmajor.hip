@@ -110,6 +110,43 @@ int dev_copy_view(Ctx* ctx, u64* dst, u64 drs, u64 dcs, const u64* src, u64 srs,
     return 0;
 }
 
+// dst[a * ds0 + b * ds1 + i] = src[a * ss0 + b * ss1 + i], a < n0, b < n1, i < n: runs of n contiguous words regrouped -- the packing and
+// unpacking around the exchanges of a row-sharded proof on column-major windows (a rank's rows of a column, of a coset, are one run), the
+// halo rows of the windows (n = 1), the windows of the replicated constants
+__global__ __launch_bounds__(256) void copy_3d_kernel(u64* dst, u64 ds0, u64 ds1, const u64* src, u64 ss0, u64 ss1, u64 n1, u64 n, u64 chunks)
+{
+    const u64 blk = blockIdx.x;
+    const u64 run = blk / chunks, ch = blk % chunks;
+    const u64 a = run / n1, b = run % n1;
+    const u64 i = ch * 1024 + threadIdx.x;
+    const u64* s = src + a * ss0 + b * ss1;
+    u64* d = dst + a * ds0 + b * ds1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (i + k * 256 < n) d[i + k * 256] = s[i + k * 256];
+}
+// short runs: one thread per word
+__global__ __launch_bounds__(256) void copy_3d_small_kernel(u64* dst, u64 ds0, u64 ds1, const u64* src, u64 ss0, u64 ss1, u64 n1, u64 n, u64 total)
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const u64 i = t % n, run = t / n, a = run / n1, b = run % n1;
+    dst[a * ds0 + b * ds1 + i] = src[a * ss0 + b * ss1 + i];
+}
+int dev_copy_3d(Ctx* ctx, u64* dst, u64 ds0, u64 ds1, const u64* src, u64 ss0, u64 ss1, u64 n0, u64 n1, u64 n)
+{
+    if (!n0 || !n1 || !n) return 0;
+    if (n < 256) {
+        const u64 total = n0 * n1 * n;
+        hipLaunchKernelGGL(copy_3d_small_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, dst, ds0, ds1, src, ss0, ss1, n1, n, total);
+    } else {
+        const u64 chunks = (n + 1023) / 1024, blocks = n0 * n1 * chunks;
+        if (blocks >> 31) return xlp_fail("copy 3d: too many blocks");
+        hipLaunchKernelGGL(copy_3d_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, dst, ds0, ds1, src, ss0, ss1, n1, n, chunks);
+    }
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
 // extendPol (starks.cpp:53,134,215) on column-major sections: in = ncols columns of n rows (in_cstride apart), out = ncols columns of n_ext rows,
 // coset-major (out_cstride apart, cosets out_cos apart).  2^17 <= n <= 2^23 with blow-up <= 8 takes the three column-major kernels of
 // ntt_lde_cm.hip; every other geometry goes through a row-major staging chunk of <= 64 columns and the row-major engine.

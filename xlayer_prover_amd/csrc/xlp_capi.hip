@@ -436,6 +436,13 @@ int xlp_dev_copy_view(uint64_t* dst, uint64_t dst_row_stride, uint64_t dst_comp_
     if (n && dim && (!dst || !src)) return xlp_fail("xlp_dev_copy_view: null pointer");
     return dev_copy_view(&g_ctx, dst, dst_row_stride, dst_comp_stride, src, src_row_stride, src_comp_stride, n, dim);
 }
+int xlp_dev_copy_3d(uint64_t* dst, uint64_t dst_stride0, uint64_t dst_stride1, const uint64_t* src, uint64_t src_stride0, uint64_t src_stride1, uint64_t n0, uint64_t n1, uint64_t n)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if (n0 && n1 && n && (!dst || !src)) return xlp_fail("xlp_dev_copy_3d: null pointer");
+    return dev_copy_3d(&g_ctx, dst, dst_stride0, dst_stride1, src, src_stride0, src_stride1, n0, n1, n);
+}
 int xlp_dev_extend_cm(uint64_t* out, uint64_t out_cstride, uint64_t out_coset_stride, const uint64_t* in, uint64_t in_cstride, uint64_t n_ext, uint64_t n, uint64_t ncols)
 {
     XLP_ENTER;

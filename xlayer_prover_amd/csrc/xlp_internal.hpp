@@ -80,6 +80,7 @@ int dev_extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld
 int dev_rows_to_cm(Ctx* ctx, u64* dst, u64 cstride, u64 cos, const u64* src, u64 ld, u64 col0, u64 ncols, u64 rows, u32 ext);
 int dev_cm_to_rows(Ctx* ctx, u64* dst, u64 ld, u64 col0, const u64* src, u64 cstride, u64 cos, u64 ncols, u64 rows, u32 ext);
 int dev_copy_view(Ctx* ctx, u64* dst, u64 drs, u64 dcs, const u64* src, u64 srs, u64 scs, u64 n, u32 dim);
+int dev_copy_3d(Ctx* ctx, u64* dst, u64 ds0, u64 ds1, const u64* src, u64 ss0, u64 ss1, u64 n0, u64 n1, u64 n);
 int dev_extend_cm(Ctx* ctx, u64* out, u64 out_cstride, u64 out_cos, const u64* in, u64 in_cstride, u64 n_ext, u64 n, u64 ncols);
 
 // poseidon.hip

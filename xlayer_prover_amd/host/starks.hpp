@@ -282,9 +282,53 @@ private:
         }
         return d_shard;
     }
+    // ---- column-major windows: a column of a base section = nLoc + haloN rows, of an extended one = 2^extendBits coset blocks of nLoc + haloN
+    // rows each (the halo row of a coset block = the next rank's first row of that coset); cosets(s) blocks, cosStride() apart
+    uint64_t cosets(eSection s) const { return isExtSection(s) ? (1ULL << extendBits) : 1; }
+    uint64_t cosStride() const { return nLoc + haloN; }
+    // dst (cols x cosets x rows, dense) <- rows [first, first + rows) of every coset block of `cols` columns of a section (or back: toSection)
+    void windowRuns(uint64_t* dense, uint64_t* sec, uint64_t cs, uint64_t cols, uint64_t ncos, uint64_t first, uint64_t rows, bool toSection)
+    {
+        if (!cols || !rows) return;
+        if (toSection) XLP_CHECK(xlp_dev_copy_3d(sec + first, cs, cosStride(), dense, ncos * rows, rows, cols, ncos, rows));
+        else XLP_CHECK(xlp_dev_copy_3d(dense, ncos * rows, rows, sec + first, cs, cosStride(), cols, ncos, rows));
+    }
+    void fillHaloCm(eSection s)
+    {
+        const uint64_t W = starkInfo.mapSectionsN.section[s];
+        if (!W || !haloN) return;
+        const uint64_t ncos = cosets(s), words = W * ncos * haloN;
+        uint64_t *pack = shardScratch(2 * words), *recv = pack + words;
+        windowRuns(pack, section(s), colStride(s), W, ncos, 0, haloN, false);              // my first rows of every (column, coset) -> the previous rank
+        XLP_CHECK(xlp_comm_sendrecv(recv, (rank + 1) % world, pack, (rank + world - 1) % world, words));
+        windowRuns(recv, section(s), colStride(s), W, ncos, nLoc, haloN, true);             // the next rank's first rows: my halo
+    }
+    void haloWritebackCm(const std::vector<NextRowStore>& stores)
+    {
+        if (stores.empty() || world == 1) return;
+        uint64_t total = 0;
+        auto reach = [&](const NextRowStore& st) { return isExtSection((eSection)st.section) ? st.next >> extendBits : st.next; };   // rows of a coset block
+        for (const NextRowStore& st : stores) total += reach(st) * st.cols * cosets((eSection)st.section);
+        uint64_t *pack = shardScratch(2 * total), *recv = pack + total, o = 0;
+        for (const NextRowStore& st : stores) {
+            const eSection sec = (eSection)st.section;
+            if (reach(st) > haloN || (reach(st) << (isExtSection(sec) ? extendBits : 0)) != st.next || st.col + st.cols > starkInfo.mapSectionsN.section[sec])
+                xlp_exit_process("Starks: next-row store outside the halo");
+            windowRuns(pack + o, section(sec) + st.col * colStride(sec), colStride(sec), st.cols, cosets(sec), nLoc, reach(st), false);
+            o += reach(st) * st.cols * cosets(sec);
+        }
+        XLP_CHECK(xlp_comm_sendrecv(recv, (rank + world - 1) % world, pack, (rank + 1) % world, total));
+        o = 0;
+        for (const NextRowStore& st : stores) {
+            const eSection sec = (eSection)st.section;
+            windowRuns(recv + o, section(sec) + st.col * colStride(sec), colStride(sec), st.cols, cosets(sec), 0, reach(st), true);
+            o += reach(st) * st.cols * cosets(sec);
+        }
+    }
     // the window's halo rows <- the first rows of the next rank (ring): my first rows go to the previous rank
     void fillHalo(eSection s)
     {
+        if (colMajor) { fillHaloCm(s); return; }
         const uint64_t W = starkInfo.mapSectionsN.section[s];
         if (!W) return;
         XLP_CHECK(xlp_comm_sendrecv(section(s) + ownRows(s) * W, (rank + 1) % world, section(s), (rank + world - 1) % world, haloRows(s) * W));
@@ -293,6 +337,7 @@ private:
     void haloWriteback(const std::vector<NextRowStore>& stores)
     {
         // (one rank: the window is the whole domain, the operand's own modulus wraps the store of the last row to row 0 -- nothing lands in the halo)
+        if (colMajor) { haloWritebackCm(stores); return; }
         if (stores.empty() || world == 1) return;
         uint64_t total = 0;
         for (const NextRowStore& st : stores) total += st.next * st.cols;
@@ -318,7 +363,8 @@ private:
     uint64_t commitBandPlan(uint64_t W, uint64_t& nb, uint64_t& bandTotalMax, uint64_t& wcbMax, uint64_t minBands = 1) const
     {
         const uint64_t wcMax = (W + world - 1) / world;
-        const uint64_t allWords = nLoc * W + N * wcMax + NExtended * wcMax + neLoc * W;
+        const uint64_t regroup = colMajor ? 2 : 1;                  // column-major windows: what arrives / leaves is regrouped through a second buffer
+        const uint64_t allWords = nLoc * W + regroup * (N * wcMax + NExtended * wcMax) + neLoc * W;
         uint64_t budget = 24ULL << 30;
         if (const char* e = getenv("XLP_SHARD_SCRATCH_MB")) { const uint64_t v = strtoull(e, NULL, 10); if (v) budget = v << 20; }
         budget /= 2;                                                // two sets: band k + 1 is exchanged while band k is extended
@@ -336,7 +382,7 @@ private:
             }
             if (tot > bandTotalMax) bandTotalMax = tot;
         }
-        return nLoc * bandTotalMax + N * wcbMax + NExtended * wcbMax + neLoc * bandTotalMax;
+        return nLoc * bandTotalMax + regroup * (N * wcbMax + NExtended * wcbMax) + neLoc * bandTotalMax;
     }
     // ntt.extendPol(cmX_2ns, cmX_n, ...) + treesGL[i]->merkelize() (starks.cpp:53-60,134-141,215-222) over the ranks: the LDE runs per
     // COLUMN (all N rows of my W / G columns), the leaf sponge per ROW (all W columns of my NExtended / G rows):
@@ -349,8 +395,114 @@ private:
     // their longest message and never wait for the host.
     // h_src != NULL (step 1): my rows of the section are still in HOST memory (the executor's output): their columns are uploaded band by band
     // on the copy stream, band k + 1 crossing PCIe while band k is exchanged and extended (at least 4 bands then)
+    // COLUMN-MAJOR windows: the same bands, marks and streams.  What travels is runs of nLoc words -- my rows of one column (of one coset):
+    //   front: block p = [band columns of rank p][nLoc] out of the section; what arrives from p, [my columns][nLoc], is regrouped into whole
+    //          columns [my columns][N]                                                         (xlp_dev_copy_3d)
+    //   xlp_dev_extend_cm: [my columns][2^ext cosets][N]
+    //   back:  block p = [my columns][2^ext][rows of rank p]; what arrives from p, [its band columns][2^ext][nLoc], goes to the coset blocks
+    //          of those columns of the section
+    // h_src: the band's columns of my rows cross PCIe into the row-major image `stage` (nLoc x W words) and are transposed from there
+    void commitShardedCm(typename H::Tree* tree, eSection sn, eSection s2, const uint64_t* h_src = NULL, uint64_t* stage = NULL)
+    {
+        const uint64_t W = starkInfo.mapSectionsN.section[sn], E = 1ULL << extendBits, cs = colStride(sn), cs2 = colStride(s2);
+        tree->d_source = section(s2);
+        if (W) {
+            uint64_t nb, bandTotalMax, wcbMax;
+            const uint64_t setWords = commitBandPlan(W, nb, bandTotalMax, wcbMax, h_src ? 4 : 1);
+            auto band = [&](int r, uint64_t k, uint64_t& a, uint64_t& b) {
+                uint64_t c0, c1; colSpan(W, r, c0, c1);
+                a = c0 + (c1 - c0) * k / nb; b = c0 + (c1 - c0) * (k + 1) / nb;
+            };
+            auto widest = [&](uint64_t k) { uint64_t m = 0; for (int p_ = 0; p_ < world; p_++) { uint64_t a, b; band(p_, k, a, b); if (b - a > m) m = b - a; } return m; };
+            uint64_t* base = shardScratch(2 * setWords);
+            struct Set { uint64_t *pack, *arrv, *colb, *extb, *send, *rowb; } S[2];
+            for (int i = 0; i < 2; i++) {
+                S[i].pack = base + (uint64_t)i * setWords;
+                S[i].arrv = S[i].pack + nLoc * bandTotalMax; S[i].colb = S[i].arrv + N * wcbMax; S[i].extb = S[i].colb + N * wcbMax;
+                S[i].send = S[i].extb + NExtended * wcbMax; S[i].rowb = S[i].send + NExtended * wcbMax;
+            }
+            std::vector<uint64_t*> rp(world);
+            std::vector<const uint64_t*> spc(world);
+            std::vector<uint64_t> rw(world), sw(world);
+            enum { M_FRONT = 0, M_EXT = 2, M_BACK = 4 };
+            auto upload = [&](uint64_t k) {
+                for (int p_ = 0; p_ < world; p_++) {
+                    uint64_t a, b; band(p_, k, a, b);
+                    if (b > a) XLP_CHECK(xlp_dev_upload_cols_async(stage, h_src, W, a, b - a, nLoc));
+                }
+            };
+            auto front = [&](uint64_t k) {
+                Set& B = S[k & 1];
+                if (h_src) {
+                    XLP_CHECK(xlp_dev_upload_fence());
+                    if (k + 1 < nb) upload(k + 1);
+                    for (int p_ = 0; p_ < world; p_++) {                 // the band's columns of the image -> columns of the section
+                        uint64_t a, b; band(p_, k, a, b);
+                        if (b > a) XLP_CHECK(xlp_dev_rows_to_cm(section(sn) + a * cs, cs, 0, stage, W, a, b - a, nLoc, 0));
+                    }
+                }
+                if (k >= 2) XLP_CHECK(xlp_stream_wait_mark(1, M_EXT + (int)(k & 1)));
+                uint64_t ma, mb; band(rank, k, ma, mb);
+                const uint64_t wc = mb - ma;
+                uint64_t o = 0;
+                for (int p_ = 0; p_ < world; p_++) {
+                    uint64_t a, b; band(p_, k, a, b);
+                    uint64_t* blk = B.pack + o;
+                    spc[p_] = blk; sw[p_] = nLoc * (b - a);
+                    if (b > a) XLP_CHECK(xlp_dev_copy_3d(blk, nLoc, 0, section(sn) + a * cs, cs, 0, b - a, 1, nLoc));
+                    o += sw[p_];
+                    rp[p_] = B.arrv + (uint64_t)p_ * nLoc * wc; rw[p_] = nLoc * wc;
+                }
+                XLP_CHECK(xlp_comm_exchange(rp.data(), rw.data(), spc.data(), sw.data(), nLoc * widest(k)));
+                for (int p_ = 0; p_ < world && wc; p_++)                 // rows [p nLoc, (p + 1) nLoc) of my columns
+                    XLP_CHECK(xlp_dev_copy_3d(B.colb + (uint64_t)p_ * nLoc, N, 0, rp[p_], nLoc, 0, wc, 1, nLoc));
+                XLP_CHECK(xlp_stream_mark(1, M_FRONT + (int)(k & 1)));
+            };
+            auto back = [&](uint64_t k) {
+                Set& B = S[k & 1];
+                XLP_CHECK(xlp_stream_wait_mark(1, M_EXT + (int)(k & 1)));
+                uint64_t ma, mb; band(rank, k, ma, mb);
+                const uint64_t wc = mb - ma;
+                uint64_t o = 0;
+                for (int p_ = 0; p_ < world; p_++) {
+                    uint64_t a, b; band(p_, k, a, b);
+                    uint64_t* blk = B.send + (uint64_t)p_ * neLoc * wc;
+                    if (wc) XLP_CHECK(xlp_dev_copy_3d(blk, E * nLoc, nLoc, B.extb + (uint64_t)p_ * nLoc, NExtended, N, wc, E, nLoc));
+                    spc[p_] = blk; sw[p_] = neLoc * wc;
+                    rp[p_] = B.rowb + o; rw[p_] = neLoc * (b - a);
+                    o += rw[p_];
+                }
+                XLP_CHECK(xlp_comm_exchange(rp.data(), rw.data(), spc.data(), sw.data(), neLoc * widest(k)));
+                for (int p_ = 0; p_ < world; p_++) {
+                    uint64_t a, b; band(p_, k, a, b);
+                    if (b > a) XLP_CHECK(xlp_dev_copy_3d(section(s2) + a * cs2, cs2, cosStride(), rp[p_], E * nLoc, nLoc, b - a, E, nLoc));
+                }
+                XLP_CHECK(xlp_stream_mark(1, M_BACK + (int)(k & 1)));
+            };
+            XLP_CHECK(xlp_stream_wait(1, 0));
+            XLP_CHECK(xlp_stream_select(1));
+            if (h_src) { XLP_CHECK(xlp_dev_upload_begin()); upload(0); }
+            front(0);
+            for (uint64_t k = 0; k < nb; k++) {
+                uint64_t ma, mb; band(rank, k, ma, mb);
+                XLP_CHECK(xlp_stream_select(0));
+                XLP_CHECK(xlp_stream_wait_mark(0, M_FRONT + (int)(k & 1)));
+                if (k >= 2) XLP_CHECK(xlp_stream_wait_mark(0, M_BACK + (int)(k & 1)));
+                if (mb > ma) XLP_CHECK(xlp_dev_extend_cm(S[k & 1].extb, NExtended, 0, S[k & 1].colb, N, NExtended, N, mb - ma));
+                XLP_CHECK(xlp_stream_mark(0, M_EXT + (int)(k & 1)));
+                XLP_CHECK(xlp_stream_select(1));
+                if (k + 1 < nb) front(k + 1);
+                back(k);
+            }
+            XLP_CHECK(xlp_stream_select(0));
+            XLP_CHECK(xlp_stream_wait(0, 1));
+        }
+        tree->merkelize();
+        fillHalo(s2);
+    }
     void commitSharded(typename H::Tree* tree, eSection sn, eSection s2, const uint64_t* h_src = NULL)
     {
+        if (colMajor) { commitShardedCm(tree, sn, s2, h_src, NULL); return; }
         const uint64_t W = starkInfo.mapSectionsN.section[sn];
         tree->d_source = section(s2);
         if (W) {
@@ -459,6 +611,7 @@ private:
         lastTimers.clear();
         lastExchanges.clear();
         XLP_CHECK(xlp_comm_stats(&commSeconds, &commBytes, &commCalls, 0));
+        if (steps->colMajor() != colMajor) xlp_exit_process("Starks: the step programs and the starkinfo disagree on the layout of the sections (colMajor)");
         if (XlpDeviceSlab::get().reserve(slabWords) == NULL) xlp_exit_process("Starks: no device slab");
         const eSection secs2ns[4] = {cm1_2ns, cm2_2ns, cm3_2ns, cm4_2ns};
         for (int i = 0; i < 4; i++) treesGL[i]->d_source = section(secs2ns[i]);
@@ -485,7 +638,21 @@ private:
         {
             Timer t(this, "STARK_STEP_1_LDE_AND_MERKLETREE");
             const uint64_t* h_cm1 = (const uint64_t*)pAddress + starkInfo.mapOffsets.section[cm1_n];
-            if (W1 && pipelineWitness) commitSharded(treesGL[0], cm1_n, cm1_2ns, h_cm1);
+            if (colMajor) {
+                // my rows arrive as the executor wrote them (row-major): their image lands in the still dead base-domain sections behind
+                // cm1_n (or in a buffer of its own when they are too small) and is transposed from there, band by band when pipelined
+                const uint64_t from = starkInfo.mapOffsets.section[cm2_n], to = starkInfo.mapOffsets.section[tmpExp_n] + (nLoc + haloN) * starkInfo.mapSectionsN.section[tmpExp_n];
+                const bool inSections = to > from && to <= slabWords && to - from >= nLoc * W1;
+                uint64_t* stage = inSections ? mem() + from : dalloc(nLoc * W1);
+                if (W1 && pipelineWitness) commitShardedCm(treesGL[0], cm1_n, cm1_2ns, h_cm1, stage);
+                else {
+                    XLP_CHECK(xlp_copy_h2d(stage, h_cm1, nLoc * W1 * sizeof(uint64_t)));
+                    if (W1) XLP_CHECK(xlp_dev_rows_to_cm(section(cm1_n), colStride(cm1_n), 0, stage, W1, 0, W1, nLoc, 0));
+                    commitShardedCm(treesGL[0], cm1_n, cm1_2ns);
+                }
+                if (inSections) XLP_CHECK(xlp_dev_memset(stage, 0, nLoc * W1 * sizeof(uint64_t)));
+                else { XLP_CHECK(xlp_sync()); xlp_dev_free(stage); }
+            } else if (W1 && pipelineWitness) commitSharded(treesGL[0], cm1_n, cm1_2ns, h_cm1);
             else {
                 XLP_CHECK(xlp_copy_h2d(section(cm1_n), h_cm1, nLoc * W1 * sizeof(uint64_t)));
                 commitSharded(treesGL[0], cm1_n, cm1_2ns);
@@ -511,16 +678,16 @@ private:
                 if (f.dim != tt.dim || h1.dim != f.dim || h2.dim != f.dim) xlp_exit_process("Starks: plookup polynomials of different dimensions");
                 const uint64_t d = f.dim;
                 uint64_t *tLoc = d_work, *tFull = d_work + N * 3, *fFull = d_work + 2 * N * 3, *hh1 = d_work + 3 * N * 3, *hh2 = d_work + 4 * N * 3, *fLoc = d_work + 5 * N * 3;
-                XLP_CHECK(xlp_dev_copy_cols(tLoc, d, tt.p, tt.stride, nLoc, (uint32_t)d));
+                toDense(tLoc, tt, nLoc);                     // (row-major sections: a strided copy; column-major: the d columns interleaved)
                 XLP_CHECK(xlp_comm_all_gather(tFull, tLoc, nLoc * d));
                 if (config.xlpSyntheticLookups) XLP_CHECK(xlp_dev_gather_rows(fFull, tFull, d, N, (uint32_t)d, 0x5EED0500ULL + i));
                 else {
-                    XLP_CHECK(xlp_dev_copy_cols(fLoc, d, f.p, f.stride, nLoc, (uint32_t)d));
+                    toDense(fLoc, f, nLoc);
                     XLP_CHECK(xlp_comm_all_gather(fFull, fLoc, nLoc * d));
                 }
                 XLP_CHECK(xlp_dev_calculate_h1h2(hh1, hh2, fFull, tFull, N, (uint32_t)d));
-                XLP_CHECK(xlp_dev_copy_cols(h1.p, h1.stride, hh1 + row0 * d, d, nLoc, (uint32_t)d));
-                XLP_CHECK(xlp_dev_copy_cols(h2.p, h2.stride, hh2 + row0 * d, d, nLoc, (uint32_t)d));
+                fromDense(h1, hh1 + row0 * d, nLoc);
+                fromDense(h2, hh2 + row0 * d, nLoc);
             }
             numCommited += starkInfo.puCtx.size() * 2;
         }
@@ -551,6 +718,14 @@ private:
             for (uint64_t i = 0; i < nd.size(); i++) {
                 const PolRef num = pol(exp2pol(nd[i].first)), den = pol(exp2pol(nd[i].second)), z = pol(starkInfo.cm_n[numCommited + i]);
                 if (num.dim != 3 || den.dim != 3 || z.dim != 3) xlp_exit_process("Starks: Z polynomials must be ext-3");
+                if (colMajor) {
+                    uint64_t *dn = d_work, *dd = d_work + (nLoc + 1) * 3, *dz = d_work + 2 * (nLoc + 1) * 3;
+                    toDense(dn, num, nLoc + 1); toDense(dd, den, nLoc + 1);
+                    XLP_CHECK(xlp_dev_calculate_z(dz, dn, dd, nLoc + 1));
+                    fromDense(z, dz, nLoc + 1);
+                    XLP_CHECK(xlp_copy_d2h(&totals[3 * i], dz + nLoc * 3, 3 * sizeof(uint64_t)));
+                    continue;
+                }
                 XLP_CHECK(xlp_dev_calculate_z_strided(z.p, z.stride, num.p, num.stride, den.p, den.stride, nLoc + 1));
                 XLP_CHECK(xlp_copy_d2h(&totals[3 * i], z.p + nLoc * z.stride, 3 * sizeof(uint64_t)));
             }
@@ -565,6 +740,11 @@ private:
                 }
                 const uint64_t pw[3] = {Goldilocks::toU64(prefix[0]), Goldilocks::toU64(prefix[1]), Goldilocks::toU64(prefix[2])};
                 const PolRef z = pol(starkInfo.cm_n[numCommited + i]);
+                if (colMajor) {
+                    toDense(d_work, z, nLoc);
+                    XLP_CHECK(xlp_dev_scale3_strided(d_work, 3, nLoc, pw));
+                    fromDense(z, d_work, nLoc);
+                } else
                 XLP_CHECK(xlp_dev_scale3_strided(z.p, z.stride, nLoc, pw));
             }
         }
@@ -581,6 +761,7 @@ private:
         }
         //-------------------------------- 4. the quotient: qDim columns, all-gathered and transformed on every rank; my rows of cm4_2ns kept
         challenge(4);
+        if (colMajor) { P.coset_rows = nLoc; P.coset_stride = cosStride(); }   // the extended-domain programs run coset block by coset block
         {
             Timer t(this, "STARK_STEP_4_CALCULATE_EXPS_2NS");
             runStep(steps, 3, P, neLoc);
@@ -594,6 +775,8 @@ private:
             const Goldilocks::Element shiftIn = Goldilocks::exp(Goldilocks::inv(Goldilocks::shift()), N);
             XLP_CHECK(xlp_dev_q_split(qq2, qfull, N, NExtended, (uint32_t)starkInfo.qDeg, (uint32_t)starkInfo.qDim, Goldilocks::toU64(shiftIn)));
             XLP_CHECK(xlp_dev_ntt(qq2, qq2, NExtended, W4, 0));
+            if (colMajor) XLP_CHECK(xlp_dev_rows_to_cm(section(cm4_2ns), colStride(cm4_2ns), cosStride(), qq2 + ext0 * W4, W4, 0, W4, neLoc, (uint32_t)extendBits));
+            else
             XLP_CHECK(xlp_dev_copy_cols(section(cm4_2ns), W4, qq2 + ext0 * W4, W4, neLoc, (uint32_t)W4));
         }
         {
@@ -635,6 +818,17 @@ private:
                     ents[i] = {p.p, p.stride, (uint32_t)p.dim, ev.prime ? 1u : 0u};
                 }
             }
+            if (colMajor) {                                  // coset block 0 of a window column = my rows of the base domain
+                for (size_t i = 0; i < ents.size(); i++) {
+                    const EvMap& ev = starkInfo.evMap[i];
+                    if (ev.type == EvMap::_const) ents[i] = {d_const_2ns_win + ev.id * (neLoc + haloExt), neLoc + haloExt, 1, ev.prime ? 1u : 0u};
+                    else {
+                        const PolRef p = pol(ev.type == EvMap::cm ? starkInfo.cm_2ns[ev.id] : starkInfo.qs[ev.id]);
+                        ents[i] = {p.p, p.cs, (uint32_t)p.dim, ev.prime ? 1u : 0u};
+                    }
+                }
+                XLP_CHECK(xlp_dev_evmap_cm(d_evals, d_work + 3 * row0, d_work + N * 3 + 3 * row0, nLoc, (uint32_t)ents.size(), ents.data()));
+            } else
             XLP_CHECK(xlp_dev_evmap(d_evals, d_work + 3 * row0, d_work + N * 3 + 3 * row0, nLoc, (uint32_t)extendBits, (uint32_t)ents.size(), ents.data()));
             std::vector<uint64_t> part(evals.size()), all((size_t)world * evals.size());
             XLP_CHECK(xlp_copy_d2h(part.data(), d_evals, part.size() * sizeof(uint64_t)));
@@ -705,8 +899,8 @@ public:
         // column-major: the file / the synthetic fill is row-major (the same VALUES in both layouts): it lands in the still unused device slab
         // and is transposed from there
         const bool viaSlab = colMajor && slabWords >= NExtended * starkInfo.nConstants;
-        if (colMajor && !viaSlab) xlp_exit_process("Starks: device slab smaller than the extended constants (column-major load)");
-        uint64_t* constLand = colMajor ? mem() : constFull;
+        uint64_t* ownLand = colMajor && !viaSlab ? dalloc(NExtended * starkInfo.nConstants) : NULL;      // (a rank's window slab can be smaller than the replicated constants)
+        uint64_t* constLand = ownLand ? ownLand : colMajor ? mem() : constFull;
         if (starkFiles.zkevmConstPols.rfind("synthetic:", 0) == 0)
             XLP_CHECK(xlp_dev_fill(constLand, N * starkInfo.nConstants, strtoull(starkFiles.zkevmConstPols.c_str() + 10, NULL, 0), 0));
         else fileToDevice(constLand, starkFiles.zkevmConstPols, 0, N * starkInfo.nConstants * sizeof(uint64_t));
@@ -714,6 +908,11 @@ public:
         if (sharded) {
             d_const_n_full = constFull;
             d_const_n = dalloc((nLoc + haloN) * starkInfo.nConstants);
+            if (colMajor) {                               // my rows of every column, then the halo rows one by one (the last rank's wrap to row 0)
+                XLP_CHECK(xlp_dev_copy_3d(d_const_n, cosStride(), 0, constFull + row0, N, 0, starkInfo.nConstants, 1, nLoc));
+                for (uint64_t i = 0; i < haloN; i++)
+                    XLP_CHECK(xlp_dev_copy_3d(d_const_n + nLoc + i, cosStride(), 0, constFull + (row0 + nLoc + i) % N, N, 0, starkInfo.nConstants, 1, 1));
+            } else
             windowRows(d_const_n, constFull, starkInfo.nConstants, row0, nLoc + haloN, N);
         } else d_const_n = constFull;
         // ---- constant tree (LOAD_CONST_TREE_TO_MEMORY / LOAD_CONST_POLS_2NS_TO_MEMORY, starks.hpp:117-146)
@@ -731,8 +930,8 @@ public:
             fclose(fp);
             if (hdr[0] != starkInfo.nConstants || hdr[1] != NExtended) xlp_exit_process("Starks: constant tree does not match the starkinfo");
             if (colMajor && !const2nsInSlab) {            // the file's source is row-major, natural order: through the slab, then coset-major columns
-                fileToDevice(mem(), starkFiles.zkevmConstantsTree, 16, NExtended * starkInfo.nConstants * 8);
-                XLP_CHECK(xlp_dev_rows_to_cm(constPols2ns(), NExtended, 0, mem(), starkInfo.nConstants, 0, starkInfo.nConstants, NExtended, (uint32_t)extendBits));
+                fileToDevice(constLand, starkFiles.zkevmConstantsTree, 16, NExtended * starkInfo.nConstants * 8);
+                XLP_CHECK(xlp_dev_rows_to_cm(constPols2ns(), NExtended, 0, constLand, starkInfo.nConstants, 0, starkInfo.nConstants, NExtended, (uint32_t)extendBits));
             } else if (colMajor) {                        // (the extended constants live IN the slab: recomputed from the base ones instead, as in every proof)
                 XLP_CHECK(xlp_dev_extend_cm(constPols2ns(), NExtended, 0, constFull, N, NExtended, N, starkInfo.nConstants));
             } else fileToDevice(constPols2ns(), starkFiles.zkevmConstantsTree, 16, NExtended * starkInfo.nConstants * 8);
@@ -744,8 +943,15 @@ public:
             treesGL[4]->merkelize();
         }
         treesGL[4]->getRoot(constRoot);
+        if (ownLand) { XLP_CHECK(xlp_sync()); xlp_dev_free(ownLand); }
         if (sharded) {                                    // the extended constants and their tree are replicated; the 2ns programs read my window
             d_const_2ns_win = dalloc((neLoc + haloExt) * starkInfo.nConstants);
+            if (colMajor) {                               // [column][coset][my rows + halo] out of [column][coset][N]
+                const uint64_t E = 1ULL << extendBits;
+                XLP_CHECK(xlp_dev_copy_3d(d_const_2ns_win, neLoc + haloExt, cosStride(), constPols2ns() + row0, NExtended, N, starkInfo.nConstants, E, nLoc));
+                for (uint64_t i = 0; i < haloN; i++)
+                    XLP_CHECK(xlp_dev_copy_3d(d_const_2ns_win + nLoc + i, neLoc + haloExt, cosStride(), constPols2ns() + (row0 + nLoc + i) % N, NExtended, N, starkInfo.nConstants, E, 1));
+            } else
             windowRows(d_const_2ns_win, constPols2ns(), starkInfo.nConstants, ext0, neLoc + haloExt, NExtended);
         }
         // ---- x_n, x_2ns (COMPUTE_X_N_AND_X_2_NS, starks.hpp:149-160), ZhInv (zhInv.cpp:7-32); sharded: my rows of them
@@ -756,9 +962,9 @@ public:
                        sh = Goldilocks::toU64(Goldilocks::mul(Goldilocks::shift(), Goldilocks::exp(wneE, ext0))), wne = Goldilocks::toU64(wneE);
         XLP_CHECK(xlp_dev_geometric(d_x_n, ownN, 1, &one, &wn));
         if (colMajor) {                                   // coset-major: x of storage row r N + q = shift w_ext^r (w_N)^q
-            for (uint64_t r = 0; r < (1ULL << extendBits); r++) {
-                const uint64_t first = Goldilocks::toU64(Goldilocks::mul(Goldilocks::shift(), Goldilocks::exp(wneE, r)));
-                XLP_CHECK(xlp_dev_geometric(d_x_2ns + r * N, N, 1, &first, &wn));
+            for (uint64_t r = 0; r < (1ULL << extendBits); r++) {      // (sharded: my rows of every coset, densely)
+                const uint64_t first = Goldilocks::toU64(Goldilocks::mul(Goldilocks::mul(Goldilocks::shift(), Goldilocks::exp(wneE, r)), Goldilocks::exp(wnE, row0)));
+                XLP_CHECK(xlp_dev_geometric(d_x_2ns + r * ownN, ownN, 1, &first, &wn));
             }
         } else XLP_CHECK(xlp_dev_geometric(d_x_2ns, ownE, 1, &sh, &wne));
         {
@@ -788,12 +994,12 @@ public:
         for (int i = 0; i < 4; i++) {
             if constexpr (H::kShardable) treesGL[i] = new typename H::Tree(NExtended, starkInfo.mapSectionsN.section[secs[i]], NULL, true, sharded ? world : 0, rank);
             else treesGL[i] = new typename H::Tree(NExtended, starkInfo.mapSectionsN.section[secs[i]], NULL, true);
-            if constexpr (H::kCommitTimes) { if (colMajor) treesGL[i]->setColMajor((uint32_t)extendBits, NExtended); }
+            if constexpr (H::kCommitTimes) { if (colMajor) treesGL[i]->setColMajor((uint32_t)extendBits, sharded ? neLoc + haloExt : NExtended, sharded ? cosStride() : 0); }
         }
         if (colMajor) {
             for (int i = 0; i < 11; i++) {
                 const eSection sec = (eSection)i;
-                const uint64_t want = isExtSection(sec) ? NExtended : N;
+                const uint64_t want = sharded ? (isExtSection(sec) ? neLoc + haloExt : nLoc + haloN) : isExtSection(sec) ? NExtended : N;
                 if (starkInfo.mapSectionsN.section[sec] && starkInfo.mapDeg.section[sec] != want) xlp_exit_process("Starks: column-major starkinfo whose sections are not whole domains");
             }
         }

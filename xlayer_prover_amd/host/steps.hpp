@@ -100,7 +100,9 @@ class XlpSteps : public Steps
         if (!s.dots.empty() && colMajor_) {
             // the sums as 3 * ngroups COLUMNS of nrows words (what the converted row program reads); entries: the columns' first words, constant
             // polynomials at column * rows of their buffer
-            const uint64_t words = nrows * 3 * s.ngroups;
+            // (storage rows: a rank's window keeps halo rows behind every coset block -- coset_stride > coset_rows -- and the sums are laid out like the sections)
+            const uint64_t srows = params.coset_rows && params.coset_stride > params.coset_rows ? nrows / params.coset_rows * params.coset_stride : nrows;
+            const uint64_t words = srows * 3 * s.ngroups;
             if (s.dotOutWords < words) {
                 if (s.dotOut) XLP_CHECK(xlp_dev_free(s.dotOut));
                 void* d = NULL;
@@ -114,7 +116,7 @@ class XlpSteps : public Steps
                 if (d.kind == 0) ents[i] = {params.pols + d.offset, d.stride, (uint32_t)d.dim, (uint32_t)d.group, d.coef};
                 else ents[i] = {params.const_pols_2ns + d.offset * crows, crows, 1u, (uint32_t)d.group, d.coef};
             }
-            XLP_CHECK(xlp_dev_dot_columns_cm(s.dotOut, nrows, ents.data(), ents.size(), (uint32_t)s.ngroups, s.ext, 3 * s.n_ext, nrows));
+            XLP_CHECK(xlp_dev_dot_columns_cm(s.dotOut, srows, ents.data(), ents.size(), (uint32_t)s.ngroups, s.ext, 3 * s.n_ext, srows));
             r.pols = s.dotOut; r.pols_size = words;
         } else if (!s.dots.empty()) {
             const uint64_t words = nrows * 3 * s.ngroups;

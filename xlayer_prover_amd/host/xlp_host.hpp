@@ -213,8 +213,8 @@ public:
     // (cmStride apart), coset-major with 2^cmExtBits cosets; leaves, nodes and openings are the same as over the row-major section
     bool colMajor = false;
     uint32_t cmExtBits = 0;
-    uint64_t cmStride = 0;
-    void setColMajor(uint32_t extBits, uint64_t cstride) { colMajor = true; cmExtBits = extBits; cmStride = cstride; }
+    uint64_t cmStride = 0, cmCos = 0;                          // words between the columns / between the cosets of a column (0: rows >> extBits)
+    void setColMajor(uint32_t extBits, uint64_t cstride, uint64_t cosetStride = 0) { colMajor = true; cmExtBits = extBits; cmStride = cstride; cmCos = cosetStride; }
     std::vector<std::vector<uint64_t>> capLevels;              // [sub-roots (world x 4)], ..., [root (4)]
     MerkleTreeGL(uint64_t _height, uint64_t _width, uint64_t* dSource, bool /*deviceTag*/, int world = 0, int rank = 0)
         : height(_height), width(_width), source(NULL), nodes(NULL), d_source(dSource), shardRank(rank), shardWorld(world)
@@ -277,8 +277,9 @@ public:
     void copySource(Goldilocks::Element* _source) { std::memcpy(source, _source, height * width * sizeof(Goldilocks::Element)); }
     void merkelize()
     {
+        if (d_nodes && shardWorld && colMajor) { XLP_CHECK(xlp_dev_merkle_cm(d_nodes, d_source, cmStride, cmCos, width, localHeight(), cmExtBits)); assembleCap(); return; }
         if (d_nodes && shardWorld) { XLP_CHECK(xlp_dev_merkle(d_nodes, d_source, width, localHeight())); assembleCap(); return; }
-        if (d_nodes && colMajor) { XLP_CHECK(xlp_dev_merkle_cm(d_nodes, d_source, cmStride, 0, width, height, cmExtBits)); return; }
+        if (d_nodes && colMajor) { XLP_CHECK(xlp_dev_merkle_cm(d_nodes, d_source, cmStride, cmCos, width, height, cmExtBits)); return; }
         if (d_nodes) { XLP_CHECK(xlp_dev_merkle(d_nodes, d_source, width, height)); return; }
         PoseidonGoldilocks::merkletree_avx(nodes, source, width, height);
     }
@@ -318,7 +319,8 @@ public:
             }
             if (!mine.empty()) {
                 std::vector<uint64_t> loc(mine.size() * perLocal);
-                XLP_CHECK(xlp_dev_merkle_proofs(loc.data(), d_source, d_nodes, width, lh, mine.data(), mine.size()));
+                if (colMajor) XLP_CHECK(xlp_dev_merkle_proofs_cm(loc.data(), d_source, cmStride, cmCos, d_nodes, width, lh, cmExtBits, mine.data(), mine.size()));
+                else XLP_CHECK(xlp_dev_merkle_proofs(loc.data(), d_source, d_nodes, width, lh, mine.data(), mine.size()));
                 for (size_t k = 0; k < mine.size(); k++) {
                     uint64_t* o = xlp_raw(&proofs[pos[k] * per]);
                     std::memcpy(o, &loc[k * perLocal], perLocal * sizeof(uint64_t));
@@ -335,7 +337,7 @@ public:
             }
             return;
         }
-        if (d_nodes && colMajor) { XLP_CHECK(xlp_dev_merkle_proofs_cm(xlp_raw(proofs.data()), d_source, cmStride, 0, d_nodes, width, height, cmExtBits, idxs.data(), idxs.size())); return; }
+        if (d_nodes && colMajor) { XLP_CHECK(xlp_dev_merkle_proofs_cm(xlp_raw(proofs.data()), d_source, cmStride, cmCos, d_nodes, width, height, cmExtBits, idxs.data(), idxs.size())); return; }
         if (d_nodes) { XLP_CHECK(xlp_dev_merkle_proofs(xlp_raw(proofs.data()), d_source, d_nodes, width, height, idxs.data(), idxs.size())); return; }
         for (size_t q = 0; q < idxs.size(); q++) getGroupProof(&proofs[q * per], idxs[q]);
     }
@@ -834,7 +836,7 @@ public:
         if (j.contains("xlp") && j["xlp"].contains("colMajor") && j["xlp"]["colMajor"].kind == xlp_json::Value::Bool) xlpColMajor = (bool)j["xlp"]["colMajor"];
         if (j.contains("xlp") && j["xlp"].contains("world")) {
             xlpWorld = j["xlp"]["world"]; xlpHaloN = j["xlp"]["haloN"]; xlpHaloExt = j["xlp"]["haloExt"];
-            if (!xlpWorld || (xlpWorld & (xlpWorld - 1)) || xlpConst2nsInSlab || xlpColMajor) xlp_exit_process("StarkInfo: bad sharded (\"xlp\") layout");
+            if (!xlpWorld || (xlpWorld & (xlpWorld - 1)) || xlpConst2nsInSlab) xlp_exit_process("StarkInfo: bad sharded (\"xlp\") layout");
         }
     }
     void getPol(void* pAddress, uint64_t idPol, PolInfo& polInfo)     // stark_info.cpp:456-464
