@@ -390,7 +390,10 @@ def genproof_sharded_cpp_leg(world, rank, local_rank, backend, log_n=23, timeout
     import subprocess
     import tempfile
     exe = os.path.join(ROOT, "xlayer_prover_amd", "host", "zkprover_batch")
-    bundle = os.path.join(ROOT, "xlayer_prover_amd", "chelpers", "bundles", f"zkevm.geo{log_n}w{world}")
+    bdir = os.path.join(ROOT, "xlayer_prover_amd", "chelpers", "bundles")
+    # the windows as COLUMNS (the layout of the one-GPU product path) when that bundle was built, else the row-major windows
+    colmajor = os.environ.get("XLP_BENCH_WINDOW_LAYOUT", "colmajor") == "colmajor" and os.path.exists(os.path.join(bdir, f"zkevm.geo{log_n}w{world}c", "zkevm.starkinfo.json"))
+    bundle = os.path.join(bdir, f"zkevm.geo{log_n}w{world}" + ("c" if colmajor else ""))
     built_here = False
     if not os.path.exists(os.path.join(bundle, "zkevm.starkinfo.json")):
         if rank == 0:                                        # (no reference tree needed: the converted programs travel with the repo)
@@ -400,7 +403,7 @@ def genproof_sharded_cpp_leg(world, rank, local_rank, backend, log_n=23, timeout
                 built_here = True
             except Exception as e:
                 return {"error": "no window bundle: " + repr(e)[:200]}
-    base = json.load(open(os.path.join(ROOT, "tools", "config_runFile_BatchProof_synthetic.json")))
+    base = json.load(open(os.path.join(ROOT, "tools", "config_runFile_BatchProof_synthetic_colmajor.json" if colmajor else "config_runFile_BatchProof_synthetic.json")))
     base["zkevmStarkInfo"] = os.path.join(bundle, "zkevm.starkinfo.json")
     port = int(os.environ.get("MASTER_PORT", "29500"))
     cfg = os.path.join(tempfile.gettempdir(), f"xlp_sharded_cfg_{port}_{world}.json")
@@ -434,7 +437,7 @@ def genproof_sharded_cpp_leg(world, rank, local_rank, backend, log_n=23, timeout
                           "witness rows uploaded per rank inside the wall; c12a / recursive1 on rank 0",
                 "wall_s": round(j["three_starks_s"], 4), "zkevm_sharded_s": round(t["STARK_PROOF_BATCH_PROOF"], 4), "c12a_s": round(t["STARK_C12_A_PROOF_BATCH_PROOF"], 4),
                 "recursive1_s": round(t["STARK_RECURSIVE_1_PROOF_BATCH_PROOF"], 4), "zkevm_stage_timers_s_rank0": z, "sharded": j.get("sharded"), "programs": modes,
-                "window_bundle_built_in_this_run": built_here, "log_n": log_n, "recursive1_root1": j.get("recursive1_root1"),
+                "window_bundle_built_in_this_run": built_here, "window_layout": "colmajor" if colmajor else "rowmajor", "log_n": log_n, "recursive1_root1": j.get("recursive1_root1"),
                 "note": "no run on more than one GPU exists yet: correctness of the multi-rank path is covered by tests/test_cpp_sharded.py (ranks sharing one GPU)"}
     except Exception as e:
         return {"error": repr(e)[:200] + " / " + out[-200:]}

@@ -44,6 +44,27 @@ def test_transposes_between_the_two_layouts(xlp, orc, rows, w, ext, col0, ncols)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n0,n1,n", [(5, 2, 3000), (7, 4, 1), (3, 1, 255), (2, 8, 1024), (1, 1, 1025)])
+def test_copy_3d_regroups_runs(xlp, orc, n0, n1, n):
+    """the packing of a sharded commit on column-major windows: [columns][cosets][a rank's rows] out of whole columns and back, with the
+    window's halo row behind every coset block (stride n + 1); short runs (the halo itself: n = 1) take the per-word kernel"""
+    import numpy as np
+    import torch
+    full = 3 * n + 5                                                     # a coset of the whole column; the rank's rows start at n + 2
+    a = orc.fill(n0 * n1 * full, 0x5EED0D30).reshape(n0, n1, full)
+    src = xlp.from_np(a.reshape(-1))
+    packed = torch.zeros(n0 * n1 * n, dtype=torch.int64, device="cuda")
+    xlp.dev_copy_3d(packed, n1 * n, n, src, n1 * full, full, n0, n1, n, src_off=n + 2)
+    xlp.sync()
+    assert (xlp.to_np(packed).reshape(n0, n1, n) == a[:, :, n + 2:2 * n + 2]).all()
+    win = torch.full((n0 * n1 * (n + 1),), 7, dtype=torch.int64, device="cuda")
+    xlp.dev_copy_3d(win, n1 * (n + 1), n + 1, packed, n1 * n, n, n0, n1, n)
+    xlp.sync()
+    w = xlp.to_np(win).reshape(n0, n1, n + 1)
+    assert (w[:, :, :n] == a[:, :, n + 2:2 * n + 2]).all() and (w[:, :, n] == np.uint64(7)).all()
+
+
+@pytest.mark.gpu
 def test_copy_view_between_layouts(xlp, orc):
     import torch
     n = 1000

@@ -107,24 +107,26 @@ def test_colmajor_program_on_a_row_range_and_in_several_slabs(xlp, orc, tmp_path
     assert (G.slab_from_colmajor(xlp.to_np(dev["pols"]), L, ext) == exp["pols"]).all()
 
 
-def test_to_colmajor_addresses_the_same_cells():
+@pytest.mark.parametrize("world", [0, 2])
+def test_to_colmajor_addresses_the_same_cells(world):
     """no GPU: every operand of the converted program names, for every row, the cell its row-major original names (checked through the
-    transposition of a slab that holds its own word indices)"""
+    transposition of a slab that holds its own word indices).  world: a rank's WINDOW of a row-sharded proof (its rows + the halo row; an
+    extended column = 2^ext coset blocks of rows + halo row): a next-row operand of the last row names the halo word of its coset block"""
     from tools import zkevm_geometry as G
     from xlayer_prover_amd import expr as E
     from xlayer_prover_amd import programs as R
     if not os.path.exists(os.path.join(R.REF_DIR, "zkevm.step52ns.xlpexpr")):
         pytest.skip("converted reference programs not built")
     ln, ext = 5, 1
-    progs, info = G.load(ln, False, "zkevm")
-    L = G.layout(ln)
-    n = 1 << ln
+    L = G.layout_window(ln, world) if world else G.layout(ln)
+    progs, info = G.load(ln, False, "zkevm", L if world else None)
+    n = (1 << ln) // (world or 1)                                       # rows of the program's range (a rank's own rows)
     ident = np.arange(L["end"][0], dtype=np.uint64)
     cmslab = G.slab_to_colmajor(ident, L, ext)                          # cmslab[storage address] = row-major address of the cell stored there
     for step, (code, _, _) in progs.items():
         rows = n << ext if step.endswith("2ns") else n
         cm = G.to_colmajor(code, L, ext)
-        nb = n if step.endswith("2ns") else rows
+        nb = (n + 1 if world else n) if step.endswith("2ns") else rows  # storage rows of a coset block
         for (op, d, a, b), (_, dc, ac, bc) in zip(E.decode(code), E.decode(cm)):
             for o, oc in ((d, dc), (a, ac), (b, bc)):
                 if o is None or o.kind not in (E.K_POLS, E.K_POLS_PRIME):

@@ -4,8 +4,10 @@
 through the host).  What it shows: (1) the same proof comes out (zkin text hash), (2) what the sharded orchestration itself costs when
 nothing is gained from it (a world of one: the window copies, exchanges that are device copies, gathered 3-column polynomials), which is
 the overhead term of the scaling model in DESIGN.md 6.  The multi-rank rates mean nothing (one GPU, host-staged); no multi-GPU box exists
-in this pool.  Step programs run interpreted here (no ahead-of-time kernels are built for this size).
-    python tools/bench_sharded_cpp.py [--log-n 20] [--worlds 1,2,4]"""
+in this pool.  Step programs run interpreted unless ahead-of-time kernels of this geometry were built
+(`python tools/build_expr_plugins.py --geometry L [--world G] [--colmajor] --opt-only` in xlayer_prover_amd/chelpers).
+--layouts rowmajor,colmajor: every configuration with row-major sections / windows and with column-major ones (round 4).
+    python tools/bench_sharded_cpp.py [--log-n 20] [--worlds 1,2,4] [--layouts rowmajor,colmajor]"""
 import argparse
 import hashlib
 import json
@@ -40,9 +42,10 @@ def run(bundle, world=0, backend="self", tag=""):
         if p.returncode != 0:
             return {"error": f"rank {r}: exit {p.returncode}: {se[-400:]}"}
     t = timers(outs[0][1])
+    modes = f"{outs[0][1].count('compiled')} compiled"
     ex = re.search(r"(\d+) exchanges, ([0-9.]+) GB sent to peers in ([0-9.]+) s", outs[0][1])
     return {"proof_sha256_16": hashlib.sha256(outs[0][0].strip().splitlines()[-1].encode()).hexdigest()[:16], "sum_timed_s": round(sum(t.values()), 4),
-            "timers_s_rank0": {k: round(v, 4) for k, v in t.items()},
+            "timers_s_rank0": {k: round(v, 4) for k, v in t.items()}, "programs": modes,
             "exchanges_rank0": {"calls": int(ex.group(1)), "GB_sent_to_peers": float(ex.group(2)), "seconds": float(ex.group(3))} if ex else None}
 
 
@@ -50,19 +53,25 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--worlds", default="1,2,4")
+    ap.add_argument("--layouts", default="rowmajor")
     a = ap.parse_args()
     from tools import make_stark_bundle as B
     tmp = tempfile.mkdtemp(prefix="xlp_bsc_")
-    out = {"workload": f"zkEVM-geometry genProof (C++ Starks, interpreted step programs), N = 2^{a.log_n}, ONE GPU", "runs": {}}
-    one = run(B.make("zkevm", a.log_n, False, out=os.path.join(tmp, "one")))
-    out["runs"]["one_gpu"] = one
-    for w in [int(x) for x in a.worlds.split(",")]:
-        b = B.make("zkevm", a.log_n, False, out=os.path.join(tmp, f"w{w}"), world=w)
-        if w == 1:
-            out["runs"]["sharded_world1_self"] = run(b, 1, "self", "w1s")
-            out["runs"]["sharded_world1_rccl"] = run(b, 1, "rccl", "w1r")
-        else:
-            out["runs"][f"sharded_world{w}_shm_ranks_sharing_the_gpu"] = run(b, w, "shm", f"w{w}")
+    out = {"workload": f"zkEVM-geometry genProof (C++ Starks), N = 2^{a.log_n}, ONE GPU", "runs": {}}
+    one = None
+    for layout in a.layouts.split(","):
+        cm = layout == "colmajor"
+        sfx = "_colmajor" if cm else ""
+        r1 = run(B.make("zkevm", a.log_n, False, out=os.path.join(tmp, "one" + sfx), colmajor=cm))
+        one = one or r1
+        out["runs"]["one_gpu" + sfx] = r1
+        for w in [int(x) for x in a.worlds.split(",")]:
+            b = B.make("zkevm", a.log_n, False, out=os.path.join(tmp, f"w{w}{sfx}"), world=w, colmajor=cm)
+            if w == 1:
+                out["runs"]["sharded_world1_self" + sfx] = run(b, 1, "self", "w1s")
+                out["runs"]["sharded_world1_rccl" + sfx] = run(b, 1, "rccl", "w1r")
+            else:
+                out["runs"][f"sharded_world{w}_shm_ranks_sharing_the_gpu" + sfx] = run(b, w, "shm", f"w{w}")
     ref = one.get("proof_sha256_16")
     out["same_proof_everywhere"] = all(r.get("proof_sha256_16") == ref for r in out["runs"].values())
     print(json.dumps(out))

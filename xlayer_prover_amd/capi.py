@@ -474,6 +474,11 @@ def dev_copy_view(dst, drs, dcs, src, srs, scs, n, dim, dst_off=0, src_off=0):
     _ck(load().xlp_dev_copy_view(_dpo(dst, dst_off), drs, dcs, _dpo(src, src_off), srs, scs, n, dim), "xlp_dev_copy_view")
 
 
+def dev_copy_3d(dst, ds0, ds1, src, ss0, ss1, n0, n1, n, dst_off=0, src_off=0):
+    """dst[a * ds0 + b * ds1 + i] = src[a * ss0 + b * ss1 + i] (a < n0, b < n1, i < n): runs of n contiguous words regrouped"""
+    _ck(load().xlp_dev_copy_3d(_dpo(dst, dst_off), ds0, ds1, _dpo(src, src_off), ss0, ss1, n0, n1, n), "xlp_dev_copy_3d")
+
+
 def dev_extend_cm(out, out_cstride, src, in_cstride, n_ext, n, ncols, out_off=0, src_off=0, out_coset_stride=0):
     _ck(load().xlp_dev_extend_cm(_dpo(out, out_off), out_cstride, out_coset_stride, _dpo(src, src_off), in_cstride, n_ext, n, ncols), "xlp_dev_extend_cm")
 

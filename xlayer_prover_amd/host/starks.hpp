@@ -132,7 +132,7 @@ private:
     // COLUMN-MAJOR device sections ("xlp": {"colMajor": true} in the starkinfo; include/xlp_gl.h): every section of the device slab is stored
     // as columns at the offsets and sizes the starkinfo names (the extended ones coset-major), the constant polynomials likewise; the step
     // programs of the bundle are converted to match.  The host slab pAddress keeps the reference's row-major form: the witness is transposed
-    // band by band as it arrives, opened rows are gathered.  One-GPU mode only.
+    // band by band as it arrives, opened rows are gathered.  Row-sharded: the rank's WINDOW as columns (see commitShardedCm).
     bool colMajor = false;
     uint64_t *d_const_n = NULL, *d_const_2ns_own = NULL, *d_x_n = NULL, *d_x_2ns = NULL, *d_zi = NULL, *d_xdx = NULL, *d_xdwx = NULL;
     uint64_t *d_challenges = NULL, *d_publics = NULL, *d_evals = NULL, *d_work = NULL;
