@@ -54,7 +54,7 @@ def _run_ranks(bundle, world, backend, tmp_path, timeout=900, env=None):
         cmd = [EXE, "bundle", bundle, "zkevm", str(WSEED), str(CSEED), "--world", str(world), "--rank", str(r)]
         if backend != "self":
             cmd += ["--backend", backend, "--rendezvous", rdv]
-        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(env or os.environ, XLP_COMM_BARRIER_TIMEOUT_S="200")))
     outs = []
     try:
         for p in procs:

@@ -369,9 +369,12 @@ static int shm_barrier()
         h->generation.store(gen + 1, std::memory_order_release);
         return 0;
     }
-    if (!wait_for([&] { return h->generation.load(std::memory_order_acquire) != gen; }, 600.0)) {
+    double limit = 600.0;                                       // (XLP_COMM_BARRIER_TIMEOUT_S: harnesses that are themselves watched for silence)
+    if (const char* e = getenv("XLP_COMM_BARRIER_TIMEOUT_S")) { const double v = atof(e); if (v >= 1.0) limit = v; }
+    if (!wait_for([&] { return h->generation.load(std::memory_order_acquire) != gen; }, limit)) {
         if (aborted()) return fail_abort("xlp_comm");
-        return comm_fail("xlp_comm: a rank did not reach the barrier within 600 s");
+        return comm_fail(("xlp_comm: rank " + std::to_string(g_comm.rank) + " waited " + std::to_string((int)limit) + " s at barrier " + std::to_string(gen) +
+                          " of the shm transport: a rank did not reach it").c_str());
     }
     return 0;
 }
