@@ -331,6 +331,47 @@ int xlp_fft_bn254(uint64_t* data, uint64_t n, int inverse);
 int xlp_dev_msm_bn254(uint64_t* out, const uint64_t* bases, const uint64_t* scalars, uint64_t n);
 int xlp_msm_bn254(uint64_t* out, const uint64_t* bases, const uint64_t* scalars, uint64_t n);
 
+/* ---- the fflonk prover's vectors (src/rapidsnark/fflonk_prover.c.hpp, src/rapidsnark/polynomial/polynomial.c.hpp) -------
+ * DEVICE vectors of Fr elements (4 x uint64 Montgomery limbs each); scalars and small tables are HOST arrays of such elements.  Asynchronous on
+ * the current stream except xlp_dev_fr_eval (its result is on the host when it returns).  host/fflonk_prover.hpp drives them.
+ *   xlp_dev_fr_gather_mont     out[i] = toMontgomery(values[map[i]]), 0 past the table: FflonkProver::getWitness + the toMontgomery of
+ *                              computeWirePolynomial (fflonk_prover.c.hpp:615-629,702-706); values = 32-byte little-endian integers (.wtns form)
+ *   xlp_dev_fr_from_mont       FflonkProver::polynomialFromMontgomery (:1683-1698): the scalars of a multi-exponentiation
+ *   xlp_dev_fr_mul             out[i] = a[i] * b[i]
+ *   xlp_dev_fr_lincomb         out[i] = sum_t coefs[t] * pols[t][i], i < len (a term reads 0 past its lens[t]); at most 6 terms:
+ *                              Polynomial::add / sub / mulScalar / subScalar chains (polynomial.c.hpp:216-283) in one pass
+ *   xlp_dev_fr_interleave      CPolynomial::getPolynomial (cpolynomial.c.hpp:39-63): out[i * k + j] = pols[j][i] (0 past lens[j]), k <= 8
+ *   xlp_dev_fr_div_zh          Polynomial::divZh (polynomial.c.hpp:537-569): pol / (X^n - 1) in place, len a multiple of n
+ *   xlp_dev_fr_batch_inverse   FflonkProver::batchInverse (:1531-1555), out of place
+ *   xlp_dev_fr_prefix_product  out[i] = in[0] * ... * in[i] (the running products of computeZ :915-930), as a scan
+ *   xlp_dev_fr_div_xm_minus    Polynomial::divByZerofier (polynomial.c.hpp:571-634): out = in / (X^m - beta) for a divisible polynomial of len
+ *                              coefficients, out of place; the recurrence of every residue class mod m as a scan (the reference: one thread
+ *                              per class -- a single thread for X - y)
+ *   xlp_dev_fr_eval            Polynomial::fastEvaluate (polynomial.c.hpp:184-214) at npoints <= 8 points at once; values / points: HOST
+ *   xlp_dev_fflonk_t0          the loop of computeT0 (:730-778) over the n4 = 4n evaluations (lagrange: npub blocks of n4; pub: device, npub values)
+ *   xlp_dev_fflonk_z_numden    the first loop of computeZ (:880-913): scalars = beta, gamma, k1, k2; wpow[k] = omega_n^(2^k), k < nw
+ *   xlp_dev_fflonk_z_rotate    z[(i + 1) % n] = run[i] (:915-946)
+ *   xlp_dev_fflonk_t1          the loop of computeT1 (:988-1011) over n2 = 2n points: blinding = b7, b8, b9; wpow of omega_2n
+ *   xlp_dev_fflonk_t2          the loop of computeT2 (:1041-1113) over 4n points: scalars = beta, gamma, k1, k2, omega_n, b7, b8, b9; wpow of omega_4n */
+int xlp_dev_fr_gather_mont(uint64_t* out, const uint32_t* map, uint64_t nmap, const uint64_t* values, uint64_t nvalues);
+int xlp_dev_fr_from_mont(uint64_t* out, const uint64_t* in, uint64_t n);
+int xlp_dev_fr_mul(uint64_t* out, const uint64_t* a, const uint64_t* b, uint64_t n);
+int xlp_dev_fr_lincomb(uint64_t* out, uint64_t len, uint32_t nterms, const uint64_t* const* pols, const uint64_t* lens, const uint64_t* coefs);
+int xlp_dev_fr_interleave(uint64_t* out, uint64_t out_len, uint32_t k, const uint64_t* const* pols, const uint64_t* lens);
+int xlp_dev_fr_div_zh(uint64_t* pol, uint64_t len, uint64_t n);
+int xlp_dev_fr_batch_inverse(uint64_t* out, const uint64_t* in, uint64_t n);
+int xlp_dev_fr_prefix_product(uint64_t* out, const uint64_t* in, uint64_t n);
+int xlp_dev_fr_div_xm_minus(uint64_t* out, const uint64_t* in, uint64_t len, uint32_t m, const uint64_t* beta);
+int xlp_dev_fr_eval(uint64_t* values, const uint64_t* pol, uint64_t len, const uint64_t* points, uint32_t npoints);
+int xlp_dev_fflonk_t0(uint64_t* out, const uint64_t* a, const uint64_t* b, const uint64_t* c, const uint64_t* ql, const uint64_t* qr, const uint64_t* qm, const uint64_t* qo,
+                      const uint64_t* qc, const uint64_t* lagrange, const uint64_t* pub, uint32_t npub, uint64_t n4);
+int xlp_dev_fflonk_z_numden(uint64_t* num, uint64_t* den, const uint64_t* a, const uint64_t* b, const uint64_t* c, const uint64_t* s1, const uint64_t* s2, const uint64_t* s3, uint64_t n,
+                            const uint64_t* scalars, const uint64_t* wpow, uint32_t nw);
+int xlp_dev_fflonk_z_rotate(uint64_t* z, const uint64_t* run, uint64_t n);
+int xlp_dev_fflonk_t1(uint64_t* t1, uint64_t* t1z, const uint64_t* z, const uint64_t* lagrange1, uint64_t n2, const uint64_t* blinding, const uint64_t* wpow, uint32_t nw);
+int xlp_dev_fflonk_t2(uint64_t* t2, uint64_t* t2z, const uint64_t* a, const uint64_t* b, const uint64_t* c, const uint64_t* z, const uint64_t* s1, const uint64_t* s2, const uint64_t* s3,
+                      uint64_t n4, const uint64_t* scalars, const uint64_t* wpow, uint32_t nw);
+
 /* Test hook: out[i] = op(a[i], b[i]) using the device field functions the kernels are built
  * from (op codes: csrc/fri.hip field_op_kernel).  Host pointers.  Not part of the reference surface. */
 int xlp_field_op(uint64_t* out, const uint64_t* a, const uint64_t* b, uint64_t n, int op);

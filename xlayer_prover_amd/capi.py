@@ -72,6 +72,21 @@ SIGNATURES = {
     "xlp_dev_fft_bn254": [_pu, _u64, C.c_int],
     "xlp_fft_bn254": [_pu, _u64, C.c_int],
     "xlp_dev_msm_bn254": [_pu, _pu, _pu, _u64],
+    "xlp_dev_fr_gather_mont": [_pu, _pu, _u64, _pu, _u64],
+    "xlp_dev_fr_from_mont": [_pu, _pu, _u64],
+    "xlp_dev_fr_mul": [_pu, _pu, _pu, _u64],
+    "xlp_dev_fr_lincomb": [_pu, _u64, _u32, _pu, _pu, _pu],
+    "xlp_dev_fr_interleave": [_pu, _u64, _u32, _pu, _pu],
+    "xlp_dev_fr_div_zh": [_pu, _u64, _u64],
+    "xlp_dev_fr_batch_inverse": [_pu, _pu, _u64],
+    "xlp_dev_fr_prefix_product": [_pu, _pu, _u64],
+    "xlp_dev_fr_div_xm_minus": [_pu, _pu, _u64, _u32, _pu],
+    "xlp_dev_fr_eval": [_pu, _pu, _u64, _pu, _u32],
+    "xlp_dev_fflonk_t0": [_pu] * 11 + [_u32, _u64],
+    "xlp_dev_fflonk_z_numden": [_pu] * 8 + [_u64, _pu, _pu, _u32],
+    "xlp_dev_fflonk_z_rotate": [_pu, _pu, _u64],
+    "xlp_dev_fflonk_t1": [_pu, _pu, _pu, _pu, _u64, _pu, _pu, _u32],
+    "xlp_dev_fflonk_t2": [_pu] * 9 + [_u64, _pu, _pu, _u32],
     "xlp_msm_bn254": [_pu, _pu, _pu, _u64],
     "xlp_profile_read": [C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
     "xlp_dev_extend_cols": [_pu, _pu, _u64, _u64, _u64, _u64, _u64],
@@ -325,6 +340,56 @@ def msm_bn254(bases, scalars):
 
 def dev_msm_bn254(out, bases, scalars, n):
     _ck(load().xlp_dev_msm_bn254(_dp(out), _dp(bases), _dp(scalars), n), "xlp_dev_msm_bn254")
+
+
+# ---- vectors of BN254 Fr elements (the fflonk prover's primitives): device tensors of (n, 4) int64 Montgomery limbs; scalars as numpy (k, 4) uint64
+def dev_fr_mul(out, a, b, n):
+    _ck(load().xlp_dev_fr_mul(_dp(out), _dp(a), _dp(b), n), "xlp_dev_fr_mul")
+
+
+def dev_fr_from_mont(out, a, n):
+    _ck(load().xlp_dev_fr_from_mont(_dp(out), _dp(a), n), "xlp_dev_fr_from_mont")
+
+
+def dev_fr_batch_inverse(out, a, n):
+    _ck(load().xlp_dev_fr_batch_inverse(_dp(out), _dp(a), n), "xlp_dev_fr_batch_inverse")
+
+
+def dev_fr_prefix_product(out, a, n):
+    _ck(load().xlp_dev_fr_prefix_product(_dp(out), _dp(a), n), "xlp_dev_fr_prefix_product")
+
+
+def dev_fr_div_zh(pol, length, n):
+    _ck(load().xlp_dev_fr_div_zh(_dp(pol), length, n), "xlp_dev_fr_div_zh")
+
+
+def dev_fr_div_xm_minus(out, a, length, m, beta):
+    b = np.ascontiguousarray(beta, dtype=np.uint64).reshape(4)
+    _ck(load().xlp_dev_fr_div_xm_minus(_dp(out), _dp(a), length, m, _p(b)), "xlp_dev_fr_div_xm_minus")
+
+
+def dev_fr_eval(pol, length, points):
+    pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros_like(pts)
+    _ck(load().xlp_dev_fr_eval(_p(out), _dp(pol), length, _p(pts), pts.shape[0]), "xlp_dev_fr_eval")
+    return out
+
+
+def dev_fr_lincomb(out, length, terms):
+    """terms: [(device tensor, offset in elements, len, coefficient (4,) uint64)]"""
+    k = len(terms)
+    ptrs = (C.c_void_p * k)(*[_dpo(t, 4 * off) for t, off, _, _ in terms])
+    lens = np.array([l for _, _, l, _ in terms], dtype=np.uint64)
+    coefs = np.ascontiguousarray(np.stack([np.asarray(c, dtype=np.uint64).reshape(4) for _, _, _, c in terms]))
+    _ck(load().xlp_dev_fr_lincomb(_dp(out), length, k, C.cast(ptrs, C.c_void_p), _p(lens), _p(coefs)), "xlp_dev_fr_lincomb")
+
+
+def dev_fr_interleave(out, out_len, pols):
+    """pols: [(device tensor, len)]"""
+    k = len(pols)
+    ptrs = (C.c_void_p * k)(*[_dp(t) for t, _ in pols])
+    lens = np.array([l for _, l in pols], dtype=np.uint64)
+    _ck(load().xlp_dev_fr_interleave(_dp(out), out_len, k, C.cast(ptrs, C.c_void_p), _p(lens)), "xlp_dev_fr_interleave")
 
 
 def dev_fft_bn254(data, n, inverse=False):

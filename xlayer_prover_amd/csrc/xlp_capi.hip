@@ -1316,6 +1316,46 @@ int xlp_msm_bn254(uint64_t* out, const uint64_t* bases, const uint64_t* scalars,
     return 0;
 }
 
+// ---- vectors of BN254 Fr elements (fflonk.hip): device pointers, asynchronous on the current stream unless a HOST result is returned
+#define XLP_FR_CALL(name, check, call)                         \
+    XLP_ENTER;                                                 \
+    if (ensure_init()) return -1;                              \
+    if (check) return xlp_fail(name ": null pointer");         \
+    return call;
+int xlp_dev_fr_gather_mont(uint64_t* out, const uint32_t* map, uint64_t nmap, const uint64_t* values, uint64_t nvalues)
+{ XLP_FR_CALL("xlp_dev_fr_gather_mont", nmap && (!out || !map || (nvalues && !values)), dev_fr_gather_mont(&g_ctx, out, map, nmap, values, nvalues)) }
+int xlp_dev_fr_from_mont(uint64_t* out, const uint64_t* in, uint64_t n)
+{ XLP_FR_CALL("xlp_dev_fr_from_mont", n && (!out || !in), dev_fr_from_mont(&g_ctx, out, in, n)) }
+int xlp_dev_fr_mul(uint64_t* out, const uint64_t* a, const uint64_t* b, uint64_t n)
+{ XLP_FR_CALL("xlp_dev_fr_mul", n && (!out || !a || !b), dev_fr_mul(&g_ctx, out, a, b, n)) }
+int xlp_dev_fr_lincomb(uint64_t* out, uint64_t len, uint32_t nterms, const uint64_t* const* pols, const uint64_t* lens, const uint64_t* coefs)
+{ XLP_FR_CALL("xlp_dev_fr_lincomb", len && (!out || (nterms && (!pols || !lens || !coefs))), dev_fr_lincomb(&g_ctx, out, len, nterms, pols, lens, coefs)) }
+int xlp_dev_fr_interleave(uint64_t* out, uint64_t out_len, uint32_t k, const uint64_t* const* pols, const uint64_t* lens)
+{ XLP_FR_CALL("xlp_dev_fr_interleave", out_len && (!out || !pols || !lens), dev_fr_interleave(&g_ctx, out, out_len, k, pols, lens)) }
+int xlp_dev_fr_div_zh(uint64_t* pol, uint64_t len, uint64_t n)
+{ XLP_FR_CALL("xlp_dev_fr_div_zh", len && !pol, dev_fr_div_zh(&g_ctx, pol, len, n)) }
+int xlp_dev_fr_batch_inverse(uint64_t* out, const uint64_t* in, uint64_t n)
+{ XLP_FR_CALL("xlp_dev_fr_batch_inverse", n && (!out || !in), dev_fr_batch_inverse(&g_ctx, out, in, n)) }
+int xlp_dev_fr_prefix_product(uint64_t* out, const uint64_t* in, uint64_t n)
+{ XLP_FR_CALL("xlp_dev_fr_prefix_product", n && (!out || !in), dev_fr_prefix_product(&g_ctx, out, in, n)) }
+int xlp_dev_fr_div_xm_minus(uint64_t* out, const uint64_t* in, uint64_t len, uint32_t m, const uint64_t* beta)
+{ XLP_FR_CALL("xlp_dev_fr_div_xm_minus", len && (!out || !in || !beta), dev_fr_div_xm_minus(&g_ctx, out, in, len, m, beta)) }
+int xlp_dev_fr_eval(uint64_t* values, const uint64_t* pol, uint64_t len, const uint64_t* points, uint32_t npoints)
+{ XLP_FR_CALL("xlp_dev_fr_eval", !values || !points || (len && !pol), dev_fr_eval(&g_ctx, values, pol, len, points, npoints)) }
+int xlp_dev_fflonk_t0(uint64_t* out, const uint64_t* a, const uint64_t* b, const uint64_t* c, const uint64_t* ql, const uint64_t* qr, const uint64_t* qm, const uint64_t* qo,
+                      const uint64_t* qc, const uint64_t* lagrange, const uint64_t* pub, uint32_t npub, uint64_t n4)
+{ XLP_FR_CALL("xlp_dev_fflonk_t0", !out || !a || !b || !c || !ql || !qr || !qm || !qo || !qc || (npub && (!lagrange || !pub)), dev_fflonk_t0(&g_ctx, out, a, b, c, ql, qr, qm, qo, qc, lagrange, pub, npub, n4)) }
+int xlp_dev_fflonk_z_numden(uint64_t* num, uint64_t* den, const uint64_t* a, const uint64_t* b, const uint64_t* c, const uint64_t* s1, const uint64_t* s2, const uint64_t* s3, uint64_t n,
+                            const uint64_t* scalars, const uint64_t* wpow, uint32_t nw)
+{ XLP_FR_CALL("xlp_dev_fflonk_z_numden", !num || !den || !a || !b || !c || !s1 || !s2 || !s3 || !scalars || !wpow || nw > 32, dev_fflonk_z_numden(&g_ctx, num, den, a, b, c, s1, s2, s3, n, scalars, wpow, nw)) }
+int xlp_dev_fflonk_z_rotate(uint64_t* z, const uint64_t* run, uint64_t n)
+{ XLP_FR_CALL("xlp_dev_fflonk_z_rotate", !z || !run, dev_fflonk_z_rotate(&g_ctx, z, run, n)) }
+int xlp_dev_fflonk_t1(uint64_t* t1, uint64_t* t1z, const uint64_t* z, const uint64_t* lagrange1, uint64_t n2, const uint64_t* blinding, const uint64_t* wpow, uint32_t nw)
+{ XLP_FR_CALL("xlp_dev_fflonk_t1", !t1 || !t1z || !z || !lagrange1 || !blinding || !wpow || nw > 32, dev_fflonk_t1(&g_ctx, t1, t1z, z, lagrange1, n2, blinding, wpow, nw)) }
+int xlp_dev_fflonk_t2(uint64_t* t2, uint64_t* t2z, const uint64_t* a, const uint64_t* b, const uint64_t* c, const uint64_t* z, const uint64_t* s1, const uint64_t* s2, const uint64_t* s3,
+                      uint64_t n4, const uint64_t* scalars, const uint64_t* wpow, uint32_t nw)
+{ XLP_FR_CALL("xlp_dev_fflonk_t2", !t2 || !t2z || !a || !b || !c || !z || !s1 || !s2 || !s3 || !scalars || !wpow || nw > 32, dev_fflonk_t2(&g_ctx, t2, t2z, a, b, c, z, s1, s2, s3, n4, scalars, wpow, nw)) }
+
 int xlp_linear_hash(uint64_t* out, const uint64_t* src, uint64_t w, uint64_t h)
 {
     XLP_ENTER;

@@ -130,6 +130,24 @@ int dev_fft_bn254(Ctx* ctx, u64* data, u64 n, int inverse);
 // bn254_msm.hip
 int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 n);
 
+// fflonk.hip (vectors of BN254 Fr elements: the per-coefficient / per-evaluation work of the fflonk prover)
+int dev_fr_gather_mont(Ctx* ctx, u64* out, const u32* map, u64 nmap, const u64* values, u64 nvalues);
+int dev_fr_from_mont(Ctx* ctx, u64* out, const u64* in, u64 n);
+int dev_fr_mul(Ctx* ctx, u64* out, const u64* a, const u64* b, u64 n);
+int dev_fr_lincomb(Ctx* ctx, u64* out, u64 len, u32 nterms, const u64* const* pols, const u64* lens, const u64* coefs);
+int dev_fr_interleave(Ctx* ctx, u64* out, u64 out_len, u32 k, const u64* const* pols, const u64* lens);
+int dev_fr_div_zh(Ctx* ctx, u64* pol, u64 len, u64 n);
+int dev_fr_batch_inverse(Ctx* ctx, u64* out, const u64* in, u64 n);
+int dev_fr_prefix_product(Ctx* ctx, u64* out, const u64* in, u64 n);
+int dev_fr_div_xm_minus(Ctx* ctx, u64* out, const u64* in, u64 len, u32 m, const u64* beta);
+int dev_fr_eval(Ctx* ctx, u64* values, const u64* pol, u64 len, const u64* points, u32 npoints);
+int dev_fflonk_t0(Ctx* ctx, u64* out, const u64* a, const u64* b, const u64* c, const u64* ql, const u64* qr, const u64* qm, const u64* qo, const u64* qc, const u64* lagrange,
+                  const u64* pub, u32 npub, u64 n4);
+int dev_fflonk_z_numden(Ctx* ctx, u64* num, u64* den, const u64* a, const u64* b, const u64* c, const u64* s1, const u64* s2, const u64* s3, u64 n, const u64* scalars, const u64* wpow, u32 nw);
+int dev_fflonk_z_rotate(Ctx* ctx, u64* z, const u64* run, u64 n);
+int dev_fflonk_t1(Ctx* ctx, u64* t1, u64* t1z, const u64* z, const u64* lagrange1, u64 n2, const u64* blinding, const u64* wpow, u32 nw);
+int dev_fflonk_t2(Ctx* ctx, u64* t2, u64* t2z, const u64* a, const u64* b, const u64* c, const u64* z, const u64* s1, const u64* s2, const u64* s3, u64 n4, const u64* scalars, const u64* wpow, u32 nw);
+
 // comm.hip (transport between the ranks of a row-sharded proof)
 int comm_init(Ctx* ctx, int rank, int world, const char* backend, const char* rendezvous);
 void comm_shutdown();

@@ -11,6 +11,7 @@
 #include "xlp_host_bn128.hpp"
 #include "starkRecursiveF.hpp"
 #include "prover.hpp"
+#include "fflonk_prover.hpp"
 
 // `polinomial <n> <seed>`: Polinomial::batchInverse / calculateZ / calculateH1H2 through STRIDED views of one slab
 // (offset > dim, as the section views of starks.cpp:108-184 are), results as JSON for the oracle comparison.
@@ -319,6 +320,31 @@ int main(int argc, char** argv)
         const int r = bundle_mode(argv[2], argv[3], strtoull(argv[4], 0, 0), strtoull(argv[5], 0, 0), timers, world, rank, backend, rendezvous);
         xlp_shutdown();
         return r;
+    }
+    // fflonk <zkey> <wtns> [blinding.bin] [proofs]: Fflonk::FflonkProver::setZkey + prove (host/fflonk_prover.hpp); blinding.bin = b_1 .. b_9 as 32-byte
+    // little-endian integers (a test fixes them; without the file they are random, as in the reference).  Prints {"proof": ..., "publics": ..., "timers_s": ...}
+    if ((argc >= 4 && argc <= 6) && std::string(argv[1]) == "fflonk") {
+        auto zk = BinFileUtils::openExisting(argv[2], "zkey", 1);
+        auto wt = BinFileUtils::openExisting(argv[3], "wtns", 2);
+        Fflonk::FflonkProver prover;
+        if (argc >= 5 && argv[4][0]) {
+            FILE* f = fopen(argv[4], "rb");
+            uint64_t b[36];
+            if (!f || fread(b, 8, 36, f) != 36) { fprintf(stderr, "cannot read the blinding factors\n"); return 2; }
+            fclose(f);
+            prover.setBlindingFactors(b);
+        }
+        prover.setZkey(zk.get());
+        const int proofs = argc == 6 ? atoi(argv[5]) : 1;
+        for (int k = 0; k < proofs; k++) {
+            const auto r = prover.prove(wt.get());
+            std::string t = "{";
+            for (const auto& kv : prover.lastTimers) t += std::string(t.size() > 1 ? "," : "") + "\"" + kv.first + "\":" + std::to_string(kv.second);
+            printf("{\"proof\":%s,\"publics\":%s,\"timers_s\":%s}}\n", r.first.c_str(), r.second.c_str(), t.c_str());
+        }
+        prover.removePrecomputedData();
+        xlp_shutdown();
+        return 0;
     }
     if (argc == 3 && std::string(argv[1]) == "starkinfo") return starkinfo_mode(argv[2]);
     const bool aggregate = argc == 6 && std::string(argv[1]) == "aggregate";   // aggregate a.json b.json verkey.json steps: genAggregatedProof's input checks, then joinzkin
