@@ -353,6 +353,28 @@ def test_gpu_msm_bn254_large_properties(xlp):
 
 
 @pytest.mark.gpu
+def test_gpu_msm_bn254_wide_windows_at_the_size_of_a_commitment(xlp):
+    """2^22 points: windows of 18 bits (the sizes the fflonk commitments run at use 18..22-bit windows), full-width random scalars, against
+    the oracle on the 256 distinct points the bases are drawn from: sum_k (sum of the scalars that multiply point k) * P_k"""
+    n = 1 << 22
+    rng = np.random.default_rng(4242)
+    base_pts = _random_points(rng, 256)
+    idx = rng.integers(0, 256, size=n)
+    table = np.array([bo.g1_to_limbs(p) for p in base_pts], dtype=np.uint64)
+    bases = table[idx]
+    sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    sc[:, 3] &= np.uint64(0x1FFFFFFFFFFFFFFF)                           # < 2^253
+    got = bo.g1_from_limbs(xlp.msm_bn254(bases, sc))
+    halves = np.stack([(sc >> np.uint64(0)) & np.uint64(0xFFFFFFFF), sc >> np.uint64(32)], axis=2).reshape(n, 8)      # 32-bit digits, little-endian
+    tot = [0] * 256
+    for d in range(8):                                                  # exact in float64: 2^14 terms of 32 bits per point
+        s = np.bincount(idx, weights=halves[:, d].astype(np.float64), minlength=256)
+        for k in range(256):
+            tot[k] += int(s[k]) << (32 * d)
+    assert got == bo.msm(base_pts, [t % bo.R_MOD for t in tot])
+
+
+@pytest.mark.gpu
 @needs_constants
 @pytest.mark.parametrize("nbits,steps,nq", [(6, [7, 4], 5), (9, [10, 6, 3], 9)])
 def test_cpp_stark_recursivef_genproof_equals_flow(orc, K, tmp_path, nbits, steps, nq):

@@ -208,41 +208,69 @@ __global__ void msm_starts_kernel(u32* __restrict__ start, const u32* __restrict
     for (u32 k = prev + 1; k <= cur; k++) start[k] = (u32)gid;
 }
 
-// A bucket with more than HEAVY points is not walked by one lane: skewed scalars (many equal digits) and the top window (256 mod c
-// bits: few buckets, n / 2^bits points each) would serialise thousands of additions on one lane.  Such buckets are listed and summed by a
-// whole workgroup each (msm_heavy_kernel).
+// A bucket with more than HEAVY points is not walked by one lane: skewed scalars (many equal digits) and the top window (254 mod c
+// significant bits: few buckets, n / 2^bits points each) would serialise thousands of additions on one lane.  Such buckets are listed and
+// summed in SEGMENTS of SEG points, one workgroup per segment (msm_heavy_kernel), the partial sums of a bucket folded by one workgroup
+// (msm_heavy_fold_kernel): a bucket of millions of points (round 4: a 21-bit window leaves 2 bits to the top window, three buckets of
+// 9 x 2^22 / 4 points each -- 1 s of three lonely workgroups) spreads over the chip.
+// heavy[0] = segments so far, heavy[1] = heavy buckets so far; hb[3 i ..] = (key, first segment, segments); hs[2 e ..] = (key, segment)
 constexpr u32 HEAVY = 256;
+constexpr u32 SEG = 4096;
 __global__ __launch_bounds__(64) void msm_buckets_kernel(Jac* __restrict__ buckets, const u32* __restrict__ start, const u32* __restrict__ sorted_vals,
-                                                          const Aff* __restrict__ bases, const u32 nkeys, const u32 c, u32* __restrict__ heavy /* [0] = count, then keys */)
+                                                          const Aff* __restrict__ bases, const u32 nkeys, const u32 c, u32* __restrict__ heavy, u32* __restrict__ hb, u32* __restrict__ hs)
 {
     const u32 key = blockIdx.x * blockDim.x + threadIdx.x;
     if (key >= nkeys) return;
     Jac acc = jzero();
     if ((key & ((1u << c) - 1)) != 0) {
         const u32 b = start[key], e = start[key + 1];
-        if (e - b > HEAVY) { heavy[1 + atomicAdd(&heavy[0], 1u)] = key; return; }
+        if (e - b > HEAVY) {
+            const u32 nseg = (e - b + SEG - 1) / SEG;
+            const u32 first = atomicAdd(&heavy[0], nseg), i = atomicAdd(&heavy[1], 1u);
+            hb[3 * i] = key; hb[3 * i + 1] = first; hb[3 * i + 2] = nseg;
+            for (u32 s_ = 0; s_ < nseg; s_++) { hs[2 * (first + s_)] = key; hs[2 * (first + s_) + 1] = s_; }
+            return;
+        }
         for (u32 k = b; k < e; k++) acc = jmadd(acc, bases[sorted_vals[k]]);
     }
     buckets[key] = acc;
 }
-__global__ __launch_bounds__(256) void msm_heavy_kernel(Jac* __restrict__ buckets, const u32* __restrict__ start, const u32* __restrict__ sorted_vals,
-                                                         const Aff* __restrict__ bases, const u32* __restrict__ heavy)
+__device__ __forceinline__ Jac block_sum_256(Jac acc, Jac* sh, const u32 t)
+{
+    sh[t] = acc;
+    __syncthreads();
+    for (u32 step = 128; step >= 1; step >>= 1) {
+        if (t < step) sh[t] = jadd(sh[t], sh[t + step]);
+        __syncthreads();
+    }
+    const Jac r = sh[0];
+    __syncthreads();
+    return r;
+}
+__global__ __launch_bounds__(256) void msm_heavy_kernel(Jac* __restrict__ part, const u32* __restrict__ start, const u32* __restrict__ sorted_vals,
+                                                         const Aff* __restrict__ bases, const u32* __restrict__ heavy, const u32* __restrict__ hs)
 {
     __shared__ Jac sh[256];
     const u32 t = threadIdx.x;
-    for (u32 hb = blockIdx.x; hb < heavy[0]; hb += gridDim.x) {
-        const u32 key = heavy[1 + hb];
-        const u32 b = start[key], e = start[key + 1];
+    for (u32 e_ = blockIdx.x; e_ < heavy[0]; e_ += gridDim.x) {
+        const u32 key = hs[2 * e_], seg = hs[2 * e_ + 1];
+        const u32 b = start[key] + seg * SEG, lim = start[key + 1], e = b + SEG < lim ? b + SEG : lim;
         Jac acc = jzero();
         for (u32 k = b + t; k < e; k += 256) acc = jmadd(acc, bases[sorted_vals[k]]);
-        sh[t] = acc;
-        __syncthreads();
-        for (u32 step = 128; step >= 1; step >>= 1) {
-            if (t < step) sh[t] = jadd(sh[t], sh[t + step]);
-            __syncthreads();
-        }
-        if (t == 0) buckets[key] = sh[0];
-        __syncthreads();
+        const Jac r = block_sum_256(acc, sh, t);
+        if (t == 0) part[e_] = r;
+    }
+}
+__global__ __launch_bounds__(256) void msm_heavy_fold_kernel(Jac* __restrict__ buckets, const Jac* __restrict__ part, const u32* __restrict__ heavy, const u32* __restrict__ hb)
+{
+    __shared__ Jac sh[256];
+    const u32 t = threadIdx.x;
+    for (u32 i = blockIdx.x; i < heavy[1]; i += gridDim.x) {
+        const u32 key = hb[3 * i], first = hb[3 * i + 1], nseg = hb[3 * i + 2];
+        Jac acc = jzero();
+        for (u32 s_ = t; s_ < nseg; s_ += 256) acc = jadd(acc, part[first + s_]);
+        const Jac r = block_sum_256(acc, sh, t);
+        if (t == 0) buckets[key] = r;
     }
 }
 
@@ -325,7 +353,9 @@ int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 
     u32 lg = 0;
     while ((2ull << lg) <= n) lg++;
     u32 c = lg > 6 ? lg - 4 : 2;                 // ~16 points per bucket on average
-    if (c > 16) c = 16;
+    // (round 4: the cap was 16 -- at the 9 x 2^22 points of an fflonk commitment every bucket then held 576 points, i.e. was "heavy", and
+    // the whole sum went through the one-workgroup-per-bucket kernel with its 256-way LDS tree: 376 ms per commitment, 81 % of the prover)
+    if (c > 22) c = 22;
     if (c < 2) c = 2;
     const u32 nwin = (256 + c - 1) / c;
     const u64 total = n * nwin;
@@ -336,9 +366,10 @@ int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 
     size_t temp_bytes = 0;
     u32* nul = nullptr;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, nul, nul, nul, nul, (int)total, 0, 32, ctx->stream);
-    const size_t nheavy_max = total / HEAVY + 2;
-    const size_t words32 = 4 * total + (nkeys + 2) + nheavy_max + 1;
-    const size_t jac_count = (size_t)nkeys + (size_t)nwin * gpw + nwin;
+    const size_t nheavy_max = total / HEAVY + 2;                    // heavy buckets at most
+    const size_t nseg_max = total / SEG + nheavy_max + 2;            // their segments at most
+    const size_t words32 = 4 * total + (nkeys + 2) + 2 + 3 * nheavy_max + 2 * nseg_max;
+    const size_t jac_count = (size_t)nkeys + (size_t)nwin * gpw + nwin + nseg_max;
     const size_t bytes = ((words32 * 4 + 255) / 256) * 256 + jac_count * sizeof(Jac) + temp_bytes + 256;
     u64* scratch = nullptr;
     if (ctx_scratch(ctx, bytes, 7, &scratch)) return -1;
@@ -348,19 +379,23 @@ int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 
     u32* vals2 = keys2 + total;
     u32* start = vals2 + total;
     u32* heavy = start + (nkeys + 2);
+    u32* hb = heavy + 2;
+    u32* hs = hb + 3 * nheavy_max;
     Jac* buckets = (Jac*)((char*)scratch + ((words32 * 4 + 255) / 256) * 256);
     Jac* groups = buckets + nkeys;
     Jac* wsum = groups + (size_t)nwin * gpw;
-    void* temp = (void*)(wsum + nwin);
+    Jac* part = wsum + nwin;
+    void* temp = (void*)(part + nseg_max);
     const unsigned T = 256;
     hipLaunchKernelGGL(msm_keys_kernel, dim3((unsigned)((total + T - 1) / T)), dim3(T), 0, ctx->stream, keys, vals, (const u32*)scalars, (const Aff*)bases, n, nwin, c);
     u32 key_bits = 0;
     while ((1ull << key_bits) < nkeys) key_bits++;
     XLP_HIP(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys2, vals, vals2, (int)total, 0, (int)key_bits, ctx->stream));
     hipLaunchKernelGGL(msm_starts_kernel, dim3((unsigned)((total + 1 + T - 1) / T)), dim3(T), 0, ctx->stream, start, keys2, total, nkeys);
-    XLP_HIP(hipMemsetAsync(heavy, 0, sizeof(u32), ctx->stream));
-    hipLaunchKernelGGL(msm_buckets_kernel, dim3((nkeys + 63) / 64), dim3(64), 0, ctx->stream, buckets, start, vals2, (const Aff*)bases, nkeys, c, heavy);
-    hipLaunchKernelGGL(msm_heavy_kernel, dim3((unsigned)(nheavy_max < 2048 ? nheavy_max : 2048)), dim3(256), 0, ctx->stream, buckets, start, vals2, (const Aff*)bases, heavy);
+    XLP_HIP(hipMemsetAsync(heavy, 0, 2 * sizeof(u32), ctx->stream));
+    hipLaunchKernelGGL(msm_buckets_kernel, dim3((nkeys + 63) / 64), dim3(64), 0, ctx->stream, buckets, start, vals2, (const Aff*)bases, nkeys, c, heavy, hb, hs);
+    hipLaunchKernelGGL(msm_heavy_kernel, dim3((unsigned)(nseg_max < 4096 ? nseg_max : 4096)), dim3(256), 0, ctx->stream, part, start, vals2, (const Aff*)bases, heavy, hs);
+    hipLaunchKernelGGL(msm_heavy_fold_kernel, dim3((unsigned)(nheavy_max < 1024 ? nheavy_max : 1024)), dim3(256), 0, ctx->stream, buckets, part, heavy, hb);
     hipLaunchKernelGGL(msm_groups_kernel, dim3((nwin * gpw + 63) / 64), dim3(64), 0, ctx->stream, groups, buckets, nwin, c);
     hipLaunchKernelGGL(msm_window_sums_kernel, dim3(nwin), dim3(256), 0, ctx->stream, wsum, groups, nwin, gpw);
     hipLaunchKernelGGL(msm_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, (Aff*)out, wsum, nwin, c);

@@ -47,6 +47,13 @@ public:
         raw.resize((size_t)sz);
         if (sz && fread(raw.data(), 1, (size_t)sz, f) != (size_t)sz) { fclose(f); xlp_exit_process(("BinFile: short read on " + fileName).c_str()); }
         fclose(f);
+        parse(type, maxVersion);
+    }
+    // the image of a file already in memory (binfile_utils.cpp:17-56); the vector is taken over
+    BinFile(std::vector<char>&& image, const std::string& type, uint32_t maxVersion) : raw(std::move(image)) { parse(type, maxVersion); }
+private:
+    void parse(const std::string& type, uint32_t maxVersion)
+    {
         if (raw.size() < 12 || std::string(raw.data(), 4) != type) xlp_exit_process(("Invalid file type. It should be " + type).c_str());
         uint32_t version, n;
         memcpy(&version, raw.data() + 4, 4); memcpy(&n, raw.data() + 8, 4);
@@ -62,6 +69,7 @@ public:
             pos += size;
         }
     }
+public:
     void* getSectionData(uint32_t id) { if (!sections.count(id)) xlp_exit_process(("BinFile: section " + std::to_string(id) + " does not exist").c_str()); return raw.data() + sections[id].first; }
     uint64_t getSectionSize(uint32_t id) { if (!sections.count(id)) xlp_exit_process(("BinFile: section " + std::to_string(id) + " does not exist").c_str()); return sections[id].second; }
     void startReadSection(uint32_t id) { cur = (const char*)getSectionData(id); curEnd = cur + getSectionSize(id); }

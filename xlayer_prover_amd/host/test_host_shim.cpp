@@ -12,6 +12,7 @@
 #include "starkRecursiveF.hpp"
 #include "prover.hpp"
 #include "fflonk_prover.hpp"
+#include "fflonk_bench_key.hpp"
 
 // `polinomial <n> <seed>`: Polinomial::batchInverse / calculateZ / calculateH1H2 through STRIDED views of one slab
 // (offset > dim, as the section views of starks.cpp:108-184 are), results as JSON for the oracle comparison.
@@ -341,6 +342,33 @@ int main(int argc, char** argv)
             std::string t = "{";
             for (const auto& kv : prover.lastTimers) t += std::string(t.size() > 1 ? "," : "") + "\"" + kv.first + "\":" + std::to_string(kv.second);
             printf("{\"proof\":%s,\"publics\":%s,\"timers_s\":%s}}\n", r.first.c_str(), r.second.c_str(), t.c_str());
+        }
+        prover.removePrecomputedData();
+        xlp_shutdown();
+        return 0;
+    }
+    // fflonk_bench <power> [proofs]: the prover on a synthetic key of 2^power rows built in memory (host/fflonk_bench_key.hpp): per-round seconds
+    if ((argc == 3 || argc == 4) && std::string(argv[1]) == "fflonk_bench") {
+        const uint32_t power = (uint32_t)atoi(argv[2]);
+        if (power < 4 || power > 24) { fprintf(stderr, "power 4..24\n"); return 2; }
+        XLP_CHECK(xlp_init(0));
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<FrElement> witness;
+        BinFileUtils::BinFile zk(FflonkBench::build(power, witness), "zkey", 1);
+        const double tBuild = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        Fflonk::FflonkProver prover;
+        const auto t1 = std::chrono::steady_clock::now();
+        prover.setZkey(&zk);
+        const double tKey = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+        const int proofs = argc == 4 ? atoi(argv[3]) : 2;
+        for (int k = 0; k < proofs; k++) {
+            const auto t2 = std::chrono::steady_clock::now();
+            const auto r = prover.prove(witness.data());
+            const double tp = std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count();
+            std::string t = "{";
+            for (const auto& kv : prover.lastTimers) t += std::string(t.size() > 1 ? "," : "") + "\"" + kv.first + "\":" + std::to_string(kv.second);
+            printf("{\"power\":%u,\"proof\":%d,\"prove_s\":%.6f,\"timers_s\":%s},\"key_build_s\":%.3f,\"set_zkey_s\":%.3f,\"proof_bytes\":%zu}\n", power, k, tp, t.c_str(), tBuild, tKey, r.first.size());
+            fflush(stdout);
         }
         prover.removePrecomputedData();
         xlp_shutdown();
