@@ -444,7 +444,7 @@ def genproof_sharded_cpp_leg(world, rank, local_rank, backend, log_n=23, timeout
 
 
 def e2e_leg(timeout_s=300, layout="colmajor"):
-    """BASELINE configs[4] minus the SNARK wrap, through the C++ Prover (host/zkprover_batch --e2e): two consecutive batch proofs
+    """BASELINE configs[4] through the C++ Prover (host/zkprover_batch --e2e; the SNARK wrap on a synthetic final circuit): two consecutive batch proofs
     (each: zkEVM 2^23 + c12a + recursive1), Prover::genAggregatedProof (joinzkin + the recursive2 STARK) and Prover::genFinalProof up
     to the recursivef STARK (Poseidon-BN128 trees / transcript).  Synthetic witnesses; the circom witness calculators and the fflonk
     prover around them are CPU / out-of-scope work."""
@@ -458,7 +458,7 @@ def e2e_leg(timeout_s=300, layout="colmajor"):
         lines = [json.loads(l) for l in r.stdout.strip().splitlines()]
     except Exception as e:
         return {"error": repr(e)[:300]}
-    t = {l["stage"]: l["timers_s"] for l in lines}
+    t = {l["stage"]: l["timers_s"] for l in lines if "timers_s" in l}
     batch = lambda k: round(sum(t[k][n] for n in ("STARK_PROOF_BATCH_PROOF", "STARK_C12_A_PROOF_BATCH_PROOF", "STARK_RECURSIVE_1_PROOF_BATCH_PROOF")), 4)
     agg, fin = t["genAggregatedProof"], t["genFinalProof(recursivef)"]
     out = {"metric": "STARK seconds of batch + batch + aggregated + final(recursivef) in the C++ Prover, one GPU",
@@ -466,6 +466,11 @@ def e2e_leg(timeout_s=300, layout="colmajor"):
            "aggregated_recursive2_s": round(agg["STARK_RECURSIVE_2_PROOF_BATCH_PROOF"], 4), "final_recursivef_s": round(fin["STARK_RECURSIVE_F_PROOF_BATCH_PROOF"], 4),
            "recursivef_stages_s": {k[len("recursivef."):]: round(v, 4) for k, v in fin.items() if k.startswith("recursivef.")}}
     out["starks_total_s"] = round(out["batch_proof_1_s"] + out["batch_proof_2_s"] + out["aggregated_recursive2_s"] + out["final_recursivef_s"], 4)
+    if "RAPID_SNARK" in fin:                            # the fflonk proof of the final circuit (synthetic key: tools/config_runFile_e2e_synthetic*.json "finalStarkZkey")
+        out["final_fflonk_s"] = round(fin["RAPID_SNARK"], 4)
+        out["final_fflonk_rounds_s"] = {k[len("fflonk."):]: round(v, 4) for k, v in fin.items() if k.startswith("fflonk.")}
+        out["final_fflonk_key"] = "synthetic key of 2^22 rows built in memory (host/fflonk_bench_key.hpp): the cost of a proof, verifiable against nothing; the reference's final.fflonk.zkey is not in the snapshot"
+        out["chain_total_s"] = round(out["starks_total_s"] + out["final_fflonk_s"], 4)
     return out
 
 

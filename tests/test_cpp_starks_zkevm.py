@@ -187,7 +187,7 @@ def _cpp_bundle_verkey(bundle, cfg_file):
 
 @pytest.mark.gpu
 def test_e2e_chain_batch_aggregated_final(orc, tmp_path):
-    """BASELINE configs[4] minus the SNARK wrap, in C++ (host/prover.hpp through `zkprover_batch --e2e`): two consecutive batch proofs
+    """BASELINE configs[4] in C++ (host/prover.hpp through `zkprover_batch --e2e`; the SNARK wrap on a synthetic final circuit): two consecutive batch proofs
     (zkEVM programs at 2^13 rows; c12a, recursive1 at their real geometry) -> Prover::genAggregatedProof (joinzkin + the recursive2
     STARK) -> Prover::genFinalProof up to the recursivef STARK (real geometry 2^17 x 16, Poseidon-BN128 trees and transcript).
     The aggregated proof verifies on the Goldilocks oracle and carries the joined publics; the recursivef proof verifies on the BN128
@@ -208,11 +208,22 @@ def test_e2e_chain_batch_aggregated_final(orc, tmp_path):
     geo = {"zkevm": (13, True), "c12a": (20, False), "recursive1": (17, False), "recursive2": (17, False), "recursivef": (17, False)}
     bundles = {c: B.make(c, ln, al, out=str(tmp_path / c)) for c, (ln, al) in geo.items()}
     cfg = _batch_config(tmp_path, bundles)
+    # the SNARK wrap: an fflonk key for a synthetic final circuit (known tau, oracle/fflonk_oracle.py) as config.finalStarkZkey, its witness
+    # through --final-wtns in place of the final circuit's witness calculator
+    from oracle import fflonk_oracle as FF
+    zk, wit, tau = FF.setup(6, n_public=1, n_additions=2, seed=31)
+    FF.write_zkey(str(tmp_path / "final.fflonk.zkey"), zk)
+    FF.write_wtns(str(tmp_path / "final.wtns"), wit)
+    cj = json.load(open(cfg))
+    cj["finalStarkZkey"] = str(tmp_path / "final.fflonk.zkey")
+    json.dump(cj, open(cfg, "w"))
     exe = os.path.join(HOST, "zkprover_batch")
-    r = subprocess.run([exe, "-c", cfg, "--e2e"], capture_output=True, text=True, timeout=1200)
+    r = subprocess.run([exe, "-c", cfg, "--e2e", "--final-wtns", str(tmp_path / "final.wtns")], capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [json.loads(l) for l in r.stdout.strip().splitlines()]
-    assert [l["stage"] for l in lines] == ["genBatchProof#1", "genBatchProof#2", "genAggregatedProof", "genFinalProof(recursivef)"]
+    assert [l["stage"] for l in lines] == ["genBatchProof#1", "genBatchProof#2", "genAggregatedProof", "genFinalProof(recursivef)", "finalProof(fflonk)"]
+    assert "RAPID_SNARK" in lines[3]["timers_s"] and "fflonk.FFLONK_ROUND_5" in lines[3]["timers_s"]
+    assert FF.verify(zk, tau, lines[4]["proof"], lines[4]["publics"]) and lines[4]["publics"] == [str(wit[1])]
     assert lines[0]["output_fnv"] != lines[1]["output_fnv"]
     assert "STARK_RECURSIVE_2_PROOF_BATCH_PROOF" in lines[2]["timers_s"] and "STARK_RECURSIVE_F_PROOF_BATCH_PROOF" in lines[3]["timers_s"]
     # ---- the aggregated (recursive2) proof

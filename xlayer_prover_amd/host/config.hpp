@@ -24,6 +24,7 @@ public:
     std::string recursive1ConstPols, recursive1ConstantsTree, recursive1StarkInfo, recursive1Verkey;
     std::string recursive2ConstPols, recursive2ConstantsTree, recursive2StarkInfo, recursive2Verkey;
     std::string recursivefConstPols, recursivefConstantsTree, recursivefStarkInfo, recursivefVerkey;
+    std::string finalStarkZkey;                      // config.cpp:268 (default <configPath>/final/final.fflonk.zkey); here: empty = no fflonk prover is set up
     std::string xlpChelpersPath;
     bool xlpSyntheticLookups = false, xlpResidentConstants = true;
     uint64_t xlpDevice = 0;
@@ -59,6 +60,7 @@ public:
             ParseString(config, (n + "StarkInfo").c_str(), (up + "_STARK_INFO").c_str(), *s.s, dir + ".starkinfo.json");
             ParseString(config, (n + "Verkey").c_str(), (up + "_VERKEY").c_str(), *s.v, dir + ".verkey.json");
         }
+        ParseString(config, "finalStarkZkey", "FINAL_STARK_ZKEY", finalStarkZkey, "");
         ParseString(config, "xlpChelpersPath", "XLP_CHELPERS_PATH", xlpChelpersPath, "");
         ParseBool(config, "xlpSyntheticLookups", "XLP_SYNTHETIC_LOOKUPS", xlpSyntheticLookups, false);
         ParseBool(config, "xlpResidentConstants", "XLP_RESIDENT_CONSTANTS", xlpResidentConstants, true);

@@ -14,6 +14,8 @@
 #include <sys/stat.h>
 #include "starks.hpp"
 #include "starkRecursiveF.hpp"
+#include "fflonk_prover.hpp"
+#include "fflonk_bench_key.hpp"
 
 class ProverRequest
 {
@@ -25,6 +27,10 @@ public:
     WitnessCalculator c12aWitness, recursive1Witness, recursive2Witness, recursivefWitness;
     std::string aggregatedProofInput1, aggregatedProofInput2, aggregatedProofOutput;     // zkin JSON texts (prover.cpp:674-783)
     std::string finalProofInput, recursivefProofOutput;                                  // prover.cpp:836-885
+    // the final circuit's witness from the recursivef zkin (CircomFinal::loadJsonImpl + getBinWitness, prover.cpp:897-912: generated circom
+    // code, host work): values as in a .wtns, NOT Montgomery.  With it and config.finalStarkZkey, genFinalProof ends with the fflonk proof
+    std::function<void(const std::string& zkinRecursiveF, std::vector<FrElement>& witness)> finalWitness;
+    std::string finalProofOutput, finalPublicsOutput;                                    // prover.cpp:931-945: the SNARK proof and its public signals (JSON)
     std::string aggregatorAddress = "0";
     int result = 1;                                  // zkresult numbering of src/config/zkresult.hpp:9-19: ZKR_SUCCESS = 1, ZKR_AGGREGATED_PROOF_INVALID_INPUT = 9
     std::string batchProofOutput;                    // zkin of the recursive1 proof + publics: the input of genAggregatedProof (prover.cpp:653)
@@ -75,6 +81,9 @@ class Prover
 public:
     Starks *starkZkevm = NULL, *starksC12a = NULL, *starksRecursive1 = NULL, *starksRecursive2 = NULL;
     StarkRecursiveF* starksRecursiveF = NULL;
+    Fflonk::FflonkProver* prover = NULL;             // prover.cpp:117-118
+    std::vector<FrElement> syntheticFinalWitness;    // the witness that goes with a "synthetic:<power>" finalStarkZkey
+    std::unique_ptr<BinFileUtils::BinFile> zkey;     // prover.cpp:52
     ZkevmSteps* zkevmSteps = NULL;
     C12aSteps* c12aSteps = NULL;
     Recursive1Steps* recursive1Steps = NULL;
@@ -114,9 +123,23 @@ public:
             starksRecursiveF = new StarkRecursiveF(config, {config.recursivefConstPols, config.mapConstPolsFile, config.recursivefConstantsTree, config.recursivefStarkInfo}, pAddress);
             recursivefSteps = new StarkRecursiveFSteps(dirOf(config.recursivefStarkInfo));
         }
+        if (config.finalStarkZkey.size()) {               // prover.cpp:52-53,117-118: the key goes to the GPU once (fflonk only: the Groth16 branch is not built)
+            // "synthetic:<power>": a key of 2^power rows built in memory (host/fflonk_bench_key.hpp; like "synthetic:<seed>" constant
+            // polynomials, for runs without the reference's 75 GB archive) with its witness in syntheticFinalWitness
+            if (config.finalStarkZkey.rfind("synthetic:", 0) == 0) {
+                const uint32_t power = (uint32_t)strtoul(config.finalStarkZkey.c_str() + 10, NULL, 0);
+                if (power < 4 || power > 26) xlp_exit_process("Prover: finalStarkZkey synthetic:<power> with 4 <= power <= 26");
+                zkey.reset(new BinFileUtils::BinFile(FflonkBench::build(power, syntheticFinalWitness), "zkey", 1));
+            } else
+            zkey = BinFileUtils::openExisting(config.finalStarkZkey, "zkey", 1);
+            if (Zkey::getProtocolIdFromZkey(zkey.get()) != Zkey::FFLONK_PROTOCOL_ID) xlp_exit_process("Prover: config.finalStarkZkey is not an fflonk key");
+            prover = new Fflonk::FflonkProver();
+            prover->setZkey(zkey.get());
+        }
     }
     ~Prover()
     {
+        delete prover;
         delete zkevmSteps; delete c12aSteps; delete recursive1Steps; delete recursive2Steps; delete recursivefSteps;
         delete starkZkevm; delete starksC12a; delete starksRecursive1; delete starksRecursive2; delete starksRecursiveF;
         if (pAddress) xlp_host_free(pAddress);
@@ -338,9 +361,10 @@ public:
         req.result = ZKR_SUCCESS;
     }
 
-    // Prover::genFinalProof (prover.cpp:836-885 up to the recursivef proof): aggregated proof -> StarkRecursiveF (BN128 trees and transcript).
-    // The final circom witness and the fflonk prover behind it (prover.cpp:887-960) are not part of this build: the output is the
-    // recursivef zkin the final circuit would consume.
+    // Prover::genFinalProof (prover.cpp:836-960): aggregated proof -> StarkRecursiveF (BN128 trees and transcript) -> the final circuit's
+    // witness -> the fflonk proof (RAPID_SNARK, prover.cpp:927-945).  The witness calculator of the final circuit is generated circom code
+    // (CircomFinal, host work): it comes in as ProverRequest::finalWitness like the other witness calculators; without it, or without
+    // config.finalStarkZkey, the request ends with the recursivef zkin the final circuit would consume.
     void genFinalProof(ProverRequest* pProverRequest)
     {
         if (!config.generateProof() || pProverRequest == NULL || !starksRecursiveF) xlp_exit_process("Prover::genFinalProof: recursivef is not configured");
@@ -368,6 +392,18 @@ public:
         xlp_json::arr(pj, publics);
         req.recursivefProofOutput = withMembers(proof2zkinStarkC12(fproof), ",\"publics\":" + pj.str() + ",\"aggregatorAddr\":\"" + req.aggregatorAddress + "\"");
         if (config.saveProofToFile) json2file(req.recursivefProofOutput, req.filePrefix + "recursivef.proof.json");
+        if (prover && req.finalWitness) {
+            std::vector<FrElement> witness;
+            {
+                Tm t(&req, "CIRCOM_GET_BIN_WITNESS_FINAL");
+                req.finalWitness(req.recursivefProofOutput, witness);
+            }
+            Tm t(&req, "RAPID_SNARK");
+            const auto r = prover->prove(witness.data());                // (the header check of prove(BinFile*) is the witness calculator's business here)
+            req.finalProofOutput = r.first; req.finalPublicsOutput = r.second;
+            for (const auto& kv : prover->lastTimers) req.timers.emplace_back("fflonk." + kv.first, kv.second);
+            if (config.saveProofToFile) json2file(req.finalProofOutput, req.filePrefix + "final_proof.proof.json");
+        }
         req.result = ZKR_SUCCESS;
     }
 };

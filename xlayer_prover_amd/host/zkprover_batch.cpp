@@ -1,5 +1,5 @@
 // zkProver in file mode for a batch proof (src/main.cpp:83-112 runFileGenBatchProof -> Prover::genBatchProof) on the GPU build:
-//     zkprover_batch -c config.json [--proofs K] [--seed S] [--sequential-upload] [--timers] [--e2e]
+//     zkprover_batch -c config.json [--proofs K] [--seed S] [--sequential-upload] [--timers] [--e2e [--final-wtns FILE]]
 //                    [--world G --rank r --backend rccl|shm --rendezvous <file | name> [--device d]]
 // --world: this process is rank r of G (one process per GPU): the transport is set up before any other GPU work, the zkEVM
 // STARK runs row-sharded (the config's zkevmStarkInfo must be the window bundle of that world, tools/make_stark_bundle.py --world G), rank 0
@@ -40,6 +40,7 @@ int main(int argc, char** argv)
     int proofs = 2;
     uint64_t seed = 0x5EED0401;
     bool sequential = false, timers = false, e2e = false;
+    std::string finalWtns;
     int world = 0, rank = 0, device = -1;
     std::string backend, rendezvous;
     for (int i = 1; i < argc; i++) {
@@ -50,6 +51,7 @@ int main(int argc, char** argv)
         else if (a == "--sequential-upload") sequential = true;
         else if (a == "--timers") timers = true;
         else if (a == "--e2e") e2e = true;
+        else if (a == "--final-wtns" && i + 1 < argc) finalWtns = argv[++i];
         else if (a == "--world" && i + 1 < argc) world = atoi(argv[++i]);
         else if (a == "--rank" && i + 1 < argc) rank = atoi(argv[++i]);
         else if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
@@ -122,8 +124,21 @@ int main(int argc, char** argv)
             stat("genAggregatedProof", req, req.aggregatedProofOutput, vk.str());
         }
         req.finalProofInput = req.aggregatedProofOutput;
+        // the final circuit's witness calculator (generated circom code in the reference): --final-wtns FILE reads a .wtns, a "synthetic:<power>"
+        // finalStarkZkey brings its own witness; without either genFinalProof ends with the recursivef zkin
+        if (finalWtns.size())
+            req.finalWitness = [&](const std::string&, std::vector<FrElement>& w) {
+                auto f = BinFileUtils::openExisting(finalWtns, "wtns", 2);
+                auto h = WtnsUtils::loadHeader(f.get());
+                w.resize(h->nVars);
+                if (f->getSectionSize(2) < (uint64_t)h->nVars * 32) xlp_exit_process("--final-wtns: data section too short");
+                memcpy(w.data(), f->getSectionData(2), (size_t)h->nVars * 32);
+            };
+        else if (prover.syntheticFinalWitness.size())
+            req.finalWitness = [&](const std::string&, std::vector<FrElement>& w) { w = prover.syntheticFinalWitness; };
         prover.genFinalProof(&req);
         stat("genFinalProof(recursivef)", req, req.recursivefProofOutput, "\"" + RawFr::field.toString(prover.starksRecursiveF->constRoot[0], 10) + "\"");
+        if (req.finalProofOutput.size()) printf("{\"stage\":\"finalProof(fflonk)\",\"proof\":%s,\"publics\":%s}\n", req.finalProofOutput.c_str(), req.finalPublicsOutput.c_str());
         if (config.saveOutputToFile) {
             FILE* f = fopen((config.outputPath + "/aggregated_proof.output.json").c_str(), "wb"); if (f) { fwrite(req.aggregatedProofOutput.data(), 1, req.aggregatedProofOutput.size(), f); fclose(f); }
             f = fopen((config.outputPath + "/recursivef.zkin.json").c_str(), "wb"); if (f) { fwrite(req.recursivefProofOutput.data(), 1, req.recursivefProofOutput.size(), f); fclose(f); }
