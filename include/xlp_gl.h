@@ -521,6 +521,9 @@ int xlp_dev_alloc(void** ptr, size_t bytes);
  * (host/starks.hpp: the extended constant polynomials, 31 GB at the zkEVM geometry -- starks.hpp:138-146 keeps them loaded). */
 int xlp_dev_mem_info(size_t* free_bytes, size_t* total_bytes);
 int xlp_dev_free(void* ptr);
+/* Give back grow-only scratch of the context (bit k of mask = slot k; 0xFF = all): for a stage that grew much of it and shares the card with
+ * others -- the fflonk prover releases its transform / scan / multi-exponentiation scratch (slots 3, 4, 5, 7) after a final proof. */
+int xlp_scratch_release(uint32_t mask);
 int xlp_dev_memset(void* dst_dev, int value, size_t bytes);          /* asynchronous on the context's stream */
 int xlp_copy_h2d(void* dst_dev, const void* src_host, size_t bytes);
 int xlp_copy_d2h(void* dst_host, const void* src_dev, size_t bytes);

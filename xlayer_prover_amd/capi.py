@@ -72,6 +72,7 @@ SIGNATURES = {
     "xlp_dev_fft_bn254": [_pu, _u64, C.c_int],
     "xlp_fft_bn254": [_pu, _u64, C.c_int],
     "xlp_dev_msm_bn254": [_pu, _pu, _pu, _u64],
+    "xlp_scratch_release": [_u32],
     "xlp_dev_fr_gather_mont": [_pu, _pu, _u64, _pu, _u64],
     "xlp_dev_fr_from_mont": [_pu, _pu, _u64],
     "xlp_dev_fr_mul": [_pu, _pu, _pu, _u64],

@@ -161,6 +161,23 @@ static void commit_times_clear();
 
 extern "C" {
 
+// xlp_scratch_release: give grow-only scratch slots back (bit k of mask = slot k): a prover that shares the card with others releases what its
+// last stage grew (the fflonk commitments: 11 GB of sort / bucket scratch at 9 x 2^22 points) instead of holding it for the process' life
+int xlp_scratch_release(uint32_t mask)
+{
+    XLP_ENTER;
+    if (!g_ctx.inited) return 0;
+    XLP_HIP(hipStreamSynchronize(g_ctx.stream));
+    for (int k = 0; k < 8; k++)
+        if (((mask >> k) & 1) && g_ctx.scratch[k]) {
+            XLP_HIP(hipFree(g_ctx.scratch[k]));
+            g_ctx.scratch[k] = nullptr;
+            g_ctx.scratch_bytes[k] = 0;
+        }
+    return 0;
+}
+
+
 int xlp_version(void) { return 0x000100; }
 
 const char* xlp_last_error(void) { return g_err.c_str(); }

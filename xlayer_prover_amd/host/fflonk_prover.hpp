@@ -16,14 +16,15 @@
 // Differences from the reference, by design: prove() returns the two JSON documents as text (no nlohmann here); the degree checks read the
 // coefficients that must vanish through one evaluation at a transcript-independent point instead of Polynomial::fixDegree scans on the host;
 // setBlindingFactors() lets a test fix b_1 .. b_9 (the reference draws them with libsodium, fflonk_prover.c.hpp:645-650).
-// PARITY UNPINNED against the reference (the snapshot has no zkey): checked against oracle/fflonk_oracle.py -- same proof for the same
-// blinding, and the proof passes the fflonk verification equation (tests/test_fflonk.py).
+// PARITY UNPINNED against the reference (the snapshot has no zkey): checked against the CPU restatement of the prover -- same proof for the
+// same blinding -- and against the fflonk verification equation (tests/test_fflonk.py).
 #pragma once
 #include <algorithm>
 #include <array>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <string>
@@ -294,13 +295,28 @@ class FflonkProver
     std::map<std::string, FrElement> evaluationCommitments;
     std::vector<FrElement> R0, R1, R2;
 
-    DevFr dalloc(uint64_t elems)
+    // reserved-memory mode (the reference's FflonkProver(E, reservedMemoryPtr, reservedMemorySize), prover.cpp:117: the STARKs' polynomial
+    // memory doubles as the prover's): every device vector -- the key's too -- is carved from this region at the start of each proof, the
+    // key uploaded again from the host image; nothing of the prover stays in HBM between final proofs (the zkEVM slab fills the card)
+    char* reserved = NULL;
+    uint64_t reservedBytes = 0, reservedUsed = 0;
+    std::function<std::pair<void*, uint64_t>()> reservedProvider;
+    BinFileUtils::BinFile* keyFile = NULL;
+    void* rawAlloc(uint64_t bytes)
     {
+        if (reserved) {
+            const uint64_t at_ = (reservedUsed + 255) & ~255ULL;
+            if (at_ + bytes > reservedBytes)
+                xlp_exit_process(("Not enough reserved memory to generate a prove. Increase reserved memory size at least to " + std::to_string(at_ + bytes) + " bytes").c_str());
+            reservedUsed = at_ + bytes;
+            return reserved + at_;
+        }
         void* p = NULL;
-        XLP_CHECK(xlp_dev_alloc(&p, (elems ? elems : 1) * 32));
+        XLP_CHECK(xlp_dev_alloc(&p, bytes ? bytes : 1));
         owned.push_back(p);
-        return (DevFr)p;
+        return p;
     }
+    DevFr dalloc(uint64_t elems) { return (DevFr)rawAlloc((elems ? elems : 1) * 32); }
     static DevFr at(DevFr p, uint64_t elem) { return p + 4 * elem; }
     FrElement root(uint32_t bits, uint64_t idx) const                  // FFT::root(domainPow, idx) (fft.c.hpp:52-84): w_(2^bits)^idx, w = 5^((r - 1) / 2^bits)
     {
@@ -409,6 +425,12 @@ class FflonkProver
 public:
     std::vector<std::pair<std::string, double>> lastTimers;
     FflonkProver() { memset(blindingFactors, 0, sizeof blindingFactors); }
+    // reserved-memory mode: the region is asked for at the start of every proof (the STARKs' device slab may have been re-reserved since)
+    explicit FflonkProver(std::function<std::pair<void*, uint64_t>()> reservedDeviceMemory) : reservedProvider(reservedDeviceMemory)
+    {
+        memset(blindingFactors, 0, sizeof blindingFactors);
+        reserved = (char*)1;                               // (non-null: nothing is allocated before the first proof)
+    }
     ~FflonkProver() { removePrecomputedData(); }
     FflonkProver(const FflonkProver&) = delete;
     FflonkProver& operator=(const FflonkProver&) = delete;
@@ -426,11 +448,13 @@ public:
         delete zkey; zkey = NULL;
     }
 
-    // FflonkProver::setZkey (:94-330): everything circuit-dependent goes to the GPU once
+    // FflonkProver::setZkey (:94-330): everything circuit-dependent goes to the GPU once (reserved-memory mode: at every proof; the file
+    // image must then outlive the prover)
     void setZkey(BinFileUtils::BinFile* fdZkey)
     {
         if (zkey) removePrecomputedData();
         XLP_CHECK(xlp_init(0));
+        keyFile = fdZkey;
         if (Zkey::getProtocolIdFromZkey(fdZkey) != Zkey::FFLONK_PROTOCOL_ID) xlp_exit_process("zkey file is not fflonk");
         zkey = Zkey::FflonkZkeyHeader::loadFflonkZkeyHeader(fdZkey);
         if (memcmp(zkey->rPrime, FrModulus::Q, 32) != 0) xlp_exit_process("zkey curve not supported");
@@ -440,6 +464,23 @@ public:
         while ((1ULL << zkeyPower) < N) zkeyPower++;
         if (zkey->nPublic < 1) xlp_exit_process("zkey: at least one public input expected (the Lagrange section holds max(nPublic, 1) polynomials)");
         if (zkey->nConstraints > N - 2) xlp_exit_process("zkey: more constraints than rows (the last two rows are the prover's)");
+        if (fdZkey->getSectionSize(Zkey::ZKEY_FF_ADDITIONS_SECTION) < (uint64_t)zkey->nAdditions * sizeof(Zkey::Addition)) xlp_exit_process("zkey: additions section too short");
+        additionsBuff.resize(zkey->nAdditions);
+        if (zkey->nAdditions) memcpy(additionsBuff.data(), fdZkey->getSectionData(Zkey::ZKEY_FF_ADDITIONS_SECTION), (size_t)zkey->nAdditions * sizeof(Zkey::Addition));
+        if (!reserved) deviceSetup();
+    }
+
+private:
+    void deviceSetup()
+    {
+        BinFileUtils::BinFile* fdZkey = keyFile;
+        if (reservedProvider) {
+            const auto r = reservedProvider();
+            if (!r.first) xlp_exit_process("FflonkProver: no reserved device memory");
+            reserved = (char*)r.first; reservedBytes = r.second;
+        }
+        reservedUsed = 0;
+        polPtr.clear(); evalPtr.clear(); buffers.clear();
         auto section = [&](int id, uint64_t elems) {
             if (fdZkey->getSectionSize(id) < elems * 32) xlp_exit_process(("zkey: section " + std::to_string(id) + " too short").c_str());
             return (const uint64_t*)fdZkey->getSectionData(id);
@@ -464,15 +505,10 @@ public:
         const int mapIds[3] = {Zkey::ZKEY_FF_A_MAP_SECTION, Zkey::ZKEY_FF_B_MAP_SECTION, Zkey::ZKEY_FF_C_MAP_SECTION};
         for (int k = 0; k < 3; k++) {
             if (fdZkey->getSectionSize(mapIds[k]) < (uint64_t)zkey->nConstraints * 4) xlp_exit_process("zkey: map section too short");
-            void* p = NULL;
-            XLP_CHECK(xlp_dev_alloc(&p, ((uint64_t)zkey->nConstraints + 1) * 4));
-            owned.push_back(p);
+            void* p = rawAlloc(((uint64_t)zkey->nConstraints + 1) * 4);
             mapBuffers[k] = (uint32_t*)p;
             XLP_CHECK(xlp_copy_h2d(p, fdZkey->getSectionData(mapIds[k]), (uint64_t)zkey->nConstraints * 4));
         }
-        if (fdZkey->getSectionSize(Zkey::ZKEY_FF_ADDITIONS_SECTION) < (uint64_t)zkey->nAdditions * sizeof(Zkey::Addition)) xlp_exit_process("zkey: additions section too short");
-        additionsBuff.resize(zkey->nAdditions);
-        if (zkey->nAdditions) memcpy(additionsBuff.data(), fdZkey->getSectionData(Zkey::ZKEY_FF_ADDITIONS_SECTION), (size_t)zkey->nAdditions * sizeof(Zkey::Addition));
         // per-proof vectors (the reference's nonPrecomputedBigBuffer, :296-371; here every polynomial has its own buffer)
         const std::pair<const char*, uint64_t> pols[] = {{"A", N}, {"B", N}, {"C", N}, {"T0", 4 * N}, {"C1", 8 * N}, {"Z", 2 * N}, {"T1", 2 * N}, {"T1z", 2 * N}, {"T2", 4 * N},
                                                          {"T2z", 4 * N}, {"C2", 16 * N}, {"F", 16 * N}, {"L", 16 * N}, {"tmp2", 16 * N}};
@@ -486,6 +522,7 @@ public:
         XLP_CHECK(xlp_sync());
         keyAllocs = owned.size();
     }
+public:
 
     // FflonkProver::prove (:427-596).  Returns (proof JSON, public signals JSON) as text.
     std::pair<std::string, std::string> prove(BinFileUtils::BinFile* fdZkey, BinFileUtils::BinFile* fdWtns) { setZkey(fdZkey); return prove(fdWtns); }
@@ -504,6 +541,7 @@ public:
                 xlp_exit_process(("Invalid witness length. Circuit: " + std::to_string(zkey->nVars) + ", witness: " + std::to_string(wtnsHeader->nVars) + ", " + std::to_string(zkey->nAdditions)).c_str());
         }
         lastTimers.clear();
+        if (reserved) timed("FFLONK_KEY_TO_DEVICE", [&] { deviceSetup(); });
         transcript.reset(); polynomialCommitments.clear(); evaluationCommitments.clear(); toInverse.clear(); challenges.clear(); roots.clear();
         // the witness with the additions behind it (calculateAdditions :598-612: an addition may read earlier additions, so a host loop as in
         // the reference; values stay in the .wtns form, NOT Montgomery: factor (Montgomery) x value (plain) = plain)
@@ -523,6 +561,7 @@ public:
         timed("FFLONK_ROUND_4", [&] { round4(); });
         timed("FFLONK_ROUND_5", [&] { round5(); });
         evaluationCommitments["inv"] = getMontgomeryBatchedInverse();
+        if (reserved) XLP_CHECK(xlp_scratch_release((1u << 3) | (1u << 4) | (1u << 5) | (1u << 7)));     // the card goes back to the STARKs as it was
         std::string pub = "[";
         for (uint32_t i = 1; i <= zkey->nPublic; i++) pub += std::string(i > 1 ? "," : "") + "\"" + FrH::toString(FrH::toMontgomery(wit[i])) + "\"";      // :546-553
         pub += "]";

@@ -133,7 +133,9 @@ public:
             } else
             zkey = BinFileUtils::openExisting(config.finalStarkZkey, "zkey", 1);
             if (Zkey::getProtocolIdFromZkey(zkey.get()) != Zkey::FFLONK_PROTOCOL_ID) xlp_exit_process("Prover: config.finalStarkZkey is not an fflonk key");
-            prover = new Fflonk::FflonkProver();
+            // prover.cpp:117: the STARKs' polynomial memory is the prover's reserved memory -- here the DEVICE slab (the zkEVM slab fills the card:
+            // nothing of the fflonk prover may stay in HBM between final proofs); the key is uploaded from the host image at every proof
+            prover = new Fflonk::FflonkProver([] { return std::make_pair((void*)XlpDeviceSlab::get().address(), XlpDeviceSlab::get().capacityWords() * 8); });
             prover->setZkey(zkey.get());
         }
     }

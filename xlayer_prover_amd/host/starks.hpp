@@ -61,6 +61,7 @@ public:
         return p;
     }
     uint64_t* address() { return p; }
+    uint64_t capacityWords() const { return words; }
     void release() { if (p) xlp_dev_free(p); p = NULL; words = 0; }
 };
 
