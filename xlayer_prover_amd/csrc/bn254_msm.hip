@@ -197,19 +197,16 @@ __global__ void msm_keys_kernel(u32* __restrict__ keys, u32* __restrict__ vals, 
     vals[gid] = (u32)i;
 }
 
-// start[k] = first sorted position with key k; start[nkeys] = total.  Keys absent from the sorted array inherit the next start.
-// (eight positions per lane: one lane per position was 30 ms for the 4.9e8 pairs of a 9 x 2^22-point sum)
-__global__ void msm_starts_kernel(u32* __restrict__ start, const u32* __restrict__ sorted_keys, const u64 total, const u32 nkeys)
+// start[k] / stop[k] = first / one past the last sorted position with key k; a key absent from the sorted array keeps start = stop = 0
+// (both arrays are zeroed first).  (Until round 4 absent keys inherited the next key's start: the lane at the END of the array then filled
+// the whole unused top of the top window -- up to 2^c words, one after the other: 30 ms of a 195 ms sum at 9 x 2^22 points.)
+__global__ void msm_starts_kernel(u32* __restrict__ start, u32* __restrict__ stop, const u32* __restrict__ sorted_keys, const u64 total)
 {
-    const u64 g0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 8;
-    if (g0 > total) return;
-    u32 prev = g0 == 0 ? 0xFFFFFFFFu : sorted_keys[g0 - 1];
-    for (u64 gid = g0; gid < g0 + 8 && gid <= total; gid++) {
-        const u32 cur = gid < total ? sorted_keys[gid] : nkeys;
-        if (gid == 0) { for (u32 k = 0; k <= cur; k++) start[k] = 0; }
-        else for (u32 k = prev + 1; k <= cur; k++) start[k] = (u32)gid;
-        prev = cur;
-    }
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const u32 cur = sorted_keys[gid];
+    if (gid == 0 || sorted_keys[gid - 1] != cur) start[cur] = (u32)gid;
+    if (gid + 1 == total || sorted_keys[gid + 1] != cur) stop[cur] = (u32)(gid + 1);
 }
 
 // A bucket with more than HEAVY points is not walked by one lane: skewed scalars (many equal digits) and the top window (254 mod c
@@ -221,17 +218,17 @@ __global__ void msm_starts_kernel(u32* __restrict__ start, const u32* __restrict
 constexpr u32 HEAVY = 256;
 constexpr u32 SEG = 4096;
 // cnt[key] = points of the bucket, capped (the sort key that puts buckets of like size into the same wavefront)
-__global__ void msm_counts_kernel(u32* __restrict__ cnt, u32* __restrict__ ids, const u32* __restrict__ start, const u32 nkeys, const u32 c)
+__global__ void msm_counts_kernel(u32* __restrict__ cnt, u32* __restrict__ ids, const u32* __restrict__ start, const u32* __restrict__ stop, const u32 nkeys, const u32 c)
 {
     const u32 key = blockIdx.x * blockDim.x + threadIdx.x;
     if (key >= nkeys) return;
-    const u32 n = (key & ((1u << c) - 1)) != 0 ? start[key + 1] - start[key] : 0;
+    const u32 n = (key & ((1u << c) - 1)) != 0 ? stop[key] - start[key] : 0;
     cnt[key] = n < 511 ? n : 511;
     ids[key] = key;
 }
 // One lane per bucket, the buckets taken in order of their size (`order`): the 64 lanes of a wavefront walk runs of (nearly) the same length.
 // In bucket order a wavefront waits for its longest run -- Poisson(16) sizes: 16 of 27 lane-steps useful (round 4: 109 -> 70 ms at 9 x 2^22 points).
-__global__ __launch_bounds__(64) void msm_buckets_kernel(Jac* __restrict__ buckets, const u32* __restrict__ start, const u32* __restrict__ sorted_vals,
+__global__ __launch_bounds__(64) void msm_buckets_kernel(Jac* __restrict__ buckets, const u32* __restrict__ start, const u32* __restrict__ stop, const u32* __restrict__ sorted_vals,
                                                           const Aff* __restrict__ bases, const u32 nkeys, const u32 c, u32* __restrict__ heavy, u32* __restrict__ hb, u32* __restrict__ hs,
                                                           const u32* __restrict__ order)
 {
@@ -240,7 +237,7 @@ __global__ __launch_bounds__(64) void msm_buckets_kernel(Jac* __restrict__ bucke
     const u32 key = order[gid];
     Jac acc = jzero();
     if ((key & ((1u << c) - 1)) != 0) {
-        const u32 b = start[key], e = start[key + 1];
+        const u32 b = start[key], e = stop[key];
         if (e - b > HEAVY) {
             const u32 nseg = (e - b + SEG - 1) / SEG;
             const u32 first = atomicAdd(&heavy[0], nseg), i = atomicAdd(&heavy[1], 1u);
@@ -264,14 +261,14 @@ __device__ __forceinline__ Jac block_sum_256(Jac acc, Jac* sh, const u32 t)
     __syncthreads();
     return r;
 }
-__global__ __launch_bounds__(256) void msm_heavy_kernel(Jac* __restrict__ part, const u32* __restrict__ start, const u32* __restrict__ sorted_vals,
+__global__ __launch_bounds__(256) void msm_heavy_kernel(Jac* __restrict__ part, const u32* __restrict__ start, const u32* __restrict__ stop, const u32* __restrict__ sorted_vals,
                                                          const Aff* __restrict__ bases, const u32* __restrict__ heavy, const u32* __restrict__ hs)
 {
     __shared__ Jac sh[256];
     const u32 t = threadIdx.x;
     for (u32 e_ = blockIdx.x; e_ < heavy[0]; e_ += gridDim.x) {
         const u32 key = hs[2 * e_], seg = hs[2 * e_ + 1];
-        const u32 b = start[key] + seg * SEG, lim = start[key + 1], e = b + SEG < lim ? b + SEG : lim;
+        const u32 b = start[key] + seg * SEG, lim = stop[key], e = b + SEG < lim ? b + SEG : lim;
         Jac acc = jzero();
         for (u32 k = b + t; k < e; k += 256) acc = jmadd(acc, bases[sorted_vals[k]]);
         const Jac r = block_sum_256(acc, sh, t);
@@ -385,7 +382,7 @@ int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, nul, nul, nul, nul, (int)total, 0, 32, ctx->stream);
     const size_t nheavy_max = total / HEAVY + 2;                    // heavy buckets at most
     const size_t nseg_max = total / SEG + nheavy_max + 2;            // their segments at most
-    const size_t words32 = 4 * total + (nkeys + 2) + 2 + 3 * nheavy_max + 2 * nseg_max + 4 * (size_t)nkeys;
+    const size_t words32 = 4 * total + 2 * ((size_t)nkeys + 2) + 2 + 3 * nheavy_max + 2 * nseg_max + 4 * (size_t)nkeys;
     const size_t jac_count = (size_t)nkeys + (size_t)nwin * gpw + nwin + nseg_max;
     const size_t bytes = ((words32 * 4 + 255) / 256) * 256 + jac_count * sizeof(Jac) + temp_bytes + 256;
     u64* scratch = nullptr;
@@ -395,7 +392,8 @@ int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 
     u32* keys2 = vals + total;
     u32* vals2 = keys2 + total;
     u32* start = vals2 + total;
-    u32* heavy = start + (nkeys + 2);
+    u32* stop = start + (nkeys + 2);
+    u32* heavy = stop + (nkeys + 2);
     u32* hb = heavy + 2;
     u32* hs = hb + 3 * nheavy_max;
     u32* ord = hs + 2 * nseg_max;                                     // bucket sizes / ids, in and out of their sort
@@ -409,11 +407,12 @@ int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 
     u32 key_bits = 0;
     while ((1ull << key_bits) < nkeys) key_bits++;
     XLP_HIP(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys2, vals, vals2, (int)total, 0, (int)key_bits, ctx->stream));
-    hipLaunchKernelGGL(msm_starts_kernel, dim3((unsigned)(((total + 8) / 8 + T - 1) / T)), dim3(T), 0, ctx->stream, start, keys2, total, nkeys);
+    XLP_HIP(hipMemsetAsync(start, 0, 2 * ((size_t)nkeys + 2) * sizeof(u32), ctx->stream));
+    hipLaunchKernelGGL(msm_starts_kernel, dim3((unsigned)((total + T - 1) / T)), dim3(T), 0, ctx->stream, start, stop, keys2, total);
     XLP_HIP(hipMemsetAsync(heavy, 0, 2 * sizeof(u32), ctx->stream));
     // buckets by size
     u32 *cnt = ord, *ids = ord + nkeys, *cnt2 = ord + 2 * (size_t)nkeys, *ids2 = ord + 3 * (size_t)nkeys;
-    hipLaunchKernelGGL(msm_counts_kernel, dim3((nkeys + T - 1) / T), dim3(T), 0, ctx->stream, cnt, ids, start, nkeys, c);
+    hipLaunchKernelGGL(msm_counts_kernel, dim3((nkeys + T - 1) / T), dim3(T), 0, ctx->stream, cnt, ids, start, stop, nkeys, c);
     size_t tb = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, nul, nul, nul, nul, (int)nkeys, 0, 9, ctx->stream);
     const u32* order = ids;
@@ -421,8 +420,8 @@ int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 
         XLP_HIP(hipcub::DeviceRadixSort::SortPairs(temp, tb, cnt, cnt2, ids, ids2, (int)nkeys, 0, 9, ctx->stream));
         order = ids2;
     }
-    hipLaunchKernelGGL(msm_buckets_kernel, dim3((nkeys + 63) / 64), dim3(64), 0, ctx->stream, buckets, start, vals2, (const Aff*)bases, nkeys, c, heavy, hb, hs, order);
-    hipLaunchKernelGGL(msm_heavy_kernel, dim3((unsigned)(nseg_max < 4096 ? nseg_max : 4096)), dim3(256), 0, ctx->stream, part, start, vals2, (const Aff*)bases, heavy, hs);
+    hipLaunchKernelGGL(msm_buckets_kernel, dim3((nkeys + 63) / 64), dim3(64), 0, ctx->stream, buckets, start, stop, vals2, (const Aff*)bases, nkeys, c, heavy, hb, hs, order);
+    hipLaunchKernelGGL(msm_heavy_kernel, dim3((unsigned)(nseg_max < 4096 ? nseg_max : 4096)), dim3(256), 0, ctx->stream, part, start, stop, vals2, (const Aff*)bases, heavy, hs);
     hipLaunchKernelGGL(msm_heavy_fold_kernel, dim3((unsigned)(nheavy_max < 1024 ? nheavy_max : 1024)), dim3(256), 0, ctx->stream, buckets, part, heavy, hb);
     hipLaunchKernelGGL(msm_groups_kernel, dim3((nwin * gpw + 63) / 64), dim3(64), 0, ctx->stream, groups, buckets, nwin, c);
     hipLaunchKernelGGL(msm_window_sums_kernel, dim3(nwin), dim3(256), 0, ctx->stream, wsum, groups, nwin, gpw);
