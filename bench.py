@@ -29,8 +29,9 @@ LDE_KERNELS = ["xlp::lde_top_dif<11>", "xlp::lde_mid", "xlp::lde_top_dit<11>"]  
 
 
 def cpu_baseline(log_n, ncols, budget_s=20.0):
-    """Oracle (restated CPU path) timed on this host, bounded sample, EVERY host core: orc_extend_pol_team puts the whole OpenMP team on
-    one column at a time (the butterflies of a stage are independent), so an 8-column trace uses all 128 cores of the GPU box."""
+    """Oracle (restated CPU path) timed on this host, bounded sample, EVERY host core: orc_extend_pol_team puts the whole OpenMP team on all
+    columns together (the first 16 stages of a transform inside 2^16-point blocks, the rest stage by stage: butterflies of a stage are
+    independent), so an 8-column trace uses all 128 cores of the GPU box."""
     from oracle import gl_oracle as orc
     threads = orc.num_threads()
     # pick a sample size whose run time is ~10-30 s: calibrate on 2^16
@@ -50,7 +51,7 @@ def cpu_baseline(log_n, ncols, budget_s=20.0):
     t = time.perf_counter() - t0
     out = {
         "value": (n << EXT_BITS) * ncols / t / 1e9, "unit": "GFE/s", "cores": threads, "kind": "port",
-        "sample": f"oracle extendPol 2^{lg} x {ncols} -> 2^{lg + EXT_BITS} x {ncols} ({t:.2f} s, OpenMP team of {threads} threads on one column at a time, "
+        "sample": f"oracle extendPol 2^{lg} x {ncols} -> 2^{lg + EXT_BITS} x {ncols} ({t:.2f} s, OpenMP team of {threads} threads on all columns together, blocked stages, "
                   f"scalar u128 arithmetic; restated CPU path, not the reference's AVX2 binary)",
     }
     # the other two legs of the path on the same host cores (bounded samples): the Merkle leaf sponge + tree, and one small complete genProof
