@@ -36,6 +36,23 @@ def test_keccak256_against_hashlib_and_known_answers():
     assert F.keccak256(b"The quick brown fox jumps over the lazy dog").hex() == "4d741b6f1eb29cb2a9b9911c82f56fa8d73b04959d3d9d222895df6c0b28aa15"
 
 
+def test_host_keccak_and_challenge_equal_the_oracles():
+    """host/fflonk_prover.hpp without a GPU: keccak256() and the challenge derivation of Keccak256Transcript (digest as a big-endian integer
+    mod r through the Montgomery product, back to bytes, a field inversion) against the oracle, on one- and many-block messages"""
+    from oracle import fflonk_oracle as F
+    if not os.path.exists(EXE):
+        pytest.skip("host/test_host_shim not built")
+    for n in (0, 1, 64, 135, 136, 137, 300):
+        msg = bytes((11 * i + 3 * n) & 255 for i in range(n))
+        r = subprocess.run([EXE, "keccak", msg.hex()], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr[-500:]
+        j = json.loads(r.stdout)
+        d = F.keccak256(msg)
+        ch = int.from_bytes(d, "big") % F.P
+        assert j["keccak256"] == d.hex() and j["challenge"] == str(ch) and j["challenge_be"] == ch.to_bytes(32, "big").hex(), n
+        assert j["inverse_times_value"] == ("1" if ch else "0")
+
+
 @pytest.mark.parametrize("power,npub,nadd,seed", [(4, 1, 0, 3), (5, 2, 3, 7), (6, 1, 5, 11)])
 def test_oracle_proof_passes_the_verification_equation_and_tampering_does_not(power, npub, nadd, seed):
     from oracle import fflonk_oracle as F

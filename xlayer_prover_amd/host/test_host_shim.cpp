@@ -347,6 +347,25 @@ int main(int argc, char** argv)
         xlp_shutdown();
         return 0;
     }
+    // keccak <hex>: host only -- Keccak-256 of the bytes and the challenge Keccak256Transcript::getChallenge would derive from them
+    if (argc == 3 && std::string(argv[1]) == "keccak") {
+        const std::string hex = argv[2];
+        std::vector<uint8_t> data;
+        for (size_t i = 0; i + 1 < hex.size(); i += 2) data.push_back((uint8_t)strtoul(hex.substr(i, 2).c_str(), NULL, 16));
+        uint8_t h[32];
+        keccak256(data.data(), data.size(), h);
+        std::string hs;
+        char b[3];
+        for (int i = 0; i < 32; i++) { snprintf(b, sizeof b, "%02x", h[i]); hs += b; }
+        const FrElement ch = FrH::fromRprBE(h);
+        uint8_t back[32];
+        FrH::toRprBE(ch, back);
+        std::string bs;
+        for (int i = 0; i < 32; i++) { snprintf(b, sizeof b, "%02x", back[i]); bs += b; }
+        printf("{\"keccak256\":\"%s\",\"challenge\":\"%s\",\"challenge_be\":\"%s\",\"inverse_times_value\":\"%s\"}\n", hs.c_str(), FrH::toString(ch).c_str(), bs.c_str(),
+               FrH::toString(FrH::mul(ch, FrH::inv(ch))).c_str());
+        return 0;
+    }
     // fflonk_bench <power> [proofs]: the prover on a synthetic key of 2^power rows built in memory (host/fflonk_bench_key.hpp): per-round seconds
     if ((argc == 3 || argc == 4) && std::string(argv[1]) == "fflonk_bench") {
         const uint32_t power = (uint32_t)atoi(argv[2]);
