@@ -359,6 +359,14 @@ private:
             o += st.next * st.cols;
         }
     }
+    // band k of a W-column section cut into nb bands = the columns [lo(k), lo(k + 1)), boundaries on multiples of 8 (the leaf sponge takes a
+    // section band by band, eight columns per permutation); rank r extends the r-th share [a, b) of the band
+    void bandSpan(uint64_t W, uint64_t nb, uint64_t k, int r, uint64_t& a, uint64_t& b) const
+    {
+        auto lo = [&](uint64_t j) { return j >= nb ? W : (W * j / nb) & ~7ULL; };
+        const uint64_t c0 = lo(k), w = lo(k + 1) - c0;
+        a = c0 + w * (uint64_t)r / (uint64_t)world; b = c0 + w * ((uint64_t)r + 1) / (uint64_t)world;
+    }
     // how the sharded commit of a W-column section is cut into column bands (see commitSharded): number of bands, and per band the most
     // columns all ranks together / one rank can hold; -> words of ONE of the two staging sets it needs
     uint64_t commitBandPlan(uint64_t W, uint64_t& nb, uint64_t& bandTotalMax, uint64_t& wcbMax, uint64_t minBands = 1) const
@@ -377,8 +385,7 @@ private:
         for (uint64_t k = 0; k < nb; k++) {
             uint64_t tot = 0;
             for (int p_ = 0; p_ < world; p_++) {
-                uint64_t c0, c1; colSpan(W, p_, c0, c1);
-                const uint64_t a = c0 + (c1 - c0) * k / nb, b = c0 + (c1 - c0) * (k + 1) / nb;
+                uint64_t a, b; bandSpan(W, nb, k, p_, a, b);
                 tot += b - a; if (b - a > wcbMax) wcbMax = b - a;
             }
             if (tot > bandTotalMax) bandTotalMax = tot;
@@ -410,10 +417,7 @@ private:
         if (W) {
             uint64_t nb, bandTotalMax, wcbMax;
             const uint64_t setWords = commitBandPlan(W, nb, bandTotalMax, wcbMax, h_src ? 4 : 1);
-            auto band = [&](int r, uint64_t k, uint64_t& a, uint64_t& b) {
-                uint64_t c0, c1; colSpan(W, r, c0, c1);
-                a = c0 + (c1 - c0) * k / nb; b = c0 + (c1 - c0) * (k + 1) / nb;
-            };
+            auto band = [&](int r, uint64_t k, uint64_t& a, uint64_t& b) { bandSpan(W, nb, k, r, a, b); };
             auto widest = [&](uint64_t k) { uint64_t m = 0; for (int p_ = 0; p_ < world; p_++) { uint64_t a, b; band(p_, k, a, b); if (b - a > m) m = b - a; } return m; };
             uint64_t* base = shardScratch(2 * setWords);
             struct Set { uint64_t *pack, *arrv, *colb, *extb, *send, *rowb; } S[2];
@@ -480,6 +484,18 @@ private:
                 }
                 XLP_CHECK(xlp_stream_mark(1, M_BACK + (int)(k & 1)));
             };
+            // the leaf sponge of my rows takes band k (whole blocks of 8 columns, in column order) once it has come back: on stream 0, after the mark of
+            // back(k) -- between the extendPol of later bands, beside their exchanges (until round 4: the whole sponge after the last exchange)
+            const bool sponge = W > 8;
+            uint64_t firstBand = nb, lastBand = 0;
+            for (uint64_t k = 0; k < nb; k++) { uint64_t a0, b0, a1, b1; band(0, k, a0, b0); band(world - 1, k, a1, b1); if (b1 > a0) { if (firstBand == nb) firstBand = k; lastBand = k; } }
+            auto absorb = [&](uint64_t k) {
+                if (!sponge) return;
+                uint64_t a0, b0, a1, b1; band(0, k, a0, b0); band(world - 1, k, a1, b1);
+                if (b1 <= a0) return;
+                XLP_CHECK(xlp_stream_wait_mark(0, M_BACK + (int)(k & 1)));
+                tree->absorbBand(a0, b1 - a0, k == firstBand, k == lastBand);
+            };
             XLP_CHECK(xlp_stream_wait(1, 0));
             XLP_CHECK(xlp_stream_select(1));
             if (h_src) { XLP_CHECK(xlp_dev_upload_begin()); upload(0); }
@@ -491,12 +507,15 @@ private:
                 if (k >= 2) XLP_CHECK(xlp_stream_wait_mark(0, M_BACK + (int)(k & 1)));
                 if (mb > ma) XLP_CHECK(xlp_dev_extend_cm(S[k & 1].extb, NExtended, 0, S[k & 1].colb, N, NExtended, N, mb - ma));
                 XLP_CHECK(xlp_stream_mark(0, M_EXT + (int)(k & 1)));
+                if (k >= 1) absorb(k - 1);                                   // band k - 1 is back in my rows: its leaf sponge behind band k's extendPol
                 XLP_CHECK(xlp_stream_select(1));
                 if (k + 1 < nb) front(k + 1);
                 back(k);
             }
             XLP_CHECK(xlp_stream_select(0));
+            absorb(nb - 1);
             XLP_CHECK(xlp_stream_wait(0, 1));
+            if (sponge) { tree->finishFromLeaves(); fillHalo(s2); return; }
         }
         tree->merkelize();
         fillHalo(s2);
@@ -510,10 +529,7 @@ private:
             uint64_t nb, bandTotalMax, wcbMax;
             const uint64_t setWords = commitBandPlan(W, nb, bandTotalMax, wcbMax, h_src ? 4 : 1);
             // band k of a rank's span [a, b): [a + (b - a) k / nb, a + (b - a) (k + 1) / nb)
-            auto band = [&](int r, uint64_t k, uint64_t& a, uint64_t& b) {
-                uint64_t c0, c1; colSpan(W, r, c0, c1);
-                a = c0 + (c1 - c0) * k / nb; b = c0 + (c1 - c0) * (k + 1) / nb;
-            };
+            auto band = [&](int r, uint64_t k, uint64_t& a, uint64_t& b) { bandSpan(W, nb, k, r, a, b); };
             auto widest = [&](uint64_t k) { uint64_t m = 0; for (int p_ = 0; p_ < world; p_++) { uint64_t a, b; band(p_, k, a, b); if (b - a > m) m = b - a; } return m; };
             uint64_t* base = shardScratch(2 * setWords);
             struct Set { uint64_t *pack, *colb, *extb, *rowb; } S[2];
@@ -573,6 +589,18 @@ private:
                 }
                 XLP_CHECK(xlp_stream_mark(1, M_BACK + (int)(k & 1)));
             };
+            // the leaf sponge of my rows takes band k (whole blocks of 8 columns, in column order) once it has come back: on stream 0, after the mark of
+            // back(k) -- between the extendPol of later bands, beside their exchanges (until round 4: the whole sponge after the last exchange)
+            const bool sponge = W > 8;
+            uint64_t firstBand = nb, lastBand = 0;
+            for (uint64_t k = 0; k < nb; k++) { uint64_t a0, b0, a1, b1; band(0, k, a0, b0); band(world - 1, k, a1, b1); if (b1 > a0) { if (firstBand == nb) firstBand = k; lastBand = k; } }
+            auto absorb = [&](uint64_t k) {
+                if (!sponge) return;
+                uint64_t a0, b0, a1, b1; band(0, k, a0, b0); band(world - 1, k, a1, b1);
+                if (b1 <= a0) return;
+                XLP_CHECK(xlp_stream_wait_mark(0, M_BACK + (int)(k & 1)));
+                tree->absorbBand(a0, b1 - a0, k == firstBand, k == lastBand);
+            };
             XLP_CHECK(xlp_stream_wait(1, 0));                             // the section is what stream 0 has made of it so far
             XLP_CHECK(xlp_stream_select(1));
             if (h_src) { XLP_CHECK(xlp_dev_upload_begin()); upload(0); }
@@ -584,12 +612,15 @@ private:
                 if (k >= 2) XLP_CHECK(xlp_stream_wait_mark(0, M_BACK + (int)(k & 1)));    // band k - 2's extended columns have left this set
                 if (mb > ma) XLP_CHECK(xlp_dev_extend(S[k & 1].extb, S[k & 1].colb, NExtended, N, mb - ma, NULL));
                 XLP_CHECK(xlp_stream_mark(0, M_EXT + (int)(k & 1)));
+                if (k >= 1) absorb(k - 1);
                 XLP_CHECK(xlp_stream_select(1));
                 if (k + 1 < nb) front(k + 1);
                 back(k);
             }
             XLP_CHECK(xlp_stream_select(0));
+            absorb(nb - 1);
             XLP_CHECK(xlp_stream_wait(0, 1));
+            if (sponge) { tree->finishFromLeaves(); fillHalo(s2); return; }
         }
         tree->merkelize();                                    // my sub-tree + the cap
         fillHalo(s2);

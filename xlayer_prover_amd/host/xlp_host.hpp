@@ -248,6 +248,15 @@ public:
             capLevels.push_back(nxt);
         }
     }
+    // row-sharded commits absorb the section band by band behind the exchanges (host/starks.hpp commitSharded): the leaf sponge of my rows
+    // over the columns [col0, col0 + ncols) of d_source, then -- after the last band -- the levels of my sub-tree and the cap
+    void absorbBand(uint64_t col0, uint64_t ncols, bool first, bool last)
+    {
+        if (!d_nodes || !shardWorld) xlp_exit_process("MerkleTreeGL::absorbBand: a sharded device tree only");
+        if (colMajor) XLP_CHECK(xlp_dev_linear_hash_absorb_cm(d_nodes, d_source, cmStride, cmCos, col0, ncols, localHeight(), cmExtBits, first ? 1 : 0, last ? 1 : 0));
+        else XLP_CHECK(xlp_dev_linear_hash_absorb(d_nodes, d_source, width, col0, ncols, localHeight(), first ? 1 : 0, last ? 1 : 0));
+    }
+    void finishFromLeaves() { XLP_CHECK(xlp_dev_merkle_levels(d_nodes, localHeight())); assembleCap(); }
     MerkleTreeGL() : height(0), width(0), source(NULL), nodes(NULL) {}
     // file-backed layout [width, height, source(height*width), nodes] (build_const_tree.cpp:566-603)
     MerkleTreeGL(Goldilocks::Element* tree)
