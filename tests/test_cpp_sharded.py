@@ -153,7 +153,8 @@ def test_genbatchproof_with_the_zkevm_stark_sharded_equals_one_gpu(tmp_path, col
 
 
 @pytest.mark.gpu
-def test_genbatchproof_two_ranks_at_2p18_with_the_default_staging_budget(tmp_path):
+@pytest.mark.parametrize("ln,colmajor", [(18, False), (20, True)])
+def test_genbatchproof_two_ranks_at_2p18_with_the_default_staging_budget(tmp_path, ln, colmajor):
     """the multi-rank product path at a size where the exchanges are hundreds of MB (2^18 rows: 0.8 GB of witness per rank, sections
     of 751 / 168 / 408 columns), through host/zkprover_batch with the DEFAULT staging budget and message size, ranks sharing the box's GPU (shm).
     Rank 0's line must name 2 ranks seen by the transport, the same zkEVM proof on both ranks, per-stage exchange volumes -- and the batch proof
@@ -174,13 +175,13 @@ def test_genbatchproof_two_ranks_at_2p18_with_the_default_staging_budget(tmp_pat
         f = tmp_path / name
         f.write_text(json.dumps(cfg))
         return str(f)
-    ln = 18
+    # (2^20 rows on COLUMN-MAJOR windows: 3.1 GB per rank through the exchanges of step 1, regrouped runs, the band-wise leaf sponge)
     one = config("one.json", B.make("zkevm", ln, False, out=str(tmp_path / "zk1")))
     r = subprocess.run([exe, "-c", one, "--proofs", "1"], capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
     expect = json.loads(r.stdout.strip().splitlines()[-1])
-    two = config("two.json", B.make("zkevm", ln, False, out=str(tmp_path / "zk2"), world=2))
-    name = f"xlp_test_bp18_{os.getpid()}"
+    two = config("two.json", B.make("zkevm", ln, False, out=str(tmp_path / "zk2"), world=2, colmajor=colmajor))
+    name = f"xlp_test_bp{ln}_{os.getpid()}"
     procs = [subprocess.Popen([exe, "-c", two, "--proofs", "1", "--timers", "--world", "2", "--rank", str(k), "--backend", "shm", "--rendezvous", name],
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in range(2)]
     outs = []
