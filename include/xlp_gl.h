@@ -524,6 +524,10 @@ int xlp_dev_free(void* ptr);
 /* Give back grow-only scratch of the context (bit k of mask = slot k; 0xFF = all): for a stage that grew much of it and shares the card with
  * others -- the fflonk prover releases its transform / scan / multi-exponentiation scratch (slots 3, 4, 5, 7) after a final proof. */
 int xlp_scratch_release(uint32_t mask);
+/* Let a scratch slot use a caller-owned DEVICE region instead of growing its own (dev_ptr = NULL takes it back); a request the region cannot
+ * hold falls through to the slot's own scratch.  The fflonk prover in reserved-memory mode lends the rest of its region to the transform /
+ * scan / multi-exponentiation slots for the duration of a proof (no allocation inside the proof, nothing left behind). */
+int xlp_scratch_lend(uint32_t slot, void* dev_ptr, size_t bytes);
 int xlp_dev_memset(void* dst_dev, int value, size_t bytes);          /* asynchronous on the context's stream */
 int xlp_copy_h2d(void* dst_dev, const void* src_host, size_t bytes);
 int xlp_copy_d2h(void* dst_host, const void* src_dev, size_t bytes);

@@ -44,6 +44,7 @@ int xlp_fail_hip(hipError_t e, const char* file, int line)
 
 int ctx_scratch(Ctx* ctx, size_t bytes, int slot, u64** out)
 {
+    if (ctx->lent[slot] && ctx->lent_bytes[slot] >= bytes) { *out = (u64*)ctx->lent[slot]; return 0; }     // a lent region that is large enough serves
     if (ctx->scratch_bytes[slot] < bytes) {
         if (ctx->scratch[slot]) {
             XLP_HIP(hipStreamSynchronize(ctx->stream));
@@ -163,6 +164,18 @@ extern "C" {
 
 // xlp_scratch_release: give grow-only scratch slots back (bit k of mask = slot k): a prover that shares the card with others releases what its
 // last stage grew (the fflonk commitments: 11 GB of sort / bucket scratch at 9 x 2^22 points) instead of holding it for the process' life
+// xlp_scratch_lend: let slot `slot` use a caller-owned device region instead of growing its own (ptr = NULL: take it back).  A request the
+// region cannot hold falls through to the slot's own scratch.  The caller keeps the region alive and unused until it takes it back.
+int xlp_scratch_lend(uint32_t slot, void* dev_ptr, size_t bytes)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if (slot >= 8) return xlp_fail("xlp_scratch_lend: slot 0..7");
+    XLP_HIP(hipStreamSynchronize(g_ctx.stream));
+    g_ctx.lent[slot] = dev_ptr;
+    g_ctx.lent_bytes[slot] = dev_ptr ? bytes : 0;
+    return 0;
+}
 int xlp_scratch_release(uint32_t mask)
 {
     XLP_ENTER;

@@ -51,6 +51,8 @@ struct Ctx {
     std::map<std::tuple<u32, u64, u64>, u64*> tables;  // (L, root, mult) -> device power tables
     void* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void* lent[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // caller-owned regions standing in for a slot (xlp_scratch_lend)
+    size_t lent_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool inited = false;
     u32 ncu = 256;             // compute units of the bound device (persistent-kernel grid size)
     // optional per-kernel timing of the LDE fast path (xlp_profile_*): HIP events on ctx->stream
