@@ -39,6 +39,7 @@ def main():
                     "(tools/zkevm_geometry.py layout_window) -> zkevm.<step>.geo<N>w<G>.so")
     ap.add_argument("--colmajor", action="store_true", help="with --geometry: column-major device sections (tools/zkevm_geometry.py to_colmajor; XLP_EXPR_COLMAJOR) "
                     "-> zkevm.<step>.geo<N>[a]c.so")
+    ap.add_argument("--out-dir", default="", help="write the plugins (and their build directory) here instead of xlayer_prover_amd/chelpers (experiments)")
     a = ap.parse_args()
     sizes = ["full"] if a.full else [int(x) for x in a.log_rows.split(",")]
     geo = None
@@ -65,7 +66,7 @@ def main():
             lr = (24 if step.endswith("2ns") else 23) if size in ("full", "geo") else size
             src = os.path.join(R.REF_DIR, f"{a.circuit if geo else 'zkevm'}.{step.replace('_opt', '').replace('_tab', '')}.xlpexpr")
             name = f"{a.circuit}.{step}.geo{a.geometry}{'a' if a.aliased else ''}{f'w{a.world}' if a.world else ''}{'c' if a.colmajor else ''}" if geo else f"zkevm.{step}.n{lr}"
-            so = os.path.join(R.REF_DIR, name + ".so")
+            so = os.path.join(a.out_dir or R.REF_DIR, name + ".so")
             if not os.path.exists(src):
                 print("missing", src); continue
             code, ntmp1, ntmp3 = R.read_program(src)
@@ -80,7 +81,7 @@ def main():
             p = capi.ExprProgram(code, ntmp1, ntmp3, colmajor=bool(geo) and a.colmajor and not step.endswith("_tab"))
             # regenerate the launcher text (cheap) and rebuild only if it changed: its signature covers the whole
             # compiled program, so a change of the library's compile step invalidates the plugin too
-            build = os.path.join(R.REF_DIR, "build")
+            build = os.path.join(a.out_dir or R.REF_DIR, "build")
             os.makedirs(build, exist_ok=True)
             probe = os.path.join(build, name + ".probe.hip")
             p.codegen(probe)

@@ -45,7 +45,7 @@ def bundle_dir(circ, log_n, aliased, world=0, colmajor=False):
     return os.path.join(R.REF_DIR, "bundles", f"{circ}.{geo_tag(log_n, aliased, world, colmajor)}")
 
 
-def make(circ, log_n, aliased, out=None, fri_steps=None, queries=None, use_opt=True, use_dots=True, world=0, colmajor=False):
+def make(circ, log_n, aliased, out=None, fri_steps=None, queries=None, use_opt=True, use_dots=True, world=0, colmajor=False, plugin_dir=None):
     """world > 0: the bundle of ONE RANK of a proof row-sharded over `world` ranks (every rank uses the same files): window starkinfo,
     programs relocated to the window slab (tools/zkevm_geometry.py layout_window), and per step the next-row stores whose halo rows go
     back to their owner.
@@ -69,7 +69,7 @@ def make(circ, log_n, aliased, out=None, fri_steps=None, queries=None, use_opt=T
     rel = lambda p: os.path.relpath(p, out)
 
     def plugin(name):
-        so = os.path.join(R.REF_DIR, name)
+        so = os.path.join(plugin_dir or R.REF_DIR, name)
         return rel(so) if os.path.exists(so) else None
     for st, (code, n1, n3) in progs.items():
         write_prog(os.path.join(out, f"{circ}.{st}.xlpexpr"), cm(code), n1, n3)

@@ -894,7 +894,9 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
     char buf[256];
     for (size_t sg = 0; sg < nseg; sg++) {
         std::ostringstream os;
-        os << "extern \"C\" __global__ __launch_bounds__(256) void seg_" << sg << "(XlpJitArgs A)\n{\n"
+        // XLP_EXPR_MIN_WAVES (experiment; read when the text is generated): a floor on the waves per SIMD = a ceiling on the registers of a segment
+        const int minWaves = env_int("XLP_EXPR_MIN_WAVES", 0);
+        os << "extern \"C\" __global__ __launch_bounds__(256" << (minWaves > 0 ? ", " + std::to_string(minWaves) : std::string()) << ") void seg_" << sg << "(XlpJitArgs A)\n{\n"
               "    const u64 gt = (u64)blockIdx.x * 256 + threadIdx.x;\n    if (gt >= A.nrows) return;\n    const u64 row = A.row0 + gt;\n"
               "    u64* __restrict__ T = A.tmp + gt; const u64 TS = A.tstride;\n"
               "    const u64* __restrict__ C = A.cols + gt; u64* __restrict__ CW = A.cols + gt; const u64 CAP = A.cap;\n"
