@@ -97,3 +97,38 @@ def test_genbatchproof_colmajor_equals_rowmajor(tmp_path):
         assert v["batch_proof_fnv"] == ref["batch_proof_fnv"] and v["batch_proof_bytes"] == ref["batch_proof_bytes"], k
     t = outs[(True, False)]["timers_s"]
     assert "zkevm.STARK_STEP_1_LDE" in t and "zkevm.STARK_STEP_1_MERKLETREE" in t
+
+
+@pytest.mark.gpu
+def test_commit_file_round_trip_through_the_prover(tmp_path):
+    """config.zkevmCmPolsAfterExecutor (prover.cpp:452-457): the executor's output is written as the reference's zkevm.commit (row-major,
+    pilDegree x nCommitted words); fed back with --witness-file in place of the executor it gives the same batch proof"""
+    from tools import make_stark_bundle as B
+    if not _programs_built():
+        pytest.skip("converted reference programs not built (needs the reference tree at build time)")
+    exe = os.path.join(ROOT, "xlayer_prover_amd", "host", "zkprover_batch")
+    bundles = {"zkevm": B.make("zkevm", 12, True, out=str(tmp_path / "zk"), colmajor=True), "c12a": B.make("c12a", 20, False, out=str(tmp_path / "c12a"), colmajor=True),
+               "recursive1": B.make("recursive1", 17, False, out=str(tmp_path / "r1"), colmajor=True)}
+    commit = str(tmp_path / "zkevm.commit")
+
+    def config(name, dump):
+        cfg = {"runFileGenBatchProof": True, "saveOutputToFile": False, "saveProofToFile": False, "outputPath": str(tmp_path), "xlpSyntheticLookups": True}
+        if dump:
+            cfg["zkevmCmPolsAfterExecutor"] = commit
+        for n, b in bundles.items():
+            cfg[n + "StarkInfo"] = os.path.join(b, f"{n}.starkinfo.json")
+            cfg[n + "ConstPols"] = f"synthetic:{CSEED + len(n)}"
+            cfg[n + "ConstantsTree"] = ""
+            cfg[n + "Verkey"] = ""
+        f = tmp_path / name
+        f.write_text(json.dumps(cfg))
+        return str(f)
+    r = subprocess.run([exe, "-c", config("dump.json", True), "--proofs", "1"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    first = json.loads(r.stdout.strip().splitlines()[-1])
+    w = json.load(open(os.path.join(bundles["zkevm"], "zkevm.starkinfo.json")))["mapSectionsN"]["cm1_n"]
+    assert os.path.getsize(commit) == (1 << 12) * w * 8
+    r = subprocess.run([exe, "-c", config("read.json", False), "--proofs", "1", "--seed", "12345", "--witness-file", commit], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    again = json.loads(r.stdout.strip().splitlines()[-1])
+    assert again["batch_proof_fnv"] == first["batch_proof_fnv"] and again["batch_proof_bytes"] == first["batch_proof_bytes"]

@@ -167,6 +167,15 @@ public:
             req.firstRow = starkZkevm->firstRow();
             req.executor(cmPols, Nz, Wz);                    // executor.execute(*pProverRequest, cmPols), prover.cpp:435
         }
+        // prover.cpp:452-457: the committed polynomials as the executor left them -> zkevm.commit (row-major, pilDegree x nCommitted words);
+        // a row-sharded rank writes its rows at their offset of the same file
+        if (config.zkevmCmPolsAfterExecutor.size()) {
+            FILE* f = fopen(config.zkevmCmPolsAfterExecutor.c_str(), shardedZ && req.firstRow ? "r+b" : "wb");
+            if (!f && shardedZ) f = fopen(config.zkevmCmPolsAfterExecutor.c_str(), "wb");
+            if (!f || fseek(f, (long)(req.firstRow * Wz * sizeof(Goldilocks::Element)), SEEK_SET) || fwrite(cmPols, sizeof(Goldilocks::Element), Nz * Wz, f) != Nz * Wz)
+                xlp_exit_process(("Prover::genBatchProof: cannot write " + config.zkevmCmPolsAfterExecutor).c_str());
+            fclose(f);
+        }
         if (req.result != ZKR_SUCCESS) return;           // prover.cpp:437: the executor reports through the request
         // ---- publics (prover.cpp:494-559): first / last row of Main's registers; recursive2's verification key behind them
         const uint64_t nPublics = nPublicsBatch;              // recursive1's count (prover.cpp:494: the publics of the batch proof; known on every rank)

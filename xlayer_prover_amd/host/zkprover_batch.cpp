@@ -1,5 +1,5 @@
 // zkProver in file mode for a batch proof (src/main.cpp:83-112 runFileGenBatchProof -> Prover::genBatchProof) on the GPU build:
-//     zkprover_batch -c config.json [--proofs K] [--seed S] [--sequential-upload] [--timers] [--e2e [--final-wtns FILE]]
+//     zkprover_batch -c config.json [--proofs K] [--seed S] [--sequential-upload] [--timers] [--e2e [--final-wtns FILE]] [--witness-file zkevm.commit]
 //                    [--world G --rank r --backend rccl|shm --rendezvous <file | name> [--device d]]
 // --world: this process is rank r of G (one process per GPU): the transport is set up before any other GPU work, the zkEVM
 // STARK runs row-sharded (the config's zkevmStarkInfo must be the window bundle of that world, tools/make_stark_bundle.py --world G), rank 0
@@ -40,7 +40,7 @@ int main(int argc, char** argv)
     int proofs = 2;
     uint64_t seed = 0x5EED0401;
     bool sequential = false, timers = false, e2e = false;
-    std::string finalWtns;
+    std::string finalWtns, witnessFile;
     int world = 0, rank = 0, device = -1;
     std::string backend, rendezvous;
     for (int i = 1; i < argc; i++) {
@@ -52,6 +52,7 @@ int main(int argc, char** argv)
         else if (a == "--timers") timers = true;
         else if (a == "--e2e") e2e = true;
         else if (a == "--final-wtns" && i + 1 < argc) finalWtns = argv[++i];
+        else if (a == "--witness-file" && i + 1 < argc) witnessFile = argv[++i];
         else if (a == "--world" && i + 1 < argc) world = atoi(argv[++i]);
         else if (a == "--rank" && i + 1 < argc) rank = atoi(argv[++i]);
         else if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
@@ -84,6 +85,15 @@ int main(int argc, char** argv)
     ProverRequest req;
     req.filePrefix = config.outputPath + "/";
     req.executor = [&](Goldilocks::Element* p, uint64_t n, uint64_t w) { syntheticWitness(p, n, w, seed, req.firstRow); };
+    // --witness-file F: the executor's output comes from a zkevm.commit file (config.zkevmCmPolsAfterExecutor of an earlier run, or the
+    // reference's own dump: row-major, pilDegree x nCommitted words): a rank reads its rows
+    if (witnessFile.size())
+        req.executor = [&](Goldilocks::Element* p, uint64_t n, uint64_t w) {
+            FILE* f = fopen(witnessFile.c_str(), "rb");
+            if (!f || fseek(f, (long)(req.firstRow * w * sizeof(Goldilocks::Element)), SEEK_SET) || fread(p, sizeof(Goldilocks::Element), n * w, f) != n * w)
+                xlp_exit_process(("--witness-file: cannot read " + std::to_string(n) + " x " + std::to_string(w) + " words from " + witnessFile).c_str());
+            fclose(f);
+        };
     req.c12aWitness = [&](const std::string& zkin, Goldilocks::Element* p, uint64_t n, uint64_t w) { syntheticWitness(p, n, w, fnv1a(zkin)); };
     req.recursive1Witness = req.c12aWitness;
     req.recursive2Witness = req.c12aWitness;
