@@ -3,8 +3,10 @@
 // Montgomery limbs, the reference's RawFr::Element).  The transforms and the multi-exponentiations are xlp_dev_fft_bn254 / xlp_dev_msm_bn254
 // (bn128.hip, bn254_msm.hip); host/fflonk_prover.hpp strings the rounds together.
 //
-// All of it is HBM-bound integer work (32 bytes per element, tens of field products per element at most): one lane per element (or per
-// run of a recurrence), 32-byte vector loads, nothing staged.  The sequential recurrences of the reference -- Polynomial::divByZerofier
+// One lane per element (or per run of a recurrence), 32-byte vector loads, nothing staged.  A Montgomery product is ~350 vector
+// instructions, so the loops of the rounds (10-60 products per element) and the linear combinations run at the vector-issue rate of the
+// chip (580-630 G wave-instr/s measured, profiles/r4/fflonk_2p22_valu_instructions.txt), not at HBM's; the scans (2 products per element over
+// strided views) and the evaluation passes are the memory / latency-bound ones.  The sequential recurrences of the reference -- Polynomial::divByZerofier
 // (one thread per residue class: a single thread when dividing by X - y), the running products of computeZ, fastEvaluate's Horner -- are
 // first-order linear recurrences and run as three-pass scans (runs of SCAN_K elements: local pass, scan of the run totals, fix-up).
 #include "xlp_internal.hpp"
