@@ -15,7 +15,7 @@ the key it was made with): the prover is "parity unpinned" against the reference
   * `setup()` builds a SYNTHETIC proving key for a random PLONK circuit in the byte format the reference reads (section by section; the setup
     itself is snarkjs' and not in the snapshot: C0 = QL, QR, QO, QM, QC, S1, S2, S3 interleaved by 8, the last two rows of the domain left out
     of the copy constraints because the prover blinds there, fflonk_prover.c.hpp:708-709) from a KNOWN tau;
-  * `verify()` is the fflonk verification equation (Gabizon-Williamson 2021, section 7; the batched opening check of the three combined
+  * `verify()` is the fflonk verification equation (the fflonk paper, Gabizon and Williamson 2021, as the prover's rounds imply it; the batched opening check of the three combined
     polynomials at the roots of xi) with the pairing replaced by the trapdoor:  e(A, [1]_2) = e(W2, [tau]_2)  <=>  A = tau * W2 in G1.
     A proof only passes if every round of the prover -- transcript, quotients, interpolations, openings -- is what the protocol says.
   * Keccak-256: the sponge with the NIST suffix equals hashlib.sha3_256 on one- and many-block messages (permutation, absorption and
@@ -636,7 +636,7 @@ def proof_to_json(proof, publics):
 
 # ------------------------------------------------------------------------------------------------ the verifier, with the trapdoor for the pairing
 def verify(z, tau, proof_json, publics_json):
-    """fflonk verification (paper section 7 / the Solidity verifier's steps) on the JSON proof: recompute the challenges, the values the three
+    """fflonk verification on the JSON proof, written from what the prover's rounds commit to (no verifier is in the reference snapshot): recompute the challenges, the values the three
     combined polynomials must take at the roots (from the claimed evaluations and the circuit identities), interpolate r0, r1, r2 at y and check
         [preL0] C0 + [preL1] C1 + [preL2] C2 - [preL0 r0(y) + preL1 r1(y) + preL2 r2(y)] G - [ZT(y)] W1  ==  [ZTS2(y) (tau - y)] W2
     (the pairing e(lhs, [1]_2) = e([ZTS2(y)] W2, [tau - y]_2) read in G1 through the known tau).  Also checks `inv`."""
