@@ -91,40 +91,44 @@ __global__ void batch_inverse_kernel(Fr* __restrict__ out, const Fr* __restrict_
     gst(&out[t], inv);
 }
 
-// ------------------------------------------------------------------------------------------------ first-order recurrences as scans
-// View: element p of a sequence lives at base[start + p * step] (step may be negative), p < count.
-//   LINREC:  s_p = beta * s_(p-1) + x_p         (division by X^m - beta from the top; Horner)
-//   PROD:    s_p = s_(p-1) * x_p                (running products)
+// ------------------------------------------------------------------------------------------------ recurrences of lag m as scans
+// View: element j of a sequence lives at base[start + j * step] (step may be negative), j < count.
+//   LINREC:  s_j = beta * s_(j-m) + x_j         (division by X^m - beta from the top: m interleaved Horner chains; m = 1: Horner)
+//   PROD:    s_j = s_(j-1) * x_j                (running products; m = 1)
+// A lane owns (run r, class c): the SCAN_K elements j = (r * SCAN_K + t) * m + c -- the m lanes of a run read neighbouring elements, so one pass
+// over the array serves all m chains (until round 4 every class was a scan of its own over the same cache lines).
 constexpr u64 SCAN_K = 128;
 template <bool PROD>
 __global__ void scan_local_kernel(Fr* __restrict__ out, const long long ostart, const long long ostep, const Fr* __restrict__ in, const long long istart, const long long istep,
-                                  const u64 count, Fr* __restrict__ totals, const Fr beta)
+                                  const u64 count, const u64 m, const u64 lanes, Fr* __restrict__ totals, const Fr beta)
 {
-    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u64 p0 = r * SCAN_K;
-    if (p0 >= count) return;
-    const u64 p1 = p0 + SCAN_K < count ? p0 + SCAN_K : count;
+    const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= lanes) return;
+    const u64 r = q / m, c = q % m;
     Fr s = PROD ? one() : zero();
-    for (u64 p = p0; p < p1; p++) {
-        const Fr x = gld(&in[istart + (long long)p * istep]);
+    for (u64 t = 0; t < SCAN_K; t++) {
+        const u64 j = (r * SCAN_K + t) * m + c;
+        if (j >= count) break;
+        const Fr x = gld(&in[istart + (long long)j * istep]);
         s = PROD ? mul(s, x) : add(mul(s, beta), x);
-        gst(&out[ostart + (long long)p * ostep], s);
+        gst(&out[ostart + (long long)j * ostep], s);
     }
-    gst(&totals[r], s);
+    gst(&totals[q], s);
 }
-// carry[r] = the true value at the end of run r - 1 (carry[0] = identity), from the scanned totals
+// lane (r, c), r >= 1: the true value at the end of (r - 1, c) enters its elements
 template <bool PROD>
-__global__ void scan_fix_kernel(Fr* __restrict__ out, const long long ostart, const long long ostep, const u64 count, const Fr* __restrict__ scanned, const Fr beta)
+__global__ void scan_fix_kernel(Fr* __restrict__ out, const long long ostart, const long long ostep, const u64 count, const u64 m, const u64 lanes, const Fr* __restrict__ scanned, const Fr beta)
 {
-    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u64 p0 = r * SCAN_K;
-    if (r == 0 || p0 >= count) return;
-    const u64 p1 = p0 + SCAN_K < count ? p0 + SCAN_K : count;
-    Fr c = gld(&scanned[r - 1]);
-    for (u64 p = p0; p < p1; p++) {
-        Fr* o = &out[ostart + (long long)p * ostep];
-        if (PROD) gst(o, mul(gld(o), c));
-        else { c = mul(c, beta); gst(o, add(gld(o), c)); }
+    const u64 q = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= lanes || q < m) return;
+    const u64 r = q / m, c = q % m;
+    Fr carry = gld(&scanned[q - m]);
+    for (u64 t = 0; t < SCAN_K; t++) {
+        const u64 j = (r * SCAN_K + t) * m + c;
+        if (j >= count) break;
+        Fr* o = &out[ostart + (long long)j * ostep];
+        if (PROD) gst(o, mul(gld(o), carry));
+        else { carry = mul(carry, beta); gst(o, add(gld(o), carry)); }
     }
 }
 
@@ -285,25 +289,21 @@ int dev_fr_batch_inverse(Ctx* ctx, u64* out, const u64* in, u64 n)
 }
 
 void fr_host_sqr(u64* a);
-// s_p over a view, the run totals scanned recursively in scratch (slot 4): totals of level l at tot + offset_l
+// the recurrence over a view; the lanes' totals obey the same recurrence (lag m, beta^K) and are scanned recursively in scratch (slot 4)
 template <bool PROD>
-static int scan_view(Ctx* ctx, Fr* out, long long ostart, long long ostep, const Fr* in, long long istart, long long istep, u64 count, const u64* beta_host, Fr* tot, u64 tot_cap)
+static int scan_view(Ctx* ctx, Fr* out, long long ostart, long long ostep, const Fr* in, long long istart, long long istep, u64 count, u64 m, const u64* beta_host, Fr* tot, u64 tot_cap)
 {
     if (!count) return 0;
-    const u64 runs = (count + ffr::SCAN_K - 1) / ffr::SCAN_K;
-    if (runs > tot_cap) return xlp_fail("fr scan: scratch too small");
+    const u64 runs = (count + ffr::SCAN_K * m - 1) / (ffr::SCAN_K * m), lanes = runs * m;
+    if (lanes > tot_cap) return xlp_fail("fr scan: scratch too small");
     const Fr beta = ffr::load_host(beta_host);
-    hipLaunchKernelGGL(ffr::scan_local_kernel<PROD>, dim3(ffr::blocks(runs)), dim3(ffr::TPB), 0, ctx->stream, out, ostart, ostep, in, istart, istep, count, tot, beta);
+    hipLaunchKernelGGL(ffr::scan_local_kernel<PROD>, dim3(ffr::blocks(lanes)), dim3(ffr::TPB), 0, ctx->stream, out, ostart, ostep, in, istart, istep, count, m, lanes, tot, beta);
     XLP_HIP(hipGetLastError());
     if (runs > 1) {
-        // the totals obey the same recurrence with beta^K: t'_r = beta^K t'_(r-1) + total_r (PROD: a running product of the totals)
         u64 bk[4] = {beta_host[0], beta_host[1], beta_host[2], beta_host[3]};
-        if (!PROD) {
-            // beta^K by repeated squaring on the host (K a power of two)
-            for (u64 k = ffr::SCAN_K; k > 1; k >>= 1) fr_host_sqr(bk);
-        }
-        if (scan_view<PROD>(ctx, tot, 0, 1, tot, 0, 1, runs, bk, tot + runs, tot_cap - runs)) return -1;
-        hipLaunchKernelGGL(ffr::scan_fix_kernel<PROD>, dim3(ffr::blocks(runs)), dim3(ffr::TPB), 0, ctx->stream, out, ostart, ostep, count, tot, beta);
+        if (!PROD) for (u64 k = ffr::SCAN_K; k > 1; k >>= 1) fr_host_sqr(bk);      // beta^K (K a power of two)
+        if (scan_view<PROD>(ctx, tot, 0, 1, tot, 0, 1, lanes, m, bk, tot + lanes, tot_cap - lanes)) return -1;
+        hipLaunchKernelGGL(ffr::scan_fix_kernel<PROD>, dim3(ffr::blocks(lanes)), dim3(ffr::TPB), 0, ctx->stream, out, ostart, ostep, count, m, lanes, tot, beta);
         XLP_HIP(hipGetLastError());
     }
     return 0;
@@ -331,11 +331,11 @@ void fr_host_sqr(u64* a)
     for (int i = 0; i < 4; i++) a[i] = t[i];
 }
 
-static int scan_scratch(Ctx* ctx, u64 count, Fr** tot, u64* cap)
+static int scan_scratch(Ctx* ctx, u64 count, u64 m, Fr** tot, u64* cap)
 {
     u64 need = 0;
-    for (u64 c = count; c > 1;) { c = (c + ffr::SCAN_K - 1) / ffr::SCAN_K; need += c; }
-    need += 8;
+    for (u64 c = count; c > m;) { c = ((c + ffr::SCAN_K * m - 1) / (ffr::SCAN_K * m)) * m; need += c; }
+    need += 8 + 2 * m;
     u64* p = nullptr;
     if (ctx_scratch(ctx, need * sizeof(Fr), 4, &p)) return -1;
     *tot = (Fr*)p; *cap = need;
@@ -347,12 +347,13 @@ int dev_fr_prefix_product(Ctx* ctx, u64* out, const u64* in, u64 n)
 {
     if (!n) return 0;
     Fr* tot; u64 cap;
-    if (scan_scratch(ctx, n, &tot, &cap)) return -1;
+    if (scan_scratch(ctx, n, 1, &tot, &cap)) return -1;
     const u64 unused[4] = {0, 0, 0, 0};
-    return scan_view<true>(ctx, (Fr*)out, 0, 1, (const Fr*)in, 0, 1, n, unused, tot, cap);
+    return scan_view<true>(ctx, (Fr*)out, 0, 1, (const Fr*)in, 0, 1, n, 1, unused, tot, cap);
 }
 // Polynomial::divByZerofier (polynomial.c.hpp:571-634): out = in / (X^m - beta) for a polynomial that IS divisible (len coefficients in,
-// len out, the top m zero).  From the top: q[k] = in[k + m] + beta q[k + m], one recurrence per residue class of k mod m.
+// len out, the top m zero).  From the top: q[k] = in[k + m] + beta q[k + m]; with j counting down from the top coefficient this is
+// s_j = beta s_(j-m) + x_j, x_j = in[len - 1 - j], q[len - m - 1 - j] = s_j.
 int dev_fr_div_xm_minus(Ctx* ctx, u64* out, const u64* in, u64 len, u32 m, const u64* beta)
 {
     if (!len) return 0;
@@ -361,15 +362,8 @@ int dev_fr_div_xm_minus(Ctx* ctx, u64* out, const u64* in, u64 len, u32 m, const
     if (len <= m) { XLP_HIP(hipMemsetAsync(out, 0, len * sizeof(Fr), ctx->stream)); return 0; }
     XLP_HIP(hipMemsetAsync((Fr*)out + (len - m), 0, (u64)m * sizeof(Fr), ctx->stream));
     Fr* tot; u64 cap;
-    if (scan_scratch(ctx, (len - m + m - 1) / m + 1, &tot, &cap)) return -1;
-    for (u32 c = 0; c < m; c++) {
-        // the k of this class, from the top: kmax = the largest k = c (mod m) with k + m <= len - 1
-        if (len - 1 < m + c) continue;
-        const u64 kmax = c + ((len - 1 - m - c) / m) * m;
-        const u64 count = (kmax - c) / m + 1;
-        if (scan_view<false>(ctx, (Fr*)out, (long long)kmax, -(long long)m, (const Fr*)in, (long long)(kmax + m), -(long long)m, count, beta, tot, cap)) return -1;
-    }
-    return 0;
+    if (scan_scratch(ctx, len - m, m, &tot, &cap)) return -1;
+    return scan_view<false>(ctx, (Fr*)out, (long long)(len - m - 1), -1, (const Fr*)in, (long long)(len - 1), -1, len - m, m, beta, tot, cap);
 }
 // values[q] = pol(points[q]), q < npoints <= 8 (HOST arrays; one pass over the coefficients per level)
 int dev_fr_eval(Ctx* ctx, u64* values, const u64* pol, u64 len, const u64* points, u32 npoints)
