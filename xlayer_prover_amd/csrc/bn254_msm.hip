@@ -367,11 +367,28 @@ int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 
     if (n >= (1ull << 28)) return xlp_fail("msm_bn254: more than 2^28 points");
     u32 lg = 0;
     while ((2ull << lg) <= n) lg++;
-    u32 c = lg > 6 ? lg - 4 : 2;                 // ~16 points per bucket on average
-    // (round 4: the cap was 16 -- at the 9 x 2^22 points of an fflonk commitment every bucket then held 576 points, i.e. was "heavy", and
-    // the whole sum went through the one-workgroup-per-bucket kernel with its 256-way LDS tree: 376 ms per commitment, 81 % of the prover)
-    if (c > 22) c = 22;
-    if (c < 2) c = 2;
+    // window width: the bucket pass costs one mixed addition per (point, non-zero digit), the reduction of a window two full additions per
+    // bucket (~5 mixed additions' worth of instructions: 14 000 against 2 880, `--pmc SQ_INSTS_VALU`), the sort ~0.2 per pair; scalars have 254
+    // significant bits, so the top window often has few buckets.  Pick the width with the least modelled work (round 4: lg - 4, "16 points per
+    // bucket", before: at 9 x 2^22 points the model prefers 20 bits to 21)
+    u32 c = 2;
+    {
+        double best = 0;
+        const u32 lo = lg > 9 ? lg - 8 : 2, hi = lg < 22 ? (lg > 2 ? lg : 2) : 22;
+        for (u32 cc = lo; cc <= hi; cc++) {
+            const u32 nw = (256 + cc - 1) / cc;
+            if ((double)n * nw >= 2147483648.0) continue;
+            double cost = 0;
+            for (u32 w = 0; w < nw; w++) {
+                const int bits = 254 - (int)(w * cc) >= (int)cc ? (int)cc : 254 - (int)(w * cc);
+                if (bits <= 0) { cost += 0.2 * (double)n; continue; }
+                const double nb_ = (double)(1ull << bits);
+                cost += (double)n * (1.0 - 1.0 / nb_) * 1.0 + 0.2 * (double)n + 4.9 * nb_;
+            }
+            if (best == 0 || cost < best) { best = cost; c = cc; }
+        }
+    }
+    if (const char* e = getenv("XLP_MSM_WINDOW_BITS")) { const int v = atoi(e); if (v >= 2 && v <= 22) c = (u32)v; }     // (experiments)
     const u32 nwin = (256 + c - 1) / c;
     const u64 total = n * nwin;
     if (total >= (1ull << 31)) return xlp_fail("msm_bn254: n * windows exceeds 2^31 pairs");
