@@ -43,7 +43,17 @@ def run(bundle, world=0, backend="self", tag=""):
             if backend != "self":
                 cmd += ["--backend", backend, "--rendezvous", rdv]
         procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, XLP_COMM_BARRIER_TIMEOUT_S="200")))
-    outs = [p.communicate(timeout=1500) for p in procs]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=300))
+    except subprocess.TimeoutExpired:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        tails = [p.communicate()[1][-300:] for p in procs]
+        print(f"[bench_sharded_cpp] {os.path.basename(bundle)} world {world} {backend}: no result within 300 s", file=sys.stderr, flush=True)
+        return {"error": "no result within 300 s", "stderr_tails": tails}
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
         if p.returncode != 0:
             return {"error": f"rank {r}: exit {p.returncode}: {se[-400:]}"}
