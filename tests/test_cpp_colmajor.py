@@ -19,7 +19,7 @@ def _programs_built():
 
 
 def _proof(bundle, circ="zkevm"):
-    r = subprocess.run([EXE, "bundle", bundle, circ, str(WSEED), str(CSEED)], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([EXE, "bundle", bundle, circ, str(WSEED), str(CSEED)], capture_output=True, text=True, timeout=360)
     assert r.returncode == 0, r.stderr[-3000:]
     return json.loads(r.stdout), r.stderr
 
@@ -87,7 +87,7 @@ def test_genbatchproof_colmajor_equals_rowmajor(tmp_path):
     outs = {}
     for cm in (False, True):
         for extra in ([], ["--sequential-upload"]) if cm else ([],):
-            r = subprocess.run([exe, "-c", config(f"cfg{cm}.json", cm), "--proofs", "2"] + extra, capture_output=True, text=True, timeout=900)
+            r = subprocess.run([exe, "-c", config(f"cfg{cm}.json", cm), "--proofs", "2"] + extra, capture_output=True, text=True, timeout=360)
             assert r.returncode == 0, r.stderr[-3000:]
             lines = [json.loads(l) for l in r.stdout.strip().splitlines()]
             assert lines[0]["batch_proof_fnv"] == lines[1]["batch_proof_fnv"]          # the second proof of a process (resident constants, reused scratch)
@@ -123,12 +123,12 @@ def test_commit_file_round_trip_through_the_prover(tmp_path):
         f = tmp_path / name
         f.write_text(json.dumps(cfg))
         return str(f)
-    r = subprocess.run([exe, "-c", config("dump.json", True), "--proofs", "1"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([exe, "-c", config("dump.json", True), "--proofs", "1"], capture_output=True, text=True, timeout=360)
     assert r.returncode == 0, r.stderr[-3000:]
     first = json.loads(r.stdout.strip().splitlines()[-1])
     w = json.load(open(os.path.join(bundles["zkevm"], "zkevm.starkinfo.json")))["mapSectionsN"]["cm1_n"]
     assert os.path.getsize(commit) == (1 << 12) * w * 8
-    r = subprocess.run([exe, "-c", config("read.json", False), "--proofs", "1", "--seed", "12345", "--witness-file", commit], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([exe, "-c", config("read.json", False), "--proofs", "1", "--seed", "12345", "--witness-file", commit], capture_output=True, text=True, timeout=360)
     assert r.returncode == 0, r.stderr[-3000:]
     again = json.loads(r.stdout.strip().splitlines()[-1])
     assert again["batch_proof_fnv"] == first["batch_proof_fnv"] and again["batch_proof_bytes"] == first["batch_proof_bytes"]

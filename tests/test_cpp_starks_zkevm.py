@@ -70,7 +70,7 @@ def _flow(circ, ln, aliased):
     return out
 
 
-def _cpp_bundle(bundle, circ, timeout=600):
+def _cpp_bundle(bundle, circ, timeout=360):
     r = subprocess.run([EXE, "bundle", bundle, circ, str(WSEED), str(CSEED)], capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
     return json.loads(r.stdout), r.stderr
@@ -139,7 +139,7 @@ def test_genbatchproof_chains_three_starks(orc, tmp_path):
     exe = os.path.join(HOST, "zkprover_batch")
 
     def run(*extra):
-        r = subprocess.run([exe, "-c", cfg, "--proofs", "1"] + list(extra), capture_output=True, text=True, timeout=900)
+        r = subprocess.run([exe, "-c", cfg, "--proofs", "1"] + list(extra), capture_output=True, text=True, timeout=360)
         assert r.returncode == 0, r.stderr[-3000:]
         return json.loads(r.stdout.strip().splitlines()[-1]), json.load(open(tmp_path / "batch_proof.output.json")), json.load(open(tmp_path / "batch_proof.public.json"))
     line, Z, pub = run()
@@ -168,7 +168,7 @@ def test_genbatchproof_chains_three_starks(orc, tmp_path):
     # three proofs in one process: in the aliased layout the extended constants are recomputed in step 4 of a proof; from the second proof
     # on a resident copy is taken when the memory is there (here it is; at 2^23 rows on 288 GB it is not: 10.5 GB free at that point) and
     # the third proof no longer extends them -- the proofs stay the same
-    r = subprocess.run([exe, "-c", cfg, "--proofs", "3"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([exe, "-c", cfg, "--proofs", "3"], capture_output=True, text=True, timeout=360)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [json.loads(l) for l in r.stdout.strip().splitlines() if l.startswith("{") and "timers_s" in l]
     assert len(lines) == 3 and all(l["batch_proof_fnv"] == line["batch_proof_fnv"] for l in lines)
@@ -180,7 +180,7 @@ def _cpp_bundle_verkey(bundle, cfg_file):
     """constRoot of the recursive1 constants named by the batch config (synthetic:<seed>): a bundle run with that seed prints it"""
     cfg = json.load(open(cfg_file))
     seed = int(cfg["recursive1ConstPols"].split(":")[1])
-    r = subprocess.run([EXE, "bundle", bundle, "recursive1", "1", str(seed)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([EXE, "bundle", bundle, "recursive1", "1", str(seed)], capture_output=True, text=True, timeout=360)
     assert r.returncode == 0, r.stderr[-2000:]
     return json.loads(r.stdout)["verkey"], None
 
@@ -218,7 +218,7 @@ def test_e2e_chain_batch_aggregated_final(orc, tmp_path):
     cj["finalStarkZkey"] = str(tmp_path / "final.fflonk.zkey")
     json.dump(cj, open(cfg, "w"))
     exe = os.path.join(HOST, "zkprover_batch")
-    r = subprocess.run([exe, "-c", cfg, "--e2e", "--final-wtns", str(tmp_path / "final.wtns")], capture_output=True, text=True, timeout=1200)
+    r = subprocess.run([exe, "-c", cfg, "--e2e", "--final-wtns", str(tmp_path / "final.wtns")], capture_output=True, text=True, timeout=360)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [json.loads(l) for l in r.stdout.strip().splitlines()]
     assert [l["stage"] for l in lines] == ["genBatchProof#1", "genBatchProof#2", "genAggregatedProof", "genFinalProof(recursivef)", "finalProof(fflonk)"]

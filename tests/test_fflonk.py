@@ -102,7 +102,7 @@ def _run(tmp_path, z, wit, blinding):
             for v in blinding:
                 f.write(int(v).to_bytes(32, "little"))
         args.append(str(tmp_path / "b.bin"))
-    r = subprocess.run(args, capture_output=True, text=True, timeout=900)
+    r = subprocess.run(args, capture_output=True, text=True, timeout=360)
     assert r.returncode == 0, r.stderr[-3000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
 
@@ -133,7 +133,7 @@ def test_gpu_prover_refuses_a_witness_that_breaks_the_copy_constraints(tmp_path)
     wrong[3] = (wrong[3] + 1) % F.P
     F.write_zkey(str(tmp_path / "k.zkey"), z)
     F.write_wtns(str(tmp_path / "w.wtns"), wrong)
-    r = subprocess.run([EXE, "fflonk", str(tmp_path / "k.zkey"), str(tmp_path / "w.wtns")], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([EXE, "fflonk", str(tmp_path / "k.zkey"), str(tmp_path / "w.wtns")], capture_output=True, text=True, timeout=360)
     assert r.returncode != 0 and ("not well calculated" in r.stderr or "Copy constraints" in r.stderr), r.stderr[-500:]
 
 
