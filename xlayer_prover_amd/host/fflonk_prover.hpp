@@ -39,6 +39,7 @@ class BinFile
     std::vector<char> raw;
     std::map<uint32_t, std::pair<uint64_t, uint64_t>> sections;      // id -> (offset, size)
     const char* cur = NULL; const char* curEnd = NULL;
+    bool pinned = false;
 public:
     BinFile(const std::string& fileName, const std::string& type, uint32_t maxVersion)
     {
@@ -71,6 +72,11 @@ private:
         }
     }
 public:
+    // page-lock the image (a prover in reserved-memory mode uploads the key's sections at every proof)
+    void pin() { if (!pinned && raw.size()) pinned = xlp_host_register(raw.data(), raw.size()) == 0; }
+    ~BinFile() { if (pinned) xlp_host_unregister(raw.data()); }
+    BinFile(const BinFile&) = delete;
+    BinFile& operator=(const BinFile&) = delete;
     void* getSectionData(uint32_t id) { if (!sections.count(id)) xlp_exit_process(("BinFile: section " + std::to_string(id) + " does not exist").c_str()); return raw.data() + sections[id].first; }
     uint64_t getSectionSize(uint32_t id) { if (!sections.count(id)) xlp_exit_process(("BinFile: section " + std::to_string(id) + " does not exist").c_str()); return sections[id].second; }
     void startReadSection(uint32_t id) { cur = (const char*)getSectionData(id); curEnd = cur + getSectionSize(id); }

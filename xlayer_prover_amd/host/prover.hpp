@@ -136,6 +136,7 @@ public:
             // prover.cpp:117: the STARKs' polynomial memory is the prover's reserved memory -- here the DEVICE slab (the zkEVM slab fills the card:
             // nothing of the fflonk prover may stay in HBM between final proofs); the key is uploaded from the host image at every proof
             prover = new Fflonk::FflonkProver([] { return std::make_pair((void*)XlpDeviceSlab::get().address(), XlpDeviceSlab::get().capacityWords() * 8); });
+            zkey->pin();
             prover->setZkey(zkey.get());
         }
     }
