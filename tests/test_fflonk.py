@@ -240,3 +240,37 @@ def test_div_zh_interleave_and_linear_combinations(xlp):
     xlp.sync()
     want = [((pols[0][i] * ks[0] if i < 10 else 0) + (pols[1][2 + i] * ks[1] if i < 5 else 0) + pols[2][i] * ks[2]) % F.P for i in range(12)]
     assert _vals(xlp.to_np(out))[:12] == want
+
+
+@pytest.mark.gpu
+def test_scratch_slots_can_be_lent_and_released(xlp):
+    """xlp_scratch_lend / xlp_scratch_release (include/xlp_gl.h): a scan whose run totals need scratch slot 4 works in a region lent by the
+    caller (and writes there), falls through to the library's own scratch when the region is too small, and again after everything was released"""
+    import torch
+    from oracle import fflonk_oracle as F
+    n = 5000
+    rng = F.Rng(4040)
+    a = [rng.fr() or 1 for _ in range(n)]
+    run, acc = [], 1
+    for v in a:
+        acc = acc * v % F.P
+        run.append(acc)
+    src = xlp.from_np(_limbs(a).reshape(-1))
+    out = torch.zeros(4 * n, dtype=torch.int64, device="cuda")
+    region = torch.zeros(1 << 16, dtype=torch.int64, device="cuda")
+    xlp.scratch_lend(4, region)
+    xlp.dev_fr_prefix_product(out, src, n)
+    xlp.sync()
+    assert _vals(xlp.to_np(out)) == run and int((region != 0).sum()) > 0          # the run totals went through the lent region
+    tiny = torch.zeros(8, dtype=torch.int64, device="cuda")
+    xlp.scratch_lend(4, tiny)                                                       # too small: the slot's own scratch serves
+    out.zero_()
+    xlp.dev_fr_prefix_product(out, src, n)
+    xlp.sync()
+    assert _vals(xlp.to_np(out)) == run and int((tiny != 0).sum()) == 0
+    xlp.scratch_lend(4, None)
+    xlp.scratch_release(1 << 4)
+    out.zero_()
+    xlp.dev_fr_prefix_product(out, src, n)
+    xlp.sync()
+    assert _vals(xlp.to_np(out)) == run

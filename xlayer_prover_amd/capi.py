@@ -345,6 +345,18 @@ def dev_msm_bn254(out, bases, scalars, n):
 
 
 # ---- vectors of BN254 Fr elements (the fflonk prover's primitives): device tensors of (n, 4) int64 Montgomery limbs; scalars as numpy (k, 4) uint64
+def scratch_lend(slot, tensor=None):
+    """let a scratch slot of the library use a caller-owned device tensor (None: take it back)"""
+    if tensor is None:
+        _ck(load().xlp_scratch_lend(slot, None, 0), "xlp_scratch_lend")
+    else:
+        _ck(load().xlp_scratch_lend(slot, _dp(tensor), tensor.numel() * tensor.element_size()), "xlp_scratch_lend")
+
+
+def scratch_release(mask=0xFF):
+    _ck(load().xlp_scratch_release(mask), "xlp_scratch_release")
+
+
 def dev_fr_mul(out, a, b, n):
     _ck(load().xlp_dev_fr_mul(_dp(out), _dp(a), _dp(b), n), "xlp_dev_fr_mul")
 
