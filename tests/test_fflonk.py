@@ -92,7 +92,7 @@ def test_zkey_and_wtns_files_have_the_sections_the_reference_reads(tmp_path):
     assert int.from_bytes(w[1][36:40], "little") == len(wit) and int.from_bytes(w[2][32:64], "little") == wit[1]
 
 
-def _run(tmp_path, z, wit, blinding):
+def _run(tmp_path, z, wit, blinding, env=None):
     from oracle import fflonk_oracle as F
     F.write_zkey(str(tmp_path / "k.zkey"), z)
     F.write_wtns(str(tmp_path / "w.wtns"), wit)
@@ -102,7 +102,7 @@ def _run(tmp_path, z, wit, blinding):
             for v in blinding:
                 f.write(int(v).to_bytes(32, "little"))
         args.append(str(tmp_path / "b.bin"))
-    r = subprocess.run(args, capture_output=True, text=True, timeout=360)
+    r = subprocess.run(args, capture_output=True, text=True, timeout=360, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr[-3000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
 
@@ -123,6 +123,18 @@ def test_gpu_prover_returns_the_oracles_proof(tmp_path, power, npub, nadd, seed)
     assert F.verify(z, tau, got["proof"], got["publics"])
     rnd = _run(tmp_path, z, wit, None)                               # blinding drawn by the prover: another proof, as valid
     assert rnd["proof"] != got["proof"] and F.verify(z, tau, rnd["proof"], rnd["publics"])
+
+
+@pytest.mark.gpu
+def test_gpu_prover_commitments_in_several_multiexponentiation_calls(tmp_path):
+    """a commitment over more points than one xlp_dev_msm_bn254 call takes (2^26 in production: 9 x 2^24 points = three calls) is the sum of
+    partial sums, added by one more multi-exponentiation with unit scalars: forced here with a chunk of 500 points (XLP_FFLONK_MSM_CHUNK)"""
+    from oracle import fflonk_oracle as F
+    z, wit, tau = F.setup(8, n_public=1, n_additions=3, seed=33)
+    blinding = [F.Rng(133).fr() for _ in range(9)]
+    expect = F.proof_to_json(*F.prove(z, wit, tau, blinding)[:2])
+    got = _run(tmp_path, z, wit, blinding, env={"XLP_FFLONK_MSM_CHUNK": "500"})
+    assert got["proof"] == expect[0] and got["publics"] == expect[1]
 
 
 @pytest.mark.gpu

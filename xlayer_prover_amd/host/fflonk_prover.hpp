@@ -366,7 +366,8 @@ class FflonkProver
     {
         DevFr sc = buffers["tmp"];
         XLP_CHECK(xlp_dev_fr_from_mont(sc, pol, count));                // polynomialFromMontgomery
-        const uint64_t chunk = 1ULL << 26;
+        uint64_t chunk = 1ULL << 26;                                    // (xlp_dev_msm_bn254 takes < 2^27 points per call)
+        if (const char* e = getenv("XLP_FFLONK_MSM_CHUNK")) { const uint64_t v = strtoull(e, NULL, 10); if (v >= 16 && v < chunk) chunk = v; }     // tests: the partial sums' path at small sizes
         std::vector<G1PointAffine> parts;
         uint64_t* d_out = buffers["msm_out"];
         for (uint64_t o = 0; o < count; o += chunk) {
