@@ -246,9 +246,12 @@ def main():
               open(os.path.join(HERE, "aggregation_chain.json"), "w"), indent=1)
     # the four G1 commitments of the reference's fflonk proof: real BN254 curve points held by the reference (pin q and b = 3)
     blob = open(REF + "/finalProof/proof.json").read().strip()[2:]
-    w = [int(blob[64 * i:64 * i + 64], 16) for i in range(8)]
-    json.dump({"source": "testvectors/finalProof/proof.json: the first eight 32-byte words = the G1 commitments C1, C2, W1, W2 of the reference's fflonk proof (affine x, y)",
-               "points": [[str(w[2 * i]), str(w[2 * i + 1])] for i in range(4)]}, open(os.path.join(HERE, "fflonk_proof_g1_points.json"), "w"), indent=1)
+    w = [int(blob[64 * i:64 * i + 64], 16) for i in range(len(blob) // 64)]
+    assert len(w) == 24 and len(blob) == 24 * 64
+    json.dump({"source": "testvectors/finalProof/proof.json: 24 32-byte words = the G1 commitments C1, C2, W1, W2 of the reference's fflonk proof (affine x, y), "
+                         "then its 16 evaluations",
+               "points": [[str(w[2 * i]), str(w[2 * i + 1])] for i in range(4)], "evaluations": [str(x) for x in w[8:]]},
+              open(os.path.join(HERE, "fflonk_proof_g1_points.json"), "w"), indent=1)
     # BN254 field constants the reference's generated field code holds as DATA (src/ffiasm/fr.asm / fq.asm, section .data): modulus, R^2, R^3 and
     # np = -q^-1 mod 2^64 of the 4 x 64-bit Montgomery form.  They pin the element representation (R = 2^256) of RawFr / RawFq -- what "the bytes of
     # a RawFr::Element" means -- for the oracle (oracle/bn128_oracle.py) and for the limbs / N0INV the kernels are built with.

@@ -36,6 +36,21 @@ def test_keccak256_against_hashlib_and_known_answers():
     assert F.keccak256(b"The quick brown fox jumps over the lazy dog").hex() == "4d741b6f1eb29cb2a9b9911c82f56fa8d73b04959d3d9d222895df6c0b28aa15"
 
 
+def test_the_references_own_fflonk_proof_has_the_shape_this_prover_emits():
+    """testvectors/finalProof/proof.json (the aggregator service test's mock output, test/service/aggregator/aggregator_service.cpp:56) is a real fflonk
+    proof as 24 32-byte words; without its verification key nothing in it can be re-derived, but its SHAPE pins what a proof consists of: four G1
+    commitments (on the curve: tests/test_bn128.py) and sixteen scalars below r -- the sixteen evaluations ql qr qm qo qc s1 s2 s3 a b c z zw t1w t2w inv
+    that FflonkProver::prove adds to its proof (fflonk_prover.c.hpp:1217-1238,537), no more, no fewer"""
+    from oracle import fflonk_oracle as F
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "fflonk_proof_g1_points.json")))
+    assert len(g["points"]) == 4 and len(g["evaluations"]) == 16
+    assert all(0 <= int(v) < F.P for v in g["evaluations"]) and len(set(g["evaluations"])) == 16
+    z, wit, tau = F.setup(4, n_public=1, n_additions=0, seed=3)
+    pj, _ = F.proof_to_json(*F.prove(z, wit, tau, list(range(1, 10)))[:2])
+    assert sorted(pj["polynomials"]) == ["C1", "C2", "W1", "W2"]
+    assert sorted(pj["evaluations"]) == sorted(["ql", "qr", "qm", "qo", "qc", "s1", "s2", "s3", "a", "b", "c", "z", "zw", "t1w", "t2w", "inv"])
+
+
 def test_host_keccak_and_challenge_equal_the_oracles():
     """host/fflonk_prover.hpp without a GPU: keccak256() and the challenge derivation of Keccak256Transcript (digest as a big-endian integer
     mod r through the Montgomery product, back to bytes, a field inversion) against the oracle, on one- and many-block messages"""
