@@ -18,6 +18,8 @@ the key it was made with): the prover is "parity unpinned" against the reference
   * `verify()` is the fflonk verification equation (the fflonk paper, Gabizon and Williamson 2021, as the prover's rounds imply it; the batched opening check of the three combined
     polynomials at the roots of xi) with the pairing replaced by the trapdoor:  e(A, [1]_2) = e(W2, [tau]_2)  <=>  A = tau * W2 in G1.
     A proof only passes if every round of the prover -- transcript, quotients, interpolations, openings -- is what the protocol says.
+  * the SHAPE of a proof -- four commitments, sixteen evaluations -- is that of the reference's own fflonk proof (testvectors/finalProof/proof.json,
+    24 words: tests/golden/fflonk_proof_g1_points.json); its values cannot be re-derived without its verification key;
   * Keccak-256: the sponge with the NIST suffix equals hashlib.sha3_256 on one- and many-block messages (permutation, absorption and
     padding pinned by an independent implementation); the 0x01 suffix by the digests of "", "abc" and the fox sentence (tests/test_fflonk.py).
 """
