@@ -399,6 +399,7 @@ int dev_fr_eval(Ctx* ctx, u64* values, const u64* pol, u64 len, const u64* point
 
 static int upload_wpow(Ctx* ctx, const u64* wpow_host, u32 count, Fr** d)
 {
+    if (count > 64) return xlp_fail("fflonk: at most 64 powers of the root");
     u64* p = nullptr;
     if (ctx_scratch(ctx, 64 * sizeof(Fr), 5, &p)) return -1;
     XLP_HIP(hipMemcpyAsync(p, wpow_host, (u64)count * sizeof(Fr), hipMemcpyHostToDevice, ctx->stream));
@@ -410,6 +411,7 @@ static int upload_wpow(Ctx* ctx, const u64* wpow_host, u32 count, Fr** d)
 int dev_fflonk_t0(Ctx* ctx, u64* out, const u64* a, const u64* b, const u64* c, const u64* ql, const u64* qr, const u64* qm, const u64* qo, const u64* qc, const u64* lagrange,
                   const u64* pub, u32 npub, u64 n4)
 {
+    if (!n4) return 0;
     hipLaunchKernelGGL(ffr::t0_kernel, dim3(ffr::blocks(n4)), dim3(ffr::TPB), 0, ctx->stream, (Fr*)out, (const Fr*)a, (const Fr*)b, (const Fr*)c, (const Fr*)ql, (const Fr*)qr, (const Fr*)qm,
                        (const Fr*)qo, (const Fr*)qc, (const Fr*)lagrange, (const Fr*)pub, npub, n4);
     XLP_HIP(hipGetLastError());
@@ -418,6 +420,7 @@ int dev_fflonk_t0(Ctx* ctx, u64* out, const u64* a, const u64* b, const u64* c, 
 // scalars (HOST, Montgomery): beta, gamma, k1, k2; wpow (HOST): omega_n^(2^k), k < log2 n
 int dev_fflonk_z_numden(Ctx* ctx, u64* num, u64* den, const u64* a, const u64* b, const u64* c, const u64* s1, const u64* s2, const u64* s3, u64 n, const u64* scalars, const u64* wpow, u32 nw)
 {
+    if (!n) return 0;
     Fr* dw;
     if (upload_wpow(ctx, wpow, nw, &dw)) return -1;
     ffr::ZArgs A = {ffr::load_host(scalars), ffr::load_host(scalars + 4), ffr::load_host(scalars + 8), ffr::load_host(scalars + 12)};
@@ -428,6 +431,7 @@ int dev_fflonk_z_numden(Ctx* ctx, u64* num, u64* den, const u64* a, const u64* b
 }
 int dev_fflonk_z_rotate(Ctx* ctx, u64* z, const u64* run, u64 n)
 {
+    if (!n) return 0;
     hipLaunchKernelGGL(ffr::z_rotate_kernel, dim3(ffr::blocks(n)), dim3(ffr::TPB), 0, ctx->stream, (Fr*)z, (const Fr*)run, n);
     XLP_HIP(hipGetLastError());
     return 0;
@@ -435,6 +439,7 @@ int dev_fflonk_z_rotate(Ctx* ctx, u64* z, const u64* run, u64 n)
 // blinding (HOST): b7, b8, b9; wpow: omega_2n^(2^k)
 int dev_fflonk_t1(Ctx* ctx, u64* t1, u64* t1z, const u64* z, const u64* lagrange1, u64 n2, const u64* blinding, const u64* wpow, u32 nw)
 {
+    if (!n2) return 0;
     Fr* dw;
     if (upload_wpow(ctx, wpow, nw, &dw)) return -1;
     ffr::BArgs B = {ffr::load_host(blinding), ffr::load_host(blinding + 4), ffr::load_host(blinding + 8)};
@@ -445,6 +450,7 @@ int dev_fflonk_t1(Ctx* ctx, u64* t1, u64* t1z, const u64* z, const u64* lagrange
 // scalars (HOST): beta, gamma, k1, k2, omega_n, b7, b8, b9; wpow: omega_4n^(2^k)
 int dev_fflonk_t2(Ctx* ctx, u64* t2, u64* t2z, const u64* a, const u64* b, const u64* c, const u64* z, const u64* s1, const u64* s2, const u64* s3, u64 n4, const u64* scalars, const u64* wpow, u32 nw)
 {
+    if (!n4) return 0;
     Fr* dw;
     if (upload_wpow(ctx, wpow, nw, &dw)) return -1;
     ffr::T2Args A;

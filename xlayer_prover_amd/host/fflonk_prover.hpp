@@ -46,6 +46,7 @@ public:
         FILE* f = fopen(fileName.c_str(), "rb");
         if (!f) xlp_exit_process(("BinFile: cannot open " + fileName).c_str());
         fseek(f, 0, SEEK_END); const long sz = ftell(f); fseek(f, 0, SEEK_SET);
+        if (sz < 0) { fclose(f); xlp_exit_process(("BinFile: cannot size " + fileName).c_str()); }
         raw.resize((size_t)sz);
         if (sz && fread(raw.data(), 1, (size_t)sz, f) != (size_t)sz) { fclose(f); xlp_exit_process(("BinFile: short read on " + fileName).c_str()); }
         fclose(f);
@@ -66,7 +67,7 @@ private:
             uint32_t id; uint64_t size;
             memcpy(&id, raw.data() + pos, 4); memcpy(&size, raw.data() + pos + 4, 8);
             pos += 12;
-            if (pos + size > raw.size()) xlp_exit_process("BinFile: section past the end of the file");
+            if (size > raw.size() - pos) xlp_exit_process("BinFile: section past the end of the file");
             if (!sections.count(id)) sections[id] = {pos, size};
             pos += size;
         }
@@ -81,7 +82,7 @@ public:
     uint64_t getSectionSize(uint32_t id) { if (!sections.count(id)) xlp_exit_process(("BinFile: section " + std::to_string(id) + " does not exist").c_str()); return sections[id].second; }
     void startReadSection(uint32_t id) { cur = (const char*)getSectionData(id); curEnd = cur + getSectionSize(id); }
     void endReadSection() { cur = curEnd = NULL; }
-    void* read(uint64_t len) { if (!cur || cur + len > curEnd) xlp_exit_process("BinFile: read past the section"); const char* p = cur; cur += len; return (void*)p; }
+    void* read(uint64_t len) { if (!cur || len > (uint64_t)(curEnd - cur)) xlp_exit_process("BinFile: read past the section"); const char* p = cur; cur += len; return (void*)p; }
     uint32_t readU32LE() { uint32_t v; memcpy(&v, read(4), 4); return v; }
 };
 inline std::unique_ptr<BinFile> openExisting(const std::string& filename, const std::string& type, uint32_t maxVersion) { return std::unique_ptr<BinFile>(new BinFile(filename, type, maxVersion)); }
