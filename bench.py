@@ -215,6 +215,21 @@ def bn128_leg(capi, torch, dev):
     res = torch.empty(8, dtype=torch.int64, device=dev)
     ms = timed(lambda: capi.dev_msm_bn254(res, bases, sc, n), 2)
     out["msm_bn254"] = {"workload": "G1 multiexp 2^22 points, 256-bit scalars", "ms": round(ms, 2), "Mpoints_per_s": round(n / ms / 1e3, 1)}
+    # the bucket pass against its ALU ceiling: n x windows mixed additions per multi-exponentiation; the ceiling = the same additions chained
+    # on register-resident operands (xlp_dev_msm_resident), one lane per bucket as in the pass, 64 additions per lane
+    lib = capi.load()
+    c = lib.xlp_msm_bn254_window_bits(n)
+    nwin = (256 + c - 1) // c
+    lanes, iters = nwin << c, 64
+    sink = torch.empty(lanes * 12, dtype=torch.int64, device=dev)
+    one_pt = bases[:8].clone()
+    ms_r = timed(lambda: capi._ck(lib.xlp_dev_msm_resident(capi._dp(sink), capi._dp(one_pt), lanes, iters), "xlp_dev_msm_resident"), 2)
+    ceil_rate = lanes * iters / (ms_r * 1e-3)
+    rate = n * nwin / (ms * 1e-3)
+    out["msm_bn254"]["roofline"] = {"bound": "valu", "unit": "mixed G1 additions/s", "window_bits": c, "windows": nwin, "additions_per_multiexp": n * nwin,
+                                    "achieved": round(rate, 0), "peak": round(ceil_rate, 0), "frac": round(rate / ceil_rate, 4),
+                                    "peak_from": "xlp::g1::msm_resident_kernel: %d lanes x %d chained additions of a resident point, %.3f ms (measured in this run; no memory traffic)" % (lanes, iters, ms_r),
+                                    "note": "achieved counts the WHOLE multi-exponentiation (keys, sort, bucket pass, window reductions, Horner) against the bucket pass's ceiling"}
     return out
 
 

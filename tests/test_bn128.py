@@ -503,3 +503,24 @@ def test_cpp_stark_recursivef_loads_bctree_bn128_tree(tmp_path):
     assert r1.returncode == 0, r1.stderr[-2000:]
     assert r1.stdout == r0.stdout
     assert json.loads(r1.stdout)["verkey"] == json.load(open(tmp_path / "toy.verkey_bn128.json"))["constRoot"]
+
+
+@pytest.mark.gpu
+def test_gpu_msm_resident_ceiling_kernel_adds_what_it_says(xlp):
+    """the measurement aid behind bench.py's msm_bn254.roofline (xlp_dev_msm_resident): every lane ends at (iters + 1) * P, Jacobian"""
+    import torch
+    P = _golden_points()[0]
+    pt = xlp.from_np(np.array(bo.g1_to_limbs(P), dtype=np.uint64))
+    lanes, iters = 130, 5
+    out = torch.zeros(lanes * 12, dtype=torch.int64, device="cuda")
+    xlp._ck(xlp.load().xlp_dev_msm_resident(xlp._dp(out), xlp._dp(pt), lanes, iters), "xlp_dev_msm_resident")
+    jac = xlp.to_np(out).reshape(lanes, 3, 4)
+
+    def coord(w):
+        return sum(int(v) << (64 * i) for i, v in enumerate(w)) * bo.Q_MONT_RINV % bo.Q_MOD
+
+    for i in (0, 1, 63, 64, 129):
+        X, Y, Z = (coord(jac[i, k]) for k in range(3))
+        zi = pow(Z, -1, bo.Q_MOD)
+        assert ((X * zi * zi) % bo.Q_MOD, (Y * zi * zi * zi) % bo.Q_MOD) == bo.g1_mul(P, iters + 1)
+    assert 2 <= xlp.load().xlp_msm_bn254_window_bits(1 << 22) <= 22

@@ -69,6 +69,20 @@ def _run_ranks(bundle, world, backend, tmp_path, timeout=300, env=None):
     return json.loads(outs[0][0].strip().splitlines()[-1]), [se for _, se in outs]      # (RCCL prints a banner on stdout first)
 
 
+_ONE_GPU = {}
+
+
+def _one_gpu_proof(tmp_path, ln):
+    """the one-GPU proof of the same witness and constants (one run per size serves every parametrisation)"""
+    from tools import make_stark_bundle as B
+    if ln not in _ONE_GPU:
+        one = B.make("zkevm", ln, False, out=str(tmp_path / "one"))
+        r = subprocess.run([EXE, "bundle", one, "zkevm", str(WSEED), str(CSEED)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-3000:]
+        _ONE_GPU[ln] = json.loads(r.stdout)
+    return json.loads(json.dumps(_ONE_GPU[ln]))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,backend,scratch_mb,msg_words,colmajor", [
     (1, "self", 0, 0, False), (1, "rccl", 0, 0, False), (2, "shm", 0, 0, False), (4, "shm", 0, 0, False), (2, "shm", 1, 0, False),
@@ -86,10 +100,7 @@ def test_cpp_sharded_starks_proof_equals_one_gpu_proof(tmp_path, world, backend,
     if not _programs_built():
         pytest.skip("converted reference programs not built (needs the reference tree at build time)")
     ln = 12
-    one = B.make("zkevm", ln, False, out=str(tmp_path / "one"))
-    r = subprocess.run([EXE, "bundle", one, "zkevm", str(WSEED), str(CSEED)], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0, r.stderr[-3000:]
-    expect = json.loads(r.stdout)
+    expect = _one_gpu_proof(tmp_path, ln)
     win = B.make("zkevm", ln, False, out=str(tmp_path / "win"), world=world, colmajor=colmajor)
     env = dict(os.environ)
     if scratch_mb:

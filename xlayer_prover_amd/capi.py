@@ -72,6 +72,8 @@ SIGNATURES = {
     "xlp_dev_fft_bn254": [_pu, _u64, C.c_int],
     "xlp_fft_bn254": [_pu, _u64, C.c_int],
     "xlp_dev_msm_bn254": [_pu, _pu, _pu, _u64],
+    "xlp_dev_msm_resident": [_pu, _pu, _u32, _u32],
+    "xlp_msm_bn254_window_bits": [_u64],
     "xlp_scratch_release": [_u32],
     "xlp_scratch_lend": [_u32, _pu, C.c_size_t],
     "xlp_dev_fr_gather_mont": [_pu, _pu, _u64, _pu, _u64],

@@ -357,14 +357,26 @@ __global__ __launch_bounds__(256) void msm_window_sums_kernel(Jac* __restrict__ 
     if (t == 0) wsum[w] = sh[0];
 }
 
+// MEASUREMENT AID: the bucket pass's arithmetic with no memory traffic -- every lane of a 64-lane workgroup (msm_buckets_kernel's launch
+// bounds) adds one resident affine point to its accumulator `iters` times, the additions chained as in a bucket's walk.  What this reaches
+// in mixed additions per second is the ceiling of THIS formulation (Jacobian + affine, mont256 products) on this chip; the multi-exponentiation's
+// distance from it is what its gathers, its sort and its reductions cost.
+__global__ __launch_bounds__(64) void msm_resident_kernel(Jac* __restrict__ out, const Aff* __restrict__ point, const u32 lanes, const u32 iters)
+{
+    const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= lanes) return;
+    const Aff q = point[0];
+    Jac acc = jmadd(jzero(), q);                               // q; the first addition below doubles, none after it meets q again
+#pragma unroll 1
+    for (u32 k = 0; k < iters; k++) acc = jmadd(acc, q);       // (iters + 1) q
+    out[gid] = acc;
+}
+
 }  // namespace g1
 
-// out (device, 8 words: x, y affine Montgomery; (0, 0) = infinity) = sum scalars[i] * bases[i]
-int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 n)
+// window width for n points (see the comment inside): shared by dev_msm_bn254 and the measurement aid below
+static u32 msm_window_bits(u64 n)
 {
-    using namespace g1;
-    if (n == 0) { XLP_HIP(hipMemsetAsync(out, 0, sizeof(Aff), ctx->stream)); return 0; }
-    if (n >= (1ull << 28)) return xlp_fail("msm_bn254: more than 2^28 points");
     u32 lg = 0;
     while ((2ull << lg) <= n) lg++;
     // window width: the bucket pass costs one mixed addition per (point, non-zero digit), the reduction of a window two full additions per
@@ -388,6 +400,16 @@ int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 
             if (best == 0 || cost < best) { best = cost; c = cc; }
         }
     }
+    return c;
+}
+
+// out (device, 8 words: x, y affine Montgomery; (0, 0) = infinity) = sum scalars[i] * bases[i]
+int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 n)
+{
+    using namespace g1;
+    if (n == 0) { XLP_HIP(hipMemsetAsync(out, 0, sizeof(Aff), ctx->stream)); return 0; }
+    if (n >= (1ull << 28)) return xlp_fail("msm_bn254: more than 2^28 points");
+    u32 c = msm_window_bits(n);
     if (const char* e = getenv("XLP_MSM_WINDOW_BITS")) { const int v = atoi(e); if (v >= 2 && v <= 22) c = (u32)v; }     // (experiments)
     const u32 nwin = (256 + c - 1) / c;
     const u64 total = n * nwin;
@@ -444,6 +466,17 @@ int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 
     hipLaunchKernelGGL(msm_groups_kernel, dim3((nwin * gpw + 63) / 64), dim3(64), 0, ctx->stream, groups, buckets, nwin, c);
     hipLaunchKernelGGL(msm_window_sums_kernel, dim3(nwin), dim3(256), 0, ctx->stream, wsum, groups, nwin, gpw);
     hipLaunchKernelGGL(msm_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, (Aff*)out, wsum, nwin, c);
+    XLP_HIP(hipGetLastError());
+    return 0;
+}
+
+u32 msm_bn254_window_bits(u64 n) { return msm_window_bits(n); }
+
+// out (device, lanes x 12 words): the lanes' sums in Jacobian coordinates (kept so that the work is); point: one affine point (device, 8 words)
+int dev_msm_resident(Ctx* ctx, u64* out, const u64* point, u32 lanes, u32 iters)
+{
+    if (!lanes) return 0;
+    hipLaunchKernelGGL(g1::msm_resident_kernel, dim3((lanes + 63) / 64), dim3(64), 0, ctx->stream, (g1::Jac*)out, (const g1::Aff*)point, lanes, iters);
     XLP_HIP(hipGetLastError());
     return 0;
 }

@@ -1333,6 +1333,14 @@ int xlp_dev_msm_bn254(uint64_t* out, const uint64_t* bases, const uint64_t* scal
     if (!out || (n && (!bases || !scalars))) return xlp_fail("xlp_dev_msm_bn254: null pointer");
     return dev_msm_bn254(&g_ctx, out, bases, scalars, n);
 }
+int xlp_dev_msm_resident(uint64_t* out, const uint64_t* point, uint32_t lanes, uint32_t iters)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if (lanes && (!out || !point)) return xlp_fail("xlp_dev_msm_resident: null pointer");
+    return dev_msm_resident(&g_ctx, out, point, lanes, iters);
+}
+int xlp_msm_bn254_window_bits(uint64_t n) { return (int)msm_bn254_window_bits(n); }
 int xlp_msm_bn254(uint64_t* out, const uint64_t* bases, const uint64_t* scalars, uint64_t n)
 {
     XLP_ENTER;

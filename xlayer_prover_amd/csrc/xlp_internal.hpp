@@ -131,6 +131,8 @@ int dev_merkle_bn128_proofs(Ctx* ctx, u64* out, const u64* src, const u64* nodes
 int dev_fft_bn254(Ctx* ctx, u64* data, u64 n, int inverse);
 // bn254_msm.hip
 int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 n);
+int dev_msm_resident(Ctx* ctx, u64* out, const u64* point, u32 lanes, u32 iters);
+u32 msm_bn254_window_bits(u64 n);
 
 // fflonk.hip (vectors of BN254 Fr elements: the per-coefficient / per-evaluation work of the fflonk prover)
 int dev_fr_gather_mont(Ctx* ctx, u64* out, const u32* map, u64 nmap, const u64* values, u64 nvalues);
