@@ -228,7 +228,7 @@ def bn128_leg(capi, torch, dev):
     rate = n * nwin / (ms * 1e-3)
     out["msm_bn254"]["roofline"] = {"bound": "valu", "unit": "mixed G1 additions/s", "window_bits": c, "windows": nwin, "additions_per_multiexp": n * nwin,
                                     "achieved": round(rate, 0), "peak": round(ceil_rate, 0), "frac": round(rate / ceil_rate, 4),
-                                    "peak_from": "xlp::g1::msm_resident_kernel: %d lanes x %d chained additions of a resident point, %.3f ms (measured in this run; no memory traffic)" % (lanes, iters, ms_r),
+                                    "peak_from": "xlp::g1::msm_resident_kernel: %d lanes x %d chained additions of one cached point, %.3f ms (measured in this run; no HBM traffic)" % (lanes, iters, ms_r),
                                     "note": "achieved counts the WHOLE multi-exponentiation (keys, sort, bucket pass, window reductions, Horner) against the bucket pass's ceiling"}
     return out
 

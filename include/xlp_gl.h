@@ -331,8 +331,8 @@ int xlp_fft_bn254(uint64_t* data, uint64_t n, int inverse);
 int xlp_dev_msm_bn254(uint64_t* out, const uint64_t* bases, const uint64_t* scalars, uint64_t n);
 int xlp_msm_bn254(uint64_t* out, const uint64_t* bases, const uint64_t* scalars, uint64_t n);
 /* Measurement aids for the multi-exponentiation (SURVEY.md 8d applied to row f4): the window width xlp_[dev_]msm_bn254 picks for n points
- * (n x ceil(256 / width) mixed additions in its bucket pass), and the ALU ceiling of that pass -- `lanes` lanes each add the resident affine
- * point `point` (device, 8 words) to a register-resident Jacobian accumulator `iters` times, no memory traffic; out (device, lanes x 12 words)
+ * (n x ceil(256 / width) mixed additions in its bucket pass), and the ALU ceiling of that pass -- `lanes` lanes each add the affine point
+ * `point` (device, 8 words: a cache hit for every lane) to a register-resident Jacobian accumulator `iters` times, no HBM traffic; out (device, lanes x 12 words)
  * keeps the sums.  bench.py reports the multi-exponentiation's additions/s against what this reaches. */
 int xlp_msm_bn254_window_bits(uint64_t n);
 int xlp_dev_msm_resident(uint64_t* out, const uint64_t* point, uint32_t lanes, uint32_t iters);

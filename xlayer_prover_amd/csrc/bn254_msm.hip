@@ -89,7 +89,9 @@ struct FqParams {
     static constexpr u32 N[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
     static constexpr u32 N0INV = 0xe4866389u;
 };
-__device__ __noinline__ Fq fmul(const Fq& a, const Fq& b)      // mont256.hpp: product scanning, 2 VALU per multiply-accumulate
+// (operands BY VALUE: 2 x 8 registers in, 8 out.  By reference the caller parks both operands in scratch memory and the function starts with
+// four loads and a wait -- a memory round trip in front of each of the 11 products of a mixed addition)
+__device__ __noinline__ Fq fmul(const Fq a, const Fq b)        // mont256.hpp: product scanning, 2 VALU per multiply-accumulate
 {
     Fq r;
     mont::mul<FqParams>(r.v, a.v, b.v);
@@ -119,8 +121,10 @@ __device__ __noinline__ Jac jdbl(const Jac& p)
     r.z = fdbl(fmul(p.y, p.z));
     return r;
 }
-// madd-2007-bl with the exceptional cases
-__device__ __noinline__ Jac jmadd(const Jac& p, const Aff& q)
+// madd-2007-bl with the exceptional cases.  jmadd_inl: inlined into the loops of the bucket kernels -- the accumulator and the temporaries
+// then live in the KERNEL's registers across the calls of fmul; as a function of its own it saves and restores ~100 callee-saved registers
+// through scratch memory on every call (464 bytes of stack per lane) and hands its result back through memory.
+__device__ __forceinline__ Jac jmadd_inl(const Jac& p, const Aff& q)
 {
     if (ainf(q)) return p;
     if (jinf(p)) { Jac r; r.x = q.x; r.y = q.y; r.z = fone(); return r; }
@@ -139,8 +143,9 @@ __device__ __noinline__ Jac jmadd(const Jac& p, const Aff& q)
     r.z = fsub(fsub(fsqr(fadd(p.z, H)), Z1Z1), HH);
     return r;
 }
-// add-2007-bl with the exceptional cases
-__device__ __noinline__ Jac jadd(const Jac& p, const Jac& q)
+__device__ __noinline__ Jac jmadd(const Jac& p, const Aff& q) { return jmadd_inl(p, q); }
+// add-2007-bl with the exceptional cases (jadd_inl: for the running sums of msm_groups_kernel, as jmadd_inl above)
+__device__ __forceinline__ Jac jadd_inl(const Jac& p, const Jac& q)
 {
     if (jinf(q)) return p;
     if (jinf(p)) return q;
@@ -161,6 +166,7 @@ __device__ __noinline__ Jac jadd(const Jac& p, const Jac& q)
     r.z = fmul(fsub(fsub(fsqr(fadd(p.z, q.z)), Z1Z1), Z2Z2), H);
     return r;
 }
+__device__ __noinline__ Jac jadd(const Jac& p, const Jac& q) { return jadd_inl(p, q); }
 // k * p for a small k (<= 16 bits), double-and-add from the top
 __device__ __forceinline__ Jac jmul_small(const Jac& p, u32 k)
 {
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(64) void msm_buckets_kernel(Jac* __restrict__ bucke
             for (u32 s_ = 0; s_ < nseg; s_++) { hs[2 * (first + s_)] = key; hs[2 * (first + s_) + 1] = s_; }
             return;
         }
-        for (u32 k = b; k < e; k++) acc = jmadd(acc, bases[sorted_vals[k]]);
+        for (u32 k = b; k < e; k++) acc = jmadd_inl(acc, bases[sorted_vals[k]]);
     }
     buckets[key] = acc;
 }
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(256) void msm_heavy_kernel(Jac* __restrict__ part, 
         const u32 key = hs[2 * e_], seg = hs[2 * e_ + 1];
         const u32 b = start[key] + seg * SEG, lim = stop[key], e = b + SEG < lim ? b + SEG : lim;
         Jac acc = jzero();
-        for (u32 k = b + t; k < e; k += 256) acc = jmadd(acc, bases[sorted_vals[k]]);
+        for (u32 k = b + t; k < e; k += 256) acc = jmadd_inl(acc, bases[sorted_vals[k]]);
         const Jac r = block_sum_256(acc, sh, t);
         if (t == 0) part[e_] = r;
     }
@@ -300,8 +306,8 @@ __global__ __launch_bounds__(64) void msm_groups_kernel(Jac* __restrict__ groups
     const Jac* __restrict__ B = buckets + ((u64)w << c) + (u64)g * gs;
     Jac run = jzero(), sum = jzero();
     for (int d = (int)gs - 1; d >= 0; d--) {          // sum = sum_d (d + 1) * B[d] ... shifted below
-        run = jadd(run, B[d]);
-        sum = jadd(sum, run);
+        run = jadd_inl(run, B[d]);
+        sum = jadd_inl(sum, run);
     }
     // sum = sum_d (d + 1) B[d]; wanted sum_d (g * gs + d) B[d] = sum + (g * gs - 1) * run  (run = group total); g * gs = 0: sum - run
     if (g == 0) {
@@ -357,18 +363,19 @@ __global__ __launch_bounds__(256) void msm_window_sums_kernel(Jac* __restrict__ 
     if (t == 0) wsum[w] = sh[0];
 }
 
-// MEASUREMENT AID: the bucket pass's arithmetic with no memory traffic -- every lane of a 64-lane workgroup (msm_buckets_kernel's launch
-// bounds) adds one resident affine point to its accumulator `iters` times, the additions chained as in a bucket's walk.  What this reaches
-// in mixed additions per second is the ceiling of THIS formulation (Jacobian + affine, mont256 products) on this chip; the multi-exponentiation's
-// distance from it is what its gathers, its sort and its reductions cost.
+// MEASUREMENT AID: the bucket pass's arithmetic without its gathers -- every lane of a 64-lane workgroup (msm_buckets_kernel's launch
+// bounds) adds ONE affine point to its register-resident accumulator `iters` times, the additions chained as in a bucket's walk; the point is
+// read where it lies, as in the pass (jmadd takes it by reference: a copy in registers would be spilled to scratch for the call), but it is
+// the same 64 bytes for every lane and step -- a cache hit, no HBM traffic.  What this reaches in mixed additions per second is the ceiling
+// of THIS formulation (Jacobian + affine, mont256 products) on this chip; the multi-exponentiation's distance from it is what its gathers,
+// its sort and its reductions cost.
 __global__ __launch_bounds__(64) void msm_resident_kernel(Jac* __restrict__ out, const Aff* __restrict__ point, const u32 lanes, const u32 iters)
 {
     const u32 gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= lanes) return;
-    const Aff q = point[0];
-    Jac acc = jmadd(jzero(), q);                               // q; the first addition below doubles, none after it meets q again
+    Jac acc; acc.x = point[0].x; acc.y = point[0].y; acc.z = fone();      // q; the first addition below doubles, none after it meets q again
 #pragma unroll 1
-    for (u32 k = 0; k < iters; k++) acc = jmadd(acc, q);       // (iters + 1) q
+    for (u32 k = 0; k < iters; k++) acc = jmadd_inl(acc, point[0]);       // (iters + 1) q
     out[gid] = acc;
 }
 
