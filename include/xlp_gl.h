@@ -327,7 +327,8 @@ int xlp_fft_bn254(uint64_t* data, uint64_t n, int inverse);
 /*   xlp_[dev_]msm_bn254        ParallelMultiexp<G1>::multiexp (src/ffiasm/multiexp.c.hpp:118-164, Curve::multiMulByScalar as called at
  *                              fflonk_prover.c.hpp:1700): out = sum_i scalars[i] * bases[i] on BN254 G1.  bases: n affine points, 8 words each
  *                              (x, y as Fq Montgomery limbs; (0, 0) = infinity, skipped); scalars: n x 4 words, raw little-endian 256-bit
- *                              integers; out: 8 words, the sum as an affine point ((0, 0) = infinity).  n < 2^27. */
+ *                              integers; out: 8 words, the sum as an affine point ((0, 0) = infinity).  n < 2^27.  The call returns with the sum
+ *                              in place: its last step (Horner over the window sums, one inversion) runs on the host. */
 int xlp_dev_msm_bn254(uint64_t* out, const uint64_t* bases, const uint64_t* scalars, uint64_t n);
 int xlp_msm_bn254(uint64_t* out, const uint64_t* bases, const uint64_t* scalars, uint64_t n);
 /* Measurement aids for the multi-exponentiation (SURVEY.md 8d applied to row f4): the window width xlp_[dev_]msm_bn254 picks for n points

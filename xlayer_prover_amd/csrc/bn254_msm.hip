@@ -14,7 +14,7 @@
 //   3. msm_buckets   one lane per non-empty-able bucket (w, digit != 0): Jacobian accumulator += its points (mixed addition)
 //   4. msm_groups    per window, 2^c / 64 lanes: running-sum trick on 64 consecutive buckets, then the group's offset * total;
 //      msm_window_sums: one workgroup per window folds the groups (LDS tree)
-//   5. msm_finish    one lane: Horner over the windows (c doublings each), Jacobian -> affine
+//   5. on the host: Horner over the windows (c doublings each), Jacobian -> affine (hostfq::finish; the call synchronises the stream)
 // Fq arithmetic: 8 x 32-bit limbs, Montgomery (R = 2^256), CIOS on v_mad_u64_u32 -- integer-VALU bound like everything else here.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -98,6 +98,9 @@ __device__ __noinline__ Fq fmul(const Fq a, const Fq b)        // mont256.hpp: p
     return r;
 }
 __device__ __forceinline__ Fq fsqr(const Fq& a) { return fmul(a, a); }
+// the product inlined: for the one addition formula that runs per (point, window) pair (jmadd_inl; 38 KB of kernel, fflonk 2^22 -1.7 % against calls)
+__device__ __forceinline__ Fq fmul_i(const Fq& a, const Fq& b) { Fq r; mont::mul<FqParams>(r.v, a.v, b.v); return r; }
+__device__ __forceinline__ Fq fsqr_i(const Fq& a) { return fmul_i(a, a); }
 
 struct Aff { Fq x, y; };            // (0, 0) = infinity
 struct Jac { Fq x, y, z; };         // z = 0 = infinity
@@ -122,13 +125,13 @@ __device__ __noinline__ Jac jdbl(const Jac& p)
     return r;
 }
 // madd-2007-bl with the exceptional cases.  jmadd_inl: inlined into the loops of the bucket kernels -- the accumulator and the temporaries
-// then live in the KERNEL's registers across the calls of fmul; as a function of its own it saves and restores ~100 callee-saved registers
+// then live in the KERNEL's registers; as a function of its own it saves and restores ~100 callee-saved registers
 // through scratch memory on every call (464 bytes of stack per lane) and hands its result back through memory.
 __device__ __forceinline__ Jac jmadd_inl(const Jac& p, const Aff& q)
 {
     if (ainf(q)) return p;
     if (jinf(p)) { Jac r; r.x = q.x; r.y = q.y; r.z = fone(); return r; }
-    const Fq Z1Z1 = fsqr(p.z), U2 = fmul(q.x, Z1Z1), S2 = fmul(fmul(q.y, p.z), Z1Z1);
+    const Fq Z1Z1 = fsqr_i(p.z), U2 = fmul_i(q.x, Z1Z1), S2 = fmul_i(fmul_i(q.y, p.z), Z1Z1);
     const Fq H = fsub(U2, p.x);
     Fq rr = fsub(S2, p.y);
     if (is_zero(H)) {
@@ -136,11 +139,11 @@ __device__ __forceinline__ Jac jmadd_inl(const Jac& p, const Aff& q)
         return jzero();
     }
     rr = fdbl(rr);
-    const Fq HH = fsqr(H), I = fdbl(fdbl(HH)), J = fmul(H, I), V = fmul(p.x, I);
+    const Fq HH = fsqr_i(H), I = fdbl(fdbl(HH)), J = fmul_i(H, I), V = fmul_i(p.x, I);
     Jac r;
-    r.x = fsub(fsub(fsqr(rr), J), fdbl(V));
-    r.y = fsub(fmul(rr, fsub(V, r.x)), fdbl(fmul(p.y, J)));
-    r.z = fsub(fsub(fsqr(fadd(p.z, H)), Z1Z1), HH);
+    r.x = fsub(fsub(fsqr_i(rr), J), fdbl(V));
+    r.y = fsub(fmul_i(rr, fsub(V, r.x)), fdbl(fmul_i(p.y, J)));
+    r.z = fsub(fsub(fsqr_i(fadd(p.z, H)), Z1Z1), HH);
     return r;
 }
 __device__ __noinline__ Jac jmadd(const Jac& p, const Aff& q) { return jmadd_inl(p, q); }
@@ -318,35 +321,6 @@ __global__ __launch_bounds__(64) void msm_groups_kernel(Jac* __restrict__ groups
     }
 }
 
-__device__ Fq finv(const Fq& a)          // a^(q - 2)
-{
-    const u32 e[8] = {0xd87cfd45u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
-    Fq r = fone();
-    for (int i = 255; i >= 0; i--) {
-        r = fsqr(r);
-        if ((e[i >> 5] >> (i & 31)) & 1) r = fmul(r, a);
-    }
-    return r;
-}
-
-__global__ void msm_finish_kernel(Aff* __restrict__ out, const Jac* __restrict__ wsum, const u32 nwin, const u32 c)
-{
-    if (blockIdx.x || threadIdx.x) return;
-    Jac r = jzero();
-    for (int w = (int)nwin - 1; w >= 0; w--) {          // Horner over the windows (multiexp.c.hpp:155-159)
-        for (u32 k = 0; k < c; k++) r = jdbl(r);
-        r = jadd(r, wsum[w]);
-    }
-    Aff a;
-    if (jinf(r)) { a.x = fzero(); a.y = fzero(); }
-    else {
-        const Fq zi = finv(r.z), zi2 = fsqr(zi);
-        a.x = fmul(r.x, zi2);
-        a.y = fmul(r.y, fmul(zi2, zi));
-    }
-    *out = a;
-}
-
 // per-window sum of the groups: one 256-lane workgroup per window, every lane folds its share, then an LDS tree
 __global__ __launch_bounds__(256) void msm_window_sums_kernel(Jac* __restrict__ wsum, const Jac* __restrict__ groups, const u32 nwin, const u32 gpw)
 {
@@ -380,6 +354,106 @@ __global__ __launch_bounds__(64) void msm_resident_kernel(Jac* __restrict__ out,
 }
 
 }  // namespace g1
+
+
+// The last step on the HOST: Horner over the <= 128 window sums (c doublings each, multiexp.c.hpp:155-159) and the conversion to affine are ~2 300
+// field products in ONE dependent chain -- 3.3 ms on one GPU lane (1.5 us per product), 0.15 ms on a host core.
+namespace hostfq {
+typedef unsigned __int128 u128;
+struct F { u64 v[4]; };
+struct J { F x, y, z; };
+static const u64 Q[4] = {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+static const u64 NP = 0x87d20782e4866389ULL;                       // -q^-1 mod 2^64
+static inline bool geq(const u64* t) { for (int i = 3; i >= 0; i--) if (t[i] != Q[i]) return t[i] > Q[i]; return true; }
+static inline void subq(u64* t) { u128 bw = 0; for (int i = 0; i < 4; i++) { const u128 d = (u128)t[i] - Q[i] - (u64)bw; t[i] = (u64)d; bw = (d >> 64) & 1; } }
+static F mul(const F& a, const F& b)                                // Montgomery product, R = 2^256 (the device's representation)
+{
+    u64 t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) { const u128 p = (u128)a.v[j] * b.v[i] + t[j] + (u64)c; t[j] = (u64)p; c = p >> 64; }
+        u128 s_ = (u128)t[4] + (u64)c; t[4] = (u64)s_; t[5] = (u64)(s_ >> 64);
+        const u64 m = t[0] * NP;
+        u128 p = (u128)m * Q[0] + t[0]; c = p >> 64;
+        for (int j = 1; j < 4; j++) { p = (u128)m * Q[j] + t[j] + (u64)c; t[j - 1] = (u64)p; c = p >> 64; }
+        s_ = (u128)t[4] + (u64)c; t[3] = (u64)s_; t[4] = t[5] + (u64)(s_ >> 64);
+    }
+    if (t[4] != 0 || geq(t)) subq(t);
+    return F{{t[0], t[1], t[2], t[3]}};
+}
+static F add(const F& a, const F& b)
+{
+    u64 t[4]; u128 c = 0;
+    for (int i = 0; i < 4; i++) { const u128 s_ = (u128)a.v[i] + b.v[i] + (u64)c; t[i] = (u64)s_; c = s_ >> 64; }
+    if (c || geq(t)) subq(t);
+    return F{{t[0], t[1], t[2], t[3]}};
+}
+static F sub(const F& a, const F& b)
+{
+    u64 t[4]; u128 bw = 0;
+    for (int i = 0; i < 4; i++) { const u128 d = (u128)a.v[i] - b.v[i] - (u64)bw; t[i] = (u64)d; bw = (d >> 64) & 1; }
+    if (bw) { u128 c = 0; for (int i = 0; i < 4; i++) { const u128 s_ = (u128)t[i] + Q[i] + (u64)c; t[i] = (u64)s_; c = s_ >> 64; } }
+    return F{{t[0], t[1], t[2], t[3]}};
+}
+static inline F dbl(const F& a) { return add(a, a); }
+static inline F sqr(const F& a) { return mul(a, a); }
+static inline bool zero(const F& a) { return (a.v[0] | a.v[1] | a.v[2] | a.v[3]) == 0; }
+static F one() { F x = {{1, 0, 0, 0}}; for (int i = 0; i < 256; i++) x = dbl(x); return x; }      // 2^256 mod q
+static J jdbl(const J& p)                                           // dbl-2009-l, as on the device
+{
+    if (zero(p.z)) return p;
+    const F A = sqr(p.x), B = sqr(p.y), C = sqr(B);
+    const F D = dbl(sub(sub(sqr(add(p.x, B)), A), C));
+    const F E = add(dbl(A), A), Fv = sqr(E);
+    J r;
+    r.x = sub(Fv, dbl(D));
+    r.y = sub(mul(E, sub(D, r.x)), dbl(dbl(dbl(C))));
+    r.z = dbl(mul(p.y, p.z));
+    return r;
+}
+static J jadd(const J& p, const J& q)                               // add-2007-bl with the exceptional cases, as on the device
+{
+    if (zero(q.z)) return p;
+    if (zero(p.z)) return q;
+    const F Z1Z1 = sqr(p.z), Z2Z2 = sqr(q.z);
+    const F U1 = mul(p.x, Z2Z2), U2 = mul(q.x, Z1Z1);
+    const F S1 = mul(mul(p.y, q.z), Z2Z2), S2 = mul(mul(q.y, p.z), Z1Z1);
+    const F H = sub(U2, U1);
+    F rr = sub(S2, S1);
+    if (zero(H)) {
+        if (zero(rr)) return jdbl(p);
+        J inf; inf.x = one(); inf.y = inf.x; inf.z = F{{0, 0, 0, 0}};
+        return inf;
+    }
+    rr = dbl(rr);
+    const F I = sqr(dbl(H)), Jv = mul(H, I), V = mul(U1, I);
+    J r;
+    r.x = sub(sub(sqr(rr), Jv), dbl(V));
+    r.y = sub(mul(rr, sub(V, r.x)), dbl(mul(S1, Jv)));
+    r.z = mul(sub(sub(sqr(add(p.z, q.z)), Z1Z1), Z2Z2), H);
+    return r;
+}
+static F inv(const F& a)                                            // a^(q - 2)
+{
+    const u64 e[4] = {Q[0] - 2, Q[1], Q[2], Q[3]};
+    F r = one();
+    for (int i = 255; i >= 0; i--) { r = sqr(r); if ((e[i >> 6] >> (i & 63)) & 1) r = mul(r, a); }
+    return r;
+}
+// out[8] (affine, Montgomery; (0, 0) = infinity) = sum_w 2^(c w) wsum[w]
+static void finish(u64* out, const J* wsum, u32 nwin, u32 c)
+{
+    J r; r.x = one(); r.y = r.x; r.z = F{{0, 0, 0, 0}};
+    for (int w = (int)nwin - 1; w >= 0; w--) {
+        for (u32 k = 0; k < c; k++) r = jdbl(r);
+        r = jadd(r, wsum[w]);
+    }
+    if (zero(r.z)) { for (int i = 0; i < 8; i++) out[i] = 0; return; }
+    const F zi = inv(r.z), zi2 = sqr(zi);
+    const F x = mul(r.x, zi2), y = mul(r.y, mul(zi2, zi));
+    for (int i = 0; i < 4; i++) { out[i] = x.v[i]; out[4 + i] = y.v[i]; }
+}
+}  // namespace hostfq
 
 // window width for n points (see the comment inside): shared by dev_msm_bn254 and the measurement aid below
 static u32 msm_window_bits(u64 n)
@@ -472,8 +546,14 @@ int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 
     hipLaunchKernelGGL(msm_heavy_fold_kernel, dim3((unsigned)(nheavy_max < 1024 ? nheavy_max : 1024)), dim3(256), 0, ctx->stream, buckets, part, heavy, hb);
     hipLaunchKernelGGL(msm_groups_kernel, dim3((nwin * gpw + 63) / 64), dim3(64), 0, ctx->stream, groups, buckets, nwin, c);
     hipLaunchKernelGGL(msm_window_sums_kernel, dim3(nwin), dim3(256), 0, ctx->stream, wsum, groups, nwin, gpw);
-    hipLaunchKernelGGL(msm_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, (Aff*)out, wsum, nwin, c);
     XLP_HIP(hipGetLastError());
+    hostfq::J hw[128];                                                // (nwin <= 128: c >= 2)
+    u64 res[8];
+    XLP_HIP(hipMemcpyAsync(hw, wsum, (size_t)nwin * sizeof(Jac), hipMemcpyDeviceToHost, ctx->stream));
+    XLP_HIP(hipStreamSynchronize(ctx->stream));
+    hostfq::finish(res, hw, nwin, c);
+    XLP_HIP(hipMemcpyAsync(out, res, sizeof res, hipMemcpyHostToDevice, ctx->stream));
+    XLP_HIP(hipStreamSynchronize(ctx->stream));                       // (res lives on this stack)
     return 0;
 }
 
