@@ -528,8 +528,9 @@ int xlp_dev_alloc(void** ptr, size_t bytes);
  * (host/starks.hpp: the extended constant polynomials, 31 GB at the zkEVM geometry -- starks.hpp:138-146 keeps them loaded). */
 int xlp_dev_mem_info(size_t* free_bytes, size_t* total_bytes);
 int xlp_dev_free(void* ptr);
-/* Give back grow-only scratch of the context (bit k of mask = slot k; 0xFF = all): for a stage that grew much of it and shares the card with
- * others -- the fflonk prover releases its transform / scan / multi-exponentiation scratch (slots 3, 4, 5, 7) after a final proof. */
+/* Give back grow-only scratch of the context (bit k of mask = slot k, k < 9; 0x1FF = all): for a stage that grew much of it and shares the card
+ * with others -- the fflonk prover releases its transform / scan / multi-exponentiation scratch (slots 8, 4, 5, 7) after a final proof.  Slot 8 holds
+ * the twiddle table xlp_[dev_]fft_bn254 keeps from call to call; releasing or lending it drops the table. */
 int xlp_scratch_release(uint32_t mask);
 /* Let a scratch slot use a caller-owned DEVICE region instead of growing its own (dev_ptr = NULL takes it back); a request the region cannot
  * hold falls through to the slot's own scratch.  The fflonk prover in reserved-memory mode lends the rest of its region to the transform /

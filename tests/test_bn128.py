@@ -524,3 +524,34 @@ def test_gpu_msm_resident_ceiling_kernel_adds_what_it_says(xlp):
         zi = pow(Z, -1, bo.Q_MOD)
         assert ((X * zi * zi) % bo.Q_MOD, (Y * zi * zi * zi) % bo.Q_MOD) == bo.g1_mul(P, iters + 1)
     assert 2 <= xlp.load().xlp_msm_bn254_window_bits(1 << 22) <= 22
+
+
+@pytest.mark.gpu
+def test_gpu_fft_bn254_twiddle_table_is_kept_and_shared_between_sizes(xlp):
+    """xlp_[dev_]fft_bn254 keeps its table of twiddles in scratch slot 8: a transform after a LARGER one reads the larger table with a
+    stride, a transform after a release / a lend rebuilds it -- all equal the oracle"""
+    import torch
+    rng = np.random.default_rng(77)
+
+    def check(logn):
+        n = 1 << logn
+        a = [int.from_bytes(rng.bytes(32), "little") % bo.R_MOD for _ in range(n)]
+        limbs = np.array([bo.to_mont_limbs(x) for x in a], dtype=np.uint64)
+        got = xlp.fft_bn254(limbs)
+        assert [bo.from_mont_limbs(r) for r in got] == bo.fft(a)
+        assert (xlp.fft_bn254(got, inverse=True) == limbs).all()
+
+    xlp.scratch_release(1 << 8)
+    check(6)                                    # builds the 2^6 table
+    check(11)                                   # grows it
+    check(6); check(9); check(1)                # smaller domains on the 2^11 table (9: stages through HBM)
+    region = torch.zeros(1 << 16, dtype=torch.int64, device="cuda")          # 512 KiB: holds the 2^11 table (32 KiB), not a 2^15 one
+    xlp.scratch_lend(8, region)
+    check(10)                                   # rebuilt inside the lent region
+    assert int((region != 0).sum()) > 0
+    check(15)                                   # does not fit the region: the slot's own scratch
+    check(10)
+    xlp.scratch_lend(8, None)
+    check(7)
+    xlp.scratch_release(1 << 8)
+    check(8)

@@ -354,7 +354,7 @@ __global__ void fr_bitrev_kernel(Fr* __restrict__ a, const u32 logn)
 
 // stages 1..LB of FFT::fft on one block of 2^LB consecutive elements held in LDS (the butterflies of those stages stay inside the block)
 constexpr int FFT_LB = 8;
-__global__ __launch_bounds__(1 << (FFT_LB - 1)) void fr_fft_low_kernel(Fr* __restrict__ a, const Fr* __restrict__ tw, const u32 logn, const u32 nst)
+__global__ __launch_bounds__(1 << (FFT_LB - 1)) void fr_fft_low_kernel(Fr* __restrict__ a, const Fr* __restrict__ tw, const u32 tl, const u32 nst)
 {
     __shared__ u32 sm[8 << FFT_LB];                 // [limb][element]
     const u32 tid = threadIdx.x, B = 1u << nst;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(1 << (FFT_LB - 1)) void fr_fft_low_kernel(Fr* __res
             Fr u, v;
 #pragma unroll
             for (int l = 0; l < 8; l++) { u.v[l] = sm[l * (1 << FFT_LB) + k + j]; v.v[l] = sm[l * (1 << FFT_LB) + k + j + mdiv2]; }
-            const Fr t = mul1(gld(&tw[(u64)j << (logn - s)]), v);
+            const Fr t = mul1(gld(&tw[(u64)j << (tl - s)]), v);          // root(s, j) in the table of the 2^tl-th root
             const Fr x = add(u, t), y = sub(u, t);
 #pragma unroll
             for (int l = 0; l < 8; l++) { sm[l * (1 << FFT_LB) + k + j] = x.v[l]; sm[l * (1 << FFT_LB) + k + j + mdiv2] = y.v[l]; }
@@ -388,13 +388,13 @@ __global__ __launch_bounds__(1 << (FFT_LB - 1)) void fr_fft_low_kernel(Fr* __res
 }
 
 // one stage s > LB of FFT::fft (fft.c.hpp:186-201) through HBM
-__global__ void fr_fft_stage_kernel(Fr* __restrict__ a, const Fr* __restrict__ tw, const u32 logn, const u32 s)
+__global__ void fr_fft_stage_kernel(Fr* __restrict__ a, const Fr* __restrict__ tw, const u32 logn, const u32 s, const u32 tl)
 {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >> (logn - 1)) return;
     const u64 mdiv2 = 1ull << (s - 1);
     const u64 k = (i >> (s - 1)) << s, j = i & (mdiv2 - 1);
-    const Fr t = mul1(gld(&tw[j << (logn - s)]), gld(&a[k + j + mdiv2]));
+    const Fr t = mul1(gld(&tw[j << (tl - s)]), gld(&a[k + j + mdiv2]));
     const Fr u = gld(&a[k + j]);
     gst(&a[k + j], add(u, t));
     gst(&a[k + j + mdiv2], sub(u, t));
@@ -402,18 +402,18 @@ __global__ void fr_fft_stage_kernel(Fr* __restrict__ a, const Fr* __restrict__ t
 
 // stages s and s + 1 of FFT::fft in one pass through HBM (half the traffic of two radix-2 passes): the four elements
 // k + j + {0, h, 2h, 3h}, h = 2^(s-1), carry both butterflies (same four products)
-__global__ void fr_fft_stage2_kernel(Fr* __restrict__ a, const Fr* __restrict__ tw, const u32 logn, const u32 s)
+__global__ void fr_fft_stage2_kernel(Fr* __restrict__ a, const Fr* __restrict__ tw, const u32 logn, const u32 s, const u32 tl)
 {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >> (logn - 2)) return;
     const u64 h = 1ull << (s - 1);
     const u64 k = (i >> (s - 1)) << (s + 1), j = i & (h - 1);
     Fr* p = a + k + j;
-    const Fr w1 = gld(&tw[j << (logn - s)]);                         // root(s, j)
+    const Fr w1 = gld(&tw[j << (tl - s)]);                           // root(s, j)
     const Fr x0 = gld(&p[0]), x1 = mul1(w1, gld(&p[h])), x2 = gld(&p[2 * h]), x3 = mul1(w1, gld(&p[3 * h]));
     const Fr y0 = add(x0, x1), y1 = sub(x0, x1), y2 = add(x2, x3), y3 = sub(x2, x3);
-    const Fr t2 = mul1(gld(&tw[j << (logn - s - 1)]), y2);           // root(s + 1, j)
-    const Fr t3 = mul1(gld(&tw[(j + h) << (logn - s - 1)]), y3);     // root(s + 1, j + h)
+    const Fr t2 = mul1(gld(&tw[j << (tl - s - 1)]), y2);             // root(s + 1, j)
+    const Fr t3 = mul1(gld(&tw[(j + h) << (tl - s - 1)]), y3);       // root(s + 1, j + h)
     gst(&p[0], add(y0, t2));
     gst(&p[2 * h], sub(y0, t2));
     gst(&p[h], add(y1, t3));
@@ -692,31 +692,40 @@ int dev_fft_bn254(Ctx* ctx, u64* data, u64 n, int inverse)
     if (logn > 28) return xlp_fail("fft_bn254: domain too big for the curve (2-adicity 28)");
     bn::Fr* a = (bn::Fr*)data;
     if (logn == 0) return 0;
-    // (q - 1) >> logn
-    u64 e[4];
-    {
-        u64 qm1[4] = {hfr::Q[0] - 1, hfr::Q[1], hfr::Q[2], hfr::Q[3]};
-        for (int i = 0; i < 4; i++) e[i] = (qm1[i] >> logn) | (i < 3 && logn ? qm1[i + 1] << (64 - logn) : 0);
+    // The table of twiddles w^j (j < n / 2) lives in a scratch slot of its own and is kept from call to call: a table built for a larger domain
+    // serves a smaller one (root(s, j) = w_L^(j << (L - s))).  (Until round 4 every call rebuilt it: 0.9 ms of a 5.7 ms transform at 2^24.)
+    u32 tl = ctx->fft_tw_log >= logn ? ctx->fft_tw_log : logn;
+    u64* tslot = nullptr;
+    if (ctx_scratch(ctx, ((1ull << (tl - 1)) + 32) * sizeof(bn::Fr), 8, &tslot)) return -1;
+    bn::Fr* tw = (bn::Fr*)tslot;
+    if (ctx->fft_tw_log < logn || ctx->fft_tw_ptr != (const void*)tslot) {
+        tl = logn;
+        const u64 half_t = 1ull << (tl - 1);
+        u64 e[4];                                   // (q - 1) >> tl
+        {
+            u64 qm1[4] = {hfr::Q[0] - 1, hfr::Q[1], hfr::Q[2], hfr::Q[3]};
+            for (int i = 0; i < 4; i++) e[i] = (qm1[i] >> tl) | (i < 3 && tl ? qm1[i + 1] << (64 - tl) : 0);
+        }
+        hfr::E w = hfr::pow(hfr::from_u64(5), e);
+        std::vector<bn::Fr> wpow(tl);
+        for (u32 k = 0; k < tl; k++) { wpow[k] = to_dev(w); w = hfr::mont(w, w); }
+        bn::Fr* d_wpow = tw + half_t;
+        XLP_HIP(hipMemcpyAsync(d_wpow, wpow.data(), tl * sizeof(bn::Fr), hipMemcpyHostToDevice, ctx->stream));
+        XLP_HIP(hipStreamSynchronize(ctx->stream));       // wpow is a host temporary
+        hipLaunchKernelGGL(bn::fr_twiddle_kernel, dim3((unsigned)((half_t + 255) / 256)), dim3(256), 0, ctx->stream, tw, half_t, d_wpow, to_dev(hfr::from_u64(1)));
+        XLP_HIP(hipGetLastError());
+        ctx->fft_tw_log = tl;
+        ctx->fft_tw_ptr = (const void*)tslot;
     }
-    hfr::E w = hfr::pow(hfr::from_u64(5), e);
-    std::vector<bn::Fr> wpow(logn);
-    for (u32 k = 0; k < logn; k++) { wpow[k] = to_dev(w); w = hfr::mont(w, w); }
     const u64 half = n >> 1;
-    u64* scratch = nullptr;
-    if (ctx_scratch(ctx, (half + 32) * sizeof(bn::Fr), 3, &scratch)) return -1;
-    bn::Fr* tw = (bn::Fr*)scratch;
-    bn::Fr* d_wpow = tw + half;
-    XLP_HIP(hipMemcpyAsync(d_wpow, wpow.data(), logn * sizeof(bn::Fr), hipMemcpyHostToDevice, ctx->stream));
-    XLP_HIP(hipStreamSynchronize(ctx->stream));       // wpow is a host temporary
-    hipLaunchKernelGGL(bn::fr_twiddle_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, ctx->stream, tw, half, d_wpow, to_dev(hfr::from_u64(1)));
     hipLaunchKernelGGL(bn::fr_bitrev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, logn);
     const u32 nst = logn < (u32)bn::FFT_LB ? logn : (u32)bn::FFT_LB;
-    hipLaunchKernelGGL(bn::fr_fft_low_kernel, dim3((unsigned)(n >> nst)), dim3(1 << (bn::FFT_LB - 1)), 0, ctx->stream, a, tw, logn, nst);
+    hipLaunchKernelGGL(bn::fr_fft_low_kernel, dim3((unsigned)(n >> nst)), dim3(1 << (bn::FFT_LB - 1)), 0, ctx->stream, a, tw, tl, nst);
     u32 s = nst + 1;
     for (; s + 1 <= logn; s += 2)
-        hipLaunchKernelGGL(bn::fr_fft_stage2_kernel, dim3((unsigned)(((n >> 2) + 255) / 256)), dim3(256), 0, ctx->stream, a, tw, logn, s);
+        hipLaunchKernelGGL(bn::fr_fft_stage2_kernel, dim3((unsigned)(((n >> 2) + 255) / 256)), dim3(256), 0, ctx->stream, a, tw, logn, s, tl);
     if (s <= logn)
-        hipLaunchKernelGGL(bn::fr_fft_stage_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, ctx->stream, a, tw, logn, s);
+        hipLaunchKernelGGL(bn::fr_fft_stage_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, ctx->stream, a, tw, logn, s, tl);
     if (inverse) {
         // 1 / n = 2^-logn: (q + 1) / 2 raised to logn
         hfr::E inv2 = hfr::from_u64(2);

@@ -170,8 +170,9 @@ int xlp_scratch_lend(uint32_t slot, void* dev_ptr, size_t bytes)
 {
     XLP_ENTER;
     if (ensure_init()) return -1;
-    if (slot >= 8) return xlp_fail("xlp_scratch_lend: slot 0..7");
+    if (slot >= 9) return xlp_fail("xlp_scratch_lend: slot 0..8");
     XLP_HIP(hipStreamSynchronize(g_ctx.stream));
+    if (slot == 8) { g_ctx.fft_tw_log = 0; g_ctx.fft_tw_ptr = nullptr; }
     g_ctx.lent[slot] = dev_ptr;
     g_ctx.lent_bytes[slot] = dev_ptr ? bytes : 0;
     return 0;
@@ -181,11 +182,12 @@ int xlp_scratch_release(uint32_t mask)
     XLP_ENTER;
     if (!g_ctx.inited) return 0;
     XLP_HIP(hipStreamSynchronize(g_ctx.stream));
-    for (int k = 0; k < 8; k++)
+    for (int k = 0; k < 9; k++)
         if (((mask >> k) & 1) && g_ctx.scratch[k]) {
             XLP_HIP(hipFree(g_ctx.scratch[k]));
             g_ctx.scratch[k] = nullptr;
             g_ctx.scratch_bytes[k] = 0;
+            if (k == 8) { g_ctx.fft_tw_log = 0; g_ctx.fft_tw_ptr = nullptr; }
         }
     return 0;
 }
@@ -297,11 +299,12 @@ void xlp_shutdown(void)
     (void)hipStreamSynchronize(g_ctx.stream);
     for (auto& kv : g_ctx.tables) (void)hipFree(kv.second);
     g_ctx.tables.clear();
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < 9; i++) {
         if (g_ctx.scratch[i]) (void)hipFree(g_ctx.scratch[i]);
         g_ctx.scratch[i] = nullptr;
         g_ctx.scratch_bytes[i] = 0;
     }
+    g_ctx.fft_tw_log = 0; g_ctx.fft_tw_ptr = nullptr;
     if (g_ctx.selected != 0) { g_ctx.stream = g_ctx.main_stream; g_ctx.selected = 0; }
     for (int i = 0; i < 8; i++) { if (g_marks[i]) (void)hipEventDestroy(g_marks[i]); g_marks[i] = nullptr; g_marked[i] = false; }
     commit_times_clear();

@@ -49,10 +49,14 @@ struct Ctx {
     hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};   // more compute streams: the slabs of a step program go round them (dev_expr_run)
     hipStream_t copy_stream = nullptr;      // host <-> device transfers that overlap kernels on `stream` (xlp_dev_commit_from_host)
     std::map<std::tuple<u32, u64, u64>, u64*> tables;  // (L, root, mult) -> device power tables
-    void* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    void* lent[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // caller-owned regions standing in for a slot (xlp_scratch_lend)
-    size_t lent_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void* scratch[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};      // slot 8: the BN254 transform's twiddle table, nobody else's
+    size_t scratch_bytes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    void* lent[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // caller-owned regions standing in for a slot (xlp_scratch_lend)
+    size_t lent_bytes[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // the table slot 8 holds: w^j, j < 2^(fft_tw_log - 1), w the 2^fft_tw_log-th root, at fft_tw_ptr (0 / null: none).  Kept across calls of
+    // xlp_[dev_]fft_bn254; dropped when the slot is released, lent or taken back.
+    u32 fft_tw_log = 0;
+    const void* fft_tw_ptr = nullptr;
     bool inited = false;
     u32 ncu = 256;             // compute units of the bound device (persistent-kernel grid size)
     // optional per-kernel timing of the LDE fast path (xlp_profile_*): HIP events on ctx->stream

@@ -556,14 +556,14 @@ public:
         lastTimers.clear();
         if (reserved) {
             timed("FFLONK_KEY_TO_DEVICE", [&] { deviceSetup(); });
-            // what is left of the region serves as the library's scratch for the proof: transforms (slot 3), scans / evaluations (4), multi-exponentiation (7)
+            // what is left of the region serves as the library's scratch for the proof: the transforms' twiddle table (slot 8), scans / evaluations (4), multi-exponentiation (7)
             auto lend = [&](uint32_t slot, uint64_t bytes) {
                 const uint64_t at_ = (reservedUsed + 255) & ~255ULL;
                 if (at_ + bytes > reservedBytes) return;               // (too small: the slot grows its own scratch and it is released below)
                 XLP_CHECK(xlp_scratch_lend(slot, reserved + at_, bytes));
                 reservedUsed = at_ + bytes;
             };
-            lend(3, 80 * N + (1 << 12));
+            lend(8, 80 * N + (1 << 12));
             lend(4, 128 * N + (1 << 20));
             const uint64_t at_ = (reservedUsed + 255) & ~255ULL;
             if (at_ < reservedBytes) XLP_CHECK(xlp_scratch_lend(7, reserved + at_, reservedBytes - at_));
@@ -588,8 +588,8 @@ public:
         timed("FFLONK_ROUND_5", [&] { round5(); });
         evaluationCommitments["inv"] = getMontgomeryBatchedInverse();
         if (reserved) {                                                 // the card goes back to the STARKs as it was
-            for (uint32_t slot : {3u, 4u, 7u}) XLP_CHECK(xlp_scratch_lend(slot, NULL, 0));
-            XLP_CHECK(xlp_scratch_release((1u << 3) | (1u << 4) | (1u << 5) | (1u << 7)));
+            for (uint32_t slot : {8u, 4u, 7u}) XLP_CHECK(xlp_scratch_lend(slot, NULL, 0));
+            XLP_CHECK(xlp_scratch_release((1u << 8) | (1u << 4) | (1u << 5) | (1u << 7)));
         }
         std::string pub = "[";
         for (uint32_t i = 1; i <= zkey->nPublic; i++) pub += std::string(i > 1 ? "," : "") + "\"" + FrH::toString(FrH::toMontgomery(wit[i])) + "\"";      // :546-553
