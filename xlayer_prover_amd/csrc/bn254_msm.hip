@@ -226,7 +226,7 @@ __global__ void msm_starts_kernel(u32* __restrict__ start, u32* __restrict__ sto
 // 9 x 2^22 / 4 points each -- 1 s of three lonely workgroups) spreads over the chip.
 // heavy[0] = segments so far, heavy[1] = heavy buckets so far; hb[3 i ..] = (key, first segment, segments); hs[2 e ..] = (key, segment)
 constexpr u32 HEAVY = 256;
-constexpr u32 SEG = 4096;
+constexpr u32 SEG = 16384;     // (64 additions per lane before the 8-level tree of full additions; 4 096: the same wall time at 9 x 2^22 points)
 // cnt[key] = points of the bucket, capped (the sort key that puts buckets of like size into the same wavefront)
 __global__ void msm_counts_kernel(u32* __restrict__ cnt, u32* __restrict__ ids, const u32* __restrict__ start, const u32* __restrict__ stop, const u32 nkeys, const u32 c)
 {
@@ -264,7 +264,7 @@ __device__ __forceinline__ Jac block_sum_256(Jac acc, Jac* sh, const u32 t)
     sh[t] = acc;
     __syncthreads();
     for (u32 step = 128; step >= 1; step >>= 1) {
-        if (t < step) sh[t] = jadd(sh[t], sh[t + step]);
+        if (t < step) sh[t] = jadd_inl(sh[t], sh[t + step]);
         __syncthreads();
     }
     const Jac r = sh[0];
