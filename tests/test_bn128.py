@@ -210,7 +210,7 @@ def test_oracle_fft_is_the_dft_and_inverts():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("logn", [0, 1, 2, 5, 8, 9, 12, 14])
+@pytest.mark.parametrize("logn", [0, 1, 2, 5, 8, 9, 10, 12, 14, 16, 17])
 def test_gpu_fft_bn254_vs_oracle(xlp, logn):
     rng = np.random.default_rng(300 + logn)
     n = 1 << logn

@@ -387,37 +387,47 @@ __global__ __launch_bounds__(1 << (FFT_LB - 1)) void fr_fft_low_kernel(Fr* __res
     }
 }
 
-// one stage s > LB of FFT::fft (fft.c.hpp:186-201) through HBM
-__global__ void fr_fft_stage_kernel(Fr* __restrict__ a, const Fr* __restrict__ tw, const u32 logn, const u32 s, const u32 tl)
+// stages s0 + 1 .. s0 + nst (nst <= 8) of FFT::fft in ONE pass through HBM: index = hi * 2^(s0 + nst) + m * 2^s0 + lo; a workgroup holds, for one hi,
+// all 2^nst values of m for T consecutive lo (T * 2^nst = 2^FFT_MB elements in LDS, rows of T x 32 bytes in HBM) -- the butterflies of those stages pair
+// values of m only.  (Until round 4 these stages went two at a time through HBM: 8 passes over 2^24 elements instead of 2; 4.35 -> 3.62 ms, the rest is the
+// 24 x 2^23 Montgomery products themselves.)
+constexpr int FFT_MB = 10;
+__global__ __launch_bounds__(256) void fr_fft_mid_kernel(Fr* __restrict__ a, const Fr* __restrict__ tw, const u32 s0, const u32 nst, const u32 lt, const u32 tl)
 {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >> (logn - 1)) return;
-    const u64 mdiv2 = 1ull << (s - 1);
-    const u64 k = (i >> (s - 1)) << s, j = i & (mdiv2 - 1);
-    const Fr t = mul1(gld(&tw[j << (tl - s)]), gld(&a[k + j + mdiv2]));
-    const Fr u = gld(&a[k + j]);
-    gst(&a[k + j], add(u, t));
-    gst(&a[k + j + mdiv2], sub(u, t));
-}
-
-// stages s and s + 1 of FFT::fft in one pass through HBM (half the traffic of two radix-2 passes): the four elements
-// k + j + {0, h, 2h, 3h}, h = 2^(s-1), carry both butterflies (same four products)
-__global__ void fr_fft_stage2_kernel(Fr* __restrict__ a, const Fr* __restrict__ tw, const u32 logn, const u32 s, const u32 tl)
-{
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >> (logn - 2)) return;
-    const u64 h = 1ull << (s - 1);
-    const u64 k = (i >> (s - 1)) << (s + 1), j = i & (h - 1);
-    Fr* p = a + k + j;
-    const Fr w1 = gld(&tw[j << (tl - s)]);                           // root(s, j)
-    const Fr x0 = gld(&p[0]), x1 = mul1(w1, gld(&p[h])), x2 = gld(&p[2 * h]), x3 = mul1(w1, gld(&p[3 * h]));
-    const Fr y0 = add(x0, x1), y1 = sub(x0, x1), y2 = add(x2, x3), y3 = sub(x2, x3);
-    const Fr t2 = mul1(gld(&tw[j << (tl - s - 1)]), y2);             // root(s + 1, j)
-    const Fr t3 = mul1(gld(&tw[(j + h) << (tl - s - 1)]), y3);       // root(s + 1, j + h)
-    gst(&p[0], add(y0, t2));
-    gst(&p[2 * h], sub(y0, t2));
-    gst(&p[h], add(y1, t3));
-    gst(&p[3 * h], sub(y1, t3));
+    __shared__ u32 sm[8 << FFT_MB];                 // [limb][m * T + l]
+    const u32 tid = threadIdx.x, T = 1u << lt, E = 1u << (nst + lt);
+    const u64 tiles = 1ull << (s0 - lt);            // tiles of T consecutive lo per hi
+    const u64 hi = blockIdx.x / tiles, lo0 = (blockIdx.x % tiles) << lt;
+    Fr* base = a + (hi << (s0 + nst)) + lo0;
+    for (u32 e = tid; e < E; e += 256) {
+        const Fr x = gld(&base[((u64)(e >> lt) << s0) + (e & (T - 1))]);
+#pragma unroll
+        for (int l = 0; l < 8; l++) sm[l * (1 << FFT_MB) + e] = x.v[l];
+    }
+    __syncthreads();
+    for (u32 t = 1; t <= nst; t++) {
+        const u32 half = 1u << (t - 1);
+        for (u32 i = tid; i < (E >> 1); i += 256) {
+            const u32 im = i >> lt, l = i & (T - 1);
+            const u32 mlow = im & (half - 1), m = ((im >> (t - 1)) << t) | mlow;
+            const u32 e0 = (m << lt) | l, e1 = e0 + (half << lt);
+            Fr u, v;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { u.v[k] = sm[k * (1 << FFT_MB) + e0]; v.v[k] = sm[k * (1 << FFT_MB) + e1]; }
+            const u64 j = ((u64)mlow << s0) + lo0 + l;                                       // position inside the half-group of stage s0 + t
+            const Fr w = mul1(gld(&tw[j << (tl - s0 - t)]), v);
+            const Fr x = add(u, w), y = sub(u, w);
+#pragma unroll
+            for (int k = 0; k < 8; k++) { sm[k * (1 << FFT_MB) + e0] = x.v[k]; sm[k * (1 << FFT_MB) + e1] = y.v[k]; }
+        }
+        __syncthreads();
+    }
+    for (u32 e = tid; e < E; e += 256) {
+        Fr x;
+#pragma unroll
+        for (int l = 0; l < 8; l++) x.v[l] = sm[l * (1 << FFT_MB) + e];
+        gst(&base[((u64)(e >> lt) << s0) + (e & (T - 1))], x);
+    }
 }
 
 // the tail of FFT::ifft (fft.c.hpp:205-221): a[i] <-> a[n - i], everything times 1 / n
@@ -721,11 +731,14 @@ int dev_fft_bn254(Ctx* ctx, u64* data, u64 n, int inverse)
     hipLaunchKernelGGL(bn::fr_bitrev_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, a, logn);
     const u32 nst = logn < (u32)bn::FFT_LB ? logn : (u32)bn::FFT_LB;
     hipLaunchKernelGGL(bn::fr_fft_low_kernel, dim3((unsigned)(n >> nst)), dim3(1 << (bn::FFT_LB - 1)), 0, ctx->stream, a, tw, tl, nst);
-    u32 s = nst + 1;
-    for (; s + 1 <= logn; s += 2)
-        hipLaunchKernelGGL(bn::fr_fft_stage2_kernel, dim3((unsigned)(((n >> 2) + 255) / 256)), dim3(256), 0, ctx->stream, a, tw, logn, s, tl);
-    if (s <= logn)
-        hipLaunchKernelGGL(bn::fr_fft_stage_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, ctx->stream, a, tw, logn, s, tl);
+    // the stages above the first LDS pass, up to 8 at a time (fr_fft_mid_kernel); s0 = stages done so far
+    for (u32 s0 = nst; s0 < logn;) {
+        const u32 m = logn - s0 < 8 ? logn - s0 : 8;                       // stages of this pass
+        u32 lt = (u32)bn::FFT_MB - m;                                       // log2 T: the tile is 2^FFT_MB elements ...
+        if (lt > s0) lt = s0;                                               // ... when that many consecutive lo exist
+        hipLaunchKernelGGL(bn::fr_fft_mid_kernel, dim3((unsigned)(n >> (m + lt))), dim3(256), 0, ctx->stream, a, tw, s0, m, lt, tl);
+        s0 += m;
+    }
     if (inverse) {
         // 1 / n = 2^-logn: (q + 1) / 2 raised to logn
         hfr::E inv2 = hfr::from_u64(2);
