@@ -181,7 +181,7 @@ __device__ __forceinline__ void mix_lazy_rows(u32* st, const int t, const Fr* __
 
 // Poseidon_opt::hash(vector<FrElement>& state) (poseidon_opt.cpp:9-66) on the lane's LDS state, t = 2..17
 template <int MT>
-__device__ __noinline__ void permute(u32* st, const int t, const Tables& K)
+__device__ __forceinline__ void permute(u32* st, const int t, const Tables& K)
 {
     const int k = t - 2;
     const Fr* __restrict__ c = K.C[k];
