@@ -224,8 +224,9 @@ __device__ __forceinline__ void permute(u32* st, const int t, const Tables& K)
 
 // ----------------------------------------------------------------- kernels
 // leaves: MerkleTreeBN128::linearHash (merkleTreeBN128.cpp:89-157), one row per lane
+// (MT = 5: rows of up to 12 columns -- recursivef's cm1 -- hash with t = 5; 10 KB of LDS per wavefront: 16 of them per CU instead of 10 with MT = 8)
 template <int MT>
-__global__ __launch_bounds__(WAVE, MT <= 8 ? 2 : 1) void bn128_leaf_kernel(Fr* __restrict__ nodes, const u64* __restrict__ src, const u64 w, const u64 h, const Tables K)
+__global__ __launch_bounds__(WAVE, MT <= 5 ? 3 : MT <= 8 ? 2 : 1) void bn128_leaf_kernel(Fr* __restrict__ nodes, const u64* __restrict__ src, const u64 w, const u64 h, const Tables K)
 {
     __shared__ u32 lds[MT * 8 * WAVE];
     u32* st = lds + threadIdx.x;
@@ -601,7 +602,8 @@ int dev_merkle_bn128(Ctx* ctx, u64* nodes, const u64* src, u64 w, u64 h)
     bn::Fr* nd = (bn::Fr*)nodes;
     XLP_HIP(hipMemsetAsync(nd, 0, bn128_num_nodes(h) * sizeof(bn::Fr), ctx->stream));     // calloc'ed in the reference: padding slots stay zero
     const u64 nfr = (w + 2) / 3;          // Fr elements per leaf: a leaf hashes min(nfr, 16) + 1 elements at a time
-    if (w > 4 && nfr <= 7) hipLaunchKernelGGL(bn::bn128_leaf_kernel<8>, dim3((unsigned)((h + bn::WAVE - 1) / bn::WAVE)), dim3(bn::WAVE), 0, ctx->stream, nd, src, w, h, g_bn_tables);
+    if (w > 4 && nfr <= 4) hipLaunchKernelGGL(bn::bn128_leaf_kernel<5>, dim3((unsigned)((h + bn::WAVE - 1) / bn::WAVE)), dim3(bn::WAVE), 0, ctx->stream, nd, src, w, h, g_bn_tables);
+    else if (w > 4 && nfr <= 7) hipLaunchKernelGGL(bn::bn128_leaf_kernel<8>, dim3((unsigned)((h + bn::WAVE - 1) / bn::WAVE)), dim3(bn::WAVE), 0, ctx->stream, nd, src, w, h, g_bn_tables);
     else hipLaunchKernelGGL(bn::bn128_leaf_kernel<bn::MAXT>, dim3((unsigned)((h + bn::WAVE - 1) / bn::WAVE)), dim3(bn::WAVE), 0, ctx->stream, nd, src, w, h, g_bn_tables);
     XLP_HIP(hipGetLastError());
     u64 n256 = h, cursor = 0, cursor_next = h;
