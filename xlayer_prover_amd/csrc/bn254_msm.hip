@@ -109,8 +109,9 @@ __device__ __forceinline__ Jac jzero() { Jac p; p.x = fone(); p.y = fone(); p.z 
 __device__ __forceinline__ bool jinf(const Jac& p) { return is_zero(p.z); }
 __device__ __forceinline__ bool ainf(const Aff& p) { return is_zero(p.x) && is_zero(p.y); }
 
-// dbl-2009-l (a = 0)
-__device__ __noinline__ Jac jdbl(const Jac& p)
+// dbl-2009-l (a = 0).  jdbl_inl: for the rare equal-points branch of jmadd_inl -- as a CALL there, the callee's register budget became the bucket
+// kernels' (196 registers, 2 wavefronts per SIMD; inlined: 128, 4 wavefronts)
+__device__ __forceinline__ Jac jdbl_inl(const Jac& p)
 {
     if (jinf(p)) return p;
     const Fq A = fsqr(p.x), B = fsqr(p.y), C = fsqr(B);
@@ -124,6 +125,7 @@ __device__ __noinline__ Jac jdbl(const Jac& p)
     r.z = fdbl(fmul(p.y, p.z));
     return r;
 }
+__device__ __noinline__ Jac jdbl(const Jac& p) { return jdbl_inl(p); }
 // madd-2007-bl with the exceptional cases.  jmadd_inl: inlined into the loops of the bucket kernels -- the accumulator and the temporaries
 // then live in the KERNEL's registers; as a function of its own it saves and restores ~100 callee-saved registers
 // through scratch memory on every call (464 bytes of stack per lane) and hands its result back through memory.
@@ -135,7 +137,7 @@ __device__ __forceinline__ Jac jmadd_inl(const Jac& p, const Aff& q)
     const Fq H = fsub(U2, p.x);
     Fq rr = fsub(S2, p.y);
     if (is_zero(H)) {
-        if (is_zero(rr)) { Jac t; t.x = q.x; t.y = q.y; t.z = fone(); return jdbl(t); }
+        if (is_zero(rr)) { Jac t; t.x = q.x; t.y = q.y; t.z = fone(); return jdbl_inl(t); }
         return jzero();
     }
     rr = fdbl(rr);
