@@ -160,7 +160,7 @@ __device__ __forceinline__ Jac jadd_inl(const Jac& p, const Jac& q)
     const Fq H = fsub(U2, U1);
     Fq rr = fsub(S2, S1);
     if (is_zero(H)) {
-        if (is_zero(rr)) return jdbl(p);
+        if (is_zero(rr)) return jdbl_inl(p);
         return jzero();
     }
     rr = fdbl(rr);
@@ -177,8 +177,8 @@ __device__ __forceinline__ Jac jmul_small(const Jac& p, u32 k)
 {
     Jac r = jzero();
     for (int b = 31 - __clz(k | 1); b >= 0; b--) {
-        r = jdbl(r);
-        if ((k >> b) & 1) r = jadd(r, p);
+        r = jdbl_inl(r);
+        if ((k >> b) & 1) r = jadd_inl(r, p);
     }
     return k ? r : jzero();
 }
@@ -317,9 +317,9 @@ __global__ __launch_bounds__(64) void msm_groups_kernel(Jac* __restrict__ groups
     // sum = sum_d (d + 1) B[d]; wanted sum_d (g * gs + d) B[d] = sum + (g * gs - 1) * run  (run = group total); g * gs = 0: sum - run
     if (g == 0) {
         Jac neg = run; neg.y = fsub(fzero(), neg.y);
-        groups[gid] = jadd(sum, neg);
+        groups[gid] = jadd_inl(sum, neg);
     } else {
-        groups[gid] = jadd(sum, jmul_small(run, g * gs - 1));
+        groups[gid] = jadd_inl(sum, jmul_small(run, g * gs - 1));
     }
 }
 
