@@ -12,6 +12,7 @@ static inline int hipGetLastError() { return hipSuccess; }
 #define __forceinline__ inline
 #define __launch_bounds__(x)
 #define __restrict__
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)      /* a scheduling fence of the GPU compiler (xlayer_prover_amd/expr_hoist.py) */
 #define hipLaunchKernelGGL(k, g, b, sh, st, ...)                                   \
     for (unsigned bx_ = 0; bx_ < (g).x; bx_++)                                     \
         for (unsigned tx_ = 0; tx_ < (b).x; tx_++) { blockIdx.x = bx_; threadIdx.x = tx_; k(__VA_ARGS__); }

@@ -245,8 +245,9 @@ def test_converter_covers_reference_tables():
         assert (info["nops"], info["nargs"]) == (nops, nargs) and info["ninstr"] >= nops
 
 
-def _run_generated_on_cpu(tmp_path, code, ntmp1, ntmp3, bufs, row0, nrows, nconst, nconst2):
-    """codegen (no GPU needed) -> host compiler with the CPU stand-ins of tests/jit_cpu + ASan -> run"""
+def _run_generated_on_cpu(tmp_path, code, ntmp1, ntmp3, bufs, row0, nrows, nconst, nconst2, hoist=0):
+    """codegen (no GPU needed) -> host compiler with the CPU stand-ins of tests/jit_cpu + ASan -> run.  hoist: the text goes through
+    xlayer_prover_amd/expr_hoist.py first (what ExprProgram.compile does under XLP_EXPR_HOIST_LOADS)"""
     import os
     import subprocess
     from xlayer_prover_amd import capi
@@ -254,6 +255,10 @@ def _run_generated_on_cpu(tmp_path, code, ntmp1, ntmp3, bufs, row0, nrows, ncons
     p = capi.ExprProgram(code, ntmp1, ntmp3)
     src = str(tmp_path / "prog.hip")
     p.codegen(src); p.close()
+    if hoist:
+        from xlayer_prover_amd import expr_hoist
+        text = open(src).read()
+        open(src, "w").write(expr_hoist.transform(text, hoist))
     exe = str(tmp_path / "harness")
     subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-std=c++17", "-x", "c++",
                            f"-DPLUGIN_SRC=\"{src}\"", "-I", os.path.join(here, "jit_cpu"), "-I", os.path.join(here, "..", "xlayer_prover_amd", "csrc"),
@@ -288,6 +293,35 @@ def test_expr_generated_code_on_cpu(orc, tmp_path, seed, n, ninstr, row0, nrows)
     orc.expr_run(prog.code, prog.ntmp1, prog.ntmp3, exp, row0, nrows, 5, 4)
     for k in ("pols", "q_2ns", "f_2ns"):
         assert (got[k] == exp[k]).all(), f"{k}: {np.flatnonzero(got[k] != exp[k])[:5]}"
+
+
+@pytest.mark.parametrize("seed,n,ninstr,seg,batch", [(33, 128, 700, 256, 4), (35, 300, 700, 128, 3)])
+def test_expr_generated_code_with_hoisted_loads_on_cpu(orc, tmp_path, seed, n, ninstr, seg, batch):
+    """xlayer_prover_amd/expr_hoist.py (the column loads of a generated kernel issued a batch ahead of their use, what the zkEVM plugins of the
+    one-GPU path are built with): the transformed text computes what the oracle computes, and the pass did move loads"""
+    os.environ["XLP_EXPR_SEG"] = str(seg)
+    try:
+        prog, width = random_program(seed, n, ninstr)
+        bufs = make_buffers(orc, 0x5EED0900 + seed, n, width)
+        got = _run_generated_on_cpu(tmp_path, prog.code, prog.ntmp1, prog.ntmp3, bufs, 0, n, 5, 4, hoist=batch)
+    finally:
+        del os.environ["XLP_EXPR_SEG"]
+    text = open(tmp_path / "prog.hip").read()
+    assert "_raw = " in text and "__builtin_amdgcn_sched_barrier(0);" in text
+    exp = {k: v.copy() for k, v in bufs.items()}
+    orc.expr_run(prog.code, prog.ntmp1, prog.ntmp3, exp, 0, n, 5, 4)
+    for k in ("pols", "q_2ns", "f_2ns"):
+        assert (got[k] == exp[k]).all(), f"{k}: {np.flatnonzero(got[k] != exp[k])[:5]}"
+
+
+def test_expr_hoist_leaves_a_kernel_with_a_load_after_a_store_alone():
+    from xlayer_prover_amd import expr_hoist
+    k = 'extern "C" __global__ void seg_0(XlpJitArgs A)\n{\n' + "".join(f"    const u64 v{i} = gl::canon(PR[0x{i}ULL + row]);\n" for i in range(20))
+    safe = k + "    T[0ULL * TS] = v3;\n}\n"
+    unsafe = k + "    T[0ULL * TS] = v3;\n    const u64 v99 = T[0ULL * TS];\n}\n"
+    out = expr_hoist.transform("// head\n" + safe, 4)
+    assert out.count("_raw = PR[") == 20 and out.count("sched_barrier") == 5 and out.index("const u64 v8 = gl::canon(v8_raw)") < out.index("v19_raw") < out.index("const u64 v12 = gl::canon(v12_raw)")      # one batch ahead
+    assert expr_hoist.transform("// head\n" + unsafe, 4) == "// head\n" + unsafe
 
 
 @pytest.mark.parametrize("seed,n,nterms,seg,accs", [(61, 64, 120, 64, 3), (62, 100, 400, 256, 3), (63, 64, 1500, 100000, 1), (64, 64, 200, 32, 2), (65, 64, 1300, 100000, -1)])

@@ -39,6 +39,8 @@ def main():
                     "(tools/zkevm_geometry.py layout_window) -> zkevm.<step>.geo<N>w<G>.so")
     ap.add_argument("--colmajor", action="store_true", help="with --geometry: column-major device sections (tools/zkevm_geometry.py to_colmajor; XLP_EXPR_COLMAJOR) "
                     "-> zkevm.<step>.geo<N>[a]c.so")
+    ap.add_argument("--hoist-loads", type=int, default=0, help="software-pipeline the column loads of the generated kernels in batches of this many "
+                    "(xlayer_prover_amd/expr_hoist.py; 0 = as generated)")
     ap.add_argument("--out-dir", default="", help="write the plugins (and their build directory) here instead of xlayer_prover_amd/chelpers (experiments)")
     a = ap.parse_args()
     sizes = ["full"] if a.full else [int(x) for x in a.log_rows.split(",")]
@@ -91,10 +93,17 @@ def main():
             # ... and so does a change of the generator itself (segment size, lazy accumulation): the stamp covers the generated text
             import hashlib
             sig = [l for l in open(probe) if "xlpjit_signature" in l][0] + "headers " + headers_hash() + "\ntext " + hashlib.sha256(open(probe, "rb").read()).hexdigest()[:16] + "\n"
+            if a.hoist_loads:
+                sig += f"hoist {a.hoist_loads} " + hashlib.sha256(open(os.path.join(os.path.dirname(os.path.abspath(capi.__file__)), "expr_hoist.py"), "rb").read()).hexdigest()[:16] + "\n"
             if os.path.exists(so) and os.path.exists(stamp) and open(stamp).read() == sig and not a.force:
                 print("up to date", so); continue
             t = time.time()
-            p.compile(build, name, parts=a.parts)
+            if a.hoist_loads:
+                os.environ["XLP_EXPR_HOIST_LOADS"] = str(a.hoist_loads)
+            try:
+                p.compile(build, name, parts=a.parts)
+            finally:
+                os.environ.pop("XLP_EXPR_HOIST_LOADS", None)
             os.replace(os.path.join(build, name + ".so"), so)
             open(stamp, "w").write(sig)
             print(f"{so}: {time.time() - t:.1f} s", flush=True)
