@@ -314,6 +314,42 @@ def test_expr_generated_code_with_hoisted_loads_on_cpu(orc, tmp_path, seed, n, n
         assert (got[k] == exp[k]).all(), f"{k}: {np.flatnonzero(got[k] != exp[k])[:5]}"
 
 
+def test_expr_hoist_is_a_pure_reordering_of_the_generated_text(tmp_path):
+    """undoing the pass line by line -- the raw load back in front of its use, the fences dropped -- gives the generated text back: nothing is
+    added, lost or altered but the place (and the name) of a load"""
+    import re
+    from xlayer_prover_amd import capi, expr_hoist
+    os.environ["XLP_EXPR_SEG"] = "200"
+    try:
+        prog, _ = random_program(36, 256, 1200)
+        p = capi.ExprProgram(prog.code, prog.ntmp1, prog.ntmp3)
+        src = str(tmp_path / "prog.hip")
+        p.codegen(src); p.close()
+    finally:
+        del os.environ["XLP_EXPR_SEG"]
+    text = open(src).read()
+    out = expr_hoist.transform(text, 5)
+    assert out != text and out.count("_raw = ") >= 10
+    raw = {}
+    back = []
+    for l in out.split("\n"):
+        m = re.match(r"^(\s*)const u64 (v\d+)_raw = (.*);$", l)
+        if m:
+            assert m.group(2) not in raw                                  # (names are per kernel: cleared at each kernel head below)
+            raw[m.group(2)] = m.group(3)
+            continue
+        if l.strip() == "__builtin_amdgcn_sched_barrier(0);":
+            continue
+        if l.startswith('extern "C" __global__'):
+            raw = {}
+        m = re.match(r"^(\s*)const u64 (v\d+) = (gl::canon\()?(v\d+)_raw\)?;$", l)
+        if m:
+            assert m.group(2) == m.group(4) and m.group(2) in raw         # defined earlier in this kernel
+            l = f"{m.group(1)}const u64 {m.group(2)} = " + (f"gl::canon({raw[m.group(2)]});" if m.group(3) else f"{raw[m.group(2)]};")
+        back.append(l)
+    assert "\n".join(back) == text
+
+
 def test_expr_hoist_leaves_a_kernel_with_a_load_after_a_store_alone():
     from xlayer_prover_amd import expr_hoist
     k = 'extern "C" __global__ void seg_0(XlpJitArgs A)\n{\n' + "".join(f"    const u64 v{i} = gl::canon(PR[0x{i}ULL + row]);\n" for i in range(20))
