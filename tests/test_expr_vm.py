@@ -246,19 +246,20 @@ def test_converter_covers_reference_tables():
 
 
 def _run_generated_on_cpu(tmp_path, code, ntmp1, ntmp3, bufs, row0, nrows, nconst, nconst2, hoist=0):
-    """codegen (no GPU needed) -> host compiler with the CPU stand-ins of tests/jit_cpu + ASan -> run.  hoist: the text goes through
-    xlayer_prover_amd/expr_hoist.py first (what ExprProgram.compile does under XLP_EXPR_HOIST_LOADS)"""
+    """codegen (no GPU needed) -> host compiler with the CPU stand-ins of tests/jit_cpu + ASan -> run.  hoist: the generator pipelines the loads
+    in batches of this many (XLP_EXPR_HOIST_LOADS, csrc/expr.hip place_loads: how the product's plugins are built)"""
     import os
     import subprocess
     from xlayer_prover_amd import capi
     here = os.path.dirname(os.path.abspath(__file__))
     p = capi.ExprProgram(code, ntmp1, ntmp3)
     src = str(tmp_path / "prog.hip")
-    p.codegen(src); p.close()
     if hoist:
-        from xlayer_prover_amd import expr_hoist
-        text = open(src).read()
-        open(src, "w").write(expr_hoist.transform(text, hoist))
+        os.environ["XLP_EXPR_HOIST_LOADS"] = str(hoist)
+    try:
+        p.codegen(src); p.close()
+    finally:
+        os.environ.pop("XLP_EXPR_HOIST_LOADS", None)
     exe = str(tmp_path / "harness")
     subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-std=c++17", "-x", "c++",
                            f"-DPLUGIN_SRC=\"{src}\"", "-I", os.path.join(here, "jit_cpu"), "-I", os.path.join(here, "..", "xlayer_prover_amd", "csrc"),
@@ -295,17 +296,21 @@ def test_expr_generated_code_on_cpu(orc, tmp_path, seed, n, ninstr, row0, nrows)
         assert (got[k] == exp[k]).all(), f"{k}: {np.flatnonzero(got[k] != exp[k])[:5]}"
 
 
-@pytest.mark.parametrize("seed,n,ninstr,seg,batch", [(33, 128, 700, 256, 4), (35, 300, 700, 128, 3)])
-def test_expr_generated_code_with_hoisted_loads_on_cpu(orc, tmp_path, seed, n, ninstr, seg, batch):
-    """xlayer_prover_amd/expr_hoist.py (the column loads of a generated kernel issued a batch ahead of their use, what the zkEVM plugins of the
-    one-GPU path are built with): the transformed text computes what the oracle computes, and the pass did move loads"""
-    os.environ["XLP_EXPR_SEG"] = str(seg)
+@pytest.mark.parametrize("seed,n,ninstr,seg,batch,cut", [(33, 128, 700, 256, 4, 0), (35, 300, 700, 128, 3, 0), (37, 128, 900, 0, 4, 160)])
+def test_expr_generated_code_with_pipelined_loads_on_cpu(orc, tmp_path, seed, n, ninstr, seg, batch, cut):
+    """the generator's load pipelining (the loads of a segment issued a batch ahead of their use: how the product's plugins are built), also with
+    the segment boundaries chosen by XLP_EXPR_CUT: the text computes what the oracle computes, and loads did move"""
+    if seg:
+        os.environ["XLP_EXPR_SEG"] = str(seg)
+    if cut:
+        os.environ["XLP_EXPR_CUT"] = str(cut); os.environ["XLP_EXPR_CUT_MIN"] = "16"
     try:
         prog, width = random_program(seed, n, ninstr)
         bufs = make_buffers(orc, 0x5EED0900 + seed, n, width)
         got = _run_generated_on_cpu(tmp_path, prog.code, prog.ntmp1, prog.ntmp3, bufs, 0, n, 5, 4, hoist=batch)
     finally:
-        del os.environ["XLP_EXPR_SEG"]
+        for k in ("XLP_EXPR_SEG", "XLP_EXPR_CUT", "XLP_EXPR_CUT_MIN"):
+            os.environ.pop(k, None)
     text = open(tmp_path / "prog.hip").read()
     assert "_raw = " in text and "__builtin_amdgcn_sched_barrier(0);" in text
     exp = {k: v.copy() for k, v in bufs.items()}
@@ -314,22 +319,29 @@ def test_expr_generated_code_with_hoisted_loads_on_cpu(orc, tmp_path, seed, n, n
         assert (got[k] == exp[k]).all(), f"{k}: {np.flatnonzero(got[k] != exp[k])[:5]}"
 
 
-def test_expr_hoist_is_a_pure_reordering_of_the_generated_text(tmp_path):
-    """undoing the pass line by line -- the raw load back in front of its use, the fences dropped -- gives the generated text back: nothing is
-    added, lost or altered but the place (and the name) of a load"""
-    import re
-    from xlayer_prover_amd import capi, expr_hoist
-    os.environ["XLP_EXPR_SEG"] = "200"
+def _codegen_text(tmp_path, prog, name, **env):
+    from xlayer_prover_amd import capi
+    for k, v in env.items():
+        os.environ[k] = str(v)
     try:
-        prog, _ = random_program(36, 256, 1200)
         p = capi.ExprProgram(prog.code, prog.ntmp1, prog.ntmp3)
-        src = str(tmp_path / "prog.hip")
+        src = str(tmp_path / name)
         p.codegen(src); p.close()
     finally:
-        del os.environ["XLP_EXPR_SEG"]
-    text = open(src).read()
-    out = expr_hoist.transform(text, 5)
+        for k in env:
+            del os.environ[k]
+    return open(src).read()
+
+
+def test_expr_load_pipelining_is_a_pure_reordering_of_the_generated_text(tmp_path):
+    """undoing the pipelining line by line -- the raw load back in front of its use, the fences dropped -- gives the text the generator writes
+    without it: nothing is added, lost or altered but the place (and the name) of a load.  A load of a column the segment also WRITES is never moved."""
+    import re
+    prog, _ = random_program(36, 256, 1200)
+    text = _codegen_text(tmp_path, prog, "plain.hip", XLP_EXPR_SEG=200)
+    out = _codegen_text(tmp_path, prog, "piped.hip", XLP_EXPR_SEG=200, XLP_EXPR_HOIST_LOADS=5)
     assert out != text and out.count("_raw = ") >= 10
+    assert not re.search(r"_raw = (CW|PW)\[", out)                                      # written columns are read in place, through the writing pointer
     raw = {}
     back = []
     for l in out.split("\n"):
@@ -347,17 +359,25 @@ def test_expr_hoist_is_a_pure_reordering_of_the_generated_text(tmp_path):
             assert m.group(2) == m.group(4) and m.group(2) in raw         # defined earlier in this kernel
             l = f"{m.group(1)}const u64 {m.group(2)} = " + (f"gl::canon({raw[m.group(2)]});" if m.group(3) else f"{raw[m.group(2)]};")
         back.append(l)
-    assert "\n".join(back) == text
+    strip = lambda t: "\n".join(x for x in t.split("\n") if not x.startswith("// xlp_expr_codegen:"))
+    assert strip("\n".join(back)) == strip(text)
+    # one batch ahead: the raw loads of batch b + 1 stand in front of the first use of batch b
+    k = out[out.index('seg_0('):]
+    names = re.findall(r"const u64 (v\d+)_raw = ", k[:k.index("\n}\n")])
+    assert len(names) >= 15 and k.index(f"const u64 {names[5]} = ") > k.index(f"const u64 {names[9]}_raw = ") and k.index(f"const u64 {names[4]} = ") < k.index(f"const u64 {names[10]}_raw = ")
 
 
-def test_expr_hoist_leaves_a_kernel_with_a_load_after_a_store_alone():
-    from xlayer_prover_amd import expr_hoist
-    k = 'extern "C" __global__ void seg_0(XlpJitArgs A)\n{\n' + "".join(f"    const u64 v{i} = gl::canon(PR[0x{i}ULL + row]);\n" for i in range(20))
-    safe = k + "    T[0ULL * TS] = v3;\n}\n"
-    unsafe = k + "    T[0ULL * TS] = v3;\n    const u64 v99 = T[0ULL * TS];\n}\n"
-    out = expr_hoist.transform("// head\n" + safe, 4)
-    assert out.count("_raw = PR[") == 20 and out.count("sched_barrier") == 5 and out.index("const u64 v8 = gl::canon(v8_raw)") < out.index("v19_raw") < out.index("const u64 v12 = gl::canon(v12_raw)")      # one batch ahead
-    assert expr_hoist.transform("// head\n" + unsafe, 4) == "// head\n" + unsafe
+def test_expr_segment_cuts_by_dynamic_programming_move_fewer_words(tmp_path):
+    """XLP_EXPR_CUT: the generator's own account (the stats line of the generated file) of the words a row moves through HBM is not larger with the
+    boundaries chosen by dynamic programming than with a cut every so many instructions of the same maximum length, and no segment is longer"""
+    import re
+    prog, _ = random_program(38, 256, 3000, ntmp1=40, ntmp3=20)
+    def words(text):
+        m = re.search(r"// xlp_expr_codegen: (\d+) instructions in (\d+) segments \(longest (\d+)\), per row (\d+) column words loaded, (\d+) temporary words loaded, (\d+) temporary words stored", text)
+        return int(m.group(4)) + int(m.group(5)) + int(m.group(6)), int(m.group(3)), int(m.group(2))
+    fixed = words(_codegen_text(tmp_path, prog, "fixed.hip", XLP_EXPR_SEG=192))
+    dp = words(_codegen_text(tmp_path, prog, "dp.hip", XLP_EXPR_CUT=192, XLP_EXPR_CUT_MIN=32, XLP_EXPR_CUT_SEGCOST=0))
+    assert dp[1] <= 192 and dp[0] <= fixed[0], (fixed, dp)
 
 
 @pytest.mark.parametrize("seed,n,nterms,seg,accs", [(61, 64, 120, 64, 3), (62, 100, 400, 256, 3), (63, 64, 1500, 100000, 1), (64, 64, 200, 32, 2), (65, 64, 1300, 100000, -1)])

@@ -39,10 +39,16 @@ def main():
                     "(tools/zkevm_geometry.py layout_window) -> zkevm.<step>.geo<N>w<G>.so")
     ap.add_argument("--colmajor", action="store_true", help="with --geometry: column-major device sections (tools/zkevm_geometry.py to_colmajor; XLP_EXPR_COLMAJOR) "
                     "-> zkevm.<step>.geo<N>[a]c.so")
-    ap.add_argument("--hoist-loads", type=int, default=0, help="software-pipeline the column loads of the generated kernels in batches of this many "
-                    "(xlayer_prover_amd/expr_hoist.py; 0 = as generated)")
+    ap.add_argument("--hoist-loads", type=int, default=0, help="the generator pipelines the loads of a segment in batches of this many "
+                    "(XLP_EXPR_HOIST_LOADS, csrc/expr.hip place_loads; 0 = every load at its first use)")
+    ap.add_argument("--seg", type=int, default=0, help="a segment boundary every this many instructions (XLP_EXPR_SEG; default: the generator's 256)")
+    ap.add_argument("--cut", type=int, default=0, help="segment boundaries by dynamic programming, segments of at most this many instructions (XLP_EXPR_CUT)")
     ap.add_argument("--out-dir", default="", help="write the plugins (and their build directory) here instead of xlayer_prover_amd/chelpers (experiments)")
     a = ap.parse_args()
+    # the generator reads its options when it writes the text: the stamp below covers the text, so a change of an option rebuilds the plugin
+    for k, v in (("XLP_EXPR_HOIST_LOADS", a.hoist_loads), ("XLP_EXPR_SEG", a.seg), ("XLP_EXPR_CUT", a.cut)):
+        if v:
+            os.environ[k] = str(v)
     sizes = ["full"] if a.full else [int(x) for x in a.log_rows.split(",")]
     geo = None
     if a.geometry:
@@ -76,10 +82,6 @@ def main():
                 code, ntmp1, ntmp3 = geo[step]
             else:
                 code, _ = R.shrink(code, 1 << lr)
-            if geo and not step.endswith("_tab"):             # what the segment form moves per row (offline model of the generated kernels)
-                from xlayer_prover_amd import expr_opt
-                cw, tw = expr_opt.segment_traffic(code, int(os.environ.get("XLP_EXPR_SEG", "256")))
-                print(f"{name}: segment model: {cw} column words loaded per row, {tw} temporary words across segment boundaries", flush=True)
             p = capi.ExprProgram(code, ntmp1, ntmp3, colmajor=bool(geo) and a.colmajor and not step.endswith("_tab"))
             # regenerate the launcher text (cheap) and rebuild only if it changed: its signature covers the whole
             # compiled program, so a change of the library's compile step invalidates the plugin too
@@ -93,20 +95,19 @@ def main():
             # ... and so does a change of the generator itself (segment size, lazy accumulation): the stamp covers the generated text
             import hashlib
             sig = [l for l in open(probe) if "xlpjit_signature" in l][0] + "headers " + headers_hash() + "\ntext " + hashlib.sha256(open(probe, "rb").read()).hexdigest()[:16] + "\n"
-            if a.hoist_loads:
-                sig += f"hoist {a.hoist_loads} " + hashlib.sha256(open(os.path.join(os.path.dirname(os.path.abspath(capi.__file__)), "expr_hoist.py"), "rb").read()).hexdigest()[:16] + "\n"
             if os.path.exists(so) and os.path.exists(stamp) and open(stamp).read() == sig and not a.force:
                 print("up to date", so); continue
             t = time.time()
-            if a.hoist_loads:
-                os.environ["XLP_EXPR_HOIST_LOADS"] = str(a.hoist_loads)
-            try:
-                p.compile(build, name, parts=a.parts)
-            finally:
-                os.environ.pop("XLP_EXPR_HOIST_LOADS", None)
+            p.compile(build, name, parts=a.parts)
             os.replace(os.path.join(build, name + ".so"), so)
             open(stamp, "w").write(sig)
             print(f"{so}: {time.time() - t:.1f} s", flush=True)
+            # what the generator says the kernels move per row, and what the compiled code does about latency and registers (CPU: llvm-objdump)
+            import json
+            from tools import isa_loads_in_flight as ISA
+            rep = {"generator": next((l.strip()[3:] for l in open(probe) if l.startswith("// xlp_expr_codegen:")), ""), "isa": ISA.summary(so)}
+            json.dump(rep, open(so[:-3] + ".report.json", "w"), indent=1)
+            print(f"{name}: {rep['generator']}\n{name}: {rep['isa']}", flush=True)
 
 
 if __name__ == "__main__":

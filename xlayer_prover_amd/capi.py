@@ -750,12 +750,6 @@ class ExprProgram:
             del os.environ["XLP_EXPR_PARTS"]
         flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I", os.path.join(_HERE, "csrc")] + os.environ.get("XLP_JIT_EXTRA_FLAGS", "").split()
         srcs = [src] + [f"{src}.part{k}.hip" for k in range(parts) if os.path.exists(f"{src}.part{k}.hip")]
-        hoist = int(os.environ.get("XLP_EXPR_HOIST_LOADS", "0") or 0)       # expr_hoist.py: the column loads a batch ahead of their use
-        if hoist > 0:
-            from . import expr_hoist
-            for f in srcs:
-                text = open(f).read()
-                open(f, "w").write(expr_hoist.transform(text, hoist))
         procs = [subprocess.Popen(["hipcc"] + flags + ["-c", f, "-o", f + ".o"]) for f in srcs]
         if any(p.wait() != 0 for p in procs):
             raise XlpError("hipcc failed on a generated expression kernel")

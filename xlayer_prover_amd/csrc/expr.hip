@@ -836,22 +836,141 @@ static std::vector<DInstr> decode_dcode(const xlp_expr_program* P)
     return out;
 }
 
+// LOAD PIPELINING (round 5; round 4 did this as a pass over the generated text).  hipcc issues each global load of a generated segment right before
+// its first use and waits for it almost at once (tools/isa_loads_in_flight.py on zkEVM step42ns as generated: 1.4 loads per wait, the youngest load
+// a median of 10 instructions before its wait), so a wavefront exposes the whole memory latency ~60 times per segment and only the 2-5 wavefronts per
+// SIMD hide it: the segments ran at 2 TB/s and 30 % vector issue, neither pipe full.  The generator therefore records every load whose address no
+// store of the segment can alias -- temporaries of earlier segments (T: a segment stores its temporaries at its end), columns the segment does not
+// write (C / PR: the ones it writes go through CW / PW and stay where they are), constant columns (KN / KE) -- and place_loads issues the RAW loads
+// in batches of XLP_EXPR_HOIST_LOADS, each batch XLP_EXPR_HOIST_AHEAD (1) batches ahead of the first use of its first value and pinned by
+// __builtin_amdgcn_sched_barrier(0) (no scheduling strategy of the compiler does this by itself: tried max-ilp, max-memory-clause); the
+// canonicalisation stays at the place of use.  Same values, same statements.  0 = every load at its first use.
+struct SegLoad { std::string name, expr; bool canon; };
+struct LoadStats { size_t segments = 0, pipelined_segments = 0, loads = 0, pipelined_loads = 0, batches = 0, tmp_loads = 0, tmp_stores = 0, longest = 0; };
+
+static std::string place_loads(const std::string& body, const std::vector<SegLoad>& loads, size_t batch, size_t ahead, LoadStats& st)
+{
+    st.segments++; st.loads += loads.size();
+    for (const SegLoad& l : loads) st.tmp_loads += l.expr[0] == 'T';
+    const bool pipe = batch > 0 && loads.size() >= 2 * batch;
+    const size_t nb = pipe ? (loads.size() + batch - 1) / batch : 0;
+    if (pipe) { st.pipelined_segments++; st.pipelined_loads += loads.size(); st.batches += nb; }
+    std::vector<std::vector<size_t>> issue_at(pipe ? loads.size() : 0);        // mark k -> the batches whose raw loads go in front of it
+    for (size_t b = 0; b < nb; b++) issue_at[b <= ahead ? 0 : (b - ahead) * batch].push_back(b);
+    std::string out;
+    out.reserve(body.size() + loads.size() * 48);
+    for (size_t p = 0; p < body.size();) {
+        size_t q = body.find('\n', p);
+        if (q == std::string::npos) q = body.size();
+        if (body[p] != '\x01') { out.append(body, p, q - p + 1); p = q + 1; continue; }
+        const size_t k = (size_t)strtoull(body.c_str() + p + 1, nullptr, 10);
+        p = q + 1;
+        const SegLoad& l = loads[k];
+        if (!pipe) {
+            out += "    const u64 " + l.name + " = " + (l.canon ? "gl::canon(" + l.expr + ")" : l.expr) + ";\n";
+            continue;
+        }
+        for (size_t b : issue_at[k]) {
+            for (size_t j = b * batch; j < std::min(loads.size(), (b + 1) * batch); j++) out += "    const u64 " + loads[j].name + "_raw = " + loads[j].expr + ";\n";
+            out += "    __builtin_amdgcn_sched_barrier(0);\n";
+        }
+        out += "    const u64 " + l.name + " = " + (l.canon ? "gl::canon(" + l.name + "_raw)" : l.name + "_raw") + ";\n";
+    }
+    return out;
+}
+
+// Where the segments of the generated code begin: {0, ..., ins.size()}.
+//   XLP_EXPR_SEG = n (default 256): a cut every n instructions.
+//   XLP_EXPR_CUT = L > 0: the cut points that move the fewest words per row through HBM, by dynamic programming over the program, with segments
+//   of XLP_EXPR_CUT_MIN (64) .. L instructions.  What a segment [s, e) moves: one load per distinct column word it names, one load per temporary
+//   word it reads whose value was defined before s, one store per temporary word it defines that is read at or after e -- the same accounting
+//   as xlayer_prover_amd/expr_opt.py segment_traffic -- plus XLP_EXPR_CUT_SEGCOST (8) words per segment for what every kernel loads anyway
+//   (challenges, the launch).  zkEVM step42ns: 9 450 words per row at a cut every 256 -> 8 751 (L = 256), 7 114 (L = 512), 6 438 (L = 768).
+static std::vector<size_t> segment_cuts(const std::vector<DInstr>& ins, u64 W)
+{
+    const size_t n = ins.size();
+    std::vector<size_t> cut;
+    const size_t L = (size_t)std::max(0, env_int("XLP_EXPR_CUT", 0));
+    if (!L || n <= L) {
+        const size_t SEG = (size_t)std::max(1, env_int("XLP_EXPR_SEG", 256));
+        for (size_t i = 0; i < n; i += SEG) cut.push_back(i);
+        cut.push_back(n);
+        return cut;
+    }
+    const size_t Lmin = std::min(L, (size_t)std::max(1, env_int("XLP_EXPR_CUT_MIN", 64)));
+    const double segcost = (double)env_int("XLP_EXPR_CUT_SEGCOST", 8);
+    // per instruction: the column words it reads (ids), the temporary words it reads (with the instruction that defined the value), the
+    // temporary words it defines (with the last instruction that reads that value)
+    std::map<std::array<u64, 6>, u32> colid;
+    std::vector<std::vector<u32>> cols(n);
+    std::vector<std::vector<std::pair<u64, long>>> tread(n), tdef(n);
+    std::vector<long> lastdef(W, -1);
+    for (size_t i = 0; i < n; i++) {
+        const DInstr& in = ins[i];
+        for (int o = 1; o < 3; o++) {
+            const u32 k = in.k[o];
+            if (k == XD_TMP) {
+                for (u32 c = 0; c < in.dim[o]; c++) {
+                    const u64 w = in.prm[o][0] + c;
+                    const long d = lastdef[w];
+                    tread[i].push_back({w, d});
+                    if (d >= 0) tdef[d][w - ins[d].prm[0][0]].second = (long)i;
+                }
+            } else if (k == XD_COL || (k >= XLP_K_POLS && k <= XLP_K_CONST2NS_PRIME)) {
+                for (u32 c = 0; c < in.dim[o]; c++) {
+                    const std::array<u64, 6> key = {k, in.prm[o][0], in.prm[o][1], in.prm[o][2], in.prm[o][3], c};
+                    cols[i].push_back(colid.emplace(key, (u32)colid.size()).first->second);
+                }
+            }
+        }
+        if (in.k[0] == XD_TMP)
+            for (u32 c = 0; c < in.dim[0]; c++) { tdef[i].push_back({in.prm[0][0] + c, -1}); lastdef[in.prm[0][0] + c] = (long)i; }
+    }
+    std::vector<double> f(n + 1, 1e300);
+    std::vector<size_t> prev(n + 1, 0);
+    std::vector<size_t> col_seen(colid.size(), 0), tmp_seen(W, 0);     // stamps: s + 1
+    std::vector<u32> pend(n + 1, 0);                                   // stores that stop being needed once the segment reaches past index k
+    f[0] = 0;
+    for (size_t s = 0; s < n; s++) {
+        if (f[s] >= 1e299) continue;
+        size_t words = 0, stores = 0;
+        const size_t emax = std::min(n, s + L);
+        for (size_t e = s + 1; e <= emax; e++) {
+            const size_t i = e - 1;
+            for (u32 c : cols[i]) if (col_seen[c] != s + 1) { col_seen[c] = s + 1; words++; }
+            for (const auto& r : tread[i]) if (r.second < (long)s && tmp_seen[r.first] != s + 1) { tmp_seen[r.first] = s + 1; words++; }
+            for (const auto& d : tdef[i]) if (d.second >= (long)e) { stores++; pend[d.second]++; }
+            stores -= pend[i]; pend[i] = 0;                            // values last read by instruction i are not live out of [s, e)
+            if (e - s < Lmin && e != n) continue;
+            const double c = f[s] + (double)(words + stores) + segcost;
+            if (c < f[e]) { f[e] = c; prev[e] = s; }
+        }
+        for (size_t e = s + 1; e <= emax; e++) for (const auto& d : tdef[e - 1]) if (d.second >= 0) pend[d.second] = 0;
+    }
+    for (size_t e = n; e > 0; e = prev[e]) cut.push_back(e);
+    cut.push_back(0);
+    std::reverse(cut.begin(), cut.end());
+    return cut;
+}
+
 int expr_codegen(const xlp_expr_program* P, const char* path)
 {
     if (!P || !path) return xlp_fail("expr codegen: null argument");
     const std::vector<DInstr> ins = decode_dcode(P);
-    const size_t SEG = (size_t)env_int("XLP_EXPR_SEG", 256);
-    const size_t nseg = (ins.size() + SEG - 1) / SEG;
     const u64 W = P->tmp_words;
+    // segment sg = instructions [cut[sg], cut[sg + 1])
+    const std::vector<size_t> cut = segment_cuts(ins, W);
+    const size_t nseg = cut.size() - 1;
     // words live at the start of each segment (backward dataflow over the temporaries)
     std::vector<std::vector<bool>> live_in(nseg + 1, std::vector<bool>(W, false));
     {
         std::vector<bool> live(W, false);
+        size_t sg = nseg;
         for (size_t i = ins.size(); i-- > 0;) {
             const DInstr& in = ins[i];
             if (in.k[0] == XD_TMP) for (u32 c = 0; c < in.dim[0]; c++) live[in.prm[0][0] + c] = false;
             for (int o = 1; o < 3; o++) if (in.k[o] == XD_TMP) for (u32 c = 0; c < in.dim[o]; c++) live[in.prm[o][0] + c] = true;
-            if (i % SEG == 0) live_in[i / SEG] = live;
+            if (sg > 0 && i == cut[sg - 1]) live_in[--sg] = live;
         }
     }
     // dies[i][o]: the temporary operand o of instruction i is not read again (its words are overwritten first, or never touched)
@@ -890,6 +1009,8 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
         "static __device__ __forceinline__ u64 wrapr(u64 r, u64 n) { return (n & (n - 1)) == 0 ? (r & (n - 1)) : r % n; }\n"
         "static __device__ __forceinline__ u64 wrapc(u64 j, u64 base, u64 n) { return j - base >= n ? j - n : j; }\n";
     const bool CM = P->colmajor;
+    const size_t hoist = (size_t)std::max(0, env_int("XLP_EXPR_HOIST_LOADS", 0)), hoist_ahead = (size_t)std::max(1, env_int("XLP_EXPR_HOIST_AHEAD", 1));
+    LoadStats stats;
     std::vector<std::string> segsrc(nseg);
     char buf[256];
     for (size_t sg = 0; sg < nseg; sg++) {
@@ -905,7 +1026,7 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
             os << "    const u64* __restrict__ PR = A.P.pols; u64* __restrict__ PW = A.P.pols; const u64* __restrict__ KN = A.P.const_pols; const u64* __restrict__ KE = A.P.const_pols_2ns;\n"
                   "    const u64 KNR = A.crows, KER = A.crows2, drow = row - A.dshift, nat3 = 3 * ((row - A.cbase) * A.P.zi_size + A.coset);\n"
                   "    (void)PR; (void)PW; (void)KN; (void)KE; (void)KNR; (void)KER; (void)drow; (void)nat3;\n";
-        const size_t i0 = sg * SEG, i1 = std::min(ins.size(), i0 + SEG);
+        const size_t i0 = cut[sg], i1 = cut[sg + 1];
         std::set<u64> wcol;                              // columns this segment writes: all their accesses go through CW (restrict-clean)
         for (size_t i = i0; i < i1; i++) if (ins[i].k[0] == XD_COL) for (u32 c = 0; c < ins[i].dim[0]; c++) wcol.insert(ins[i].prm[0][0] + c);
         // column-major form: a column is named by (buffer, first word | constant column); the ones this segment writes go through PW
@@ -922,6 +1043,15 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
         std::map<std::string, std::string> dval;         // direct scalar expressions -> SSA name
         u64 nv = 0;
         auto fresh = [&]() { snprintf(buf, sizeof buf, "v%llu", (unsigned long long)nv++); return std::string(buf); };
+        // a load of a value no store of this segment can alias (a temporary of an earlier segment, a staged / section column the segment does
+        // not write, a constant column): its statement is placed when the segment is assembled (place_loads), here it leaves a mark
+        std::vector<SegLoad> loads;
+        auto load = [&](const std::string& expr, bool canon) {
+            const std::string n = fresh();
+            os << '\x01' << loads.size() << "\n";
+            loads.push_back({n, expr, canon});
+            return n;
+        };
         auto direct = [&](const std::string& expr) {
             auto it = dval.find(expr);
             if (it != dval.end()) return it->second;
@@ -994,8 +1124,7 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
                 const u64 w = p[0] + c;
                 auto it = tval.find(w);
                 if (it != tval.end()) return it->second;
-                const std::string n = fresh();
-                os << "    const u64 " << n << " = T[" << w << "ULL * TS];\n";
+                const std::string n = load("T[" + std::to_string(w) + "ULL * TS]", false);
                 tval[w] = n; tdef[w] = false;
                 return n;
             }
@@ -1003,8 +1132,9 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
                 const std::pair<u64, u64> key(p[0] + c, p[1]);
                 auto it = cval.find(key);
                 if (it != cval.end()) return it->second;
-                const std::string n = fresh();
-                os << "    const u64 " << n << " = " << (wcol.count(key.first) ? "CW[" : "C[") << key.first << "ULL * CAP + " << key.second << "ULL];\n";
+                std::string n;
+                if (wcol.count(key.first)) { n = fresh(); os << "    const u64 " << n << " = CW[" << key.first << "ULL * CAP + " << key.second << "ULL];\n"; }
+                else n = load("C[" + std::to_string(key.first) + "ULL * CAP + " + std::to_string(key.second) + "ULL]", false);
                 cval[key] = n;
                 return n;
             }
@@ -1018,9 +1148,10 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
                     auto it = mval.find(key);
                     if (it != mval.end()) return it->second;
                     const std::string idx = pr ? "wrapc(row + " + num(p[1]) + ", A.cbase, " + num(p[2]) + ")" : std::string("row");
-                    const std::string n = fresh();
-                    if (pol) os << "    const u64 " << n << " = gl::canon(" << (wcolm.count(col) ? "PW[" : "PR[") << num(col) << " + " << idx << "]);\n";
-                    else os << "    const u64 " << n << " = gl::canon(" << (buf == 1 ? "KN[" : "KE[") << num(col) << " * " << (buf == 1 ? "KNR" : "KER") << " + " << idx << "]);\n";
+                    std::string n;
+                    if (pol && wcolm.count(col)) { n = fresh(); os << "    const u64 " << n << " = gl::canon(PW[" << num(col) << " + " << idx << "]);\n"; }
+                    else if (pol) n = load("PR[" + num(col) + " + " + idx + "]", true);
+                    else n = load(std::string(buf == 1 ? "KN[" : "KE[") + num(col) + " * " + (buf == 1 ? "KNR" : "KER") + " + " + idx + "]", true);
                     mval[key] = n;
                     return n;
                 }
@@ -1196,9 +1327,10 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
             }
         }
         for (const auto& kv : tval)
-            if (tdef[kv.first] && live_in[sg + 1][kv.first]) { const std::string v = real(kv.second); os << "    T[" << kv.first << "ULL * TS] = " << v << ";\n"; }
+            if (tdef[kv.first] && live_in[sg + 1][kv.first]) { const std::string v = real(kv.second); os << "    T[" << kv.first << "ULL * TS] = " << v << ";\n"; stats.tmp_stores++; }
+        stats.longest = std::max(stats.longest, i1 - i0);
         os << "}\n";
-        segsrc[sg] = os.str();
+        segsrc[sg] = place_loads(os.str(), loads, hoist, hoist_ahead, stats);
     }
     // XLP_EXPR_PARTS > 1: the kernels go round-robin to <path>.partK.hip (compiled in parallel, linked with <path>)
     size_t parts = (size_t)env_int("XLP_EXPR_PARTS", 1);
@@ -1213,6 +1345,10 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
     };
     std::ostringstream os;
     os << prologue;
+    // what the kernels move per row, for the build log (tools/build_expr_plugins.py reads this line)
+    os << "// xlp_expr_codegen: " << ins.size() << " instructions in " << nseg << " segments (longest " << stats.longest << "), per row " << stats.loads - stats.tmp_loads
+       << " column words loaded, " << stats.tmp_loads << " temporary words loaded, " << stats.tmp_stores << " temporary words stored; " << stats.pipelined_loads << " of " << stats.loads
+       << " loads pipelined in " << stats.batches << " batches of " << hoist << " in " << stats.pipelined_segments << " segments\n";
     if (parts == 1) for (size_t sg = 0; sg < nseg; sg++) os << segsrc[sg];
     else {
         for (size_t k = 0; k < parts; k++) {

@@ -101,14 +101,18 @@ __device__ __forceinline__ void partial3(u64 (&st)[12], const u64* __restrict__ 
     // The table pointer is laundered per call: as a loop invariant the compiler loads all 193 constants ahead of the loop over the
     // groups, runs out of SGPRs and parks them in VGPR lanes (311 v_readlane per call, VALU slots); loaded where they are used they
     // are scalar loads beside the VALU stream.
-    const u32* F = POSEIDON_FU32;
+    // (the pointer keeps the CONSTANT address space through the SGPR laundering below: typed as a generic pointer it lost it, and the 193 constants
+    // arrived by 49 flat_load_dwordx4 of a uniform address into VECTOR registers per call, 7 calls per permutation; now 77 s_load, 17 registers fewer.
+    // Round 5 A/B on one box, profiles/r5/poseidon_scalar_constants_ab.json: leaf sponge 2.712 -> 2.857 G permutations/s, resident ceiling 2.765 -> 2.860)
+    typedef const __attribute__((address_space(4))) u32* cu32p;
+    cu32p F = (cu32p)POSEIDON_FU32;
     asm volatile("" : "+s"(F));
-    const u32* __restrict__ R1 = F;             // row 0 of M
-    const u32* __restrict__ R2 = F + 12;        // row 0 of M Z M
+    cu32p R1 = F;             // row 0 of M
+    cu32p R2 = F + 12;        // row 0 of M Z M
     const u32 m00 = F[24];
-    const u32* __restrict__ B3 = F + 25;        // M Z M Z M, row-major
-    const u32* __restrict__ B2 = F + 25 + 144;  // M Z M e0
-    const u32* __restrict__ A1 = F + 25 + 156;  // M e0
+    cu32p B3 = F + 25;        // M Z M Z M, row-major
+    cu32p B2 = F + 25 + 144;  // M Z M e0
+    cu32p A1 = F + 25 + 156;  // M e0
     st[0] = pow7(st[0]);
     u32 lo[12], hi[12];
 #pragma unroll
