@@ -393,6 +393,12 @@ int xlp_profile_enable(int on);
  * permutations of a state that never leaves its registers (no HBM traffic; out[i] = a checksum of lane i's final state so that the work is
  * kept).  bench.py reports the sponge's permutations/s against what this kernel reaches on the same grid. */
 int xlp_dev_perm_resident(uint64_t* out, uint64_t count, uint64_t iters);
+/* Measurement aid: the ALU ceiling of extendPol -- the three kernels of xlp_dev_extend(n_ext, n, ncols) in their RESIDENT form: same
+ * butterfly networks, twiddle tables, LDS tiles, barriers and grids, the global data traffic removed (an input word is made from its index, an output
+ * word folded into a per-lane checksum; csrc/ntt_lde_common.hpp).  n = 2^22 or 2^23, 4..64 columns.  sink: >= 1024 words of device memory (written only
+ * if a checksum takes an impossible value).  Recorded by xlp_profile_enable / xlp_profile_read like an extendPol.  bench.py reports the headline's
+ * kernel time against what these take (roofline.alu_ceiling). */
+int xlp_dev_lde_resident(uint64_t* sink, uint64_t n_ext, uint64_t n, uint64_t ncols);
 int xlp_profile_read(double ms_sum[3], uint64_t* count);
 
 /* ---- transport between the ranks of a row-sharded proof: one process per GPU -----------------------------------------

@@ -129,6 +129,11 @@ if mode in ("abort", "die") and rank == world - 1:
         lib.xlp_comm_abort(b"boom from the last rank")
     os._exit(3)                                        # no shutdown: the way a crashed rank goes
 t0 = time.time()
+if mode == "stuck":                                    # a main thread that never returns to the library: the way a rank sits inside ncclRecv / a stream synchronise
+    if rank == world - 1:
+        os._exit(3)
+    time.sleep(60)
+    os._exit(4)                                        # not reached: this rank's own watchdog ends the process (exit code 86)
 rc = lib.xlp_comm_all_gather_host(out, mine, 1)
 if mode in ("abort", "die"):
     assert rc != 0, "the gather must fail when a rank is gone"
@@ -211,6 +216,21 @@ def test_comm_failure_of_one_rank_ends_the_others(tmp_path, mode):
         procs, outs = _run_ranks(tmp_path, _COMM_WORKER_FAIL, 2, name, mode, env={"XLP_COMM_HEARTBEAT_STALE_MS": "1500"})
         assert procs[1].returncode == 3
         assert procs[0].returncode == 0 and outs[0][0].startswith("failed-fast 0"), outs[0][1][-1500:]
+    finally:
+        for n in (name, name + ".ctl"):
+            if os.path.exists("/dev/shm/" + n):
+                os.remove("/dev/shm/" + n)
+
+
+def test_comm_watchdog_that_finds_the_dead_peer_itself_still_ends_its_process(tmp_path):
+    """the watchdog skipped the kill whenever the abort flag carried its own rank -- also when IT had raised the flag for a peer whose
+    heartbeat went stale, so with two ranks the survivor sat in its RCCL call for ever.  Who raised the flag is now separate from who failed: only
+    a flag raised by this rank's MAIN thread (already on its way out) spares the process.  (The kill is the RCCL transport's; the hook runs it over shm.)"""
+    name = f"xlp_abi_stuck_{os.getpid()}"
+    try:
+        procs, outs = _run_ranks(tmp_path, _COMM_WORKER_FAIL, 2, name, "stuck", env={"XLP_COMM_HEARTBEAT_STALE_MS": "1000", "XLP_COMM_WATCHDOG_ENDS_PROCESS": "1"}, timeout=50)
+        assert procs[1].returncode == 3
+        assert procs[0].returncode == 86 and "watchdog gave up on a peer" in outs[0][1] and "rank 1 stopped responding" in outs[0][1], (procs[0].returncode, outs[0][1][-1500:])
     finally:
         for n in (name, name + ".ctl"):
             if os.path.exists("/dev/shm/" + n):

@@ -63,6 +63,7 @@ SIGNATURES = {
     "xlp_dev_expr_run": [_pu, _pu, _u64, _u64],
     "xlp_profile_enable": [C.c_int],
     "xlp_dev_perm_resident": [_pu, _u64, _u64],
+    "xlp_dev_lde_resident": [_pu, _u64, _u64, _u64],
     "xlp_bn128_init": [C.c_char_p],
     "xlp_dev_merkle_bn128": [_pu, _pu, _u64, _u64],
     "xlp_merkle_bn128": [_pu, _pu, _u64, _u64],

@@ -22,8 +22,11 @@ __global__ __launch_bounds__(256) void rows_to_cm_kernel(u64* dst, u64 cstride, 
 {
     __shared__ u64 tile[64][65];
     const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const u32 c0 = blockIdx.x * 64;
-    const u64 q0 = (u64)blockIdx.y * 64;
+    // grid: x = row tile * column tiles + column tile (the column tile runs fastest: neighbouring workgroups touch neighbouring bytes of the same
+    // rows), z = coset.  (Row tiles used to sit in gridDim.y: 2^17 .. 2^18 of them at 2^23 .. 2^24 rows, past the 65 535 hipDeviceProp.maxGridSize[1] allows.)
+    const u32 nct = (ncols + 63) / 64;
+    const u32 c0 = (blockIdx.x % nct) * 64;
+    const u64 q0 = (u64)(blockIdx.x / nct) * 64;
     const u32 r = blockIdx.z;
     for (u32 i = wv; i < 64; i += 4) {
         const u64 q = q0 + i;
@@ -42,8 +45,11 @@ __global__ __launch_bounds__(256) void cm_to_rows_kernel(u64* dst, u64 ld, u64 c
 {
     __shared__ u64 tile[64][65];
     const u32 lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const u32 c0 = blockIdx.x * 64;
-    const u64 q0 = (u64)blockIdx.y * 64;
+    // grid: x = row tile * column tiles + column tile (the column tile runs fastest: neighbouring workgroups touch neighbouring bytes of the same
+    // rows), z = coset.  (Row tiles used to sit in gridDim.y: 2^17 .. 2^18 of them at 2^23 .. 2^24 rows, past the 65 535 hipDeviceProp.maxGridSize[1] allows.)
+    const u32 nct = (ncols + 63) / 64;
+    const u32 c0 = (blockIdx.x % nct) * 64;
+    const u64 q0 = (u64)(blockIdx.x / nct) * 64;
     const u32 r = blockIdx.z;
     for (u32 k = wv; k < 64; k += 4) {
         const u64 q = q0 + lane;
@@ -75,7 +81,9 @@ int dev_rows_to_cm(Ctx* ctx, u64* dst, u64 cstride, u64 cos, const u64* src, u64
     if (col0 + ncols > ld) return xlp_fail("rows -> columns: columns exceed the row stride");
     if (ncols >> 31) return xlp_fail("rows -> columns: too many columns");
     const u64 nq = rows >> ext;
-    const dim3 grid((unsigned)((ncols + 63) / 64), (unsigned)((nq + 63) / 64), 1u << ext);
+    const u64 tiles = ((ncols + 63) / 64) * ((nq + 63) / 64);
+    if (tiles >> 31) return xlp_fail("rows <-> columns: more than 2^31 tiles in one launch");
+    const dim3 grid((unsigned)tiles, 1, 1u << ext);
     hipLaunchKernelGGL(rows_to_cm_kernel, grid, dim3(256), 0, ctx->stream, dst, cstride, cos, src, ld, col0, (u32)ncols, nq, ext);
     XLP_HIP(hipGetLastError());
     return 0;
@@ -88,7 +96,9 @@ int dev_cm_to_rows(Ctx* ctx, u64* dst, u64 ld, u64 col0, const u64* src, u64 cst
     if (col0 + ncols > ld) return xlp_fail("columns -> rows: columns exceed the row stride");
     if (ncols >> 31) return xlp_fail("columns -> rows: too many columns");
     const u64 nq = rows >> ext;
-    const dim3 grid((unsigned)((ncols + 63) / 64), (unsigned)((nq + 63) / 64), 1u << ext);
+    const u64 tiles = ((ncols + 63) / 64) * ((nq + 63) / 64);
+    if (tiles >> 31) return xlp_fail("rows <-> columns: more than 2^31 tiles in one launch");
+    const dim3 grid((unsigned)tiles, 1, 1u << ext);
     hipLaunchKernelGGL(cm_to_rows_kernel, grid, dim3(256), 0, ctx->stream, dst, ld, col0, src, cstride, cos, (u32)ncols, nq, ext);
     XLP_HIP(hipGetLastError());
     return 0;

@@ -170,6 +170,10 @@ static bool aborted()
     CtlBlock* c = ctl();
     return c && c->abort.load(std::memory_order_acquire) != 0;
 }
+// set when THIS rank's main thread raised the abort (comm_fail / comm_abort): it is already on its way out with the error, so the watchdog
+// leaves the process alone.  Who raised the flag and who failed are different things: when the watchdog itself raises it for a dead peer the
+// main thread may be inside ncclSend / ncclRecv or a stream synchronise for ever, and the watchdog must still end the process.
+static std::atomic<bool> g_main_raised{false};
 static void raise_abort(const char* why)
 {
     CtlBlock* c = ctl();
@@ -192,6 +196,7 @@ static int fail_abort(const char* where)
 // an error of this rank inside the transport: tell the others, then report it
 static int comm_fail(const char* msg)
 {
+    g_main_raised.store(true, std::memory_order_release);
     raise_abort(msg);
     return xlp_fail(msg);
 }
@@ -401,7 +406,8 @@ static void watchdog_main()
             }
         }
         const uint32_t ab = b->abort.load(std::memory_order_acquire);
-        if (ab && ab != 1u + (uint32_t)c.rank && c.kind == Comm::RCCL) {
+        // (XLP_COMM_WATCHDOG_ENDS_PROCESS: the CPU test of this path runs it over the shm transport, whose waits poll the flag by themselves)
+        if (ab && !g_main_raised.load(std::memory_order_acquire) && (c.kind == Comm::RCCL || getenv("XLP_COMM_WATCHDOG_ENDS_PROCESS"))) {
             // RCCL calls and the kernels they enqueue have no timeout: a rank waiting for a peer that is gone waits for ever, inside the call or
             // in the next stream synchronise.  Give the main thread a moment to notice by itself (its next xlp_comm_* call fails), then end the
             // process: the proof cannot complete and the communicator is unusable anyway
@@ -409,7 +415,8 @@ static void watchdog_main()
             if (c.watchdog_stop.load(std::memory_order_acquire)) break;
             char why[sizeof b->why + 1];
             memcpy(why, b->why, sizeof b->why); why[sizeof b->why] = 0;
-            fprintf(stderr, "xlp_comm rank %d: another rank failed (%s): aborting the communicator and ending this process\n", c.rank, why);
+            fprintf(stderr, "xlp_comm rank %d: %s (%s): aborting the communicator and ending this process\n", c.rank,
+                    ab == 1u + (uint32_t)c.rank ? "this rank's watchdog gave up on a peer" : "another rank failed", why);
             fflush(stderr);
             if (c.nccl && c.rccl.CommAbort) (void)c.rccl.CommAbort(c.nccl);
             _exit(86);
@@ -432,6 +439,7 @@ static int ctl_open(const std::string& rendezvous, int rank, int world)
     if (seg_join(c.ctl, ctl_name(rendezvous), sizeof(CtlBlock), rank, world, [](char* p) { return &((CtlBlock*)p)->attached; }, [](char*) {})) return -1;
     ctl()->beat[rank].store(now_ms(), std::memory_order_release);
     c.watchdog_stop.store(false);
+    g_main_raised.store(false);
     c.watchdog = std::thread(watchdog_main);
     return 0;
 }
@@ -451,6 +459,7 @@ struct InTransport {                                          // the main thread
 
 void comm_abort(const char* why)
 {
+    g_main_raised.store(true, std::memory_order_release);
     raise_abort(why && *why ? why : "the host gave up");
 }
 

@@ -46,9 +46,10 @@ __device__ __forceinline__ void prefetch_rows(const u64* base, u64 ld, u32 lo, u
         prefetch_touch(base + (((u64)tpos << 12) | lo) * ld, lds_off);
 }
 
-template <int BT, bool INV = true>
+template <int BT, bool INV = true, bool RES = false>
 __global__ __launch_bounds__(XLP_WGT) void lde_top_dif(const LdeParams p)
 {
+    u64 sink = 0; (void)sink;
     constexpr int V = XLP_TOPV, m = (BT + 3) / 4, dtop = BT - 4 * (m - 1);
     extern __shared__ u64 smem[];
     u64* sm = smem + (XLP_PF ? LDE_PF_LDS / 8 : 0);        // tile (the first 256 bytes: the prefetch's dummy target, LDS offset 0)
@@ -62,14 +63,16 @@ __global__ __launch_bounds__(XLP_WGT) void lde_top_dif(const LdeParams p)
     auto gload = [&](u32 tpos, u32 v, u32) -> u64 {
         const u32 col = c + v < p.wc ? c + v : p.wc - 1;
         const u64 row = ((u64)tpos << 12) | lo;
-        return gl::canon(gld<0>(&p.in[row * p.ld_in + p.col0 + col]));
+        if constexpr (RES) return gl::canon(res_word(row * p.ld_in + p.col0 + col));
+        else return gl::canon(gld<0>(&p.in[row * p.ld_in + p.col0 + col]));
     };
     auto lload = [&](u32, u32 v, u32 lrow) -> u64 { return sm[lrow * V + v]; };
     auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { sm[lrow * V + v] = val; };
     u64* __restrict__ Ag = p.A + (((u64)cc << p.L) << 3);     // this workgroup's 8-column group of the scratch (lde_sidx)
     auto gstore = [&](u32 tpos, u32 v, u64 val, u32) {
         const u64 row = ((u64)tpos << 12) | lo;
-        if (c + v < p.wc) gst<1>(&Ag[row * 8 + v], val);
+        if constexpr (RES) sink ^= val + row;
+        else if (c + v < p.wc) gst<1>(&Ag[row * 8 + v], val);
     };
     auto crossf = [&](u32 tpos, u32) -> u64 { return cross[tile_natural_c<BT>(tpos)]; };
     if constexpr (m == 2) {
@@ -82,17 +85,18 @@ __global__ __launch_bounds__(XLP_WGT) void lde_top_dif(const LdeParams p)
         fast_round<BT, V, 4, 4, false, INV>(p.twi_bt, lload, lstore);
         XLP_SYNC();
 #if XLP_PF
-        if (gridDim.x >= 16 && (gridDim.x & 7) == 0 && blockIdx.x + XLP_PF < gridDim.x) {
+        if (!RES && gridDim.x >= 16 && (gridDim.x & 7) == 0 && blockIdx.x + XLP_PF < gridDim.x) {
             const u32 nt = tile + (XLP_PF >> 3);
             prefetch_rows<BT>(p.in + p.col0 + (nt % ncc) * V, p.ld_in, nt / ncc, 0u);
         }
 #endif
         fast_round<BT, V, 0, 4, false, INV, false, true>(p.twi_bt, lload, gstore, NoFactor{}, crossf);
     }
+    if constexpr (RES) res_sink(p.A, sink);
 }
 
 // K2 (lde_mid) lives in ntt_lde_mid.hip: it is compiled with another instruction-scheduling strategy (see csrc/Makefile)
-int launch_lde_mid(Ctx* ctx, const LdeParams& p, u32 BT);
+int launch_lde_mid(Ctx* ctx, const LdeParams& p, u32 BT, bool resident = false);
 
 // ---------------------------------------------------------- stand-alone NTT, bottom pass
 // Second pass of a natural-order NTT / INTT of size 2^(BT+12): DIF over the low 12 bits of one
@@ -134,9 +138,10 @@ __global__ __launch_bounds__(XLP_WGT) void ntt_bot_dif(const LdeParams p, u32 BT
 }
 
 // ------------------------------------------------------------------------ K3
-template <int BT>
+template <int BT, bool RES = false>
 __global__ __launch_bounds__(XLP_WGT) void lde_top_dit(const LdeParams p)
 {
+    u64 sink = 0; (void)sink;
     constexpr int V = XLP_TOPV, m = (BT + 3) / 4, dtop = BT - 4 * (m - 1);
     extern __shared__ u64 smem[];
     u64* sm = smem;
@@ -155,14 +160,16 @@ __global__ __launch_bounds__(XLP_WGT) void lde_top_dit(const LdeParams p)
     auto gload = [&](u32 tpos, u32 v, u32) -> u64 {
         const u32 vv = c + v < p.wc ? v : p.wc - 1 - c;
         const u64 row = ((u64)tpos << 12) | lo;
-        return gld<4>(&Br[row * 8 + vv]);
+        if constexpr (RES) return res_word(row * 8 + vv + ((u64)r << 40));
+        else return gld<4>(&Br[row * 8 + vv]);
     };
     auto crossf = [&](u32 tpos, u32) -> u64 { return cross[tile_natural_c<BT>(tpos)]; };
     auto lload = [&](u32, u32 v, u32 lrow) -> u64 { return sm[lrow * V + v]; };
     auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { sm[lrow * V + v] = val; };
     auto gstore = [&](u32 tpos, u32 v, u64 val, u32) {
         const u64 row = (((((u64)tpos << 12) | lo)) << p.e) | r;
-        if (c + v < p.wc) gst<5>(&p.out[row * p.ld_out + p.col0 + c + v], val);
+        if constexpr (RES) sink ^= val + row;
+        else if (c + v < p.wc) gst<5>(&p.out[row * p.ld_out + p.col0 + c + v], val);
     };
     if constexpr (m == 2) {
         fast_round<BT, V, 0, 4, true, false, true, false>(p.twf_bt, gload, lstore, crossf, NoFactor{});
@@ -175,6 +182,7 @@ __global__ __launch_bounds__(XLP_WGT) void lde_top_dit(const LdeParams p)
         XLP_SYNC();
         fast_round<BT, V, 8, dtop, true, false>(p.twf_bt, lload, gstore);
     }
+    if constexpr (RES) res_sink(p.A, sink);
 }
 
 // tw2[pos] = G^nat(pos & ~15) * w(12)^(((pos >> 4) & 15) * (pos & 15) << 4),  pos < 4096
@@ -206,7 +214,7 @@ int lde_tw2_table(Ctx* ctx, u32 BT, u64 gk, const u64* sk, const u64* twf12, con
     return 0;
 }
 
-template <int BT>
+template <int BT, bool RES = false>
 static int launch_top(Ctx* ctx, const LdeParams& p, bool dit)
 {
     constexpr u32 V = XLP_TOPV;
@@ -216,16 +224,16 @@ static int launch_top(Ctx* ctx, const LdeParams& p, bool dit)
     const size_t lds = ((size_t)((1u << BT) + (1u << BT) / 16 + 1) * V + (1u << BT)) * sizeof(u64) + (XLP_PF ? LDE_PF_LDS : 0);
     static bool attr_done = false;
     if (!attr_done) {
-        XLP_HIP(hipFuncSetAttribute((const void*)lde_top_dif<BT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        XLP_HIP(hipFuncSetAttribute((const void*)lde_top_dit<BT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        XLP_HIP(hipFuncSetAttribute((const void*)lde_top_dif<BT, true, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        XLP_HIP(hipFuncSetAttribute((const void*)lde_top_dit<BT, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     if (!dit) {
         const u64 grid = (u64)ncc << 12;
-        hipLaunchKernelGGL(lde_top_dif<BT>, dim3((unsigned)grid), dim3(threads), lds, ctx->stream, p);
+        hipLaunchKernelGGL((lde_top_dif<BT, true, RES>), dim3((unsigned)grid), dim3(threads), lds, ctx->stream, p);
     } else {
         const u64 grid = ((u64)ncc << 12) << p.e;
-        hipLaunchKernelGGL(lde_top_dit<BT>, dim3((unsigned)grid), dim3(threads), lds, ctx->stream, p);
+        hipLaunchKernelGGL((lde_top_dit<BT, RES>), dim3((unsigned)grid), dim3(threads), lds, ctx->stream, p);
     }
     XLP_HIP(hipGetLastError());
     return 0;
@@ -337,7 +345,19 @@ int dev_extend_fast(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ncols)
 }
 
 // columns [first, first + ncols) of row-major matrices with row stride ld (in: n rows, out: n << e rows)
+static int extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld, u64 first, u64 ncols, bool resident);
 int dev_extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld, u64 first, u64 ncols)
+{
+    return extend_fast_cols(ctx, out, in, L, e, ld, first, ncols, false);
+}
+// The resident forms of the three kernels on the geometry of an extendPol of 2^L x ncols (2^22 and 2^23 rows: the bench's sizes): same tables, same
+// grids, same LDS, no global data traffic (ntt_lde_common.hpp).  `sink` (>= 1024 words) is only written if a checksum takes an impossible value.
+int dev_lde_resident(Ctx* ctx, u64* sink, u32 L, u32 e, u64 ncols)
+{
+    if (L < 22 || L > 23 || e > 3 || ncols < 4 || ncols > 64) return xlp_fail("lde resident: 2^22 or 2^23 rows, blow-up <= 8, 4..64 columns");
+    return extend_fast_cols(ctx, sink, sink, L, e, ncols, 0, ncols, true);
+}
+static int extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld, u64 first, u64 ncols, bool resident)
 {
     const u32 BT = L - 12;
     const u64 n = 1ull << L;
@@ -370,7 +390,8 @@ int dev_extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld
     // column chunks: scratch = (1 + 2^e) * n * wc elements
     const u32 wc_max = ncols < 64 ? (u32)ncols : 64;
     u64* scratch = nullptr;
-    if (ctx_scratch(ctx, (size_t)(1 + ncos) * lde_swords(wc_max, L) * sizeof(u64), 1, &scratch)) return -1;
+    if (resident) scratch = out;                             // (the sink: never dereferenced but by res_sink)
+    else if (ctx_scratch(ctx, (size_t)(1 + ncos) * lde_swords(wc_max, L) * sizeof(u64), 1, &scratch)) return -1;
     p.A = scratch;
     p.B = scratch + lde_swords(wc_max, L);
     for (u64 col0 = 0; col0 < ncols; col0 += wc_max) {
@@ -382,11 +403,11 @@ int dev_extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld
             for (int i = 0; i < 4; i++) { XLP_HIP(hipEventCreate(&ev[i])); ctx->prof_events.push_back(ev[i]); }
             XLP_HIP(hipEventRecord(ev[0], ctx->stream));
         }
-        if (launch_top_bt(ctx, p, BT, false)) return -1;
+        if (resident ? (BT == 11 ? launch_top<11, true>(ctx, p, false) : launch_top<10, true>(ctx, p, false)) : launch_top_bt(ctx, p, BT, false)) return -1;
         if (ctx->profile) XLP_HIP(hipEventRecord(ev[1], ctx->stream));
-        if (launch_lde_mid(ctx, p, BT)) return -1;
+        if (launch_lde_mid(ctx, p, BT, resident)) return -1;
         if (ctx->profile) XLP_HIP(hipEventRecord(ev[2], ctx->stream));
-        if (launch_top_bt(ctx, p, BT, true)) return -1;
+        if (resident ? (BT == 11 ? launch_top<11, true>(ctx, p, true) : launch_top<10, true>(ctx, p, true)) : launch_top_bt(ctx, p, BT, true)) return -1;
         if (ctx->profile) XLP_HIP(hipEventRecord(ev[3], ctx->stream));
     }
     return 0;

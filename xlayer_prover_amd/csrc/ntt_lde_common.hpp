@@ -65,6 +65,13 @@ __device__ __forceinline__ void prefetch_touch(const u64* q, u32 lds_off)
                  : "=&s"(m0_saved) : "v"(q), "s"(lds_off) : "memory");
 }
 
+// RESIDENT forms of the three extendPol kernels (xlp_dev_lde_resident, the ALU ceiling of bench.py's headline, SURVEY.md 8d: "measured by a
+// register-resident microbenchmark"): the same kernels -- butterfly networks, twiddle tables, LDS tiles, barriers, grid -- with the global DATA traffic
+// removed: an input word is made from its index (res_word), an output word is folded into a per-lane checksum that is stored only if it takes
+// an impossible value (res_sink).  What a launch of the resident form takes is what the arithmetic and the LDS exchanges cost by themselves.
+__device__ __forceinline__ u64 res_word(u64 index) { return index ^ 0x5EED0001ULL; }                       // (< 2^63: canonical; the kernels' timing does not depend on values)
+__device__ __forceinline__ void res_sink(u64* out, u64 sink) { if (sink == 0x5EED5EED5EED5EEDULL) out[threadIdx.x] = sink; }
+
 struct NoFactor { __device__ __forceinline__ u64 operator()(u32, u32) const { return 1; } };   // (tile position, column of the tile)
 
 

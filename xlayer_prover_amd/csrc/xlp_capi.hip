@@ -42,12 +42,22 @@ int xlp_fail_hip(hipError_t e, const char* file, int line)
     return -1;
 }
 
+// The scratch slots are shared by every stream of the library (main, side, the slab streams of the step programs): before a slot is freed,
+// swapped or lent, ALL of them are drained -- the selected one alone may be the side stream (xlp_stream_select(1)) while a kernel of the main
+// stream still reads the slot.  These are rare paths (a slot grows a handful of times per process).
+static int ctx_drain_streams(Ctx* ctx)
+{
+    for (hipStream_t s : {ctx->stream, ctx->main_stream, ctx->side_stream, ctx->aux_stream[0], ctx->aux_stream[1], ctx->aux_stream[2]})
+        if (s) XLP_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
 int ctx_scratch(Ctx* ctx, size_t bytes, int slot, u64** out)
 {
     if (ctx->lent[slot] && ctx->lent_bytes[slot] >= bytes) { *out = (u64*)ctx->lent[slot]; return 0; }     // a lent region that is large enough serves
     if (ctx->scratch_bytes[slot] < bytes) {
         if (ctx->scratch[slot]) {
-            XLP_HIP(hipStreamSynchronize(ctx->stream));
+            if (ctx_drain_streams(ctx)) return -1;
             XLP_HIP(hipFree(ctx->scratch[slot]));
             ctx->scratch[slot] = nullptr;
             ctx->scratch_bytes[slot] = 0;
@@ -171,7 +181,7 @@ int xlp_scratch_lend(uint32_t slot, void* dev_ptr, size_t bytes)
     XLP_ENTER;
     if (ensure_init()) return -1;
     if (slot >= 9) return xlp_fail("xlp_scratch_lend: slot 0..8");
-    XLP_HIP(hipStreamSynchronize(g_ctx.stream));
+    if (ctx_drain_streams(&g_ctx)) return -1;
     if (slot == 8) { g_ctx.fft_tw_log = 0; g_ctx.fft_tw_ptr = nullptr; }
     g_ctx.lent[slot] = dev_ptr;
     g_ctx.lent_bytes[slot] = dev_ptr ? bytes : 0;
@@ -181,7 +191,7 @@ int xlp_scratch_release(uint32_t mask)
 {
     XLP_ENTER;
     if (!g_ctx.inited) return 0;
-    XLP_HIP(hipStreamSynchronize(g_ctx.stream));
+    if (ctx_drain_streams(&g_ctx)) return -1;
     for (int k = 0; k < 9; k++)
         if (((mask >> k) & 1) && g_ctx.scratch[k]) {
             XLP_HIP(hipFree(g_ctx.scratch[k]));
@@ -303,6 +313,8 @@ void xlp_shutdown(void)
         if (g_ctx.scratch[i]) (void)hipFree(g_ctx.scratch[i]);
         g_ctx.scratch[i] = nullptr;
         g_ctx.scratch_bytes[i] = 0;
+        g_ctx.lent[i] = nullptr;                               // a caller-owned region is not ours past a shutdown: a re-init must not hand it out
+        g_ctx.lent_bytes[i] = 0;
     }
     g_ctx.fft_tw_log = 0; g_ctx.fft_tw_ptr = nullptr;
     if (g_ctx.selected != 0) { g_ctx.stream = g_ctx.main_stream; g_ctx.selected = 0; }
@@ -587,6 +599,14 @@ int xlp_dev_perm_resident(uint64_t* out, uint64_t count, uint64_t iters)
     if (ensure_init()) return -1;
     if (count && !out) return xlp_fail("xlp_dev_perm_resident: null pointer");
     return dev_perm_resident(&g_ctx, out, count, iters);
+}
+int xlp_dev_lde_resident(uint64_t* sink, uint64_t n_ext, uint64_t n, uint64_t ncols)
+{
+    XLP_ENTER;
+    if (ensure_init()) return -1;
+    if (!sink) return xlp_fail("xlp_dev_lde_resident: null pointer");
+    if (!n || (n & (n - 1)) || n_ext < n || (n_ext & (n_ext - 1))) return xlp_fail("xlp_dev_lde_resident: sizes must be powers of two, n_ext >= n");
+    return dev_lde_resident(&g_ctx, sink, (u32)__builtin_ctzll(n), (u32)(__builtin_ctzll(n_ext) - __builtin_ctzll(n)), ncols);
 }
 int xlp_profile_enable(int on)
 {

@@ -81,6 +81,7 @@ bool ntt_fast_supported(u32 L, u64 ncols);
 int dev_ntt_fast(Ctx* ctx, u64* dst, const u64* src, u32 L, u64 ncols, int inverse);
 int dev_extend_fast(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ncols);
 int dev_extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld, u64 first, u64 ncols);
+int dev_lde_resident(Ctx* ctx, u64* sink, u32 L, u32 e, u64 ncols);
 
 // colmajor.hip / ntt_lde_cm.hip (column-major device sections)
 int dev_rows_to_cm(Ctx* ctx, u64* dst, u64 cstride, u64 cos, const u64* src, u64 ld, u64 col0, u64 ncols, u64 rows, u32 ext);

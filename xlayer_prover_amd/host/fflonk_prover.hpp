@@ -305,6 +305,7 @@ class FflonkProver
     // reserved-memory mode (the reference's FflonkProver(E, reservedMemoryPtr, reservedMemorySize), prover.cpp:117: the STARKs' polynomial
     // memory doubles as the prover's): every device vector -- the key's too -- is carved from this region at the start of each proof, the
     // key uploaded again from the host image; nothing of the prover stays in HBM between final proofs (the zkEVM slab fills the card)
+    uint32_t releaseMask = 0;                                           // scratch slots this proof could not be lent a region for
     char* reserved = NULL;
     uint64_t reservedBytes = 0, reservedUsed = 0;
     std::function<std::pair<void*, uint64_t>()> reservedProvider;
@@ -557,9 +558,10 @@ public:
         if (reserved) {
             timed("FFLONK_KEY_TO_DEVICE", [&] { deviceSetup(); });
             // what is left of the region serves as the library's scratch for the proof: the transforms' twiddle table (slot 8), scans / evaluations (4), multi-exponentiation (7)
+            releaseMask = 0;
             auto lend = [&](uint32_t slot, uint64_t bytes) {
                 const uint64_t at_ = (reservedUsed + 255) & ~255ULL;
-                if (at_ + bytes > reservedBytes) return;               // (too small: the slot grows its own scratch and it is released below)
+                if (at_ + bytes > reservedBytes) { releaseMask |= 1u << slot; return; }      // (too small: the slot grows its own scratch and it is released below)
                 XLP_CHECK(xlp_scratch_lend(slot, reserved + at_, bytes));
                 reservedUsed = at_ + bytes;
             };
@@ -589,7 +591,10 @@ public:
         evaluationCommitments["inv"] = getMontgomeryBatchedInverse();
         if (reserved) {                                                 // the card goes back to the STARKs as it was
             for (uint32_t slot : {8u, 4u, 7u}) XLP_CHECK(xlp_scratch_lend(slot, NULL, 0));
-            XLP_CHECK(xlp_scratch_release((1u << 8) | (1u << 4) | (1u << 5) | (1u << 7)));
+            // ... and what THIS proof made the library grow goes back: the slots only this prover uses (7: multi-exponentiation, 8: twiddles -- a lent
+            // region that a request outgrew falls through to the slot's own scratch) and slot 4 when its lending did not fit.  Slots 4 / 5 otherwise
+            // serve the STARKs' step programs (csrc/expr.hip), which would re-allocate them inside the next batch proof's timers
+            XLP_CHECK(xlp_scratch_release((1u << 7) | (1u << 8) | (releaseMask & (1u << 4))));
         }
         std::string pub = "[";
         for (uint32_t i = 1; i <= zkey->nPublic; i++) pub += std::string(i > 1 ? "," : "") + "\"" + FrH::toString(FrH::toMontgomery(wit[i])) + "\"";      // :546-553

@@ -12,6 +12,8 @@
 #pragma once
 #include <functional>
 #include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include "starks.hpp"
 #include "starkRecursiveF.hpp"
 #include "fflonk_prover.hpp"
@@ -170,12 +172,21 @@ public:
         }
         // prover.cpp:452-457: the committed polynomials as the executor left them -> zkevm.commit (row-major, pilDegree x nCommitted words);
         // a row-sharded rank writes its rows at their offset of the same file
+        // (no rank truncates: the ranks' executors run concurrently, and a later "wb" open would drop rows another rank has written.  Every rank opens
+        // the file O_CREAT | O_RDWR and pwrites at its offset; rank 0 cuts it to the full size -- a shorter file of an earlier run grows, a longer one shrinks)
         if (config.zkevmCmPolsAfterExecutor.size()) {
-            FILE* f = fopen(config.zkevmCmPolsAfterExecutor.c_str(), shardedZ && req.firstRow ? "r+b" : "wb");
-            if (!f && shardedZ) f = fopen(config.zkevmCmPolsAfterExecutor.c_str(), "wb");
-            if (!f || fseek(f, (long)(req.firstRow * Wz * sizeof(Goldilocks::Element)), SEEK_SET) || fwrite(cmPols, sizeof(Goldilocks::Element), Nz * Wz, f) != Nz * Wz)
-                xlp_exit_process(("Prover::genBatchProof: cannot write " + config.zkevmCmPolsAfterExecutor).c_str());
-            fclose(f);
+            const std::string& fn = config.zkevmCmPolsAfterExecutor;
+            const int fd = ::open(fn.c_str(), O_CREAT | O_RDWR, 0644);
+            bool ok = fd >= 0;
+            const size_t rowBytes = Wz * sizeof(Goldilocks::Element);
+            if (ok && req.firstRow == 0) ok = ::ftruncate(fd, (off_t)((uint64_t)world * Nz * rowBytes)) == 0;
+            const char* src = (const char*)cmPols;
+            for (size_t done = 0, total = Nz * rowBytes; ok && done < total;) {
+                const ssize_t w = ::pwrite(fd, src + done, std::min<size_t>(total - done, (size_t)1 << 30), (off_t)(req.firstRow * rowBytes + done));
+                if (w <= 0) ok = false; else done += (size_t)w;
+            }
+            if (fd >= 0 && ::close(fd)) ok = false;
+            if (!ok) xlp_exit_process(("Prover::genBatchProof: cannot write " + fn).c_str());
         }
         if (req.result != ZKR_SUCCESS) return;           // prover.cpp:437: the executor reports through the request
         // ---- publics (prover.cpp:494-559): first / last row of Main's registers; recursive2's verification key behind them
@@ -411,7 +422,13 @@ public:
                 req.finalWitness(req.recursivefProofOutput, witness);
             }
             Tm t(&req, "RAPID_SNARK");
-            const auto r = prover->prove(witness.data());                // (the header check of prove(BinFile*) is the witness calculator's business here)
+            // the checks of prove(BinFile*) against the key -- field and length -- on what the witness calculator handed over (its field is BN254's
+            // scalar field by construction; a --final-wtns file's prime is compared where it is read): a witness of another circuit ends with the
+            // reference's "Invalid witness length" instead of an out-of-bounds read of the vector
+            WtnsUtils::Header wh;
+            wh.n8 = 32; wh.nVars = (uint32_t)witness.size(); memcpy(wh.prime, FrModulus::Q, 32);
+            if (witness.size() > 0xffffffffULL) xlp_exit_process("Prover::genFinalProof: the witness has more than 2^32 values");
+            const auto r = prover->prove(witness.data(), &wh);
             req.finalProofOutput = r.first; req.finalPublicsOutput = r.second;
             for (const auto& kv : prover->lastTimers) req.timers.emplace_back("fflonk." + kv.first, kv.second);
             if (config.saveProofToFile) json2file(req.finalProofOutput, req.filePrefix + "final_proof.proof.json");

@@ -140,6 +140,7 @@ int main(int argc, char** argv)
             req.finalWitness = [&](const std::string&, std::vector<FrElement>& w) {
                 auto f = BinFileUtils::openExisting(finalWtns, "wtns", 2);
                 auto h = WtnsUtils::loadHeader(f.get());
+                if (memcmp(h->prime, FrModulus::Q, 32) != 0) xlp_exit_process("--final-wtns: the witness is not over BN254's scalar field");
                 w.resize(h->nVars);
                 if (f->getSectionSize(2) < (uint64_t)h->nVars * 32) xlp_exit_process("--final-wtns: data section too short");
                 memcpy(w.data(), f->getSectionData(2), (size_t)h->nVars * 32);
