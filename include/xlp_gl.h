@@ -283,6 +283,12 @@ int xlp_expr_create(xlp_expr_program** out, const uint64_t* code, uint64_t ncode
  *   INTT of the quotient and FRI read them).
  * Base-domain programs: coset_rows = 0, one coset, cbase = 0.  tools/zkevm_geometry.py to_colmajor converts a program. */
 #define XLP_EXPR_COLMAJOR 1ULL
+/* XLP_EXPR_CANONICAL (with XLP_EXPR_COLMAJOR): the caller promises that every word of pols / const_pols / const_pols_2ns the program reads is CANONICAL
+ * (< p).  The ahead-of-time kernels then use the words as loaded (xlp_expr_codegen leaves out one canonicalisation per column load: 4 vector
+ * instructions of ~60 a load is followed by); the interpreter does not care.  host/starks.hpp keeps that promise: what enters a column-major section is
+ * canonical -- the witness and the constants are canonicalised as they are transposed (xlp_dev_rows_to_cm), every kernel of this library stores
+ * canonical words.  A plugin generated under the promise only attaches to a program created with it. */
+#define XLP_EXPR_CANONICAL 2ULL
 int xlp_expr_create_ex(xlp_expr_program** out, const uint64_t* code, uint64_t ncode, uint64_t ntmp1, uint64_t ntmp3, uint64_t flags);
 int xlp_expr_destroy(xlp_expr_program* prog);
 /* Ahead-of-time path (the counterpart of the reference's generated straight-line chelpers,

@@ -44,6 +44,21 @@ def test_transposes_between_the_two_layouts(xlp, orc, rows, w, ext, col0, ncols)
 
 
 @pytest.mark.gpu
+def test_rows_to_cm_canonicalises(xlp, orc):
+    """what enters a column-major section is canonical (XLP_EXPR_CANONICAL, include/xlp_gl.h): words >= p of a row-major image leave the transposition
+    reduced, everything else as it is"""
+    import torch
+    P = 0xFFFFFFFF00000001
+    rows, w = 256, 7
+    a = orc.fill(rows * w, 0x5EED0D77).reshape(rows, w).copy()
+    a[3, 2] = P; a[100, 6] = 2**64 - 1; a[255, 0] = P + 5
+    dst = torch.zeros(w * rows, dtype=torch.int64, device="cuda")
+    xlp.dev_rows_to_cm(dst, rows, xlp.from_np(a.reshape(-1)), w, 0, w, rows, 1)
+    xlp.sync()
+    assert (xlp.to_np(dst) == _cm(a % np.uint64(P), 1)).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n0,n1,n", [(5, 2, 3000), (7, 4, 1), (3, 1, 255), (2, 8, 1024), (1, 1, 1025)])
 def test_copy_3d_regroups_runs(xlp, orc, n0, n1, n):
     """the packing of a sharded commit on column-major windows: [columns][cosets][a rank's rows] out of whole columns and back, with the

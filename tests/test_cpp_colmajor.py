@@ -132,3 +132,28 @@ def test_commit_file_round_trip_through_the_prover(tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     again = json.loads(r.stdout.strip().splitlines()[-1])
     assert again["batch_proof_fnv"] == first["batch_proof_fnv"] and again["batch_proof_bytes"] == first["batch_proof_bytes"]
+
+
+@pytest.mark.gpu
+def test_merkelize_memory_is_the_merkle_root_of_the_slab_words(tmp_path, orc):
+    """Starks::merkelizeMemory (starks.cpp:671-700; host/starks.hpp): the reference's debug hash of the polynomial memory -- the slab's words as a matrix of
+    2^k rows (k as the reference's loop finds it), merkletree, the root -- over the device slab after a proof == the oracle's merkletree of the same words"""
+    import numpy as np
+    from tools import make_stark_bundle as B
+    if not _programs_built():
+        pytest.skip("converted reference programs not built (needs the reference tree at build time)")
+    col = B.make("zkevm", 10, False, out=str(tmp_path / "col"), colmajor=True)
+    dump = str(tmp_path / "slab.bin")
+    r = subprocess.run([EXE, "bundle", col, "zkevm", str(WSEED), str(CSEED), "--merkelize", dump], capture_output=True, text=True, timeout=360)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stderr.splitlines() if l.startswith("rootDBG ")][-1].split()
+    root, words = [int(x) for x in line[1:5]], int(line[6])
+    slab = np.fromfile(dump, dtype=np.uint64)
+    assert slab.size == words and words % 2 == 0
+    nrows = 2
+    while words % (nrows * 2) == 0:
+        nrows *= 2
+    ncols = words // nrows
+    assert ncols > 4                                          # (a real sponge per row, not the copy rule of narrow trees)
+    nodes = orc.merkletree(slab.reshape(nrows, ncols), ncols, nrows)
+    assert [int(x) for x in nodes[-4:]] == root

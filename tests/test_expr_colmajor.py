@@ -56,7 +56,7 @@ CASES = [("zkevm", "step2prev"), ("zkevm", "step3prev"), ("zkevm", "step3"), ("z
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("circ,step", CASES)
-def test_colmajor_program_on_the_gpu_equals_the_rowmajor_program_on_the_oracle(xlp, orc, tmp_path, circ, step):
+def test_colmajor_program_on_the_gpu_equals_the_rowmajor_program_on_the_oracle(xlp, orc, tmp_path, monkeypatch, circ, step):
     ln = 8
     G, progs, info, L, ext = _programs(circ, ln)
     code, n1, n3 = progs[step]
@@ -68,9 +68,12 @@ def test_colmajor_program_on_the_gpu_equals_the_rowmajor_program_on_the_oracle(x
     assert any((exp[k] != bufs[k]).any() for k in ("pols", "q_2ns", "f_2ns"))
     code_cm = G.to_colmajor(code, L, ext)
     cm = _to_colmajor_buffers(G, bufs, L, n, ext, nc)
-    p = xlp.ExprProgram(code_cm, n1, n3, colmajor=True)
+    # the ahead-of-time kernels are generated the way the product's plugins are (chelpers/Makefile GEN: loads pipelined, segment cuts by dynamic
+    # programming) and under the promise of canonical sections (XLP_EXPR_CANONICAL: the buffers here are orc.fill's, canonical)
+    p = xlp.ExprProgram(code_cm, n1, n3, colmajor=True, canonical=True)
     for compiled in (False, True):
         if compiled:
+            monkeypatch.setenv("XLP_EXPR_HOIST_LOADS", "4"); monkeypatch.setenv("XLP_EXPR_CUT", "384")
             p.compile(str(tmp_path / "jit"), parts=8)
         dev = {k: xlp.from_np(v) for k, v in cm.items()}
         sp = xlp.steps_params(n_const_pols=nc, n_const_pols_2ns=nc, coset_rows=n if step.endswith("2ns") else 0, **dev)

@@ -319,6 +319,34 @@ def test_expr_generated_code_with_pipelined_loads_on_cpu(orc, tmp_path, seed, n,
         assert (got[k] == exp[k]).all(), f"{k}: {np.flatnonzero(got[k] != exp[k])[:5]}"
 
 
+@pytest.mark.parametrize("kind,seed,n,size,seg", [("random", 41, 64, 700, 128), ("random", 42, 64, 1500, 0), ("accumulation", 43, 64, 400, 96), ("random", 44, 96, 900, 64)])
+def test_expr_generated_representations_on_small_values_on_cpu(orc, tmp_path, kind, seed, n, size, seg):
+    """"any" words where canonical ones are required (csrc/expr.hip, REPRESENTATIONS: a product is only canonicalised where its reader needs it): the CPU
+    stand-in of gl_field.hpp traps on a non-canonical word handed to addc / subc / mul3 / mac3 / neg / an accumulator base, and its mul / add / sub return the
+    non-canonical representative whenever r + p fits 64 bits -- which needs SMALL values, so every input here is one of 0, 1, 2, 3, p - 1, p - 2, p, p + 1
+    (products and sums of those stay small for many instructions).  Outputs equal the oracle's: what is stored is canonical."""
+    P = 0xFFFFFFFF00000001
+    prog, width = (random_program(seed, n, size) if kind == "random" else accumulation_program(seed, n, size))
+    bufs = make_buffers(orc, 0x5EED0A00 + seed, n, width)
+    pick = np.array([0, 1, 2, 3, P - 1, P - 2, P, P + 1], dtype=np.uint64)
+    rng = np.random.default_rng(seed)
+    for k in bufs:
+        bufs[k] = pick[rng.integers(0, len(pick) if k == "pols" else 6, size=bufs[k].size)]      # (only pols may hold non-canonical words)
+    env = {"XLP_EXPR_SEG": str(seg)} if seg else {"XLP_EXPR_CUT": "200", "XLP_EXPR_CUT_MIN": "16"}
+    os.environ.update(env)
+    try:
+        got = _run_generated_on_cpu(tmp_path, prog.code, prog.ntmp1, prog.ntmp3, bufs, 0, n, 5, 4, hoist=3)
+    finally:
+        for k in env:
+            del os.environ[k]
+    text = open(tmp_path / "prog.hip").read()
+    assert "gl::mul(" in text and ("gl::add(" in text or "gl::sub(" in text) and "gl::canon(v" in text
+    exp = {k: v.copy() for k, v in bufs.items()}
+    orc.expr_run(prog.code, prog.ntmp1, prog.ntmp3, exp, 0, n, 5, 4)
+    for k in ("pols", "q_2ns", "f_2ns"):
+        assert (got[k] == exp[k]).all(), f"{k}: {np.flatnonzero(got[k] != exp[k])[:5]}"
+
+
 def _codegen_text(tmp_path, prog, name, **env):
     from xlayer_prover_amd import capi
     for k, v in env.items():

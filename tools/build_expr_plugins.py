@@ -82,7 +82,8 @@ def main():
                 code, ntmp1, ntmp3 = geo[step]
             else:
                 code, _ = R.shrink(code, 1 << lr)
-            p = capi.ExprProgram(code, ntmp1, ntmp3, colmajor=bool(geo) and a.colmajor and not step.endswith("_tab"))
+            cm = bool(geo) and a.colmajor and not step.endswith("_tab")
+            p = capi.ExprProgram(code, ntmp1, ntmp3, colmajor=cm, canonical=cm)      # (canonical: as host/steps.hpp creates the column-major programs)
             # regenerate the launcher text (cheap) and rebuild only if it changed: its signature covers the whole
             # compiled program, so a change of the library's compile step invalidates the plugin too
             build = os.path.join(a.out_dir or R.REF_DIR, "build")

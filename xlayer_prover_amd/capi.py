@@ -724,11 +724,12 @@ def steps_params(n_const_pols=0, n_const_pols_2ns=0, coset_rows=0, coset_stride=
 class ExprProgram:
     """xlp_expr_program handle (xlp_expr_create / xlp_expr_destroy)"""
 
-    def __init__(self, code, ntmp1, ntmp3, colmajor=False):
-        """colmajor: the program addresses column-major buffers (XLP_EXPR_COLMAJOR, include/xlp_gl.h)"""
+    def __init__(self, code, ntmp1, ntmp3, colmajor=False, canonical=False):
+        """colmajor: the program addresses column-major buffers (XLP_EXPR_COLMAJOR, include/xlp_gl.h); canonical: and they hold canonical words
+        (XLP_EXPR_CANONICAL: what host/starks.hpp promises and the product's plugins are generated under)"""
         code = np.ascontiguousarray(code, dtype=np.uint64)
         self._h = C.c_void_p(None)
-        _ck(load().xlp_expr_create_ex(C.byref(self._h), code.ctypes.data_as(C.c_void_p), code.size, ntmp1, ntmp3, 1 if colmajor else 0), "xlp_expr_create")
+        _ck(load().xlp_expr_create_ex(C.byref(self._h), code.ctypes.data_as(C.c_void_p), code.size, ntmp1, ntmp3, (1 if colmajor else 0) | (2 if canonical else 0)), "xlp_expr_create")
 
     def run(self, params, row0, nrows):
         _ck(load().xlp_dev_expr_run(self._h, C.byref(params), row0, nrows), "xlp_dev_expr_run")

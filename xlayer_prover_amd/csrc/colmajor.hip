@@ -16,7 +16,7 @@
 
 namespace xlp {
 
-// dst[c * cstride + r * cos + q] = src[((q << ext) | r) * ld + col0 + c],  c < ncols, (q << ext | r) < rows.
+// dst[c * cstride + r * cos + q] = canon(src[((q << ext) | r) * ld + col0 + c]),  c < ncols, (q << ext | r) < rows.
 // One workgroup: 64 storage rows of one coset x 64 columns through LDS (reads run along the row-major rows, writes along the columns).
 __global__ __launch_bounds__(256) void rows_to_cm_kernel(u64* dst, u64 cstride, u64 cos, const u64* src, u64 ld, u64 col0, u32 ncols, u64 nq, u32 ext)
 {
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void rows_to_cm_kernel(u64* dst, u64 cstride, 
     for (u32 i = wv; i < 64; i += 4) {
         const u64 q = q0 + i;
         u64 v = 0;
-        if (q < nq && c0 + lane < ncols) v = src[(((q << ext) | r)) * ld + col0 + c0 + lane];
+        if (q < nq && c0 + lane < ncols) v = gl::canon(src[(((q << ext) | r)) * ld + col0 + c0 + lane]);   // what enters a column-major section is canonical (XLP_EXPR_CANONICAL)
         tile[i][lane] = v;
     }
     __syncthreads();

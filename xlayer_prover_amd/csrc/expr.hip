@@ -47,6 +47,7 @@ struct xlp_expr_program {
     std::vector<uint32_t> wcols;  // indices of the written columns
     uint64_t halo = 0, modulus = 0;
     bool serial_slabs = false;    // some row-major operand is addressed directly (not staged): slabs must run one after the other
+    bool canonical = false;       // XLP_EXPR_CANONICAL: the column-major buffers hold canonical words (the generated kernels use them as loaded)
     bool colmajor = false;        // XLP_EXPR_COLMAJOR: the buffers are column-major (see include/xlp_gl.h): nothing is staged, every access is direct
     void* jit_handle = nullptr;   // dlopen'ed plugin (xlp_expr_attach)
     void* jit_launch = nullptr;
@@ -807,7 +808,7 @@ static u64 program_signature(const xlp_expr_program* P)
     h = fnv(P->dcode.data(), P->dcode.size() * 8, h);
     for (const xlp_expr_column& c : P->cols) { h = fnv(&c.buf, 4, h); h = fnv(&c.off, 8, h); h = fnv(&c.stride, 8, h); }
     h = fnv(&P->tmp_words, 8, h);
-    const u64 cm = P->colmajor ? 1 : 0;
+    const u64 cm = (P->colmajor ? 1 : 0) | (P->canonical ? 2 : 0);
     if (cm) h = fnv(&cm, 8, h);
     return h;
 }
@@ -1001,6 +1002,7 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
     // the three canonical words are only computed (fold) where something else reads them or at the end of the segment.  Results are the
     // same field elements.  XLP_EXPR_LAZY=0 generates the plain form; XLP_EXPR_LAZY_ACCS bounds the accumulators alive at once
     // (42 registers each).
+    const bool lazy_canon = env_int("XLP_EXPR_LAZY_CANON", 1) != 0;
     const bool lazy_on = env_int("XLP_EXPR_LAZY", 1) != 0;
     const size_t lazy_max = (size_t)env_int("XLP_EXPR_LAZY_ACCS", 3);
     const std::string prologue =
@@ -1043,6 +1045,24 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
         std::map<std::string, std::string> dval;         // direct scalar expressions -> SSA name
         u64 nv = 0;
         auto fresh = [&]() { snprintf(buf, sizeof buf, "v%llu", (unsigned long long)nv++); return std::string(buf); };
+        // REPRESENTATIONS (round 5).  A name is either a CANONICAL word (< p: everything loaded, every constant, every addc / subc / mul3 / fold result) or
+        // an "ANY" word (< 2^64, congruent: what gl::mul / gl::add / gl::sub return, csrc/gl_field.hpp).  A product is not canonicalised (4 vector
+        // instructions + two hazard wait states) when what reads it does not need that: another multiplication, the carry-free accumulators, an addition
+        // or subtraction whose OTHER operand is canonical (any + canon, any - canon stay "any" at the cost of addc / subc).  cn() makes the canonical
+        // word where one is required -- stores, mul3 / mac3 operands, the subtrahend, one side of any + any -- once per value.  XLP_EXPR_LAZY_CANON=0: all canonical.
+        std::set<std::string> anyv;
+        std::map<std::string, std::string> canon_of;
+        auto cn = [&](const std::string& n) -> std::string {
+            if (!anyv.count(n)) return n;
+            auto it = canon_of.find(n);
+            if (it != canon_of.end()) return it->second;
+            const std::string c = fresh();
+            os << "    const u64 " << c << " = gl::canon(" << n << ");\n";
+            canon_of[n] = c;
+            return c;
+        };
+        auto anyname = [&](const std::string& n) { if (lazy_canon) anyv.insert(n); return n; };
+        const char* const MUL = lazy_canon ? "gl::mul(" : "gl::mulc(";
         // a load of a value no store of this segment can alias (a temporary of an earlier segment, a staged / section column the segment does
         // not write, a constant column): its statement is placed when the segment is assembled (place_loads), here it leaves a mark
         std::vector<SegLoad> loads;
@@ -1099,7 +1119,7 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
                     p.done = true;
                 }
                 if (!p.done) {
-                    for (u32 q = 0; q < 3; q++) { p.mat[q] = fresh(); os << "    const u64 " << p.mat[q] << " = gl::mulc(" << p.k[q] << ", " << p.v << ");\n"; }
+                    for (u32 q = 0; q < 3; q++) { p.mat[q] = anyname(fresh()); os << "    const u64 " << p.mat[q] << " = " << MUL << p.k[q] << ", " << p.v << ");\n"; }
                     p.done = true;
                 }
                 return p.mat[c];
@@ -1149,9 +1169,10 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
                     if (it != mval.end()) return it->second;
                     const std::string idx = pr ? "wrapc(row + " + num(p[1]) + ", A.cbase, " + num(p[2]) + ")" : std::string("row");
                     std::string n;
-                    if (pol && wcolm.count(col)) { n = fresh(); os << "    const u64 " << n << " = gl::canon(PW[" << num(col) << " + " << idx << "]);\n"; }
-                    else if (pol) n = load("PR[" + num(col) + " + " + idx + "]", true);
-                    else n = load(std::string(buf == 1 ? "KN[" : "KE[") + num(col) + " * " + (buf == 1 ? "KNR" : "KER") + " + " + idx + "]", true);
+                    const bool cnl = !P->canonical;            // (XLP_EXPR_CANONICAL: the sections hold canonical words)
+                    if (pol && wcolm.count(col)) { n = fresh(); os << "    const u64 " << n << " = " << (cnl ? "gl::canon(" : "(") << "PW[" << num(col) << " + " << idx << "]);\n"; }
+                    else if (pol) n = load("PR[" + num(col) + " + " + idx + "]", cnl);
+                    else n = load(std::string(buf == 1 ? "KN[" : "KE[") + num(col) + " * " + (buf == 1 ? "KNR" : "KER") + " + " + idx + "]", cnl);
                     mval[key] = n;
                     return n;
                 }
@@ -1190,8 +1211,8 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
                 for (u32 c = 0; c < 3; c++) p.k[c] = raw(arr + num(3 * in.prm[ko][0] + c) + "]");
                 const int vo = ko == 1 ? 2 : 1;
                 p.ext = in.dim[vo] == 3;
-                if (p.ext) for (u32 c = 0; c < 3; c++) p.x[c] = real(src(in, vo, c));
-                else p.v = real(src(in, vo, 0));
+                if (p.ext) for (u32 c = 0; c < 3; c++) p.x[c] = cn(real(src(in, vo, c)));     // mul3 / mac3 take canonical words
+                else p.v = real(src(in, vo, 0));                                              // (any word: mac and mul take it as it is)
                 prods.push_back(p);
                 for (u32 c = 0; c < 3; c++) r[c] = sym('P', (u32)prods.size() - 1, 0, c);
             } else {
@@ -1237,7 +1258,7 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
                         if (others) (void)real(X[0]);
                     } else {
                         std::string base[3] = {"0ULL", "0ULL", "0ULL"};
-                        if (X) for (u32 c = 0; c < xd; c++) base[c] = real(X[c]);
+                        if (X) for (u32 c = 0; c < xd; c++) base[c] = cn(real(X[c]));
                         size_t alive = 0;
                         for (const Acc& A : accs) alive += !A.retired;
                         while (alive >= lazy_max && alive) {                     // retire the accumulator touched longest ago
@@ -1273,29 +1294,40 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
             else if (in.op == XLP_OP_COPY) { for (u32 c = 0; c < dd; c++) r[c] = a[c]; }
             else if (in.op == XLP_OP_ADD || in.op == XLP_OP_SUB) {
                 for (u32 c = 0; c < 3; c++) { a[c] = real(a[c]); b[c] = real(b[c]); }
-                const char* f = in.op == XLP_OP_ADD ? "gl::addc" : "gl::subc";
                 for (u32 c = 0; c < dd; c++) {
                     const bool ha = c < ad, hb = c < bd;
-                    if (ha && hb) { r[c] = fresh(); os << "    const u64 " << r[c] << " = " << f << "(" << a[c] << ", " << b[c] << ");\n"; }
+                    if (ha && hb) {
+                        // any + canon / canon + any / any - canon stay "any"; any + any and canon - any canonicalise one side first
+                        std::string x = a[c], y = b[c];
+                        if (in.op == XLP_OP_ADD) {
+                            if (anyv.count(x) && anyv.count(y)) y = cn(y);
+                            if (anyv.count(y)) std::swap(x, y);                          // gl::add(any, canon)
+                        } else y = cn(y);
+                        const bool res_any = anyv.count(x) != 0;
+                        const char* f = in.op == XLP_OP_ADD ? (res_any ? "gl::add" : "gl::addc") : (res_any ? "gl::sub" : "gl::subc");
+                        r[c] = fresh(); os << "    const u64 " << r[c] << " = " << f << "(" << x << ", " << y << ");\n";
+                        if (res_any) anyv.insert(r[c]);
+                    }
                     else if (ha) r[c] = a[c];
                     else if (in.op == XLP_OP_ADD) r[c] = b[c];
-                    else { r[c] = fresh(); os << "    const u64 " << r[c] << " = gl::neg(" << b[c] << ");\n"; }
+                    else { const std::string y = cn(b[c]); r[c] = fresh(); os << "    const u64 " << r[c] << " = gl::neg(" << y << ");\n"; }
                 }
             } else {
                 for (u32 c = 0; c < 3; c++) { a[c] = real(a[c]); b[c] = real(b[c]); }
                 if (ad == 3 && bd == 3) {
+                    for (u32 c = 0; c < 3; c++) { a[c] = cn(a[c]); b[c] = cn(b[c]); }
                     const std::string e = fresh();
                     os << "    const gl::e3 " << e << " = gl::mul3(gl::e3{{" << a[0] << ", " << a[1] << ", " << a[2] << "}}, gl::e3{{" << b[0] << ", " << b[1] << ", " << b[2] << "}});\n";
                     for (u32 c = 0; c < 3; c++) r[c] = e + ".c[" + std::to_string(c) + "]";
                 } else if (ad == 3 || bd == 3) {
                     const std::string* x = ad == 3 ? a : b;
                     const std::string& s = ad == 3 ? b[0] : a[0];
-                    for (u32 c = 0; c < 3; c++) { r[c] = fresh(); os << "    const u64 " << r[c] << " = gl::mulc(" << x[c] << ", " << s << ");\n"; }
-                } else { r[0] = fresh(); os << "    const u64 " << r[0] << " = gl::mulc(" << a[0] << ", " << b[0] << ");\n"; }
+                    for (u32 c = 0; c < 3; c++) { r[c] = anyname(fresh()); os << "    const u64 " << r[c] << " = " << MUL << x[c] << ", " << s << ");\n"; }
+                } else { r[0] = anyname(fresh()); os << "    const u64 " << r[0] << " = " << MUL << a[0] << ", " << b[0] << ");\n"; }
             }
             }
             // destination (a temporary may hold a symbol; anything stored is a word)
-            if (in.k[0] != XD_TMP) for (u32 c = 0; c < dd; c++) r[c] = real(r[c]);
+            if (in.k[0] != XD_TMP) for (u32 c = 0; c < dd; c++) r[c] = cn(real(r[c]));       // what is stored is a canonical word
             const u64* p = in.prm[0];
             switch (in.k[0]) {
             case XD_TMP: for (u32 c = 0; c < dd; c++) { tval[p[0] + c] = r[c]; tdef[p[0] + c] = true; } break;
@@ -1327,7 +1359,7 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
             }
         }
         for (const auto& kv : tval)
-            if (tdef[kv.first] && live_in[sg + 1][kv.first]) { const std::string v = real(kv.second); os << "    T[" << kv.first << "ULL * TS] = " << v << ";\n"; stats.tmp_stores++; }
+            if (tdef[kv.first] && live_in[sg + 1][kv.first]) { const std::string v = cn(real(kv.second)); os << "    T[" << kv.first << "ULL * TS] = " << v << ";\n"; stats.tmp_stores++; }
         stats.longest = std::max(stats.longest, i1 - i0);
         os << "}\n";
         segsrc[sg] = place_loads(os.str(), loads, hoist, hoist_ahead, stats);
@@ -1547,7 +1579,8 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
 
 int expr_create(xlp_expr_program** out, const u64* code, u64 ncode, u64 ntmp1, u64 ntmp3, u64 flags)
 {
-    if (flags & ~(u64)XLP_EXPR_COLMAJOR) return xlp_fail("expr create: unknown flag");
+    if (flags & ~(u64)(XLP_EXPR_COLMAJOR | XLP_EXPR_CANONICAL)) return xlp_fail("expr create: unknown flag");
+    if ((flags & XLP_EXPR_CANONICAL) && !(flags & XLP_EXPR_COLMAJOR)) return xlp_fail("expr create: XLP_EXPR_CANONICAL goes with XLP_EXPR_COLMAJOR");
     if (!out) return xlp_fail("expr create: null output");
     *out = nullptr;
     if (ncode && !code) return xlp_fail("expr create: null code");
@@ -1569,6 +1602,7 @@ int expr_create(xlp_expr_program** out, const u64* code, u64 ncode, u64 ntmp1, u
     }
     p->ntmp1 = ntmp1; p->ntmp3 = ntmp3; p->ninstr = ninstr;
     p->colmajor = (flags & XLP_EXPR_COLMAJOR) != 0;
+    p->canonical = (flags & XLP_EXPR_CANONICAL) != 0;
     compile(p);
     // the device copy is made by the first run: creating, generating code and attaching need no GPU
     *out = p;

@@ -24,6 +24,7 @@
 //    transformed on every rank; evmap = local sums + one all-gather; openings come from the owning rank.  Every rank runs the transcript
 //    and ends with the complete proof.  pAddress then holds the rank's ROWS of the witness.  See genProofSharded below.
 #pragma once
+#include <iostream>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -1050,6 +1051,32 @@ public:
     bool isSharded() const { return sharded; }
     uint64_t localRows() const { return sharded ? nLoc : N; }
     uint64_t firstRow() const { return row0; }
+
+    // Starks::merkelizeMemory (starks.cpp:671-700): the debug hash of the polynomial memory -- the words of the slab as they lie, taken as a matrix of
+    // 2^k rows (the largest power of two that divides the word count, at least 2; the reference's loop) and hashed with merkletree; the reference prints the
+    // root.  Here the slab is THIS process's device slab (a rank's window in a sharded run; the aliased one-GPU layout has no second copy of cm3_2ns behind
+    // mapTotalN, so the count is mapTotalN): a parity probe between runs, layouts being equal -- with row-major, unaliased sections the words are the
+    // reference's slab and the root is the one the reference prints.  Returns the root (and prints it as the reference does when `print`).
+    void merkelizeMemory(Goldilocks::Element rootDBG[4], bool print = true)
+    {
+        const uint64_t polsSize = slabWords;
+        if (polsSize < 2 || (polsSize & 1)) xlp_exit_process("Starks::merkelizeMemory: the slab has an odd number of words");
+        uint64_t nrowsDGB = 2;
+        while (polsSize % (nrowsDGB * 2) == 0) nrowsDGB *= 2;
+        const uint64_t ncolsDGB = polsSize / nrowsDGB;
+        const uint64_t numElementsTreeDBG = MerklehashGoldilocks::getTreeNumElements(nrowsDGB);
+        uint64_t* treeDBG = dalloc(numElementsTreeDBG);
+        XLP_CHECK(xlp_dev_merkle(treeDBG, mem(), ncolsDGB, nrowsDGB));
+        uint64_t root[4];
+        XLP_CHECK(xlp_copy_d2h(root, treeDBG + numElementsTreeDBG - 4, 4 * sizeof(uint64_t)));       // MerklehashGoldilocks::root: the last four elements
+        XLP_CHECK(xlp_dev_free(treeDBG));
+        for (int i = 0; i < 4; i++) {
+            rootDBG[i] = Goldilocks::fromU64(root[i]);
+            if (print) std::cout << "rootDBG[" << i << "]: [ " << root[i] << " ]" << std::endl;
+        }
+    }
+    uint64_t slabSizeWords() const { return slabWords; }
+    const uint64_t* slabDevice() { return mem(); }
 
     void genProof(typename H::Proof& proof, Goldilocks::Element* publicInputs, Goldilocks::Element verkey[4], Steps* steps)
     {

@@ -71,7 +71,8 @@ class XlpSteps : public Steps
         if (w.size() < nh || w[0] != magic || w.size() != nh + w[3]) xlp_exit_process(("XlpSteps: bad header in " + path).c_str());
         if (extra) *extra = w[4];
         xlp_expr_program* p = NULL;
-        XLP_CHECK(xlp_expr_create_ex(&p, w.data() + nh, w[3], w[1], w[2], colMajor ? XLP_EXPR_COLMAJOR : 0));
+        // (column-major sections of host/starks.hpp hold canonical words by construction: the promise XLP_EXPR_CANONICAL asks for)
+        XLP_CHECK(xlp_expr_create_ex(&p, w.data() + nh, w[3], w[1], w[2], colMajor ? (XLP_EXPR_COLMAJOR | XLP_EXPR_CANONICAL) : 0));
         return p;
     }
     static void attach(xlp_expr_program* p, const std::string& so, std::string& mode)

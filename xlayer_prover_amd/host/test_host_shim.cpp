@@ -131,7 +131,7 @@ static int genproof_mode(const std::string& dir, const std::string& name, bool t
 // this process is rank r of a row-sharded proof (host/starks.hpp), its host slab holds ITS rows of the same synthetic witness, and rank 0
 // prints the proof, which must equal the one-GPU proof bit for bit.
 static int bundle_mode(const std::string& dir, const std::string& name, uint64_t wseed, uint64_t cseed, bool timers, int world, int rank,
-                       const std::string& backend, const std::string& rendezvous)
+                       const std::string& backend, const std::string& rendezvous, const std::string& merkelize = "")
 {
     Config config;
     config.runFileGenBatchProof = true;
@@ -174,6 +174,17 @@ static int bundle_mode(const std::string& dir, const std::string& name, uint64_t
             const std::string out = zkinWithPublics(starks, proof);
             fwrite(out.data(), 1, out.size(), stdout);
             printf("\n");
+        }
+        if (merkelize.size()) {                            // Starks::merkelizeMemory after the proof: the root on stderr, the slab's words to the file (the test hashes them on the oracle)
+            Goldilocks::Element r[4];
+            starks.merkelizeMemory(r, false);
+            fprintf(stderr, "rootDBG %llu %llu %llu %llu words %llu\n", (unsigned long long)Goldilocks::toU64(r[0]), (unsigned long long)Goldilocks::toU64(r[1]),
+                    (unsigned long long)Goldilocks::toU64(r[2]), (unsigned long long)Goldilocks::toU64(r[3]), (unsigned long long)starks.slabSizeWords());
+            std::vector<uint64_t> h(starks.slabSizeWords());
+            XLP_CHECK(xlp_copy_d2h(h.data(), starks.slabDevice(), h.size() * 8));
+            FILE* f = fopen(merkelize.c_str(), "wb");
+            if (!f || fwrite(h.data(), 8, h.size(), f) != h.size()) { fprintf(stderr, "cannot write %s\n", merkelize.c_str()); return 2; }
+            fclose(f);
         }
         if (world) XLP_CHECK(xlp_comm_barrier());
     }
@@ -309,16 +320,17 @@ int main(int argc, char** argv)
     if (argc >= 6 && std::string(argv[1]) == "bundle") {
         bool timers = false;
         int world = 0, rank = 0;
-        std::string backend, rendezvous;
+        std::string backend, rendezvous, merkelize;
         for (int i = 6; i < argc; i++) {
             const std::string a = argv[i];
             if (a == "--world" && i + 1 < argc) world = atoi(argv[++i]);
+            else if (a == "--merkelize" && i + 1 < argc) merkelize = argv[++i];
             else if (a == "--rank" && i + 1 < argc) rank = atoi(argv[++i]);
             else if (a == "--backend" && i + 1 < argc) backend = argv[++i];
             else if (a == "--rendezvous" && i + 1 < argc) rendezvous = argv[++i];
             else timers = true;
         }
-        const int r = bundle_mode(argv[2], argv[3], strtoull(argv[4], 0, 0), strtoull(argv[5], 0, 0), timers, world, rank, backend, rendezvous);
+        const int r = bundle_mode(argv[2], argv[3], strtoull(argv[4], 0, 0), strtoull(argv[5], 0, 0), timers, world, rank, backend, rendezvous, merkelize);
         xlp_shutdown();
         return r;
     }
