@@ -332,7 +332,7 @@ def sharded_commit_leg(capi, torch, dist, dev, world, rank, log_n=23, ncols=751,
             "root": [int(v) & 0xFFFFFFFFFFFFFFFF for v in root.tolist()], "root_equals_single_gpu_commit": ok}
 
 
-def genproof_leg(timeout_s=300, layout="colmajor"):
+def genproof_leg(timeout_s=300):
     """The other half of BASELINE.json's metric: wall-clock of Prover::genBatchProof's three STARKs (prover.cpp:572-645: zkEVM 2^23
     rows, c12a 2^20, recursive1 2^17), each a whole Starks::genProof (starks.cpp:9-404, every stage, the reference's converted step
     programs), through the C++ entry points with the reference's shape (host/prover.hpp, host/starks.hpp; binary
@@ -341,9 +341,9 @@ def genproof_leg(timeout_s=300, layout="colmajor"):
     pipeline hides).  Reported next to the headline value, never as it; a failure is reported as such."""
     import subprocess
     exe = os.path.join(ROOT, "xlayer_prover_amd", "host", "zkprover_batch")
-    # the product path keeps the device sections COLUMN-MAJOR (round 4: bundles *.geo23ac / geo20c / geo17c; include/xlp_gl.h); layout="rowmajor" times
-    # the reference's row-major slab on the device (the same proof, bit for bit: tests/test_cpp_colmajor.py)
-    cfg = os.path.join(ROOT, "tools", "config_runFile_BatchProof_synthetic_colmajor.json" if layout == "colmajor" else "config_runFile_BatchProof_synthetic.json")
+    # the device sections are COLUMN-MAJOR (bundles *.geo23ac / geo20c / geo17c; include/xlp_gl.h): the same proof as on the reference's row-major slab,
+    # bit for bit (tests/test_cpp_colmajor.py compares the layouts once, at 2^12 / 2^13 rows; no row-major bundle is built since round 5)
+    cfg = os.path.join(ROOT, "tools", "config_runFile_BatchProof_synthetic_colmajor.json")
     starks = ("STARK_PROOF_BATCH_PROOF", "STARK_C12_A_PROOF_BATCH_PROOF", "STARK_RECURSIVE_1_PROOF_BATCH_PROOF")
 
     def run(*extra):
@@ -378,7 +378,7 @@ def genproof_leg(timeout_s=300, layout="colmajor"):
                                "h1h2_z": grp(lambda k: "H1H2" in k or k.endswith("_Z")), "evmap_lev_xdiv": grp(lambda k: "STEP_5" in k and "EXPS" not in k),
                                "q_intt_ntt": grp(lambda k: "INTT" in k), "fri_and_openings": grp(lambda k: k.endswith("_FRI"))},
                   "timers_s": {k: round(v, 4) for k, v in z.items()}, "programs": modes,
-                  "layout": "one-GPU aliased slab (239 GB), device sections " + ("column-major (extended ones coset-major)" if layout == "colmajor" else "row-major"),
+                  "layout": "one-GPU aliased slab (239 GB), device sections column-major (extended ones coset-major)",
                   "batch_proof_fnv": pip["batch_proof_fnv"]},
         "note": "synthetic witnesses and constants (the archive is absent); the executor and the circom witness calculators between the STARKs are "
                 "CPU work outside the hot path, replaced by stand-ins outside the timed STARKs",
@@ -442,9 +442,9 @@ def genproof_sharded_cpp_leg(world, rank, local_rank, backend, log_n=23, timeout
     import tempfile
     exe = os.path.join(ROOT, "xlayer_prover_amd", "host", "zkprover_batch")
     bdir = os.path.join(ROOT, "xlayer_prover_amd", "chelpers", "bundles")
-    # the windows as COLUMNS (the layout of the one-GPU product path) when that bundle was built, else the row-major windows
-    colmajor = os.environ.get("XLP_BENCH_WINDOW_LAYOUT", "colmajor") == "colmajor" and os.path.exists(os.path.join(bdir, f"zkevm.geo{log_n}w{world}c", "zkevm.starkinfo.json"))
-    bundle = os.path.join(bdir, f"zkevm.geo{log_n}w{world}" + ("c" if colmajor else ""))
+    # the windows as COLUMNS (the layout of the one-GPU product path; the only window bundles built since round 5)
+    colmajor = True
+    bundle = os.path.join(bdir, f"zkevm.geo{log_n}w{world}c")
     built_here = False
     if not os.path.exists(os.path.join(bundle, "zkevm.starkinfo.json")):
         if rank == 0:                                        # (no reference tree needed: the converted programs travel with the repo)
@@ -454,7 +454,7 @@ def genproof_sharded_cpp_leg(world, rank, local_rank, backend, log_n=23, timeout
                 built_here = True
             except Exception as e:
                 return {"error": "no window bundle: " + repr(e)[:200]}
-    base = json.load(open(os.path.join(ROOT, "tools", "config_runFile_BatchProof_synthetic_colmajor.json" if colmajor else "config_runFile_BatchProof_synthetic.json")))
+    base = json.load(open(os.path.join(ROOT, "tools", "config_runFile_BatchProof_synthetic_colmajor.json")))
     base["zkevmStarkInfo"] = os.path.join(bundle, "zkevm.starkinfo.json")
     port = int(os.environ.get("MASTER_PORT", "29500"))
     cfg = os.path.join(tempfile.gettempdir(), f"xlp_sharded_cfg_{port}_{world}.json")
@@ -494,14 +494,14 @@ def genproof_sharded_cpp_leg(world, rank, local_rank, backend, log_n=23, timeout
         return {"error": repr(e)[:200] + " / " + out[-200:]}
 
 
-def e2e_leg(timeout_s=300, layout="colmajor"):
+def e2e_leg(timeout_s=300):
     """BASELINE configs[4] through the C++ Prover (host/zkprover_batch --e2e; the SNARK wrap on a synthetic final circuit): two consecutive batch proofs
     (each: zkEVM 2^23 + c12a + recursive1), Prover::genAggregatedProof (joinzkin + the recursive2 STARK) and Prover::genFinalProof up
     to the recursivef STARK (Poseidon-BN128 trees / transcript).  Synthetic witnesses; the circom witness calculators and the fflonk
     prover around them are CPU / out-of-scope work."""
     import subprocess
     exe = os.path.join(ROOT, "xlayer_prover_amd", "host", "zkprover_batch")
-    cfg = os.path.join(ROOT, "tools", "config_runFile_e2e_synthetic_colmajor.json" if layout == "colmajor" else "config_runFile_e2e_synthetic.json")
+    cfg = os.path.join(ROOT, "tools", "config_runFile_e2e_synthetic_colmajor.json")
     try:
         r = subprocess.run([exe, "-c", cfg, "--e2e"], capture_output=True, text=True, timeout=timeout_s, cwd=ROOT)
         if r.returncode != 0:
@@ -594,8 +594,6 @@ def main():
     ap.add_argument("--no-bn128", action="store_true", help="skip the BN128 / fflonk kernel leg (N=1 only; a few seconds)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the batch + batch + aggregated + final(recursivef) chain (N=1 only; ~20 s)")
     ap.add_argument("--no-genproof", action="store_true", help="skip the whole-genProof leg (N=1 only; ~25 s)")
-    ap.add_argument("--genproof-rowmajor", action="store_true", help="also time genBatchProof with ROW-MAJOR device sections (the layout of rounds 1-3) next to the "
-                    "column-major product path: same proof, A/B on the same box (+25 s)")
     ap.add_argument("--sharded-commit", type=int, default=-1, help="time the section commit sharded over the ranks (default: on for --gpus > 1; 1 forces it at N=1 "
                     "through RCCL in a world of one)")
     ap.add_argument("--sharded-genproof", type=int, default=-1, help="log2 N of the row-sharded zkEVM-geometry genProof run over the ranks "
@@ -840,10 +838,6 @@ def main():
             g = budget.grant(300.0, 120.0, 60.0)              # (two runs of the binary; the CPU baseline after it needs ~45 s)
             if g:
                 line["genproof"] = genproof_leg(timeout_s=g / 2)
-                if args.genproof_rowmajor and budget.left() > 150:
-                    rm = genproof_leg(timeout_s=min(120.0, budget.left() / 3), layout="rowmajor")
-                    line["genproof_rowmajor_sections"] = {k: rm.get(k) for k in ("wall_s", "wall_without_upload_s", "per_stark_s", "error") if k in rm} | (
-                        {"stages_s": rm["zkevm"]["stages_s"], "same_proof_as_colmajor": rm["zkevm"].get("batch_proof_fnv") == line["genproof"].get("zkevm", {}).get("batch_proof_fnv")} if "zkevm" in rm else {})
             else:
                 skipped["genproof"] = f"{budget.left():.0f} s left of the {args.budget:.0f} s budget"
             if not args.no_e2e:

@@ -406,6 +406,17 @@ int xlp_dev_perm_resident(uint64_t* out, uint64_t count, uint64_t iters);
  * kernel time against what these take (roofline.alu_ceiling). */
 int xlp_dev_lde_resident(uint64_t* sink, uint64_t n_ext, uint64_t n, uint64_t ncols);
 int xlp_profile_read(double ms_sum[3], uint64_t* count);
+/* PLAN MODE: a dry run of the host orchestration that touches no GPU (none needs to exist).  After xlp_plan_begin -- or with XLP_PLAN=1 in the environment
+ * before the first call -- device allocations (xlp_dev_alloc, the library's scratch slots and tables) are ACCOUNTED against `hbm_bytes` (0 = 288 GiB): each
+ * returns a unique fake address that is never dereferenced; every other device operation returns 0 without doing anything (kernels, copies, exchanges;
+ * xlp_copy_d2h zero-fills its destination, xlp_comm_init only records rank and world, xlp_dev_mem_info answers from the account).  The entry points that
+ * SIZE memory run their host side as always, so a scratch slot grows to what the real call would make it.  xlp_plan_report: peak and live bytes, the
+ * number of allocations, the `nlargest` largest allocations live at the peak, the nine scratch slots.  What it is for: host/zkprover_batch under
+ * XLP_PLAN=1 --world G --rank r walks Starks::genProofSharded at 2^23 rows and prints what rank r would allocate (tests/test_memory_plan.py: fits 288 GiB
+ * with the margin the one-GPU path keeps, G = 2, 4, 8) -- the code that allocates is the code that is counted. */
+int xlp_plan_begin(uint64_t hbm_bytes);
+int xlp_plan_active(void);
+int xlp_plan_report(uint64_t* peak_bytes, uint64_t* live_bytes, uint64_t* allocations, uint64_t* largest_at_peak, uint32_t nlargest, uint64_t scratch_slot_bytes[9]);
 
 /* ---- transport between the ranks of a row-sharded proof: one process per GPU -----------------------------------------
  * The reference commits a section with ntt.extendPol + treesGL[i]->merkelize() on one host (starks.cpp:53-60,134-141,215-222) and runs

@@ -85,9 +85,8 @@ def _one_gpu_proof(tmp_path, ln):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,backend,scratch_mb,msg_words,colmajor", [
-    (1, "self", 0, 0, False), (1, "rccl", 0, 0, False), (2, "shm", 0, 0, False), (4, "shm", 0, 0, False), (2, "shm", 1, 0, False),
-    (1, "rccl", 1, 1000, False), (2, "shm", 0, 777, False), (1, "self", 1, 0, False),
-    (1, "self", 0, 0, True), (1, "self", 1, 0, True), (2, "shm", 0, 0, True), (2, "shm", 1, 0, True), (4, "shm", 1, 777, True), (1, "rccl", 1, 1000, True)])
+    (2, "shm", 1, 777, False),                          # row-major windows: one case (the layout is kept for the equivalence test only)
+    (1, "self", 0, 0, True), (1, "rccl", 0, 0, True), (2, "shm", 0, 0, True), (2, "shm", 1, 0, True), (4, "shm", 1, 777, True), (4, "shm", 0, 0, True), (1, "rccl", 1, 1000, True)])
 def test_cpp_sharded_starks_proof_equals_one_gpu_proof(tmp_path, world, backend, scratch_mb, msg_words, colmajor):
     """colmajor: the windows as COLUMNS (a column of a section = the rank's rows + halo; the extended ones as 2^ext coset blocks): what
     travels in the exchanges is regrouped runs of a rank's rows, the halo of a section is one row per column and coset.
@@ -118,7 +117,7 @@ def test_cpp_sharded_starks_proof_equals_one_gpu_proof(tmp_path, world, backend,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("colmajor", [False, True])
+@pytest.mark.parametrize("colmajor", [True])
 def test_genbatchproof_with_the_zkevm_stark_sharded_equals_one_gpu(tmp_path, colmajor):
     """Prover::genBatchProof (host/prover.hpp, binary host/zkprover_batch) with --world 2: both ranks prove their rows of the zkEVM STARK
     (window bundle, 2^13 rows), the publics come from rank 0's first and rank 1's last witness row, rank 0 goes on with c12a and
@@ -165,7 +164,7 @@ def test_genbatchproof_with_the_zkevm_stark_sharded_equals_one_gpu(tmp_path, col
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ln,colmajor", [(18, False), (20, True)])
+@pytest.mark.parametrize("ln,colmajor", [(20, True)])
 def test_genbatchproof_two_ranks_at_2p18_with_the_default_staging_budget(tmp_path, ln, colmajor):
     """the multi-rank product path at a size where the exchanges are hundreds of MB (2^18 rows: 0.8 GB of witness per rank, sections
     of 751 / 168 / 408 columns), through host/zkprover_batch with the DEFAULT staging budget and message size, ranks sharing the box's GPU (shm).
@@ -218,7 +217,7 @@ def test_genbatchproof_two_ranks_at_2p18_with_the_default_staging_budget(tmp_pat
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["geo12w2", "geo12w2c"])
+@pytest.mark.parametrize("tag", ["geo12w2c"])
 def test_cpp_sharded_starks_on_compiled_window_programs(tmp_path, tag):
     """two ranks on the AHEAD-OF-TIME kernels of the window-relocated step programs (the prebuilt bundle chelpers/bundles/zkevm.geo12w2, made by
     `make -C xlayer_prover_amd/chelpers bundles` like the 2^23 bundles bench.py --gpus N uses): every rank reports its four step programs as compiled,

@@ -45,7 +45,7 @@ def bundle_dir(circ, log_n, aliased, world=0, colmajor=False):
     return os.path.join(R.REF_DIR, "bundles", f"{circ}.{geo_tag(log_n, aliased, world, colmajor)}")
 
 
-def make(circ, log_n, aliased, out=None, fri_steps=None, queries=None, use_opt=True, use_dots=True, world=0, colmajor=False, plugin_dir=None):
+def make(circ, log_n, aliased, out=None, fri_steps=None, queries=None, use_opt=True, use_dots=True, world=0, colmajor=True, plugin_dir=None):
     """world > 0: the bundle of ONE RANK of a proof row-sharded over `world` ranks (every rank uses the same files): window starkinfo,
     programs relocated to the window slab (tools/zkevm_geometry.py layout_window), and per step the next-row stores whose halo rows go
     back to their owner.
@@ -53,6 +53,8 @@ def make(circ, log_n, aliased, out=None, fri_steps=None, queries=None, use_opt=T
     (the extended ones coset-major); the programs are converted last (tools/zkevm_geometry.py to_colmajor), the starkinfo and the manifest
     say "colMajor": true.  With world > 0: the window slab as columns -- a column of a base-domain section = the rank's rows + the halo row,
     of an extended one = 2^ext coset blocks of (the rank's rows + the halo row)"""
+    if circ == "recursivef":
+        colmajor = False                                       # its sections feed Poseidon-BN128 trees row by row (StarkRecursiveF): the reference's layout
     out = out or bundle_dir(circ, log_n, aliased, world, colmajor)
     os.makedirs(out, exist_ok=True)
     geo = geo_tag(log_n, aliased, world, colmajor)

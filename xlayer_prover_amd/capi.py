@@ -64,6 +64,9 @@ SIGNATURES = {
     "xlp_profile_enable": [C.c_int],
     "xlp_dev_perm_resident": [_pu, _u64, _u64],
     "xlp_dev_lde_resident": [_pu, _u64, _u64, _u64],
+    "xlp_plan_begin": [_u64],
+    "xlp_plan_active": [],
+    "xlp_plan_report": [_pu, _pu, _pu, _pu, _u32, _pu],
     "xlp_bn128_init": [C.c_char_p],
     "xlp_dev_merkle_bn128": [_pu, _pu, _u64, _u64],
     "xlp_merkle_bn128": [_pu, _pu, _u64, _u64],

@@ -536,7 +536,7 @@ static std::string default_constants_path()
 // the tables live on the device the context was bound to: they go with it (xlp_shutdown), a later xlp_init loads them again
 void bn128_shutdown()
 {
-    if (g_bn_blob) { (void)hipFree(g_bn_blob); g_bn_blob = nullptr; }
+    if (g_bn_blob) { (void)plan_free(g_bn_blob); g_bn_blob = nullptr; }
     g_bn_tables = bn::Tables{};
     g_bn_ready = false;
 }
@@ -565,8 +565,8 @@ int bn128_init(Ctx* ctx, const char* path)
     }
     const size_t body = 16 + 32 * 16;
     if (raw.size() != body + total * 32) return xlp_fail("bn128: constants file truncated");
-    if (g_bn_blob) { (void)hipFree(g_bn_blob); g_bn_blob = nullptr; }
-    XLP_HIP(hipMalloc(&g_bn_blob, total * 32));
+    if (g_bn_blob) { (void)plan_free(g_bn_blob); g_bn_blob = nullptr; }
+    XLP_ALLOC(plan_malloc((void**)&g_bn_blob, total * 32));
     XLP_HIP(hipMemcpy(g_bn_blob, raw.data() + body, total * 32, hipMemcpyHostToDevice));
     const bn::Fr* p = (const bn::Fr*)g_bn_blob;
     for (int k = 0; k < 16; k++) {

@@ -502,7 +502,7 @@ int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 
     // scratch: keys/vals in+out (4 x total u32), starts (nkeys + 1), buckets (nkeys Jac), groups, window sums, sort temp
     size_t temp_bytes = 0;
     u32* nul = nullptr;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, nul, nul, nul, nul, (int)total, 0, 32, ctx->stream);
+    XLP_HIPV(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, nul, nul, nul, nul, (int)total, 0, 32, ctx->stream));
     const size_t nheavy_max = total / HEAVY + 2;                    // heavy buckets at most
     const size_t nseg_max = total / SEG + nheavy_max + 2;            // their segments at most
     const size_t words32 = 4 * total + 2 * ((size_t)nkeys + 2) + 2 + 3 * nheavy_max + 2 * nseg_max + 4 * (size_t)nkeys;
@@ -537,7 +537,7 @@ int dev_msm_bn254(Ctx* ctx, u64* out, const u64* bases, const u64* scalars, u64 
     u32 *cnt = ord, *ids = ord + nkeys, *cnt2 = ord + 2 * (size_t)nkeys, *ids2 = ord + 3 * (size_t)nkeys;
     hipLaunchKernelGGL(msm_counts_kernel, dim3((nkeys + T - 1) / T), dim3(T), 0, ctx->stream, cnt, ids, start, stop, nkeys, c);
     size_t tb = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, tb, nul, nul, nul, nul, (int)nkeys, 0, 9, ctx->stream);
+    XLP_HIPV(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, nul, nul, nul, nul, (int)nkeys, 0, 9, ctx->stream));
     const u32* order = ids;
     if (tb <= temp_bytes) {                                           // (the pair sort's temporary storage serves; always so beyond toy sizes)
         XLP_HIP(hipcub::DeviceRadixSort::SortPairs(temp, tb, cnt, cnt2, ids, ids2, (int)nkeys, 0, 9, ctx->stream));

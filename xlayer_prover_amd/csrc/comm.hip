@@ -471,6 +471,10 @@ int comm_init(Ctx* ctx, int rank, int world, const char* backend, const char* re
     if (world & (world - 1)) return xlp_fail("xlp_comm_init: the number of ranks must be a power of two (row shards of a 2^k-row trace)");
     const std::string be = backend ? backend : "";
     c.rank = rank; c.world = world; c.ranks_seen = 1;
+    if (plan_active()) {                                          // plan mode (xlp_internal.hpp): this process IS rank `rank` of `world`, nobody is contacted
+        c.kind = Comm::SELF; c.ranks_seen = world;
+        return 0;
+    }
     c.max_message_words = 1ull << 25;
     if (const char* e = getenv("XLP_COMM_MAX_MESSAGE_WORDS")) { const u64 v = strtoull(e, nullptr, 10); if (v >= 1) c.max_message_words = v; }
     c.self_via_rccl = getenv("XLP_COMM_SELF_VIA_RCCL") != nullptr;
@@ -548,8 +552,8 @@ void comm_shutdown()
         c.nccl = nullptr;
     }
     if (!c.id_file.empty()) { unlink(c.id_file.c_str()); c.id_file.clear(); }
-    if (c.small) { (void)hipFree(c.small); c.small = nullptr; c.small_words = 0; }
-    if (c.bounce) { (void)hipHostFree(c.bounce); c.bounce = nullptr; }
+    if (c.small) { (void)plan_free(c.small); c.small = nullptr; c.small_words = 0; }
+    if (c.bounce) { XLP_HIPV(hipHostFree(c.bounce)); c.bounce = nullptr; }
     seg_close(c.data);
     ctl_close();
     c.kind = Comm::NONE; c.rank = 0; c.world = 1; c.ranks_seen = 1;
@@ -728,8 +732,8 @@ int comm_all_gather_host(Ctx* ctx, u64* out, const u64* in, u64 words)
         InTransport guard;
         const size_t need = (size_t)words * (c.world + 1);
         if (c.small_words < need) {
-            if (c.small) { XLP_HIP(hipStreamSynchronize(ctx->stream)); XLP_HIP(hipFree(c.small)); c.small = nullptr; }
-            XLP_HIP(hipMalloc((void**)&c.small, need * sizeof(u64)));
+            if (c.small) { XLP_HIP(hipStreamSynchronize(ctx->stream)); XLP_ALLOC(plan_free(c.small)); c.small = nullptr; }
+            XLP_ALLOC(plan_malloc((void**)&c.small, need * sizeof(u64)));
             c.small_words = need;
         }
         XLP_HIP(hipMemcpyAsync(c.small, in, words * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
@@ -762,8 +766,8 @@ int comm_stats(double* seconds, u64* bytes_sent, u64* calls, int mode)
     for (auto& pr : c.timed) {                                    // (an exchange that failed half way left its second event unrecorded: skipped)
         float ms = 0.f;
         if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) c.seconds += ms * 1e-3;
-        (void)hipGetLastError();
-        (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second);
+        XLP_HIPV(hipGetLastError());
+        XLP_HIPV(hipEventDestroy(pr.first)); XLP_HIPV(hipEventDestroy(pr.second));
     }
     c.timed.clear();
     if (seconds) *seconds = c.seconds;

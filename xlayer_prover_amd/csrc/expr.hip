@@ -1447,7 +1447,7 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
     for (const Range& g : ranges) longest = std::max(longest, g.n);
     if (!prog->d_dcode) {
         xlp_expr_program* mp = const_cast<xlp_expr_program*>(prog);
-        XLP_HIP(hipMalloc((void**)&mp->d_dcode, prog->dcode.size() * sizeof(u64)));
+        XLP_ALLOC(plan_malloc((void**)&mp->d_dcode, prog->dcode.size() * sizeof(u64)));
         XLP_HIP(hipMemcpy(mp->d_dcode, prog->dcode.data(), prog->dcode.size() * sizeof(u64), hipMemcpyHostToDevice));
     }
     const xlp_steps_params& P = *params;
@@ -1530,18 +1530,19 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
         u64* cols = cols_all ? cols_all + (size_t)s * ncols * cap : nullptr;
         A.tmp = tmp_all ? tmp_all + (size_t)s * spill * A.tstride : nullptr;
         A.cols = cols;
-        if (S > 1 && i == nslabs - 1 && i > 0 && first_written) (void)hipStreamWaitEvent(st, first_written, 0);   // its halo wraps to slab 0's rows: the values written there
+        if (S > 1 && i == nslabs - 1 && i > 0 && first_written) XLP_HIPV(hipStreamWaitEvent(st, first_written, 0));   // its halo wraps to slab 0's rows: the values written there
         if (ncols) {
             const dim3 grid((ncols + 63) / 64, (unsigned)((rows + prog->halo + 63) / 64));
             hipLaunchKernelGGL(expr_gather_kernel, grid, dim3(256), 0, st, cols, d_tab, ncols, cap, row0 + r0, rows, prog->halo, prog->modulus);
         }
         if (S > 1) {
-            (void)hipEventCreateWithFlags(&gathered[i], hipEventDisableTiming);
-            (void)hipEventRecord(gathered[i], st);
+            XLP_HIPV(hipEventCreateWithFlags(&gathered[i], hipEventDisableTiming));
+            XLP_HIPV(hipEventRecord(gathered[i], st));
         }
         A.row0 = row0 + r0; A.nrows = rows;
-        if (S > 1 && chain && computed) { (void)hipStreamWaitEvent(st, computed, 0); (void)hipEventDestroy(computed); computed = nullptr; }
-        if (jit) {
+        if (S > 1 && chain && computed) { XLP_HIPV(hipStreamWaitEvent(st, computed, 0)); XLP_HIPV(hipEventDestroy(computed)); computed = nullptr; }
+        if (jit && plan_active()) {}                          // (plan mode: the plugin's kernels are not launched either)
+        else if (jit) {
             XlpJitArgs J;
             J.cols = cols; J.cap = cap; J.tmp = A.tmp; J.tstride = A.tstride; J.row0 = row0 + r0; J.nrows = rows; J.P = P;
             J.coset = A.coset; J.cbase = A.cbase; J.dshift = A.dshift; J.crows = A.crows; J.crows2 = A.crows2;
@@ -1552,25 +1553,25 @@ int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params*
             else if (R == 2) hipLaunchKernelGGL(expr_kernel<2>, vgrid, dim3(256), lds, st, A);
             else hipLaunchKernelGGL(expr_kernel<4>, vgrid, dim3(256), lds, st, A);
         }
-        if (S > 1 && chain) { (void)hipEventCreateWithFlags(&computed, hipEventDisableTiming); (void)hipEventRecord(computed, st); }
+        if (S > 1 && chain) { XLP_HIPV(hipEventCreateWithFlags(&computed, hipEventDisableTiming)); XLP_HIPV(hipEventRecord(computed, st)); }
         if (nw && !rc) {
-            if (S > 1 && i > 0) (void)hipStreamWaitEvent(st, gathered[i - 1], 0);    // slab i-1 staged its halo (= my first rows) before I overwrite them
+            if (S > 1 && i > 0) XLP_HIPV(hipStreamWaitEvent(st, gathered[i - 1], 0));    // slab i-1 staged its halo (= my first rows) before I overwrite them
             const dim3 grid((nw + 63) / 64, (unsigned)((rows + 63) / 64));
             hipLaunchKernelGGL(expr_scatter_kernel, grid, dim3(256), 0, st, cols, d_tab, d_wl, nw, cap, row0 + r0, rows);
-            if (S > 1 && i == 0) { (void)hipEventCreateWithFlags(&first_written, hipEventDisableTiming); (void)hipEventRecord(first_written, st); }
+            if (S > 1 && i == 0) { XLP_HIPV(hipEventCreateWithFlags(&first_written, hipEventDisableTiming)); XLP_HIPV(hipEventRecord(first_written, st)); }
         }
     }
     if (S > 1) {                                          // later work on the library's stream sees every slab
         for (int a = 1; a < S; a++) {
             hipEvent_t done;
-            (void)hipEventCreateWithFlags(&done, hipEventDisableTiming);
-            (void)hipEventRecord(done, streams[a]);
-            (void)hipStreamWaitEvent(ctx->stream, done, 0);
-            (void)hipEventDestroy(done);
+            XLP_HIPV(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+            XLP_HIPV(hipEventRecord(done, streams[a]));
+            XLP_HIPV(hipStreamWaitEvent(ctx->stream, done, 0));
+            XLP_HIPV(hipEventDestroy(done));
         }
-        for (hipEvent_t e : gathered) if (e) (void)hipEventDestroy(e);
-        if (first_written) (void)hipEventDestroy(first_written);
-        if (computed) (void)hipEventDestroy(computed);
+        for (hipEvent_t e : gathered) if (e) XLP_HIPV(hipEventDestroy(e));
+        if (first_written) XLP_HIPV(hipEventDestroy(first_written));
+        if (computed) XLP_HIPV(hipEventDestroy(computed));
     }
     if (rc) return rc;
     XLP_HIP(hipGetLastError());
@@ -1612,7 +1613,7 @@ int expr_create(xlp_expr_program** out, const u64* code, u64 ncode, u64 ntmp1, u
 int expr_destroy(xlp_expr_program* p)
 {
     if (!p) return 0;
-    if (p->d_dcode) (void)hipFree(p->d_dcode);
+    if (p->d_dcode) (void)plan_free(p->d_dcode);
     if (p->jit_handle) dlclose(p->jit_handle);
     delete p;
     return 0;

@@ -288,7 +288,7 @@ int get_pow_tables(Ctx* ctx, u32 L, u64 root, u64 mult, const u64** lo, const u6
     if (it == ctx->tables.end()) {
         u64 nlo = L < 12 ? (1ull << L) : 4096, nhi = L > 12 ? (1ull << (L - 12)) : 0;
         u64* d = nullptr;
-        XLP_HIP(hipMalloc(&d, (4096 + nhi) * sizeof(u64)));
+        XLP_ALLOC(plan_malloc((void**)&d, (4096 + nhi) * sizeof(u64)));
         XLP_HIP(hipMemsetAsync(d, 0, (4096 + nhi) * sizeof(u64), ctx->stream));
         hipLaunchKernelGGL(pow_table_kernel, dim3((nlo + 255) / 256), dim3(256), 0, ctx->stream, d, root, 0u, nlo, mult);
         if (nhi) hipLaunchKernelGGL(pow_table_kernel, dim3((nhi + 255) / 256), dim3(256), 0, ctx->stream, d + 4096, root, 12u, nhi, (u64)1);

@@ -205,7 +205,7 @@ int lde_tw2_table(Ctx* ctx, u32 BT, u64 gk, const u64* sk, const u64* twf12, con
     auto it = ctx->tables.find(key);
     if (it == ctx->tables.end()) {
         u64* d = nullptr;
-        XLP_HIP(hipMalloc(&d, 4096 * sizeof(u64)));
+        XLP_ALLOC(plan_malloc((void**)&d, 4096 * sizeof(u64)));
         hipLaunchKernelGGL(lde_tw2_kernel, dim3(16), dim3(256), 0, ctx->stream, d, sk, twf12);
         XLP_HIP(hipGetLastError());
         it = ctx->tables.emplace(key, d).first;

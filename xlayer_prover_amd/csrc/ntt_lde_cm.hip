@@ -176,7 +176,7 @@ int dev_extend_cm_fast(Ctx* ctx, u64* out, u64 out_cstride, u64 out_cos, const u
         auto it = ctx->tables.find(key);
         if (it == ctx->tables.end()) {
             u64* d = nullptr;
-            XLP_HIP(hipMalloc(&d, (size_t)(8u << BT) * sizeof(u64)));
+            XLP_ALLOC(plan_malloc((void**)&d, (size_t)(8u << BT) * sizeof(u64)));
             hipLaunchKernelGGL(lde_cm_etable_kernel, dim3(((8u << BT) + 255) / 256), dim3(256), 0, ctx->stream, d, dir ? p.crf_lo : p.cri_lo, dir ? p.crf_hi : p.cri_hi, BT);
             XLP_HIP(hipGetLastError());
             it = ctx->tables.emplace(key, d).first;

@@ -26,7 +26,42 @@ static Ctx g_ctx;
 static std::recursive_mutex g_mu;
 static hipEvent_t g_marks[8];
 static bool g_marked[8];
-#define XLP_ENTER std::lock_guard<std::recursive_mutex> xlp_api_lock(g_mu)
+// XLP_ENTER: the lock of the C ABI; in PLAN MODE (xlp_internal.hpp) the entry point ends here with 0 -- nothing it would do touches the GPU.
+// XLP_ENTER_PLAN: the entry points that run in plan mode too: the ones that allocate or size device memory (their HIP calls and kernel launches are
+// no-ops there) and the host-only ones.
+#define XLP_ENTER_PLAN std::lock_guard<std::recursive_mutex> xlp_api_lock(g_mu)
+#define XLP_ENTER XLP_ENTER_PLAN; if (xlp::g_plan_active) return 0
+
+bool g_plan_active = false;
+struct PlanState {
+    std::map<uintptr_t, size_t> live;
+    uint64_t cur = 0, peak = 0, allocs = 0, hbm = 0;
+    uintptr_t next = (uintptr_t)1 << 44;                 // fake device addresses: unique, aligned, never dereferenced
+    std::vector<size_t> at_peak;                         // sizes of the live allocations when the peak was reached
+};
+static PlanState g_plan;
+hipError_t plan_malloc(void** p, size_t bytes)
+{
+    if (!g_plan_active) return (hipMalloc)(p, bytes);
+    if (!bytes) bytes = 8;
+    *p = (void*)g_plan.next;
+    g_plan.next += (bytes + 4095) / 4096 * 4096 + 4096;
+    g_plan.live[(uintptr_t)*p] = bytes;
+    g_plan.cur += bytes; g_plan.allocs++;
+    if (g_plan.cur > g_plan.peak) {
+        g_plan.peak = g_plan.cur;
+        g_plan.at_peak.clear();
+        for (const auto& kv : g_plan.live) g_plan.at_peak.push_back(kv.second);
+    }
+    return hipSuccess;
+}
+hipError_t plan_free(void* p)
+{
+    if (!g_plan_active) return (hipFree)(p);
+    auto it = g_plan.live.find((uintptr_t)p);
+    if (it != g_plan.live.end()) { g_plan.cur -= it->second; g_plan.live.erase(it); }
+    return hipSuccess;
+}
 
 int xlp_fail(const char* msg)
 {
@@ -38,7 +73,7 @@ int xlp_fail_hip(hipError_t e, const char* file, int line)
     char buf[512];
     snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s:%d", (int)e, hipGetErrorString(e), file, line);
     g_err = buf;
-    (void)hipGetLastError();
+    XLP_HIPV(hipGetLastError());
     return -1;
 }
 
@@ -58,11 +93,11 @@ int ctx_scratch(Ctx* ctx, size_t bytes, int slot, u64** out)
     if (ctx->scratch_bytes[slot] < bytes) {
         if (ctx->scratch[slot]) {
             if (ctx_drain_streams(ctx)) return -1;
-            XLP_HIP(hipFree(ctx->scratch[slot]));
+            XLP_ALLOC(plan_free(ctx->scratch[slot]));
             ctx->scratch[slot] = nullptr;
             ctx->scratch_bytes[slot] = 0;
         }
-        XLP_HIP(hipMalloc(&ctx->scratch[slot], bytes));
+        XLP_ALLOC(plan_malloc((void**)&ctx->scratch[slot], bytes));
         ctx->scratch_bytes[slot] = bytes;
     }
     *out = (u64*)ctx->scratch[slot];
@@ -72,17 +107,17 @@ int ctx_scratch(Ctx* ctx, size_t bytes, int slot, u64** out)
 static int ensure_init()
 {
     if (g_ctx.inited) return 0;
-    return xlp_init(0);
+    return xlp_init(0);                                      // (XLP_PLAN=1 in the environment: plan mode, no GPU)
 }
 
 // RAII device staging buffer for the host-pointer entry points.
 struct DevBuf {
     void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    ~DevBuf() { if (p) (void)plan_free(p); }
     int alloc(size_t bytes)
     {
         if (bytes == 0) bytes = 8;
-        XLP_HIP(hipMalloc(&p, bytes));
+        XLP_ALLOC(plan_malloc((void**)&p, bytes));
         return 0;
     }
     u64* u() { return (u64*)p; }
@@ -91,7 +126,7 @@ struct DevBuf {
 // Events of one pipelined call: all destroyed when the call returns, whichever way it returns.
 struct EventPool {
     std::vector<hipEvent_t> all;
-    ~EventPool() { for (hipEvent_t e : all) (void)hipEventDestroy(e); }
+    ~EventPool() { for (hipEvent_t e : all) XLP_HIPV(hipEventDestroy(e)); }
     int make(hipEvent_t* out, bool timing = false)
     {
         hipEvent_t e = nullptr;
@@ -114,7 +149,7 @@ struct EventPool {
 // A device allocation that is either handed on (release) or freed on return.
 struct DevOwner {
     void* p = nullptr;
-    ~DevOwner() { if (p) (void)hipFree(p); }
+    ~DevOwner() { if (p) (void)plan_free(p); }
     void* release() { void* q = p; p = nullptr; return q; }
 };
 
@@ -126,7 +161,7 @@ uint64_t g_cache_tick = 0;
 
 void cache_drop(size_t i)
 {
-    (void)hipFree(g_cache[i].dev);
+    (void)plan_free(g_cache[i].dev);
     g_cache_used -= g_cache[i].bytes;
     g_cache.erase(g_cache.begin() + i);
 }
@@ -140,7 +175,7 @@ void cache_drop_overlapping(const void* host, size_t bytes)
 void cache_put(const void* host, size_t bytes, void* dev)
 {
     cache_drop_overlapping(host, bytes);
-    if (bytes > g_cache_cap) { (void)hipFree(dev); return; }
+    if (bytes > g_cache_cap) { (void)plan_free(dev); return; }
     while (g_cache_used + bytes > g_cache_cap && !g_cache.empty()) {
         size_t lru = 0;
         for (size_t i = 1; i < g_cache.size(); i++) if (g_cache[i].tick < g_cache[lru].tick) lru = i;
@@ -178,7 +213,7 @@ extern "C" {
 // region cannot hold falls through to the slot's own scratch.  The caller keeps the region alive and unused until it takes it back.
 int xlp_scratch_lend(uint32_t slot, void* dev_ptr, size_t bytes)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (ensure_init()) return -1;
     if (slot >= 9) return xlp_fail("xlp_scratch_lend: slot 0..8");
     if (ctx_drain_streams(&g_ctx)) return -1;
@@ -189,12 +224,12 @@ int xlp_scratch_lend(uint32_t slot, void* dev_ptr, size_t bytes)
 }
 int xlp_scratch_release(uint32_t mask)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (!g_ctx.inited) return 0;
     if (ctx_drain_streams(&g_ctx)) return -1;
     for (int k = 0; k < 9; k++)
         if (((mask >> k) & 1) && g_ctx.scratch[k]) {
-            XLP_HIP(hipFree(g_ctx.scratch[k]));
+            XLP_ALLOC(plan_free(g_ctx.scratch[k]));
             g_ctx.scratch[k] = nullptr;
             g_ctx.scratch_bytes[k] = 0;
             if (k == 8) { g_ctx.fft_tw_log = 0; g_ctx.fft_tw_ptr = nullptr; }
@@ -207,9 +242,35 @@ int xlp_version(void) { return 0x000100; }
 
 const char* xlp_last_error(void) { return g_err.c_str(); }
 
+int xlp_plan_begin(uint64_t hbm_bytes)
+{
+    XLP_ENTER_PLAN;
+    if (g_ctx.inited && !g_plan_active) return xlp_fail("xlp_plan_begin: the library is already bound to a GPU (plan mode starts before any other call)");
+    g_plan_active = true;
+    g_plan.hbm = hbm_bytes ? hbm_bytes : (uint64_t)288 << 30;          // MI355X: 288 GiB of HBM3E
+    g_ctx.device = 0; g_ctx.ncu = 256; g_ctx.inited = true;
+    return 0;
+}
+int xlp_plan_active(void) { return g_plan_active ? 1 : 0; }
+int xlp_plan_report(uint64_t* peak_bytes, uint64_t* live_bytes, uint64_t* allocations, uint64_t* largest_at_peak, uint32_t nlargest, uint64_t scratch_slot_bytes[9])
+{
+    XLP_ENTER_PLAN;
+    if (!g_plan_active) return xlp_fail("xlp_plan_report: not in plan mode");
+    if (peak_bytes) *peak_bytes = g_plan.peak;
+    if (live_bytes) *live_bytes = g_plan.cur;
+    if (allocations) *allocations = g_plan.allocs;
+    std::vector<size_t> v = g_plan.at_peak;
+    std::sort(v.begin(), v.end(), [](size_t a, size_t b) { return a > b; });
+    for (uint32_t i = 0; i < nlargest && largest_at_peak; i++) largest_at_peak[i] = i < v.size() ? v[i] : 0;
+    for (int k = 0; k < 9 && scratch_slot_bytes; k++) scratch_slot_bytes[k] = g_ctx.scratch_bytes[k];
+    return 0;
+}
+
 int xlp_init(int device)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
+    if (!g_plan_active && !g_ctx.inited && getenv("XLP_PLAN")) { if (xlp_plan_begin(strtoull(getenv("XLP_PLAN_HBM_BYTES") ? getenv("XLP_PLAN_HBM_BYTES") : "0", nullptr, 0))) return -1; }
+    if (g_plan_active) return 0;
     if (g_ctx.inited && g_ctx.device == device) return 0;
     if (g_ctx.inited) return xlp_fail("xlp_init: already bound to another device");
     int n = 0;
@@ -304,13 +365,13 @@ int xlp_stream_wait(int waiter, int signaller)
 
 void xlp_shutdown(void)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (!g_ctx.inited) return;
-    (void)hipStreamSynchronize(g_ctx.stream);
-    for (auto& kv : g_ctx.tables) (void)hipFree(kv.second);
+    XLP_HIPV(hipStreamSynchronize(g_ctx.stream));
+    for (auto& kv : g_ctx.tables) (void)plan_free(kv.second);
     g_ctx.tables.clear();
     for (int i = 0; i < 9; i++) {
-        if (g_ctx.scratch[i]) (void)hipFree(g_ctx.scratch[i]);
+        if (g_ctx.scratch[i]) (void)plan_free(g_ctx.scratch[i]);
         g_ctx.scratch[i] = nullptr;
         g_ctx.scratch_bytes[i] = 0;
         g_ctx.lent[i] = nullptr;                               // a caller-owned region is not ours past a shutdown: a re-init must not hand it out
@@ -318,13 +379,13 @@ void xlp_shutdown(void)
     }
     g_ctx.fft_tw_log = 0; g_ctx.fft_tw_ptr = nullptr;
     if (g_ctx.selected != 0) { g_ctx.stream = g_ctx.main_stream; g_ctx.selected = 0; }
-    for (int i = 0; i < 8; i++) { if (g_marks[i]) (void)hipEventDestroy(g_marks[i]); g_marks[i] = nullptr; g_marked[i] = false; }
+    for (int i = 0; i < 8; i++) { if (g_marks[i]) XLP_HIPV(hipEventDestroy(g_marks[i])); g_marks[i] = nullptr; g_marked[i] = false; }
     commit_times_clear();
-    if (g_ctx.side_stream) { (void)hipStreamSynchronize(g_ctx.side_stream); (void)hipStreamDestroy(g_ctx.side_stream); g_ctx.side_stream = nullptr; }
-    if (g_ctx.own_stream) (void)hipStreamDestroy(g_ctx.stream);
-    if (g_ctx.copy_stream) { (void)hipStreamSynchronize(g_ctx.copy_stream); (void)hipStreamDestroy(g_ctx.copy_stream); g_ctx.copy_stream = nullptr; }
-    for (hipStream_t& a : g_ctx.aux_stream) if (a) { (void)hipStreamSynchronize(a); (void)hipStreamDestroy(a); a = nullptr; }
-    if (g_ctx.down_stream) { (void)hipStreamSynchronize(g_ctx.down_stream); (void)hipStreamDestroy(g_ctx.down_stream); g_ctx.down_stream = nullptr; }
+    if (g_ctx.side_stream) { XLP_HIPV(hipStreamSynchronize(g_ctx.side_stream)); XLP_HIPV(hipStreamDestroy(g_ctx.side_stream)); g_ctx.side_stream = nullptr; }
+    if (g_ctx.own_stream) XLP_HIPV(hipStreamDestroy(g_ctx.stream));
+    if (g_ctx.copy_stream) { XLP_HIPV(hipStreamSynchronize(g_ctx.copy_stream)); XLP_HIPV(hipStreamDestroy(g_ctx.copy_stream)); g_ctx.copy_stream = nullptr; }
+    for (hipStream_t& a : g_ctx.aux_stream) if (a) { XLP_HIPV(hipStreamSynchronize(a)); XLP_HIPV(hipStreamDestroy(a)); a = nullptr; }
+    if (g_ctx.down_stream) { XLP_HIPV(hipStreamSynchronize(g_ctx.down_stream)); XLP_HIPV(hipStreamDestroy(g_ctx.down_stream)); g_ctx.down_stream = nullptr; }
     while (!g_cache.empty()) cache_drop(0);
     g_cache_cap = 0;
     bn128_shutdown();
@@ -337,13 +398,13 @@ void xlp_shutdown(void)
 // ------------------------------------------------------------- device layer
 int xlp_dev_ntt(uint64_t* dst, const uint64_t* src, uint64_t n, uint64_t ncols, int inverse)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (ensure_init()) return -1;
     return dev_ntt(&g_ctx, dst, src, n, ncols, inverse);
 }
 int xlp_dev_extend(uint64_t* out, const uint64_t* in, uint64_t n_ext, uint64_t n, uint64_t ncols, uint64_t* scratch)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (ensure_init()) return -1;
     return dev_extend(&g_ctx, out, in, n_ext, n, ncols, scratch);
 }
@@ -386,19 +447,19 @@ int xlp_dev_fill(uint64_t* dst, uint64_t n, uint64_t seed, uint64_t start)
 
 int xlp_dev_batch_inverse(uint64_t* res, const uint64_t* src, uint64_t n, uint32_t dim)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (ensure_init()) return -1;
     return dev_batch_inverse(&g_ctx, res, src, n, dim);
 }
 int xlp_dev_calculate_z(uint64_t* z, const uint64_t* num, const uint64_t* den, uint64_t n)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (ensure_init()) return -1;
     return dev_calculate_z(&g_ctx, z, 3, num, 3, den, 3, n);
 }
 int xlp_dev_calculate_z_strided(uint64_t* z, uint64_t z_stride, const uint64_t* num, uint64_t num_stride, const uint64_t* den, uint64_t den_stride, uint64_t n)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (ensure_init()) return -1;
     return dev_calculate_z(&g_ctx, z, z_stride, num, num_stride, den, den_stride, n);
 }
@@ -411,33 +472,33 @@ int xlp_dev_scale3_strided(uint64_t* z, uint64_t z_stride, uint64_t n, const uin
 }
 int xlp_dev_calculate_h1h2(uint64_t* h1, uint64_t* h2, const uint64_t* f, const uint64_t* t, uint64_t n, uint32_t dim)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (ensure_init()) return -1;
     return dev_calculate_h1h2(&g_ctx, h1, dim, h2, dim, f, dim, t, dim, n, dim);
 }
 int xlp_dev_calculate_h1h2_strided(uint64_t* h1, uint64_t h1_stride, uint64_t* h2, uint64_t h2_stride, const uint64_t* f, uint64_t f_stride,
                                    const uint64_t* t, uint64_t t_stride, uint64_t n, uint32_t dim)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (ensure_init()) return -1;
     return dev_calculate_h1h2(&g_ctx, h1, h1_stride, h2, h2_stride, f, f_stride, t, t_stride, n, dim);
 }
 int xlp_expr_create(xlp_expr_program** out, const uint64_t* code, uint64_t ncode, uint64_t ntmp1, uint64_t ntmp3)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     return expr_create(out, code, ncode, ntmp1, ntmp3, 0);   // host-only: validation + compilation to the device form
 }
 int xlp_expr_create_ex(xlp_expr_program** out, const uint64_t* code, uint64_t ncode, uint64_t ntmp1, uint64_t ntmp3, uint64_t flags)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     return expr_create(out, code, ncode, ntmp1, ntmp3, flags);
 }
-int xlp_expr_destroy(xlp_expr_program* prog) { XLP_ENTER; return expr_destroy(prog); }
-int xlp_expr_codegen(const xlp_expr_program* prog, const char* path) { XLP_ENTER; return expr_codegen(prog, path); }
-int xlp_expr_attach(xlp_expr_program* prog, const char* path) { XLP_ENTER; return expr_attach(prog, path); }
+int xlp_expr_destroy(xlp_expr_program* prog) { XLP_ENTER_PLAN; return expr_destroy(prog); }
+int xlp_expr_codegen(const xlp_expr_program* prog, const char* path) { XLP_ENTER_PLAN; return expr_codegen(prog, path); }
+int xlp_expr_attach(xlp_expr_program* prog, const char* path) { XLP_ENTER_PLAN; return expr_attach(prog, path); }
 int xlp_dev_expr_run(const xlp_expr_program* prog, const xlp_steps_params* params, uint64_t row0, uint64_t nrows)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (ensure_init()) return -1;
     return dev_expr_run(&g_ctx, prog, params, row0, nrows);
 }
@@ -490,7 +551,7 @@ int xlp_dev_copy_3d(uint64_t* dst, uint64_t dst_stride0, uint64_t dst_stride1, c
 }
 int xlp_dev_extend_cm(uint64_t* out, uint64_t out_cstride, uint64_t out_coset_stride, const uint64_t* in, uint64_t in_cstride, uint64_t n_ext, uint64_t n, uint64_t ncols)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (ensure_init()) return -1;
     if (n && ncols && (!out || !in)) return xlp_fail("xlp_dev_extend_cm: null pointer");
     return dev_extend_cm(&g_ctx, out, out_cstride, out_coset_stride, in, in_cstride, n_ext, n, ncols);
@@ -560,7 +621,7 @@ int xlp_dev_x_div_x_sub_xi(uint64_t* out, const uint64_t* x, const uint64_t* xi,
 int xlp_dev_dot_columns(uint64_t* out, const xlp_dot_entry* entries, uint64_t nentries, uint32_t ngroups,
                         const uint64_t* coefs, uint64_t coefs_size, uint64_t nrows)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (ensure_init()) return -1;
     if (!nrows || !ngroups) return 0;
     if (!out || (nentries && (!entries || !coefs))) return xlp_fail("xlp_dev_dot_columns: null pointer");
@@ -570,7 +631,7 @@ int xlp_dev_dot_columns(uint64_t* out, const xlp_dot_entry* entries, uint64_t ne
 int xlp_dev_evmap(uint64_t* evals, const uint64_t* LEv, const uint64_t* LpEv, uint64_t n, uint32_t extend_bits, uint32_t nev,
                   const xlp_evmap_entry* entries)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (ensure_init()) return -1;
     if (nev && !entries) return xlp_fail("xlp_dev_evmap: null entries");
     return dev_evmap(&g_ctx, evals, LEv, LpEv, n, extend_bits, nev, entries);
@@ -578,7 +639,7 @@ int xlp_dev_evmap(uint64_t* evals, const uint64_t* LEv, const uint64_t* LpEv, ui
 
 int xlp_dev_evmap_cm(uint64_t* evals, const uint64_t* LEv, const uint64_t* LpEv, uint64_t n, uint32_t nev, const xlp_evmap_entry* entries)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (ensure_init()) return -1;
     if (nev && !entries) return xlp_fail("xlp_dev_evmap_cm: null entries");
     return dev_evmap_cm(&g_ctx, evals, LEv, LpEv, n, nev, entries);
@@ -586,7 +647,7 @@ int xlp_dev_evmap_cm(uint64_t* evals, const uint64_t* LEv, const uint64_t* LpEv,
 int xlp_dev_dot_columns_cm(uint64_t* out, uint64_t out_cstride, const xlp_dot_entry* entries, uint64_t nentries, uint32_t ngroups,
                            const uint64_t* coefs, uint64_t coefs_size, uint64_t nrows)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (ensure_init()) return -1;
     if (!nrows || !ngroups) return 0;
     if (!out || (nentries && (!entries || !coefs))) return xlp_fail("xlp_dev_dot_columns_cm: null pointer");
@@ -613,7 +674,7 @@ int xlp_profile_enable(int on)
     XLP_ENTER;
     if (ensure_init()) return -1;
     XLP_HIP(hipStreamSynchronize(g_ctx.stream));
-    for (hipEvent_t e : g_ctx.prof_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g_ctx.prof_events) XLP_HIPV(hipEventDestroy(e));
     g_ctx.prof_events.clear();
     g_ctx.profile = on != 0;
     return 0;
@@ -638,16 +699,17 @@ int xlp_profile_read(double ms_sum[3], uint64_t* count)
 
 int xlp_dev_alloc(void** ptr, size_t bytes)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (ensure_init()) return -1;
-    XLP_HIP(hipMalloc(ptr, bytes ? bytes : 8));
+    XLP_ALLOC(plan_malloc((void**)ptr, bytes ? bytes : 8));
     return 0;
 }
 int xlp_dev_mem_info(size_t* free_bytes, size_t* total_bytes)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (ensure_init()) return -1;
     size_t f = 0, t = 0;
+    if (g_plan_active) { t = g_plan.hbm; f = g_plan.cur < t ? t - g_plan.cur : 0; }
     XLP_HIP(hipMemGetInfo(&f, &t));
     if (free_bytes) *free_bytes = f;
     if (total_bytes) *total_bytes = t;
@@ -655,9 +717,9 @@ int xlp_dev_mem_info(size_t* free_bytes, size_t* total_bytes)
 }
 int xlp_dev_free(void* ptr)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (!ptr) return 0;
-    XLP_HIP(hipFree(ptr));
+    XLP_ALLOC(plan_free(ptr));
     return 0;
 }
 int xlp_dev_memset(void* dst_dev, int value, size_t bytes)
@@ -679,9 +741,10 @@ int xlp_copy_h2d(void* dst_dev, const void* src_host, size_t bytes)
 }
 int xlp_copy_d2h(void* dst_host, const void* src_dev, size_t bytes)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (ensure_init()) return -1;
     if (!bytes) return 0;
+    if (g_plan_active) { memset(dst_host, 0, bytes); return 0; }        // (plan mode: what the host reads back is zeros, deterministically)
     // the host range is rewritten: device copies of it kept by the host-pointer cache (xlp_cache_enable) are stale from here on.  Every
     // host-pointer entry point returns its results through this function (the D2H macro), so none of them can leave a stale copy behind.
     cache_drop_overlapping(dst_host, bytes);
@@ -692,15 +755,17 @@ int xlp_copy_d2h(void* dst_host, const void* src_dev, size_t bytes)
 
 int xlp_host_alloc(void** ptr, size_t bytes)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (ensure_init()) return -1;
+    if (g_plan_active) { *ptr = calloc(bytes ? bytes : 8, 1); return *ptr ? 0 : xlp_fail("xlp_host_alloc: out of host memory"); }   // (untouched pages cost nothing)
     XLP_HIP(hipHostMalloc(ptr, bytes ? bytes : 8, hipHostMallocDefault));
     return 0;
 }
 int xlp_host_free(void* ptr)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (!ptr) return 0;
+    if (g_plan_active) { free(ptr); return 0; }
     XLP_HIP(hipHostFree(ptr));
     return 0;
 }
@@ -722,7 +787,7 @@ int xlp_host_unregister(void* ptr)
 
 int xlp_dev_extend_cols(uint64_t* out, const uint64_t* in, uint64_t n_ext, uint64_t n, uint64_t ld, uint64_t col0, uint64_t ncols)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (ensure_init()) return -1;
     return dev_extend_cols(&g_ctx, out, in, n_ext, n, ld, col0, ncols);
 }
@@ -748,7 +813,7 @@ struct CommitTimes {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> lde, merkle;
     void clear()
     {
-        for (auto* v : {&lde, &merkle}) { for (auto& pr : *v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); } v->clear(); }
+        for (auto* v : {&lde, &merkle}) { for (auto& pr : *v) { XLP_HIPV(hipEventDestroy(pr.first)); XLP_HIPV(hipEventDestroy(pr.second)); } v->clear(); }
     }
     int begin(std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, hipStream_t st)
     {
@@ -938,14 +1003,14 @@ static int commit_bands_cm(uint64_t* sec_n, uint64_t csn, uint64_t* sec_2ns, uin
 }
 int xlp_dev_commit_cm(uint64_t* sec_2ns, uint64_t cs2, uint64_t* nodes, const uint64_t* sec_n, uint64_t csn, uint64_t n_ext, uint64_t n, uint64_t ncols)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (ensure_init()) return -1;
     return commit_bands_cm(const_cast<uint64_t*>(sec_n), csn, sec_2ns, cs2, nodes, nullptr, nullptr, 0, n_ext, n, ncols, nullptr);
 }
 int xlp_dev_commit_from_host_cm(uint64_t* sec_n, uint64_t csn, uint64_t* sec_2ns, uint64_t cs2, uint64_t* nodes, const uint64_t* h_src, uint64_t* stage, uint64_t stage_words,
                                 int clear_stage, uint64_t n_ext, uint64_t n, uint64_t ncols, double* upload_ms)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (ensure_init()) return -1;
     if (ncols && n && (!h_src || !stage)) return xlp_fail("xlp_dev_commit_from_host_cm: null host pointer or staging area");
     return commit_bands_cm(sec_n, csn, sec_2ns, cs2, nodes, h_src, stage, stage_words, n_ext, n, ncols, upload_ms, clear_stage);
@@ -1010,7 +1075,7 @@ int xlp_dev_upload_fence(void)
 }
 int xlp_dev_commit(uint64_t* sec_2ns, uint64_t* nodes, const uint64_t* sec_n, uint64_t n_ext, uint64_t n, uint64_t ncols)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     if (ensure_init()) return -1;
     return commit_bands(const_cast<uint64_t*>(sec_n), sec_2ns, nodes, nullptr, n_ext, n, ncols, nullptr);
 }
@@ -1078,7 +1143,7 @@ int xlp_extend(uint64_t* out, const uint64_t* in, uint64_t n_ext, uint64_t n, ui
     d_in.p = cache_take(in, in_bytes);
     const bool in_cached = d_in.p != nullptr;
     cache_drop_overlapping(out, out_bytes);
-    if (!d_in.p) XLP_HIP(hipMalloc(&d_in.p, in_bytes));
+    if (!d_in.p) XLP_ALLOC(plan_malloc((void**)&d_in.p, in_bytes));
     if (hipMalloc(&d_out.p, out_bytes) != hipSuccess) return xlp_fail("xlp_extend: out of device memory");
     const u64 band = 64;
     if (ncols <= band || n_ext * ncols < (1ull << 22)) {       // small: no pipeline
@@ -1107,8 +1172,8 @@ int xlp_extend(uint64_t* out, const uint64_t* in, uint64_t n_ext, uint64_t n, ui
             if (!rc && hipMemcpy2DAsync(out + c0, ncols * 8, (u64*)d_out.p + c0, ncols * 8, wc * 8, n_ext, hipMemcpyDeviceToHost, ctx->down_stream) != hipSuccess) rc = xlp_fail("xlp_extend: download failed");
         }
         // nothing of this call may still be in flight when the buffers are released, failed or not
-        (void)hipStreamSynchronize(ctx->copy_stream);
-        (void)hipStreamSynchronize(ctx->stream);
+        XLP_HIPV(hipStreamSynchronize(ctx->copy_stream));
+        XLP_HIPV(hipStreamSynchronize(ctx->stream));
         if (hipStreamSynchronize(ctx->down_stream) != hipSuccess && !rc) rc = xlp_fail("xlp_extend: download failed");
         if (rc) return rc;
     }
@@ -1134,7 +1199,7 @@ int xlp_merkle(uint64_t* nodes, const uint64_t* src, uint64_t w, uint64_t h)
     if (b.alloc(node_bytes)) { if (d_src.p) cache_put(src, src_bytes, d_src.release()); return -1; }
     int rc = 0;
     if (!cached && w) {
-        XLP_HIP(hipMalloc(&d_src.p, src_bytes));
+        XLP_ALLOC(plan_malloc((void**)&d_src.p, src_bytes));
         // rows are hashed independently: upload row chunks on the copy stream while the previous chunk is hashed
         const u64 chunk_rows = w > 4 && src_bytes > (256ull << 20) ? std::max<u64>(1, (128ull << 20) / (w * 8)) : h;
         if (chunk_rows >= h) {
@@ -1158,7 +1223,7 @@ int xlp_merkle(uint64_t* nodes, const uint64_t* src, uint64_t w, uint64_t h)
                 if (hipStreamWaitEvent(ctx->stream, ev[k], 0) != hipSuccess) rc = xlp_fail("xlp_merkle: stream wait failed");
                 if (!rc) rc = dev_linear_hash(ctx, b.u() + 4 * r0, (const u64*)d_src.p + r0 * w, w, nr);
             }
-            (void)hipStreamSynchronize(ctx->copy_stream);      // no copy into d_src may outlive this call
+            XLP_HIPV(hipStreamSynchronize(ctx->copy_stream));      // no copy into d_src may outlive this call
         }
     } else {
         rc = dev_linear_hash(ctx, b.u(), (const u64*)d_src.p, w, h);
@@ -1214,13 +1279,13 @@ int xlp_perm_chain(uint64_t out[12], const uint64_t state[4], const uint64_t* el
 // ---- transport between the ranks of a row-sharded proof (comm.hip)
 int xlp_comm_init(int rank, int world, const char* backend, const char* rendezvous)
 {
-    XLP_ENTER;
+    XLP_ENTER_PLAN;
     // RCCL binds the communicator to the context's device.  The shared-memory backend needs no device for its rendezvous, barrier and host-word
     // all-gather (tests/test_abi.py runs those as two processes on a CPU-only box); its device transfers fail like every other GPU call there.
     if (backend && !strcmp(backend, "rccl") && ensure_init()) return -1;
     return comm_init(&g_ctx, rank, world, backend, rendezvous);
 }
-void xlp_comm_shutdown(void) { XLP_ENTER; comm_shutdown(); }
+void xlp_comm_shutdown(void) { XLP_ENTER_PLAN; comm_shutdown(); }
 int xlp_comm_rank(void) { return comm_rank(); }
 int xlp_comm_world(void) { return comm_world(); }
 int xlp_comm_ranks_seen(void) { return comm_ranks_seen(); }
@@ -1257,7 +1322,7 @@ int xlp_comm_barrier(void)
     XLP_ENTER;
     return comm_barrier(&g_ctx);
 }
-int xlp_comm_stats(double* seconds, uint64_t* bytes_sent, uint64_t* calls, int mode) { XLP_ENTER; return comm_stats(seconds, bytes_sent, calls, mode); }
+int xlp_comm_stats(double* seconds, uint64_t* bytes_sent, uint64_t* calls, int mode) { XLP_ENTER_PLAN; return comm_stats(seconds, bytes_sent, calls, mode); }
 
 // ---- BN128 (StarkRecursiveF)
 int xlp_bn128_init(const char* constants_path)

@@ -32,11 +32,31 @@ inline u64 inv(u64 a) { return pow(a, P - 2); }
 int xlp_fail(const char* msg);             // records msg, returns -1
 int xlp_fail_hip(hipError_t e, const char* file, int line);
 
+// ---- PLAN MODE (xlp_plan_begin / XLP_PLAN=1; include/xlp_gl.h): a dry run of the host orchestration that touches no GPU.  Device allocations are
+// ACCOUNTED (a fake, never dereferenced address per allocation; live and peak bytes), everything else the library would ask of the HIP runtime is
+// skipped: the entry points return 0 at XLP_ENTER unless they are the ones that size memory (allocation, scratch slots, tables), and inside those every
+// HIP call (XLP_HIP / XLP_HIPV), kernel launch (hipLaunchKernelGGL below) and plugin launch is a no-op.  What it is for: the memory plan of a row-sharded
+// proof at sizes and rank counts no box of the build pool can hold (tests/test_memory_plan.py: 2^23 rows over 2, 4, 8 ranks), from the code that allocates.
+extern bool g_plan_active;
+inline bool plan_active() { return g_plan_active; }
+hipError_t plan_malloc(void** p, size_t bytes);       // hipMalloc, or its account in plan mode
+hipError_t plan_free(void* p);                        // hipFree, or its account in plan mode
+
 #define XLP_HIP(expr)                                                   \
+    do {                                                                \
+        if (!xlp::plan_active()) {                                      \
+            hipError_t _e = (expr);                                     \
+            if (_e != hipSuccess) return xlp_fail_hip(_e, __FILE__, __LINE__); \
+        }                                                               \
+    } while (0)
+// an allocation / release: always evaluated (plan mode accounts it)
+#define XLP_ALLOC(expr)                                                 \
     do {                                                                \
         hipError_t _e = (expr);                                         \
         if (_e != hipSuccess) return xlp_fail_hip(_e, __FILE__, __LINE__); \
     } while (0)
+// a HIP call whose result is ignored
+#define XLP_HIPV(expr) do { if (!xlp::plan_active()) (void)(expr); } while (0)
 
 struct Ctx {
     int device = 0;
@@ -179,3 +199,7 @@ int expr_attach(xlp_expr_program* prog, const char* so_path);
 int dev_expr_run(Ctx* ctx, const xlp_expr_program* prog, const xlp_steps_params* params, u64 row0, u64 nrows);
 
 }  // namespace xlp
+
+// every kernel of the library is launched through hipLaunchKernelGGL: in plan mode (above) none is
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, ...) do { if (!xlp::plan_active()) hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__); } while (0)

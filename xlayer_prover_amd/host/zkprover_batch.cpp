@@ -24,6 +24,7 @@ static uint64_t fnv1a(const std::string& s)
 static void syntheticWitness(Goldilocks::Element* cmPols, uint64_t degree, uint64_t nCols, uint64_t seed, uint64_t firstRow = 0)
 {
     const uint64_t total = degree * nCols, chunk = 1ULL << 28, start = firstRow * nCols;
+    if (xlp_plan_active()) return;                     // plan mode (XLP_PLAN=1): this stand-in is not the product -- its device buffer stays out of the account, the witness stays zero
     void* d = NULL;
     XLP_CHECK(xlp_dev_alloc(&d, (total < chunk ? total : chunk) * 8));
     for (uint64_t o = 0; o < total; o += chunk) {
@@ -159,6 +160,20 @@ int main(int argc, char** argv)
     for (int it = 0; it < proofs; it++) {
         if (world) XLP_CHECK(xlp_comm_stats(NULL, NULL, NULL, 1 | (timers ? 2 : 0)));
         prover.genBatchProof(&req);
+        if (xlp_plan_active()) {                       // XLP_PLAN=1: what THIS rank allocated on the device while it walked the batch proof (include/xlp_gl.h, plan mode)
+            uint64_t peak = 0, live = 0, allocs = 0, big[12], slots[9];
+            XLP_CHECK(xlp_plan_report(&peak, &live, &allocs, big, 12, slots));
+            std::ostringstream os;
+            os << "{\"memory_plan\":{\"world\":" << (world ? world : 1) << ",\"rank\":" << rank << ",\"run\":" << it << ",\"peak_bytes\":" << peak << ",\"live_bytes\":" << live
+               << ",\"allocations\":" << allocs << ",\"largest_at_peak\":[";
+            for (int i = 0; i < 12; i++) os << (i ? "," : "") << big[i];
+            os << "],\"scratch_slot_bytes\":[";
+            for (int i = 0; i < 9; i++) os << (i ? "," : "") << slots[i];
+            os << "]}}";
+            printf("%s\n", os.str().c_str());
+            fflush(stdout);
+            continue;
+        }
         if (world) {
             XLP_CHECK(xlp_comm_barrier());
             if (rank != 0) continue;
