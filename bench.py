@@ -398,7 +398,9 @@ def genproof_leg(timeout_s=300):
             tot_b += b; tot_t += z[names[st]]
         out["roofline_steps"] = {"bound": "hbm", "achieved": round(tot_b / tot_t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(tot_b / tot_t / 1e9 / HBM_PEAK_GBS, 4),
                                  "alg_bytes": tot_b, "seconds": round(tot_t, 4), "per_program": per,
-                                 "note": "algorithmic bytes: each column / table word a program reads or writes, once per row (temporaries are not traffic); measured inside the C++ genProof"}
+                                 "note": "algorithmic bytes: each column / table word a program reads or writes, once per row (temporaries are not traffic); measured inside the C++ genProof. "
+                                         "The metric asks for the HBM fraction; what bounds the largest program (step42ns) is vector issue, not bytes: a quarter fewer bytes through HBM "
+                                         "left its time where it was (profiles/r5/step_program_variant_sweep.txt)"}
     except Exception as e:
         out["roofline_steps"] = {"error": repr(e)[:200]}
     return out

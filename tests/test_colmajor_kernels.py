@@ -142,7 +142,7 @@ def test_merkle_cm_equals_oracle_and_openings(xlp, orc, lg, ext, w):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lg,ext,w,from_host", [(10, 1, 751, True), (10, 1, 168, False), (11, 2, 78, True), (9, 1, 4, True), (9, 1, 70, True), (17, 1, 130, True), (17, 1, 70, False)])
+@pytest.mark.parametrize("lg,ext,w,from_host", [(10, 1, 751, True), (10, 1, 168, False), (11, 2, 78, True), (9, 1, 4, True), (9, 1, 70, True), (17, 1, 70, True), (17, 1, 9, False)])
 def test_commit_cm_equals_oracle(xlp, orc, lg, ext, w, from_host):
     import torch
     n, ne = 1 << lg, 1 << (lg + ext)

@@ -88,9 +88,8 @@ def main():
                           "hbm_bytes_per_lde": sum(per[k]["hbm_bytes"] for k in ("lde_cm_top_dif", "lde_cm_mid", "lde_cm_top_dit")), "algorithmic_bytes_per_lde": 8 * n * ncols * 3,
                           "valu_wave_instructions_per_lde": sum(per[k]["SQ_INSTS_VALU"] for k in ("lde_cm_top_dif", "lde_cm_mid", "lde_cm_top_dit"))}
                          if all(k in per for k in ("lde_cm_top_dif", "lde_cm_mid", "lde_cm_top_dit")) else None),
-        "issue_peak_wave_instructions_per_s": 610e9,
-        "issue_peak_basis": "1024 SIMDs x 2.4 GHz / 4.2 cycles per half-rate wave64 instruction (carry adds, v_mad_u64_u32, v_cndmask: "
-                            "profiles/r1/ubench_instruction_rates.txt), ~10% full-rate moves",
+        # (rounds 1-4 carried a modelled issue peak here -- 610 G wave-instructions/s -- that the leaf sponge measurably exceeded; the ceilings bench.py
+        # quotes are now MEASURED on register-resident forms of the kernels: xlp_dev_perm_resident, xlp_dev_lde_resident, xlp_dev_msm_resident)
     }
     os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
     json.dump(res, open(out_path, "w"), indent=1)
