@@ -365,6 +365,20 @@ void orc_extend_pol(u64 *out, const u64 *in, u64 n_ext, u64 n, u64 ncols)
  * the first 16 stages of a transform stay inside blocks of 2^16 points (one block = one task, in cache), the remaining stages run over
  * all butterflies of all columns; twiddles come from a table w(log2 n)^i built in parallel chunks.  Same arithmetic, same results as
  * orc_extend_pol (tests/test_oracle_golden.py compares the two). */
+/* The team transform multiplies with the special-form reduction (2^64 = 2^32 - 1, 2^96 = -1 mod p) instead of gl_mul's `% p` on 128 bits (a library
+ * call of ~40 ns): what any CPU implementation of this field does, and what makes the cpu_baseline of bench.py a fair scalar figure (round 5: the `%` form
+ * was ~10x off a competent scalar transform).  Only here: every other function of the oracle keeps the plain `%`, and tests/test_oracle_golden.py
+ * compares this transform with orc_extend_pol word for word. */
+static inline u64 gl_mul_fast(u64 a, u64 b)
+{
+    const u128 x = (u128)a * (u128)b;
+    const u64 lo = (u64)x, hi = (u64)(x >> 64), hh = hi >> 32, hl = hi & 0xFFFFFFFFULL;
+    u64 t0, r;
+    if (__builtin_sub_overflow(lo, hh, &t0)) t0 -= 0xFFFFFFFFULL;     /* lo - hh < 0: + p = - EPS (mod 2^64), no second borrow */
+    if (__builtin_add_overflow(t0, hl * 0xFFFFFFFFULL, &r)) r += 0xFFFFFFFFULL;   /* carried: 2^64 = EPS, no second carry */
+    return r >= GL_P ? r - GL_P : r;
+}
+u64 orc_mul_fast(u64 a, u64 b) { return gl_mul_fast(a, b); }        /* (exported for the test that pins it to gl_mul on the reduction's edge cases) */
 #define TEAM_BLOCK_LOG 16
 static void ntt_cols_team(u64 *a /* [ncols][n] */, u64 ncols, u64 n, int inverse, const u64 *tw /* w(log2 n)^(+-i), i < n/2 */)
 {
@@ -373,17 +387,17 @@ static void ntt_cols_team(u64 *a /* [ncols][n] */, u64 ncols, u64 n, int inverse
     const u64 nblk = n >> lb;
 #pragma omp for schedule(static)
     for (u64 t = 0; t < ncols * n; t++) {
-        const u64 c = t / n, i = t % n, j = bitrev(i, lg);
+        const u64 c = t >> lg, i = t & (n - 1), j = bitrev(i, lg);        /* (n is a power of two: shifts, not the divisions `t / n` compiles to) */
         if (i < j) { u64 *col = a + c * n; u64 x = col[i]; col[i] = col[j]; col[j] = x; }
     }
 #pragma omp for schedule(dynamic, 1)
     for (u64 t = 0; t < ncols * nblk; t++) {
-        u64 *b = a + (t / nblk) * n + ((t % nblk) << lb);
+        u64 *b = a + (t >> (lg - lb)) * n + ((t & (nblk - 1)) << lb);
         for (unsigned s = 1; s <= lb; s++) {
             const u64 h = 1ULL << (s - 1), step = n >> s;
             for (u64 k = 0; k < (1ULL << lb); k += 2 * h)
                 for (u64 j = 0; j < h; j++) {
-                    const u64 x = gl_mul(tw[j * step], b[k + j + h]), u = b[k + j];
+                    const u64 x = gl_mul_fast(tw[j * step], b[k + j + h]), u = b[k + j];
                     b[k + j] = gl_add(u, x);
                     b[k + j + h] = gl_sub(u, x);
                 }
@@ -393,9 +407,9 @@ static void ntt_cols_team(u64 *a /* [ncols][n] */, u64 ncols, u64 n, int inverse
         const u64 h = 1ULL << (s - 1), step = n >> s;
 #pragma omp for schedule(static)
         for (u64 t = 0; t < ncols * (n / 2); t++) {
-            u64 *col = a + (t / (n / 2)) * n;
-            const u64 i = t % (n / 2), j = i & (h - 1), k = (i >> (s - 1)) << s;
-            const u64 x = gl_mul(tw[j * step], col[k + j + h]), u = col[k + j];
+            u64 *col = a + (t >> (lg - 1)) * n;
+            const u64 i = t & (n / 2 - 1), j = i & (h - 1), k = (i >> (s - 1)) << s;
+            const u64 x = gl_mul_fast(tw[j * step], col[k + j + h]), u = col[k + j];
             col[k + j] = gl_add(u, x);
             col[k + j + h] = gl_sub(u, x);
         }
@@ -403,7 +417,7 @@ static void ntt_cols_team(u64 *a /* [ncols][n] */, u64 ncols, u64 n, int inverse
     if (inverse) {
         const u64 ninv = gl_inv(n % GL_P);
 #pragma omp for schedule(static)
-        for (u64 t = 0; t < ncols * n; t++) a[t] = gl_mul(a[t], ninv);
+        for (u64 t = 0; t < ncols * n; t++) a[t] = gl_mul_fast(a[t], ninv);
     }
 }
 static void pow_table_team(u64 *t, u64 count, u64 base)       /* t[i] = base^i */
@@ -411,7 +425,7 @@ static void pow_table_team(u64 *t, u64 count, u64 base)       /* t[i] = base^i *
 #pragma omp for schedule(static)
     for (u64 c = 0; c < (count + 4095) / 4096; c++) {
         u64 v = gl_pow(base, c * 4096);
-        for (u64 i = c * 4096; i < count && i < (c + 1) * 4096; i++) { t[i] = v; v = gl_mul(v, base); }
+        for (u64 i = c * 4096; i < count && i < (c + 1) * 4096; i++) { t[i] = v; v = gl_mul_fast(v, base); }
     }
 }
 void orc_extend_pol_team(u64 *out, const u64 *in, u64 n_ext, u64 n, u64 ncols)
@@ -431,8 +445,8 @@ void orc_extend_pol_team(u64 *out, const u64 *in, u64 n_ext, u64 n, u64 ncols)
         ntt_cols_team(base, ncols, n, 1, twi);
 #pragma omp for schedule(static)
         for (u64 t = 0; t < ncols * n_ext; t++) {
-            const u64 c = t / n_ext, i = t % n_ext;
-            cols[t] = i < n ? gl_mul(base[c * n + i], sh[i]) : 0;
+            const u64 c = t >> ilog2(n_ext), i = t & (n_ext - 1);
+            cols[t] = i < n ? gl_mul_fast(base[c * n + i], sh[i]) : 0;
         }
         ntt_cols_team(cols, ncols, n_ext, 0, twf);
 #pragma omp for schedule(static)

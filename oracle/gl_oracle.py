@@ -27,7 +27,7 @@ def _load():
     build()
     lib = C.CDLL(_SO)
     sig = {
-        "orc_add": (u64, [u64, u64]), "orc_sub": (u64, [u64, u64]), "orc_mul": (u64, [u64, u64]),
+        "orc_add": (u64, [u64, u64]), "orc_sub": (u64, [u64, u64]), "orc_mul": (u64, [u64, u64]), "orc_mul_fast": (u64, [u64, u64]),
         "orc_inv": (u64, [u64]), "orc_pow": (u64, [u64, u64]), "orc_w": (u64, [C.c_uint]),
         "orc_shift": (u64, []),
         "orc_mul3": (None, [_pu64, _pu64, _pu64]),
@@ -88,6 +88,7 @@ def _vec(x):
 def add(a, b): return lib.orc_add(a, b)
 def sub(a, b): return lib.orc_sub(a, b)
 def mul(a, b): return lib.orc_mul(a, b)
+def mul_fast(a, b): return lib.orc_mul_fast(a, b)
 def inv(a): return lib.orc_inv(a)
 def pow_(a, e): return lib.orc_pow(a, e)
 def w(n): return lib.orc_w(n)

@@ -1005,6 +1005,8 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
     const bool lazy_canon = env_int("XLP_EXPR_LAZY_CANON", 1) != 0;
     const bool lazy_on = env_int("XLP_EXPR_LAZY", 1) != 0;
     const size_t lazy_max = (size_t)env_int("XLP_EXPR_LAZY_ACCS", 3);
+    const size_t reuse_dist = (size_t)std::max(0, env_int("XLP_EXPR_REUSE", 0));
+    const int lazy_min_gain = env_int("XLP_EXPR_LAZY_MIN_GAIN", 190);        // vector instructions a new accumulator must save to be created (0: always, as in rounds 3-4)
     const std::string prologue =
         "// generated by xlp_expr_codegen -- do not edit\n#include <hip/hip_runtime.h>\n#include \"gl_field.hpp\"\n#include \"xlp_expr_jit.h\"\n"
         "typedef unsigned long long u64_;\nusing gl::u64;\n"
@@ -1135,6 +1137,12 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
             return it->second[c];
         };
         // value of component c of a source operand
+        // XLP_EXPR_REUSE = D > 0 (round 5 experiment): a LOADED word (a column the segment does not write, a temporary of an earlier segment) whose last use lies more
+        // than D instructions back is loaded again instead of being held in its register: bytes (which have slack: the segments are bound by vector issue and
+        // registers) for registers.  0: a word is loaded once per segment.
+        size_t cur_i = i0;
+        std::map<u64, size_t> tlast;
+        std::map<MKey, size_t> mlast;
         auto src = [&](const DInstr& in, int o, u32 c) -> std::string {
             const u64* p = in.prm[o];
             const u32 k = in.k[o];
@@ -1143,9 +1151,9 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
             case XD_TMP: {
                 const u64 w = p[0] + c;
                 auto it = tval.find(w);
-                if (it != tval.end()) return it->second;
+                if (it != tval.end() && !(reuse_dist && !tdef[w] && cur_i - tlast[w] > reuse_dist)) { tlast[w] = cur_i; return it->second; }
                 const std::string n = load("T[" + std::to_string(w) + "ULL * TS]", false);
-                tval[w] = n; tdef[w] = false;
+                tval[w] = n; tdef[w] = false; tlast[w] = cur_i;
                 return n;
             }
             case XD_COL: {
@@ -1166,7 +1174,9 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
                     const u64 col = pol ? p[0] + c * (pr ? p[3] : p[1]) : p[0];
                     const MKey key(buf, col, pr ? p[1] : 0);
                     auto it = mval.find(key);
-                    if (it != mval.end()) return it->second;
+                    const bool held_long = reuse_dist && !(pol && wcolm.count(col)) && it != mval.end() && cur_i - mlast[key] > reuse_dist;
+                    if (it != mval.end() && !held_long) { mlast[key] = cur_i; return it->second; }
+                    mlast[key] = cur_i;
                     const std::string idx = pr ? "wrapc(row + " + num(p[1]) + ", A.cbase, " + num(p[2]) + ")" : std::string("row");
                     std::string n;
                     const bool cnl = !P->canonical;            // (XLP_EXPR_CANONICAL: the sections hold canonical words)
@@ -1200,6 +1210,7 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
             }
         };
         for (size_t i = i0; i < i1; i++) {
+            cur_i = i;
             const DInstr& in = ins[i];
             const u32 dd = in.dim[0], ad = in.dim[1], bd = in.dim[2];
             std::string a[3], b[3], r[3];
@@ -1232,7 +1243,45 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
                     if (x[1] != sym('A', id, ver, 1) || x[2] != sym('A', id, ver, 2)) return -1;
                     return (!accs[id].retired && accs[id].ver == ver) ? (int)id : -1;
                 };
-                const int pa = in.op == XLP_OP_ADD ? prod_of(a, ad) : -1, pb = prod_of(b, bd);   // a - k v = a + (-k) v; (k v) - b stays plain
+                int pa = in.op == XLP_OP_ADD ? prod_of(a, ad) : -1, pb = prod_of(b, bd);   // a - k v = a + (-k) v; (k v) - b stays plain
+                // IS A NEW ACCUMULATOR WORTH IT (round 5)?  Folding one costs ~190 vector instructions (three components x two reduce128 + the 128-bit
+                // recombination); a product that goes through it saves ~51 (base-field value: 18 multiply-adds instead of three mulc + three addc) or ~126
+                // (Fp^3 value: mac3 instead of mul3 + add3).  An accumulator that takes a single product before its sum is read -- 193 of the 434 of zkEVM step42ns:
+                // the steps of Horner chains the dot-product rewrite could not open, acc = c + k * (previous acc) -- costs more than the plain form.  One is only
+                // created when what is added now pays for the fold, or when the NEXT reader of the sum adds another product to it (the chain goes on).
+                if ((pa >= 0 || pb >= 0) && lazy_min_gain > 0) {
+                    const std::string* X0 = (pa >= 0 && pb >= 0) ? nullptr : (pb >= 0 ? a : b);
+                    const bool joins = X0 && acc_of(X0, X0 == a ? ad : bd) >= 0;
+                    if (!joins) {
+                        int gain = 0;
+                        if (pa >= 0) gain += prods[pa].ext ? 126 : 51;
+                        if (pb >= 0) gain += prods[pb].ext ? 126 : 51;
+                        bool goes_on = false;
+                        if (in.k[0] == XD_TMP) {
+                            const u64 w0 = in.prm[0][0];
+                            for (size_t j = i + 1; j < i1 && !goes_on; j++) {
+                                const DInstr& nx = ins[j];
+                                int rd = 0;
+                                for (int o = 1; o < 3; o++) if (nx.k[o] == XD_TMP && nx.prm[o][0] <= w0 && w0 < nx.prm[o][0] + nx.dim[o]) rd = o;
+                                if (rd) {                                       // the first reader of the sum: another accumulation step?
+                                    const int oo = 3 - rd;
+                                    if ((nx.op == XLP_OP_ADD || (nx.op == XLP_OP_SUB && rd == 1)) && nx.dim[0] == 3 && nx.k[oo] == XD_TMP && nx.dim[oo] == 3) {
+                                        for (size_t q = j; q-- > i0;) {           // who wrote the other operand last: a product by a challenge / evaluation?
+                                            const DInstr& wr = ins[q];
+                                            if (wr.k[0] != XD_TMP || !(wr.prm[0][0] <= nx.prm[oo][0] && nx.prm[oo][0] < wr.prm[0][0] + wr.dim[0])) continue;
+                                            auto u3 = [&](int o) { return wr.dim[o] == 3 && (wr.k[o] == XLP_K_CHALLENGE || wr.k[o] == XLP_K_EVAL); };
+                                            goes_on = wr.op == XLP_OP_MUL && (u3(1) || u3(2));
+                                            break;
+                                        }
+                                    }
+                                    break;
+                                }
+                                if (nx.k[0] == XD_TMP && nx.prm[0][0] <= w0 && w0 < nx.prm[0][0] + nx.dim[0]) break;     // overwritten unread
+                            }
+                        }
+                        if (!goes_on && gain < lazy_min_gain) pa = pb = -1;      // the plain form: the products are multiplied out below
+                    }
+                }
                 if (pa >= 0 || pb >= 0) {
                     accumulated = true;
                     const std::string* X = (pa >= 0 && pb >= 0) ? nullptr : (pb >= 0 ? a : b);
