@@ -43,6 +43,8 @@ def main():
                     "(XLP_EXPR_HOIST_LOADS, csrc/expr.hip place_loads; 0 = every load at its first use)")
     ap.add_argument("--seg", type=int, default=0, help="a segment boundary every this many instructions (XLP_EXPR_SEG; default: the generator's 256)")
     ap.add_argument("--cut", type=int, default=0, help="segment boundaries by dynamic programming, segments of at most this many instructions (XLP_EXPR_CUT)")
+    ap.add_argument("--tune", action="append", default=[], metavar="STEP=HOIST,CUT", help="per-program generator options that override --hoist-loads / --cut for that step "
+                    "(e.g. --tune step3prev=6,256 --tune step42ns=4,512: the programs differ in what they like -- profiles/r5/step_program_variant_sweep.txt)")
     ap.add_argument("--out-dir", default="", help="write the plugins (and their build directory) here instead of xlayer_prover_amd/chelpers (experiments)")
     a = ap.parse_args()
     # the generator reads its options when it writes the text: the stamp below covers the text, so a change of an option rebuilds the plugin
@@ -66,18 +68,37 @@ def main():
             tabp = G.load_fri_dots(a.geometry, a.aliased, a.circuit, LW)[0]
             geo["step52ns_tab"] = (tabp.code, tabp.ntmp1, tabp.ntmp3)
             a.steps += ",step52ns_tab"
+        drow_layout = None
+        if want52:                                        # ... and its 12-instruction ROW program (reads the sums xlp_dev_dot_columns[_cm] leaves: 3 x ngroups columns;
+            _, dots, rowp, _ = G.load_fri_dots(a.geometry, a.aliased, a.circuit, LW)     # interpreted it cost 27 ms of a zkEVM proof: round 5)
+            geo["step52ns_drow"] = (rowp.code, rowp.ntmp1, rowp.ntmp3)
+            a.steps += ",step52ns_drow"
+            Ld = LW or G.layout(a.geometry, a.aliased, a.circuit)
+            drow_layout = {"dots": (0, 3 * dots["ngroups"], Ld["cm1_2ns"][2])}
         if a.colmajor:                                    # (the one-row table programs address their own table: row-major as they are)
             Lc, ext = LW or G.layout(a.geometry, a.aliased, a.circuit), G.CIRCUITS[a.circuit]["ext"]
-            geo = {st: ((G.to_colmajor(v[0], Lc, ext), v[1], v[2]) if not st.endswith("_tab") else v) for st, v in geo.items()}
+            geo = {st: ((G.to_colmajor(v[0], drow_layout if st == "step52ns_drow" else Lc, ext), v[1], v[2]) if not st.endswith("_tab") else v) for st, v in geo.items()}
     for size in sizes:
-        for step in a.steps.split(","):
+        for step in (x for x in a.steps.split(",") if x):
             lr = (24 if step.endswith("2ns") else 23) if size in ("full", "geo") else size
-            src = os.path.join(R.REF_DIR, f"{a.circuit if geo else 'zkevm'}.{step.replace('_opt', '').replace('_tab', '')}.xlpexpr")
+            src = os.path.join(R.REF_DIR, f"{a.circuit if geo else 'zkevm'}.{step.replace('_opt', '').replace('_tab', '').replace('_drow', '')}.xlpexpr")
             name = f"{a.circuit}.{step}.geo{a.geometry}{'a' if a.aliased else ''}{f'w{a.world}' if a.world else ''}{'c' if a.colmajor else ''}" if geo else f"zkevm.{step}.n{lr}"
             so = os.path.join(a.out_dir or R.REF_DIR, name + ".so")
             if not os.path.exists(src):
                 print("missing", src); continue
             code, ntmp1, ntmp3 = R.read_program(src)
+            for tn in a.tune:                                 # this step's own generator options (read when the text is written)
+                nm, val = tn.split("=")
+                if nm == step.replace("_opt", ""):
+                    h, c = (int(x) for x in val.split(","))
+                    os.environ["XLP_EXPR_HOIST_LOADS"] = str(h); os.environ["XLP_EXPR_CUT"] = str(c)
+                    break
+            else:
+                for k, v in (("XLP_EXPR_HOIST_LOADS", a.hoist_loads), ("XLP_EXPR_CUT", a.cut)):
+                    if v:
+                        os.environ[k] = str(v)
+                    else:
+                        os.environ.pop(k, None)
             if geo:
                 code, ntmp1, ntmp3 = geo[step]
             else:

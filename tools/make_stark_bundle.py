@@ -105,7 +105,7 @@ def make(circ, log_n, aliased, out=None, fri_steps=None, queries=None, use_opt=T
         with open(os.path.join(out, f"{circ}.step52ns.dots"), "wb") as f:
             f.write(struct.pack("<3Q", MAGIC_DOTS, dots["ngroups"], len(dots["entries"]))); f.write(np.array(ents, dtype="<u8").tobytes())
         man["step52ns"] = {"prog": f"{circ}.step52ns.drow.xlpexpr", "tab": f"{circ}.step52ns.dtab.xlpexpr", "n_ext": n_ext, "dots": f"{circ}.step52ns.dots",
-                           "tab_plugin": plugin(f"{circ}.step52ns_tab.{geo}.so"), "plugin": None}
+                           "tab_plugin": plugin(f"{circ}.step52ns_tab.{geo}.so"), "plugin": plugin(f"{circ}.step52ns_drow.{geo}.so")}
     if world:
         for st, (code, n1, n3) in progs.items():               # (the rewritten forms store to the same places)
             man[st]["nextRowStores"] = [list(x) for x in G.next_row_stores(code, LW)]

@@ -1001,10 +1001,12 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
     // ("@P"), an ADD / SUB of such a symbol becomes gl::lazy3::mac on an accumulator ("@A", 18 vector instructions instead of ~63), and
     // the three canonical words are only computed (fold) where something else reads them or at the end of the segment.  Results are the
     // same field elements.  XLP_EXPR_LAZY=0 generates the plain form; XLP_EXPR_LAZY_ACCS bounds the accumulators alive at once
-    // (42 registers each).
+    // (42 registers each); XLP_EXPR_LAZY_MIN_GAIN: what a NEW accumulator must save to be created (below).
     const bool lazy_canon = env_int("XLP_EXPR_LAZY_CANON", 1) != 0;
     const bool lazy_on = env_int("XLP_EXPR_LAZY", 1) != 0;
-    const size_t lazy_max = (size_t)env_int("XLP_EXPR_LAZY_ACCS", 3);
+    // (ONE accumulator alive at a time since round 5 -- 3 in rounds 3-4: an accumulator is 42 registers and the segments are bound by what their registers allow in
+    // flight: zkEVM step42ns 0.272 -> 0.241 s, 0.249 with two, slower with four or more; without the accumulators at all 0.306 s: profiles/r5/step_program_variant_sweep.txt)
+    const size_t lazy_max = (size_t)env_int("XLP_EXPR_LAZY_ACCS", 1);
     const size_t reuse_dist = (size_t)std::max(0, env_int("XLP_EXPR_REUSE", 0));
     const int lazy_min_gain = env_int("XLP_EXPR_LAZY_MIN_GAIN", 190);        // vector instructions a new accumulator must save to be created (0: always, as in rounds 3-4)
     const std::string prologue =
