@@ -77,7 +77,7 @@ def _cpp_bundle(bundle, circ, timeout=360):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("circ,ln,aliased", [("zkevm", 14, True), ("zkevm", 14, False), ("recursive1", 17, False), ("c12a", 20, False)])
+@pytest.mark.parametrize("circ,ln,aliased", [("zkevm", 14, True), ("recursive1", 17, False), ("c12a", 20, False)])     # (the unaliased zkEVM slab: tests/test_cpp_sharded.py's one-GPU reference, tests/test_full_size.py)
 def test_cpp_starks_equals_python_flow_and_verifies(orc, tmp_path, circ, ln, aliased):
     import torch
     from tools import make_stark_bundle as B

@@ -74,8 +74,15 @@ def test_colmajor_program_on_the_gpu_equals_the_rowmajor_program_on_the_oracle(x
     # (step52ns: the product runs the FRI polynomial on xlp_dev_dot_columns_cm, not as generated kernels -- interpreter only here, its build is the longest)
     for compiled in ((False,) if step == "step52ns" else (False, True)):
         if compiled:
-            monkeypatch.setenv("XLP_EXPR_HOIST_LOADS", "4"); monkeypatch.setenv("XLP_EXPR_CUT", "320")
-            p.compile(str(tmp_path / "jit"), parts=16)
+            # the plugin `make -C xlayer_prover_amd/chelpers colmajor-plugins` built for this geometry (attach refuses it unless it was generated from exactly this
+            # program under these flags); built here only if it is not there
+            from xlayer_prover_amd import programs as R
+            so = os.path.join(R.REF_DIR, f"{circ}.{step}.geo{ln}c.so")
+            if os.path.exists(so):
+                p.attach(so)
+            else:
+                monkeypatch.setenv("XLP_EXPR_HOIST_LOADS", "4"); monkeypatch.setenv("XLP_EXPR_CUT", "320")
+                p.compile(str(tmp_path / "jit"), parts=16)
         dev = {k: xlp.from_np(v) for k, v in cm.items()}
         sp = xlp.steps_params(n_const_pols=nc, n_const_pols_2ns=nc, coset_rows=n if step.endswith("2ns") else 0, **dev)
         p.run(sp, 0, rows); xlp.sync()

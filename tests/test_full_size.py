@@ -117,7 +117,7 @@ def _programs_built(circ):
     return os.path.exists(os.path.join(R.REF_DIR, f"{circ}.step52ns.xlpexpr"))
 
 
-@pytest.mark.parametrize("circ,args", [("recursive1", []), ("c12a", []), ("zkevm", ["--log-n", "14", "--aliased", "1"]), ("zkevm", ["--log-n", "16", "--aliased", "0"])])
+@pytest.mark.parametrize("circ,args", [("recursive1", []), ("c12a", []), ("zkevm", ["--log-n", "14", "--aliased", "1"]), ("zkevm", ["--log-n", "14", "--aliased", "0"])])
 def test_genproof_small_geometries_checked(xlp, circ, args):
     """the checked run on the two small STARKs of genBatchProof at their real geometry (prover.cpp:610,644) and on the zkEVM
     programs at reduced row counts, both slab layouts: every check of tests/zkevm_checks.py"""

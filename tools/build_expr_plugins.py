@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--circuit", default="zkevm", help="with --geometry: zkevm, c12a or recursive1 (tools/zkevm_geometry.py CIRCUITS; the small ones only at their real size)")
     ap.add_argument("--opt-only", action="store_true", help="with --geometry: only the dot-product forms of steps 2-4 (what the genProof bench runs by default; the one-row table "
                     "program of step52ns costs the same few ms interpreted and the longest build)")
+    ap.add_argument("--plain-only", action="store_true", help="with --geometry: only the programs as converted (no dot-product forms, no table / row programs): what "
+                    "tests/test_expr_colmajor.py attaches at 2^8 rows instead of compiling on the GPU box")
     ap.add_argument("--aliased", action="store_true", help="with --geometry: the one-GPU aliased slab layout -> zkevm.<step>.geo<N>a.so")
     ap.add_argument("--world", type=int, default=0, help="with --geometry: the window layout of one rank of a proof row-sharded over this many ranks "
                     "(tools/zkevm_geometry.py layout_window) -> zkevm.<step>.geo<N>w<G>.so")
@@ -63,7 +65,9 @@ def main():
             geo[st + "_opt"] = v[0]
         sizes = ["geo"]
         want52 = "step52ns" in a.steps.split(",")
-        a.steps = ",".join(x for st in a.steps.split(",") for x in ((st + "_opt",) if a.opt_only else (st, st + "_opt")) if x != "step52ns_opt" or not a.opt_only)
+        a.steps = ",".join(x for st in a.steps.split(",") for x in ((st + "_opt",) if a.opt_only else (st,) if a.plain_only else (st, st + "_opt")) if x != "step52ns_opt" or not a.opt_only)
+        if a.plain_only:
+            want52 = False
         if want52 and not a.opt_only:                     # the one-row table program of the dot-columns form of step52ns
             tabp = G.load_fri_dots(a.geometry, a.aliased, a.circuit, LW)[0]
             geo["step52ns_tab"] = (tabp.code, tabp.ntmp1, tabp.ntmp3)
