@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--circuit", default="zkevm", help="with --geometry: zkevm, c12a or recursive1 (tools/zkevm_geometry.py CIRCUITS; the small ones only at their real size)")
     ap.add_argument("--opt-only", action="store_true", help="with --geometry: only the dot-product forms of steps 2-4 (what the genProof bench runs by default; the one-row table "
                     "program of step52ns costs the same few ms interpreted and the longest build)")
+    ap.add_argument("--drow", action="store_true", help="with --geometry: also the 12-instruction row program of the dot-columns form of step52ns (-> <circuit>.step52ns_drow.geo<N>.so; "
+                    "measured in round 5: nothing gained over the interpreter, so the bundles ship without it)")
     ap.add_argument("--plain-only", action="store_true", help="with --geometry: only the programs as converted (no dot-product forms, no table / row programs): what "
                     "tests/test_expr_colmajor.py attaches at 2^8 rows instead of compiling on the GPU box")
     ap.add_argument("--aliased", action="store_true", help="with --geometry: the one-GPU aliased slab layout -> zkevm.<step>.geo<N>a.so")
@@ -73,7 +75,7 @@ def main():
             geo["step52ns_tab"] = (tabp.code, tabp.ntmp1, tabp.ntmp3)
             a.steps += ",step52ns_tab"
         drow_layout = None
-        if want52:                                        # ... and its 12-instruction ROW program (reads the sums xlp_dev_dot_columns[_cm] leaves: 3 x ngroups columns;
+        if want52 and a.drow:                             # ... and its 12-instruction ROW program (reads the sums xlp_dev_dot_columns[_cm] leaves: 3 x ngroups columns;
             _, dots, rowp, _ = G.load_fri_dots(a.geometry, a.aliased, a.circuit, LW)     # interpreted it cost 27 ms of a zkEVM proof: round 5)
             geo["step52ns_drow"] = (rowp.code, rowp.ntmp1, rowp.ntmp3)
             a.steps += ",step52ns_drow"
