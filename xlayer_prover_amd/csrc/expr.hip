@@ -1007,6 +1007,7 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
     // (ONE accumulator alive at a time since round 5 -- 3 in rounds 3-4: an accumulator is 42 registers and the segments are bound by what their registers allow in
     // flight: zkEVM step42ns 0.272 -> 0.241 s, 0.249 with two, slower with four or more; without the accumulators at all 0.306 s: profiles/r5/step_program_variant_sweep.txt)
     const size_t lazy_max = (size_t)env_int("XLP_EXPR_LAZY_ACCS", 1);
+    const bool early_stores = env_int("XLP_EXPR_EARLY_STORES", 0) != 0;     // (measured, not adopted: see where it is used)
     const size_t reuse_dist = (size_t)std::max(0, env_int("XLP_EXPR_REUSE", 0));
     const int lazy_min_gain = env_int("XLP_EXPR_LAZY_MIN_GAIN", 190);        // vector instructions a new accumulator must save to be created (0: always, as in rounds 3-4)
     const std::string prologue =
@@ -1043,6 +1044,9 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
             for (size_t i = i0; i < i1; i++)
                 if (ins[i].k[0] == XLP_K_POLS || ins[i].k[0] == XLP_K_POLS_PRIME)
                     for (u32 c = 0; c < ins[i].dim[0]; c++) wcolm.insert(ins[i].prm[0][0] + c * ins[i].prm[0][ins[i].k[0] == XLP_K_POLS ? 1 : 3]);
+        std::map<u64, size_t> last_def;                  // tmp word -> the last instruction of this segment that defines it
+        for (size_t i = i0; i < i1; i++) if (ins[i].k[0] == XD_TMP) for (u32 c = 0; c < ins[i].dim[0]; c++) last_def[ins[i].prm[0][0] + c] = i;
+        std::set<u64> stored;                            // live-out words already stored (early stores)
         std::map<u64, std::string> tval;                 // tmp word -> SSA name
         std::map<u64, bool> tdef;                        // defined (not just loaded) in this segment
         std::map<std::pair<u64, u64>, std::string> cval; // (column, next) -> SSA name
@@ -1381,7 +1385,24 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
             if (in.k[0] != XD_TMP) for (u32 c = 0; c < dd; c++) r[c] = cn(real(r[c]));       // what is stored is a canonical word
             const u64* p = in.prm[0];
             switch (in.k[0]) {
-            case XD_TMP: for (u32 c = 0; c < dd; c++) { tval[p[0] + c] = r[c]; tdef[p[0] + c] = true; } break;
+            case XD_TMP:
+                for (u32 c = 0; c < dd; c++) { tval[p[0] + c] = r[c]; tdef[p[0] + c] = true; }
+                // EARLY STORES (round 5): a temporary that is live out of the segment used to be stored at the segment's END -- its value sat in a register pair until
+                // then, and the compiler cannot move the store up by itself: the fences of the load pipelining (sched_barrier(0)) hold every instruction in place.
+                // It is stored HERE when this is its last definition in the segment (the words of a chain that is still accumulating are not: every step redefines them).
+                // MEASURED (profiles/r5/step_program_variant_sweep.txt, thirteenth call): step42ns 0.230 -> 0.241 s, the others unchanged -- the register allocation moved the
+                // wrong way (four kernels above 256 registers instead of one, one with scratch).  Off by default; XLP_EXPR_EARLY_STORES=1 generates it.
+                if (early_stores)
+                    for (u32 c = 0; c < dd; c++) {
+                        const u64 w = p[0] + c;
+                        if (!live_in[sg + 1][w] || last_def[w] != i || stored.count(w)) continue;
+                        char kind; u32 id, ver, cc;
+                        if (parse(r[c], kind, id, ver, cc)) continue;                  // (a product / accumulator symbol: materialised where it is read or at the end)
+                        const std::string v = cn(r[c]);
+                        os << "    T[" << w << "ULL * TS] = " << v << ";\n";
+                        stats.tmp_stores++; stored.insert(w);
+                    }
+                break;
             case XD_COL:
                 for (u32 c = 0; c < dd; c++) {
                     os << "    CW[" << (p[0] + c) << "ULL * CAP] = " << r[c] << ";\n";
@@ -1410,7 +1431,7 @@ int expr_codegen(const xlp_expr_program* P, const char* path)
             }
         }
         for (const auto& kv : tval)
-            if (tdef[kv.first] && live_in[sg + 1][kv.first]) { const std::string v = cn(real(kv.second)); os << "    T[" << kv.first << "ULL * TS] = " << v << ";\n"; stats.tmp_stores++; }
+            if (tdef[kv.first] && live_in[sg + 1][kv.first] && !stored.count(kv.first)) { const std::string v = cn(real(kv.second)); os << "    T[" << kv.first << "ULL * TS] = " << v << ";\n"; stats.tmp_stores++; }
         stats.longest = std::max(stats.longest, i1 - i0);
         os << "}\n";
         segsrc[sg] = place_loads(os.str(), loads, hoist, hoist_ahead, stats);
