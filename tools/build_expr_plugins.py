@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
-"""Ahead-of-time plugins for the converted zkEVM programs on the synthetic slab the tests / benchmarks use
-(tests/expr_real.py: sections packed for n rows).  Writes xlayer_prover_amd/chelpers/zkevm.<step>.n<log2 n>.so next to
-the converted programs (git-ignored, travels to the GPU box).  Needs hipcc, no GPU.
-    python tools/build_expr_plugins.py --log-rows 8,19 [--steps step3,...] [--parts 8]"""
+"""Ahead-of-time plugins of the converted step programs (xlp_expr_codegen -> hipcc -> <name>.so next to the programs in xlayer_prover_amd/chelpers: git-ignored,
+travels to the GPU box).  Needs hipcc, no GPU.  Two families:
+    --log-rows 8,19                         the zkEVM programs on the synthetic slab of tests/expr_real.py              -> zkevm.<step>.n<log2 n>.so
+    --geometry N [--circuit C] [--aliased] [--world G] [--colmajor] [--opt-only | --plain-only]
+                                            relocated to a zkEVM-geometry slab / a rank's window (tools/zkevm_geometry.py) -> <C>.<step>[_opt].geo<N>[a][wG][c].so
+Generator options (read when the text is written; the stamp covers the text, so a change rebuilds): --hoist-loads, --cut / --seg, --tune STEP=HOIST,CUT per program.
+After each build: the generator's account of what the kernels move per row, and what the COMPILED code does (tools/isa_loads_in_flight.py), printed and written to
+<name>.report.json.  xlayer_prover_amd/chelpers/Makefile holds the product's settings (GEN, TUNE)."""
 import argparse
 import os
 import sys

@@ -788,8 +788,12 @@ __global__ __launch_bounds__(256) void expr_scatter_kernel(const u64* cols, cons
 }
 
 // --------------------------------------------------------------------------------------- ahead-of-time code
-// xlp_expr_codegen writes the compiled program as straight-line HIP: segments of XLP_EXPR_SEG instructions, one
-// __global__ per segment, one row per lane.  Inside a segment every temporary is an SSA value (the compiler
+// xlp_expr_codegen writes the compiled program as straight-line HIP: segments (segment_cuts: a cut every XLP_EXPR_SEG instructions, or the cut points
+// that move the fewest words through HBM, XLP_EXPR_CUT), one __global__ per segment, one row per lane.  What the generator decides itself, each with the
+// environment variable that sets it WHEN THE TEXT IS WRITTEN (tools/build_expr_plugins.py stamps a plugin with its text): where the loads are issued
+// (place_loads: XLP_EXPR_HOIST_LOADS / _AHEAD), which products go through carry-free accumulators and how many are alive (XLP_EXPR_LAZY, _LAZY_ACCS,
+// _LAZY_MIN_GAIN), which values are canonicalised (REPRESENTATIONS: XLP_EXPR_LAZY_CANON; the program flag XLP_EXPR_CANONICAL), and two measured-and-rejected
+// variants kept as switches (XLP_EXPR_REUSE, XLP_EXPR_EARLY_STORES).  Inside a segment every temporary is an SSA value (the compiler
 // allocates registers and hoists the coalesced column loads far ahead of their uses, which the interpreter's
 // decode -> load -> wait -> compute -> store loop cannot); only the temporaries that are live across a segment
 // boundary go through the HBM array tmp[word][lane].  The plugin is built with
