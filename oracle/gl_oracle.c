@@ -471,6 +471,45 @@ void orc_extend_naive(u64 *out, const u64 *in, u64 n_ext, u64 n)
     free(coef);
 }
 
+/* P(z) of the interpolant of evals[i * stride] on the coset {shift * w(log2 n)^i}, z outside it, by the BARYCENTRIC formula
+ *     P(z) = (z^n - shift^n) / (n shift^n) * sum_i f_i x_i / (z - x_i),      x_i = shift w^i
+ * (Lagrange with Z(x) = x^n - shift^n, Z'(x_i) = n shift^n / x_i).  No transform of any kind: an INDEPENDENT check of extendPol's values at any size
+ * (tests: the input column on <w_N> and the output column on shift <w_Next> must give the same P(z) at random z -- two polynomials of degree < N that
+ * agree at a random point of a 2^64 field).  The inverses by Montgomery's trick in chunks; OpenMP over chunks. */
+u64 orc_barycentric_eval(const u64 *evals, u64 n, u64 stride, u64 shift, u64 z)
+{
+    const u64 w = orc_w(ilog2(n));
+    const u64 CH = 4096, nch = (n + CH - 1) / CH;
+    u64 total = 0;
+#pragma omp parallel
+    {
+        u64 acc = 0;
+        u64 *d = (u64 *)malloc(CH * sizeof(u64)), *pre = (u64 *)malloc(CH * sizeof(u64)), *x = (u64 *)malloc(CH * sizeof(u64));
+#pragma omp for schedule(static)
+        for (u64 c = 0; c < nch; c++) {
+            const u64 i0 = c * CH, m = n - i0 < CH ? n - i0 : CH;
+            u64 xi = gl_mul(shift, gl_pow(w, i0)), run = 1;
+            for (u64 k = 0; k < m; k++) {
+                x[k] = xi; d[k] = gl_sub(z, xi);              /* z is not on the coset: d != 0 */
+                pre[k] = run; run = gl_mul(run, d[k]);
+                xi = gl_mul(xi, w);
+            }
+            u64 inv = gl_inv(run);
+            for (u64 k = m; k-- > 0;) {
+                const u64 dinv = gl_mul(inv, pre[k]);          /* 1 / (z - x_k) */
+                inv = gl_mul(inv, d[k]);
+                acc = gl_add(acc, gl_mul(gl_mul(gl_canon(evals[(i0 + k) * stride]), x[k]), dinv));
+            }
+        }
+#pragma omp critical
+        total = gl_add(total, acc);
+        free(d); free(pre); free(x);
+    }
+    const u64 sn = gl_pow(shift, n);
+    const u64 lead = gl_mul(gl_sub(gl_pow(z, n), sn), gl_inv(gl_mul(n % GL_P, sn)));
+    return gl_mul(lead, total);
+}
+
 /* -------------------------------------------------------------- Transcript */
 /* src/starkpil/transcript/transcript.cpp:4-87, transcript.hpp:13-37. */
 typedef struct {

@@ -42,6 +42,7 @@ def _load():
         "orc_extend_pol": (None, [_pu64, _pu64, u64, u64, u64]),
         "orc_extend_pol_team": (None, [_pu64, _pu64, u64, u64, u64]),
         "orc_extend_naive": (None, [_pu64, _pu64, u64, u64]),
+        "orc_barycentric_eval": (u64, [_pu64, u64, u64, u64, u64]),
         "orc_fri_fold": (None, [_pu64, _pu64, C.c_uint, C.c_uint, _pu64, u64]),
         "orc_fri_fold_one": (None, [_pu64, _pu64, C.c_uint, C.c_uint, u64, _pu64, u64]),
         "orc_transpose3": (None, [_pu64, _pu64, u64, C.c_uint]),
@@ -174,6 +175,11 @@ def extend_pol_team(src, n_ext, n, ncols):
     if n * ncols:
         lib.orc_extend_pol_team(out, src, n_ext, n, ncols)
     return out.reshape(n_ext, ncols)
+
+
+def barycentric_eval(evals, n, stride, shift_, z):
+    """P(z) of the interpolant of evals[i * stride], i < n, on the coset shift * <w(log2 n)>: barycentric formula, no transform (an independent check of extendPol)"""
+    return lib.orc_barycentric_eval(_a(evals).ravel(), n, stride, shift_, z)
 
 
 def extend_naive(col, n_ext):

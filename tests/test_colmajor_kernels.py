@@ -113,6 +113,29 @@ def test_extend_cm_equals_oracle(xlp, orc, lg, ext, w):
 
 
 @pytest.mark.gpu
+def test_extend_cm_at_the_size_of_config2_by_the_barycentric_formula(xlp, orc):
+    """the column-major extendPol (what genBatchProof runs) at BASELINE configs[1]'s size, 2^23 x 8 -> 2^24 x 8: the VALUES of all eight columns against an
+    algorithm without a transform -- the input column on <w_N> and the output column (coset-major storage back to natural order) on shift <w_Next> have the same
+    barycentric interpolant at random points (oracle, orc_barycentric_eval)"""
+    import random
+    import torch
+    lg, w = 23, 8
+    n, ne = 1 << lg, 2 << lg
+    src = torch.empty(n * w, dtype=torch.int64, device="cuda")
+    xlp.dev_fill(src, 0x5EED0D99, 0)                                   # [column][row]: column c is the words c * n .. (c + 1) * n of the fill
+    out = torch.zeros(ne * w, dtype=torch.int64, device="cuda")
+    xlp.dev_extend_cm(out, ne, src, n, ne, n, w)
+    xlp.sync()
+    h_in = xlp.to_np(src).reshape(w, n)
+    h_out = xlp.to_np(out).reshape(w, 2, n)                           # coset-major: [column][coset r][q], natural row (q << 1) | r
+    rng = random.Random(99)
+    for c in range(w):
+        nat = np.ascontiguousarray(h_out[c].T).reshape(-1)
+        z = rng.randrange(0xFFFFFFFF00000001)
+        assert orc.barycentric_eval(h_in[c], n, 1, 1, z) == orc.barycentric_eval(nat, ne, 1, orc.shift(), z), c
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("lg,ext,w", [(8, 1, 751), (10, 2, 20), (9, 1, 4), (9, 1, 3), (7, 3, 9), (6, 0, 16), (9, 1, 0)])
 def test_merkle_cm_equals_oracle_and_openings(xlp, orc, lg, ext, w):
     import torch

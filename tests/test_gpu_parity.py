@@ -199,6 +199,13 @@ def test_lde_config2_device_resident_properties(xlp, orc):
         s = orc.pow_(7, i)
         for c in range(ncols):
             assert int(h_co[i, c]) == orc.mul(int(h_ci[i, c]), s)
+    # the VALUES of every column, by an algorithm without a transform: input and output are evaluations of one polynomial of degree < n, so their barycentric
+    # interpolants (oracle, orc_barycentric_eval) agree at random points of the field -- at the full size, all eight columns
+    import random
+    rng = random.Random(23)
+    for c in range(ncols):
+        z = rng.randrange(0xFFFFFFFF00000001)
+        assert orc.barycentric_eval(h_src.ravel()[c:], n, ncols, 1, z) == orc.barycentric_eval(h_out.ravel()[c:], n_ext, ncols, orc.shift(), z), c
     # and the first rows of a second, different-seed run differ (no stale buffers)
     assert h_out.any()
 
