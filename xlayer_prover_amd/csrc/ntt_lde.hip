@@ -346,6 +346,13 @@ int dev_extend_fast(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ncols)
 
 // columns [first, first + ncols) of row-major matrices with row stride ld (in: n rows, out: n << e rows)
 static int extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld, u64 first, u64 ncols, bool resident);
+int launch_lde_mid_mfma(Ctx* ctx, const LdeParams& p, u32 BT, const u64* gk);   // ntt_lde_mid_mfma.hip
+// XLP_LDE_MFMA=1: the middle pass on the matrix pipe (ntt_lde_mid_mfma.hip) instead of the vector kernel
+static bool lde_mid_mfma_enabled()
+{
+    const char* s = getenv("XLP_LDE_MFMA");
+    return s && s[0] == '1';
+}
 int dev_extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld, u64 first, u64 ncols)
 {
     return extend_fast_cols(ctx, out, in, L, e, ld, first, ncols, false);
@@ -373,10 +380,12 @@ static int extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64
     if (get_pow_tables(ctx, L, hgl::inv(wn), 1, &p.cri_lo, &p.cri_hi)) return -1;
     if (get_pow_tables(ctx, L, wn, 1, &p.crf_lo, &p.crf_hi)) return -1;
     const u64 ninv = hgl::inv(n % hgl::P);
+    u64 gks[LDE_MAX_COSETS] = {};
     for (u32 r = 0; r < ncos; r++) {
         const u64 g = hgl::mul(7, hgl::pow(wext, r));          // shift * w_ext^r
         u64 gk = g;
         for (u32 i = 0; i < BT; i++) gk = hgl::mul(gk, gk);    // g^(2^BT)
+        gks[r] = gk;
         const u64* sk;
         if (get_pow_tables(ctx, 12, gk, 1, &sk, &dummy)) return -1;
         if (lde_tw2_table(ctx, BT, gk, sk, p.twf_12, &p.tw2[r])) return -1;
@@ -405,7 +414,8 @@ static int extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64
         }
         if (resident ? (BT == 11 ? launch_top<11, true>(ctx, p, false) : launch_top<10, true>(ctx, p, false)) : launch_top_bt(ctx, p, BT, false)) return -1;
         if (ctx->profile) XLP_HIP(hipEventRecord(ev[1], ctx->stream));
-        if (launch_lde_mid(ctx, p, BT, resident)) return -1;
+        if (!resident && lde_mid_mfma_enabled()) { if (launch_lde_mid_mfma(ctx, p, BT, gks)) return -1; }
+        else if (launch_lde_mid(ctx, p, BT, resident)) return -1;
         if (ctx->profile) XLP_HIP(hipEventRecord(ev[2], ctx->stream));
         if (resident ? (BT == 11 ? launch_top<11, true>(ctx, p, true) : launch_top<10, true>(ctx, p, true)) : launch_top_bt(ctx, p, BT, true)) return -1;
         if (ctx->profile) XLP_HIP(hipEventRecord(ev[3], ctx->stream));
