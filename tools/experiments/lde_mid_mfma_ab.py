@@ -44,6 +44,9 @@ def main():
     capi.use_torch_stream()
     report = {"parity": [], "timing": {}}
     cases = [(17, 1, 8), (17, 0, 4), (18, 2, 5), (19, 3, 7), (20, 1, 12), (21, 1, 9), (22, 1, 8), (23, 1, 8), (20, 1, 70)]
+    quick = "--quick" in sys.argv
+    if quick:
+        cases = [(17, 1, 8), (19, 3, 7), (23, 1, 8)]
     ok = True
     for lg, e, ncols in cases:
         a, src, _ = extend(lg, e, ncols, False)
@@ -54,8 +57,8 @@ def main():
         ok = ok and same
         del a, b, src
     report["parity_ok"] = ok
-    if "--time" in sys.argv:
-        for lg, ncols in ((23, 8), (23, 64), (22, 8)):
+    if "--time" in sys.argv or quick:
+        for lg, ncols in (((23, 8),) if quick else ((23, 8), (23, 64), (22, 8))):
             rows = []
             for m in (False, True, False, True):
                 _, _, r = extend(lg, 1, ncols, m, steps=10)

@@ -40,7 +40,7 @@ constexpr u32 MM_THREADS = 512;
 
 struct MidMfma {
     const v4i* mat;                    // [matrix][tile 4][k chunk 4][lane 64] x 16 bytes
-    const u64* t3[LDE_MAX_COSETS];     // t3[r][low8 + 256 j] = G_r^j w4096^(j low8)
+    const u64* t3[LDE_MAX_COSETS];     // t3[r][low8 + 256 j] = G_r^j w4096^(j low8): what input j of r3' at low8 is multiplied by (applied when r2' stores it)
     int cz[8], cb[8];                  // accumulator start digits: sum = 0 / = B0 (mod p)
     u32 k0lo, k0hi;                    // 16 B0 mod p
 };
@@ -58,11 +58,13 @@ __device__ __forceinline__ RecK rec_consts()
 // digits d[0..7] (each < 2^23) at weights 2^(8m) -> any 64-bit representative of their sum mod p; (a0, a1): + a0 + a1 2^32
 __device__ __forceinline__ u64 recombine(const int* d, const RecK& K, u32 a0, u32 a1)
 {
-    const u32 a = ((u32)d[1] << 8) + (u32)d[0];
-    u64 W0 = (u64)(u32)d[2] * K.k16 + a;
+    u64 W0 = ((u32)d[1] << 8) + (u32)d[0];
+    W0 = (u64)(u32)d[2] * K.k16 + W0;
+    asm("" : "+v"(W0));                                                             // (or the compiler adds the low digits last: one 64-bit add more)
     W0 = (u64)(u32)d[3] * K.k24 + W0;                                               // < 2^47
-    const u32 c = ((u32)d[5] << 8) + (u32)d[4];
-    u64 W1 = (u64)(u32)d[6] * K.k16 + c;
+    u64 W1 = ((u32)d[5] << 8) + (u32)d[4];
+    W1 = (u64)(u32)d[6] * K.k16 + W1;
+    asm("" : "+v"(W1));
     W1 = (u64)(u32)d[7] * K.k24 + W1;
     W0 += a0; W1 += a1;
     const u64 Z = (u64)(u32)(W1 >> 32) * K.eps + W0;                                // W0 + (W1 >> 32) 2^64 (mod p), < 2^49
@@ -87,8 +89,10 @@ __device__ __forceinline__ void load_mat(v4i (&A)[4][4], const v4i* __restrict__
 
 // 32 DFT16 of a wave: lane (n = lane % 32, h = lane / 32) holds inputs j = 4q + 2h + ee at e[2q + ee] of DFT n and receives outputs
 // k = 4t + 2h + u at y[2t + u].  K0: output 0 (t = 0, u = 0, lanes h = 0) gets + (k0lo, k0hi) (the caller passes zeros in the other lanes).
+// next >= 0: once the last chain has been issued, A is reloaded with matrix `next`.
 template <bool K0>
-__device__ __forceinline__ void dft_op(const v4i (&A)[4][4], const u64 (&e)[8], const v16i& C, const RecK& K, u32 k0lo, u32 k0hi, u64 (&y)[8])
+__device__ __forceinline__ void dft_op(v4i (&A)[4][4], const u64 (&e)[8], const v16i& C, const RecK& K, u32 k0lo, u32 k0hi, u64 (&y)[8],
+                                       const v4i* __restrict__ mat = nullptr, int next = -1, u32 lane = 0)
 {
     v4i b[4];
 #pragma unroll
@@ -96,17 +100,35 @@ __device__ __forceinline__ void dft_op(const v4i (&A)[4][4], const u64 (&e)[8], 
         b[q].x = (int)((u32)e[2 * q] ^ 0x80808080u); b[q].y = (int)((u32)(e[2 * q] >> 32) ^ 0x80808080u);
         b[q].z = (int)((u32)e[2 * q + 1] ^ 0x80808080u); b[q].w = (int)((u32)(e[2 * q + 1] >> 32) ^ 0x80808080u);
     }
+    // two accumulators in turn: the digits of one chain are recombined (vector pipe) while the next chain runs (matrix pipe)
+    v16i acc[2];
+    auto chain = [&](int t) {
+        acc[t & 1] = C;
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        v16i acc = C;
-#pragma unroll
-        for (int q = 0; q < 4; q++) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[t][q], b[q], acc, 0, 0, 0);
+        for (int q = 0; q < 4; q++) acc[t & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[t][q], b[q], acc[t & 1], 0, 0, 0);
+    };
+    auto rec = [&](int t) {
         int d[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) d[i] = acc[i];
+        for (int i = 0; i < 16; i++) d[i] = acc[t & 1][i];
         y[2 * t] = recombine(d, K, (K0 && t == 0) ? k0lo : 0u, (K0 && t == 0) ? k0hi : 0u);
         y[2 * t + 1] = recombine(d + 8, K, 0u, 0u);
-    }
+    };
+    chain(0);
+    chain(1);
+    __builtin_amdgcn_sched_barrier(0);
+    rec(0);
+    __builtin_amdgcn_sched_barrier(0);
+    chain(2);
+    __builtin_amdgcn_sched_barrier(0);
+    rec(1);
+    __builtin_amdgcn_sched_barrier(0);
+    chain(3);
+    __builtin_amdgcn_sched_barrier(0);
+    if (next >= 0) load_mat(A, mat, (u32)next, lane);        // the next phase's matrix: its latency runs under what is left of this phase
+    __builtin_amdgcn_sched_barrier(0);
+    rec(2);
+    rec(3);
 }
 
 __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma(const LdeParams p, const MidMfma t, u32 BT)
@@ -131,45 +153,45 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma(const LdeParams p, co
     u64 y[8];
     u64 sink = 0;
 
-    // ---- r1: inverse DFT over digit 2 (positions low8 + 256 j), x w4096^-(k low8), global -> LDS
+    // ---- r1: inverse DFT over digit 2 (positions low8 + 256 j), x w4096^-(k low8), global -> LDS.  All of the tile's words are requested up front.
     load_mat(A, t.mat, MM_INV, lane);
-#pragma unroll 1
-    for (u32 half = 0; half < 2; half++) {
-        u64 e[2][8], tw[2][8];
+    {
+        u64 e[4][8];
 #pragma unroll
-        for (u32 i = 0; i < 2; i++) {
-            const u32 low8 = 8 * (wave + 8 * (2 * half + i)) + b;
+        for (u32 i = 0; i < 4; i++) {
+            const u32 low8 = 8 * (wave + 8 * i) + b;
 #pragma unroll
             for (u32 s = 0; s < 8; s++) {
                 const u32 j = 4 * (s >> 1) + 2 * h + (s & 1);
                 e[i][s] = XLP_MM_ABL >= 2 ? res_word((u64)(low8 + 256 * j) * 8 + vv + hi) : Ag[(u64)(low8 + 256 * j) * 8 + vv];
-                tw[i][s] = XLP_MM_ABL >= 3 ? res_word(j * low8) : p.twi_12[j * low8];
             }
         }
 #pragma unroll
-        for (u32 i = 0; i < 2; i++) {
-            const u32 low8 = 8 * (wave + 8 * (2 * half + i)) + b;
-            dft_op<true>(A, e[i], Cz, K, k0lo, k0hi, y);
+        for (u32 i = 0; i < 4; i++) {
+            const u32 low8 = 8 * (wave + 8 * i) + b;
+            u64 tw[8];
+#pragma unroll
+            for (u32 s = 0; s < 8; s++) tw[s] = XLP_MM_ABL >= 3 ? res_word(s * low8) : p.twi_12[(4 * (s >> 1) + 2 * h + (s & 1)) * low8];
+            dft_op<true>(A, e[i], Cz, K, k0lo, k0hi, y, t.mat, i == 3 ? (int)(MM_R2 + wave) : -1, lane);
 #pragma unroll
             for (u32 s = 0; s < 8; s++) {
                 const u32 k = 4 * (s >> 1) + 2 * h + (s & 1);
-                sm[mm_row(low8 + 256 * k) * 4 + v] = gl::mul(y[s], tw[i][s]);
+                sm[mm_row(low8 + 256 * k) * 4 + v] = gl::mul(y[s], tw[s]);
             }
         }
     }
+    __syncthreads();
     // ---- r2: inverse DFT over digit 1 (positions 256 high + 16 j + low4) x w256^-(k low4): the wave's two matrices, in place
 #pragma unroll 1
     for (u32 s2 = 0; s2 < 2; s2++) {
         const u32 low4 = wave + 8 * s2;
-        load_mat(A, t.mat, MM_R2 + low4, lane);
-        if (s2 == 0) __syncthreads();
 #pragma unroll
         for (u32 i = 0; i < 2; i++) {
             const u32 base = 256 * (8 * i + b) + low4;
             u64 e[8];
 #pragma unroll
             for (u32 s = 0; s < 8; s++) e[s] = sm[mm_row(base + 16 * (4 * (s >> 1) + 2 * h + (s & 1))) * 4 + v];
-            dft_op<true>(A, e, Cb, K, k0lo, k0hi, y);
+            dft_op<true>(A, e, Cb, K, k0lo, k0hi, y, t.mat, i == 1 ? (int)(s2 == 0 ? MM_R2 + wave + 8 : MM_COSET0) : -1, lane);
 #pragma unroll
             for (u32 s = 0; s < 8; s++) sm[mm_row(base + 16 * (4 * (s >> 1) + 2 * h + (s & 1))) * 4 + v] = y[s];
         }
@@ -183,62 +205,54 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma(const LdeParams p, co
 #pragma unroll
         for (u32 s = 0; s < 8; s++) X[i][s] = sm[mm_row(base + 4 * (s >> 1) + 2 * h + (s & 1)) * 4 + v];
     }
-    for (u32 r = 0; r < (1u << p.e); r++) {
+    const u32 ncos = 1u << p.e;
+    for (u32 r = 0; r < ncos; r++) {
         u64* __restrict__ Br = p.B + (u64)r * lde_swords(p.wc, p.L) + goff + ((u64)hi << 12) * 8;
         const u64* __restrict__ t3 = t.t3[r];
+        const u32 mr = MM_COSET0 + MM_PER_COSET * r;
         // ---- M_r: inverse DFT over digit 0, coset scale G^(256 i), forward DFT over digit 0: one matrix
-        load_mat(A, t.mat, MM_COSET0 + MM_PER_COSET * r, lane);
         __syncthreads();                                                             // the tile's previous readers are done
 #pragma unroll
         for (u32 i = 0; i < 4; i++) {
             const u32 base = 16 * (8 * (wave + 8 * i) + b);
-            dft_op<false>(A, X[i], Cb, K, 0u, 0u, y);
+            dft_op<false>(A, X[i], Cb, K, 0u, 0u, y, t.mat, i == 3 ? (int)(mr + 1 + wave) : -1, lane);
 #pragma unroll
             for (u32 s = 0; s < 8; s++) sm[mm_row(base + 4 * (s >> 1) + 2 * h + (s & 1)) * 4 + v] = y[s];
         }
-        // ---- r2': x G^(16 j) w256^(j low4), forward DFT over digit 1, in place
+        __syncthreads();
+        // ---- r2': x G^(16 j) w256^(j low4), forward DFT over digit 1, in place; the outputs leave multiplied by the next round's
+        //      input factors t3 = G^j' w4096^(j' low8') (j' = high, low8' = 16 k + low4), whose loads run under the round's own work
 #pragma unroll 1
         for (u32 s2 = 0; s2 < 2; s2++) {
             const u32 low4 = wave + 8 * s2;
-            load_mat(A, t.mat, MM_COSET0 + MM_PER_COSET * r + 1 + low4, lane);
-            if (s2 == 0) __syncthreads();
 #pragma unroll
             for (u32 i = 0; i < 2; i++) {
                 const u32 base = 256 * (8 * i + b) + low4;
-                u64 e[8];
+                u64 e[8], f[8];
+#pragma unroll
+                for (u32 s = 0; s < 8; s++) f[s] = XLP_MM_ABL >= 3 ? res_word(base + s) : t3[base + 16 * (4 * (s >> 1) + 2 * h + (s & 1))];
 #pragma unroll
                 for (u32 s = 0; s < 8; s++) e[s] = sm[mm_row(base + 16 * (4 * (s >> 1) + 2 * h + (s & 1))) * 4 + v];
-                dft_op<false>(A, e, Cz, K, 0u, 0u, y);
+                dft_op<false>(A, e, Cz, K, 0u, 0u, y, t.mat, i == 1 ? (int)(s2 == 0 ? mr + 1 + wave + 8 : MM_FWD) : -1, lane);
 #pragma unroll
-                for (u32 s = 0; s < 8; s++) sm[mm_row(base + 16 * (4 * (s >> 1) + 2 * h + (s & 1))) * 4 + v] = y[s];
+                for (u32 s = 0; s < 8; s++) sm[mm_row(base + 16 * (4 * (s >> 1) + 2 * h + (s & 1))) * 4 + v] = gl::mul(y[s], f[s]);
             }
         }
-        // ---- r3': x G^j w4096^(j low8) (t3), forward DFT over digit 2, LDS -> B_r
-        load_mat(A, t.mat, MM_FWD, lane);
         __syncthreads();
+        // ---- r3': forward DFT over digit 2, LDS -> B_r
 #pragma unroll 1
-        for (u32 half = 0; half < 2; half++) {
-            u64 f[2][8];
+        for (u32 i = 0; i < 4; i++) {
+            const u32 low8 = 8 * (wave + 8 * i) + b;
+            u64 e[8];
 #pragma unroll
-            for (u32 i = 0; i < 2; i++) {
-                const u32 low8 = 8 * (wave + 8 * (2 * half + i)) + b;
+            for (u32 s = 0; s < 8; s++) e[s] = sm[mm_row(low8 + 256 * (4 * (s >> 1) + 2 * h + (s & 1))) * 4 + v];
+            dft_op<true>(A, e, Cz, K, k0lo, k0hi, y, t.mat, (i == 3 && r + 1 < ncos) ? (int)(mr + MM_PER_COSET) : -1, lane);
+            if (XLP_MM_ABL >= 2) {
 #pragma unroll
-                for (u32 s = 0; s < 8; s++) f[i][s] = XLP_MM_ABL >= 3 ? res_word(low8 + s) : t3[low8 + 256 * (4 * (s >> 1) + 2 * h + (s & 1))];
-            }
+                for (u32 s = 0; s < 8; s++) sink ^= gl::canon(y[s]) + low8;
+            } else if (valid) {
 #pragma unroll
-            for (u32 i = 0; i < 2; i++) {
-                const u32 low8 = 8 * (wave + 8 * (2 * half + i)) + b;
-                u64 e[8];
-#pragma unroll
-                for (u32 s = 0; s < 8; s++) e[s] = gl::mul(sm[mm_row(low8 + 256 * (4 * (s >> 1) + 2 * h + (s & 1))) * 4 + v], f[i][s]);
-                dft_op<true>(A, e, Cz, K, k0lo, k0hi, y);
-                if (XLP_MM_ABL >= 2) {
-#pragma unroll
-                    for (u32 s = 0; s < 8; s++) sink ^= gl::canon(y[s]) + low8;
-                } else if (valid) {
-#pragma unroll
-                    for (u32 s = 0; s < 8; s++) Br[(u64)(low8 + 256 * (4 * (s >> 1) + 2 * h + (s & 1))) * 8 + v] = gl::canon(y[s]);
-                }
+                for (u32 s = 0; s < 8; s++) Br[(u64)(low8 + 256 * (4 * (s >> 1) + 2 * h + (s & 1))) * 8 + v] = gl::canon(y[s]);
             }
         }
     }
