@@ -347,11 +347,12 @@ int dev_extend_fast(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ncols)
 // columns [first, first + ncols) of row-major matrices with row stride ld (in: n rows, out: n << e rows)
 static int extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld, u64 first, u64 ncols, bool resident);
 int launch_lde_mid_mfma(Ctx* ctx, const LdeParams& p, u32 BT, const u64* gk);   // ntt_lde_mid_mfma.hip
-// XLP_LDE_MFMA=1: the middle pass on the matrix pipe (ntt_lde_mid_mfma.hip) instead of the vector kernel
-static bool lde_mid_mfma_enabled()
+// The middle pass runs on the matrix pipe (ntt_lde_mid_mfma.hip); XLP_LDE_MFMA=0 selects the vector kernel (ntt_lde_mid_kernel.inc) instead
+// (A/B: tools/experiments/lde_mid_mfma_ab.py; the two produce the same bits).
+bool lde_mid_mfma_enabled()
 {
     const char* s = getenv("XLP_LDE_MFMA");
-    return s && s[0] == '1';
+    return !(s && s[0] == '0');
 }
 int dev_extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld, u64 first, u64 ncols)
 {
