@@ -12,7 +12,7 @@ from xlayer_prover_amd import capi
 
 
 def extend(lg, e, ncols, mfma, src=None, steps=0):
-    os.environ["XLP_LDE_MFMA"] = "1" if mfma else "0"
+    os.environ["XLP_LDE_MFMA"] = os.environ["XLP_LDE_TOP_MFMA"] = "1" if mfma else "0"
     n, n_ext = 1 << lg, 1 << (lg + e)
     if src is None:
         src = torch.empty(n * ncols, dtype=torch.int64, device="cuda")
@@ -40,7 +40,7 @@ def extend(lg, e, ncols, mfma, src=None, steps=0):
 
 
 def extend_cm(lg, e, ncols, mfma, src=None, steps=0):
-    os.environ["XLP_LDE_MFMA"] = "1" if mfma else "0"
+    os.environ["XLP_LDE_MFMA"] = os.environ["XLP_LDE_TOP_MFMA"] = "1" if mfma else "0"
     n, n_ext = 1 << lg, 1 << (lg + e)
     if src is None:
         src = torch.empty(n * ncols, dtype=torch.int64, device="cuda")

@@ -28,11 +28,9 @@
 #include "xlp_internal.hpp"
 #include "ntt_common.hpp"
 #include "ntt_lde_common.hpp"
+#include "ntt_mfma_common.hpp"
 
 namespace xlp {
-
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int MM_INV = 0, MM_FWD = 1, MM_R2 = 2, MM_COSET0 = 18, MM_PER_COSET = 17;   // per coset: M_r, then r2'[16]
 constexpr u32 MM_ROWS = 4096 + 256 + 16;                                             // LDS rows of the tile (mm_row)
@@ -45,92 +43,6 @@ struct MidMfma {
     int cz[8], cb[8];                  // accumulator start digits: sum = 0 / = B0 (mod p)
     u32 k0lo, k0hi;                    // 16 B0 mod p
 };
-
-// 1 pad row per 16 and per 256 positions: the three access patterns of the rounds (8 neighbouring groups x 4 columns per half wave) are conflict-free
-__device__ __forceinline__ u32 mm_row(u32 pos) { return pos + (pos >> 4) + (pos >> 8); }
-
-struct RecK { u32 k16, k24, eps; };
-__device__ __forceinline__ RecK rec_consts()
-{
-    RecK k{65536u, 0x1000000u, 0xFFFFFFFFu};
-    asm("" : "+s"(k.k16), "+s"(k.k24), "+s"(k.eps));      // (kept opaque: the compiler would turn the products into shift + 64-bit add chains)
-    return k;
-}
-// digits d[0..7] (each < 2^23) at weights 2^(8m) -> any 64-bit representative of their sum mod p; (a0, a1): + a0 + a1 2^32
-__device__ __forceinline__ u64 recombine(const int* d, const RecK& K, u32 a0, u32 a1)
-{
-    u64 W0 = ((u32)d[1] << 8) + (u32)d[0];
-    W0 = (u64)(u32)d[2] * K.k16 + W0;
-    asm("" : "+v"(W0));                                                             // (or the compiler adds the low digits last: one 64-bit add more)
-    W0 = (u64)(u32)d[3] * K.k24 + W0;                                               // < 2^47
-    u64 W1 = ((u32)d[5] << 8) + (u32)d[4];
-    W1 = (u64)(u32)d[6] * K.k16 + W1;
-    asm("" : "+v"(W1));
-    W1 = (u64)(u32)d[7] * K.k24 + W1;
-    W0 += a0; W1 += a1;
-    const u64 Z = (u64)(u32)(W1 >> 32) * K.eps + W0;                                // W0 + (W1 >> 32) 2^64 (mod p), < 2^49
-    u32 cy;
-    const u32 hi = __builtin_addc((u32)(Z >> 32), (u32)W1, 0u, &cy);                // + (W1 mod 2^32) 2^32; a carry is worth 2^64 = EPS
-    asm("" : "+v"(cy));
-    return (u64)cy * K.eps + gl::pack((u32)Z, hi);
-}
-
-#ifndef XLP_MM_ABL
-#define XLP_MM_ABL 0      // timing experiments only (wrong results): 1 = the matrices are loaded once, 2 = and no global data traffic, 3 = and no twiddle loads
-#endif
-__device__ __forceinline__ void load_mat(v4i (&A)[4][4], const v4i* __restrict__ mat, u32 idx, u32 lane)
-{
-    if (XLP_MM_ABL >= 1 && idx != MM_INV) return;
-    const v4i* m = mat + (size_t)idx * 1024 + lane;
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) A[t][q] = m[(t * 4 + q) * 64];
-}
-
-// 32 DFT16 of a wave: lane (n = lane % 32, h = lane / 32) holds inputs j = 4q + 2h + ee at e[2q + ee] of DFT n and receives outputs
-// k = 4t + 2h + u at y[2t + u].  K0: output 0 (t = 0, u = 0, lanes h = 0) gets + (k0lo, k0hi) (the caller passes zeros in the other lanes).
-// next >= 0: once the last chain has been issued, A is reloaded with matrix `next`.
-template <bool K0>
-__device__ __forceinline__ void dft_op(v4i (&A)[4][4], const u64 (&e)[8], const v16i& C, const RecK& K, u32 k0lo, u32 k0hi, u64 (&y)[8],
-                                       const v4i* __restrict__ mat = nullptr, int next = -1, u32 lane = 0)
-{
-    v4i b[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        b[q].x = (int)((u32)e[2 * q] ^ 0x80808080u); b[q].y = (int)((u32)(e[2 * q] >> 32) ^ 0x80808080u);
-        b[q].z = (int)((u32)e[2 * q + 1] ^ 0x80808080u); b[q].w = (int)((u32)(e[2 * q + 1] >> 32) ^ 0x80808080u);
-    }
-    // two accumulators in turn: the digits of one chain are recombined (vector pipe) while the next chain runs (matrix pipe)
-    v16i acc[2];
-    auto chain = [&](int t) {
-        acc[t & 1] = C;
-#pragma unroll
-        for (int q = 0; q < 4; q++) acc[t & 1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[t][q], b[q], acc[t & 1], 0, 0, 0);
-    };
-    auto rec = [&](int t) {
-        int d[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) d[i] = acc[t & 1][i];
-        y[2 * t] = recombine(d, K, (K0 && t == 0) ? k0lo : 0u, (K0 && t == 0) ? k0hi : 0u);
-        y[2 * t + 1] = recombine(d + 8, K, 0u, 0u);
-    };
-    chain(0);
-    chain(1);
-    __builtin_amdgcn_sched_barrier(0);
-    rec(0);
-    __builtin_amdgcn_sched_barrier(0);
-    chain(2);
-    __builtin_amdgcn_sched_barrier(0);
-    rec(1);
-    __builtin_amdgcn_sched_barrier(0);
-    chain(3);
-    __builtin_amdgcn_sched_barrier(0);
-    if (next >= 0) load_mat(A, mat, (u32)next, lane);        // the next phase's matrix: its latency runs under what is left of this phase
-    __builtin_amdgcn_sched_barrier(0);
-    rec(2);
-    rec(3);
-}
 
 // What the kernel needs to know about the scratch matrices, for both layouts:
 //   row-major (ntt_lde.hip, lde_sidx): groups of 8 columns, every group a [2^L][8] matrix; a workgroup's 4 columns are half of a 64-byte line
@@ -156,7 +68,9 @@ struct MidMap {
     static __device__ __forceinline__ u32 lds(u32 pos, u32 v) { return CM ? v * MM_ROWS + mm_row(pos) : mm_row(pos) * 4 + v; }
 };
 
-template <bool CM>
+// RES: the RESIDENT form (ntt_lde_common.hpp: the ALU ceiling of bench.py's headline): the same kernel with its global DATA traffic removed -- a word of
+// the tile is made from its index, an output word is folded into a checksum; matrices and twiddle tables are read as in the product.
+template <bool CM, bool RES = false>
 __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma(const MidIO p, const MidMfma t, u32 BT)
 {
     typedef MidMap<CM> Map;
@@ -196,7 +110,7 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma(const MidIO p, const 
 #pragma unroll
             for (u32 s = 0; s < 8; s++) {
                 const u32 j = 4 * (s >> 1) + 2 * h + (s & 1);
-                e[i][s] = XLP_MM_ABL >= 2 ? res_word((u64)(low8 + 256 * j) * 8 + v + hi) : *a_word(low8 + 256 * j, v);
+                e[i][s] = (RES || XLP_MM_ABL >= 2) ? res_word((u64)(low8 + 256 * j) * 8 + v + hi) : *a_word(low8 + 256 * j, v);
             }
         }
 #pragma unroll
@@ -278,7 +192,7 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma(const MidIO p, const 
 #pragma unroll
             for (u32 s = 0; s < 8; s++) e[s] = sm[Map::lds(low8 + 256 * (4 * (s >> 1) + 2 * h + (s & 1)), v)];
             dft_op<true>(A, e, Cz, K, k0lo, k0hi, y, t.mat, (i == 3 && r + 1 < ncos) ? (int)(mr + MM_PER_COSET) : -1, lane);
-            if (XLP_MM_ABL >= 2) {
+            if (RES || XLP_MM_ABL >= 2) {
 #pragma unroll
                 for (u32 s = 0; s < 8; s++) sink ^= gl::canon(y[s]) + low8;
             } else if (c + v < p.wc) {
@@ -287,61 +201,11 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma(const MidIO p, const 
             }
         }
     }
-    if (XLP_MM_ABL >= 2) res_sink((u64*)p.A, sink);
+    if (RES || XLP_MM_ABL >= 2) res_sink((u64*)p.A, sink);
     (void)BT; (void)sink;
 }
 
 // ----------------------------------------------------------------- host: matrices, offsets, tables
-namespace {
-typedef unsigned __int128 u128;
-typedef __int128 i128;
-
-// balanced signed byte digits (weights 2^(8m), m < 8) of the canonical constant c, or of c - p
-bool balanced(i128 v, int8_t d[8])
-{
-    for (int m = 0; m < 8; m++) {
-        int dm = (int)(((v % 256) + 256) % 256);
-        if (dm >= 128) dm -= 256;
-        d[m] = (int8_t)dm;
-        v = (v - dm) / 256;
-    }
-    return v == 0;
-}
-void signed_digits(u64 c, int8_t d[8])
-{
-    if (c > hgl::P / 2) { if (balanced((i128)c - (i128)hgl::P, d)) return; if (balanced((i128)c, d)) return; }
-    else { if (balanced((i128)c, d)) return; if (balanced((i128)c - (i128)hgl::P, d)) return; }
-    abort();
-}
-// the int8 image of a 16 x 16 field matrix in the lane layout dft_op() reads (same layout as tools/ubench_dft16_mfma.hip)
-void emit_matrix(const u64 M[16][16], uint8_t* out)
-{
-    static thread_local int8_t dig[16][16][8][8];      // [k][j][l][m]
-    for (int k = 0; k < 16; k++) for (int j = 0; j < 16; j++) {
-        u64 c = M[k][j];
-        for (int l = 0; l < 8; l++) { signed_digits(c, dig[k][j][l]); c = hgl::mul(c, 256); }
-    }
-    for (int tau = 0; tau < 4; tau++) for (int q = 0; q < 4; q++) for (int lane = 0; lane < 64; lane++) {
-        const int rho = lane & 31, h = lane >> 5;
-        const int u = rho >> 4, mhi = (rho >> 3) & 1, hh = (rho >> 2) & 1, mlo = rho & 3;
-        const int k = 4 * tau + 2 * hh + u, m = 4 * mhi + mlo;
-        uint8_t* o = out + (((size_t)(tau * 4 + q) * 64 + lane) * 16);
-        for (int e = 0; e < 2; e++) for (int l = 0; l < 8; l++) o[8 * e + l] = (uint8_t)dig[k][4 * q + 2 * h + e][l][m];
-    }
-}
-// digits >= 2^21 whose weighted sum is off (mod p)
-void bias_digits(u64 off, int out[8])
-{
-    const u128 B = (u128)1 << 21;
-    u128 base = 0;
-    for (int m = 0; m < 8; m++) base += B << (8 * m);
-    u128 tt = (base - off + hgl::P - 1) / hgl::P;
-    u128 R = tt * hgl::P + off - base;
-    for (int m = 0; m < 7; m++) { out[m] = (int)(B + (R & 255)); R >>= 8; }
-    out[7] = (int)(B + R);
-}
-}  // namespace
-
 static int mid_mfma_tables(Ctx* ctx, u32 BT, u32 e, const u64* gk, MidMfma* out)
 {
     const u32 ncos = 1u << e;
@@ -403,32 +267,32 @@ static int mid_mfma_tables(Ctx* ctx, u32 BT, u32 e, const u64* gk, MidMfma* out)
 }
 
 // gk[r] = g_r^(2^BT), the coset generators of extend_fast_cols / dev_extend_cm_fast
-template <bool CM>
+template <bool CM, bool RES>
 static int launch_mid_mfma(Ctx* ctx, const MidIO& io, u32 BT, const u64* gk)
 {
     MidMfma t{};
     if (mid_mfma_tables(ctx, BT, io.e, gk, &t)) return -1;
     static bool attr = false;
     if (!attr) {
-        XLP_HIP(hipFuncSetAttribute((const void*)lde_mid_mfma<CM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        XLP_HIP(hipFuncSetAttribute((const void*)lde_mid_mfma<CM, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     const u32 ncc = (io.wc + 3) / 4;
     const u64 grid = (u64)ncc << BT;
     const size_t lds = (size_t)MM_ROWS * 4 * sizeof(u64);
-    hipLaunchKernelGGL(lde_mid_mfma<CM>, dim3((unsigned)grid), dim3(MM_THREADS), lds, ctx->stream, io, t, BT);
+    hipLaunchKernelGGL((lde_mid_mfma<CM, RES>), dim3((unsigned)grid), dim3(MM_THREADS), lds, ctx->stream, io, t, BT);
     XLP_HIP(hipGetLastError());
     return 0;
 }
-int launch_lde_mid_mfma(Ctx* ctx, const LdeParams& p, u32 BT, const u64* gk)
+int launch_lde_mid_mfma(Ctx* ctx, const LdeParams& p, u32 BT, const u64* gk, bool resident)
 {
     const MidIO io{p.A, p.B, p.wc, p.L, p.e, p.twi_12};
-    return launch_mid_mfma<false>(ctx, io, BT, gk);
+    return resident ? launch_mid_mfma<false, true>(ctx, io, BT, gk) : launch_mid_mfma<false, false>(ctx, io, BT, gk);
 }
 int launch_lde_cm_mid_mfma(Ctx* ctx, const u64* A, u64* B, u32 wc, u32 L, u32 e, const u64* twi_12, u32 BT, const u64* gk)
 {
     const MidIO io{A, B, wc, L, e, twi_12};
-    return launch_mid_mfma<true>(ctx, io, BT, gk);
+    return launch_mid_mfma<true, false>(ctx, io, BT, gk);
 }
 
 }  // namespace xlp
