@@ -25,7 +25,7 @@ NCOLS = 8
 EXT_BITS = 1
 SEED = 0x5EED0002
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-LDE_KERNELS = ["xlp::lde_top_dif<11>", "xlp::lde_mid", "xlp::lde_top_dit<11>"]   # one launch of each per extendPol
+LDE_KERNELS = ["xlp::lde_top_dif<11>", "xlp::lde_mid_mfma<false>", "xlp::lde_top_dit<11>"]   # one launch of each per extendPol (the middle pass: the matrix-pipe kernel, round 5)
 
 
 def cpu_baseline(log_n, ncols, budget_s=20.0):
@@ -792,12 +792,15 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 4), "hbm_frac": round(achieved / HBM_PEAK_GBS, 4), "alu_ceiling": alu_ceiling,
             "traffic": traffic, "traffic_stale": traffic_stale, "counters": counters_file,
             "achieved_from": "sum of the three kernels' average launch durations over 3 event-instrumented steps (the timed region's ms_per_step is the unbracketed figure)",
-            "kernel": "xlp::lde_mid (dominant) + lde_top_dif + lde_top_dit = one extendPol",
+            "kernel": "xlp::lde_mid_mfma + lde_top_dit (the two largest) + lde_top_dif = one extendPol",
             "launches_per_step": 3,
             "avg_launch_ms": {k: round(v, 4) for k, v in zip(LDE_KERNELS, per_kernel_ms)} if kern_cnt else None,
             "alg_bytes_per_step": alg_bytes_lde,
             "note": "bound by integer vector issue, not by HBM (Goldilocks mul = 4 v_mad_u64_u32 + carry chains on a 32-bit VALU): achieved / peak / frac are the HBM figures "
-                    "the metric asks for (algorithmic bytes / kernel time / 8 TB/s), alu_ceiling.frac is how close the kernels are to what bounds them",
+                    "the metric asks for (algorithmic bytes / kernel time / 8 TB/s), alu_ceiling.frac is how close the kernels are to what bounds them.  Since round 5 the middle pass "
+                    "does its 16-point DFTs on the matrix pipe (v_mfma_i32_32x32x32_i8 over byte limbs, in-tile twiddles folded into per-wave matrices: csrc/ntt_lde_mid_mfma.hip); what "
+                    "is left on the vector pipe there is the recombination of digit sums and 3 of the former 8 twiddle multiplications per element; the two top passes stay vector kernels "
+                    "(their matrix form measured no faster: 64-byte HBM segments bound them)",
             "valu_issue": valu_issue,
         }
         line = {

@@ -18,8 +18,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from xlayer_prover_amd.srchash import csrc_hash      # noqa: E402
 
-PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU"]]
-KERNELS = {"lde_cm_top_dif": "lde_cm_top_dif", "lde_cm_mid": "lde_cm_mid", "lde_cm_top_dit": "lde_cm_top_dit", "linear_hash_absorb_cm_kernel": "linear_hash_cm",
+PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU"],
+          ["SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY"]]
+KERNELS = {"lde_mid_mfma<true": "lde_cm_mid", "lde_mid_mfma<false": "lde_mid",        # the matrix-pipe middle pass of both layouts (round 5) under the names of the kernels it replaced
+           "lde_cm_top_dif": "lde_cm_top_dif", "lde_cm_mid": "lde_cm_mid", "lde_cm_top_dit": "lde_cm_top_dit", "linear_hash_absorb_cm_kernel": "linear_hash_cm",
            "lde_top_dif": "lde_top_dif", "lde_mid": "lde_mid", "lde_top_dit": "lde_top_dit", "linear_hash_kernel": "linear_hash",
            "merkle_level_kernel": "merkle_level", "copy_canon_kernel": "calibration_copy"}
 
@@ -75,7 +77,8 @@ def main():
                        "applied": "FETCH_SIZE x 2, WRITE_SIZE x 1 (KiB), per MI355X_MICROARCH.md; the measured factors are the calibration copy's (1 GiB each way, 8 B per lane)"},
         "per_kernel": per,
         "lde": {"workload": "extendPol 2^23 x 8 -> 2^24 x 8", "hbm_bytes_per_lde": sum(x["hbm_bytes"] for x in lde),
-                "algorithmic_bytes_per_lde": 8 * n * ncols * 3, "valu_wave_instructions_per_lde": sum(x["SQ_INSTS_VALU"] for x in lde)},
+                "algorithmic_bytes_per_lde": 8 * n * ncols * 3, "valu_wave_instructions_per_lde": sum(x["SQ_INSTS_VALU"] for x in lde),
+                "mfma_wave_instructions_per_lde": sum(x.get("SQ_INSTS_MFMA", 0) for x in lde), "mfma_busy_cycles_per_lde": sum(x.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) for x in lde)},
         "merkle": {"workload": "merkletree 2^20 x 751", "leaf_permutations": perms_leaf, "hbm_bytes_linear_hash": per["linear_hash"]["hbm_bytes"],
                    "algorithmic_bytes_linear_hash": 8 * h * w + 32 * h,
                    "valu_wave_instructions_linear_hash": per["linear_hash"]["SQ_INSTS_VALU"],

@@ -19,6 +19,9 @@ namespace xlp {
 
 constexpr int MT_F16 = 0, MT_F8 = 1, MT_T2 = 2, MT_COUNT = 18;
 constexpr u32 MT_THREADS = 512;
+#ifndef XLP_MT_R3U
+#define XLP_MT_R3U 1
+#endif
 #ifndef XLP_MT_ABL
 #define XLP_MT_ABL 0      // timing experiments only (wrong results): bit 0 = no global loads, bit 1 = no global stores
 #endif
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(MT_THREADS) void lde_top_dit_mfma(const LdeParams p
     }
     __syncthreads();
     // ---- r3: forward DFT8 over digit 2 (positions low8 + 256 j), LDS -> rows (((tpos << 12) | lo) << e) | r of the output
-#pragma unroll 1
+#pragma unroll XLP_MT_R3U
     for (u32 i = 0; i < 8; i++) {
         const u32 low8 = 4 * (wave + 8 * i) + nb;
         u64 e[4], z[4];

@@ -347,6 +347,9 @@ int dev_extend_fast(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ncols)
 // columns [first, first + ncols) of row-major matrices with row stride ld (in: n rows, out: n << e rows)
 static int extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64 ld, u64 first, u64 ncols, bool resident);
 int launch_lde_mid_mfma(Ctx* ctx, const LdeParams& p, u32 BT, const u64* gk, bool resident);   // ntt_lde_mid_mfma.hip
+#ifdef XLP_EXP_TOP_DIT_MFMA      // experiment builds only (tools/experiments/ntt_lde_top_dit_mfma.hip linked in): lde_top_dit on the matrix pipe at N = 2^23
+int launch_lde_top_dit_mfma(Ctx* ctx, const LdeParams& p, u32 BT);
+#endif
 // The middle pass runs on the matrix pipe (ntt_lde_mid_mfma.hip); XLP_LDE_MFMA=0 selects the vector kernel (ntt_lde_mid_kernel.inc) instead
 // (A/B: tools/experiments/lde_mid_mfma_ab.py; the two produce the same bits).
 bool lde_mid_mfma_enabled()
@@ -418,6 +421,9 @@ static int extend_fast_cols(Ctx* ctx, u64* out, const u64* in, u32 L, u32 e, u64
         if (lde_mid_mfma_enabled()) { if (launch_lde_mid_mfma(ctx, p, BT, gks, resident)) return -1; }
         else if (launch_lde_mid(ctx, p, BT, resident)) return -1;
         if (ctx->profile) XLP_HIP(hipEventRecord(ev[2], ctx->stream));
+#ifdef XLP_EXP_TOP_DIT_MFMA
+        if (!resident && BT == 11) { if (launch_lde_top_dit_mfma(ctx, p, BT)) return -1; } else
+#endif
         if (resident ? (BT == 11 ? launch_top<11, true>(ctx, p, true) : launch_top<10, true>(ctx, p, true)) : launch_top_bt(ctx, p, BT, true)) return -1;
         if (ctx->profile) XLP_HIP(hipEventRecord(ev[3], ctx->stream));
     }

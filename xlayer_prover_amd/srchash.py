@@ -6,7 +6,7 @@ import hashlib
 import os
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-MEASURED = ("gl_field.hpp", "ntt.hip", "ntt_common.hpp", "ntt_lde.hip", "ntt_lde_mid.hip", "ntt_lde_mid_kernel.inc", "ntt_lde_common.hpp", "ntt_lde_cm.hip", "ntt_lde_cm_mid.hip", "ntt_lde_cm_common.hpp",
+MEASURED = ("gl_field.hpp", "ntt.hip", "ntt_common.hpp", "ntt_lde.hip", "ntt_lde_mid.hip", "ntt_lde_mid_kernel.inc", "ntt_lde_mid_mfma.hip", "ntt_mfma_common.hpp", "ntt_lde_common.hpp", "ntt_lde_cm.hip", "ntt_lde_cm_mid.hip", "ntt_lde_cm_common.hpp",
             "poseidon.hip", "poseidon_constants.inc", "poseidon_fused.inc")
 
 
