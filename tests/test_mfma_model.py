@@ -199,3 +199,55 @@ def test_round_structure_of_the_matrix_kernel_equals_the_vector_kernel():
     a = [rng.randrange(P) for _ in range(4096)]
     G = rng.randrange(1, P)
     assert vector_kernel_rounds(a, G) == matrix_kernel_rounds(a, G)
+
+
+def matrix_kernel_rounds_all_folded(a, G):
+    """lde_mid_mfma with EVERY in-tile factor folded into a matrix that one wave owns (no vector multiplication left):
+       r1  by a = high nibble of low8:  diag_k(w256^-(k a)) F^-1            (the other half of the twiddle, w4096^-(k b), waits)
+       r2  by b = low4:                 diag_k(w256^-(k b)) F^-1
+       M   by d2:                       diag_k(w4096^(d2 k)) F diag(G^(256 i)) F^-1 diag_j(w4096^-(d2 j))   (takes the waiting half in, puts r3's k0-half out)
+       r2' by k0 = low4:                F diag_j(G^(16 j) w256^(j k0))
+       r3' by k1 = high nibble of low8: F diag_j(G^j w256^(j k1))"""
+    R1 = [[[twi[(k * aa) << 4] * w16m[(j * k) % 16] % P for j in range(16)] for k in range(16)] for aa in range(16)]
+    b = [0] * 4096
+    for low in range(256):
+        aa = low >> 4
+        for k in range(16):
+            b[low + 256 * k] = sum(R1[aa][k][j] * a[low + 256 * j] for j in range(16)) % P
+    R2 = [[[twi[(k * low) << 4] * w16m[(j * k) % 16] % P for j in range(16)] for k in range(16)] for low in range(16)]
+    c = [0] * 4096
+    for high in range(16):
+        for low in range(16):
+            base = (high << 8) | low
+            for k in range(16):
+                c[base + 16 * k] = sum(R2[low][k][j] * b[base + 16 * j] for j in range(16)) % P
+    hk = [pow(G, 256 * j, P) for j in range(16)]
+    M0 = [[sum(w16p[(i * k) % 16] * hk[i] % P * w16m[(i * j) % 16] for i in range(16)) % P for j in range(16)] for k in range(16)]
+    d = [0] * 4096
+    for d2 in range(16):
+        M = [[twf[d2 * k] * M0[k][j] % P * twi[d2 * j] % P for j in range(16)] for k in range(16)]
+        for d1 in range(16):
+            base = 256 * d2 + 16 * d1
+            for k in range(16):
+                d[base + k] = sum(M[k][j] * c[base + j] for j in range(16)) % P
+    R2p = [[[w16p[(j * k) % 16] * pow(G, 16 * j, P) % P * twf[(j * low) << 4] % P for j in range(16)] for k in range(16)] for low in range(16)]
+    e = [0] * 4096
+    for high in range(16):
+        for low in range(16):
+            base = (high << 8) | low
+            for k in range(16):
+                e[base + 16 * k] = sum(R2p[low][k][j] * d[base + 16 * j] for j in range(16)) % P
+    R3 = [[[w16p[(j * k) % 16] * pow(G, j, P) % P * twf[(j * k1) << 4] % P for j in range(16)] for k in range(16)] for k1 in range(16)]
+    out = [0] * 4096
+    for low in range(256):
+        k1 = low >> 4
+        for k in range(16):
+            out[low + 256 * k] = sum(R3[k1][k][j] * e[low + 256 * j] for j in range(16)) % P
+    return out
+
+
+def test_round_structure_with_every_factor_folded_equals_the_vector_kernel():
+    rng = random.Random(4)
+    a = [rng.randrange(P) for _ in range(4096)]
+    G = rng.randrange(1, P)
+    assert vector_kernel_rounds(a, G) == matrix_kernel_rounds_all_folded(a, G)

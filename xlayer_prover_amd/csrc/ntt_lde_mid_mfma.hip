@@ -33,12 +33,15 @@
 namespace xlp {
 
 constexpr int MM_INV = 0, MM_FWD = 1, MM_R2 = 2, MM_COSET0 = 18, MM_PER_COSET = 17;   // per coset: M_r, then r2'[16]
+// the all-folded form (lde_mid_mfma_folded): behind the matrices above, per coset M[d2] (16), r3'[k1] (16); its r2' matrices are the ones above
+constexpr int MF_M = 0, MF_R3 = 16, MF_PER_COSET = 32;
 constexpr u32 MM_ROWS = 4096 + 256 + 16;                                             // LDS rows of the tile (mm_row)
 constexpr u32 MM_THREADS = 512;
 
 
 struct MidMfma {
     const v4i* mat;                    // [matrix][tile 4][k chunk 4][lane 64] x 16 bytes
+    u32 folded0;                       // index of the first matrix of the all-folded form (coset 0's M[0])
     const u64* t3[LDE_MAX_COSETS];     // t3[r][low8 + 256 j] = G_r^j w4096^(j low8): what input j of r3' at low8 is multiplied by (applied when r2' stores it)
     int cz[8], cb[8];                  // accumulator start digits: sum = 0 / = B0 (mod p)
     u32 k0lo, k0hi;                    // 16 B0 mod p
@@ -206,12 +209,151 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma(const MidIO p, const 
 }
 
 // ----------------------------------------------------------------- host: matrices, offsets, tables
+// ALL-FOLDED form: every in-tile factor sits in a matrix that one wave owns -- no vector multiplication is left in the middle pass.
+//     r1  wave-owned by a = high nibble of low8:  diag_k(w256^-(k a)) F^-1   (= the r2 matrix of the same index); the other half of that
+//         twiddle, w4096^-(k b), is constant over the next round's DFTs and waits until M
+//     r2  by b = low4:                            diag_k(w256^-(k b)) F^-1
+//     M   by d2:      diag_k(w4096^(d2 k)) F diag(G^(256 i)) F^-1 diag_j(w4096^-(d2 j))    (takes the waiting half in, hands r3' its k0-half)
+//     r2' by k0 = low4:                           F diag_j(G^(16 j) w256^(j k0))
+//     r3' by k1 = high nibble of low8:            F diag_j(G^j w256^(j k1))
+// (tests/test_mfma_model.py restates this structure and compares it with the vector kernel's.)  Every round is a "W" round: a wave's two values of the
+// owning digit x 2 chains; only r1 sees raw words (+ 16 B0 at output 0: its row scale is 1 in row 0), every other round is fed by a matrix round (+ B0).
+template <bool CM, bool RES = false>
+__global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma_folded(const MidIO p, const MidMfma t, u32 BT)
+{
+    typedef MidMap<CM> Map;
+    extern __shared__ u64 sm[];
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 h = lane >> 5;
+    const u32 ncc = (p.wc + 3) / 4;
+    const u32 tile = xcd_tile();
+    const u32 cc = tile % ncc, hi = tile / ncc;
+    const u32 c = cc * 4;
+    const u64 rm_off = (((u64)(cc >> 1) << p.L) << 3) + (cc & 1) * 4 + ((u64)hi << 12) * 8;     // (lde_sidx)
+    auto clampv = [&](u32 v) -> u32 { return c + v < p.wc ? v : p.wc - 1 - c; };
+    auto a_word = [&](u32 pos, u32 v) -> const u64* {
+        return CM ? p.A + ((u64)(c + clampv(v)) << p.L) + (((u64)hi << 12) | pos) : p.A + rm_off + (u64)pos * 8 + clampv(v);
+    };
+    auto b_word = [&](u32 r, u32 pos, u32 v) -> u64* {
+        return CM ? p.B + (((u64)r * p.wc + c + v) << p.L) + (((u64)hi << 12) | pos) : p.B + (u64)r * lde_swords(p.wc, p.L) + rm_off + (u64)pos * 8 + v;
+    };
+    const RecK K = rec_consts();
+    const u32 k0lo = h == 0 ? t.k0lo : 0u, k0hi = h == 0 ? t.k0hi : 0u;
+    const u32 ncos = 1u << p.e;
+    v16i Cz, Cb;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { Cz[i] = t.cz[i & 7]; Cb[i] = t.cb[i & 7]; }
+    v4i A[4][4];
+    u64 y[8];
+    u64 sink = 0;
+    // chain (s2, i) of a W round: the wave's owning digit w = wave + 8 s2 (r1 and r3' take them in this order, r2 and r2' in the other: the matrix
+    // a round ends with is the one the next round starts with when both are indexed alike), the other digit x = whigh(i), column wcol(i)
+    // ---- r1: inverse DFT over digit 2 (positions 256 j + 16 a + b), x w256^-(k a); global -> LDS
+    load_mat(A, t.mat, MM_R2 + wave, lane);
+    {
+        u64 e[4][8];
+#pragma unroll
+        for (u32 o = 0; o < 4; o++) {
+            const u32 low8 = 16 * (wave + 8 * (o >> 1)) + Map::whigh(o & 1, lane), v = Map::wcol(o & 1, lane);
+#pragma unroll
+            for (u32 s = 0; s < 8; s++) {
+                const u32 j = 4 * (s >> 1) + 2 * h + (s & 1);
+                e[o][s] = RES ? res_word((u64)(low8 + 256 * j) * 8 + v + hi) : *a_word(low8 + 256 * j, v);
+            }
+        }
+#pragma unroll
+        for (u32 o = 0; o < 4; o++) {
+            const u32 low8 = 16 * (wave + 8 * (o >> 1)) + Map::whigh(o & 1, lane), v = Map::wcol(o & 1, lane);
+            dft_op<true>(A, e[o], Cb, K, k0lo, k0hi, y, t.mat, o == 1 ? (int)(MM_R2 + wave + 8) : -1, lane);     // (after o = 3 the matrix stays: r2 starts with it)
+#pragma unroll
+            for (u32 s = 0; s < 8; s++) sm[Map::lds(low8 + 256 * (4 * (s >> 1) + 2 * h + (s & 1)), v)] = y[s];
+        }
+    }
+    __syncthreads();
+    // ---- r2: inverse DFT over digit 1 (positions 256 d2 + 16 j + b) x w256^-(k b), in place; low4 = wave + 8 first
+#pragma unroll 1
+    for (u32 s2 = 0; s2 < 2; s2++) {
+        const u32 low4 = wave + 8 * (1 - s2);
+#pragma unroll
+        for (u32 i = 0; i < 2; i++) {
+            const u32 base = 256 * Map::whigh(i, lane) + low4, v = Map::wcol(i, lane);
+            u64 e[8];
+#pragma unroll
+            for (u32 s = 0; s < 8; s++) e[s] = sm[Map::lds(base + 16 * (4 * (s >> 1) + 2 * h + (s & 1)), v)];
+            dft_op<false>(A, e, Cb, K, 0u, 0u, y, t.mat, i == 1 ? (int)(s2 == 0 ? MM_R2 + wave : t.folded0 + MF_M + wave) : -1, lane);
+#pragma unroll
+            for (u32 s = 0; s < 8; s++) sm[Map::lds(base + 16 * (4 * (s >> 1) + 2 * h + (s & 1)), v)] = y[s];
+        }
+    }
+    __syncthreads();
+    // ---- the inputs of the digit-0 round (d2 = the wave's, d1 = whigh) stay in registers (+ B0) for every coset
+    u64 X[4][8];
+#pragma unroll
+    for (u32 o = 0; o < 4; o++) {
+        const u32 base = 256 * (wave + 8 * (o >> 1)) + 16 * Map::whigh(o & 1, lane), v = Map::wcol(o & 1, lane);
+#pragma unroll
+        for (u32 s = 0; s < 8; s++) X[o][s] = sm[Map::lds(base + 4 * (s >> 1) + 2 * h + (s & 1), v)];
+    }
+    for (u32 r = 0; r < ncos; r++) {
+        const u32 mf = t.folded0 + MF_PER_COSET * r, mr2p = MM_COSET0 + MM_PER_COSET * r + 1;
+        // ---- M: over digit 0 (positions 256 d2 + 16 d1 + j), the wave's d2 = wave, wave + 8
+        __syncthreads();                                                             // the tile's previous readers are done
+#pragma unroll
+        for (u32 o = 0; o < 4; o++) {
+            const u32 base = 256 * (wave + 8 * (o >> 1)) + 16 * Map::whigh(o & 1, lane), v = Map::wcol(o & 1, lane);
+            dft_op<false>(A, X[o], Cb, K, 0u, 0u, y, t.mat, o == 1 ? (int)(mf + MF_M + wave + 8) : o == 3 ? (int)(mr2p + wave + 8) : -1, lane);
+#pragma unroll
+            for (u32 s = 0; s < 8; s++) sm[Map::lds(base + 4 * (s >> 1) + 2 * h + (s & 1), v)] = y[s];
+        }
+        __syncthreads();
+        // ---- r2': x G^(16 j) w256^(j k0), forward DFT over digit 1, in place; k0 = wave + 8 first
+#pragma unroll 1
+        for (u32 s2 = 0; s2 < 2; s2++) {
+            const u32 low4 = wave + 8 * (1 - s2);
+#pragma unroll
+            for (u32 i = 0; i < 2; i++) {
+                const u32 base = 256 * Map::whigh(i, lane) + low4, v = Map::wcol(i, lane);
+                u64 e[8];
+#pragma unroll
+                for (u32 s = 0; s < 8; s++) e[s] = sm[Map::lds(base + 16 * (4 * (s >> 1) + 2 * h + (s & 1)), v)];
+                dft_op<false>(A, e, Cb, K, 0u, 0u, y, t.mat, i == 1 ? (int)(s2 == 0 ? mr2p + wave : mf + MF_R3 + wave) : -1, lane);
+#pragma unroll
+                for (u32 s = 0; s < 8; s++) sm[Map::lds(base + 16 * (4 * (s >> 1) + 2 * h + (s & 1)), v)] = y[s];
+            }
+        }
+        __syncthreads();
+        // ---- r3': x G^j w256^(j k1), forward DFT over digit 2 (positions 256 j + 16 k1 + k0), LDS -> B_r; k1 = wave, wave + 8
+#pragma unroll 1
+        for (u32 s2 = 0; s2 < 2; s2++) {
+#pragma unroll
+            for (u32 i = 0; i < 2; i++) {
+                const u32 low8 = 16 * (wave + 8 * s2) + Map::whigh(i, lane), v = Map::wcol(i, lane);
+                u64 e[8];
+#pragma unroll
+                for (u32 s = 0; s < 8; s++) e[s] = sm[Map::lds(low8 + 256 * (4 * (s >> 1) + 2 * h + (s & 1)), v)];
+                dft_op<false>(A, e, Cz, K, 0u, 0u, y, t.mat,
+                              i == 1 ? (int)(s2 == 0 ? mf + MF_R3 + wave + 8 : (r + 1 < ncos ? mf + MF_PER_COSET + MF_M + wave : -1)) : -1, lane);
+                if (RES) {
+#pragma unroll
+                    for (u32 s = 0; s < 8; s++) sink ^= gl::canon(y[s]) + low8;
+                } else if (c + v < p.wc) {
+#pragma unroll
+                    for (u32 s = 0; s < 8; s++) *b_word(r, low8 + 256 * (4 * (s >> 1) + 2 * h + (s & 1)), v) = gl::canon(y[s]);
+                }
+            }
+        }
+    }
+    if (RES) res_sink((u64*)p.A, sink);
+    (void)BT; (void)sink;
+}
+
 static int mid_mfma_tables(Ctx* ctx, u32 BT, u32 e, const u64* gk, MidMfma* out)
 {
     const u32 ncos = 1u << e;
-    const size_t nmat = MM_COSET0 + (size_t)MM_PER_COSET * ncos;
+    const size_t folded0 = MM_COSET0 + (size_t)MM_PER_COSET * ncos;
+    const size_t nmat = folded0 + (size_t)MF_PER_COSET * ncos;
     const size_t mat_bytes = nmat * 16384, t3_bytes = (size_t)ncos * 4096 * 8;
-    auto key = std::make_tuple(300u + 32 * e + BT, gk[0], (u64)3);
+    auto key = std::make_tuple(300u + 32 * e + BT, gk[0], (u64)4);
     auto it = ctx->tables.find(key);
     if (it == ctx->tables.end()) {
         u64* d = nullptr;
@@ -243,6 +385,23 @@ static int mid_mfma_tables(Ctx* ctx, u32 BT, u32 e, const u64* gk, MidMfma* out)
                         M[k][j] = hgl::mul(hgl::mul(hgl::pow(w16, (u64)(j * k)), hgl::pow(g16, (u64)j)), hgl::pow(w12, (u64)(j * low) << 4));
                     emit_matrix(M, &hst[(size_t)(MM_COSET0 + MM_PER_COSET * r + 1 + low) * 16384]);
                 }
+                // the all-folded form: M[d2] = diag_k(w4096^(d2 k)) (F diag(G^(256 i)) F^-1) diag_j(w4096^-(d2 j)), r3'[k1] = F diag_j(G^j w256^(j k1))
+                u64 M0[16][16];
+                for (int k = 0; k < 16; k++) for (int j = 0; j < 16; j++) {
+                    u64 sacc = 0;
+                    for (int i = 0; i < 16; i++) sacc = hgl::add(sacc, hgl::mul(hgl::mul(hgl::pow(w16, (u64)(i * k)), hgl::pow(g256, (u64)i)), hgl::pow(w16i, (u64)(i * j))));
+                    M0[k][j] = sacc;
+                }
+                for (int d2 = 0; d2 < 16; d2++) {
+                    for (int k = 0; k < 16; k++) for (int j = 0; j < 16; j++)
+                        M[k][j] = hgl::mul(hgl::mul(hgl::pow(w12, (u64)(d2 * k)), M0[k][j]), hgl::pow(w12i, (u64)(d2 * j)));
+                    emit_matrix(M, &hst[(size_t)(folded0 + MF_PER_COSET * r + MF_M + d2) * 16384]);
+                }
+                for (int k1 = 0; k1 < 16; k1++) {
+                    for (int k = 0; k < 16; k++) for (int j = 0; j < 16; j++)
+                        M[k][j] = hgl::mul(hgl::mul(hgl::pow(w16, (u64)(j * k)), hgl::pow(G, (u64)j)), hgl::pow(w12, (u64)(j * k1) << 4));
+                    emit_matrix(M, &hst[(size_t)(folded0 + MF_PER_COSET * r + MF_R3 + k1) * 16384]);
+                }
                 u64* t3 = (u64*)&hst[mat_bytes + (size_t)r * 4096 * 8];
                 for (u32 j = 0; j < 16; j++) {
                     const u64 gj = hgl::pow(G, j), wj = hgl::pow(w12, j);
@@ -257,6 +416,7 @@ static int mid_mfma_tables(Ctx* ctx, u32 BT, u32 e, const u64* gk, MidMfma* out)
     }
     const uint8_t* base = (const uint8_t*)it->second;
     out->mat = (const v4i*)base;
+    out->folded0 = (u32)folded0;
     for (u32 r = 0; r < ncos; r++) out->t3[r] = (const u64*)(base + mat_bytes) + (size_t)r * 4096;
     const u64 B0 = 0x8080808080808080ull % hgl::P;
     bias_digits(0, out->cz);
@@ -280,7 +440,16 @@ static int launch_mid_mfma(Ctx* ctx, const MidIO& io, u32 BT, const u64* gk)
     const u32 ncc = (io.wc + 3) / 4;
     const u64 grid = (u64)ncc << BT;
     const size_t lds = (size_t)MM_ROWS * 4 * sizeof(u64);
-    hipLaunchKernelGGL((lde_mid_mfma<CM, RES>), dim3((unsigned)grid), dim3(MM_THREADS), lds, ctx->stream, io, t, BT);
+    const char* form = getenv("XLP_LDE_MFMA");
+    const bool folded = form && form[0] == '2';
+    if (folded) {
+        static bool attr2 = false;
+        if (!attr2) {
+            XLP_HIP(hipFuncSetAttribute((const void*)lde_mid_mfma_folded<CM, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr2 = true;
+        }
+        hipLaunchKernelGGL((lde_mid_mfma_folded<CM, RES>), dim3((unsigned)grid), dim3(MM_THREADS), lds, ctx->stream, io, t, BT);
+    } else hipLaunchKernelGGL((lde_mid_mfma<CM, RES>), dim3((unsigned)grid), dim3(MM_THREADS), lds, ctx->stream, io, t, BT);
     XLP_HIP(hipGetLastError());
     return 0;
 }
