@@ -2,7 +2,7 @@
 plain integers, no GPU, no library call.
   1. A DFT16 (any 16 x 16 field matrix) as an int8 matrix product over byte limbs: signed digits of the constants, the xor-0x80 offset (k0), the
      accumulator start digits (bias = a multiple of p, or B0 more), the recombination of eight digit sums -- reproduces the field result.
-  2. The round structure of lde_mid_mfma (r1, r2, M_r, r2', r3' with their folded factors) equals the round structure of the vector kernel
+  2. The round structure of lde_mid_mfma (r1, r2, M, r2', r3': every in-tile factor folded into wave-owned matrices) equals the round structure of the vector kernel
      (ntt_lde_mid_kernel.inc: three inverse rounds, coset scale, three forward rounds with tw2 / twf_12) on a random tile.
 The GPU side of the same statement is tests/test_lde_mfma.py (both kernels, same bits)."""
 import random
@@ -158,51 +158,7 @@ def vector_kernel_rounds(a, G):
 
 
 def matrix_kernel_rounds(a, G):
-    hk = [pow(G, 256 * j, P) for j in range(16)]
-    b = [0] * 4096
-    for low in range(256):
-        for k in range(16):
-            b[low + 256 * k] = sum(a[low + 256 * j] * w16m[(j * k) % 16] for j in range(16)) % P * twi[k * low] % P
-    A2 = [[[twi[(k * low) << 4] * w16m[(j * k) % 16] % P for j in range(16)] for k in range(16)] for low in range(16)]
-    c = [0] * 4096
-    for high in range(16):
-        for low in range(16):
-            base = (high << 8) | low
-            for k in range(16):
-                c[base + 16 * k] = sum(A2[low][k][j] * b[base + 16 * j] for j in range(16)) % P
-    M = [[sum(w16p[(i * k) % 16] * hk[i] % P * w16m[(i * j) % 16] for i in range(16)) % P for j in range(16)] for k in range(16)]
-    d = [0] * 4096
-    for g in range(256):
-        for k in range(16):
-            d[16 * g + k] = sum(M[k][j] * c[16 * g + j] for j in range(16)) % P
-    A2p = [[[w16p[(j * k) % 16] * pow(G, 16 * j, P) % P * twf[(j * low) << 4] % P for j in range(16)] for k in range(16)] for low in range(16)]
-    t3 = [0] * 4096
-    for j in range(16):
-        for low8 in range(256):
-            t3[low8 + 256 * j] = pow(G, j, P) * twf[j * low8] % P
-    e = [0] * 4096
-    for high in range(16):
-        for low in range(16):
-            base = (high << 8) | low
-            for k in range(16):
-                pos = base + 16 * k
-                e[pos] = sum(A2p[low][k][j] * d[base + 16 * j] for j in range(16)) % P * t3[pos] % P       # the next round's input factor, applied at the store
-    out = [0] * 4096
-    for low in range(256):
-        for k in range(16):
-            out[low + 256 * k] = sum(e[low + 256 * j] * w16p[(j * k) % 16] for j in range(16)) % P
-    return out
-
-
-def test_round_structure_of_the_matrix_kernel_equals_the_vector_kernel():
-    rng = random.Random(3)
-    a = [rng.randrange(P) for _ in range(4096)]
-    G = rng.randrange(1, P)
-    assert vector_kernel_rounds(a, G) == matrix_kernel_rounds(a, G)
-
-
-def matrix_kernel_rounds_all_folded(a, G):
-    """lde_mid_mfma with EVERY in-tile factor folded into a matrix that one wave owns (no vector multiplication left):
+    """lde_mid_mfma: EVERY in-tile factor folded into a matrix that one wave owns (no vector multiplication left):
        r1  by a = high nibble of low8:  diag_k(w256^-(k a)) F^-1            (the other half of the twiddle, w4096^-(k b), waits)
        r2  by b = low4:                 diag_k(w256^-(k b)) F^-1
        M   by d2:                       diag_k(w4096^(d2 k)) F diag(G^(256 i)) F^-1 diag_j(w4096^-(d2 j))   (takes the waiting half in, puts r3's k0-half out)
@@ -246,8 +202,8 @@ def matrix_kernel_rounds_all_folded(a, G):
     return out
 
 
-def test_round_structure_with_every_factor_folded_equals_the_vector_kernel():
+def test_round_structure_of_the_matrix_kernel_equals_the_vector_kernel():
     rng = random.Random(4)
     a = [rng.randrange(P) for _ in range(4096)]
     G = rng.randrange(1, P)
-    assert vector_kernel_rounds(a, G) == matrix_kernel_rounds_all_folded(a, G)
+    assert vector_kernel_rounds(a, G) == matrix_kernel_rounds(a, G)

@@ -12,7 +12,7 @@ from xlayer_prover_amd import capi
 
 
 def extend(lg, e, ncols, mfma, src=None, steps=0):
-    os.environ["XLP_LDE_MFMA"] = str(int(mfma))            # 0: vector kernels, 1: matrix pipe, 2: matrix pipe with every factor folded
+    os.environ["XLP_LDE_MFMA"] = str(int(mfma))            # 0: vector kernels, otherwise the matrix pipe
     n, n_ext = 1 << lg, 1 << (lg + e)
     if src is None:
         src = torch.empty(n * ncols, dtype=torch.int64, device="cuda")
@@ -40,7 +40,7 @@ def extend(lg, e, ncols, mfma, src=None, steps=0):
 
 
 def extend_cm(lg, e, ncols, mfma, src=None, steps=0):
-    os.environ["XLP_LDE_MFMA"] = str(int(mfma))            # 0: vector kernels, 1: matrix pipe, 2: matrix pipe with every factor folded
+    os.environ["XLP_LDE_MFMA"] = str(int(mfma))            # 0: vector kernels, otherwise the matrix pipe
     n, n_ext = 1 << lg, 1 << (lg + e)
     if src is None:
         src = torch.empty(n * ncols, dtype=torch.int64, device="cuda")
@@ -79,8 +79,7 @@ def main():
     for lg, e, ncols in cases:
         a, src, _ = extend(lg, e, ncols, 0)
         b, _, _ = extend(lg, e, ncols, 1, src=src)
-        b2, _, _ = extend(lg, e, ncols, 2, src=src)
-        same = bool(torch.equal(a, b)) and bool(torch.equal(a, b2))
+        same = bool(torch.equal(a, b))
         nbad = 0 if same else int((a != b).sum().item())
         report["parity"].append({"lg": lg, "e": e, "ncols": ncols, "equal": same, "mismatches": nbad})
         ok = ok and same
@@ -88,8 +87,7 @@ def main():
     for lg, e, ncols in ([(17, 1, 8), (19, 3, 7), (23, 1, 8)] if quick else [(17, 1, 8), (17, 0, 4), (18, 2, 5), (19, 3, 7), (20, 1, 33), (22, 1, 8), (23, 1, 8)]):
         a, src, _ = extend_cm(lg, e, ncols, 0)
         b, _, _ = extend_cm(lg, e, ncols, 1, src=src)
-        b2, _, _ = extend_cm(lg, e, ncols, 2, src=src)
-        same = bool(torch.equal(a, b)) and bool(torch.equal(a, b2))
+        same = bool(torch.equal(a, b))
         report["parity"].append({"layout": "column-major", "lg": lg, "e": e, "ncols": ncols, "equal": same, "mismatches": 0 if same else int((a != b).sum().item())})
         ok = ok and same
         del a, b, src
@@ -97,12 +95,12 @@ def main():
     if "--time" in sys.argv or quick:
         for lg, ncols in (((23, 8),) if quick else ((23, 8), (23, 64), (22, 8))):
             rows = []
-            for m in (0, 1, 2, 0, 1, 2):
+            for m in (0, 1, 0, 1):
                 _, _, r = extend(lg, 1, ncols, m, steps=10)
                 rows.append(r)
             report["timing"][f"2^{lg}x{ncols}"] = rows
             rows = []
-            for m in (0, 1, 2, 0, 1, 2):
+            for m in (0, 1, 0, 1):
                 _, _, r = extend_cm(lg, 1, ncols, m, steps=10)
                 rows.append(r)
             report["timing"][f"2^{lg}x{ncols} column-major"] = rows

@@ -154,7 +154,7 @@ static int launch_cm_top_bt(Ctx* ctx, const LdeCmParams& p, u32 BT, bool dit)
 }
 
 bool lde_mid_mfma_enabled();                                                                                          // ntt_lde.hip (XLP_LDE_MFMA)
-int launch_lde_cm_mid_mfma(Ctx* ctx, const u64* A, u64* B, u32 wc, u32 L, u32 e, const u64* twi_12, u32 BT, const u64* gk);   // ntt_lde_mid_mfma.hip
+int launch_lde_cm_mid_mfma(Ctx* ctx, const u64* A, u64* B, u32 wc, u32 L, u32 e, u32 BT, const u64* gk);   // ntt_lde_mid_mfma.hip
 
 bool lde_cm_fast_supported(u32 L, u32 e) { return L >= 17 && L <= 23 && e <= 3; }
 
@@ -221,7 +221,7 @@ int dev_extend_cm_fast(Ctx* ctx, u64* out, u64 out_cstride, u64 out_cos, const u
         }
         if (launch_cm_top_bt(ctx, p, BT, false)) return -1;
         if (ctx->profile) XLP_HIP(hipEventRecord(ev[1], ctx->stream));
-        if (lde_mid_mfma_enabled()) { if (launch_lde_cm_mid_mfma(ctx, p.A, p.B, p.wc, p.L, p.e, p.twi_12, BT, gks)) return -1; }
+        if (lde_mid_mfma_enabled()) { if (launch_lde_cm_mid_mfma(ctx, p.A, p.B, p.wc, p.L, p.e, BT, gks)) return -1; }
         else if (launch_lde_cm_mid(ctx, p, BT)) return -1;
         if (ctx->profile) XLP_HIP(hipEventRecord(ev[2], ctx->stream));
         if (launch_cm_top_bt(ctx, p, BT, true)) return -1;

@@ -1,25 +1,30 @@
-// K2 of the extendPol fast path on the MATRIX pipe (round 5): the 12-bit middle pass of ntt_lde_mid_kernel.inc with its 16-point DFTs done by
-// v_mfma_i32_32x32x32_i8 and most of its twiddle multiplications folded into the matrices.
+// K2 of the extendPol fast path on the MATRIX pipe (round 5): the 12-bit middle pass of ntt_lde_mid_kernel.inc / ntt_lde_cm_mid.hip with its
+// 16-point DFTs done by v_mfma_i32_32x32x32_i8 and EVERY in-tile factor folded into the matrices: no vector multiplication, no add / sub / shift
+// butterfly is left; the vector pipe recombines digit sums.
 //
 // Why it works.  w16 = 2^12 (ntt_common.hpp), so a DFT16 over Goldilocks is a 16 x 16 matrix of field constants applied to 16 words.  A word is its
 // own eight byte limbs; limb l of input j times the constant M[k][j] contributes M[k][j] 2^(8l) mod p, a 64-bit constant whose eight SIGNED byte
 // digits (weights 2^(8m)) make one column of a 128 x 128 int8 matrix (rows (k, m), columns (j, l)).  One MFMA chain (K = 128 = 4 instructions of
-// K = 32) gives, for 32 DFT16 at once, the eight int32 digit sums of every output; ten vector instructions put them back together (recombine()).
-// The matrix is ANY 16 x 16 field matrix, so whatever multiplies the inputs or outputs of a DFT16 by constants that do not depend on the DFT's
-// position beyond what ONE WAVE handles is free:
-//     r1   inverse DFT over digit 2 of the tile position, then x w4096^-(k low8)         shared matrix; the twiddle stays a vector multiplication
-//     r2   inverse DFT over digit 1, then x w256^-(k low4)                               16 matrices, wave w owns low4 = w and w + 8
-//     M_r  inverse DFT over digit 0, x G^(256 i) (coset scale), forward DFT over digit 0  ONE matrix per coset (two rounds of the VALU kernel)
-//     r2'  x G^(16 j) w256^(j low4), forward DFT over digit 1                              16 matrices per coset, wave-owned
-//     r3'  x G^j w4096^(j low8) (vector multiplication, table t3), forward DFT over digit 2  shared matrix
-// 3 vector multiplications per input element at blow-up 2 where ntt_lde_mid_kernel.inc has 8, 8 rounds instead of 9, and no add / sub / shift
-// butterflies at all.  Checked in tools/ubench_dft16_mfma.hip (profiles/r5/ubench_dft16_mfma.txt) before it was built.
+// K = 32) gives, for 32 DFT16 at once, the eight int32 digit sums of every output; ~13 vector instructions put them back together (recombine()).
+// The matrix is ANY 16 x 16 field matrix, so whatever multiplies the inputs or outputs of a DFT16 by constants is free as long as ONE WAVE can keep
+// the matrix: every round is organised so that the factors depend on one hexadecimal digit besides the DFT's own, and wave w owns the values w and
+// w + 8 of that digit (positions of the tile: 256 d2 + 16 d1 + d0; G = g_r^(2^BT), the coset generator to the tile's stride):
+//     r1  by a = d1:   diag_k(w256^-(k a)) F^-1 over d2      the other half of the twiddle w4096^-(k (16 a + b)), w4096^-(k b), is constant over the
+//                                                            next round's DFTs and waits until M
+//     r2  by b = d0:   diag_k(w256^-(k b)) F^-1 over d1      (the same 16 matrices as r1)
+//     M   by d2:       diag_k(w4096^(d2 k)) F diag(G^(256 i)) F^-1 diag_j(w4096^-(d2 j)) over d0: the last inverse round, the coset scale and the
+//                                                            first forward round in ONE matrix; takes the waiting half in, hands r3' its d0-half
+//     r2' by k0 = d0:  F diag_j(G^(16 j) w256^(j k0)) over d1
+//     r3' by k1 = d1:  F diag_j(G^j w256^(j k1)) over d2
+// 2 + 3 x 2^e rounds (the vector kernel: 3 + 3 x 2^e) and 0 of its 2 + 3 x 2^e multiplications per element.  tests/test_mfma_model.py restates both
+// round structures on integers and compares them; tests/test_lde_mfma.py compares the kernels bit for bit.  The idea was measured in isolation first
+// (tools/ubench_dft16_mfma.hip); a first form that kept two of the factors as vector multiplications is tools/experiments/ntt_lde_mid_mfma_partly_folded.hip.txt.
 //
 // Signs and offsets.  MFMA int8 operands are signed: a word's bytes are xor-ed with 0x80, i.e. the matrix sees x - B0, B0 = 0x8080808080808080.
-// (a) Rounds whose result goes straight into the next matrix round start their accumulators at digits that sum to B0 (mod p): the stored word is
-//     y + B0 and the next round's xor takes it off again.  (b) Rounds fed by a vector multiplication see raw words: M (x - B0) = M x - B0 M 1, and
-//     for the matrices used there (row-scaled DFTs with factor 1 in row 0) M 1 = 16 e_0: output 0 gets + 16 B0 (k0).  The accumulators start at
-//     bias digits >= 2^21 (the largest |digit sum| of a general matrix), so every digit is a non-negative number below 2^23 and recombine() needs no signs.
+// Rounds whose result goes into another matrix round (all but the last) start their accumulators at digits that sum to B0 (mod p): the stored word
+// is y + B0 and the next round's xor takes it off again.  r1 sees raw words: M (x - B0) = M x - B0 M 1, and for a row-scaled DFT with factor 1 in
+// row 0, M 1 = 16 e_0: output 0 gets + 16 B0 (k0).  The accumulators start at bias digits >= 2^21 (the largest |digit sum| of a dense matrix), so
+// every digit is a non-negative number below 2^23 and recombine() needs no signs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -32,17 +37,16 @@
 
 namespace xlp {
 
-constexpr int MM_INV = 0, MM_FWD = 1, MM_R2 = 2, MM_COSET0 = 18, MM_PER_COSET = 17;   // per coset: M_r, then r2'[16]
-// the all-folded form (lde_mid_mfma_folded): behind the matrices above, per coset M[d2] (16), r3'[k1] (16); its r2' matrices are the ones above
-constexpr int MF_M = 0, MF_R3 = 16, MF_PER_COSET = 32;
-constexpr u32 MM_ROWS = 4096 + 256 + 16;                                             // LDS rows of the tile (mm_row)
+// Matrix table: [2 unused][r1 / r2: 16][per coset: 1 unused, r2'[16]][per coset: M[16], r3'[16]] -- the second per-coset block starts at the run-time index
+// MidMfma::second.  (The layout of the first, partly folded form of this kernel, kept on purpose: with one per-coset block and literal indices the register
+// allocator spills 25 instead of 18 registers in the row-major kernel and the pass runs 6 % slower -- same text otherwise; measured twice.)
+constexpr int MM_R = 2, MM_R2P = 19, MM_R2P_PER_COSET = 17, MM_M = 0, MM_R3 = 16, MM_SECOND_PER_COSET = 32;
+constexpr u32 MM_ROWS = 4096 + 256 + 16;                                                     // LDS rows of the tile (mm_row)
 constexpr u32 MM_THREADS = 512;
-
 
 struct MidMfma {
     const v4i* mat;                    // [matrix][tile 4][k chunk 4][lane 64] x 16 bytes
-    u32 folded0;                       // index of the first matrix of the all-folded form (coset 0's M[0])
-    const u64* t3[LDE_MAX_COSETS];     // t3[r][low8 + 256 j] = G_r^j w4096^(j low8): what input j of r3' at low8 is multiplied by (applied when r2' stores it)
+    u32 second;                        // index of coset 0's M[0]
     int cz[8], cb[8];                  // accumulator start digits: sum = 0 / = B0 (mod p)
     u32 k0lo, k0hi;                    // 16 B0 mod p
 };
@@ -53,173 +57,27 @@ struct MidMfma {
 struct MidIO {
     const u64* A; u64* B;
     u32 wc, L, e;
-    const u64* twi_12;      // w4096^-i
 };
 
-// Lanes -> DFTs.  A wave's MFMA chain transforms 32 DFT16: lane (n = lane % 32, h = lane / 32) holds 8 of the 16 words of DFT n.
-//   row-major:    n = 8 neighbouring groups x the 4 columns (adjacent lanes = adjacent columns: 32-byte pieces of 8 neighbouring rows)
-//   column-major: n = 16 neighbouring groups x 2 columns (adjacent lanes = adjacent words of a column: 128-byte pieces)
-// "S" rounds (shared matrix; r1, M_r, r3'): 256 groups x 4 columns = 32 chains, wave w takes chains w, w + 8, w + 16, w + 24.
-// "W" rounds (the wave's own matrices; r2, r2'): for each of the wave's two low4: 16 highs x 4 columns = 2 chains.
+// Lanes -> DFTs.  A wave's MFMA chain transforms 32 DFT16: lane (n = lane % 32, h = lane / 32) holds 8 of the 16 words of DFT n.  For each of the
+// wave's two values of the owning digit there are 16 values of the third digit x 4 columns = 64 DFTs = 2 chains (i = 0, 1):
+//   row-major:    n = 8 neighbouring values x the 4 columns (adjacent lanes = adjacent columns: 32-byte pieces of 8 neighbouring rows)
+//   column-major: n = all 16 values x 2 columns (adjacent lanes = adjacent words of a column: 128-byte pieces)
 // The LDS image (row-major: [mm_row][4]; column-major: [4][MM_ROWS], MM_ROWS = 16 mod 32) is conflict-free for every access of both maps.
 template <bool CM>
 struct MidMap {
-    static __device__ __forceinline__ u32 sgrp(u32 o, u32 lane) { return CM ? 16 * (o >> 1) + (lane & 15) : 8 * o + ((lane & 31) >> 2); }
-    static __device__ __forceinline__ u32 scol(u32 o, u32 lane) { return CM ? 2 * (o & 1) + ((lane >> 4) & 1) : lane & 3; }
     static __device__ __forceinline__ u32 whigh(u32 i, u32 lane) { return CM ? lane & 15 : 8 * i + ((lane & 31) >> 2); }
     static __device__ __forceinline__ u32 wcol(u32 i, u32 lane) { return CM ? 2 * i + ((lane >> 4) & 1) : lane & 3; }
     static __device__ __forceinline__ u32 lds(u32 pos, u32 v) { return CM ? v * MM_ROWS + mm_row(pos) : mm_row(pos) * 4 + v; }
 };
 
 // RES: the RESIDENT form (ntt_lde_common.hpp: the ALU ceiling of bench.py's headline): the same kernel with its global DATA traffic removed -- a word of
-// the tile is made from its index, an output word is folded into a checksum; matrices and twiddle tables are read as in the product.
+// the tile is made from its index, an output word is folded into a checksum; the matrices are read as in the product.
+// Every round: the wave's owning digit takes the values wave, wave + 8 (r1, M, r3' in this order, r2 and r2' in the other: the matrix a round ends
+// with is the one the next round starts with when both are indexed alike); per value two chains (MidMap).  The next matrix is requested right
+// behind the last chain that uses the current one (dft_op), so its latency runs under the recombination of that chain.
 template <bool CM, bool RES = false>
 __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma(const MidIO p, const MidMfma t, u32 BT)
-{
-    typedef MidMap<CM> Map;
-    extern __shared__ u64 sm[];
-    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const u32 h = lane >> 5;
-    const u32 ncc = (p.wc + 3) / 4;
-    const u32 tile = xcd_tile();
-    const u32 cc = tile % ncc, hi = tile / ncc;
-    const u32 c = cc * 4;
-    // word `pos` of column v of the tile, in A (col = v clamped into the chunk) and in coset r's B
-    const u64 rm_off = (((u64)(cc >> 1) << p.L) << 3) + (cc & 1) * 4 + ((u64)hi << 12) * 8;     // (lde_sidx)
-    auto clampv = [&](u32 v) -> u32 { return c + v < p.wc ? v : p.wc - 1 - c; };
-    auto a_word = [&](u32 pos, u32 v) -> const u64* {
-        return CM ? p.A + ((u64)(c + clampv(v)) << p.L) + (((u64)hi << 12) | pos) : p.A + rm_off + (u64)pos * 8 + clampv(v);
-    };
-    auto b_word = [&](u32 r, u32 pos, u32 v) -> u64* {
-        return CM ? p.B + (((u64)r * p.wc + c + v) << p.L) + (((u64)hi << 12) | pos) : p.B + (u64)r * lde_swords(p.wc, p.L) + rm_off + (u64)pos * 8 + v;
-    };
-    const RecK K = rec_consts();
-    const u32 k0lo = h == 0 ? t.k0lo : 0u, k0hi = h == 0 ? t.k0hi : 0u;
-    const u32 ncos = 1u << p.e;
-    v16i Cz, Cb;
-#pragma unroll
-    for (int i = 0; i < 16; i++) { Cz[i] = t.cz[i & 7]; Cb[i] = t.cb[i & 7]; }
-    v4i A[4][4];
-    u64 y[8];
-    u64 sink = 0;
-
-    // ---- r1: inverse DFT over digit 2 (positions low8 + 256 j), x w4096^-(k low8), global -> LDS.  All of the tile's words are requested up front.
-    load_mat(A, t.mat, MM_INV, lane);
-    {
-        u64 e[4][8];
-#pragma unroll
-        for (u32 i = 0; i < 4; i++) {
-            const u32 low8 = Map::sgrp(wave + 8 * i, lane), v = Map::scol(wave + 8 * i, lane);
-#pragma unroll
-            for (u32 s = 0; s < 8; s++) {
-                const u32 j = 4 * (s >> 1) + 2 * h + (s & 1);
-                e[i][s] = (RES || XLP_MM_ABL >= 2) ? res_word((u64)(low8 + 256 * j) * 8 + v + hi) : *a_word(low8 + 256 * j, v);
-            }
-        }
-#pragma unroll
-        for (u32 i = 0; i < 4; i++) {
-            const u32 low8 = Map::sgrp(wave + 8 * i, lane), v = Map::scol(wave + 8 * i, lane);
-            u64 tw[8];
-#pragma unroll
-            for (u32 s = 0; s < 8; s++) tw[s] = XLP_MM_ABL >= 3 ? res_word(s * low8) : p.twi_12[(4 * (s >> 1) + 2 * h + (s & 1)) * low8];
-            dft_op<true>(A, e[i], Cz, K, k0lo, k0hi, y, t.mat, i == 3 ? (int)(MM_R2 + wave) : -1, lane);
-#pragma unroll
-            for (u32 s = 0; s < 8; s++) {
-                const u32 k = 4 * (s >> 1) + 2 * h + (s & 1);
-                sm[Map::lds(low8 + 256 * k, v)] = gl::mul(y[s], tw[s]);
-            }
-        }
-    }
-    __syncthreads();
-    // ---- r2: inverse DFT over digit 1 (positions 256 high + 16 j + low4) x w256^-(k low4): the wave's two matrices, in place
-#pragma unroll 1
-    for (u32 s2 = 0; s2 < 2; s2++) {
-        const u32 low4 = wave + 8 * s2;
-#pragma unroll
-        for (u32 i = 0; i < 2; i++) {
-            const u32 base = 256 * Map::whigh(i, lane) + low4, v = Map::wcol(i, lane);
-            u64 e[8];
-#pragma unroll
-            for (u32 s = 0; s < 8; s++) e[s] = sm[Map::lds(base + 16 * (4 * (s >> 1) + 2 * h + (s & 1)), v)];
-            dft_op<true>(A, e, Cb, K, k0lo, k0hi, y, t.mat, i == 1 ? (int)(s2 == 0 ? MM_R2 + wave + 8 : MM_COSET0) : -1, lane);
-#pragma unroll
-            for (u32 s = 0; s < 8; s++) sm[Map::lds(base + 16 * (4 * (s >> 1) + 2 * h + (s & 1)), v)] = y[s];
-        }
-    }
-    __syncthreads();
-    // ---- the inputs of the digit-0 round stay in registers (+ B0) for every coset
-    u64 X[4][8];
-#pragma unroll
-    for (u32 i = 0; i < 4; i++) {
-        const u32 base = 16 * Map::sgrp(wave + 8 * i, lane), v = Map::scol(wave + 8 * i, lane);
-#pragma unroll
-        for (u32 s = 0; s < 8; s++) X[i][s] = sm[Map::lds(base + 4 * (s >> 1) + 2 * h + (s & 1), v)];
-    }
-    for (u32 r = 0; r < ncos; r++) {
-        const u64* __restrict__ t3 = t.t3[r];
-        const u32 mr = MM_COSET0 + MM_PER_COSET * r;
-        // ---- M_r: inverse DFT over digit 0, coset scale G^(256 i), forward DFT over digit 0: one matrix
-        __syncthreads();                                                             // the tile's previous readers are done
-#pragma unroll
-        for (u32 i = 0; i < 4; i++) {
-            const u32 base = 16 * Map::sgrp(wave + 8 * i, lane), v = Map::scol(wave + 8 * i, lane);
-            dft_op<false>(A, X[i], Cb, K, 0u, 0u, y, t.mat, i == 3 ? (int)(mr + 1 + wave) : -1, lane);
-#pragma unroll
-            for (u32 s = 0; s < 8; s++) sm[Map::lds(base + 4 * (s >> 1) + 2 * h + (s & 1), v)] = y[s];
-        }
-        __syncthreads();
-        // ---- r2': x G^(16 j) w256^(j low4), forward DFT over digit 1, in place; the outputs leave multiplied by the next round's
-        //      input factors t3 = G^j' w4096^(j' low8') (j' = high, low8' = 16 k + low4), whose loads run under the round's own work
-#pragma unroll 1
-        for (u32 s2 = 0; s2 < 2; s2++) {
-            const u32 low4 = wave + 8 * s2;
-#pragma unroll
-            for (u32 i = 0; i < 2; i++) {
-                const u32 base = 256 * Map::whigh(i, lane) + low4, v = Map::wcol(i, lane);
-                u64 e[8], f[8];
-#pragma unroll
-                for (u32 s = 0; s < 8; s++) f[s] = XLP_MM_ABL >= 3 ? res_word(base + s) : t3[base + 16 * (4 * (s >> 1) + 2 * h + (s & 1))];
-#pragma unroll
-                for (u32 s = 0; s < 8; s++) e[s] = sm[Map::lds(base + 16 * (4 * (s >> 1) + 2 * h + (s & 1)), v)];
-                dft_op<false>(A, e, Cz, K, 0u, 0u, y, t.mat, i == 1 ? (int)(s2 == 0 ? mr + 1 + wave + 8 : MM_FWD) : -1, lane);
-#pragma unroll
-                for (u32 s = 0; s < 8; s++) sm[Map::lds(base + 16 * (4 * (s >> 1) + 2 * h + (s & 1)), v)] = gl::mul(y[s], f[s]);
-            }
-        }
-        __syncthreads();
-        // ---- r3': forward DFT over digit 2, LDS -> B_r
-#pragma unroll 1
-        for (u32 i = 0; i < 4; i++) {
-            const u32 low8 = Map::sgrp(wave + 8 * i, lane), v = Map::scol(wave + 8 * i, lane);
-            u64 e[8];
-#pragma unroll
-            for (u32 s = 0; s < 8; s++) e[s] = sm[Map::lds(low8 + 256 * (4 * (s >> 1) + 2 * h + (s & 1)), v)];
-            dft_op<true>(A, e, Cz, K, k0lo, k0hi, y, t.mat, (i == 3 && r + 1 < ncos) ? (int)(mr + MM_PER_COSET) : -1, lane);
-            if (RES || XLP_MM_ABL >= 2) {
-#pragma unroll
-                for (u32 s = 0; s < 8; s++) sink ^= gl::canon(y[s]) + low8;
-            } else if (c + v < p.wc) {
-#pragma unroll
-                for (u32 s = 0; s < 8; s++) *b_word(r, low8 + 256 * (4 * (s >> 1) + 2 * h + (s & 1)), v) = gl::canon(y[s]);
-            }
-        }
-    }
-    if (RES || XLP_MM_ABL >= 2) res_sink((u64*)p.A, sink);
-    (void)BT; (void)sink;
-}
-
-// ----------------------------------------------------------------- host: matrices, offsets, tables
-// ALL-FOLDED form: every in-tile factor sits in a matrix that one wave owns -- no vector multiplication is left in the middle pass.
-//     r1  wave-owned by a = high nibble of low8:  diag_k(w256^-(k a)) F^-1   (= the r2 matrix of the same index); the other half of that
-//         twiddle, w4096^-(k b), is constant over the next round's DFTs and waits until M
-//     r2  by b = low4:                            diag_k(w256^-(k b)) F^-1
-//     M   by d2:      diag_k(w4096^(d2 k)) F diag(G^(256 i)) F^-1 diag_j(w4096^-(d2 j))    (takes the waiting half in, hands r3' its k0-half)
-//     r2' by k0 = low4:                           F diag_j(G^(16 j) w256^(j k0))
-//     r3' by k1 = high nibble of low8:            F diag_j(G^j w256^(j k1))
-// (tests/test_mfma_model.py restates this structure and compares it with the vector kernel's.)  Every round is a "W" round: a wave's two values of the
-// owning digit x 2 chains; only r1 sees raw words (+ 16 B0 at output 0: its row scale is 1 in row 0), every other round is fed by a matrix round (+ B0).
-template <bool CM, bool RES = false>
-__global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma_folded(const MidIO p, const MidMfma t, u32 BT)
 {
     typedef MidMap<CM> Map;
     extern __shared__ u64 sm[];
@@ -249,7 +107,7 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma_folded(const MidIO p,
     // chain (s2, i) of a W round: the wave's owning digit w = wave + 8 s2 (r1 and r3' take them in this order, r2 and r2' in the other: the matrix
     // a round ends with is the one the next round starts with when both are indexed alike), the other digit x = whigh(i), column wcol(i)
     // ---- r1: inverse DFT over digit 2 (positions 256 j + 16 a + b), x w256^-(k a); global -> LDS
-    load_mat(A, t.mat, MM_R2 + wave, lane);
+    load_mat(A, t.mat, MM_R + wave, lane);
     {
         u64 e[4][8];
 #pragma unroll
@@ -264,7 +122,7 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma_folded(const MidIO p,
 #pragma unroll
         for (u32 o = 0; o < 4; o++) {
             const u32 low8 = 16 * (wave + 8 * (o >> 1)) + Map::whigh(o & 1, lane), v = Map::wcol(o & 1, lane);
-            dft_op<true>(A, e[o], Cb, K, k0lo, k0hi, y, t.mat, o == 1 ? (int)(MM_R2 + wave + 8) : -1, lane);     // (after o = 3 the matrix stays: r2 starts with it)
+            dft_op<true>(A, e[o], Cb, K, k0lo, k0hi, y, t.mat, o == 1 ? (int)(MM_R + wave + 8) : -1, lane);     // (after o = 3 the matrix stays: r2 starts with it)
 #pragma unroll
             for (u32 s = 0; s < 8; s++) sm[Map::lds(low8 + 256 * (4 * (s >> 1) + 2 * h + (s & 1)), v)] = y[s];
         }
@@ -280,7 +138,7 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma_folded(const MidIO p,
             u64 e[8];
 #pragma unroll
             for (u32 s = 0; s < 8; s++) e[s] = sm[Map::lds(base + 16 * (4 * (s >> 1) + 2 * h + (s & 1)), v)];
-            dft_op<false>(A, e, Cb, K, 0u, 0u, y, t.mat, i == 1 ? (int)(s2 == 0 ? MM_R2 + wave : t.folded0 + MF_M + wave) : -1, lane);
+            dft_op<false>(A, e, Cb, K, 0u, 0u, y, t.mat, i == 1 ? (int)(s2 == 0 ? MM_R + wave : t.second + MM_M + wave) : -1, lane);
 #pragma unroll
             for (u32 s = 0; s < 8; s++) sm[Map::lds(base + 16 * (4 * (s >> 1) + 2 * h + (s & 1)), v)] = y[s];
         }
@@ -295,13 +153,13 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma_folded(const MidIO p,
         for (u32 s = 0; s < 8; s++) X[o][s] = sm[Map::lds(base + 4 * (s >> 1) + 2 * h + (s & 1), v)];
     }
     for (u32 r = 0; r < ncos; r++) {
-        const u32 mf = t.folded0 + MF_PER_COSET * r, mr2p = MM_COSET0 + MM_PER_COSET * r + 1;
+        const u32 mf = t.second + MM_SECOND_PER_COSET * r, mr2p = MM_R2P + MM_R2P_PER_COSET * r;
         // ---- M: over digit 0 (positions 256 d2 + 16 d1 + j), the wave's d2 = wave, wave + 8
         __syncthreads();                                                             // the tile's previous readers are done
 #pragma unroll
         for (u32 o = 0; o < 4; o++) {
             const u32 base = 256 * (wave + 8 * (o >> 1)) + 16 * Map::whigh(o & 1, lane), v = Map::wcol(o & 1, lane);
-            dft_op<false>(A, X[o], Cb, K, 0u, 0u, y, t.mat, o == 1 ? (int)(mf + MF_M + wave + 8) : o == 3 ? (int)(mr2p + wave + 8) : -1, lane);
+            dft_op<false>(A, X[o], Cb, K, 0u, 0u, y, t.mat, o == 1 ? (int)(mf + MM_M + wave + 8) : o == 3 ? (int)(mr2p + wave + 8) : -1, lane);
 #pragma unroll
             for (u32 s = 0; s < 8; s++) sm[Map::lds(base + 4 * (s >> 1) + 2 * h + (s & 1), v)] = y[s];
         }
@@ -316,7 +174,7 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma_folded(const MidIO p,
                 u64 e[8];
 #pragma unroll
                 for (u32 s = 0; s < 8; s++) e[s] = sm[Map::lds(base + 16 * (4 * (s >> 1) + 2 * h + (s & 1)), v)];
-                dft_op<false>(A, e, Cb, K, 0u, 0u, y, t.mat, i == 1 ? (int)(s2 == 0 ? mr2p + wave : mf + MF_R3 + wave) : -1, lane);
+                dft_op<false>(A, e, Cb, K, 0u, 0u, y, t.mat, i == 1 ? (int)(s2 == 0 ? mr2p + wave : mf + MM_R3 + wave) : -1, lane);
 #pragma unroll
                 for (u32 s = 0; s < 8; s++) sm[Map::lds(base + 16 * (4 * (s >> 1) + 2 * h + (s & 1)), v)] = y[s];
             }
@@ -332,7 +190,7 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma_folded(const MidIO p,
 #pragma unroll
                 for (u32 s = 0; s < 8; s++) e[s] = sm[Map::lds(low8 + 256 * (4 * (s >> 1) + 2 * h + (s & 1)), v)];
                 dft_op<false>(A, e, Cz, K, 0u, 0u, y, t.mat,
-                              i == 1 ? (int)(s2 == 0 ? mf + MF_R3 + wave + 8 : (r + 1 < ncos ? mf + MF_PER_COSET + MF_M + wave : -1)) : -1, lane);
+                              i == 1 ? (int)(s2 == 0 ? mf + MM_R3 + wave + 8 : (r + 1 < ncos ? mf + MM_SECOND_PER_COSET + MM_M + wave : -1)) : -1, lane);
                 if (RES) {
 #pragma unroll
                     for (u32 s = 0; s < 8; s++) sink ^= gl::canon(y[s]) + low8;
@@ -350,63 +208,45 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma_folded(const MidIO p,
 static int mid_mfma_tables(Ctx* ctx, u32 BT, u32 e, const u64* gk, MidMfma* out)
 {
     const u32 ncos = 1u << e;
-    const size_t folded0 = MM_COSET0 + (size_t)MM_PER_COSET * ncos;
-    const size_t nmat = folded0 + (size_t)MF_PER_COSET * ncos;
-    const size_t mat_bytes = nmat * 16384, t3_bytes = (size_t)ncos * 4096 * 8;
-    auto key = std::make_tuple(300u + 32 * e + BT, gk[0], (u64)4);
+    const size_t second = 18 + (size_t)MM_R2P_PER_COSET * ncos, nmat = second + (size_t)MM_SECOND_PER_COSET * ncos, mat_bytes = nmat * 16384;      // 1.8 MiB at blow-up 2
+    auto key = std::make_tuple(300u + 32 * e + BT, gk[0], (u64)7);
     auto it = ctx->tables.find(key);
     if (it == ctx->tables.end()) {
         u64* d = nullptr;
-        XLP_ALLOC(plan_malloc((void**)&d, mat_bytes + t3_bytes));
+        XLP_ALLOC(plan_malloc((void**)&d, mat_bytes));
         if (!plan_active()) {
-            std::vector<uint8_t> hst(mat_bytes + t3_bytes);
+            std::vector<uint8_t> hst(mat_bytes);
             const u64 w12 = host_w(12), w12i = hgl::inv(w12), w16 = hgl::pow(w12, 256), w16i = hgl::inv(w16);
             if (w16 != 4096) return xlp_fail("lde mfma: w(4) is not 2^12");
             u64 M[16][16];
-            for (int k = 0; k < 16; k++) for (int j = 0; j < 16; j++) M[k][j] = hgl::pow(w16i, (u64)(j * k));
-            emit_matrix(M, &hst[(size_t)MM_INV * 16384]);
-            for (int k = 0; k < 16; k++) for (int j = 0; j < 16; j++) M[k][j] = hgl::pow(w16, (u64)(j * k));
-            emit_matrix(M, &hst[(size_t)MM_FWD * 16384]);
-            for (int low = 0; low < 16; low++) {
+            for (int x = 0; x < 16; x++) {                                   // r1 (x = a) and r2 (x = b): diag_k(w256^-(k x)) F^-1
                 for (int k = 0; k < 16; k++) for (int j = 0; j < 16; j++)
-                    M[k][j] = hgl::mul(hgl::pow(w12i, (u64)(k * low) << 4), hgl::pow(w16i, (u64)(j * k)));
-                emit_matrix(M, &hst[(size_t)(MM_R2 + low) * 16384]);
+                    M[k][j] = hgl::mul(hgl::pow(w12i, (u64)(k * x) << 4), hgl::pow(w16i, (u64)(j * k)));
+                emit_matrix(M, &hst[(size_t)(MM_R + x) * 16384]);
             }
             for (u32 r = 0; r < ncos; r++) {
                 const u64 G = gk[r], g16 = hgl::pow(G, 16), g256 = hgl::pow(G, 256);
+                const size_t mf = second + (size_t)MM_SECOND_PER_COSET * r, mr2p = MM_R2P + (size_t)MM_R2P_PER_COSET * r;
+                u64 M0[16][16];                                              // F diag(G^(256 i)) F^-1
                 for (int k = 0; k < 16; k++) for (int j = 0; j < 16; j++) {
                     u64 s = 0;
                     for (int i = 0; i < 16; i++) s = hgl::add(s, hgl::mul(hgl::mul(hgl::pow(w16, (u64)(i * k)), hgl::pow(g256, (u64)i)), hgl::pow(w16i, (u64)(i * j))));
-                    M[k][j] = s;
+                    M0[k][j] = s;
                 }
-                emit_matrix(M, &hst[(size_t)(MM_COSET0 + MM_PER_COSET * r) * 16384]);
-                for (int low = 0; low < 16; low++) {
-                    for (int k = 0; k < 16; k++) for (int j = 0; j < 16; j++)
-                        M[k][j] = hgl::mul(hgl::mul(hgl::pow(w16, (u64)(j * k)), hgl::pow(g16, (u64)j)), hgl::pow(w12, (u64)(j * low) << 4));
-                    emit_matrix(M, &hst[(size_t)(MM_COSET0 + MM_PER_COSET * r + 1 + low) * 16384]);
-                }
-                // the all-folded form: M[d2] = diag_k(w4096^(d2 k)) (F diag(G^(256 i)) F^-1) diag_j(w4096^-(d2 j)), r3'[k1] = F diag_j(G^j w256^(j k1))
-                u64 M0[16][16];
-                for (int k = 0; k < 16; k++) for (int j = 0; j < 16; j++) {
-                    u64 sacc = 0;
-                    for (int i = 0; i < 16; i++) sacc = hgl::add(sacc, hgl::mul(hgl::mul(hgl::pow(w16, (u64)(i * k)), hgl::pow(g256, (u64)i)), hgl::pow(w16i, (u64)(i * j))));
-                    M0[k][j] = sacc;
-                }
-                for (int d2 = 0; d2 < 16; d2++) {
+                for (int d2 = 0; d2 < 16; d2++) {                             // M[d2] = diag_k(w4096^(d2 k)) M0 diag_j(w4096^-(d2 j))
                     for (int k = 0; k < 16; k++) for (int j = 0; j < 16; j++)
                         M[k][j] = hgl::mul(hgl::mul(hgl::pow(w12, (u64)(d2 * k)), M0[k][j]), hgl::pow(w12i, (u64)(d2 * j)));
-                    emit_matrix(M, &hst[(size_t)(folded0 + MF_PER_COSET * r + MF_M + d2) * 16384]);
+                    emit_matrix(M, &hst[(mf + MM_M + d2) * 16384]);
                 }
-                for (int k1 = 0; k1 < 16; k1++) {
+                for (int k0 = 0; k0 < 16; k0++) {                             // r2'[k0] = F diag_j(G^(16 j) w256^(j k0))
+                    for (int k = 0; k < 16; k++) for (int j = 0; j < 16; j++)
+                        M[k][j] = hgl::mul(hgl::mul(hgl::pow(w16, (u64)(j * k)), hgl::pow(g16, (u64)j)), hgl::pow(w12, (u64)(j * k0) << 4));
+                    emit_matrix(M, &hst[(mr2p + k0) * 16384]);
+                }
+                for (int k1 = 0; k1 < 16; k1++) {                             // r3'[k1] = F diag_j(G^j w256^(j k1))
                     for (int k = 0; k < 16; k++) for (int j = 0; j < 16; j++)
                         M[k][j] = hgl::mul(hgl::mul(hgl::pow(w16, (u64)(j * k)), hgl::pow(G, (u64)j)), hgl::pow(w12, (u64)(j * k1) << 4));
-                    emit_matrix(M, &hst[(size_t)(folded0 + MF_PER_COSET * r + MF_R3 + k1) * 16384]);
-                }
-                u64* t3 = (u64*)&hst[mat_bytes + (size_t)r * 4096 * 8];
-                for (u32 j = 0; j < 16; j++) {
-                    const u64 gj = hgl::pow(G, j), wj = hgl::pow(w12, j);
-                    u64 f = gj;                                      // G^j w4096^(j low8), low8 = 0
-                    for (u32 low8 = 0; low8 < 256; low8++) { t3[low8 + 256 * j] = f; f = hgl::mul(f, wj); }
+                    emit_matrix(M, &hst[(mf + MM_R3 + k1) * 16384]);
                 }
             }
             XLP_HIP(hipMemcpyAsync(d, hst.data(), hst.size(), hipMemcpyHostToDevice, ctx->stream));
@@ -414,10 +254,8 @@ static int mid_mfma_tables(Ctx* ctx, u32 BT, u32 e, const u64* gk, MidMfma* out)
         }
         it = ctx->tables.emplace(key, d).first;
     }
-    const uint8_t* base = (const uint8_t*)it->second;
-    out->mat = (const v4i*)base;
-    out->folded0 = (u32)folded0;
-    for (u32 r = 0; r < ncos; r++) out->t3[r] = (const u64*)(base + mat_bytes) + (size_t)r * 4096;
+    out->mat = (const v4i*)it->second;
+    out->second = (u32)second;
     const u64 B0 = 0x8080808080808080ull % hgl::P;
     bias_digits(0, out->cz);
     bias_digits(B0, out->cb);
@@ -440,27 +278,18 @@ static int launch_mid_mfma(Ctx* ctx, const MidIO& io, u32 BT, const u64* gk)
     const u32 ncc = (io.wc + 3) / 4;
     const u64 grid = (u64)ncc << BT;
     const size_t lds = (size_t)MM_ROWS * 4 * sizeof(u64);
-    const char* form = getenv("XLP_LDE_MFMA");
-    const bool folded = form && form[0] == '2';
-    if (folded) {
-        static bool attr2 = false;
-        if (!attr2) {
-            XLP_HIP(hipFuncSetAttribute((const void*)lde_mid_mfma_folded<CM, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr2 = true;
-        }
-        hipLaunchKernelGGL((lde_mid_mfma_folded<CM, RES>), dim3((unsigned)grid), dim3(MM_THREADS), lds, ctx->stream, io, t, BT);
-    } else hipLaunchKernelGGL((lde_mid_mfma<CM, RES>), dim3((unsigned)grid), dim3(MM_THREADS), lds, ctx->stream, io, t, BT);
+    hipLaunchKernelGGL((lde_mid_mfma<CM, RES>), dim3((unsigned)grid), dim3(MM_THREADS), lds, ctx->stream, io, t, BT);
     XLP_HIP(hipGetLastError());
     return 0;
 }
 int launch_lde_mid_mfma(Ctx* ctx, const LdeParams& p, u32 BT, const u64* gk, bool resident)
 {
-    const MidIO io{p.A, p.B, p.wc, p.L, p.e, p.twi_12};
+    const MidIO io{p.A, p.B, p.wc, p.L, p.e};
     return resident ? launch_mid_mfma<false, true>(ctx, io, BT, gk) : launch_mid_mfma<false, false>(ctx, io, BT, gk);
 }
-int launch_lde_cm_mid_mfma(Ctx* ctx, const u64* A, u64* B, u32 wc, u32 L, u32 e, const u64* twi_12, u32 BT, const u64* gk)
+int launch_lde_cm_mid_mfma(Ctx* ctx, const u64* A, u64* B, u32 wc, u32 L, u32 e, u32 BT, const u64* gk)
 {
-    const MidIO io{A, B, wc, L, e, twi_12};
+    const MidIO io{A, B, wc, L, e};
     return launch_mid_mfma<true, false>(ctx, io, BT, gk);
 }
 
