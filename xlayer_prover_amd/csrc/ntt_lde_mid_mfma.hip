@@ -72,7 +72,9 @@ struct MidMap {
 };
 
 // RES: the RESIDENT form (ntt_lde_common.hpp: the ALU ceiling of bench.py's headline): the same kernel with its global DATA traffic removed -- a word of
-// the tile is made from its index, an output word is folded into a checksum; the matrices are read as in the product.
+// the tile is read from the 8 KiB the sink points at (cache-resident: the instruction stream keeps its loads; made from its index instead, the resident form
+// came out of the register allocator with 51 spilled registers against the product's 18 and ran SLOWER than the product), an output word goes back
+// into the LDS tile; the matrices are read as in the product.
 // Every round: the wave's owning digit takes the values wave, wave + 8 (r1, M, r3' in this order, r2 and r2' in the other: the matrix a round ends
 // with is the one the next round starts with when both are indexed alike); per value two chains (MidMap).  The next matrix is requested right
 // behind the last chain that uses the current one (dft_op), so its latency runs under the recombination of that chain.
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma(const MidIO p, const 
 #pragma unroll
             for (u32 s = 0; s < 8; s++) {
                 const u32 j = 4 * (s >> 1) + 2 * h + (s & 1);
-                e[o][s] = RES ? res_word((u64)(low8 + 256 * j) * 8 + v + hi) : *a_word(low8 + 256 * j, v);
+                e[o][s] = RES ? p.A[((low8 + 256 * j) * 8 + v) & 1023] : *a_word(low8 + 256 * j, v);      // (RES: the sink's 1024 words, cache-resident)
             }
         }
 #pragma unroll
@@ -191,9 +193,9 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma(const MidIO p, const 
                 for (u32 s = 0; s < 8; s++) e[s] = sm[Map::lds(low8 + 256 * (4 * (s >> 1) + 2 * h + (s & 1)), v)];
                 dft_op<false>(A, e, Cz, K, 0u, 0u, y, t.mat,
                               i == 1 ? (int)(s2 == 0 ? mf + MM_R3 + wave + 8 : (r + 1 < ncos ? mf + MM_SECOND_PER_COSET + MM_M + wave : -1)) : -1, lane);
-                if (RES) {
+                if (RES) {                                                               // (back into the tile: nobody reads it before the next barrier)
 #pragma unroll
-                    for (u32 s = 0; s < 8; s++) sink ^= gl::canon(y[s]) + low8;
+                    for (u32 s = 0; s < 8; s++) sm[Map::lds(low8 + 256 * (4 * (s >> 1) + 2 * h + (s & 1)), v)] = gl::canon(y[s]);
                 } else if (c + v < p.wc) {
 #pragma unroll
                     for (u32 s = 0; s < 8; s++) *b_word(r, low8 + 256 * (4 * (s >> 1) + 2 * h + (s & 1)), v) = gl::canon(y[s]);
@@ -201,7 +203,6 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma(const MidIO p, const 
             }
         }
     }
-    if (RES) res_sink((u64*)p.A, sink);
     (void)BT; (void)sink;
 }
 
