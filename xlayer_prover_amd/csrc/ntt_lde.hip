@@ -70,7 +70,7 @@ __global__ __launch_bounds__(XLP_WGT) void lde_top_dif(const LdeParams p)
     auto lstore = [&](u32, u32 v, u64 val, u32 lrow) { sm[lrow * V + v] = val; };
     u64* __restrict__ Ag = p.A + (((u64)cc << p.L) << 3);     // this workgroup's 8-column group of the scratch (lde_sidx)
     auto gstore = [&](u32 tpos, u32 v, u64 val, u32) {
-        const u64 row = ((u64)tpos << 12) | lo;
+        const u64 row = lde_srow(tpos, lo, BT);
         if constexpr (RES) sink ^= val + row;
         else if (c + v < p.wc) gst<1>(&Ag[row * 8 + v], val);
     };
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(XLP_WGT) void ntt_bot_dif(const LdeParams p, u32 BT
     const u64* __restrict__ Ag = p.A + (((u64)(cc >> 1) << p.L) << 3) + (cc & 1) * 4;   // my 4 columns inside their 8-column group (lde_sidx)
     auto gload = [&](u32 tpos, u32 v, u32) -> u64 {
         const u32 vv = c + v < p.wc ? v : p.wc - 1 - c;
-        const u64 row = ((u64)hi << 12) | tpos;
+        const u64 row = lde_srow(hi, tpos, BT);
         return gld<2>(&Ag[row * 8 + vv]);
     };
     auto lload = [&](u32, u32 v, u32 lrow) -> u64 { return sm[lrow * V + v]; };
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(XLP_WGT) void lde_top_dit(const LdeParams p)
     const u64* __restrict__ Br = p.B + (u64)r * lde_swords(p.wc, p.L) + (((u64)cc << p.L) << 3);   // coset r, this workgroup's 8-column group (lde_sidx)
     auto gload = [&](u32 tpos, u32 v, u32) -> u64 {
         const u32 vv = c + v < p.wc ? v : p.wc - 1 - c;
-        const u64 row = ((u64)tpos << 12) | lo;
+        const u64 row = lde_srow(tpos, lo, BT);
         if constexpr (RES) return res_word(row * 8 + vv + ((u64)r << 40));
         else return gld<4>(&Br[row * 8 + vv]);
     };

@@ -38,6 +38,16 @@ struct LdeParams {
 // 4-column workgroups share the lines of one group, exactly as in the 8-column bench (with [row][chunk width] rows of 512 bytes the middle
 // pass ran 21 % slower inside a proof than in the bench: profiles/r3/lde_scratch_layout_ab.txt).
 __host__ __device__ __forceinline__ u64 lde_sidx(u64 row, u32 col, u32 L) { return ((((u64)(col >> 3)) << L) + row) * 8 + (col & 7); }
+// Scratch ROW of position (t, lo), t = the top BT bits: the rows of 8 neighbouring lo stay together, then t, then the rest of lo.  A top-pass workgroup (one lo,
+// every t) then touches 64-byte pieces 512 bytes apart -- with its neighbours (lo +- 1, co-resident under xcd_tile) whole 512-byte runs -- instead of pieces
+// 256 KiB apart; a middle-pass workgroup (one t, every lo) touches 512-byte runs 2^(BT+3) rows apart instead of one 256 KiB run.
+#ifndef XLP_SROW_BITS
+#define XLP_SROW_BITS 3       // measured at 2^23 x 8 on one box, ms per extendPol: rows as they come 2.31-2.37, 2 bits 2.36, 3 bits 2.26-2.29, 5 bits 2.30; only A or only B
+#endif                        // re-indexed 2.29-2.34 / 2.28-2.31; blocked forms that also split t: middle pass 1.15 ms (profiles/r5/lde_scratch_rows_ab.txt)
+__host__ __device__ __forceinline__ u64 lde_srow(u64 t, u32 lo, u32 BT)
+{
+    return ((u64)(lo >> XLP_SROW_BITS) << (BT + XLP_SROW_BITS)) | (t << XLP_SROW_BITS) | (lo & ((1u << XLP_SROW_BITS) - 1));
+}
 __host__ __device__ __forceinline__ u64 lde_swords(u32 wc, u32 L) { return ((u64)((wc + 7) >> 3) << L) * 8; }   // words of one scratch matrix of wc columns
 
 template <int B>

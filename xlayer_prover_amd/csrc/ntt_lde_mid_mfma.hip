@@ -89,13 +89,13 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma(const MidIO p, const 
     const u32 tile = xcd_tile();
     const u32 cc = tile % ncc, hi = tile / ncc;
     const u32 c = cc * 4;
-    const u64 rm_off = (((u64)(cc >> 1) << p.L) << 3) + (cc & 1) * 4 + ((u64)hi << 12) * 8;     // (lde_sidx)
+    const u64 rm_off = (((u64)(cc >> 1) << p.L) << 3) + (cc & 1) * 4;                          // (lde_sidx; the row of a position: lde_srow)
     auto clampv = [&](u32 v) -> u32 { return c + v < p.wc ? v : p.wc - 1 - c; };
     auto a_word = [&](u32 pos, u32 v) -> const u64* {
-        return CM ? p.A + ((u64)(c + clampv(v)) << p.L) + (((u64)hi << 12) | pos) : p.A + rm_off + (u64)pos * 8 + clampv(v);
+        return CM ? p.A + ((u64)(c + clampv(v)) << p.L) + (((u64)hi << 12) | pos) : p.A + rm_off + lde_srow(hi, pos, BT) * 8 + clampv(v);
     };
     auto b_word = [&](u32 r, u32 pos, u32 v) -> u64* {
-        return CM ? p.B + (((u64)r * p.wc + c + v) << p.L) + (((u64)hi << 12) | pos) : p.B + (u64)r * lde_swords(p.wc, p.L) + rm_off + (u64)pos * 8 + v;
+        return CM ? p.B + (((u64)r * p.wc + c + v) << p.L) + (((u64)hi << 12) | pos) : p.B + (u64)r * lde_swords(p.wc, p.L) + rm_off + lde_srow(hi, pos, BT) * 8 + v;
     };
     const RecK K = rec_consts();
     const u32 k0lo = h == 0 ? t.k0lo : 0u, k0hi = h == 0 ? t.k0hi : 0u;
