@@ -655,7 +655,7 @@ def main():
     # per-kernel HIP events (recorded inside the library on the stream the kernels run on)
     torch.cuda.synchronize()
     capi.profile_enable(True)
-    for _ in range(3):
+    for _ in range(10):
         step()
     kern_ms_sum, kern_cnt = capi.profile_read()
     capi.profile_enable(False)
@@ -669,7 +669,7 @@ def main():
             run_res()
             torch.cuda.synchronize()
             capi.profile_enable(True)
-            for _ in range(3):
+            for _ in range(10):
                 run_res()
             res_ms_sum, res_cnt = capi.profile_read()
             capi.profile_enable(False)
@@ -791,7 +791,7 @@ def main():
             "bound": "valu", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "hbm_frac": round(achieved / HBM_PEAK_GBS, 4), "alu_ceiling": alu_ceiling,
             "traffic": traffic, "traffic_stale": traffic_stale, "counters": counters_file,
-            "achieved_from": "sum of the three kernels' average launch durations over 3 event-instrumented steps (the timed region's ms_per_step is the unbracketed figure)",
+            "achieved_from": "sum of the three kernels' average launch durations over 10 event-instrumented steps (the timed region's ms_per_step is the unbracketed figure)",
             "kernel": "xlp::lde_mid_mfma + lde_top_dit (the two largest) + lde_top_dif = one extendPol",
             "launches_per_step": 3,
             "avg_launch_ms": {k: round(v, 4) for k, v in zip(LDE_KERNELS, per_kernel_ms)} if kern_cnt else None,
