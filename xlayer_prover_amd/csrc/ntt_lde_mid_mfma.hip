@@ -69,6 +69,11 @@ struct MidMap {
     static __device__ __forceinline__ u32 whigh(u32 i, u32 lane) { return CM ? lane & 15 : 8 * i + ((lane & 31) >> 2); }
     static __device__ __forceinline__ u32 wcol(u32 i, u32 lane) { return CM ? 2 * i + ((lane >> 4) & 1) : lane & 3; }
     static __device__ __forceinline__ u32 lds(u32 pos, u32 v) { return CM ? v * MM_ROWS + mm_row(pos) : mm_row(pos) * 4 + v; }
+    // word s (< 8) of a lane's DFT over the digit at bit TP (0, 4, 8): position p0 + (4 (s >> 1) + (s & 1)) << TP, p0 = the DFT's base + (2 h << TP).  mm_row is
+    // affine in that digit (no carry leaves it: 2 h + 4 (s >> 1) + (s & 1) <= 15), so the eight addresses are ONE register + literals -- as lds(pos, v) per word
+    // they cost ~5 vector instructions each, a third of the pass's vector instructions
+    template <int TP>
+    static __device__ __forceinline__ u32 lds8(u32 a0, u32 s) { return a0 + (4 * (s >> 1) + (s & 1)) * (TP == 0 ? 1u : TP == 4 ? 17u : 273u) * (CM ? 1u : 4u); }
 };
 
 // RES: the RESIDENT form (ntt_lde_common.hpp: the ALU ceiling of bench.py's headline): the same kernel with its global DATA traffic removed -- a word of
@@ -125,8 +130,9 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma(const MidIO p, const 
         for (u32 o = 0; o < 4; o++) {
             const u32 low8 = 16 * (wave + 8 * (o >> 1)) + Map::whigh(o & 1, lane), v = Map::wcol(o & 1, lane);
             dft_op<true>(A, e[o], Cb, K, k0lo, k0hi, y, t.mat, o == 1 ? (int)(MM_R + wave + 8) : -1, lane);     // (after o = 3 the matrix stays: r2 starts with it)
+            const u32 a0 = Map::lds(low8 + 512 * h, v);
 #pragma unroll
-            for (u32 s = 0; s < 8; s++) sm[Map::lds(low8 + 256 * (4 * (s >> 1) + 2 * h + (s & 1)), v)] = y[s];
+            for (u32 s = 0; s < 8; s++) sm[Map::template lds8<8>(a0, s)] = y[s];
         }
     }
     __syncthreads();
@@ -138,11 +144,12 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma(const MidIO p, const 
         for (u32 i = 0; i < 2; i++) {
             const u32 base = 256 * Map::whigh(i, lane) + low4, v = Map::wcol(i, lane);
             u64 e[8];
+            const u32 a0 = Map::lds(base + 32 * h, v);
 #pragma unroll
-            for (u32 s = 0; s < 8; s++) e[s] = sm[Map::lds(base + 16 * (4 * (s >> 1) + 2 * h + (s & 1)), v)];
+            for (u32 s = 0; s < 8; s++) e[s] = sm[Map::template lds8<4>(a0, s)];
             dft_op<false>(A, e, Cb, K, 0u, 0u, y, t.mat, i == 1 ? (int)(s2 == 0 ? MM_R + wave : t.second + MM_M + wave) : -1, lane);
 #pragma unroll
-            for (u32 s = 0; s < 8; s++) sm[Map::lds(base + 16 * (4 * (s >> 1) + 2 * h + (s & 1)), v)] = y[s];
+            for (u32 s = 0; s < 8; s++) sm[Map::template lds8<4>(a0, s)] = y[s];
         }
     }
     __syncthreads();
@@ -151,8 +158,9 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma(const MidIO p, const 
 #pragma unroll
     for (u32 o = 0; o < 4; o++) {
         const u32 base = 256 * (wave + 8 * (o >> 1)) + 16 * Map::whigh(o & 1, lane), v = Map::wcol(o & 1, lane);
+        const u32 a0 = Map::lds(base + 2 * h, v);
 #pragma unroll
-        for (u32 s = 0; s < 8; s++) X[o][s] = sm[Map::lds(base + 4 * (s >> 1) + 2 * h + (s & 1), v)];
+        for (u32 s = 0; s < 8; s++) X[o][s] = sm[Map::template lds8<0>(a0, s)];
     }
     for (u32 r = 0; r < ncos; r++) {
         const u32 mf = t.second + MM_SECOND_PER_COSET * r, mr2p = MM_R2P + MM_R2P_PER_COSET * r;
@@ -162,8 +170,9 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma(const MidIO p, const 
         for (u32 o = 0; o < 4; o++) {
             const u32 base = 256 * (wave + 8 * (o >> 1)) + 16 * Map::whigh(o & 1, lane), v = Map::wcol(o & 1, lane);
             dft_op<false>(A, X[o], Cb, K, 0u, 0u, y, t.mat, o == 1 ? (int)(mf + MM_M + wave + 8) : o == 3 ? (int)(mr2p + wave + 8) : -1, lane);
+            const u32 a0 = Map::lds(base + 2 * h, v);
 #pragma unroll
-            for (u32 s = 0; s < 8; s++) sm[Map::lds(base + 4 * (s >> 1) + 2 * h + (s & 1), v)] = y[s];
+            for (u32 s = 0; s < 8; s++) sm[Map::template lds8<0>(a0, s)] = y[s];
         }
         __syncthreads();
         // ---- r2': x G^(16 j) w256^(j k0), forward DFT over digit 1, in place; k0 = wave + 8 first
@@ -174,11 +183,12 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma(const MidIO p, const 
             for (u32 i = 0; i < 2; i++) {
                 const u32 base = 256 * Map::whigh(i, lane) + low4, v = Map::wcol(i, lane);
                 u64 e[8];
+                const u32 a0 = Map::lds(base + 32 * h, v);
 #pragma unroll
-                for (u32 s = 0; s < 8; s++) e[s] = sm[Map::lds(base + 16 * (4 * (s >> 1) + 2 * h + (s & 1)), v)];
+            for (u32 s = 0; s < 8; s++) e[s] = sm[Map::template lds8<4>(a0, s)];
                 dft_op<false>(A, e, Cb, K, 0u, 0u, y, t.mat, i == 1 ? (int)(s2 == 0 ? mr2p + wave : mf + MM_R3 + wave) : -1, lane);
 #pragma unroll
-                for (u32 s = 0; s < 8; s++) sm[Map::lds(base + 16 * (4 * (s >> 1) + 2 * h + (s & 1)), v)] = y[s];
+                for (u32 s = 0; s < 8; s++) sm[Map::template lds8<4>(a0, s)] = y[s];
             }
         }
         __syncthreads();
@@ -189,13 +199,14 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma(const MidIO p, const 
             for (u32 i = 0; i < 2; i++) {
                 const u32 low8 = 16 * (wave + 8 * s2) + Map::whigh(i, lane), v = Map::wcol(i, lane);
                 u64 e[8];
+                const u32 a0 = Map::lds(low8 + 512 * h, v);
 #pragma unroll
-                for (u32 s = 0; s < 8; s++) e[s] = sm[Map::lds(low8 + 256 * (4 * (s >> 1) + 2 * h + (s & 1)), v)];
+                for (u32 s = 0; s < 8; s++) e[s] = sm[Map::template lds8<8>(a0, s)];
                 dft_op<false>(A, e, Cz, K, 0u, 0u, y, t.mat,
                               i == 1 ? (int)(s2 == 0 ? mf + MM_R3 + wave + 8 : (r + 1 < ncos ? mf + MM_SECOND_PER_COSET + MM_M + wave : -1)) : -1, lane);
                 if (RES) {                                                               // (back into the tile: nobody reads it before the next barrier)
 #pragma unroll
-                    for (u32 s = 0; s < 8; s++) sm[Map::lds(low8 + 256 * (4 * (s >> 1) + 2 * h + (s & 1)), v)] = gl::canon(y[s]);
+                    for (u32 s = 0; s < 8; s++) sm[Map::template lds8<8>(a0, s)] = gl::canon(y[s]);
                 } else if (c + v < p.wc) {
 #pragma unroll
                     for (u32 s = 0; s < 8; s++) *b_word(r, low8 + 256 * (4 * (s >> 1) + 2 * h + (s & 1)), v) = gl::canon(y[s]);
