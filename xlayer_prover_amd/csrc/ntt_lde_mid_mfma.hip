@@ -102,6 +102,8 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma(const MidIO p, const 
     auto b_word = [&](u32 r, u32 pos, u32 v) -> u64* {
         return CM ? p.B + (((u64)r * p.wc + c + v) << p.L) + (((u64)hi << 12) | pos) : p.B + (u64)r * lde_swords(p.wc, p.L) + rm_off + lde_srow(hi, pos, BT) * 8 + v;
     };
+    // words between positions pos and pos + 256 of a column in A / B_r (digit 2 of the position: the words of a lane's first / last DFT)
+    const u64 kstride = CM ? 256 : (u64)256 << (BT + 3);            // (row-major: 2^(8 + BT) scratch rows of 8 words, whatever XLP_SROW_BITS <= 8)
     const RecK K = rec_consts();
     const u32 k0lo = h == 0 ? t.k0lo : 0u, k0hi = h == 0 ? t.k0hi : 0u;
     const u32 ncos = 1u << p.e;
@@ -120,10 +122,11 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma(const MidIO p, const 
 #pragma unroll
         for (u32 o = 0; o < 4; o++) {
             const u32 low8 = 16 * (wave + 8 * (o >> 1)) + Map::whigh(o & 1, lane), v = Map::wcol(o & 1, lane);
+            const u64* a0 = a_word(low8 + 512 * h, v);
 #pragma unroll
             for (u32 s = 0; s < 8; s++) {
-                const u32 j = 4 * (s >> 1) + 2 * h + (s & 1);
-                e[o][s] = RES ? p.A[((low8 + 256 * j) * 8 + v) & 1023] : *a_word(low8 + 256 * j, v);      // (RES: the sink's 1024 words, cache-resident)
+                const u32 j = 4 * (s >> 1) + (s & 1);
+                e[o][s] = RES ? p.A[((low8 + 256 * (j + 2 * h)) * 8 + v) & 1023] : a0[j * kstride];      // (RES: the sink's 1024 words, cache-resident)
             }
         }
 #pragma unroll
@@ -208,8 +211,9 @@ __global__ __launch_bounds__(MM_THREADS) void lde_mid_mfma(const MidIO p, const 
 #pragma unroll
                     for (u32 s = 0; s < 8; s++) sm[Map::template lds8<8>(a0, s)] = gl::canon(y[s]);
                 } else if (c + v < p.wc) {
+                    u64* b0 = b_word(r, low8 + 512 * h, v);
 #pragma unroll
-                    for (u32 s = 0; s < 8; s++) *b_word(r, low8 + 256 * (4 * (s >> 1) + 2 * h + (s & 1)), v) = gl::canon(y[s]);
+                    for (u32 s = 0; s < 8; s++) b0[(4 * (s >> 1) + (s & 1)) * kstride] = gl::canon(y[s]);
                 }
             }
         }
